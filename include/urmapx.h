@@ -1,0 +1,151 @@
+/*
+ * urmapx.h -- C ABI of the MI355X-native urmap mapping path (liburmapx.so).
+ *
+ * The reference (rcedgar/urmap) has no plugin / FFI layer: the per-read path is compiled
+ * into its one executable.  The seam it uses internally is
+ *     State1::SetMethod / State1::SetUFI / State1::Search / State1::Output1   (map.cpp:11-25)
+ *     UFIndex::FromFile                                                        (ufindexio.cpp:51-115)
+ * and this header is the batch form of exactly that seam: plain pointers and sizes, no
+ * C++ or torch types, error codes instead of Die()/exit (myutils.cpp:915).
+ * INTEGRATION.md shows the binding a maintainer of the reference would add.
+ *
+ * All functions return 0 on success or a negative URMAPX_E_* code.  Nothing in this
+ * library has a CPU fallback: without a HIP device every compute entry point returns
+ * URMAPX_E_NODEVICE.
+ */
+#ifndef URMAPX_H
+#define URMAPX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define URMAPX_OK 0
+#define URMAPX_E_IO (-1)          /* cannot open / short read */
+#define URMAPX_E_FORMAT (-2)      /* bad .ufi magic or header */
+#define URMAPX_E_NOMEM (-3)       /* host or device allocation failed */
+#define URMAPX_E_NODEVICE (-4)    /* no usable HIP device / HIP runtime error */
+#define URMAPX_E_ARG (-5)         /* invalid argument */
+#define URMAPX_E_UNSUPPORTED (-6) /* input outside the device path's domain (see status bits) */
+
+/* per-read status bits (urmapx_result.status); non-zero => that read's result is not valid */
+#define URMAPX_ST_HIT_OVERFLOW 0x01  /* more than 64 live hits */
+#define URMAPX_ST_HSP_OVERFLOW 0x02  /* more than 64 live HSPs */
+#define URMAPX_ST_PATH_OVERFLOW 0x04 /* alignment path longer than URMAPX_MAX_PATH_OPS runs */
+#define URMAPX_ST_BAND_TOO_WIDE 0x08 /* banded DP wider than one wavefront */
+#define URMAPX_ST_BAD_LENGTH 0x10    /* read shorter than the word length or longer than URMAPX_MAX_QL */
+
+#define URMAPX_MAX_QL 320
+#define URMAPX_MAX_PATH_OPS 48
+
+typedef struct urmapx_index urmapx_index;
+typedef struct urmapx_ctx urmapx_ctx;
+
+/* State1::SetMethod constants (state1.cpp:147-183). */
+typedef struct urmapx_params {
+	int32_t mismatch_score;
+	int32_t gap_open_score;
+	int32_t gap_ext_score;
+	int32_t min_hsp_score_pct;
+	int32_t term_hsp_score_pct_phase3;
+	int32_t xdrop;
+	int32_t max_penalty;
+	int32_t xphase1, xphase3, xphase4;
+	uint32_t band_radius;
+} urmapx_params;
+
+/* method 6 = urmap -map default, 7 = -veryfast (state1.cpp:152-179) */
+int urmapx_params_for_method(unsigned method, urmapx_params *out);
+
+/* One read's outcome of State1::Search (search1.cpp:7-24) incl. SetMappedPos (state1.cpp:129-145). */
+typedef struct urmapx_result {
+	uint32_t dbpos;     /* top hit start in the concatenated sequence; UINT32_MAX = unmapped */
+	uint32_t seq_index; /* sequence directory index, UINT32_MAX if unmapped */
+	uint32_t coord;     /* 0-based position in that sequence */
+	int16_t score;      /* m_BestScore */
+	int16_t second;     /* m_SecondBestScore */
+	uint8_t mapq;       /* m_Mapq */
+	uint8_t plus;       /* 1 = read maps as given, 0 = reverse complement */
+	uint8_t exit_phase; /* 1..6: phase of Search_Lo (search1m6.cpp:35-277) that returned */
+	uint8_t status;     /* URMAPX_ST_* bits */
+	uint16_t hit_count; /* m_HitCount */
+	uint16_t path_nops; /* 0 => ungapped ("<QL>M"); else run count in the path arena */
+	uint32_t path_off;  /* first run of this read in the path arena */
+} urmapx_result;
+
+/* Path arena entry: (len << 2) | code; code 0 = M, 1 = D (query base vs gap), 2 = I (target base vs gap),
+ * the reference's own path alphabet (pathinfo.h); CIGAR swaps D and I (cigar.cpp:22-25). */
+typedef uint16_t urmapx_path_op;
+
+/* ---- index: UFIndex::FromFile (ufindexio.cpp:51-115) + the device-load path ---- */
+int urmapx_index_open(const char *ufi_path, urmapx_index **out);
+/* Wrap caller-owned HOST arrays (no copy; must outlive the index).  labels = seq_count NUL-terminated strings. */
+int urmapx_index_wrap_host(uint32_t word_length, uint32_t max_ix, uint64_t slot_count, const uint8_t *blob,
+                           const uint8_t *seqdata, uint32_t seqdata_size, uint32_t seq_count,
+                           const uint32_t *seq_lengths, const uint32_t *offsets, const char *labels,
+                           urmapx_index **out);
+/* Adopt caller-owned DEVICE arrays on `device` (index already resident in HBM, e.g. built there).
+ * d_blob must have >= 5*slot_count+8 bytes, d_seqdata >= seqdata_size+4096 bytes with the tail zeroed. */
+int urmapx_index_wrap_device(int device, uint32_t word_length, uint32_t max_ix, uint64_t slot_count,
+                             const void *d_blob, const void *d_seqdata, uint32_t seqdata_size, uint32_t seq_count,
+                             const uint32_t *seq_lengths, const uint32_t *offsets, const char *labels,
+                             urmapx_index **out);
+/* Copy slot table + sequence to HBM of `device` (once per GPU); no-op if already resident there. */
+int urmapx_index_upload(urmapx_index *, int device);
+void urmapx_index_close(urmapx_index *);
+
+uint32_t urmapx_index_word_length(const urmapx_index *);
+uint32_t urmapx_index_max_ix(const urmapx_index *);
+uint64_t urmapx_index_slot_count(const urmapx_index *);
+uint32_t urmapx_index_seqdata_size(const urmapx_index *);
+uint32_t urmapx_index_seq_count(const urmapx_index *);
+const char *urmapx_index_label(const urmapx_index *, uint32_t i);
+uint32_t urmapx_index_seq_length(const urmapx_index *, uint32_t i);
+uint32_t urmapx_index_seq_offset(const urmapx_index *, uint32_t i);
+
+/* ---- mapping context: one per (index, device, host thread); replaces State1 + SetUFI ---- */
+int urmapx_ctx_create(const urmapx_index *, int device, const urmapx_params *, urmapx_ctx **out);
+void urmapx_ctx_destroy(urmapx_ctx *);
+
+/* State1::Search over a batch of single-end reads held in HOST memory.
+ * bases: concatenated ASCII reads (exactly as in the FASTQ); offs[n+1] byte offsets.
+ * results[n] and path_ops[path_cap] are caller-owned host arrays; *path_used receives the
+ * number of arena entries written.  Returns URMAPX_E_UNSUPPORTED (results still filled,
+ * offending reads carry status bits) if any read fell outside the device path's domain. */
+int urmapx_map_se(urmapx_ctx *, const uint8_t *bases, const uint64_t *offs, uint32_t n, urmapx_result *results,
+                  urmapx_path_op *path_ops, size_t path_cap, size_t *path_used);
+
+/* Same with inputs and outputs already resident in HBM of the ctx's device (no PCIe in the call):
+ * d_bases, d_offs (uint64[n+1]), d_results[n], d_path_ops[n*URMAPX_MAX_PATH_OPS], d_path_used (uint32).
+ * Asynchronous on the ctx stream; urmapx_ctx_sync() waits. total_bases = offs[n]. */
+int urmapx_map_se_device(urmapx_ctx *, const void *d_bases, const void *d_offs, uint32_t n, uint64_t total_bases,
+                         uint32_t max_read_len, void *d_results, void *d_path_ops, void *d_path_used);
+int urmapx_ctx_sync(urmapx_ctx *);
+/* Device time (ms, HIP events on the ctx stream) of the two kernels in the most recent *_device call that has
+ * completed: [0] seed+probe, [1] search/extend. */
+int urmapx_ctx_last_kernel_ms(urmapx_ctx *, float ms[2]);
+
+/* ---- stage-level entry points (same device code the batch call runs; used by parity tests and bench) ---- */
+/* State1::SetSlotsVec (state1.cpp:396-438) + UFIndex::GetBlob (ufindex.h:184-187) for both strands of every read.
+ * Host arrays; per read r, entries [2*offs[r], 2*offs[r]+L) are the plus strand by query position and
+ * [2*offs[r]+L, 2*offs[r]+2L) the minus strand (positions > L-W unused).  slots: UINT64_MAX = no k-mer. */
+int urmapx_seed_probe(urmapx_ctx *, const uint8_t *bases, const uint64_t *offs, uint32_t n, uint64_t *slots,
+                      uint8_t *tallies, uint32_t *positions);
+/* State1::Viterbi (viterbi.cpp:11-261) + TraceBackBitMem for a batch of (A,B) pairs.
+ * a/b: concatenated sequences with offsets; flags bit0 = Left, bit1 = Right.  Outputs per problem: score,
+ * status (URMAPX_ST_*), and the run-length path in ops[i*URMAPX_MAX_PATH_OPS ..] with nops[i] entries. */
+int urmapx_viterbi_batch(urmapx_ctx *, const uint8_t *a, const uint32_t *a_offs, const uint8_t *b,
+                         const uint32_t *b_offs, const uint8_t *flags, uint32_t n, float *scores, uint8_t *status,
+                         urmapx_path_op *ops, uint16_t *nops);
+
+const char *urmapx_strerror(int code);
+/* "gfx950" etc. of the ctx's device; NULL without a device */
+const char *urmapx_device_arch(urmapx_ctx *);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,157 @@
+"""GPU parity tests: the HIP path (through the C ABI, liburmapx.so) against the CPU oracle on the same
+seeded inputs.  Bit-exact: slots, tallies, positions, hit position/strand/score/MAPQ, alignment paths."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu(small_case):
+    from urmap_amd import api
+    idx = api.Index.open(small_case["ufi"]).upload(0)
+    m = api.Mapper(idx, device=0, method=6)
+    assert m.arch.startswith("gfx950"), m.arch
+    return {"index": idx, "mapper": m}
+
+
+def mutate_edge_reads(reads, seed):
+    """N's, lower case, IUPAC and 'u' letters sprinkled into a few reads."""
+    rng = np.random.default_rng(seed)
+    out = list(reads)
+    for k in range(0, len(out), 17):
+        lab, s, q = out[k]
+        s = s.copy()
+        s[int(rng.integers(0, len(s)))] = ord("N")
+        out[k] = (lab, s, q)
+    for k in range(3, len(out), 61):
+        lab, s, q = out[k]
+        out[k] = (lab, s | 0x20, q)
+    for k in range(5, len(out), 97):
+        lab, s, q = out[k]
+        s = s.copy()
+        s[int(rng.integers(0, len(s)))] = ord("R")
+        s[int(rng.integers(0, len(s)))] = ord("u")
+        out[k] = (lab, s, q)
+    return out
+
+
+def compare_results(gres, gops, ores, opaths):
+    from urmap_amd import api
+    assert (gres["status"] == 0).all(), f"status bits set: {np.unique(gres['status'])}"
+    for name in ("dbpos", "seq_index", "coord", "score", "second", "mapq", "hit_count", "exit_phase"):
+        a = gres[name].astype(np.int64)
+        b = ores[name].astype(np.int64)
+        bad = np.nonzero(a != b)[0]
+        assert len(bad) == 0, f"{name}: {len(bad)} mismatches, first read {bad[0]}: gpu {a[bad[0]]} oracle {b[bad[0]]}"
+    mapped = ores["dbpos"] != 0xFFFFFFFF
+    assert (gres["plus"][mapped] == ores["plus"][mapped]).all()
+    for i in np.nonzero(mapped)[0]:
+        gp = api.decode_path(gops[int(gres["path_off"][i]): int(gres["path_off"][i]) + int(gres["path_nops"][i])])
+        assert gp == opaths[i], f"read {i}: path gpu {gp!r} oracle {opaths[i]!r}"
+
+
+def test_seed_probe_matches_oracle(small_case, gpu):
+    """SetSlotsVec + GetBlob for every k-mer of both strands (state1.cpp:396-438, ufindex.h:184-187)."""
+    import oracle_lib as ol
+    from urmap_amd import synth
+    from conftest import reads_to_arrays
+    oi = small_case["oracle_index"]
+    reads = mutate_edge_reads(synth.make_reads(7, small_case["genome"], 300, read_len=150), 1)
+    reads += synth.make_reads(8, small_case["genome"], 50, read_len=250, sub=0.04)
+    reads += synth.make_reads(9, small_case["genome"], 50, read_len=37)
+    bases, offs = reads_to_arrays(reads)
+    slots, tallies, positions = gpu["mapper"].seed_probe(bases, offs)
+    blob = oi.blob()
+    W = oi.word_length
+    for r, (_, seq, _) in enumerate(reads):
+        L = len(seq)
+        rc = np.zeros(L, np.uint8)
+        ol.lib().uo_revcomp(np.ascontiguousarray(seq).ctypes.data, L, rc.ctypes.data)
+        for strand, s in ((0, seq), (1, rc)):
+            want = oi.slots_vec(s)
+            base = 2 * int(offs[r]) + strand * L
+            got = slots[base: base + L - W + 1]
+            assert (got == want).all(), f"read {r} strand {strand}: slots differ"
+            valid = want != np.iinfo(np.uint64).max
+            wt = np.zeros(len(want), np.uint8)
+            wp = np.full(len(want), 0xFFFFFFFF, np.uint32)
+            sv = want[valid].astype(np.int64)
+            wt[valid] = blob[5 * sv]
+            wp[valid] = (blob[5 * sv + 1].astype(np.uint32) | (blob[5 * sv + 2].astype(np.uint32) << 8)
+                         | (blob[5 * sv + 3].astype(np.uint32) << 16) | (blob[5 * sv + 4].astype(np.uint32) << 24))
+            assert (tallies[base: base + len(want)] == wt).all(), f"read {r} strand {strand}: tallies differ"
+            gp = positions[base: base + len(want)]
+            assert (gp[valid] == wp[valid]).all(), f"read {r} strand {strand}: positions differ"
+
+
+def test_viterbi_matches_oracle(gpu):
+    """State1::Viterbi + TraceBackBitMem (viterbi.cpp:11-261): score and full path, Left/Right variants."""
+    import oracle_lib as ol
+    rng = np.random.default_rng(5)
+    pairs, flags = [], []
+    for k in range(400):
+        la = int(rng.integers(1, 140))
+        extra = int(rng.integers(0, 30))
+        core = rng.integers(0, 4, size=la + extra)
+        t = np.frombuffer(b"ACGT", np.uint8)[core]
+        q = list(t[:la]) if k % 2 else list(t[extra:extra + la])
+        # edits
+        i = 0
+        out = []
+        while i < len(q):
+            x = rng.random()
+            if x < 0.05:
+                out.append(int(np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4)]))
+            elif x < 0.08:
+                pass
+            elif x < 0.11:
+                out.append(q[i]); out.append(int(np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4)]))
+            else:
+                out.append(q[i])
+            i += 1
+        a = bytes(out)
+        if len(a) == 0:
+            a = b"A"
+        lb = len(a) + 24 + (k % 2)
+        tt = t.tobytes()
+        b = (tt + bytes(np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, size=lb)]))[:lb]
+        pairs.append((a, b))
+        flags.append(1 if k % 2 == 0 else 2)
+    # degenerate shapes
+    pairs += [(b"ACGT", b""), (b"A", b"A"), (b"A", b"CCCCCCCCCCCCCCCCCCCCCCCCC"), (b"ACGTACGTAC", b"ACGTACGTAC"),
+              (b"ACGTACGTAC" * 5, (b"ACGTACGTAC" * 5)[:30])]
+    flags += [2, 1, 1, 3, 2]
+    scores, status, paths = gpu["mapper"].viterbi_batch(pairs, flags)
+    assert (status == 0).all()
+    for k, ((a, b), fl) in enumerate(zip(pairs, flags)):
+        s, p = ol.viterbi(a, b, bool(fl & 1), bool(fl & 2))
+        assert float(scores[k]) == s, f"case {k}: score gpu {scores[k]} oracle {s}"
+        assert paths[k] == p, f"case {k}: path gpu {paths[k]} oracle {p}"
+
+
+@pytest.mark.parametrize("read_len,sub,indel,n", [(150, 0.01, 0.001, 3000), (250, 0.04, 0.01, 1500),
+                                                   (100, 0.02, 0.004, 1500), (30, 0.0, 0.0, 500)])
+def test_map_se_matches_oracle(small_case, gpu, read_len, sub, indel, n):
+    """State1::Search end to end (search1.cpp:7-24): top hit, scores, MAPQ, path -- bit-exact."""
+    from urmap_amd import synth
+    from conftest import reads_to_arrays
+    reads = synth.make_reads(1000 + read_len, small_case["genome"], n, read_len=read_len, sub=sub, ins=indel / 2,
+                             dele=indel / 2, random_frac=0.03)
+    reads = mutate_edge_reads(reads, read_len)
+    bases, offs = reads_to_arrays(reads)
+    ores, opaths, _ = small_case["oracle_index"].map_se(bases, offs, threads=4)
+    gres, gops = gpu["mapper"].map_se(bases, offs)
+    compare_results(gres, gops, ores, opaths)
+
+
+def test_bad_lengths_are_flagged(small_case, gpu):
+    """Reads shorter than W or longer than the device cap are reported, not silently mis-mapped."""
+    from urmap_amd import api
+    seqs = [np.frombuffer(b"ACGTACGTACGTACGT", np.uint8), np.frombuffer(b"ACGT" * 100, np.uint8)]
+    offs = np.array([0, 16, 416], dtype=np.uint64)
+    with pytest.raises(api.UrmapxError) as e:
+        gpu["mapper"].map_se(np.concatenate(seqs), offs)
+    assert e.value.code == api.E_UNSUPPORTED
+    res, _ = gpu["mapper"].map_se(np.concatenate(seqs), offs, allow_unsupported=True)
+    assert (res["status"] == 0x10).all()

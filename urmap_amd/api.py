@@ -1,0 +1,296 @@
+"""ctypes binding of liburmapx.so (include/urmapx.h) -- the host-side mirror of the reference seam
+State1::SetMethod / SetUFI / Search (map.cpp:11-25) and UFIndex::FromFile (ufindexio.cpp:51-115).
+
+Nothing here computes on the CPU: every call goes to the HIP library, and a missing or unloadable
+library is a hard error.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liburmapx.so")
+
+MAX_QL = 320
+MAX_PATH_OPS = 48
+E_UNSUPPORTED = -6
+
+RESULT_DTYPE = np.dtype([("dbpos", "<u4"), ("seq_index", "<u4"), ("coord", "<u4"), ("score", "<i2"),
+                         ("second", "<i2"), ("mapq", "u1"), ("plus", "u1"), ("exit_phase", "u1"),
+                         ("status", "u1"), ("hit_count", "<u2"), ("path_nops", "<u2"), ("path_off", "<u4")])
+assert RESULT_DTYPE.itemsize == 28
+
+EXPORTS = (
+    "urmapx_params_for_method", "urmapx_index_open", "urmapx_index_wrap_host", "urmapx_index_wrap_device",
+    "urmapx_index_upload", "urmapx_index_close", "urmapx_index_word_length", "urmapx_index_max_ix",
+    "urmapx_index_slot_count", "urmapx_index_seqdata_size", "urmapx_index_seq_count", "urmapx_index_label",
+    "urmapx_index_seq_length", "urmapx_index_seq_offset", "urmapx_ctx_create", "urmapx_ctx_destroy",
+    "urmapx_map_se", "urmapx_map_se_device", "urmapx_ctx_sync", "urmapx_ctx_last_kernel_ms",
+    "urmapx_seed_probe", "urmapx_viterbi_batch", "urmapx_strerror", "urmapx_device_arch",
+)
+
+
+class Params(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "mismatch_score", "gap_open_score", "gap_ext_score", "min_hsp_score_pct",
+        "term_hsp_score_pct_phase3", "xdrop", "max_penalty", "xphase1", "xphase3", "xphase4")] + [
+        ("band_radius", C.c_uint32)]
+
+
+class UrmapxError(RuntimeError):
+    def __init__(self, code, what):
+        self.code = code
+        super().__init__(f"{what}: {strerror(code)} ({code})")
+
+
+_lib = None
+
+
+def lib():
+    """Load liburmapx.so (built in-tree by __graft_entry__.build()); fails loudly if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(the HIP library is the only compute path; there is no fallback)")
+    L = C.CDLL(LIB_PATH)
+    vp, cp, u32, u64, i32 = C.c_void_p, C.c_char_p, C.c_uint32, C.c_uint64, C.c_int
+    L.urmapx_params_for_method.argtypes = [C.c_uint, C.POINTER(Params)]
+    L.urmapx_index_open.argtypes = [cp, C.POINTER(vp)]
+    L.urmapx_index_wrap_host.argtypes = [u32, u32, u64, vp, vp, u32, u32, vp, vp, cp, C.POINTER(vp)]
+    L.urmapx_index_wrap_device.argtypes = [i32, u32, u32, u64, vp, vp, u32, u32, vp, vp, cp, C.POINTER(vp)]
+    L.urmapx_index_upload.argtypes = [vp, i32]
+    L.urmapx_index_close.argtypes = [vp]
+    L.urmapx_index_close.restype = None
+    for name, rt in (("word_length", u32), ("max_ix", u32), ("slot_count", u64), ("seqdata_size", u32),
+                     ("seq_count", u32)):
+        f = getattr(L, "urmapx_index_" + name)
+        f.restype = rt
+        f.argtypes = [vp]
+    L.urmapx_index_label.restype = cp
+    L.urmapx_index_label.argtypes = [vp, u32]
+    L.urmapx_index_seq_length.restype = u32
+    L.urmapx_index_seq_length.argtypes = [vp, u32]
+    L.urmapx_index_seq_offset.restype = u32
+    L.urmapx_index_seq_offset.argtypes = [vp, u32]
+    L.urmapx_ctx_create.argtypes = [vp, i32, C.POINTER(Params), C.POINTER(vp)]
+    L.urmapx_ctx_destroy.argtypes = [vp]
+    L.urmapx_ctx_destroy.restype = None
+    L.urmapx_map_se.argtypes = [vp, vp, vp, u32, vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.urmapx_map_se_device.argtypes = [vp, vp, vp, u32, u64, u32, vp, vp, vp]
+    L.urmapx_ctx_sync.argtypes = [vp]
+    L.urmapx_ctx_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float * 2)]
+    L.urmapx_seed_probe.argtypes = [vp, vp, vp, u32, vp, vp, vp]
+    L.urmapx_viterbi_batch.argtypes = [vp, vp, vp, vp, vp, vp, u32, vp, vp, vp, vp]
+    L.urmapx_strerror.restype = cp
+    L.urmapx_strerror.argtypes = [i32]
+    L.urmapx_device_arch.restype = cp
+    L.urmapx_device_arch.argtypes = [vp]
+    _lib = L
+    return L
+
+
+def strerror(code):
+    return lib().urmapx_strerror(code).decode()
+
+
+def _check(rc, what, allow=()):
+    if rc != 0 and rc not in allow:
+        raise UrmapxError(rc, what)
+    return rc
+
+
+def params_for_method(method=6) -> Params:
+    """State1::SetMethod (state1.cpp:147-183): 6 = default, 7 = -veryfast."""
+    p = Params()
+    _check(lib().urmapx_params_for_method(method, C.byref(p)), "urmapx_params_for_method")
+    return p
+
+
+class Index:
+    """UFIndex (read side): parsed .ufi + its copy in HBM."""
+
+    def __init__(self, handle, keep=()):
+        self.h = C.c_void_p(handle)
+        self._keep = keep
+
+    @classmethod
+    def open(cls, path):
+        h = C.c_void_p()
+        _check(lib().urmapx_index_open(os.fsencode(path), C.byref(h)), f"urmapx_index_open({path})")
+        return cls(h.value)
+
+    @classmethod
+    def wrap_host(cls, word_length, max_ix, slot_count, blob, seqdata, seq_lengths, offsets, labels):
+        sl = np.ascontiguousarray(seq_lengths, dtype=np.uint32)
+        of = np.ascontiguousarray(offsets, dtype=np.uint32)
+        lab = b"".join(l.encode() + b"\0" for l in labels)
+        h = C.c_void_p()
+        _check(lib().urmapx_index_wrap_host(word_length, max_ix, slot_count, blob.ctypes.data, seqdata.ctypes.data,
+                                            len(seqdata), len(labels), sl.ctypes.data, of.ctypes.data, lab,
+                                            C.byref(h)), "urmapx_index_wrap_host")
+        return cls(h.value, keep=(blob, seqdata, sl, of, lab))
+
+    @classmethod
+    def wrap_device(cls, device, word_length, max_ix, slot_count, d_blob_ptr, d_seq_ptr, seqdata_size, seq_lengths,
+                    offsets, labels, keep=()):
+        """Adopt arrays already resident in HBM (raw device pointers, e.g. torch tensor .data_ptr())."""
+        sl = np.ascontiguousarray(seq_lengths, dtype=np.uint32)
+        of = np.ascontiguousarray(offsets, dtype=np.uint32)
+        lab = b"".join(l.encode() + b"\0" for l in labels)
+        h = C.c_void_p()
+        _check(lib().urmapx_index_wrap_device(device, word_length, max_ix, slot_count, d_blob_ptr, d_seq_ptr,
+                                              seqdata_size, len(labels), sl.ctypes.data, of.ctypes.data, lab,
+                                              C.byref(h)), "urmapx_index_wrap_device")
+        return cls(h.value, keep=tuple(keep) + (sl, of, lab))
+
+    def upload(self, device=0):
+        _check(lib().urmapx_index_upload(self.h, device), "urmapx_index_upload")
+        return self
+
+    @property
+    def word_length(self): return lib().urmapx_index_word_length(self.h)
+    @property
+    def max_ix(self): return lib().urmapx_index_max_ix(self.h)
+    @property
+    def slot_count(self): return lib().urmapx_index_slot_count(self.h)
+    @property
+    def seqdata_size(self): return lib().urmapx_index_seqdata_size(self.h)
+
+    def directory(self):
+        n = lib().urmapx_index_seq_count(self.h)
+        return [(lib().urmapx_index_label(self.h, i).decode(), lib().urmapx_index_seq_length(self.h, i),
+                 lib().urmapx_index_seq_offset(self.h, i)) for i in range(n)]
+
+    def close(self):
+        if self.h:
+            lib().urmapx_index_close(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def decode_path(ops: np.ndarray) -> str:
+    """Run-length path arena entries -> the reference's M/D/I path string."""
+    return "".join("MDI"[int(o) & 3] * (int(o) >> 2) for o in ops)
+
+
+class Mapper:
+    """One mapping context (the State1 of one OMP thread in map.cpp:11-25), batch form."""
+
+    def __init__(self, index: Index, device=0, method=6, params: Params | None = None):
+        self.index = index
+        self.device = device
+        self.params = params if params is not None else params_for_method(method)
+        h = C.c_void_p()
+        _check(lib().urmapx_ctx_create(index.h, device, C.byref(self.params), C.byref(h)), "urmapx_ctx_create")
+        self.h = h
+
+    @property
+    def arch(self):
+        return lib().urmapx_device_arch(self.h).decode()
+
+    def map_se(self, bases: np.ndarray, offs: np.ndarray, allow_unsupported=False):
+        """-> (results structured array, path op arena).  Raises UrmapxError(E_UNSUPPORTED) if any read
+        fell outside the device domain unless allow_unsupported (then check results['status'])."""
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offs = np.ascontiguousarray(offs, dtype=np.uint64)
+        n = len(offs) - 1
+        res = np.zeros(n, dtype=RESULT_DTYPE)
+        cap = max(1, n * MAX_PATH_OPS)
+        ops = np.zeros(cap, dtype=np.uint16)
+        used = C.c_size_t(0)
+        rc = lib().urmapx_map_se(self.h, bases.ctypes.data, offs.ctypes.data, n, res.ctypes.data, ops.ctypes.data, cap,
+                                 C.byref(used))
+        _check(rc, "urmapx_map_se", allow=(E_UNSUPPORTED,) if allow_unsupported else ())
+        return res, ops[: used.value].copy()
+
+    def map_se_device(self, d_bases_ptr, d_offs_ptr, n, total_bases, max_read_len, d_results_ptr, d_path_ops_ptr,
+                      d_path_used_ptr):
+        _check(lib().urmapx_map_se_device(self.h, d_bases_ptr, d_offs_ptr, n, total_bases, max_read_len,
+                                          d_results_ptr, d_path_ops_ptr, d_path_used_ptr), "urmapx_map_se_device")
+
+    def sync(self):
+        _check(lib().urmapx_ctx_sync(self.h), "urmapx_ctx_sync")
+
+    def last_kernel_ms(self):
+        ms = (C.c_float * 2)()
+        _check(lib().urmapx_ctx_last_kernel_ms(self.h, C.byref(ms)), "urmapx_ctx_last_kernel_ms")
+        return float(ms[0]), float(ms[1])
+
+    def seed_probe(self, bases: np.ndarray, offs: np.ndarray):
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offs = np.ascontiguousarray(offs, dtype=np.uint64)
+        n = len(offs) - 1
+        total = int(offs[-1])
+        slots = np.zeros(2 * total, dtype=np.uint64)
+        tallies = np.zeros(2 * total, dtype=np.uint8)
+        positions = np.zeros(2 * total, dtype=np.uint32)
+        _check(lib().urmapx_seed_probe(self.h, bases.ctypes.data, offs.ctypes.data, n, slots.ctypes.data,
+                                       tallies.ctypes.data, positions.ctypes.data), "urmapx_seed_probe")
+        return slots, tallies, positions
+
+    def viterbi_batch(self, pairs, flags):
+        """pairs: list of (A bytes, B bytes); flags: list of ints (bit0 Left, bit1 Right)."""
+        n = len(pairs)
+        a = np.frombuffer(b"".join(p[0] for p in pairs), dtype=np.uint8)
+        b = np.frombuffer(b"".join(p[1] for p in pairs), dtype=np.uint8)
+        ao = np.zeros(n + 1, dtype=np.uint32)
+        bo = np.zeros(n + 1, dtype=np.uint32)
+        ao[1:] = np.cumsum([len(p[0]) for p in pairs])
+        bo[1:] = np.cumsum([len(p[1]) for p in pairs])
+        fl = np.ascontiguousarray(flags, dtype=np.uint8)
+        scores = np.zeros(n, dtype=np.float32)
+        status = np.zeros(n, dtype=np.uint8)
+        ops = np.zeros(n * MAX_PATH_OPS, dtype=np.uint16)
+        nops = np.zeros(n, dtype=np.uint16)
+        a_ = np.ascontiguousarray(a) if len(a) else np.zeros(1, np.uint8)
+        b_ = np.ascontiguousarray(b) if len(b) else np.zeros(1, np.uint8)
+        _check(lib().urmapx_viterbi_batch(self.h, a_.ctypes.data, ao.ctypes.data, b_.ctypes.data, bo.ctypes.data,
+                                          fl.ctypes.data, n, scores.ctypes.data, status.ctypes.data, ops.ctypes.data,
+                                          nops.ctypes.data), "urmapx_viterbi_batch")
+        paths = [decode_path(ops[i * MAX_PATH_OPS: i * MAX_PATH_OPS + int(nops[i])]) for i in range(n)]
+        return scores, status, paths
+
+    def close(self):
+        if self.h:
+            lib().urmapx_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def read_fastq_arrays(path):
+    """Minimal FASTQ -> (labels, bases uint8, offs uint64, quals uint8) for tests and bench."""
+    labels, seqs, quals = [], [], []
+    with open(path, "rb") as f:
+        while True:
+            l1 = f.readline()
+            if not l1:
+                break
+            l1 = l1.rstrip(b"\r\n")
+            if not l1:
+                continue
+            s = f.readline().rstrip(b"\r\n")
+            f.readline()
+            q = f.readline().rstrip(b"\r\n")
+            labels.append(l1[1:].decode())
+            seqs.append(s)
+            quals.append(q)
+    offs = np.zeros(len(seqs) + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum([len(s) for s in seqs])
+    bases = np.frombuffer(b"".join(seqs), dtype=np.uint8)
+    qual = np.frombuffer(b"".join(quals), dtype=np.uint8)
+    return labels, bases, offs, qual

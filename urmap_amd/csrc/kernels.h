@@ -1,0 +1,44 @@
+// kernels.h -- launch wrappers of the gfx950 device code (kernels.hip), called by the C ABI (urmapx.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/urmapx.h"
+
+namespace urx {
+
+// Device-resident view of a UFIndex (ufindex.h:97-131): two big read-only arrays + the directory.
+struct DevIndex {
+	const uint8_t *blob;        // 5*slotCount bytes (+8 pad): {tally u8, pos u32 LE} per slot
+	const uint8_t *seq;         // seqDataSize ASCII bytes (+4096 zero pad)
+	uint64_t slotCount;
+	uint64_t slotMagic;         // floor(2^64 / slotCount): Barrett reciprocal for h % slotCount
+	uint64_t shiftMask;
+	uint32_t W;
+	uint32_t maxIx;
+	uint32_t seqDataSize;
+	uint32_t seqCount;
+	const uint32_t *seqLengths; // device
+	const uint32_t *seqOffsets; // device
+};
+
+// per-k-mer output of the seed+probe stage, SoA; index = 2*offs[r] + strand*L + qpos
+struct ProbeOut {
+	uint64_t *slots;
+	uint8_t *tallies;
+	uint32_t *positions;
+};
+
+hipError_t launch_seed_probe(const DevIndex &X, const uint8_t *d_bases, const uint64_t *d_offs, uint32_t n,
+                             uint32_t max_read_len, ProbeOut out, hipStream_t s);
+
+hipError_t launch_search_se(const DevIndex &X, const urmapx_params &P, const uint8_t *d_bases, const uint64_t *d_offs,
+                            uint32_t n, uint32_t max_read_len, ProbeOut probe, urmapx_result *d_results,
+                            urmapx_path_op *d_path_ops, uint32_t *d_path_used, hipStream_t s);
+
+hipError_t launch_viterbi_batch(const urmapx_params &P, const uint8_t *d_a, const uint32_t *d_aoffs,
+                                const uint8_t *d_b, const uint32_t *d_boffs, const uint8_t *d_flags, uint32_t n,
+                                float *d_scores, uint8_t *d_status, urmapx_path_op *d_ops, uint16_t *d_nops,
+                                hipStream_t s);
+
+}  // namespace urx

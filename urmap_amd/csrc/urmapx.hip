@@ -1,0 +1,418 @@
+// urmapx.hip -- C ABI (include/urmapx.h) over the gfx950 kernels.  Host side only: .ufi parsing
+// (UFIndex::FromFile, ufindexio.cpp:51-115), device upload, workspace management, batch calls.
+// There is no CPU compute path in this library.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+
+using namespace urx;
+
+namespace {
+
+const uint32_t MAGIC1 = ('U' << 24) | ('F' << 16) | ('I' << 8) | '1';
+const uint32_t MAGIC2 = ('U' << 24) | ('F' << 16) | ('I' << 8) | '2';
+const uint32_t MAGIC3 = ('U' << 24) | ('F' << 16) | ('I' << 8) | '3';
+const uint32_t MAGIC5 = ('U' << 24) | ('F' << 16) | ('I' << 8) | '5';
+const size_t SEQ_TAIL_PAD = 4096;  // zero bytes after the sequence: windows may run past the end
+const size_t BLOB_TAIL_PAD = 8;    // the last slot is fetched with an 8-byte load
+
+int hip_rc(hipError_t e) {
+	if (e == hipSuccess) return URMAPX_OK;
+	if (e == hipErrorOutOfMemory) return URMAPX_E_NOMEM;
+	return URMAPX_E_NODEVICE;
+}
+#define HIP_TRY(x)                         \
+	do {                                   \
+		hipError_t e_ = (x);               \
+		if (e_ != hipSuccess) return hip_rc(e_); \
+	} while (0)
+
+bool rd(FILE *f, void *p, size_t n) { return fread(p, 1, n, f) == n; }
+
+template <class T>
+struct DevBuf {
+	T *p = nullptr;
+	size_t cap = 0;
+	int ensure(size_t n) {
+		if (n <= cap) return URMAPX_OK;
+		if (p) (void)hipFree(p);
+		p = nullptr; cap = 0;
+		size_t want = n + n / 4 + 64;
+		hipError_t e = hipMalloc((void **)&p, want * sizeof(T));
+		if (e != hipSuccess) { p = nullptr; return hip_rc(e); }
+		cap = want;
+		return URMAPX_OK;
+	}
+	void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+}  // namespace
+
+struct urmapx_index {
+	uint32_t W = 0, maxIx = 0, seqDataSize = 0;
+	uint64_t slotCount = 0;
+	std::vector<std::string> labels;
+	std::vector<uint32_t> seqLengths, seqOffsets;
+	// host copy (owned or borrowed)
+	const uint8_t *h_blob = nullptr, *h_seq = nullptr;
+	uint8_t *own_blob = nullptr, *own_seq = nullptr;
+	// device copy
+	int device = -1;
+	const uint8_t *d_blob = nullptr, *d_seq = nullptr;
+	bool own_dev = false;
+	uint32_t *d_seqLengths = nullptr, *d_seqOffsets = nullptr;
+
+	DevIndex view() const {
+		DevIndex X;
+		X.blob = d_blob; X.seq = d_seq; X.slotCount = slotCount;
+		X.slotMagic = (uint64_t)((((unsigned __int128)1) << 64) / slotCount);
+		X.shiftMask = (W >= 32) ? ~0ull : ((1ull << (2 * W)) - 1ull);
+		X.W = W; X.maxIx = maxIx; X.seqDataSize = seqDataSize; X.seqCount = (uint32_t)labels.size();
+		X.seqLengths = d_seqLengths; X.seqOffsets = d_seqOffsets;
+		return X;
+	}
+};
+
+struct urmapx_ctx {
+	const urmapx_index *index = nullptr;
+	int device = -1;
+	hipStream_t stream = nullptr;
+	urmapx_params params;
+	DevIndex X;
+	char arch[64];
+	hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+	bool ev_valid = false;
+	// workspace
+	DevBuf<uint8_t> bases, tallies, vflags, vstatus, va, vb;
+	DevBuf<uint64_t> offs, slots;
+	DevBuf<uint32_t> positions, used, vaoffs, vboffs;
+	DevBuf<urmapx_result> results;
+	DevBuf<urmapx_path_op> pathops, vops;
+	DevBuf<float> vscores;
+	DevBuf<uint16_t> vnops;
+};
+
+extern "C" {
+
+const char *urmapx_strerror(int code) {
+	switch (code) {
+	case URMAPX_OK: return "ok";
+	case URMAPX_E_IO: return "I/O error";
+	case URMAPX_E_FORMAT: return "bad .ufi format";
+	case URMAPX_E_NOMEM: return "out of memory";
+	case URMAPX_E_NODEVICE: return "no usable HIP device / HIP runtime error";
+	case URMAPX_E_ARG: return "invalid argument";
+	case URMAPX_E_UNSUPPORTED: return "input outside the device path's domain";
+	default: return "unknown error";
+	}
+}
+
+int urmapx_params_for_method(unsigned method, urmapx_params *p) {  // state1.cpp:147-183
+	if (!p) return URMAPX_E_ARG;
+	if (method == 6 || method == 8) { *p = urmapx_params{-3, -5, -1, 20, 60, 9, 100, 1, 1, 1, 12}; return URMAPX_OK; }
+	if (method == 7) { *p = urmapx_params{-4, -6, -2, 35, 35, 12, 75, 8, 6, 5, 8}; return URMAPX_OK; }
+	return URMAPX_E_ARG;
+}
+
+static int set_directory(urmapx_index *I, uint32_t seq_count, const uint32_t *seq_lengths, const uint32_t *offsets,
+                         const char *labels) {
+	const char *p = labels;
+	for (uint32_t i = 0; i < seq_count; ++i) {
+		I->seqLengths.push_back(seq_lengths[i]);
+		I->seqOffsets.push_back(offsets[i]);
+		I->labels.push_back(std::string(p));
+		p += strlen(p) + 1;
+	}
+	return URMAPX_OK;
+}
+
+int urmapx_index_open(const char *path, urmapx_index **out) {
+	if (!path || !out) return URMAPX_E_ARG;
+	*out = nullptr;
+	FILE *f = fopen(path, "rb");
+	if (!f) return URMAPX_E_IO;
+	urmapx_index *I = new urmapx_index;
+	uint32_t u = 0, seqCount = 0;
+	bool ok = rd(f, &u, 4) && u == MAGIC1 && rd(f, &I->W, 4) && rd(f, &I->maxIx, 4) && rd(f, &I->seqDataSize, 4) &&
+	          rd(f, &I->slotCount, 8) && rd(f, &seqCount, 4);
+	for (uint32_t i = 0; ok && i < seqCount; ++i) {
+		uint32_t L, off, n;
+		ok = rd(f, &L, 4) && rd(f, &off, 4) && rd(f, &n, 4) && n < (1u << 20);
+		if (!ok) break;
+		std::string s(n, '\0');
+		ok = rd(f, &s[0], n);
+		I->seqLengths.push_back(L);
+		I->seqOffsets.push_back(off);
+		I->labels.push_back(std::string(s.c_str()));
+	}
+	ok = ok && rd(f, &u, 4) && u == MAGIC2 && I->slotCount > 0 && I->W >= 1 && I->W <= 32;
+	if (!ok) { fclose(f); delete I; return URMAPX_E_FORMAT; }
+	I->own_blob = (uint8_t *)malloc(5 * I->slotCount + BLOB_TAIL_PAD);
+	I->own_seq = (uint8_t *)calloc((size_t)I->seqDataSize + SEQ_TAIL_PAD, 1);
+	if (!I->own_blob || !I->own_seq) { fclose(f); urmapx_index_close(I); return URMAPX_E_NOMEM; }
+	memset(I->own_blob + 5 * I->slotCount, 0, BLOB_TAIL_PAD);
+	ok = rd(f, I->own_blob, 5 * I->slotCount) && rd(f, &u, 4) && u == MAGIC3 && rd(f, I->own_seq, I->seqDataSize) &&
+	     rd(f, &u, 4) && u == MAGIC5;
+	fclose(f);
+	if (!ok) { urmapx_index_close(I); return URMAPX_E_FORMAT; }
+	I->h_blob = I->own_blob;
+	I->h_seq = I->own_seq;
+	*out = I;
+	return URMAPX_OK;
+}
+
+int urmapx_index_wrap_host(uint32_t W, uint32_t max_ix, uint64_t slot_count, const uint8_t *blob, const uint8_t *seqdata,
+                           uint32_t seqdata_size, uint32_t seq_count, const uint32_t *seq_lengths,
+                           const uint32_t *offsets, const char *labels, urmapx_index **out) {
+	if (!out || !blob || !seqdata || slot_count == 0 || W < 1 || W > 32) return URMAPX_E_ARG;
+	urmapx_index *I = new urmapx_index;
+	I->W = W; I->maxIx = max_ix; I->slotCount = slot_count; I->seqDataSize = seqdata_size;
+	I->h_blob = blob; I->h_seq = seqdata;
+	set_directory(I, seq_count, seq_lengths, offsets, labels);
+	*out = I;
+	return URMAPX_OK;
+}
+
+static int upload_directory(urmapx_index *I) {
+	size_t n = I->labels.size();
+	HIP_TRY(hipMalloc((void **)&I->d_seqLengths, (n + 1) * 4));
+	HIP_TRY(hipMalloc((void **)&I->d_seqOffsets, (n + 1) * 4));
+	HIP_TRY(hipMemcpy(I->d_seqLengths, I->seqLengths.data(), n * 4, hipMemcpyHostToDevice));
+	HIP_TRY(hipMemcpy(I->d_seqOffsets, I->seqOffsets.data(), n * 4, hipMemcpyHostToDevice));
+	return URMAPX_OK;
+}
+
+int urmapx_index_wrap_device(int device, uint32_t W, uint32_t max_ix, uint64_t slot_count, const void *d_blob,
+                             const void *d_seqdata, uint32_t seqdata_size, uint32_t seq_count,
+                             const uint32_t *seq_lengths, const uint32_t *offsets, const char *labels,
+                             urmapx_index **out) {
+	if (!out || !d_blob || !d_seqdata || slot_count == 0 || W < 1 || W > 32) return URMAPX_E_ARG;
+	HIP_TRY(hipSetDevice(device));
+	urmapx_index *I = new urmapx_index;
+	I->W = W; I->maxIx = max_ix; I->slotCount = slot_count; I->seqDataSize = seqdata_size;
+	I->device = device; I->d_blob = (const uint8_t *)d_blob; I->d_seq = (const uint8_t *)d_seqdata; I->own_dev = false;
+	set_directory(I, seq_count, seq_lengths, offsets, labels);
+	int rc = upload_directory(I);
+	if (rc) { urmapx_index_close(I); return rc; }
+	*out = I;
+	return URMAPX_OK;
+}
+
+int urmapx_index_upload(urmapx_index *I, int device) {
+	if (!I) return URMAPX_E_ARG;
+	if (I->d_blob && I->device == device) return URMAPX_OK;
+	if (I->d_blob) return URMAPX_E_ARG;  // one device per index object (one process per GPU)
+	if (!I->h_blob || !I->h_seq) return URMAPX_E_ARG;
+	HIP_TRY(hipSetDevice(device));
+	uint8_t *db = nullptr, *ds = nullptr;
+	const size_t nb = 5 * I->slotCount;
+	HIP_TRY(hipMalloc((void **)&db, nb + BLOB_TAIL_PAD));
+	hipError_t e = hipMalloc((void **)&ds, (size_t)I->seqDataSize + SEQ_TAIL_PAD);
+	if (e != hipSuccess) { (void)hipFree(db); return hip_rc(e); }
+	I->d_blob = db; I->d_seq = ds; I->own_dev = true; I->device = device;
+	HIP_TRY(hipMemset(db + nb, 0, BLOB_TAIL_PAD));
+	HIP_TRY(hipMemset(ds + I->seqDataSize, 0, SEQ_TAIL_PAD));
+	HIP_TRY(hipMemcpy(db, I->h_blob, nb, hipMemcpyHostToDevice));
+	HIP_TRY(hipMemcpy(ds, I->h_seq, I->seqDataSize, hipMemcpyHostToDevice));
+	return upload_directory(I);
+}
+
+void urmapx_index_close(urmapx_index *I) {
+	if (!I) return;
+	if (I->own_dev) { (void)hipFree((void *)I->d_blob); (void)hipFree((void *)I->d_seq); }
+	if (I->d_seqLengths) (void)hipFree(I->d_seqLengths);
+	if (I->d_seqOffsets) (void)hipFree(I->d_seqOffsets);
+	free(I->own_blob);
+	free(I->own_seq);
+	delete I;
+}
+
+uint32_t urmapx_index_word_length(const urmapx_index *I) { return I->W; }
+uint32_t urmapx_index_max_ix(const urmapx_index *I) { return I->maxIx; }
+uint64_t urmapx_index_slot_count(const urmapx_index *I) { return I->slotCount; }
+uint32_t urmapx_index_seqdata_size(const urmapx_index *I) { return I->seqDataSize; }
+uint32_t urmapx_index_seq_count(const urmapx_index *I) { return (uint32_t)I->labels.size(); }
+const char *urmapx_index_label(const urmapx_index *I, uint32_t i) { return i < I->labels.size() ? I->labels[i].c_str() : nullptr; }
+uint32_t urmapx_index_seq_length(const urmapx_index *I, uint32_t i) { return i < I->seqLengths.size() ? I->seqLengths[i] : 0; }
+uint32_t urmapx_index_seq_offset(const urmapx_index *I, uint32_t i) { return i < I->seqOffsets.size() ? I->seqOffsets[i] : 0; }
+
+int urmapx_ctx_create(const urmapx_index *I, int device, const urmapx_params *P, urmapx_ctx **out) {
+	if (!I || !P || !out) return URMAPX_E_ARG;
+	*out = nullptr;
+	if (!I->d_blob || I->device != device) return URMAPX_E_ARG;  // urmapx_index_upload first
+	HIP_TRY(hipSetDevice(device));
+	urmapx_ctx *C = new urmapx_ctx;
+	C->index = I; C->device = device; C->params = *P; C->X = I->view();
+	hipDeviceProp_t prop;
+	hipError_t e = hipGetDeviceProperties(&prop, device);
+	if (e != hipSuccess) { delete C; return hip_rc(e); }
+	snprintf(C->arch, sizeof C->arch, "%s", prop.gcnArchName);
+	if (char *colon = strchr(C->arch, ':')) *colon = 0;
+	e = hipStreamCreateWithFlags(&C->stream, hipStreamNonBlocking);
+	if (e != hipSuccess) { delete C; return hip_rc(e); }
+	for (int i = 0; i < 3; ++i) {
+		e = hipEventCreate(&C->ev[i]);
+		if (e != hipSuccess) { urmapx_ctx_destroy(C); return hip_rc(e); }
+	}
+	*out = C;
+	return URMAPX_OK;
+}
+
+void urmapx_ctx_destroy(urmapx_ctx *C) {
+	if (!C) return;
+	(void)hipSetDevice(C->device);
+	if (C->stream) (void)hipStreamSynchronize(C->stream);
+	C->bases.release(); C->tallies.release(); C->vflags.release(); C->vstatus.release(); C->va.release(); C->vb.release();
+	C->offs.release(); C->slots.release(); C->positions.release(); C->used.release(); C->vaoffs.release(); C->vboffs.release();
+	C->results.release(); C->pathops.release(); C->vops.release(); C->vscores.release(); C->vnops.release();
+	for (int i = 0; i < 3; ++i)
+		if (C->ev[i]) (void)hipEventDestroy(C->ev[i]);
+	if (C->stream) (void)hipStreamDestroy(C->stream);
+	delete C;
+}
+
+const char *urmapx_device_arch(urmapx_ctx *C) { return C ? C->arch : nullptr; }
+
+int urmapx_ctx_sync(urmapx_ctx *C) {
+	if (!C) return URMAPX_E_ARG;
+	HIP_TRY(hipStreamSynchronize(C->stream));
+	return URMAPX_OK;
+}
+
+int urmapx_ctx_last_kernel_ms(urmapx_ctx *C, float ms[2]) {
+	if (!C || !ms || !C->ev_valid) return URMAPX_E_ARG;
+	HIP_TRY(hipEventSynchronize(C->ev[2]));
+	HIP_TRY(hipEventElapsedTime(&ms[0], C->ev[0], C->ev[1]));
+	HIP_TRY(hipEventElapsedTime(&ms[1], C->ev[1], C->ev[2]));
+	return URMAPX_OK;
+}
+
+static int ensure_probe(urmapx_ctx *C, uint64_t total_bases) {
+	int rc;
+	if ((rc = C->slots.ensure(2 * total_bases + 64))) return rc;
+	if ((rc = C->tallies.ensure(2 * total_bases + 64))) return rc;
+	if ((rc = C->positions.ensure(2 * total_bases + 64))) return rc;
+	return URMAPX_OK;
+}
+
+int urmapx_map_se_device(urmapx_ctx *C, const void *d_bases, const void *d_offs, uint32_t n, uint64_t total_bases,
+                         uint32_t max_read_len, void *d_results, void *d_path_ops, void *d_path_used) {
+	if (!C || (n && (!d_bases || !d_offs || !d_results || !d_path_ops || !d_path_used))) return URMAPX_E_ARG;
+	if (max_read_len > URMAPX_MAX_QL) return URMAPX_E_UNSUPPORTED;
+	HIP_TRY(hipSetDevice(C->device));
+	int rc = ensure_probe(C, total_bases);
+	if (rc) return rc;
+	ProbeOut po{C->slots.p, C->tallies.p, C->positions.p};
+	HIP_TRY(hipMemsetAsync(d_path_used, 0, 4, C->stream));
+	HIP_TRY(hipEventRecord(C->ev[0], C->stream));
+	HIP_TRY(launch_seed_probe(C->X, (const uint8_t *)d_bases, (const uint64_t *)d_offs, n, max_read_len, po, C->stream));
+	HIP_TRY(hipEventRecord(C->ev[1], C->stream));
+	HIP_TRY(launch_search_se(C->X, C->params, (const uint8_t *)d_bases, (const uint64_t *)d_offs, n, max_read_len, po,
+	                         (urmapx_result *)d_results, (urmapx_path_op *)d_path_ops, (uint32_t *)d_path_used, C->stream));
+	HIP_TRY(hipEventRecord(C->ev[2], C->stream));
+	C->ev_valid = true;
+	return URMAPX_OK;
+}
+
+static uint32_t max_len(const uint64_t *offs, uint32_t n) {
+	uint64_t m = 0;
+	for (uint32_t i = 0; i < n; ++i) m = offs[i + 1] - offs[i] > m ? offs[i + 1] - offs[i] : m;
+	return m > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)m;
+}
+
+int urmapx_map_se(urmapx_ctx *C, const uint8_t *bases, const uint64_t *offs, uint32_t n, urmapx_result *results,
+                  urmapx_path_op *path_ops, size_t path_cap, size_t *path_used) {
+	if (!C || (n && (!bases || !offs || !results))) return URMAPX_E_ARG;
+	if (path_used) *path_used = 0;
+	if (n == 0) return URMAPX_OK;
+	HIP_TRY(hipSetDevice(C->device));
+	const uint64_t total = offs[n];
+	uint32_t mx = max_len(offs, n);
+	// reads longer than the device domain are flagged per read by the kernel; size the kernel for the cap
+	if (mx > URMAPX_MAX_QL) mx = URMAPX_MAX_QL;
+	int rc;
+	if ((rc = C->bases.ensure(total + 64))) return rc;
+	if ((rc = C->offs.ensure((size_t)n + 1))) return rc;
+	if ((rc = C->results.ensure(n))) return rc;
+	if ((rc = C->pathops.ensure((size_t)n * URMAPX_MAX_PATH_OPS))) return rc;
+	if ((rc = C->used.ensure(1))) return rc;
+	HIP_TRY(hipMemcpyAsync(C->bases.p, bases, total, hipMemcpyHostToDevice, C->stream));
+	HIP_TRY(hipMemcpyAsync(C->offs.p, offs, ((size_t)n + 1) * 8, hipMemcpyHostToDevice, C->stream));
+	rc = urmapx_map_se_device(C, C->bases.p, C->offs.p, n, total, mx, C->results.p, C->pathops.p, C->used.p);
+	if (rc) return rc;
+	uint32_t used = 0;
+	HIP_TRY(hipMemcpyAsync(results, C->results.p, (size_t)n * sizeof(urmapx_result), hipMemcpyDeviceToHost, C->stream));
+	HIP_TRY(hipMemcpyAsync(&used, C->used.p, 4, hipMemcpyDeviceToHost, C->stream));
+	HIP_TRY(hipStreamSynchronize(C->stream));
+	if (used > path_cap || (used && !path_ops)) return URMAPX_E_ARG;
+	if (used) HIP_TRY(hipMemcpy(path_ops, C->pathops.p, (size_t)used * sizeof(urmapx_path_op), hipMemcpyDeviceToHost));
+	if (path_used) *path_used = used;
+	for (uint32_t i = 0; i < n; ++i)
+		if (results[i].status) return URMAPX_E_UNSUPPORTED;
+	return URMAPX_OK;
+}
+
+int urmapx_seed_probe(urmapx_ctx *C, const uint8_t *bases, const uint64_t *offs, uint32_t n, uint64_t *slots,
+                      uint8_t *tallies, uint32_t *positions) {
+	if (!C || (n && (!bases || !offs || !slots || !tallies || !positions))) return URMAPX_E_ARG;
+	if (n == 0) return URMAPX_OK;
+	HIP_TRY(hipSetDevice(C->device));
+	const uint64_t total = offs[n];
+	uint32_t mx = max_len(offs, n);
+	if (mx > URMAPX_MAX_QL) return URMAPX_E_UNSUPPORTED;
+	int rc;
+	if ((rc = C->bases.ensure(total + 64))) return rc;
+	if ((rc = C->offs.ensure((size_t)n + 1))) return rc;
+	if ((rc = ensure_probe(C, total))) return rc;
+	HIP_TRY(hipMemcpyAsync(C->bases.p, bases, total, hipMemcpyHostToDevice, C->stream));
+	HIP_TRY(hipMemcpyAsync(C->offs.p, offs, ((size_t)n + 1) * 8, hipMemcpyHostToDevice, C->stream));
+	// entries the kernel does not write (positions > L-W) read back as "no k-mer"
+	HIP_TRY(hipMemsetAsync(C->slots.p, 0xFF, 2 * total * 8, C->stream));
+	HIP_TRY(hipMemsetAsync(C->tallies.p, 0, 2 * total, C->stream));
+	HIP_TRY(hipMemsetAsync(C->positions.p, 0xFF, 2 * total * 4, C->stream));
+	ProbeOut po{C->slots.p, C->tallies.p, C->positions.p};
+	HIP_TRY(launch_seed_probe(C->X, C->bases.p, C->offs.p, n, mx, po, C->stream));
+	HIP_TRY(hipMemcpyAsync(slots, C->slots.p, 2 * total * 8, hipMemcpyDeviceToHost, C->stream));
+	HIP_TRY(hipMemcpyAsync(tallies, C->tallies.p, 2 * total, hipMemcpyDeviceToHost, C->stream));
+	HIP_TRY(hipMemcpyAsync(positions, C->positions.p, 2 * total * 4, hipMemcpyDeviceToHost, C->stream));
+	HIP_TRY(hipStreamSynchronize(C->stream));
+	return URMAPX_OK;
+}
+
+int urmapx_viterbi_batch(urmapx_ctx *C, const uint8_t *a, const uint32_t *a_offs, const uint8_t *b, const uint32_t *b_offs,
+                         const uint8_t *flags, uint32_t n, float *scores, uint8_t *status, urmapx_path_op *ops,
+                         uint16_t *nops) {
+	if (!C || (n && (!a_offs || !b_offs || !flags || !scores || !status || !ops || !nops))) return URMAPX_E_ARG;
+	if (n == 0) return URMAPX_OK;
+	HIP_TRY(hipSetDevice(C->device));
+	const size_t ta = a_offs[n], tb = b_offs[n];
+	int rc;
+	if ((rc = C->va.ensure(ta + 64))) return rc;
+	if ((rc = C->vb.ensure(tb + 64))) return rc;
+	if ((rc = C->vaoffs.ensure((size_t)n + 1))) return rc;
+	if ((rc = C->vboffs.ensure((size_t)n + 1))) return rc;
+	if ((rc = C->vflags.ensure(n))) return rc;
+	if ((rc = C->vstatus.ensure(n))) return rc;
+	if ((rc = C->vscores.ensure(n))) return rc;
+	if ((rc = C->vnops.ensure(n))) return rc;
+	if ((rc = C->vops.ensure((size_t)n * URMAPX_MAX_PATH_OPS))) return rc;
+	if (ta) HIP_TRY(hipMemcpyAsync(C->va.p, a, ta, hipMemcpyHostToDevice, C->stream));
+	if (tb) HIP_TRY(hipMemcpyAsync(C->vb.p, b, tb, hipMemcpyHostToDevice, C->stream));
+	HIP_TRY(hipMemcpyAsync(C->vaoffs.p, a_offs, ((size_t)n + 1) * 4, hipMemcpyHostToDevice, C->stream));
+	HIP_TRY(hipMemcpyAsync(C->vboffs.p, b_offs, ((size_t)n + 1) * 4, hipMemcpyHostToDevice, C->stream));
+	HIP_TRY(hipMemcpyAsync(C->vflags.p, flags, n, hipMemcpyHostToDevice, C->stream));
+	HIP_TRY(launch_viterbi_batch(C->params, C->va.p, C->vaoffs.p, C->vb.p, C->vboffs.p, C->vflags.p, n, C->vscores.p,
+	                             C->vstatus.p, C->vops.p, C->vnops.p, C->stream));
+	HIP_TRY(hipMemcpyAsync(scores, C->vscores.p, (size_t)n * 4, hipMemcpyDeviceToHost, C->stream));
+	HIP_TRY(hipMemcpyAsync(status, C->vstatus.p, n, hipMemcpyDeviceToHost, C->stream));
+	HIP_TRY(hipMemcpyAsync(nops, C->vnops.p, (size_t)n * 2, hipMemcpyDeviceToHost, C->stream));
+	HIP_TRY(hipMemcpyAsync(ops, C->vops.p, (size_t)n * URMAPX_MAX_PATH_OPS * 2, hipMemcpyDeviceToHost, C->stream));
+	HIP_TRY(hipStreamSynchronize(C->stream));
+	return URMAPX_OK;
+}
+
+}  // extern "C"
