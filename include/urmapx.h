@@ -141,6 +141,15 @@ int urmapx_viterbi_batch(urmapx_ctx *, const uint8_t *a, const uint32_t *a_offs,
                          const uint32_t *b_offs, const uint8_t *flags, uint32_t n, float *scores, uint8_t *status,
                          urmapx_path_op *ops, uint16_t *nops);
 
+/* ---- index construction (host side; the command line's -make_ufi) ---- */
+/* cmd_make_ufi (ufindexio.cpp:117-179): FASTA -> .ufi, byte-identical to the reference's for the same slot count.
+ * slots is mandatory here (the reference's default picks the first entry >= file_size/0.6 of its built-in prime
+ * table, primes.h, which is data this library does not carry). */
+int urmapx_make_ufi(const char *fasta_path, const char *ufi_path, uint32_t word_length, uint32_t max_ix, uint64_t slots);
+/* UFIndex::MakeIndex (ufindex.cpp:83-151) on an already concatenated upper-case sequence store; blob: 5*slots bytes. */
+int urmapx_build_slots(const uint8_t *seqdata, uint32_t seqdata_size, uint32_t word_length, uint32_t max_ix,
+                       uint64_t slots, uint8_t *blob, uint32_t *truncated_out);
+
 const char *urmapx_strerror(int code);
 /* "gfx950" etc. of the ctx's device; NULL without a device */
 const char *urmapx_device_arch(urmapx_ctx *);

@@ -30,6 +30,7 @@ EXPORTS = (
     "urmapx_index_seq_length", "urmapx_index_seq_offset", "urmapx_ctx_create", "urmapx_ctx_destroy",
     "urmapx_map_se", "urmapx_map_se_device", "urmapx_ctx_sync", "urmapx_ctx_last_kernel_ms",
     "urmapx_seed_probe", "urmapx_viterbi_batch", "urmapx_strerror", "urmapx_device_arch",
+    "urmapx_make_ufi", "urmapx_build_slots",
 )
 
 
@@ -86,6 +87,8 @@ def lib():
     L.urmapx_ctx_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float * 2)]
     L.urmapx_seed_probe.argtypes = [vp, vp, vp, u32, vp, vp, vp]
     L.urmapx_viterbi_batch.argtypes = [vp, vp, vp, vp, vp, vp, u32, vp, vp, vp, vp]
+    L.urmapx_make_ufi.argtypes = [cp, cp, u32, u32, u64]
+    L.urmapx_build_slots.argtypes = [vp, u32, u32, u32, u64, vp, C.POINTER(u32)]
     L.urmapx_strerror.restype = cp
     L.urmapx_strerror.argtypes = [i32]
     L.urmapx_device_arch.restype = cp
@@ -109,6 +112,22 @@ def params_for_method(method=6) -> Params:
     p = Params()
     _check(lib().urmapx_params_for_method(method, C.byref(p)), "urmapx_params_for_method")
     return p
+
+
+def make_ufi(fasta, ufi, slots, word_length=24, max_ix=32):
+    """urmap -make_ufi FASTA -output UFI -slots N (ufindexio.cpp:117-179)."""
+    _check(lib().urmapx_make_ufi(os.fsencode(fasta), os.fsencode(ufi), word_length, max_ix, slots), "urmapx_make_ufi")
+
+
+def build_slots(seqdata: np.ndarray, slots, word_length=24, max_ix=32) -> np.ndarray:
+    """UFIndex::MakeIndex on a concatenated upper-case sequence store -> 5*slots byte slot table."""
+    seqdata = np.ascontiguousarray(seqdata, dtype=np.uint8)
+    blob = np.empty(5 * slots + 8, dtype=np.uint8)
+    blob[5 * slots:] = 0
+    trunc = C.c_uint32(0)
+    _check(lib().urmapx_build_slots(seqdata.ctypes.data, len(seqdata), word_length, max_ix, slots, blob.ctypes.data,
+                                    C.byref(trunc)), "urmapx_build_slots")
+    return blob
 
 
 class Index:

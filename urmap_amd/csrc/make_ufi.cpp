@@ -1,0 +1,249 @@
+// make_ufi.cpp -- host-side index construction for the command line's -make_ufi (product code).
+// Behaviour of cmd_make_ufi / UFIndex::ReadSeqData / CountSlots / CountSlots_Minus / MakeIndex / UpdateSlot /
+// FindEndOfList / FindFreeSlot / TruncateSlot / ToFile (ufindexio.cpp:14-49,117-179; ufindex.cpp:83-322,338-408,
+// 462-511,945-1000): the insertion pass is order dependent (each overflow position takes the first free
+// borrowable slot after its chain's current end), so it stays sequential on the host; slots are hashed a
+// block ahead and prefetched so the pass runs at memory-level parallelism instead of one miss at a time.
+#include <cctype>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/urmapx.h"
+
+namespace {
+
+const uint8_t T_FREE = 0, T_END = 127, T_MINE = 128, T_PLUS1 = 254, T_BOTH1 = 255, T_MAXNEXT = 124, T_LONG_MINE = 253,
+              T_LONG_OTHER = 125;
+const unsigned LINK_LIMIT = 0xffff, PAD = 32;
+const uint32_t M1 = 0x55464931u, M2 = 0x55464932u, M3 = 0x55464933u, M5 = 0x55464935u;
+
+inline uint64_t mix(uint64_t h) {
+	h ^= h >> 33; h *= 0xff51afd7ed558ccdULL; h ^= h >> 33; h *= 0xc4ceb9fe1a85ec53ULL; h ^= h >> 33;
+	return h;
+}
+
+struct Table {
+	uint8_t *blob;
+	uint64_t N;
+	uint32_t maxIx;
+	std::vector<uint8_t> nplus, nminus;
+	unsigned truncated = 0;
+
+	uint8_t tally(uint64_t s) const { return blob[5 * s]; }
+	uint32_t pos(uint64_t s) const { uint32_t p; memcpy(&p, blob + 5 * s + 1, 4); return p; }
+	void put(uint64_t s, uint8_t t, uint32_t p) { blob[5 * s] = t; memcpy(blob + 5 * s + 1, &p, 4); }
+
+	bool advance(uint64_t &s) const {  // one chain link; false at the end
+		uint8_t t = tally(s);
+		if (t == T_PLUS1 || t == T_BOTH1 || t == T_END) return false;
+		if (t == T_LONG_MINE || t == T_LONG_OTHER) {
+			uint32_t p = pos(s);
+			s = ((s + (p & 0xffff)) % N + (p >> 16)) % N;
+		} else
+			s = (s + (t & 127)) % N;
+		return true;
+	}
+	unsigned free_after(uint64_t s) const {
+		for (unsigned i = 1; i < LINK_LIMIT; ++i) {
+			uint64_t c = (s + i) % N;
+			uint8_t n = nplus[c];
+			if (n > 0 && n <= maxIx) continue;  // a home slot of some indexed word: never lent out
+			if (tally(c) == T_FREE) return i;
+		}
+		return ~0u;
+	}
+	void wipe(uint64_t head) {
+		++truncated;
+		uint64_t s = head;
+		for (;;) {
+			uint64_t nxt = s;
+			bool more = advance(nxt);
+			put(s, T_FREE, 0xffffffffu);
+			if (!more) return;
+			s = nxt;
+		}
+	}
+	void insert(uint64_t slot, uint32_t p) {
+		uint8_t n = nplus[slot], nm = nminus[slot];
+		if (n > maxIx || nm > maxIx) return;
+		if (tally(slot) == T_FREE) { put(slot, (n == 1 && nm == 0) ? T_BOTH1 : T_PLUS1, p); return; }
+		uint64_t eol = slot;
+		while (advance(eol)) {}
+		unsigned s1 = free_after(eol);
+		if (s1 == ~0u) { wipe(slot); return; }
+		uint64_t f1 = (eol + s1) % N;
+		if (s1 <= T_MAXNEXT) {
+			blob[5 * eol] = (uint8_t)((tally(eol) & T_MINE) | s1);
+			put(f1, T_END, p);
+			return;
+		}
+		unsigned s2 = free_after(f1);
+		if (s2 == ~0u) { wipe(slot); return; }
+		uint64_t f2 = (f1 + s2) % N;
+		uint32_t eolpos = pos(eol);
+		put(eol, eol == slot ? T_LONG_MINE : T_LONG_OTHER, s1 | (s2 << 16));
+		put(f1, T_LONG_OTHER, eolpos);
+		put(f2, T_END, p);
+	}
+};
+
+inline int code_of(uint8_t c) {
+	switch (c) {
+	case 'A': case 'a': return 0; case 'C': case 'c': return 1; case 'G': case 'g': return 2;
+	case 'T': case 't': case 'U': case 'u': return 3; default: return -1;
+	}
+}
+inline int comp_code_of(uint8_t c) {  // complement letter; lower-case 'u' has none (alpha.cpp:3525)
+	if (c == 'u') return -1;
+	int k = code_of(c);
+	return k < 0 ? -1 : 3 - k;
+}
+
+bool load_fasta(const char *path, std::vector<std::string> &labels, std::vector<std::string> &seqs) {
+	FILE *f = fopen(path, "rb");
+	if (!f) return false;
+	std::vector<char> buf(1 << 22);
+	std::string line;
+	bool in_rec = false;
+	auto end_rec = [&]() {
+		if (in_rec && seqs.back().empty()) { seqs.pop_back(); labels.pop_back(); }  // empty records are dropped
+	};
+	auto take = [&](const std::string &l) {
+		if (!l.empty() && l[0] == '>') {
+			end_rec();
+			size_t e = 1;
+			while (e < l.size() && !isspace((unsigned char)l[e])) ++e;  // -make_ufi truncates labels at white space
+			labels.push_back(l.substr(1, e - 1));
+			seqs.emplace_back();
+			in_rec = true;
+		} else if (in_rec) {
+			std::string &s = seqs.back();
+			for (unsigned char c : l)
+				if (isalpha(c)) s.push_back((char)toupper(c));  // gaps, digits, blanks dropped; upper-cased
+		}
+	};
+	size_t n;
+	while ((n = fread(buf.data(), 1, buf.size(), f)) > 0) {
+		for (size_t i = 0; i < n; ++i) {
+			char c = buf[i];
+			if (c == '\n') { take(line); line.clear(); }
+			else if (c != '\r') line.push_back(c);
+		}
+	}
+	if (!line.empty()) take(line);
+	end_rec();
+	fclose(f);
+	return true;
+}
+
+}  // namespace
+
+// Builds the slot table for an already concatenated, upper-cased sequence store.  blob must hold 5*slots bytes.
+extern "C" int urmapx_build_slots(const uint8_t *seqdata, uint32_t size, uint32_t W, uint32_t max_ix, uint64_t slots,
+                                  uint8_t *blob, uint32_t *truncated_out) {
+	if (!seqdata || !blob || slots == 0 || W < 1 || W > 32) return URMAPX_E_ARG;
+	Table T;
+	T.blob = blob; T.N = slots; T.maxIx = max_ix;
+	for (uint64_t s = 0; s < slots; ++s) T.put(s, T_FREE, 0xffffffffu);
+	T.nplus.assign(slots, 0);
+	T.nminus.assign(slots, 0);
+	const uint64_t mask = W >= 32 ? ~0ull : ((1ull << (2 * W)) - 1);
+	const int BLK = 4096;
+	std::vector<uint64_t> hs(BLK);
+	std::vector<uint32_t> hp(BLK);
+	// pass 1: plus-strand counts (forward), pass 2: minus-strand counts (backward, complemented letters)
+	for (int pass = 0; pass < 2; ++pass) {
+		std::vector<uint8_t> &cnt = pass == 0 ? T.nplus : T.nminus;
+		uint64_t word = 0; unsigned k = 0; int nb = 0;
+		auto flush = [&]() {
+			for (int i = 0; i < nb; ++i) { uint8_t &c = cnt[hs[i]]; if (c < 255) ++c; }
+			nb = 0;
+		};
+		for (uint32_t t = 0; t < size; ++t) {
+			uint32_t p = pass == 0 ? t : size - 1 - t;
+			int L = pass == 0 ? code_of(seqdata[p]) : comp_code_of(seqdata[p]);
+			if (L < 0) { k = 0; word = 0; continue; }
+			if (k < W) ++k;
+			word = (word << 2) | (uint64_t)L;
+			if (k == W) {
+				uint64_t s = mix(word & mask) % slots;
+				__builtin_prefetch(&cnt[s], 1);
+				hs[nb++] = s;
+				if (nb == BLK) flush();
+			}
+		}
+		flush();
+	}
+	// pass 3: insertion in genome order
+	{
+		uint64_t word = 0; unsigned k = 0; int nb = 0;
+		auto flush = [&]() {
+			for (int i = 0; i < nb; ++i) T.insert(hs[i], hp[i]);
+			nb = 0;
+		};
+		for (uint32_t p = 0; p < size; ++p) {
+			int L = code_of(seqdata[p]);
+			if (L < 0) { k = 0; word = 0; continue; }
+			if (k < W) ++k;
+			word = (word << 2) | (uint64_t)L;
+			if (k == W) {
+				uint64_t s = mix(word & mask) % slots;
+				__builtin_prefetch(blob + 5 * s, 1);
+				__builtin_prefetch(&T.nplus[s], 0);
+				__builtin_prefetch(&T.nminus[s], 0);
+				hs[nb] = s; hp[nb] = p - (W - 1); ++nb;
+				if (nb == BLK) flush();
+			}
+		}
+		flush();
+	}
+	if (truncated_out) *truncated_out = T.truncated;
+	return URMAPX_OK;
+}
+
+// -make_ufi FASTA -output UFI [-wordlength W] [-maxix N] -slots S
+extern "C" int urmapx_make_ufi(const char *fasta_path, const char *ufi_path, uint32_t W, uint32_t max_ix, uint64_t slots) {
+	if (!fasta_path || !ufi_path || slots == 0) return URMAPX_E_ARG;
+	std::vector<std::string> labels, seqs;
+	if (!load_fasta(fasta_path, labels, seqs)) return URMAPX_E_IO;
+	if (seqs.empty()) return URMAPX_E_FORMAT;
+	std::vector<uint32_t> lens, offs;
+	uint64_t total = 0;
+	for (size_t i = 0; i < seqs.size(); ++i) {
+		lens.push_back((uint32_t)seqs[i].size());
+		offs.push_back((uint32_t)total);
+		total += seqs[i].size();
+		if (i + 1 != seqs.size()) total += PAD;
+	}
+	if (total > 0xFFFFFFFFull - 100000) return URMAPX_E_UNSUPPORTED;  // "Genome too big", ufindexio.cpp:152-154
+	std::vector<uint8_t> store((size_t)total);
+	for (size_t i = 0; i < seqs.size(); ++i) {
+		memcpy(store.data() + offs[i], seqs[i].data(), seqs[i].size());
+		if (i + 1 != seqs.size()) memset(store.data() + offs[i] + seqs[i].size(), '-', PAD);
+		std::string().swap(seqs[i]);
+	}
+	uint8_t *blob = (uint8_t *)malloc(5 * slots);
+	if (!blob) return URMAPX_E_NOMEM;
+	int rc = urmapx_build_slots(store.data(), (uint32_t)total, W, max_ix, slots, blob, nullptr);
+	if (rc) { free(blob); return rc; }
+	FILE *f = fopen(ufi_path, "wb");
+	if (!f) { free(blob); return URMAPX_E_IO; }
+	auto w32 = [&](uint32_t v) { fwrite(&v, 4, 1, f); };
+	w32(M1); w32(W); w32(max_ix); w32((uint32_t)total);
+	fwrite(&slots, 8, 1, f);
+	w32((uint32_t)labels.size());
+	for (size_t i = 0; i < labels.size(); ++i) {
+		w32(lens[i]); w32(offs[i]); w32((uint32_t)labels[i].size());
+		fwrite(labels[i].data(), 1, labels[i].size(), f);
+	}
+	w32(M2);
+	fwrite(blob, 1, 5 * slots, f);
+	w32(M3);
+	fwrite(store.data(), 1, store.size(), f);
+	w32(M5);
+	free(blob);
+	return fclose(f) == 0 ? URMAPX_OK : URMAPX_E_IO;
+}
