@@ -122,11 +122,29 @@ def test_viterbi_matches_oracle(gpu):
     pairs += [(b"ACGT", b""), (b"A", b"A"), (b"A", b"CCCCCCCCCCCCCCCCCCCCCCCCC"), (b"ACGTACGTAC", b"ACGTACGTAC"),
               (b"ACGTACGTAC" * 5, (b"ACGTACGTAC" * 5)[:30])]
     flags += [2, 1, 1, 3, 2]
+    # bands wider than one wavefront: flank windows clipped at the end of the sequence store (alignhsp.cpp:143-145)
+    # and the paired-end rescue's whole-read DP against a 1024+2*QL window (scan.cpp:14-39)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    for la, lb in ((100, 20), (140, 3), (90, 60), (150, 1324), (150, 1200), (250, 1524), (64, 200)):
+        t = acgt[rng.integers(0, 4, size=lb)]
+        q = acgt[rng.integers(0, 4, size=la)]
+        if lb > la + 50:
+            st = int(rng.integers(0, lb - la))
+            q = t[st:st + la].copy()
+            q[rng.integers(0, la, size=la // 20)] = acgt[rng.integers(0, 4, size=la // 20)]
+        for fl in (0, 1, 2, 3):
+            pairs.append((q.tobytes(), t.tobytes()))
+            flags.append(fl)
     scores, status, paths = gpu["mapper"].viterbi_batch(pairs, flags)
-    assert (status == 0).all()
+    import itertools
     for k, ((a, b), fl) in enumerate(zip(pairs, flags)):
         s, p = ol.viterbi(a, b, bool(fl & 1), bool(fl & 2))
         assert float(scores[k]) == s, f"case {k}: score gpu {scores[k]} oracle {s}"
+        runs = sum(1 for _ in itertools.groupby(p))
+        if runs > 48:  # more runs than URMAPX_MAX_PATH_OPS: must be flagged, never truncated silently
+            assert status[k] == 0x04, f"case {k}: {runs} runs, status {status[k]}"
+            continue
+        assert status[k] == 0, f"case {k}: status {status[k]}"
         assert paths[k] == p, f"case {k}: path gpu {paths[k]} oracle {p}"
 
 

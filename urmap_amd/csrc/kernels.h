@@ -32,13 +32,24 @@ struct ProbeOut {
 hipError_t launch_seed_probe(const DevIndex &X, const uint8_t *d_bases, const uint64_t *d_offs, uint32_t n,
                              uint32_t max_read_len, ProbeOut out, hipStream_t s);
 
+// workspace of the persistent search kernel: a ticket counter and per-block global scratch
+struct SearchWork {
+	uint32_t *ticket;
+	uint8_t *scratch;
+	size_t scratch_stride;  // search_scratch_stride(max_read_len)
+	int blocks;             // search_block_count(max_read_len, device)
+};
+size_t search_scratch_stride(uint32_t max_read_len);
+int search_block_count(uint32_t max_read_len, int device);
+size_t viterbi_batch_scratch_stride();
+
 hipError_t launch_search_se(const DevIndex &X, const urmapx_params &P, const uint8_t *d_bases, const uint64_t *d_offs,
                             uint32_t n, uint32_t max_read_len, ProbeOut probe, urmapx_result *d_results,
-                            urmapx_path_op *d_path_ops, uint32_t *d_path_used, hipStream_t s);
+                            urmapx_path_op *d_path_ops, uint32_t *d_path_used, const SearchWork &wk, hipStream_t s);
 
 hipError_t launch_viterbi_batch(const urmapx_params &P, const uint8_t *d_a, const uint32_t *d_aoffs,
                                 const uint8_t *d_b, const uint32_t *d_boffs, const uint8_t *d_flags, uint32_t n,
                                 float *d_scores, uint8_t *d_status, urmapx_path_op *d_ops, uint16_t *d_nops,
-                                hipStream_t s);
+                                uint8_t *d_scratch, hipStream_t s);
 
 }  // namespace urx

@@ -94,6 +94,9 @@ struct urmapx_ctx {
 	DevBuf<urmapx_path_op> pathops, vops;
 	DevBuf<float> vscores;
 	DevBuf<uint16_t> vnops;
+	DevBuf<uint8_t> scratch, vscratch;
+	DevBuf<uint32_t> ticket;
+	int blocks[2] = {0, 0};  // persistent grid size of the search kernel for read length classes <=192, <=320
 };
 
 extern "C" {
@@ -269,6 +272,7 @@ void urmapx_ctx_destroy(urmapx_ctx *C) {
 	C->bases.release(); C->tallies.release(); C->vflags.release(); C->vstatus.release(); C->va.release(); C->vb.release();
 	C->offs.release(); C->slots.release(); C->positions.release(); C->used.release(); C->vaoffs.release(); C->vboffs.release();
 	C->results.release(); C->pathops.release(); C->vops.release(); C->vscores.release(); C->vnops.release();
+	C->scratch.release(); C->vscratch.release(); C->ticket.release();
 	for (int i = 0; i < 3; ++i)
 		if (C->ev[i]) (void)hipEventDestroy(C->ev[i]);
 	if (C->stream) (void)hipStreamDestroy(C->stream);
@@ -307,12 +311,22 @@ int urmapx_map_se_device(urmapx_ctx *C, const void *d_bases, const void *d_offs,
 	int rc = ensure_probe(C, total_bases);
 	if (rc) return rc;
 	ProbeOut po{C->slots.p, C->tallies.p, C->positions.p};
+	const int cls = max_read_len <= 192 ? 0 : 1;
+	if (C->blocks[cls] == 0) C->blocks[cls] = search_block_count(max_read_len, C->device);
+	if (C->blocks[cls] <= 0) return URMAPX_E_NODEVICE;
+	SearchWork wk;
+	wk.blocks = C->blocks[cls];
+	wk.scratch_stride = search_scratch_stride(max_read_len);
+	if ((rc = C->scratch.ensure(wk.scratch_stride * (size_t)wk.blocks))) return rc;
+	if ((rc = C->ticket.ensure(4))) return rc;
+	wk.scratch = C->scratch.p;
+	wk.ticket = C->ticket.p;
 	HIP_TRY(hipMemsetAsync(d_path_used, 0, 4, C->stream));
 	HIP_TRY(hipEventRecord(C->ev[0], C->stream));
 	HIP_TRY(launch_seed_probe(C->X, (const uint8_t *)d_bases, (const uint64_t *)d_offs, n, max_read_len, po, C->stream));
 	HIP_TRY(hipEventRecord(C->ev[1], C->stream));
 	HIP_TRY(launch_search_se(C->X, C->params, (const uint8_t *)d_bases, (const uint64_t *)d_offs, n, max_read_len, po,
-	                         (urmapx_result *)d_results, (urmapx_path_op *)d_path_ops, (uint32_t *)d_path_used, C->stream));
+	                         (urmapx_result *)d_results, (urmapx_path_op *)d_path_ops, (uint32_t *)d_path_used, wk, C->stream));
 	HIP_TRY(hipEventRecord(C->ev[2], C->stream));
 	C->ev_valid = true;
 	return URMAPX_OK;
@@ -400,13 +414,14 @@ int urmapx_viterbi_batch(urmapx_ctx *C, const uint8_t *a, const uint32_t *a_offs
 	if ((rc = C->vscores.ensure(n))) return rc;
 	if ((rc = C->vnops.ensure(n))) return rc;
 	if ((rc = C->vops.ensure((size_t)n * URMAPX_MAX_PATH_OPS))) return rc;
+	if ((rc = C->vscratch.ensure((size_t)n * viterbi_batch_scratch_stride()))) return rc;
 	if (ta) HIP_TRY(hipMemcpyAsync(C->va.p, a, ta, hipMemcpyHostToDevice, C->stream));
 	if (tb) HIP_TRY(hipMemcpyAsync(C->vb.p, b, tb, hipMemcpyHostToDevice, C->stream));
 	HIP_TRY(hipMemcpyAsync(C->vaoffs.p, a_offs, ((size_t)n + 1) * 4, hipMemcpyHostToDevice, C->stream));
 	HIP_TRY(hipMemcpyAsync(C->vboffs.p, b_offs, ((size_t)n + 1) * 4, hipMemcpyHostToDevice, C->stream));
 	HIP_TRY(hipMemcpyAsync(C->vflags.p, flags, n, hipMemcpyHostToDevice, C->stream));
 	HIP_TRY(launch_viterbi_batch(C->params, C->va.p, C->vaoffs.p, C->vb.p, C->vboffs.p, C->vflags.p, n, C->vscores.p,
-	                             C->vstatus.p, C->vops.p, C->vnops.p, C->stream));
+	                             C->vstatus.p, C->vops.p, C->vnops.p, C->vscratch.p, C->stream));
 	HIP_TRY(hipMemcpyAsync(scores, C->vscores.p, (size_t)n * 4, hipMemcpyDeviceToHost, C->stream));
 	HIP_TRY(hipMemcpyAsync(status, C->vstatus.p, n, hipMemcpyDeviceToHost, C->stream));
 	HIP_TRY(hipMemcpyAsync(nops, C->vnops.p, (size_t)n * 2, hipMemcpyDeviceToHost, C->stream));

@@ -1,0 +1,316 @@
+// viterbi_dev.h -- banded Viterbi + traceback on one wavefront; see kernels.hip for the overview.
+#pragma once
+#include "dev_common.h"
+
+namespace urx {
+
+// ------------------------------------------------------------------------------------------------
+// banded Viterbi on one wavefront (lane = diagonal), viterbi.cpp:11-261 + tracebackbitmem.cpp:8-75
+// ------------------------------------------------------------------------------------------------
+// Per-wavefront global scratch of the wide-band fallback: DP rows and a byte-per-cell trace matrix.
+struct WideScratch {
+	float *Mr;    // lb_cap + 4 floats, Mr[j + 1] = Mrow[j] (j >= -1)
+	float *Dr;    // lb_cap + 4 floats
+	uint8_t *TB;  // (la_cap + 1) x (lb_cap + 1) bytes
+	int la_cap, lb_cap;
+	__host__ __device__ static size_t bytes(int la_cap, int lb_cap) {
+		return (size_t)2 * (lb_cap + 4) * 4 + (size_t)(la_cap + 1) * (lb_cap + 1);
+	}
+	__device__ void carve(uint8_t *base, int la, int lb) {
+		la_cap = la; lb_cap = lb;
+		Mr = reinterpret_cast<float *>(base);
+		Dr = Mr + (lb + 4);
+		TB = reinterpret_cast<uint8_t *>(Dr + (lb + 4));
+	}
+};
+
+struct RevOps {  // run-length path, traceback order (last column first)
+	uint16_t *ops;  // LDS, OPS_CAP entries
+	int n;
+	int cur_op, cur_len;
+	bool overflow;
+	__device__ __forceinline__ void begin() { n = 0; cur_op = -1; cur_len = 0; overflow = false; }
+	__device__ __forceinline__ void push_run(int op, int len, int lane) {
+		if (n < OPS_CAP) {
+			if (lane == 0) ops[n] = (uint16_t)((len << 2) | op);
+			++n;
+		} else
+			overflow = true;
+	}
+	__device__ __forceinline__ void emit(int op, int lane) {
+		if (op == cur_op) ++cur_len;
+		else {
+			if (cur_len) push_run(cur_op, cur_len, lane);
+			cur_op = op; cur_len = 1;
+		}
+	}
+	__device__ __forceinline__ void emit_run(int op, int len, int lane) {
+		if (len <= 0) return;
+		if (op == cur_op) cur_len += len;
+		else {
+			if (cur_len) push_run(cur_op, cur_len, lane);
+			cur_op = op; cur_len = len;
+		}
+	}
+	__device__ __forceinline__ void end(int lane) {
+		if (cur_len) push_run(cur_op, cur_len, lane);
+		cur_len = 0; cur_op = -1;
+	}
+};
+
+// A, B, tb: LDS of this wavefront.  tb holds (tb_rows8*64) dwords: 8 rows of 4-bit trace cells per dword.
+// Returns the score; R receives the path in traceback order.  status gets URMAPX_ST_* bits.
+__device__ float viterbi_wide(const urmapx_params &P, const uint8_t *A, int LA, const uint8_t *B, int LB, bool Left,
+                              bool Right, const WideScratch &ws, RevOps &R, uint32_t &status, int lane);
+
+__device__ float viterbi_wave(const urmapx_params &P, const uint8_t *A, int LA, const uint8_t *B, int LB, bool Left,
+                              bool Right, uint32_t *tb, int tb_rows8, const WideScratch *ws, RevOps &R,
+                              uint32_t &status, int lane) {
+	R.begin();
+	const float GO = (float)P.gap_open_score, GE = (float)P.gap_ext_score;
+	if (LA == 0 || LB == 0) {
+		if (LA == 0 && LB == 0) return 0.0f;
+		if (LA == 0) { R.emit_run(OP_I, LB, lane); R.end(lane); return (float)(P.gap_open_score + (LB - 1) * P.gap_ext_score); }
+		R.emit_run(OP_D, LA, lane); R.end(lane);
+		return (float)(P.gap_open_score + (LA - 1) * P.gap_ext_score);
+	}
+	const int Rad = (int)P.band_radius;
+	int dlo = min(LA, LB), dhi = max(LA, LB);
+	dlo = dlo > Rad ? dlo - Rad : 1;
+	dhi += Rad;
+	if (dhi > LA + LB - 1) dhi = LA + LB - 1;
+	const int ND = dhi - dlo + 1;
+	// lanes: 0 = column Startj-1, 1..ND = band, ND+1 = column LB; final cells sit at lanes LB-dlo .. LB-dlo+2
+	if (ND + 2 > 64 || LB - dlo + 2 > 63 || ((LA + 1 + 7) >> 3) > tb_rows8) {
+		if (ws && LA <= ws->la_cap && LB <= ws->lb_cap) return viterbi_wide(P, A, LA, B, LB, Left, Right, *ws, R, status, lane);
+		status |= URMAPX_ST_BAND_TOO_WIDE;
+		return 0.0f;
+	}
+	const float flane = (float)lane;
+	float M = NEG, Dn = NEG;
+	uint32_t acc = 0;
+	const int jbase = dlo - 1 + lane - LA;  // column of this lane in row i is jbase + i
+	const bool real = lane >= 1 && lane <= ND;
+	for (int i = 0; i < LA; ++i) {
+		const int j = jbase + i;
+		const bool active = real && j >= 0 && j < LB;
+		const bool semi = (j == LB) && lane >= 1 && lane <= ND + 1;
+		const float OpenA = (Left && i == 0) ? 0.0f : GO;
+		const float ExtA = (Left && i == 0) ? 0.0f : GE;
+		float Mcur = M;
+		if (i == 0 && j == 0) Mcur = 0.0f;
+		const float D = wave_shl1(Dn, NEG);
+		const uint32_t a = A[i];
+		const uint32_t b = active ? B[j] : 0u;
+		// DPI[i][j] for every lane: max-plus prefix over the lanes to the left
+		const float v = active ? (Mcur + OpenA) : NEG;
+		const float u = v - ExtA * flane;
+		const float Pm = wave_prefix_max(u);
+		const float I = wave_shr1(Pm, NEG) + ExtA * (flane - 1.0f);
+		uint32_t bits = 0;
+		if (active) {
+			float xM = Mcur;
+			if (D > xM) { xM = D; bits = TB_DM; }
+			if (I > xM) { xM = I; bits = TB_IM; }
+			M = xM + (float)(a == b ? 1 : P.mismatch_score);
+			const bool freeB = (j == 0 && Left);
+			const float md = Mcur + (freeB ? 0.0f : GO);
+			float Dnew = D + (freeB ? 0.0f : GE);
+			if (md >= Dnew) { Dnew = md; bits |= TB_MD; }
+			Dn = Dnew;
+			const float mi = Mcur + OpenA;
+			const float Ie = I + ExtA;
+			if (mi >= Ie) bits |= TB_MI;
+		} else if (semi) {
+			const float md = Mcur + GO;
+			float Dnew = D + GE;
+			if (md >= Dnew) { Dnew = md; bits = TB_MD; }
+			Dn = Dnew;
+			M = NEG;
+		} else if (lane == 0 && j >= 0) {
+			bits = TB_IM;
+		}
+		acc |= bits << (4 * (i & 7));
+		if ((i & 7) == 7) { tb[(i >> 3) * 64 + lane] = acc; acc = 0; }
+	}
+	// last row of the insert matrix (strict '>' there)
+	float FinalI;
+	{
+		const int jf = dlo - 1 + lane;
+		const bool validf = jf < LB;
+		const float GapOp = Right ? 0.0f : GO, GapEx = Right ? 0.0f : GE;
+		const float Mlast = (lane == 0) ? NEG : M;
+		const float v = validf ? (Mlast + GapOp) : NEG;
+		const float u = v - GapEx * flane;
+		const float Pm = wave_prefix_max(u);
+		const float Ibefore = (lane == 0) ? NEG : (wave_shr1(Pm, NEG) + GapEx * (flane - 1.0f));
+		const float Ie = Ibefore + GapEx;
+		uint32_t bits = (validf && v > Ie) ? TB_MI : 0u;
+		const float Iafter = fmaxf(v, Ie);
+		acc |= bits << (4 * (LA & 7));
+		tb[(LA >> 3) * 64 + lane] = acc;
+		FinalI = rdlane(Iafter, LB - dlo);
+	}
+	const float FinalM = rdlane(M, LB - dlo + 1);
+	const float FinalD = rdlane(Dn, LB - dlo + 2);
+	float Score = FinalM;
+	int st = OP_M;
+	if (FinalD > Score) { Score = FinalD; st = OP_D; }
+	if (FinalI > Score) { Score = FinalI; st = OP_I; }
+	__syncthreads();
+
+	// traceback (wave-uniform; LDS reads are broadcasts)
+	int i = LA, j = LB;
+	int guard = LA + LB + 2;
+	while ((i | j) != 0 && guard-- > 0) {
+		R.emit(st, lane);
+		int ri, cj;
+		if (st == OP_M) { ri = i - 1; cj = j - 1; }
+		else if (st == OP_D) { ri = i - 1; cj = j; }
+		else { ri = i; cj = j - 1; }
+		int l = (LA - ri + cj - dlo + 1) & 63;
+		uint32_t t = (tb[(ri >> 3) * 64 + l] >> (4 * (ri & 7))) & 15u;
+		t = uni(t);
+		if (st == OP_M) { st = (t & TB_DM) ? OP_D : (t & TB_IM) ? OP_I : OP_M; --i; --j; }
+		else if (st == OP_D) { st = (t & TB_MD) ? OP_M : OP_D; --i; }
+		else { st = (t & TB_MI) ? OP_M : OP_I; --j; }
+	}
+	R.end(lane);
+	if (R.overflow) status |= URMAPX_ST_PATH_OVERFLOW;
+	__syncthreads();
+	return Score;
+}
+
+// Wide-band fallback (band wider than one wavefront: a flank window clipped at the end of the sequence store,
+// or the paired-end rescue's whole-read DP).  Same recurrences, lanes = 64 consecutive columns of a row, the
+// in-row insert chain carried from chunk to chunk; rows and trace cells live in global scratch.  Rare and slow.
+__device__ float viterbi_wide(const urmapx_params &P, const uint8_t *A, int LA, const uint8_t *B, int LB, bool Left,
+                              bool Right, const WideScratch &ws, RevOps &R, uint32_t &status, int lane) {
+	const float GO = (float)P.gap_open_score, GE = (float)P.gap_ext_score;
+	const int Rad = (int)P.band_radius;
+	int dlo = min(LA, LB), dhi = max(LA, LB);
+	dlo = dlo > Rad ? dlo - Rad : 1;
+	dhi += Rad;
+	if (dhi > LA + LB - 1) dhi = LA + LB - 1;
+	float *Mr = ws.Mr, *Dr = ws.Dr;
+	uint8_t *TB = ws.TB;
+	const size_t stride = (size_t)LB + 1;
+	const float flane = (float)lane;
+	for (int k = lane; k <= LB + 1; k += 64) { Mr[k] = NEG; Dr[k] = NEG; }
+	__syncthreads();
+	auto range_j = [&](int i, int &Startj, int &Endj) {  // diagbox.h:150-170
+		Startj = (dlo + i >= LA) ? dlo + i - LA : 0;
+		if (Startj >= LB) Startj = LB - 1;
+		Endj = (dhi + i + 1 >= LA) ? dhi + i + 1 - LA : 0;
+		if (Endj > LB) Endj = LB;
+	};
+	for (int i = 0; i < LA; ++i) {
+		int Startj, Endj;
+		range_j(i, Startj, Endj);
+		if (Endj == 0) continue;
+		const float OpenA = (Left && i == 0) ? 0.0f : GO, ExtA = (Left && i == 0) ? 0.0f : GE;
+		const uint32_t a = A[i];
+		float carryI = NEG;
+		float M0first = (i == 0) ? 0.0f : (Startj == 0 ? NEG : Mr[Startj - 1 + 1]);
+		M0first = __int_as_float(uni(__float_as_int(M0first)));
+		float M0last = M0first;
+		uint8_t *TBrow = TB + (size_t)i * stride;
+		if (Startj > 0 && lane == 0) TBrow[Startj - 1] = (uint8_t)TB_IM;
+		for (int j0 = Startj; j0 < Endj; j0 += 64) {
+			const int j = j0 + lane;
+			const bool act = j < Endj;
+			const float oldM = act ? Mr[j + 1] : NEG;
+			const float Dcur = act ? Dr[j] : NEG;
+			const uint32_t b = act ? B[j] : 0u;
+			__syncthreads();
+			const float Mcur = wave_shr1(oldM, M0first);
+			const float v = act ? (Mcur + OpenA) : NEG;
+			const float u = v - ExtA * flane;
+			const float Pm = wave_prefix_max(u);
+			const float Ichain = wave_shr1(Pm, NEG) + ExtA * (flane - 1.0f);
+			const float Icarry = carryI + ExtA * flane;
+			const float I = fmaxf(Ichain, Icarry);
+			uint32_t bits = 0;
+			float xM = Mcur;
+			if (Dcur > xM) { xM = Dcur; bits = TB_DM; }
+			if (I > xM) { xM = I; bits = TB_IM; }
+			const float Mnew = xM + (float)(a == b ? 1 : P.mismatch_score);
+			const bool freeB = (j == 0 && Left);
+			const float md = Mcur + (freeB ? 0.0f : GO);
+			float Dnew = Dcur + (freeB ? 0.0f : GE);
+			if (md >= Dnew) { Dnew = md; bits |= TB_MD; }
+			const float mi = Mcur + OpenA;
+			const float Ie = I + ExtA;
+			if (mi >= Ie) bits |= TB_MI;
+			const float Iafter = fmaxf(mi, Ie);
+			carryI = rdlane(Iafter, 63);
+			M0first = rdlane(oldM, 63);
+			const int lastl = Endj - 1 - j0;
+			if (lastl < 64) M0last = rdlane(oldM, lastl);
+			if (act) { Mr[j + 1] = Mnew; Dr[j] = Dnew; TBrow[j] = (uint8_t)bits; }
+			__syncthreads();
+		}
+		if (lane == 0) {
+			float d = Dr[LB] + GE;
+			const float md = M0last + GO;
+			uint8_t t = 0;
+			if (md >= d) { d = md; t = (uint8_t)TB_MD; }
+			Dr[LB] = d;
+			TBrow[LB] = t;
+		}
+		__syncthreads();
+	}
+	int Startj, Endj;
+	range_j(LA - 1, Startj, Endj);
+	if (lane == 0) Mr[Startj - 1 + 1] = NEG;
+	__syncthreads();
+	float FinalI = NEG;
+	{
+		const float GapOp = Right ? 0.0f : GO, GapEx = Right ? 0.0f : GE;
+		uint8_t *TBlast = TB + (size_t)LA * stride;
+		float carry = NEG;
+		for (int j0 = Startj; j0 < Endj; j0 += 64) {
+			const int j = j0 + lane;
+			const bool act = j < Endj;
+			const float mprev = act ? Mr[j - 1 + 1] : NEG;
+			const float v = act ? (mprev + GapOp) : NEG;
+			const float u = v - GapEx * flane;
+			const float Pm = wave_prefix_max(u);
+			const float Ichain = (lane == 0) ? NEG : (wave_shr1(Pm, NEG) + GapEx * (flane - 1.0f));
+			const float Ibefore = fmaxf(Ichain, carry + GapEx * flane);
+			const float Ie = Ibefore + GapEx;
+			const float Iafter = fmaxf(v, Ie);
+			if (act) TBlast[j] = (v > Ie) ? (uint8_t)TB_MI : (uint8_t)0;
+			carry = rdlane(Iafter, 63);
+			const int lastl = Endj - 1 - j0;
+			if (lastl < 64) FinalI = rdlane(Iafter, lastl);
+		}
+	}
+	__syncthreads();
+	float FinalM = Mr[LB - 1 + 1], FinalD = Dr[LB];
+	FinalM = __int_as_float(uni(__float_as_int(FinalM)));
+	FinalD = __int_as_float(uni(__float_as_int(FinalD)));
+	float Score = FinalM;
+	int st = OP_M;
+	if (FinalD > Score) { Score = FinalD; st = OP_D; }
+	if (FinalI > Score) { Score = FinalI; st = OP_I; }
+	int i = LA, j = LB;
+	int guard = LA + LB + 2;
+	while ((i | j) != 0 && guard-- > 0) {
+		R.emit(st, lane);
+		uint32_t t;
+		if (st == OP_M) t = TB[(size_t)(i - 1) * stride + (j - 1)];
+		else if (st == OP_D) t = TB[(size_t)(i - 1) * stride + j];
+		else t = TB[(size_t)i * stride + (j - 1)];
+		t = uni(t);
+		if (st == OP_M) { st = (t & TB_DM) ? OP_D : (t & TB_IM) ? OP_I : OP_M; --i; --j; }
+		else if (st == OP_D) { st = (t & TB_MD) ? OP_M : OP_D; --i; }
+		else { st = (t & TB_MI) ? OP_M : OP_I; --j; }
+	}
+	R.end(lane);
+	if (R.overflow) status |= URMAPX_ST_PATH_OVERFLOW;
+	__syncthreads();
+	return Score;
+}
+
+}  // namespace urx
