@@ -543,6 +543,7 @@ __global__ __launch_bounds__(64) void search_se_kernel(DevIndex X, urmapx_params
 		const int minScore3 = QL + P.xphase3 * P.mismatch_score;
 		const int minScore4 = QL + P.xphase4 * P.mismatch_score;
 		const int termHSP3 = (QL * P.term_hsp_score_pct_phase3) / 100;
+		const int minhsp = (int)((uint32_t)P.min_hsp_score_pct * (uint32_t)QL / 100.0);
 		int phase = 1;
 		bool done = false;
 
@@ -562,18 +563,62 @@ __global__ __launch_bounds__(64) void search_se_kernel(DevIndex X, urmapx_params
 					c_ok = c_db >= c_qpos;
 					if (c_ok) lane_mismatch_mask<NCH>(seq, c_db - c_qpos, sQ2 + (c_plus ? 0 : SW::QMAX), QL, mm);
 				}
-				const int nb = min(64, total - base);
-				for (int t = 0; t < nb; ++t) {
-					const uint32_t qp = rdlane(c_qpos, t), db = rdlane(c_db, t);
-					const bool pl = rdlane((uint32_t)c_plus, t) != 0;
+				// ExtendPen's two x-drop walks (extendpen.cpp:25-78), every lane on its own bit vector, WITHOUT the
+				// running penalty cap: the accumulated penalty only grows along the walk, so the capped walk aborts
+				// iff the uncapped walk's final penalty exceeds the cap -- which is checked in order below.
+				int e_kind = 0, e_bst = 0, e_start = 0, e_end = 0, e_pen = 0;
+				if (c_ok) {
 					BitVec<NCH> bv;
 #pragma unroll
-					for (int c = 0; c < NCH; ++c) {
-						uint32_t lo = rdlane((uint32_t)mm[c], t), hi = rdlane((uint32_t)(mm[c] >> 32), t);
-						bv.w[c] = ((uint64_t)hi << 32) | lo;
+					for (int c = 0; c < NCH; ++c) bv.w[c] = mm[c];
+					const int mis = P.mismatch_score, xdrop = P.xdrop;
+					int score = W, bst = 0, pen = 0;
+					int endpos = (int)c_qpos + W - 1;
+					int cur = endpos + 1;
+					while (cur < QL) {
+						int m = bv.next_set(cur);
+						if (m > QL) m = QL;
+						const int run = m - cur;
+						if (run > 0) { score += run; if (score > bst) { bst = score; endpos = m - 1; } }
+						if (m >= QL) break;
+						pen -= mis;
+						score += mis;
+						if (bst - score > xdrop) break;
+						cur = m + 1;
 					}
-					int sc = S.extend_pen(bv, qp, db, pl);
-					if (exit_on_score && sc >= minScore1) { done = true; break; }
+					int startpos = (int)c_qpos;
+					cur = startpos - 1;
+					while (cur >= 0) {
+						const int m = bv.prev_set(cur);
+						const int run = cur - m;
+						if (run > 0) { score += run; if (score > bst) { bst = score; startpos = m + 1; } }
+						if (m < 0) break;
+						pen -= mis;
+						score += mis;
+						if (bst - score > xdrop) break;
+						cur = m - 1;
+					}
+					if (startpos == 0 && endpos == QL - 1) e_kind = 1;
+					else if (bst >= minhsp) e_kind = 2;
+					e_bst = bst; e_start = startpos; e_end = endpos; e_pen = pen;
+				}
+				// order-dependent part: only candidates that can change the state, in the reference's order
+				uint64_t todo = __ballot(e_kind != 0);
+				while (todo) {
+					const int t = __builtin_ctzll(todo);
+					todo &= todo - 1;
+					const uint32_t dblo = rdlane(c_db, t) - rdlane(c_qpos, t);
+					if (S.overlaps_hit(dblo)) continue;          // extendpen.cpp:15-17
+					if (rdlane(e_pen, t) > S.maxPen) continue;   // extendpen.cpp:43-44,69-70
+					const bool pl = rdlane((uint32_t)c_plus, t) != 0;
+					const int bst = rdlane(e_bst, t);
+					if (rdlane(e_kind, t) == 1) {
+						S.add_hit(dblo, pl, bst, 0);
+						if (exit_on_score && bst >= minScore1) { done = true; break; }
+					} else {
+						const int sp = rdlane(e_start, t), ep = rdlane(e_end, t);
+						S.add_hsp((uint32_t)sp, dblo + (uint32_t)sp, pl, (uint32_t)(ep - sp + 1), bst);
+					}
 				}
 			}
 		};
