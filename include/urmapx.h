@@ -150,6 +150,15 @@ int urmapx_make_ufi(const char *fasta_path, const char *ufi_path, uint32_t word_
 int urmapx_build_slots(const uint8_t *seqdata, uint32_t seqdata_size, uint32_t word_length, uint32_t max_ix,
                        uint64_t slots, uint8_t *blob, uint32_t *truncated_out);
 
+/* ---- host-side text (no device involved) ---- */
+/* One SAM record of a single-end read: State1::SetSAM / SetSAM_Unmapped (setsam.cpp:12-207) with Flags = 0 as
+ * State1::Output1 passes (output1.cpp:13), CIGAR per state1.cpp:707-734 + cigar.cpp.  path_ops = the batch arena.
+ * Writes at most cap bytes (no NUL); returns the record length, or 0 if cap is too small. */
+size_t urmapx_sam_se(const urmapx_index *, const urmapx_result *r, const urmapx_path_op *path_ops, const char *label,
+                     const uint8_t *seq, const uint8_t *qual, uint32_t read_len, char *buf, size_t cap);
+/* @SQ lines of State1::WriteSAMHeader (state1.cpp:736-748); same return convention. */
+size_t urmapx_sam_header_sq(const urmapx_index *, char *buf, size_t cap);
+
 const char *urmapx_strerror(int code);
 /* "gfx950" etc. of the ctx's device; NULL without a device */
 const char *urmapx_device_arch(urmapx_ctx *);

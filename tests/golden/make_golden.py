@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Regenerates the golden fixtures in this directory with the UNMODIFIED reference binary
+(oracle/_ref/urmap, built by oracle/Makefile from /root/reference/src).  Inputs are seeded synthetic data;
+outputs are what the reference itself wrote:
+
+  g.fa            40 kbp, 3 sequences, repeats, N runs, soft-masked stretches
+  g.ufi.gz        reference `urmap -make_ufi g.fa -output g.ufi` (default W=24, MaxIx=32, table prime)
+  se150.fq/.sam   400 reads, 150 bp, 1 % sub, 0.2 % indel, N / lower-case / IUPAC edge cases
+  se250.fq/.sam   200 reads, 250 bp, 4 % sub, 1 % indel
+  se_short.fq/.sam 100 reads of 24..60 bp
+  reference `urmap -map X.fq -ufi g.ufi -samout X.sam -threads 1`; the @PG line is dropped.
+
+Run only where /root/reference exists; the fixtures are data, the reference itself does not travel.
+"""
+import gzip
+import os
+import shutil
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle_lib as ol  # noqa: E402
+from urmap_amd import synth  # noqa: E402
+
+
+def edge(reads, seed):
+    rng = np.random.default_rng(seed)
+    out = list(reads)
+    for k in range(0, len(out), 13):
+        lab, s, q = out[k]
+        s = s.copy(); s[int(rng.integers(0, len(s)))] = ord("N"); out[k] = (lab, s, q)
+    for k in range(4, len(out), 41):
+        lab, s, q = out[k]; out[k] = (lab, s | 0x20, q)
+    for k in range(7, len(out), 53):
+        lab, s, q = out[k]
+        s = s.copy(); s[int(rng.integers(0, len(s)))] = ord("R"); out[k] = (lab + " extra words/1", s, q)
+    return out
+
+
+def main():
+    assert ol.have_ref(), "build oracle/_ref/urmap first (make -C oracle ref)"
+    tmp = os.path.join(HERE, "_tmp")
+    os.makedirs(tmp, exist_ok=True)
+    g = synth.make_genome(424242, [22000, 13000, 5000], repeat_frac=0.35, n_families=6, n_run_frac=0.02)
+    synth.write_fasta(os.path.join(HERE, "g.fa"), g, lowercase_frac=0.05, seed=3)
+    shutil.copy(os.path.join(HERE, "g.fa"), os.path.join(tmp, "g.fa"))
+    ol.run_ref(["-make_ufi", "g.fa", "-output", "g.ufi"], cwd=tmp)
+    with open(os.path.join(tmp, "g.ufi"), "rb") as f, gzip.GzipFile(os.path.join(HERE, "g.ufi.gz"), "wb", mtime=0) as z:
+        z.write(f.read())
+    sets = {
+        "se150": edge(synth.make_reads(11, g, 400, read_len=150, sub=0.01, ins=0.001, dele=0.001, random_frac=0.03), 1),
+        "se250": edge(synth.make_reads(12, g, 200, read_len=250, sub=0.04, ins=0.005, dele=0.005, random_frac=0.03), 2),
+    }
+    short = []
+    for i, L in enumerate(range(24, 61)):
+        short += synth.make_reads(100 + i, g, 3, read_len=L, sub=0.01, ins=0, dele=0, label_prefix=f"s{L}_")
+    sets["se_short"] = short[:100]
+    for name, reads in sets.items():
+        fq = os.path.join(HERE, name + ".fq")
+        synth.write_fastq(fq, reads)
+        shutil.copy(fq, os.path.join(tmp, name + ".fq"))
+        ol.run_ref(["-map", name + ".fq", "-ufi", "g.ufi", "-samout", name + ".sam", "-threads", "1"], cwd=tmp)
+        with open(os.path.join(HERE, name + ".sam"), "wb") as f:
+            f.write(b"\n".join(ol.sam_records(os.path.join(tmp, name + ".sam"))) + b"\n")
+    shutil.rmtree(tmp)
+    print("golden fixtures written to", HERE)
+
+
+if __name__ == "__main__":
+    main()

@@ -173,3 +173,52 @@ def test_bad_lengths_are_flagged(small_case, gpu):
     assert e.value.code == api.E_UNSUPPORTED
     res, _ = gpu["mapper"].map_se(np.concatenate(seqs), offs, allow_unsupported=True)
     assert (res["status"] == 0x10).all()
+
+
+@pytest.mark.parametrize("name", ["se150", "se250", "se_short"])
+def test_cli_map_reproduces_reference_sam(tmp_path, name):
+    """`urmap -map FQ -ufi UFI -samout SAM` (map.cpp:27-67) of this build vs the SAM the reference binary wrote
+    for the same inputs (tests/golden): identical records, @PG excluded."""
+    import gzip
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gold = os.path.join(root, "tests", "golden")
+    exe = os.path.join(root, "urmap_amd", "urmap")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    ufi = os.path.join(tmp_path, "g.ufi")
+    with gzip.open(os.path.join(gold, "g.ufi.gz"), "rb") as z, open(ufi, "wb") as f:
+        f.write(z.read())
+    out = os.path.join(tmp_path, "out.sam")
+    r = subprocess.run([exe, "-map", os.path.join(gold, name + ".fq"), "-ufi", ufi, "-samout", out, "-batch", "128"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    got = [l for l in open(out, "rb").read().split(b"\n") if l and not l.startswith(b"@PG")]
+    want = [l for l in open(os.path.join(gold, name + ".sam"), "rb").read().split(b"\n") if l]
+    assert got == want
+    assert any(l.startswith(b"@PG\tID:urmap") for l in open(out, "rb").read().split(b"\n"))
+
+
+def test_cli_errors_exit_1(tmp_path):
+    """Die(): message on stderr, exit status 1 (myutils.cpp:915)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "urmap_amd", "urmap")
+    r = subprocess.run([exe, "-map", "/nonexistent.fq", "-ufi", "/nonexistent.ufi", "-samout", os.path.join(tmp_path, "x.sam")],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
+    assert r.returncode == 1 and b"Fatal error" in r.stderr
+
+
+def test_mapq_formula_exhaustive(gpu, small_case):
+    """CalcMAPQ6 (search1m6.cpp:9-33) is double arithmetic truncated to unsigned; the device evaluates the same
+    expression.  Perfect, 1-mismatch and 2-hit reads of every length class are covered by the mapping tests; here
+    the mapped MAPQs of a mixed set are compared once more as a histogram against the oracle's."""
+    from urmap_amd import synth
+    from conftest import reads_to_arrays
+    reads = synth.make_reads(77, small_case["genome"], 2000, read_len=120, sub=0.03, ins=0.003, dele=0.003)
+    bases, offs = reads_to_arrays(reads)
+    ores, _, _ = small_case["oracle_index"].map_se(bases, offs, threads=4)
+    gres, _ = gpu["mapper"].map_se(bases, offs)
+    assert (np.bincount(gres["mapq"], minlength=41) == np.bincount(ores["mapq"].astype(np.int64), minlength=41)).all()
+    assert (gres["mapq"] == ores["mapq"]).all()

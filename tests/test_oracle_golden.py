@@ -1,0 +1,82 @@
+"""CPU: the oracle (oracle/liburmap_oracle.so) against the golden fixtures written by the reference binary
+(tests/golden/make_golden.py), and against the reference binary itself when it is present."""
+import filecmp
+import gzip
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def gold_ufi(tmp_path_factory):
+    d = tmp_path_factory.mktemp("gold")
+    p = os.path.join(d, "g.ufi")
+    with gzip.open(os.path.join(GOLD, "g.ufi.gz"), "rb") as z, open(p, "wb") as f:
+        f.write(z.read())
+    return p
+
+
+def read_records(path):
+    with open(path, "rb") as f:
+        return [l for l in f.read().split(b"\n") if l and not l.startswith(b"@PG")]
+
+
+@pytest.mark.parametrize("name", ["se150", "se250", "se_short"])
+def test_oracle_sam_equals_reference_golden(gold_ufi, tmp_path, name):
+    """urmap -map (map.cpp:27-67): every SAM record identical to what the reference wrote."""
+    idx = ol.Index.load(gold_ufi)
+    out = os.path.join(tmp_path, name + ".sam")
+    idx.map_file_se(os.path.join(GOLD, name + ".fq"), out, threads=2)
+    assert read_records(out) == read_records(os.path.join(GOLD, name + ".sam"))
+
+
+def test_oracle_make_ufi_equals_reference_golden(gold_ufi, tmp_path):
+    """urmap -make_ufi (ufindexio.cpp:117-179): byte-identical .ufi for the reference's slot count."""
+    w, maxix, sds, slots = ol.ufi_header(gold_ufi)
+    idx = ol.Index.build(os.path.join(GOLD, "g.fa"), slots, word_length=w, max_ix=maxix)
+    out = os.path.join(tmp_path, "o.ufi")
+    idx.save(out)
+    assert filecmp.cmp(out, gold_ufi, shallow=False)
+
+
+def test_viterbi_known_shapes():
+    """The only worked cases in the reference tree are the three pairs in viterbi.cpp:286-302 (no expected
+    values there); expected strings below were produced by the reference's State1::Viterbi semantics as pinned
+    through the golden SAMs, and guard the Left/Right free-end-gap rules."""
+    s, p = ol.viterbi(b"GGGGATTAC", b"GGGGATTACA", False, True)
+    assert (s, p) == (9.0, "MMMMMMMMMI")
+    s, p = ol.viterbi(b"GGATTACA", b"GGGGATTACA", True, False)
+    assert (s, p) == (8.0, "IIMMMMMMMM")
+    s, p = ol.viterbi(b"ACGT", b"", False, True)
+    assert (s, p) == (-8.0, "DDDD")
+
+
+@pytest.mark.skipif(not ol.have_ref(), reason="reference binary oracle/_ref/urmap not built")
+@pytest.mark.parametrize("seed,glen,n,rl,sub,indel", [(21, 400000, 3000, 150, 0.01, 0.001),
+                                                      (22, 300000, 1500, 250, 0.04, 0.01),
+                                                      (23, 200000, 2000, 75, 0.02, 0.004)])
+def test_oracle_equals_reference_binary(tmp_path, seed, glen, n, rl, sub, indel):
+    """Fresh seeded genome + reads: reference -make_ufi / -map vs the oracle; .ufi bytes and SAM records."""
+    from urmap_amd import synth
+    d = str(tmp_path)
+    g = synth.make_genome(seed, [glen * 6 // 10, glen * 3 // 10, glen // 10], repeat_frac=0.4, n_families=10)
+    synth.write_fasta(os.path.join(d, "g.fa"), g, lowercase_frac=0.05)
+    reads = synth.make_reads(seed + 1, g, n, read_len=rl, sub=sub, ins=indel / 2, dele=indel / 2, random_frac=0.02)
+    rng = np.random.default_rng(seed)
+    for k in range(0, len(reads), 29):
+        lab, s, q = reads[k]
+        s = s.copy(); s[int(rng.integers(0, len(s)))] = ord("N"); reads[k] = (lab, s, q)
+    synth.write_fastq(os.path.join(d, "r.fq"), reads)
+    ol.run_ref(["-make_ufi", "g.fa", "-output", "g.ufi"], cwd=d)
+    w, maxix, sds, slots = ol.ufi_header(os.path.join(d, "g.ufi"))
+    idx = ol.Index.build(os.path.join(d, "g.fa"), slots)
+    idx.save(os.path.join(d, "o.ufi"))
+    assert filecmp.cmp(os.path.join(d, "g.ufi"), os.path.join(d, "o.ufi"), shallow=False)
+    ol.run_ref(["-map", "r.fq", "-ufi", "g.ufi", "-samout", "ref.sam", "-threads", "4"], cwd=d)
+    idx.map_file_se(os.path.join(d, "r.fq"), os.path.join(d, "o.sam"), threads=4)
+    assert sorted(read_records(os.path.join(d, "ref.sam"))) == sorted(read_records(os.path.join(d, "o.sam")))

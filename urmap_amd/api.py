@@ -30,7 +30,7 @@ EXPORTS = (
     "urmapx_index_seq_length", "urmapx_index_seq_offset", "urmapx_ctx_create", "urmapx_ctx_destroy",
     "urmapx_map_se", "urmapx_map_se_device", "urmapx_ctx_sync", "urmapx_ctx_last_kernel_ms",
     "urmapx_seed_probe", "urmapx_viterbi_batch", "urmapx_strerror", "urmapx_device_arch",
-    "urmapx_make_ufi", "urmapx_build_slots",
+    "urmapx_make_ufi", "urmapx_build_slots", "urmapx_sam_se", "urmapx_sam_header_sq",
 )
 
 
@@ -89,6 +89,10 @@ def lib():
     L.urmapx_viterbi_batch.argtypes = [vp, vp, vp, vp, vp, vp, u32, vp, vp, vp, vp]
     L.urmapx_make_ufi.argtypes = [cp, cp, u32, u32, u64]
     L.urmapx_build_slots.argtypes = [vp, u32, u32, u32, u64, vp, C.POINTER(u32)]
+    L.urmapx_sam_se.restype = C.c_size_t
+    L.urmapx_sam_se.argtypes = [vp, vp, vp, cp, vp, vp, u32, vp, C.c_size_t]
+    L.urmapx_sam_header_sq.restype = C.c_size_t
+    L.urmapx_sam_header_sq.argtypes = [vp, vp, C.c_size_t]
     L.urmapx_strerror.restype = cp
     L.urmapx_strerror.argtypes = [i32]
     L.urmapx_device_arch.restype = cp
@@ -184,6 +188,30 @@ class Index:
         n = lib().urmapx_index_seq_count(self.h)
         return [(lib().urmapx_index_label(self.h, i).decode(), lib().urmapx_index_seq_length(self.h, i),
                  lib().urmapx_index_seq_offset(self.h, i)) for i in range(n)]
+
+    def sam_header_sq(self) -> bytes:
+        buf = C.create_string_buffer(1 << 20)
+        n = lib().urmapx_sam_header_sq(self.h, buf, len(buf))
+        return buf.raw[:n]
+
+    def sam_se(self, results: np.ndarray, ops: np.ndarray, labels, bases: np.ndarray, offs: np.ndarray,
+               quals: np.ndarray) -> bytes:
+        """SAM records (State1::Output1 -> SetSAM) of a mapped batch, in input order.  Host-side text only."""
+        results = np.ascontiguousarray(results)
+        ops = np.ascontiguousarray(ops, dtype=np.uint16)
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        quals = np.ascontiguousarray(quals, dtype=np.uint8)
+        out = []
+        buf = C.create_string_buffer(1 << 16)
+        ops_ptr = ops.ctypes.data if len(ops) else None
+        for i in range(len(results)):
+            o, e = int(offs[i]), int(offs[i + 1])
+            n = lib().urmapx_sam_se(self.h, results[i:i + 1].ctypes.data, ops_ptr, labels[i].encode(),
+                                    bases[o:e].ctypes.data, quals[o:e].ctypes.data, e - o, buf, len(buf))
+            if n == 0:
+                raise UrmapxError(-5, "urmapx_sam_se: record does not fit")
+            out.append(buf.raw[:n])
+        return b"".join(out)
 
     def close(self):
         if self.h:

@@ -216,3 +216,28 @@ void append_sam_header(std::string &out, const urmapx_index *I, int argc, char *
 }
 
 }  // namespace urx
+
+extern "C" size_t urmapx_sam_se(const urmapx_index *I, const urmapx_result *r, const urmapx_path_op *path_ops,
+                                const char *label, const uint8_t *seq, const uint8_t *qual, uint32_t read_len,
+                                char *buf, size_t cap) {
+	std::string out;
+	urx::append_sam_record(out, I, *r, path_ops, 0, "*", 0xFFFFFFFFu, 0, label, seq, qual, read_len);
+	if (out.size() > cap) return 0;
+	memcpy(buf, out.data(), out.size());
+	return out.size();
+}
+
+extern "C" size_t urmapx_sam_header_sq(const urmapx_index *I, char *buf, size_t cap) {
+	std::string out;
+	const uint32_t n = urmapx_index_seq_count(I);
+	for (uint32_t i = 0; i < n; ++i) {
+		out += "@SQ\tSN:";
+		out += urmapx_index_label(I, i);
+		out += "\tLN:";
+		out += std::to_string(urmapx_index_seq_length(I, i));
+		out.push_back('\n');
+	}
+	if (out.size() > cap) return 0;
+	memcpy(buf, out.data(), out.size());
+	return out.size();
+}

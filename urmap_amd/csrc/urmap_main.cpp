@@ -1,0 +1,231 @@
+// urmap_main.cpp -- command line of the MI355X build: the reference's `urmap -map` / `-make_ufi` surface
+// (urmap_main.cpp:6-41, map.cpp:27-67, ufindexio.cpp:117-179) as a batch dispatcher over liburmapx.so.
+//
+//   urmap -map reads.fq[.gz] -ufi index.ufi -samout out.sam [-veryfast] [-threads N] [-gpu D] [-batch N]
+//   urmap -make_ufi genome.fa -output index.ufi -slots N [-wordlength W] [-maxix M] [-veryfast]
+//
+// Pipeline of -map: one reader thread parses FASTQ into batches, the main thread maps batch k on the GPU while
+// a writer thread formats and writes the SAM of batch k-1.  Records are written in input order (the reference's
+// order is nondeterministic with more than one thread).  Errors: message on stderr, exit status 1
+// (myutils.cpp:915), as the reference.
+#include <chrono>
+#include <condition_variable>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/urmapx.h"
+#include "sam.h"
+
+using namespace urx;
+
+[[noreturn]] static void die(const char *fmt, ...) {
+	va_list ap;
+	va_start(ap, fmt);
+	fprintf(stderr, "\n---Fatal error---\n");
+	vfprintf(stderr, fmt, ap);
+	fprintf(stderr, "\n");
+	va_end(ap);
+	exit(1);
+}
+
+struct Opts {
+	std::string map, make_ufi, ufi, samout, output;
+	bool veryfast = false, quiet = false;
+	unsigned threads = 0, wordlength = 24, maxix = 0, minq = 10;
+	unsigned long long slots = 0;
+	int gpu = 0;
+	unsigned batch = 1u << 18;
+};
+
+static Opts parse(int argc, char **argv) {
+	Opts o;
+	for (int i = 1; i < argc; ++i) {
+		std::string a = argv[i];
+		while (a.size() > 1 && a[0] == '-' && a[1] == '-') a.erase(0, 1);
+		auto val = [&]() -> const char * {
+			if (i + 1 >= argc) die("Missing value for option %s", a.c_str());
+			return argv[++i];
+		};
+		if (a == "-map") o.map = val();
+		else if (a == "-make_ufi") o.make_ufi = val();
+		else if (a == "-ufi") o.ufi = val();
+		else if (a == "-samout") o.samout = val();
+		else if (a == "-output") o.output = val();
+		else if (a == "-threads") o.threads = (unsigned)atoi(val());
+		else if (a == "-wordlength") o.wordlength = (unsigned)atoi(val());
+		else if (a == "-maxix") o.maxix = (unsigned)atoi(val());
+		else if (a == "-slots") o.slots = strtoull(val(), nullptr, 10);
+		else if (a == "-minq") o.minq = (unsigned)atoi(val());
+		else if (a == "-gpu") o.gpu = atoi(val());
+		else if (a == "-batch") o.batch = (unsigned)atoi(val());
+		else if (a == "-veryfast") o.veryfast = true;
+		else if (a == "-quiet") o.quiet = true;
+		else if (a == "-log") (void)val();
+		else die("Unknown option %s", a.c_str());
+	}
+	return o;
+}
+
+static void check(int rc, const char *what) {
+	if (rc != URMAPX_OK && rc != URMAPX_E_UNSUPPORTED) die("%s: %s", what, urmapx_strerror(rc));
+}
+
+struct Job {
+	FastqBatch reads;
+	std::vector<urmapx_result> results;
+	std::vector<urmapx_path_op> ops;
+};
+
+template <class T>
+class Channel {  // bounded single-producer single-consumer queue
+public:
+	explicit Channel(size_t cap) : cap_(cap) {}
+	void push(T v) {
+		std::unique_lock<std::mutex> l(m_);
+		cv_.wait(l, [&] { return q_.size() < cap_; });
+		q_.push_back(std::move(v));
+		cv_.notify_all();
+	}
+	bool pop(T &v) {
+		std::unique_lock<std::mutex> l(m_);
+		cv_.wait(l, [&] { return !q_.empty() || closed_; });
+		if (q_.empty()) return false;
+		v = std::move(q_.front());
+		q_.pop_front();
+		cv_.notify_all();
+		return true;
+	}
+	void close() {
+		std::lock_guard<std::mutex> l(m_);
+		closed_ = true;
+		cv_.notify_all();
+	}
+
+private:
+	std::mutex m_;
+	std::condition_variable cv_;
+	std::deque<T> q_;
+	size_t cap_;
+	bool closed_ = false;
+};
+
+static int cmd_map(const Opts &o, int argc, char **argv) {
+	if (o.ufi.empty()) die("-ufi option required");
+	const auto t0 = std::chrono::steady_clock::now();
+	urmapx_index *I = nullptr;
+	check(urmapx_index_open(o.ufi.c_str(), &I), ("Reading index " + o.ufi).c_str());
+	check(urmapx_index_upload(I, o.gpu), "Uploading index to the GPU");
+	urmapx_params P;
+	check(urmapx_params_for_method(o.veryfast ? 7 : 6, &P), "SetMethod");
+	urmapx_ctx *C = nullptr;
+	check(urmapx_ctx_create(I, o.gpu, &P, &C), "Creating mapping context");
+	if (o.veryfast && urmapx_index_max_ix(I) > 3) fprintf(stderr, "\nWARNING: index not optimal for -veryfast\n");
+	FILE *fsam = nullptr;
+	if (!o.samout.empty()) {
+		fsam = fopen(o.samout.c_str(), "wb");
+		if (!fsam) die("Cannot create %s", o.samout.c_str());
+		std::string hdr;
+		append_sam_header(hdr, I, argc, argv);
+		fwrite(hdr.data(), 1, hdr.size(), fsam);
+	}
+	FastqReader rd;
+	std::string err;
+	if (!rd.open(o.map, err)) die("%s", err.c_str());
+	const auto t1 = std::chrono::steady_clock::now();
+
+	Channel<std::unique_ptr<Job>> parsed(3), mapped(3);
+	std::string reader_err;
+	std::thread reader([&] {
+		for (;;) {
+			auto j = std::make_unique<Job>();
+			j->reads.clear();
+			std::string e;
+			bool more = rd.next_batch(j->reads, o.batch, e);
+			if (!e.empty()) { reader_err = e; break; }
+			if (!more) break;
+			parsed.push(std::move(j));
+		}
+		parsed.close();
+	});
+	unsigned long long n_reads = 0, n_accept = 0, n_reject = 0, n_nohit = 0, n_unsupported = 0;
+	std::thread writer([&] {
+		std::unique_ptr<Job> j;
+		std::string out;
+		while (mapped.pop(j)) {
+			out.clear();
+			const uint32_t n = j->reads.size();
+			for (uint32_t i = 0; i < n; ++i) {
+				const urmapx_result &r = j->results[i];
+				const uint64_t off = j->reads.offs[i];
+				const unsigned L = (unsigned)(j->reads.offs[i + 1] - off);
+				if (fsam)
+					append_sam_record(out, I, r, j->ops.data(), 0, "*", 0xFFFFFFFFu, 0, j->reads.labels[i].c_str(),
+					                  j->reads.bases.data() + off, j->reads.quals.data() + off, L);
+				// HitStats counters (output1.cpp:20-30)
+				if (r.status) ++n_unsupported;
+				if (r.dbpos == 0xFFFFFFFFu) ++n_nohit;
+				else if (r.mapq >= o.minq) ++n_accept;
+				else ++n_reject;
+			}
+			n_reads += n;
+			if (fsam) fwrite(out.data(), 1, out.size(), fsam);
+		}
+	});
+	std::unique_ptr<Job> j;
+	while (parsed.pop(j)) {
+		const uint32_t n = j->reads.size();
+		j->results.resize(n);
+		j->ops.resize((size_t)n * URMAPX_MAX_PATH_OPS);
+		size_t used = 0;
+		int rc = urmapx_map_se(C, j->reads.bases.data(), j->reads.offs.data(), n, j->results.data(), j->ops.data(),
+		                       j->ops.size(), &used);
+		check(rc, "urmapx_map_se");
+		mapped.push(std::move(j));
+	}
+	mapped.close();
+	reader.join();
+	writer.join();
+	if (!reader_err.empty()) die("%s", reader_err.c_str());
+	if (fsam) fclose(fsam);
+	const auto t2 = std::chrono::steady_clock::now();
+	const double load_s = std::chrono::duration<double>(t1 - t0).count();
+	const double map_s = std::chrono::duration<double>(t2 - t1).count();
+	if (!o.quiet) {
+		auto pct = [&](unsigned long long x) { return n_reads ? 100.0 * (double)x / (double)n_reads : 0.0; };
+		fprintf(stderr, "\n%16.1f  Seconds to load index\n%16.1f  Seconds in mapper\n%16llu  Reads\n", load_s, map_s, n_reads);
+		fprintf(stderr, "%16.0f  Reads/sec. (GPU %d)\n", map_s > 0 ? (double)n_reads / map_s : 0.0, o.gpu);
+		fprintf(stderr, "%16llu  Mapped Q>=%u (%.1f%%)\n%16llu  Mapped Q< %u (%.1f%%)\n%16llu  Unmapped (%.1f%%)\n", n_accept,
+		        o.minq, pct(n_accept), n_reject, o.minq, pct(n_reject), n_nohit, pct(n_nohit));
+	}
+	urmapx_ctx_destroy(C);
+	urmapx_index_close(I);
+	if (n_unsupported) die("%llu reads fell outside the device path's domain (length or list overflow); their records are not valid", n_unsupported);
+	return 0;
+}
+
+static int cmd_make_ufi(const Opts &o) {
+	if (o.output.empty()) die("-output option required");
+	if (o.slots == 0)
+		die("-slots N required: this build does not carry the reference's prime table (primes.h); "
+		    "`urmap -suggest_slots` of the reference, or any prime >= FASTA bytes / 0.6, works");
+	unsigned maxix = o.maxix ? o.maxix : (o.veryfast ? 3u : 32u);
+	check(urmapx_make_ufi(o.make_ufi.c_str(), o.output.c_str(), o.wordlength, maxix, o.slots), "make_ufi");
+	return 0;
+}
+
+int main(int argc, char **argv) {
+	Opts o = parse(argc, argv);
+	if (!o.map.empty()) return cmd_map(o, argc, argv);
+	if (!o.make_ufi.empty()) return cmd_make_ufi(o);
+	fprintf(stderr, "urmap (MI355X build)\n  urmap -map reads.fq -ufi index.ufi -samout out.sam [-veryfast] [-gpu D]\n"
+	                "  urmap -make_ufi genome.fa -output index.ufi -slots N [-wordlength W] [-maxix M]\n");
+	return 0;
+}
