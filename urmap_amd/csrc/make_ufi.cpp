@@ -4,6 +4,7 @@
 // 462-511,945-1000): the insertion pass is order dependent (each overflow position takes the first free
 // borrowable slot after its chain's current end), so it stays sequential on the host; slots are hashed a
 // block ahead and prefetched so the pass runs at memory-level parallelism instead of one miss at a time.
+#include <algorithm>
 #include <cctype>
 #include <cstdio>
 #include <cstdlib>
@@ -147,36 +148,48 @@ extern "C" int urmapx_build_slots(const uint8_t *seqdata, uint32_t size, uint32_
 	if (!seqdata || !blob || slots == 0 || W < 1 || W > 32) return URMAPX_E_ARG;
 	Table T;
 	T.blob = blob; T.N = slots; T.maxIx = max_ix;
-	for (uint64_t s = 0; s < slots; ++s) T.put(s, T_FREE, 0xffffffffu);
+#pragma omp parallel for schedule(static)
+	for (int64_t s = 0; s < (int64_t)slots; ++s) T.put((uint64_t)s, T_FREE, 0xffffffffu);
 	T.nplus.assign(slots, 0);
 	T.nminus.assign(slots, 0);
 	const uint64_t mask = W >= 32 ? ~0ull : ((1ull << (2 * W)) - 1);
 	const int BLK = 4096;
-	std::vector<uint64_t> hs(BLK);
-	std::vector<uint32_t> hp(BLK);
-	// pass 1: plus-strand counts (forward), pass 2: minus-strand counts (backward, complemented letters)
+	// passes 1 and 2: per-slot counts of plus-strand words (forward scan) and minus-strand words (backward scan,
+	// complemented letters), saturating at 255.  Counting commutes, so the sequence is cut into chunks that are
+	// scanned in parallel; each chunk re-reads the W-1 bases before it to rebuild the rolling word.
+	auto bump = [](uint8_t &c) {
+		uint8_t old = __atomic_load_n(&c, __ATOMIC_RELAXED);
+		while (old < 255 && !__atomic_compare_exchange_n(&c, &old, (uint8_t)(old + 1), true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+	};
+	const uint32_t CHUNK = 1u << 22;
+	const int64_t nchunks = ((int64_t)size + CHUNK - 1) / CHUNK;
 	for (int pass = 0; pass < 2; ++pass) {
 		std::vector<uint8_t> &cnt = pass == 0 ? T.nplus : T.nminus;
-		uint64_t word = 0; unsigned k = 0; int nb = 0;
-		auto flush = [&]() {
-			for (int i = 0; i < nb; ++i) { uint8_t &c = cnt[hs[i]]; if (c < 255) ++c; }
-			nb = 0;
-		};
-		for (uint32_t t = 0; t < size; ++t) {
-			uint32_t p = pass == 0 ? t : size - 1 - t;
-			int L = pass == 0 ? code_of(seqdata[p]) : comp_code_of(seqdata[p]);
-			if (L < 0) { k = 0; word = 0; continue; }
-			if (k < W) ++k;
-			word = (word << 2) | (uint64_t)L;
-			if (k == W) {
-				uint64_t s = mix(word & mask) % slots;
-				__builtin_prefetch(&cnt[s], 1);
-				hs[nb++] = s;
-				if (nb == BLK) flush();
+#pragma omp parallel for schedule(dynamic, 1)
+		for (int64_t ch = 0; ch < nchunks; ++ch) {
+			// scan positions t in [lo, hi) of the pass order, counting words that END inside [cs, hi)
+			const uint64_t cs = (uint64_t)ch * CHUNK, hi = std::min<uint64_t>(size, cs + CHUNK);
+			const uint64_t lo = cs >= W - 1 ? cs - (W - 1) : 0;
+			uint64_t word = 0; unsigned k = 0;
+			uint64_t pend[64]; int np = 0;
+			for (uint64_t t = lo; t < hi; ++t) {
+				const uint32_t p = pass == 0 ? (uint32_t)t : (uint32_t)(size - 1 - t);
+				const int L = pass == 0 ? code_of(seqdata[p]) : comp_code_of(seqdata[p]);
+				if (L < 0) { k = 0; word = 0; continue; }
+				if (k < W) ++k;
+				word = (word << 2) | (uint64_t)L;
+				if (k == W && t >= cs) {
+					const uint64_t s = mix(word & mask) % slots;
+					__builtin_prefetch(&cnt[s], 1);
+					pend[np++] = s;
+					if (np == 64) { for (int i = 0; i < 64; ++i) bump(cnt[pend[i]]); np = 0; }
+				}
 			}
+			for (int i = 0; i < np; ++i) bump(cnt[pend[i]]);
 		}
-		flush();
 	}
+	std::vector<uint64_t> hs(BLK);
+	std::vector<uint32_t> hp(BLK);
 	// pass 3: insertion in genome order
 	{
 		uint64_t word = 0; unsigned k = 0; int nb = 0;
