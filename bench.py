@@ -28,7 +28,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--genome-mbp", type=float, default=float(os.environ.get("URMAP_BENCH_GENOME_MBP", 200)))
+    ap.add_argument("--genome-mbp", type=float, default=float(os.environ.get("URMAP_BENCH_GENOME_MBP", 3100)))
     ap.add_argument("--reads-per-step", type=int, default=int(os.environ.get("URMAP_BENCH_READS", 1_000_000)))
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--sub", type=float, default=0.01)
@@ -53,41 +53,74 @@ def next_prime(n):
     return n
 
 
-def make_genome_np(seed, total_bp, n_seqs=8, repeat_frac=0.3, n_frac=0.02):
-    """Concatenated upper-case sequence store as make_ufi lays it out: sequences joined by 32 '-' bytes."""
-    rng = np.random.Generator(np.random.PCG64(seed))
-    acgt = np.frombuffer(b"ACGT", np.uint8)
-    lens = np.full(n_seqs, total_bp // n_seqs, dtype=np.int64)
-    parts, offsets, off = [], [], 0
-    fams = [acgt[rng.integers(0, 4, size=int(rng.integers(300, 6000)), dtype=np.uint8)] for _ in range(200)]
-    for si, L in enumerate(lens):
-        L = int(L)
-        s = acgt[rng.integers(0, 4, size=L, dtype=np.uint8)]
-        # repeat families: copies with 0..15 % divergence
-        covered, target = 0, int(L * repeat_frac)
-        while covered < target:
-            fam = fams[int(rng.integers(0, len(fams)))]
-            fl = len(fam)
-            p = int(rng.integers(0, L - fl))
-            c = fam.copy()
-            nm = int(rng.random() * 0.15 * fl)
-            if nm:
-                c[rng.integers(0, fl, size=nm)] = acgt[rng.integers(0, 4, size=nm, dtype=np.uint8)]
-            s[p:p + fl] = c
-            covered += fl
-        nleft = int(L * n_frac)
-        while nleft > 0:
-            rl = int(min(nleft, rng.integers(100, 50000)))
-            p = int(rng.integers(0, L - rl))
-            s[p:p + rl] = ord("N")
-            nleft -= rl
+HG38_LENGTHS_MBP = [248.96, 242.19, 198.30, 190.21, 181.54, 170.81, 159.35, 145.14, 138.39, 133.80, 135.09, 133.28,
+                    114.36, 107.04, 101.99, 90.34, 83.26, 80.37, 58.62, 64.44, 46.71, 50.82, 156.04, 57.23]
+
+
+def make_genome_torch(torch, seed, total_bp, device, repeat_frac=0.3, n_frac=0.02, n_families=200):
+    """Concatenated upper-case sequence store as -make_ufi lays it out (ufindex.cpp:462-511): 24 sequences with
+    hg38's chromosome length proportions, joined by 32 '-' bytes; `repeat_frac` of the bases overwritten by copies
+    of `n_families` repeat families (0..15 % divergence per copy), `n_frac` in runs of N.  Built on the GPU,
+    returned as a device uint8 tensor plus the directory."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    scale = total_bp / (sum(HG38_LENGTHS_MBP) * 1e6)
+    lens = [max(2000, int(x * 1e6 * scale)) for x in HG38_LENGTHS_MBP]
+    offsets, off = [], 0
+    for i, L in enumerate(lens):
         offsets.append(off)
-        parts.append(s)
-        off += L
-        if si + 1 != n_seqs:
-            parts.append(np.full(32, ord("-"), np.uint8))
-            off += 32
-    return np.concatenate(parts), lens.astype(np.uint32), np.array(offsets, np.uint32), [f"chr{i + 1}" for i in range(n_seqs)]
+        off += L + (32 if i + 1 != len(lens) else 0)
+    size = off
+    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=device)
+    seq = torch.empty(size, dtype=torch.uint8, device=device)
+    step = 1 << 28
+    for lo in range(0, size, step):
+        hi = min(size, lo + step)
+        seq[lo:hi] = lut[torch.randint(0, 4, (hi - lo,), generator=g, device=device)]
+    # repeat families, vectorised per family
+    lens_t = torch.tensor(lens, dtype=torch.int64, device=device)
+    offs_t = torch.tensor(offsets, dtype=torch.int64, device=device)
+    cum = torch.cumsum(lens_t, 0)
+    fam_len = torch.randint(300, 6000, (n_families,), generator=g, device="cpu" if False else device).tolist()
+    copies_total = int(total_bp * repeat_frac / (sum(fam_len) / n_families))
+    per_fam = max(1, copies_total // n_families)
+    for fl in fam_len:
+        fam = lut[torch.randint(0, 4, (fl,), generator=g, device=device)]
+        # uniform start over the concatenated sequences, kept inside one sequence
+        u = (torch.rand(per_fam, generator=g, device=device, dtype=torch.float64) * float(cum[-1])).long()
+        si = torch.searchsorted(cum, u, right=True).clamp(max=len(lens) - 1)
+        p = u - (cum[si] - lens_t[si])
+        p = torch.minimum(p, (lens_t[si] - fl - 1).clamp(min=0))
+        ok = lens_t[si] > fl + 1
+        start = (offs_t[si] + p)[ok]
+        n = int(start.numel())
+        if n == 0:
+            continue
+        copy = fam[None, :].expand(n, fl).clone()
+        div = torch.rand(n, 1, generator=g, device=device) * 0.15
+        mut = torch.rand(n, fl, generator=g, device=device) < div
+        rnd = lut[torch.randint(0, 4, (n, fl), generator=g, device=device)]
+        copy = torch.where(mut, rnd, copy)
+        idx = (start[:, None] + torch.arange(fl, device=device)[None, :]).reshape(-1)
+        seq[idx] = copy.reshape(-1)
+    # N runs
+    n_left = int(total_bp * n_frac)
+    rl_all = torch.randint(100, 50000, (max(1, n_left // 25000 + 8),), generator=g, device=device).tolist()
+    pos_u = torch.rand(len(rl_all), generator=g, device=device, dtype=torch.float64).tolist()
+    for rl, u in zip(rl_all, pos_u):
+        if n_left <= 0:
+            break
+        rl = min(rl, n_left)
+        k = int(u * len(lens)) % len(lens)
+        if lens[k] <= rl + 2:
+            continue
+        p = offsets[k] + int(u * 1e9) % (lens[k] - rl)
+        seq[p:p + rl] = ord("N")
+        n_left -= rl
+    for i in range(len(lens) - 1):
+        seq[offsets[i] + lens[i]: offsets[i] + lens[i] + 32] = ord("-")
+    labels = [f"chr{i + 1}" for i in range(22)] + ["chrX", "chrY"]
+    return seq, np.array(lens, np.uint32), np.array(offsets, np.uint32), labels
 
 
 def make_reads_torch(torch, seed, d_seq, seq_lengths, seq_offsets, n, L, sub, indel, device):
@@ -148,12 +181,40 @@ def main():
     t_setup = time.time()
     L = args.read_len
     total_bp = int(args.genome_mbp * 1e6)
-    seq_np, seq_lengths, seq_offsets, labels = make_genome_np(20260101, total_bp)
-    slots = next_prime(int(len(seq_np) / 0.6))
-    blob_np = api.build_slots(seq_np, slots)  # host-side MakeIndex (order dependent), outside the timed region
+    d_seq, seq_lengths, seq_offsets, labels = make_genome_torch(torch, 20260101, total_bp, device)
+    slots = next_prime(int(d_seq.numel() / 0.6))  # cmd_make_ufi: slots >= bytes / load_factor 0.6 (ufindexio.cpp:138-150)
+    t_gen = time.time() - t_setup
+    # The slot table is built by the product's -make_ufi code on the host (UFIndex::MakeIndex is order dependent),
+    # outside the timed region.  With several ranks, local rank 0 builds once and shares it through /dev/shm.
+    shm = f"/dev/shm/urmap_bench_{os.environ.get('MASTER_PORT', 'solo')}_{total_bp}"
+    t0 = time.time()
+    if world == 1:
+        seq_np = d_seq.cpu().numpy()
+        blob_np = api.build_slots(seq_np, slots)
+    else:
+        if local_rank == 0:
+            seq_np = d_seq.cpu().numpy()
+            blob_np = api.build_slots(seq_np, slots)
+            np.save(shm + "_blob.npy", blob_np)
+            np.save(shm + "_seq.npy", seq_np)
+        dist.barrier()
+        if local_rank != 0:
+            blob_np = np.load(shm + "_blob.npy", mmap_mode="r")
+            seq_np = np.load(shm + "_seq.npy", mmap_mode="r")
+            d_seq = torch.from_numpy(np.ascontiguousarray(seq_np)).to(device)  # the genome the index was built from
+    t_build = time.time() - t0
+    t0 = time.time()
     index = api.Index.wrap_host(24, 32, slots, blob_np, seq_np, seq_lengths, seq_offsets, labels).upload(local_rank)
+    t_upload = time.time() - t0
     mapper = api.Mapper(index, device=local_rank, method=6)
-    d_seq = torch.from_numpy(seq_np).to(device)
+    if world > 1:
+        dist.barrier()
+        if local_rank == 0:
+            for suf in ("_blob.npy", "_seq.npy"):
+                try:
+                    os.remove(shm + suf)
+                except OSError:
+                    pass
 
     nb = args.reads_per_step
     n_batches = min(args.steps + args.warmup, 10)
@@ -269,12 +330,12 @@ def main():
             "vs_baseline": None,
             "dtype": "u8/u64 (fp32 DP cells as the reference)",
             "data": "synthetic",
-            "config": {"workload": f"{L} bp SE reads vs synthetic {args.genome_mbp:g} Mbp genome "
+            "config": {"workload": f"{L} bp SE reads vs synthetic hg38-shaped {args.genome_mbp:g} Mbp genome "
                                    f"({slots} slots, {5 * slots / 1e9:.2f} GB slot table + {len(seq_np) / 1e9:.2f} GB sequence "
                                    f"resident in HBM); {nb} reads/step, {args.sub:g} sub, {args.indel:g} indel",
                        "reads_per_step": nb, "read_len": L, "genome_bp": int(len(seq_np)), "slots": int(slots),
-                       "note": "hg38-scale (3.1 Gbp, 27 GB table) needs the device-side index builder; "
-                               "the host-side MakeIndex is sequential (setup %.0f s here)" % setup_s},
+                       "setup_s": {"genome": round(t_gen, 1), "make_ufi_host": round(t_build, 1),
+                                   "upload": round(t_upload, 1), "total": round(setup_s, 1)}},
             "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": kern[dom]["achieved_GBs"],
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": kern[dom]["frac"], "traffic": None},
             "kernels": kern,

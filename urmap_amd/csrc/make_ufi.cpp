@@ -5,6 +5,8 @@
 // borrowable slot after its chain's current end), so it stays sequential on the host; slots are hashed a
 // block ahead and prefetched so the pass runs at memory-level parallelism instead of one miss at a time.
 #include <algorithm>
+#include <chrono>
+#include <sys/mman.h>
 #include <cctype>
 #include <cstdio>
 #include <cstdlib>
@@ -30,26 +32,33 @@ struct Table {
 	uint8_t *blob;
 	uint64_t N;
 	uint32_t maxIx;
-	std::vector<uint8_t> nplus, nminus;
+	uint8_t *nplus = nullptr, *nminus = nullptr;
 	unsigned truncated = 0;
 
 	uint8_t tally(uint64_t s) const { return blob[5 * s]; }
 	uint32_t pos(uint64_t s) const { uint32_t p; memcpy(&p, blob + 5 * s + 1, 4); return p; }
 	void put(uint64_t s, uint8_t t, uint32_t p) { blob[5 * s] = t; memcpy(blob + 5 * s + 1, &p, 4); }
 
+	// (a + b) mod N for a < N; 64-bit division only when the table is smaller than a link step
+	uint64_t wrap(uint64_t a, uint64_t b) const {
+		uint64_t x = a + b;
+		if (x >= N) { x -= N; if (x >= N) x %= N; }
+		return x;
+	}
 	bool advance(uint64_t &s) const {  // one chain link; false at the end
 		uint8_t t = tally(s);
 		if (t == T_PLUS1 || t == T_BOTH1 || t == T_END) return false;
 		if (t == T_LONG_MINE || t == T_LONG_OTHER) {
 			uint32_t p = pos(s);
-			s = ((s + (p & 0xffff)) % N + (p >> 16)) % N;
+			s = wrap(wrap(s, p & 0xffff), p >> 16);
 		} else
-			s = (s + (t & 127)) % N;
+			s = wrap(s, t & 127);
 		return true;
 	}
 	unsigned free_after(uint64_t s) const {
+		uint64_t c = s;
 		for (unsigned i = 1; i < LINK_LIMIT; ++i) {
-			uint64_t c = (s + i) % N;
+			if (++c >= N) c = (N > 1) ? c % N : 0;
 			uint8_t n = nplus[c];
 			if (n > 0 && n <= maxIx) continue;  // a home slot of some indexed word: never lent out
 			if (tally(c) == T_FREE) return i;
@@ -67,15 +76,15 @@ struct Table {
 			s = nxt;
 		}
 	}
+	// UpdateSlot for a position that is NOT the first indexed occurrence of its slot (so its plus count is >= 2 and
+	// both counts are <= MaxIx): the slot is FREE only after a TruncateSlot, and then it restarts as PLUS1.
 	void insert(uint64_t slot, uint32_t p) {
-		uint8_t n = nplus[slot], nm = nminus[slot];
-		if (n > maxIx || nm > maxIx) return;
-		if (tally(slot) == T_FREE) { put(slot, (n == 1 && nm == 0) ? T_BOTH1 : T_PLUS1, p); return; }
+		if (tally(slot) == T_FREE) { put(slot, T_PLUS1, p); return; }
 		uint64_t eol = slot;
 		while (advance(eol)) {}
 		unsigned s1 = free_after(eol);
 		if (s1 == ~0u) { wipe(slot); return; }
-		uint64_t f1 = (eol + s1) % N;
+		uint64_t f1 = wrap(eol, s1);
 		if (s1 <= T_MAXNEXT) {
 			blob[5 * eol] = (uint8_t)((tally(eol) & T_MINE) | s1);
 			put(f1, T_END, p);
@@ -83,7 +92,7 @@ struct Table {
 		}
 		unsigned s2 = free_after(f1);
 		if (s2 == ~0u) { wipe(slot); return; }
-		uint64_t f2 = (f1 + s2) % N;
+		uint64_t f2 = wrap(f1, s2);
 		uint32_t eolpos = pos(eol);
 		put(eol, eol == slot ? T_LONG_MINE : T_LONG_OTHER, s1 | (s2 << 16));
 		put(f1, T_LONG_OTHER, eolpos);
@@ -148,12 +157,39 @@ extern "C" int urmapx_build_slots(const uint8_t *seqdata, uint32_t size, uint32_
 	if (!seqdata || !blob || slots == 0 || W < 1 || W > 32) return URMAPX_E_ARG;
 	Table T;
 	T.blob = blob; T.N = slots; T.maxIx = max_ix;
+	const bool verbose = getenv("URMAPX_VERBOSE") != nullptr;
+	auto tprev = std::chrono::steady_clock::now();
+	auto lap = [&](const char *what) {
+		auto now = std::chrono::steady_clock::now();
+		if (verbose) fprintf(stderr, "[make_ufi] %-28s %.2f s\n", what, std::chrono::duration<double>(now - tprev).count());
+		tprev = now;
+	};
+	auto huge = [](void *p, size_t bytes) {  // transparent huge pages for the big random-access arrays
+		uintptr_t a = ((uintptr_t)p + 0x1fffff) & ~(uintptr_t)0x1fffff, e = ((uintptr_t)p + bytes) & ~(uintptr_t)0x1fffff;
+		if (e > a) (void)madvise((void *)a, e - a, MADV_HUGEPAGE);
+	};
+	huge(blob, 5 * slots);
 #pragma omp parallel for schedule(static)
 	for (int64_t s = 0; s < (int64_t)slots; ++s) T.put((uint64_t)s, T_FREE, 0xffffffffu);
-	T.nplus.assign(slots, 0);
-	T.nminus.assign(slots, 0);
+	// big scratch arrays: 2 MB aligned, huge pages requested before the first touch, first touch in parallel
+	auto big_alloc = [&](size_t bytes, int fill) -> void * {
+		void *p = aligned_alloc(1u << 21, (bytes + (1u << 21) - 1) & ~(size_t)((1u << 21) - 1));
+		if (!p) return nullptr;
+		huge(p, bytes);
+		const int64_t nblk = (int64_t)((bytes + (1u << 21) - 1) >> 21);
+#pragma omp parallel for schedule(static)
+		for (int64_t b = 0; b < nblk; ++b) {
+			const size_t o = (size_t)b << 21;
+			memset((uint8_t *)p + o, fill, std::min<size_t>(1u << 21, bytes - o));
+		}
+		return p;
+	};
+	T.nplus = (uint8_t *)big_alloc(slots, 0);
+	T.nminus = (uint8_t *)big_alloc(slots, 0);
+	uint32_t *firstpos = (uint32_t *)big_alloc(4 * slots, 0xff);
+	if (!T.nplus || !T.nminus || !firstpos) { free(T.nplus); free(T.nminus); free(firstpos); return URMAPX_E_NOMEM; }
+	lap("init");
 	const uint64_t mask = W >= 32 ? ~0ull : ((1ull << (2 * W)) - 1);
-	const int BLK = 4096;
 	// passes 1 and 2: per-slot counts of plus-strand words (forward scan) and minus-strand words (backward scan,
 	// complemented letters), saturating at 255.  Counting commutes, so the sequence is cut into chunks that are
 	// scanned in parallel; each chunk re-reads the W-1 bases before it to rebuild the rolling word.
@@ -164,7 +200,7 @@ extern "C" int urmapx_build_slots(const uint8_t *seqdata, uint32_t size, uint32_
 	const uint32_t CHUNK = 1u << 22;
 	const int64_t nchunks = ((int64_t)size + CHUNK - 1) / CHUNK;
 	for (int pass = 0; pass < 2; ++pass) {
-		std::vector<uint8_t> &cnt = pass == 0 ? T.nplus : T.nminus;
+		uint8_t *cnt = pass == 0 ? T.nplus : T.nminus;
 #pragma omp parallel for schedule(dynamic, 1)
 		for (int64_t ch = 0; ch < nchunks; ++ch) {
 			// scan positions t in [lo, hi) of the pass order, counting words that END inside [cs, hi)
@@ -188,31 +224,96 @@ extern "C" int urmapx_build_slots(const uint8_t *seqdata, uint32_t size, uint32_
 			for (int i = 0; i < np; ++i) bump(cnt[pend[i]]);
 		}
 	}
-	std::vector<uint64_t> hs(BLK);
-	std::vector<uint32_t> hp(BLK);
-	// pass 3: insertion in genome order
-	{
-		uint64_t word = 0; unsigned k = 0; int nb = 0;
-		auto flush = [&]() {
-			for (int i = 0; i < nb; ++i) T.insert(hs[i], hp[i]);
-			nb = 0;
-		};
-		for (uint32_t p = 0; p < size; ++p) {
-			int L = code_of(seqdata[p]);
+	// Insertion (UFIndex::MakeIndex + UpdateSlot, ufindex.cpp:107-148,194-322) is order dependent only for the
+	// second and later occurrences of a slot: the FIRST indexed occurrence of a slot always lands in the slot
+	// itself (BOTH1/PLUS1), and FindFreeSlot never lends out a slot with 1 <= count <= MaxIx whether or not its
+	// head has been written yet (ufindex.cpp:991-993).  So heads are found with a parallel minimum and written in
+	// parallel, and only the remaining ("overflow") positions run through the sequential UpdateSlot, in genome order.
+	lap("count passes");
+
+	auto scan_chunk = [&](int64_t ch, auto &&fn) {  // fn(slot, startpos) for every indexed-eligible word ending in the chunk
+		const uint64_t cs = (uint64_t)ch * CHUNK, hi = std::min<uint64_t>(size, cs + CHUNK);
+		const uint64_t lo = cs >= W - 1 ? cs - (W - 1) : 0;
+		uint64_t word = 0; unsigned k = 0;
+		for (uint64_t t = lo; t < hi; ++t) {
+			const int L = code_of(seqdata[t]);
 			if (L < 0) { k = 0; word = 0; continue; }
 			if (k < W) ++k;
 			word = (word << 2) | (uint64_t)L;
-			if (k == W) {
-				uint64_t s = mix(word & mask) % slots;
-				__builtin_prefetch(blob + 5 * s, 1);
-				__builtin_prefetch(&T.nplus[s], 0);
-				__builtin_prefetch(&T.nminus[s], 0);
-				hs[nb] = s; hp[nb] = p - (W - 1); ++nb;
-				if (nb == BLK) flush();
+			if (k == W && t >= cs) {
+				const uint64_t sl = mix(word & mask) % slots;
+				fn(sl, (uint32_t)(t - (W - 1)));
 			}
 		}
-		flush();
+	};
+#pragma omp parallel for schedule(dynamic, 1)
+	for (int64_t ch = 0; ch < nchunks; ++ch)
+		scan_chunk(ch, [&](uint64_t sl, uint32_t p) {
+			if (T.nplus[sl] > max_ix || T.nminus[sl] > max_ix) return;
+			uint32_t old = __atomic_load_n(&firstpos[sl], __ATOMIC_RELAXED);
+			while (p < old && !__atomic_compare_exchange_n(&firstpos[sl], &old, p, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+		});
+	lap("first occurrences");
+	struct Ovf { uint64_t slot; uint32_t pos; };
+	std::vector<std::vector<Ovf>> ovf((size_t)nchunks);
+#pragma omp parallel for schedule(dynamic, 1)
+	for (int64_t ch = 0; ch < nchunks; ++ch)
+		scan_chunk(ch, [&](uint64_t sl, uint32_t p) {
+			const uint8_t n = T.nplus[sl], nm = T.nminus[sl];
+			if (n > max_ix || nm > max_ix) return;
+			if (firstpos[sl] == p) T.put(sl, (n == 1 && nm == 0) ? T_BOTH1 : T_PLUS1, p);
+			else ovf[(size_t)ch].push_back(Ovf{sl, p});
+		});
+	free(firstpos);
+	lap("heads + overflow lists");
+	size_t novf = 0;
+	for (auto &v : ovf) novf += v.size();
+	// flatten (parallel) so that the sequential pass can look ahead across chunk borders
+	std::vector<size_t> obase((size_t)nchunks + 1, 0);
+	for (int64_t ch = 0; ch < nchunks; ++ch) obase[(size_t)ch + 1] = obase[(size_t)ch] + ovf[(size_t)ch].size();
+	std::vector<Ovf> items(novf);
+#pragma omp parallel for schedule(dynamic, 1)
+	for (int64_t ch = 0; ch < nchunks; ++ch) {
+		std::copy(ovf[(size_t)ch].begin(), ovf[(size_t)ch].end(), items.begin() + (ptrdiff_t)obase[(size_t)ch]);
+		std::vector<Ovf>().swap(ovf[(size_t)ch]);
 	}
+	lap("flatten overflow list");
+	// The inserts themselves must run one after the other, but what each will touch can be guessed ahead of time:
+	// read-only "walkers" follow the chain of the items 16..64 places ahead, one link per visit, prefetching the next
+	// link and finally the lines FindFreeSlot will scan after the chain's end.  Walkers may see a slightly stale
+	// table; they only warm the cache, so the result is unaffected.
+	struct Walker { uint64_t slot; int phase; };
+	Walker ring[128];
+	for (auto &w : ring) w = Walker{0, 1};
+	auto wstep = [&](size_t j) {
+		Walker &w = ring[j & 127];
+		if (w.phase != 0) return;
+		uint64_t nxt = w.slot;
+		if (T.advance(nxt)) {
+			w.slot = nxt;
+			__builtin_prefetch(blob + 5 * nxt, 0);
+		} else {
+			w.phase = 1;
+			const uint64_t c = T.wrap(w.slot, 1);
+			__builtin_prefetch(&T.nplus[c], 0);
+			__builtin_prefetch(&T.nplus[c] + 64, 0);
+			__builtin_prefetch(blob + 5 * c, 1);
+			__builtin_prefetch(blob + 5 * c + 64, 1);
+			__builtin_prefetch(blob + 5 * c + 128, 1);
+		}
+	};
+	for (size_t i = 0; i < novf; ++i) {
+		if (i + 128 < novf) __builtin_prefetch(blob + 5 * items[i + 128].slot, 0);
+		if (i + 64 < novf) { ring[(i + 64) & 127] = Walker{items[i + 64].slot, 0}; wstep(i + 64); }
+		if (i + 48 < novf) wstep(i + 48);
+		if (i + 32 < novf) wstep(i + 32);
+		if (i + 16 < novf) wstep(i + 16);
+		T.insert(items[i].slot, items[i].pos);
+	}
+	lap("sequential overflow inserts");
+	if (verbose) fprintf(stderr, "[make_ufi] %zu overflow positions, %u truncated\n", novf, T.truncated);
+	free(T.nplus);
+	free(T.nminus);
 	if (truncated_out) *truncated_out = T.truncated;
 	return URMAPX_OK;
 }
