@@ -257,6 +257,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     kms /= max(1, args.steps)
+    if os.environ.get("URMAPX_PHASE_STATS") and rank == 0:
+        pc = mapper.phase_cycles()
+        sub = pc[8:]
+        pc = pc[:8]
+        tot = max(1, sum(pc))
+        names = ("setup", "phase1+2", "phase3", "chain walks", "phase4", "phase5", "phase6", "output")
+        print("phase cycle shares: " + ", ".join(f"{n} {100.0 * c / tot:.1f}%" for n, c in zip(names, pc)) +
+              f"; cycles/read {tot / nb:.0f}; batch parts: " + ", ".join(f"{n} {100.0 * c / tot:.1f}%" for n, c in zip(("locate+fetch", "compare", "xdrop", "ordered"), sub)), file=sys.stderr, flush=True)
     reads_per_s = world * args.steps * nb / dt
 
     # ---- parity + CPU baseline on a bounded sample of the last batch (rank 0, N=1 only for the baseline) ----

@@ -128,6 +128,12 @@ int urmapx_ctx_sync(urmapx_ctx *);
  * completed: [0] seed+probe, [1] search/extend. */
 int urmapx_ctx_last_kernel_ms(urmapx_ctx *, float ms[2]);
 
+/* Diagnostic: shader cycles spent per phase by the last search kernel, summed over wavefronts:
+ * [0] setup, [1] phases 1+2, [2] phase 3, [3] chain walks, [4] phase 4, [5] phase 5, [6] phase 6, [7] output;
+ * inside the candidate batches of phases 1,2,4,5: [8] locate+fetch, [9] window compare, [10] x-drop walks, [11] ordered part.
+ * Only collected when URMAPX_PHASE_STATS is set in the environment (otherwise all zero / E_ARG). */
+int urmapx_ctx_phase_cycles(urmapx_ctx *, uint64_t out[12]);
+
 /* ---- stage-level entry points (same device code the batch call runs; used by parity tests and bench) ---- */
 /* State1::SetSlotsVec (state1.cpp:396-438) + UFIndex::GetBlob (ufindex.h:184-187) for both strands of every read.
  * Host arrays; per read r, entries [2*offs[r], 2*offs[r]+L) are the plus strand by query position and

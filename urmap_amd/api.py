@@ -30,7 +30,7 @@ EXPORTS = (
     "urmapx_index_seq_length", "urmapx_index_seq_offset", "urmapx_ctx_create", "urmapx_ctx_destroy",
     "urmapx_map_se", "urmapx_map_se_device", "urmapx_ctx_sync", "urmapx_ctx_last_kernel_ms",
     "urmapx_seed_probe", "urmapx_viterbi_batch", "urmapx_strerror", "urmapx_device_arch",
-    "urmapx_make_ufi", "urmapx_build_slots", "urmapx_sam_se", "urmapx_sam_header_sq",
+    "urmapx_make_ufi", "urmapx_build_slots", "urmapx_sam_se", "urmapx_sam_header_sq", "urmapx_ctx_phase_cycles",
 )
 
 
@@ -85,6 +85,7 @@ def lib():
     L.urmapx_map_se_device.argtypes = [vp, vp, vp, u32, u64, u32, vp, vp, vp]
     L.urmapx_ctx_sync.argtypes = [vp]
     L.urmapx_ctx_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float * 2)]
+    L.urmapx_ctx_phase_cycles.argtypes = [vp, C.POINTER(C.c_uint64 * 12)]
     L.urmapx_seed_probe.argtypes = [vp, vp, vp, u32, vp, vp, vp]
     L.urmapx_viterbi_batch.argtypes = [vp, vp, vp, vp, vp, vp, u32, vp, vp, vp, vp]
     L.urmapx_make_ufi.argtypes = [cp, cp, u32, u32, u64]
@@ -272,6 +273,11 @@ class Mapper:
         ms = (C.c_float * 2)()
         _check(lib().urmapx_ctx_last_kernel_ms(self.h, C.byref(ms)), "urmapx_ctx_last_kernel_ms")
         return float(ms[0]), float(ms[1])
+
+    def phase_cycles(self):
+        out = (C.c_uint64 * 12)()
+        _check(lib().urmapx_ctx_phase_cycles(self.h, C.byref(out)), "urmapx_ctx_phase_cycles")
+        return [int(x) for x in out]
 
     def seed_probe(self, bases: np.ndarray, offs: np.ndarray):
         bases = np.ascontiguousarray(bases, dtype=np.uint8)

@@ -199,30 +199,33 @@ __device__ __forceinline__ uint32_t nonzero_bytes(uint32_t x) {
 // (extendpen.cpp:29-78 compares the same bytes one at a time): bit p = (query[p] != seq[dblo+p]), p < QL.
 // q16 = the query strand in LDS, 16-byte aligned.  Unaligned windows are re-aligned with v_alignbyte.
 template <int NCH>
-__device__ __forceinline__ void lane_mismatch_mask(const uint8_t *seq, uint32_t dblo, const uint8_t *q16, int QL,
-                                                   uint64_t (&mm)[NCH]) {
+__device__ __forceinline__ void lane_mismatch_mask(const uint8_t *__restrict__ seq, uint32_t dblo, const uint8_t *q16,
+                                                   int QL, uint64_t (&mm)[NCH]) {
 	const uint32_t sh = dblo & 3u;
 	const uint32_t *p = reinterpret_cast<const uint32_t *>(seq + (dblo & ~3u));
 	const uint4 *q4 = reinterpret_cast<const uint4 *>(q16);
-	uint32_t prev = p[0];
+	// all window loads are issued before any is used (the sequence store is padded, so reading the whole
+	// 64*NCH-byte span is safe whatever QL is); bits at or beyond QL are cleared at the end
+	uint32_t first = p[0];
+	u32x4_a4 v[4 * NCH];
+#pragma unroll
+	for (int g = 0; g < 4 * NCH; ++g) v[g] = load4_a4(p + 1 + 4 * g);
+	uint32_t prev = first;
 #pragma unroll
 	for (int c = 0; c < NCH; ++c) {
 		uint64_t w = 0;
 #pragma unroll
 		for (int gg = 0; gg < 4; ++gg) {
 			const int g = 4 * c + gg;
-			if (16 * g < QL) {
-				u32x4_a4 v = load4_a4(p + 1 + 4 * g);
-				uint4 q = q4[g];
-				uint32_t t0 = __builtin_amdgcn_alignbyte(v.x, prev, sh);
-				uint32_t t1 = __builtin_amdgcn_alignbyte(v.y, v.x, sh);
-				uint32_t t2 = __builtin_amdgcn_alignbyte(v.z, v.y, sh);
-				uint32_t t3 = __builtin_amdgcn_alignbyte(v.w, v.z, sh);
-				prev = v.w;
-				uint32_t bits = nonzero_bytes(t0 ^ q.x) | (nonzero_bytes(t1 ^ q.y) << 4) | (nonzero_bytes(t2 ^ q.z) << 8) |
-				                (nonzero_bytes(t3 ^ q.w) << 12);
-				w |= (uint64_t)bits << (16 * gg);
-			}
+			const uint4 q = q4[g];
+			const uint32_t t0 = __builtin_amdgcn_alignbyte(v[g].x, prev, sh);
+			const uint32_t t1 = __builtin_amdgcn_alignbyte(v[g].y, v[g].x, sh);
+			const uint32_t t2 = __builtin_amdgcn_alignbyte(v[g].z, v[g].y, sh);
+			const uint32_t t3 = __builtin_amdgcn_alignbyte(v[g].w, v[g].z, sh);
+			prev = v[g].w;
+			const uint32_t bits = nonzero_bytes(t0 ^ q.x) | (nonzero_bytes(t1 ^ q.y) << 4) | (nonzero_bytes(t2 ^ q.z) << 8) |
+			                      (nonzero_bytes(t3 ^ q.w) << 12);
+			w |= (uint64_t)bits << (16 * gg);
 		}
 		const int rem = QL - 64 * c;
 		if (rem <= 0) w = 0;

@@ -161,6 +161,8 @@ struct SearchWave {
 	const DevIndex &X;
 	const urmapx_params &P;
 	const int lane;
+	const uint8_t *__restrict__ gseq;   // = X.seq / X.blob, passed as plain kernel arguments so that the
+	const uint8_t *__restrict__ gblob;  // compiler emits global_load (not flat) and can keep many loads in flight
 	int QL, W, nwords;
 	// LDS of this wavefront
 	uint8_t *sQ[2];  // [0] = plus (read as given), [1] = minus (reverse complement); 16-byte aligned
@@ -290,7 +292,7 @@ struct SearchWave {
 	__device__ __forceinline__ bool load_window(uint32_t tlo, int tl) {
 		bool gap = false;
 		for (int i = lane; i < tl; i += 64) {
-			uint8_t c = X.seq[tlo + i];
+			uint8_t c = gseq[tlo + i];
 			sT[i] = c;
 			gap |= (c == '-');
 		}
@@ -419,11 +421,11 @@ struct SearchWave {
 					uint64_t slotA = addmod(slot2, pos & 0xFFFFu, N);
 					slot2 = addmod(slotA, pos >> 16, N);
 					uint32_t tA, pA;
-					load_slot(X.blob, slotA, tA, pA);
+					load_slot(gblob, slotA, tA, pA);
 					rs[(K - 1) * 64] = pA;
 				} else
 					slot2 = addmod(slot2, T & TALLY_NEXT_MASK, N);
-				load_slot(X.blob, slot2, T, pos);
+				load_slot(gblob, slot2, T, pos);
 			}
 		}
 		return K;
@@ -457,16 +459,21 @@ struct SearchWave {
 	}
 };
 
+#ifndef SEARCH_WAVES_PER_EU
+#define SEARCH_WAVES_PER_EU 3
+#endif
 template <int NCH>
-__global__ __launch_bounds__(64) void search_se_kernel(DevIndex X, urmapx_params P, const uint8_t *__restrict__ bases,
+__global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU) void search_se_kernel(DevIndex X, urmapx_params P, const uint8_t *__restrict__ bases,
                                                        const uint64_t *__restrict__ offs, uint32_t n, ProbeOut probe,
                                                        urmapx_result *__restrict__ results,
                                                        urmapx_path_op *__restrict__ path_ops, uint32_t *path_used,
-                                                       uint32_t *ticket, uint8_t *scratch, size_t scratch_stride) {
+                                                       uint32_t *ticket, uint8_t *scratch, size_t scratch_stride,
+                                                       const uint8_t *__restrict__ g_seq, const uint8_t *__restrict__ g_blob) {
+	// ticket != nullptr: diagnostic build-in -- per-phase shader cycles are accumulated into ticket[2..] (u64 each)
 	using SW = SearchWave<NCH>;
 	__shared__ __attribute__((aligned(16))) uint8_t sQ2[2 * SW::QMAX];  // plus strand, then reverse complement
 	uint8_t *const sQp = sQ2, *const sQm = sQ2 + SW::QMAX;
-	const uint8_t *__restrict__ const seq = X.seq;
+	const uint8_t *__restrict__ const seq = g_seq;
 	__shared__ uint8_t sT[SW::QMAX + 64];
 	__shared__ uint32_t tb[SW::TB_ROWS8 * 64];
 	__shared__ uint16_t ropsL[OPS_CAP], ropsR[OPS_CAP], cand[URMAPX_MAX_PATH_OPS], top[URMAPX_MAX_PATH_OPS];
@@ -478,6 +485,7 @@ __global__ __launch_bounds__(64) void search_se_kernel(DevIndex X, urmapx_params
 	const int W = (int)X.W;
 	SW S(X, P, lane);
 	S.W = W;
+	S.gseq = g_seq; S.gblob = g_blob;
 	S.sQ[0] = sQp; S.sQ[1] = sQm; S.sT = sT; S.tb = tb;
 	S.ropsL = ropsL; S.ropsR = ropsR; S.cand = cand; S.top = top; S.pre = pre;
 	S.hsp_db = hsp_db; S.hsp_ql = hsp_ql; S.hsp_sf = hsp_sf;
@@ -546,82 +554,14 @@ __global__ __launch_bounds__(64) void search_se_kernel(DevIndex X, urmapx_params
 		const int minhsp = (int)((uint32_t)P.min_hsp_score_pct * (uint32_t)QL / 100.0);
 		int phase = 1;
 		bool done = false;
-
-		// gather + consume one candidate list.  fetch(row, k, qpos&, plus&, dbpos&) is evaluated per lane.
-		auto run_candidates = [&](int total, int nrows, bool exit_on_score, auto fetch) {
-			for (int base = 0; base < total && !done; base += 64) {
-				const int g = base + lane;
-				uint32_t c_qpos = 0, c_db = 0;
-				bool c_plus = true, c_ok = false;
-				uint64_t mm[NCH];
-#pragma unroll
-				for (int c = 0; c < NCH; ++c) mm[c] = 0;
-				if (g < total) {
-					int row, k;
-					S.locate(g, nrows, row, k);
-					fetch(row, k, c_qpos, c_plus, c_db);
-					c_ok = c_db >= c_qpos;
-					if (c_ok) lane_mismatch_mask<NCH>(seq, c_db - c_qpos, sQ2 + (c_plus ? 0 : SW::QMAX), QL, mm);
-				}
-				// ExtendPen's two x-drop walks (extendpen.cpp:25-78), every lane on its own bit vector, WITHOUT the
-				// running penalty cap: the accumulated penalty only grows along the walk, so the capped walk aborts
-				// iff the uncapped walk's final penalty exceeds the cap -- which is checked in order below.
-				int e_kind = 0, e_bst = 0, e_start = 0, e_end = 0, e_pen = 0;
-				if (c_ok) {
-					BitVec<NCH> bv;
-#pragma unroll
-					for (int c = 0; c < NCH; ++c) bv.w[c] = mm[c];
-					const int mis = P.mismatch_score, xdrop = P.xdrop;
-					int score = W, bst = 0, pen = 0;
-					int endpos = (int)c_qpos + W - 1;
-					int cur = endpos + 1;
-					while (cur < QL) {
-						int m = bv.next_set(cur);
-						if (m > QL) m = QL;
-						const int run = m - cur;
-						if (run > 0) { score += run; if (score > bst) { bst = score; endpos = m - 1; } }
-						if (m >= QL) break;
-						pen -= mis;
-						score += mis;
-						if (bst - score > xdrop) break;
-						cur = m + 1;
-					}
-					int startpos = (int)c_qpos;
-					cur = startpos - 1;
-					while (cur >= 0) {
-						const int m = bv.prev_set(cur);
-						const int run = cur - m;
-						if (run > 0) { score += run; if (score > bst) { bst = score; startpos = m + 1; } }
-						if (m < 0) break;
-						pen -= mis;
-						score += mis;
-						if (bst - score > xdrop) break;
-						cur = m - 1;
-					}
-					if (startpos == 0 && endpos == QL - 1) e_kind = 1;
-					else if (bst >= minhsp) e_kind = 2;
-					e_bst = bst; e_start = startpos; e_end = endpos; e_pen = pen;
-				}
-				// order-dependent part: only candidates that can change the state, in the reference's order
-				uint64_t todo = __ballot(e_kind != 0);
-				while (todo) {
-					const int t = __builtin_ctzll(todo);
-					todo &= todo - 1;
-					const uint32_t dblo = rdlane(c_db, t) - rdlane(c_qpos, t);
-					if (S.overlaps_hit(dblo)) continue;          // extendpen.cpp:15-17
-					if (rdlane(e_pen, t) > S.maxPen) continue;   // extendpen.cpp:43-44,69-70
-					const bool pl = rdlane((uint32_t)c_plus, t) != 0;
-					const int bst = rdlane(e_bst, t);
-					if (rdlane(e_kind, t) == 1) {
-						S.add_hit(dblo, pl, bst, 0);
-						if (exit_on_score && bst >= minScore1) { done = true; break; }
-					} else {
-						const int sp = rdlane(e_start, t), ep = rdlane(e_end, t);
-						S.add_hsp((uint32_t)sp, dblo + (uint32_t)sp, pl, (uint32_t)(ep - sp + 1), bst);
-					}
-				}
-			}
+		uint64_t tstamp = ticket ? __builtin_amdgcn_s_memtime() : 0;
+		auto lapc = [&](int slot) {
+			if (!ticket) return;
+			uint64_t now = __builtin_amdgcn_s_memtime();
+			if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long *>(ticket) + 1 + slot, (unsigned long long)(now - tstamp));
+			tstamp = now;
 		};
+		lapc(0);
 
 		// BOTH1 seed positions by query position, for cross-lane fetches (tb is idle outside align_hsp)
 		uint32_t *xp = reinterpret_cast<uint32_t *>(tb);
@@ -630,77 +570,152 @@ __global__ __launch_bounds__(64) void search_se_kernel(DevIndex X, urmapx_params
 			xp[64 * c + lane] = (ptal[0][c] == TALLY_BOTH1) ? ppos[0][c] : 0xFFFFFFFFu;
 			xp[SW::QMAX + 64 * c + lane] = (ptal[1][c] == TALLY_BOTH1) ? ppos[1][c] : 0xFFFFFFFFu;
 		}
-		auto fetch12 = [&](int row, int k, uint32_t &qpos, bool &plus, uint32_t &db) {
-			qpos = (uint32_t)row;
-			const uint32_t pp = xp[row], pm = xp[SW::QMAX + row];
-			if (k == 0 && pp != 0xFFFFFFFFu) { plus = true; db = pp; }  // plus-strand seed first (search1m6.cpp:69-108)
-			else { plus = false; db = pm; }
-		};
-		// ---- phases 1 (query positions on the stride W) and 2 (the rest): BOTH1 seeds ----
-		for (int pass = 0; pass < 2 && !done; ++pass) {
-			phase = pass + 1;
-			int cnt[NCH];
+		// The six phases of Search_Lo as ONE loop, so that the gather/consume code and the DP code exist once
+		// (the kernel has to stay inside the instruction cache):
+		//   1, 2  BOTH1 seeds on / off the stride W      3  AlignHSP if the best HSP is long enough
+		//   4, 5  chain rows of length <= 2 / > 2        6  AlignHSP
+		int rl[SW::NSEG];
 #pragma unroll
-			for (int c = 0; c < NCH; ++c) {
-				const int p = 64 * c + lane;
-				const bool sel = (p < nwords) && (((p % W) == 0) == (pass == 0));
-				cnt[c] = sel ? ((ptal[0][c] == TALLY_BOTH1 ? 1 : 0) + (ptal[1][c] == TALLY_BOTH1 ? 1 : 0)) : 0;
+		for (int g = 0; g < SW::NSEG; ++g) rl[g] = 0;
+		for (int step = 1; step <= 6 && !done; ++step) {
+			phase = step;
+			if (step == 3 || step == 6) {
+				if (step == 6 || S.bestHSP > termHSP3) {
+					for (int k = 0; k < S.hspCount; ++k) S.align_hsp(k);
+					if (step == 3 && S.best >= minScore1) done = true;
+				}
+				lapc(step == 3 ? 2 : 6);
+				continue;
 			}
-			const int total = S.template scan_counts<NCH>(cnt);
-			run_candidates(total, NCH * 64, true, fetch12);
-		}
-		// ---- phase 3: gapped extension of the HSPs found so far (search1m6.cpp:162-171) ----
-		if (!done) {
-			phase = 3;
-			if (S.bestHSP > termHSP3) {
-				for (int k = 0; k < S.hspCount; ++k) S.align_hsp(k);
-				if (S.best >= minScore1) done = true;
-			}
-		}
-		// ---- phases 4 and 5: seeds from collision chains; short rows (<= 2) first, then the rest ----
-		if (!done) {
-			phase = 4;
-			int rl[SW::NSEG];
+			int cnt[SW::NSEG];
 #pragma unroll
-			for (int s = 0; s < 2; ++s) {
+			for (int g = 0; g < SW::NSEG; ++g) cnt[g] = 0;
+			if (step <= 2) {
 #pragma unroll
 				for (int c = 0; c < NCH; ++c) {
 					const int p = 64 * c + lane;
-					const uint32_t T = ptal[s][c];
-					const bool active = (p < nwords) && (T & TALLY_MY_BIT) != 0 && T != TALLY_BOTH1;
-					uint64_t slot = 0;
-					if (active) slot = probe.slots[base2 + (uint64_t)s * QL + p];
-					rl[s * NCH + c] = S.walk_rows(s * NCH + c, active, slot, T, ppos[s][c]);
+					const bool sel = (p < nwords) && (((p % W) == 0) == (step == 1));
+					cnt[c] = sel ? ((ptal[0][c] == TALLY_BOTH1 ? 1 : 0) + (ptal[1][c] == TALLY_BOTH1 ? 1 : 0)) : 0;
 				}
-			}
-			__syncthreads();
-				auto fetch45 = [&](int row, int k, uint32_t &qpos, bool &plus, uint32_t &db) {
-				const int seg = row >> 6, l = row & 63;
-				plus = seg < NCH;
-				qpos = (uint32_t)((seg - (plus ? 0 : NCH)) * 64 + l);
-				db = S.rowstore[((size_t)seg * ROW_CAP + k) * 64 + l];
-			};
-			int cnt[SW::NSEG];
+			} else {
+				if (step == 4) {  // walk every collision chain of the read once, one chain per lane
 #pragma unroll
-			for (int g = 0; g < SW::NSEG; ++g) cnt[g] = rl[g] <= 2 ? rl[g] : 0;
-			int total = S.template scan_counts<SW::NSEG>(cnt);
-			run_candidates(total, SW::NSEG * 64, false, fetch45);
-			if (S.best >= minScore3) done = true;
-			if (!done) {
-				phase = 5;
+					for (int sgm = 0; sgm < SW::NSEG; ++sgm) {
+						const int s2 = sgm / NCH, c = sgm % NCH;
+						const int p = 64 * c + lane;
+						const uint32_t T = ptal[s2][c];
+						const bool active = (p < nwords) && (T & TALLY_MY_BIT) != 0 && T != TALLY_BOTH1;
+						uint64_t slot = 0;
+						if (active) slot = probe.slots[base2 + (uint64_t)s2 * QL + p];
+						rl[sgm] = S.walk_rows(sgm, active, slot, T, ppos[s2][c]);
+					}
+					__syncthreads();
+					lapc(3);
+				}
 #pragma unroll
-				for (int g = 0; g < SW::NSEG; ++g) cnt[g] = rl[g] > 2 ? rl[g] : 0;
-				total = S.template scan_counts<SW::NSEG>(cnt);
-				run_candidates(total, SW::NSEG * 64, false, fetch45);
-				if (S.best >= minScore4) done = true;
+				for (int g = 0; g < SW::NSEG; ++g) cnt[g] = (step == 4) ? (rl[g] <= 2 ? rl[g] : 0) : (rl[g] > 2 ? rl[g] : 0);
 			}
-		}
-		// ---- phase 6 ----
-		if (!done) {
-			phase = 6;
-			for (int k = 0; k < S.hspCount; ++k) S.align_hsp(k);
-		}
+			const int total = S.template scan_counts<SW::NSEG>(cnt);
+				for (int base = 0; base < total && !done; base += 64) {
+					uint64_t tsub = ticket ? __builtin_amdgcn_s_memtime() : 0;
+					auto laps = [&](int slot) {
+						if (!ticket) return;
+						uint64_t now = __builtin_amdgcn_s_memtime();
+						if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long *>(ticket) + 1 + slot, (unsigned long long)(now - tsub));
+						tsub = now;
+					};
+					const int g = base + lane;
+					uint32_t c_qpos = 0, c_db = 0;
+					bool c_plus = true, c_ok = false;
+					uint64_t mm[NCH];
+	#pragma unroll
+					for (int c = 0; c < NCH; ++c) mm[c] = 0;
+					if (g < total) {
+						int row, k;
+						S.locate(g, SW::NSEG * 64, row, k);
+						if (step <= 2) {  // BOTH1 seeds: plus-strand seed first, then minus (search1m6.cpp:69-108)
+							c_qpos = (uint32_t)row;
+							const uint32_t pp = xp[row], pm = xp[SW::QMAX + row];
+							if (k == 0 && pp != 0xFFFFFFFFu) { c_plus = true; c_db = pp; }
+							else { c_plus = false; c_db = pm; }
+						} else {  // chain rows: [strand][chunk][k][lane]
+							const int seg = row >> 6, l = row & 63;
+							c_plus = seg < NCH;
+							c_qpos = (uint32_t)((seg - (c_plus ? 0 : NCH)) * 64 + l);
+							c_db = S.rowstore[((size_t)seg * ROW_CAP + k) * 64 + l];
+						}
+						c_ok = c_db >= c_qpos;
+						laps(8);
+						if (c_ok) lane_mismatch_mask<NCH>(seq, c_db - c_qpos, sQ2 + (c_plus ? 0 : SW::QMAX), QL, mm);
+					}
+					__builtin_amdgcn_s_waitcnt(0);
+					laps(9);
+					// ExtendPen's two x-drop walks (extendpen.cpp:25-78), every lane on its own bit vector, WITHOUT the
+					// running penalty cap: the accumulated penalty only grows along the walk, so the capped walk aborts
+					// iff the uncapped walk's final penalty exceeds the cap -- which is checked in order below.
+					int e_kind = 0, e_bst = 0, e_start = 0, e_end = 0, e_pen = 0;
+					if (c_ok) {
+						BitVec<NCH> bv;
+	#pragma unroll
+						for (int c = 0; c < NCH; ++c) bv.w[c] = mm[c];
+						const int mis = P.mismatch_score, xdrop = P.xdrop;
+						int score = W, bst = 0, pen = 0;
+						int endpos = (int)c_qpos + W - 1;
+						int cur = endpos + 1;
+						while (cur < QL) {
+							int m = bv.next_set(cur);
+							if (m > QL) m = QL;
+							const int run = m - cur;
+							if (run > 0) { score += run; if (score > bst) { bst = score; endpos = m - 1; } }
+							if (m >= QL) break;
+							pen -= mis;
+							score += mis;
+							if (bst - score > xdrop) break;
+							cur = m + 1;
+						}
+						int startpos = (int)c_qpos;
+						cur = startpos - 1;
+						while (cur >= 0) {
+							const int m = bv.prev_set(cur);
+							const int run = cur - m;
+							if (run > 0) { score += run; if (score > bst) { bst = score; startpos = m + 1; } }
+							if (m < 0) break;
+							pen -= mis;
+							score += mis;
+							if (bst - score > xdrop) break;
+							cur = m - 1;
+						}
+						if (startpos == 0 && endpos == QL - 1) e_kind = 1;
+						else if (bst >= minhsp) e_kind = 2;
+						e_bst = bst; e_start = startpos; e_end = endpos; e_pen = pen;
+					}
+					laps(10);
+					// order-dependent part: only candidates that can change the state, in the reference's order
+					uint64_t todo = __ballot(e_kind != 0);
+					while (todo) {
+						const int t = __builtin_ctzll(todo);
+						todo &= todo - 1;
+						const uint32_t dblo = rdlane(c_db, t) - rdlane(c_qpos, t);
+						if (S.overlaps_hit(dblo)) continue;          // extendpen.cpp:15-17
+						if (rdlane(e_pen, t) > S.maxPen) continue;   // extendpen.cpp:43-44,69-70
+						const bool pl = rdlane((uint32_t)c_plus, t) != 0;
+						const int bst = rdlane(e_bst, t);
+						if (rdlane(e_kind, t) == 1) {
+							S.add_hit(dblo, pl, bst, 0);
+							if (step <= 2 && bst >= minScore1) { done = true; break; }
+						} else {
+							const int sp = rdlane(e_start, t), ep = rdlane(e_end, t);
+							S.add_hsp((uint32_t)sp, dblo + (uint32_t)sp, pl, (uint32_t)(ep - sp + 1), bst);
+						}
+					}
+					laps(11);
+				}
 
+			if (step == 2) lapc(1);
+			if (step == 4) { lapc(4); if (S.best >= minScore3) done = true; }
+			if (step == 5) { lapc(5); if (S.best >= minScore4) done = true; }
+		}
+		lapc(6);
 		res.mapq = (uint8_t)S.calc_mapq();
 		res.score = (int16_t)S.best; res.second = (int16_t)S.second;
 		res.hit_count = (uint16_t)S.hitCount; res.exit_phase = (uint8_t)phase; res.status = (uint8_t)S.status;
@@ -727,6 +742,7 @@ __global__ __launch_bounds__(64) void search_se_kernel(DevIndex X, urmapx_params
 			}
 		}
 		if (lane == 0) results[r] = res;
+		lapc(7);
 	}
 }
 
@@ -774,15 +790,17 @@ hipError_t launch_search_se(const DevIndex &X, const urmapx_params &P, const uin
                             urmapx_path_op *d_path_ops, uint32_t *d_path_used, const SearchWork &wk, hipStream_t s) {
 	if (n == 0) return hipSuccess;
 	const int nch = nch_for(max_read_len);
-	hipError_t e = hipMemsetAsync(wk.ticket, 0, 4, s);
-	if (e != hipSuccess) return e;
+	if (wk.ticket) {
+		hipError_t e = hipMemsetAsync(wk.ticket, 0, 192, s);
+		if (e != hipSuccess) return e;
+	}
 	dim3 block(64), grid((unsigned)wk.blocks);
 	if (nch == 3)
 		hipLaunchKernelGGL(search_se_kernel<3>, grid, block, 0, s, X, P, d_bases, d_offs, n, probe, d_results, d_path_ops,
-		                   d_path_used, wk.ticket, wk.scratch, wk.scratch_stride);
+		                   d_path_used, wk.ticket, wk.scratch, wk.scratch_stride, X.seq, X.blob);
 	else
 		hipLaunchKernelGGL(search_se_kernel<5>, grid, block, 0, s, X, P, d_bases, d_offs, n, probe, d_results, d_path_ops,
-		                   d_path_used, wk.ticket, wk.scratch, wk.scratch_stride);
+		                   d_path_used, wk.ticket, wk.scratch, wk.scratch_stride, X.seq, X.blob);
 	return hipGetLastError();
 }
 

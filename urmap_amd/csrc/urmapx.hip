@@ -281,6 +281,16 @@ void urmapx_ctx_destroy(urmapx_ctx *C) {
 
 const char *urmapx_device_arch(urmapx_ctx *C) { return C ? C->arch : nullptr; }
 
+// diagnostic: shader cycles per phase of the last search kernel (needs URMAPX_PHASE_STATS=1 in the environment)
+int urmapx_ctx_phase_cycles(urmapx_ctx *C, uint64_t out[12]) {
+	if (!C || !out || !C->ticket.p) return URMAPX_E_ARG;
+	HIP_TRY(hipStreamSynchronize(C->stream));
+	uint64_t buf[13];
+	HIP_TRY(hipMemcpy(buf, C->ticket.p, sizeof buf, hipMemcpyDeviceToHost));
+	for (int i = 0; i < 12; ++i) out[i] = buf[i + 1];
+	return URMAPX_OK;
+}
+
 int urmapx_ctx_sync(urmapx_ctx *C) {
 	if (!C) return URMAPX_E_ARG;
 	HIP_TRY(hipStreamSynchronize(C->stream));
@@ -318,9 +328,9 @@ int urmapx_map_se_device(urmapx_ctx *C, const void *d_bases, const void *d_offs,
 	wk.blocks = C->blocks[cls];
 	wk.scratch_stride = search_scratch_stride(max_read_len);
 	if ((rc = C->scratch.ensure(wk.scratch_stride * (size_t)wk.blocks))) return rc;
-	if ((rc = C->ticket.ensure(4))) return rc;
+	if ((rc = C->ticket.ensure(64))) return rc;
 	wk.scratch = C->scratch.p;
-	wk.ticket = C->ticket.p;
+	wk.ticket = getenv("URMAPX_PHASE_STATS") ? C->ticket.p : nullptr;
 	HIP_TRY(hipMemsetAsync(d_path_used, 0, 4, C->stream));
 	HIP_TRY(hipEventRecord(C->ev[0], C->stream));
 	HIP_TRY(launch_seed_probe(C->X, (const uint8_t *)d_bases, (const uint64_t *)d_offs, n, max_read_len, po, C->stream));
