@@ -159,6 +159,23 @@ def make_reads_torch(torch, seed, d_seq, seq_lengths, seq_offsets, n, L, sub, in
     return reads.reshape(-1).contiguous()
 
 
+def pmc_traffic(kernel, reads_per_launch, total_bp):
+    """HBM read bytes per launch of `kernel` from the committed rocprofv3 --pmc FETCH_SIZE pass of this same
+    workload (profiles/r1/pmc_fetch_hg38scale_*.json; bench.py cannot collect PMCs itself).  None when no
+    profile of this workload size is committed."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_fetch_hg38scale_*.json"))):
+        try:
+            d = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if abs(total_bp - 3.1e9) > 1e8 or kernel not in d.get("kernels", {}):
+            continue
+        best = d["kernels"][kernel]["hbm_read_bytes_per_launch"] * reads_per_launch / d["reads_per_launch"]
+    return None if best is None else round(best)
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", 0))
@@ -345,7 +362,8 @@ def main():
                        "setup_s": {"genome": round(t_gen, 1), "make_ufi_host": round(t_build, 1),
                                    "upload": round(t_upload, 1), "total": round(setup_s, 1)}},
             "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": kern[dom]["achieved_GBs"],
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": kern[dom]["frac"], "traffic": None},
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": kern[dom]["frac"],
+                         "traffic": pmc_traffic(names[dom], nb, total_bp)},
             "kernels": kern,
             "parity": parity,
             "work_per_read": {k: round(v, 2) for k, v in counters.items()},

@@ -222,3 +222,25 @@ def test_mapq_formula_exhaustive(gpu, small_case):
     gres, _ = gpu["mapper"].map_se(bases, offs)
     assert (np.bincount(gres["mapq"], minlength=41) == np.bincount(ores["mapq"].astype(np.int64), minlength=41)).all()
     assert (gres["mapq"] == ores["mapq"]).all()
+
+
+def test_veryfast_method7_matches_oracle(small_case, tmp_path):
+    """`-veryfast`: State1::SetMethod(7) constants (state1.cpp:166-179: mismatch -4, gaps -6/-2, x-drop 12, band
+    radius 8, three-phase exits) on a MaxIx = 3 index (ufindexio.cpp:133-136)."""
+    import os
+    import oracle_lib as ol
+    from urmap_amd import api, synth
+    from conftest import reads_to_arrays
+    ufi = os.path.join(tmp_path, "vf.ufi")
+    api.make_ufi(small_case["fasta"], ufi, 524309, max_ix=3)
+    oi = ol.Index.build(small_case["fasta"], 524309, max_ix=3)
+    oi.save(os.path.join(tmp_path, "vf_o.ufi"))
+    assert open(ufi, "rb").read() == open(os.path.join(tmp_path, "vf_o.ufi"), "rb").read()
+    reads = synth.make_reads(4242, small_case["genome"], 2500, read_len=150, sub=0.02, ins=0.002, dele=0.002, random_frac=0.03)
+    reads = mutate_edge_reads(reads, 7)
+    bases, offs = reads_to_arrays(reads)
+    ores, opaths, _ = oi.map_se(bases, offs, method=7, threads=4)
+    idx = api.Index.open(ufi).upload(0)
+    m = api.Mapper(idx, device=0, method=7)
+    gres, gops = m.map_se(bases, offs)
+    compare_results(gres, gops, ores, opaths)

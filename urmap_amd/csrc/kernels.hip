@@ -431,6 +431,59 @@ struct SearchWave {
 		return K;
 	}
 
+	// All collision chains of the read at once: lane = query position mod 64, the 2*NCH [strand][chunk] segments
+	// advance in lock step so that up to 2*NCH dependent slot loads per lane are in flight instead of one.
+	__device__ __forceinline__ void walk_all(const ProbeOut &probe, uint64_t base2, int (&rl)[NSEG]) {
+		uint64_t sl[NSEG];
+		uint32_t T[NSEG], ps[NSEG];
+		bool act[NSEG];
+		const uint64_t N = X.slotCount;
+		const int maxIx = (int)X.maxIx;
+#pragma unroll
+		for (int g = 0; g < NSEG; ++g) {
+			const int s2 = g / NCH, c = g % NCH;
+			const int p = 64 * c + lane;
+			T[g] = 0; ps[g] = 0; sl[g] = 0; rl[g] = 0;
+			if (p < nwords) {
+				const uint64_t idx = base2 + (uint64_t)s2 * QL + p;
+				T[g] = probe.tallies[idx];
+				ps[g] = probe.positions[idx];
+			}
+			act[g] = (T[g] & TALLY_MY_BIT) != 0 && T[g] != TALLY_BOTH1;
+			if (act[g]) sl[g] = probe.slots[base2 + (uint64_t)s2 * QL + p];
+		}
+		bool any = false;
+#pragma unroll
+		for (int g = 0; g < NSEG; ++g) any |= act[g];
+		while (any) {
+#pragma unroll
+			for (int g = 0; g < NSEG; ++g) {
+				if (!act[g]) continue;
+				uint32_t *rs = rowstore + (size_t)g * ROW_CAP * 64 + lane;
+				rs[rl[g] * 64] = ps[g];
+				++rl[g];
+				const uint32_t t = T[g];
+				if (rl[g] == maxIx || rl[g] >= ROW_CAP) act[g] = false;
+				else if (t == TALLY_PLUS1 || t == TALLY_BOTH1) { rl[g] = 1; act[g] = false; }
+				else if (t == TALLY_END) act[g] = false;
+				else if (t == TALLY_LONG_MINE || t == TALLY_LONG_OTHER) {
+					const uint64_t slotA = addmod(sl[g], ps[g] & 0xFFFFu, N);
+					sl[g] = addmod(slotA, ps[g] >> 16, N);
+					uint32_t tA, pA;
+					load_slot(gblob, slotA, tA, pA);
+					rs[(rl[g] - 1) * 64] = pA;
+				} else
+					sl[g] = addmod(sl[g], t & TALLY_NEXT_MASK, N);
+			}
+			any = false;
+#pragma unroll
+			for (int g = 0; g < NSEG; ++g) {
+				if (act[g]) load_slot(gblob, sl[g], T[g], ps[g]);
+				any |= act[g];
+			}
+		}
+	}
+
 	// exclusive prefix over NS segments of per-lane counts -> pre[]; returns the total
 	template <int NS>
 	__device__ __forceinline__ int scan_counts(const int (&cnt)[NS]) {
@@ -598,17 +651,8 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU) void search_se_kernel(DevI
 					cnt[c] = sel ? ((ptal[0][c] == TALLY_BOTH1 ? 1 : 0) + (ptal[1][c] == TALLY_BOTH1 ? 1 : 0)) : 0;
 				}
 			} else {
-				if (step == 4) {  // walk every collision chain of the read once, one chain per lane
-#pragma unroll
-					for (int sgm = 0; sgm < SW::NSEG; ++sgm) {
-						const int s2 = sgm / NCH, c = sgm % NCH;
-						const int p = 64 * c + lane;
-						const uint32_t T = ptal[s2][c];
-						const bool active = (p < nwords) && (T & TALLY_MY_BIT) != 0 && T != TALLY_BOTH1;
-						uint64_t slot = 0;
-						if (active) slot = probe.slots[base2 + (uint64_t)s2 * QL + p];
-						rl[sgm] = S.walk_rows(sgm, active, slot, T, ppos[s2][c]);
-					}
+				if (step == 4) {  // walk every collision chain of the read once, one chain per lane and segment
+					S.walk_all(probe, base2, rl);
 					__syncthreads();
 					lapc(3);
 				}
