@@ -160,17 +160,22 @@ __device__ float viterbi_wave(const urmapx_params &P, const uint8_t *A, int LA, 
 	__syncthreads();
 
 	// traceback (wave-uniform; LDS reads are broadcasts)
+	// A run of M steps stays on one diagonal (= one lane) and 8 rows share a dword, so the last dword is kept:
+	// only every 8th step of a match run touches LDS.
 	int i = LA, j = LB;
 	int guard = LA + LB + 2;
+	int ckey = -1;
+	uint32_t cword = 0;
 	while ((i | j) != 0 && guard-- > 0) {
 		R.emit(st, lane);
 		int ri, cj;
 		if (st == OP_M) { ri = i - 1; cj = j - 1; }
 		else if (st == OP_D) { ri = i - 1; cj = j; }
 		else { ri = i; cj = j - 1; }
-		int l = (LA - ri + cj - dlo + 1) & 63;
-		uint32_t t = (tb[(ri >> 3) * 64 + l] >> (4 * (ri & 7))) & 15u;
-		t = uni(t);
+		const int l = (LA - ri + cj - dlo + 1) & 63;
+		const int key = (ri >> 3) * 64 + l;
+		if (key != ckey) { cword = uni(tb[key]); ckey = key; }
+		uint32_t t = (cword >> (4 * (ri & 7))) & 15u;
 		if (st == OP_M) { st = (t & TB_DM) ? OP_D : (t & TB_IM) ? OP_I : OP_M; --i; --j; }
 		else if (st == OP_D) { st = (t & TB_MD) ? OP_M : OP_D; --i; }
 		else { st = (t & TB_MI) ? OP_M : OP_I; --j; }
