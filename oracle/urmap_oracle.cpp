@@ -860,6 +860,238 @@ struct Searcher {
 		HitCount = 0; HSPCount = 0; TopHit = -1; BestScore = 0; SecondBestScore = 0; Mapq = unsigned(-1);
 	}
 
+
+	// =============================== paired-end additions (State1 side) ===============================
+	std::vector<uint8_t> PendPlus, PendMinus;  // m_QPosPendingVec_*: query positions stored in a BYTE (state1.h:86-87)
+	unsigned PendCountPlus = 0, PendCountMinus = 0;
+
+	// state1.cpp:95-127
+	void InitPE(const byte *Seq, unsigned L) {
+		SetQuery(Seq, L);
+		++C.n_reads; C.n_qbases += L;
+		SlotsPlus.assign(L, 0); SlotsMinus.assign(L, 0);
+		BlobPlus.assign(5 * L, 0); BlobMinus.assign(5 * L, 0);
+		PendPlus.assign(L, 0); PendMinus.assign(L, 0);
+		PendCountPlus = PendCountMinus = 0;
+		PosVec.resize(X->MaxIx + 1);
+		if (L >= X->W) {
+			SetSlotsVec(X, Q, L, SlotsPlus.data());
+			SetSlotsVec(X, QRC.data(), L, SlotsMinus.data());
+		}
+		HitCount = 0; HSPCount = 0; TopHit = -1;
+		BestScore = 0; BestHSPScore = 0; SecondBestScore = 0;
+		Mapq = unsigned(-1);
+		MaxPenalty = P.max_penalty;
+		ExitPhase = 0;
+	}
+
+	// getseed.cpp:9-54
+	unsigned GetFirstBoth1Seed(uint32_t &QPos, bool &Plus, uint32_t &DBPos) {
+		const unsigned QWC = QL - (X->W - 1);
+		for (unsigned k = 0; k < QWC; ++k) {
+			QPos = (k * PRIME_STRIDE) % QWC;
+			for (int s = 0; s < 2; ++s) {
+				const bool plus = (s == 0);
+				uint64_t Slot = (plus ? SlotsPlus : SlotsMinus)[QPos];
+				if (Slot == UINT64_MAX) continue;
+				byte *B = &(plus ? BlobPlus : BlobMinus)[5 * QPos];
+				GetBlob(Slot, B);
+				byte T = B[0];
+				if (TallyOther(T)) continue;
+				if (T != TALLY_BOTH1) {
+					if (plus) PendPlus[PendCountPlus++] = (uint8_t)QPos;
+					else PendMinus[PendCountMinus++] = (uint8_t)QPos;
+					continue;
+				}
+				memcpy(&DBPos, B + 1, 4);
+				Plus = plus;
+				return k;
+			}
+		}
+		return UINT_MAX;
+	}
+
+	// getseed.cpp:56-138
+	unsigned GetNextBoth1Seed(unsigned ak, uint32_t &aQPos, bool &Plus, uint32_t &DBPos) {
+		const unsigned QWC = QL - (X->W - 1);
+		if (Plus) {  // the minus strand of the same k has not been looked at yet
+			unsigned QPos = (ak * PRIME_STRIDE) % QWC;
+			uint64_t Slot = SlotsMinus[QPos];
+			if (Slot != UINT64_MAX) {
+				byte *B = &BlobMinus[5 * QPos];
+				GetBlob(Slot, B);
+				byte T = B[0];
+				if (!TallyOther(T) && T == TALLY_BOTH1) {  // a "mine" slot that is not BOTH1 is NOT queued here (quirk)
+					uint32_t NewDBPos;
+					memcpy(&NewDBPos, B + 1, 4);
+					if (uint32_t(NewDBPos - QPos) != uint32_t(DBPos - aQPos)) {
+						DBPos = NewDBPos; aQPos = QPos; Plus = false;
+						return ak;
+					}
+					PendMinus[PendCountMinus++] = (uint8_t)QPos;
+				}
+			}
+		}
+		for (unsigned k = ak + 1; k < QWC; ++k) {
+			unsigned QPos = (k * PRIME_STRIDE) % QWC;
+			for (int s = 0; s < 2; ++s) {
+				const bool plus = (s == 0);
+				uint64_t Slot = (plus ? SlotsPlus : SlotsMinus)[QPos];
+				if (Slot == UINT64_MAX) continue;
+				byte *B = &(plus ? BlobPlus : BlobMinus)[5 * QPos];
+				GetBlob(Slot, B);
+				byte T = B[0];
+				if (TallyOther(T)) continue;
+				if (T != TALLY_BOTH1) {
+					if (plus) PendPlus[PendCountPlus++] = (uint8_t)QPos;
+					else PendMinus[PendCountMinus++] = (uint8_t)QPos;
+					continue;
+				}
+				uint32_t NewDBPos;
+				memcpy(&NewDBPos, B + 1, 4);
+				if (uint32_t(NewDBPos - QPos) == uint32_t(DBPos - aQPos)) continue;  // same diagonal as the last seed
+				DBPos = NewDBPos; aQPos = QPos; Plus = plus;
+				return k;
+			}
+		}
+		return UINT_MAX;
+	}
+
+	// search1pepend.cpp:9-130 (the GetNextBoth1SeedEx loop never runs: k is UINT_MAX after Search4's seed loop)
+	void SearchPE_Pending() {
+		MaxPenalty = P.max_penalty;
+		const int MinScorePhase1 = int(QL) + P.xphase1 * P.mismatch_score;
+		const int TermHSPScorePhase3 = (int(QL) * P.term_hsp_score_pct_phase3) / 100;
+		if (BestScore >= MinScorePhase1) { Mapq = CalcMAPQ6(); return; }
+		if (BestHSPScore >= TermHSPScorePhase3) {
+			for (unsigned i = 0; i < HSPCount; ++i) AlignHSP(i);
+			if (BestScore >= MinScorePhase1) { Mapq = CalcMAPQ6(); return; }
+		}
+		unsigned Count2[2] = {0, 0};
+		for (int s = 0; s < 2; ++s) {  // round 1: rows of length <= 2; longer rows are compacted to the front
+			const bool plus = (s == 0);
+			std::vector<uint8_t> &Pend = plus ? PendPlus : PendMinus;
+			const unsigned n = plus ? PendCountPlus : PendCountMinus;
+			for (unsigned i = 0; i < n; ++i) {
+				unsigned QPos = Pend[i];
+				uint64_t Slot = (plus ? SlotsPlus : SlotsMinus)[QPos];
+				unsigned RowLength = GetRow_Blob(Slot, &(plus ? BlobPlus : BlobMinus)[5 * QPos], PosVec.data());
+				if (RowLength > 2) { Pend[Count2[s]++] = (uint8_t)QPos; continue; }
+				for (unsigned r = 0; r < RowLength; ++r) ExtendPen(QPos, PosVec[r], plus);
+			}
+		}
+		for (int s = 0; s < 2; ++s) {  // round 2
+			const bool plus = (s == 0);
+			std::vector<uint8_t> &Pend = plus ? PendPlus : PendMinus;
+			for (unsigned i = 0; i < Count2[s]; ++i) {
+				unsigned QPos = Pend[i];
+				uint64_t Slot = (plus ? SlotsPlus : SlotsMinus)[QPos];
+				unsigned RowLength = GetRow_Blob(Slot, &(plus ? BlobPlus : BlobMinus)[5 * QPos], PosVec.data());
+				for (unsigned r = 0; r < RowLength; ++r) ExtendPen(QPos, PosVec[r], plus);
+			}
+		}
+		const int Bmin = std::max(BestScore, BestHSPScore) - 8;
+		for (unsigned i = 0; i < HSPCount; ++i) {
+			if (HSPs[i].Score < Bmin) continue;
+			AlignHSP(i);
+		}
+		Mapq = CalcMAPQ6();
+	}
+
+	// extendscan.cpp:8-49
+	unsigned AddHSPScan(unsigned StartPosQ, uint32_t StartPosDB, bool Plus, unsigned Length, int Score) {
+		unsigned k = OverlapsHSP(StartPosQ, StartPosDB);
+		if (k != UINT_MAX) {
+			if (Score > HSPs[k].Score) HSPs[k] = HSP{StartPosQ, StartPosDB, Length, Score, Plus, false};
+			return k;
+		}
+		if (HSPs.size() <= HSPCount) HSPs.resize(HSPCount + 1);
+		k = HSPCount++;
+		HSPs[k] = HSP{StartPosQ, StartPosDB, Length, Score, Plus, false};
+		if (Score > BestHSPScore) BestHSPScore = Score;
+		return k;
+	}
+
+	// extendscan.cpp:51-187: no overlap test, and the leftward loop never adds to Pen (quirk)
+	unsigned ExtendScan(uint32_t SeedPosQ, uint32_t SeedPosDB, bool Plus) {
+		if (SeedPosDB < SeedPosQ) return UINT_MAX;
+		uint32_t DBLo = SeedPosDB - SeedPosQ;
+		const byte *QSeq = Plus ? Q : QRC.data();
+		const byte *DBSeq = X->SeqData + DBLo;
+		const int W = int(X->W);
+		const int MinHSPScore = W * 2;
+		int Pen = 0, Score = W, Best = 0;
+		int EndPos = int(SeedPosQ) + W - 1;
+		for (int p = EndPos + 1; p < int(QL); ++p) {
+			if (QSeq[p] == DBSeq[p]) { if (++Score > Best) { Best = Score; EndPos = p; } }
+			else {
+				Pen -= P.mismatch_score;
+				if (Pen > MaxPenalty) return UINT_MAX;
+				Score += P.mismatch_score;
+				if (Best - Score > P.xdrop) break;
+			}
+		}
+		int StartPos = int(SeedPosQ);
+		for (int p = StartPos - 1; p >= 0; --p) {
+			if (QSeq[p] == DBSeq[p]) { if (++Score > Best) { Best = Score; StartPos = p; } }
+			else {
+				if (Pen > MaxPenalty) return UINT_MAX;
+				Score += P.mismatch_score;
+				if (Best - Score > P.xdrop) break;
+			}
+		}
+		if (StartPos == 0 && EndPos == int(QL) - 1) return AddHitX(DBLo, Plus, Best, std::string());
+		if (Best < MinHSPScore) return UINT_MAX;
+		unsigned k = AddHSPScan(unsigned(StartPos), DBLo + unsigned(StartPos), Plus, unsigned(EndPos - StartPos + 1), Best);
+		return AlignHSP(k);
+	}
+
+	// scanslots.cpp:7-62
+	void ScanSlots(uint32_t DBLo, unsigned DBSegLength, bool Plus) {
+		const unsigned W = X->W;
+		const unsigned QWC = QL - (W - 1);
+		const std::vector<uint64_t> &Slots = Plus ? SlotsPlus : SlotsMinus;
+		if (QL <= W * 4) return;
+		const byte *Seg = X->SeqData + DBLo;
+		uint64_t Word = 0;
+		byte K = 0;
+		for (uint32_t p = 0; p < DBSegLength; ++p) {
+			byte L = g_Letter[Seg[p]];
+			if (L == 0xff) { K = 0; Word = 0; continue; }
+			if (K < W) ++K;
+			Word = (Word << 2) | L;
+			if (p >= W - 1 && K == W) {
+				uint64_t Slot = X->WordToSlot(Word & X->ShiftMask);
+				for (unsigned k = 0; k < SCANK; ++k) {
+					unsigned QPos = (k * PRIME_STRIDE) % QWC;
+					if (Slot == Slots[QPos]) ExtendScan(QPos, DBLo + p - W + 1, Plus);
+				}
+			}
+		}
+	}
+
+	// scan.cpp:14-39
+	void Scan(uint32_t DBPos, unsigned DBSegLength, bool Plus, bool DoVit) {
+		int SavedMaxPenalty = MaxPenalty;
+		unsigned SavedHitCount = HitCount;
+		MaxPenalty = 130;
+		ScanSlots(DBPos, DBSegLength, Plus);
+		MaxPenalty = SavedMaxPenalty;
+		if (HitCount > SavedHitCount) return;
+		if (!DoVit) return;
+		const byte *Qs = Plus ? Q : QRC.data();
+		std::string Path;
+		++C.n_viterbi; C.n_dptarget += DBSegLength;
+		float Score = dp.Viterbi(P, Qs, QL, X->SeqData + DBPos, DBSegLength, true, true, Path);
+		if (Score >= QL / 3.0) {
+			unsigned nI = 0;
+			while (nI < Path.size() && Path[nI] == 'I') ++nI;
+			Path.erase(0, nI);
+			while (Path.size() > 1 && Path.back() == 'I') Path.pop_back();
+			AddHitX(DBPos + nI, Plus, int(Score), Path);
+		}
+	}
+
 	// phases 1+2 body for one (QPos, strand); returns true if Search_Lo must return
 	bool SeedBoth1(uint32_t QPos, bool Plus, int MinScorePhase1) {
 		std::vector<uint64_t> &Slots = Plus ? SlotsPlus : SlotsMinus;
@@ -1208,7 +1440,233 @@ extern "C" int uo_map_file_se(const uo_index *X, const uo_params *P, const char 
 	return 0;
 }
 
-extern "C" int uo_map_file_pe(const uo_index *, const uo_params *, const char *, const char *, const char *, int, int,
-                              uo_counters *) {
-	return -100;  // paired-end restatement: not yet written
+// ---------------------------------------------------------------------------------------
+// paired-end: State2 (state2.h/.cpp), Search4 (search2m4.cpp), AdjustTopHitsAndMapqs (search2.cpp:8-57),
+// SetSAM2 / GetPairedFlags (output2.cpp:18-128)
+// ---------------------------------------------------------------------------------------
+namespace {
+struct PairSearcher {
+	Searcher F, R;
+	std::vector<unsigned> PairF, PairR;
+	std::vector<int> PairScore;
+	int BestPairScore = 0, SecondBestPairScore = 0;
+	unsigned BestPairIndex = 0, SecondPairIndex = UINT_MAX;
+	int TermPairScorePhase1 = 0;
+
+	PairSearcher(const uo_index *X, const uo_params &P) : F(X, P), R(X, P) {}
+
+	// search2m4.cpp:189-208
+	bool ExtendBoth1Pair4(uint32_t QPosf, uint32_t DBPosf, bool Plusf, uint32_t QPosr, uint32_t DBPosr) {
+		int FwdScore = F.ExtendPen(QPosf, DBPosf, Plusf);
+		if (FwdScore <= 0) return false;
+		int RevScore = R.ExtendPen(QPosr, DBPosr, !Plusf);
+		if (RevScore <= 0) return false;
+		if (FwdScore + RevScore < TermPairScorePhase1) return false;
+		F.Mapq = 40; R.Mapq = 40;
+		return true;
+	}
+
+	// state2.cpp:20-85
+	void FindPairs() {
+		PairF.clear(); PairR.clear(); PairScore.clear();
+		const unsigned QL2 = (F.QL + R.QL) / 2;
+		BestPairIndex = UINT_MAX; SecondPairIndex = UINT_MAX;
+		BestPairScore = -1; SecondBestPairScore = -1;
+		for (unsigned i = 0; i < F.HitCount; ++i) {
+			const Hit &Hf = F.Hits[i];
+			if (Hf.Score < F.SecondBestScore - 12) continue;
+			for (unsigned j = 0; j < R.HitCount; ++j) {
+				const Hit &Hr = R.Hits[j];
+				if (Hr.Score < R.SecondBestScore - 12) continue;
+				int64_t TL = std::llabs(int64_t(Hf.DBStartPos) - int64_t(Hr.DBStartPos)) + int64_t(QL2);
+				if (TL > 1000) continue;
+				if (Hr.Plus == Hf.Plus) continue;
+				int Total = Hf.Score + Hr.Score;
+				const unsigned idx = (unsigned)PairScore.size();
+				if (Total > BestPairScore) {
+					SecondPairIndex = BestPairIndex; SecondBestPairScore = BestPairScore;
+					BestPairScore = Total; BestPairIndex = idx;
+				} else if (Total == BestPairScore) {
+					SecondPairIndex = idx; SecondBestPairScore = BestPairScore;
+				} else if (Total > SecondBestPairScore) {
+					SecondPairIndex = BestPairIndex;  // sic (state2.cpp:74): the index of the BEST pair
+					SecondBestPairScore = Total;
+				}
+				PairScore.push_back(Total); PairF.push_back(i); PairR.push_back(j);
+			}
+		}
+	}
+
+	// state2.cpp:87-137
+	void ScanPair() {
+		const unsigned SEG = 1024;
+		const bool DoVitF = int(F.Mapq) >= 10, DoVitR = int(R.Mapq) >= 10;
+		const unsigned HCf = F.HitCount, HCr = R.HitCount;
+		for (unsigned i = 0; i < HCf; ++i) {
+			const unsigned QLx = F.QL;  // sic: the forward read's length is used for the reverse read's window
+			const Hit H = F.Hits[i];
+			if (H.Score < F.SecondBestScore) continue;
+			if (H.Plus) R.Scan(H.DBStartPos, SEG, false, DoVitF);
+			else if (H.DBStartPos >= SEG) R.Scan(H.DBStartPos - SEG, SEG + 2 * QLx, true, DoVitF);
+		}
+		for (unsigned j = 0; j < HCr; ++j) {
+			const unsigned QLx = F.QL;
+			const Hit H = R.Hits[j];
+			if (H.Score < R.SecondBestScore) continue;
+			if (H.Plus) F.Scan(H.DBStartPos, SEG, false, DoVitR);
+			else if (H.DBStartPos >= SEG) F.Scan(H.DBStartPos - SEG, SEG + 2 * QLx, true, DoVitR);
+		}
+	}
+
+	// search2.cpp:8-57
+	void AdjustTopHitsAndMapqs() {
+		if (PairScore.empty()) { F.Mapq /= 2; R.Mapq /= 2; return; }
+		double Fract = double(BestPairScore) / double(F.QL + R.QL);
+		double Drop = BestPairScore - SecondBestPairScore;
+		if (Drop > 30) Drop = 30;
+		unsigned mapq = (unsigned)(Drop * Fract * Fract);
+		if (mapq > 40) mapq = 40;
+		if (mapq > F.Mapq) F.Mapq = mapq;
+		if (mapq > R.Mapq) R.Mapq = mapq;
+		if (BestPairIndex != UINT_MAX) { F.TopHit = int(PairF[BestPairIndex]); R.TopHit = int(PairR[BestPairIndex]); }
+	}
+
+	// search2m4.cpp:15-187
+	void Search4(const byte *Seqf, unsigned Lf, const byte *Seqr, unsigned Lr) {
+		F.InitPE(Seqf, Lf);
+		R.InitPE(Seqr, Lr);
+		BestPairScore = 0; SecondBestPairScore = 0; BestPairIndex = 0; SecondPairIndex = UINT_MAX;
+		PairF.clear(); PairR.clear(); PairScore.clear();
+		if (Lf < F.X->W || Lr < F.X->W) { F.Mapq = 0; R.Mapq = 0; return; }  // outside the reference's domain
+		const unsigned QL2 = (Lf + Lr) / 2;
+		TermPairScorePhase1 = int(Lf) + int(Lr) + 5 * F.P.mismatch_score;
+		std::vector<uint32_t> Qf, Qr, Df, Dr;
+		std::vector<char> Pf, Pr;
+		uint32_t QPosf = 0, QPosr = 0, DBPosf = 0, DBPosr = 0;
+		bool Plusf = false, Plusr = false;
+		unsigned kf = F.GetFirstBoth1Seed(QPosf, Plusf, DBPosf);
+		unsigned kr = R.GetFirstBoth1Seed(QPosr, Plusr, DBPosr);
+		do {
+			if (kf != UINT_MAX) {
+				Qf.push_back(QPosf); Pf.push_back(Plusf); Df.push_back(DBPosf);
+				for (size_t i = 0; i < Qr.size(); ++i) {
+					int64_t TL = std::llabs(int64_t(DBPosf) - int64_t(Dr[i])) + int64_t(QL2);
+					if (TL <= MAX_TL && ExtendBoth1Pair4(QPosf, DBPosf, Plusf, Qr[i], Dr[i])) return;
+				}
+			}
+			if (kr != UINT_MAX) {
+				Qr.push_back(QPosr); Pr.push_back(Plusr); Dr.push_back(DBPosr);
+				for (size_t i = 0; i < Qf.size(); ++i) {
+					int64_t TL = std::llabs(int64_t(Df[i]) - int64_t(DBPosr)) + int64_t(QL2);
+					if (TL <= MAX_TL && ExtendBoth1Pair4(Qf[i], Df[i], !Plusr, QPosr, DBPosr)) return;
+				}
+			}
+			if (kf != UINT_MAX) kf = F.GetNextBoth1Seed(kf, QPosf, Plusf, DBPosf);
+			if (kr != UINT_MAX) kr = R.GetNextBoth1Seed(kr, QPosr, Plusr, DBPosr);
+		} while (kf != UINT_MAX || kr != UINT_MAX);
+		for (size_t i = 0; i < Qf.size(); ++i) F.ExtendPen(Qf[i], Df[i], Pf[i] != 0);
+		for (size_t i = 0; i < Qr.size(); ++i) R.ExtendPen(Qr[i], Dr[i], Pr[i] != 0);
+		if (F.BestScore >= int((Lf * 9) / 10) && R.BestScore >= int((Lr * 9) / 10)) {
+			int64_t TL = std::llabs(int64_t(F.Hits[F.TopHit].DBStartPos) - int64_t(R.Hits[R.TopHit].DBStartPos)) + int64_t(QL2);
+			if (TL <= MAX_TL) { F.Mapq = 40; R.Mapq = 40; return; }
+		}
+		F.SearchPE_Pending();
+		R.SearchPE_Pending();
+		FindPairs();
+		if (PairScore.empty()) { ScanPair(); FindPairs(); }
+		AdjustTopHitsAndMapqs();
+	}
+};
+
+struct MateOut {
+	bool Mapped; uint32_t SeqIndex, Coord; bool Plus; unsigned Mapq; std::string Path; bool HasHit;
+};
+
+static void MateMapped(Searcher &S, MateOut &M) {  // SetMappedPos, state1.cpp:129-145
+	M.Mapped = false; M.SeqIndex = UINT32_MAX; M.Coord = UINT32_MAX; M.Plus = false; M.Mapq = S.Mapq; M.HasHit = false;
+	M.Path.clear();
+	if (S.TopHit < 0) return;
+	const Hit &H = S.Hits[S.TopHit];
+	unsigned TargetL = 0;
+	uint32_t si = UINT32_MAX;
+	uint32_t Coord = S.PosToCoordL(H.DBStartPos, si, TargetL);
+	if (uint32_t(Coord + S.QL) > TargetL) return;  // un-mapped: m_TopHit = 0
+	M.Mapped = true; M.SeqIndex = si; M.Coord = Coord; M.Plus = H.Plus; M.Path = H.Path; M.HasHit = true;
 }
+}  // namespace
+
+static uint32_t PairedFlags(bool First, bool RevComp, bool MateRevComp, bool MateUnmapped) {  // output2.cpp:18-36
+	uint32_t f = First ? 0x41 : 0x81;
+	if (RevComp) f |= 0x10;
+	if (MateUnmapped) f |= 0x08;
+	else if (MateRevComp) f |= 0x20;
+	return f;
+}
+
+extern "C" int uo_map_file_pe(const uo_index *X, const uo_params *P, const char *fq1, const char *fq2, const char *sam,
+                              int threads, int veryfast, uo_counters *counters) {
+	if (veryfast) return -101;  // Search5 (search2m5.cpp) is not restated
+	std::vector<FastqRec> R1, R2;
+	int rc = ReadFastq(fq1, R1);
+	if (rc) return rc;
+	rc = ReadFastq(fq2, R2);
+	if (rc) return rc;
+	if (R1.size() != R2.size()) return -4;
+	const int64_t n = (int64_t)R1.size();
+	std::vector<std::string> Out((size_t)n);
+	if (threads < 1) threads = 1;
+	if (counters) memset(counters, 0, sizeof *counters);
+#pragma omp parallel num_threads(threads)
+	{
+		PairSearcher S(X, *P);
+		std::vector<char> buf;
+#pragma omp for schedule(dynamic, 64)
+		for (int64_t i = 0; i < n; ++i) {
+			const FastqRec &A = R1[(size_t)i], &B = R2[(size_t)i];
+			S.Search4((const byte *)A.Seq.data(), (unsigned)A.Seq.size(), (const byte *)B.Seq.data(), (unsigned)B.Seq.size());
+			// SetSAM2, output2.cpp:61-128
+			MateOut M1, M2;
+			MateMapped(S.F, M1);
+			MateMapped(S.R, M2);
+			int TLEN1 = 0, TLEN2 = 0;
+			const bool Plus1 = M1.HasHit && M1.Plus, Plus2 = M2.HasHit && M2.Plus;
+			const bool StrandsConsistent = M1.HasHit && M2.HasHit && (Plus1 != Plus2);
+			bool CorrectlyPaired = false;
+			if (M1.Mapped && M2.Mapped) {
+				// NB the reference compares coordinates inside the sequences, not global positions
+				if (M1.Coord <= M2.Coord) {
+					TLEN1 = int(M2.Coord + S.R.QL) - int(M1.Coord);
+					if (TLEN1 > 0 && TLEN1 < 1000 && StrandsConsistent) CorrectlyPaired = true;
+					if (TLEN1 > 1000) TLEN1 = 0;
+					TLEN2 = -TLEN1;
+				} else {
+					TLEN2 = int(M1.Coord + S.F.QL) - int(M2.Coord);
+					if (TLEN2 > 0 && TLEN2 < 1000 && StrandsConsistent) CorrectlyPaired = true;
+					if (TLEN2 > 1000) TLEN2 = 0;
+					TLEN1 = -TLEN2;
+				}
+			}
+			const bool RevComp1 = M1.Mapped && !M1.Plus, RevComp2 = M2.Mapped && !M2.Plus;
+			uint32_t Flags1 = PairedFlags(true, RevComp1, RevComp2, !M2.Mapped);
+			uint32_t Flags2 = PairedFlags(false, RevComp2, RevComp1, !M1.Mapped);
+			if (CorrectlyPaired) { Flags1 |= 0x02; Flags2 |= 0x02; }
+			const char *L1 = M1.Mapped ? X->Labels[M1.SeqIndex].c_str() : "";
+			const char *L2 = M2.Mapped ? X->Labels[M2.SeqIndex].c_str() : "";
+			buf.resize(A.Label.size() + B.Label.size() + 3 * (A.Seq.size() + B.Seq.size()) + 1024);
+			size_t k = SamRecord(X, M1.Mapped, M1.SeqIndex, M1.Coord, M1.Plus, M1.Mapq, M1.Path.c_str(), Flags1, L2, M2.Coord, TLEN1,
+			                     A.Label.c_str(), (const byte *)A.Seq.data(), (const byte *)A.Qual.data(), (unsigned)A.Seq.size(), buf.data());
+			k += SamRecord(X, M2.Mapped, M2.SeqIndex, M2.Coord, M2.Plus, M2.Mapq, M2.Path.c_str(), Flags2, L1, M1.Coord, TLEN2,
+			               B.Label.c_str(), (const byte *)B.Seq.data(), (const byte *)B.Qual.data(), (unsigned)B.Seq.size(), buf.data() + k);
+			Out[(size_t)i].assign(buf.data(), k);
+		}
+#pragma omp critical
+		{ AddCounters(counters, S.F.C); AddCounters(counters, S.R.C); }
+	}
+	FILE *f = fopen(sam, "wb");
+	if (!f) return -3;
+	WriteSQ(f, X);
+	for (int64_t i = 0; i < n; ++i) fwrite(Out[(size_t)i].data(), 1, Out[(size_t)i].size(), f);
+	fclose(f);
+	return 0;
+}
+

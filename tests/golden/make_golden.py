@@ -9,6 +9,7 @@ outputs are what the reference itself wrote:
   se250.fq/.sam   200 reads, 250 bp, 4 % sub, 1 % indel
   se_short.fq/.sam 100 reads of 24..60 bp
   reference `urmap -map X.fq -ufi g.ufi -samout X.sam -threads 1`; the @PG line is dropped.
+  pe150_1/2.fq, pe100_noisy_1/2.fq + .sam   300 pairs each, reference `urmap -map2 A_1.fq -reverse A_2.fq ...`
 
 Run only where /root/reference exists; the fixtures are data, the reference itself does not travel.
 """
@@ -64,6 +65,28 @@ def main():
         synth.write_fastq(fq, reads)
         shutil.copy(fq, os.path.join(tmp, name + ".fq"))
         ol.run_ref(["-map", name + ".fq", "-ufi", "g.ufi", "-samout", name + ".sam", "-threads", "1"], cwd=tmp)
+        with open(os.path.join(HERE, name + ".sam"), "wb") as f:
+            f.write(b"\n".join(ol.sam_records(os.path.join(tmp, name + ".sam"))) + b"\n")
+    # paired-end: urmap -map2 R1 -reverse R2 (map2.cpp:39-90)
+    pe_sets = {
+        "pe150": synth.make_pairs(21, g, 300, read_len=150, sub1=0.01, sub2=0.02, ins=0.001, dele=0.001),
+        "pe100_noisy": synth.make_pairs(22, g, 300, read_len=100, sub1=0.04, sub2=0.08, ins=0.01, dele=0.01),
+    }
+    rng = np.random.default_rng(5)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    for name, (r1, r2) in pe_sets.items():
+        for k in range(5, len(r1), 37):  # one mate replaced by random sequence: rescue scan / unpaired output
+            lab, s, q = r2[k]
+            r2[k] = (lab, acgt[rng.integers(0, 4, size=len(s))], q)
+        for k in range(9, len(r1), 97):
+            lab, s, q = r1[k]
+            s = s.copy(); s[int(rng.integers(0, len(s)))] = ord("N"); r1[k] = (lab, s, q)
+        synth.write_fastq(os.path.join(HERE, name + "_1.fq"), r1)
+        synth.write_fastq(os.path.join(HERE, name + "_2.fq"), r2)
+        for suf in ("_1.fq", "_2.fq"):
+            shutil.copy(os.path.join(HERE, name + suf), os.path.join(tmp, name + suf))
+        ol.run_ref(["-map2", name + "_1.fq", "-reverse", name + "_2.fq", "-ufi", "g.ufi", "-samout", name + ".sam",
+                    "-threads", "1"], cwd=tmp)
         with open(os.path.join(HERE, name + ".sam"), "wb") as f:
             f.write(b"\n".join(ol.sam_records(os.path.join(tmp, name + ".sam"))) + b"\n")
     shutil.rmtree(tmp)

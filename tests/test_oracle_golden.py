@@ -35,6 +35,16 @@ def test_oracle_sam_equals_reference_golden(gold_ufi, tmp_path, name):
     assert read_records(out) == read_records(os.path.join(GOLD, name + ".sam"))
 
 
+@pytest.mark.parametrize("name", ["pe150", "pe100_noisy"])
+def test_oracle_pe_sam_equals_reference_golden(gold_ufi, tmp_path, name):
+    """urmap -map2 (map2.cpp:39-90; State2::Search4, FindPairs, ScanPair, AdjustTopHitsAndMapqs, SetSAM2): every
+    record of both mates identical to what the reference wrote (flags, RNEXT/PNEXT, TLEN included)."""
+    idx = ol.Index.load(gold_ufi)
+    out = os.path.join(tmp_path, name + ".sam")
+    idx.map_file_pe(os.path.join(GOLD, name + "_1.fq"), os.path.join(GOLD, name + "_2.fq"), out, threads=2)
+    assert read_records(out) == read_records(os.path.join(GOLD, name + ".sam"))
+
+
 def test_oracle_make_ufi_equals_reference_golden(gold_ufi, tmp_path):
     """urmap -make_ufi (ufindexio.cpp:117-179): byte-identical .ufi for the reference's slot count."""
     w, maxix, sds, slots = ol.ufi_header(gold_ufi)
@@ -80,3 +90,14 @@ def test_oracle_equals_reference_binary(tmp_path, seed, glen, n, rl, sub, indel)
     ol.run_ref(["-map", "r.fq", "-ufi", "g.ufi", "-samout", "ref.sam", "-threads", "4"], cwd=d)
     idx.map_file_se(os.path.join(d, "r.fq"), os.path.join(d, "o.sam"), threads=4)
     assert sorted(read_records(os.path.join(d, "ref.sam"))) == sorted(read_records(os.path.join(d, "o.sam")))
+    # paired-end on the same genome
+    r1, r2 = synth.make_pairs(seed + 2, g, n // 2, read_len=min(rl, 150), sub1=sub, sub2=2 * sub, ins=indel / 2, dele=indel / 2)
+    synth.write_fastq(os.path.join(d, "p1.fq"), r1)
+    synth.write_fastq(os.path.join(d, "p2.fq"), r2)
+    ol.run_ref(["-map2", "p1.fq", "-reverse", "p2.fq", "-ufi", "g.ufi", "-samout", "refpe.sam", "-threads", "4"], cwd=d)
+    idx.map_file_pe(os.path.join(d, "p1.fq"), os.path.join(d, "p2.fq"), os.path.join(d, "ope.sam"), threads=4)
+
+    def pairs(path):
+        body = [x for x in read_records(path) if not x.startswith(b"@")]
+        return sorted(body[i] + b"|" + body[i + 1] for i in range(0, len(body), 2))
+    assert pairs(os.path.join(d, "refpe.sam")) == pairs(os.path.join(d, "ope.sam"))
