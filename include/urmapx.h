@@ -118,6 +118,14 @@ void urmapx_ctx_destroy(urmapx_ctx *);
 int urmapx_map_se(urmapx_ctx *, const uint8_t *bases, const uint64_t *offs, uint32_t n, urmapx_result *results,
                   urmapx_path_op *path_ops, size_t path_cap, size_t *path_used);
 
+/* State2::Search (search2.cpp:59-73; -map2, method 4) over a batch of read PAIRS in host memory: reads 2i and 2i+1 of
+ * (bases, offs) are the two mates of pair i (R1, R2).  results[2*npairs]: per mate the hit AdjustTopHitsAndMapqs
+ * (search2.cpp:8-57) settled on, after SetMappedPos; `score` is that hit's score.  Flags, RNEXT/PNEXT and TLEN are
+ * host-side text (urmapx_sam_pe).  Device-domain limits as urmapx_map_se, plus read length <= 279 (the reference
+ * keeps pending seed positions in a byte, state1.h:86-87). */
+int urmapx_map_pe(urmapx_ctx *, const uint8_t *bases, const uint64_t *offs, uint32_t npairs, urmapx_result *results,
+                  urmapx_path_op *path_ops, size_t path_cap, size_t *path_used);
+
 /* Same with inputs and outputs already resident in HBM of the ctx's device (no PCIe in the call):
  * d_bases, d_offs (uint64[n+1]), d_results[n], d_path_ops[n*URMAPX_MAX_PATH_OPS], d_path_used (uint32).
  * Asynchronous on the ctx stream; urmapx_ctx_sync() waits. total_bases = offs[n]. */
@@ -162,6 +170,10 @@ int urmapx_build_slots(const uint8_t *seqdata, uint32_t seqdata_size, uint32_t w
  * Writes at most cap bytes (no NUL); returns the record length, or 0 if cap is too small. */
 size_t urmapx_sam_se(const urmapx_index *, const urmapx_result *r, const urmapx_path_op *path_ops, const char *label,
                      const uint8_t *seq, const uint8_t *qual, uint32_t read_len, char *buf, size_t cap);
+/* The two SAM records of a read pair: State2::SetSAM2 / GetPairedFlags (output2.cpp:18-128) + SetSAM. */
+size_t urmapx_sam_pe(const urmapx_index *, const urmapx_result *r1, const urmapx_result *r2, const urmapx_path_op *path_ops,
+                     const char *label1, const uint8_t *seq1, const uint8_t *qual1, uint32_t len1, const char *label2,
+                     const uint8_t *seq2, const uint8_t *qual2, uint32_t len2, char *buf, size_t cap);
 /* @SQ lines of State1::WriteSAMHeader (state1.cpp:736-748); same return convention. */
 size_t urmapx_sam_header_sq(const urmapx_index *, char *buf, size_t cap);
 

@@ -135,6 +135,14 @@ def test_viterbi_matches_oracle(gpu):
         for fl in (0, 1, 2, 3):
             pairs.append((q.tobytes(), t.tobytes()))
             flags.append(fl)
+    # whole-read DP of the paired-end rescue: the alignment's last column swept across the 64-column chunk borders of
+    # the wide path (regression: a cross-lane shift under a lane-dependent select lost the chunk's first column)
+    t = acgt[rng.integers(0, 4, size=1024)]
+    for st in list(range(170, 186)) + list(range(230, 250)):
+        q = t[st:st + 120].copy()
+        q[rng.integers(0, 120, size=8)] = acgt[rng.integers(0, 4, size=8)]
+        pairs.append((q.tobytes(), t.tobytes()))
+        flags.append(3)
     scores, status, paths = gpu["mapper"].viterbi_batch(pairs, flags)
     import itertools
     for k, ((a, b), fl) in enumerate(zip(pairs, flags)):
@@ -244,3 +252,58 @@ def test_veryfast_method7_matches_oracle(small_case, tmp_path):
     m = api.Mapper(idx, device=0, method=7)
     gres, gops = m.map_se(bases, offs)
     compare_results(gres, gops, ores, opaths)
+
+
+def _map_pe_sam(ufi, fq1, fq2):
+    from urmap_amd import api
+    idx = api.Index.open(ufi).upload(0)
+    m = api.Mapper(idx, device=0, method=6)
+    labels, bases, offs, quals = api.interleave_pairs(api.read_fastq_arrays(fq1), api.read_fastq_arrays(fq2))
+    res, ops = m.map_pe(bases, offs)
+    return idx.sam_header_sq() + idx.sam_pe(res, ops, labels, bases, offs, quals)
+
+
+@pytest.mark.parametrize("name", ["pe150", "pe100_noisy"])
+def test_pe_reproduces_reference_golden_sam(tmp_path, name):
+    """urmap -map2 (State2::Search4 ... SetSAM2): both records of every pair identical to the reference's SAM."""
+    import gzip
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gold = os.path.join(root, "tests", "golden")
+    ufi = os.path.join(tmp_path, "g.ufi")
+    with gzip.open(os.path.join(gold, "g.ufi.gz"), "rb") as z, open(ufi, "wb") as f:
+        f.write(z.read())
+    got = _map_pe_sam(ufi, os.path.join(gold, name + "_1.fq"), os.path.join(gold, name + "_2.fq"))
+    want = open(os.path.join(gold, name + ".sam"), "rb").read()
+    if got != want:
+        g, w = got.split(b"\n"), want.split(b"\n")
+        bad = [i for i in range(min(len(g), len(w))) if g[i] != w[i]]
+        raise AssertionError(f"{len(bad)} differing records, first: {g[bad[0]][:160]!r} vs {w[bad[0]][:160]!r}")
+
+
+@pytest.mark.parametrize("rl,s1,s2,indel,n", [(150, 0.01, 0.02, 0.001, 3000), (120, 0.04, 0.08, 0.01, 2000)])
+def test_pe_matches_oracle(small_case, tmp_path, rl, s1, s2, indel, n):
+    """Fresh pairs on the 300 kbp genome (incl. one-mate-random pairs that go through ScanPair): SAM of the device
+    path == SAM of the oracle's Search4 restatement."""
+    import os
+    from urmap_amd import synth
+    r1, r2 = synth.make_pairs(500 + rl, small_case["genome"], n, read_len=rl, sub1=s1, sub2=s2, ins=indel, dele=indel)
+    rng = np.random.default_rng(rl)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    for k in range(3, n, 29):
+        lab, s, q = r2[k]
+        r2[k] = (lab, acgt[rng.integers(0, 4, size=len(s))], q)
+    for k in range(5, n, 31):
+        lab, s, q = r1[k]
+        s = s.copy(); s[int(rng.integers(0, len(s)))] = ord("N"); r1[k] = (lab, s, q)
+    f1, f2 = os.path.join(tmp_path, "r1.fq"), os.path.join(tmp_path, "r2.fq")
+    synth.write_fastq(f1, r1)
+    synth.write_fastq(f2, r2)
+    osam = os.path.join(tmp_path, "o.sam")
+    small_case["oracle_index"].map_file_pe(f1, f2, osam, threads=4)
+    got = _map_pe_sam(small_case["ufi"], f1, f2)
+    want = open(osam, "rb").read()
+    if got != want:
+        g, w = got.split(b"\n"), want.split(b"\n")
+        bad = [i for i in range(min(len(g), len(w))) if g[i] != w[i]]
+        raise AssertionError(f"{len(bad)} differing records of {len(w)}, first: {g[bad[0]][:200]!r} vs {w[bad[0]][:200]!r}")

@@ -30,7 +30,7 @@ EXPORTS = (
     "urmapx_index_seq_length", "urmapx_index_seq_offset", "urmapx_ctx_create", "urmapx_ctx_destroy",
     "urmapx_map_se", "urmapx_map_se_device", "urmapx_ctx_sync", "urmapx_ctx_last_kernel_ms",
     "urmapx_seed_probe", "urmapx_viterbi_batch", "urmapx_strerror", "urmapx_device_arch",
-    "urmapx_make_ufi", "urmapx_build_slots", "urmapx_sam_se", "urmapx_sam_header_sq", "urmapx_ctx_phase_cycles",
+    "urmapx_make_ufi", "urmapx_build_slots", "urmapx_sam_se", "urmapx_sam_header_sq", "urmapx_ctx_phase_cycles", "urmapx_map_pe", "urmapx_sam_pe",
 )
 
 
@@ -82,6 +82,9 @@ def lib():
     L.urmapx_ctx_destroy.argtypes = [vp]
     L.urmapx_ctx_destroy.restype = None
     L.urmapx_map_se.argtypes = [vp, vp, vp, u32, vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.urmapx_map_pe.argtypes = [vp, vp, vp, u32, vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.urmapx_sam_pe.restype = C.c_size_t
+    L.urmapx_sam_pe.argtypes = [vp, vp, vp, vp, cp, vp, vp, u32, cp, vp, vp, u32, vp, C.c_size_t]
     L.urmapx_map_se_device.argtypes = [vp, vp, vp, u32, u64, u32, vp, vp, vp]
     L.urmapx_ctx_sync.argtypes = [vp]
     L.urmapx_ctx_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float * 2)]
@@ -214,6 +217,27 @@ class Index:
             out.append(buf.raw[:n])
         return b"".join(out)
 
+    def sam_pe(self, results: np.ndarray, ops: np.ndarray, labels, bases: np.ndarray, offs: np.ndarray,
+               quals: np.ndarray) -> bytes:
+        """SAM records of mapped PAIRS (reads 2i, 2i+1 = mates of pair i): State2::SetSAM2 + SetSAM."""
+        results = np.ascontiguousarray(results)
+        ops = np.ascontiguousarray(ops, dtype=np.uint16)
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        quals = np.ascontiguousarray(quals, dtype=np.uint8)
+        out = []
+        buf = C.create_string_buffer(1 << 16)
+        ops_ptr = ops.ctypes.data if len(ops) else None
+        for i in range(0, len(results), 2):
+            o1, e1, e2 = int(offs[i]), int(offs[i + 1]), int(offs[i + 2])
+            n = lib().urmapx_sam_pe(self.h, results[i:i + 1].ctypes.data, results[i + 1:i + 2].ctypes.data, ops_ptr,
+                                    labels[i].encode(), bases[o1:e1].ctypes.data, quals[o1:e1].ctypes.data, e1 - o1,
+                                    labels[i + 1].encode(), bases[e1:e2].ctypes.data, quals[e1:e2].ctypes.data, e2 - e1,
+                                    buf, len(buf))
+            if n == 0:
+                raise UrmapxError(-5, "urmapx_sam_pe: record does not fit")
+            out.append(buf.raw[:n])
+        return b"".join(out)
+
     def close(self):
         if self.h:
             lib().urmapx_index_close(self.h)
@@ -259,6 +283,21 @@ class Mapper:
         rc = lib().urmapx_map_se(self.h, bases.ctypes.data, offs.ctypes.data, n, res.ctypes.data, ops.ctypes.data, cap,
                                  C.byref(used))
         _check(rc, "urmapx_map_se", allow=(E_UNSUPPORTED,) if allow_unsupported else ())
+        return res, ops[: used.value].copy()
+
+    def map_pe(self, bases: np.ndarray, offs: np.ndarray, allow_unsupported=False):
+        """Pairs interleaved: reads 2i, 2i+1 are R1, R2 of pair i.  -> (results[2*npairs], path op arena)."""
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offs = np.ascontiguousarray(offs, dtype=np.uint64)
+        n = len(offs) - 1
+        assert n % 2 == 0
+        res = np.zeros(n, dtype=RESULT_DTYPE)
+        cap = max(1, n * MAX_PATH_OPS)
+        ops = np.zeros(cap, dtype=np.uint16)
+        used = C.c_size_t(0)
+        rc = lib().urmapx_map_pe(self.h, bases.ctypes.data, offs.ctypes.data, n // 2, res.ctypes.data, ops.ctypes.data,
+                                 cap, C.byref(used))
+        _check(rc, "urmapx_map_pe", allow=(E_UNSUPPORTED,) if allow_unsupported else ())
         return res, ops[: used.value].copy()
 
     def map_se_device(self, d_bases_ptr, d_offs_ptr, n, total_bases, max_read_len, d_results_ptr, d_path_ops_ptr,
@@ -323,6 +362,21 @@ class Mapper:
             self.close()
         except Exception:
             pass
+
+
+def interleave_pairs(a, b):
+    """(labels, bases, offs, quals) of R1 and of R2 -> one interleaved set (R1_0, R2_0, R1_1, ...)."""
+    la, ba, oa, qa = a
+    lb, bb, ob, qb = b
+    assert len(la) == len(lb)
+    labels, seqs, quals = [], [], []
+    for i in range(len(la)):
+        labels += [la[i], lb[i]]
+        seqs += [ba[int(oa[i]):int(oa[i + 1])], bb[int(ob[i]):int(ob[i + 1])]]
+        quals += [qa[int(oa[i]):int(oa[i + 1])], qb[int(ob[i]):int(ob[i + 1])]]
+    offs = np.zeros(len(seqs) + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum([len(s) for s in seqs])
+    return labels, np.concatenate(seqs), offs, np.concatenate(quals)
 
 
 def read_fastq_arrays(path):

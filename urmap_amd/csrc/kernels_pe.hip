@@ -1,0 +1,791 @@
+// kernels_pe.hip -- paired-end search (urmap -map2): State2::Search4 (search2m4.cpp:15-208) and everything under it,
+// one wavefront per read PAIR.
+//
+// First correct version: the schedule is emulated step by step, wave-uniform, with the 64 lanes used inside each
+// primitive (64 bases per compare in ExtendPen / ExtendScan, one DP diagonal per lane in Viterbi, 64 window
+// positions per step in ScanSlots, one hit / HSP per lane in the list searches).  It does not yet batch candidate
+// windows the way search_se_kernel does; correctness against the oracle first, memory-level parallelism next.
+//
+// Reference functions: GetFirstBoth1Seed / GetNextBoth1Seed (getseed.cpp:9-138), ExtendBoth1Pair4
+// (search2m4.cpp:189-208), ExtendPen (extendpen.cpp:9-95), SearchPE_Pending (search1pepend.cpp:9-130),
+// GetRow_Blob (ufindex.cpp:883-943), AlignHSP (alignhsp.cpp:60-172), FindPairs / ScanPair (state2.cpp:20-137),
+// Scan / ScanSlots / ExtendScan / AddHSPScan (scan.cpp:14-39, scanslots.cpp:7-62, extendscan.cpp:8-187),
+// AdjustTopHitsAndMapqs (search2.cpp:8-57), CalcMAPQ6 (search1m6.cpp:9-33), SetMappedPos (state1.cpp:129-145).
+#include "dev_common.h"
+#include "viterbi_dev.h"
+
+namespace urx {
+
+static constexpr int PE_HIT_CAP = 64;
+static constexpr int PE_HSP_CAP = 128;
+static constexpr int PE_SEED_CAP = 640;   // >= 2 * (QMAX - W + 1)
+static constexpr int PE_PAIR_CAP = 256;
+static constexpr int PE_SCAN_SEG = 1024;  // SCAN_DB_SEG_LENGTH, state2.cpp:92
+static constexpr uint32_t PRIME_STRIDE = 27, SCANK = 4;
+static constexpr int MAX_TL = 1000;
+
+template <int NCH>
+struct Mate {
+	static constexpr int QMAX = 64 * NCH;
+	static constexpr int TB_ROWS8 = QMAX / 8 + 2;
+	// wave constants
+	const DevIndex *X;
+	const urmapx_params *P;
+	const uint8_t *__restrict__ gseq;
+	const uint8_t *__restrict__ gblob;
+	int lane;
+	// this mate
+	int QL, W, nwords;
+	uint8_t *sQ[2];  // LDS: [0] read as given, [1] reverse complement
+	uint32_t qch[2][NCH];
+	const uint64_t *pslots;  // probe output of this read (global), index strand*QL + qpos
+	const uint8_t *ptal;
+	const uint32_t *ppos;
+	// shared LDS scratch (one set per wave)
+	uint8_t *sT;
+	uint32_t *tb;
+	uint16_t *ropsL, *ropsR, *cand;
+	WideScratch ws;
+	// lists
+	uint32_t hit_db;      // lane k: hit k
+	uint32_t hit_sp;      // score << 1 | plus
+	uint16_t *hit_nops;   // LDS [PE_HIT_CAP]
+	urmapx_path_op *hit_paths;  // global [PE_HIT_CAP][URMAPX_MAX_PATH_OPS]
+	uint32_t *hsp_db, *hsp_ql;  // LDS [PE_HSP_CAP]
+	uint16_t *hsp_sf;
+	uint8_t *pend[2];     // LDS [QMAX] each: pending query positions (stored in a byte, state1.h:86-87)
+	int pendCount[2];
+	int hitCount, hspCount, topHit;
+	int maxPen, best, second, bestHSP;
+	uint32_t mapq;
+	uint32_t status;
+
+	__device__ __forceinline__ bool overlaps_hit(uint32_t db) const {
+		return __ballot(lane < hitCount && (hit_db >> 6) == (db >> 6)) != 0;
+	}
+
+	// state1.cpp:508-551; returns the hit index or -1.  A path, if any, is in `cand`.
+	__device__ __forceinline__ int add_hit(uint32_t db, bool plus, int score, int cand_nops) {
+		if (score < 10) return -1;
+		if (overlaps_hit(db)) return -1;
+		int mp = (QL - score) - 2 * P->mismatch_score;
+		if (mp < maxPen) maxPen = mp;
+		const int idx = hitCount;
+		bool keep = true;
+		if (score > best) { second = best; best = score; topHit = idx; }
+		else if (score == best) second = score;
+		else {
+			if (score < best - 12) keep = false;
+			else if (score > second) second = score;
+		}
+		if (!keep) return -1;
+		if (hitCount >= PE_HIT_CAP) { status |= URMAPX_ST_HIT_OVERFLOW; if (topHit == idx) topHit = -1; return -1; }
+		if (lane == idx) { hit_db = db; hit_sp = ((uint32_t)score << 1) | (plus ? 1u : 0u); }
+		if (lane == 0) hit_nops[idx] = (uint16_t)cand_nops;
+		for (int t = lane; t < cand_nops; t += 64) hit_paths[(size_t)idx * URMAPX_MAX_PATH_OPS + t] = cand[t];
+		__syncthreads();
+		++hitCount;
+		return idx;
+	}
+
+	__device__ __forceinline__ int find_hsp_diag(uint32_t diag) const {
+		for (int base = 0; base < hspCount; base += 64) {
+			const int i = base + lane;
+			bool eq = false;
+			if (i < hspCount) eq = (hsp_db[i] - (hsp_ql[i] & 0xFFFFu)) == diag;
+			uint64_t m = __ballot(eq);
+			if (m) return base + __builtin_ctzll(m);
+		}
+		return -1;
+	}
+	__device__ __forceinline__ void put_hsp(int k, uint32_t startq, uint32_t startdb, bool plus, uint32_t len, int score) {
+		if (lane == 0) {
+			hsp_db[k] = startdb; hsp_ql[k] = startq | (len << 16); hsp_sf[k] = (uint16_t)((score << 2) | (plus ? 1 : 0));
+		}
+		__syncthreads();
+	}
+	// state1.cpp:553-591
+	__device__ __forceinline__ void add_hsp(uint32_t startq, uint32_t startdb, bool plus, uint32_t len, int score) {
+		if (score < best - 4) return;
+		int k = find_hsp_diag(startdb - startq);
+		if (k >= 0) {
+			if (score > (int)(hsp_sf[k] >> 2)) put_hsp(k, startq, startdb, plus, len, score);
+			return;
+		}
+		if (hspCount >= PE_HSP_CAP) { status |= URMAPX_ST_HSP_OVERFLOW; return; }
+		put_hsp(hspCount, startq, startdb, plus, len, score);
+		++hspCount;
+		if (score > bestHSP) bestHSP = score;
+	}
+	// extendscan.cpp:8-49
+	__device__ __forceinline__ int add_hsp_scan(uint32_t startq, uint32_t startdb, bool plus, uint32_t len, int score) {
+		int k = find_hsp_diag(startdb - startq);
+		if (k >= 0) {
+			if (score > (int)(hsp_sf[k] >> 2)) put_hsp(k, startq, startdb, plus, len, score);
+			return k;
+		}
+		if (hspCount >= PE_HSP_CAP) { status |= URMAPX_ST_HSP_OVERFLOW; return -1; }
+		k = hspCount;
+		put_hsp(k, startq, startdb, plus, len, score);
+		++hspCount;
+		if (score > bestHSP) bestHSP = score;
+		return k;
+	}
+
+	__device__ __forceinline__ void window_mask(uint32_t dblo, bool plus, BitVec<NCH> &mm) const {
+		const uint8_t *t = gseq + dblo;
+		const int s = plus ? 0 : 1;
+#pragma unroll
+		for (int c = 0; c < NCH; ++c) {
+			const int p = 64 * c + lane;
+			bool ne = false;
+			if (p < QL) ne = ((uint32_t)t[p] != qch[s][c]);
+			mm.w[c] = __ballot(ne);
+		}
+	}
+
+	// The two x-drop walks shared by ExtendPen (extendpen.cpp:25-78) and ExtendScan (extendscan.cpp:77-133).
+	// scan = true: the leftward walk does not add to the penalty (the reference's omission, kept).
+	// Returns false if the penalty cap aborted the extension.
+	__device__ __forceinline__ bool xdrop_walk(const BitVec<NCH> &mm, int seedq, bool scan, int &bst, int &startpos, int &endpos) const {
+		const int mis = P->mismatch_score, xdrop = P->xdrop;
+		int pen = 0, score = W;
+		bst = 0;
+		endpos = seedq + W - 1;
+		int cur = endpos + 1;
+		while (cur < QL) {
+			int m = mm.next_set(cur);
+			if (m > QL) m = QL;
+			const int run = m - cur;
+			if (run > 0) { score += run; if (score > bst) { bst = score; endpos = m - 1; } }
+			if (m >= QL) break;
+			pen -= mis;
+			if (pen > maxPen) return false;
+			score += mis;
+			if (bst - score > xdrop) break;
+			cur = m + 1;
+		}
+		startpos = seedq;
+		cur = startpos - 1;
+		while (cur >= 0) {
+			const int m = mm.prev_set(cur);
+			const int run = cur - m;
+			if (run > 0) { score += run; if (score > bst) { bst = score; startpos = m + 1; } }
+			if (m < 0) break;
+			if (!scan) pen -= mis;
+			if (pen > maxPen) return false;
+			score += mis;
+			if (bst - score > xdrop) break;
+			cur = m - 1;
+		}
+		return true;
+	}
+
+	// extendpen.cpp:9-95
+	__device__ __forceinline__ int extend_pen(uint32_t seedq, uint32_t seeddb, bool plus) {
+		if (seeddb < seedq) return -1;
+		const uint32_t dblo = seeddb - seedq;
+		if (overlaps_hit(dblo)) return -1;
+		BitVec<NCH> mm;
+		window_mask(dblo, plus, mm);
+		int bst, sp, ep;
+		if (!xdrop_walk(mm, (int)seedq, false, bst, sp, ep)) return -1;
+		if (sp == 0 && ep == QL - 1) {
+			add_hit(dblo, plus, bst, 0);
+			return bst;
+		}
+		const int minhsp = (int)((uint32_t)P->min_hsp_score_pct * (uint32_t)QL / 100.0);
+		if (bst >= minhsp) {
+			add_hsp((uint32_t)sp, dblo + (uint32_t)sp, plus, (uint32_t)(ep - sp + 1), bst);
+			return -2;
+		}
+		return -1;
+	}
+
+	__device__ __forceinline__ bool load_window(uint32_t tlo, int tl) {
+		bool gap = false;
+		for (int i = lane; i < tl; i += 64) {
+			uint8_t c = gseq[tlo + i];
+			sT[i] = c;
+			gap |= (c == '-');
+		}
+		__syncthreads();
+		return __ballot(gap) != 0;
+	}
+
+	// alignhsp.cpp:60-172; returns the new hit index or -1
+	__device__ __forceinline__ int align_hsp(int k) {
+		const uint32_t sf = hsp_sf[k];
+		if (sf & 2u) return -1;
+		__syncthreads();
+		if (lane == 0) hsp_sf[k] = (uint16_t)(sf | 2u);
+		const uint32_t ql = hsp_ql[k];
+		const int startq = (int)(ql & 0xFFFFu), len = (int)(ql >> 16);
+		const uint32_t startdb = hsp_db[k];
+		const int hscore = (int)(sf >> 2);
+		const bool plus = sf & 1u;
+		__syncthreads();
+		int totalPen = len - hscore;
+		int totalScore = hscore;
+		if (totalPen > maxPen) return -1;
+		const int BR = 2 * (int)P->band_radius;
+		const uint32_t TL = X->seqDataSize;
+		uint32_t combinedTLo = startdb;
+		const uint8_t *Q = sQ[plus ? 0 : 1];
+		RevOps RL, RR;
+		RL.ops = ropsL; RR.ops = ropsR;
+		RL.begin(); RR.begin();
+		int rtrim = 0;
+		uint32_t vst = 0;
+		if (startq > 0) {
+			if (startdb < (uint32_t)startq) return -1;
+			const int leftQL = startq;
+			const uint32_t leftTHi = startdb - 1;
+			const uint32_t leftTL = (uint32_t)(leftQL + BR);
+			if (leftTL >= leftTHi) return -1;
+			const uint32_t leftTLo = leftTHi - leftTL + 1;
+			if (load_window(leftTLo, (int)leftTL)) return -1;
+			int leftScore = (int)viterbi_wave(*P, Q, leftQL, sT, (int)leftTL, true, false, tb, TB_ROWS8, &ws, RL, vst, lane);
+			status |= vst;
+			int nTrimI = 0;
+			if (RL.n > 0) {
+				uint32_t lastop = ropsL[RL.n - 1];
+				if ((lastop & 3u) == OP_I) { nTrimI = (int)(lastop >> 2); --RL.n; }
+			}
+			combinedTLo = leftTLo + (uint32_t)nTrimI;
+			int allGap = P->gap_open_score + (leftQL - 1) * P->gap_ext_score;
+			if (allGap > leftScore) leftScore = allGap;
+			totalScore += leftScore;
+			totalPen += leftQL - leftScore;
+			if (totalPen > maxPen) return -1;
+		}
+		const int rightQLo = startq + len;
+		if (rightQLo < QL) {
+			const int rightQL = QL - rightQLo;
+			const uint32_t rightTLo = startdb + (uint32_t)len;
+			uint32_t rightTHi = rightTLo + (uint32_t)rightQL + (uint32_t)BR;
+			if (rightTHi >= TL) rightTHi = TL - 1;
+			const uint32_t rightTL = rightTHi - rightTLo + 1;
+			if (load_window(rightTLo, (int)rightTL)) return -1;
+			int rightScore = (int)viterbi_wave(*P, Q + rightQLo, rightQL, sT, (int)rightTL, false, true, tb, TB_ROWS8, &ws, RR, vst, lane);
+			status |= vst;
+			if (RR.n > 1 && (ropsR[0] & 3u) == OP_I) rtrim = 1;
+			int allGap = P->gap_open_score + (rightQL - 1) * P->gap_ext_score;
+			if (allGap > rightScore) rightScore = allGap;
+			totalScore += rightScore;
+			totalPen += rightQL - rightScore;
+			if (totalPen > maxPen) return -1;
+		}
+		if (status & (URMAPX_ST_BAND_TOO_WIDE | URMAPX_ST_PATH_OVERFLOW)) return -1;
+		int nc = 0, cop = -1, clen = 0;
+		bool ovf = false;
+		auto put = [&](int op, int l) {
+			if (l <= 0) return;
+			if (op == cop) { clen += l; return; }
+			if (clen) { if (nc < URMAPX_MAX_PATH_OPS) { if (lane == 0) cand[nc] = (uint16_t)((clen << 2) | cop); ++nc; } else ovf = true; }
+			cop = op; clen = l;
+		};
+		for (int t = RL.n - 1; t >= 0; --t) { uint32_t o = ropsL[t]; put((int)(o & 3u), (int)(o >> 2)); }
+		put(OP_M, len);
+		for (int t = RR.n - 1; t >= rtrim; --t) { uint32_t o = ropsR[t]; put((int)(o & 3u), (int)(o >> 2)); }
+		put(-2, 1);
+		if (ovf) { status |= URMAPX_ST_PATH_OVERFLOW; return -1; }
+		__syncthreads();
+		return add_hit(combinedTLo, plus, totalScore, nc);
+	}
+
+	// search1m6.cpp:9-33
+	__device__ __forceinline__ uint32_t calc_mapq() const {
+		if (hitCount == 0) return 0;
+		if (best <= 0) return 0;
+		double bp = (double)QL;
+		double sec = (double)second;
+		if (sec < bp / 2.0) {
+			sec = bp / 2.0;
+			if ((double)best <= sec) return 0;
+		}
+		double fract = (double)best / bp;
+		double drop = (double)best - sec;
+		if (drop > 40) drop = 40;
+		double x = drop * fract;
+		x = x * fract;
+		uint32_t mq = (uint32_t)x;
+		if (mq > 40) mq = 40;
+		return mq;
+	}
+
+	// ufindex.cpp:883-943 (wave-uniform walk); positions land on lanes 0..K-1 of `row`
+	__device__ __forceinline__ int get_row(uint64_t slot, uint32_t T, uint32_t pos, uint32_t &row) const {
+		if ((T & TALLY_MY_BIT) == 0) return 0;
+		uint64_t slot2 = slot;
+		int K = 0;
+		const uint64_t N = X->slotCount;
+		for (;;) {
+			if (K > 0) {
+				uint32_t t2, p2;
+				load_slot(gblob, slot2, t2, p2);
+				T = uni(t2); pos = uni(p2);
+			}
+			if (lane == K) row = pos;
+			++K;
+			if (K == (int)X->maxIx || K >= 64) return K;
+			if (T == TALLY_PLUS1 || T == TALLY_BOTH1) return 1;
+			if (T == TALLY_END) return K;
+			if (T == TALLY_LONG_MINE || T == TALLY_LONG_OTHER) {
+				uint64_t slotA = addmod(slot2, pos & 0xFFFFu, N);
+				slot2 = addmod(slotA, pos >> 16, N);
+				uint32_t tA, pA;
+				load_slot(gblob, slotA, tA, pA);
+				pA = uni(pA);
+				if (lane == K - 1) row = pA;
+			} else
+				slot2 = addmod(slot2, T & TALLY_NEXT_MASK, N);
+		}
+	}
+
+	// search1pepend.cpp:9-130
+	__device__ void search_pending() {
+		maxPen = P->max_penalty;
+		const int minScore1 = QL + P->xphase1 * P->mismatch_score;
+		const int termHSP3 = (QL * P->term_hsp_score_pct_phase3) / 100;
+		if (best >= minScore1) { mapq = calc_mapq(); return; }
+		if (bestHSP >= termHSP3) {
+			for (int k = 0; k < hspCount; ++k) align_hsp(k);
+			if (best >= minScore1) { mapq = calc_mapq(); return; }
+		}
+		int count2[2] = {0, 0};
+		for (int round = 0; round < 2; ++round) {
+			for (int s = 0; s < 2; ++s) {
+				const bool plus = (s == 0);
+				const int n = round == 0 ? pendCount[s] : count2[s];
+				for (int i = 0; i < n; ++i) {
+					const uint32_t qpos = pend[s][i];
+					const size_t idx = (size_t)s * QL + qpos;
+					const uint64_t slot = uni64(pslots[idx]);
+					const uint32_t T = uni((uint32_t)ptal[idx]);
+					const uint32_t pos = uni(ppos[idx]);
+					uint32_t row = 0;
+					const int K = get_row(slot, T, pos, row);
+					if (round == 0 && K > 2) {
+						__syncthreads();
+						if (lane == 0) pend[s][count2[s]] = (uint8_t)qpos;
+						__syncthreads();
+						++count2[s];
+						continue;
+					}
+					for (int t = 0; t < K; ++t) extend_pen(qpos, rdlane(row, t), plus);
+				}
+			}
+		}
+		const int bmin = max(best, bestHSP) - 8;
+		for (int k = 0; k < hspCount; ++k) {
+			if ((int)(hsp_sf[k] >> 2) < bmin) continue;
+			align_hsp(k);
+		}
+		mapq = calc_mapq();
+	}
+
+	// extendscan.cpp:51-187
+	__device__ __forceinline__ void extend_scan(uint32_t seedq, uint32_t seeddb, bool plus) {
+		if (seeddb < seedq) return;
+		const uint32_t dblo = seeddb - seedq;
+		BitVec<NCH> mm;
+		window_mask(dblo, plus, mm);
+		int bst, sp, ep;
+		if (!xdrop_walk(mm, (int)seedq, true, bst, sp, ep)) return;
+		if (sp == 0 && ep == QL - 1) { add_hit(dblo, plus, bst, 0); return; }
+		if (bst < 2 * W) return;
+		const int k = add_hsp_scan((uint32_t)sp, dblo + (uint32_t)sp, plus, (uint32_t)(ep - sp + 1), bst);
+		if (k >= 0) align_hsp(k);
+	}
+
+	// scanslots.cpp:7-62: every window k-mer against the read's slots at the first SCANK prime-stride positions
+	__device__ void scan_slots(uint32_t dblo, uint32_t seglen, bool plus) {
+		if (QL <= 4 * W) return;
+		const int s = plus ? 0 : 1;
+		uint64_t qslot[SCANK];
+		uint32_t qposk[SCANK];
+#pragma unroll
+		for (uint32_t k = 0; k < SCANK; ++k) {
+			qposk[k] = (k * PRIME_STRIDE) % (uint32_t)nwords;
+			qslot[k] = uni64(pslots[(size_t)s * QL + qposk[k]]);
+		}
+		const uint64_t wmask = X->shiftMask;
+		// lane handles window start positions base+lane; a k-mer is valid iff its W letters are all ACGT
+		for (uint32_t base = 0; base + (uint32_t)W <= seglen; base += 64) {
+			const uint32_t p = base + lane;
+			uint64_t word = 0;
+			bool valid = p + (uint32_t)W <= seglen;
+			if (valid) {
+				const uint8_t *t = gseq + dblo + p;
+				for (int i = 0; i < W; ++i) {
+					const uint32_t L = letter_of(t[i]);
+					if (L > 3u) valid = false;
+					word = (word << 2) | (L & 3u);
+				}
+			}
+			uint64_t slot = ~0ull;
+			if (valid) slot = mod_slots(murmur64(word & wmask), X->slotCount, X->slotMagic);
+			uint32_t hitmask = 0;
+#pragma unroll
+			for (uint32_t k = 0; k < SCANK; ++k)
+				if (valid && slot == qslot[k]) hitmask |= (1u << k);
+			uint64_t any = __ballot(hitmask != 0);
+			while (any) {  // window positions in ascending order, k ascending inside (scanslots.cpp:50-59)
+				const int l = __builtin_ctzll(any);
+				any &= any - 1;
+				const uint32_t hm = rdlane(hitmask, l);
+#pragma unroll
+				for (uint32_t k = 0; k < SCANK; ++k)
+					if (hm & (1u << k)) extend_scan(qposk[k], dblo + base + (uint32_t)l, plus);
+			}
+		}
+	}
+
+	// scan.cpp:14-39
+	__device__ void scan(uint32_t dbpos, uint32_t seglen, bool plus, bool dovit) {
+		const int savedMaxPen = maxPen;
+		const int savedHits = hitCount;
+		maxPen = 130;
+		scan_slots(dbpos, seglen, plus);
+		maxPen = savedMaxPen;
+		if (hitCount > savedHits) return;
+		if (!dovit) return;
+		RevOps R;
+		R.ops = ropsL;
+		uint32_t vst = 0;
+		// whole read against the window: a band far wider than a wavefront -> wide path (B read from global memory)
+		const float score = viterbi_wave(*P, sQ[plus ? 0 : 1], QL, gseq + dbpos, (int)seglen, true, true, tb, TB_ROWS8, &ws, R, vst, lane);
+		status |= vst;
+		if (vst) return;
+		if ((double)score >= (double)QL / 3.0) {
+			int n = R.n, nI = 0, r0 = 0;
+			if (n > 0 && (ropsL[n - 1] & 3u) == OP_I) { nI = (int)(ropsL[n - 1] >> 2); --n; }  // TrimLeftIs
+			if (n > 1 && (ropsL[0] & 3u) == OP_I) r0 = 1;                                     // TrimRightIs
+			const int nc = n - r0;
+			if (nc > URMAPX_MAX_PATH_OPS) { status |= URMAPX_ST_PATH_OVERFLOW; return; }
+			__syncthreads();
+			for (int t = lane; t < nc; t += 64) cand[t] = ropsL[n - 1 - t];
+			__syncthreads();
+			add_hit(dbpos + (uint32_t)nI, plus, (int)score, nc);
+		}
+	}
+};
+
+template <int NCH>
+__global__ __launch_bounds__(64) void search_pe_kernel(DevIndex X, urmapx_params P, const uint8_t *__restrict__ bases,
+                                                       const uint64_t *__restrict__ offs, uint32_t npairs, ProbeOut probe,
+                                                       urmapx_result *__restrict__ results,
+                                                       urmapx_path_op *__restrict__ path_ops, uint32_t *path_used,
+                                                       uint8_t *scratch, size_t scratch_stride,
+                                                       const uint8_t *__restrict__ g_seq, const uint8_t *__restrict__ g_blob) {
+	using M = Mate<NCH>;
+	constexpr int QMAX = M::QMAX;
+	__shared__ uint8_t sQ[4][QMAX];
+	__shared__ uint8_t sT[QMAX + 64];
+	__shared__ uint32_t tb[M::TB_ROWS8 * 64];
+	__shared__ uint16_t ropsL[OPS_CAP], ropsR[OPS_CAP], cand[URMAPX_MAX_PATH_OPS];
+	__shared__ uint16_t hit_nops[2][PE_HIT_CAP];
+	__shared__ uint32_t hsp_db[2][PE_HSP_CAP], hsp_ql[2][PE_HSP_CAP];
+	__shared__ uint16_t hsp_sf[2][PE_HSP_CAP];
+	__shared__ uint8_t pend[4][QMAX];
+	// Both1 seed lists of the two mates in enumeration order: qpos | plus << 15, db position
+	__shared__ uint16_t seed_q[2][PE_SEED_CAP];
+	__shared__ uint32_t seed_db[2][PE_SEED_CAP];
+	__shared__ uint16_t pair_f[PE_PAIR_CAP], pair_r[PE_PAIR_CAP];
+
+	const int lane = threadIdx.x;
+	const int W = (int)X.W;
+	uint8_t *sc = scratch + (size_t)blockIdx.x * scratch_stride;
+	M m[2];
+	for (int a = 0; a < 2; ++a) {
+		m[a].X = &X; m[a].P = &P; m[a].gseq = g_seq; m[a].gblob = g_blob; m[a].lane = lane; m[a].W = W;
+		m[a].sQ[0] = sQ[2 * a]; m[a].sQ[1] = sQ[2 * a + 1];
+		m[a].sT = sT; m[a].tb = tb; m[a].ropsL = ropsL; m[a].ropsR = ropsR; m[a].cand = cand;
+		m[a].hit_nops = hit_nops[a];
+		m[a].hit_paths = reinterpret_cast<urmapx_path_op *>(sc) + (size_t)a * PE_HIT_CAP * URMAPX_MAX_PATH_OPS;
+		m[a].hsp_db = hsp_db[a]; m[a].hsp_ql = hsp_ql[a]; m[a].hsp_sf = hsp_sf[a];
+		m[a].pend[0] = pend[2 * a]; m[a].pend[1] = pend[2 * a + 1];
+		m[a].ws.carve(sc + (size_t)2 * PE_HIT_CAP * URMAPX_MAX_PATH_OPS * 2, QMAX, PE_SCAN_SEG + 2 * QMAX + 64);
+	}
+
+	for (uint32_t pr = blockIdx.x; pr < npairs; pr += gridDim.x) {
+		urmapx_result res[2];
+		bool bad = false;
+		for (int a = 0; a < 2; ++a) {
+			const uint32_t r = 2 * pr + a;
+			const uint64_t off = offs[r];
+			const int QL = (int)(offs[r + 1] - off);
+			res[a].dbpos = 0xFFFFFFFFu; res[a].seq_index = 0xFFFFFFFFu; res[a].coord = 0xFFFFFFFFu;
+			res[a].score = 0; res[a].second = 0; res[a].mapq = 0; res[a].plus = 0; res[a].exit_phase = 0; res[a].status = 0;
+			res[a].hit_count = 0; res[a].path_nops = 0; res[a].path_off = 0;
+			if (QL < W || QL > QMAX || W > 32 || X.maxIx > 32 || QL - (W - 1) > 256) bad = true;  // pending positions are bytes
+			m[a].QL = QL; m[a].nwords = QL - (W - 1);
+			m[a].pslots = probe.slots + 2 * off; m[a].ptal = probe.tallies + 2 * off; m[a].ppos = probe.positions + 2 * off;
+		}
+		if (bad) {
+			for (int a = 0; a < 2; ++a) { res[a].status = URMAPX_ST_BAD_LENGTH; if (lane == 0) results[2 * pr + a] = res[a]; }
+			continue;
+		}
+		__syncthreads();
+		// ---- InitPE x2 (state1.cpp:95-127) ----
+		for (int a = 0; a < 2; ++a) {
+			const uint8_t *q = bases + offs[2 * pr + a];
+			const int QL = m[a].QL;
+#pragma unroll
+			for (int c = 0; c < NCH; ++c) {
+				const int p = 64 * c + lane;
+				uint32_t cp = 0, cm = 0;
+				if (p < QL) {
+					cp = q[p]; cm = comp_char(q[QL - 1 - p]);
+					m[a].sQ[0][p] = (uint8_t)cp; m[a].sQ[1][p] = (uint8_t)cm;
+				}
+				m[a].qch[0][c] = cp; m[a].qch[1][c] = cm;
+			}
+			m[a].hit_db = 0; m[a].hit_sp = 0;
+			m[a].pendCount[0] = m[a].pendCount[1] = 0;
+			m[a].hitCount = 0; m[a].hspCount = 0; m[a].topHit = -1;
+			m[a].maxPen = P.max_penalty; m[a].best = 0; m[a].second = 0; m[a].bestHSP = 0;
+			m[a].mapq = 0xFFFFFFFFu; m[a].status = 0;
+		}
+		__syncthreads();
+
+		// ---- seed enumeration of both mates (GetFirstBoth1Seed / GetNextBoth1Seed) ----
+		// State independent, so it is run to the end up front; the pending lists are cut back to the point the
+		// pairing loop reached if that loop returns early (they are not used then anyway).
+		int nseed[2];
+		for (int a = 0; a < 2; ++a) {
+			const int QL = m[a].QL, QWC = m[a].nwords;
+			int ns = 0;
+			bool have = false, lastPlus = false;
+			uint32_t lastDiag = 0;
+			int np = 0, nm = 0;
+			for (int k = 0; k < QWC; ++k) {
+				const uint32_t qpos = ((uint32_t)k * PRIME_STRIDE) % (uint32_t)QWC;
+				bool plusReturnedHere = false;
+				for (int s = 0; s < 2; ++s) {
+					const size_t idx = (size_t)s * QL + qpos;
+					const uint32_t T = uni((uint32_t)m[a].ptal[idx]);  // slots without a k-mer carry tally 0 = FREE = "other"
+					if ((T & TALLY_MY_BIT) == 0) continue;
+					const bool special = (s == 1) && plusReturnedHere;  // the re-check branch of GetNextBoth1Seed
+					if (T != TALLY_BOTH1) {
+						if (!special) {
+							if (lane == 0) m[a].pend[s][s == 0 ? np : nm] = (uint8_t)qpos;
+							if (s == 0) ++np; else ++nm;
+						}
+						continue;
+					}
+					const uint32_t db = uni(m[a].ppos[idx]);
+					const uint32_t diag = db - qpos;
+					if (have && diag == lastDiag) {
+						if (special) { if (lane == 0) m[a].pend[1][nm] = (uint8_t)qpos; ++nm; }
+						continue;
+					}
+					if (ns < PE_SEED_CAP) {
+						if (lane == 0) { seed_q[a][ns] = (uint16_t)(qpos | (s == 0 ? 0x8000u : 0u)); seed_db[a][ns] = db; }
+						++ns;
+					} else
+						m[a].status |= URMAPX_ST_HSP_OVERFLOW;
+					have = true; lastDiag = diag; lastPlus = (s == 0);
+					if (s == 0) plusReturnedHere = true;
+					else break;  // a minus seed was returned: the enumeration resumes at k + 1
+				}
+				(void)lastPlus;
+			}
+			nseed[a] = ns;
+			m[a].pendCount[0] = np; m[a].pendCount[1] = nm;
+		}
+		__syncthreads();
+
+		// ---- Search4 pairing loop (search2m4.cpp:71-143) ----
+		const int QLf = m[0].QL, QLr = m[1].QL;
+		const int64_t QL2 = (int64_t)((QLf + QLr) / 2);
+		const int termPair = QLf + QLr + 5 * P.mismatch_score;
+		bool done = false;
+		{
+			const int steps = max(nseed[0], nseed[1]);
+			for (int t = 0; t < steps && !done; ++t) {
+				if (t < nseed[0]) {
+					const uint32_t qf = seed_q[0][t] & 0x7FFFu, dbf = seed_db[0][t];
+					const bool plusf = (seed_q[0][t] & 0x8000u) != 0;
+					const int nr = min(t, nseed[1]);
+					for (int i = 0; i < nr && !done; ++i) {
+						const uint32_t dbr = seed_db[1][i];
+						int64_t d = (int64_t)dbf - (int64_t)dbr;
+						if (d < 0) d = -d;
+						if (d + QL2 > MAX_TL) continue;
+						const int fs = m[0].extend_pen(qf, dbf, plusf);
+						if (fs <= 0) continue;
+						const int rs = m[1].extend_pen(seed_q[1][i] & 0x7FFFu, dbr, !plusf);
+						if (rs <= 0) continue;
+						if (fs + rs < termPair) continue;
+						m[0].mapq = 40; m[1].mapq = 40; done = true;
+					}
+				}
+				if (t < nseed[1] && !done) {
+					const uint32_t qr = seed_q[1][t] & 0x7FFFu, dbr = seed_db[1][t];
+					const bool plusr = (seed_q[1][t] & 0x8000u) != 0;
+					const int nf = min(t + 1, nseed[0]);
+					for (int i = 0; i < nf && !done; ++i) {
+						const uint32_t dbf = seed_db[0][i];
+						int64_t d = (int64_t)dbf - (int64_t)dbr;
+						if (d < 0) d = -d;
+						if (d + QL2 > MAX_TL) continue;
+						const int fs = m[0].extend_pen(seed_q[0][i] & 0x7FFFu, dbf, !plusr);
+						if (fs <= 0) continue;
+						const int rs = m[1].extend_pen(qr, dbr, plusr);
+						if (rs <= 0) continue;
+						if (fs + rs < termPair) continue;
+						m[0].mapq = 40; m[1].mapq = 40; done = true;
+					}
+				}
+			}
+		}
+		int npairs_found = 0, bestPairScore = -1, secondPairScore = -1, bestPairIndex = -1;
+		if (!done) {
+			// all collected seeds, each mate (search2m4.cpp:145-158)
+			for (int a = 0; a < 2; ++a)
+				for (int i = 0; i < nseed[a]; ++i)
+					m[a].extend_pen(seed_q[a][i] & 0x7FFFu, seed_db[a][i], (seed_q[a][i] & 0x8000u) != 0);
+			if (m[0].best >= (QLf * 9) / 10 && m[1].best >= (QLr * 9) / 10 && m[0].topHit >= 0 && m[1].topHit >= 0) {
+				int64_t d = (int64_t)rdlane(m[0].hit_db, m[0].topHit) - (int64_t)rdlane(m[1].hit_db, m[1].topHit);
+				if (d < 0) d = -d;
+				if (d + QL2 <= MAX_TL) { m[0].mapq = 40; m[1].mapq = 40; done = true; }
+			}
+		}
+		if (!done) {
+			m[0].search_pending();
+			m[1].search_pending();
+			// FindPairs (state2.cpp:20-85), ScanPair if there is none (state2.cpp:87-137), FindPairs again
+			for (int attempt = 0; attempt < 2; ++attempt) {
+				npairs_found = 0; bestPairScore = -1; secondPairScore = -1; bestPairIndex = -1;
+				for (int i = 0; i < m[0].hitCount; ++i) {
+					const uint32_t spf = rdlane(m[0].hit_sp, i);
+					const int sf = (int)(spf >> 1);
+					if (sf < m[0].second - 12) continue;
+					const int64_t dbf = (int64_t)rdlane(m[0].hit_db, i);
+					for (int j = 0; j < m[1].hitCount; ++j) {
+						const uint32_t spr = rdlane(m[1].hit_sp, j);
+						const int sr = (int)(spr >> 1);
+						if (sr < m[1].second - 12) continue;
+						int64_t d = dbf - (int64_t)rdlane(m[1].hit_db, j);
+						if (d < 0) d = -d;
+						if (d + QL2 > 1000) continue;
+						if ((spf & 1u) == (spr & 1u)) continue;
+						const int total = sf + sr;
+						if (total > bestPairScore) { secondPairScore = bestPairScore; bestPairScore = total; bestPairIndex = npairs_found; }
+						else if (total == bestPairScore) secondPairScore = bestPairScore;
+						else if (total > secondPairScore) secondPairScore = total;
+						if (npairs_found < PE_PAIR_CAP) {
+							if (lane == 0) { pair_f[npairs_found] = (uint16_t)i; pair_r[npairs_found] = (uint16_t)j; }
+						} else
+							m[0].status |= URMAPX_ST_HIT_OVERFLOW;
+						++npairs_found;
+					}
+				}
+				__syncthreads();
+				if (npairs_found > 0 || attempt == 1) break;
+				// ScanPair
+				const bool dovitF = (int)m[0].mapq >= 10, dovitR = (int)m[1].mapq >= 10;
+				const int hcf = m[0].hitCount, hcr = m[1].hitCount;
+				for (int i = 0; i < hcf; ++i) {
+					const uint32_t sp = rdlane(m[0].hit_sp, i);
+					if ((int)(sp >> 1) < m[0].second) continue;
+					const uint32_t db = rdlane(m[0].hit_db, i);
+					if (sp & 1u) m[1].scan(db, PE_SCAN_SEG, false, dovitF);
+					else if (db >= (uint32_t)PE_SCAN_SEG) m[1].scan(db - PE_SCAN_SEG, PE_SCAN_SEG + 2 * (uint32_t)QLf, true, dovitF);
+				}
+				for (int j = 0; j < hcr; ++j) {
+					const uint32_t sp = rdlane(m[1].hit_sp, j);
+					if ((int)(sp >> 1) < m[1].second) continue;
+					const uint32_t db = rdlane(m[1].hit_db, j);
+					if (sp & 1u) m[0].scan(db, PE_SCAN_SEG, false, dovitR);
+					else if (db >= (uint32_t)PE_SCAN_SEG) m[0].scan(db - PE_SCAN_SEG, PE_SCAN_SEG + 2 * (uint32_t)QLf, true, dovitR);
+				}
+			}
+			// AdjustTopHitsAndMapqs (search2.cpp:8-57)
+			if (npairs_found == 0) { m[0].mapq /= 2; m[1].mapq /= 2; }
+			else {
+				const double fract = (double)bestPairScore / (double)(QLf + QLr);
+				double drop = (double)(bestPairScore - secondPairScore);
+				if (drop > 30) drop = 30;
+				double x = drop * fract;
+				x = x * fract;
+				uint32_t mq = (uint32_t)x;
+				if (mq > 40) mq = 40;
+				if (mq > m[0].mapq) m[0].mapq = mq;
+				if (mq > m[1].mapq) m[1].mapq = mq;
+				if (bestPairIndex >= 0 && bestPairIndex < PE_PAIR_CAP) { m[0].topHit = pair_f[bestPairIndex]; m[1].topHit = pair_r[bestPairIndex]; }
+			}
+		}
+
+		// ---- per-mate output: SetMappedPos (state1.cpp:129-145) ----
+		for (int a = 0; a < 2; ++a) {
+			urmapx_result &R = res[a];
+			R.mapq = (uint8_t)(m[a].mapq > 255 ? 255 : m[a].mapq);
+			R.second = (int16_t)m[a].second; R.hit_count = (uint16_t)m[a].hitCount; R.status = (uint8_t)(m[a].status | m[1 - a].status);
+			R.exit_phase = done ? 1 : 2;
+			if (m[a].topHit >= 0) {
+				const uint32_t db = rdlane(m[a].hit_db, m[a].topHit);
+				const uint32_t sp = rdlane(m[a].hit_sp, m[a].topHit);
+				R.score = (int16_t)(sp >> 1);
+				uint32_t lo = 0, hi = X.seqCount - 1;
+				uint32_t found = 0xFFFFFFFFu, coord = 0xFFFFFFFFu, tl = 0;
+				while (lo <= hi && hi != 0xFFFFFFFFu) {
+					uint32_t k = (lo + hi) / 2;
+					uint32_t o = X.seqOffsets[k], sl = X.seqLengths[k];
+					if (db >= o && db < o + sl) { found = k; coord = db - o; tl = sl; break; }
+					if (db > o) lo = k + 1;
+					else hi = k - 1;
+				}
+				if (found != 0xFFFFFFFFu && coord + (uint32_t)m[a].QL <= tl) {
+					R.dbpos = db; R.seq_index = found; R.coord = coord; R.plus = (uint8_t)(sp & 1u);
+					const int nops = m[a].hit_nops[m[a].topHit];
+					if (nops > 0) {
+						uint32_t po = 0;
+						if (lane == 0) po = atomicAdd(path_used, (uint32_t)nops);
+						po = uni(po);
+						for (int t = lane; t < nops; t += 64) path_ops[po + t] = m[a].hit_paths[(size_t)m[a].topHit * URMAPX_MAX_PATH_OPS + t];
+						R.path_off = po; R.path_nops = (uint16_t)nops;
+					}
+				}
+			}
+			if (lane == 0) results[2 * pr + a] = R;
+		}
+	}
+}
+
+static int pe_nch_for(uint32_t max_read_len) { return max_read_len <= 192 ? 3 : (max_read_len <= 320 ? 5 : 0); }
+
+size_t search_pe_scratch_stride(uint32_t max_read_len) {
+	const int qmax = 64 * pe_nch_for(max_read_len);
+	size_t b = (size_t)2 * PE_HIT_CAP * URMAPX_MAX_PATH_OPS * 2 + WideScratch::bytes(qmax, PE_SCAN_SEG + 2 * qmax + 64);
+	return (b + 255) & ~(size_t)255;
+}
+
+int search_pe_block_count(uint32_t max_read_len, int device) {
+	hipDeviceProp_t prop;
+	if (hipGetDeviceProperties(&prop, device) != hipSuccess) return 0;
+	int per_cu = 0;
+	hipError_t e = pe_nch_for(max_read_len) == 3
+	                   ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, search_pe_kernel<3>, 64, 0)
+	                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, search_pe_kernel<5>, 64, 0);
+	if (e != hipSuccess || per_cu < 1) per_cu = 4;
+	return per_cu * prop.multiProcessorCount;
+}
+
+hipError_t launch_search_pe(const DevIndex &X, const urmapx_params &P, const uint8_t *d_bases, const uint64_t *d_offs,
+                            uint32_t npairs, uint32_t max_read_len, ProbeOut probe, urmapx_result *d_results,
+                            urmapx_path_op *d_path_ops, uint32_t *d_path_used, const SearchWork &wk, hipStream_t s) {
+	if (npairs == 0) return hipSuccess;
+	dim3 block(64), grid((unsigned)wk.blocks);
+	if (pe_nch_for(max_read_len) == 3)
+		hipLaunchKernelGGL(search_pe_kernel<3>, grid, block, 0, s, X, P, d_bases, d_offs, npairs, probe, d_results, d_path_ops,
+		                   d_path_used, wk.scratch, wk.scratch_stride, X.seq, X.blob);
+	else
+		hipLaunchKernelGGL(search_pe_kernel<5>, grid, block, 0, s, X, P, d_bases, d_offs, npairs, probe, d_results, d_path_ops,
+		                   d_path_used, wk.scratch, wk.scratch_stride, X.seq, X.blob);
+	return hipGetLastError();
+}
+
+}  // namespace urx

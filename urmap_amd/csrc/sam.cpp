@@ -241,3 +241,47 @@ extern "C" size_t urmapx_sam_header_sq(const urmapx_index *I, char *buf, size_t 
 	memcpy(buf, out.data(), out.size());
 	return out.size();
 }
+
+static uint32_t paired_flags(bool first, bool revcomp, bool mate_revcomp, bool mate_unmapped) {  // output2.cpp:18-36
+	uint32_t f = first ? 0x41u : 0x81u;
+	if (revcomp) f |= 0x10u;
+	if (mate_unmapped) f |= 0x08u;
+	else if (mate_revcomp) f |= 0x20u;
+	return f;
+}
+
+extern "C" size_t urmapx_sam_pe(const urmapx_index *I, const urmapx_result *r1, const urmapx_result *r2,
+                                const urmapx_path_op *path_ops, const char *label1, const uint8_t *seq1,
+                                const uint8_t *qual1, uint32_t len1, const char *label2, const uint8_t *seq2,
+                                const uint8_t *qual2, uint32_t len2, char *buf, size_t cap) {
+	// SetSAM2, output2.cpp:61-128 (positions compared are coordinates inside the sequences, as the reference does)
+	const bool m1 = r1->dbpos != 0xFFFFFFFFu, m2 = r2->dbpos != 0xFFFFFFFFu;
+	const bool plus1 = m1 && r1->plus, plus2 = m2 && r2->plus;
+	const bool consistent = m1 && m2 && (plus1 != plus2);
+	int tlen1 = 0, tlen2 = 0;
+	bool proper = false;
+	if (m1 && m2) {
+		if (r1->coord <= r2->coord) {
+			tlen1 = (int)(r2->coord + len2) - (int)r1->coord;
+			if (tlen1 > 0 && tlen1 < 1000 && consistent) proper = true;
+			if (tlen1 > 1000) tlen1 = 0;
+			tlen2 = -tlen1;
+		} else {
+			tlen2 = (int)(r1->coord + len1) - (int)r2->coord;
+			if (tlen2 > 0 && tlen2 < 1000 && consistent) proper = true;
+			if (tlen2 > 1000) tlen2 = 0;
+			tlen1 = -tlen2;
+		}
+	}
+	const bool rc1 = m1 && !r1->plus, rc2 = m2 && !r2->plus;
+	uint32_t f1 = paired_flags(true, rc1, rc2, !m2), f2 = paired_flags(false, rc2, rc1, !m1);
+	if (proper) { f1 |= 2u; f2 |= 2u; }
+	const char *l1 = m1 ? urmapx_index_label(I, r1->seq_index) : "";
+	const char *l2 = m2 ? urmapx_index_label(I, r2->seq_index) : "";
+	std::string out;
+	urx::append_sam_record(out, I, *r1, path_ops, f1, l2, m2 ? r2->coord : 0xFFFFFFFFu, tlen1, label1, seq1, qual1, len1);
+	urx::append_sam_record(out, I, *r2, path_ops, f2, l1, m1 ? r1->coord : 0xFFFFFFFFu, tlen2, label2, seq2, qual2, len2);
+	if (out.size() > cap) return 0;
+	memcpy(buf, out.data(), out.size());
+	return out.size();
+}

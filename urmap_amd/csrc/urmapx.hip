@@ -96,6 +96,8 @@ struct urmapx_ctx {
 	DevBuf<uint16_t> vnops;
 	DevBuf<uint8_t> scratch, vscratch;
 	DevBuf<uint32_t> ticket;
+	DevBuf<uint8_t> pe_scratch;
+	int pe_blocks[2] = {0, 0};
 	int blocks[2] = {0, 0};  // persistent grid size of the search kernel for read length classes <=192, <=320
 };
 
@@ -272,7 +274,7 @@ void urmapx_ctx_destroy(urmapx_ctx *C) {
 	C->bases.release(); C->tallies.release(); C->vflags.release(); C->vstatus.release(); C->va.release(); C->vb.release();
 	C->offs.release(); C->slots.release(); C->positions.release(); C->used.release(); C->vaoffs.release(); C->vboffs.release();
 	C->results.release(); C->pathops.release(); C->vops.release(); C->vscores.release(); C->vnops.release();
-	C->scratch.release(); C->vscratch.release(); C->ticket.release();
+	C->scratch.release(); C->vscratch.release(); C->ticket.release(); C->pe_scratch.release();
 	for (int i = 0; i < 3; ++i)
 		if (C->ev[i]) (void)hipEventDestroy(C->ev[i]);
 	if (C->stream) (void)hipStreamDestroy(C->stream);
@@ -368,6 +370,60 @@ int urmapx_map_se(urmapx_ctx *C, const uint8_t *bases, const uint64_t *offs, uin
 	HIP_TRY(hipMemcpyAsync(C->offs.p, offs, ((size_t)n + 1) * 8, hipMemcpyHostToDevice, C->stream));
 	rc = urmapx_map_se_device(C, C->bases.p, C->offs.p, n, total, mx, C->results.p, C->pathops.p, C->used.p);
 	if (rc) return rc;
+	uint32_t used = 0;
+	HIP_TRY(hipMemcpyAsync(results, C->results.p, (size_t)n * sizeof(urmapx_result), hipMemcpyDeviceToHost, C->stream));
+	HIP_TRY(hipMemcpyAsync(&used, C->used.p, 4, hipMemcpyDeviceToHost, C->stream));
+	HIP_TRY(hipStreamSynchronize(C->stream));
+	if (used > path_cap || (used && !path_ops)) return URMAPX_E_ARG;
+	if (used) HIP_TRY(hipMemcpy(path_ops, C->pathops.p, (size_t)used * sizeof(urmapx_path_op), hipMemcpyDeviceToHost));
+	if (path_used) *path_used = used;
+	for (uint32_t i = 0; i < n; ++i)
+		if (results[i].status) return URMAPX_E_UNSUPPORTED;
+	return URMAPX_OK;
+}
+
+// State2::Search (search2.cpp:59-73, method 4) over a batch of read pairs held in HOST memory: reads 2i and 2i+1 are
+// the mates of pair i.  results[2*npairs].
+int urmapx_map_pe(urmapx_ctx *C, const uint8_t *bases, const uint64_t *offs, uint32_t npairs, urmapx_result *results,
+                  urmapx_path_op *path_ops, size_t path_cap, size_t *path_used) {
+	if (!C || (npairs && (!bases || !offs || !results))) return URMAPX_E_ARG;
+	if (path_used) *path_used = 0;
+	if (npairs == 0) return URMAPX_OK;
+	if (npairs > 0x7FFFFFFFu) return URMAPX_E_ARG;
+	HIP_TRY(hipSetDevice(C->device));
+	const uint32_t n = 2 * npairs;
+	const uint64_t total = offs[n];
+	uint32_t mx = max_len(offs, n);
+	if (mx > URMAPX_MAX_QL) mx = URMAPX_MAX_QL;
+	int rc;
+	if ((rc = C->bases.ensure(total + 64))) return rc;
+	if ((rc = C->offs.ensure((size_t)n + 1))) return rc;
+	if ((rc = C->results.ensure(n))) return rc;
+	if ((rc = C->pathops.ensure((size_t)n * URMAPX_MAX_PATH_OPS))) return rc;
+	if ((rc = C->used.ensure(1))) return rc;
+	if ((rc = ensure_probe(C, total))) return rc;
+	const int cls = mx <= 192 ? 0 : 1;
+	if (C->pe_blocks[cls] == 0) C->pe_blocks[cls] = search_pe_block_count(mx, C->device);
+	if (C->pe_blocks[cls] <= 0) return URMAPX_E_NODEVICE;
+	SearchWork wk;
+	wk.blocks = C->pe_blocks[cls];
+	wk.scratch_stride = search_pe_scratch_stride(mx);
+	if ((rc = C->pe_scratch.ensure(wk.scratch_stride * (size_t)wk.blocks))) return rc;
+	wk.scratch = C->pe_scratch.p;
+	wk.ticket = nullptr;
+	HIP_TRY(hipMemcpyAsync(C->bases.p, bases, total, hipMemcpyHostToDevice, C->stream));
+	HIP_TRY(hipMemcpyAsync(C->offs.p, offs, ((size_t)n + 1) * 8, hipMemcpyHostToDevice, C->stream));
+	HIP_TRY(hipMemsetAsync(C->used.p, 0, 4, C->stream));
+	ProbeOut po{C->slots.p, C->tallies.p, C->positions.p};
+	// positions the probe kernel does not write (qpos > L-W) must read as "no k-mer"
+	HIP_TRY(hipMemsetAsync(C->tallies.p, 0, 2 * total, C->stream));
+	HIP_TRY(hipEventRecord(C->ev[0], C->stream));
+	HIP_TRY(launch_seed_probe(C->X, C->bases.p, C->offs.p, n, mx, po, C->stream));
+	HIP_TRY(hipEventRecord(C->ev[1], C->stream));
+	HIP_TRY(launch_search_pe(C->X, C->params, C->bases.p, C->offs.p, npairs, mx, po, C->results.p, C->pathops.p, C->used.p,
+	                         wk, C->stream));
+	HIP_TRY(hipEventRecord(C->ev[2], C->stream));
+	C->ev_valid = true;
 	uint32_t used = 0;
 	HIP_TRY(hipMemcpyAsync(results, C->results.p, (size_t)n * sizeof(urmapx_result), hipMemcpyDeviceToHost, C->stream));
 	HIP_TRY(hipMemcpyAsync(&used, C->used.p, 4, hipMemcpyDeviceToHost, C->stream));

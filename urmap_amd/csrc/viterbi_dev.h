@@ -143,7 +143,9 @@ __device__ float viterbi_wave(const urmapx_params &P, const uint8_t *A, int LA, 
 		const float v = validf ? (Mlast + GapOp) : NEG;
 		const float u = v - GapEx * flane;
 		const float Pm = wave_prefix_max(u);
-		const float Ibefore = (lane == 0) ? NEG : (wave_shr1(Pm, NEG) + GapEx * (flane - 1.0f));
+		// cross-lane ops stay outside any lane-dependent select: a DPP read from a lane masked off by EXEC returns the
+		// fill value, not that lane's register.  Lane 0 gets NEG from the shift itself (and NEG absorbs the addend).
+		const float Ibefore = wave_shr1(Pm, NEG) + GapEx * (flane - 1.0f);
 		const float Ie = Ibefore + GapEx;
 		uint32_t bits = (validf && v > Ie) ? TB_MI : 0u;
 		const float Iafter = fmaxf(v, Ie);
@@ -281,7 +283,7 @@ __device__ float viterbi_wide(const urmapx_params &P, const uint8_t *A, int LA, 
 			const float v = act ? (mprev + GapOp) : NEG;
 			const float u = v - GapEx * flane;
 			const float Pm = wave_prefix_max(u);
-			const float Ichain = (lane == 0) ? NEG : (wave_shr1(Pm, NEG) + GapEx * (flane - 1.0f));
+			const float Ichain = wave_shr1(Pm, NEG) + GapEx * (flane - 1.0f);  // unconditional: see viterbi_wave
 			const float Ibefore = fmaxf(Ichain, carry + GapEx * flane);
 			const float Ie = Ibefore + GapEx;
 			const float Iafter = fmaxf(v, Ie);
