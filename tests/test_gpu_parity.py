@@ -307,3 +307,24 @@ def test_pe_matches_oracle(small_case, tmp_path, rl, s1, s2, indel, n):
         g, w = got.split(b"\n"), want.split(b"\n")
         bad = [i for i in range(min(len(g), len(w))) if g[i] != w[i]]
         raise AssertionError(f"{len(bad)} differing records of {len(w)}, first: {g[bad[0]][:200]!r} vs {w[bad[0]][:200]!r}")
+
+
+@pytest.mark.parametrize("name", ["pe150", "pe100_noisy"])
+def test_cli_map2_reproduces_reference_sam(tmp_path, name):
+    """`urmap -map2 R1 -reverse R2 -ufi UFI -samout SAM` (map2.cpp:39-90) vs the reference's golden SAM."""
+    import gzip
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gold = os.path.join(root, "tests", "golden")
+    exe = os.path.join(root, "urmap_amd", "urmap")
+    ufi = os.path.join(tmp_path, "g.ufi")
+    with gzip.open(os.path.join(gold, "g.ufi.gz"), "rb") as z, open(ufi, "wb") as f:
+        f.write(z.read())
+    out = os.path.join(tmp_path, "out.sam")
+    r = subprocess.run([exe, "-map2", os.path.join(gold, name + "_1.fq"), "-reverse", os.path.join(gold, name + "_2.fq"),
+                        "-ufi", ufi, "-samout", out, "-batch", "100"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    got = [l for l in open(out, "rb").read().split(b"\n") if l and not l.startswith(b"@PG")]
+    want = [l for l in open(os.path.join(gold, name + ".sam"), "rb").read().split(b"\n") if l]
+    assert got == want

@@ -4,6 +4,8 @@
 //   urmap -map reads.fq[.gz] -ufi index.ufi -samout out.sam [-veryfast] [-threads N] [-gpu D] [-batch N]
 //   urmap -make_ufi genome.fa -output index.ufi -slots N [-wordlength W] [-maxix M] [-veryfast]
 //
+//   urmap -map2 R1.fq -reverse R2.fq -ufi index.ufi -samout out.sam            (paired-end, map2.cpp:39-90)
+//
 // Pipeline of -map: one reader thread parses FASTQ into batches, the main thread maps batch k on the GPU while
 // a writer thread formats and writes the SAM of batch k-1.  Records are written in input order (the reference's
 // order is nondeterministic with more than one thread).  Errors: message on stderr, exit status 1
@@ -37,7 +39,7 @@ using namespace urx;
 }
 
 struct Opts {
-	std::string map, make_ufi, ufi, samout, output;
+	std::string map, map2, reverse, make_ufi, ufi, samout, output;
 	bool veryfast = false, quiet = false;
 	unsigned threads = 0, wordlength = 24, maxix = 0, minq = 10;
 	unsigned long long slots = 0;
@@ -55,6 +57,8 @@ static Opts parse(int argc, char **argv) {
 			return argv[++i];
 		};
 		if (a == "-map") o.map = val();
+		else if (a == "-map2") o.map2 = val();
+		else if (a == "-reverse") o.reverse = val();
 		else if (a == "-make_ufi") o.make_ufi = val();
 		else if (a == "-ufi") o.ufi = val();
 		else if (a == "-samout") o.samout = val();
@@ -117,7 +121,14 @@ private:
 	bool closed_ = false;
 };
 
+extern "C" size_t urmapx_sam_pe(const urmapx_index *, const urmapx_result *, const urmapx_result *, const urmapx_path_op *,
+                                const char *, const uint8_t *, const uint8_t *, uint32_t, const char *, const uint8_t *,
+                                const uint8_t *, uint32_t, char *, size_t);
+
 static int cmd_map(const Opts &o, int argc, char **argv) {
+	const bool paired = !o.map2.empty();
+	if (paired && o.reverse.empty()) die("-reverse required");
+	if (paired && o.veryfast) die("-map2 -veryfast (Search5) is not available in this build");
 	if (o.ufi.empty()) die("-ufi option required");
 	const auto t0 = std::chrono::steady_clock::now();
 	urmapx_index *I = nullptr;
@@ -136,9 +147,10 @@ static int cmd_map(const Opts &o, int argc, char **argv) {
 		append_sam_header(hdr, I, argc, argv);
 		fwrite(hdr.data(), 1, hdr.size(), fsam);
 	}
-	FastqReader rd;
+	FastqReader rd, rd2;
 	std::string err;
-	if (!rd.open(o.map, err)) die("%s", err.c_str());
+	if (!rd.open(paired ? o.map2 : o.map, err)) die("%s", err.c_str());
+	if (paired && !rd2.open(o.reverse, err)) die("%s", err.c_str());
 	const auto t1 = std::chrono::steady_clock::now();
 
 	Channel<std::unique_ptr<Job>> parsed(3), mapped(3);
@@ -148,7 +160,26 @@ static int cmd_map(const Opts &o, int argc, char **argv) {
 			auto j = std::make_unique<Job>();
 			j->reads.clear();
 			std::string e;
-			bool more = rd.next_batch(j->reads, o.batch, e);
+			bool more;
+			if (!paired)
+				more = rd.next_batch(j->reads, o.batch, e);
+			else {  // mates interleaved: reads 2i, 2i+1 (map2.cpp:27-32 reads one record from each file under one lock)
+				FastqBatch a, b;
+				a.clear(); b.clear();
+				more = rd.next_batch(a, o.batch / 2, e);
+				std::string e2;
+				bool more2 = rd2.next_batch(b, o.batch / 2, e2);
+				if (e.empty()) e = e2;
+				if (e.empty() && (more != more2 || a.size() != b.size())) e = std::string("Premature end of file in FASTQ") + (a.size() > b.size() ? "2" : "1");
+				for (uint32_t i = 0; e.empty() && i < a.size(); ++i) {
+					for (const FastqBatch *src : {&a, &b}) {
+						j->reads.labels.push_back(src->labels[i]);
+						j->reads.bases.insert(j->reads.bases.end(), src->bases.begin() + (ptrdiff_t)src->offs[i], src->bases.begin() + (ptrdiff_t)src->offs[i + 1]);
+						j->reads.quals.insert(j->reads.quals.end(), src->quals.begin() + (ptrdiff_t)src->offs[i], src->quals.begin() + (ptrdiff_t)src->offs[i + 1]);
+						j->reads.offs.push_back(j->reads.bases.size());
+					}
+				}
+			}
 			if (!e.empty()) { reader_err = e; break; }
 			if (!more) break;
 			parsed.push(std::move(j));
@@ -162,13 +193,24 @@ static int cmd_map(const Opts &o, int argc, char **argv) {
 		while (mapped.pop(j)) {
 			out.clear();
 			const uint32_t n = j->reads.size();
+			std::vector<char> pbuf;
 			for (uint32_t i = 0; i < n; ++i) {
 				const urmapx_result &r = j->results[i];
 				const uint64_t off = j->reads.offs[i];
 				const unsigned L = (unsigned)(j->reads.offs[i + 1] - off);
-				if (fsam)
+				if (fsam && !paired)
 					append_sam_record(out, I, r, j->ops.data(), 0, "*", 0xFFFFFFFFu, 0, j->reads.labels[i].c_str(),
 					                  j->reads.bases.data() + off, j->reads.quals.data() + off, L);
+				if (fsam && paired && (i & 1) == 0) {
+					const uint64_t off2 = j->reads.offs[i + 1];
+					const unsigned L2 = (unsigned)(j->reads.offs[i + 2] - off2);
+					pbuf.resize(j->reads.labels[i].size() + j->reads.labels[i + 1].size() + 3 * (size_t)(L + L2) + 2048);
+					size_t k = urmapx_sam_pe(I, &j->results[i], &j->results[i + 1], j->ops.data(), j->reads.labels[i].c_str(),
+					                         j->reads.bases.data() + off, j->reads.quals.data() + off, L,
+					                         j->reads.labels[i + 1].c_str(), j->reads.bases.data() + off2,
+					                         j->reads.quals.data() + off2, L2, pbuf.data(), pbuf.size());
+					out.append(pbuf.data(), k);
+				}
 				// HitStats counters (output1.cpp:20-30)
 				if (r.status) ++n_unsupported;
 				if (r.dbpos == 0xFFFFFFFFu) ++n_nohit;
@@ -185,9 +227,11 @@ static int cmd_map(const Opts &o, int argc, char **argv) {
 		j->results.resize(n);
 		j->ops.resize((size_t)n * URMAPX_MAX_PATH_OPS);
 		size_t used = 0;
-		int rc = urmapx_map_se(C, j->reads.bases.data(), j->reads.offs.data(), n, j->results.data(), j->ops.data(),
-		                       j->ops.size(), &used);
-		check(rc, "urmapx_map_se");
+		int rc = paired ? urmapx_map_pe(C, j->reads.bases.data(), j->reads.offs.data(), n / 2, j->results.data(), j->ops.data(),
+		                                j->ops.size(), &used)
+		                : urmapx_map_se(C, j->reads.bases.data(), j->reads.offs.data(), n, j->results.data(), j->ops.data(),
+		                                j->ops.size(), &used);
+		check(rc, paired ? "urmapx_map_pe" : "urmapx_map_se");
 		mapped.push(std::move(j));
 	}
 	mapped.close();
@@ -223,9 +267,10 @@ static int cmd_make_ufi(const Opts &o) {
 
 int main(int argc, char **argv) {
 	Opts o = parse(argc, argv);
-	if (!o.map.empty()) return cmd_map(o, argc, argv);
+	if (!o.map.empty() || !o.map2.empty()) return cmd_map(o, argc, argv);
 	if (!o.make_ufi.empty()) return cmd_make_ufi(o);
 	fprintf(stderr, "urmap (MI355X build)\n  urmap -map reads.fq -ufi index.ufi -samout out.sam [-veryfast] [-gpu D]\n"
+	                "  urmap -map2 R1.fq -reverse R2.fq -ufi index.ufi -samout out.sam [-gpu D]\n"
 	                "  urmap -make_ufi genome.fa -output index.ufi -slots N [-wordlength W] [-maxix M]\n");
 	return 0;
 }
