@@ -35,6 +35,7 @@ def parse_args():
     ap.add_argument("--indel", type=float, default=0.001)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", choices=("se", "pe"), default="se", help="pe: 2x150 read pairs through State2::Search4 (config 3; not the headline metric)")
     return ap.parse_args()
 
 
@@ -159,6 +160,37 @@ def make_reads_torch(torch, seed, d_seq, seq_lengths, seq_offsets, n, L, sub, in
     return reads.reshape(-1).contiguous()
 
 
+def make_pairs_torch(torch, seed, d_seq, seq_lengths, seq_offsets, npairs, L, sub1, sub2, device):
+    """npairs FR pairs (insert ~ N(300, 50) clipped to [L+20, 600]), mates interleaved: uint8 tensor [2*npairs*L]."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    ns = len(seq_lengths)
+    si = torch.randint(0, ns, (npairs,), generator=g, device=device)
+    lens = torch.tensor(seq_lengths.astype(np.int64), device=device)[si]
+    offs = torch.tensor(seq_offsets.astype(np.int64), device=device)[si]
+    ins = (300 + 50 * torch.randn(npairs, generator=g, device=device)).long().clamp(L + 20, 600)
+    start = offs + (torch.rand(npairs, generator=g, device=device, dtype=torch.float64) * (lens - 700).clamp(min=1).double()).long()
+    ar = torch.arange(L, device=device)
+    a = d_seq[(start[:, None] + ar[None, :]).reshape(-1)].reshape(npairs, L)
+    b = d_seq[((start + ins - L)[:, None] + ar[None, :]).reshape(-1)].reshape(npairs, L)
+    acgt = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=device)
+    comp = torch.full((256,), ord("N"), dtype=torch.uint8, device=device)
+    for x, y in zip(b"ACGTN", b"TGCAN"):
+        comp[x] = y
+
+    def mutate(r, sub):
+        rnd = acgt[torch.randint(0, 4, r.shape, generator=g, device=device)]
+        m = torch.rand(r.shape, generator=g, device=device) < sub
+        isbase = (r == 65) | (r == 67) | (r == 71) | (r == 84)
+        return torch.where(m & isbase, rnd, r)
+    a = mutate(a, sub1)
+    b = comp[mutate(b, sub2).flip(1).long()]
+    swap = torch.rand(npairs, generator=g, device=device) < 0.5
+    r1 = torch.where(swap[:, None], b, a)
+    r2 = torch.where(swap[:, None], a, b)
+    return torch.stack([r1, r2], dim=1).reshape(-1).contiguous()
+
+
 def pmc_traffic(kernel, reads_per_launch, total_bp):
     """HBM read bytes per launch of `kernel` from the committed rocprofv3 --pmc FETCH_SIZE pass of this same
     workload (profiles/r1/pmc_fetch_hg38scale_*.json; bench.py cannot collect PMCs itself).  None when no
@@ -237,9 +269,14 @@ def main():
     n_batches = min(args.steps + args.warmup, 10)
     batches = []
     d_offs = (torch.arange(nb + 1, device=device, dtype=torch.int64) * L).contiguous()
+    pe = args.mode == "pe"
     for b in range(n_batches):
-        batches.append(make_reads_torch(torch, 1000 + 97 * rank + b, d_seq, seq_lengths, seq_offsets, nb, L, args.sub,
-                                        args.indel, device))
+        if pe:
+            batches.append(make_pairs_torch(torch, 1000 + 97 * rank + b, d_seq, seq_lengths, seq_offsets, nb // 2, L,
+                                            args.sub, 1.5 * args.sub, device))
+        else:
+            batches.append(make_reads_torch(torch, 1000 + 97 * rank + b, d_seq, seq_lengths, seq_offsets, nb, L, args.sub,
+                                            args.indel, device))
     d_results = torch.zeros(nb * api.RESULT_DTYPE.itemsize, dtype=torch.uint8, device=device)
     d_pathops = torch.zeros(nb * api.MAX_PATH_OPS, dtype=torch.int16, device=device)
     d_used = torch.zeros(1, dtype=torch.int32, device=device)
@@ -247,8 +284,12 @@ def main():
     setup_s = time.time() - t_setup
 
     def step(b):
-        mapper.map_se_device(batches[b % n_batches].data_ptr(), d_offs.data_ptr(), nb, nb * L, L,
-                             d_results.data_ptr(), d_pathops.data_ptr(), d_used.data_ptr())
+        if pe:
+            mapper.map_pe_device(batches[b % n_batches].data_ptr(), d_offs.data_ptr(), nb // 2, nb * L, L,
+                                 d_results.data_ptr(), d_pathops.data_ptr(), d_used.data_ptr())
+        else:
+            mapper.map_se_device(batches[b % n_batches].data_ptr(), d_offs.data_ptr(), nb, nb * L, L,
+                                 d_results.data_ptr(), d_pathops.data_ptr(), d_used.data_ptr())
 
     for w in range(args.warmup):
         step(w)
@@ -299,15 +340,16 @@ def main():
         hb = last[: probe_n * L].cpu().numpy()
         ho = (np.arange(probe_n + 1, dtype=np.uint64) * L)
         t1 = time.perf_counter()
-        ores, opaths, cnt = oi.map_se(hb, ho, threads=cores)
+        omap = (lambda bb, oo: oi.map_pe(bb, oo, threads=cores)) if pe else (lambda bb, oo: oi.map_se(bb, oo, threads=cores))
+        ores, opaths, cnt = omap(hb, ho)
         t_probe = time.perf_counter() - t1
         sample_n = probe_n
         if world == 1 and not args.no_cpu_baseline:
-            sample_n = int(min(nb, max(probe_n, probe_n * args.cpu_seconds / max(t_probe, 1e-3))))
+            sample_n = int(min(nb, max(probe_n, probe_n * args.cpu_seconds / max(t_probe, 1e-3)))) & ~1
             hb = last[: sample_n * L].cpu().numpy()
             ho = (np.arange(sample_n + 1, dtype=np.uint64) * L)
             t1 = time.perf_counter()
-            ores, opaths, cnt = oi.map_se(hb, ho, threads=cores)
+            ores, opaths, cnt = omap(hb, ho)
             t_cpu = time.perf_counter() - t1
             cpu = {"value": round(sample_n / t_cpu, 1), "unit": "reads/s", "cores": cores, "kind": "port",
                    "sample": f"first {sample_n} reads of the last timed batch, same index, oracle/liburmap_oracle.so "
@@ -334,7 +376,7 @@ def main():
         c = counters
         alg_probe = 5.0 * c["n_getblob"] + L
         alg_search = 5.0 * c["n_rowhop"] + c["n_extbases"] + c["n_dptarget"] + api.RESULT_DTYPE.itemsize
-        names = ("seed_probe_kernel", "search_se_kernel")
+        names = ("seed_probe_kernel", "search_pe_kernel" if pe else "search_se_kernel")
         algs = (alg_probe, alg_search)
         dom = int(np.argmax(kms))
         kern = []
@@ -343,7 +385,8 @@ def main():
             kern.append({"kernel": names[i], "avg_ms": round(float(kms[i]), 4), "alg_bytes_per_read": round(algs[i], 1),
                          "achieved_GBs": round(ach, 2), "frac": round(ach / HBM_PEAK_GBS, 5)})
         out = {
-            "metric": "reads/s mapped, 150 bp SE, index resident in HBM, SAM fields bit-identical",
+            "metric": ("reads/s mapped, 2x150 bp PE (-map2), index resident in HBM, SAM fields bit-identical" if pe else
+                       "reads/s mapped, 150 bp SE, index resident in HBM, SAM fields bit-identical"),
             "value": round(reads_per_s, 1),
             "unit": "reads/s",
             "n_gpus": world,
@@ -355,7 +398,7 @@ def main():
             "vs_baseline": None,
             "dtype": "u8/u64 (fp32 DP cells as the reference)",
             "data": "synthetic",
-            "config": {"workload": f"{L} bp SE reads vs synthetic hg38-shaped {args.genome_mbp:g} Mbp genome "
+            "config": {"workload": f"{L} bp {'PE mates (pairs interleaved)' if pe else 'SE reads'} vs synthetic hg38-shaped {args.genome_mbp:g} Mbp genome "
                                    f"({slots} slots, {5 * slots / 1e9:.2f} GB slot table + {len(seq_np) / 1e9:.2f} GB sequence "
                                    f"resident in HBM); {nb} reads/step, {args.sub:g} sub, {args.indel:g} indel",
                        "reads_per_step": nb, "read_len": L, "genome_bp": int(len(seq_np)), "slots": int(slots),

@@ -131,6 +131,9 @@ int urmapx_map_pe(urmapx_ctx *, const uint8_t *bases, const uint64_t *offs, uint
  * Asynchronous on the ctx stream; urmapx_ctx_sync() waits. total_bases = offs[n]. */
 int urmapx_map_se_device(urmapx_ctx *, const void *d_bases, const void *d_offs, uint32_t n, uint64_t total_bases,
                          uint32_t max_read_len, void *d_results, void *d_path_ops, void *d_path_used);
+/* Paired form of urmapx_map_se_device: 2*npairs reads resident in HBM, mates interleaved. */
+int urmapx_map_pe_device(urmapx_ctx *, const void *d_bases, const void *d_offs, uint32_t npairs, uint64_t total_bases,
+                         uint32_t max_read_len, void *d_results, void *d_path_ops, void *d_path_used);
 int urmapx_ctx_sync(urmapx_ctx *);
 /* Device time (ms, HIP events on the ctx stream) of the two kernels in the most recent *_device call that has
  * completed: [0] seed+probe, [1] search/extend. */

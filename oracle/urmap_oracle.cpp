@@ -1595,6 +1595,54 @@ static void MateMapped(Searcher &S, MateOut &M) {  // SetMappedPos, state1.cpp:1
 }
 }  // namespace
 
+// In-memory paired-end batch: reads 2i, 2i+1 are the mates of pair i.  results[2*npairs] carry, per mate, the hit
+// State2 settled on after SetMappedPos (score = that hit's score, second = m_SecondBestScore, mapq = m_Mapq).
+extern "C" int uo_map_pe(const uo_index *X, const uo_params *P, const uint8_t *bases, const uint64_t *offs, uint32_t npairs,
+                         int threads, uo_result *results, char **path_arena, uo_counters *counters) {
+	if (threads < 1) threads = 1;
+	std::vector<std::string> Paths((size_t)2 * npairs);
+	if (counters) memset(counters, 0, sizeof *counters);
+#pragma omp parallel num_threads(threads)
+	{
+		PairSearcher S(X, *P);
+#pragma omp for schedule(dynamic, 64)
+		for (int64_t i = 0; i < (int64_t)npairs; ++i) {
+			const uint64_t o0 = offs[2 * i], o1 = offs[2 * i + 1], o2 = offs[2 * i + 2];
+			S.Search4(bases + o0, unsigned(o1 - o0), bases + o1, unsigned(o2 - o1));
+			Searcher *M[2] = {&S.F, &S.R};
+			for (int a = 0; a < 2; ++a) {
+				MateOut mo;
+				MateMapped(*M[a], mo);
+				uo_result &R = results[2 * i + a];
+				memset(&R, 0, sizeof R);
+				R.dbpos = UINT32_MAX; R.seq_index = UINT32_MAX; R.coord = UINT32_MAX;
+				R.second = M[a]->SecondBestScore; R.mapq = M[a]->Mapq; R.hit_count = M[a]->HitCount; R.hsp_count = M[a]->HSPCount;
+				if (M[a]->TopHit >= 0) R.score = M[a]->Hits[M[a]->TopHit].Score;
+				if (mo.Mapped) {
+					R.dbpos = M[a]->Hits[M[a]->TopHit].DBStartPos; R.seq_index = mo.SeqIndex; R.coord = mo.Coord; R.plus = mo.Plus;
+					Paths[2 * i + a] = mo.Path;
+					R.path_len = (uint16_t)mo.Path.size();
+				}
+			}
+		}
+#pragma omp critical
+		{ AddCounters(counters, S.F.C); AddCounters(counters, S.R.C); }
+	}
+	size_t total = 1;
+	for (auto &p : Paths) total += p.size() + 1;
+	char *arena = (char *)malloc(total);
+	if (!arena) return -1;
+	size_t off = 0;
+	for (size_t i = 0; i < Paths.size(); ++i) {
+		results[i].path_off = (uint32_t)off;
+		memcpy(arena + off, Paths[i].c_str(), Paths[i].size() + 1);
+		off += Paths[i].size() + 1;
+	}
+	if (path_arena) *path_arena = arena;
+	else free(arena);
+	return 0;
+}
+
 static uint32_t PairedFlags(bool First, bool RevComp, bool MateRevComp, bool MateUnmapped) {  // output2.cpp:18-36
 	uint32_t f = First ? 0x41 : 0x81;
 	if (RevComp) f |= 0x10;

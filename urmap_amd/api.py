@@ -30,7 +30,7 @@ EXPORTS = (
     "urmapx_index_seq_length", "urmapx_index_seq_offset", "urmapx_ctx_create", "urmapx_ctx_destroy",
     "urmapx_map_se", "urmapx_map_se_device", "urmapx_ctx_sync", "urmapx_ctx_last_kernel_ms",
     "urmapx_seed_probe", "urmapx_viterbi_batch", "urmapx_strerror", "urmapx_device_arch",
-    "urmapx_make_ufi", "urmapx_build_slots", "urmapx_sam_se", "urmapx_sam_header_sq", "urmapx_ctx_phase_cycles", "urmapx_map_pe", "urmapx_sam_pe",
+    "urmapx_make_ufi", "urmapx_build_slots", "urmapx_sam_se", "urmapx_sam_header_sq", "urmapx_ctx_phase_cycles", "urmapx_map_pe", "urmapx_sam_pe", "urmapx_map_pe_device",
 )
 
 
@@ -86,6 +86,7 @@ def lib():
     L.urmapx_sam_pe.restype = C.c_size_t
     L.urmapx_sam_pe.argtypes = [vp, vp, vp, vp, cp, vp, vp, u32, cp, vp, vp, u32, vp, C.c_size_t]
     L.urmapx_map_se_device.argtypes = [vp, vp, vp, u32, u64, u32, vp, vp, vp]
+    L.urmapx_map_pe_device.argtypes = [vp, vp, vp, u32, u64, u32, vp, vp, vp]
     L.urmapx_ctx_sync.argtypes = [vp]
     L.urmapx_ctx_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float * 2)]
     L.urmapx_ctx_phase_cycles.argtypes = [vp, C.POINTER(C.c_uint64 * 12)]
@@ -304,6 +305,11 @@ class Mapper:
                       d_path_used_ptr):
         _check(lib().urmapx_map_se_device(self.h, d_bases_ptr, d_offs_ptr, n, total_bases, max_read_len,
                                           d_results_ptr, d_path_ops_ptr, d_path_used_ptr), "urmapx_map_se_device")
+
+    def map_pe_device(self, d_bases_ptr, d_offs_ptr, npairs, total_bases, max_read_len, d_results_ptr, d_path_ops_ptr,
+                      d_path_used_ptr):
+        _check(lib().urmapx_map_pe_device(self.h, d_bases_ptr, d_offs_ptr, npairs, total_bases, max_read_len,
+                                          d_results_ptr, d_path_ops_ptr, d_path_used_ptr), "urmapx_map_pe_device")
 
     def sync(self):
         _check(lib().urmapx_ctx_sync(self.h), "urmapx_ctx_sync")

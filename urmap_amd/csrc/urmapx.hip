@@ -382,6 +382,38 @@ int urmapx_map_se(urmapx_ctx *C, const uint8_t *bases, const uint64_t *offs, uin
 	return URMAPX_OK;
 }
 
+// State2::Search over pairs already resident in HBM (reads 2i, 2i+1 = mates of pair i); asynchronous on the ctx stream.
+int urmapx_map_pe_device(urmapx_ctx *C, const void *d_bases, const void *d_offs, uint32_t npairs, uint64_t total_bases,
+                         uint32_t max_read_len, void *d_results, void *d_path_ops, void *d_path_used) {
+	if (!C || (npairs && (!d_bases || !d_offs || !d_results || !d_path_ops || !d_path_used))) return URMAPX_E_ARG;
+	if (max_read_len > URMAPX_MAX_QL || npairs > 0x7FFFFFFFu) return URMAPX_E_UNSUPPORTED;
+	HIP_TRY(hipSetDevice(C->device));
+	const uint32_t n = 2 * npairs;
+	int rc = ensure_probe(C, total_bases);
+	if (rc) return rc;
+	const int cls = max_read_len <= 192 ? 0 : 1;
+	if (C->pe_blocks[cls] == 0) C->pe_blocks[cls] = search_pe_block_count(max_read_len, C->device);
+	if (C->pe_blocks[cls] <= 0) return URMAPX_E_NODEVICE;
+	SearchWork wk;
+	wk.blocks = C->pe_blocks[cls];
+	wk.scratch_stride = search_pe_scratch_stride(max_read_len);
+	if ((rc = C->pe_scratch.ensure(wk.scratch_stride * (size_t)wk.blocks))) return rc;
+	wk.scratch = C->pe_scratch.p;
+	wk.ticket = nullptr;
+	ProbeOut po{C->slots.p, C->tallies.p, C->positions.p};
+	HIP_TRY(hipMemsetAsync(d_path_used, 0, 4, C->stream));
+	// positions the probe kernel does not write (qpos > L-W) must read as "no k-mer"
+	HIP_TRY(hipMemsetAsync(C->tallies.p, 0, 2 * total_bases, C->stream));
+	HIP_TRY(hipEventRecord(C->ev[0], C->stream));
+	HIP_TRY(launch_seed_probe(C->X, (const uint8_t *)d_bases, (const uint64_t *)d_offs, n, max_read_len, po, C->stream));
+	HIP_TRY(hipEventRecord(C->ev[1], C->stream));
+	HIP_TRY(launch_search_pe(C->X, C->params, (const uint8_t *)d_bases, (const uint64_t *)d_offs, npairs, max_read_len, po,
+	                         (urmapx_result *)d_results, (urmapx_path_op *)d_path_ops, (uint32_t *)d_path_used, wk, C->stream));
+	HIP_TRY(hipEventRecord(C->ev[2], C->stream));
+	C->ev_valid = true;
+	return URMAPX_OK;
+}
+
 // State2::Search (search2.cpp:59-73, method 4) over a batch of read pairs held in HOST memory: reads 2i and 2i+1 are
 // the mates of pair i.  results[2*npairs].
 int urmapx_map_pe(urmapx_ctx *C, const uint8_t *bases, const uint64_t *offs, uint32_t npairs, urmapx_result *results,
@@ -401,29 +433,9 @@ int urmapx_map_pe(urmapx_ctx *C, const uint8_t *bases, const uint64_t *offs, uin
 	if ((rc = C->results.ensure(n))) return rc;
 	if ((rc = C->pathops.ensure((size_t)n * URMAPX_MAX_PATH_OPS))) return rc;
 	if ((rc = C->used.ensure(1))) return rc;
-	if ((rc = ensure_probe(C, total))) return rc;
-	const int cls = mx <= 192 ? 0 : 1;
-	if (C->pe_blocks[cls] == 0) C->pe_blocks[cls] = search_pe_block_count(mx, C->device);
-	if (C->pe_blocks[cls] <= 0) return URMAPX_E_NODEVICE;
-	SearchWork wk;
-	wk.blocks = C->pe_blocks[cls];
-	wk.scratch_stride = search_pe_scratch_stride(mx);
-	if ((rc = C->pe_scratch.ensure(wk.scratch_stride * (size_t)wk.blocks))) return rc;
-	wk.scratch = C->pe_scratch.p;
-	wk.ticket = nullptr;
 	HIP_TRY(hipMemcpyAsync(C->bases.p, bases, total, hipMemcpyHostToDevice, C->stream));
 	HIP_TRY(hipMemcpyAsync(C->offs.p, offs, ((size_t)n + 1) * 8, hipMemcpyHostToDevice, C->stream));
-	HIP_TRY(hipMemsetAsync(C->used.p, 0, 4, C->stream));
-	ProbeOut po{C->slots.p, C->tallies.p, C->positions.p};
-	// positions the probe kernel does not write (qpos > L-W) must read as "no k-mer"
-	HIP_TRY(hipMemsetAsync(C->tallies.p, 0, 2 * total, C->stream));
-	HIP_TRY(hipEventRecord(C->ev[0], C->stream));
-	HIP_TRY(launch_seed_probe(C->X, C->bases.p, C->offs.p, n, mx, po, C->stream));
-	HIP_TRY(hipEventRecord(C->ev[1], C->stream));
-	HIP_TRY(launch_search_pe(C->X, C->params, C->bases.p, C->offs.p, npairs, mx, po, C->results.p, C->pathops.p, C->used.p,
-	                         wk, C->stream));
-	HIP_TRY(hipEventRecord(C->ev[2], C->stream));
-	C->ev_valid = true;
+	if ((rc = urmapx_map_pe_device(C, C->bases.p, C->offs.p, npairs, total, mx, C->results.p, C->pathops.p, C->used.p))) return rc;
 	uint32_t used = 0;
 	HIP_TRY(hipMemcpyAsync(results, C->results.p, (size_t)n * sizeof(urmapx_result), hipMemcpyDeviceToHost, C->stream));
 	HIP_TRY(hipMemcpyAsync(&used, C->used.p, 4, hipMemcpyDeviceToHost, C->stream));
