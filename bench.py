@@ -216,13 +216,19 @@ def main():
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the mapping path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # URMAP_BENCH_FORCE_DEVICE: testing aid -- run several ranks on one GPU (gloo for the barrier / reductions)
+    forced = os.environ.get("URMAP_BENCH_FORCE_DEVICE")
+    dev_index = int(forced) if forced is not None else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if forced is not None:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from urmap_amd import api
     api.lib()  # fail loudly if the HIP library is missing
@@ -253,9 +259,9 @@ def main():
             d_seq = torch.from_numpy(np.ascontiguousarray(seq_np)).to(device)  # the genome the index was built from
     t_build = time.time() - t0
     t0 = time.time()
-    index = api.Index.wrap_host(24, 32, slots, blob_np, seq_np, seq_lengths, seq_offsets, labels).upload(local_rank)
+    index = api.Index.wrap_host(24, 32, slots, blob_np, seq_np, seq_lengths, seq_offsets, labels).upload(dev_index)
     t_upload = time.time() - t0
-    mapper = api.Mapper(index, device=local_rank, method=6)
+    mapper = api.Mapper(index, device=dev_index, method=6)
     if world > 1:
         dist.barrier()
         if local_rank == 0:
@@ -311,7 +317,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        t = torch.tensor([dt], device=device if forced is None else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     kms /= max(1, args.steps)
