@@ -131,6 +131,9 @@ int urmapx_map_pe(urmapx_ctx *, const uint8_t *bases, const uint64_t *offs, uint
  * Asynchronous on the ctx stream; urmapx_ctx_sync() waits. total_bases = offs[n]. */
 int urmapx_map_se_device(urmapx_ctx *, const void *d_bases, const void *d_offs, uint32_t n, uint64_t total_bases,
                          uint32_t max_read_len, void *d_results, void *d_path_ops, void *d_path_used);
+/* `urmap -map2 ... -veryfast`: State2 method 5 = Search5 (search2m5.cpp:9-156) with band radius 4 (map2.cpp:17-21).
+ * The context's State1 parameters stay method 6, as in the reference (map2.cpp:15-16). */
+int urmapx_ctx_set_pe_veryfast(urmapx_ctx *, int on);
 /* Paired form of urmapx_map_se_device: 2*npairs reads resident in HBM, mates interleaved. */
 int urmapx_map_pe_device(urmapx_ctx *, const void *d_bases, const void *d_offs, uint32_t npairs, uint64_t total_bases,
                          uint32_t max_read_len, void *d_results, void *d_path_ops, void *d_path_used);

@@ -1532,7 +1532,9 @@ struct PairSearcher {
 	}
 
 	// search2m4.cpp:15-187
-	void Search4(const byte *Seqf, unsigned Lf, const byte *Seqr, unsigned Lr) {
+	// search2m4.cpp:15-187; veryfast = Search5 (search2m5.cpp:9-127): the same seed loop, then no 90 % shortcut, no
+	// FindPairs / ScanPair / AdjustTopHitsAndMapqs -- each mate keeps its own top hit and CalcMAPQ6
+	void Search4(const byte *Seqf, unsigned Lf, const byte *Seqr, unsigned Lr, bool veryfast = false) {
 		F.InitPE(Seqf, Lf);
 		R.InitPE(Seqr, Lr);
 		BestPairScore = 0; SecondBestPairScore = 0; BestPairIndex = 0; SecondPairIndex = UINT_MAX;
@@ -1566,6 +1568,7 @@ struct PairSearcher {
 		} while (kf != UINT_MAX || kr != UINT_MAX);
 		for (size_t i = 0; i < Qf.size(); ++i) F.ExtendPen(Qf[i], Df[i], Pf[i] != 0);
 		for (size_t i = 0; i < Qr.size(); ++i) R.ExtendPen(Qr[i], Dr[i], Pr[i] != 0);
+		if (veryfast) { F.SearchPE_Pending(); R.SearchPE_Pending(); return; }
 		if (F.BestScore >= int((Lf * 9) / 10) && R.BestScore >= int((Lr * 9) / 10)) {
 			int64_t TL = std::llabs(int64_t(F.Hits[F.TopHit].DBStartPos) - int64_t(R.Hits[R.TopHit].DBStartPos)) + int64_t(QL2);
 			if (TL <= MAX_TL) { F.Mapq = 40; R.Mapq = 40; return; }
@@ -1597,8 +1600,21 @@ static void MateMapped(Searcher &S, MateOut &M) {  // SetMappedPos, state1.cpp:1
 
 // In-memory paired-end batch: reads 2i, 2i+1 are the mates of pair i.  results[2*npairs] carry, per mate, the hit
 // State2 settled on after SetMappedPos (score = that hit's score, second = m_SecondBestScore, mapq = m_Mapq).
+extern "C" int uo_map_pe_opts(const uo_index *X, const uo_params *P, const uint8_t *bases, const uint64_t *offs,
+                              uint32_t npairs, int threads, int veryfast, uo_result *results, char **path_arena,
+                              uo_counters *counters);
 extern "C" int uo_map_pe(const uo_index *X, const uo_params *P, const uint8_t *bases, const uint64_t *offs, uint32_t npairs,
                          int threads, uo_result *results, char **path_arena, uo_counters *counters) {
+	return uo_map_pe_opts(X, P, bases, offs, npairs, threads, 0, results, path_arena, counters);
+}
+
+// veryfast: State2 method 5 (map2.cpp:17-21 sets the band radius to 4; Search5)
+extern "C" int uo_map_pe_opts(const uo_index *X, const uo_params *Pin, const uint8_t *bases, const uint64_t *offs,
+                              uint32_t npairs, int threads, int veryfast, uo_result *results, char **path_arena,
+                              uo_counters *counters) {
+	uo_params Pv = *Pin;
+	if (veryfast) Pv.band_radius = 4;
+	const uo_params *P = &Pv;
 	if (threads < 1) threads = 1;
 	std::vector<std::string> Paths((size_t)2 * npairs);
 	if (counters) memset(counters, 0, sizeof *counters);
@@ -1608,7 +1624,7 @@ extern "C" int uo_map_pe(const uo_index *X, const uo_params *P, const uint8_t *b
 #pragma omp for schedule(dynamic, 64)
 		for (int64_t i = 0; i < (int64_t)npairs; ++i) {
 			const uint64_t o0 = offs[2 * i], o1 = offs[2 * i + 1], o2 = offs[2 * i + 2];
-			S.Search4(bases + o0, unsigned(o1 - o0), bases + o1, unsigned(o2 - o1));
+			S.Search4(bases + o0, unsigned(o1 - o0), bases + o1, unsigned(o2 - o1), veryfast != 0);
 			Searcher *M[2] = {&S.F, &S.R};
 			for (int a = 0; a < 2; ++a) {
 				MateOut mo;
@@ -1651,9 +1667,11 @@ static uint32_t PairedFlags(bool First, bool RevComp, bool MateRevComp, bool Mat
 	return f;
 }
 
-extern "C" int uo_map_file_pe(const uo_index *X, const uo_params *P, const char *fq1, const char *fq2, const char *sam,
+extern "C" int uo_map_file_pe(const uo_index *X, const uo_params *Pin, const char *fq1, const char *fq2, const char *sam,
                               int threads, int veryfast, uo_counters *counters) {
-	if (veryfast) return -101;  // Search5 (search2m5.cpp) is not restated
+	uo_params Pv = *Pin;
+	if (veryfast) Pv.band_radius = 4;  // map2.cpp:17-21
+	const uo_params *P = &Pv;
 	std::vector<FastqRec> R1, R2;
 	int rc = ReadFastq(fq1, R1);
 	if (rc) return rc;
@@ -1671,7 +1689,7 @@ extern "C" int uo_map_file_pe(const uo_index *X, const uo_params *P, const char 
 #pragma omp for schedule(dynamic, 64)
 		for (int64_t i = 0; i < n; ++i) {
 			const FastqRec &A = R1[(size_t)i], &B = R2[(size_t)i];
-			S.Search4((const byte *)A.Seq.data(), (unsigned)A.Seq.size(), (const byte *)B.Seq.data(), (unsigned)B.Seq.size());
+			S.Search4((const byte *)A.Seq.data(), (unsigned)A.Seq.size(), (const byte *)B.Seq.data(), (unsigned)B.Seq.size(), veryfast != 0);
 			// SetSAM2, output2.cpp:61-128
 			MateOut M1, M2;
 			MateMapped(S.F, M1);

@@ -90,6 +90,7 @@ def lib():
     L.uo_viterbi.argtypes = [C.POINTER(Params), vp, C.c_uint, vp, C.c_uint, C.c_int, C.c_int, vp]
     L.uo_map_se.argtypes = [vp, C.POINTER(Params), vp, vp, u32, C.c_int, vp, C.POINTER(vp), C.POINTER(Counters)]
     L.uo_map_pe.argtypes = [vp, C.POINTER(Params), vp, vp, u32, C.c_int, vp, C.POINTER(vp), C.POINTER(Counters)]
+    L.uo_map_pe_opts.argtypes = [vp, C.POINTER(Params), vp, vp, u32, C.c_int, C.c_int, vp, C.POINTER(vp), C.POINTER(Counters)]
     L.uo_free.argtypes = [vp]
     L.uo_sam_se.restype = C.c_size_t
     L.uo_sam_se.argtypes = [vp, vp, cp, cp, vp, vp, u32, vp]
@@ -190,7 +191,7 @@ class Index:
         lib().uo_free(arena)
         return res, paths, cnt.asdict()
 
-    def map_pe(self, bases: np.ndarray, offs: np.ndarray, threads=1):
+    def map_pe(self, bases: np.ndarray, offs: np.ndarray, threads=1, veryfast=False):
         """pairs interleaved (reads 2i, 2i+1) -> (results[2*npairs], paths, counters)"""
         bases = np.ascontiguousarray(bases, dtype=np.uint8)
         offs = np.ascontiguousarray(offs, dtype=np.uint64)
@@ -199,8 +200,8 @@ class Index:
         arena = C.c_void_p()
         cnt = Counters()
         p = params(6)
-        rc = lib().uo_map_pe(self.h, C.byref(p), bases.ctypes.data, offs.ctypes.data, n // 2, threads, res.ctypes.data,
-                             C.byref(arena), C.byref(cnt))
+        rc = lib().uo_map_pe_opts(self.h, C.byref(p), bases.ctypes.data, offs.ctypes.data, n // 2, threads, int(veryfast),
+                                  res.ctypes.data, C.byref(arena), C.byref(cnt))
         assert rc == 0
         paths = [C.string_at(arena.value + int(r["path_off"])).decode() for r in res]
         lib().uo_free(arena)

@@ -254,10 +254,12 @@ def test_veryfast_method7_matches_oracle(small_case, tmp_path):
     compare_results(gres, gops, ores, opaths)
 
 
-def _map_pe_sam(ufi, fq1, fq2):
+def _map_pe_sam(ufi, fq1, fq2, veryfast=False):
     from urmap_amd import api
     idx = api.Index.open(ufi).upload(0)
     m = api.Mapper(idx, device=0, method=6)
+    if veryfast:
+        m.set_pe_veryfast(True)
     labels, bases, offs, quals = api.interleave_pairs(api.read_fastq_arrays(fq1), api.read_fastq_arrays(fq2))
     res, ops = m.map_pe(bases, offs)
     return idx.sam_header_sq() + idx.sam_pe(res, ops, labels, bases, offs, quals)
@@ -327,4 +329,25 @@ def test_cli_map2_reproduces_reference_sam(tmp_path, name):
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     got = [l for l in open(out, "rb").read().split(b"\n") if l and not l.startswith(b"@PG")]
     want = [l for l in open(os.path.join(gold, name + ".sam"), "rb").read().split(b"\n") if l]
+    assert got == want
+
+
+def test_pe_veryfast_search5_matches_oracle(small_case, tmp_path):
+    """`-map2 -veryfast`: State2::Search5 (search2m5.cpp:9-156), band radius 4 (map2.cpp:17-21)."""
+    import os
+    from urmap_amd import synth
+    n = 2500
+    r1, r2 = synth.make_pairs(909, small_case["genome"], n, read_len=150, sub1=0.02, sub2=0.05, ins=0.004, dele=0.004)
+    rng = np.random.default_rng(9)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    for k in range(3, n, 23):
+        lab, s, q = r1[k]
+        r1[k] = (lab, acgt[rng.integers(0, 4, size=len(s))], q)
+    f1, f2 = os.path.join(tmp_path, "r1.fq"), os.path.join(tmp_path, "r2.fq")
+    synth.write_fastq(f1, r1)
+    synth.write_fastq(f2, r2)
+    osam = os.path.join(tmp_path, "o.sam")
+    small_case["oracle_index"].map_file_pe(f1, f2, osam, threads=4, veryfast=True)
+    got = _map_pe_sam(small_case["ufi"], f1, f2, veryfast=True)
+    want = open(osam, "rb").read()
     assert got == want

@@ -30,7 +30,7 @@ EXPORTS = (
     "urmapx_index_seq_length", "urmapx_index_seq_offset", "urmapx_ctx_create", "urmapx_ctx_destroy",
     "urmapx_map_se", "urmapx_map_se_device", "urmapx_ctx_sync", "urmapx_ctx_last_kernel_ms",
     "urmapx_seed_probe", "urmapx_viterbi_batch", "urmapx_strerror", "urmapx_device_arch",
-    "urmapx_make_ufi", "urmapx_build_slots", "urmapx_sam_se", "urmapx_sam_header_sq", "urmapx_ctx_phase_cycles", "urmapx_map_pe", "urmapx_sam_pe", "urmapx_map_pe_device",
+    "urmapx_make_ufi", "urmapx_build_slots", "urmapx_sam_se", "urmapx_sam_header_sq", "urmapx_ctx_phase_cycles", "urmapx_map_pe", "urmapx_sam_pe", "urmapx_map_pe_device", "urmapx_ctx_set_pe_veryfast",
 )
 
 
@@ -87,6 +87,7 @@ def lib():
     L.urmapx_sam_pe.argtypes = [vp, vp, vp, vp, cp, vp, vp, u32, cp, vp, vp, u32, vp, C.c_size_t]
     L.urmapx_map_se_device.argtypes = [vp, vp, vp, u32, u64, u32, vp, vp, vp]
     L.urmapx_map_pe_device.argtypes = [vp, vp, vp, u32, u64, u32, vp, vp, vp]
+    L.urmapx_ctx_set_pe_veryfast.argtypes = [vp, i32]
     L.urmapx_ctx_sync.argtypes = [vp]
     L.urmapx_ctx_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float * 2)]
     L.urmapx_ctx_phase_cycles.argtypes = [vp, C.POINTER(C.c_uint64 * 12)]
@@ -285,6 +286,9 @@ class Mapper:
                                  C.byref(used))
         _check(rc, "urmapx_map_se", allow=(E_UNSUPPORTED,) if allow_unsupported else ())
         return res, ops[: used.value].copy()
+
+    def set_pe_veryfast(self, on=True):
+        _check(lib().urmapx_ctx_set_pe_veryfast(self.h, int(on)), "urmapx_ctx_set_pe_veryfast")
 
     def map_pe(self, bases: np.ndarray, offs: np.ndarray, allow_unsupported=False):
         """Pairs interleaved: reads 2i, 2i+1 are R1, R2 of pair i.  -> (results[2*npairs], path op arena)."""

@@ -478,7 +478,8 @@ __global__ __launch_bounds__(64) void search_pe_kernel(DevIndex X, urmapx_params
                                                        urmapx_result *__restrict__ results,
                                                        urmapx_path_op *__restrict__ path_ops, uint32_t *path_used,
                                                        uint8_t *scratch, size_t scratch_stride,
-                                                       const uint8_t *__restrict__ g_seq, const uint8_t *__restrict__ g_blob) {
+                                                       const uint8_t *__restrict__ g_seq, const uint8_t *__restrict__ g_blob,
+                                                       int veryfast) {
 	using M = Mate<NCH>;
 	constexpr int QMAX = M::QMAX;
 	__shared__ uint8_t sQ[4][QMAX];
@@ -647,7 +648,12 @@ __global__ __launch_bounds__(64) void search_pe_kernel(DevIndex X, urmapx_params
 			for (int a = 0; a < 2; ++a)
 				for (int i = 0; i < nseed[a]; ++i)
 					m[a].extend_pen(seed_q[a][i] & 0x7FFFu, seed_db[a][i], (seed_q[a][i] & 0x8000u) != 0);
-			if (m[0].best >= (QLf * 9) / 10 && m[1].best >= (QLr * 9) / 10 && m[0].topHit >= 0 && m[1].topHit >= 0) {
+			if (veryfast) {
+				// Search5 (search2m5.cpp:112-127): no 90 % shortcut and no pair stage; each mate finishes on its own
+				m[0].search_pending();
+				m[1].search_pending();
+				done = true;
+			} else if (m[0].best >= (QLf * 9) / 10 && m[1].best >= (QLr * 9) / 10 && m[0].topHit >= 0 && m[1].topHit >= 0) {
 				int64_t d = (int64_t)rdlane(m[0].hit_db, m[0].topHit) - (int64_t)rdlane(m[1].hit_db, m[1].topHit);
 				if (d < 0) d = -d;
 				if (d + QL2 <= MAX_TL) { m[0].mapq = 40; m[1].mapq = 40; done = true; }
@@ -776,15 +782,16 @@ int search_pe_block_count(uint32_t max_read_len, int device) {
 
 hipError_t launch_search_pe(const DevIndex &X, const urmapx_params &P, const uint8_t *d_bases, const uint64_t *d_offs,
                             uint32_t npairs, uint32_t max_read_len, ProbeOut probe, urmapx_result *d_results,
-                            urmapx_path_op *d_path_ops, uint32_t *d_path_used, const SearchWork &wk, hipStream_t s) {
+                            urmapx_path_op *d_path_ops, uint32_t *d_path_used, const SearchWork &wk, int veryfast,
+                            hipStream_t s) {
 	if (npairs == 0) return hipSuccess;
 	dim3 block(64), grid((unsigned)wk.blocks);
 	if (pe_nch_for(max_read_len) == 3)
 		hipLaunchKernelGGL(search_pe_kernel<3>, grid, block, 0, s, X, P, d_bases, d_offs, npairs, probe, d_results, d_path_ops,
-		                   d_path_used, wk.scratch, wk.scratch_stride, X.seq, X.blob);
+		                   d_path_used, wk.scratch, wk.scratch_stride, X.seq, X.blob, veryfast);
 	else
 		hipLaunchKernelGGL(search_pe_kernel<5>, grid, block, 0, s, X, P, d_bases, d_offs, npairs, probe, d_results, d_path_ops,
-		                   d_path_used, wk.scratch, wk.scratch_stride, X.seq, X.blob);
+		                   d_path_used, wk.scratch, wk.scratch_stride, X.seq, X.blob, veryfast);
 	return hipGetLastError();
 }
 

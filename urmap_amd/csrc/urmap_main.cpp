@@ -128,16 +128,16 @@ extern "C" size_t urmapx_sam_pe(const urmapx_index *, const urmapx_result *, con
 static int cmd_map(const Opts &o, int argc, char **argv) {
 	const bool paired = !o.map2.empty();
 	if (paired && o.reverse.empty()) die("-reverse required");
-	if (paired && o.veryfast) die("-map2 -veryfast (Search5) is not available in this build");
 	if (o.ufi.empty()) die("-ufi option required");
 	const auto t0 = std::chrono::steady_clock::now();
 	urmapx_index *I = nullptr;
 	check(urmapx_index_open(o.ufi.c_str(), &I), ("Reading index " + o.ufi).c_str());
 	check(urmapx_index_upload(I, o.gpu), "Uploading index to the GPU");
 	urmapx_params P;
-	check(urmapx_params_for_method(o.veryfast ? 7 : 6, &P), "SetMethod");
+	check(urmapx_params_for_method((o.veryfast && o.map2.empty()) ? 7 : 6, &P), "SetMethod");  // -map2 always uses method 6 (map2.cpp:15-16)
 	urmapx_ctx *C = nullptr;
 	check(urmapx_ctx_create(I, o.gpu, &P, &C), "Creating mapping context");
+	if (!o.map2.empty() && o.veryfast) check(urmapx_ctx_set_pe_veryfast(C, 1), "Search5");
 	if (o.veryfast && urmapx_index_max_ix(I) > 3) fprintf(stderr, "\nWARNING: index not optimal for -veryfast\n");
 	FILE *fsam = nullptr;
 	if (!o.samout.empty()) {

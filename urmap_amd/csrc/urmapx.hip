@@ -97,6 +97,7 @@ struct urmapx_ctx {
 	DevBuf<uint8_t> scratch, vscratch;
 	DevBuf<uint32_t> ticket;
 	DevBuf<uint8_t> pe_scratch;
+	int pe_veryfast = 0;  // State2::m_Method 5
 	int pe_blocks[2] = {0, 0};
 	int blocks[2] = {0, 0};  // persistent grid size of the search kernel for read length classes <=192, <=320
 };
@@ -382,6 +383,13 @@ int urmapx_map_se(urmapx_ctx *C, const uint8_t *bases, const uint64_t *offs, uin
 	return URMAPX_OK;
 }
 
+// cmd_map2's `-veryfast`: State2::m_Method = 5 (Search5, search2m5.cpp) with band radius 4 (map2.cpp:47-49,17-21)
+int urmapx_ctx_set_pe_veryfast(urmapx_ctx *C, int on) {
+	if (!C) return URMAPX_E_ARG;
+	C->pe_veryfast = on ? 1 : 0;
+	return URMAPX_OK;
+}
+
 // State2::Search over pairs already resident in HBM (reads 2i, 2i+1 = mates of pair i); asynchronous on the ctx stream.
 int urmapx_map_pe_device(urmapx_ctx *C, const void *d_bases, const void *d_offs, uint32_t npairs, uint64_t total_bases,
                          uint32_t max_read_len, void *d_results, void *d_path_ops, void *d_path_used) {
@@ -407,8 +415,11 @@ int urmapx_map_pe_device(urmapx_ctx *C, const void *d_bases, const void *d_offs,
 	HIP_TRY(hipEventRecord(C->ev[0], C->stream));
 	HIP_TRY(launch_seed_probe(C->X, (const uint8_t *)d_bases, (const uint64_t *)d_offs, n, max_read_len, po, C->stream));
 	HIP_TRY(hipEventRecord(C->ev[1], C->stream));
-	HIP_TRY(launch_search_pe(C->X, C->params, (const uint8_t *)d_bases, (const uint64_t *)d_offs, npairs, max_read_len, po,
-	                         (urmapx_result *)d_results, (urmapx_path_op *)d_path_ops, (uint32_t *)d_path_used, wk, C->stream));
+	urmapx_params Ppe = C->params;
+	if (C->pe_veryfast) Ppe.band_radius = 4;  // map2.cpp:17-21
+	HIP_TRY(launch_search_pe(C->X, Ppe, (const uint8_t *)d_bases, (const uint64_t *)d_offs, npairs, max_read_len, po,
+	                         (urmapx_result *)d_results, (urmapx_path_op *)d_path_ops, (uint32_t *)d_path_used, wk,
+	                         C->pe_veryfast, C->stream));
 	HIP_TRY(hipEventRecord(C->ev[2], C->stream));
 	C->ev_valid = true;
 	return URMAPX_OK;
