@@ -144,3 +144,21 @@ def test_cigar_dangling_m_rules():
     assert cigar("M" * 2 + "D" * 4 + "M" * 100, 106) == "2M4I100M"    # indel not > 4: untouched
     assert cigar("M" * 1 + "D" * 6 + "M" * 100 + "I" * 6 + "M" * 1, 108) == "6I101M6D1M"  # head rule XOR tail rule
     assert cigar("", 150) == "150M"
+
+
+def test_cli_make_ufi_is_byte_identical(gold_ufi, tmp_path):
+    """`urmap -make_ufi FASTA -output UFI -slots N` of this build vs the reference's .ufi (no GPU involved)."""
+    import subprocess
+    exe = os.path.join(ROOT, "urmap_amd", "urmap")
+    if not os.path.exists(exe):
+        pytest.skip("CLI not built")
+    w, maxix, sds, slots = ol.ufi_header(gold_ufi)
+    out = os.path.join(tmp_path, "cli.ufi")
+    r = subprocess.run([exe, "-make_ufi", os.path.join(GOLD, "g.fa"), "-output", out, "-slots", str(slots)],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert r.returncode == 0, r.stderr.decode()
+    assert filecmp.cmp(out, gold_ufi, shallow=False)
+    # missing -slots is a loud error, exit status 1 (myutils.cpp:915)
+    r = subprocess.run([exe, "-make_ufi", os.path.join(GOLD, "g.fa"), "-output", out], stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=60)
+    assert r.returncode == 1 and b"-slots" in r.stderr

@@ -32,9 +32,9 @@ struct ProbeOut {
 hipError_t launch_seed_probe(const DevIndex &X, const uint8_t *d_bases, const uint64_t *d_offs, uint32_t n,
                              uint32_t max_read_len, ProbeOut out, hipStream_t s);
 
-// workspace of the persistent search kernel: a ticket counter and per-block global scratch
+// workspace of the persistent search kernels: per-block global scratch (+ optional diagnostics buffer)
 struct SearchWork {
-	uint32_t *ticket;
+	uint32_t *stats;  // optional cycle-stamp accumulator (URMAPX_PHASE_STATS), else nullptr
 	uint8_t *scratch;
 	size_t scratch_stride;  // search_scratch_stride(max_read_len)
 	int blocks;             // search_block_count(max_read_len, device)

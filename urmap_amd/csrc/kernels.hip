@@ -137,14 +137,14 @@ __global__ __launch_bounds__(64) void viterbi_batch_kernel(urmapx_params P, cons
 }
 
 // ------------------------------------------------------------------------------------------------
-// kernel B: per-read search.  One wavefront per read (persistent blocks pull reads from a ticket counter).
+// kernel B: per-read search.  One wavefront per read (persistent blocks stride over the batch).
 //
 // The reference's schedule (search1m6.cpp:35-277) is a chain of ~600 dependent memory accesses per read
 // (one target window per ExtendPen, one slot per chain hop).  The accesses themselves do not depend on the
 // search state -- only WHAT IS DONE with each window does -- so every phase is split in two:
 //   gather   (order independent, 64-wide): each lane takes one candidate seed of the phase, in the reference's
 //            order, and computes that candidate's whole mismatch bit vector against its reference window
-//            (lane_mismatch_mask); chain walks put one collision chain on each lane (walk_rows).
+//            (lane_mismatch_mask); chain walks put one collision chain on each lane (walk_all).
 //   consume  (order dependent, wave-uniform): the candidates' bit vectors are read back lane by lane and run
 //            through ExtendPen's x-drop / penalty logic, AddHitX / AddHSPX, early exits -- exactly in order.
 // ------------------------------------------------------------------------------------------------
@@ -402,37 +402,9 @@ struct SearchWave {
 		return mapq;
 	}
 
-	// UFIndex::GetRow_Blob (ufindex.cpp:883-943), one collision chain per lane; positions go to
-	// rowstore[seg][k][lane].  Returns the row length of this lane's chain (0 for inactive lanes).
-	__device__ __forceinline__ int walk_rows(int seg, bool active, uint64_t slot, uint32_t T, uint32_t pos) {
-		uint32_t *rs = rowstore + (size_t)seg * ROW_CAP * 64 + lane;
-		int K = 0;
-		if (active && (T & TALLY_MY_BIT) != 0) {
-			uint64_t slot2 = slot;
-			const uint64_t N = X.slotCount;
-			const int maxIx = (int)X.maxIx;
-			for (;;) {
-				rs[K * 64] = pos;
-				++K;
-				if (K == maxIx || K >= ROW_CAP) break;
-				if (T == TALLY_PLUS1 || T == TALLY_BOTH1) { K = 1; break; }
-				if (T == TALLY_END) break;
-				if (T == TALLY_LONG_MINE || T == TALLY_LONG_OTHER) {
-					uint64_t slotA = addmod(slot2, pos & 0xFFFFu, N);
-					slot2 = addmod(slotA, pos >> 16, N);
-					uint32_t tA, pA;
-					load_slot(gblob, slotA, tA, pA);
-					rs[(K - 1) * 64] = pA;
-				} else
-					slot2 = addmod(slot2, T & TALLY_NEXT_MASK, N);
-				load_slot(gblob, slot2, T, pos);
-			}
-		}
-		return K;
-	}
-
-	// All collision chains of the read at once: lane = query position mod 64, the 2*NCH [strand][chunk] segments
-	// advance in lock step so that up to 2*NCH dependent slot loads per lane are in flight instead of one.
+	// UFIndex::GetRow_Blob (ufindex.cpp:883-943) for all collision chains of the read at once: lane = query position
+	// mod 64, the 2*NCH [strand][chunk] segments advance in lock step so that up to 2*NCH dependent slot loads per lane
+	// are in flight; positions go to rowstore[seg][k][lane], row lengths to rl[seg].
 	__device__ __forceinline__ void walk_all(const ProbeOut &probe, uint64_t base2, int (&rl)[NSEG]) {
 		uint64_t sl[NSEG];
 		uint32_t T[NSEG], ps[NSEG];
@@ -520,9 +492,9 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU) void search_se_kernel(DevI
                                                        const uint64_t *__restrict__ offs, uint32_t n, ProbeOut probe,
                                                        urmapx_result *__restrict__ results,
                                                        urmapx_path_op *__restrict__ path_ops, uint32_t *path_used,
-                                                       uint32_t *ticket, uint8_t *scratch, size_t scratch_stride,
+                                                       uint32_t *stats, uint8_t *scratch, size_t scratch_stride,
                                                        const uint8_t *__restrict__ g_seq, const uint8_t *__restrict__ g_blob) {
-	// ticket != nullptr: diagnostic build-in -- per-phase shader cycles are accumulated into ticket[2..] (u64 each)
+	// stats != nullptr (URMAPX_PHASE_STATS): per-phase shader cycles are accumulated into stats (u64 each, from byte 8)
 	using SW = SearchWave<NCH>;
 	__shared__ __attribute__((aligned(16))) uint8_t sQ2[2 * SW::QMAX];  // plus strand, then reverse complement
 	uint8_t *const sQp = sQ2, *const sQm = sQ2 + SW::QMAX;
@@ -607,11 +579,11 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU) void search_se_kernel(DevI
 		const int minhsp = (int)((uint32_t)P.min_hsp_score_pct * (uint32_t)QL / 100.0);
 		int phase = 1;
 		bool done = false;
-		uint64_t tstamp = ticket ? __builtin_amdgcn_s_memtime() : 0;
+		uint64_t tstamp = stats ? __builtin_amdgcn_s_memtime() : 0;
 		auto lapc = [&](int slot) {
-			if (!ticket) return;
+			if (!stats) return;
 			uint64_t now = __builtin_amdgcn_s_memtime();
-			if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long *>(ticket) + 1 + slot, (unsigned long long)(now - tstamp));
+			if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long *>(stats) + 1 + slot, (unsigned long long)(now - tstamp));
 			tstamp = now;
 		};
 		lapc(0);
@@ -661,11 +633,11 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU) void search_se_kernel(DevI
 			}
 			const int total = S.template scan_counts<SW::NSEG>(cnt);
 				for (int base = 0; base < total && !done; base += 64) {
-					uint64_t tsub = ticket ? __builtin_amdgcn_s_memtime() : 0;
+					uint64_t tsub = stats ? __builtin_amdgcn_s_memtime() : 0;
 					auto laps = [&](int slot) {
-						if (!ticket) return;
+						if (!stats) return;
 						uint64_t now = __builtin_amdgcn_s_memtime();
-						if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long *>(ticket) + 1 + slot, (unsigned long long)(now - tsub));
+						if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long *>(stats) + 1 + slot, (unsigned long long)(now - tsub));
 						tsub = now;
 					};
 					const int g = base + lane;
@@ -834,17 +806,17 @@ hipError_t launch_search_se(const DevIndex &X, const urmapx_params &P, const uin
                             urmapx_path_op *d_path_ops, uint32_t *d_path_used, const SearchWork &wk, hipStream_t s) {
 	if (n == 0) return hipSuccess;
 	const int nch = nch_for(max_read_len);
-	if (wk.ticket) {
-		hipError_t e = hipMemsetAsync(wk.ticket, 0, 192, s);
+	if (wk.stats) {
+		hipError_t e = hipMemsetAsync(wk.stats, 0, 192, s);
 		if (e != hipSuccess) return e;
 	}
 	dim3 block(64), grid((unsigned)wk.blocks);
 	if (nch == 3)
 		hipLaunchKernelGGL(search_se_kernel<3>, grid, block, 0, s, X, P, d_bases, d_offs, n, probe, d_results, d_path_ops,
-		                   d_path_used, wk.ticket, wk.scratch, wk.scratch_stride, X.seq, X.blob);
+		                   d_path_used, wk.stats, wk.scratch, wk.scratch_stride, X.seq, X.blob);
 	else
 		hipLaunchKernelGGL(search_se_kernel<5>, grid, block, 0, s, X, P, d_bases, d_offs, n, probe, d_results, d_path_ops,
-		                   d_path_used, wk.ticket, wk.scratch, wk.scratch_stride, X.seq, X.blob);
+		                   d_path_used, wk.stats, wk.scratch, wk.scratch_stride, X.seq, X.blob);
 	return hipGetLastError();
 }
 

@@ -95,7 +95,7 @@ struct urmapx_ctx {
 	DevBuf<float> vscores;
 	DevBuf<uint16_t> vnops;
 	DevBuf<uint8_t> scratch, vscratch;
-	DevBuf<uint32_t> ticket;
+	DevBuf<uint32_t> statsbuf;
 	DevBuf<uint8_t> pe_scratch;
 	int pe_veryfast = 0;  // State2::m_Method 5
 	int pe_blocks[2] = {0, 0};
@@ -275,7 +275,7 @@ void urmapx_ctx_destroy(urmapx_ctx *C) {
 	C->bases.release(); C->tallies.release(); C->vflags.release(); C->vstatus.release(); C->va.release(); C->vb.release();
 	C->offs.release(); C->slots.release(); C->positions.release(); C->used.release(); C->vaoffs.release(); C->vboffs.release();
 	C->results.release(); C->pathops.release(); C->vops.release(); C->vscores.release(); C->vnops.release();
-	C->scratch.release(); C->vscratch.release(); C->ticket.release(); C->pe_scratch.release();
+	C->scratch.release(); C->vscratch.release(); C->statsbuf.release(); C->pe_scratch.release();
 	for (int i = 0; i < 3; ++i)
 		if (C->ev[i]) (void)hipEventDestroy(C->ev[i]);
 	if (C->stream) (void)hipStreamDestroy(C->stream);
@@ -286,10 +286,10 @@ const char *urmapx_device_arch(urmapx_ctx *C) { return C ? C->arch : nullptr; }
 
 // diagnostic: shader cycles per phase of the last search kernel (needs URMAPX_PHASE_STATS=1 in the environment)
 int urmapx_ctx_phase_cycles(urmapx_ctx *C, uint64_t out[12]) {
-	if (!C || !out || !C->ticket.p) return URMAPX_E_ARG;
+	if (!C || !out || !C->statsbuf.p) return URMAPX_E_ARG;
 	HIP_TRY(hipStreamSynchronize(C->stream));
 	uint64_t buf[13];
-	HIP_TRY(hipMemcpy(buf, C->ticket.p, sizeof buf, hipMemcpyDeviceToHost));
+	HIP_TRY(hipMemcpy(buf, C->statsbuf.p, sizeof buf, hipMemcpyDeviceToHost));
 	for (int i = 0; i < 12; ++i) out[i] = buf[i + 1];
 	return URMAPX_OK;
 }
@@ -331,9 +331,9 @@ int urmapx_map_se_device(urmapx_ctx *C, const void *d_bases, const void *d_offs,
 	wk.blocks = C->blocks[cls];
 	wk.scratch_stride = search_scratch_stride(max_read_len);
 	if ((rc = C->scratch.ensure(wk.scratch_stride * (size_t)wk.blocks))) return rc;
-	if ((rc = C->ticket.ensure(64))) return rc;
+	if ((rc = C->statsbuf.ensure(64))) return rc;
 	wk.scratch = C->scratch.p;
-	wk.ticket = getenv("URMAPX_PHASE_STATS") ? C->ticket.p : nullptr;
+	wk.stats = getenv("URMAPX_PHASE_STATS") ? C->statsbuf.p : nullptr;
 	HIP_TRY(hipMemsetAsync(d_path_used, 0, 4, C->stream));
 	HIP_TRY(hipEventRecord(C->ev[0], C->stream));
 	HIP_TRY(launch_seed_probe(C->X, (const uint8_t *)d_bases, (const uint64_t *)d_offs, n, max_read_len, po, C->stream));
@@ -407,7 +407,7 @@ int urmapx_map_pe_device(urmapx_ctx *C, const void *d_bases, const void *d_offs,
 	wk.scratch_stride = search_pe_scratch_stride(max_read_len);
 	if ((rc = C->pe_scratch.ensure(wk.scratch_stride * (size_t)wk.blocks))) return rc;
 	wk.scratch = C->pe_scratch.p;
-	wk.ticket = nullptr;
+	wk.stats = nullptr;
 	ProbeOut po{C->slots.p, C->tallies.p, C->positions.p};
 	HIP_TRY(hipMemsetAsync(d_path_used, 0, 4, C->stream));
 	// positions the probe kernel does not write (qpos > L-W) must read as "no k-mer"
