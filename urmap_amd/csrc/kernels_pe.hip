@@ -494,6 +494,9 @@ __global__ __launch_bounds__(64) void search_pe_kernel(DevIndex X, urmapx_params
 	__shared__ uint16_t seed_q[2][PE_SEED_CAP];
 	__shared__ uint32_t seed_db[2][PE_SEED_CAP];
 	__shared__ uint16_t pair_f[PE_PAIR_CAP], pair_r[PE_PAIR_CAP];
+	// probe results of both mates staged in LDS ([mate][strand][qpos]): the seed enumeration reads them one by one
+	__shared__ uint8_t s_tal[2][2][QMAX];
+	__shared__ uint32_t s_pos[2][2][QMAX];
 
 	const int lane = threadIdx.x;
 	const int W = (int)X.W;
@@ -543,6 +546,18 @@ __global__ __launch_bounds__(64) void search_pe_kernel(DevIndex X, urmapx_params
 				}
 				m[a].qch[0][c] = cp; m[a].qch[1][c] = cm;
 			}
+#pragma unroll
+			for (int st = 0; st < 2; ++st) {
+#pragma unroll
+				for (int c = 0; c < NCH; ++c) {
+					const int p = 64 * c + lane;
+					if (p < QL) {
+						const bool in = p < m[a].nwords;
+						s_tal[a][st][p] = in ? m[a].ptal[(size_t)st * QL + p] : (uint8_t)0;
+						s_pos[a][st][p] = in ? m[a].ppos[(size_t)st * QL + p] : 0xFFFFFFFFu;
+					}
+				}
+			}
 			m[a].hit_db = 0; m[a].hit_sp = 0;
 			m[a].pendCount[0] = m[a].pendCount[1] = 0;
 			m[a].hitCount = 0; m[a].hspCount = 0; m[a].topHit = -1;
@@ -556,7 +571,7 @@ __global__ __launch_bounds__(64) void search_pe_kernel(DevIndex X, urmapx_params
 		// pairing loop reached if that loop returns early (they are not used then anyway).
 		int nseed[2];
 		for (int a = 0; a < 2; ++a) {
-			const int QL = m[a].QL, QWC = m[a].nwords;
+			const int QWC = m[a].nwords;
 			int ns = 0;
 			bool have = false, lastPlus = false;
 			uint32_t lastDiag = 0;
@@ -565,8 +580,7 @@ __global__ __launch_bounds__(64) void search_pe_kernel(DevIndex X, urmapx_params
 				const uint32_t qpos = ((uint32_t)k * PRIME_STRIDE) % (uint32_t)QWC;
 				bool plusReturnedHere = false;
 				for (int s = 0; s < 2; ++s) {
-					const size_t idx = (size_t)s * QL + qpos;
-					const uint32_t T = uni((uint32_t)m[a].ptal[idx]);  // slots without a k-mer carry tally 0 = FREE = "other"
+					const uint32_t T = s_tal[a][s][qpos];  // slots without a k-mer carry tally 0 = FREE = "other"
 					if ((T & TALLY_MY_BIT) == 0) continue;
 					const bool special = (s == 1) && plusReturnedHere;  // the re-check branch of GetNextBoth1Seed
 					if (T != TALLY_BOTH1) {
@@ -576,7 +590,7 @@ __global__ __launch_bounds__(64) void search_pe_kernel(DevIndex X, urmapx_params
 						}
 						continue;
 					}
-					const uint32_t db = uni(m[a].ppos[idx]);
+					const uint32_t db = s_pos[a][s][qpos];
 					const uint32_t diag = db - qpos;
 					if (have && diag == lastDiag) {
 						if (special) { if (lane == 0) m[a].pend[1][nm] = (uint8_t)qpos; ++nm; }
@@ -605,39 +619,53 @@ __global__ __launch_bounds__(64) void search_pe_kernel(DevIndex X, urmapx_params
 		bool done = false;
 		{
 			const int steps = max(nseed[0], nseed[1]);
+			// The template-length test of a new seed against every seed of the other mate is done 64 seeds per step
+			// (ballot); only the few that pass go through ExtendBoth1Pair4, in list order.
+			auto near_mask = [&](int other, int base, int n, uint32_t db) -> uint64_t {
+				const int i = base + lane;
+				bool ok = false;
+				if (i < n) {
+					int64_t d = (int64_t)db - (int64_t)seed_db[other][i];
+					if (d < 0) d = -d;
+					ok = d + QL2 <= MAX_TL;
+				}
+				return __ballot(ok);
+			};
 			for (int t = 0; t < steps && !done; ++t) {
 				if (t < nseed[0]) {
 					const uint32_t qf = seed_q[0][t] & 0x7FFFu, dbf = seed_db[0][t];
 					const bool plusf = (seed_q[0][t] & 0x8000u) != 0;
 					const int nr = min(t, nseed[1]);
-					for (int i = 0; i < nr && !done; ++i) {
-						const uint32_t dbr = seed_db[1][i];
-						int64_t d = (int64_t)dbf - (int64_t)dbr;
-						if (d < 0) d = -d;
-						if (d + QL2 > MAX_TL) continue;
-						const int fs = m[0].extend_pen(qf, dbf, plusf);
-						if (fs <= 0) continue;
-						const int rs = m[1].extend_pen(seed_q[1][i] & 0x7FFFu, dbr, !plusf);
-						if (rs <= 0) continue;
-						if (fs + rs < termPair) continue;
-						m[0].mapq = 40; m[1].mapq = 40; done = true;
+					for (int base = 0; base < nr && !done; base += 64) {
+						uint64_t mk = near_mask(1, base, nr, dbf);
+						while (mk && !done) {
+							const int i = base + __builtin_ctzll(mk);
+							mk &= mk - 1;
+							const int fs = m[0].extend_pen(qf, dbf, plusf);
+							if (fs <= 0) continue;
+							const int rs = m[1].extend_pen(seed_q[1][i] & 0x7FFFu, seed_db[1][i], !plusf);
+							if (rs <= 0) continue;
+							if (fs + rs < termPair) continue;
+							m[0].mapq = 40; m[1].mapq = 40; done = true;
+						}
 					}
 				}
 				if (t < nseed[1] && !done) {
 					const uint32_t qr = seed_q[1][t] & 0x7FFFu, dbr = seed_db[1][t];
 					const bool plusr = (seed_q[1][t] & 0x8000u) != 0;
 					const int nf = min(t + 1, nseed[0]);
-					for (int i = 0; i < nf && !done; ++i) {
-						const uint32_t dbf = seed_db[0][i];
-						int64_t d = (int64_t)dbf - (int64_t)dbr;
-						if (d < 0) d = -d;
-						if (d + QL2 > MAX_TL) continue;
-						const int fs = m[0].extend_pen(seed_q[0][i] & 0x7FFFu, dbf, !plusr);
-						if (fs <= 0) continue;
-						const int rs = m[1].extend_pen(qr, dbr, plusr);
-						if (rs <= 0) continue;
-						if (fs + rs < termPair) continue;
-						m[0].mapq = 40; m[1].mapq = 40; done = true;
+					for (int base = 0; base < nf && !done; base += 64) {
+						uint64_t mk = near_mask(0, base, nf, dbr);
+						while (mk && !done) {
+							const int i = base + __builtin_ctzll(mk);
+							mk &= mk - 1;
+							const int fs = m[0].extend_pen(seed_q[0][i] & 0x7FFFu, seed_db[0][i], !plusr);
+							if (fs <= 0) continue;
+							const int rs = m[1].extend_pen(qr, dbr, plusr);
+							if (rs <= 0) continue;
+							if (fs + rs < termPair) continue;
+							m[0].mapq = 40; m[1].mapq = 40; done = true;
+						}
 					}
 				}
 			}
