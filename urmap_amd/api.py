@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liburmapx.so")
+LIB_PATH = os.environ.get("URMAPX_LIB") or os.path.join(_HERE, "liburmapx.so")  # URMAPX_LIB: A/B builds
 
 MAX_QL = 320
 MAX_PATH_OPS = 48

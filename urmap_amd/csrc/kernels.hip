@@ -126,7 +126,7 @@ __global__ __launch_bounds__(64) void viterbi_batch_kernel(urmapx_params P, cons
 		__syncthreads();
 		WideScratch ws;
 		ws.carve(scratch + (size_t)k * scratch_stride, VB_WIDE_LA, VB_WIDE_LB);
-		score = viterbi_wave(P, sA, LA, b + boffs[k], LB, flags[k] & 1, (flags[k] >> 1) & 1, tb, VB_MAXL / 8 + 2, &ws, R,
+		score = viterbi_wave(VPar(P), sA, LA, b + boffs[k], LB, flags[k] & 1, (flags[k] >> 1) & 1, tb, VB_MAXL / 8 + 2, ws, R,
 		                     status, lane);
 	}
 	int nout = R.n;
@@ -318,11 +318,14 @@ struct SearchWave {
 		const int BR = 2 * (int)P.band_radius;
 		const uint32_t TL = X.seqDataSize;
 		uint32_t combinedTLo = startdb;
-		const uint8_t *Q = sQ[plus ? 0 : 1];
+		const uint8_t *Q = plus ? sQ[0] : sQ[1];
 		RevOps RL, RR;
 		RL.ops = ropsL; RR.ops = ropsR;
 		RL.begin(); RR.begin();
 		int rtrim = 0;
+		const VPar VP(P);
+		const WideScratch wsv = ws;
+		uint32_t vst = 0;
 
 		if (startq > 0) {
 			if (startdb < (uint32_t)startq) return;
@@ -332,7 +335,8 @@ struct SearchWave {
 			if (leftTL >= leftTHi) return;
 			const uint32_t leftTLo = leftTHi - leftTL + 1;
 			if (load_window(leftTLo, (int)leftTL)) return;
-			int leftScore = (int)viterbi_wave(P, Q, leftQL, sT, (int)leftTL, true, false, tb, TB_ROWS8, &ws, RL, status, lane);
+			int leftScore = (int)viterbi_wave(VP, Q, leftQL, sT, (int)leftTL, true, false, tb, TB_ROWS8, wsv, RL, vst, lane);
+			status |= vst;
 			// TrimLeftIs (pathinfo.cpp:153-171): the leading I run is the last run in traceback order
 			int nTrimI = 0;
 			if (RL.n > 0) {
@@ -354,7 +358,8 @@ struct SearchWave {
 			if (rightTHi >= TL) rightTHi = TL - 1;
 			const uint32_t rightTL = rightTHi - rightTLo + 1;
 			if (load_window(rightTLo, (int)rightTL)) return;
-			int rightScore = (int)viterbi_wave(P, Q + rightQLo, rightQL, sT, (int)rightTL, false, true, tb, TB_ROWS8, &ws, RR, status, lane);
+			int rightScore = (int)viterbi_wave(VP, Q + rightQLo, rightQL, sT, (int)rightTL, false, true, tb, TB_ROWS8, wsv, RR, vst, lane);
+			status |= vst;
 			// TrimRightIs (pathinfo.cpp:173-190): trailing I run = first run in traceback order, never the whole path
 			if (RR.n > 1 && (ropsR[0] & 3u) == OP_I) rtrim = 1;
 			int allGap = P.gap_open_score + (rightQL - 1) * P.gap_ext_score;
@@ -363,7 +368,7 @@ struct SearchWave {
 			totalPen += rightQL - rightScore;
 			if (totalPen > maxPen) return;
 		}
-		if (status & (URMAPX_ST_BAND_TOO_WIDE | URMAPX_ST_PATH_OVERFLOW)) return;
+		if (vst & (URMAPX_ST_BAND_TOO_WIDE | URMAPX_ST_PATH_OVERFLOW)) return;
 		// path = Left || M x len || Right, run-length merged, into cand (uniform; lane 0 stores)
 		int nc = 0, cop = -1, clen = 0;
 		bool ovf = false;
@@ -502,7 +507,7 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU) void search_se_kernel(DevI
 	__shared__ uint8_t sT[SW::QMAX + 64];
 	__shared__ uint32_t tb[SW::TB_ROWS8 * 64];
 	__shared__ uint16_t ropsL[OPS_CAP], ropsR[OPS_CAP], cand[URMAPX_MAX_PATH_OPS], top[URMAPX_MAX_PATH_OPS];
-	__shared__ uint16_t pre[SW::NSEG * 64 + 2];
+	__shared__ uint16_t pre[2 * SW::NSEG * 64 + 2];
 	__shared__ uint32_t hsp_db[HSP_CAP], hsp_ql[HSP_CAP];
 	__shared__ uint16_t hsp_sf[HSP_CAP];
 
@@ -553,24 +558,24 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU) void search_se_kernel(DevI
 		}
 		__syncthreads();
 
-		// probe results of this read, lane = query position mod 64
+		// BOTH1 seed positions of this read by [strand][query position] in LDS (tb is idle outside align_hsp); every
+		// other k-mer gets the sentinel.  Chain heads are re-read from the probe output when the walk starts.
 		const uint64_t base2 = 2ull * off;
-		uint32_t ppos[2][NCH], ptal[2][NCH];
+		uint32_t *xp = reinterpret_cast<uint32_t *>(tb);
 #pragma unroll
 		for (int s = 0; s < 2; ++s) {
 #pragma unroll
 			for (int c = 0; c < NCH; ++c) {
-				int p = 64 * c + lane;
-				uint32_t T = 0, ps = 0;
+				const int p = 64 * c + lane;
+				uint32_t v = 0xFFFFFFFFu;
 				if (p < nwords) {
-					uint64_t idx = base2 + (uint64_t)s * QL + p;
-					T = probe.tallies[idx];
-					ps = probe.positions[idx];
+					const uint64_t idx = base2 + (uint64_t)s * QL + p;
+					if (probe.tallies[idx] == TALLY_BOTH1) v = probe.positions[idx];
 				}
-				ppos[s][c] = ps;
-				ptal[s][c] = T;
+				xp[s * SW::QMAX + p] = v;
 			}
 		}
+		__syncthreads();
 
 		const int minScore1 = QL + P.xphase1 * P.mismatch_score;
 		const int minScore3 = QL + P.xphase3 * P.mismatch_score;
@@ -588,21 +593,16 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU) void search_se_kernel(DevI
 		};
 		lapc(0);
 
-		// BOTH1 seed positions by query position, for cross-lane fetches (tb is idle outside align_hsp)
-		uint32_t *xp = reinterpret_cast<uint32_t *>(tb);
-#pragma unroll
-		for (int c = 0; c < NCH; ++c) {
-			xp[64 * c + lane] = (ptal[0][c] == TALLY_BOTH1) ? ppos[0][c] : 0xFFFFFFFFu;
-			xp[SW::QMAX + 64 * c + lane] = (ptal[1][c] == TALLY_BOTH1) ? ppos[1][c] : 0xFFFFFFFFu;
-		}
 		// The six phases of Search_Lo as ONE loop, so that the gather/consume code and the DP code exist once
 		// (the kernel has to stay inside the instruction cache):
 		//   1, 2  BOTH1 seeds on / off the stride W      3  AlignHSP if the best HSP is long enough
 		//   4, 5  chain rows of length <= 2 / > 2        6  AlignHSP
+		// Phases 1+2 and 4+5 each form ONE candidate list (gathered together, so that batches stay full); the ordered
+		// part applies the phase boundary (exit test after phase 4) when it crosses it.
 		int rl[SW::NSEG];
 #pragma unroll
 		for (int g = 0; g < SW::NSEG; ++g) rl[g] = 0;
-		for (int step = 1; step <= 6 && !done; ++step) {
+		for (int step = 1; step <= 6 && !done; step += (step == 1 ? 2 : (step == 3 ? 1 : 2))) {  // 1 (=1+2), 3, 4 (=4+5), 6
 			phase = step;
 			if (step == 3 || step == 6) {
 				if (step == 6 || S.bestHSP > termHSP3) {
@@ -612,26 +612,31 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU) void search_se_kernel(DevI
 				lapc(step == 3 ? 2 : 6);
 				continue;
 			}
-			int cnt[SW::NSEG];
+			int cnt[2 * SW::NSEG];
 #pragma unroll
-			for (int g = 0; g < SW::NSEG; ++g) cnt[g] = 0;
-			if (step <= 2) {
+			for (int g = 0; g < 2 * SW::NSEG; ++g) cnt[g] = 0;
+			if (step == 1) {  // segments [0, NCH): phase 1 (stride positions), [NCH, 2 NCH): phase 2
 #pragma unroll
 				for (int c = 0; c < NCH; ++c) {
 					const int p = 64 * c + lane;
-					const bool sel = (p < nwords) && (((p % W) == 0) == (step == 1));
-					cnt[c] = sel ? ((ptal[0][c] == TALLY_BOTH1 ? 1 : 0) + (ptal[1][c] == TALLY_BOTH1 ? 1 : 0)) : 0;
+					const int nb1 = (xp[p] != 0xFFFFFFFFu ? 1 : 0) + (xp[SW::QMAX + p] != 0xFFFFFFFFu ? 1 : 0);
+					const bool onStride = (p % W) == 0;
+					cnt[c] = onStride ? nb1 : 0;
+					cnt[NCH + c] = onStride ? 0 : nb1;
 				}
-			} else {
-				if (step == 4) {  // walk every collision chain of the read once, one chain per lane and segment
-					S.walk_all(probe, base2, rl);
-					__syncthreads();
-					lapc(3);
-				}
+			} else {  // walk every collision chain once; segments [0, NSEG): rows <= 2 (phase 4), [NSEG, 2 NSEG): rows > 2 (phase 5)
+				S.walk_all(probe, base2, rl);
+				__syncthreads();
+				lapc(3);
 #pragma unroll
-				for (int g = 0; g < SW::NSEG; ++g) cnt[g] = (step == 4) ? (rl[g] <= 2 ? rl[g] : 0) : (rl[g] > 2 ? rl[g] : 0);
+				for (int g = 0; g < SW::NSEG; ++g) {
+					cnt[g] = rl[g] <= 2 ? rl[g] : 0;
+					cnt[SW::NSEG + g] = rl[g] > 2 ? rl[g] : 0;
+				}
 			}
-			const int total = S.template scan_counts<SW::NSEG>(cnt);
+			const int total = S.template scan_counts<2 * SW::NSEG>(cnt);
+			const int totalFirst = (int)S.pre[(step == 1 ? NCH : SW::NSEG) * 64];  // candidates of the first of the two phases
+			bool crossed = false;
 				for (int base = 0; base < total && !done; base += 64) {
 					uint64_t tsub = stats ? __builtin_amdgcn_s_memtime() : 0;
 					auto laps = [&](int slot) {
@@ -648,14 +653,17 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU) void search_se_kernel(DevI
 					for (int c = 0; c < NCH; ++c) mm[c] = 0;
 					if (g < total) {
 						int row, k;
-						S.locate(g, SW::NSEG * 64, row, k);
-						if (step <= 2) {  // BOTH1 seeds: plus-strand seed first, then minus (search1m6.cpp:69-108)
+						S.locate(g, 2 * SW::NSEG * 64, row, k);
+						if (step == 1) {  // BOTH1 seeds: plus-strand seed first, then minus (search1m6.cpp:69-108)
+							if (row >= NCH * 64) row -= NCH * 64;
 							c_qpos = (uint32_t)row;
 							const uint32_t pp = xp[row], pm = xp[SW::QMAX + row];
 							if (k == 0 && pp != 0xFFFFFFFFu) { c_plus = true; c_db = pp; }
 							else { c_plus = false; c_db = pm; }
 						} else {  // chain rows: [strand][chunk][k][lane]
-							const int seg = row >> 6, l = row & 63;
+							int seg = row >> 6;
+							const int l = row & 63;
+							if (seg >= SW::NSEG) seg -= SW::NSEG;
 							c_plus = seg < NCH;
 							c_qpos = (uint32_t)((seg - (c_plus ? 0 : NCH)) * 64 + l);
 							c_db = S.rowstore[((size_t)seg * ROW_CAP + k) * 64 + l];
@@ -711,6 +719,10 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU) void search_se_kernel(DevI
 					while (todo) {
 						const int t = __builtin_ctzll(todo);
 						todo &= todo - 1;
+						if (base + t >= totalFirst && !crossed) {  // first candidate of the second phase of this list
+							crossed = true;
+							if (step == 4 && S.best >= minScore3) { done = true; break; }  // exit test between phases 4 and 5
+						}
 						const uint32_t dblo = rdlane(c_db, t) - rdlane(c_qpos, t);
 						if (S.overlaps_hit(dblo)) continue;          // extendpen.cpp:15-17
 						if (rdlane(e_pen, t) > S.maxPen) continue;   // extendpen.cpp:43-44,69-70
@@ -718,7 +730,7 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU) void search_se_kernel(DevI
 						const int bst = rdlane(e_bst, t);
 						if (rdlane(e_kind, t) == 1) {
 							S.add_hit(dblo, pl, bst, 0);
-							if (step <= 2 && bst >= minScore1) { done = true; break; }
+							if (step == 1 && bst >= minScore1) { done = true; phase = crossed ? 2 : 1; break; }
 						} else {
 							const int sp = rdlane(e_start, t), ep = rdlane(e_end, t);
 							S.add_hsp((uint32_t)sp, dblo + (uint32_t)sp, pl, (uint32_t)(ep - sp + 1), bst);
@@ -727,9 +739,12 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU) void search_se_kernel(DevI
 					laps(11);
 				}
 
-			if (step == 2) lapc(1);
-			if (step == 4) { lapc(4); if (S.best >= minScore3) done = true; }
-			if (step == 5) { lapc(5); if (S.best >= minScore4) done = true; }
+			if (step == 1) { lapc(1); if (!done) phase = 2; }
+			if (step == 4) {
+				lapc(4);
+				if (!done && !crossed && S.best >= minScore3) done = true;  // no state-changing phase-5 candidate was met
+				if (!done) { phase = 5; if (S.best >= minScore4) done = true; }
+			}
 		}
 		lapc(6);
 		res.mapq = (uint8_t)S.calc_mapq();

@@ -231,7 +231,7 @@ struct Mate {
 		const int BR = 2 * (int)P->band_radius;
 		const uint32_t TL = X->seqDataSize;
 		uint32_t combinedTLo = startdb;
-		const uint8_t *Q = sQ[plus ? 0 : 1];
+		const uint8_t *Q = plus ? sQ[0] : sQ[1];
 		RevOps RL, RR;
 		RL.ops = ropsL; RR.ops = ropsR;
 		RL.begin(); RR.begin();
@@ -245,7 +245,7 @@ struct Mate {
 			if (leftTL >= leftTHi) return -1;
 			const uint32_t leftTLo = leftTHi - leftTL + 1;
 			if (load_window(leftTLo, (int)leftTL)) return -1;
-			int leftScore = (int)viterbi_wave(*P, Q, leftQL, sT, (int)leftTL, true, false, tb, TB_ROWS8, &ws, RL, vst, lane);
+			int leftScore = (int)viterbi_wave(VPar(*P), Q, leftQL, sT, (int)leftTL, true, false, tb, TB_ROWS8, ws, RL, vst, lane);
 			status |= vst;
 			int nTrimI = 0;
 			if (RL.n > 0) {
@@ -267,7 +267,7 @@ struct Mate {
 			if (rightTHi >= TL) rightTHi = TL - 1;
 			const uint32_t rightTL = rightTHi - rightTLo + 1;
 			if (load_window(rightTLo, (int)rightTL)) return -1;
-			int rightScore = (int)viterbi_wave(*P, Q + rightQLo, rightQL, sT, (int)rightTL, false, true, tb, TB_ROWS8, &ws, RR, vst, lane);
+			int rightScore = (int)viterbi_wave(VPar(*P), Q + rightQLo, rightQL, sT, (int)rightTL, false, true, tb, TB_ROWS8, ws, RR, vst, lane);
 			status |= vst;
 			if (RR.n > 1 && (ropsR[0] & 3u) == OP_I) rtrim = 1;
 			int allGap = P->gap_open_score + (rightQL - 1) * P->gap_ext_score;
@@ -455,7 +455,7 @@ struct Mate {
 		R.ops = ropsL;
 		uint32_t vst = 0;
 		// whole read against the window: a band far wider than a wavefront -> wide path (B read from global memory)
-		const float score = viterbi_wave(*P, sQ[plus ? 0 : 1], QL, gseq + dbpos, (int)seglen, true, true, tb, TB_ROWS8, &ws, R, vst, lane);
+		const float score = viterbi_wave(VPar(*P), plus ? sQ[0] : sQ[1], QL, gseq + dbpos, (int)seglen, true, true, tb, TB_ROWS8, ws, R, vst, lane);
 		status |= vst;
 		if (vst) return;
 		if ((double)score >= (double)QL / 3.0) {

@@ -24,6 +24,14 @@ struct WideScratch {
 	}
 };
 
+// Scoring constants the DP needs, by value (a reference to the kernel's parameter block would pin it in scratch).
+struct VPar {
+	int gap_open_score, gap_ext_score, mismatch_score, band_radius;
+	__device__ __forceinline__ VPar(const urmapx_params &P)
+	    : gap_open_score(P.gap_open_score), gap_ext_score(P.gap_ext_score), mismatch_score(P.mismatch_score),
+	      band_radius((int)P.band_radius) {}
+};
+
 struct RevOps {  // run-length path, traceback order (last column first)
 	uint16_t *ops;  // LDS, OPS_CAP entries
 	int n;
@@ -60,12 +68,12 @@ struct RevOps {  // run-length path, traceback order (last column first)
 
 // A, B, tb: LDS of this wavefront.  tb holds (tb_rows8*64) dwords: 8 rows of 4-bit trace cells per dword.
 // Returns the score; R receives the path in traceback order.  status gets URMAPX_ST_* bits.
-__device__ float viterbi_wide(const urmapx_params &P, const uint8_t *A, int LA, const uint8_t *B, int LB, bool Left,
-                              bool Right, const WideScratch &ws, RevOps &R, uint32_t &status, int lane);
+__device__ __forceinline__ float viterbi_wide(const VPar P, const uint8_t *A, int LA, const uint8_t *B, int LB, bool Left, bool Right,
+                              const WideScratch ws, RevOps &R, uint32_t &status, int lane);
 
-__device__ float viterbi_wave(const urmapx_params &P, const uint8_t *A, int LA, const uint8_t *B, int LB, bool Left,
-                              bool Right, uint32_t *tb, int tb_rows8, const WideScratch *ws, RevOps &R,
-                              uint32_t &status, int lane) {
+// ws.la_cap == 0: no wide-band scratch (the band must fit one wavefront).
+__device__ __forceinline__ float viterbi_wave(const VPar P, const uint8_t *A, int LA, const uint8_t *B, int LB, bool Left, bool Right,
+                              uint32_t *tb, int tb_rows8, const WideScratch ws, RevOps &R, uint32_t &status, int lane) {
 	R.begin();
 	const float GO = (float)P.gap_open_score, GE = (float)P.gap_ext_score;
 	if (LA == 0 || LB == 0) {
@@ -74,7 +82,7 @@ __device__ float viterbi_wave(const urmapx_params &P, const uint8_t *A, int LA, 
 		R.emit_run(OP_D, LA, lane); R.end(lane);
 		return (float)(P.gap_open_score + (LA - 1) * P.gap_ext_score);
 	}
-	const int Rad = (int)P.band_radius;
+	const int Rad = P.band_radius;
 	int dlo = min(LA, LB), dhi = max(LA, LB);
 	dlo = dlo > Rad ? dlo - Rad : 1;
 	dhi += Rad;
@@ -82,7 +90,7 @@ __device__ float viterbi_wave(const urmapx_params &P, const uint8_t *A, int LA, 
 	const int ND = dhi - dlo + 1;
 	// lanes: 0 = column Startj-1, 1..ND = band, ND+1 = column LB; final cells sit at lanes LB-dlo .. LB-dlo+2
 	if (ND + 2 > 64 || LB - dlo + 2 > 63 || ((LA + 1 + 7) >> 3) > tb_rows8) {
-		if (ws && LA <= ws->la_cap && LB <= ws->lb_cap) return viterbi_wide(P, A, LA, B, LB, Left, Right, *ws, R, status, lane);
+		if (LA <= ws.la_cap && LB <= ws.lb_cap) return viterbi_wide(P, A, LA, B, LB, Left, Right, ws, R, status, lane);
 		status |= URMAPX_ST_BAND_TOO_WIDE;
 		return 0.0f;
 	}
@@ -191,10 +199,10 @@ __device__ float viterbi_wave(const urmapx_params &P, const uint8_t *A, int LA, 
 // Wide-band fallback (band wider than one wavefront: a flank window clipped at the end of the sequence store,
 // or the paired-end rescue's whole-read DP).  Same recurrences, lanes = 64 consecutive columns of a row, the
 // in-row insert chain carried from chunk to chunk; rows and trace cells live in global scratch.  Rare and slow.
-__device__ float viterbi_wide(const urmapx_params &P, const uint8_t *A, int LA, const uint8_t *B, int LB, bool Left,
-                              bool Right, const WideScratch &ws, RevOps &R, uint32_t &status, int lane) {
+__device__ __forceinline__ float viterbi_wide(const VPar P, const uint8_t *A, int LA, const uint8_t *B, int LB, bool Left, bool Right,
+                              const WideScratch ws, RevOps &R, uint32_t &status, int lane) {
 	const float GO = (float)P.gap_open_score, GE = (float)P.gap_ext_score;
-	const int Rad = (int)P.band_radius;
+	const int Rad = P.band_radius;
 	int dlo = min(LA, LB), dhi = max(LA, LB);
 	dlo = dlo > Rad ? dlo - Rad : 1;
 	dhi += Rad;
