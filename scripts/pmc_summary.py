@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Summarise a rocprofv3 --pmc run: per kernel and counter, the average counter value per dispatch.
+
+usage: pmc_summary.py <rocprofv3 output dir> [out.json]
+Reads every *counter_collection.csv under the directory (columns Kernel_Name, Counter_Name, Counter_Value).
+"""
+import csv, glob, json, os, sys
+from collections import defaultdict
+
+
+def main():
+    d = sys.argv[1]
+    acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
+    files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+    for f in files:
+        with open(f, newline="") as fh:
+            for row in csv.DictReader(fh):
+                k = row["Kernel_Name"].split("(")[0]
+                for short in ("search_se_kernel", "search_pe_kernel", "seed_probe_kernel", "viterbi_batch_kernel"):
+                    if short in k:
+                        k = short
+                a = acc[k][row["Counter_Name"]]
+                a[0] += float(row["Counter_Value"])
+                a[1] += 1
+    out = {k: {c: {"avg": v[0] / v[1], "dispatches": v[1]} for c, v in cs.items()} for k, cs in acc.items()
+           if k in ("search_se_kernel", "search_pe_kernel", "seed_probe_kernel", "viterbi_batch_kernel")}
+    s = json.dumps(out, indent=1, sort_keys=True)
+    if len(sys.argv) > 2:
+        open(sys.argv[2], "w").write(s + "\n")
+    print(s)
+
+
+if __name__ == "__main__":
+    main()

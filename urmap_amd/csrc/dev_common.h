@@ -169,6 +169,67 @@ struct BitVec {
 	}
 };
 
+// ExtendPen's two x-drop walks (extendpen.cpp:25-78) over a precomputed mismatch bit vector, one candidate per lane,
+// WITHOUT the running penalty cap (the caller compares the final penalty: it only grows along the walk).
+// The walk visits mismatches only.  The loop over the N words is wave-uniform and unrolled; inside a word the set
+// bits are consumed one by one (x &= x - 1), so an iteration is ~20 VALU instructions with no word selection.
+template <int N>
+__device__ __forceinline__ void xdrop_walk_lane(const uint64_t (&w)[N], int qpos, int W, int QL, int mis, int xdrop,
+                                                int &bst_out, int &startpos_out, int &endpos_out, int &pen_out) {
+	int score = W, bst = 0, pen = 0;
+	int endpos = qpos + W - 1;
+	int cur = endpos + 1;
+	bool alive = cur < QL;
+#pragma unroll
+	for (int c = 0; c < N; ++c) {
+		uint64_t x = w[c];
+		const int lo = cur - 64 * c;  // first wanted bit of this word
+		if (!alive || lo >= 64) x = 0;
+		else if (lo > 0) x &= ~0ull << lo;
+		while (x) {
+			const int m = 64 * c + __builtin_ctzll(x);
+			x &= x - 1;
+			if (m >= QL) break;  // padding bits past the read: the tail run below ends the walk
+			const int run = m - cur;
+			if (run > 0) { score += run; if (score > bst) { bst = score; endpos = m - 1; } }
+			pen -= mis;
+			score += mis;
+			cur = m + 1;
+			if (bst - score > xdrop) { alive = false; break; }
+		}
+	}
+	if (alive) {  // no mismatch left: the run to the end of the read
+		const int run = QL - cur;
+		if (run > 0) { score += run; if (score > bst) { bst = score; endpos = QL - 1; } }
+	}
+	int startpos = qpos;
+	cur = startpos - 1;
+	alive = cur >= 0;
+#pragma unroll
+	for (int c = N - 1; c >= 0; --c) {
+		uint64_t x = w[c];
+		const int hi = cur - 64 * c;  // last wanted bit of this word
+		if (!alive || hi < 0) x = 0;
+		else if (hi < 63) x &= ~0ull >> (63 - hi);
+		while (x) {
+			const int b = 63 - __builtin_clzll(x);
+			const int m = 64 * c + b;
+			x ^= 1ull << b;
+			const int run = cur - m;
+			if (run > 0) { score += run; if (score > bst) { bst = score; startpos = m + 1; } }
+			pen -= mis;
+			score += mis;
+			cur = m - 1;
+			if (bst - score > xdrop) { alive = false; break; }
+		}
+	}
+	if (alive) {
+		const int run = cur + 1;  // down to position 0
+		if (run > 0) { score += run; if (score > bst) { bst = score; startpos = 0; } }
+	}
+	bst_out = bst; startpos_out = startpos; endpos_out = endpos; pen_out = pen;
+}
+
 // inclusive prefix sum of a non-negative int over the 64 lanes (DPP, same ladder as wave_prefix_max)
 template <int CTRL, int ROWMASK>
 __device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, ROWMASK, 0xF, false); }
@@ -186,13 +247,9 @@ __device__ __forceinline__ int wave_prefix_sum(int v) {
 typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 __device__ __forceinline__ u32x4_a4 load4_a4(const uint32_t *p) { return *reinterpret_cast<const u32x4_a4 *>(p); }
 
-// bit i of the result = byte i of x is non-zero
-__device__ __forceinline__ uint32_t nonzero_bytes(uint32_t x) {
-	uint32_t y = x | (x >> 4);
-	y |= y >> 2;
-	y |= y >> 1;
-	y &= 0x01010101u;
-	return ((y * 0x00204081u) >> 21) & 15u;
+// bit 7 of every non-zero byte of x (exact per byte: no carry crosses a byte boundary)
+__device__ __forceinline__ uint32_t nonzero_bytes_b7(uint32_t x) {
+	return (((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;
 }
 
 // Mismatch bit vector of a whole read against the reference window starting at seq+dblo, computed by ONE lane
@@ -204,12 +261,13 @@ __device__ __forceinline__ void lane_mismatch_mask(const uint8_t *__restrict__ s
 	const uint32_t sh = dblo & 3u;
 	const uint32_t *p = reinterpret_cast<const uint32_t *>(seq + (dblo & ~3u));
 	const uint4 *q4 = reinterpret_cast<const uint4 *>(q16);
-	// all window loads are issued before any is used (the sequence store is padded, so reading the whole
-	// 64*NCH-byte span is safe whatever QL is); bits at or beyond QL are cleared at the end
+	// all window loads are issued before any is used (16-byte granules up to QL; the sequence store is padded);
+	// bits at or beyond QL are cleared at the end
 	uint32_t first = p[0];
 	u32x4_a4 v[4 * NCH];
 #pragma unroll
-	for (int g = 0; g < 4 * NCH; ++g) v[g] = load4_a4(p + 1 + 4 * g);
+	for (int g = 0; g < 4 * NCH; ++g)
+		if (16 * g < QL) v[g] = load4_a4(p + 1 + 4 * g);  // wave-uniform: the whole wavefront works on one read
 	uint32_t prev = first;
 #pragma unroll
 	for (int c = 0; c < NCH; ++c) {
@@ -217,15 +275,21 @@ __device__ __forceinline__ void lane_mismatch_mask(const uint8_t *__restrict__ s
 #pragma unroll
 		for (int gg = 0; gg < 4; ++gg) {
 			const int g = 4 * c + gg;
-			const uint4 q = q4[g];
-			const uint32_t t0 = __builtin_amdgcn_alignbyte(v[g].x, prev, sh);
-			const uint32_t t1 = __builtin_amdgcn_alignbyte(v[g].y, v[g].x, sh);
-			const uint32_t t2 = __builtin_amdgcn_alignbyte(v[g].z, v[g].y, sh);
-			const uint32_t t3 = __builtin_amdgcn_alignbyte(v[g].w, v[g].z, sh);
+			if (16 * g < QL) {  // wave-uniform: the whole wavefront works on one read
+				const uint4 q = q4[g];
+				const uint32_t t0 = __builtin_amdgcn_alignbyte(v[g].x, prev, sh);
+				const uint32_t t1 = __builtin_amdgcn_alignbyte(v[g].y, v[g].x, sh);
+				const uint32_t t2 = __builtin_amdgcn_alignbyte(v[g].z, v[g].y, sh);
+				const uint32_t t3 = __builtin_amdgcn_alignbyte(v[g].w, v[g].z, sh);
+				// v_dot4_u32_u8 gathers the per-byte flags (0 or 128) of two dwords into 128 * (8-bit mask)
+				uint32_t lo = __builtin_amdgcn_udot4(nonzero_bytes_b7(t0 ^ q.x), 0x08040201u, 0u, false);
+				lo = __builtin_amdgcn_udot4(nonzero_bytes_b7(t1 ^ q.y), 0x80402010u, lo, false);
+				uint32_t hi = __builtin_amdgcn_udot4(nonzero_bytes_b7(t2 ^ q.z), 0x08040201u, 0u, false);
+				hi = __builtin_amdgcn_udot4(nonzero_bytes_b7(t3 ^ q.w), 0x80402010u, hi, false);
+				const uint32_t bits = (lo >> 7) | ((hi << 1) & 0xFF00u);
+				w |= (uint64_t)bits << (16 * gg);
+			}
 			prev = v[g].w;
-			const uint32_t bits = nonzero_bytes(t0 ^ q.x) | (nonzero_bytes(t1 ^ q.y) << 4) | (nonzero_bytes(t2 ^ q.z) << 8) |
-			                      (nonzero_bytes(t3 ^ q.w) << 12);
-			w |= (uint64_t)bits << (16 * gg);
 		}
 		const int rem = QL - 64 * c;
 		if (rem <= 0) w = 0;

@@ -242,52 +242,6 @@ struct SearchWave {
 		if (score > bestHSP) bestHSP = score;
 	}
 
-	// extendpen.cpp:9-95 on a precomputed mismatch vector
-	__device__ __forceinline__ int extend_pen(const BitVec<NCH> &mm, uint32_t seedq, uint32_t seeddb, bool plus) {
-		if (seeddb < seedq) return -1;
-		const uint32_t dblo = seeddb - seedq;
-		if (overlaps_hit(dblo)) return -1;
-		const int mis = P.mismatch_score, xdrop = P.xdrop;
-		int pen = 0, score = W, bst = 0;
-		int endpos = (int)seedq + W - 1;
-		int cur = endpos + 1;
-		while (cur < QL) {
-			int m = mm.next_set(cur);
-			if (m > QL) m = QL;
-			int run = m - cur;
-			if (run > 0) { score += run; if (score > bst) { bst = score; endpos = m - 1; } }
-			if (m >= QL) break;
-			pen -= mis;
-			if (pen > maxPen) return -1;
-			score += mis;
-			if (bst - score > xdrop) break;
-			cur = m + 1;
-		}
-		int startpos = (int)seedq;
-		cur = startpos - 1;
-		while (cur >= 0) {
-			int m = mm.prev_set(cur);
-			int run = cur - m;
-			if (run > 0) { score += run; if (score > bst) { bst = score; startpos = m + 1; } }
-			if (m < 0) break;
-			pen -= mis;
-			if (pen > maxPen) return -1;
-			score += mis;
-			if (bst - score > xdrop) break;
-			cur = m - 1;
-		}
-		if (startpos == 0 && endpos == QL - 1) {
-			add_hit(dblo, plus, bst, 0);
-			return bst;
-		}
-		const int minhsp = (int)((uint32_t)P.min_hsp_score_pct * (uint32_t)QL / 100.0);
-		if (bst >= minhsp) {
-			add_hsp((uint32_t)startpos, dblo + (uint32_t)startpos, plus, (uint32_t)(endpos - startpos + 1), bst);
-			return -2;
-		}
-		return -1;
-	}
-
 	// load a target window into LDS; returns true if it contains a '-' pad byte
 	__device__ __forceinline__ bool load_window(uint32_t tlo, int tl) {
 		bool gap = false;
@@ -513,6 +467,8 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU) void search_se_kernel(DevI
 
 	const int lane = threadIdx.x;
 	const int W = (int)X.W;
+	const int dbg_stop = stats ? (int)stats[0] : 0;  // diagnostic only (URMAPX_DEBUG_STOP)
+	const bool timing = stats && stats[1] == 0;
 	SW S(X, P, lane);
 	S.W = W;
 	S.gseq = g_seq; S.gblob = g_blob;
@@ -584,9 +540,9 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU) void search_se_kernel(DevI
 		const int minhsp = (int)((uint32_t)P.min_hsp_score_pct * (uint32_t)QL / 100.0);
 		int phase = 1;
 		bool done = false;
-		uint64_t tstamp = stats ? __builtin_amdgcn_s_memtime() : 0;
+		uint64_t tstamp = timing ? __builtin_amdgcn_s_memtime() : 0;
 		auto lapc = [&](int slot) {
-			if (!stats) return;
+			if (!timing) return;
 			uint64_t now = __builtin_amdgcn_s_memtime();
 			if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long *>(stats) + 1 + slot, (unsigned long long)(now - tstamp));
 			tstamp = now;
@@ -604,6 +560,7 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU) void search_se_kernel(DevI
 		for (int g = 0; g < SW::NSEG; ++g) rl[g] = 0;
 		for (int step = 1; step <= 6 && !done; step += (step == 1 ? 2 : (step == 3 ? 1 : 2))) {  // 1 (=1+2), 3, 4 (=4+5), 6
 			phase = step;
+			if (dbg_stop && step > dbg_stop) break;
 			if (step == 3 || step == 6) {
 				if (step == 6 || S.bestHSP > termHSP3) {
 					for (int k = 0; k < S.hspCount; ++k) S.align_hsp(k);
@@ -628,6 +585,7 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU) void search_se_kernel(DevI
 				S.walk_all(probe, base2, rl);
 				__syncthreads();
 				lapc(3);
+				if (dbg_stop == 104) break;
 #pragma unroll
 				for (int g = 0; g < SW::NSEG; ++g) {
 					cnt[g] = rl[g] <= 2 ? rl[g] : 0;
@@ -638,9 +596,9 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU) void search_se_kernel(DevI
 			const int totalFirst = (int)S.pre[(step == 1 ? NCH : SW::NSEG) * 64];  // candidates of the first of the two phases
 			bool crossed = false;
 				for (int base = 0; base < total && !done; base += 64) {
-					uint64_t tsub = stats ? __builtin_amdgcn_s_memtime() : 0;
+					uint64_t tsub = timing ? __builtin_amdgcn_s_memtime() : 0;
 					auto laps = [&](int slot) {
-						if (!stats) return;
+						if (!timing) return;
 						uint64_t now = __builtin_amdgcn_s_memtime();
 						if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long *>(stats) + 1 + slot, (unsigned long long)(now - tsub));
 						tsub = now;
@@ -679,43 +637,15 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU) void search_se_kernel(DevI
 					// iff the uncapped walk's final penalty exceeds the cap -- which is checked in order below.
 					int e_kind = 0, e_bst = 0, e_start = 0, e_end = 0, e_pen = 0;
 					if (c_ok) {
-						BitVec<NCH> bv;
-	#pragma unroll
-						for (int c = 0; c < NCH; ++c) bv.w[c] = mm[c];
-						const int mis = P.mismatch_score, xdrop = P.xdrop;
-						int score = W, bst = 0, pen = 0;
-						int endpos = (int)c_qpos + W - 1;
-						int cur = endpos + 1;
-						while (cur < QL) {
-							int m = bv.next_set(cur);
-							if (m > QL) m = QL;
-							const int run = m - cur;
-							if (run > 0) { score += run; if (score > bst) { bst = score; endpos = m - 1; } }
-							if (m >= QL) break;
-							pen -= mis;
-							score += mis;
-							if (bst - score > xdrop) break;
-							cur = m + 1;
-						}
-						int startpos = (int)c_qpos;
-						cur = startpos - 1;
-						while (cur >= 0) {
-							const int m = bv.prev_set(cur);
-							const int run = cur - m;
-							if (run > 0) { score += run; if (score > bst) { bst = score; startpos = m + 1; } }
-							if (m < 0) break;
-							pen -= mis;
-							score += mis;
-							if (bst - score > xdrop) break;
-							cur = m - 1;
-						}
-						if (startpos == 0 && endpos == QL - 1) e_kind = 1;
-						else if (bst >= minhsp) e_kind = 2;
-						e_bst = bst; e_start = startpos; e_end = endpos; e_pen = pen;
+						xdrop_walk_lane<NCH>(mm, (int)c_qpos, W, QL, P.mismatch_score, P.xdrop, e_bst, e_start, e_end, e_pen);
+						if (e_start == 0 && e_end == QL - 1) e_kind = 1;
+						else if (e_bst >= minhsp) e_kind = 2;
 					}
 					laps(10);
 					// order-dependent part: only candidates that can change the state, in the reference's order
-					uint64_t todo = __ballot(e_kind != 0);
+					// (lanes that cannot change it are dropped up front: the penalty cap only falls and the best score only
+					// rises, so a candidate failing extendpen.cpp:43-44 or state1.cpp:555 now fails it at its turn too)
+					uint64_t todo = __ballot(e_kind != 0 && e_pen <= S.maxPen && !(e_kind == 2 && e_bst < S.best - 4));
 					while (todo) {
 						const int t = __builtin_ctzll(todo);
 						todo &= todo - 1;
@@ -822,7 +752,7 @@ hipError_t launch_search_se(const DevIndex &X, const urmapx_params &P, const uin
 	if (n == 0) return hipSuccess;
 	const int nch = nch_for(max_read_len);
 	if (wk.stats) {
-		hipError_t e = hipMemsetAsync(wk.stats, 0, 192, s);
+		hipError_t e = hipMemsetAsync(wk.stats + 2, 0, 184, s);
 		if (e != hipSuccess) return e;
 	}
 	dim3 block(64), grid((unsigned)wk.blocks);

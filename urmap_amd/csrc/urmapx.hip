@@ -333,7 +333,14 @@ int urmapx_map_se_device(urmapx_ctx *C, const void *d_bases, const void *d_offs,
 	if ((rc = C->scratch.ensure(wk.scratch_stride * (size_t)wk.blocks))) return rc;
 	if ((rc = C->statsbuf.ensure(64))) return rc;
 	wk.scratch = C->scratch.p;
-	wk.stats = getenv("URMAPX_PHASE_STATS") ? C->statsbuf.p : nullptr;
+	// diagnostics: URMAPX_PHASE_STATS = per-phase cycle counters; URMAPX_DEBUG_STOP=N = cut the schedule after step N
+	// (results are then NOT the reference's).  Words 0/1 of the buffer: stop step, "no timing" flag.
+	const char *ds = getenv("URMAPX_DEBUG_STOP");
+	wk.stats = (getenv("URMAPX_PHASE_STATS") || ds) ? C->statsbuf.p : nullptr;
+	if (wk.stats) {
+		const uint32_t ctl[2] = {ds ? (uint32_t)atoi(ds) : 0u, getenv("URMAPX_PHASE_STATS") ? 0u : 1u};
+		HIP_TRY(hipMemcpyAsync(C->statsbuf.p, ctl, 8, hipMemcpyHostToDevice, C->stream));
+	}
 	HIP_TRY(hipMemsetAsync(d_path_used, 0, 4, C->stream));
 	HIP_TRY(hipEventRecord(C->ev[0], C->stream));
 	HIP_TRY(launch_seed_probe(C->X, (const uint8_t *)d_bases, (const uint64_t *)d_offs, n, max_read_len, po, C->stream));
