@@ -188,6 +188,13 @@ struct SearchWave {
 		return __ballot(lane < hitCount && (hit_db >> 6) == (db >> 6)) != 0;
 	}
 
+	// per-lane form: does this lane's diagonal start fall in the 64-base block of any hit found so far
+	__device__ __forceinline__ bool overlaps_any_hit(uint32_t db) const {
+		bool ov = false;
+		for (int k = 0; k < hitCount; ++k) ov |= (rdlane(hit_db, k) >> 6) == (db >> 6);
+		return ov;
+	}
+
 	// state1.cpp:508-551.  path (if any) is in `cand` with cand_nops runs.
 	__device__ __forceinline__ void add_hit(uint32_t db, bool plus, int score, int cand_nops) {
 		if (score < 10) return;
@@ -464,6 +471,8 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU) void search_se_kernel(DevI
 	__shared__ uint16_t pre[2 * SW::NSEG * 64 + 2];
 	__shared__ uint32_t hsp_db[HSP_CAP], hsp_ql[HSP_CAP];
 	__shared__ uint16_t hsp_sf[HSP_CAP];
+	__shared__ uint32_t cq_db[128];  // candidate queue (ring): reference position, query position | plus << 14 | second phase << 15
+	__shared__ uint16_t cq_qp[128];
 
 	const int lane = threadIdx.x;
 	const int W = (int)X.W;
@@ -595,79 +604,115 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU) void search_se_kernel(DevI
 			const int total = S.template scan_counts<2 * SW::NSEG>(cnt);
 			const int totalFirst = (int)S.pre[(step == 1 ? NCH : SW::NSEG) * 64];  // candidates of the first of the two phases
 			bool crossed = false;
-				for (int base = 0; base < total && !done; base += 64) {
-					uint64_t tsub = timing ? __builtin_amdgcn_s_memtime() : 0;
-					auto laps = [&](int slot) {
-						if (!timing) return;
-						uint64_t now = __builtin_amdgcn_s_memtime();
-						if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long *>(stats) + 1 + slot, (unsigned long long)(now - tsub));
-						tsub = now;
-					};
-					const int g = base + lane;
-					uint32_t c_qpos = 0, c_db = 0;
-					bool c_plus = true, c_ok = false;
-					uint64_t mm[NCH];
-	#pragma unroll
-					for (int c = 0; c < NCH; ++c) mm[c] = 0;
+			// The candidate stream is first filtered -- a candidate on the 64-base diagonal block of a hit already found
+			// returns at once in the reference (extendpen.cpp:15-17), and hits are never removed -- and the survivors are
+			// compacted, in order, into a small LDS queue; gather/consume then always run on full batches.
+			int scanned = 0, qhead = 0, qcount = 0;
+			while (!done && (scanned < total || qcount > 0)) {
+				uint64_t tsub = timing ? __builtin_amdgcn_s_memtime() : 0;
+				auto laps = [&](int slot) {
+					if (!timing) return;
+					uint64_t now = __builtin_amdgcn_s_memtime();
+					if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long *>(stats) + 1 + slot, (unsigned long long)(now - tsub));
+					tsub = now;
+				};
+				while (qcount < 64 && scanned < total) {
+					const int g = scanned + lane;
+					uint32_t s_qpos = 0, s_db = 0;
+					bool s_plus = true, ok = false;
 					if (g < total) {
 						int row, k;
 						S.locate(g, 2 * SW::NSEG * 64, row, k);
 						if (step == 1) {  // BOTH1 seeds: plus-strand seed first, then minus (search1m6.cpp:69-108)
 							if (row >= NCH * 64) row -= NCH * 64;
-							c_qpos = (uint32_t)row;
+							s_qpos = (uint32_t)row;
 							const uint32_t pp = xp[row], pm = xp[SW::QMAX + row];
-							if (k == 0 && pp != 0xFFFFFFFFu) { c_plus = true; c_db = pp; }
-							else { c_plus = false; c_db = pm; }
+							if (k == 0 && pp != 0xFFFFFFFFu) { s_plus = true; s_db = pp; }
+							else { s_plus = false; s_db = pm; }
 						} else {  // chain rows: [strand][chunk][k][lane]
 							int seg = row >> 6;
 							const int l = row & 63;
 							if (seg >= SW::NSEG) seg -= SW::NSEG;
-							c_plus = seg < NCH;
-							c_qpos = (uint32_t)((seg - (c_plus ? 0 : NCH)) * 64 + l);
-							c_db = S.rowstore[((size_t)seg * ROW_CAP + k) * 64 + l];
+							s_plus = seg < NCH;
+							s_qpos = (uint32_t)((seg - (s_plus ? 0 : NCH)) * 64 + l);
+							s_db = S.rowstore[((size_t)seg * ROW_CAP + k) * 64 + l];
 						}
-						c_ok = c_db >= c_qpos;
-						laps(8);
-						if (c_ok) lane_mismatch_mask<NCH>(seq, c_db - c_qpos, sQ2 + (c_plus ? 0 : SW::QMAX), QL, mm);
+						ok = s_db >= s_qpos;  // extendpen.cpp:12-13
 					}
-					__builtin_amdgcn_s_waitcnt(0);
-					laps(9);
-					// ExtendPen's two x-drop walks (extendpen.cpp:25-78), every lane on its own bit vector, WITHOUT the
-					// running penalty cap: the accumulated penalty only grows along the walk, so the capped walk aborts
-					// iff the uncapped walk's final penalty exceeds the cap -- which is checked in order below.
-					int e_kind = 0, e_bst = 0, e_start = 0, e_end = 0, e_pen = 0;
-					if (c_ok) {
-						xdrop_walk_lane<NCH>(mm, (int)c_qpos, W, QL, P.mismatch_score, P.xdrop, e_bst, e_start, e_end, e_pen);
-						if (e_start == 0 && e_end == QL - 1) e_kind = 1;
-						else if (e_bst >= minhsp) e_kind = 2;
+					ok = ok && !S.overlaps_any_hit(s_db - s_qpos);
+					const uint64_t m = __ballot(ok);
+					if (ok) {
+						const int pos = (qhead + qcount + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))) & 127;
+						cq_db[pos] = s_db;
+						cq_qp[pos] = (uint16_t)(s_qpos | (s_plus ? 0x4000u : 0u) | (g >= totalFirst ? 0x8000u : 0u));
 					}
-					laps(10);
-					// order-dependent part: only candidates that can change the state, in the reference's order
-					// (lanes that cannot change it are dropped up front: the penalty cap only falls and the best score only
-					// rises, so a candidate failing extendpen.cpp:43-44 or state1.cpp:555 now fails it at its turn too)
-					uint64_t todo = __ballot(e_kind != 0 && e_pen <= S.maxPen && !(e_kind == 2 && e_bst < S.best - 4));
-					while (todo) {
-						const int t = __builtin_ctzll(todo);
-						todo &= todo - 1;
-						if (base + t >= totalFirst && !crossed) {  // first candidate of the second phase of this list
-							crossed = true;
-							if (step == 4 && S.best >= minScore3) { done = true; break; }  // exit test between phases 4 and 5
-						}
-						const uint32_t dblo = rdlane(c_db, t) - rdlane(c_qpos, t);
-						if (S.overlaps_hit(dblo)) continue;          // extendpen.cpp:15-17
-						if (rdlane(e_pen, t) > S.maxPen) continue;   // extendpen.cpp:43-44,69-70
-						const bool pl = rdlane((uint32_t)c_plus, t) != 0;
-						const int bst = rdlane(e_bst, t);
-						if (rdlane(e_kind, t) == 1) {
-							S.add_hit(dblo, pl, bst, 0);
-							if (step == 1 && bst >= minScore1) { done = true; phase = crossed ? 2 : 1; break; }
-						} else {
-							const int sp = rdlane(e_start, t), ep = rdlane(e_end, t);
-							S.add_hsp((uint32_t)sp, dblo + (uint32_t)sp, pl, (uint32_t)(ep - sp + 1), bst);
-						}
-					}
-					laps(11);
+					qcount += __builtin_popcountll(m);
+					scanned += 64;
 				}
+				__syncthreads();
+				const int nb = qcount < 64 ? qcount : 64;
+				if (nb == 0) break;
+				uint32_t c_qpos = 0, c_db = 0;
+				bool c_plus = true, c_second = false;
+				const bool c_ok = lane < nb;
+				if (c_ok) {
+					const int pos = (qhead + lane) & 127;
+					c_db = cq_db[pos];
+					const uint32_t qp = cq_qp[pos];
+					c_qpos = qp & 0x3FFFu; c_plus = (qp & 0x4000u) != 0; c_second = (qp & 0x8000u) != 0;
+				}
+				qhead = (qhead + nb) & 127; qcount -= nb;
+				__syncthreads();
+				laps(8);
+				uint64_t mm[NCH];
+#pragma unroll
+				for (int c = 0; c < NCH; ++c) mm[c] = 0;
+				if (c_ok) lane_mismatch_mask<NCH>(seq, c_db - c_qpos, sQ2 + (c_plus ? 0 : SW::QMAX), QL, mm);
+				__builtin_amdgcn_s_waitcnt(0);
+				laps(9);
+				// ExtendPen's two x-drop walks (extendpen.cpp:25-78), every lane on its own bit vector, WITHOUT the
+				// running penalty cap: the accumulated penalty only grows along the walk, so the capped walk aborts
+				// iff the uncapped walk's final penalty exceeds the cap -- which is checked in order below.
+				int e_kind = 0, e_bst = 0, e_start = 0, e_end = 0, e_pen = 0;
+				if (c_ok) {
+					xdrop_walk_lane<NCH>(mm, (int)c_qpos, W, QL, P.mismatch_score, P.xdrop, e_bst, e_start, e_end, e_pen);
+					if (e_start == 0 && e_end == QL - 1) e_kind = 1;
+					else if (e_bst >= minhsp) e_kind = 2;
+				}
+				laps(10);
+				// order-dependent part: only candidates that can change the state, in the reference's order.  Lanes that
+				// cannot change it are dropped, up front and again after every change: the penalty cap only falls, the best
+				// score only rises and hits are only added, so a candidate failing extendpen.cpp:15-17, extendpen.cpp:43-44
+				// or state1.cpp:555 now fails it at its turn too.
+				const uint32_t my_dblo = c_db - c_qpos;
+				uint64_t todo = __ballot(e_kind != 0 && e_pen <= S.maxPen && !(e_kind == 2 && e_bst < S.best - 4) &&
+				                         !S.overlaps_any_hit(my_dblo));
+				while (todo) {
+					const int t = __builtin_ctzll(todo);
+					todo &= todo - 1;
+					if (rdlane((uint32_t)c_second, t) != 0 && !crossed) {  // first candidate of the second phase of this list
+						crossed = true;
+						if (step == 4 && S.best >= minScore3) { done = true; break; }  // exit test between phases 4 and 5
+					}
+					const uint32_t dblo = rdlane(my_dblo, t);
+					if (S.overlaps_hit(dblo)) continue;          // extendpen.cpp:15-17
+					if (rdlane(e_pen, t) > S.maxPen) continue;   // extendpen.cpp:43-44,69-70
+					const bool pl = rdlane((uint32_t)c_plus, t) != 0;
+					const int bst = rdlane(e_bst, t);
+					const int hc0 = S.hitCount, mp0 = S.maxPen, b0 = S.best;
+					if (rdlane(e_kind, t) == 1) {
+						S.add_hit(dblo, pl, bst, 0);
+						if (step == 1 && bst >= minScore1) { done = true; phase = crossed ? 2 : 1; break; }
+					} else {
+						const int sp = rdlane(e_start, t), ep = rdlane(e_end, t);
+						S.add_hsp((uint32_t)sp, dblo + (uint32_t)sp, pl, (uint32_t)(ep - sp + 1), bst);
+					}
+					if (S.hitCount != hc0 || S.maxPen != mp0 || S.best != b0)
+						todo &= __ballot(e_pen <= S.maxPen && !(e_kind == 2 && e_bst < S.best - 4) &&
+						                 !(S.hitCount != hc0 && (my_dblo >> 6) == (dblo >> 6)));
+				}
+				laps(11);
+			}
 
 			if (step == 1) { lapc(1); if (!done) phase = 2; }
 			if (step == 4) {
