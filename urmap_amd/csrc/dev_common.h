@@ -176,6 +176,8 @@ struct BitVec {
 template <int N>
 __device__ __forceinline__ void xdrop_walk_lane(const uint64_t (&w)[N], int qpos, int W, int QL, int mis, int xdrop,
                                                 int &bst_out, int &startpos_out, int &endpos_out, int &pen_out) {
+	// The loop bodies are written with selects only (one divergent loop, no divergent branches inside): a lane that
+	// has stopped simply carries x == 0.
 	int score = W, bst = 0, pen = 0;
 	int endpos = qpos + W - 1;
 	int cur = endpos + 1;
@@ -184,23 +186,30 @@ __device__ __forceinline__ void xdrop_walk_lane(const uint64_t (&w)[N], int qpos
 	for (int c = 0; c < N; ++c) {
 		uint64_t x = w[c];
 		const int lo = cur - 64 * c;  // first wanted bit of this word
-		if (!alive || lo >= 64) x = 0;
-		else if (lo > 0) x &= ~0ull << lo;
+		const uint64_t keep = lo > 0 ? (~0ull << (lo & 63)) : ~0ull;
+		x = (!alive || lo >= 64) ? 0ull : (x & keep);
 		while (x) {
 			const int m = 64 * c + __builtin_ctzll(x);
 			x &= x - 1;
-			if (m >= QL) break;  // padding bits past the read: the tail run below ends the walk
-			const int run = m - cur;
-			if (run > 0) { score += run; if (score > bst) { bst = score; endpos = m - 1; } }
-			pen -= mis;
-			score += mis;
-			cur = m + 1;
-			if (bst - score > xdrop) { alive = false; break; }
+			const bool in = m < QL;  // padding bits past the read end the word; the tail run below ends the walk
+			const int s1 = score + (m - cur);
+			const bool nb = in && m > cur && s1 > bst;
+			bst = nb ? s1 : bst;
+			endpos = nb ? m - 1 : endpos;
+			score = in ? s1 + mis : score;
+			pen = in ? pen - mis : pen;
+			cur = in ? m + 1 : cur;
+			const bool stop = in && (bst - score > xdrop);
+			alive = alive && !stop;
+			x = (stop || !in) ? 0ull : x;
 		}
 	}
-	if (alive) {  // no mismatch left: the run to the end of the read
-		const int run = QL - cur;
-		if (run > 0) { score += run; if (score > bst) { bst = score; endpos = QL - 1; } }
+	{  // no mismatch left: the run to the end of the read
+		const int s1 = score + (QL - cur);
+		const bool nb = alive && QL > cur && s1 > bst;
+		score = (alive && QL > cur) ? s1 : score;
+		bst = nb ? s1 : bst;
+		endpos = nb ? QL - 1 : endpos;
 	}
 	int startpos = qpos;
 	cur = startpos - 1;
@@ -209,23 +218,29 @@ __device__ __forceinline__ void xdrop_walk_lane(const uint64_t (&w)[N], int qpos
 	for (int c = N - 1; c >= 0; --c) {
 		uint64_t x = w[c];
 		const int hi = cur - 64 * c;  // last wanted bit of this word
-		if (!alive || hi < 0) x = 0;
-		else if (hi < 63) x &= ~0ull >> (63 - hi);
+		const uint64_t keep = hi < 63 ? (~0ull >> ((63 - hi) & 63)) : ~0ull;
+		x = (!alive || hi < 0) ? 0ull : (x & keep);
 		while (x) {
 			const int b = 63 - __builtin_clzll(x);
 			const int m = 64 * c + b;
 			x ^= 1ull << b;
-			const int run = cur - m;
-			if (run > 0) { score += run; if (score > bst) { bst = score; startpos = m + 1; } }
+			const int s1 = score + (cur - m);
+			const bool nb = cur > m && s1 > bst;
+			bst = nb ? s1 : bst;
+			startpos = nb ? m + 1 : startpos;
+			score = s1 + mis;
 			pen -= mis;
-			score += mis;
 			cur = m - 1;
-			if (bst - score > xdrop) { alive = false; break; }
+			const bool stop = bst - score > xdrop;
+			alive = alive && !stop;
+			x = stop ? 0ull : x;
 		}
 	}
-	if (alive) {
-		const int run = cur + 1;  // down to position 0
-		if (run > 0) { score += run; if (score > bst) { bst = score; startpos = 0; } }
+	{
+		const int s1 = score + (cur + 1);  // down to position 0
+		const bool nb = alive && cur >= 0 && s1 > bst;
+		bst = nb ? s1 : bst;
+		startpos = nb ? 0 : startpos;
 	}
 	bst_out = bst; startpos_out = startpos; endpos_out = endpos; pen_out = pen;
 }

@@ -569,7 +569,7 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU) void search_se_kernel(DevI
 		for (int g = 0; g < SW::NSEG; ++g) rl[g] = 0;
 		for (int step = 1; step <= 6 && !done; step += (step == 1 ? 2 : (step == 3 ? 1 : 2))) {  // 1 (=1+2), 3, 4 (=4+5), 6
 			phase = step;
-			if (dbg_stop && step > dbg_stop) break;
+			if (dbg_stop && step > (dbg_stop > 400 ? 4 : dbg_stop)) break;
 			if (step == 3 || step == 6) {
 				if (step == 6 || S.bestHSP > termHSP3) {
 					for (int k = 0; k < S.hspCount; ++k) S.align_hsp(k);
@@ -664,12 +664,14 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU) void search_se_kernel(DevI
 				qhead = (qhead + nb) & 127; qcount -= nb;
 				__syncthreads();
 				laps(8);
+				if (dbg_stop == 401 && step == 4) continue;
 				uint64_t mm[NCH];
 #pragma unroll
 				for (int c = 0; c < NCH; ++c) mm[c] = 0;
 				if (c_ok) lane_mismatch_mask<NCH>(seq, c_db - c_qpos, sQ2 + (c_plus ? 0 : SW::QMAX), QL, mm);
 				__builtin_amdgcn_s_waitcnt(0);
 				laps(9);
+				if (dbg_stop == 402 && step == 4) { if (mm[0] == 0x123456789ull) done = true; continue; }
 				// ExtendPen's two x-drop walks (extendpen.cpp:25-78), every lane on its own bit vector, WITHOUT the
 				// running penalty cap: the accumulated penalty only grows along the walk, so the capped walk aborts
 				// iff the uncapped walk's final penalty exceeds the cap -- which is checked in order below.
@@ -680,6 +682,7 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU) void search_se_kernel(DevI
 					else if (e_bst >= minhsp) e_kind = 2;
 				}
 				laps(10);
+				if (dbg_stop == 403 && step == 4) { if (__ballot(e_bst == 12345)) done = true; continue; }
 				// order-dependent part: only candidates that can change the state, in the reference's order.  Lanes that
 				// cannot change it are dropped, up front and again after every change: the penalty cap only falls, the best
 				// score only rises and hits are only added, so a candidate failing extendpen.cpp:15-17, extendpen.cpp:43-44
