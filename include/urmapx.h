@@ -183,6 +183,20 @@ size_t urmapx_sam_pe(const urmapx_index *, const urmapx_result *r1, const urmapx
 /* @SQ lines of State1::WriteSAMHeader (state1.cpp:736-748); same return convention. */
 size_t urmapx_sam_header_sq(const urmapx_index *, char *buf, size_t cap);
 
+/* ---- FASTQ input (host) ---- */
+/* Batch form of FASTQSeqSource::GetNextLo (fastqseqsource.cpp:9-116) over LineReader (linereader.cpp:14-113):
+ * plain or .gz by suffix; '\r' dropped; a final unterminated line counts; blank lines only at end of file; the same
+ * accept/reject rules and messages ('@' expected, letters only, #bases == #quals).  One reader per file. */
+typedef struct urmapx_fastq urmapx_fastq;
+int urmapx_fastq_open(const char *path, urmapx_fastq **out);
+/* Reads up to max_reads records.  Returns the number read (0 at end of file) or URMAPX_E_FORMAT with the reference's
+ * message in urmapx_fastq_error().  The arrays belong to the reader and stay valid until its next call:
+ * bases/quals concatenated, offs[n+1]; labels (text after '@', NUL terminated) at label_data + label_offs[i]. */
+int64_t urmapx_fastq_next(urmapx_fastq *, uint32_t max_reads, const uint8_t **bases, const uint8_t **quals,
+                          const uint64_t **offs, const char **label_data, const uint64_t **label_offs);
+const char *urmapx_fastq_error(const urmapx_fastq *);
+void urmapx_fastq_close(urmapx_fastq *);
+
 const char *urmapx_strerror(int code);
 /* "gfx950" etc. of the ctx's device; NULL without a device */
 const char *urmapx_device_arch(urmapx_ctx *);

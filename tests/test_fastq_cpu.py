@@ -1,0 +1,115 @@
+"""The product's FASTQ reader (urmapx_fastq_*, the batch form of FASTQSeqSource::GetNextLo, fastqseqsource.cpp:9-116)
+on the edge cases the reference's reader defines.  CPU only."""
+import gzip
+import os
+
+import numpy as np
+import pytest
+
+from urmap_amd import api
+
+
+def _records(n, L=50, seed=0):
+    rng = np.random.default_rng(seed)
+    recs = []
+    for i in range(n):
+        ln = L if L > 0 else int(rng.integers(1, 200))
+        s = bytes(rng.choice(np.frombuffer(b"ACGTN", dtype=np.uint8), ln))
+        q = bytes(rng.integers(33, 74, ln, dtype=np.uint8))
+        recs.append((f"read{i} extra/1".encode(), s, q))
+    return recs
+
+
+def _text(recs, eol=b"\n", final_eol=True):
+    t = b"".join(b"@" + l + eol + s + eol + b"+" + eol + q + eol for l, s, q in recs)
+    return t if final_eol else t[:-len(eol)]
+
+
+def _read_all(path, batch):
+    rd = api.FastqReader(path)
+    out = []
+    while True:
+        b = rd.next(batch)
+        if b is None:
+            break
+        labels, bases, offs, quals = b
+        for i, lab in enumerate(labels):
+            out.append((lab.encode("latin-1"), bases[int(offs[i]):int(offs[i + 1])].tobytes(),
+                        quals[int(offs[i]):int(offs[i + 1])].tobytes()))
+    rd.close()
+    return out
+
+
+@pytest.mark.parametrize("batch", [1, 7, 1000, 1 << 20])
+@pytest.mark.parametrize("variant", ["plain", "crlf", "no_final_eol", "trailing_blank", "ragged", "gz"])
+def test_reader_round_trip(tmp_path, batch, variant):
+    recs = _records(2500 if batch > 1 else 300, L=0 if variant == "ragged" else 50, seed=3)
+    if variant == "crlf":
+        data = _text(recs, eol=b"\r\n")
+    elif variant == "no_final_eol":
+        data = _text(recs, final_eol=False)
+    elif variant == "trailing_blank":
+        data = _text(recs) + b"\n\n\r\n\n\n"
+    else:
+        data = _text(recs)
+    p = tmp_path / ("r.fq.gz" if variant == "gz" else "r.fq")
+    if variant == "gz":
+        with gzip.open(p, "wb") as f:
+            f.write(data)
+    else:
+        p.write_bytes(data)
+    assert _read_all(str(p), batch) == recs
+
+
+def test_empty_file_and_missing_file(tmp_path):
+    p = tmp_path / "e.fq"
+    p.write_bytes(b"")
+    assert _read_all(str(p), 10) == []
+    with pytest.raises(api.UrmapxError):
+        api.FastqReader(str(tmp_path / "nope.fq"))
+
+
+@pytest.mark.parametrize("bad,msg", [
+    (b"@a\nACGT\n+\nIIII\nXa\nACGT\n+\nIIII\n", "expected '@'"),
+    (b"@a\nAC1T\n+\nIIII\n", "Invalid sequence letter"),
+    (b"@a\nACGT\n+\nIII\n", "Bad FASTQ record: 4 bases, 3 quals"),
+    (b"@a\nACGT\n+\n", "Unexpected end-of-file"),
+    (b"@a\n", "Unexpected end-of-file"),
+    (b"@a\nACGT\n+\nIIII\n\n@b\nACGT\n+\nIIII\n", "Empty line in FASTQ file"),
+])
+@pytest.mark.parametrize("batch", [1, 100])
+def test_reader_errors_use_reference_messages(tmp_path, bad, msg, batch):
+    p = tmp_path / "bad.fq"
+    p.write_bytes(bad)
+    rd = api.FastqReader(str(p))
+    with pytest.raises(ValueError, match=msg):
+        while rd.next(batch) is not None:
+            pass
+
+
+def test_large_file_crosses_buffer_boundaries(tmp_path):
+    # > 64 MiB of input so that the reader's block buffer is refilled several times
+    recs = _records(1000, L=150, seed=9)
+    data = _text(recs)
+    reps = (70 << 20) // len(data) + 1
+    p = tmp_path / "big.fq"
+    with open(p, "wb") as f:
+        for _ in range(reps):
+            f.write(data)
+    rd = api.FastqReader(str(p))
+    n = 0
+    while True:
+        b = rd.next(300_000)
+        if b is None:
+            break
+        labels, bases, offs, quals = b
+        assert np.all(np.diff(offs) == 150)
+        k = len(labels)
+        for j in (0, k // 2, k - 1):  # record j of this batch is record (n + j) % 1000 of the template
+            lab, s, q = recs[(n + j) % 1000]
+            assert labels[j].encode() == lab
+            assert bases[int(offs[j]):int(offs[j + 1])].tobytes() == s
+            assert quals[int(offs[j]):int(offs[j + 1])].tobytes() == q
+        n += k
+    assert n == reps * 1000
+    os.remove(p)

@@ -31,6 +31,7 @@ EXPORTS = (
     "urmapx_map_se", "urmapx_map_se_device", "urmapx_ctx_sync", "urmapx_ctx_last_kernel_ms",
     "urmapx_seed_probe", "urmapx_viterbi_batch", "urmapx_strerror", "urmapx_device_arch",
     "urmapx_make_ufi", "urmapx_build_slots", "urmapx_sam_se", "urmapx_sam_header_sq", "urmapx_ctx_phase_cycles", "urmapx_map_pe", "urmapx_sam_pe", "urmapx_map_pe_device", "urmapx_ctx_set_pe_veryfast",
+    "urmapx_fastq_open", "urmapx_fastq_next", "urmapx_fastq_error", "urmapx_fastq_close",
 )
 
 
@@ -103,6 +104,13 @@ def lib():
     L.urmapx_strerror.argtypes = [i32]
     L.urmapx_device_arch.restype = cp
     L.urmapx_device_arch.argtypes = [vp]
+    L.urmapx_fastq_open.argtypes = [cp, C.POINTER(vp)]
+    L.urmapx_fastq_next.restype = C.c_int64
+    L.urmapx_fastq_next.argtypes = [vp, u32] + [C.POINTER(vp)] * 5
+    L.urmapx_fastq_error.restype = cp
+    L.urmapx_fastq_error.argtypes = [vp]
+    L.urmapx_fastq_close.restype = None
+    L.urmapx_fastq_close.argtypes = [vp]
     _lib = L
     return L
 
@@ -389,25 +397,64 @@ def interleave_pairs(a, b):
     return labels, np.concatenate(seqs), offs, np.concatenate(quals)
 
 
-def read_fastq_arrays(path):
-    """Minimal FASTQ -> (labels, bases uint8, offs uint64, quals uint8) for tests and bench."""
-    labels, seqs, quals = [], [], []
-    with open(path, "rb") as f:
-        while True:
-            l1 = f.readline()
-            if not l1:
-                break
-            l1 = l1.rstrip(b"\r\n")
-            if not l1:
-                continue
-            s = f.readline().rstrip(b"\r\n")
-            f.readline()
-            q = f.readline().rstrip(b"\r\n")
-            labels.append(l1[1:].decode())
-            seqs.append(s)
-            quals.append(q)
-    offs = np.zeros(len(seqs) + 1, dtype=np.uint64)
-    offs[1:] = np.cumsum([len(s) for s in seqs])
-    bases = np.frombuffer(b"".join(seqs), dtype=np.uint8)
-    qual = np.frombuffer(b"".join(quals), dtype=np.uint8)
+class FastqReader:
+    """ctypes view of urmapx_fastq_* (the product's FASTQSeqSource): iterate batches of records."""
+
+    def __init__(self, path):
+        self._h = C.c_void_p()
+        rc = lib().urmapx_fastq_open(os.fsencode(path), C.byref(self._h))
+        if rc:
+            raise UrmapxError(rc, f"urmapx_fastq_open({path})")
+
+    def next(self, max_reads):
+        """-> (labels list[str], bases uint8, offs uint64, quals uint8) or None at end of file."""
+        L = lib()
+        pb, pq, po, pl, plo = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        n = L.urmapx_fastq_next(self._h, max_reads, C.byref(pb), C.byref(pq), C.byref(po), C.byref(pl), C.byref(plo))
+        if n < 0:
+            raise ValueError(L.urmapx_fastq_error(self._h).decode())
+        if n == 0:
+            return None
+        offs = np.ctypeslib.as_array(C.cast(po, C.POINTER(C.c_uint64)), shape=(n + 1,)).copy()
+        nb = int(offs[-1])
+        if nb:
+            bases = np.ctypeslib.as_array(C.cast(pb, C.POINTER(C.c_uint8)), shape=(nb,)).copy()
+            quals = np.ctypeslib.as_array(C.cast(pq, C.POINTER(C.c_uint8)), shape=(nb,)).copy()
+        else:
+            bases = np.zeros(0, dtype=np.uint8)
+            quals = np.zeros(0, dtype=np.uint8)
+        lo = np.ctypeslib.as_array(C.cast(plo, C.POINTER(C.c_uint64)), shape=(n,))
+        labels = [C.string_at(pl.value + int(o)).decode("latin-1") for o in lo]
+        return labels, bases, offs, quals
+
+    def close(self):
+        if self._h:
+            lib().urmapx_fastq_close(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def read_fastq_arrays(path, batch=1 << 16):
+    """FASTQ -> (labels, bases uint8, offs uint64, quals uint8) through the product's reader."""
+    rd = FastqReader(path)
+    labels, bl, ql, lens = [], [], [], []
+    while True:
+        b = rd.next(batch)
+        if b is None:
+            break
+        labels += b[0]
+        bl.append(b[1])
+        ql.append(b[3])
+        lens.append(np.diff(b[2]))
+    rd.close()
+    offs = np.zeros(len(labels) + 1, dtype=np.uint64)
+    if lens:
+        offs[1:] = np.cumsum(np.concatenate(lens))
+    bases = np.concatenate(bl) if bl else np.zeros(0, dtype=np.uint8)
+    qual = np.concatenate(ql) if ql else np.zeros(0, dtype=np.uint8)
     return labels, bases, offs, qual

@@ -1,5 +1,7 @@
 #include "sam.h"
 
+#include <omp.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <cctype>
@@ -15,83 +17,241 @@ FastqReader::~FastqReader() {
 
 bool FastqReader::open(const std::string &path, std::string &err) {
 	path_ = path;
-	buf_.resize(8u << 20);
+	buf_.resize(64u << 20);
 	const bool gz = path.size() > 3 && path.compare(path.size() - 3, 3, ".gz") == 0;
 	if (gz) {
 		gz_ = gzopen(path.c_str(), "rb");
 		if (!gz_) { err = "cannot open " + path; return false; }
+		gzbuffer((gzFile)gz_, 1u << 20);
 	} else {
 		f_ = fopen(path.c_str(), "rb");
 		if (!f_) { err = "cannot open " + path; return false; }
+		setvbuf(f_, nullptr, _IONBF, 0);
 	}
 	return true;
 }
 
-bool FastqReader::fill() {
-	if (eof_) return false;
-	pos_ = 0;
+size_t FastqReader::read_some(char *dst, size_t cap) {
 	if (gz_) {
-		int n = gzread((gzFile)gz_, buf_.data(), (unsigned)buf_.size());
-		len_ = n > 0 ? (size_t)n : 0;
-	} else
-		len_ = fread(buf_.data(), 1, buf_.size(), f_);
-	if (len_ == 0) eof_ = true;
-	return len_ > 0;
+		if (cap > (1u << 30)) cap = 1u << 30;
+		int n = gzread((gzFile)gz_, dst, (unsigned)cap);
+		return n > 0 ? (size_t)n : 0;
+	}
+	// plain file: the block is read by all threads at their own offsets (one thread copies ~2.5 GB/s from the page cache)
+	const int fd = fileno(f_);
+	const int T = cap >= (8u << 20) ? omp_get_max_threads() : 1;
+	std::vector<size_t> got((size_t)T, 0);
+#pragma omp parallel for schedule(static, 1) num_threads(T)
+	for (int t = 0; t < T; ++t) {
+		const size_t lo = cap * (size_t)t / (size_t)T, hi = cap * (size_t)(t + 1) / (size_t)T;
+		size_t done = 0;
+		while (lo + done < hi) {
+			ssize_t n = pread(fd, dst + lo + done, hi - lo - done, (off_t)(file_off_ + lo + done));
+			if (n <= 0) break;
+			done += (size_t)n;
+		}
+		got[(size_t)t] = done;
+	}
+	size_t total = 0;
+	for (int t = 0; t < T; ++t) {  // a short slice means end of file: nothing after it counts
+		total += got[(size_t)t];
+		const size_t lo = cap * (size_t)t / (size_t)T, hi = cap * (size_t)(t + 1) / (size_t)T;
+		if (got[(size_t)t] < hi - lo) break;
+	}
+	file_off_ += total;
+	return total;
 }
 
-// '\r' dropped anywhere, '\n' ends the line; a final unterminated line counts (linereader.cpp:54-101)
-bool FastqReader::read_line(std::string &s) {
-	s.clear();
-	if (eof_) return false;
-	for (;;) {
-		if (pos_ >= len_) {
-			if (!fill()) {
-				if (s.empty()) return false;
-				++line_nr_;
-				return true;
-			}
-		}
-		const char *p = buf_.data() + pos_;
-		const char *e = buf_.data() + len_;
-		const char *nl = (const char *)memchr(p, '\n', (size_t)(e - p));
-		const char *stop = nl ? nl : e;
-		for (const char *c = p; c < stop; ++c)
-			if (*c != '\r') s.push_back(*c);
-		if (nl) { pos_ = (size_t)(nl - buf_.data()) + 1; ++line_nr_; return true; }
-		pos_ = len_;
-	}
+namespace {
+// a line = [s, e) without its '\n'; '\r' is dropped anywhere in it (linereader.cpp:54-101)
+inline size_t line_len(const char *s, const char *e) {
+	size_t n = (size_t)(e - s);
+	for (const char *c = (const char *)memchr(s, '\r', n); c; c = (const char *)memchr(c + 1, '\r', (size_t)(e - c - 1))) --n;
+	return n;
 }
+inline void line_copy(char *dst, const char *s, const char *e) {
+	if (!memchr(s, '\r', (size_t)(e - s))) { memcpy(dst, s, (size_t)(e - s)); return; }
+	for (; s < e; ++s)
+		if (*s != '\r') *dst++ = *s;
+}
+}  // namespace
 
 bool FastqReader::next_batch(FastqBatch &B, uint32_t max_reads, std::string &err) {
-	if (B.offs.empty()) B.offs.assign(1, 0);
-	std::string l1, l2, l3, l4;
-	uint32_t got = 0;
-	while (got < max_reads) {
-		if (!read_line(l1)) break;
+	if (B.offs.empty()) { B.offs.resize(1); B.offs[0] = 0; }
+	if (finished_ || max_reads == 0) return false;
+	// 1. line ends of up to max_reads records (a final unterminated line counts)
+	const size_t want = 4 * (size_t)max_reads;
+	ends_.clear();
+	size_t scan = 0;
+	for (;;) {
+		while (ends_.size() < want && scan < have_) {
+			// look ahead about as far as the missing lines are likely to reach; big windows are scanned by all threads
+			size_t win = (want - ends_.size()) * 160;
+			if (win < (1u << 20)) win = 1u << 20;
+			if (win > have_ - scan) win = have_ - scan;
+			const char *w0 = buf_.data() + scan;
+			if (win < (4u << 20)) {
+				const char *c = w0, *e = w0 + win;
+				while (ends_.size() < want && c < e) {
+					const char *nl = (const char *)memchr(c, '\n', (size_t)(e - c));
+					if (!nl) { c = e; break; }
+					ends_.push_back((size_t)(nl - buf_.data()));
+					c = nl + 1;
+				}
+				scan = (size_t)(c - buf_.data());
+			} else {
+				const int T = omp_get_max_threads();
+				std::vector<std::vector<size_t>> part((size_t)T);
+#pragma omp parallel for schedule(static, 1) num_threads(T)
+				for (int t = 0; t < T; ++t) {
+					const char *c = w0 + win * (size_t)t / (size_t)T, *e = w0 + win * (size_t)(t + 1) / (size_t)T;
+					std::vector<size_t> &v = part[(size_t)t];
+					while (c < e) {
+						const char *nl = (const char *)memchr(c, '\n', (size_t)(e - c));
+						if (!nl) break;
+						v.push_back((size_t)(nl - buf_.data()));
+						c = nl + 1;
+					}
+				}
+				bool full = false;
+				for (int t = 0; t < T && !full; ++t)
+					for (size_t x : part[(size_t)t]) {
+						ends_.push_back(x);
+						if (ends_.size() >= want) { full = true; break; }
+					}
+				scan = full ? ends_.back() + 1 : scan + win;
+			}
+		}
+		if (ends_.size() >= want || eof_) break;
+		if (have_ == buf_.size()) buf_.resize(buf_.size() * 2);
+		const size_t n = read_some(buf_.data() + have_, buf_.size() - have_);
+		if (n == 0) eof_ = true;
+		have_ += n;
+	}
+	const size_t last_end = ends_.empty() ? 0 : ends_.back() + 1;
+	bool virtual_tail = false;
+	if (eof_ && ends_.size() < want && last_end < have_) { ends_.push_back(have_); virtual_tail = true; }
+	const size_t nlines = ends_.size();
+	if (nlines == 0) { finished_ = true; return false; }
+	const char *base = buf_.data();
+	auto lstart = [&](size_t k) { return base + (k == 0 ? 0 : ends_[k - 1] + 1); };
+	auto lend = [&](size_t k) { return base + ends_[k]; };
+	size_t nrec = nlines / 4;
+	// 2. validate all complete records (parallel); the lowest-numbered problem wins
+	const size_t n0 = B.label_offs.size();
+	std::vector<uint32_t> blen(nrec), llen(nrec);
+	size_t bad = nrec;  // first record that is blank or malformed
+#pragma omp parallel for schedule(static) reduction(min : bad)
+	for (size_t i = 0; i < nrec; ++i) {
+		const char *s1 = lstart(4 * i), *e1 = lend(4 * i);
+		const size_t l1 = line_len(s1, e1);
+		bool ok = l1 > 0;
+		if (ok) {
+			const char *c = s1;
+			while (*c == '\r') ++c;
+			ok = *c == '@';
+		}
+		const char *s2 = lstart(4 * i + 1), *e2 = lend(4 * i + 1);
+		const size_t l2 = line_len(s2, e2);
+		if (ok)
+			for (const char *c = s2; c < e2; ++c)
+				if (*c != '\r' && !isalpha((unsigned char)*c)) { ok = false; break; }
+		const size_t l4 = line_len(lstart(4 * i + 3), lend(4 * i + 3));
+		if (l4 != l2) ok = false;
+		blen[i] = (uint32_t)l2;
+		llen[i] = (uint32_t)(l1 > 0 ? l1 - 1 : 0);
+		if (!ok && i < bad) bad = i;
+	}
+	size_t leftover_from = 4 * nrec;  // first line not consumed by a good record
+	if (bad < nrec) { nrec = bad; leftover_from = 4 * bad; }
+	// 3. copy (parallel) after a prefix sum of the lengths
+	std::vector<uint64_t> bo(nrec + 1), lo(nrec + 1);
+	bo[0] = B.bases.size(); lo[0] = B.label_data.size();
+	for (size_t i = 0; i < nrec; ++i) { bo[i + 1] = bo[i] + blen[i]; lo[i + 1] = lo[i] + llen[i] + 1; }
+	B.bases.resize(bo[nrec]); B.quals.resize(bo[nrec]); B.label_data.resize(lo[nrec]);
+	B.label_offs.resize(n0 + nrec); B.offs.resize(n0 + nrec + 1);
+#pragma omp parallel for schedule(static)
+	for (size_t i = 0; i < nrec; ++i) {
+		const char *s1 = lstart(4 * i), *e1 = lend(4 * i);
+		while (*s1 == '\r') ++s1;
+		line_copy(B.label_data.data() + lo[i], s1 + 1, e1);
+		B.label_data[lo[i] + llen[i]] = 0;
+		line_copy((char *)B.bases.data() + bo[i], lstart(4 * i + 1), lend(4 * i + 1));
+		line_copy((char *)B.quals.data() + bo[i], lstart(4 * i + 3), lend(4 * i + 3));
+		B.label_offs[n0 + i] = lo[i];
+		B.offs[n0 + i + 1] = bo[i + 1];
+	}
+	line_nr_ += 4 * nrec;
+	// 4. whatever follows the good records: the next batch's input, or a problem to report in the reference's words
+	const bool partial_at_eof = eof_ && leftover_from < nlines && (nlines - leftover_from) < 4 && bad >= nlines / 4;
+	if (bad < nlines / 4 || partial_at_eof) {
+		const size_t k = leftover_from;  // line index of the record's first line
+		auto text = [&](size_t j) { std::string t(line_len(lstart(j), lend(j)), 0); line_copy(&t[0], lstart(j), lend(j)); return t; };
+		const std::string l1 = text(k);
 		if (l1.empty()) {
 			// blank lines are only allowed at end of file (fastqseqsource.cpp:31-43)
-			while (read_line(l1))
-				if (!l1.empty()) { err = "Empty line in FASTQ file '" + path_ + "'"; return false; }
-			break;
+			bool only_blank = true;
+			for (size_t j = k; j < nlines && only_blank; ++j) only_blank = line_len(lstart(j), lend(j)) == 0;
+			size_t pos = nlines ? (virtual_tail ? have_ : ends_.back() + 1) : 0;
+			while (only_blank) {
+				for (; pos < have_ && only_blank; ++pos) only_blank = buf_[pos] == '\n' || buf_[pos] == '\r';
+				if (!only_blank || eof_) break;
+				have_ = read_some(buf_.data(), buf_.size());
+				pos = 0;
+				if (have_ == 0) eof_ = true;
+			}
+			if (!only_blank) { err = "Empty line in FASTQ file '" + path_ + "'"; return false; }
+			finished_ = true;
+			have_ = 0;
+			return nrec > 0;
 		}
-		if (l1[0] != '@') { err = "Bad line " + std::to_string(line_nr_) + " in FASTQ file '" + path_ + "': expected '@'"; return false; }
-		if (!read_line(l2)) { err = "Unexpected end-of-file in FASTQ file " + path_; return false; }
+		const uint64_t ln = line_nr_ + 1;
+		if (l1[0] != '@') { err = "Bad line " + std::to_string(ln) + " in FASTQ file '" + path_ + "': expected '@'"; return false; }
+		if (k + 1 >= nlines) { err = "Unexpected end-of-file in FASTQ file " + path_; return false; }
+		const std::string l2 = text(k + 1);
 		for (unsigned char c : l2)
-			if (!isalpha(c)) { err = "Invalid sequence letter in FASTQ, line " + std::to_string(line_nr_) + " file " + path_; return false; }
-		read_line(l3);
-		if (!read_line(l4)) { err = "Unexpected end-of-file in FASTQ file " + path_; return false; }
-		if (l4.size() != l2.size()) {
-			err = "Bad FASTQ record: " + std::to_string(l2.size()) + " bases, " + std::to_string(l4.size()) + " quals line " +
-			      std::to_string(line_nr_) + " file " + path_;
-			return false;
-		}
-		B.labels.push_back(l1.substr(1));
-		B.bases.insert(B.bases.end(), l2.begin(), l2.end());
-		B.quals.insert(B.quals.end(), l4.begin(), l4.end());
-		B.offs.push_back(B.bases.size());
-		++got;
+			if (!isalpha(c)) { err = "Invalid sequence letter in FASTQ, line " + std::to_string(ln + 1) + " file " + path_; return false; }
+		if (k + 3 >= nlines) { err = "Unexpected end-of-file in FASTQ file " + path_; return false; }
+		const std::string l4 = text(k + 3);
+		err = "Bad FASTQ record: " + std::to_string(l2.size()) + " bases, " + std::to_string(l4.size()) + " quals line " +
+		      std::to_string(ln + 3) + " file " + path_;
+		return false;
 	}
-	return got > 0;
+	// keep the unconsumed tail for the next call
+	const size_t consumed = leftover_from == 0 ? 0 : (leftover_from == nlines && virtual_tail ? have_ : ends_[leftover_from - 1] + 1);
+	if (consumed < have_) memmove(buf_.data(), buf_.data() + consumed, have_ - consumed);
+	have_ -= consumed;
+	if (eof_ && have_ == 0) finished_ = true;
+	return nrec > 0;
+}
+
+void interleave_batches(const FastqBatch &a, const FastqBatch &b, FastqBatch &out) {
+	const size_t n = a.size();
+	out.clear();
+	out.label_offs.resize(2 * n);
+	out.offs.resize(2 * n + 1);
+	uint64_t bo = 0, lo = 0;
+	for (size_t i = 0; i < n; ++i) {
+		for (int m = 0; m < 2; ++m) {
+			const FastqBatch &s = m ? b : a;
+			out.label_offs[2 * i + m] = lo;
+			lo += strlen(s.label((uint32_t)i)) + 1;
+			out.offs[2 * i + m] = bo;
+			bo += s.offs[i + 1] - s.offs[i];
+		}
+	}
+	out.offs[2 * n] = bo;
+	out.bases.resize(bo); out.quals.resize(bo); out.label_data.resize(lo);
+#pragma omp parallel for schedule(static)
+	for (size_t i = 0; i < n; ++i) {
+		for (int m = 0; m < 2; ++m) {
+			const FastqBatch &s = m ? b : a;
+			const size_t L = (size_t)(s.offs[i + 1] - s.offs[i]);
+			memcpy(out.bases.data() + out.offs[2 * i + m], s.bases.data() + s.offs[i], L);
+			memcpy(out.quals.data() + out.offs[2 * i + m], s.quals.data() + s.offs[i], L);
+			strcpy(out.label_data.data() + out.label_offs[2 * i + m], s.label((uint32_t)i));
+		}
+	}
 }
 
 // ---------------- SAM ----------------
@@ -107,33 +267,50 @@ static struct CompInit {
 	}
 } g_comp_init;
 
-std::string path_to_cigar(const urmapx_path_op *ops, unsigned nops, unsigned QL) {
-	if (nops == 0) return std::to_string(QL) + "M";
-	std::vector<char> op;
-	std::vector<unsigned> len;
+static inline void append_uint(std::string &out, uint64_t v) {
+	char tmp[24];
+	int n = 0;
+	do { tmp[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+	const size_t at = out.size();
+	out.resize(at + (size_t)n);
+	for (int i = 0; i < n; ++i) out[at + (size_t)i] = tmp[n - 1 - i];
+}
+static inline void append_int(std::string &out, int64_t v) {
+	if (v < 0) { out.push_back('-'); append_uint(out, (uint64_t)(-v)); }
+	else append_uint(out, (uint64_t)v);
+}
+
+static void append_cigar(std::string &out, const urmapx_path_op *ops, unsigned nops, unsigned QL) {
+	if (nops == 0) { append_uint(out, QL); out.push_back('M'); return; }
+	char op[URMAPX_MAX_PATH_OPS + 1];
+	unsigned len[URMAPX_MAX_PATH_OPS + 1];
+	unsigned N = 0;
+	if (nops > URMAPX_MAX_PATH_OPS) nops = URMAPX_MAX_PATH_OPS;
 	for (unsigned i = 0; i < nops; ++i) {
 		unsigned code = ops[i] & 3u, n = ops[i] >> 2;
 		char c = code == 0 ? 'M' : code == 1 ? 'I' : 'D';  // path D (query only) is CIGAR I and vice versa
-		if (!op.empty() && op.back() == c) len.back() += n;
-		else { op.push_back(c); len.push_back(n); }
+		if (N && op[N - 1] == c) len[N - 1] += n;
+		else { op[N] = c; len[N] = n; ++N; }
 	}
 	// dangling terminal M of length <= 2 next to an indel > 4 is merged into the far side M (cigar.cpp:141-199);
 	// the reference evaluates its tail rule against the pre-shrink size, which can never hold once the head
 	// rule has fired, so it is head rule XOR tail rule.
-	size_t N = op.size();
+	unsigned first = 0;
 	if (N >= 3) {
 		if (op[0] == 'M' && len[0] <= 2 && len[1] > 4 && op[2] == 'M') {
 			len[2] += len[0];
-			op.erase(op.begin());
-			len.erase(len.begin());
+			first = 1;
 		} else if (op[N - 1] == 'M' && len[N - 1] <= 2 && len[N - 2] > 4 && op[N - 3] == 'M') {
 			len[N - 3] += len[N - 1];
-			op.pop_back();
-			len.pop_back();
+			--N;
 		}
 	}
+	for (unsigned i = first; i < N; ++i) { append_uint(out, len[i]); out.push_back(op[i]); }
+}
+
+std::string path_to_cigar(const urmapx_path_op *ops, unsigned nops, unsigned QL) {
 	std::string s;
-	for (size_t i = 0; i < op.size(); ++i) { s += std::to_string(len[i]); s.push_back(op[i]); }
+	append_cigar(s, ops, nops, QL);
 	return s;
 }
 
@@ -155,7 +332,7 @@ static void append_unmapped(std::string &out, uint32_t aflags, const char *label
 	else if (aflags & 0x20) flags |= 0x20;
 	out.append(label, qname_len(label));
 	out.push_back('\t');
-	out += std::to_string(flags);
+	append_uint(out, flags);
 	out += "\t*\t0\t0\t*\t*\t0\t0\t";
 	out.append((const char *)seq, QL);
 	out.push_back('\t');
@@ -171,34 +348,42 @@ void append_sam_record(std::string &out, const urmapx_index *I, const urmapx_res
 	const char *tlabel = urmapx_index_label(I, r.seq_index);
 	out.append(label, qname_len(label));
 	out.push_back('\t');
-	out += std::to_string(flags);
+	append_uint(out, flags);
 	out.push_back('\t');
 	out += tlabel;
 	out.push_back('\t');
-	out += std::to_string(r.coord + 1);
+	append_uint(out, (uint64_t)r.coord + 1);
 	out.push_back('\t');
-	out += std::to_string((unsigned)r.mapq);
+	append_uint(out, (unsigned)r.mapq);
 	out.push_back('\t');
-	out += path_to_cigar(r.path_nops ? ops + r.path_off : nullptr, r.path_nops, QL);
+	append_cigar(out, r.path_nops ? ops + r.path_off : nullptr, r.path_nops, QL);
 	out.push_back('\t');
 	if (!mate_label || !*mate_label || strcmp(mate_label, "*") == 0) out.push_back('*');
 	else if (strcmp(mate_label, tlabel) == 0) out.push_back('=');
 	else out += mate_label;
 	out.push_back('\t');
 	if (mate_pos == 0 || mate_pos == 0xFFFFFFFFu) out.push_back('0');
-	else out += std::to_string(mate_pos + 1);
+	else append_uint(out, (uint64_t)mate_pos + 1);
 	out.push_back('\t');
-	out += std::to_string(tlen);
+	append_int(out, tlen);
 	out.push_back('\t');
-	if (r.plus) out.append((const char *)seq, QL);
-	else
-		for (unsigned i = 0; i < QL; ++i) out.push_back((char)g_comp[seq[QL - 1 - i]]);
-	out.push_back('\t');
-	if (!qual) out.push_back('*');
-	else if (r.plus) out.append((const char *)qual, QL);
-	else
-		for (unsigned i = 1; i <= QL; ++i) out.push_back((char)qual[QL - i]);
-	out.push_back('\n');
+	{
+		const size_t at = out.size();
+		out.resize(at + 2 * (size_t)QL + 2 - (qual ? 0 : QL - 1));
+		char *d = &out[at];
+		if (r.plus) memcpy(d, seq, QL);
+		else
+			for (unsigned i = 0; i < QL; ++i) d[i] = (char)g_comp[seq[QL - 1 - i]];
+		d += QL;
+		*d++ = '\t';
+		if (!qual) *d++ = '*';
+		else if (r.plus) { memcpy(d, qual, QL); d += QL; }
+		else {
+			for (unsigned i = 1; i <= QL; ++i) d[i - 1] = (char)qual[QL - i];
+			d += QL;
+		}
+		*d = '\n';
+	}
 }
 
 void append_sam_header(std::string &out, const urmapx_index *I, int argc, char **argv) {
@@ -226,6 +411,38 @@ extern "C" size_t urmapx_sam_se(const urmapx_index *I, const urmapx_result *r, c
 	memcpy(buf, out.data(), out.size());
 	return out.size();
 }
+
+struct urmapx_fastq {
+	urx::FastqReader rd;
+	urx::FastqBatch batch;
+	std::string err;
+};
+
+extern "C" int urmapx_fastq_open(const char *path, urmapx_fastq **out) {
+	if (!path || !out) return URMAPX_E_ARG;
+	urmapx_fastq *F = new urmapx_fastq;
+	if (!F->rd.open(path, F->err)) { delete F; return URMAPX_E_IO; }
+	*out = F;
+	return URMAPX_OK;
+}
+
+extern "C" int64_t urmapx_fastq_next(urmapx_fastq *F, uint32_t max_reads, const uint8_t **bases, const uint8_t **quals,
+                                     const uint64_t **offs, const char **label_data, const uint64_t **label_offs) {
+	if (!F) return URMAPX_E_ARG;
+	F->batch.clear();
+	F->err.clear();
+	F->rd.next_batch(F->batch, max_reads, F->err);
+	if (!F->err.empty()) return URMAPX_E_FORMAT;
+	if (bases) *bases = F->batch.bases.data();
+	if (quals) *quals = F->batch.quals.data();
+	if (offs) *offs = F->batch.offs.data();
+	if (label_data) *label_data = F->batch.label_data.data();
+	if (label_offs) *label_offs = F->batch.label_offs.data();
+	return (int64_t)F->batch.size();
+}
+
+extern "C" const char *urmapx_fastq_error(const urmapx_fastq *F) { return F ? F->err.c_str() : ""; }
+extern "C" void urmapx_fastq_close(urmapx_fastq *F) { delete F; }
 
 extern "C" size_t urmapx_sam_header_sq(const urmapx_index *I, char *buf, size_t cap) {
 	std::string out;

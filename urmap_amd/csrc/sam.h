@@ -4,6 +4,8 @@
 #pragma once
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -11,15 +13,51 @@
 
 namespace urx {
 
-struct FastqBatch {
-	std::vector<std::string> labels;
-	std::vector<uint8_t> bases, quals;  // concatenated
-	std::vector<uint64_t> offs;         // n+1
-	uint32_t size() const { return (uint32_t)labels.size(); }
-	void clear() { labels.clear(); bases.clear(); quals.clear(); offs.assign(1, 0); }
+// growable array of plain data whose new elements are NOT zero-filled (the batch arrays are tens of MB and are
+// overwritten at once; std::vector::resize would clear them on one thread first)
+template <class T>
+class PodVec {
+public:
+	PodVec() = default;
+	PodVec(const PodVec &) = delete;
+	PodVec &operator=(const PodVec &) = delete;
+	~PodVec() { free(p_); }
+	T *data() { return p_; }
+	const T *data() const { return p_; }
+	size_t size() const { return n_; }
+	bool empty() const { return n_ == 0; }
+	T &operator[](size_t i) { return p_[i]; }
+	const T &operator[](size_t i) const { return p_[i]; }
+	void clear() { n_ = 0; }
+	void resize(size_t n) {
+		if (n > cap_) {
+			size_t c = cap_ ? cap_ : 1024;
+			while (c < n) c *= 2;
+			T *q = (T *)realloc(p_, c * sizeof(T));
+			if (!q) throw std::bad_alloc();
+			p_ = q; cap_ = c;
+		}
+		n_ = n;
+	}
+
+private:
+	T *p_ = nullptr;
+	size_t n_ = 0, cap_ = 0;
 };
 
-// Line-oriented FASTQ reader (plain or .gz by suffix, like LineReader::Open, linereader.cpp:14-29).
+struct FastqBatch {
+	PodVec<char> label_data;      // NUL-terminated labels, back to back
+	PodVec<uint64_t> label_offs;  // n
+	PodVec<uint8_t> bases, quals;  // concatenated
+	PodVec<uint64_t> offs;         // n+1
+	uint32_t size() const { return (uint32_t)label_offs.size(); }
+	const char *label(uint32_t i) const { return label_data.data() + label_offs[i]; }
+	void clear() { label_data.clear(); label_offs.clear(); bases.clear(); quals.clear(); offs.resize(1); offs[0] = 0; }
+};
+
+// FASTQ reader (plain or .gz by suffix, like LineReader::Open, linereader.cpp:14-29).  The file is read in large
+// blocks; line ends are located once, then the records of a batch are validated and copied by all host threads
+// (the reference parses one line at a time under a lock, fastqseqsource.cpp:9-116 -- same accept/reject rules).
 class FastqReader {
 public:
 	~FastqReader();
@@ -29,16 +67,20 @@ public:
 	const std::string &path() const { return path_; }
 
 private:
-	bool read_line(std::string &s);
-	bool fill();
+	size_t read_some(char *dst, size_t cap);
 	std::string path_;
 	FILE *f_ = nullptr;
 	void *gz_ = nullptr;
 	std::vector<char> buf_;
-	size_t pos_ = 0, len_ = 0;
-	bool eof_ = false;
-	uint64_t line_nr_ = 0;
+	size_t have_ = 0;  // valid bytes in buf_ (unconsumed input)
+	uint64_t file_off_ = 0;  // plain files: next byte to read
+	bool eof_ = false, finished_ = false;
+	uint64_t line_nr_ = 0;  // lines consumed so far
+	std::vector<size_t> ends_;  // scratch: end offset of every line of the batch
 };
+
+// mates interleaved (reads 2i, 2i+1 = pair i), all host threads
+void interleave_batches(const FastqBatch &a, const FastqBatch &b, FastqBatch &out);
 
 // CIGAR of a run-length path (NULL/0 => "<QL>M"), D<->I swapped, dangling terminal M merged.
 std::string path_to_cigar(const urmapx_path_op *ops, unsigned nops, unsigned QL);

@@ -10,6 +10,12 @@
 // a writer thread formats and writes the SAM of batch k-1.  Records are written in input order (the reference's
 // order is nondeterministic with more than one thread).  Errors: message on stderr, exit status 1
 // (myutils.cpp:915), as the reference.
+#include <fcntl.h>
+#include <omp.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <cstdarg>
@@ -107,6 +113,14 @@ public:
 		cv_.notify_all();
 		return true;
 	}
+	bool try_pop(T &v) {
+		std::lock_guard<std::mutex> l(m_);
+		if (q_.empty()) return false;
+		v = std::move(q_.front());
+		q_.pop_front();
+		cv_.notify_all();
+		return true;
+	}
 	void close() {
 		std::lock_guard<std::mutex> l(m_);
 		closed_ = true;
@@ -139,13 +153,19 @@ static int cmd_map(const Opts &o, int argc, char **argv) {
 	check(urmapx_ctx_create(I, o.gpu, &P, &C), "Creating mapping context");
 	if (!o.map2.empty() && o.veryfast) check(urmapx_ctx_set_pe_veryfast(C, 1), "Search5");
 	if (o.veryfast && urmapx_index_max_ix(I) > 3) fprintf(stderr, "\nWARNING: index not optimal for -veryfast\n");
-	FILE *fsam = nullptr;
+	// host threads for FASTQ parsing and SAM formatting (-threads; the mapping itself runs on the GPU)
+	int host_threads = o.threads ? (int)o.threads : std::min(16, std::max(1, (int)std::thread::hardware_concurrency()));
+	omp_set_num_threads(host_threads);
+	int fsam = -1;
+	uint64_t sam_off = 0;
+	std::atomic<bool> write_failed{false};
 	if (!o.samout.empty()) {
-		fsam = fopen(o.samout.c_str(), "wb");
-		if (!fsam) die("Cannot create %s", o.samout.c_str());
+		fsam = open(o.samout.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+		if (fsam < 0) die("Cannot create %s", o.samout.c_str());
 		std::string hdr;
 		append_sam_header(hdr, I, argc, argv);
-		fwrite(hdr.data(), 1, hdr.size(), fsam);
+		if (write(fsam, hdr.data(), hdr.size()) != (ssize_t)hdr.size()) die("Cannot write %s", o.samout.c_str());
+		sam_off = hdr.size();
 	}
 	FastqReader rd, rd2;
 	std::string err;
@@ -153,14 +173,19 @@ static int cmd_map(const Opts &o, int argc, char **argv) {
 	if (paired && !rd2.open(o.reverse, err)) die("%s", err.c_str());
 	const auto t1 = std::chrono::steady_clock::now();
 
-	Channel<std::unique_ptr<Job>> parsed(3), mapped(3);
+	Channel<std::unique_ptr<Job>> parsed(3), mapped(3), recycled(16);  // finished jobs go back to the reader: their arrays are reused
+	double t_parse = 0, t_gpu = 0, t_format = 0, t_write = 0;  // busy seconds per stage (URMAPX_VERBOSE)
+	auto now = [] { return std::chrono::steady_clock::now(); };
+	auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
 	std::string reader_err;
 	std::thread reader([&] {
 		for (;;) {
-			auto j = std::make_unique<Job>();
+			std::unique_ptr<Job> j;
+			if (!recycled.try_pop(j)) j = std::make_unique<Job>();
 			j->reads.clear();
 			std::string e;
 			bool more;
+			const auto tp0 = now();
 			if (!paired)
 				more = rd.next_batch(j->reads, o.batch, e);
 			else {  // mates interleaved: reads 2i, 2i+1 (map2.cpp:27-32 reads one record from each file under one lock)
@@ -171,15 +196,9 @@ static int cmd_map(const Opts &o, int argc, char **argv) {
 				bool more2 = rd2.next_batch(b, o.batch / 2, e2);
 				if (e.empty()) e = e2;
 				if (e.empty() && (more != more2 || a.size() != b.size())) e = std::string("Premature end of file in FASTQ") + (a.size() > b.size() ? "2" : "1");
-				for (uint32_t i = 0; e.empty() && i < a.size(); ++i) {
-					for (const FastqBatch *src : {&a, &b}) {
-						j->reads.labels.push_back(src->labels[i]);
-						j->reads.bases.insert(j->reads.bases.end(), src->bases.begin() + (ptrdiff_t)src->offs[i], src->bases.begin() + (ptrdiff_t)src->offs[i + 1]);
-						j->reads.quals.insert(j->reads.quals.end(), src->quals.begin() + (ptrdiff_t)src->offs[i], src->quals.begin() + (ptrdiff_t)src->offs[i + 1]);
-						j->reads.offs.push_back(j->reads.bases.size());
-					}
-				}
+				if (e.empty()) interleave_batches(a, b, j->reads);
 			}
+			t_parse += secs(tp0, now());
 			if (!e.empty()) { reader_err = e; break; }
 			if (!more) break;
 			parsed.push(std::move(j));
@@ -188,37 +207,70 @@ static int cmd_map(const Opts &o, int argc, char **argv) {
 	});
 	unsigned long long n_reads = 0, n_accept = 0, n_reject = 0, n_nohit = 0, n_unsupported = 0;
 	std::thread writer([&] {
+		// SAM text of a batch is formatted by all host threads, each on a contiguous range of reads (pairs), and the
+		// pieces are written at their file offsets in input order.
 		std::unique_ptr<Job> j;
-		std::string out;
+		std::vector<std::string> outs((size_t)host_threads);
+		struct Cnt { unsigned long long accept = 0, reject = 0, nohit = 0, unsupported = 0; };
 		while (mapped.pop(j)) {
-			out.clear();
 			const uint32_t n = j->reads.size();
-			std::vector<char> pbuf;
-			for (uint32_t i = 0; i < n; ++i) {
-				const urmapx_result &r = j->results[i];
-				const uint64_t off = j->reads.offs[i];
-				const unsigned L = (unsigned)(j->reads.offs[i + 1] - off);
-				if (fsam && !paired)
-					append_sam_record(out, I, r, j->ops.data(), 0, "*", 0xFFFFFFFFu, 0, j->reads.labels[i].c_str(),
-					                  j->reads.bases.data() + off, j->reads.quals.data() + off, L);
-				if (fsam && paired && (i & 1) == 0) {
-					const uint64_t off2 = j->reads.offs[i + 1];
-					const unsigned L2 = (unsigned)(j->reads.offs[i + 2] - off2);
-					pbuf.resize(j->reads.labels[i].size() + j->reads.labels[i + 1].size() + 3 * (size_t)(L + L2) + 2048);
-					size_t k = urmapx_sam_pe(I, &j->results[i], &j->results[i + 1], j->ops.data(), j->reads.labels[i].c_str(),
-					                         j->reads.bases.data() + off, j->reads.quals.data() + off, L,
-					                         j->reads.labels[i + 1].c_str(), j->reads.bases.data() + off2,
-					                         j->reads.quals.data() + off2, L2, pbuf.data(), pbuf.size());
-					out.append(pbuf.data(), k);
+			const uint32_t units = paired ? n / 2 : n;
+			std::vector<Cnt> cnt((size_t)host_threads);
+			const auto tf0 = now();
+#pragma omp parallel for schedule(static, 1) num_threads(host_threads)
+			for (int t = 0; t < host_threads; ++t) {
+				std::string &out = outs[(size_t)t];
+				out.clear();
+				Cnt &c = cnt[(size_t)t];
+				const uint32_t u0 = (uint32_t)((uint64_t)units * (uint64_t)t / (uint64_t)host_threads);
+				const uint32_t u1 = (uint32_t)((uint64_t)units * (uint64_t)(t + 1) / (uint64_t)host_threads);
+				std::vector<char> pbuf;
+				for (uint32_t i = paired ? 2 * u0 : u0; i < (paired ? 2 * u1 : u1); ++i) {
+					const urmapx_result &r = j->results[i];
+					const uint64_t off = j->reads.offs[i];
+					const unsigned L = (unsigned)(j->reads.offs[i + 1] - off);
+					if (fsam >= 0 && !paired)
+						append_sam_record(out, I, r, j->ops.data(), 0, "*", 0xFFFFFFFFu, 0, j->reads.label(i),
+						                  j->reads.bases.data() + off, j->reads.quals.data() + off, L);
+					if (fsam >= 0 && paired && (i & 1) == 0) {
+						const uint64_t off2 = j->reads.offs[i + 1];
+						const unsigned L2 = (unsigned)(j->reads.offs[i + 2] - off2);
+						pbuf.resize(strlen(j->reads.label(i)) + strlen(j->reads.label(i + 1)) + 3 * (size_t)(L + L2) + 2048);
+						size_t k = urmapx_sam_pe(I, &j->results[i], &j->results[i + 1], j->ops.data(), j->reads.label(i),
+						                         j->reads.bases.data() + off, j->reads.quals.data() + off, L,
+						                         j->reads.label(i + 1), j->reads.bases.data() + off2,
+						                         j->reads.quals.data() + off2, L2, pbuf.data(), pbuf.size());
+						out.append(pbuf.data(), k);
+					}
+					// HitStats counters (output1.cpp:20-30)
+					if (r.status) ++c.unsupported;
+					if (r.dbpos == 0xFFFFFFFFu) ++c.nohit;
+					else if (r.mapq >= o.minq) ++c.accept;
+					else ++c.reject;
 				}
-				// HitStats counters (output1.cpp:20-30)
-				if (r.status) ++n_unsupported;
-				if (r.dbpos == 0xFFFFFFFFu) ++n_nohit;
-				else if (r.mapq >= o.minq) ++n_accept;
-				else ++n_reject;
 			}
+			for (const Cnt &c : cnt) { n_accept += c.accept; n_reject += c.reject; n_nohit += c.nohit; n_unsupported += c.unsupported; }
 			n_reads += n;
-			if (fsam) fwrite(out.data(), 1, out.size(), fsam);
+			const auto tf1 = now();
+			t_format += secs(tf0, tf1);
+			if (fsam >= 0) {
+				std::vector<uint64_t> at((size_t)host_threads + 1);
+				at[0] = sam_off;
+				for (int t = 0; t < host_threads; ++t) at[(size_t)t + 1] = at[(size_t)t] + outs[(size_t)t].size();
+				sam_off = at[(size_t)host_threads];
+#pragma omp parallel for schedule(static, 1) num_threads(host_threads)
+				for (int t = 0; t < host_threads; ++t) {
+					const std::string &out = outs[(size_t)t];
+					size_t done = 0;
+					while (done < out.size()) {
+						ssize_t w = pwrite(fsam, out.data() + done, out.size() - done, (off_t)(at[(size_t)t] + done));
+						if (w <= 0) { write_failed = true; break; }
+						done += (size_t)w;
+					}
+				}
+			}
+			t_write += secs(tf1, now());
+			recycled.push(std::move(j));
 		}
 	});
 	std::unique_ptr<Job> j;
@@ -227,21 +279,27 @@ static int cmd_map(const Opts &o, int argc, char **argv) {
 		j->results.resize(n);
 		j->ops.resize((size_t)n * URMAPX_MAX_PATH_OPS);
 		size_t used = 0;
+		const auto tg0 = now();
 		int rc = paired ? urmapx_map_pe(C, j->reads.bases.data(), j->reads.offs.data(), n / 2, j->results.data(), j->ops.data(),
 		                                j->ops.size(), &used)
 		                : urmapx_map_se(C, j->reads.bases.data(), j->reads.offs.data(), n, j->results.data(), j->ops.data(),
 		                                j->ops.size(), &used);
 		check(rc, paired ? "urmapx_map_pe" : "urmapx_map_se");
+		t_gpu += secs(tg0, now());
 		mapped.push(std::move(j));
 	}
 	mapped.close();
 	reader.join();
 	writer.join();
 	if (!reader_err.empty()) die("%s", reader_err.c_str());
-	if (fsam) fclose(fsam);
+	if (fsam >= 0) close(fsam);
+	if (write_failed) die("Error writing %s", o.samout.c_str());
 	const auto t2 = std::chrono::steady_clock::now();
 	const double load_s = std::chrono::duration<double>(t1 - t0).count();
 	const double map_s = std::chrono::duration<double>(t2 - t1).count();
+	if (getenv("URMAPX_VERBOSE"))
+		fprintf(stderr, "stage busy seconds: parse %.2f, gpu (copies + kernels) %.2f, format %.2f, write %.2f; %d host threads\n",
+		        t_parse, t_gpu, t_format, t_write, host_threads);
 	if (!o.quiet) {
 		auto pct = [&](unsigned long long x) { return n_reads ? 100.0 * (double)x / (double)n_reads : 0.0; };
 		fprintf(stderr, "\n%16.1f  Seconds to load index\n%16.1f  Seconds in mapper\n%16llu  Reads\n", load_s, map_s, n_reads);
@@ -266,6 +324,7 @@ static int cmd_make_ufi(const Opts &o) {
 }
 
 int main(int argc, char **argv) {
+	setenv("OMP_WAIT_POLICY", "passive", 0);  // idle pool threads sleep: three pipeline stages share the cores
 	Opts o = parse(argc, argv);
 	if (!o.map.empty() || !o.map2.empty()) return cmd_map(o, argc, argv);
 	if (!o.make_ufi.empty()) return cmd_make_ufi(o);
