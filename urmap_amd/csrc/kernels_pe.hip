@@ -1,10 +1,12 @@
 // kernels_pe.hip -- paired-end search (urmap -map2): State2::Search4 (search2m4.cpp:15-208) and everything under it,
 // one wavefront per read PAIR.
 //
-// First correct version: the schedule is emulated step by step, wave-uniform, with the 64 lanes used inside each
-// primitive (64 bases per compare in ExtendPen / ExtendScan, one DP diagonal per lane in Viterbi, 64 window
-// positions per step in ScanSlots, one hit / HSP per lane in the list searches).  It does not yet batch candidate
-// windows the way search_se_kernel does; correctness against the oracle first, memory-level parallelism next.
+// The schedule is emulated step by step, wave-uniform, with the 64 lanes used inside each primitive (one DP
+// diagonal per lane in Viterbi, 64 window positions per step in ScanSlots, one hit / HSP per lane in the list
+// searches).  The ExtendPen outcome of every Both1 seed does not depend on the search state, so it is computed up
+// front, one seed per lane (the same gather as search_se_kernel's), and the ordered pairing loop only consumes the
+// cached outcomes; repeated calls on a seed that cannot change anything any more are dropped 64 at a time.
+// The pending-list stage (SearchPE_Pending) still extends its chain rows one window at a time.
 //
 // Reference functions: GetFirstBoth1Seed / GetNextBoth1Seed (getseed.cpp:9-138), ExtendBoth1Pair4
 // (search2m4.cpp:189-208), ExtendPen (extendpen.cpp:9-95), SearchPE_Pending (search1pepend.cpp:9-130),
@@ -18,7 +20,6 @@ namespace urx {
 
 static constexpr int PE_HIT_CAP = 64;
 static constexpr int PE_HSP_CAP = 128;
-static constexpr int PE_SEED_CAP = 640;   // >= 2 * (QMAX - W + 1)
 static constexpr int PE_PAIR_CAP = 256;
 static constexpr int PE_SCAN_SEG = 1024;  // SCAN_DB_SEG_LENGTH, state2.cpp:92
 static constexpr uint32_t PRIME_STRIDE = 27, SCANK = 4;
@@ -62,6 +63,13 @@ struct Mate {
 
 	__device__ __forceinline__ bool overlaps_hit(uint32_t db) const {
 		return __ballot(lane < hitCount && (hit_db >> 6) == (db >> 6)) != 0;
+	}
+
+	// per-lane form of OverlapsHit
+	__device__ __forceinline__ bool overlaps_any_hit(uint32_t db) const {
+		bool ov = false;
+		for (int k = 0; k < hitCount; ++k) ov |= (rdlane(hit_db, k) >> 6) == (db >> 6);
+		return ov;
 	}
 
 	// state1.cpp:508-551; returns the hit index or -1.  A path, if any, is in `cand`.
@@ -197,6 +205,27 @@ struct Mate {
 		const int minhsp = (int)((uint32_t)P->min_hsp_score_pct * (uint32_t)QL / 100.0);
 		if (bst >= minhsp) {
 			add_hsp((uint32_t)sp, dblo + (uint32_t)sp, plus, (uint32_t)(ep - sp + 1), bst);
+			return -2;
+		}
+		return -1;
+	}
+
+	// ExtendPen (extendpen.cpp:9-95) from the outcome cached by the seed gather: res = kind << 27 | end << 18 |
+	// start << 9 | score of the uncapped x-drop walk, pen = its accumulated penalty (the capped walk aborts iff the
+	// final penalty exceeds the cap, because the penalty only grows along the walk)
+	__device__ __forceinline__ int extend_pen_cached(uint32_t seedq, uint32_t seeddb, bool plus, uint32_t res, int pen) {
+		if (seeddb < seedq) return -1;
+		const uint32_t dblo = seeddb - seedq;
+		if (overlaps_hit(dblo)) return -1;
+		if (pen > maxPen) return -1;
+		const int kind = (int)(res >> 27), bst = (int)(res & 511u);
+		if (kind == 1) {
+			add_hit(dblo, plus, bst, 0);
+			return bst;
+		}
+		if (kind == 2) {
+			const uint32_t sp = (res >> 9) & 511u, ep = (res >> 18) & 511u;
+			add_hsp(sp, dblo + sp, plus, ep - sp + 1, bst);
 			return -2;
 		}
 		return -1;
@@ -482,7 +511,7 @@ __global__ __launch_bounds__(64) void search_pe_kernel(DevIndex X, urmapx_params
                                                        int veryfast) {
 	using M = Mate<NCH>;
 	constexpr int QMAX = M::QMAX;
-	__shared__ uint8_t sQ[4][QMAX];
+	__shared__ __attribute__((aligned(16))) uint8_t sQ[4][QMAX];
 	__shared__ uint8_t sT[QMAX + 64];
 	__shared__ uint32_t tb[M::TB_ROWS8 * 64];
 	__shared__ uint16_t ropsL[OPS_CAP], ropsR[OPS_CAP], cand[URMAPX_MAX_PATH_OPS];
@@ -491,8 +520,12 @@ __global__ __launch_bounds__(64) void search_pe_kernel(DevIndex X, urmapx_params
 	__shared__ uint16_t hsp_sf[2][PE_HSP_CAP];
 	__shared__ uint8_t pend[4][QMAX];
 	// Both1 seed lists of the two mates in enumeration order: qpos | plus << 15, db position
-	__shared__ uint16_t seed_q[2][PE_SEED_CAP];
-	__shared__ uint32_t seed_db[2][PE_SEED_CAP];
+	constexpr int SEED_CAP = 2 * QMAX;  // >= 2 * (QMAX - W + 1)
+	__shared__ uint16_t seed_q[2][SEED_CAP];
+	__shared__ uint32_t seed_db[2][SEED_CAP];
+	// cached ExtendPen outcome of every seed (see extend_pen_cached); bit 15 of seed_pen = "already extended once"
+	__shared__ uint32_t seed_res[2][SEED_CAP];
+	__shared__ uint16_t seed_pen[2][SEED_CAP];
 	__shared__ uint16_t pair_f[PE_PAIR_CAP], pair_r[PE_PAIR_CAP];
 	// probe results of both mates staged in LDS ([mate][strand][qpos]): the seed enumeration reads them one by one
 	__shared__ uint8_t s_tal[2][2][QMAX];
@@ -596,7 +629,7 @@ __global__ __launch_bounds__(64) void search_pe_kernel(DevIndex X, urmapx_params
 						if (special) { if (lane == 0) m[a].pend[1][nm] = (uint8_t)qpos; ++nm; }
 						continue;
 					}
-					if (ns < PE_SEED_CAP) {
+					if (ns < SEED_CAP) {
 						if (lane == 0) { seed_q[a][ns] = (uint16_t)(qpos | (s == 0 ? 0x8000u : 0u)); seed_db[a][ns] = db; }
 						++ns;
 					} else
@@ -611,6 +644,68 @@ __global__ __launch_bounds__(64) void search_pe_kernel(DevIndex X, urmapx_params
 			m[a].pendCount[0] = np; m[a].pendCount[1] = nm;
 		}
 		__syncthreads();
+
+		// ---- seed gather: the ExtendPen outcome of every seed, one seed per lane ----
+		for (int a = 0; a < 2; ++a) {
+			const int QL = m[a].QL;
+			const int minhsp = (int)((uint32_t)P.min_hsp_score_pct * (uint32_t)QL / 100.0);
+			for (int base = 0; base < nseed[a]; base += 64) {
+				const int i = base + lane;
+				uint32_t res = 0;
+				int pen = 0;
+				if (i < nseed[a]) {
+					const uint32_t q = seed_q[a][i] & 0x7FFFu, db = seed_db[a][i];
+					const bool plus = (seed_q[a][i] & 0x8000u) != 0;
+					if (db >= q) {
+						uint64_t mm[NCH];
+						lane_mismatch_mask<NCH>(g_seq, db - q, sQ[2 * a + (plus ? 0 : 1)], QL, mm);
+						int bst, sp, ep;
+						xdrop_walk_lane<NCH>(mm, (int)q, W, QL, P.mismatch_score, P.xdrop, bst, sp, ep, pen);
+						const uint32_t kind = (sp == 0 && ep == QL - 1) ? 1u : (bst >= minhsp ? 2u : 0u);
+						res = (kind << 27) | ((uint32_t)ep << 18) | ((uint32_t)sp << 9) | (uint32_t)bst;
+					}
+					seed_res[a][i] = res;
+					seed_pen[a][i] = (uint16_t)pen;
+				}
+			}
+		}
+		__syncthreads();
+		// ExtendPen on seed i of mate a, in order (state changing), through the cache
+		auto extend_seed = [&](int a, int i) -> int {
+			const uint32_t sq = seed_q[a][i];
+			const uint32_t pn = seed_pen[a][i];
+			const int r = m[a].extend_pen_cached(sq & 0x7FFFu, seed_db[a][i], (sq & 0x8000u) != 0, seed_res[a][i], (int)(pn & 0x7FFFu));
+			if ((pn & 0x8000u) == 0) {
+				__syncthreads();
+				if (lane == 0) seed_pen[a][i] = (uint16_t)(pn | 0x8000u);
+				__syncthreads();
+			}
+			return r;
+		};
+		// ExtendBoth1Pair4 extends the partner seed on the strand OPPOSITE to the new seed's, whatever strand the partner
+		// seed itself was found on (search2m4.cpp:189-208).  The cache holds a seed's outcome on its own strand; the
+		// rare same-strand partner is extended the slow way (one window, 64 bases per compare).
+		auto extend_seed_as = [&](int a, int i, bool plus_req) -> int {
+			const uint32_t sq = seed_q[a][i];
+			if (((sq & 0x8000u) != 0) == plus_req) return extend_seed(a, i);
+			return m[a].extend_pen(sq & 0x7FFFu, seed_db[a][i], plus_req);
+		};
+		// Lanes = seeds base.. of mate a: true where a repeated ExtendPen on that seed is certain to return <= 0 without
+		// changing anything: it has been extended before, and it is not a full-length hit, or its penalty exceeds the
+		// cap (which only falls here), or it lies on a found hit's diagonal block (hits are never removed).  An HSP seed
+		// extended again re-offers the same HSP (no change); a hit seed extended again either overlaps its own hit or
+		// was rejected by AddHitX for its score, which stays rejected because the best score only rises.
+		auto settled = [&](int a, int base, int n, bool plus_req) -> uint64_t {
+			const int i = base + lane;
+			bool st = false;
+			if (i < n) {
+				const uint32_t pn = seed_pen[a][i], res = seed_res[a][i];
+				const uint32_t q = seed_q[a][i] & 0x7FFFu, db = seed_db[a][i];
+				if ((pn & 0x8000u) && ((seed_q[a][i] & 0x8000u) != 0) == plus_req)
+					st = db < q || (res >> 27) != 1u || (int)(pn & 0x7FFFu) > m[a].maxPen || m[a].overlaps_any_hit(db - q);
+			}
+			return __ballot(st);
+		};
 
 		// ---- Search4 pairing loop (search2m4.cpp:71-143) ----
 		const int QLf = m[0].QL, QLr = m[1].QL;
@@ -633,17 +728,20 @@ __global__ __launch_bounds__(64) void search_pe_kernel(DevIndex X, urmapx_params
 			};
 			for (int t = 0; t < steps && !done; ++t) {
 				if (t < nseed[0]) {
-					const uint32_t qf = seed_q[0][t] & 0x7FFFu, dbf = seed_db[0][t];
+					// ExtendBoth1Pair4(new forward seed t, earlier reverse seed i): the forward seed is extended first,
+					// every time.  Once that returns <= 0 it does so for the rest of this step (settled), so the step ends.
+					const uint32_t dbf = seed_db[0][t];
 					const bool plusf = (seed_q[0][t] & 0x8000u) != 0;
 					const int nr = min(t, nseed[1]);
-					for (int base = 0; base < nr && !done; base += 64) {
+					bool fwd_dead = false;
+					for (int base = 0; base < nr && !done && !fwd_dead; base += 64) {
 						uint64_t mk = near_mask(1, base, nr, dbf);
 						while (mk && !done) {
 							const int i = base + __builtin_ctzll(mk);
 							mk &= mk - 1;
-							const int fs = m[0].extend_pen(qf, dbf, plusf);
-							if (fs <= 0) continue;
-							const int rs = m[1].extend_pen(seed_q[1][i] & 0x7FFFu, seed_db[1][i], !plusf);
+							const int fs = extend_seed(0, t);
+							if (fs <= 0) { fwd_dead = true; break; }
+							const int rs = extend_seed_as(1, i, !plusf);
 							if (rs <= 0) continue;
 							if (fs + rs < termPair) continue;
 							m[0].mapq = 40; m[1].mapq = 40; done = true;
@@ -651,17 +749,20 @@ __global__ __launch_bounds__(64) void search_pe_kernel(DevIndex X, urmapx_params
 					}
 				}
 				if (t < nseed[1] && !done) {
-					const uint32_t qr = seed_q[1][t] & 0x7FFFu, dbr = seed_db[1][t];
+					// ExtendBoth1Pair4(earlier forward seed i, new reverse seed t): forward seeds that are settled are
+					// skipped (their ExtendPen returns <= 0 and the pair is dropped before the reverse seed is touched)
+					const uint32_t dbr = seed_db[1][t];
 					const bool plusr = (seed_q[1][t] & 0x8000u) != 0;
 					const int nf = min(t + 1, nseed[0]);
 					for (int base = 0; base < nf && !done; base += 64) {
 						uint64_t mk = near_mask(0, base, nf, dbr);
+						if (mk) mk &= ~settled(0, base, nf, !plusr);
 						while (mk && !done) {
 							const int i = base + __builtin_ctzll(mk);
 							mk &= mk - 1;
-							const int fs = m[0].extend_pen(seed_q[0][i] & 0x7FFFu, seed_db[0][i], !plusr);
+							const int fs = extend_seed_as(0, i, !plusr);
 							if (fs <= 0) continue;
-							const int rs = m[1].extend_pen(qr, dbr, plusr);
+							const int rs = extend_seed(1, t);
 							if (rs <= 0) continue;
 							if (fs + rs < termPair) continue;
 							m[0].mapq = 40; m[1].mapq = 40; done = true;
@@ -673,9 +774,17 @@ __global__ __launch_bounds__(64) void search_pe_kernel(DevIndex X, urmapx_params
 		int npairs_found = 0, bestPairScore = -1, secondPairScore = -1, bestPairIndex = -1;
 		if (!done) {
 			// all collected seeds, each mate (search2m4.cpp:145-158)
+			// (a seed extended before changes nothing when extended again, see settled(); only the others are visited)
 			for (int a = 0; a < 2; ++a)
-				for (int i = 0; i < nseed[a]; ++i)
-					m[a].extend_pen(seed_q[a][i] & 0x7FFFu, seed_db[a][i], (seed_q[a][i] & 0x8000u) != 0);
+				for (int base = 0; base < nseed[a]; base += 64) {
+					const int i0 = base + lane;
+					uint64_t mk = __ballot(i0 < nseed[a] && (seed_pen[a][i0 < nseed[a] ? i0 : 0] & 0x8000u) == 0);
+					while (mk) {
+						const int i = base + __builtin_ctzll(mk);
+						mk &= mk - 1;
+						extend_seed(a, i);
+					}
+				}
 			if (veryfast) {
 				// Search5 (search2m5.cpp:112-127): no 90 % shortcut and no pair stage; each mate finishes on its own
 				m[0].search_pending();
