@@ -21,9 +21,16 @@ namespace urx {
 static constexpr int PE_HIT_CAP = 64;
 static constexpr int PE_HSP_CAP = 128;
 static constexpr int PE_PAIR_CAP = 256;
+static constexpr int PE_ROW_CAP = 32;   // UFIndex m_MaxIx of every index this build accepts
 static constexpr int PE_SCAN_SEG = 1024;  // SCAN_DB_SEG_LENGTH, state2.cpp:92
 static constexpr uint32_t PRIME_STRIDE = 27, SCANK = 4;
 static constexpr int MAX_TL = 1000;
+
+// per-block global scratch: hit paths of both mates, the wide-band Viterbi scratch, then the pending rows
+__host__ __device__ inline size_t pe_rowstore_offset(int qmax) {
+	size_t b = (size_t)2 * PE_HIT_CAP * URMAPX_MAX_PATH_OPS * 2 + WideScratch::bytes(qmax, PE_SCAN_SEG + 2 * qmax + 64);
+	return (b + 15) & ~(size_t)15;
+}
 
 template <int NCH>
 struct Mate {
@@ -55,6 +62,9 @@ struct Mate {
 	uint32_t *hsp_db, *hsp_ql;  // LDS [PE_HSP_CAP]
 	uint16_t *hsp_sf;
 	uint8_t *pend[2];     // LDS [QMAX] each: pending query positions (stored in a byte, state1.h:86-87)
+	uint8_t *rowlen;      // LDS [2 * QMAX]: row length of every pending position, [strand][i]
+	uint16_t *pre;        // LDS [65]
+	uint32_t *rowstore;   // global, this block: [strand][chunk][k][lane]
 	int pendCount[2];
 	int hitCount, hspCount, topHit;
 	int maxPen, best, second, bestHSP;
@@ -372,7 +382,11 @@ struct Mate {
 		}
 	}
 
-	// search1pepend.cpp:9-130
+	// search1pepend.cpp:9-130.  The reference walks the pending query positions one by one (GetRow_Blob, then ExtendPen on
+	// every row entry): rows of length <= 2 first, plus strand then minus, longer rows in a second round.  Here, per
+	// strand, the chains of 64 pending positions are walked at once (one chain per lane), and each (round, strand,
+	// chunk) group of row entries goes through the same gather / ordered-consume split as search_se_kernel: outcome of
+	// the uncapped x-drop walk per lane, then only the state-changing candidates in the reference's order.
 	__device__ void search_pending() {
 		maxPen = P->max_penalty;
 		const int minScore1 = QL + P->xphase1 * P->mismatch_score;
@@ -382,27 +396,109 @@ struct Mate {
 			for (int k = 0; k < hspCount; ++k) align_hsp(k);
 			if (best >= minScore1) { mapq = calc_mapq(); return; }
 		}
-		int count2[2] = {0, 0};
+		const int minhsp = (int)((uint32_t)P->min_hsp_score_pct * (uint32_t)QL / 100.0);
+		const uint64_t N = X->slotCount;
+		const int maxIx = (int)X->maxIx;
+		// 1. all chains: rowstore[strand][chunk][k][lane], row length in rowlen[strand][i]
+		for (int s = 0; s < 2; ++s) {
+			for (int base = 0; base < pendCount[s]; base += 64) {
+				const int i = base + lane;
+				uint32_t *rs = rowstore + ((size_t)(s * NCH + (base >> 6)) * PE_ROW_CAP) * 64 + lane;
+				int K = 0;
+				bool act = i < pendCount[s];
+				uint64_t slot2 = 0;
+				uint32_t T = 0, pos = 0;
+				if (act) {
+					const size_t idx = (size_t)s * QL + pend[s][i];
+					slot2 = pslots[idx]; T = ptal[idx]; pos = ppos[idx];
+					act = (T & TALLY_MY_BIT) != 0;  // GetRow_Blob returns 0 for a slot that is not "mine"
+				}
+				while (__ballot(act)) {
+					if (act) {
+						rs[K * 64] = pos;
+						++K;
+						if (K == maxIx || K >= PE_ROW_CAP) act = false;
+						else if (T == TALLY_PLUS1 || T == TALLY_BOTH1) { K = 1; act = false; }
+						else if (T == TALLY_END) act = false;
+						else if (T == TALLY_LONG_MINE || T == TALLY_LONG_OTHER) {
+							const uint64_t slotA = addmod(slot2, pos & 0xFFFFu, N);
+							slot2 = addmod(slotA, pos >> 16, N);
+							uint32_t tA, pA;
+							load_slot(gblob, slotA, tA, pA);
+							rs[(K - 1) * 64] = pA;
+						} else
+							slot2 = addmod(slot2, T & TALLY_NEXT_MASK, N);
+						if (act) load_slot(gblob, slot2, T, pos);
+					}
+				}
+				if (i < pendCount[s]) rowlen[s * QMAX + i] = (uint8_t)K;
+			}
+		}
+		__syncthreads();
+		// 2. the four groups in the reference's order, 64 pending positions at a time
 		for (int round = 0; round < 2; ++round) {
 			for (int s = 0; s < 2; ++s) {
 				const bool plus = (s == 0);
-				const int n = round == 0 ? pendCount[s] : count2[s];
-				for (int i = 0; i < n; ++i) {
-					const uint32_t qpos = pend[s][i];
-					const size_t idx = (size_t)s * QL + qpos;
-					const uint64_t slot = uni64(pslots[idx]);
-					const uint32_t T = uni((uint32_t)ptal[idx]);
-					const uint32_t pos = uni(ppos[idx]);
-					uint32_t row = 0;
-					const int K = get_row(slot, T, pos, row);
-					if (round == 0 && K > 2) {
-						__syncthreads();
-						if (lane == 0) pend[s][count2[s]] = (uint8_t)qpos;
-						__syncthreads();
-						++count2[s];
-						continue;
+				for (int base = 0; base < pendCount[s]; base += 64) {
+					const int i = base + lane;
+					int K = 0;
+					if (i < pendCount[s]) K = rowlen[s * QMAX + i];
+					const int cnt = (round == 0 ? K <= 2 : K > 2) ? K : 0;
+					const int inc = wave_prefix_sum(cnt);
+					const int total = rdlane(inc, 63);
+					if (total == 0) continue;
+					__syncthreads();
+					pre[lane] = (uint16_t)(inc - cnt);
+					if (lane == 0) pre[64] = (uint16_t)total;
+					__syncthreads();
+					const uint32_t *rs0 = rowstore + ((size_t)(s * NCH + (base >> 6)) * PE_ROW_CAP) * 64;
+					for (int gb = 0; gb < total; gb += 64) {
+						const int g = gb + lane;
+						uint32_t c_q = 0, c_db = 0;
+						bool ok = false;
+						if (g < total) {
+							int lo = 0, hi = 63;  // row r with pre[r] <= g < pre[r + 1]; empty rows share a prefix value
+							while (lo < hi) {
+								const int mid = (lo + hi + 1) >> 1;
+								if ((int)pre[mid] <= g) lo = mid;
+								else hi = mid - 1;
+							}
+							const int k = g - (int)pre[lo];
+							c_q = pend[s][base + lo];
+							c_db = rs0[k * 64 + lo];
+							ok = c_db >= c_q;
+						}
+						const uint32_t dblo = c_db - c_q;
+						ok = ok && !overlaps_any_hit(dblo);
+						int e_kind = 0, e_bst = 0, e_sp = 0, e_ep = 0, e_pen = 0;
+						if (ok) {
+							uint64_t mm[NCH];
+							lane_mismatch_mask<NCH>(gseq, dblo, sQ[s], QL, mm);
+							xdrop_walk_lane<NCH>(mm, (int)c_q, W, QL, P->mismatch_score, P->xdrop, e_bst, e_sp, e_ep, e_pen);
+							if (e_sp == 0 && e_ep == QL - 1) e_kind = 1;
+							else if (e_bst >= minhsp) e_kind = 2;
+						}
+						// ordered part (see search_se_kernel): candidates that cannot change the state are dropped, up front
+						// and after every change
+						uint64_t todo = __ballot(e_kind != 0 && e_pen <= maxPen && !(e_kind == 2 && e_bst < best - 4));
+						while (todo) {
+							const int t = __builtin_ctzll(todo);
+							todo &= todo - 1;
+							const uint32_t d = rdlane(dblo, t);
+							if (overlaps_hit(d)) continue;
+							if (rdlane(e_pen, t) > maxPen) continue;
+							const int bst = rdlane(e_bst, t);
+							const int hc0 = hitCount, mp0 = maxPen, b0 = best;
+							if (rdlane(e_kind, t) == 1) add_hit(d, plus, bst, 0);
+							else {
+								const uint32_t sp = (uint32_t)rdlane(e_sp, t), ep = (uint32_t)rdlane(e_ep, t);
+								add_hsp(sp, d + sp, plus, ep - sp + 1, bst);
+							}
+							if (hitCount != hc0 || maxPen != mp0 || best != b0)
+								todo &= __ballot(e_pen <= maxPen && !(e_kind == 2 && e_bst < best - 4) &&
+								                 !(hitCount != hc0 && (dblo >> 6) == (d >> 6)));
+						}
 					}
-					for (int t = 0; t < K; ++t) extend_pen(qpos, rdlane(row, t), plus);
 				}
 			}
 		}
@@ -519,6 +615,8 @@ __global__ __launch_bounds__(64) void search_pe_kernel(DevIndex X, urmapx_params
 	__shared__ uint32_t hsp_db[2][PE_HSP_CAP], hsp_ql[2][PE_HSP_CAP];
 	__shared__ uint16_t hsp_sf[2][PE_HSP_CAP];
 	__shared__ uint8_t pend[4][QMAX];
+	__shared__ uint8_t rowlen[2 * QMAX];  // shared by the two mates: SearchPE_Pending runs on one mate at a time
+	__shared__ uint16_t pre[66];
 	// Both1 seed lists of the two mates in enumeration order: qpos | plus << 15, db position
 	constexpr int SEED_CAP = 2 * QMAX;  // >= 2 * (QMAX - W + 1)
 	__shared__ uint16_t seed_q[2][SEED_CAP];
@@ -533,6 +631,8 @@ __global__ __launch_bounds__(64) void search_pe_kernel(DevIndex X, urmapx_params
 
 	const int lane = threadIdx.x;
 	const int W = (int)X.W;
+	const int dbg_stop = veryfast >> 8;  // diagnostic only (URMAPX_DEBUG_STOP_PE): results are NOT the reference's
+	veryfast &= 1;
 	uint8_t *sc = scratch + (size_t)blockIdx.x * scratch_stride;
 	M m[2];
 	for (int a = 0; a < 2; ++a) {
@@ -543,6 +643,8 @@ __global__ __launch_bounds__(64) void search_pe_kernel(DevIndex X, urmapx_params
 		m[a].hit_paths = reinterpret_cast<urmapx_path_op *>(sc) + (size_t)a * PE_HIT_CAP * URMAPX_MAX_PATH_OPS;
 		m[a].hsp_db = hsp_db[a]; m[a].hsp_ql = hsp_ql[a]; m[a].hsp_sf = hsp_sf[a];
 		m[a].pend[0] = pend[2 * a]; m[a].pend[1] = pend[2 * a + 1];
+		m[a].rowlen = rowlen; m[a].pre = pre;
+		m[a].rowstore = reinterpret_cast<uint32_t *>(sc + pe_rowstore_offset(QMAX));
 		m[a].ws.carve(sc + (size_t)2 * PE_HIT_CAP * URMAPX_MAX_PATH_OPS * 2, QMAX, PE_SCAN_SEG + 2 * QMAX + 64);
 	}
 
@@ -670,6 +772,7 @@ __global__ __launch_bounds__(64) void search_pe_kernel(DevIndex X, urmapx_params
 			}
 		}
 		__syncthreads();
+		if (dbg_stop == 1) continue;
 		// ExtendPen on seed i of mate a, in order (state changing), through the cache
 		auto extend_seed = [&](int a, int i) -> int {
 			const uint32_t sq = seed_q[a][i];
@@ -772,6 +875,7 @@ __global__ __launch_bounds__(64) void search_pe_kernel(DevIndex X, urmapx_params
 			}
 		}
 		int npairs_found = 0, bestPairScore = -1, secondPairScore = -1, bestPairIndex = -1;
+		if (dbg_stop == 2) done = true;
 		if (!done) {
 			// all collected seeds, each mate (search2m4.cpp:145-158)
 			// (a seed extended before changes nothing when extended again, see settled(); only the others are visited)
@@ -796,9 +900,11 @@ __global__ __launch_bounds__(64) void search_pe_kernel(DevIndex X, urmapx_params
 				if (d + QL2 <= MAX_TL) { m[0].mapq = 40; m[1].mapq = 40; done = true; }
 			}
 		}
+		if (dbg_stop == 3) done = true;
 		if (!done) {
 			m[0].search_pending();
 			m[1].search_pending();
+			if (dbg_stop == 4) goto pe_output;
 			// FindPairs (state2.cpp:20-85), ScanPair if there is none (state2.cpp:87-137), FindPairs again
 			for (int attempt = 0; attempt < 2; ++attempt) {
 				npairs_found = 0; bestPairScore = -1; secondPairScore = -1; bestPairIndex = -1;
@@ -862,6 +968,7 @@ __global__ __launch_bounds__(64) void search_pe_kernel(DevIndex X, urmapx_params
 			}
 		}
 
+	pe_output:
 		// ---- per-mate output: SetMappedPos (state1.cpp:129-145) ----
 		for (int a = 0; a < 2; ++a) {
 			urmapx_result &R = res[a];
@@ -902,7 +1009,7 @@ static int pe_nch_for(uint32_t max_read_len) { return max_read_len <= 192 ? 3 : 
 
 size_t search_pe_scratch_stride(uint32_t max_read_len) {
 	const int qmax = 64 * pe_nch_for(max_read_len);
-	size_t b = (size_t)2 * PE_HIT_CAP * URMAPX_MAX_PATH_OPS * 2 + WideScratch::bytes(qmax, PE_SCAN_SEG + 2 * qmax + 64);
+	size_t b = pe_rowstore_offset(qmax) + (size_t)2 * (qmax / 64) * PE_ROW_CAP * 64 * 4;
 	return (b + 255) & ~(size_t)255;
 }
 

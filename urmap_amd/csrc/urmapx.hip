@@ -426,7 +426,7 @@ int urmapx_map_pe_device(urmapx_ctx *C, const void *d_bases, const void *d_offs,
 	if (C->pe_veryfast) Ppe.band_radius = 4;  // map2.cpp:17-21
 	HIP_TRY(launch_search_pe(C->X, Ppe, (const uint8_t *)d_bases, (const uint64_t *)d_offs, npairs, max_read_len, po,
 	                         (urmapx_result *)d_results, (urmapx_path_op *)d_path_ops, (uint32_t *)d_path_used, wk,
-	                         C->pe_veryfast, C->stream));
+	                         C->pe_veryfast | (getenv("URMAPX_DEBUG_STOP_PE") ? atoi(getenv("URMAPX_DEBUG_STOP_PE")) << 8 : 0), C->stream));  // bits 8..: diagnostic schedule cut
 	HIP_TRY(hipEventRecord(C->ev[2], C->stream));
 	C->ev_valid = true;
 	return URMAPX_OK;
