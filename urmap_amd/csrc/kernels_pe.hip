@@ -705,43 +705,57 @@ __global__ __launch_bounds__(64) void search_pe_kernel(DevIndex X, urmapx_params
 		// State independent, so it is run to the end up front; the pending lists are cut back to the point the
 		// pairing loop reached if that loop returns early (they are not used then anyway).
 		int nseed[2];
+		// 64 enumeration steps k at a time, one per lane.  The only order dependence is "skip a seed on the diagonal of
+		// the last seed returned" (getseed.cpp:60-66,118-124), and because a skipped seed has that very diagonal, it is
+		// the same as "skip a seed on the diagonal of the previous BOTH1 candidate": a neighbour comparison.
 		for (int a = 0; a < 2; ++a) {
 			const int QWC = m[a].nwords;
-			int ns = 0;
-			bool have = false, lastPlus = false;
+			int ns = 0, np = 0, nm = 0;
+			bool have = false;
 			uint32_t lastDiag = 0;
-			int np = 0, nm = 0;
-			for (int k = 0; k < QWC; ++k) {
-				const uint32_t qpos = ((uint32_t)k * PRIME_STRIDE) % (uint32_t)QWC;
-				bool plusReturnedHere = false;
-				for (int s = 0; s < 2; ++s) {
-					const uint32_t T = s_tal[a][s][qpos];  // slots without a k-mer carry tally 0 = FREE = "other"
-					if ((T & TALLY_MY_BIT) == 0) continue;
-					const bool special = (s == 1) && plusReturnedHere;  // the re-check branch of GetNextBoth1Seed
-					if (T != TALLY_BOTH1) {
-						if (!special) {
-							if (lane == 0) m[a].pend[s][s == 0 ? np : nm] = (uint8_t)qpos;
-							if (s == 0) ++np; else ++nm;
-						}
-						continue;
-					}
-					const uint32_t db = s_pos[a][s][qpos];
-					const uint32_t diag = db - qpos;
-					if (have && diag == lastDiag) {
-						if (special) { if (lane == 0) m[a].pend[1][nm] = (uint8_t)qpos; ++nm; }
-						continue;
-					}
-					if (ns < SEED_CAP) {
-						if (lane == 0) { seed_q[a][ns] = (uint16_t)(qpos | (s == 0 ? 0x8000u : 0u)); seed_db[a][ns] = db; }
-						++ns;
-					} else
-						m[a].status |= URMAPX_ST_HSP_OVERFLOW;
-					have = true; lastDiag = diag; lastPlus = (s == 0);
-					if (s == 0) plusReturnedHere = true;
-					else break;  // a minus seed was returned: the enumeration resumes at k + 1
+			for (int kb = 0; kb < QWC; kb += 64) {
+				const int k = kb + lane;
+				const bool in = k < QWC;
+				const uint32_t qpos = in ? ((uint32_t)k * PRIME_STRIDE) % (uint32_t)QWC : 0u;
+				const uint32_t Tp = in ? s_tal[a][0][qpos] : 0u, Tm = in ? s_tal[a][1][qpos] : 0u;
+				const bool candP = Tp == TALLY_BOTH1, candM = Tm == TALLY_BOTH1;
+				const uint32_t dbP = s_pos[a][0][qpos], dbM = s_pos[a][1][qpos];
+				const uint32_t diagP = dbP - qpos, diagM = dbM - qpos;
+				// diagonal of the last candidate before this lane's
+				const uint64_t anyc = __ballot(candP || candM);
+				const uint32_t lastHere = candM ? diagM : diagP;
+				const uint64_t below = anyc & ((1ull << lane) - 1ull);
+				const int src = below ? 63 - __builtin_clzll(below) : 0;
+				const uint32_t fromLane = (uint32_t)__shfl((int)lastHere, src);
+				const bool havePrev = below ? true : have;
+				const uint32_t prev = below ? fromLane : lastDiag;
+				const bool retP = candP && !(havePrev && diagP == prev);
+				const bool havePrevM = candP || havePrev;
+				const uint32_t prevM = candP ? diagP : prev;
+				const bool retM = candM && !(havePrevM && diagM == prevM);
+				// pending lists: "mine" slots that are not BOTH1; the minus slot is not looked at again when the plus seed of
+				// this step was returned (the re-check branch of GetNextBoth1Seed), except that a BOTH1 minus seed skipped for
+				// its diagonal in that branch is pushed (getseed.cpp:96-138)
+				const bool pendP = (Tp & TALLY_MY_BIT) != 0 && !candP;
+				const bool pendM = (Tm & TALLY_MY_BIT) != 0 && ((!candM && !retP) || (candM && !retM && retP));
+				const uint64_t mp = __ballot(pendP), mmn = __ballot(pendM);
+				const uint64_t lt = (1ull << lane) - 1ull;
+				if (pendP) m[a].pend[0][np + __builtin_popcountll(mp & lt)] = (uint8_t)qpos;
+				if (pendM) m[a].pend[1][nm + __builtin_popcountll(mmn & lt)] = (uint8_t)qpos;
+				np += __builtin_popcountll(mp); nm += __builtin_popcountll(mmn);
+				const int nret = (retP ? 1 : 0) + (retM ? 1 : 0);
+				const int inc = wave_prefix_sum(nret);
+				int at = ns + inc - nret;
+				if (retP && at < SEED_CAP) { seed_q[a][at] = (uint16_t)(qpos | 0x8000u); seed_db[a][at] = dbP; }
+				if (retP) ++at;
+				if (retM && at < SEED_CAP) { seed_q[a][at] = (uint16_t)qpos; seed_db[a][at] = dbM; }
+				ns += rdlane(inc, 63);
+				if (anyc) {
+					have = true;
+					lastDiag = (uint32_t)__shfl((int)lastHere, 63 - __builtin_clzll(anyc));
 				}
-				(void)lastPlus;
 			}
+			if (ns > SEED_CAP) { ns = SEED_CAP; m[a].status |= URMAPX_ST_HSP_OVERFLOW; }
 			nseed[a] = ns;
 			m[a].pendCount[0] = np; m[a].pendCount[1] = nm;
 		}
