@@ -39,7 +39,7 @@ extern "C" {
 #define URMAPX_ST_BAD_LENGTH 0x10    /* read shorter than the word length or longer than URMAPX_MAX_QL */
 
 #define URMAPX_MAX_QL 320
-#define URMAPX_MAX_PATH_OPS 48
+#define URMAPX_MAX_PATH_OPS 96
 
 typedef struct urmapx_index urmapx_index;
 typedef struct urmapx_ctx urmapx_ctx;

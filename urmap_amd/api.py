@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("URMAPX_LIB") or os.path.join(_HERE, "liburmapx.so")  # URMAPX_LIB: A/B builds
 
 MAX_QL = 320
-MAX_PATH_OPS = 48
+MAX_PATH_OPS = int(os.environ.get("URMAPX_MAX_PATH_OPS_OVERRIDE", 96))
 E_UNSUPPORTED = -6
 
 RESULT_DTYPE = np.dtype([("dbpos", "<u4"), ("seq_index", "<u4"), ("coord", "<u4"), ("score", "<i2"),

@@ -10,7 +10,7 @@ static constexpr uint32_t TB_DM = 1, TB_IM = 2, TB_MD = 4, TB_MI = 8;
 static constexpr int OP_M = 0, OP_D = 1, OP_I = 2;
 static constexpr int SECONDARY_HIT_MAX_DELTA = 12;  // state1.h:16
 static constexpr float NEG = -9e9f;                 // MINUS_INFINITY of viterbi.cpp
-static constexpr int OPS_CAP = 64;                  // reversed run buffers per flank
+static constexpr int OPS_CAP = 128;                 // reversed run buffers per flank
 
 // ------------------------------------------------------------------------------------------------
 // small device helpers

@@ -450,11 +450,13 @@ struct SearchWave {
 	}
 };
 
+// waves per SIMD the register allocation aims at: 3 for reads <= 192 (168 VGPRs), 2 for reads <= 320 (the five-word
+// bit vectors and 20 window loads in flight do not fit 168 registers without hundreds of spills)
 #ifndef SEARCH_WAVES_PER_EU
-#define SEARCH_WAVES_PER_EU 3
+#define SEARCH_WAVES_PER_EU(NCH) ((NCH) <= 3 ? 3 : 2)
 #endif
 template <int NCH>
-__global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU) void search_se_kernel(DevIndex X, urmapx_params P, const uint8_t *__restrict__ bases,
+__global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel(DevIndex X, urmapx_params P, const uint8_t *__restrict__ bases,
                                                        const uint64_t *__restrict__ offs, uint32_t n, ProbeOut probe,
                                                        urmapx_result *__restrict__ results,
                                                        urmapx_path_op *__restrict__ path_ops, uint32_t *path_used,
@@ -467,8 +469,12 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU) void search_se_kernel(DevI
 	const uint8_t *__restrict__ const seq = g_seq;
 	__shared__ uint8_t sT[SW::QMAX + 64];
 	__shared__ uint32_t tb[SW::TB_ROWS8 * 64];
-	__shared__ uint16_t ropsL[OPS_CAP], ropsR[OPS_CAP], cand[URMAPX_MAX_PATH_OPS], top[URMAPX_MAX_PATH_OPS];
+	__shared__ uint16_t top[URMAPX_MAX_PATH_OPS];
 	__shared__ uint16_t pre[2 * SW::NSEG * 64 + 2];
+	// the flank run buffers and the candidate path live only inside align_hsp, the candidate prefix array only inside a
+	// gather step: they share memory (LDS per block decides how many reads a CU keeps in flight)
+	static_assert(2 * OPS_CAP + URMAPX_MAX_PATH_OPS <= 2 * SW::NSEG * 64 + 2, "alias");
+	uint16_t *const ropsL = pre, *const ropsR = pre + OPS_CAP, *const cand = pre + 2 * OPS_CAP;
 	__shared__ uint32_t hsp_db[HSP_CAP], hsp_ql[HSP_CAP];
 	__shared__ uint16_t hsp_sf[HSP_CAP];
 	__shared__ uint32_t cq_db[128];  // candidate queue (ring): reference position, query position | plus << 14 | second phase << 15

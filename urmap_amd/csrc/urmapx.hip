@@ -325,7 +325,10 @@ int urmapx_map_se_device(urmapx_ctx *C, const void *d_bases, const void *d_offs,
 	if (rc) return rc;
 	ProbeOut po{C->slots.p, C->tallies.p, C->positions.p};
 	const int cls = max_read_len <= 192 ? 0 : 1;
-	if (C->blocks[cls] == 0) C->blocks[cls] = search_block_count(max_read_len, C->device);
+	if (C->blocks[cls] == 0) {
+		C->blocks[cls] = search_block_count(max_read_len, C->device);
+		if (getenv("URMAPX_VERBOSE")) fprintf(stderr, "urmapx: search_se_kernel grid = %d persistent blocks (read class %d)\n", C->blocks[cls], cls);
+	}
 	if (C->blocks[cls] <= 0) return URMAPX_E_NODEVICE;
 	SearchWork wk;
 	wk.blocks = C->blocks[cls];
