@@ -161,6 +161,11 @@ int urmapx_viterbi_batch(urmapx_ctx *, const uint8_t *a, const uint32_t *a_offs,
                          const uint32_t *b_offs, const uint8_t *flags, uint32_t n, float *scores, uint8_t *status,
                          urmapx_path_op *ops, uint16_t *nops);
 
+/* Measurement aid (no reference counterpart): n_loads independent random 5-byte slot reads over the resident slot
+ * table and nothing else -- the random-access ceiling of this table on this device, which bench.py reports next to
+ * the probe kernel's rate (SURVEY.md section 8d asks for the denominator to be measured, not assumed). */
+int urmapx_ctx_gather_microbench(urmapx_ctx *, uint64_t n_loads, double *loads_per_s);
+
 /* ---- index construction (host side; the command line's -make_ufi) ---- */
 /* cmd_make_ufi (ufindexio.cpp:117-179): FASTA -> .ufi, byte-identical to the reference's for the same slot count.
  * slots is mandatory here (the reference's default picks the first entry >= file_size/0.6 of its built-in prime

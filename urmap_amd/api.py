@@ -32,6 +32,7 @@ EXPORTS = (
     "urmapx_seed_probe", "urmapx_viterbi_batch", "urmapx_strerror", "urmapx_device_arch",
     "urmapx_make_ufi", "urmapx_build_slots", "urmapx_sam_se", "urmapx_sam_header_sq", "urmapx_ctx_phase_cycles", "urmapx_map_pe", "urmapx_sam_pe", "urmapx_map_pe_device", "urmapx_ctx_set_pe_veryfast",
     "urmapx_fastq_open", "urmapx_fastq_next", "urmapx_fastq_error", "urmapx_fastq_close",
+    "urmapx_ctx_gather_microbench",
 )
 
 
@@ -104,6 +105,7 @@ def lib():
     L.urmapx_strerror.argtypes = [i32]
     L.urmapx_device_arch.restype = cp
     L.urmapx_device_arch.argtypes = [vp]
+    L.urmapx_ctx_gather_microbench.argtypes = [vp, u64, C.POINTER(C.c_double)]
     L.urmapx_fastq_open.argtypes = [cp, C.POINTER(vp)]
     L.urmapx_fastq_next.restype = C.c_int64
     L.urmapx_fastq_next.argtypes = [vp, u32] + [C.POINTER(vp)] * 5
@@ -330,6 +332,12 @@ class Mapper:
         ms = (C.c_float * 2)()
         _check(lib().urmapx_ctx_last_kernel_ms(self.h, C.byref(ms)), "urmapx_ctx_last_kernel_ms")
         return float(ms[0]), float(ms[1])
+
+    def gather_microbench(self, n_loads=1 << 28):
+        """Random 5-byte slot reads per second over the resident slot table (measurement aid)."""
+        r = C.c_double(0.0)
+        _check(lib().urmapx_ctx_gather_microbench(self._h, n_loads, C.byref(r)), "urmapx_ctx_gather_microbench")
+        return r.value
 
     def phase_cycles(self):
         out = (C.c_uint64 * 12)()

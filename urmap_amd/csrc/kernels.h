@@ -29,6 +29,9 @@ struct ProbeOut {
 	uint32_t *positions;
 };
 
+// random slot gathers: blocks x 256 threads x iters x 8 loads
+hipError_t launch_gather_bench(const DevIndex &X, uint32_t blocks, uint32_t iters, uint32_t *d_sink, hipStream_t s);
+
 hipError_t launch_seed_probe(const DevIndex &X, const uint8_t *d_bases, const uint64_t *d_offs, uint32_t n,
                              uint32_t max_read_len, ProbeOut out, hipStream_t s);
 

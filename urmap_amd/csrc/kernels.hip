@@ -788,6 +788,32 @@ int search_block_count(uint32_t max_read_len, int device) {
 	return per_cu * prop.multiProcessorCount;
 }
 
+// ------------------------------------------------------------------------------------------------
+// measurement aid: random 5-byte slot gathers over the resident slot table, nothing else -- the ceiling any probe of
+// this table can reach on this device (one 64-byte sector per slot, 6 % of the slots straddle two)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gather_bench_kernel(const uint8_t *__restrict__ blob, uint64_t slot_count,
+                                                           uint64_t magic, uint32_t iters, uint32_t *sink) {
+	uint64_t x = murmur64(((uint64_t)blockIdx.x << 20) + threadIdx.x + 1);
+	uint32_t acc = 0;
+	for (uint32_t i = 0; i < iters; ++i) {
+		uint32_t t[8], p[8];
+#pragma unroll
+		for (int u = 0; u < 8; ++u) {
+			x = murmur64(x + 0x9E3779B97F4A7C15ull);
+			load_slot(blob, mod_slots(x, slot_count, magic), t[u], p[u]);
+		}
+#pragma unroll
+		for (int u = 0; u < 8; ++u) acc += t[u] ^ p[u];
+	}
+	if (acc == 0x12345678u) *sink = acc;  // never true in practice; keeps the loads alive
+}
+
+hipError_t launch_gather_bench(const DevIndex &X, uint32_t blocks, uint32_t iters, uint32_t *d_sink, hipStream_t s) {
+	hipLaunchKernelGGL(gather_bench_kernel, dim3(blocks), dim3(256), 0, s, X.blob, X.slotCount, X.slotMagic, iters, d_sink);
+	return hipGetLastError();
+}
+
 size_t viterbi_batch_scratch_stride() { return (WideScratch::bytes(VB_WIDE_LA, VB_WIDE_LB) + 255) & ~(size_t)255; }
 
 hipError_t launch_seed_probe(const DevIndex &X, const uint8_t *d_bases, const uint64_t *d_offs, uint32_t n,

@@ -496,6 +496,33 @@ int urmapx_seed_probe(urmapx_ctx *C, const uint8_t *bases, const uint64_t *offs,
 	return URMAPX_OK;
 }
 
+// measurement aid for the roofline: see include/urmapx.h
+int urmapx_ctx_gather_microbench(urmapx_ctx *C, uint64_t n_loads, double *loads_per_s) {
+	if (!C || !loads_per_s || n_loads == 0) return URMAPX_E_ARG;
+	HIP_TRY(hipSetDevice(C->device));
+	int rc;
+	if ((rc = C->statsbuf.ensure(64))) return rc;
+	hipDeviceProp_t prop;
+	HIP_TRY(hipGetDeviceProperties(&prop, C->device));
+	const uint32_t blocks = (uint32_t)prop.multiProcessorCount * 8u;  // 2048 threads per CU
+	uint64_t per_iter = (uint64_t)blocks * 256u * 8u;
+	uint32_t iters = (uint32_t)((n_loads + per_iter - 1) / per_iter);
+	if (iters == 0) iters = 1;
+	hipEvent_t e0, e1;
+	HIP_TRY(hipEventCreate(&e0));
+	HIP_TRY(hipEventCreate(&e1));
+	HIP_TRY(launch_gather_bench(C->X, blocks, 1, C->statsbuf.p + 60, C->stream));  // warm-up
+	HIP_TRY(hipEventRecord(e0, C->stream));
+	HIP_TRY(launch_gather_bench(C->X, blocks, iters, C->statsbuf.p + 60, C->stream));
+	HIP_TRY(hipEventRecord(e1, C->stream));
+	HIP_TRY(hipEventSynchronize(e1));
+	float ms = 0;
+	HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+	hipEventDestroy(e0); hipEventDestroy(e1);
+	*loads_per_s = ms > 0 ? (double)per_iter * iters / (ms * 1e-3) : 0.0;
+	return URMAPX_OK;
+}
+
 int urmapx_viterbi_batch(urmapx_ctx *C, const uint8_t *a, const uint32_t *a_offs, const uint8_t *b, const uint32_t *b_offs,
                          const uint8_t *flags, uint32_t n, float *scores, uint8_t *status, urmapx_path_op *ops,
                          uint16_t *nops) {
