@@ -158,7 +158,20 @@ def test_cli_make_ufi_is_byte_identical(gold_ufi, tmp_path):
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
     assert r.returncode == 0, r.stderr.decode()
     assert filecmp.cmp(out, gold_ufi, shallow=False)
-    # missing -slots is a loud error, exit status 1 (myutils.cpp:915)
+    # without -slots: the first prime >= FASTA bytes / 0.6 (ufindexio.cpp:138-150 takes it from a prime ladder instead);
+    # the index must be what the oracle's builder makes for that slot count
     r = subprocess.run([exe, "-make_ufi", os.path.join(GOLD, "g.fa"), "-output", out], stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, timeout=60)
-    assert r.returncode == 1 and b"-slots" in r.stderr
+    assert r.returncode == 0, r.stderr.decode()
+    w2, maxix2, sds2, slots2 = ol.ufi_header(out)
+    size = os.path.getsize(os.path.join(GOLD, "g.fa"))
+    assert slots2 >= int(size / 0.6) and all(slots2 % p for p in range(2, int(slots2 ** 0.5) + 1))
+    assert all(any(c % p == 0 for p in range(2, int(c ** 0.5) + 1)) for c in range(int(size / 0.6), slots2))
+    idx = ol.Index.build(os.path.join(GOLD, "g.fa"), slots2, 24, 32)
+    ref2 = os.path.join(tmp_path, "oracle_default.ufi")
+    idx.save(ref2)
+    assert filecmp.cmp(out, ref2, shallow=False)
+    # a missing input file is a loud error, exit status 1 (myutils.cpp:915)
+    r = subprocess.run([exe, "-make_ufi", os.path.join(tmp_path, "nope.fa"), "-output", out], stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=60)
+    assert r.returncode == 1

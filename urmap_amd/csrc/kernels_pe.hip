@@ -949,7 +949,7 @@ __global__ __launch_bounds__(64) void search_pe_kernel(DevIndex X, urmapx_params
 				__syncthreads();
 				if (npairs_found > 0 || attempt == 1) break;
 				// ScanPair
-				const bool dovitF = (int)m[0].mapq >= 10, dovitR = (int)m[1].mapq >= 10;
+				const bool dovitF = (int)m[0].mapq >= 10 && dbg_stop != 5, dovitR = (int)m[1].mapq >= 10 && dbg_stop != 5;  // 5: diagnostic, no rescue DP
 				const int hcf = m[0].hitCount, hcr = m[1].hitCount;
 				for (int i = 0; i < hcf; ++i) {
 					const uint32_t sp = rdlane(m[0].hit_sp, i);

@@ -2,7 +2,7 @@
 // (urmap_main.cpp:6-41, map.cpp:27-67, ufindexio.cpp:117-179) as a batch dispatcher over liburmapx.so.
 //
 //   urmap -map reads.fq[.gz] -ufi index.ufi -samout out.sam [-veryfast] [-threads N] [-gpu D] [-batch N]
-//   urmap -make_ufi genome.fa -output index.ufi -slots N [-wordlength W] [-maxix M] [-veryfast]
+//   urmap -make_ufi genome.fa -output index.ufi [-slots N] [-wordlength W] [-maxix M] [-veryfast]
 //
 //   urmap -map2 R1.fq -reverse R2.fq -ufi index.ufi -samout out.sam            (paired-end, map2.cpp:39-90)
 //
@@ -313,13 +313,54 @@ static int cmd_map(const Opts &o, int argc, char **argv) {
 	return 0;
 }
 
+// first prime >= n (deterministic Miller-Rabin for 64-bit integers)
+static uint64_t mulmod64(uint64_t a, uint64_t b, uint64_t m) { return (uint64_t)((unsigned __int128)a * b % m); }
+static uint64_t powmod64(uint64_t a, uint64_t e, uint64_t m) {
+	uint64_t r = 1;
+	for (a %= m; e; e >>= 1, a = mulmod64(a, a, m))
+		if (e & 1) r = mulmod64(r, a, m);
+	return r;
+}
+static bool is_prime64(uint64_t n) {
+	if (n < 2) return false;
+	for (uint64_t p : {2ull, 3ull, 5ull, 7ull, 11ull, 13ull, 17ull, 19ull, 23ull, 29ull, 31ull, 37ull}) {
+		if (n % p == 0) return n == p;
+	}
+	uint64_t d = n - 1;
+	int r = 0;
+	while ((d & 1) == 0) { d >>= 1; ++r; }
+	for (uint64_t a : {2ull, 3ull, 5ull, 7ull, 11ull, 13ull, 17ull, 19ull, 23ull, 29ull, 31ull, 37ull}) {
+		uint64_t x = powmod64(a, d, n);
+		if (x == 1 || x == n - 1) continue;
+		bool comp = true;
+		for (int i = 1; i < r && comp; ++i) {
+			x = mulmod64(x, x, n);
+			if (x == n - 1) comp = false;
+		}
+		if (comp) return false;
+	}
+	return true;
+}
+
 static int cmd_make_ufi(const Opts &o) {
 	if (o.output.empty()) die("-output option required");
-	if (o.slots == 0)
-		die("-slots N required: this build does not carry the reference's prime table (primes.h); "
-		    "`urmap -suggest_slots` of the reference, or any prime >= FASTA bytes / 0.6, works");
+	uint64_t slots = o.slots;
+	if (slots == 0) {
+		// cmd_make_ufi (ufindexio.cpp:138-150): slots = GetPrime(file size / load factor 0.6).  The reference's GetPrime
+		// picks from a built-in ladder of primes (primes.h), which is data this build does not carry; the first prime
+		// >= the same bound is used instead, so the default-sized index is valid (and maps identically to an index the
+		// reference builds with -slots set to this number) but is not byte-identical to the reference's default.
+		FILE *f = fopen(o.make_ufi.c_str(), "rb");
+		if (!f) die("Cannot open %s", o.make_ufi.c_str());
+		fseeko(f, 0, SEEK_END);
+		const int64_t size = (int64_t)ftello(f);
+		fclose(f);
+		slots = (uint64_t)((double)size / 0.6);
+		while (!is_prime64(slots)) ++slots;
+		fprintf(stderr, "urmap: -slots not given, using %llu (first prime >= FASTA bytes / 0.6)\n", (unsigned long long)slots);
+	}
 	unsigned maxix = o.maxix ? o.maxix : (o.veryfast ? 3u : 32u);
-	check(urmapx_make_ufi(o.make_ufi.c_str(), o.output.c_str(), o.wordlength, maxix, o.slots), "make_ufi");
+	check(urmapx_make_ufi(o.make_ufi.c_str(), o.output.c_str(), o.wordlength, maxix, slots), "make_ufi");
 	return 0;
 }
 
@@ -330,6 +371,6 @@ int main(int argc, char **argv) {
 	if (!o.make_ufi.empty()) return cmd_make_ufi(o);
 	fprintf(stderr, "urmap (MI355X build)\n  urmap -map reads.fq -ufi index.ufi -samout out.sam [-veryfast] [-gpu D]\n"
 	                "  urmap -map2 R1.fq -reverse R2.fq -ufi index.ufi -samout out.sam [-gpu D]\n"
-	                "  urmap -make_ufi genome.fa -output index.ufi -slots N [-wordlength W] [-maxix M]\n");
+	                "  urmap -make_ufi genome.fa -output index.ufi [-slots N] [-wordlength W] [-maxix M]\n");
 	return 0;
 }
