@@ -68,8 +68,8 @@ struct RevOps {  // run-length path, traceback order (last column first)
 
 // A, B, tb: LDS of this wavefront.  tb holds (tb_rows8*64) dwords: 8 rows of 4-bit trace cells per dword.
 // Returns the score; R receives the path in traceback order.  status gets URMAPX_ST_* bits.
-__device__ __forceinline__ float viterbi_wide(const VPar P, const uint8_t *A, int LA, const uint8_t *B, int LB, bool Left, bool Right,
-                              const WideScratch ws, RevOps &R, uint32_t &status, int lane);
+__device__ float viterbi_wide(const VPar P, const uint8_t *A, int LA, const uint8_t *B, int LB, bool Left, bool Right,
+                              const WideScratch ws, uint32_t *lds, int lds_dwords, RevOps &R, uint32_t &status, int lane);
 
 // ws.la_cap == 0: no wide-band scratch (the band must fit one wavefront).
 __device__ __forceinline__ float viterbi_wave(const VPar P, const uint8_t *A, int LA, const uint8_t *B, int LB, bool Left, bool Right,
@@ -90,7 +90,7 @@ __device__ __forceinline__ float viterbi_wave(const VPar P, const uint8_t *A, in
 	const int ND = dhi - dlo + 1;
 	// lanes: 0 = column Startj-1, 1..ND = band, ND+1 = column LB; final cells sit at lanes LB-dlo .. LB-dlo+2
 	if (ND + 2 > 64 || LB - dlo + 2 > 63 || ((LA + 1 + 7) >> 3) > tb_rows8) {
-		if (LA <= ws.la_cap && LB <= ws.lb_cap) return viterbi_wide(P, A, LA, B, LB, Left, Right, ws, R, status, lane);
+		if (LA <= ws.la_cap && LB <= ws.lb_cap) return viterbi_wide(P, A, LA, B, LB, Left, Right, ws, tb, tb_rows8 * 64, R, status, lane);
 		status |= URMAPX_ST_BAND_TOO_WIDE;
 		return 0.0f;
 	}
@@ -197,53 +197,63 @@ __device__ __forceinline__ float viterbi_wave(const VPar P, const uint8_t *A, in
 }
 
 // Wide-band fallback (band wider than one wavefront: a flank window clipped at the end of the sequence store,
-// or the paired-end rescue's whole-read DP).  Same recurrences, lanes = 64 consecutive columns of a row, the
-// in-row insert chain carried from chunk to chunk; rows and trace cells live in global scratch.  Rare and slow.
-__device__ __forceinline__ float viterbi_wide(const VPar P, const uint8_t *A, int LA, const uint8_t *B, int LB, bool Left, bool Right,
-                              const WideScratch ws, RevOps &R, uint32_t &status, int lane) {
+// or the paired-end rescue's whole-read DP against a 1 kb window).  Same recurrences and tie rules.  The matrix is
+// swept in vertical strips of 64 columns, lane = column: a column's M and D values stay in that lane's registers
+// from row to row, the in-row insert chain is a prefix scan inside the strip, and what the next strip needs from
+// this one -- per row, the M value of the strip's last column before the row and the insert-chain carry after it --
+// goes through a per-row array in LDS (the narrow path's trace buffer, idle here).  Only the trace cells go to
+// global memory (byte per cell), write-only until the traceback, which skips along runs 64 cells at a time.
+__device__ float viterbi_wide(const VPar P, const uint8_t *A, int LA, const uint8_t *B, int LB, bool Left, bool Right,
+                              const WideScratch ws, uint32_t *lds, int lds_dwords, RevOps &R, uint32_t &status, int lane) {
+	if (3 * LA > lds_dwords) { status |= URMAPX_ST_BAND_TOO_WIDE; return 0.0f; }
 	const float GO = (float)P.gap_open_score, GE = (float)P.gap_ext_score;
 	const int Rad = P.band_radius;
 	int dlo = min(LA, LB), dhi = max(LA, LB);
 	dlo = dlo > Rad ? dlo - Rad : 1;
 	dhi += Rad;
 	if (dhi > LA + LB - 1) dhi = LA + LB - 1;
-	float *Mr = ws.Mr, *Dr = ws.Dr;
+	float *Bm = reinterpret_cast<float *>(lds);  // [row] M of the previous strip's last column, as it stood before that row
+	float *Bi = Bm + LA;                          // [row] insert-chain carry out of the previous strip
+	float *ML = Bi + LA;                          // [row] M (before the row) of the row's last band column
 	uint8_t *TB = ws.TB;
 	const size_t stride = (size_t)LB + 1;
 	const float flane = (float)lane;
-	for (int k = lane; k <= LB + 1; k += 64) { Mr[k] = NEG; Dr[k] = NEG; }
-	__syncthreads();
 	auto range_j = [&](int i, int &Startj, int &Endj) {  // diagbox.h:150-170
 		Startj = (dlo + i >= LA) ? dlo + i - LA : 0;
 		if (Startj >= LB) Startj = LB - 1;
 		Endj = (dhi + i + 1 >= LA) ? dhi + i + 1 - LA : 0;
 		if (Endj > LB) Endj = LB;
 	};
-	for (int i = 0; i < LA; ++i) {
-		int Startj, Endj;
-		range_j(i, Startj, Endj);
-		if (Endj == 0) continue;
-		const float OpenA = (Left && i == 0) ? 0.0f : GO, ExtA = (Left && i == 0) ? 0.0f : GE;
-		const uint32_t a = A[i];
-		float carryI = NEG;
-		float M0first = (i == 0) ? 0.0f : (Startj == 0 ? NEG : Mr[Startj - 1 + 1]);
-		M0first = __int_as_float(uni(__float_as_int(M0first)));
-		float M0last = M0first;
-		uint8_t *TBrow = TB + (size_t)i * stride;
-		if (Startj > 0 && lane == 0) TBrow[Startj - 1] = (uint8_t)TB_IM;
-		for (int j0 = Startj; j0 < Endj; j0 += 64) {
-			const int j = j0 + lane;
-			const bool act = j < Endj;
-			const float oldM = act ? Mr[j + 1] : NEG;
-			const float Dcur = act ? Dr[j] : NEG;
-			const uint32_t b = act ? B[j] : 0u;
-			__syncthreads();
-			const float Mcur = wave_shr1(oldM, M0first);
+	int StartjL, EndjL;
+	range_j(LA - 1, StartjL, EndjL);
+	const float GapOp = Right ? 0.0f : GO, GapEx = Right ? 0.0f : GE;
+	float FinalI = NEG, FinalM = NEG, carryF = NEG, MleftF = NEG;
+	__syncthreads();
+	const int nstrips = (LB + 63) >> 6;
+	for (int s = 0; s < nstrips; ++s) {
+		const int j = 64 * s + lane;
+		const bool col = j < LB;
+		const uint32_t b = col ? B[j] : 0u;
+		float Mreg = NEG, Dreg = NEG;  // this column's M / D as the last row that had it in its band left them
+		for (int i = 0; i < LA; ++i) {
+			int Startj, Endj;
+			range_j(i, Startj, Endj);
+			if (Endj == 0) continue;
+			float bm = NEG, bi = NEG;
+			if (s > 0) { bm = Bm[i]; bi = Bi[i]; }
+			const bool act = col && j >= Startj && j < Endj;
+			const float OpenA = (Left && i == 0) ? 0.0f : GO, ExtA = (Left && i == 0) ? 0.0f : GE;
+			const uint32_t a = A[i];
+			const float oldM = Mreg;
+			float Mcur = wave_shr1(oldM, NEG);
+			if (lane == 0) Mcur = bm;
+			if (i == 0 && j == Startj) Mcur = 0.0f;
+			const float Dcur = Dreg;
 			const float v = act ? (Mcur + OpenA) : NEG;
 			const float u = v - ExtA * flane;
 			const float Pm = wave_prefix_max(u);
 			const float Ichain = wave_shr1(Pm, NEG) + ExtA * (flane - 1.0f);
-			const float Icarry = carryI + ExtA * flane;
+			const float Icarry = bi + ExtA * flane;
 			const float I = fmaxf(Ichain, Icarry);
 			uint32_t bits = 0;
 			float xM = Mcur;
@@ -257,70 +267,88 @@ __device__ __forceinline__ float viterbi_wide(const VPar P, const uint8_t *A, in
 			const float mi = Mcur + OpenA;
 			const float Ie = I + ExtA;
 			if (mi >= Ie) bits |= TB_MI;
-			const float Iafter = fmaxf(mi, Ie);
-			carryI = rdlane(Iafter, 63);
-			M0first = rdlane(oldM, 63);
-			const int lastl = Endj - 1 - j0;
-			if (lastl < 64) M0last = rdlane(oldM, lastl);
-			if (act) { Mr[j + 1] = Mnew; Dr[j] = Dnew; TBrow[j] = (uint8_t)bits; }
-			__syncthreads();
+			const float Iafter = act ? fmaxf(mi, Ie) : NEG;
+			const float om63 = rdlane(oldM, 63), ia63 = rdlane(Iafter, 63);
+			const int lastcol = Endj - 1;
+			const bool haslast = (lastcol >> 6) == s;
+			float ml = 0.0f;
+			if (haslast) ml = rdlane(oldM, lastcol & 63);
+			if (lane == 0) {
+				Bm[i] = om63; Bi[i] = ia63;
+				if (haslast) ML[i] = ml;
+			}
+			if (act) { Mreg = Mnew; Dreg = Dnew; TB[(size_t)i * stride + j] = (uint8_t)bits; }
+			if (Startj > 0 && j == Startj - 1) TB[(size_t)i * stride + j] = (uint8_t)TB_IM;
 		}
-		if (lane == 0) {
-			float d = Dr[LB] + GE;
-			const float md = M0last + GO;
-			uint8_t t = 0;
-			if (md >= d) { d = md; t = (uint8_t)TB_MD; }
-			Dr[LB] = d;
-			TBrow[LB] = t;
-		}
-		__syncthreads();
-	}
-	int Startj, Endj;
-	range_j(LA - 1, Startj, Endj);
-	if (lane == 0) Mr[Startj - 1 + 1] = NEG;
-	__syncthreads();
-	float FinalI = NEG;
-	{
-		const float GapOp = Right ? 0.0f : GO, GapEx = Right ? 0.0f : GE;
-		uint8_t *TBlast = TB + (size_t)LA * stride;
-		float carry = NEG;
-		for (int j0 = Startj; j0 < Endj; j0 += 64) {
-			const int j = j0 + lane;
-			const bool act = j < Endj;
-			const float mprev = act ? Mr[j - 1 + 1] : NEG;
-			const float v = act ? (mprev + GapOp) : NEG;
+		// last row of the insert matrix for this strip's columns (strict '>' there)
+		{
+			float mprev = wave_shr1(Mreg, NEG);
+			if (lane == 0) mprev = MleftF;
+			if (j == StartjL) mprev = NEG;
+			const bool actF = col && j >= StartjL && j < EndjL;
+			const float v = actF ? (mprev + GapOp) : NEG;
 			const float u = v - GapEx * flane;
 			const float Pm = wave_prefix_max(u);
 			const float Ichain = wave_shr1(Pm, NEG) + GapEx * (flane - 1.0f);  // unconditional: see viterbi_wave
-			const float Ibefore = fmaxf(Ichain, carry + GapEx * flane);
+			const float Ibefore = fmaxf(Ichain, carryF + GapEx * flane);
 			const float Ie = Ibefore + GapEx;
 			const float Iafter = fmaxf(v, Ie);
-			if (act) TBlast[j] = (v > Ie) ? (uint8_t)TB_MI : (uint8_t)0;
-			carry = rdlane(Iafter, 63);
-			const int lastl = Endj - 1 - j0;
-			if (lastl < 64) FinalI = rdlane(Iafter, lastl);
+			if (actF) TB[(size_t)LA * stride + j] = (v > Ie) ? (uint8_t)TB_MI : (uint8_t)0;
+			carryF = rdlane(Iafter, 63);
+			const int lastl = EndjL - 1 - 64 * s;
+			if (lastl >= 0 && lastl < 64) FinalI = rdlane(Iafter, lastl);
+			MleftF = rdlane(Mreg, 63);
+			if (((LB - 1) >> 6) == s) FinalM = rdlane(Mreg, (LB - 1) & 63);
 		}
 	}
 	__syncthreads();
-	float FinalM = Mr[LB - 1 + 1], FinalD = Dr[LB];
-	FinalM = __int_as_float(uni(__float_as_int(FinalM)));
-	FinalD = __int_as_float(uni(__float_as_int(FinalD)));
+	// column LB (D only): a recurrence down the rows over the per-row M values collected above
+	float FinalD = NEG;
+	for (int i = 0; i < LA; ++i) {
+		int Startj, Endj;
+		range_j(i, Startj, Endj);
+		if (Endj == 0) continue;
+		float d = FinalD + GE;
+		const float md = ML[i] + GO;
+		uint8_t t = 0;
+		if (md >= d) { d = md; t = (uint8_t)TB_MD; }
+		FinalD = d;
+		if (lane == 0) TB[(size_t)i * stride + LB] = t;
+	}
 	float Score = FinalM;
 	int st = OP_M;
 	if (FinalD > Score) { Score = FinalD; st = OP_D; }
 	if (FinalI > Score) { Score = FinalI; st = OP_I; }
+	__threadfence_block();
+	__syncthreads();
+	// traceback: 64 cells of the current run direction per step
 	int i = LA, j = LB;
 	int guard = LA + LB + 2;
 	while ((i | j) != 0 && guard-- > 0) {
-		R.emit(st, lane);
-		uint32_t t;
-		if (st == OP_M) t = TB[(size_t)(i - 1) * stride + (j - 1)];
-		else if (st == OP_D) t = TB[(size_t)(i - 1) * stride + j];
-		else t = TB[(size_t)i * stride + (j - 1)];
-		t = uni(t);
-		if (st == OP_M) { st = (t & TB_DM) ? OP_D : (t & TB_IM) ? OP_I : OP_M; --i; --j; }
-		else if (st == OP_D) { st = (t & TB_MD) ? OP_M : OP_D; --i; }
-		else { st = (t & TB_MI) ? OP_M : OP_I; --j; }
+		int n;           // cells available in this direction
+		ptrdiff_t at;    // first cell
+		ptrdiff_t step;  // from one cell to the next
+		uint32_t stop;   // trace bits that end the run
+		if (st == OP_M) { n = min(i, j); at = (ptrdiff_t)((size_t)(i - 1) * stride + (size_t)(j - 1)); step = -(ptrdiff_t)stride - 1; stop = TB_DM | TB_IM; }
+		else if (st == OP_D) { n = i; at = (ptrdiff_t)((size_t)(i - 1) * stride + (size_t)j); step = -(ptrdiff_t)stride; stop = TB_MD; }
+		else { n = j; at = (ptrdiff_t)((size_t)i * stride + (size_t)(j - 1)); step = -1; stop = TB_MI; }
+		if (n <= 0) break;
+		if (n > 64) n = 64;
+		uint32_t t = 0;
+		if (lane < n) t = TB[at + step * lane];
+		const uint64_t ends = __ballot(lane < n && (t & stop) != 0);
+		const int len = ends ? (int)__builtin_ctzll(ends) + 1 : n;  // the cell that ends the run is still in this state
+		R.emit_run(st, len, lane);
+		int nst = st;
+		if (ends) {
+			const uint32_t te = rdlane(t, len - 1);
+			if (st == OP_M) nst = (te & TB_DM) ? OP_D : OP_I;
+			else nst = OP_M;
+		}
+		if (st == OP_M) { i -= len; j -= len; }
+		else if (st == OP_D) i -= len;
+		else j -= len;
+		st = nst;
 	}
 	R.end(lane);
 	if (R.overflow) status |= URMAPX_ST_PATH_OVERFLOW;
