@@ -336,7 +336,7 @@ class Mapper:
     def gather_microbench(self, n_loads=1 << 28):
         """Random 5-byte slot reads per second over the resident slot table (measurement aid)."""
         r = C.c_double(0.0)
-        _check(lib().urmapx_ctx_gather_microbench(self._h, n_loads, C.byref(r)), "urmapx_ctx_gather_microbench")
+        _check(lib().urmapx_ctx_gather_microbench(self.h, n_loads, C.byref(r)), "urmapx_ctx_gather_microbench")
         return r.value
 
     def phase_cycles(self):
