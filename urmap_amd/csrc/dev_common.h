@@ -39,14 +39,26 @@ template <int CTRL, int ROWMASK>
 __device__ __forceinline__ float dpp_f(float v, float fill) {
 	return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(v), CTRL, ROWMASK, 0xF, false));
 }
-// inclusive prefix max over the 64 lanes
+// inclusive prefix max over the 64 lanes: six v_max_f32 with a DPP source each.  Written as one asm block because the
+// compiler's form costs five instructions per step (constant fill, nop, v_mov_dpp, a canonicalising max, the max):
+// with dst = src1 = the value itself a lane whose DPP source does not exist is simply not written (bound_ctrl:0) and
+// keeps its value.  s_nop 1 = the two wait states a DPP read needs after the VALU write of the same register.
 __device__ __forceinline__ float wave_prefix_max(float v) {
-	v = fmaxf(v, dpp_f<0x111, 0xF>(v, NEG));  // row_shr:1
-	v = fmaxf(v, dpp_f<0x112, 0xF>(v, NEG));  // row_shr:2
-	v = fmaxf(v, dpp_f<0x114, 0xF>(v, NEG));  // row_shr:4
-	v = fmaxf(v, dpp_f<0x118, 0xF>(v, NEG));  // row_shr:8
-	v = fmaxf(v, dpp_f<0x142, 0xA>(v, NEG));  // row_bcast:15 -> rows 1,3
-	v = fmaxf(v, dpp_f<0x143, 0xC>(v, NEG));  // row_bcast:31 -> rows 2,3
+	asm volatile(
+	    "s_nop 1\n\t"
+	    "v_max_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+	    "s_nop 1\n\t"
+	    "v_max_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+	    "s_nop 1\n\t"
+	    "v_max_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+	    "s_nop 1\n\t"
+	    "v_max_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+	    "s_nop 1\n\t"
+	    "v_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+	    "s_nop 1\n\t"
+	    "v_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+	    "s_nop 1"
+	    : "+v"(v));
 	return v;
 }
 
