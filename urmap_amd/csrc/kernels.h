@@ -41,6 +41,7 @@ struct SearchWork {
 	uint8_t *scratch;
 	size_t scratch_stride;  // search_scratch_stride(max_read_len)
 	int blocks;             // search_block_count(max_read_len, device)
+	uint32_t *ticket;       // device word: work counter of the launch (zeroed by the launcher)
 };
 size_t search_scratch_stride(uint32_t max_read_len);
 int search_block_count(uint32_t max_read_len, int device);

@@ -461,7 +461,8 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
                                                        urmapx_result *__restrict__ results,
                                                        urmapx_path_op *__restrict__ path_ops, uint32_t *path_used,
                                                        uint32_t *stats, uint8_t *scratch, size_t scratch_stride,
-                                                       const uint8_t *__restrict__ g_seq, const uint8_t *__restrict__ g_blob) {
+                                                       const uint8_t *__restrict__ g_seq, const uint8_t *__restrict__ g_blob,
+                                                       uint32_t *ticket) {
 	// stats != nullptr (URMAPX_PHASE_STATS): per-phase shader cycles are accumulated into stats (u64 each, from byte 8)
 	using SW = SearchWave<NCH>;
 	__shared__ __attribute__((aligned(16))) uint8_t sQ2[2 * SW::QMAX];  // plus strand, then reverse complement
@@ -496,7 +497,15 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 		S.ws.carve(sc + (size_t)SW::NSEG * ROW_CAP * 64 * 4, SW::QMAX, SW::WIDE_LB);
 	}
 
-	for (uint32_t r = blockIdx.x; r < n; r += gridDim.x) {
+	// Reads are handed out by a ticket counter, not by a fixed stride: the cost of a read is heavy-tailed (a read in a
+	// repeat family aligns up to 256 HSPs in phase 6), and with a fixed assignment the blocks that draw such reads
+	// finish long after the rest.
+	for (;;) {
+		uint32_t r = 0;
+		// every lane takes part in the atomic (lanes 1..63 add 0): with `if (lane == 0) atomicAdd` here the compiler's
+		// wave-level atomic rewrite turns the loop divergent and the kernel hangs or faults (seen twice)
+		r = uni(atomicAdd(ticket, lane == 0 ? 1u : 0u));
+		if (r >= n) break;
 		const uint64_t off = offs[r];
 		const int QL = (int)(offs[r + 1] - off);
 
@@ -504,11 +513,9 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 		res.dbpos = 0xFFFFFFFFu; res.seq_index = 0xFFFFFFFFu; res.coord = 0xFFFFFFFFu;
 		res.score = 0; res.second = 0; res.mapq = 0; res.plus = 0; res.exit_phase = 0; res.status = 0;
 		res.hit_count = 0; res.path_nops = 0; res.path_off = 0;
-		if (QL < W || QL > SW::QMAX || W > 32 || X.maxIx > (uint32_t)ROW_CAP) {
-			res.status = URMAPX_ST_BAD_LENGTH;
-			if (lane == 0) results[r] = res;
-			continue;
-		}
+		const bool badlen = QL < W || QL > SW::QMAX || W > 32 || X.maxIx > (uint32_t)ROW_CAP;
+		if (badlen) res.status = URMAPX_ST_BAD_LENGTH;
+		if (!badlen) {
 		S.QL = QL;
 		const int nwords = QL - (W - 1);
 		S.nwords = nwords;
@@ -756,8 +763,9 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 				}
 			}
 		}
-		if (lane == 0) results[r] = res;
 		lapc(7);
+		}  // !badlen
+		if (lane == 0) results[r] = res;
 	}
 }
 
@@ -831,6 +839,10 @@ hipError_t launch_search_se(const DevIndex &X, const urmapx_params &P, const uin
                             urmapx_path_op *d_path_ops, uint32_t *d_path_used, const SearchWork &wk, hipStream_t s) {
 	if (n == 0) return hipSuccess;
 	const int nch = nch_for(max_read_len);
+	{
+		hipError_t e = hipMemsetAsync(wk.ticket, 0, 4, s);
+		if (e != hipSuccess) return e;
+	}
 	if (wk.stats) {
 		hipError_t e = hipMemsetAsync(wk.stats + 2, 0, 184, s);
 		if (e != hipSuccess) return e;
@@ -838,10 +850,10 @@ hipError_t launch_search_se(const DevIndex &X, const urmapx_params &P, const uin
 	dim3 block(64), grid((unsigned)wk.blocks);
 	if (nch == 3)
 		hipLaunchKernelGGL(search_se_kernel<3>, grid, block, 0, s, X, P, d_bases, d_offs, n, probe, d_results, d_path_ops,
-		                   d_path_used, wk.stats, wk.scratch, wk.scratch_stride, X.seq, X.blob);
+		                   d_path_used, wk.stats, wk.scratch, wk.scratch_stride, X.seq, X.blob, wk.ticket);
 	else
 		hipLaunchKernelGGL(search_se_kernel<5>, grid, block, 0, s, X, P, d_bases, d_offs, n, probe, d_results, d_path_ops,
-		                   d_path_used, wk.stats, wk.scratch, wk.scratch_stride, X.seq, X.blob);
+		                   d_path_used, wk.stats, wk.scratch, wk.scratch_stride, X.seq, X.blob, wk.ticket);
 	return hipGetLastError();
 }
 

@@ -604,7 +604,7 @@ __global__ __launch_bounds__(64) void search_pe_kernel(DevIndex X, urmapx_params
                                                        urmapx_path_op *__restrict__ path_ops, uint32_t *path_used,
                                                        uint8_t *scratch, size_t scratch_stride,
                                                        const uint8_t *__restrict__ g_seq, const uint8_t *__restrict__ g_blob,
-                                                       int veryfast) {
+                                                       int veryfast, uint32_t *ticket) {
 	using M = Mate<NCH>;
 	constexpr int QMAX = M::QMAX;
 	__shared__ __attribute__((aligned(16))) uint8_t sQ[4][QMAX];
@@ -648,7 +648,9 @@ __global__ __launch_bounds__(64) void search_pe_kernel(DevIndex X, urmapx_params
 		m[a].ws.carve(sc + (size_t)2 * PE_HIT_CAP * URMAPX_MAX_PATH_OPS * 2, QMAX, PE_SCAN_SEG + 2 * QMAX + 64);
 	}
 
-	for (uint32_t pr = blockIdx.x; pr < npairs; pr += gridDim.x) {
+	for (;;) {  // pairs are handed out by a ticket counter (heavy-tailed cost per pair: the rescue DP), see search_se_kernel
+		const uint32_t pr = uni(atomicAdd(ticket, lane == 0 ? 1u : 0u));
+		if (pr >= npairs) break;
 		urmapx_result res[2];
 		bool bad = false;
 		for (int a = 0; a < 2; ++a) {
@@ -1043,13 +1045,17 @@ hipError_t launch_search_pe(const DevIndex &X, const urmapx_params &P, const uin
                             urmapx_path_op *d_path_ops, uint32_t *d_path_used, const SearchWork &wk, int veryfast,
                             hipStream_t s) {
 	if (npairs == 0) return hipSuccess;
+	{
+		hipError_t e = hipMemsetAsync(wk.ticket, 0, 4, s);
+		if (e != hipSuccess) return e;
+	}
 	dim3 block(64), grid((unsigned)wk.blocks);
 	if (pe_nch_for(max_read_len) == 3)
 		hipLaunchKernelGGL(search_pe_kernel<3>, grid, block, 0, s, X, P, d_bases, d_offs, npairs, probe, d_results, d_path_ops,
-		                   d_path_used, wk.scratch, wk.scratch_stride, X.seq, X.blob, veryfast);
+		                   d_path_used, wk.scratch, wk.scratch_stride, X.seq, X.blob, veryfast, wk.ticket);
 	else
 		hipLaunchKernelGGL(search_pe_kernel<5>, grid, block, 0, s, X, P, d_bases, d_offs, npairs, probe, d_results, d_path_ops,
-		                   d_path_used, wk.scratch, wk.scratch_stride, X.seq, X.blob, veryfast);
+		                   d_path_used, wk.scratch, wk.scratch_stride, X.seq, X.blob, veryfast, wk.ticket);
 	return hipGetLastError();
 }
 

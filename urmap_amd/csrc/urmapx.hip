@@ -336,6 +336,7 @@ int urmapx_map_se_device(urmapx_ctx *C, const void *d_bases, const void *d_offs,
 	if ((rc = C->scratch.ensure(wk.scratch_stride * (size_t)wk.blocks))) return rc;
 	if ((rc = C->statsbuf.ensure(64))) return rc;
 	wk.scratch = C->scratch.p;
+	wk.ticket = C->statsbuf.p + 62;  // words 62/63 of the diagnostics buffer are never touched by the stamps
 	// diagnostics: URMAPX_PHASE_STATS = per-phase cycle counters; URMAPX_DEBUG_STOP=N = cut the schedule after step N
 	// (results are then NOT the reference's).  Words 0/1 of the buffer: stop step, "no timing" flag.
 	const char *ds = getenv("URMAPX_DEBUG_STOP");
@@ -418,6 +419,8 @@ int urmapx_map_pe_device(urmapx_ctx *C, const void *d_bases, const void *d_offs,
 	if ((rc = C->pe_scratch.ensure(wk.scratch_stride * (size_t)wk.blocks))) return rc;
 	wk.scratch = C->pe_scratch.p;
 	wk.stats = nullptr;
+	if ((rc = C->statsbuf.ensure(64))) return rc;
+	wk.ticket = C->statsbuf.p + 62;
 	ProbeOut po{C->slots.p, C->tallies.p, C->positions.p};
 	HIP_TRY(hipMemsetAsync(d_path_used, 0, 4, C->stream));
 	// positions the probe kernel does not write (qpos > L-W) must read as "no k-mer"
