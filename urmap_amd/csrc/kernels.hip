@@ -154,7 +154,9 @@ static constexpr int ROW_CAP = 32;  // UFIndex m_MaxIx of every index this build
 template <int NCH>
 struct SearchWave {
 	static constexpr int QMAX = 64 * NCH;
-	static constexpr int TB_ROWS8 = QMAX / 8 + 2;
+	// rows of the narrow DP's trace buffer: a flank is at most QMAX - W long (the HSP holds the seed), longer problems
+	// take the wide path
+	static constexpr int TB_ROWS8 = (QMAX - 24) / 8 + 2;
 	static constexpr int WIDE_LB = QMAX + 64;
 	static constexpr int NSEG = 2 * NCH;  // candidate row segments: [strand][chunk] or [chunk]
 
@@ -170,8 +172,8 @@ struct SearchWave {
 	uint32_t *tb;
 	uint16_t *ropsL, *ropsR, *cand, *top;
 	uint16_t *pre;   // exclusive prefix of candidate counts, NSEG*64+1 entries
-	uint32_t *hsp_db, *hsp_ql;
-	uint16_t *hsp_sf;  // score<<2 | aligned<<1 | plus
+	uint32_t *hsp_db;
+	uint32_t *hsp_pk;  // startq | len << 9 | score << 18 | aligned << 27 | plus << 28 (all <= 320: 9 bits each)
 	// global scratch of this block
 	uint32_t *rowstore;  // [strand][chunk][k][lane]
 	WideScratch ws;
@@ -227,13 +229,13 @@ struct SearchWave {
 		for (int base = 0; base < hspCount; base += 64) {
 			const int i = base + lane;
 			bool eq = false;
-			if (i < hspCount) eq = (hsp_db[i] - (hsp_ql[i] & 0xFFFFu)) == diag;
+			if (i < hspCount) eq = (hsp_db[i] - (hsp_pk[i] & 511u)) == diag;
 			uint64_t m = __ballot(eq);
 			if (m) {
 				const int k = base + __builtin_ctzll(m);
-				const int old = (int)(hsp_sf[k] >> 2);
+				const int old = (int)((hsp_pk[k] >> 18) & 511u);
 				if (score > old && lane == 0) {
-					hsp_db[k] = startdb; hsp_ql[k] = startq | (len << 16); hsp_sf[k] = (uint16_t)((score << 2) | (plus ? 1 : 0));
+					hsp_db[k] = startdb; hsp_pk[k] = startq | (len << 9) | ((uint32_t)score << 18) | (plus ? 1u << 28 : 0u);
 				}
 				__syncthreads();
 				return;
@@ -241,8 +243,8 @@ struct SearchWave {
 		}
 		if (hspCount >= HSP_CAP) { status |= URMAPX_ST_HSP_OVERFLOW; return; }
 		if (lane == 0) {
-			hsp_db[hspCount] = startdb; hsp_ql[hspCount] = startq | (len << 16);
-			hsp_sf[hspCount] = (uint16_t)((score << 2) | (plus ? 1 : 0));
+			hsp_db[hspCount] = startdb;
+			hsp_pk[hspCount] = startq | (len << 9) | ((uint32_t)score << 18) | (plus ? 1u << 28 : 0u);
 		}
 		__syncthreads();
 		++hspCount;
@@ -263,15 +265,14 @@ struct SearchWave {
 
 	// alignhsp.cpp:60-172
 	__device__ void align_hsp(int k) {
-		const uint32_t sf = hsp_sf[k];
-		if (sf & 2u) return;
+		const uint32_t pk = hsp_pk[k];
+		if (pk & (1u << 27)) return;  // m_Aligned
 		__syncthreads();
-		if (lane == 0) hsp_sf[k] = (uint16_t)(sf | 2u);
-		const uint32_t ql = hsp_ql[k];
-		const int startq = (int)(ql & 0xFFFFu), len = (int)(ql >> 16);
+		if (lane == 0) hsp_pk[k] = pk | (1u << 27);
+		const int startq = (int)(pk & 511u), len = (int)((pk >> 9) & 511u);
 		const uint32_t startdb = hsp_db[k];
-		const int hscore = (int)(sf >> 2);
-		const bool plus = sf & 1u;
+		const int hscore = (int)((pk >> 18) & 511u);
+		const bool plus = (pk >> 28) & 1u;
 		__syncthreads();
 		int totalPen = len - hscore;
 		int totalScore = hscore;
@@ -450,11 +451,14 @@ struct SearchWave {
 	}
 };
 
-// waves per SIMD the register allocation aims at: 3 for reads <= 192 (168 VGPRs), 2 for reads <= 320 (the five-word
-// bit vectors and 20 window loads in flight do not fit 168 registers without hundreds of spills)
-#ifndef SEARCH_WAVES_PER_EU
-#define SEARCH_WAVES_PER_EU(NCH) ((NCH) <= 3 ? 3 : 2)
+// waves per SIMD the register allocation aims at.  Reads <= 192: 4 (128 VGPRs, ~30 registers spilled to scratch in
+// cold paths; LDS per block is kept under 10 KB for the same 16 blocks per CU) -- measured 10 % faster than 3 waves
+// with no spills.  Reads <= 320: 2 (the five-word bit vectors and 20 window loads in flight do not fit fewer
+// registers without hundreds of spills).
+#ifndef SEARCH_WAVES_NCH3
+#define SEARCH_WAVES_NCH3 4
 #endif
+#define SEARCH_WAVES_PER_EU(NCH) ((NCH) <= 3 ? SEARCH_WAVES_NCH3 : 2)
 template <int NCH>
 __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel(DevIndex X, urmapx_params P, const uint8_t *__restrict__ bases,
                                                        const uint64_t *__restrict__ offs, uint32_t n, ProbeOut probe,
@@ -468,18 +472,20 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 	__shared__ __attribute__((aligned(16))) uint8_t sQ2[2 * SW::QMAX];  // plus strand, then reverse complement
 	uint8_t *const sQp = sQ2, *const sQm = sQ2 + SW::QMAX;
 	const uint8_t *__restrict__ const seq = g_seq;
-	__shared__ uint8_t sT[SW::QMAX + 64];
 	__shared__ uint32_t tb[SW::TB_ROWS8 * 64];
 	__shared__ uint16_t top[URMAPX_MAX_PATH_OPS];
 	__shared__ uint16_t pre[2 * SW::NSEG * 64 + 2];
 	// the flank run buffers and the candidate path live only inside align_hsp, the candidate prefix array only inside a
 	// gather step: they share memory (LDS per block decides how many reads a CU keeps in flight)
-	static_assert(2 * OPS_CAP + URMAPX_MAX_PATH_OPS <= 2 * SW::NSEG * 64 + 2, "alias");
+	static_assert(2 * OPS_CAP + URMAPX_MAX_PATH_OPS + (SW::QMAX + 64) / 2 <= 2 * SW::NSEG * 64 + 2, "alias");
 	uint16_t *const ropsL = pre, *const ropsR = pre + OPS_CAP, *const cand = pre + 2 * OPS_CAP;
-	__shared__ uint32_t hsp_db[HSP_CAP], hsp_ql[HSP_CAP];
-	__shared__ uint16_t hsp_sf[HSP_CAP];
-	__shared__ uint32_t cq_db[128];  // candidate queue (ring): reference position, query position | plus << 14 | second phase << 15
-	__shared__ uint16_t cq_qp[128];
+	uint8_t *const sT = reinterpret_cast<uint8_t *>(pre + 2 * OPS_CAP + URMAPX_MAX_PATH_OPS);  // AlignHSP's target window
+	__shared__ uint32_t hsp_db[HSP_CAP], hsp_pk[HSP_CAP];
+	// candidate queue (ring): reference position, query position | plus << 14 | second phase << 15.  It is alive inside a
+	// gather step only, like the BOTH1 seed positions (xp): both sit on the DP trace buffer, which AlignHSP owns.
+	static_assert(2 * SW::QMAX + 128 + 64 <= SW::TB_ROWS8 * 64, "alias");
+	uint32_t *const cq_db = tb + 2 * SW::QMAX;
+	uint16_t *const cq_qp = reinterpret_cast<uint16_t *>(tb + 2 * SW::QMAX + 128);
 
 	const int lane = threadIdx.x;
 	const int W = (int)X.W;
@@ -490,7 +496,7 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 	S.gseq = g_seq; S.gblob = g_blob;
 	S.sQ[0] = sQp; S.sQ[1] = sQm; S.sT = sT; S.tb = tb;
 	S.ropsL = ropsL; S.ropsR = ropsR; S.cand = cand; S.top = top; S.pre = pre;
-	S.hsp_db = hsp_db; S.hsp_ql = hsp_ql; S.hsp_sf = hsp_sf;
+	S.hsp_db = hsp_db; S.hsp_pk = hsp_pk;
 	{
 		uint8_t *sc = scratch + (size_t)blockIdx.x * scratch_stride;
 		S.rowstore = reinterpret_cast<uint32_t *>(sc);
