@@ -607,27 +607,35 @@ __global__ __launch_bounds__(64) void search_pe_kernel(DevIndex X, urmapx_params
                                                        int veryfast, uint32_t *ticket) {
 	using M = Mate<NCH>;
 	constexpr int QMAX = M::QMAX;
+	// LDS per block decides how many pairs a CU keeps in flight, so arrays share memory by lifetime:
+	//   probe results staged for the seed enumeration (s_tal, s_pos)       on  the DP trace buffer (idle until AlignHSP)
+	//   flank run buffers, candidate path, target window (AlignHSP / Scan)  on  seed_res  (seeds are dead by then)
+	//   pending-stage row lengths and prefix                               on  seed_q
+	//   FindPairs' pair list                                               on  seed_db
 	__shared__ __attribute__((aligned(16))) uint8_t sQ[4][QMAX];
-	__shared__ uint8_t sT[QMAX + 64];
-	__shared__ uint32_t tb[M::TB_ROWS8 * 64];
-	__shared__ uint16_t ropsL[OPS_CAP], ropsR[OPS_CAP], cand[URMAPX_MAX_PATH_OPS];
+	__shared__ __attribute__((aligned(16))) uint32_t tb[M::TB_ROWS8 * 64];
 	__shared__ uint16_t hit_nops[2][PE_HIT_CAP];
 	__shared__ uint32_t hsp_db[2][PE_HSP_CAP], hsp_ql[2][PE_HSP_CAP];
 	__shared__ uint16_t hsp_sf[2][PE_HSP_CAP];
 	__shared__ uint8_t pend[4][QMAX];
-	__shared__ uint8_t rowlen[2 * QMAX];  // shared by the two mates: SearchPE_Pending runs on one mate at a time
-	__shared__ uint16_t pre[66];
 	// Both1 seed lists of the two mates in enumeration order: qpos | plus << 15, db position
 	constexpr int SEED_CAP = 2 * QMAX;  // >= 2 * (QMAX - W + 1)
-	__shared__ uint16_t seed_q[2][SEED_CAP];
-	__shared__ uint32_t seed_db[2][SEED_CAP];
+	__shared__ __attribute__((aligned(16))) uint16_t seed_q[2][SEED_CAP];
+	__shared__ __attribute__((aligned(16))) uint32_t seed_db[2][SEED_CAP];
 	// cached ExtendPen outcome of every seed (see extend_pen_cached); bit 15 of seed_pen = "already extended once"
-	__shared__ uint32_t seed_res[2][SEED_CAP];
+	__shared__ __attribute__((aligned(16))) uint32_t seed_res[2][SEED_CAP];
 	__shared__ uint16_t seed_pen[2][SEED_CAP];
-	__shared__ uint16_t pair_f[PE_PAIR_CAP], pair_r[PE_PAIR_CAP];
-	// probe results of both mates staged in LDS ([mate][strand][qpos]): the seed enumeration reads them one by one
-	__shared__ uint8_t s_tal[2][2][QMAX];
-	__shared__ uint32_t s_pos[2][2][QMAX];
+	static_assert(4 * QMAX + 16 * QMAX <= sizeof(tb), "alias");
+	uint8_t (*const s_tal)[2][QMAX] = reinterpret_cast<uint8_t (*)[2][QMAX]>(tb);                 // [mate][strand][qpos]
+	uint32_t (*const s_pos)[2][QMAX] = reinterpret_cast<uint32_t (*)[2][QMAX]>(tb + QMAX);        // after the 4*QMAX tally bytes
+	static_assert((2 * OPS_CAP + URMAPX_MAX_PATH_OPS) * 2 + QMAX + 64 <= sizeof(seed_res), "alias");
+	uint16_t *const ropsL = reinterpret_cast<uint16_t *>(&seed_res[0][0]), *const ropsR = ropsL + OPS_CAP, *const cand = ropsR + OPS_CAP;
+	uint8_t *const sT = reinterpret_cast<uint8_t *>(cand + URMAPX_MAX_PATH_OPS);
+	static_assert(2 * QMAX + 66 * 2 <= sizeof(seed_q), "alias");
+	uint8_t *const rowlen = reinterpret_cast<uint8_t *>(&seed_q[0][0]);  // shared by the two mates: SearchPE_Pending runs on one mate at a time
+	uint16_t *const pre = reinterpret_cast<uint16_t *>(rowlen + 2 * QMAX);
+	static_assert(2 * PE_PAIR_CAP * 2 <= sizeof(seed_db), "alias");
+	uint16_t *const pair_f = reinterpret_cast<uint16_t *>(&seed_db[0][0]), *const pair_r = pair_f + PE_PAIR_CAP;
 
 	const int lane = threadIdx.x;
 	const int W = (int)X.W;
