@@ -351,3 +351,9 @@ def test_pe_veryfast_search5_matches_oracle(small_case, tmp_path):
     got = _map_pe_sam(small_case["ufi"], f1, f2, veryfast=True)
     want = open(osam, "rb").read()
     assert got == want
+
+
+def test_gather_microbench_reports_a_rate(gpu):
+    """The roofline denominator bench.py reports (random slot reads over the resident table) is measurable."""
+    rate = gpu["mapper"].gather_microbench(1 << 22)
+    assert rate > 1e8  # slot reads per second; a few 1e10 on MI355X
