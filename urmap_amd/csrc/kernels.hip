@@ -149,6 +149,7 @@ __global__ __launch_bounds__(64) void viterbi_batch_kernel(urmapx_params P, cons
 //            through ExtendPen's x-drop / penalty logic, AddHitX / AddHSPX, early exits -- exactly in order.
 // ------------------------------------------------------------------------------------------------
 static constexpr int HSP_CAP = 256;
+static constexpr int TICKET_CHUNK = 4;
 static constexpr int ROW_CAP = 32;  // UFIndex m_MaxIx of every index this build accepts
 
 template <int NCH>
@@ -506,15 +507,22 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 	// Reads are handed out by a ticket counter, not by a fixed stride: the cost of a read is heavy-tailed (a read in a
 	// repeat family aligns up to 256 HSPs in phase 6), and with a fixed assignment the blocks that draw such reads
 	// finish long after the rest.
+	// TICKET_CHUNK reads per ticket: same-address atomics retire at ~88 M/s on this device (a bare ticket loop over 1 M
+	// reads takes 11.4 ms), which would cap the kernel not far above its current rate.
+	uint32_t r_next = 0, r_end = 0;
 	for (;;) {
-		uint32_t r = 0;
-		// every lane takes part in the atomic (lanes 1..63 add 0): with `if (lane == 0) atomicAdd` here the compiler's
-		// wave-level atomic rewrite turns the loop divergent and the kernel hangs or faults (seen twice)
-		r = uni(atomicAdd(ticket, lane == 0 ? 1u : 0u));
-		if (r >= n) break;
+		if (r_next == r_end) {
+			// every lane takes part in the atomic (lanes 1..63 add 0): with `if (lane == 0) atomicAdd` here the compiler's
+			// wave-level atomic rewrite turns the loop divergent and the kernel hangs or faults (seen twice)
+			r_next = uni(atomicAdd(ticket, lane == 0 ? (uint32_t)TICKET_CHUNK : 0u));
+			if (r_next >= n) break;
+			r_end = r_next + TICKET_CHUNK < n ? r_next + TICKET_CHUNK : n;
+		}
+		const uint32_t r = r_next++;
 		const uint64_t off = offs[r];
 		const int QL = (int)(offs[r + 1] - off);
 
+		if (dbg_stop == 97) { if (QL == 12345) break; continue; }
 		urmapx_result res;
 		res.dbpos = 0xFFFFFFFFu; res.seq_index = 0xFFFFFFFFu; res.coord = 0xFFFFFFFFu;
 		res.score = 0; res.second = 0; res.mapq = 0; res.plus = 0; res.exit_phase = 0; res.status = 0;
@@ -544,6 +552,7 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 
 		// BOTH1 seed positions of this read by [strand][query position] in LDS (tb is idle outside align_hsp); every
 		// other k-mer gets the sentinel.  Chain heads are re-read from the probe output when the walk starts.
+		if (dbg_stop == 98) continue;
 		const uint64_t base2 = 2ull * off;
 		uint32_t *xp = reinterpret_cast<uint32_t *>(tb);
 #pragma unroll
@@ -561,6 +570,7 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 		}
 		__syncthreads();
 
+		if (dbg_stop == 99) continue;
 		const int minScore1 = QL + P.xphase1 * P.mismatch_score;
 		const int minScore3 = QL + P.xphase3 * P.mismatch_score;
 		const int minScore4 = QL + P.xphase4 * P.mismatch_score;
@@ -588,7 +598,8 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 		for (int g = 0; g < SW::NSEG; ++g) rl[g] = 0;
 		for (int step = 1; step <= 6 && !done; step += (step == 1 ? 2 : (step == 3 ? 1 : 2))) {  // 1 (=1+2), 3, 4 (=4+5), 6
 			phase = step;
-			if (dbg_stop && step > (dbg_stop > 400 ? 4 : dbg_stop)) break;
+			if (dbg_stop == 100) break;  // setup + output only
+			if (dbg_stop && step > (dbg_stop > 410 ? 1 : dbg_stop > 400 ? 4 : dbg_stop)) break;
 			if (step == 3 || step == 6) {
 				if (step == 6 || S.bestHSP > termHSP3) {
 					for (int k = 0; k < S.hspCount; ++k) S.align_hsp(k);
@@ -683,14 +694,14 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 				qhead = (qhead + nb) & 127; qcount -= nb;
 				__syncthreads();
 				laps(8);
-				if (dbg_stop == 401 && step == 4) continue;
+				if ((dbg_stop == 401 && step == 4) || dbg_stop == 411) continue;
 				uint64_t mm[NCH];
 #pragma unroll
 				for (int c = 0; c < NCH; ++c) mm[c] = 0;
 				if (c_ok) lane_mismatch_mask<NCH>(seq, c_db - c_qpos, sQ2 + (c_plus ? 0 : SW::QMAX), QL, mm);
 				__builtin_amdgcn_s_waitcnt(0);
 				laps(9);
-				if (dbg_stop == 402 && step == 4) { if (mm[0] == 0x123456789ull) done = true; continue; }
+				if ((dbg_stop == 402 && step == 4) || dbg_stop == 412) { if (mm[0] == 0x123456789ull) done = true; continue; }
 				// ExtendPen's two x-drop walks (extendpen.cpp:25-78), every lane on its own bit vector, WITHOUT the
 				// running penalty cap: the accumulated penalty only grows along the walk, so the capped walk aborts
 				// iff the uncapped walk's final penalty exceeds the cap -- which is checked in order below.
@@ -701,7 +712,7 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 					else if (e_bst >= minhsp) e_kind = 2;
 				}
 				laps(10);
-				if (dbg_stop == 403 && step == 4) { if (__ballot(e_bst == 12345)) done = true; continue; }
+				if ((dbg_stop == 403 && step == 4) || dbg_stop == 413) { if (__ballot(e_bst == 12345)) done = true; continue; }
 				// order-dependent part: only candidates that can change the state, in the reference's order.  Lanes that
 				// cannot change it are dropped, up front and again after every change: the penalty cap only falls, the best
 				// score only rises and hits are only added, so a candidate failing extendpen.cpp:15-17, extendpen.cpp:43-44
