@@ -64,6 +64,8 @@ struct Mate {
 	uint8_t *pend[2];     // LDS [QMAX] each: pending query positions (stored in a byte, state1.h:86-87)
 	uint8_t *rowlen;      // LDS [2 * QMAX]: row length of every pending position, [strand][i]
 	uint16_t *pre;        // LDS [65]
+	uint32_t *cq_db;      // LDS [128]: candidate queue of the pending stage (ring)
+	uint16_t *cq_qp;      // LDS [128]
 	uint32_t *rowstore;   // global, this block: [strand][chunk][k][lane]
 	int pendCount[2];
 	int hitCount, hspCount, topHit;
@@ -435,10 +437,60 @@ struct Mate {
 			}
 		}
 		__syncthreads();
-		// 2. the four groups in the reference's order, 64 pending positions at a time
+		// 2. the four groups in the reference's order.  Candidates that survive the hit-diagonal filter are compacted, in
+		// order, into a 128-entry LDS queue (reference position, query position | plus << 15), so that the gather below
+		// always runs on full batches even though most (round, strand, chunk) groups hold only a few row entries.
+		int qhead = 0, qcount = 0;
+		auto drain = [&](bool all) {
+			while (qcount >= 64 || (all && qcount > 0)) {
+				__syncthreads();
+				const int nb = qcount < 64 ? qcount : 64;
+				uint32_t c_q = 0, c_db = 0;
+				bool c_plus = true;
+				const bool ok = lane < nb;
+				if (ok) {
+					const int pos = (qhead + lane) & 127;
+					c_db = cq_db[pos];
+					const uint32_t qp = cq_qp[pos];
+					c_q = qp & 0x7FFFu; c_plus = (qp & 0x8000u) != 0;
+				}
+				qhead = (qhead + nb) & 127; qcount -= nb;
+				__syncthreads();
+				const uint32_t dblo = c_db - c_q;
+				int e_kind = 0, e_bst = 0, e_sp = 0, e_ep = 0, e_pen = 0;
+				if (ok) {
+					uint64_t mm[NCH];
+					lane_mismatch_mask<NCH>(gseq, dblo, c_plus ? sQ[0] : sQ[1], QL, mm);
+					xdrop_walk_lane<NCH>(mm, (int)c_q, W, QL, P->mismatch_score, P->xdrop, e_bst, e_sp, e_ep, e_pen);
+					if (e_sp == 0 && e_ep == QL - 1) e_kind = 1;
+					else if (e_bst >= minhsp) e_kind = 2;
+				}
+				// ordered part (see search_se_kernel): candidates that cannot change the state are dropped, up front and
+				// after every change
+				uint64_t todo = __ballot(e_kind != 0 && e_pen <= maxPen && !(e_kind == 2 && e_bst < best - 4) &&
+				                         !overlaps_any_hit(dblo));
+				while (todo) {
+					const int t = __builtin_ctzll(todo);
+					todo &= todo - 1;
+					const uint32_t d = rdlane(dblo, t);
+					if (overlaps_hit(d)) continue;
+					if (rdlane(e_pen, t) > maxPen) continue;
+					const int bst = rdlane(e_bst, t);
+					const bool pl = rdlane((uint32_t)c_plus, t) != 0;
+					const int hc0 = hitCount, mp0 = maxPen, b0 = best;
+					if (rdlane(e_kind, t) == 1) add_hit(d, pl, bst, 0);
+					else {
+						const uint32_t sp = (uint32_t)rdlane(e_sp, t), ep = (uint32_t)rdlane(e_ep, t);
+						add_hsp(sp, d + sp, pl, ep - sp + 1, bst);
+					}
+					if (hitCount != hc0 || maxPen != mp0 || best != b0)
+						todo &= __ballot(e_pen <= maxPen && !(e_kind == 2 && e_bst < best - 4) &&
+						                 !(hitCount != hc0 && (dblo >> 6) == (d >> 6)));
+				}
+			}
+		};
 		for (int round = 0; round < 2; ++round) {
 			for (int s = 0; s < 2; ++s) {
-				const bool plus = (s == 0);
 				for (int base = 0; base < pendCount[s]; base += 64) {
 					const int i = base + lane;
 					int K = 0;
@@ -468,40 +520,20 @@ struct Mate {
 							c_db = rs0[k * 64 + lo];
 							ok = c_db >= c_q;
 						}
-						const uint32_t dblo = c_db - c_q;
-						ok = ok && !overlaps_any_hit(dblo);
-						int e_kind = 0, e_bst = 0, e_sp = 0, e_ep = 0, e_pen = 0;
+						ok = ok && !overlaps_any_hit(c_db - c_q);
+						const uint64_t m = __ballot(ok);
 						if (ok) {
-							uint64_t mm[NCH];
-							lane_mismatch_mask<NCH>(gseq, dblo, sQ[s], QL, mm);
-							xdrop_walk_lane<NCH>(mm, (int)c_q, W, QL, P->mismatch_score, P->xdrop, e_bst, e_sp, e_ep, e_pen);
-							if (e_sp == 0 && e_ep == QL - 1) e_kind = 1;
-							else if (e_bst >= minhsp) e_kind = 2;
+							const int pos = (qhead + qcount + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))) & 127;
+							cq_db[pos] = c_db;
+							cq_qp[pos] = (uint16_t)(c_q | (s == 0 ? 0x8000u : 0u));
 						}
-						// ordered part (see search_se_kernel): candidates that cannot change the state are dropped, up front
-						// and after every change
-						uint64_t todo = __ballot(e_kind != 0 && e_pen <= maxPen && !(e_kind == 2 && e_bst < best - 4));
-						while (todo) {
-							const int t = __builtin_ctzll(todo);
-							todo &= todo - 1;
-							const uint32_t d = rdlane(dblo, t);
-							if (overlaps_hit(d)) continue;
-							if (rdlane(e_pen, t) > maxPen) continue;
-							const int bst = rdlane(e_bst, t);
-							const int hc0 = hitCount, mp0 = maxPen, b0 = best;
-							if (rdlane(e_kind, t) == 1) add_hit(d, plus, bst, 0);
-							else {
-								const uint32_t sp = (uint32_t)rdlane(e_sp, t), ep = (uint32_t)rdlane(e_ep, t);
-								add_hsp(sp, d + sp, plus, ep - sp + 1, bst);
-							}
-							if (hitCount != hc0 || maxPen != mp0 || best != b0)
-								todo &= __ballot(e_pen <= maxPen && !(e_kind == 2 && e_bst < best - 4) &&
-								                 !(hitCount != hc0 && (dblo >> 6) == (d >> 6)));
-						}
+						qcount += __builtin_popcountll(m);
+						drain(false);
 					}
 				}
 			}
 		}
+		drain(true);
 		const int bmin = max(best, bestHSP) - 8;
 		for (int k = 0; k < hspCount; ++k) {
 			if ((int)(hsp_sf[k] >> 2) < bmin) continue;
@@ -611,7 +643,7 @@ __global__ __launch_bounds__(64) void search_pe_kernel(DevIndex X, urmapx_params
 	//   probe results staged for the seed enumeration (s_tal, s_pos)       on  the DP trace buffer (idle until AlignHSP)
 	//   flank run buffers, candidate path, target window (AlignHSP / Scan)  on  seed_res  (seeds are dead by then)
 	//   pending-stage row lengths and prefix                               on  seed_q
-	//   FindPairs' pair list                                               on  seed_db
+	//   the pending stage's candidate queue, then FindPairs' pair list      on  seed_db
 	__shared__ __attribute__((aligned(16))) uint8_t sQ[4][QMAX];
 	__shared__ __attribute__((aligned(16))) uint32_t tb[M::TB_ROWS8 * 64];
 	__shared__ uint16_t hit_nops[2][PE_HIT_CAP];
@@ -634,8 +666,10 @@ __global__ __launch_bounds__(64) void search_pe_kernel(DevIndex X, urmapx_params
 	static_assert(2 * QMAX + 66 * 2 <= sizeof(seed_q), "alias");
 	uint8_t *const rowlen = reinterpret_cast<uint8_t *>(&seed_q[0][0]);  // shared by the two mates: SearchPE_Pending runs on one mate at a time
 	uint16_t *const pre = reinterpret_cast<uint16_t *>(rowlen + 2 * QMAX);
-	static_assert(2 * PE_PAIR_CAP * 2 <= sizeof(seed_db), "alias");
+	static_assert(2 * PE_PAIR_CAP * 2 <= sizeof(seed_db) && 128 * 6 <= sizeof(seed_db), "alias");
 	uint16_t *const pair_f = reinterpret_cast<uint16_t *>(&seed_db[0][0]), *const pair_r = pair_f + PE_PAIR_CAP;
+	uint32_t *const cq_db = &seed_db[0][0];  // pending stage only: before FindPairs fills the pair list
+	uint16_t *const cq_qp = reinterpret_cast<uint16_t *>(cq_db + 128);
 
 	const int lane = threadIdx.x;
 	const int W = (int)X.W;
@@ -651,7 +685,7 @@ __global__ __launch_bounds__(64) void search_pe_kernel(DevIndex X, urmapx_params
 		m[a].hit_paths = reinterpret_cast<urmapx_path_op *>(sc) + (size_t)a * PE_HIT_CAP * URMAPX_MAX_PATH_OPS;
 		m[a].hsp_db = hsp_db[a]; m[a].hsp_ql = hsp_ql[a]; m[a].hsp_sf = hsp_sf[a];
 		m[a].pend[0] = pend[2 * a]; m[a].pend[1] = pend[2 * a + 1];
-		m[a].rowlen = rowlen; m[a].pre = pre;
+		m[a].rowlen = rowlen; m[a].pre = pre; m[a].cq_db = cq_db; m[a].cq_qp = cq_qp;
 		m[a].rowstore = reinterpret_cast<uint32_t *>(sc + pe_rowstore_offset(QMAX));
 		m[a].ws.carve(sc + (size_t)2 * PE_HIT_CAP * URMAPX_MAX_PATH_OPS * 2, QMAX, PE_SCAN_SEG + 2 * QMAX + 64);
 	}
