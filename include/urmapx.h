@@ -188,6 +188,25 @@ size_t urmapx_sam_pe(const urmapx_index *, const urmapx_result *r1, const urmapx
 /* @SQ lines of State1::WriteSAMHeader (state1.cpp:736-748); same return convention. */
 size_t urmapx_sam_header_sq(const urmapx_index *, char *buf, size_t cap);
 
+/* ---- paired-end summary (-tabbedout) ---- */
+/* What State2::OutputTab2 (outputtab2.cpp:85-120) reads beyond the two mates' results: each mate's m_TopHit as the
+ * pair stage left it (BEFORE SetMappedPos, which SetSAM2 applies only when SAM output is on) and m_SecondHit, which
+ * AdjustTopHitsAndMapqs sets from the second-best pair (search2.cpp:49-56).  UINT32_MAX = no such hit. */
+typedef struct urmapx_pair_info {
+	uint32_t top_db[2], second_db[2];
+	int16_t top_score[2], second_score[2];
+	uint8_t top_plus[2], second_plus[2];
+} urmapx_pair_info;
+/* on != 0: urmapx_map_pe / urmapx_map_pe_device also record one urmapx_pair_info per pair (device side) */
+int urmapx_ctx_set_pair_info(urmapx_ctx *, int on);
+/* copies the records of the last paired-end call (npairs of them) to the host */
+int urmapx_ctx_get_pair_info(urmapx_ctx *, urmapx_pair_info *out, uint32_t npairs);
+/* One line of the reference's -tabbedout file: pair label, top pair position(s), the two MAPQs, second pair or '*',
+ * and "TL=..;Score=..;" when all four hits exist.  sam_on: the reference's line differs when -samout is also given
+ * (a top hit overhanging its sequence has been cleared by then).  Returns the length written, 0 if cap is too small. */
+size_t urmapx_tab_pe(const urmapx_index *, const urmapx_result *r1, const urmapx_result *r2, const urmapx_pair_info *info,
+                     const char *label1, uint32_t len1, uint32_t len2, int sam_on, char *buf, size_t cap);
+
 /* ---- FASTQ input (host) ---- */
 /* Batch form of FASTQSeqSource::GetNextLo (fastqseqsource.cpp:9-116) over LineReader (linereader.cpp:14-113):
  * plain or .gz by suffix; '\r' dropped; a final unterminated line counts; blank lines only at end of file; the same

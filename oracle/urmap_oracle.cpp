@@ -1451,6 +1451,7 @@ struct PairSearcher {
 	std::vector<int> PairScore;
 	int BestPairScore = 0, SecondBestPairScore = 0;
 	unsigned BestPairIndex = 0, SecondPairIndex = UINT_MAX;
+	int SecondF = -1, SecondR = -1;  // m_SecondHit of each mate: set by AdjustTopHitsAndMapqs only (search2.cpp:49-56)
 	int TermPairScorePhase1 = 0;
 
 	PairSearcher(const uo_index *X, const uo_params &P) : F(X, P), R(X, P) {}
@@ -1529,6 +1530,7 @@ struct PairSearcher {
 		if (mapq > F.Mapq) F.Mapq = mapq;
 		if (mapq > R.Mapq) R.Mapq = mapq;
 		if (BestPairIndex != UINT_MAX) { F.TopHit = int(PairF[BestPairIndex]); R.TopHit = int(PairR[BestPairIndex]); }
+		if (SecondPairIndex != UINT_MAX) { SecondF = int(PairF[SecondPairIndex]); SecondR = int(PairR[SecondPairIndex]); }
 	}
 
 	// search2m4.cpp:15-187
@@ -1538,6 +1540,7 @@ struct PairSearcher {
 		F.InitPE(Seqf, Lf);
 		R.InitPE(Seqr, Lr);
 		BestPairScore = 0; SecondBestPairScore = 0; BestPairIndex = 0; SecondPairIndex = UINT_MAX;
+		SecondF = -1; SecondR = -1;  // InitPE, state1.cpp:119
 		PairF.clear(); PairR.clear(); PairScore.clear();
 		if (Lf < F.X->W || Lr < F.X->W) { F.Mapq = 0; R.Mapq = 0; return; }  // outside the reference's domain
 		const unsigned QL2 = (Lf + Lr) / 2;
@@ -1667,8 +1670,86 @@ static uint32_t PairedFlags(bool First, bool RevComp, bool MateRevComp, bool Mat
 	return f;
 }
 
+namespace {
+// UFIndex::PosToCoord (ufindex.cpp:701-727): UINT32_MAX, label untouched, when the position is in inter-sequence padding
+static uint32_t PosToCoordTab(const uo_index *X, uint32_t Pos, std::string &Label) {
+	const unsigned n = (unsigned)X->Labels.size();
+	unsigned Lo = 0, Hi = n - 1;
+	while (Lo <= Hi && Hi != UINT_MAX) {
+		unsigned k = (Lo + Hi) / 2;
+		uint32_t Off = X->Offsets[k], SL = X->SeqLengths[k];
+		if (Pos >= Off && Pos < Off + SL) { Label = X->Labels[k]; return Pos - Off; }
+		if (Pos > Off) Lo = k + 1;
+		else Hi = k - 1;
+	}
+	return UINT32_MAX;
+}
+static std::string PairPosStr1(const uo_index *X, const Hit &H, bool Fwd) {  // outputtab2.cpp:29-42
+	std::string L;
+	uint32_t c = PosToCoordTab(X, H.DBStartPos, L);
+	char b[64];
+	snprintf(b, sizeof b, ":%u(%c)/%c", c + 1, H.Plus ? '+' : '-', Fwd ? '1' : '2');
+	return L + b;
+}
+static std::string PairPosStr(const uo_index *X, const Hit *H1, const Hit *H2) {  // outputtab2.cpp:44-83
+	if (!H1 && !H2) return "*";
+	if (H1 && !H2) return PairPosStr1(X, *H1, true);
+	if (!H1 && H2) return PairPosStr1(X, *H2, false);
+	std::string L1, L2;
+	uint32_t c1 = PosToCoordTab(X, H1->DBStartPos, L1), c2 = PosToCoordTab(X, H2->DBStartPos, L2);
+	if (L1 == L2 && H1->Plus != H2->Plus) {
+		char b[64];
+		snprintf(b, sizeof b, ":%u-%u", c1 + 1, c2 + 1);
+		return L1 + b;
+	}
+	return PairPosStr1(X, *H1, true) + "," + PairPosStr1(X, *H2, false);
+}
+static unsigned TemplateLength(const PairSearcher &S, const Hit &H1, const Hit &H2) {  // output2.cpp:49-69
+	int t;
+	if (H1.DBStartPos <= H2.DBStartPos) t = int(H2.DBStartPos + S.R.QL) - int(H1.DBStartPos);
+	else t = int(H1.DBStartPos + S.F.QL) - int(H2.DBStartPos);
+	if (t < 0 || t > 1000) t = 0;
+	return unsigned(t);
+}
+// State2::OutputTab2 (outputtab2.cpp:85-120).  top1/top2: m_TopHit of the mates as they stand when the line is
+// written -- after SetSAM2's SetMappedPos when SAM output is on (output2.cpp:12-13,73-74), which clears a top hit that
+// overhangs its sequence.
+static std::string TabLine(const uo_index *X, const PairSearcher &S, const char *Label1, const Hit *top1, const Hit *top2) {
+	std::string out;
+	size_t n = strlen(Label1);  // GetPairLabel, state1.cpp:762-778
+	if (n > 2 && Label1[n - 2] == '/' && (Label1[n - 1] == '1' || Label1[n - 1] == '2')) n -= 2;
+	for (size_t i = 0; i < n && !isspace((unsigned char)Label1[i]); ++i) out.push_back(Label1[i]);
+	const Hit *s1 = S.SecondF >= 0 ? &S.F.Hits[S.SecondF] : nullptr, *s2 = S.SecondR >= 0 ? &S.R.Hits[S.SecondR] : nullptr;
+	out += "\t" + PairPosStr(X, top1, top2);
+	char b[96];
+	snprintf(b, sizeof b, "\t%u,%u\t", S.F.Mapq, S.R.Mapq);
+	out += b;
+	out += s1 ? PairPosStr(X, s1, s2) : std::string("*");
+	if (top1 && top2 && s1 && s2) {  // GetInfoStr, outputtab2.cpp:6-27 (Psasc appends ';' after every item)
+		unsigned tl1 = TemplateLength(S, *top1, *top2), tl2 = TemplateLength(S, *s1, *s2);
+		if (tl1 == tl2) snprintf(b, sizeof b, "\tTL=%u;", tl1);
+		else snprintf(b, sizeof b, "\tTL/%u,%u;", tl1, tl2);
+		out += b;
+		int sc1 = top1->Score + top2->Score, sc2 = s1->Score + s2->Score;
+		if (sc1 == sc2) snprintf(b, sizeof b, "Score=%d;", sc1);
+		else snprintf(b, sizeof b, "Score/%d,%d;", sc1, sc2);
+		out += b;
+	}
+	out.push_back('\n');
+	return out;
+}
+}  // namespace
+
+extern "C" int uo_map_file_pe_tab(const uo_index *X, const uo_params *Pin, const char *fq1, const char *fq2, const char *sam,
+                                  const char *tab, int threads, int veryfast, uo_counters *counters);
 extern "C" int uo_map_file_pe(const uo_index *X, const uo_params *Pin, const char *fq1, const char *fq2, const char *sam,
                               int threads, int veryfast, uo_counters *counters) {
+	return uo_map_file_pe_tab(X, Pin, fq1, fq2, sam, nullptr, threads, veryfast, counters);
+}
+
+// sam and/or tab may be NULL (no such output, as without -samout / -tabbedout)
+extern "C" int uo_map_file_pe_tab(const uo_index *X, const uo_params *Pin, const char *fq1, const char *fq2, const char *sam,
+                                  const char *tab, int threads, int veryfast, uo_counters *counters) {
 	uo_params Pv = *Pin;
 	if (veryfast) Pv.band_radius = 4;  // map2.cpp:17-21
 	const uo_params *P = &Pv;
@@ -1679,7 +1760,7 @@ extern "C" int uo_map_file_pe(const uo_index *X, const uo_params *Pin, const cha
 	if (rc) return rc;
 	if (R1.size() != R2.size()) return -4;
 	const int64_t n = (int64_t)R1.size();
-	std::vector<std::string> Out((size_t)n);
+	std::vector<std::string> Out((size_t)n), OutTab(tab ? (size_t)n : 0);
 	if (threads < 1) threads = 1;
 	if (counters) memset(counters, 0, sizeof *counters);
 #pragma omp parallel num_threads(threads)
@@ -1694,6 +1775,12 @@ extern "C" int uo_map_file_pe(const uo_index *X, const uo_params *Pin, const cha
 			MateOut M1, M2;
 			MateMapped(S.F, M1);
 			MateMapped(S.R, M2);
+			if (tab) {
+				// with SAM output on, SetMappedPos has already cleared overhanging top hits when the tab line is written
+				const Hit *t1 = S.F.TopHit >= 0 && (!sam || M1.Mapped) ? &S.F.Hits[S.F.TopHit] : nullptr;
+				const Hit *t2 = S.R.TopHit >= 0 && (!sam || M2.Mapped) ? &S.R.Hits[S.R.TopHit] : nullptr;
+				OutTab[(size_t)i] = TabLine(X, S, A.Label.c_str(), t1, t2);
+			}
 			int TLEN1 = 0, TLEN2 = 0;
 			const bool Plus1 = M1.HasHit && M1.Plus, Plus2 = M2.HasHit && M2.Plus;
 			const bool StrandsConsistent = M1.HasHit && M2.HasHit && (Plus1 != Plus2);
@@ -1728,11 +1815,19 @@ extern "C" int uo_map_file_pe(const uo_index *X, const uo_params *Pin, const cha
 #pragma omp critical
 		{ AddCounters(counters, S.F.C); AddCounters(counters, S.R.C); }
 	}
-	FILE *f = fopen(sam, "wb");
-	if (!f) return -3;
-	WriteSQ(f, X);
-	for (int64_t i = 0; i < n; ++i) fwrite(Out[(size_t)i].data(), 1, Out[(size_t)i].size(), f);
-	fclose(f);
+	if (sam) {
+		FILE *f = fopen(sam, "wb");
+		if (!f) return -3;
+		WriteSQ(f, X);
+		for (int64_t i = 0; i < n; ++i) fwrite(Out[(size_t)i].data(), 1, Out[(size_t)i].size(), f);
+		fclose(f);
+	}
+	if (tab) {
+		FILE *f = fopen(tab, "wb");
+		if (!f) return -3;
+		for (int64_t i = 0; i < n; ++i) fwrite(OutTab[(size_t)i].data(), 1, OutTab[(size_t)i].size(), f);
+		fclose(f);
+	}
 	return 0;
 }
 

@@ -9,7 +9,9 @@ outputs are what the reference itself wrote:
   se250.fq/.sam   200 reads, 250 bp, 4 % sub, 1 % indel
   se_short.fq/.sam 100 reads of 24..60 bp
   reference `urmap -map X.fq -ufi g.ufi -samout X.sam -threads 1`; the @PG line is dropped.
-  pe150_1/2.fq, pe100_noisy_1/2.fq + .sam   300 pairs each, reference `urmap -map2 A_1.fq -reverse A_2.fq ...`
+  pe150_1/2.fq, pe100_noisy_1/2.fq + .sam + .tab   300 pairs each, reference `urmap -map2 A_1.fq -reverse A_2.fq ...
+                                                   -samout A.sam -tabbedout A.tab`
+  r.fa, r.ufi.gz, pe120_rep_*               repeat-rich second genome: pairs with a second-best pair (see make_repeat_set)
 
 Run only where /root/reference exists; the fixtures are data, the reference itself does not travel.
 """
@@ -40,6 +42,32 @@ def edge(reads, seed):
         lab, s, q = out[k]
         s = s.copy(); s[int(rng.integers(0, len(s)))] = ord("R"); out[k] = (lab + " extra words/1", s, q)
     return out
+
+
+def make_repeat_set(tmp):
+    """A second, repeat-rich genome (near-identical family copies) so that FindPairs sees several pairs per read pair:
+    the -tabbedout lines then carry a second pair and the TL/Score info string (outputtab2.cpp:6-27,98-102).
+    r.fa, r.ufi.gz, pe120_rep_1/2.fq, pe120_rep.sam (with -samout), pe120_rep.tab, pe120_rep_nosam.tab (without)."""
+    g = synth.make_genome(77, [30000, 30000], repeat_frac=0.6, n_families=4, max_div=0.03, label_prefix="rep")
+    synth.write_fasta(os.path.join(HERE, "r.fa"), g)
+    shutil.copy(os.path.join(HERE, "r.fa"), os.path.join(tmp, "r.fa"))
+    ol.run_ref(["-make_ufi", "r.fa", "-output", "r.ufi", "-slots", "100003"], cwd=tmp)
+    with open(os.path.join(tmp, "r.ufi"), "rb") as f, gzip.GzipFile(os.path.join(HERE, "r.ufi.gz"), "wb", mtime=0) as z:
+        z.write(f.read())
+    r1, r2 = synth.make_pairs(5, g, 400, read_len=120, sub1=0.02, sub2=0.04)
+    name = "pe120_rep"
+    synth.write_fastq(os.path.join(HERE, name + "_1.fq"), r1)
+    synth.write_fastq(os.path.join(HERE, name + "_2.fq"), r2)
+    for suf in ("_1.fq", "_2.fq"):
+        shutil.copy(os.path.join(HERE, name + suf), os.path.join(tmp, name + suf))
+    ol.run_ref(["-map2", name + "_1.fq", "-reverse", name + "_2.fq", "-ufi", "r.ufi", "-samout", name + ".sam",
+                "-tabbedout", name + ".tab", "-threads", "1"], cwd=tmp)
+    with open(os.path.join(HERE, name + ".sam"), "wb") as f:
+        f.write(b"\n".join(ol.sam_records(os.path.join(tmp, name + ".sam"))) + b"\n")
+    shutil.copy(os.path.join(tmp, name + ".tab"), os.path.join(HERE, name + ".tab"))
+    ol.run_ref(["-map2", name + "_1.fq", "-reverse", name + "_2.fq", "-ufi", "r.ufi", "-tabbedout", name + "_nosam.tab",
+                "-threads", "1"], cwd=tmp)
+    shutil.copy(os.path.join(tmp, name + "_nosam.tab"), os.path.join(HERE, name + "_nosam.tab"))
 
 
 def main():
@@ -86,9 +114,11 @@ def main():
         for suf in ("_1.fq", "_2.fq"):
             shutil.copy(os.path.join(HERE, name + suf), os.path.join(tmp, name + suf))
         ol.run_ref(["-map2", name + "_1.fq", "-reverse", name + "_2.fq", "-ufi", "g.ufi", "-samout", name + ".sam",
-                    "-threads", "1"], cwd=tmp)
+                    "-tabbedout", name + ".tab", "-threads", "1"], cwd=tmp)
         with open(os.path.join(HERE, name + ".sam"), "wb") as f:
             f.write(b"\n".join(ol.sam_records(os.path.join(tmp, name + ".sam"))) + b"\n")
+        shutil.copy(os.path.join(tmp, name + ".tab"), os.path.join(HERE, name + ".tab"))
+    make_repeat_set(tmp)
     shutil.rmtree(tmp)
     print("golden fixtures written to", HERE)
 

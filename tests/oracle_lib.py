@@ -96,6 +96,7 @@ def lib():
     L.uo_sam_se.argtypes = [vp, vp, cp, cp, vp, vp, u32, vp]
     L.uo_map_file_se.argtypes = [vp, C.POINTER(Params), cp, cp, C.c_int, C.POINTER(Counters)]
     L.uo_map_file_pe.argtypes = [vp, C.POINTER(Params), cp, cp, cp, C.c_int, C.c_int, C.POINTER(Counters)]
+    L.uo_map_file_pe_tab.argtypes = [vp, C.POINTER(Params), cp, cp, cp, cp, C.c_int, C.c_int, C.POINTER(Counters)]
     _lib = L
     return L
 
@@ -213,6 +214,16 @@ class Index:
         rc = lib().uo_map_file_se(self.h, C.byref(p), fastq.encode(), sam.encode(), threads, C.byref(cnt))
         if rc != 0:
             raise RuntimeError(f"uo_map_file_se rc={rc}")
+        return cnt.asdict()
+
+    def map_file_pe_tab(self, fq1, fq2, sam, tab, threads=1, veryfast=False):
+        """sam / tab may be None; tab gets State2::OutputTab2's lines."""
+        cnt = Counters()
+        p = params(6)
+        rc = lib().uo_map_file_pe_tab(self.h, C.byref(p), fq1.encode(), fq2.encode(), sam.encode() if sam else None,
+                                      tab.encode() if tab else None, threads, int(veryfast), C.byref(cnt))
+        if rc != 0:
+            raise RuntimeError(f"uo_map_file_pe_tab rc={rc}")
         return cnt.asdict()
 
     def map_file_pe(self, fq1, fq2, sam, threads=1, veryfast=False):

@@ -357,3 +357,55 @@ def test_gather_microbench_reports_a_rate(gpu):
     """The roofline denominator bench.py reports (random slot reads over the resident table) is measurable."""
     rate = gpu["mapper"].gather_microbench(1 << 22)
     assert rate > 1e8  # slot reads per second; a few 1e10 on MI355X
+
+
+@pytest.mark.parametrize("name,ufi_gz,with_sam", [("pe150", "g.ufi.gz", True), ("pe100_noisy", "g.ufi.gz", True),
+                                                  ("pe120_rep", "r.ufi.gz", True), ("pe120_rep", "r.ufi.gz", False)])
+def test_cli_map2_tabbedout_reproduces_reference(tmp_path, name, ufi_gz, with_sam):
+    """`urmap -map2 ... [-samout SAM] -tabbedout TAB`: State2::OutputTab2's line per pair (outputtab2.cpp:85-120) equal
+    to the reference's file byte for byte, incl. second pairs and the TL/Score info strings (pe120_rep)."""
+    import gzip
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gold = os.path.join(root, "tests", "golden")
+    exe = os.path.join(root, "urmap_amd", "urmap")
+    ufi = os.path.join(tmp_path, "x.ufi")
+    with gzip.open(os.path.join(gold, ufi_gz), "rb") as z, open(ufi, "wb") as f:
+        f.write(z.read())
+    sam, tab = os.path.join(tmp_path, "out.sam"), os.path.join(tmp_path, "out.tab")
+    cmd = [exe, "-map2", os.path.join(gold, name + "_1.fq"), "-reverse", os.path.join(gold, name + "_2.fq"), "-ufi", ufi,
+           "-tabbedout", tab, "-batch", "128"] + (["-samout", sam] if with_sam else [])
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    want = open(os.path.join(gold, name + (".tab" if with_sam else "_nosam.tab")), "rb").read()
+    got = open(tab, "rb").read()
+    if got != want:
+        g, w = got.split(b"\n"), want.split(b"\n")
+        bad = [i for i in range(min(len(g), len(w))) if g[i] != w[i]]
+        raise AssertionError(f"{len(bad)} differing lines of {len(w)}, first: {g[bad[0]]!r} vs {w[bad[0]]!r}")
+    if with_sam:
+        gots = [l for l in open(sam, "rb").read().split(b"\n") if l and not l.startswith(b"@PG")]
+        assert gots == [l for l in open(os.path.join(gold, name + ".sam"), "rb").read().split(b"\n") if l]
+
+
+def test_pair_info_through_the_library(tmp_path):
+    """urmapx_ctx_set_pair_info / urmapx_ctx_get_pair_info / urmapx_tab_pe through the ctypes binding."""
+    import gzip
+    import os
+    from urmap_amd import api
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gold = os.path.join(root, "tests", "golden")
+    ufi = os.path.join(tmp_path, "r.ufi")
+    with gzip.open(os.path.join(gold, "r.ufi.gz"), "rb") as z, open(ufi, "wb") as f:
+        f.write(z.read())
+    idx = api.Index.open(ufi).upload(0)
+    m = api.Mapper(idx, device=0, method=6)
+    m.set_pair_info(True)
+    labels, bases, offs, quals = api.interleave_pairs(api.read_fastq_arrays(os.path.join(gold, "pe120_rep_1.fq")),
+                                                      api.read_fastq_arrays(os.path.join(gold, "pe120_rep_2.fq")))
+    res, ops = m.map_pe(bases, offs)
+    info = m.pair_info(len(res) // 2)
+    assert (info["second_db"][:, 0] != 0xFFFFFFFF).sum() > 20  # this fixture has second pairs
+    assert idx.tab_pe(res, info, labels, offs, sam_on=True) == open(os.path.join(gold, "pe120_rep.tab"), "rb").read()
+    assert idx.tab_pe(res, info, labels, offs, sam_on=False) == open(os.path.join(gold, "pe120_rep_nosam.tab"), "rb").read()

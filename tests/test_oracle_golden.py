@@ -101,3 +101,22 @@ def test_oracle_equals_reference_binary(tmp_path, seed, glen, n, rl, sub, indel)
         body = [x for x in read_records(path) if not x.startswith(b"@")]
         return sorted(body[i] + b"|" + body[i + 1] for i in range(0, len(body), 2))
     assert pairs(os.path.join(d, "refpe.sam")) == pairs(os.path.join(d, "ope.sam"))
+
+
+@pytest.mark.parametrize("name,ufi_gz,with_sam", [("pe150", "g.ufi.gz", True), ("pe100_noisy", "g.ufi.gz", True),
+                                                  ("pe120_rep", "r.ufi.gz", True), ("pe120_rep", "r.ufi.gz", False)])
+def test_oracle_tabbedout_equals_reference_golden(tmp_path, name, ufi_gz, with_sam):
+    """State2::OutputTab2 (outputtab2.cpp:85-120) restated: every line of the reference's -tabbedout file, incl. the
+    second pair and the TL/Score info string (pe120_rep), with and without SAM output switched on."""
+    ufi = os.path.join(tmp_path, "x.ufi")
+    with gzip.open(os.path.join(GOLD, ufi_gz), "rb") as z, open(ufi, "wb") as f:
+        f.write(z.read())
+    idx = ol.Index.load(ufi)
+    tab = os.path.join(tmp_path, "o.tab")
+    idx.map_file_pe_tab(os.path.join(GOLD, name + "_1.fq"), os.path.join(GOLD, name + "_2.fq"),
+                        os.path.join(tmp_path, "o.sam") if with_sam else None, tab, threads=2)
+    want = open(os.path.join(GOLD, name + (".tab" if with_sam else "_nosam.tab")), "rb").read()
+    assert open(tab, "rb").read() == want
+    if with_sam:
+        assert ol.sam_records(os.path.join(tmp_path, "o.sam")) == \
+            [l for l in open(os.path.join(GOLD, name + ".sam"), "rb").read().split(b"\n") if l]

@@ -32,8 +32,13 @@ EXPORTS = (
     "urmapx_seed_probe", "urmapx_viterbi_batch", "urmapx_strerror", "urmapx_device_arch",
     "urmapx_make_ufi", "urmapx_build_slots", "urmapx_sam_se", "urmapx_sam_header_sq", "urmapx_ctx_phase_cycles", "urmapx_map_pe", "urmapx_sam_pe", "urmapx_map_pe_device", "urmapx_ctx_set_pe_veryfast",
     "urmapx_fastq_open", "urmapx_fastq_next", "urmapx_fastq_error", "urmapx_fastq_close",
-    "urmapx_ctx_gather_microbench",
+    "urmapx_ctx_gather_microbench", "urmapx_ctx_set_pair_info", "urmapx_ctx_get_pair_info", "urmapx_tab_pe",
 )
+
+
+PAIR_INFO_DTYPE = np.dtype([("top_db", "<u4", 2), ("second_db", "<u4", 2), ("top_score", "<i2", 2), ("second_score", "<i2", 2),
+                            ("top_plus", "u1", 2), ("second_plus", "u1", 2)])
+assert PAIR_INFO_DTYPE.itemsize == 28
 
 
 class Params(C.Structure):
@@ -106,6 +111,10 @@ def lib():
     L.urmapx_device_arch.restype = cp
     L.urmapx_device_arch.argtypes = [vp]
     L.urmapx_ctx_gather_microbench.argtypes = [vp, u64, C.POINTER(C.c_double)]
+    L.urmapx_ctx_set_pair_info.argtypes = [vp, i32]
+    L.urmapx_ctx_get_pair_info.argtypes = [vp, vp, u32]
+    L.urmapx_tab_pe.restype = C.c_size_t
+    L.urmapx_tab_pe.argtypes = [vp, vp, vp, vp, cp, u32, u32, i32, vp, C.c_size_t]
     L.urmapx_fastq_open.argtypes = [cp, C.POINTER(vp)]
     L.urmapx_fastq_next.restype = C.c_int64
     L.urmapx_fastq_next.argtypes = [vp, u32] + [C.POINTER(vp)] * 5
@@ -229,6 +238,20 @@ class Index:
             out.append(buf.raw[:n])
         return b"".join(out)
 
+    def tab_pe(self, res, info, labels, offs, sam_on=True):
+        """-tabbedout lines (State2::OutputTab2) for pairs interleaved as in map_pe; labels = per read."""
+        L = lib()
+        out = []
+        buf = C.create_string_buffer(4096)
+        res = np.ascontiguousarray(res)
+        info = np.ascontiguousarray(info)
+        for i in range(len(info)):
+            l1 = int(offs[2 * i + 1] - offs[2 * i]); l2 = int(offs[2 * i + 2] - offs[2 * i + 1])
+            k = L.urmapx_tab_pe(self.h, res[2 * i:].ctypes.data, res[2 * i + 1:].ctypes.data, info[i:].ctypes.data,
+                                labels[2 * i].encode("latin-1"), l1, l2, int(sam_on), buf, len(buf))
+            out.append(buf.raw[:k])
+        return b"".join(out)
+
     def sam_pe(self, results: np.ndarray, ops: np.ndarray, labels, bases: np.ndarray, offs: np.ndarray,
                quals: np.ndarray) -> bytes:
         """SAM records of mapped PAIRS (reads 2i, 2i+1 = mates of pair i): State2::SetSAM2 + SetSAM."""
@@ -332,6 +355,15 @@ class Mapper:
         ms = (C.c_float * 2)()
         _check(lib().urmapx_ctx_last_kernel_ms(self.h, C.byref(ms)), "urmapx_ctx_last_kernel_ms")
         return float(ms[0]), float(ms[1])
+
+    def set_pair_info(self, on=True):
+        _check(lib().urmapx_ctx_set_pair_info(self.h, int(on)), "urmapx_ctx_set_pair_info")
+
+    def pair_info(self, npairs):
+        """urmapx_pair_info records of the last paired-end call (needs set_pair_info(True) before it)."""
+        out = np.zeros(npairs, dtype=PAIR_INFO_DTYPE)
+        _check(lib().urmapx_ctx_get_pair_info(self.h, out.ctypes.data, npairs), "urmapx_ctx_get_pair_info")
+        return out
 
     def gather_microbench(self, n_loads=1 << 28):
         """Random 5-byte slot reads per second over the resident slot table (measurement aid)."""

@@ -57,7 +57,7 @@ int search_pe_block_count(uint32_t max_read_len, int device);
 hipError_t launch_search_pe(const DevIndex &X, const urmapx_params &P, const uint8_t *d_bases, const uint64_t *d_offs,
                             uint32_t npairs, uint32_t max_read_len, ProbeOut probe, urmapx_result *d_results,
                             urmapx_path_op *d_path_ops, uint32_t *d_path_used, const SearchWork &wk, int veryfast,
-                            hipStream_t s);
+                            urmapx_pair_info *pair_info, hipStream_t s);
 
 hipError_t launch_viterbi_batch(const urmapx_params &P, const uint8_t *d_a, const uint32_t *d_aoffs,
                                 const uint8_t *d_b, const uint32_t *d_boffs, const uint8_t *d_flags, uint32_t n,

@@ -636,7 +636,7 @@ __global__ __launch_bounds__(64) void search_pe_kernel(DevIndex X, urmapx_params
                                                        urmapx_path_op *__restrict__ path_ops, uint32_t *path_used,
                                                        uint8_t *scratch, size_t scratch_stride,
                                                        const uint8_t *__restrict__ g_seq, const uint8_t *__restrict__ g_blob,
-                                                       int veryfast, uint32_t *ticket) {
+                                                       int veryfast, uint32_t *ticket, urmapx_pair_info *pair_info) {
 	using M = Mate<NCH>;
 	constexpr int QMAX = M::QMAX;
 	// LDS per block decides how many pairs a CU keeps in flight, so arrays share memory by lifetime:
@@ -932,7 +932,8 @@ __global__ __launch_bounds__(64) void search_pe_kernel(DevIndex X, urmapx_params
 				}
 			}
 		}
-		int npairs_found = 0, bestPairScore = -1, secondPairScore = -1, bestPairIndex = -1;
+		int npairs_found = 0, bestPairScore = -1, secondPairScore = -1, bestPairIndex = -1, secondPairIndex = -1;
+		int secondHit[2] = {-1, -1};  // m_SecondHit of the mates (set by AdjustTopHitsAndMapqs only)
 		if (dbg_stop == 2) done = true;
 		if (!done) {
 			// all collected seeds, each mate (search2m4.cpp:145-158)
@@ -965,7 +966,7 @@ __global__ __launch_bounds__(64) void search_pe_kernel(DevIndex X, urmapx_params
 			if (dbg_stop == 4) goto pe_output;
 			// FindPairs (state2.cpp:20-85), ScanPair if there is none (state2.cpp:87-137), FindPairs again
 			for (int attempt = 0; attempt < 2; ++attempt) {
-				npairs_found = 0; bestPairScore = -1; secondPairScore = -1; bestPairIndex = -1;
+				npairs_found = 0; bestPairScore = -1; secondPairScore = -1; bestPairIndex = -1; secondPairIndex = -1;
 				for (int i = 0; i < m[0].hitCount; ++i) {
 					const uint32_t spf = rdlane(m[0].hit_sp, i);
 					const int sf = (int)(spf >> 1);
@@ -980,9 +981,11 @@ __global__ __launch_bounds__(64) void search_pe_kernel(DevIndex X, urmapx_params
 						if (d + QL2 > 1000) continue;
 						if ((spf & 1u) == (spr & 1u)) continue;
 						const int total = sf + sr;
-						if (total > bestPairScore) { secondPairScore = bestPairScore; bestPairScore = total; bestPairIndex = npairs_found; }
-						else if (total == bestPairScore) secondPairScore = bestPairScore;
-						else if (total > secondPairScore) secondPairScore = total;
+						if (total > bestPairScore) {
+							secondPairIndex = bestPairIndex; secondPairScore = bestPairScore;
+							bestPairScore = total; bestPairIndex = npairs_found;
+						} else if (total == bestPairScore) { secondPairIndex = npairs_found; secondPairScore = bestPairScore; }
+						else if (total > secondPairScore) { secondPairIndex = bestPairIndex; secondPairScore = total; }  // sic, state2.cpp:74
 						if (npairs_found < PE_PAIR_CAP) {
 							if (lane == 0) { pair_f[npairs_found] = (uint16_t)i; pair_r[npairs_found] = (uint16_t)j; }
 						} else
@@ -1023,10 +1026,27 @@ __global__ __launch_bounds__(64) void search_pe_kernel(DevIndex X, urmapx_params
 				if (mq > m[0].mapq) m[0].mapq = mq;
 				if (mq > m[1].mapq) m[1].mapq = mq;
 				if (bestPairIndex >= 0 && bestPairIndex < PE_PAIR_CAP) { m[0].topHit = pair_f[bestPairIndex]; m[1].topHit = pair_r[bestPairIndex]; }
+				if (secondPairIndex >= 0 && secondPairIndex < PE_PAIR_CAP) { secondHit[0] = pair_f[secondPairIndex]; secondHit[1] = pair_r[secondPairIndex]; }
 			}
 		}
 
 	pe_output:
+		if (pair_info) {  // what State2::OutputTab2 needs beyond the two results (outputtab2.cpp:85-120)
+			urmapx_pair_info pi;
+			for (int a = 0; a < 2; ++a) {
+				pi.top_db[a] = 0xFFFFFFFFu; pi.second_db[a] = 0xFFFFFFFFu;
+				pi.top_score[a] = 0; pi.second_score[a] = 0; pi.top_plus[a] = 0; pi.second_plus[a] = 0;
+				if (m[a].topHit >= 0) {
+					const uint32_t sp = rdlane(m[a].hit_sp, m[a].topHit);
+					pi.top_db[a] = rdlane(m[a].hit_db, m[a].topHit); pi.top_score[a] = (int16_t)(sp >> 1); pi.top_plus[a] = (uint8_t)(sp & 1u);
+				}
+				if (secondHit[a] >= 0) {
+					const uint32_t sp = rdlane(m[a].hit_sp, secondHit[a]);
+					pi.second_db[a] = rdlane(m[a].hit_db, secondHit[a]); pi.second_score[a] = (int16_t)(sp >> 1); pi.second_plus[a] = (uint8_t)(sp & 1u);
+				}
+			}
+			if (lane == 0) pair_info[pr] = pi;
+		}
 		// ---- per-mate output: SetMappedPos (state1.cpp:129-145) ----
 		for (int a = 0; a < 2; ++a) {
 			urmapx_result &R = res[a];
@@ -1085,7 +1105,7 @@ int search_pe_block_count(uint32_t max_read_len, int device) {
 hipError_t launch_search_pe(const DevIndex &X, const urmapx_params &P, const uint8_t *d_bases, const uint64_t *d_offs,
                             uint32_t npairs, uint32_t max_read_len, ProbeOut probe, urmapx_result *d_results,
                             urmapx_path_op *d_path_ops, uint32_t *d_path_used, const SearchWork &wk, int veryfast,
-                            hipStream_t s) {
+                            urmapx_pair_info *pair_info, hipStream_t s) {
 	if (npairs == 0) return hipSuccess;
 	{
 		hipError_t e = hipMemsetAsync(wk.ticket, 0, 4, s);
@@ -1094,10 +1114,10 @@ hipError_t launch_search_pe(const DevIndex &X, const urmapx_params &P, const uin
 	dim3 block(64), grid((unsigned)wk.blocks);
 	if (pe_nch_for(max_read_len) == 3)
 		hipLaunchKernelGGL(search_pe_kernel<3>, grid, block, 0, s, X, P, d_bases, d_offs, npairs, probe, d_results, d_path_ops,
-		                   d_path_used, wk.scratch, wk.scratch_stride, X.seq, X.blob, veryfast, wk.ticket);
+		                   d_path_used, wk.scratch, wk.scratch_stride, X.seq, X.blob, veryfast, wk.ticket, pair_info);
 	else
 		hipLaunchKernelGGL(search_pe_kernel<5>, grid, block, 0, s, X, P, d_bases, d_offs, npairs, probe, d_results, d_path_ops,
-		                   d_path_used, wk.scratch, wk.scratch_stride, X.seq, X.blob, veryfast, wk.ticket);
+		                   d_path_used, wk.scratch, wk.scratch_stride, X.seq, X.blob, veryfast, wk.ticket, pair_info);
 	return hipGetLastError();
 }
 

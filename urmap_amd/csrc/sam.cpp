@@ -412,6 +412,105 @@ extern "C" size_t urmapx_sam_se(const urmapx_index *I, const urmapx_result *r, c
 	return out.size();
 }
 
+// ---------------- -tabbedout (State2::OutputTab2, outputtab2.cpp:85-120) ----------------
+namespace {
+using urx::append_int;
+using urx::append_uint;
+struct TabHit { bool has; uint32_t db; bool plus; int score; };
+// UFIndex::PosToCoord (ufindex.cpp:701-727): UINT32_MAX and an empty label when the position is in the padding
+uint32_t pos_to_coord_tab(const urmapx_index *I, uint32_t pos, const char **label) {
+	const uint32_t n = urmapx_index_seq_count(I);
+	*label = "";
+	uint32_t lo = 0, hi = n - 1;
+	while (lo <= hi && hi != 0xFFFFFFFFu) {
+		const uint32_t k = (lo + hi) / 2;
+		const uint32_t off = urmapx_index_seq_offset(I, k), sl = urmapx_index_seq_length(I, k);
+		if (pos >= off && pos < off + sl) { *label = urmapx_index_label(I, k); return pos - off; }
+		if (pos > off) lo = k + 1;
+		else hi = k - 1;
+	}
+	return 0xFFFFFFFFu;
+}
+void pair_pos_str1(std::string &out, const urmapx_index *I, const TabHit &h, bool fwd) {  // outputtab2.cpp:29-42
+	const char *lab;
+	const uint32_t c = pos_to_coord_tab(I, h.db, &lab);
+	out += lab;
+	out.push_back(':');
+	append_uint(out, (uint32_t)(c + 1));
+	out.push_back('(');
+	out.push_back(h.plus ? '+' : '-');
+	out += fwd ? ")/1" : ")/2";
+}
+void pair_pos_str(std::string &out, const urmapx_index *I, const TabHit &h1, const TabHit &h2) {  // outputtab2.cpp:44-83
+	if (!h1.has && !h2.has) { out.push_back('*'); return; }
+	if (h1.has && !h2.has) { pair_pos_str1(out, I, h1, true); return; }
+	if (!h1.has && h2.has) { pair_pos_str1(out, I, h2, false); return; }
+	const char *l1, *l2;
+	const uint32_t c1 = pos_to_coord_tab(I, h1.db, &l1), c2 = pos_to_coord_tab(I, h2.db, &l2);
+	if (strcmp(l1, l2) == 0 && h1.plus != h2.plus) {
+		out += l1;
+		out.push_back(':');
+		append_uint(out, (uint32_t)(c1 + 1));
+		out.push_back('-');
+		append_uint(out, (uint32_t)(c2 + 1));
+		return;
+	}
+	pair_pos_str1(out, I, h1, true);
+	out.push_back(',');
+	pair_pos_str1(out, I, h2, false);
+}
+unsigned template_length(const TabHit &h1, const TabHit &h2, uint32_t len1, uint32_t len2) {  // output2.cpp:49-69
+	int t;
+	if (h1.db <= h2.db) t = (int)(h2.db + len2) - (int)h1.db;
+	else t = (int)(h1.db + len1) - (int)h2.db;
+	if (t < 0 || t > 1000) t = 0;
+	return (unsigned)t;
+}
+}  // namespace
+
+extern "C" size_t urmapx_tab_pe(const urmapx_index *I, const urmapx_result *r1, const urmapx_result *r2,
+                                const urmapx_pair_info *info, const char *label1, uint32_t len1, uint32_t len2, int sam_on,
+                                char *buf, size_t cap) {
+	if (!I || !r1 || !r2 || !info || !label1 || !buf) return 0;
+	const urmapx_result *r[2] = {r1, r2};
+	TabHit top[2], sec[2];
+	for (int a = 0; a < 2; ++a) {
+		// with SAM output on, SetSAM2's SetMappedPos has cleared a top hit that overhangs its sequence (output2.cpp:73-74)
+		top[a].has = info->top_db[a] != 0xFFFFFFFFu && (!sam_on || r[a]->dbpos != 0xFFFFFFFFu);
+		top[a].db = info->top_db[a]; top[a].plus = info->top_plus[a] != 0; top[a].score = info->top_score[a];
+		sec[a].has = info->second_db[a] != 0xFFFFFFFFu;
+		sec[a].db = info->second_db[a]; sec[a].plus = info->second_plus[a] != 0; sec[a].score = info->second_score[a];
+	}
+	std::string out;
+	size_t n = strlen(label1);  // GetPairLabel, state1.cpp:762-778
+	if (n > 2 && label1[n - 2] == '/' && (label1[n - 1] == '1' || label1[n - 1] == '2')) n -= 2;
+	for (size_t i = 0; i < n && !isspace((unsigned char)label1[i]); ++i) out.push_back(label1[i]);
+	out.push_back('\t');
+	pair_pos_str(out, I, top[0], top[1]);
+	out.push_back('\t');
+	append_uint(out, r1->mapq);
+	out.push_back(',');
+	append_uint(out, r2->mapq);
+	out.push_back('\t');
+	if (sec[0].has) pair_pos_str(out, I, sec[0], sec[1]);
+	else out.push_back('*');
+	if (top[0].has && top[1].has && sec[0].has && sec[1].has) {  // GetInfoStr, outputtab2.cpp:6-27
+		const unsigned tl1 = template_length(top[0], top[1], len1, len2), tl2 = template_length(sec[0], sec[1], len1, len2);
+		out += tl1 == tl2 ? "\tTL=" : "\tTL/";
+		append_uint(out, tl1);
+		if (tl1 != tl2) { out.push_back(','); append_uint(out, tl2); }
+		const int s1 = top[0].score + top[1].score, s2 = sec[0].score + sec[1].score;
+		out += s1 == s2 ? ";Score=" : ";Score/";
+		append_int(out, s1);
+		if (s1 != s2) { out.push_back(','); append_int(out, s2); }
+		out.push_back(';');
+	}
+	out.push_back('\n');
+	if (out.size() > cap) return 0;
+	memcpy(buf, out.data(), out.size());
+	return out.size();
+}
+
 struct urmapx_fastq {
 	urx::FastqReader rd;
 	urx::FastqBatch batch;

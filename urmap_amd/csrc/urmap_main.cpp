@@ -4,7 +4,7 @@
 //   urmap -map reads.fq[.gz] -ufi index.ufi -samout out.sam [-veryfast] [-threads N] [-gpu D] [-batch N]
 //   urmap -make_ufi genome.fa -output index.ufi [-slots N] [-wordlength W] [-maxix M] [-veryfast]
 //
-//   urmap -map2 R1.fq -reverse R2.fq -ufi index.ufi -samout out.sam            (paired-end, map2.cpp:39-90)
+//   urmap -map2 R1.fq -reverse R2.fq -ufi index.ufi -samout out.sam [-tabbedout out.tab]   (paired-end, map2.cpp:39-90)
 //
 // Pipeline of -map: one reader thread parses FASTQ into batches, the main thread maps batch k on the GPU while
 // a writer thread formats and writes the SAM of batch k-1.  Records are written in input order (the reference's
@@ -45,7 +45,7 @@ using namespace urx;
 }
 
 struct Opts {
-	std::string map, map2, reverse, make_ufi, ufi, samout, output;
+	std::string map, map2, reverse, make_ufi, ufi, samout, tabbedout, output;
 	bool veryfast = false, quiet = false;
 	unsigned threads = 0, wordlength = 24, maxix = 0, minq = 10;
 	unsigned long long slots = 0;
@@ -68,6 +68,7 @@ static Opts parse(int argc, char **argv) {
 		else if (a == "-make_ufi") o.make_ufi = val();
 		else if (a == "-ufi") o.ufi = val();
 		else if (a == "-samout") o.samout = val();
+		else if (a == "-tabbedout") o.tabbedout = val();
 		else if (a == "-output") o.output = val();
 		else if (a == "-threads") o.threads = (unsigned)atoi(val());
 		else if (a == "-wordlength") o.wordlength = (unsigned)atoi(val());
@@ -92,6 +93,7 @@ struct Job {
 	FastqBatch reads;
 	std::vector<urmapx_result> results;
 	std::vector<urmapx_path_op> ops;
+	std::vector<urmapx_pair_info> info;  // -tabbedout
 };
 
 template <class T>
@@ -166,6 +168,13 @@ static int cmd_map(const Opts &o, int argc, char **argv) {
 		append_sam_header(hdr, I, argc, argv);
 		if (write(fsam, hdr.data(), hdr.size()) != (ssize_t)hdr.size()) die("Cannot write %s", o.samout.c_str());
 		sam_off = hdr.size();
+	}
+	// -tabbedout (outfiles.cpp:7-12): State2::OutputTab2's line per pair; only -map2 writes it
+	FILE *ftab = nullptr;
+	if (!o.tabbedout.empty()) {
+		ftab = fopen(o.tabbedout.c_str(), "wb");
+		if (!ftab) die("Cannot create %s", o.tabbedout.c_str());
+		if (paired) check(urmapx_ctx_set_pair_info(C, 1), "pair info");
 	}
 	FastqReader rd, rd2;
 	std::string err;
@@ -269,6 +278,17 @@ static int cmd_map(const Opts &o, int argc, char **argv) {
 					}
 				}
 			}
+			if (ftab && paired) {
+				std::string tabs;
+				char line[4096];
+				for (uint32_t i = 0; i + 1 < n; i += 2) {
+					const unsigned L1 = (unsigned)(j->reads.offs[i + 1] - j->reads.offs[i]), L2 = (unsigned)(j->reads.offs[i + 2] - j->reads.offs[i + 1]);
+					const size_t k = urmapx_tab_pe(I, &j->results[i], &j->results[i + 1], &j->info[i / 2], j->reads.label(i), L1, L2,
+					                               fsam >= 0 ? 1 : 0, line, sizeof line);
+					tabs.append(line, k);
+				}
+				if (fwrite(tabs.data(), 1, tabs.size(), ftab) != tabs.size()) write_failed = true;
+			}
 			t_write += secs(tf1, now());
 			recycled.push(std::move(j));
 		}
@@ -285,6 +305,10 @@ static int cmd_map(const Opts &o, int argc, char **argv) {
 		                : urmapx_map_se(C, j->reads.bases.data(), j->reads.offs.data(), n, j->results.data(), j->ops.data(),
 		                                j->ops.size(), &used);
 		check(rc, paired ? "urmapx_map_pe" : "urmapx_map_se");
+		if (paired && ftab) {
+			j->info.resize(n / 2);
+			check(urmapx_ctx_get_pair_info(C, j->info.data(), n / 2), "urmapx_ctx_get_pair_info");
+		}
 		t_gpu += secs(tg0, now());
 		mapped.push(std::move(j));
 	}
@@ -293,6 +317,7 @@ static int cmd_map(const Opts &o, int argc, char **argv) {
 	writer.join();
 	if (!reader_err.empty()) die("%s", reader_err.c_str());
 	if (fsam >= 0) close(fsam);
+	if (ftab) fclose(ftab);
 	if (write_failed) die("Error writing %s", o.samout.c_str());
 	const auto t2 = std::chrono::steady_clock::now();
 	const double load_s = std::chrono::duration<double>(t1 - t0).count();
@@ -370,7 +395,7 @@ int main(int argc, char **argv) {
 	if (!o.map.empty() || !o.map2.empty()) return cmd_map(o, argc, argv);
 	if (!o.make_ufi.empty()) return cmd_make_ufi(o);
 	fprintf(stderr, "urmap (MI355X build)\n  urmap -map reads.fq -ufi index.ufi -samout out.sam [-veryfast] [-gpu D]\n"
-	                "  urmap -map2 R1.fq -reverse R2.fq -ufi index.ufi -samout out.sam [-gpu D]\n"
+	                "  urmap -map2 R1.fq -reverse R2.fq -ufi index.ufi -samout out.sam [-tabbedout out.tab] [-gpu D]\n"
 	                "  urmap -make_ufi genome.fa -output index.ufi [-slots N] [-wordlength W] [-maxix M]\n");
 	return 0;
 }

@@ -98,6 +98,9 @@ struct urmapx_ctx {
 	DevBuf<uint32_t> statsbuf;
 	DevBuf<uint8_t> pe_scratch;
 	int pe_veryfast = 0;  // State2::m_Method 5
+	int pair_info_on = 0;  // -tabbedout: record urmapx_pair_info per pair
+	DevBuf<urmapx_pair_info> pairinfo;
+	uint32_t pairinfo_n = 0;
 	int pe_blocks[2] = {0, 0};
 	int blocks[2] = {0, 0};  // persistent grid size of the search kernel for read length classes <=192, <=320
 };
@@ -275,7 +278,7 @@ void urmapx_ctx_destroy(urmapx_ctx *C) {
 	C->bases.release(); C->tallies.release(); C->vflags.release(); C->vstatus.release(); C->va.release(); C->vb.release();
 	C->offs.release(); C->slots.release(); C->positions.release(); C->used.release(); C->vaoffs.release(); C->vboffs.release();
 	C->results.release(); C->pathops.release(); C->vops.release(); C->vscores.release(); C->vnops.release();
-	C->scratch.release(); C->vscratch.release(); C->statsbuf.release(); C->pe_scratch.release();
+	C->scratch.release(); C->vscratch.release(); C->statsbuf.release(); C->pe_scratch.release(); C->pairinfo.release();
 	for (int i = 0; i < 3; ++i)
 		if (C->ev[i]) (void)hipEventDestroy(C->ev[i]);
 	if (C->stream) (void)hipStreamDestroy(C->stream);
@@ -394,6 +397,20 @@ int urmapx_map_se(urmapx_ctx *C, const uint8_t *bases, const uint64_t *offs, uin
 	return URMAPX_OK;
 }
 
+int urmapx_ctx_set_pair_info(urmapx_ctx *C, int on) {
+	if (!C) return URMAPX_E_ARG;
+	C->pair_info_on = on ? 1 : 0;
+	return URMAPX_OK;
+}
+
+int urmapx_ctx_get_pair_info(urmapx_ctx *C, urmapx_pair_info *out, uint32_t npairs) {
+	if (!C || !out || npairs > C->pairinfo_n || !C->pairinfo.p) return URMAPX_E_ARG;
+	HIP_TRY(hipSetDevice(C->device));
+	HIP_TRY(hipStreamSynchronize(C->stream));
+	HIP_TRY(hipMemcpy(out, C->pairinfo.p, (size_t)npairs * sizeof(urmapx_pair_info), hipMemcpyDeviceToHost));
+	return URMAPX_OK;
+}
+
 // cmd_map2's `-veryfast`: State2::m_Method = 5 (Search5, search2m5.cpp) with band radius 4 (map2.cpp:47-49,17-21)
 int urmapx_ctx_set_pe_veryfast(urmapx_ctx *C, int on) {
 	if (!C) return URMAPX_E_ARG;
@@ -430,9 +447,15 @@ int urmapx_map_pe_device(urmapx_ctx *C, const void *d_bases, const void *d_offs,
 	HIP_TRY(hipEventRecord(C->ev[1], C->stream));
 	urmapx_params Ppe = C->params;
 	if (C->pe_veryfast) Ppe.band_radius = 4;  // map2.cpp:17-21
+	urmapx_pair_info *d_info = nullptr;
+	if (C->pair_info_on) {
+		if ((rc = C->pairinfo.ensure(npairs))) return rc;
+		d_info = C->pairinfo.p;
+		C->pairinfo_n = npairs;
+	}
 	HIP_TRY(launch_search_pe(C->X, Ppe, (const uint8_t *)d_bases, (const uint64_t *)d_offs, npairs, max_read_len, po,
 	                         (urmapx_result *)d_results, (urmapx_path_op *)d_path_ops, (uint32_t *)d_path_used, wk,
-	                         C->pe_veryfast | (getenv("URMAPX_DEBUG_STOP_PE") ? atoi(getenv("URMAPX_DEBUG_STOP_PE")) << 8 : 0), C->stream));  // bits 8..: diagnostic schedule cut
+	                         C->pe_veryfast | (getenv("URMAPX_DEBUG_STOP_PE") ? atoi(getenv("URMAPX_DEBUG_STOP_PE")) << 8 : 0), d_info, C->stream));  // bits 8..: diagnostic schedule cut
 	HIP_TRY(hipEventRecord(C->ev[2], C->stream));
 	C->ev_valid = true;
 	return URMAPX_OK;
