@@ -21,6 +21,7 @@ namespace urx {
 static constexpr int PE_HIT_CAP = 64;
 static constexpr int PE_HSP_CAP = 128;
 static constexpr int PE_PAIR_CAP = 256;
+static constexpr int PE_TICKET_CHUNK = 2;
 static constexpr int PE_ROW_CAP = 32;   // UFIndex m_MaxIx of every index this build accepts
 static constexpr int PE_SCAN_SEG = 1024;  // SCAN_DB_SEG_LENGTH, state2.cpp:92
 static constexpr uint32_t PRIME_STRIDE = 27, SCANK = 4;
@@ -690,9 +691,16 @@ __global__ __launch_bounds__(64) void search_pe_kernel(DevIndex X, urmapx_params
 		m[a].ws.carve(sc + (size_t)2 * PE_HIT_CAP * URMAPX_MAX_PATH_OPS * 2, QMAX, PE_SCAN_SEG + 2 * QMAX + 64);
 	}
 
-	for (;;) {  // pairs are handed out by a ticket counter (heavy-tailed cost per pair: the rescue DP), see search_se_kernel
-		const uint32_t pr = uni(atomicAdd(ticket, lane == 0 ? 1u : 0u));
-		if (pr >= npairs) break;
+	// pairs are handed out by a ticket counter (heavy-tailed cost per pair: the rescue DP), PE_TICKET_CHUNK per ticket
+	// (same-address atomics retire at ~88 M/s), see search_se_kernel
+	uint32_t pr_next = 0, pr_end = 0;
+	for (;;) {
+		if (pr_next == pr_end) {
+			pr_next = uni(atomicAdd(ticket, lane == 0 ? (uint32_t)PE_TICKET_CHUNK : 0u));
+			if (pr_next >= npairs) break;
+			pr_end = pr_next + PE_TICKET_CHUNK < npairs ? pr_next + PE_TICKET_CHUNK : npairs;
+		}
+		const uint32_t pr = pr_next++;
 		urmapx_result res[2];
 		bool bad = false;
 		for (int a = 0; a < 2; ++a) {
