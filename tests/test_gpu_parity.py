@@ -283,7 +283,8 @@ def test_pe_reproduces_reference_golden_sam(tmp_path, name):
         raise AssertionError(f"{len(bad)} differing records, first: {g[bad[0]][:160]!r} vs {w[bad[0]][:160]!r}")
 
 
-@pytest.mark.parametrize("rl,s1,s2,indel,n", [(150, 0.01, 0.02, 0.001, 3000), (120, 0.04, 0.08, 0.01, 2000)])
+@pytest.mark.parametrize("rl,s1,s2,indel,n", [(150, 0.01, 0.02, 0.001, 3000), (120, 0.04, 0.08, 0.01, 2000),
+                                                (250, 0.02, 0.04, 0.005, 800)])  # 250: the 320-base kernel class
 def test_pe_matches_oracle(small_case, tmp_path, rl, s1, s2, indel, n):
     """Fresh pairs on the 300 kbp genome (incl. one-mate-random pairs that go through ScanPair): SAM of the device
     path == SAM of the oracle's Search4 restatement."""
