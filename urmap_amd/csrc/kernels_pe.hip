@@ -569,19 +569,28 @@ struct Mate {
 			qslot[k] = uni64(pslots[(size_t)s * QL + qposk[k]]);
 		}
 		const uint64_t wmask = X->shiftMask;
+		const uint64_t wbits = (W >= 32) ? 0xFFFFFFFFull : ((1ull << W) - 1ull);
+		// Letter planes of 64 window positions as three ballots (low bit, high bit, not-ACGT), as in seed_probe_kernel:
+		// lane p cuts the W bits of its k-mer out of two adjacent plane words, so a chunk costs one byte load per lane.
+		auto planes = [&](uint32_t start, uint64_t &lo, uint64_t &hi, uint64_t &inv) {
+			const uint32_t q = start + lane;
+			uint32_t L = 4;
+			if (q < seglen) L = letter_of(gseq[dblo + q]);
+			lo = __ballot(L & 1u); hi = __ballot((L >> 1) & 1u); inv = __ballot(L > 3u);
+		};
+		uint64_t lo0, hi0, inv0, lo1, hi1, inv1;
+		planes(0, lo0, hi0, inv0);
 		// lane handles window start positions base+lane; a k-mer is valid iff its W letters are all ACGT
 		for (uint32_t base = 0; base + (uint32_t)W <= seglen; base += 64) {
+			planes(base + 64, lo1, hi1, inv1);
 			const uint32_t p = base + lane;
-			uint64_t word = 0;
-			bool valid = p + (uint32_t)W <= seglen;
-			if (valid) {
-				const uint8_t *t = gseq + dblo + p;
-				for (int i = 0; i < W; ++i) {
-					const uint32_t L = letter_of(t[i]);
-					if (L > 3u) valid = false;
-					word = (word << 2) | (L & 3u);
-				}
-			}
+			uint64_t flo = lo0 >> lane, fhi = hi0 >> lane, finv = inv0 >> lane;
+			if (lane) { flo |= lo1 << (64 - lane); fhi |= hi1 << (64 - lane); finv |= inv1 << (64 - lane); }
+			flo &= wbits; fhi &= wbits; finv &= wbits;
+			const bool valid = p + (uint32_t)W <= seglen && finv == 0;
+			// first base = most significant letter
+			const uint64_t word = spread32(__brevll(flo) >> (64 - W)) | (spread32(__brevll(fhi) >> (64 - W)) << 1);
+			lo0 = lo1; hi0 = hi1; inv0 = inv1;
 			uint64_t slot = ~0ull;
 			if (valid) slot = mod_slots(murmur64(word & wmask), X->slotCount, X->slotMagic);
 			uint32_t hitmask = 0;
