@@ -739,6 +739,9 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 					} else {
 						const int sp = rdlane(e_start, t), ep = rdlane(e_end, t);
 						S.add_hsp((uint32_t)sp, dblo + (uint32_t)sp, pl, (uint32_t)(ep - sp + 1), bst);
+						// whatever AddHSPX did, the HSP on this diagonal now scores >= bst (or bst < best - 4): a later HSP
+						// candidate on the same diagonal with a score <= bst changes nothing (state1.cpp:555,563-571)
+						todo &= ~__ballot(e_kind == 2 && my_dblo == dblo && e_bst <= bst);
 					}
 					if (S.hitCount != hc0 || S.maxPen != mp0 || S.best != b0)
 						todo &= __ballot(e_pen <= S.maxPen && !(e_kind == 2 && e_bst < S.best - 4) &&

@@ -483,6 +483,7 @@ struct Mate {
 					else {
 						const uint32_t sp = (uint32_t)rdlane(e_sp, t), ep = (uint32_t)rdlane(e_ep, t);
 						add_hsp(sp, d + sp, pl, ep - sp + 1, bst);
+						todo &= ~__ballot(e_kind == 2 && dblo == d && e_bst <= bst);  // see search_se_kernel
 					}
 					if (hitCount != hc0 || maxPen != mp0 || best != b0)
 						todo &= __ballot(e_pen <= maxPen && !(e_kind == 2 && e_bst < best - 4) &&
