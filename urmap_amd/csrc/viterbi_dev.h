@@ -73,7 +73,11 @@ __device__ float viterbi_wide(const VPar P, const uint8_t *A, int LA, const uint
 
 // ws.la_cap == 0: no wide-band scratch (the band must fit one wavefront).
 __device__ __forceinline__ float viterbi_wave(const VPar P, const uint8_t *A, int LA, const uint8_t *B, int LB, bool Left, bool Right,
-                              uint32_t *tb, int tb_rows8, const WideScratch ws, RevOps &R, uint32_t &status, int lane) {
+                              uint32_t *tb, int tb_rows8, const WideScratch ws, RevOps &R, uint32_t &status, int lane_in) {
+	// the lane index is recomputed here (two mbcnt) instead of using the caller's: that one is live through the whole
+	// search kernel, gets spilled in its register-hungry parts, and was then reloaded from scratch in every DP row
+	(void)lane_in;
+	const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
 	R.begin();
 	const float GO = (float)P.gap_open_score, GE = (float)P.gap_ext_score;
 	if (LA == 0 || LB == 0) {
