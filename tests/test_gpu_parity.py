@@ -410,3 +410,38 @@ def test_pair_info_through_the_library(tmp_path):
     assert (info["second_db"][:, 0] != 0xFFFFFFFF).sum() > 20  # this fixture has second pairs
     assert idx.tab_pe(res, info, labels, offs, sam_on=True) == open(os.path.join(gold, "pe120_rep.tab"), "rb").read()
     assert idx.tab_pe(res, info, labels, offs, sam_on=False) == open(os.path.join(gold, "pe120_rep_nosam.tab"), "rb").read()
+
+
+def test_hsp_overflow_list_matches_oracle(tmp_path):
+    """Reads in a high-copy repeat family collect more HSPs than fit LDS; the rest go to the block's global scratch
+    (the reference's list is unbounded, state1.cpp:193-228).  With the LDS share lowered to 64 by the test aid, reads
+    with up to ~180 HSPs run through that path: SAM must still equal the oracle's."""
+    import os
+    import subprocess
+    import oracle_lib as ol
+    from urmap_amd import synth
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "urmap_amd", "urmap")
+    g = synth.make_genome(9, [600_000], repeat_frac=0.85, n_families=2, max_div=0.12, n_run_frac=0.0)
+    fa, ufi, fq = (os.path.join(tmp_path, x) for x in ("g.fa", "g.ufi", "r.fq"))
+    synth.write_fasta(fa, g)
+    idx = ol.Index.build(fa, 1_000_003)
+    idx.save(ufi)
+    reads = synth.make_reads(3, g, 3000, read_len=150, sub=0.02)
+    synth.write_fastq(fq, reads)
+    b = np.concatenate([r[1] for r in reads])
+    o = np.zeros(len(reads) + 1, dtype=np.uint64)
+    o[1:] = np.cumsum([len(r[1]) for r in reads])
+    res, _, _ = idx.map_se(b, o, threads=4)
+    assert (res["hsp_count"] > 64).sum() > 50, "fixture no longer exercises the overflow list"
+    osam = os.path.join(tmp_path, "o.sam")
+    idx.map_file_se(fq, osam, threads=4)
+    for cap in ("64", None):
+        env = dict(os.environ)
+        if cap:
+            env["URMAPX_TEST_HSP_LDS_CAP"] = cap
+        out = os.path.join(tmp_path, f"gpu_{cap}.sam")
+        r = subprocess.run([exe, "-map", fq, "-ufi", ufi, "-samout", out], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                           timeout=300, env=env)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        assert ol.sam_records(out) == ol.sam_records(osam), f"LDS cap {cap}"

@@ -42,8 +42,11 @@ struct SearchWork {
 	size_t scratch_stride;  // search_scratch_stride(max_read_len)
 	int blocks;             // search_block_count(max_read_len, device)
 	uint32_t *ticket;       // device word: work counter of the launch (zeroed by the launcher)
+	int hsp_lds_cap = 0;    // 0 = default; test aid (URMAPX_TEST_HSP_LDS_CAP) to exercise the HSP overflow list
+	uint32_t *ovf_list = nullptr;  // device: [0] = count, [1..n] = reads queued for the second pass
 };
 size_t search_scratch_stride(uint32_t max_read_len);
+size_t search_scratch_tail();
 int search_block_count(uint32_t max_read_len, int device);
 size_t viterbi_batch_scratch_stride();
 

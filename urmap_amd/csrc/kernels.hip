@@ -148,11 +148,45 @@ __global__ __launch_bounds__(64) void viterbi_batch_kernel(urmapx_params P, cons
 //   consume  (order dependent, wave-uniform): the candidates' bit vectors are read back lane by lane and run
 //            through ExtendPen's x-drop / penalty logic, AddHitX / AddHSPX, early exits -- exactly in order.
 // ------------------------------------------------------------------------------------------------
-static constexpr int HSP_CAP = 256;
+static constexpr int HSP_CAP = 256;        // HSPs of a read held in LDS
+static constexpr int SEARCH_OVF_BLOCKS = 256;  // grid of the second pass (reads whose HSP list outgrew LDS)
+static constexpr int HSP_TOTAL_CAP = 8192;  // beyond that: in the block's global scratch (the reference's list is unbounded;
+                                            // 8192 > 2 strands x 127 k-mers x MaxIx 32 candidate diagonals of a 150 bp read)
 static constexpr int TICKET_CHUNK = 4;
 static constexpr int ROW_CAP = 32;  // UFIndex m_MaxIx of every index this build accepts
 
-template <int NCH>
+// per-block global scratch: chain rows, the wide-band DP trace, then the HSP overflow list
+__host__ __device__ inline size_t hsp_ovf_offset(int nch) {
+	const int qmax = 64 * nch;
+	size_t b = (size_t)2 * nch * ROW_CAP * 64 * 4 + WideScratch::bytes(qmax, qmax + 64);
+	return (b + 15) & ~(size_t)15;
+}
+
+// AddHSPX over the part of a read's HSP list that lives in global scratch (reads in high-copy repeats only).  Kept out
+// of line so that its registers do not count against the search loop's.  0: same diagonal found (entry updated if the
+// score is higher), 1: appended at index n, 2: list full.
+__device__ __noinline__ int hsp_overflow_add(uint2 *ovf, int n, int cap, uint32_t diag, uint32_t startdb, uint32_t npk, int score) {
+	const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+	for (int base = 0; base < n; base += 64) {
+		const int i = base + lane;
+		bool eq = false;
+		uint2 e = make_uint2(0u, 0u);
+		if (i < n) { e = ovf[i]; eq = (e.x - (e.y & 511u)) == diag; }
+		const uint64_t m = __ballot(eq);
+		if (m) {
+			const int l = __builtin_ctzll(m);
+			const int old = (int)((rdlane(e.y, l) >> 18) & 511u);
+			if (score > old && lane == 0) ovf[base + l] = make_uint2(startdb, npk);
+			__syncthreads();
+			return 0;
+		}
+	}
+	if (n >= cap) return 2;
+	if (lane == 0) ovf[n] = make_uint2(startdb, npk);
+	return 1;
+}
+
+template <int NCH, bool OVF>
 struct SearchWave {
 	static constexpr int QMAX = 64 * NCH;
 	// rows of the narrow DP's trace buffer: a flank is at most QMAX - W long (the HSP holds the seed), longer problems
@@ -175,6 +209,8 @@ struct SearchWave {
 	uint16_t *pre;   // exclusive prefix of candidate counts, NSEG*64+1 entries
 	uint32_t *hsp_db;
 	uint32_t *hsp_pk;  // startq | len << 9 | score << 18 | aligned << 27 | plus << 28 (all <= 320: 9 bits each)
+	uint2 *hsp_ovf;    // global scratch of this block: HSPs hsp_lds.. as {db, pk} (reads in high-copy repeats only)
+	int hsp_lds;       // HSPs kept in LDS: HSP_CAP (a test aid lowers it to exercise the overflow path)
 	// global scratch of this block
 	uint32_t *rowstore;  // [strand][chunk][k][lane]
 	WideScratch ws;
@@ -227,25 +263,33 @@ struct SearchWave {
 	__device__ __forceinline__ void add_hsp(uint32_t startq, uint32_t startdb, bool plus, uint32_t len, int score) {
 		if (score < best - 4) return;
 		const uint32_t diag = startdb - startq;
-		for (int base = 0; base < hspCount; base += 64) {
+		const uint32_t npk = startq | (len << 9) | ((uint32_t)score << 18) | (plus ? 1u << 28 : 0u);
+		const int nlds = hspCount < hsp_lds ? hspCount : hsp_lds;
+		for (int base = 0; base < nlds; base += 64) {  // the HSPs in LDS (all of them, except for reads in high-copy repeats)
 			const int i = base + lane;
 			bool eq = false;
-			if (i < hspCount) eq = (hsp_db[i] - (hsp_pk[i] & 511u)) == diag;
+			if (i < nlds) eq = (hsp_db[i] - (hsp_pk[i] & 511u)) == diag;
 			uint64_t m = __ballot(eq);
 			if (m) {
 				const int k = base + __builtin_ctzll(m);
 				const int old = (int)((hsp_pk[k] >> 18) & 511u);
-				if (score > old && lane == 0) {
-					hsp_db[k] = startdb; hsp_pk[k] = startq | (len << 9) | ((uint32_t)score << 18) | (plus ? 1u << 28 : 0u);
-				}
+				if (score > old && lane == 0) { hsp_db[k] = startdb; hsp_pk[k] = npk; }
 				__syncthreads();
 				return;
 			}
 		}
-		if (hspCount >= HSP_CAP) { status |= URMAPX_ST_HSP_OVERFLOW; return; }
-		if (lane == 0) {
-			hsp_db[hspCount] = startdb;
-			hsp_pk[hspCount] = startq | (len << 9) | ((uint32_t)score << 18) | (plus ? 1u << 28 : 0u);
+		if (hspCount >= hsp_lds) {
+			// The LDS share of the list is full (a read in a high-copy repeat).  The first-pass kernel (OVF = false) only
+			// flags the read, which is then mapped again by the OVF = true instance, whose list continues in global
+			// scratch -- so the common kernel carries none of that code.
+			if constexpr (!OVF) { status |= URMAPX_ST_HSP_OVERFLOW; return; }
+			else {
+				const int rc = hsp_overflow_add(hsp_ovf, hspCount - hsp_lds, HSP_TOTAL_CAP - HSP_CAP, diag, startdb, npk, score);
+				if (rc == 0) return;
+				if (rc == 2) { status |= URMAPX_ST_HSP_OVERFLOW; return; }
+			}
+		} else if (lane == 0) {
+			hsp_db[hspCount] = startdb; hsp_pk[hspCount] = npk;
 		}
 		__syncthreads();
 		++hspCount;
@@ -266,12 +310,16 @@ struct SearchWave {
 
 	// alignhsp.cpp:60-172
 	__device__ void align_hsp(int k) {
-		const uint32_t pk = hsp_pk[k];
+		uint32_t startdb, pk;
+		if (!OVF || k < hsp_lds) { startdb = hsp_db[k]; pk = hsp_pk[k]; }
+		else { const uint2 e = hsp_ovf[k - hsp_lds]; startdb = e.x; pk = e.y; }
 		if (pk & (1u << 27)) return;  // m_Aligned
 		__syncthreads();
-		if (lane == 0) hsp_pk[k] = pk | (1u << 27);
+		if (lane == 0) {
+			if (!OVF || k < hsp_lds) hsp_pk[k] = pk | (1u << 27);
+			else hsp_ovf[k - hsp_lds].y = pk | (1u << 27);
+		}
 		const int startq = (int)(pk & 511u), len = (int)((pk >> 9) & 511u);
-		const uint32_t startdb = hsp_db[k];
 		const int hscore = (int)((pk >> 18) & 511u);
 		const bool plus = (pk >> 28) & 1u;
 		__syncthreads();
@@ -460,16 +508,16 @@ struct SearchWave {
 #define SEARCH_WAVES_NCH3 4
 #endif
 #define SEARCH_WAVES_PER_EU(NCH) ((NCH) <= 3 ? SEARCH_WAVES_NCH3 : 2)
-template <int NCH>
+template <int NCH, bool OVF>
 __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel(DevIndex X, urmapx_params P, const uint8_t *__restrict__ bases,
                                                        const uint64_t *__restrict__ offs, uint32_t n, ProbeOut probe,
                                                        urmapx_result *__restrict__ results,
                                                        urmapx_path_op *__restrict__ path_ops, uint32_t *path_used,
                                                        uint32_t *stats, uint8_t *scratch, size_t scratch_stride,
                                                        const uint8_t *__restrict__ g_seq, const uint8_t *__restrict__ g_blob,
-                                                       uint32_t *ticket) {
+                                                       uint32_t *ticket, int hsp_lds_cap, uint32_t *ovf_list, uint2 *hsp_ovf_base) {
 	// stats != nullptr (URMAPX_PHASE_STATS): per-phase shader cycles are accumulated into stats (u64 each, from byte 8)
-	using SW = SearchWave<NCH>;
+	using SW = SearchWave<NCH, OVF>;
 	__shared__ __attribute__((aligned(16))) uint8_t sQ2[2 * SW::QMAX];  // plus strand, then reverse complement
 	uint8_t *const sQp = sQ2, *const sQm = sQ2 + SW::QMAX;
 	const uint8_t *__restrict__ const seq = g_seq;
@@ -502,6 +550,8 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 		uint8_t *sc = scratch + (size_t)blockIdx.x * scratch_stride;
 		S.rowstore = reinterpret_cast<uint32_t *>(sc);
 		S.ws.carve(sc + (size_t)SW::NSEG * ROW_CAP * 64 * 4, SW::QMAX, SW::WIDE_LB);
+		S.hsp_ovf = OVF ? hsp_ovf_base + (size_t)blockIdx.x * (HSP_TOTAL_CAP - HSP_CAP) : nullptr;
+		S.hsp_lds = (hsp_lds_cap >= 64 && hsp_lds_cap <= HSP_CAP) ? (hsp_lds_cap & ~63) : HSP_CAP;  // multiple of 64
 	}
 
 	// Reads are handed out by a ticket counter, not by a fixed stride: the cost of a read is heavy-tailed (a read in a
@@ -509,6 +559,7 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 	// finish long after the rest.
 	// TICKET_CHUNK reads per ticket: same-address atomics retire at ~88 M/s on this device (a bare ticket loop over 1 M
 	// reads takes 11.4 ms), which would cap the kernel not far above its current rate.
+	if constexpr (OVF) n = ovf_list[0];  // how many reads the first pass flagged (usually none)
 	uint32_t r_next = 0, r_end = 0;
 	for (;;) {
 		if (r_next == r_end) {
@@ -518,7 +569,8 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 			if (r_next >= n) break;
 			r_end = r_next + TICKET_CHUNK < n ? r_next + TICKET_CHUNK : n;
 		}
-		const uint32_t r = r_next++;
+		uint32_t r = r_next++;
+		if constexpr (OVF) r = ovf_list[1 + r];  // second pass: the reads the first pass flagged
 		const uint64_t off = offs[r];
 		const int QL = (int)(offs[r + 1] - off);
 
@@ -785,6 +837,11 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 		}
 		lapc(7);
 		}  // !badlen
+		if constexpr (!OVF) {
+			if (res.status & URMAPX_ST_HSP_OVERFLOW) {  // queue the read for the second pass
+				if (lane == 0) ovf_list[1 + atomicAdd(ovf_list, 1u)] = r;
+			}
+		}
 		if (lane == 0) results[r] = res;
 	}
 }
@@ -800,18 +857,18 @@ static int nch_for(uint32_t max_read_len) {
 
 size_t search_scratch_stride(uint32_t max_read_len) {
 	const int nch = nch_for(max_read_len);
-	const int qmax = 64 * nch;
-	size_t b = (size_t)2 * nch * ROW_CAP * 64 * 4 + WideScratch::bytes(qmax, qmax + 64);
-	return (b + 255) & ~(size_t)255;
+	return (hsp_ovf_offset(nch) + 255) & ~(size_t)255;
 }
+// behind the strided per-block areas: the HSP overflow lists of the second pass's blocks
+size_t search_scratch_tail() { return (size_t)SEARCH_OVF_BLOCKS * (HSP_TOTAL_CAP - HSP_CAP) * sizeof(uint2); }
 
 int search_block_count(uint32_t max_read_len, int device) {
 	hipDeviceProp_t prop;
 	if (hipGetDeviceProperties(&prop, device) != hipSuccess) return 0;
 	int per_cu = 0;
 	hipError_t e = nch_for(max_read_len) == 3
-	                   ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, search_se_kernel<3>, 64, 0)
-	                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, search_se_kernel<5>, 64, 0);
+	                   ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, search_se_kernel<3, false>, 64, 0)
+	                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, search_se_kernel<5, false>, 64, 0);
 	if (e != hipSuccess || per_cu < 1) per_cu = 8;
 	return per_cu * prop.multiProcessorCount;
 }
@@ -867,13 +924,37 @@ hipError_t launch_search_se(const DevIndex &X, const urmapx_params &P, const uin
 		hipError_t e = hipMemsetAsync(wk.stats + 2, 0, 184, s);
 		if (e != hipSuccess) return e;
 	}
+	{
+		hipError_t e = hipMemsetAsync(wk.ovf_list, 0, 4, s);
+		if (e != hipSuccess) return e;
+	}
 	dim3 block(64), grid((unsigned)wk.blocks);
 	if (nch == 3)
-		hipLaunchKernelGGL(search_se_kernel<3>, grid, block, 0, s, X, P, d_bases, d_offs, n, probe, d_results, d_path_ops,
-		                   d_path_used, wk.stats, wk.scratch, wk.scratch_stride, X.seq, X.blob, wk.ticket);
+		hipLaunchKernelGGL((search_se_kernel<3, false>), grid, block, 0, s, X, P, d_bases, d_offs, n, probe, d_results, d_path_ops,
+		                   d_path_used, wk.stats, wk.scratch, wk.scratch_stride, X.seq, X.blob, wk.ticket, wk.hsp_lds_cap,
+		                   wk.ovf_list, (uint2 *)nullptr);
 	else
-		hipLaunchKernelGGL(search_se_kernel<5>, grid, block, 0, s, X, P, d_bases, d_offs, n, probe, d_results, d_path_ops,
-		                   d_path_used, wk.stats, wk.scratch, wk.scratch_stride, X.seq, X.blob, wk.ticket);
+		hipLaunchKernelGGL((search_se_kernel<5, false>), grid, block, 0, s, X, P, d_bases, d_offs, n, probe, d_results, d_path_ops,
+		                   d_path_used, wk.stats, wk.scratch, wk.scratch_stride, X.seq, X.blob, wk.ticket, wk.hsp_lds_cap,
+		                   wk.ovf_list, (uint2 *)nullptr);
+	{
+		hipError_t e = hipGetLastError();
+		if (e != hipSuccess) return e;
+		e = hipMemsetAsync(wk.ticket, 0, 4, s);
+		if (e != hipSuccess) return e;
+	}
+	// second pass over the reads whose HSP list outgrew LDS (none for almost every batch: the blocks read a zero count
+	// and leave); it runs the same search with the list continued in global scratch
+	dim3 grid2((unsigned)(wk.blocks < SEARCH_OVF_BLOCKS ? wk.blocks : SEARCH_OVF_BLOCKS));
+	uint2 *ovf_base = reinterpret_cast<uint2 *>(wk.scratch + (size_t)wk.blocks * wk.scratch_stride);
+	if (nch == 3)
+		hipLaunchKernelGGL((search_se_kernel<3, true>), grid2, block, 0, s, X, P, d_bases, d_offs, n, probe, d_results, d_path_ops,
+		                   d_path_used, (uint32_t *)nullptr, wk.scratch, wk.scratch_stride, X.seq, X.blob, wk.ticket, wk.hsp_lds_cap,
+		                   wk.ovf_list, ovf_base);
+	else
+		hipLaunchKernelGGL((search_se_kernel<5, true>), grid2, block, 0, s, X, P, d_bases, d_offs, n, probe, d_results, d_path_ops,
+		                   d_path_used, (uint32_t *)nullptr, wk.scratch, wk.scratch_stride, X.seq, X.blob, wk.ticket, wk.hsp_lds_cap,
+		                   wk.ovf_list, ovf_base);
 	return hipGetLastError();
 }
 

@@ -100,6 +100,7 @@ struct urmapx_ctx {
 	int pe_veryfast = 0;  // State2::m_Method 5
 	int pair_info_on = 0;  // -tabbedout: record urmapx_pair_info per pair
 	DevBuf<urmapx_pair_info> pairinfo;
+	DevBuf<uint32_t> ovflist;  // reads queued for the search kernel's second pass
 	uint32_t pairinfo_n = 0;
 	int pe_blocks[2] = {0, 0};
 	int blocks[2] = {0, 0};  // persistent grid size of the search kernel for read length classes <=192, <=320
@@ -278,7 +279,7 @@ void urmapx_ctx_destroy(urmapx_ctx *C) {
 	C->bases.release(); C->tallies.release(); C->vflags.release(); C->vstatus.release(); C->va.release(); C->vb.release();
 	C->offs.release(); C->slots.release(); C->positions.release(); C->used.release(); C->vaoffs.release(); C->vboffs.release();
 	C->results.release(); C->pathops.release(); C->vops.release(); C->vscores.release(); C->vnops.release();
-	C->scratch.release(); C->vscratch.release(); C->statsbuf.release(); C->pe_scratch.release(); C->pairinfo.release();
+	C->scratch.release(); C->vscratch.release(); C->statsbuf.release(); C->pe_scratch.release(); C->pairinfo.release(); C->ovflist.release();
 	for (int i = 0; i < 3; ++i)
 		if (C->ev[i]) (void)hipEventDestroy(C->ev[i]);
 	if (C->stream) (void)hipStreamDestroy(C->stream);
@@ -336,10 +337,13 @@ int urmapx_map_se_device(urmapx_ctx *C, const void *d_bases, const void *d_offs,
 	SearchWork wk;
 	wk.blocks = C->blocks[cls];
 	wk.scratch_stride = search_scratch_stride(max_read_len);
-	if ((rc = C->scratch.ensure(wk.scratch_stride * (size_t)wk.blocks))) return rc;
+	if ((rc = C->scratch.ensure(wk.scratch_stride * (size_t)wk.blocks + search_scratch_tail()))) return rc;
+	if ((rc = C->ovflist.ensure((size_t)n + 1))) return rc;
+	wk.ovf_list = C->ovflist.p;
 	if ((rc = C->statsbuf.ensure(64))) return rc;
 	wk.scratch = C->scratch.p;
 	wk.ticket = C->statsbuf.p + 62;  // words 62/63 of the diagnostics buffer are never touched by the stamps
+	if (const char *e = getenv("URMAPX_TEST_HSP_LDS_CAP")) wk.hsp_lds_cap = atoi(e);
 	// diagnostics: URMAPX_PHASE_STATS = per-phase cycle counters; URMAPX_DEBUG_STOP=N = cut the schedule after step N
 	// (results are then NOT the reference's).  Words 0/1 of the buffer: stop step, "no timing" flag.
 	const char *ds = getenv("URMAPX_DEBUG_STOP");
