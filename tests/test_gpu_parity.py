@@ -445,3 +445,38 @@ def test_hsp_overflow_list_matches_oracle(tmp_path):
                            timeout=300, env=env)
         assert r.returncode == 0, r.stderr.decode()[-2000:]
         assert ol.sam_records(out) == ol.sam_records(osam), f"LDS cap {cap}"
+
+
+def test_pe_hsp_overflow_list_matches_oracle(tmp_path):
+    """Paired-end twin of test_hsp_overflow_list_matches_oracle: mates in a high-copy repeat family, LDS share of the
+    HSP lists lowered to 64, pairs re-mapped by the second-pass kernel with the lists continued in global scratch."""
+    import os
+    import subprocess
+    import oracle_lib as ol
+    from urmap_amd import synth
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "urmap_amd", "urmap")
+    g = synth.make_genome(9, [600_000], repeat_frac=0.85, n_families=2, max_div=0.12, n_run_frac=0.0)
+    fa, ufi, f1, f2 = (os.path.join(tmp_path, x) for x in ("g.fa", "g.ufi", "r1.fq", "r2.fq"))
+    synth.write_fasta(fa, g)
+    idx = ol.Index.build(fa, 1_000_003)
+    idx.save(ufi)
+    r1, r2 = synth.make_pairs(4, g, 1500, read_len=150, sub1=0.02, sub2=0.03)
+    synth.write_fastq(f1, r1)
+    synth.write_fastq(f2, r2)
+    b = np.concatenate([x[1] for pair in zip(r1, r2) for x in pair])
+    o = np.zeros(2 * len(r1) + 1, dtype=np.uint64)
+    o[1:] = np.cumsum([len(x[1]) for pair in zip(r1, r2) for x in pair])
+    res, _, _ = idx.map_pe(b, o, threads=4)
+    assert (res["hsp_count"] > 64).sum() > 20, "fixture no longer exercises the overflow list"
+    osam = os.path.join(tmp_path, "o.sam")
+    idx.map_file_pe(f1, f2, osam, threads=4)
+    for cap in ("64", None):
+        env = dict(os.environ)
+        if cap:
+            env["URMAPX_TEST_HSP_LDS_CAP"] = cap
+        out = os.path.join(tmp_path, f"gpu_{cap}.sam")
+        r = subprocess.run([exe, "-map2", f1, "-reverse", f2, "-ufi", ufi, "-samout", out], stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, timeout=300, env=env)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        assert ol.sam_records(out) == ol.sam_records(osam), f"LDS cap {cap}"

@@ -47,6 +47,7 @@ struct SearchWork {
 };
 size_t search_scratch_stride(uint32_t max_read_len);
 size_t search_scratch_tail();
+size_t search_pe_scratch_tail();
 int search_block_count(uint32_t max_read_len, int device);
 size_t viterbi_batch_scratch_stride();
 

@@ -19,7 +19,9 @@
 namespace urx {
 
 static constexpr int PE_HIT_CAP = 64;
-static constexpr int PE_HSP_CAP = 128;
+static constexpr int PE_HSP_CAP = 128;       // HSPs of a mate held in LDS
+static constexpr int PE_HSP_OVF_CAP = 8064;  // per mate, in global scratch, second pass only
+static constexpr int PE_OVF_BLOCKS = 128;    // grid of the second pass
 static constexpr int PE_PAIR_CAP = 256;
 static constexpr int PE_TICKET_CHUNK = 2;
 static constexpr int PE_ROW_CAP = 32;   // UFIndex m_MaxIx of every index this build accepts
@@ -33,7 +35,7 @@ __host__ __device__ inline size_t pe_rowstore_offset(int qmax) {
 	return (b + 15) & ~(size_t)15;
 }
 
-template <int NCH>
+template <int NCH, bool OVF>
 struct Mate {
 	static constexpr int QMAX = 64 * NCH;
 	static constexpr int TB_ROWS8 = QMAX / 8 + 2;
@@ -62,6 +64,8 @@ struct Mate {
 	urmapx_path_op *hit_paths;  // global [PE_HIT_CAP][URMAPX_MAX_PATH_OPS]
 	uint32_t *hsp_db, *hsp_ql;  // LDS [PE_HSP_CAP]
 	uint16_t *hsp_sf;
+	uint2 *hsp_ovf;   // OVF pass only: HSPs hsp_lds.. in global scratch as {db, startq | len << 9 | sf << 18}
+	int hsp_lds;      // HSPs kept in LDS (PE_HSP_CAP; a test aid lowers it)
 	uint8_t *pend[2];     // LDS [QMAX] each: pending query positions (stored in a byte, state1.h:86-87)
 	uint8_t *rowlen;      // LDS [2 * QMAX]: row length of every pending position, [strand][i]
 	uint16_t *pre;        // LDS [65]
@@ -109,20 +113,39 @@ struct Mate {
 		return idx;
 	}
 
+	// HSP k: LDS below hsp_lds; beyond it the list continues in global scratch, in the second-pass kernel only (the
+	// first pass flags the pair and queues it: see search_se_kernel).  sf = score << 2 | aligned << 1 | plus.
+	__device__ __forceinline__ void hsp_get(int k, uint32_t &db, uint32_t &ql, uint32_t &sf) const {
+		if (!OVF || k < hsp_lds) { db = hsp_db[k]; ql = hsp_ql[k]; sf = hsp_sf[k]; }
+		else { const uint2 e = hsp_ovf[k - hsp_lds]; db = e.x; ql = (e.y & 511u) | (((e.y >> 9) & 511u) << 16); sf = e.y >> 18; }
+	}
+	__device__ __forceinline__ void hsp_put(int k, uint32_t db, uint32_t ql, uint32_t sf) {  // one lane
+		if (!OVF || k < hsp_lds) { hsp_db[k] = db; hsp_ql[k] = ql; hsp_sf[k] = (uint16_t)sf; }
+		else hsp_ovf[k - hsp_lds] = make_uint2(db, (ql & 511u) | ((ql >> 16) << 9) | (sf << 18));
+	}
+	__device__ __forceinline__ int hsp_room() const { return OVF ? hsp_lds + PE_HSP_OVF_CAP : hsp_lds; }
+	__device__ __forceinline__ int hsp_score(int k) const {
+		uint32_t db, ql, sf;
+		hsp_get(k, db, ql, sf);
+		return (int)(sf >> 2);
+	}
+
 	__device__ __forceinline__ int find_hsp_diag(uint32_t diag) const {
 		for (int base = 0; base < hspCount; base += 64) {
 			const int i = base + lane;
 			bool eq = false;
-			if (i < hspCount) eq = (hsp_db[i] - (hsp_ql[i] & 0xFFFFu)) == diag;
+			if (i < hspCount) {
+				uint32_t db, ql, sf;
+				hsp_get(i, db, ql, sf);
+				eq = (db - (ql & 0xFFFFu)) == diag;
+			}
 			uint64_t m = __ballot(eq);
 			if (m) return base + __builtin_ctzll(m);
 		}
 		return -1;
 	}
 	__device__ __forceinline__ void put_hsp(int k, uint32_t startq, uint32_t startdb, bool plus, uint32_t len, int score) {
-		if (lane == 0) {
-			hsp_db[k] = startdb; hsp_ql[k] = startq | (len << 16); hsp_sf[k] = (uint16_t)((score << 2) | (plus ? 1 : 0));
-		}
+		if (lane == 0) hsp_put(k, startdb, startq | (len << 16), (uint32_t)((score << 2) | (plus ? 1 : 0)));
 		__syncthreads();
 	}
 	// state1.cpp:553-591
@@ -130,10 +153,10 @@ struct Mate {
 		if (score < best - 4) return;
 		int k = find_hsp_diag(startdb - startq);
 		if (k >= 0) {
-			if (score > (int)(hsp_sf[k] >> 2)) put_hsp(k, startq, startdb, plus, len, score);
+			if (score > hsp_score(k)) put_hsp(k, startq, startdb, plus, len, score);
 			return;
 		}
-		if (hspCount >= PE_HSP_CAP) { status |= URMAPX_ST_HSP_OVERFLOW; return; }
+		if (hspCount >= hsp_room()) { status |= URMAPX_ST_HSP_OVERFLOW; return; }
 		put_hsp(hspCount, startq, startdb, plus, len, score);
 		++hspCount;
 		if (score > bestHSP) bestHSP = score;
@@ -142,10 +165,10 @@ struct Mate {
 	__device__ __forceinline__ int add_hsp_scan(uint32_t startq, uint32_t startdb, bool plus, uint32_t len, int score) {
 		int k = find_hsp_diag(startdb - startq);
 		if (k >= 0) {
-			if (score > (int)(hsp_sf[k] >> 2)) put_hsp(k, startq, startdb, plus, len, score);
+			if (score > hsp_score(k)) put_hsp(k, startq, startdb, plus, len, score);
 			return k;
 		}
-		if (hspCount >= PE_HSP_CAP) { status |= URMAPX_ST_HSP_OVERFLOW; return -1; }
+		if (hspCount >= hsp_room()) { status |= URMAPX_ST_HSP_OVERFLOW; return -1; }
 		k = hspCount;
 		put_hsp(k, startq, startdb, plus, len, score);
 		++hspCount;
@@ -257,13 +280,12 @@ struct Mate {
 
 	// alignhsp.cpp:60-172; returns the new hit index or -1
 	__device__ __forceinline__ int align_hsp(int k) {
-		const uint32_t sf = hsp_sf[k];
+		uint32_t startdb, ql, sf;
+		hsp_get(k, startdb, ql, sf);
 		if (sf & 2u) return -1;
 		__syncthreads();
-		if (lane == 0) hsp_sf[k] = (uint16_t)(sf | 2u);
-		const uint32_t ql = hsp_ql[k];
+		if (lane == 0) hsp_put(k, startdb, ql, sf | 2u);
 		const int startq = (int)(ql & 0xFFFFu), len = (int)(ql >> 16);
-		const uint32_t startdb = hsp_db[k];
 		const int hscore = (int)(sf >> 2);
 		const bool plus = sf & 1u;
 		__syncthreads();
@@ -538,7 +560,7 @@ struct Mate {
 		drain(true);
 		const int bmin = max(best, bestHSP) - 8;
 		for (int k = 0; k < hspCount; ++k) {
-			if ((int)(hsp_sf[k] >> 2) < bmin) continue;
+			if (hsp_score(k) < bmin) continue;
 			align_hsp(k);
 		}
 		mapq = calc_mapq();
@@ -640,15 +662,16 @@ struct Mate {
 	}
 };
 
-template <int NCH>
+template <int NCH, bool OVF>
 __global__ __launch_bounds__(64) void search_pe_kernel(DevIndex X, urmapx_params P, const uint8_t *__restrict__ bases,
                                                        const uint64_t *__restrict__ offs, uint32_t npairs, ProbeOut probe,
                                                        urmapx_result *__restrict__ results,
                                                        urmapx_path_op *__restrict__ path_ops, uint32_t *path_used,
                                                        uint8_t *scratch, size_t scratch_stride,
                                                        const uint8_t *__restrict__ g_seq, const uint8_t *__restrict__ g_blob,
-                                                       int veryfast, uint32_t *ticket, urmapx_pair_info *pair_info) {
-	using M = Mate<NCH>;
+                                                       int veryfast, uint32_t *ticket, urmapx_pair_info *pair_info,
+                                                       int hsp_lds_cap, uint32_t *ovf_list, uint2 *hsp_ovf_base) {
+	using M = Mate<NCH, OVF>;
 	constexpr int QMAX = M::QMAX;
 	// LDS per block decides how many pairs a CU keeps in flight, so arrays share memory by lifetime:
 	//   probe results staged for the seed enumeration (s_tal, s_pos)       on  the DP trace buffer (idle until AlignHSP)
@@ -697,12 +720,15 @@ __global__ __launch_bounds__(64) void search_pe_kernel(DevIndex X, urmapx_params
 		m[a].hsp_db = hsp_db[a]; m[a].hsp_ql = hsp_ql[a]; m[a].hsp_sf = hsp_sf[a];
 		m[a].pend[0] = pend[2 * a]; m[a].pend[1] = pend[2 * a + 1];
 		m[a].rowlen = rowlen; m[a].pre = pre; m[a].cq_db = cq_db; m[a].cq_qp = cq_qp;
+		m[a].hsp_lds = (hsp_lds_cap >= 64 && hsp_lds_cap <= PE_HSP_CAP) ? (hsp_lds_cap & ~63) : PE_HSP_CAP;
+		m[a].hsp_ovf = OVF ? hsp_ovf_base + ((size_t)blockIdx.x * 2 + a) * PE_HSP_OVF_CAP : nullptr;
 		m[a].rowstore = reinterpret_cast<uint32_t *>(sc + pe_rowstore_offset(QMAX));
 		m[a].ws.carve(sc + (size_t)2 * PE_HIT_CAP * URMAPX_MAX_PATH_OPS * 2, QMAX, PE_SCAN_SEG + 2 * QMAX + 64);
 	}
 
 	// pairs are handed out by a ticket counter (heavy-tailed cost per pair: the rescue DP), PE_TICKET_CHUNK per ticket
 	// (same-address atomics retire at ~88 M/s), see search_se_kernel
+	if constexpr (OVF) npairs = ovf_list[0];  // second pass: the pairs the first pass flagged (usually none)
 	uint32_t pr_next = 0, pr_end = 0;
 	for (;;) {
 		if (pr_next == pr_end) {
@@ -710,7 +736,8 @@ __global__ __launch_bounds__(64) void search_pe_kernel(DevIndex X, urmapx_params
 			if (pr_next >= npairs) break;
 			pr_end = pr_next + PE_TICKET_CHUNK < npairs ? pr_next + PE_TICKET_CHUNK : npairs;
 		}
-		const uint32_t pr = pr_next++;
+		uint32_t pr = pr_next++;
+		if constexpr (OVF) pr = ovf_list[1 + pr];
 		urmapx_result res[2];
 		bool bad = false;
 		for (int a = 0; a < 2; ++a) {
@@ -1098,6 +1125,11 @@ __global__ __launch_bounds__(64) void search_pe_kernel(DevIndex X, urmapx_params
 			}
 			if (lane == 0) results[2 * pr + a] = R;
 		}
+		if constexpr (!OVF) {
+			if ((m[0].status | m[1].status) & URMAPX_ST_HSP_OVERFLOW) {  // queue the pair for the second pass
+				if (lane == 0) ovf_list[1 + atomicAdd(ovf_list, 1u)] = pr;
+			}
+		}
 	}
 }
 
@@ -1109,13 +1141,16 @@ size_t search_pe_scratch_stride(uint32_t max_read_len) {
 	return (b + 255) & ~(size_t)255;
 }
 
+// behind the strided per-block areas: the HSP overflow lists (two mates) of the second pass's blocks
+size_t search_pe_scratch_tail() { return (size_t)PE_OVF_BLOCKS * 2 * PE_HSP_OVF_CAP * sizeof(uint2); }
+
 int search_pe_block_count(uint32_t max_read_len, int device) {
 	hipDeviceProp_t prop;
 	if (hipGetDeviceProperties(&prop, device) != hipSuccess) return 0;
 	int per_cu = 0;
 	hipError_t e = pe_nch_for(max_read_len) == 3
-	                   ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, search_pe_kernel<3>, 64, 0)
-	                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, search_pe_kernel<5>, 64, 0);
+	                   ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, search_pe_kernel<3, false>, 64, 0)
+	                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, search_pe_kernel<5, false>, 64, 0);
 	if (e != hipSuccess || per_cu < 1) per_cu = 4;
 	return per_cu * prop.multiProcessorCount;
 }
@@ -1128,14 +1163,36 @@ hipError_t launch_search_pe(const DevIndex &X, const urmapx_params &P, const uin
 	{
 		hipError_t e = hipMemsetAsync(wk.ticket, 0, 4, s);
 		if (e != hipSuccess) return e;
+		e = hipMemsetAsync(wk.ovf_list, 0, 4, s);
+		if (e != hipSuccess) return e;
 	}
 	dim3 block(64), grid((unsigned)wk.blocks);
-	if (pe_nch_for(max_read_len) == 3)
-		hipLaunchKernelGGL(search_pe_kernel<3>, grid, block, 0, s, X, P, d_bases, d_offs, npairs, probe, d_results, d_path_ops,
-		                   d_path_used, wk.scratch, wk.scratch_stride, X.seq, X.blob, veryfast, wk.ticket, pair_info);
+	const bool small = pe_nch_for(max_read_len) == 3;
+	if (small)
+		hipLaunchKernelGGL((search_pe_kernel<3, false>), grid, block, 0, s, X, P, d_bases, d_offs, npairs, probe, d_results,
+		                   d_path_ops, d_path_used, wk.scratch, wk.scratch_stride, X.seq, X.blob, veryfast, wk.ticket, pair_info,
+		                   wk.hsp_lds_cap, wk.ovf_list, (uint2 *)nullptr);
 	else
-		hipLaunchKernelGGL(search_pe_kernel<5>, grid, block, 0, s, X, P, d_bases, d_offs, npairs, probe, d_results, d_path_ops,
-		                   d_path_used, wk.scratch, wk.scratch_stride, X.seq, X.blob, veryfast, wk.ticket, pair_info);
+		hipLaunchKernelGGL((search_pe_kernel<5, false>), grid, block, 0, s, X, P, d_bases, d_offs, npairs, probe, d_results,
+		                   d_path_ops, d_path_used, wk.scratch, wk.scratch_stride, X.seq, X.blob, veryfast, wk.ticket, pair_info,
+		                   wk.hsp_lds_cap, wk.ovf_list, (uint2 *)nullptr);
+	{
+		hipError_t e = hipGetLastError();
+		if (e != hipSuccess) return e;
+		e = hipMemsetAsync(wk.ticket, 0, 4, s);
+		if (e != hipSuccess) return e;
+	}
+	// second pass over the pairs whose HSP lists outgrew LDS (see launch_search_se)
+	dim3 grid2((unsigned)(wk.blocks < PE_OVF_BLOCKS ? wk.blocks : PE_OVF_BLOCKS));
+	uint2 *ovf_base = reinterpret_cast<uint2 *>(wk.scratch + (size_t)wk.blocks * wk.scratch_stride);
+	if (small)
+		hipLaunchKernelGGL((search_pe_kernel<3, true>), grid2, block, 0, s, X, P, d_bases, d_offs, npairs, probe, d_results,
+		                   d_path_ops, d_path_used, wk.scratch, wk.scratch_stride, X.seq, X.blob, veryfast, wk.ticket, pair_info,
+		                   wk.hsp_lds_cap, wk.ovf_list, ovf_base);
+	else
+		hipLaunchKernelGGL((search_pe_kernel<5, true>), grid2, block, 0, s, X, P, d_bases, d_offs, npairs, probe, d_results,
+		                   d_path_ops, d_path_used, wk.scratch, wk.scratch_stride, X.seq, X.blob, veryfast, wk.ticket, pair_info,
+		                   wk.hsp_lds_cap, wk.ovf_list, ovf_base);
 	return hipGetLastError();
 }
 
