@@ -434,6 +434,7 @@ def test_hsp_overflow_list_matches_oracle(tmp_path):
     o[1:] = np.cumsum([len(r[1]) for r in reads])
     res, _, _ = idx.map_se(b, o, threads=4)
     assert (res["hsp_count"] > 64).sum() > 50, "fixture no longer exercises the overflow list"
+    assert (res["hit_count"] > 16).sum() > 20, "fixture no longer exercises the long hit list (test cap 16)"
     osam = os.path.join(tmp_path, "o.sam")
     idx.map_file_se(fq, osam, threads=4)
     for cap in ("64", None):

@@ -211,11 +211,14 @@ struct SearchWave {
 	uint32_t *hsp_pk;  // startq | len << 9 | score << 18 | aligned << 27 | plus << 28 (all <= 320: 9 bits each)
 	uint2 *hsp_ovf;    // global scratch of this block: HSPs hsp_lds.. as {db, pk} (reads in high-copy repeats only)
 	int hsp_lds;       // HSPs kept in LDS: HSP_CAP (a test aid lowers it to exercise the overflow path)
+	int hit_cap;       // first pass: 64 hits (the test aid lowers it along with hsp_lds)
 	// global scratch of this block
 	uint32_t *rowstore;  // [strand][chunk][k][lane]
 	WideScratch ws;
-	// hits: entry k lives on lane k
-	uint32_t hit_db;
+	// hits: entry k lives on lane k & 63 of word k >> 6.  One word (64 hits) in the first-pass kernel; the second pass
+	// (reads that outgrew a list) has HITW words = 512 hits.
+	static constexpr int HITW = OVF ? 8 : 1;
+	uint32_t hit_db[HITW];
 	int hitCount, hspCount;
 	int maxPen, best, second, bestHSP;
 	bool haveTop; uint32_t top_db; bool top_plus; int top_nops;
@@ -224,13 +227,18 @@ struct SearchWave {
 	__device__ SearchWave(const DevIndex &X_, const urmapx_params &P_, int lane_) : X(X_), P(P_), lane(lane_) {}
 
 	__device__ __forceinline__ bool overlaps_hit(uint32_t db) const {
-		return __ballot(lane < hitCount && (hit_db >> 6) == (db >> 6)) != 0;
+		bool eq = false;
+#pragma unroll
+		for (int w = 0; w < HITW; ++w) eq |= 64 * w + lane < hitCount && (hit_db[w] >> 6) == (db >> 6);
+		return __ballot(eq) != 0;
 	}
 
 	// per-lane form: does this lane's diagonal start fall in the 64-base block of any hit found so far
 	__device__ __forceinline__ bool overlaps_any_hit(uint32_t db) const {
 		bool ov = false;
-		for (int k = 0; k < hitCount; ++k) ov |= (rdlane(hit_db, k) >> 6) == (db >> 6);
+#pragma unroll
+		for (int w = 0; w < HITW; ++w)
+			for (int k = 0; k < 64 && 64 * w + k < hitCount; ++k) ov |= (rdlane(hit_db[w], k) >> 6) == (db >> 6);
 		return ov;
 	}
 
@@ -247,8 +255,10 @@ struct SearchWave {
 			if (score < best - SECONDARY_HIT_MAX_DELTA) return;
 			if (score > second) second = score;
 		}
-		if (hitCount >= 64) { status |= URMAPX_ST_HIT_OVERFLOW; return; }
-		if (lane == hitCount) hit_db = db;
+		if (hitCount >= (OVF ? 64 * HITW : hit_cap)) { status |= URMAPX_ST_HIT_OVERFLOW; return; }
+#pragma unroll
+		for (int w = 0; w < HITW; ++w)
+			if (64 * w + lane == hitCount) hit_db[w] = db;
 		++hitCount;
 		if (newTop) {
 			haveTop = true; top_db = db; top_plus = plus; top_nops = cand_nops;
@@ -552,6 +562,7 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 		S.ws.carve(sc + (size_t)SW::NSEG * ROW_CAP * 64 * 4, SW::QMAX, SW::WIDE_LB);
 		S.hsp_ovf = OVF ? hsp_ovf_base + (size_t)blockIdx.x * (HSP_TOTAL_CAP - HSP_CAP) : nullptr;
 		S.hsp_lds = (hsp_lds_cap >= 64 && hsp_lds_cap <= HSP_CAP) ? (hsp_lds_cap & ~63) : HSP_CAP;  // multiple of 64
+		S.hit_cap = (hsp_lds_cap >= 64 && hsp_lds_cap <= HSP_CAP) ? S.hsp_lds / 4 : 64;
 	}
 
 	// Reads are handed out by a ticket counter, not by a fixed stride: the cost of a read is heavy-tailed (a read in a
@@ -585,7 +596,9 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 		S.QL = QL;
 		const int nwords = QL - (W - 1);
 		S.nwords = nwords;
-		S.hit_db = 0; S.hitCount = 0; S.hspCount = 0;
+#pragma unroll
+		for (int w = 0; w < SW::HITW; ++w) S.hit_db[w] = 0;
+		S.hitCount = 0; S.hspCount = 0;
 		S.maxPen = P.max_penalty; S.best = 0; S.second = 0; S.bestHSP = 0;
 		S.haveTop = false; S.top_db = 0; S.top_plus = false; S.top_nops = 0; S.status = 0;
 
@@ -838,7 +851,7 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 		lapc(7);
 		}  // !badlen
 		if constexpr (!OVF) {
-			if (res.status & URMAPX_ST_HSP_OVERFLOW) {  // queue the read for the second pass
+			if (res.status & (URMAPX_ST_HSP_OVERFLOW | URMAPX_ST_HIT_OVERFLOW)) {  // queue the read for the second pass
 				if (lane == 0) ovf_list[1 + atomicAdd(ovf_list, 1u)] = r;
 			}
 		}
