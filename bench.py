@@ -191,10 +191,10 @@ def make_pairs_torch(torch, seed, d_seq, seq_lengths, seq_offsets, npairs, L, su
     return torch.stack([r1, r2], dim=1).reshape(-1).contiguous()
 
 
-def pmc_traffic(kernel, reads_per_launch, total_bp):
+def pmc_traffic(kernel, reads_per_launch, total_bp, read_len=150):
     """HBM read bytes per launch of `kernel` from the committed rocprofv3 --pmc FETCH_SIZE pass of this same
     workload (profiles/r1/pmc_fetch_hg38scale_*.json; bench.py cannot collect PMCs itself).  None when no
-    profile of this workload size is committed."""
+    profile of this workload (genome size, read length, kernel) is committed."""
     import glob
     best = None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_fetch_hg38scale_*.json"))):
@@ -202,7 +202,7 @@ def pmc_traffic(kernel, reads_per_launch, total_bp):
             d = json.load(open(path))
         except (OSError, ValueError):
             continue
-        if abs(total_bp - 3.1e9) > 1e8 or kernel not in d.get("kernels", {}):
+        if abs(total_bp - 3.1e9) > 1e8 or kernel not in d.get("kernels", {}) or d.get("read_len", 150) != read_len:
             continue
         best = d["kernels"][kernel]["hbm_read_bytes_per_launch"] * reads_per_launch / d["reads_per_launch"]
     return None if best is None else round(best)
@@ -425,7 +425,7 @@ def main():
         except Exception:
             gather_loads_s = 0.0
         sector_peak = 64.0 * gather_loads_s / 1e9
-        traffic = [pmc_traffic(names[i], nb, total_bp) for i in range(2)]
+        traffic = [pmc_traffic(names[i], nb, total_bp, L) for i in range(2)]
         for i in range(2):
             kern[i]["hbm_read_bytes_per_launch_pmc"] = traffic[i]
             if traffic[i] and sector_peak > 0 and kms[i] > 0:
