@@ -32,7 +32,7 @@ extern "C" {
 #define URMAPX_E_UNSUPPORTED (-6) /* input outside the device path's domain (see status bits) */
 
 /* per-read status bits (urmapx_result.status); non-zero => that read's result is not valid */
-#define URMAPX_ST_HIT_OVERFLOW 0x01 /* more live hits than the device lists hold (512 single-end, 64 per mate paired-end) */
+#define URMAPX_ST_HIT_OVERFLOW 0x01 /* more live hits than the device lists hold (512 single-end, 256 per mate paired-end) */
 #define URMAPX_ST_HSP_OVERFLOW 0x02 /* more HSPs than the device lists hold (8192 per read) */
 #define URMAPX_ST_PATH_OVERFLOW 0x04 /* alignment path longer than URMAPX_MAX_PATH_OPS runs */
 #define URMAPX_ST_BAND_TOO_WIDE 0x08 /* banded DP wider than one wavefront */

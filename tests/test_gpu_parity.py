@@ -470,6 +470,7 @@ def test_pe_hsp_overflow_list_matches_oracle(tmp_path):
     o[1:] = np.cumsum([len(x[1]) for pair in zip(r1, r2) for x in pair])
     res, _, _ = idx.map_pe(b, o, threads=4)
     assert (res["hsp_count"] > 64).sum() > 20, "fixture no longer exercises the overflow list"
+    assert (res["hit_count"] > 16).sum() > 10, "fixture no longer exercises the long hit list (test cap 16)"
     osam = os.path.join(tmp_path, "o.sam")
     idx.map_file_pe(f1, f2, osam, threads=4)
     for cap in ("64", None):

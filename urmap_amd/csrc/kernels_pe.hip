@@ -58,10 +58,28 @@ struct Mate {
 	uint16_t *ropsL, *ropsR, *cand;
 	WideScratch ws;
 	// lists
-	uint32_t hit_db;      // lane k: hit k
-	uint32_t hit_sp;      // score << 1 | plus
-	uint16_t *hit_nops;   // LDS [PE_HIT_CAP]
-	urmapx_path_op *hit_paths;  // global [PE_HIT_CAP][URMAPX_MAX_PATH_OPS]
+	// hits: entry k lives on lane k & 63 of word k >> 6 (one word = 64 hits in the first-pass kernel, HITW words in the
+	// second pass over pairs that outgrew a list)
+	static constexpr int HITW = OVF ? 4 : 1;
+	uint32_t hit_db[HITW];
+	uint32_t hit_sp[HITW];  // score << 1 | plus
+	int hit_cap;            // first pass: PE_HIT_CAP (a test aid lowers it)
+	uint16_t *hit_nops;   // LDS [PE_HIT_CAP * HITW]
+	urmapx_path_op *hit_paths;  // global [PE_HIT_CAP * HITW][URMAPX_MAX_PATH_OPS]
+	__device__ __forceinline__ uint32_t hdb(int i) const {  // i wave-uniform
+		uint32_t v = rdlane(hit_db[0], i & 63);
+#pragma unroll
+		for (int w = 1; w < HITW; ++w)
+			if ((i >> 6) == w) v = rdlane(hit_db[w], i & 63);
+		return v;
+	}
+	__device__ __forceinline__ uint32_t hsp_of(int i) const {
+		uint32_t v = rdlane(hit_sp[0], i & 63);
+#pragma unroll
+		for (int w = 1; w < HITW; ++w)
+			if ((i >> 6) == w) v = rdlane(hit_sp[w], i & 63);
+		return v;
+	}
 	uint32_t *hsp_db, *hsp_ql;  // LDS [PE_HSP_CAP]
 	uint16_t *hsp_sf;
 	uint2 *hsp_ovf;   // OVF pass only: HSPs hsp_lds.. in global scratch as {db, startq | len << 9 | sf << 18}
@@ -79,13 +97,18 @@ struct Mate {
 	uint32_t status;
 
 	__device__ __forceinline__ bool overlaps_hit(uint32_t db) const {
-		return __ballot(lane < hitCount && (hit_db >> 6) == (db >> 6)) != 0;
+		bool eq = false;
+#pragma unroll
+		for (int w = 0; w < HITW; ++w) eq |= 64 * w + lane < hitCount && (hit_db[w] >> 6) == (db >> 6);
+		return __ballot(eq) != 0;
 	}
 
 	// per-lane form of OverlapsHit
 	__device__ __forceinline__ bool overlaps_any_hit(uint32_t db) const {
 		bool ov = false;
-		for (int k = 0; k < hitCount; ++k) ov |= (rdlane(hit_db, k) >> 6) == (db >> 6);
+#pragma unroll
+		for (int w = 0; w < HITW; ++w)
+			for (int k = 0; k < 64 && 64 * w + k < hitCount; ++k) ov |= (rdlane(hit_db[w], k) >> 6) == (db >> 6);
 		return ov;
 	}
 
@@ -104,8 +127,10 @@ struct Mate {
 			else if (score > second) second = score;
 		}
 		if (!keep) return -1;
-		if (hitCount >= PE_HIT_CAP) { status |= URMAPX_ST_HIT_OVERFLOW; if (topHit == idx) topHit = -1; return -1; }
-		if (lane == idx) { hit_db = db; hit_sp = ((uint32_t)score << 1) | (plus ? 1u : 0u); }
+		if (hitCount >= (OVF ? PE_HIT_CAP * HITW : hit_cap)) { status |= URMAPX_ST_HIT_OVERFLOW; if (topHit == idx) topHit = -1; return -1; }
+#pragma unroll
+		for (int w = 0; w < HITW; ++w)
+			if (64 * w + lane == idx) { hit_db[w] = db; hit_sp[w] = ((uint32_t)score << 1) | (plus ? 1u : 0u); }
 		if (lane == 0) hit_nops[idx] = (uint16_t)cand_nops;
 		for (int t = lane; t < cand_nops; t += 64) hit_paths[(size_t)idx * URMAPX_MAX_PATH_OPS + t] = cand[t];
 		__syncthreads();
@@ -680,7 +705,7 @@ __global__ __launch_bounds__(64) void search_pe_kernel(DevIndex X, urmapx_params
 	//   the pending stage's candidate queue, then FindPairs' pair list      on  seed_db
 	__shared__ __attribute__((aligned(16))) uint8_t sQ[4][QMAX];
 	__shared__ __attribute__((aligned(16))) uint32_t tb[M::TB_ROWS8 * 64];
-	__shared__ uint16_t hit_nops[2][PE_HIT_CAP];
+	__shared__ uint16_t hit_nops[2][PE_HIT_CAP * M::HITW];
 	__shared__ uint32_t hsp_db[2][PE_HSP_CAP], hsp_ql[2][PE_HSP_CAP];
 	__shared__ uint16_t hsp_sf[2][PE_HSP_CAP];
 	__shared__ uint8_t pend[4][QMAX];
@@ -716,7 +741,10 @@ __global__ __launch_bounds__(64) void search_pe_kernel(DevIndex X, urmapx_params
 		m[a].sQ[0] = sQ[2 * a]; m[a].sQ[1] = sQ[2 * a + 1];
 		m[a].sT = sT; m[a].tb = tb; m[a].ropsL = ropsL; m[a].ropsR = ropsR; m[a].cand = cand;
 		m[a].hit_nops = hit_nops[a];
-		m[a].hit_paths = reinterpret_cast<urmapx_path_op *>(sc) + (size_t)a * PE_HIT_CAP * URMAPX_MAX_PATH_OPS;
+		m[a].hit_paths = OVF ? reinterpret_cast<urmapx_path_op *>(hsp_ovf_base + (size_t)gridDim.x * 2 * PE_HSP_OVF_CAP) +
+		                           ((size_t)blockIdx.x * 2 + a) * PE_HIT_CAP * M::HITW * URMAPX_MAX_PATH_OPS
+		                     : reinterpret_cast<urmapx_path_op *>(sc) + (size_t)a * PE_HIT_CAP * URMAPX_MAX_PATH_OPS;
+		m[a].hit_cap = (hsp_lds_cap >= 64 && hsp_lds_cap <= PE_HSP_CAP) ? (hsp_lds_cap & ~63) / 4 : PE_HIT_CAP;
 		m[a].hsp_db = hsp_db[a]; m[a].hsp_ql = hsp_ql[a]; m[a].hsp_sf = hsp_sf[a];
 		m[a].pend[0] = pend[2 * a]; m[a].pend[1] = pend[2 * a + 1];
 		m[a].rowlen = rowlen; m[a].pre = pre; m[a].cq_db = cq_db; m[a].cq_qp = cq_qp;
@@ -782,7 +810,8 @@ __global__ __launch_bounds__(64) void search_pe_kernel(DevIndex X, urmapx_params
 					}
 				}
 			}
-			m[a].hit_db = 0; m[a].hit_sp = 0;
+#pragma unroll
+			for (int w = 0; w < M::HITW; ++w) { m[a].hit_db[w] = 0; m[a].hit_sp[w] = 0; }
 			m[a].pendCount[0] = m[a].pendCount[1] = 0;
 			m[a].hitCount = 0; m[a].hspCount = 0; m[a].topHit = -1;
 			m[a].maxPen = P.max_penalty; m[a].best = 0; m[a].second = 0; m[a].bestHSP = 0;
@@ -999,7 +1028,7 @@ __global__ __launch_bounds__(64) void search_pe_kernel(DevIndex X, urmapx_params
 				m[1].search_pending();
 				done = true;
 			} else if (m[0].best >= (QLf * 9) / 10 && m[1].best >= (QLr * 9) / 10 && m[0].topHit >= 0 && m[1].topHit >= 0) {
-				int64_t d = (int64_t)rdlane(m[0].hit_db, m[0].topHit) - (int64_t)rdlane(m[1].hit_db, m[1].topHit);
+				int64_t d = (int64_t)m[0].hdb(m[0].topHit) - (int64_t)m[1].hdb(m[1].topHit);
 				if (d < 0) d = -d;
 				if (d + QL2 <= MAX_TL) { m[0].mapq = 40; m[1].mapq = 40; done = true; }
 			}
@@ -1013,15 +1042,15 @@ __global__ __launch_bounds__(64) void search_pe_kernel(DevIndex X, urmapx_params
 			for (int attempt = 0; attempt < 2; ++attempt) {
 				npairs_found = 0; bestPairScore = -1; secondPairScore = -1; bestPairIndex = -1; secondPairIndex = -1;
 				for (int i = 0; i < m[0].hitCount; ++i) {
-					const uint32_t spf = rdlane(m[0].hit_sp, i);
+					const uint32_t spf = m[0].hsp_of(i);
 					const int sf = (int)(spf >> 1);
 					if (sf < m[0].second - 12) continue;
-					const int64_t dbf = (int64_t)rdlane(m[0].hit_db, i);
+					const int64_t dbf = (int64_t)m[0].hdb(i);
 					for (int j = 0; j < m[1].hitCount; ++j) {
-						const uint32_t spr = rdlane(m[1].hit_sp, j);
+						const uint32_t spr = m[1].hsp_of(j);
 						const int sr = (int)(spr >> 1);
 						if (sr < m[1].second - 12) continue;
-						int64_t d = dbf - (int64_t)rdlane(m[1].hit_db, j);
+						int64_t d = dbf - (int64_t)m[1].hdb(j);
 						if (d < 0) d = -d;
 						if (d + QL2 > 1000) continue;
 						if ((spf & 1u) == (spr & 1u)) continue;
@@ -1044,16 +1073,16 @@ __global__ __launch_bounds__(64) void search_pe_kernel(DevIndex X, urmapx_params
 				const bool dovitF = (int)m[0].mapq >= 10 && dbg_stop != 5, dovitR = (int)m[1].mapq >= 10 && dbg_stop != 5;  // 5: diagnostic, no rescue DP
 				const int hcf = m[0].hitCount, hcr = m[1].hitCount;
 				for (int i = 0; i < hcf; ++i) {
-					const uint32_t sp = rdlane(m[0].hit_sp, i);
+					const uint32_t sp = m[0].hsp_of(i);
 					if ((int)(sp >> 1) < m[0].second) continue;
-					const uint32_t db = rdlane(m[0].hit_db, i);
+					const uint32_t db = m[0].hdb(i);
 					if (sp & 1u) m[1].scan(db, PE_SCAN_SEG, false, dovitF);
 					else if (db >= (uint32_t)PE_SCAN_SEG) m[1].scan(db - PE_SCAN_SEG, PE_SCAN_SEG + 2 * (uint32_t)QLf, true, dovitF);
 				}
 				for (int j = 0; j < hcr; ++j) {
-					const uint32_t sp = rdlane(m[1].hit_sp, j);
+					const uint32_t sp = m[1].hsp_of(j);
 					if ((int)(sp >> 1) < m[1].second) continue;
-					const uint32_t db = rdlane(m[1].hit_db, j);
+					const uint32_t db = m[1].hdb(j);
 					if (sp & 1u) m[0].scan(db, PE_SCAN_SEG, false, dovitR);
 					else if (db >= (uint32_t)PE_SCAN_SEG) m[0].scan(db - PE_SCAN_SEG, PE_SCAN_SEG + 2 * (uint32_t)QLf, true, dovitR);
 				}
@@ -1082,12 +1111,12 @@ __global__ __launch_bounds__(64) void search_pe_kernel(DevIndex X, urmapx_params
 				pi.top_db[a] = 0xFFFFFFFFu; pi.second_db[a] = 0xFFFFFFFFu;
 				pi.top_score[a] = 0; pi.second_score[a] = 0; pi.top_plus[a] = 0; pi.second_plus[a] = 0;
 				if (m[a].topHit >= 0) {
-					const uint32_t sp = rdlane(m[a].hit_sp, m[a].topHit);
-					pi.top_db[a] = rdlane(m[a].hit_db, m[a].topHit); pi.top_score[a] = (int16_t)(sp >> 1); pi.top_plus[a] = (uint8_t)(sp & 1u);
+					const uint32_t sp = m[a].hsp_of(m[a].topHit);
+					pi.top_db[a] = m[a].hdb(m[a].topHit); pi.top_score[a] = (int16_t)(sp >> 1); pi.top_plus[a] = (uint8_t)(sp & 1u);
 				}
 				if (secondHit[a] >= 0) {
-					const uint32_t sp = rdlane(m[a].hit_sp, secondHit[a]);
-					pi.second_db[a] = rdlane(m[a].hit_db, secondHit[a]); pi.second_score[a] = (int16_t)(sp >> 1); pi.second_plus[a] = (uint8_t)(sp & 1u);
+					const uint32_t sp = m[a].hsp_of(secondHit[a]);
+					pi.second_db[a] = m[a].hdb(secondHit[a]); pi.second_score[a] = (int16_t)(sp >> 1); pi.second_plus[a] = (uint8_t)(sp & 1u);
 				}
 			}
 			if (lane == 0) pair_info[pr] = pi;
@@ -1099,8 +1128,8 @@ __global__ __launch_bounds__(64) void search_pe_kernel(DevIndex X, urmapx_params
 			R.second = (int16_t)m[a].second; R.hit_count = (uint16_t)m[a].hitCount; R.status = (uint8_t)(m[a].status | m[1 - a].status);
 			R.exit_phase = done ? 1 : 2;
 			if (m[a].topHit >= 0) {
-				const uint32_t db = rdlane(m[a].hit_db, m[a].topHit);
-				const uint32_t sp = rdlane(m[a].hit_sp, m[a].topHit);
+				const uint32_t db = m[a].hdb(m[a].topHit);
+				const uint32_t sp = m[a].hsp_of(m[a].topHit);
 				R.score = (int16_t)(sp >> 1);
 				uint32_t lo = 0, hi = X.seqCount - 1;
 				uint32_t found = 0xFFFFFFFFu, coord = 0xFFFFFFFFu, tl = 0;
@@ -1126,7 +1155,7 @@ __global__ __launch_bounds__(64) void search_pe_kernel(DevIndex X, urmapx_params
 			if (lane == 0) results[2 * pr + a] = R;
 		}
 		if constexpr (!OVF) {
-			if ((m[0].status | m[1].status) & URMAPX_ST_HSP_OVERFLOW) {  // queue the pair for the second pass
+			if ((m[0].status | m[1].status) & (URMAPX_ST_HSP_OVERFLOW | URMAPX_ST_HIT_OVERFLOW)) {  // queue the pair for the second pass
 				if (lane == 0) ovf_list[1 + atomicAdd(ovf_list, 1u)] = pr;
 			}
 		}
@@ -1141,8 +1170,11 @@ size_t search_pe_scratch_stride(uint32_t max_read_len) {
 	return (b + 255) & ~(size_t)255;
 }
 
-// behind the strided per-block areas: the HSP overflow lists (two mates) of the second pass's blocks
-size_t search_pe_scratch_tail() { return (size_t)PE_OVF_BLOCKS * 2 * PE_HSP_OVF_CAP * sizeof(uint2); }
+// behind the strided per-block areas, for the second pass's blocks: the HSP overflow lists (two mates), then the
+// hit paths of its longer hit lists
+size_t search_pe_scratch_tail() {
+	return (size_t)PE_OVF_BLOCKS * 2 * ((size_t)PE_HSP_OVF_CAP * sizeof(uint2) + (size_t)PE_HIT_CAP * 4 * URMAPX_MAX_PATH_OPS * 2);
+}
 
 int search_pe_block_count(uint32_t max_read_len, int device) {
 	hipDeviceProp_t prop;
