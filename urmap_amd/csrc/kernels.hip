@@ -9,11 +9,14 @@
 //   search_se_kernel   State1::Search_Lo (search1m6.cpp:35-277) incl. ExtendPen (extendpen.cpp:9-95), GetRow_Blob
 //                      (ufindex.cpp:883-943), AddHitX/AddHSPX (state1.cpp:508-591), AlignHSP (alignhsp.cpp:60-172),
 //                      Viterbi (viterbi.cpp:11-261), TraceBackBitMem (tracebackbitmem.cpp:8-75), CalcMAPQ6
-//                      (search1m6.cpp:9-33) and SetMappedPos (state1.cpp:129-145).  One wavefront per read: the
-//                      order-dependent schedule is wave-uniform (scalar), the data-parallel parts use the 64
-//                      lanes: ExtendPen compares 64 bases per instruction and walks the mismatch ballot,
-//                      the banded DP puts one diagonal on each lane (row sweep; the in-row insert dependency is
-//                      a max-plus prefix scan over DPP), hit and HSP lists live one-per-lane in VGPRs.
+//                      (search1m6.cpp:9-33) and SetMappedPos (state1.cpp:129-145).  One wavefront per read, reads
+//                      handed out by a ticket counter to 16 persistent single-wave blocks per CU.  The
+//                      order-dependent schedule is wave-uniform (scalar); the data-parallel parts use the 64
+//                      lanes: one candidate window per lane in ExtendPen (mismatch bit vector + x-drop walk), one
+//                      collision chain per lane in GetRow_Blob, one diagonal per lane in the banded DP (row sweep;
+//                      the in-row insert dependency is a max-plus prefix scan over DPP), one hit per lane.
+//                      Launched twice per batch: <NCH, false> over all reads, then <NCH, true> (lists continued in
+//                      global scratch) over the few reads whose HSP / hit lists outgrew the first pass's.
 //
 // DP scores are kept in fp32 exactly as the reference does (small integers and a -9e9f "minus infinity" that
 // absorbs small addends), so every tie and every trace bit is reproduced without re-deriving integer sentinels.
@@ -137,16 +140,18 @@ __global__ __launch_bounds__(64) void viterbi_batch_kernel(urmapx_params P, cons
 }
 
 // ------------------------------------------------------------------------------------------------
-// kernel B: per-read search.  One wavefront per read (persistent blocks stride over the batch).
+// kernel B: per-read search.  One wavefront per read.
 //
 // The reference's schedule (search1m6.cpp:35-277) is a chain of ~600 dependent memory accesses per read
 // (one target window per ExtendPen, one slot per chain hop).  The accesses themselves do not depend on the
-// search state -- only WHAT IS DONE with each window does -- so every phase is split in two:
-//   gather   (order independent, 64-wide): each lane takes one candidate seed of the phase, in the reference's
-//            order, and computes that candidate's whole mismatch bit vector against its reference window
-//            (lane_mismatch_mask); chain walks put one collision chain on each lane (walk_all).
-//   consume  (order dependent, wave-uniform): the candidates' bit vectors are read back lane by lane and run
-//            through ExtendPen's x-drop / penalty logic, AddHitX / AddHSPX, early exits -- exactly in order.
+// search state -- only WHAT IS DONE with each window does -- so every phase is split:
+//   scan     the phase's candidates are enumerated in the reference's order; those on the diagonal block of a hit
+//            already found (ExtendPen would return at once) are dropped, the rest compacted into an LDS queue
+//   gather   (order independent, 64-wide): each lane takes one queued candidate and computes that candidate's whole
+//            mismatch bit vector against its reference window (lane_mismatch_mask) and the outcome of ExtendPen's
+//            two x-drop walks on it (xdrop_walk_lane); chain walks put one collision chain on each lane (walk_all)
+//   consume  (order dependent, wave-uniform): only the candidates whose outcome can still change the search state
+//            are visited, in order: AddHitX / AddHSPX, penalty cap, early exits -- exactly as the reference
 // ------------------------------------------------------------------------------------------------
 static constexpr int HSP_CAP = 256;        // HSPs of a read held in LDS
 static constexpr int SEARCH_OVF_BLOCKS = 256;  // grid of the second pass (reads whose HSP list outgrew LDS)
