@@ -522,7 +522,10 @@ struct SearchWave {
 #ifndef SEARCH_WAVES_NCH3
 #define SEARCH_WAVES_NCH3 4
 #endif
-#define SEARCH_WAVES_PER_EU(NCH) ((NCH) <= 3 ? SEARCH_WAVES_NCH3 : 2)
+#ifndef SEARCH_WAVES_NCH4
+#define SEARCH_WAVES_NCH4 3
+#endif
+#define SEARCH_WAVES_PER_EU(NCH) ((NCH) <= 3 ? SEARCH_WAVES_NCH3 : (NCH) == 4 ? SEARCH_WAVES_NCH4 : 2)
 template <int NCH, bool OVF>
 __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel(DevIndex X, urmapx_params P, const uint8_t *__restrict__ bases,
                                                        const uint64_t *__restrict__ offs, uint32_t n, ProbeOut probe,
@@ -869,6 +872,7 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 // ------------------------------------------------------------------------------------------------
 static int nch_for(uint32_t max_read_len) {
 	if (max_read_len <= 192) return 3;
+	if (max_read_len <= 256) return 4;  // 250 bp reads: smaller per-read state than the 320-base class, one more wave per SIMD
 	if (max_read_len <= 320) return 5;
 	return 0;
 }
@@ -884,9 +888,10 @@ int search_block_count(uint32_t max_read_len, int device) {
 	hipDeviceProp_t prop;
 	if (hipGetDeviceProperties(&prop, device) != hipSuccess) return 0;
 	int per_cu = 0;
-	hipError_t e = nch_for(max_read_len) == 3
-	                   ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, search_se_kernel<3, false>, 64, 0)
-	                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, search_se_kernel<5, false>, 64, 0);
+	const int nchq = nch_for(max_read_len);
+	hipError_t e = nchq == 3   ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, search_se_kernel<3, false>, 64, 0)
+	               : nchq == 4 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, search_se_kernel<4, false>, 64, 0)
+	                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, search_se_kernel<5, false>, 64, 0);
 	if (e != hipSuccess || per_cu < 1) per_cu = 8;
 	return per_cu * prop.multiProcessorCount;
 }
@@ -925,6 +930,7 @@ hipError_t launch_seed_probe(const DevIndex &X, const uint8_t *d_bases, const ui
 	const int nch = nch_for(max_read_len);
 	dim3 block(256), grid((n + 3) / 4);
 	if (nch == 3) hipLaunchKernelGGL(seed_probe_kernel<3>, grid, block, 0, s, X, d_bases, d_offs, n, out);
+	else if (nch == 4) hipLaunchKernelGGL(seed_probe_kernel<4>, grid, block, 0, s, X, d_bases, d_offs, n, out);
 	else hipLaunchKernelGGL(seed_probe_kernel<5>, grid, block, 0, s, X, d_bases, d_offs, n, out);
 	return hipGetLastError();
 }
@@ -951,6 +957,10 @@ hipError_t launch_search_se(const DevIndex &X, const urmapx_params &P, const uin
 		hipLaunchKernelGGL((search_se_kernel<3, false>), grid, block, 0, s, X, P, d_bases, d_offs, n, probe, d_results, d_path_ops,
 		                   d_path_used, wk.stats, wk.scratch, wk.scratch_stride, X.seq, X.blob, wk.ticket, wk.hsp_lds_cap,
 		                   wk.ovf_list, (uint2 *)nullptr);
+	else if (nch == 4)
+		hipLaunchKernelGGL((search_se_kernel<4, false>), grid, block, 0, s, X, P, d_bases, d_offs, n, probe, d_results, d_path_ops,
+		                   d_path_used, wk.stats, wk.scratch, wk.scratch_stride, X.seq, X.blob, wk.ticket, wk.hsp_lds_cap,
+		                   wk.ovf_list, (uint2 *)nullptr);
 	else
 		hipLaunchKernelGGL((search_se_kernel<5, false>), grid, block, 0, s, X, P, d_bases, d_offs, n, probe, d_results, d_path_ops,
 		                   d_path_used, wk.stats, wk.scratch, wk.scratch_stride, X.seq, X.blob, wk.ticket, wk.hsp_lds_cap,
@@ -967,6 +977,10 @@ hipError_t launch_search_se(const DevIndex &X, const urmapx_params &P, const uin
 	uint2 *ovf_base = reinterpret_cast<uint2 *>(wk.scratch + (size_t)wk.blocks * wk.scratch_stride);
 	if (nch == 3)
 		hipLaunchKernelGGL((search_se_kernel<3, true>), grid2, block, 0, s, X, P, d_bases, d_offs, n, probe, d_results, d_path_ops,
+		                   d_path_used, (uint32_t *)nullptr, wk.scratch, wk.scratch_stride, X.seq, X.blob, wk.ticket, wk.hsp_lds_cap,
+		                   wk.ovf_list, ovf_base);
+	else if (nch == 4)
+		hipLaunchKernelGGL((search_se_kernel<4, true>), grid2, block, 0, s, X, P, d_bases, d_offs, n, probe, d_results, d_path_ops,
 		                   d_path_used, (uint32_t *)nullptr, wk.scratch, wk.scratch_stride, X.seq, X.blob, wk.ticket, wk.hsp_lds_cap,
 		                   wk.ovf_list, ovf_base);
 	else

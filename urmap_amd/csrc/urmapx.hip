@@ -103,7 +103,7 @@ struct urmapx_ctx {
 	DevBuf<uint32_t> ovflist;  // reads queued for the search kernel's second pass
 	uint32_t pairinfo_n = 0;
 	int pe_blocks[2] = {0, 0};
-	int blocks[2] = {0, 0};  // persistent grid size of the search kernel for read length classes <=192, <=320
+	int blocks[3] = {0, 0, 0};  // persistent grid size of the search kernel for read length classes <=192, <=320, <=256
 };
 
 extern "C" {
@@ -328,7 +328,7 @@ int urmapx_map_se_device(urmapx_ctx *C, const void *d_bases, const void *d_offs,
 	int rc = ensure_probe(C, total_bases);
 	if (rc) return rc;
 	ProbeOut po{C->slots.p, C->tallies.p, C->positions.p};
-	const int cls = max_read_len <= 192 ? 0 : 1;
+	const int cls = max_read_len <= 192 ? 0 : (max_read_len <= 256 ? 2 : 1);
 	if (C->blocks[cls] == 0) {
 		C->blocks[cls] = search_block_count(max_read_len, C->device);
 		if (getenv("URMAPX_VERBOSE")) fprintf(stderr, "urmapx: search_se_kernel grid = %d persistent blocks (read class %d)\n", C->blocks[cls], cls);
