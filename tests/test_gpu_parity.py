@@ -157,7 +157,8 @@ def test_viterbi_matches_oracle(gpu):
 
 
 @pytest.mark.parametrize("read_len,sub,indel,n", [(150, 0.01, 0.001, 3000), (250, 0.04, 0.01, 1500),
-                                                   (100, 0.02, 0.004, 1500), (30, 0.0, 0.0, 500)])
+                                                   (100, 0.02, 0.004, 1500), (30, 0.0, 0.0, 500),
+                                                   (300, 0.03, 0.008, 1000)])  # 150/100/30: 192-base kernel class, 250: 256, 300: 320
 def test_map_se_matches_oracle(small_case, gpu, read_len, sub, indel, n):
     """State1::Search end to end (search1.cpp:7-24): top hit, scores, MAPQ, path -- bit-exact."""
     from urmap_amd import synth
