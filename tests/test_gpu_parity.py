@@ -172,6 +172,22 @@ def test_map_se_matches_oracle(small_case, gpu, read_len, sub, indel, n):
     compare_results(gres, gops, ores, opaths)
 
 
+@pytest.mark.parametrize("lo,hi", [(24, 192), (24, 256), (24, 320)])
+def test_map_se_mixed_lengths_in_one_batch(small_case, gpu, lo, hi):
+    """A batch is run by the kernel instance of its longest read: reads of every length from W up to the class limit in
+    one batch, each class limit in turn."""
+    from urmap_amd import synth
+    from conftest import reads_to_arrays
+    rng = np.random.default_rng(hi)
+    reads = []
+    for i, L in enumerate(rng.integers(lo, hi + 1, size=400).tolist() + [lo, hi, hi, lo + 1, hi - 1]):
+        reads += synth.make_reads(7000 + 13 * i + hi, small_case["genome"], 1, read_len=int(L), sub=0.02, ins=0.002, dele=0.002)
+    bases, offs = reads_to_arrays(reads)
+    ores, opaths, _ = small_case["oracle_index"].map_se(bases, offs, threads=4)
+    gres, gops = gpu["mapper"].map_se(bases, offs)
+    compare_results(gres, gops, ores, opaths)
+
+
 def test_bad_lengths_are_flagged(small_case, gpu):
     """Reads shorter than W or longer than the device cap are reported, not silently mis-mapped."""
     from urmap_amd import api
