@@ -35,7 +35,7 @@ extern "C" {
 #define URMAPX_ST_HIT_OVERFLOW 0x01 /* more live hits than the device lists hold (512 single-end, 256 per mate paired-end) */
 #define URMAPX_ST_HSP_OVERFLOW 0x02 /* more HSPs than the device lists hold (8192 per read) */
 #define URMAPX_ST_PATH_OVERFLOW 0x04 /* alignment path longer than URMAPX_MAX_PATH_OPS runs */
-#define URMAPX_ST_BAND_TOO_WIDE 0x08 /* banded DP wider than one wavefront */
+#define URMAPX_ST_BAND_TOO_WIDE 0x08 /* DP problem larger than the wide-band scratch (does not occur for reads <= URMAPX_MAX_QL) */
 #define URMAPX_ST_BAD_LENGTH 0x10    /* read shorter than the word length or longer than URMAPX_MAX_QL */
 
 #define URMAPX_MAX_QL 320
