@@ -301,7 +301,7 @@ def test_pe_reproduces_reference_golden_sam(tmp_path, name):
 
 
 @pytest.mark.parametrize("rl,s1,s2,indel,n", [(150, 0.01, 0.02, 0.001, 3000), (120, 0.04, 0.08, 0.01, 2000),
-                                                (250, 0.02, 0.04, 0.005, 800)])  # 250: the 320-base kernel class
+                                                (250, 0.02, 0.04, 0.005, 800), (270, 0.02, 0.04, 0.005, 500)])  # 250 / 270: the 256- and 320-base kernel classes (pairs: <= 279 bp, byte QPos)
 def test_pe_matches_oracle(small_case, tmp_path, rl, s1, s2, indel, n):
     """Fresh pairs on the 300 kbp genome (incl. one-mate-random pairs that go through ScanPair): SAM of the device
     path == SAM of the oracle's Search4 restatement."""

@@ -1162,7 +1162,7 @@ __global__ __launch_bounds__(64) void search_pe_kernel(DevIndex X, urmapx_params
 	}
 }
 
-static int pe_nch_for(uint32_t max_read_len) { return max_read_len <= 192 ? 3 : (max_read_len <= 320 ? 5 : 0); }
+static int pe_nch_for(uint32_t max_read_len) { return max_read_len <= 192 ? 3 : (max_read_len <= 256 ? 4 : (max_read_len <= 320 ? 5 : 0)); }
 
 size_t search_pe_scratch_stride(uint32_t max_read_len) {
 	const int qmax = 64 * pe_nch_for(max_read_len);
@@ -1180,9 +1180,10 @@ int search_pe_block_count(uint32_t max_read_len, int device) {
 	hipDeviceProp_t prop;
 	if (hipGetDeviceProperties(&prop, device) != hipSuccess) return 0;
 	int per_cu = 0;
-	hipError_t e = pe_nch_for(max_read_len) == 3
-	                   ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, search_pe_kernel<3, false>, 64, 0)
-	                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, search_pe_kernel<5, false>, 64, 0);
+	const int nchq = pe_nch_for(max_read_len);
+	hipError_t e = nchq == 3   ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, search_pe_kernel<3, false>, 64, 0)
+	               : nchq == 4 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, search_pe_kernel<4, false>, 64, 0)
+	                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, search_pe_kernel<5, false>, 64, 0);
 	if (e != hipSuccess || per_cu < 1) per_cu = 4;
 	return per_cu * prop.multiProcessorCount;
 }
@@ -1199,9 +1200,13 @@ hipError_t launch_search_pe(const DevIndex &X, const urmapx_params &P, const uin
 		if (e != hipSuccess) return e;
 	}
 	dim3 block(64), grid((unsigned)wk.blocks);
-	const bool small = pe_nch_for(max_read_len) == 3;
-	if (small)
+	const int nch = pe_nch_for(max_read_len);
+	if (nch == 3)
 		hipLaunchKernelGGL((search_pe_kernel<3, false>), grid, block, 0, s, X, P, d_bases, d_offs, npairs, probe, d_results,
+		                   d_path_ops, d_path_used, wk.scratch, wk.scratch_stride, X.seq, X.blob, veryfast, wk.ticket, pair_info,
+		                   wk.hsp_lds_cap, wk.ovf_list, (uint2 *)nullptr);
+	else if (nch == 4)
+		hipLaunchKernelGGL((search_pe_kernel<4, false>), grid, block, 0, s, X, P, d_bases, d_offs, npairs, probe, d_results,
 		                   d_path_ops, d_path_used, wk.scratch, wk.scratch_stride, X.seq, X.blob, veryfast, wk.ticket, pair_info,
 		                   wk.hsp_lds_cap, wk.ovf_list, (uint2 *)nullptr);
 	else
@@ -1217,8 +1222,12 @@ hipError_t launch_search_pe(const DevIndex &X, const urmapx_params &P, const uin
 	// second pass over the pairs whose HSP lists outgrew LDS (see launch_search_se)
 	dim3 grid2((unsigned)(wk.blocks < PE_OVF_BLOCKS ? wk.blocks : PE_OVF_BLOCKS));
 	uint2 *ovf_base = reinterpret_cast<uint2 *>(wk.scratch + (size_t)wk.blocks * wk.scratch_stride);
-	if (small)
+	if (nch == 3)
 		hipLaunchKernelGGL((search_pe_kernel<3, true>), grid2, block, 0, s, X, P, d_bases, d_offs, npairs, probe, d_results,
+		                   d_path_ops, d_path_used, wk.scratch, wk.scratch_stride, X.seq, X.blob, veryfast, wk.ticket, pair_info,
+		                   wk.hsp_lds_cap, wk.ovf_list, ovf_base);
+	else if (nch == 4)
+		hipLaunchKernelGGL((search_pe_kernel<4, true>), grid2, block, 0, s, X, P, d_bases, d_offs, npairs, probe, d_results,
 		                   d_path_ops, d_path_used, wk.scratch, wk.scratch_stride, X.seq, X.blob, veryfast, wk.ticket, pair_info,
 		                   wk.hsp_lds_cap, wk.ovf_list, ovf_base);
 	else
