@@ -224,6 +224,11 @@ struct SearchWave {
 	// (reads that outgrew a list) has HITW words = 512 hits.
 	static constexpr int HITW = OVF ? 8 : 1;
 	uint32_t hit_db[HITW];
+	// hits per word: 64 (2^6).  The test aid that lowers the first pass's caps also lowers this to 16 in the second pass,
+	// so that a fixture with a few dozen hits per read runs through several words.
+	int hit_wsh;
+	__device__ __forceinline__ int wsh() const { return OVF ? hit_wsh : 6; }
+	__device__ __forceinline__ int wl() const { return 1 << wsh(); }
 	int hitCount, hspCount;
 	int maxPen, best, second, bestHSP;
 	bool haveTop; uint32_t top_db; bool top_plus; int top_nops;
@@ -234,7 +239,7 @@ struct SearchWave {
 	__device__ __forceinline__ bool overlaps_hit(uint32_t db) const {
 		bool eq = false;
 #pragma unroll
-		for (int w = 0; w < HITW; ++w) eq |= 64 * w + lane < hitCount && (hit_db[w] >> 6) == (db >> 6);
+		for (int w = 0; w < HITW; ++w) eq |= lane < wl() && (w << wsh()) + lane < hitCount && (hit_db[w] >> 6) == (db >> 6);
 		return __ballot(eq) != 0;
 	}
 
@@ -243,7 +248,7 @@ struct SearchWave {
 		bool ov = false;
 #pragma unroll
 		for (int w = 0; w < HITW; ++w)
-			for (int k = 0; k < 64 && 64 * w + k < hitCount; ++k) ov |= (rdlane(hit_db[w], k) >> 6) == (db >> 6);
+			for (int k = 0; k < wl() && (w << wsh()) + k < hitCount; ++k) ov |= (rdlane(hit_db[w], k) >> 6) == (db >> 6);
 		return ov;
 	}
 
@@ -260,10 +265,10 @@ struct SearchWave {
 			if (score < best - SECONDARY_HIT_MAX_DELTA) return;
 			if (score > second) second = score;
 		}
-		if (hitCount >= (OVF ? 64 * HITW : hit_cap)) { status |= URMAPX_ST_HIT_OVERFLOW; return; }
+		if (hitCount >= (OVF ? HITW << wsh() : hit_cap)) { status |= URMAPX_ST_HIT_OVERFLOW; return; }
 #pragma unroll
 		for (int w = 0; w < HITW; ++w)
-			if (64 * w + lane == hitCount) hit_db[w] = db;
+			if (lane < wl() && (w << wsh()) + lane == hitCount) hit_db[w] = db;
 		++hitCount;
 		if (newTop) {
 			haveTop = true; top_db = db; top_plus = plus; top_nops = cand_nops;
@@ -571,6 +576,7 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 		S.hsp_ovf = OVF ? hsp_ovf_base + (size_t)blockIdx.x * (HSP_TOTAL_CAP - HSP_CAP) : nullptr;
 		S.hsp_lds = (hsp_lds_cap >= 64 && hsp_lds_cap <= HSP_CAP) ? (hsp_lds_cap & ~63) : HSP_CAP;  // multiple of 64
 		S.hit_cap = (hsp_lds_cap >= 64 && hsp_lds_cap <= HSP_CAP) ? S.hsp_lds / 4 : 64;
+		S.hit_wsh = (hsp_lds_cap >= 64 && hsp_lds_cap <= HSP_CAP) ? 4 : 6;
 	}
 
 	// Reads are handed out by a ticket counter, not by a fixed stride: the cost of a read is heavy-tailed (a read in a

@@ -66,18 +66,25 @@ struct Mate {
 	int hit_cap;            // first pass: PE_HIT_CAP (a test aid lowers it)
 	uint16_t *hit_nops;   // LDS [PE_HIT_CAP * HITW]
 	urmapx_path_op *hit_paths;  // global [PE_HIT_CAP * HITW][URMAPX_MAX_PATH_OPS]
+	// hits per word: 64 (2^6); lowered to 16 in the second pass by the test aid that lowers the first pass's caps, so that
+	// a fixture with a few dozen hits per mate runs through several words
+	int hit_wsh;
+	__device__ __forceinline__ int wsh() const { return OVF ? hit_wsh : 6; }
+	__device__ __forceinline__ int wl() const { return 1 << wsh(); }
 	__device__ __forceinline__ uint32_t hdb(int i) const {  // i wave-uniform
-		uint32_t v = rdlane(hit_db[0], i & 63);
+		const int l = i & (wl() - 1);
+		uint32_t v = rdlane(hit_db[0], l);
 #pragma unroll
 		for (int w = 1; w < HITW; ++w)
-			if ((i >> 6) == w) v = rdlane(hit_db[w], i & 63);
+			if ((i >> wsh()) == w) v = rdlane(hit_db[w], l);
 		return v;
 	}
 	__device__ __forceinline__ uint32_t hsp_of(int i) const {
-		uint32_t v = rdlane(hit_sp[0], i & 63);
+		const int l = i & (wl() - 1);
+		uint32_t v = rdlane(hit_sp[0], l);
 #pragma unroll
 		for (int w = 1; w < HITW; ++w)
-			if ((i >> 6) == w) v = rdlane(hit_sp[w], i & 63);
+			if ((i >> wsh()) == w) v = rdlane(hit_sp[w], l);
 		return v;
 	}
 	uint32_t *hsp_db, *hsp_ql;  // LDS [PE_HSP_CAP]
@@ -99,7 +106,7 @@ struct Mate {
 	__device__ __forceinline__ bool overlaps_hit(uint32_t db) const {
 		bool eq = false;
 #pragma unroll
-		for (int w = 0; w < HITW; ++w) eq |= 64 * w + lane < hitCount && (hit_db[w] >> 6) == (db >> 6);
+		for (int w = 0; w < HITW; ++w) eq |= lane < wl() && (w << wsh()) + lane < hitCount && (hit_db[w] >> 6) == (db >> 6);
 		return __ballot(eq) != 0;
 	}
 
@@ -108,7 +115,7 @@ struct Mate {
 		bool ov = false;
 #pragma unroll
 		for (int w = 0; w < HITW; ++w)
-			for (int k = 0; k < 64 && 64 * w + k < hitCount; ++k) ov |= (rdlane(hit_db[w], k) >> 6) == (db >> 6);
+			for (int k = 0; k < wl() && (w << wsh()) + k < hitCount; ++k) ov |= (rdlane(hit_db[w], k) >> 6) == (db >> 6);
 		return ov;
 	}
 
@@ -127,10 +134,10 @@ struct Mate {
 			else if (score > second) second = score;
 		}
 		if (!keep) return -1;
-		if (hitCount >= (OVF ? PE_HIT_CAP * HITW : hit_cap)) { status |= URMAPX_ST_HIT_OVERFLOW; if (topHit == idx) topHit = -1; return -1; }
+		if (hitCount >= (OVF ? HITW << wsh() : hit_cap)) { status |= URMAPX_ST_HIT_OVERFLOW; if (topHit == idx) topHit = -1; return -1; }
 #pragma unroll
 		for (int w = 0; w < HITW; ++w)
-			if (64 * w + lane == idx) { hit_db[w] = db; hit_sp[w] = ((uint32_t)score << 1) | (plus ? 1u : 0u); }
+			if (lane < wl() && (w << wsh()) + lane == idx) { hit_db[w] = db; hit_sp[w] = ((uint32_t)score << 1) | (plus ? 1u : 0u); }
 		if (lane == 0) hit_nops[idx] = (uint16_t)cand_nops;
 		for (int t = lane; t < cand_nops; t += 64) hit_paths[(size_t)idx * URMAPX_MAX_PATH_OPS + t] = cand[t];
 		__syncthreads();
@@ -745,6 +752,7 @@ __global__ __launch_bounds__(64) void search_pe_kernel(DevIndex X, urmapx_params
 		                           ((size_t)blockIdx.x * 2 + a) * PE_HIT_CAP * M::HITW * URMAPX_MAX_PATH_OPS
 		                     : reinterpret_cast<urmapx_path_op *>(sc) + (size_t)a * PE_HIT_CAP * URMAPX_MAX_PATH_OPS;
 		m[a].hit_cap = (hsp_lds_cap >= 64 && hsp_lds_cap <= PE_HSP_CAP) ? (hsp_lds_cap & ~63) / 4 : PE_HIT_CAP;
+		m[a].hit_wsh = (hsp_lds_cap >= 64 && hsp_lds_cap <= PE_HSP_CAP) ? 4 : 6;
 		m[a].hsp_db = hsp_db[a]; m[a].hsp_ql = hsp_ql[a]; m[a].hsp_sf = hsp_sf[a];
 		m[a].pend[0] = pend[2 * a]; m[a].pend[1] = pend[2 * a + 1];
 		m[a].rowlen = rowlen; m[a].pre = pre; m[a].cq_db = cq_db; m[a].cq_qp = cq_qp;
