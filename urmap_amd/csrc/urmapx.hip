@@ -551,7 +551,8 @@ int urmapx_ctx_gather_microbench(urmapx_ctx *C, uint64_t n_loads, double *loads_
 	HIP_TRY(hipEventSynchronize(e1));
 	float ms = 0;
 	HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-	hipEventDestroy(e0); hipEventDestroy(e1);
+	(void)hipEventDestroy(e0);
+	(void)hipEventDestroy(e1);
 	*loads_per_s = ms > 0 ? (double)per_iter * iters / (ms * 1e-3) : 0.0;
 	return URMAPX_OK;
 }
