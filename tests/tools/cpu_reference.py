@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
-"""CPU side of the comparison on the GPU box's host: the reference binary itself (oracle/_ref/urmap, built from
+"""Test-side tool (it runs the oracle and the compiled reference, so it lives under tests/).
+CPU side of the comparison on the GPU box's host: the reference binary itself (oracle/_ref/urmap, built from
 /root/reference/src by oracle/Makefile; it travels with the repo snapshot) and the oracle port, timed on the same
 FASTQ + .ufi files the product CLI maps.  Prints reads/s (index load excluded for all three).  Diagnostic script."""
 import argparse, os, re, subprocess, sys, time
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, os.path.join(ROOT, "scripts"))
