@@ -278,16 +278,23 @@ static int cmd_map(const Opts &o, int argc, char **argv) {
 					}
 				}
 			}
-			if (ftab && paired) {
-				std::string tabs;
-				char line[4096];
-				for (uint32_t i = 0; i + 1 < n; i += 2) {
-					const unsigned L1 = (unsigned)(j->reads.offs[i + 1] - j->reads.offs[i]), L2 = (unsigned)(j->reads.offs[i + 2] - j->reads.offs[i + 1]);
-					const size_t k = urmapx_tab_pe(I, &j->results[i], &j->results[i + 1], &j->info[i / 2], j->reads.label(i), L1, L2,
-					                               fsam >= 0 ? 1 : 0, line, sizeof line);
-					tabs.append(line, k);
+			if (ftab && paired) {  // tab lines: formatted by all host threads (pair ranges), written in order
+				std::vector<std::string> tabs((size_t)host_threads);
+#pragma omp parallel for schedule(static, 1) num_threads(host_threads)
+				for (int t = 0; t < host_threads; ++t) {
+					const uint32_t u0 = (uint32_t)((uint64_t)units * (uint64_t)t / (uint64_t)host_threads);
+					const uint32_t u1 = (uint32_t)((uint64_t)units * (uint64_t)(t + 1) / (uint64_t)host_threads);
+					char line[4096];
+					for (uint32_t u = u0; u < u1; ++u) {
+						const uint32_t i = 2 * u;
+						const unsigned L1 = (unsigned)(j->reads.offs[i + 1] - j->reads.offs[i]), L2 = (unsigned)(j->reads.offs[i + 2] - j->reads.offs[i + 1]);
+						const size_t k = urmapx_tab_pe(I, &j->results[i], &j->results[i + 1], &j->info[u], j->reads.label(i), L1, L2,
+						                               fsam >= 0 ? 1 : 0, line, sizeof line);
+						tabs[(size_t)t].append(line, k);
+					}
 				}
-				if (fwrite(tabs.data(), 1, tabs.size(), ftab) != tabs.size()) write_failed = true;
+				for (const std::string &tb : tabs)
+					if (fwrite(tb.data(), 1, tb.size(), ftab) != tb.size()) write_failed = true;
 			}
 			t_write += secs(tf1, now());
 			recycled.push(std::move(j));
