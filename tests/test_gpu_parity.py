@@ -222,6 +222,16 @@ def test_cli_map_reproduces_reference_sam(tmp_path, name):
     want = [l for l in open(os.path.join(gold, name + ".sam"), "rb").read().split(b"\n") if l]
     assert got == want
     assert any(l.startswith(b"@PG\tID:urmap") for l in open(out, "rb").read().split(b"\n"))
+    if name == "se150":  # the same reads gzip-compressed, CRLF line ends, several host threads and one
+        fqz = os.path.join(tmp_path, "r.fq.gz")
+        with open(os.path.join(gold, name + ".fq"), "rb") as f, gzip.open(fqz, "wb") as z:
+            z.write(f.read().replace(b"\n", b"\r\n"))
+        for threads in ("1", "7"):
+            out2 = os.path.join(tmp_path, f"out_{threads}.sam")
+            r = subprocess.run([exe, "-map", fqz, "-ufi", ufi, "-samout", out2, "-batch", "100", "-threads", threads],
+                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+            assert r.returncode == 0, r.stderr.decode()[-2000:]
+            assert [l for l in open(out2, "rb").read().split(b"\n") if l and not l.startswith(b"@PG")] == want
 
 
 def test_cli_errors_exit_1(tmp_path):
