@@ -208,6 +208,18 @@ def pmc_traffic(kernel, reads_per_launch, total_bp, read_len=150):
     return None if best is None else round(best)
 
 
+def metric_name(pe, read_len):
+    """BASELINE.json's metric for the headline workload (150 bp single-end); the other modes name themselves."""
+    if pe:
+        return f"reads/s mapped, 2x{read_len} bp PE (-map2) vs hg38-scale index resident in HBM; SAM bit-identical"
+    if read_len != 150:
+        return f"reads/s mapped, {read_len} bp SE vs hg38-scale index resident in HBM; SAM bit-identical"
+    try:
+        return json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
+    except (OSError, ValueError, KeyError):
+        return "reads/s mapped, 150 bp SE vs hg38, at 1/2/4/8 MI355X; SAM bit-identical"
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", 0))
@@ -432,8 +444,7 @@ def main():
                 kern[i]["sector_GBs"] = round(traffic[i] / (kms[i] * 1e-3) / 1e9, 1)
                 kern[i]["frac_of_random_gather_peak"] = round(kern[i]["sector_GBs"] / sector_peak, 4)
         out = {
-            "metric": ("reads/s mapped, 2x150 bp PE (-map2), index resident in HBM, SAM fields bit-identical" if pe else
-                       "reads/s mapped, 150 bp SE, index resident in HBM, SAM fields bit-identical"),
+            "metric": metric_name(pe, L),
             "value": round(reads_per_s, 1),
             "unit": "reads/s",
             "n_gpus": world,
