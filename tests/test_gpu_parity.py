@@ -172,7 +172,7 @@ def test_map_se_matches_oracle(small_case, gpu, read_len, sub, indel, n):
     compare_results(gres, gops, ores, opaths)
 
 
-@pytest.mark.parametrize("lo,hi", [(24, 192), (24, 256), (24, 320)])
+@pytest.mark.parametrize("lo,hi", [(24, 128), (24, 192), (24, 256), (24, 320)])
 def test_map_se_mixed_lengths_in_one_batch(small_case, gpu, lo, hi):
     """A batch is run by the kernel instance of its longest read: reads of every length from W up to the class limit in
     one batch, each class limit in turn."""

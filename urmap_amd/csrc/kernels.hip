@@ -877,6 +877,7 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 // launchers
 // ------------------------------------------------------------------------------------------------
 static int nch_for(uint32_t max_read_len) {
+	if (max_read_len <= 128) return 2;  // 100 bp reads: two mask words, 8 window loads
 	if (max_read_len <= 192) return 3;
 	if (max_read_len <= 256) return 4;  // 250 bp reads: smaller per-read state than the 320-base class, one more wave per SIMD
 	if (max_read_len <= 320) return 5;
@@ -895,7 +896,8 @@ int search_block_count(uint32_t max_read_len, int device) {
 	if (hipGetDeviceProperties(&prop, device) != hipSuccess) return 0;
 	int per_cu = 0;
 	const int nchq = nch_for(max_read_len);
-	hipError_t e = nchq == 3   ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, search_se_kernel<3, false>, 64, 0)
+	hipError_t e = nchq == 2   ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, search_se_kernel<2, false>, 64, 0)
+	               : nchq == 3 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, search_se_kernel<3, false>, 64, 0)
 	               : nchq == 4 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, search_se_kernel<4, false>, 64, 0)
 	                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, search_se_kernel<5, false>, 64, 0);
 	if (e != hipSuccess || per_cu < 1) per_cu = 8;
@@ -935,7 +937,8 @@ hipError_t launch_seed_probe(const DevIndex &X, const uint8_t *d_bases, const ui
 	if (n == 0) return hipSuccess;
 	const int nch = nch_for(max_read_len);
 	dim3 block(256), grid((n + 3) / 4);
-	if (nch == 3) hipLaunchKernelGGL(seed_probe_kernel<3>, grid, block, 0, s, X, d_bases, d_offs, n, out);
+	if (nch == 2) hipLaunchKernelGGL(seed_probe_kernel<2>, grid, block, 0, s, X, d_bases, d_offs, n, out);
+	else if (nch == 3) hipLaunchKernelGGL(seed_probe_kernel<3>, grid, block, 0, s, X, d_bases, d_offs, n, out);
 	else if (nch == 4) hipLaunchKernelGGL(seed_probe_kernel<4>, grid, block, 0, s, X, d_bases, d_offs, n, out);
 	else hipLaunchKernelGGL(seed_probe_kernel<5>, grid, block, 0, s, X, d_bases, d_offs, n, out);
 	return hipGetLastError();
@@ -959,7 +962,11 @@ hipError_t launch_search_se(const DevIndex &X, const urmapx_params &P, const uin
 		if (e != hipSuccess) return e;
 	}
 	dim3 block(64), grid((unsigned)wk.blocks);
-	if (nch == 3)
+	if (nch == 2)
+		hipLaunchKernelGGL((search_se_kernel<2, false>), grid, block, 0, s, X, P, d_bases, d_offs, n, probe, d_results, d_path_ops,
+		                   d_path_used, wk.stats, wk.scratch, wk.scratch_stride, X.seq, X.blob, wk.ticket, wk.hsp_lds_cap,
+		                   wk.ovf_list, (uint2 *)nullptr);
+	else if (nch == 3)
 		hipLaunchKernelGGL((search_se_kernel<3, false>), grid, block, 0, s, X, P, d_bases, d_offs, n, probe, d_results, d_path_ops,
 		                   d_path_used, wk.stats, wk.scratch, wk.scratch_stride, X.seq, X.blob, wk.ticket, wk.hsp_lds_cap,
 		                   wk.ovf_list, (uint2 *)nullptr);
@@ -981,7 +988,11 @@ hipError_t launch_search_se(const DevIndex &X, const urmapx_params &P, const uin
 	// and leave); it runs the same search with the list continued in global scratch
 	dim3 grid2((unsigned)(wk.blocks < SEARCH_OVF_BLOCKS ? wk.blocks : SEARCH_OVF_BLOCKS));
 	uint2 *ovf_base = reinterpret_cast<uint2 *>(wk.scratch + (size_t)wk.blocks * wk.scratch_stride);
-	if (nch == 3)
+	if (nch == 2)
+		hipLaunchKernelGGL((search_se_kernel<2, true>), grid2, block, 0, s, X, P, d_bases, d_offs, n, probe, d_results, d_path_ops,
+		                   d_path_used, (uint32_t *)nullptr, wk.scratch, wk.scratch_stride, X.seq, X.blob, wk.ticket, wk.hsp_lds_cap,
+		                   wk.ovf_list, ovf_base);
+	else if (nch == 3)
 		hipLaunchKernelGGL((search_se_kernel<3, true>), grid2, block, 0, s, X, P, d_bases, d_offs, n, probe, d_results, d_path_ops,
 		                   d_path_used, (uint32_t *)nullptr, wk.scratch, wk.scratch_stride, X.seq, X.blob, wk.ticket, wk.hsp_lds_cap,
 		                   wk.ovf_list, ovf_base);

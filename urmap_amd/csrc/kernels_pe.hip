@@ -1170,7 +1170,9 @@ __global__ __launch_bounds__(64) void search_pe_kernel(DevIndex X, urmapx_params
 	}
 }
 
-static int pe_nch_for(uint32_t max_read_len) { return max_read_len <= 192 ? 3 : (max_read_len <= 256 ? 4 : (max_read_len <= 320 ? 5 : 0)); }
+static int pe_nch_for(uint32_t max_read_len) {
+	return max_read_len <= 128 ? 2 : max_read_len <= 192 ? 3 : max_read_len <= 256 ? 4 : max_read_len <= 320 ? 5 : 0;
+}
 
 size_t search_pe_scratch_stride(uint32_t max_read_len) {
 	const int qmax = 64 * pe_nch_for(max_read_len);
@@ -1189,7 +1191,8 @@ int search_pe_block_count(uint32_t max_read_len, int device) {
 	if (hipGetDeviceProperties(&prop, device) != hipSuccess) return 0;
 	int per_cu = 0;
 	const int nchq = pe_nch_for(max_read_len);
-	hipError_t e = nchq == 3   ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, search_pe_kernel<3, false>, 64, 0)
+	hipError_t e = nchq == 2   ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, search_pe_kernel<2, false>, 64, 0)
+	               : nchq == 3 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, search_pe_kernel<3, false>, 64, 0)
 	               : nchq == 4 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, search_pe_kernel<4, false>, 64, 0)
 	                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, search_pe_kernel<5, false>, 64, 0);
 	if (e != hipSuccess || per_cu < 1) per_cu = 4;
@@ -1209,7 +1212,11 @@ hipError_t launch_search_pe(const DevIndex &X, const urmapx_params &P, const uin
 	}
 	dim3 block(64), grid((unsigned)wk.blocks);
 	const int nch = pe_nch_for(max_read_len);
-	if (nch == 3)
+	if (nch == 2)
+		hipLaunchKernelGGL((search_pe_kernel<2, false>), grid, block, 0, s, X, P, d_bases, d_offs, npairs, probe, d_results,
+		                   d_path_ops, d_path_used, wk.scratch, wk.scratch_stride, X.seq, X.blob, veryfast, wk.ticket, pair_info,
+		                   wk.hsp_lds_cap, wk.ovf_list, (uint2 *)nullptr);
+	else if (nch == 3)
 		hipLaunchKernelGGL((search_pe_kernel<3, false>), grid, block, 0, s, X, P, d_bases, d_offs, npairs, probe, d_results,
 		                   d_path_ops, d_path_used, wk.scratch, wk.scratch_stride, X.seq, X.blob, veryfast, wk.ticket, pair_info,
 		                   wk.hsp_lds_cap, wk.ovf_list, (uint2 *)nullptr);
@@ -1230,7 +1237,11 @@ hipError_t launch_search_pe(const DevIndex &X, const urmapx_params &P, const uin
 	// second pass over the pairs whose HSP lists outgrew LDS (see launch_search_se)
 	dim3 grid2((unsigned)(wk.blocks < PE_OVF_BLOCKS ? wk.blocks : PE_OVF_BLOCKS));
 	uint2 *ovf_base = reinterpret_cast<uint2 *>(wk.scratch + (size_t)wk.blocks * wk.scratch_stride);
-	if (nch == 3)
+	if (nch == 2)
+		hipLaunchKernelGGL((search_pe_kernel<2, true>), grid2, block, 0, s, X, P, d_bases, d_offs, npairs, probe, d_results,
+		                   d_path_ops, d_path_used, wk.scratch, wk.scratch_stride, X.seq, X.blob, veryfast, wk.ticket, pair_info,
+		                   wk.hsp_lds_cap, wk.ovf_list, ovf_base);
+	else if (nch == 3)
 		hipLaunchKernelGGL((search_pe_kernel<3, true>), grid2, block, 0, s, X, P, d_bases, d_offs, npairs, probe, d_results,
 		                   d_path_ops, d_path_used, wk.scratch, wk.scratch_stride, X.seq, X.blob, veryfast, wk.ticket, pair_info,
 		                   wk.hsp_lds_cap, wk.ovf_list, ovf_base);

@@ -102,8 +102,8 @@ struct urmapx_ctx {
 	DevBuf<urmapx_pair_info> pairinfo;
 	DevBuf<uint32_t> ovflist;  // reads queued for the search kernel's second pass
 	uint32_t pairinfo_n = 0;
-	int pe_blocks[3] = {0, 0, 0};
-	int blocks[3] = {0, 0, 0};  // persistent grid size of the search kernel for read length classes <=192, <=320, <=256
+	int pe_blocks[4] = {0, 0, 0, 0};
+	int blocks[4] = {0, 0, 0, 0};  // persistent grid size of the search kernel for read length classes <=192, <=320, <=256
 };
 
 extern "C" {
@@ -328,7 +328,7 @@ int urmapx_map_se_device(urmapx_ctx *C, const void *d_bases, const void *d_offs,
 	int rc = ensure_probe(C, total_bases);
 	if (rc) return rc;
 	ProbeOut po{C->slots.p, C->tallies.p, C->positions.p};
-	const int cls = max_read_len <= 192 ? 0 : (max_read_len <= 256 ? 2 : 1);
+	const int cls = max_read_len <= 128 ? 3 : max_read_len <= 192 ? 0 : (max_read_len <= 256 ? 2 : 1);
 	if (C->blocks[cls] == 0) {
 		C->blocks[cls] = search_block_count(max_read_len, C->device);
 		if (getenv("URMAPX_VERBOSE")) fprintf(stderr, "urmapx: search_se_kernel grid = %d persistent blocks (read class %d)\n", C->blocks[cls], cls);
@@ -431,7 +431,7 @@ int urmapx_map_pe_device(urmapx_ctx *C, const void *d_bases, const void *d_offs,
 	const uint32_t n = 2 * npairs;
 	int rc = ensure_probe(C, total_bases);
 	if (rc) return rc;
-	const int cls = max_read_len <= 192 ? 0 : (max_read_len <= 256 ? 2 : 1);
+	const int cls = max_read_len <= 128 ? 3 : max_read_len <= 192 ? 0 : (max_read_len <= 256 ? 2 : 1);
 	if (C->pe_blocks[cls] == 0) C->pe_blocks[cls] = search_pe_block_count(max_read_len, C->device);
 	if (C->pe_blocks[cls] <= 0) return URMAPX_E_NODEVICE;
 	SearchWork wk;
