@@ -13,6 +13,9 @@ outputs are what the reference itself wrote:
                                                    -samout A.sam -tabbedout A.tab`
   r.fa, r.ufi.gz, pe120_rep_*               repeat-rich second genome: pairs with a second-best pair (see make_repeat_set)
 
+  hitstats.json   the count lines of the reference's end-of-run report (State1::HitStats, state1.cpp:593-632) for the
+                  sets above, incl. -minq 3 runs (python make_golden.py hitstats regenerates only this file)
+
 Run only where /root/reference exists; the fixtures are data, the reference itself does not travel.
 """
 import gzip
@@ -70,6 +73,42 @@ def make_repeat_set(tmp):
     shutil.copy(os.path.join(tmp, name + "_nosam.tab"), os.path.join(HERE, name + "_nosam.tab"))
 
 
+HITSTATS_CASES = [  # (key, mode, read set, index, extra options)
+    ("se150", "map", "se150", "g", []), ("se250", "map", "se250", "g", []), ("se_short", "map", "se_short", "g", []),
+    ("se150_minq3", "map", "se150", "g", ["-minq", "3"]),
+    ("pe150", "map2", "pe150", "g", []), ("pe100_noisy", "map2", "pe100_noisy", "g", []),
+    ("pe100_noisy_minq3", "map2", "pe100_noisy", "g", ["-minq", "3"]),
+    ("pe120_rep_minq25", "map2", "pe120_rep", "r", ["-minq", "25"]),
+]
+
+
+def hitstats_lines(stderr_text):
+    """The four count lines of the report; the timing lines are not comparable."""
+    keep = ("  Reads (", "  Mapped Q>=", "  Mapped Q< ", "  Unmapped (", "WARNING: Option -minq")
+    return [ln for ln in stderr_text.replace("\r", "\n").split("\n") if any(k in ln for k in keep)]
+
+
+def make_hitstats(tmp):
+    import json
+    for g in ("g", "r"):
+        with gzip.open(os.path.join(HERE, g + ".ufi.gz"), "rb") as z, open(os.path.join(tmp, g + ".ufi"), "wb") as f:
+            f.write(z.read())
+    out = {}
+    for key, mode, name, g, extra in HITSTATS_CASES:
+        if mode == "map":
+            shutil.copy(os.path.join(HERE, name + ".fq"), os.path.join(tmp, name + ".fq"))
+            args = ["-map", name + ".fq"]
+        else:
+            for suf in ("_1.fq", "_2.fq"):
+                shutil.copy(os.path.join(HERE, name + suf), os.path.join(tmp, name + suf))
+            args = ["-map2", name + "_1.fq", "-reverse", name + "_2.fq"]
+        r = ol.run_ref(args + ["-ufi", g + ".ufi", "-samout", "hs.sam", "-threads", "1"] + extra, cwd=tmp)
+        out[key] = hitstats_lines(r.stderr.decode())
+    with open(os.path.join(HERE, "hitstats.json"), "w") as f:
+        json.dump(out, f, indent=1)
+        f.write("\n")
+
+
 def main():
     assert ol.have_ref(), "build oracle/_ref/urmap first (make -C oracle ref)"
     tmp = os.path.join(HERE, "_tmp")
@@ -119,9 +158,16 @@ def main():
             f.write(b"\n".join(ol.sam_records(os.path.join(tmp, name + ".sam"))) + b"\n")
         shutil.copy(os.path.join(tmp, name + ".tab"), os.path.join(HERE, name + ".tab"))
     make_repeat_set(tmp)
+    make_hitstats(tmp)
     shutil.rmtree(tmp)
     print("golden fixtures written to", HERE)
 
 
 if __name__ == "__main__":
-    main()
+    if sys.argv[1:] == ["hitstats"]:
+        _tmp = os.path.join(HERE, "_tmp")
+        os.makedirs(_tmp, exist_ok=True)
+        make_hitstats(_tmp)
+        shutil.rmtree(_tmp)
+    else:
+        main()

@@ -234,6 +234,44 @@ def test_cli_map_reproduces_reference_sam(tmp_path, name):
             assert [l for l in open(out2, "rb").read().split(b"\n") if l and not l.startswith(b"@PG")] == want
 
 
+HITSTATS_CASES = [("se150", "map", "se150", "g", []), ("se250", "map", "se250", "g", []),
+                  ("se_short", "map", "se_short", "g", []), ("se150_minq3", "map", "se150", "g", ["-minq", "3"]),
+                  ("pe150", "map2", "pe150", "g", []), ("pe100_noisy", "map2", "pe100_noisy", "g", []),
+                  ("pe100_noisy_minq3", "map2", "pe100_noisy", "g", ["-minq", "3"]),
+                  ("pe120_rep_minq25", "map2", "pe120_rep", "r", ["-minq", "25"])]
+
+
+@pytest.mark.parametrize("key,mode,name,g,extra", HITSTATS_CASES)
+def test_cli_hitstats_report_equals_reference(tmp_path, key, mode, name, g, extra):
+    """End-of-run report on stderr (State1::HitStats, state1.cpp:593-632; counters output1.cpp:20-30, output2.cpp:14-15):
+    the Reads / Mapped Q>= / Mapped Q< / Unmapped lines equal the reference binary's (tests/golden/hitstats.json), incl.
+    -minq being read by -map2 only (map2.cpp:76) and the "not used" warning under -map."""
+    import gzip
+    import json
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gold = os.path.join(root, "tests", "golden")
+    exe = os.path.join(root, "urmap_amd", "urmap")
+    want = json.load(open(os.path.join(gold, "hitstats.json")))[key]
+    ufi = os.path.join(tmp_path, g + ".ufi")
+    with gzip.open(os.path.join(gold, g + ".ufi.gz"), "rb") as z, open(ufi, "wb") as f:
+        f.write(z.read())
+    if mode == "map":
+        args = ["-map", os.path.join(gold, name + ".fq")]
+    else:
+        args = ["-map2", os.path.join(gold, name + "_1.fq"), "-reverse", os.path.join(gold, name + "_2.fq")]
+    r = subprocess.run([exe] + args + ["-ufi", ufi, "-samout", os.path.join(tmp_path, "o.sam"), "-batch", "96"] + extra,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    keep = ("  Reads (", "  Mapped Q>=", "  Mapped Q< ", "  Unmapped (", "WARNING: Option -minq")
+    got = [ln for ln in r.stderr.decode().split("\n") if any(k in ln for k in keep)]
+    assert got == want
+    rq = subprocess.run([exe] + args + ["-ufi", ufi, "-samout", os.path.join(tmp_path, "q.sam"), "-quiet"],
+                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert rq.returncode == 0 and b"Mapped" not in rq.stderr
+
+
 def test_cli_errors_exit_1(tmp_path):
     """Die(): message on stderr, exit status 1 (myutils.cpp:915)."""
     import os

@@ -120,3 +120,28 @@ def test_oracle_tabbedout_equals_reference_golden(tmp_path, name, ufi_gz, with_s
     if with_sam:
         assert ol.sam_records(os.path.join(tmp_path, "o.sam")) == \
             [l for l in open(os.path.join(GOLD, name + ".sam"), "rb").read().split(b"\n") if l]
+
+
+@pytest.mark.parametrize("key,mode,name,minq", [("se150", "map", "se150", 10), ("se250", "map", "se250", 10),
+                                                ("se_short", "map", "se_short", 10), ("pe150", "map2", "pe150", 10),
+                                                ("pe100_noisy", "map2", "pe100_noisy", 10),
+                                                ("pe100_noisy_minq3", "map2", "pe100_noisy", 3)])
+def test_oracle_hitstats_equal_reference_report(gold_ufi, key, mode, name, minq):
+    """UpdateHitStats (output1.cpp:20-30): no top hit -> unmapped, else MAPQ >= minq -> accepted, else rejected.  The
+    oracle's per-read results give the counts the reference binary printed (tests/golden/hitstats.json)."""
+    import json
+    import re
+    from urmap_amd import api
+    want = json.load(open(os.path.join(GOLD, "hitstats.json")))[key]
+    idx = ol.Index.load(gold_ufi)
+    if mode == "map":
+        _, bases, offs, _ = api.read_fastq_arrays(os.path.join(GOLD, name + ".fq"))
+        res, _, _ = idx.map_se(bases, offs)
+    else:
+        _, bases, offs, _ = api.interleave_pairs(api.read_fastq_arrays(os.path.join(GOLD, name + "_1.fq")),
+                                                 api.read_fastq_arrays(os.path.join(GOLD, name + "_2.fq")))
+        res, _, _ = idx.map_pe(bases, offs)
+    mapped = res["dbpos"] != 0xFFFFFFFF
+    counts = [len(res), int((mapped & (res["mapq"] >= minq)).sum()), int((mapped & (res["mapq"] < minq)).sum()),
+              int((~mapped).sum())]
+    assert [int(re.match(r"\s*([\d,]+)", ln).group(1).replace(",", "")) for ln in want[:4]] == counts

@@ -46,7 +46,7 @@ using namespace urx;
 
 struct Opts {
 	std::string map, map2, reverse, make_ufi, ufi, samout, tabbedout, output;
-	bool veryfast = false, quiet = false;
+	bool veryfast = false, quiet = false, minq_given = false;
 	unsigned threads = 0, wordlength = 24, maxix = 0, minq = 10;
 	unsigned long long slots = 0;
 	int gpu = 0;
@@ -74,7 +74,7 @@ static Opts parse(int argc, char **argv) {
 		else if (a == "-wordlength") o.wordlength = (unsigned)atoi(val());
 		else if (a == "-maxix") o.maxix = (unsigned)atoi(val());
 		else if (a == "-slots") o.slots = strtoull(val(), nullptr, 10);
-		else if (a == "-minq") o.minq = (unsigned)atoi(val());
+		else if (a == "-minq") { o.minq = (unsigned)atoi(val()); o.minq_given = true; }
 		else if (a == "-gpu") o.gpu = atoi(val());
 		else if (a == "-batch") o.batch = (unsigned)atoi(val());
 		else if (a == "-veryfast") o.veryfast = true;
@@ -143,6 +143,7 @@ extern "C" size_t urmapx_sam_pe(const urmapx_index *, const urmapx_result *, con
 
 static int cmd_map(const Opts &o, int argc, char **argv) {
 	const bool paired = !o.map2.empty();
+	const unsigned minq = paired ? o.minq : 10;  // only cmd_map2 reads -minq (map2.cpp:76); -map keeps State1::m_Minq = 10
 	if (paired && o.reverse.empty()) die("-reverse required");
 	if (o.ufi.empty()) die("-ufi option required");
 	const auto t0 = std::chrono::steady_clock::now();
@@ -254,7 +255,7 @@ static int cmd_map(const Opts &o, int argc, char **argv) {
 					// HitStats counters (output1.cpp:20-30)
 					if (r.status) ++c.unsupported;
 					if (r.dbpos == 0xFFFFFFFFu) ++c.nohit;
-					else if (r.mapq >= o.minq) ++c.accept;
+					else if (r.mapq >= minq) ++c.accept;
 					else ++c.reject;
 				}
 			}
@@ -332,12 +333,38 @@ static int cmd_map(const Opts &o, int argc, char **argv) {
 	if (getenv("URMAPX_VERBOSE"))
 		fprintf(stderr, "stage busy seconds: parse %.2f, gpu (copies + kernels) %.2f, format %.2f, write %.2f; %d host threads\n",
 		        t_parse, t_gpu, t_format, t_write, host_threads);
-	if (!o.quiet) {
+	if (!o.quiet) {  // State1::HitStats (state1.cpp:593-632): same lines, sub-second timers, "GPU n" where it says "n threads"
 		auto pct = [&](unsigned long long x) { return n_reads ? 100.0 * (double)x / (double)n_reads : 0.0; };
-		fprintf(stderr, "\n%16.1f  Seconds to load index\n%16.1f  Seconds in mapper\n%16llu  Reads\n", load_s, map_s, n_reads);
+		auto commas = [](unsigned long long x) {  // IntToStrCommas (myutils.cpp:1400-1418)
+			std::string d = std::to_string(x), r;
+			for (size_t i = 0; i < d.size(); ++i) {
+				if (i && (d.size() - i) % 3 == 0) r += ',';
+				r += d[i];
+			}
+			return r;
+		};
+		auto short_int = [](unsigned long long x) {  // IntToStr (myutils.cpp:1420-1438): the unit steps
+			char b[64];
+			const double d = (double)x;
+			if (x < 10000) snprintf(b, sizeof b, "%u", (unsigned)x);
+			else if (d < 1e6) snprintf(b, sizeof b, "%.1fk", d / 1e3);
+			else if (d < 100e6) snprintf(b, sizeof b, "%.1fM", d / 1e6);
+			else if (d < 1e9) snprintf(b, sizeof b, "%.0fM", d / 1e6);
+			else if (d < 10e9) snprintf(b, sizeof b, "%.1fG", d / 1e9);
+			else if (d < 100e9) snprintf(b, sizeof b, "%.0fG", d / 1e9);
+			else snprintf(b, sizeof b, "%.3g", d);
+			return std::string(b);
+		};
+		fprintf(stderr, "\n%16.1f  Seconds to load index\n", load_s);
+		if (map_s < 180) fprintf(stderr, "%16.1f  Seconds in mapper\n", map_s);
+		else if (map_s < 2 * 60 * 60) fprintf(stderr, "%16.1f  Minutes in mapper\n", map_s / 60.0);
+		else fprintf(stderr, "%16.1f  Hours in mapper\n", map_s / 3600.0);
+		fprintf(stderr, "%16s  Reads (%s)\n", commas(n_reads).c_str(), short_int(n_reads).c_str());
 		fprintf(stderr, "%16.0f  Reads/sec. (GPU %d)\n", map_s > 0 ? (double)n_reads / map_s : 0.0, o.gpu);
-		fprintf(stderr, "%16llu  Mapped Q>=%u (%.1f%%)\n%16llu  Mapped Q< %u (%.1f%%)\n%16llu  Unmapped (%.1f%%)\n", n_accept,
-		        o.minq, pct(n_accept), n_reject, o.minq, pct(n_reject), n_nohit, pct(n_nohit));
+		fprintf(stderr, "%16s  Mapped Q>=%u (%.1f%%)\n", commas(n_accept).c_str(), minq, pct(n_accept));
+		fprintf(stderr, "%16s  Mapped Q< %u (%.1f%%)\n", commas(n_reject).c_str(), minq, pct(n_reject));
+		fprintf(stderr, "%16s  Unmapped (%.1f%%)\n\n", commas(n_nohit).c_str(), pct(n_nohit));
+		if (o.minq_given && !paired) fprintf(stderr, "\nWARNING: Option -minq not used\n\n");
 	}
 	urmapx_ctx_destroy(C);
 	urmapx_index_close(I);
