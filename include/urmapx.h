@@ -122,7 +122,7 @@ int urmapx_map_se(urmapx_ctx *, const uint8_t *bases, const uint64_t *offs, uint
  * (bases, offs) are the two mates of pair i (R1, R2).  results[2*npairs]: per mate the hit AdjustTopHitsAndMapqs
  * (search2.cpp:8-57) settled on, after SetMappedPos; `score` is that hit's score.  Flags, RNEXT/PNEXT and TLEN are
  * host-side text (urmapx_sam_pe).  Device-domain limits as urmapx_map_se, plus read length <= 279 (the reference
- * keeps pending seed positions in a byte, state1.h:86-87). */
+ * keeps pending seed positions in a byte, state1.h:86-87, and crashes on longer pairs). */
 int urmapx_map_pe(urmapx_ctx *, const uint8_t *bases, const uint64_t *offs, uint32_t npairs, urmapx_result *results,
                   urmapx_path_op *path_ops, size_t path_cap, size_t *path_used);
 
