@@ -69,6 +69,28 @@ inline size_t line_len(const char *s, const char *e) {
 	for (const char *c = (const char *)memchr(s, '\r', n); c; c = (const char *)memchr(c + 1, '\r', (size_t)(e - c - 1))) --n;
 	return n;
 }
+// letters = bytes in [A-Za-z]; other = bytes that are neither a letter nor '\r'.  Eight bytes per step.
+inline void count_letters(const char *s, const char *e, size_t &letters, size_t &other) {
+	const uint64_t K01 = 0x0101010101010101ull, K80 = 0x80 * K01, K7F = 0x7F * K01;
+	size_t nl = 0, ncr = 0;
+	const size_t n = (size_t)(e - s);
+	for (; s + 8 <= e; s += 8) {
+		uint64_t w;
+		memcpy(&w, s, 8);
+		const uint64_t x = (w | 0x20 * K01) & K7F;                                   // case folded, 7 bits
+		const uint64_t ge_a = x + (0x80 - 'a') * K01, gt_z = x + (0x80 - 'z' - 1) * K01;  // bit 7: x >= 'a', x > 'z'
+		nl += (size_t)__builtin_popcountll(ge_a & ~gt_z & ~w & K80);
+		const uint64_t y = w ^ 0x0D * K01;                                            // zero byte where '\r'
+		ncr += (size_t)__builtin_popcountll(~(((y & K7F) + K7F) | y) & K80);
+	}
+	for (; s < e; ++s) {
+		const unsigned char u = (unsigned char)*s;
+		nl += (unsigned char)((u | 0x20u) - 'a') < 26u;
+		ncr += u == '\r';
+	}
+	letters = nl;
+	other = n - nl - ncr;
+}
 inline void line_copy(char *dst, const char *s, const char *e) {
 	if (!memchr(s, '\r', (size_t)(e - s))) { memcpy(dst, s, (size_t)(e - s)); return; }
 	for (; s < e; ++s)
@@ -152,10 +174,10 @@ bool FastqReader::next_batch(FastqBatch &B, uint32_t max_reads, std::string &err
 			ok = *c == '@';
 		}
 		const char *s2 = lstart(4 * i + 1), *e2 = lend(4 * i + 1);
-		const size_t l2 = line_len(s2, e2);
-		if (ok)
-			for (const char *c = s2; c < e2; ++c)
-				if (*c != '\r' && !isalpha((unsigned char)*c)) { ok = false; break; }
+		size_t l2, other;  // letters (isalpha in the C locale), and bytes that are neither a letter nor '\r'
+		count_letters(s2, e2, l2, other);
+		if (other) ok = false;
+		l2 += other;  // the line's length without its '\r's
 		const size_t l4 = line_len(lstart(4 * i + 3), lend(4 * i + 3));
 		if (l4 != l2) ok = false;
 		blen[i] = (uint32_t)l2;
