@@ -4,6 +4,7 @@
 #include <unistd.h>
 #include <zlib.h>
 
+#include <algorithm>
 #include <cctype>
 #include <cstring>
 
@@ -104,11 +105,13 @@ bool FastqReader::next_batch(FastqBatch &B, uint32_t max_reads, std::string &err
 	// 1. line ends of up to max_reads records (a final unterminated line counts)
 	const size_t want = 4 * (size_t)max_reads;
 	ends_.clear();
-	size_t scan = 0;
+	size_t scan = beg_;
+	// bytes the missing lines are likely to take, from the line length seen so far (a little over: a short read is a second pass)
+	auto likely_bytes = [&]() { return (size_t)((double)(want - ends_.size()) * bytes_per_line_ * 1.02) + 4096; };
 	for (;;) {
 		while (ends_.size() < want && scan < have_) {
 			// look ahead about as far as the missing lines are likely to reach; big windows are scanned by all threads
-			size_t win = (want - ends_.size()) * 160;
+			size_t win = likely_bytes();
 			if (win < (1u << 20)) win = 1u << 20;
 			if (win > have_ - scan) win = have_ - scan;
 			const char *w0 = buf_.data() + scan;
@@ -145,18 +148,26 @@ bool FastqReader::next_batch(FastqBatch &B, uint32_t max_reads, std::string &err
 			}
 		}
 		if (ends_.size() >= want || eof_) break;
-		if (have_ == buf_.size()) buf_.resize(buf_.size() * 2);
-		const size_t n = read_some(buf_.data() + have_, buf_.size() - have_);
+		// read what the batch still needs, not the whole buffer: whatever is left over is carried to the next call
+		size_t ask = likely_bytes();
+		if (ask < (1u << 20)) ask = 1u << 20;
+		if (buf_.size() - have_ < ask && beg_) {  // consumed input in front: move the rest down (line ends found so far move with it)
+			memmove(buf_.data(), buf_.data() + beg_, have_ - beg_);
+			for (size_t &e : ends_) e -= beg_;
+			scan -= beg_; have_ -= beg_; beg_ = 0;
+		}
+		if (buf_.size() - have_ < ask) buf_.resize(std::max(buf_.size() * 2, have_ + ask));
+		const size_t n = read_some(buf_.data() + have_, ask);
 		if (n == 0) eof_ = true;
 		have_ += n;
 	}
-	const size_t last_end = ends_.empty() ? 0 : ends_.back() + 1;
+	const size_t last_end = ends_.empty() ? beg_ : ends_.back() + 1;
 	bool virtual_tail = false;
 	if (eof_ && ends_.size() < want && last_end < have_) { ends_.push_back(have_); virtual_tail = true; }
 	const size_t nlines = ends_.size();
 	if (nlines == 0) { finished_ = true; return false; }
 	const char *base = buf_.data();
-	auto lstart = [&](size_t k) { return base + (k == 0 ? 0 : ends_[k - 1] + 1); };
+	auto lstart = [&](size_t k) { return base + (k == 0 ? beg_ : ends_[k - 1] + 1); };
 	auto lend = [&](size_t k) { return base + ends_[k]; };
 	size_t nrec = nlines / 4;
 	// 2. validate all complete records (parallel); the lowest-numbered problem wins
@@ -214,17 +225,17 @@ bool FastqReader::next_batch(FastqBatch &B, uint32_t max_reads, std::string &err
 			// blank lines are only allowed at end of file (fastqseqsource.cpp:31-43)
 			bool only_blank = true;
 			for (size_t j = k; j < nlines && only_blank; ++j) only_blank = line_len(lstart(j), lend(j)) == 0;
-			size_t pos = nlines ? (virtual_tail ? have_ : ends_.back() + 1) : 0;
+			size_t pos = virtual_tail ? have_ : ends_.back() + 1;
 			while (only_blank) {
 				for (; pos < have_ && only_blank; ++pos) only_blank = buf_[pos] == '\n' || buf_[pos] == '\r';
 				if (!only_blank || eof_) break;
 				have_ = read_some(buf_.data(), buf_.size());
-				pos = 0;
+				pos = beg_ = 0;
 				if (have_ == 0) eof_ = true;
 			}
 			if (!only_blank) { err = "Empty line in FASTQ file '" + path_ + "'"; return false; }
 			finished_ = true;
-			have_ = 0;
+			have_ = beg_ = 0;
 			return nrec > 0;
 		}
 		const uint64_t ln = line_nr_ + 1;
@@ -239,10 +250,11 @@ bool FastqReader::next_batch(FastqBatch &B, uint32_t max_reads, std::string &err
 		      std::to_string(ln + 3) + " file " + path_;
 		return false;
 	}
-	// keep the unconsumed tail for the next call
-	const size_t consumed = leftover_from == 0 ? 0 : (leftover_from == nlines && virtual_tail ? have_ : ends_[leftover_from - 1] + 1);
-	if (consumed < have_) memmove(buf_.data(), buf_.data() + consumed, have_ - consumed);
-	have_ -= consumed;
+	// the unconsumed tail stays where it is for the next call
+	const size_t consumed = leftover_from == 0 ? beg_ : (leftover_from == nlines && virtual_tail ? have_ : ends_[leftover_from - 1] + 1);
+	if (nrec) bytes_per_line_ = (double)(consumed - beg_) / (double)(4 * nrec);
+	beg_ = consumed;
+	if (beg_ == have_) beg_ = have_ = 0;
 	if (eof_ && have_ == 0) finished_ = true;
 	return nrec > 0;
 }

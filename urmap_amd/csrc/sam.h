@@ -72,7 +72,8 @@ private:
 	FILE *f_ = nullptr;
 	void *gz_ = nullptr;
 	std::vector<char> buf_;
-	size_t have_ = 0;  // valid bytes in buf_ (unconsumed input)
+	size_t beg_ = 0, have_ = 0;  // unconsumed input = buf_[beg_, have_)
+	double bytes_per_line_ = 160;  // running estimate, sizes the reads and the scan windows
 	uint64_t file_off_ = 0;  // plain files: next byte to read
 	bool eof_ = false, finished_ = false;
 	uint64_t line_nr_ = 0;  // lines consumed so far
