@@ -188,7 +188,24 @@ static int cmd_map(const Opts &o, int argc, char **argv) {
 	auto now = [] { return std::chrono::steady_clock::now(); };
 	auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
 	std::string reader_err;
+	// -map2: the second file is parsed by its own thread while the reader parses the first
+	struct Side { FastqBatch b; std::string e; bool more = false; } side2;
+	Channel<int> go2(1), done2(1);
+	std::thread reader2;
+	if (paired)
+		reader2 = std::thread([&] {
+			omp_set_num_threads(std::max(1, host_threads / 2));  // a new thread starts from the default team size, not main's
+			int x;
+			while (go2.pop(x)) {
+				side2.b.clear();
+				side2.e.clear();
+				side2.more = rd2.next_batch(side2.b, o.batch / 2, side2.e);
+				done2.push(1);
+			}
+		});
 	std::thread reader([&] {
+		omp_set_num_threads(paired ? std::max(1, host_threads - host_threads / 2) : host_threads);
+		FastqBatch a;
 		for (;;) {
 			std::unique_ptr<Job> j;
 			if (!recycled.try_pop(j)) j = std::make_unique<Job>();
@@ -199,14 +216,19 @@ static int cmd_map(const Opts &o, int argc, char **argv) {
 			if (!paired)
 				more = rd.next_batch(j->reads, o.batch, e);
 			else {  // mates interleaved: reads 2i, 2i+1 (map2.cpp:27-32 reads one record from each file under one lock)
-				FastqBatch a, b;
-				a.clear(); b.clear();
+				go2.push(1);
+				a.clear();
 				more = rd.next_batch(a, o.batch / 2, e);
-				std::string e2;
-				bool more2 = rd2.next_batch(b, o.batch / 2, e2);
-				if (e.empty()) e = e2;
-				if (e.empty() && (more != more2 || a.size() != b.size())) e = std::string("Premature end of file in FASTQ") + (a.size() > b.size() ? "2" : "1");
-				if (e.empty()) interleave_batches(a, b, j->reads);
+				int x;
+				done2.pop(x);
+				const FastqBatch &b = side2.b;
+				if (e.empty()) e = side2.e;
+				if (e.empty() && (more != side2.more || a.size() != b.size())) e = std::string("Premature end of file in FASTQ") + (a.size() > b.size() ? "2" : "1");
+				if (e.empty()) {
+					omp_set_num_threads(host_threads);
+					interleave_batches(a, b, j->reads);
+					omp_set_num_threads(std::max(1, host_threads - host_threads / 2));
+				}
 			}
 			t_parse += secs(tp0, now());
 			if (!e.empty()) { reader_err = e; break; }
@@ -214,9 +236,11 @@ static int cmd_map(const Opts &o, int argc, char **argv) {
 			parsed.push(std::move(j));
 		}
 		parsed.close();
+		go2.close();
 	});
 	unsigned long long n_reads = 0, n_accept = 0, n_reject = 0, n_nohit = 0, n_unsupported = 0;
 	std::thread writer([&] {
+		omp_set_num_threads(host_threads);
 		// SAM text of a batch is formatted by all host threads, each on a contiguous range of reads (pairs), and the
 		// pieces are written at their file offsets in input order.
 		std::unique_ptr<Job> j;
@@ -322,6 +346,7 @@ static int cmd_map(const Opts &o, int argc, char **argv) {
 	}
 	mapped.close();
 	reader.join();
+	if (reader2.joinable()) reader2.join();
 	writer.join();
 	if (!reader_err.empty()) die("%s", reader_err.c_str());
 	if (fsam >= 0) close(fsam);
