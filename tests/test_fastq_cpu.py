@@ -71,14 +71,21 @@ def test_empty_file_and_missing_file(tmp_path):
 
 @pytest.mark.parametrize("bad,msg", [
     (b"@a\nACGT\n+\nIIII\nXa\nACGT\n+\nIIII\n", "expected '@'"),
-    (b"@a\nAC1T\n+\nIIII\n", "Invalid sequence letter"),
-    (b"@a\nACGT\n+\nIII\n", "Bad FASTQ record: 4 bases, 3 quals"),
-    (b"@a\nACGT\n+\n", "Unexpected end-of-file"),
-    (b"@a\n", "Unexpected end-of-file"),
-    (b"@a\nACGT\n+\nIIII\n\n@b\nACGT\n+\nIIII\n", "Empty line in FASTQ file"),
+    (b"@a\nAC1T\n+\nIIII\n", "Invalid sequence letter '1' in FASTQ, line 2 file "),
+    (b"@a\nACGT\n+\nIIII\n@b\nAC-T\n+\nIIII\n", "Invalid sequence letter '-' in FASTQ, line 6 file "),
+    (b"@a b c\nAC\x01T\n+\nIIII\n", r"Non-printing byte 0x01 in FASTQ sequence line 2 file \S+ label a b c$"),
+    (b"@a\nACGT\n+\nIII\n", r"Bad FASTQ record: 4 bases, 3 quals line 4 file \S+ label a$"),
+    (b"@a\nACGT\n+\nIIII\n@lab two\nACGTA\n+\nIIII\n", r"Bad FASTQ record: 5 bases, 4 quals line 8 file \S+ label lab two$"),
+    (b"@a\nACGT\n+\n", "Unexpected end-of-file in FASTQ file "),
+    (b"@a\n", "Unexpected end-of-file in FASTQ file "),
+    (b"@a\nACGT\n+\nIIII\n\n@b\nACGT\n+\nIIII\n", "Empty line nr 5 in FASTQ file '"),
+    (b"@a\nACGT\n+\nIIII\n\n\r\n\n@b\nACGT\n+\nIIII\n", "Empty line nr 7 in FASTQ file '"),
 ])
 @pytest.mark.parametrize("batch", [1, 100])
 def test_reader_errors_use_reference_messages(tmp_path, bad, msg, batch):
+    """Message formats of FASTQSeqSource::GetNextLo (fastqseqsource.cpp:31-43, 46-51, 67-84, 95-106); the first, third,
+    fourth, sixth and seventh were also compared with the reference binary's stderr (it crashes instead of reporting
+    when the problem comes after a good record)."""
     p = tmp_path / "bad.fq"
     p.write_bytes(bad)
     rd = api.FastqReader(str(p))
@@ -113,3 +120,24 @@ def test_large_file_crosses_buffer_boundaries(tmp_path):
         n += k
     assert n == reps * 1000
     os.remove(p)
+
+
+def test_sequence_letter_rule_at_every_offset(tmp_path):
+    """The sequence line must be letters only (isalpha, fastqseqsource.cpp:70-77): every A-Z / a-z byte is accepted,
+    the bytes just outside the two ranges and bytes >= 0x80 are refused wherever they stand (the check runs eight
+    bytes at a time with a tail), and a '\\r' inside the line is dropped, not refused."""
+    L = 21
+    letters = bytes(range(ord("A"), ord("Z") + 1)) + bytes(range(ord("a"), ord("z") + 1))
+    p = tmp_path / "ok.fq"
+    p.write_bytes(b"@all\n" + letters + b"\n+\n" + b"I" * len(letters) + b"\n@cr\nAC\rGT\r\n+\nIIII\r\n")
+    got = _read_all(str(p), 10)
+    assert got == [(b"all", letters, b"I" * len(letters)), (b"cr", b"ACGT", b"IIII")]
+    for badbyte in (b"@", b"[", b"`", b"{", b"0", b" ", b"\xc1", b"\xe1", b"\x8d", b"\x00"):
+        for at in range(L):
+            seq = b"A" * at + badbyte + b"C" * (L - 1 - at)
+            p = tmp_path / "bad.fq"
+            p.write_bytes(b"@r\n" + seq + b"\n+\n" + b"I" * L + b"\n")
+            rd = api.FastqReader(str(p))
+            with pytest.raises(ValueError, match="Invalid sequence letter '|Non-printing byte 0x"):
+                rd.next(10)
+            rd.close()

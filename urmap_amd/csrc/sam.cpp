@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <cctype>
+#include <cstdio>
 #include <cstring>
 
 namespace urx {
@@ -222,18 +223,26 @@ bool FastqReader::next_batch(FastqBatch &B, uint32_t max_reads, std::string &err
 		auto text = [&](size_t j) { std::string t(line_len(lstart(j), lend(j)), 0); line_copy(&t[0], lstart(j), lend(j)); return t; };
 		const std::string l1 = text(k);
 		if (l1.empty()) {
-			// blank lines are only allowed at end of file (fastqseqsource.cpp:31-43)
+			// blank lines are only allowed at end of file (fastqseqsource.cpp:31-43); the message carries the number of
+			// the last blank line before the text
 			bool only_blank = true;
-			for (size_t j = k; j < nlines && only_blank; ++j) only_blank = line_len(lstart(j), lend(j)) == 0;
+			uint64_t blanks = 0;
+			for (size_t j = k; j < nlines && only_blank; ++j) {
+				only_blank = line_len(lstart(j), lend(j)) == 0;
+				blanks += only_blank;
+			}
 			size_t pos = virtual_tail ? have_ : ends_.back() + 1;
 			while (only_blank) {
-				for (; pos < have_ && only_blank; ++pos) only_blank = buf_[pos] == '\n' || buf_[pos] == '\r';
+				for (; pos < have_ && only_blank; ++pos) {
+					only_blank = buf_[pos] == '\n' || buf_[pos] == '\r';
+					blanks += buf_[pos] == '\n';
+				}
 				if (!only_blank || eof_) break;
 				have_ = read_some(buf_.data(), buf_.size());
 				pos = beg_ = 0;
 				if (have_ == 0) eof_ = true;
 			}
-			if (!only_blank) { err = "Empty line in FASTQ file '" + path_ + "'"; return false; }
+			if (!only_blank) { err = "Empty line nr " + std::to_string(line_nr_ + blanks) + " in FASTQ file '" + path_ + "'"; return false; }
 			finished_ = true;
 			have_ = beg_ = 0;
 			return nrec > 0;
@@ -243,11 +252,17 @@ bool FastqReader::next_batch(FastqBatch &B, uint32_t max_reads, std::string &err
 		if (k + 1 >= nlines) { err = "Unexpected end-of-file in FASTQ file " + path_; return false; }
 		const std::string l2 = text(k + 1);
 		for (unsigned char c : l2)
-			if (!isalpha(c)) { err = "Invalid sequence letter in FASTQ, line " + std::to_string(ln + 1) + " file " + path_; return false; }
+			if (!isalpha(c)) {  // fastqseqsource.cpp:76-84
+				char hex[8];
+				snprintf(hex, sizeof hex, "0x%02x", c);
+				if (isprint(c)) err = std::string("Invalid sequence letter '") + (char)c + "' in FASTQ, line " + std::to_string(ln + 1) + " file " + path_;
+				else err = std::string("Non-printing byte ") + hex + " in FASTQ sequence line " + std::to_string(ln + 1) + " file " + path_ + " label " + l1.substr(1);
+				return false;
+			}
 		if (k + 3 >= nlines) { err = "Unexpected end-of-file in FASTQ file " + path_; return false; }
 		const std::string l4 = text(k + 3);
 		err = "Bad FASTQ record: " + std::to_string(l2.size()) + " bases, " + std::to_string(l4.size()) + " quals line " +
-		      std::to_string(ln + 3) + " file " + path_;
+		      std::to_string(ln + 3) + " file " + path_ + " label " + l1.substr(1);
 		return false;
 	}
 	// the unconsumed tail stays where it is for the next call
