@@ -141,3 +141,23 @@ def test_sequence_letter_rule_at_every_offset(tmp_path):
             with pytest.raises(ValueError, match="Invalid sequence letter '|Non-printing byte 0x"):
                 rd.next(10)
             rd.close()
+
+
+def test_reader_takes_a_fifo(tmp_path):
+    """A named pipe (e.g. `-map <(zcat reads.fq.gz)`) cannot be read at offsets: it is consumed front to back."""
+    import threading
+    recs = _records(5000, L=0, seed=11)
+    data = _text(recs)
+    p = str(tmp_path / "pipe.fq")
+    os.mkfifo(p)
+
+    def feed():
+        with open(p, "wb") as f:
+            for i in range(0, len(data), 70001):
+                f.write(data[i:i + 70001])
+    t = threading.Thread(target=feed)
+    t.start()
+    try:
+        assert _read_all(p, 777) == recs
+    finally:
+        t.join()

@@ -29,6 +29,7 @@ bool FastqReader::open(const std::string &path, std::string &err) {
 		f_ = fopen(path.c_str(), "rb");
 		if (!f_) { err = "cannot open " + path; return false; }
 		setvbuf(f_, nullptr, _IONBF, 0);
+		seekable_ = lseek(fileno(f_), 0, SEEK_CUR) != (off_t)-1;  // a pipe / FIFO is read front to back by one thread
 	}
 	return true;
 }
@@ -41,6 +42,15 @@ size_t FastqReader::read_some(char *dst, size_t cap) {
 	}
 	// plain file: the block is read by all threads at their own offsets (one thread copies ~2.5 GB/s from the page cache)
 	const int fd = fileno(f_);
+	if (!seekable_) {
+		size_t done = 0;
+		while (done < cap) {
+			ssize_t n = read(fd, dst + done, cap - done);
+			if (n <= 0) break;
+			done += (size_t)n;
+		}
+		return done;
+	}
 	const int T = cap >= (8u << 20) ? omp_get_max_threads() : 1;
 	std::vector<size_t> got((size_t)T, 0);
 #pragma omp parallel for schedule(static, 1) num_threads(T)

@@ -75,7 +75,7 @@ private:
 	size_t beg_ = 0, have_ = 0;  // unconsumed input = buf_[beg_, have_)
 	double bytes_per_line_ = 160;  // running estimate, sizes the reads and the scan windows
 	uint64_t file_off_ = 0;  // plain files: next byte to read
-	bool eof_ = false, finished_ = false;
+	bool eof_ = false, finished_ = false, seekable_ = true;
 	uint64_t line_nr_ = 0;  // lines consumed so far
 	std::vector<size_t> ends_;  // scratch: end offset of every line of the batch
 };
