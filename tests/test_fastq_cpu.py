@@ -161,3 +161,21 @@ def test_reader_takes_a_fifo(tmp_path):
         assert _read_all(p, 777) == recs
     finally:
         t.join()
+
+
+def test_open_failures_and_corrupt_gzip(tmp_path):
+    """OpenStdioFile / OpenGzipFile / ReadGzipFile messages (myutils.cpp:426-446, gzipfileio.cpp:8-22)."""
+    for name in ("nope.fq", "nope.fq.gz"):  # the C ABI reports the class (URMAPX_E_IO); the command line prints the message
+        with pytest.raises(api.UrmapxError) as e:
+            api.FastqReader(str(tmp_path / name))
+        assert e.value.code == api.E_IO
+    recs = _records(3000, L=100, seed=5)
+    p = tmp_path / "bad.fq.gz"
+    blob = bytearray(gzip.compress(_text(recs)))
+    for i in range(len(blob) // 2, len(blob) // 2 + 64):
+        blob[i] ^= 0x5A  # damage the deflate stream
+    p.write_bytes(bytes(blob))
+    rd = api.FastqReader(str(p))
+    with pytest.raises(ValueError, match="Error reading gzip file|Bad|Invalid|Non-printing|Unexpected"):
+        while rd.next(500) is not None:
+            pass

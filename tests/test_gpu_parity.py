@@ -222,6 +222,13 @@ def test_cli_map_reproduces_reference_sam(tmp_path, name):
     want = [l for l in open(os.path.join(gold, name + ".sam"), "rb").read().split(b"\n") if l]
     assert got == want
     assert any(l.startswith(b"@PG\tID:urmap") for l in open(out, "rb").read().split(b"\n"))
+    if name == "se_short":  # "-" is standard input (OpenStdioFile, myutils.cpp:430-431), here a pipe
+        out3 = os.path.join(tmp_path, "out_stdin.sam")
+        with open(os.path.join(gold, name + ".fq"), "rb") as f:
+            r = subprocess.run([exe, "-map", "-", "-ufi", ufi, "-samout", out3], input=f.read(), stdout=subprocess.PIPE,
+                               stderr=subprocess.PIPE, timeout=120)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        assert [l for l in open(out3, "rb").read().split(b"\n") if l and not l.startswith(b"@PG")] == want
     if name == "se150":  # the same reads gzip-compressed, CRLF line ends, several host threads and one
         fqz = os.path.join(tmp_path, "r.fq.gz")
         with open(os.path.join(gold, name + ".fq"), "rb") as f, gzip.open(fqz, "wb") as z:

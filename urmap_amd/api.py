@@ -16,6 +16,7 @@ LIB_PATH = os.environ.get("URMAPX_LIB") or os.path.join(_HERE, "liburmapx.so")  
 
 MAX_QL = 320
 MAX_PATH_OPS = int(os.environ.get("URMAPX_MAX_PATH_OPS_OVERRIDE", 96))
+E_IO, E_FORMAT, E_NOMEM, E_NODEVICE, E_ARG = -1, -2, -3, -4, -5
 E_UNSUPPORTED = -6
 
 RESULT_DTYPE = np.dtype([("dbpos", "<u4"), ("seq_index", "<u4"), ("coord", "<u4"), ("score", "<i2"),

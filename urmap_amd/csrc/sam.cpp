@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <cctype>
+#include <cerrno>
 #include <cstdio>
 #include <cstring>
 
@@ -13,7 +14,7 @@ namespace urx {
 
 // ---------------- FASTQ ----------------
 FastqReader::~FastqReader() {
-	if (f_) fclose(f_);
+	if (f_ && f_ != stdin) fclose(f_);
 	if (gz_) gzclose((gzFile)gz_);
 }
 
@@ -23,11 +24,13 @@ bool FastqReader::open(const std::string &path, std::string &err) {
 	const bool gz = path.size() > 3 && path.compare(path.size() - 3, 3, ".gz") == 0;
 	if (gz) {
 		gz_ = gzopen(path.c_str(), "rb");
-		if (!gz_) { err = "cannot open " + path; return false; }
+		if (!gz_) { err = "Error opening gzip file " + path; return false; }  // gzipfileio.cpp:8-14
 		gzbuffer((gzFile)gz_, 1u << 20);
 	} else {
-		f_ = fopen(path.c_str(), "rb");
-		if (!f_) { err = "cannot open " + path; return false; }
+		// OpenStdioFile (myutils.cpp:426-446): "-" is standard input
+		if (path.empty()) { err = "Missing input file name"; return false; }
+		f_ = path == "-" ? stdin : fopen(path.c_str(), "rb");
+		if (!f_) { err = "Cannot open " + path + ", errno=" + std::to_string(errno) + " " + strerror(errno); return false; }
 		setvbuf(f_, nullptr, _IONBF, 0);
 		seekable_ = lseek(fileno(f_), 0, SEEK_CUR) != (off_t)-1;  // a pipe / FIFO is read front to back by one thread
 	}
@@ -38,6 +41,7 @@ size_t FastqReader::read_some(char *dst, size_t cap) {
 	if (gz_) {
 		if (cap > (1u << 30)) cap = 1u << 30;
 		int n = gzread((gzFile)gz_, dst, (unsigned)cap);
+		if (n < 0) io_error_ = "Error reading gzip file";  // gzipfileio.cpp:16-22
 		return n > 0 ? (size_t)n : 0;
 	}
 	// plain file: the block is read by all threads at their own offsets (one thread copies ~2.5 GB/s from the page cache)
@@ -169,6 +173,7 @@ bool FastqReader::next_batch(FastqBatch &B, uint32_t max_reads, std::string &err
 		}
 		if (buf_.size() - have_ < ask) buf_.resize(std::max(buf_.size() * 2, have_ + ask));
 		const size_t n = read_some(buf_.data() + have_, ask);
+		if (!io_error_.empty()) { err = io_error_; return false; }
 		if (n == 0) eof_ = true;
 		have_ += n;
 	}

@@ -68,7 +68,7 @@ public:
 
 private:
 	size_t read_some(char *dst, size_t cap);
-	std::string path_;
+	std::string path_, io_error_;
 	FILE *f_ = nullptr;
 	void *gz_ = nullptr;
 	std::vector<char> buf_;
