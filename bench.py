@@ -12,6 +12,7 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import warnings
 import sys
 import time
 
@@ -278,7 +279,9 @@ def main():
         if local_rank != 0:
             blob_np = np.load(shm + "_blob.npy", mmap_mode="r")
             seq_np = np.load(shm + "_seq.npy", mmap_mode="r")
-            d_seq = torch.from_numpy(np.ascontiguousarray(seq_np)).to(device)  # the genome the index was built from
+            with warnings.catch_warnings():  # the shared table is mapped read-only; it is only copied to the device
+                warnings.simplefilter("ignore", UserWarning)
+                d_seq = torch.from_numpy(np.ascontiguousarray(seq_np)).to(device)  # the genome the index was built from
     t_build = time.time() - t0
     t0 = time.time()
     index = api.Index.wrap_host(24, 32, slots, blob_np, seq_np, seq_lengths, seq_offsets, labels).upload(dev_index)
