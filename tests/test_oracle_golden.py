@@ -145,3 +145,54 @@ def test_oracle_hitstats_equal_reference_report(gold_ufi, key, mode, name, minq)
     counts = [len(res), int((mapped & (res["mapq"] >= minq)).sum()), int((mapped & (res["mapq"] < minq)).sum()),
               int((~mapped).sum())]
     assert [int(re.match(r"\s*([\d,]+)", ln).group(1).replace(",", "")) for ln in want[:4]] == counts
+
+
+@pytest.mark.skipif(not ol.have_ref(), reason="reference binary oracle/_ref/urmap not built")
+@pytest.mark.parametrize("seed,maxix_opt", [(31, []), (32, ["-veryfast"])])
+def test_oracle_veryfast_equals_reference_binary(tmp_path, seed, maxix_opt):
+    """`-veryfast`: SE method 7 (state1.cpp:166-179) and PE Search5 (search2m5.cpp:9-156, band radius 4, map2.cpp:17-21),
+    on a default index and on a `-make_ufi -veryfast` index (MaxIx 3, ufindexio.cpp:133-136): oracle vs reference SAM."""
+    from urmap_amd import synth
+    d = str(tmp_path)
+    g = synth.make_genome(seed, [200000, 90000, 30000], repeat_frac=0.45, n_families=8, max_div=0.06)
+    synth.write_fasta(os.path.join(d, "g.fa"), g, lowercase_frac=0.03)
+    ol.run_ref(["-make_ufi", "g.fa", "-output", "g.ufi"] + maxix_opt, cwd=d)
+    w, maxix, sds, slots = ol.ufi_header(os.path.join(d, "g.ufi"))
+    assert maxix == (3 if maxix_opt else 32)
+    idx = ol.Index.build(os.path.join(d, "g.fa"), slots, max_ix=maxix)
+    idx.save(os.path.join(d, "o.ufi"))
+    assert filecmp.cmp(os.path.join(d, "g.ufi"), os.path.join(d, "o.ufi"), shallow=False)
+    reads = synth.make_reads(seed + 1, g, 2500, read_len=150, sub=0.03, ins=0.003, dele=0.003, random_frac=0.02)
+    synth.write_fastq(os.path.join(d, "r.fq"), reads)
+    ol.run_ref(["-map", "r.fq", "-ufi", "g.ufi", "-samout", "ref.sam", "-threads", "4", "-veryfast"], cwd=d)
+    idx.map_file_se(os.path.join(d, "r.fq"), os.path.join(d, "o.sam"), method=7, threads=4)
+    assert sorted(read_records(os.path.join(d, "ref.sam"))) == sorted(read_records(os.path.join(d, "o.sam")))
+    r1, r2 = synth.make_pairs(seed + 2, g, 1500, read_len=125, sub1=0.02, sub2=0.05, ins=0.002, dele=0.002)
+    synth.write_fastq(os.path.join(d, "p1.fq"), r1)
+    synth.write_fastq(os.path.join(d, "p2.fq"), r2)
+    ol.run_ref(["-map2", "p1.fq", "-reverse", "p2.fq", "-ufi", "g.ufi", "-samout", "refpe.sam", "-threads", "4", "-veryfast"], cwd=d)
+    idx.map_file_pe(os.path.join(d, "p1.fq"), os.path.join(d, "p2.fq"), os.path.join(d, "ope.sam"), threads=4, veryfast=True)
+
+    def pairs(path):
+        body = [x for x in read_records(path) if not x.startswith(b"@")]
+        return sorted(body[i] + b"|" + body[i + 1] for i in range(0, len(body), 2))
+    assert pairs(os.path.join(d, "refpe.sam")) == pairs(os.path.join(d, "ope.sam"))
+
+
+@pytest.mark.skipif(not ol.have_ref(), reason="reference binary oracle/_ref/urmap not built")
+@pytest.mark.parametrize("seed,rl,sub", [(41, 279, 0.02), (42, 250, 0.05)])
+def test_oracle_long_pairs_equal_reference_binary(tmp_path, seed, rl, sub):
+    """Paired-end at the top of the reference's working range (pending seed positions are bytes, state1.h:86-87: the
+    reference binary crashes from 2x280 on): oracle vs reference SAM on 250 and 279 bp pairs."""
+    from urmap_amd import synth
+    d = str(tmp_path)
+    g = synth.make_genome(seed, [240000, 120000, 40000], repeat_frac=0.5, n_families=10, max_div=0.05)
+    synth.write_fasta(os.path.join(d, "g.fa"), g)
+    ol.run_ref(["-make_ufi", "g.fa", "-output", "g.ufi"], cwd=d)
+    idx = ol.Index.load(os.path.join(d, "g.ufi"))
+    r1, r2 = synth.make_pairs(seed + 2, g, 1500, read_len=rl, sub1=sub, sub2=2 * sub, ins=0.002, dele=0.002)
+    synth.write_fastq(os.path.join(d, "p1.fq"), r1)
+    synth.write_fastq(os.path.join(d, "p2.fq"), r2)
+    ol.run_ref(["-map2", "p1.fq", "-reverse", "p2.fq", "-ufi", "g.ufi", "-samout", "ref.sam", "-threads", "1"], cwd=d)
+    idx.map_file_pe(os.path.join(d, "p1.fq"), os.path.join(d, "p2.fq"), os.path.join(d, "o.sam"), threads=4)
+    assert read_records(os.path.join(d, "ref.sam")) == read_records(os.path.join(d, "o.sam"))
