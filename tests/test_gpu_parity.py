@@ -188,6 +188,29 @@ def test_map_se_mixed_lengths_in_one_batch(small_case, gpu, lo, hi):
     compare_results(gres, gops, ores, opaths)
 
 
+def test_results_do_not_depend_on_scheduling(small_case, gpu):
+    """Reads are handed to wavefronts by a ticket counter, so which wave maps which read changes from launch to launch;
+    nothing else may.  The same batch three times, then once in reversed read order: identical results per read
+    (paths compared after expansion, their offsets in the arena differ)."""
+    from urmap_amd import synth
+    from conftest import reads_to_arrays
+    reads = synth.make_reads(4242, small_case["genome"], 4000, read_len=150, sub=0.02, ins=0.002, dele=0.002,
+                             random_frac=0.03)
+    bases, offs = reads_to_arrays(reads)
+    fields = [f for f in gpu["mapper"].map_se(bases, offs)[0].dtype.names if f != "path_off"]
+
+    def run(b, o):
+        res, ops = gpu["mapper"].map_se(b, o)
+        paths = [tuple(int(x) for x in ops[int(r["path_off"]):int(r["path_off"]) + int(r["path_nops"])]) for r in res]
+        return [tuple(r[f] for f in fields) for r in res], paths
+    first = run(bases, offs)
+    for _ in range(2):
+        assert run(bases, offs) == first
+    rbases, roffs = reads_to_arrays(reads[::-1])
+    rres, rpaths = run(rbases, roffs)
+    assert (rres[::-1], rpaths[::-1]) == first
+
+
 def test_bad_lengths_are_flagged(small_case, gpu):
     """Reads shorter than W or longer than the device cap are reported, not silently mis-mapped."""
     from urmap_amd import api
