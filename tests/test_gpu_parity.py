@@ -302,6 +302,37 @@ def test_cli_hitstats_report_equals_reference(tmp_path, key, mode, name, g, extr
     assert rq.returncode == 0 and b"Mapped" not in rq.stderr
 
 
+@pytest.mark.parametrize("short,digit", [(2, "2"), (1, "1")])
+def test_cli_map2_unequal_files_die_like_the_reference(tmp_path, short, digit):
+    """map2.cpp:27-33: one record from each file per pair; when one file ends first: Die("Premature end of file in
+    FASTQ<n>"), n = the file that ended.  Also a malformed record in the second file (read by its own thread)."""
+    import gzip
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gold = os.path.join(root, "tests", "golden")
+    exe = os.path.join(root, "urmap_amd", "urmap")
+    ufi = os.path.join(tmp_path, "g.ufi")
+    with gzip.open(os.path.join(gold, "g.ufi.gz"), "rb") as z, open(ufi, "wb") as f:
+        f.write(z.read())
+    f1, f2 = os.path.join(tmp_path, "a_1.fq"), os.path.join(tmp_path, "a_2.fq")
+    for k, dst in ((1, f1), (2, f2)):
+        lines = open(os.path.join(gold, f"pe150_{k}.fq"), "rb").read().split(b"\n")
+        keep = 4 * 250 if k == short else 4 * 300
+        open(dst, "wb").write(b"\n".join(lines[:keep]) + b"\n")
+    r = subprocess.run([exe, "-map2", f1, "-reverse", f2, "-ufi", ufi, "-samout", os.path.join(tmp_path, "o.sam"), "-batch", "64"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert r.returncode == 1 and f"Premature end of file in FASTQ{digit}".encode() in r.stderr, r.stderr.decode()[-500:]
+    if short == 2:
+        lines = open(os.path.join(gold, "pe150_2.fq"), "rb").read().split(b"\n")
+        lines[4 * 100 + 1] = lines[4 * 100 + 1][:50] + b"*" + lines[4 * 100 + 1][51:]
+        open(f2, "wb").write(b"\n".join(lines))
+        open(f1, "wb").write(open(os.path.join(gold, "pe150_1.fq"), "rb").read())
+        r = subprocess.run([exe, "-map2", f1, "-reverse", f2, "-ufi", ufi, "-samout", os.path.join(tmp_path, "o.sam"), "-batch", "64"],
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+        assert r.returncode == 1 and b"Invalid sequence letter '*' in FASTQ, line 402 file" in r.stderr, r.stderr.decode()[-500:]
+
+
 def test_cli_errors_exit_1(tmp_path):
     """Die(): message on stderr, exit status 1 (myutils.cpp:915)."""
     import os
