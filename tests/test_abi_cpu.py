@@ -121,6 +121,24 @@ def test_product_sam_text_equals_reference_golden(gold_ufi, name):
     assert sam == want
 
 
+@pytest.mark.parametrize("name,ufi_gz", [("pe150", "g.ufi.gz"), ("pe100_noisy", "g.ufi.gz"), ("pe120_rep", "r.ufi.gz")])
+def test_product_pe_sam_text_equals_reference_golden(tmp_path, name, ufi_gz):
+    """State2::SetSAM2 / GetPairedFlags / TLEN (output2.cpp:18-132) in the product's host code (urmapx_sam_pe): fed
+    with the oracle's per-mate results it must reproduce the reference's -map2 SAM records byte for byte."""
+    import gzip
+    ufi = os.path.join(tmp_path, "x.ufi")
+    with gzip.open(os.path.join(GOLD, ufi_gz), "rb") as z, open(ufi, "wb") as f:
+        f.write(z.read())
+    labels, bases, offs, quals = api.interleave_pairs(api.read_fastq_arrays(os.path.join(GOLD, name + "_1.fq")),
+                                                      api.read_fastq_arrays(os.path.join(GOLD, name + "_2.fq")))
+    ores, opaths, _ = ol.Index.load(ufi).map_pe(bases, offs)
+    res, ops = oracle_results_as_product(ores, opaths)
+    idx = api.Index.open(ufi)
+    sam = idx.sam_header_sq() + idx.sam_pe(res, ops, labels, bases, offs, quals)
+    want = open(os.path.join(GOLD, name + ".sam"), "rb").read()
+    assert sam == want
+
+
 def test_cigar_dangling_m_rules():
     """cigar.cpp:141-199: a terminal M of <= 2 next to an indel > 4 is merged into the M beyond it."""
     idx_path = None
