@@ -344,8 +344,26 @@ static inline void append_int(std::string &out, int64_t v) {
 	else append_uint(out, (uint64_t)v);
 }
 
-static void append_cigar(std::string &out, const urmapx_path_op *ops, unsigned nops, unsigned QL) {
-	if (nops == 0) { append_uint(out, QL); out.push_back('M'); return; }
+// The record writers below fill a per-thread scratch area through a plain pointer and append it to the output once.
+static inline char *put_uint(char *p, uint64_t v) {
+	char tmp[24];
+	int n = 0;
+	do { tmp[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+	while (n) *p++ = tmp[--n];
+	return p;
+}
+static inline char *put_int(char *p, int64_t v) {
+	if (v < 0) { *p++ = '-'; return put_uint(p, (uint64_t)(-v)); }
+	return put_uint(p, (uint64_t)v);
+}
+static inline char *put_bytes(char *p, const void *src, size_t n) {
+	memcpy(p, src, n);
+	return p + n;
+}
+static constexpr size_t CIGAR_MAX_CHARS = 12 * (size_t)(URMAPX_MAX_PATH_OPS + 1);
+
+static char *put_cigar(char *p, const urmapx_path_op *ops, unsigned nops, unsigned QL) {
+	if (nops == 0) { p = put_uint(p, QL); *p++ = 'M'; return p; }
 	char op[URMAPX_MAX_PATH_OPS + 1];
 	unsigned len[URMAPX_MAX_PATH_OPS + 1];
 	unsigned N = 0;
@@ -369,13 +387,13 @@ static void append_cigar(std::string &out, const urmapx_path_op *ops, unsigned n
 			--N;
 		}
 	}
-	for (unsigned i = first; i < N; ++i) { append_uint(out, len[i]); out.push_back(op[i]); }
+	for (unsigned i = first; i < N; ++i) { p = put_uint(p, len[i]); *p++ = op[i]; }
+	return p;
 }
 
 std::string path_to_cigar(const urmapx_path_op *ops, unsigned nops, unsigned QL) {
-	std::string s;
-	append_cigar(s, ops, nops, QL);
-	return s;
+	char buf[CIGAR_MAX_CHARS + 16];
+	return std::string(buf, (size_t)(put_cigar(buf, ops, nops, QL) - buf));
 }
 
 static size_t qname_len(const char *label) {
@@ -386,6 +404,12 @@ static size_t qname_len(const char *label) {
 	return k;
 }
 
+static char *record_scratch(size_t need) {
+	static thread_local std::vector<char> scratch;
+	if (scratch.size() < need) scratch.resize(2 * need);
+	return scratch.data();
+}
+
 static void append_unmapped(std::string &out, uint32_t aflags, const char *label, const uint8_t *seq, const uint8_t *qual,
                             unsigned QL) {
 	uint32_t flags = 0x04;
@@ -394,15 +418,19 @@ static void append_unmapped(std::string &out, uint32_t aflags, const char *label
 	else if (aflags & 0x80) flags |= 0x80;
 	if (aflags & 0x08) flags |= 0x08;
 	else if (aflags & 0x20) flags |= 0x20;
-	out.append(label, qname_len(label));
-	out.push_back('\t');
-	append_uint(out, flags);
-	out += "\t*\t0\t0\t*\t*\t0\t0\t";
-	out.append((const char *)seq, QL);
-	out.push_back('\t');
-	if (!qual) out.push_back('*');
-	else out.append((const char *)qual, QL);
-	out.push_back('\n');
+	const size_t ql = qname_len(label);
+	char *const buf = record_scratch(ql + 2 * (size_t)QL + 64), *p = buf;
+	p = put_bytes(p, label, ql);
+	*p++ = '\t';
+	p = put_uint(p, flags);
+	static const char kUnmappedFields[] = "\t*\t0\t0\t*\t*\t0\t0\t";
+	p = put_bytes(p, kUnmappedFields, sizeof kUnmappedFields - 1);
+	p = put_bytes(p, seq, QL);
+	*p++ = '\t';
+	if (!qual) *p++ = '*';
+	else p = put_bytes(p, qual, QL);
+	*p++ = '\n';
+	out.append(buf, (size_t)(p - buf));
 }
 
 void append_sam_record(std::string &out, const urmapx_index *I, const urmapx_result &r, const urmapx_path_op *ops,
@@ -410,44 +438,43 @@ void append_sam_record(std::string &out, const urmapx_index *I, const urmapx_res
                        const uint8_t *seq, const uint8_t *qual, unsigned QL) {
 	if (r.dbpos == 0xFFFFFFFFu) { append_unmapped(out, flags, label, seq, qual, QL); return; }
 	const char *tlabel = urmapx_index_label(I, r.seq_index);
-	out.append(label, qname_len(label));
-	out.push_back('\t');
-	append_uint(out, flags);
-	out.push_back('\t');
-	out += tlabel;
-	out.push_back('\t');
-	append_uint(out, (uint64_t)r.coord + 1);
-	out.push_back('\t');
-	append_uint(out, (unsigned)r.mapq);
-	out.push_back('\t');
-	append_cigar(out, r.path_nops ? ops + r.path_off : nullptr, r.path_nops, QL);
-	out.push_back('\t');
-	if (!mate_label || !*mate_label || strcmp(mate_label, "*") == 0) out.push_back('*');
-	else if (strcmp(mate_label, tlabel) == 0) out.push_back('=');
-	else out += mate_label;
-	out.push_back('\t');
-	if (mate_pos == 0 || mate_pos == 0xFFFFFFFFu) out.push_back('0');
-	else append_uint(out, (uint64_t)mate_pos + 1);
-	out.push_back('\t');
-	append_int(out, tlen);
-	out.push_back('\t');
-	{
-		const size_t at = out.size();
-		out.resize(at + 2 * (size_t)QL + 2 - (qual ? 0 : QL - 1));
-		char *d = &out[at];
-		if (r.plus) memcpy(d, seq, QL);
-		else
-			for (unsigned i = 0; i < QL; ++i) d[i] = (char)g_comp[seq[QL - 1 - i]];
-		d += QL;
-		*d++ = '\t';
-		if (!qual) *d++ = '*';
-		else if (r.plus) { memcpy(d, qual, QL); d += QL; }
-		else {
-			for (unsigned i = 1; i <= QL; ++i) d[i - 1] = (char)qual[QL - i];
-			d += QL;
-		}
-		*d = '\n';
+	const size_t ql = qname_len(label), tl = strlen(tlabel), ml = mate_label ? strlen(mate_label) : 0;
+	char *const buf = record_scratch(ql + tl + ml + 2 * (size_t)QL + CIGAR_MAX_CHARS + 128), *p = buf;
+	p = put_bytes(p, label, ql);
+	*p++ = '\t';
+	p = put_uint(p, flags);
+	*p++ = '\t';
+	p = put_bytes(p, tlabel, tl);
+	*p++ = '\t';
+	p = put_uint(p, (uint64_t)r.coord + 1);
+	*p++ = '\t';
+	p = put_uint(p, (unsigned)r.mapq);
+	*p++ = '\t';
+	p = put_cigar(p, r.path_nops ? ops + r.path_off : nullptr, r.path_nops, QL);
+	*p++ = '\t';
+	if (ml == 0 || (ml == 1 && mate_label[0] == '*')) *p++ = '*';
+	else if (ml == tl && memcmp(mate_label, tlabel, tl) == 0) *p++ = '=';
+	else p = put_bytes(p, mate_label, ml);
+	*p++ = '\t';
+	if (mate_pos == 0 || mate_pos == 0xFFFFFFFFu) *p++ = '0';
+	else p = put_uint(p, (uint64_t)mate_pos + 1);
+	*p++ = '\t';
+	p = put_int(p, tlen);
+	*p++ = '\t';
+	if (r.plus) p = put_bytes(p, seq, QL);
+	else {
+		for (unsigned i = 0; i < QL; ++i) p[i] = (char)g_comp[seq[QL - 1 - i]];
+		p += QL;
 	}
+	*p++ = '\t';
+	if (!qual) *p++ = '*';
+	else if (r.plus) p = put_bytes(p, qual, QL);
+	else {
+		for (unsigned i = 0; i < QL; ++i) p[i] = (char)qual[QL - 1 - i];
+		p += QL;
+	}
+	*p++ = '\n';
+	out.append(buf, (size_t)(p - buf));
 }
 
 void append_sam_header(std::string &out, const urmapx_index *I, int argc, char **argv) {
