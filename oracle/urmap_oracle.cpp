@@ -7,7 +7,7 @@
  * Searcher per thread, std::vector state, no tuning.
  *
  * Parity: pinned against the unmodified reference binary oracle/_ref/urmap (built by
- * oracle/Makefile from the sources in place) by tests/test_oracle_vs_ref.py and the
+ * oracle/Makefile from the sources in place) by tests/test_oracle_golden.py and the
  * fixtures under tests/golden/.
  */
 #include "urmap_oracle.h"
