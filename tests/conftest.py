@@ -21,7 +21,7 @@ def workdir(tmp_path_factory):
 @pytest.fixture(scope="session")
 def small_case(workdir):
     """A 300 kbp, 3-sequence synthetic genome with repeats and N runs, its index built by the ORACLE
-    (byte-identical to the reference's -make_ufi, see test_oracle_vs_ref.py), and mixed reads."""
+    (byte-identical to the reference's -make_ufi, see test_oracle_golden.py), and mixed reads."""
     import oracle_lib as ol
     from urmap_amd import synth
 
