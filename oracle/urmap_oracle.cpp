@@ -1606,6 +1606,9 @@ static void MateMapped(Searcher &S, MateOut &M) {  // SetMappedPos, state1.cpp:1
 extern "C" int uo_map_pe_opts(const uo_index *X, const uo_params *P, const uint8_t *bases, const uint64_t *offs,
                               uint32_t npairs, int threads, int veryfast, uo_result *results, char **path_arena,
                               uo_counters *counters);
+extern "C" int uo_map_pe_info(const uo_index *X, const uo_params *P, const uint8_t *bases, const uint64_t *offs,
+                              uint32_t npairs, int threads, int veryfast, uo_result *results, char **path_arena,
+                              uo_counters *counters, uo_pair_info *info);
 extern "C" int uo_map_pe(const uo_index *X, const uo_params *P, const uint8_t *bases, const uint64_t *offs, uint32_t npairs,
                          int threads, uo_result *results, char **path_arena, uo_counters *counters) {
 	return uo_map_pe_opts(X, P, bases, offs, npairs, threads, 0, results, path_arena, counters);
@@ -1615,6 +1618,14 @@ extern "C" int uo_map_pe(const uo_index *X, const uo_params *P, const uint8_t *b
 extern "C" int uo_map_pe_opts(const uo_index *X, const uo_params *Pin, const uint8_t *bases, const uint64_t *offs,
                               uint32_t npairs, int threads, int veryfast, uo_result *results, char **path_arena,
                               uo_counters *counters) {
+	return uo_map_pe_info(X, Pin, bases, offs, npairs, threads, veryfast, results, path_arena, counters, nullptr);
+}
+
+// as uo_map_pe_opts; info[npairs] (may be NULL) also receives what State2::OutputTab2 reads beyond the results: each
+// mate's m_TopHit as the pair stage left it (before SetMappedPos) and m_SecondHit (search2.cpp:49-56)
+extern "C" int uo_map_pe_info(const uo_index *X, const uo_params *Pin, const uint8_t *bases, const uint64_t *offs,
+                              uint32_t npairs, int threads, int veryfast, uo_result *results, char **path_arena,
+                              uo_counters *counters, uo_pair_info *info) {
 	uo_params Pv = *Pin;
 	if (veryfast) Pv.band_radius = 4;
 	const uo_params *P = &Pv;
@@ -1629,6 +1640,23 @@ extern "C" int uo_map_pe_opts(const uo_index *X, const uo_params *Pin, const uin
 			const uint64_t o0 = offs[2 * i], o1 = offs[2 * i + 1], o2 = offs[2 * i + 2];
 			S.Search4(bases + o0, unsigned(o1 - o0), bases + o1, unsigned(o2 - o1), veryfast != 0);
 			Searcher *M[2] = {&S.F, &S.R};
+			if (info) {
+				uo_pair_info &pi = info[i];
+				const int second[2] = {S.SecondF, S.SecondR};
+				for (int a = 0; a < 2; ++a) {
+					pi.top_db[a] = pi.second_db[a] = UINT32_MAX;
+					pi.top_score[a] = pi.second_score[a] = 0;
+					pi.top_plus[a] = pi.second_plus[a] = 0;
+					if (M[a]->TopHit >= 0) {
+						const Hit &h = M[a]->Hits[M[a]->TopHit];
+						pi.top_db[a] = h.DBStartPos; pi.top_score[a] = (int16_t)h.Score; pi.top_plus[a] = h.Plus;
+					}
+					if (second[a] >= 0) {
+						const Hit &h = M[a]->Hits[second[a]];
+						pi.second_db[a] = h.DBStartPos; pi.second_score[a] = (int16_t)h.Score; pi.second_plus[a] = h.Plus;
+					}
+				}
+			}
 			for (int a = 0; a < 2; ++a) {
 				MateOut mo;
 				MateMapped(*M[a], mo);

@@ -32,6 +32,10 @@ RESULT_DTYPE = np.dtype([("dbpos", "<u4"), ("seq_index", "<u4"), ("coord", "<u4"
                          ("plus", "u1"), ("exit_phase", "u1"), ("path_len", "<u2"), ("path_off", "<u4")])
 assert RESULT_DTYPE.itemsize == C.sizeof(Result)
 
+PAIR_INFO_DTYPE = np.dtype([("top_db", "<u4", 2), ("second_db", "<u4", 2), ("top_score", "<i2", 2),
+                            ("second_score", "<i2", 2), ("top_plus", "u1", 2), ("second_plus", "u1", 2)])
+assert PAIR_INFO_DTYPE.itemsize == 28
+
 COUNTER_NAMES = ("n_reads", "n_getblob", "n_rowcalls", "n_rowhop", "n_extend", "n_extbases",
                  "n_alignhsp", "n_viterbi", "n_dpcells", "n_dptarget", "n_qbases")
 
@@ -91,6 +95,7 @@ def lib():
     L.uo_map_se.argtypes = [vp, C.POINTER(Params), vp, vp, u32, C.c_int, vp, C.POINTER(vp), C.POINTER(Counters)]
     L.uo_map_pe.argtypes = [vp, C.POINTER(Params), vp, vp, u32, C.c_int, vp, C.POINTER(vp), C.POINTER(Counters)]
     L.uo_map_pe_opts.argtypes = [vp, C.POINTER(Params), vp, vp, u32, C.c_int, C.c_int, vp, C.POINTER(vp), C.POINTER(Counters)]
+    L.uo_map_pe_info.argtypes = [vp, C.POINTER(Params), vp, vp, u32, C.c_int, C.c_int, vp, C.POINTER(vp), vp, vp]
     L.uo_free.argtypes = [vp]
     L.uo_sam_se.restype = C.c_size_t
     L.uo_sam_se.argtypes = [vp, vp, cp, cp, vp, vp, u32, vp]
@@ -207,6 +212,22 @@ class Index:
         paths = [C.string_at(arena.value + int(r["path_off"])).decode() for r in res]
         lib().uo_free(arena)
         return res, paths, cnt.asdict()
+
+    def map_pe_info(self, bases: np.ndarray, offs: np.ndarray, threads=1, veryfast=False):
+        """as map_pe, plus the per-pair record State2::OutputTab2 reads (layout of the product's urmapx_pair_info)"""
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offs = np.ascontiguousarray(offs, dtype=np.uint64)
+        n = len(offs) - 1
+        res = np.zeros(n, dtype=RESULT_DTYPE)
+        info = np.zeros(n // 2, dtype=PAIR_INFO_DTYPE)
+        arena = C.c_void_p()
+        p = params(6)
+        rc = lib().uo_map_pe_info(self.h, C.byref(p), bases.ctypes.data, offs.ctypes.data, n // 2, threads, int(veryfast),
+                                  res.ctypes.data, C.byref(arena), None, info.ctypes.data)
+        assert rc == 0
+        paths = [C.string_at(arena.value + int(r["path_off"])).decode() for r in res]
+        lib().uo_free(arena)
+        return res, paths, info
 
     def map_file_se(self, fastq, sam, method=6, threads=1):
         cnt = Counters()

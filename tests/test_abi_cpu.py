@@ -139,6 +139,28 @@ def test_product_pe_sam_text_equals_reference_golden(tmp_path, name, ufi_gz):
     assert sam == want
 
 
+@pytest.mark.parametrize("name,ufi_gz,sam_on", [("pe150", "g.ufi.gz", True), ("pe100_noisy", "g.ufi.gz", True),
+                                                ("pe120_rep", "r.ufi.gz", True), ("pe120_rep", "r.ufi.gz", False)])
+def test_product_tabbedout_text_equals_reference_golden(tmp_path, name, ufi_gz, sam_on):
+    """State2::OutputTab2 (outputtab2.cpp:85-120) in the product's host code (urmapx_tab_pe): fed with the oracle's
+    per-mate results and pair records it must reproduce the reference's -tabbedout file byte for byte, with and
+    without SAM output switched on."""
+    import gzip
+    ufi = os.path.join(tmp_path, "x.ufi")
+    with gzip.open(os.path.join(GOLD, ufi_gz), "rb") as z, open(ufi, "wb") as f:
+        f.write(z.read())
+    labels, bases, offs, quals = api.interleave_pairs(api.read_fastq_arrays(os.path.join(GOLD, name + "_1.fq")),
+                                                      api.read_fastq_arrays(os.path.join(GOLD, name + "_2.fq")))
+    ores, opaths, oinfo = ol.Index.load(ufi).map_pe_info(bases, offs)
+    res, _ = oracle_results_as_product(ores, opaths)
+    info = np.zeros(len(oinfo), dtype=api.PAIR_INFO_DTYPE)
+    for f in info.dtype.names:
+        info[f] = oinfo[f]
+    tab = api.Index.open(ufi).tab_pe(res, info, labels, offs, sam_on=sam_on)
+    want = open(os.path.join(GOLD, name + (".tab" if sam_on else "_nosam.tab")), "rb").read()
+    assert tab == want
+
+
 def test_cigar_dangling_m_rules():
     """cigar.cpp:141-199: a terminal M of <= 2 next to an indel > 4 is merged into the M beyond it."""
     idx_path = None
