@@ -179,3 +179,45 @@ def test_open_failures_and_corrupt_gzip(tmp_path):
     with pytest.raises(ValueError, match="Error reading gzip file|Bad|Invalid|Non-printing|Unexpected"):
         while rd.next(500) is not None:
             pass
+
+
+@pytest.mark.parametrize("batch", [50_000, 333_333])
+def test_record_length_shifts_midway(tmp_path, batch):
+    """The reader sizes its reads from the line length seen so far; a file whose records get six times longer (and
+    shorter again) in the middle must still come back record for record, across buffer refills and compactions."""
+    short = _records(997, L=40, seed=21)
+    long_ = _records(991, L=300, seed=22)
+    blocks = [(short, 300), (long_, 200), (short, 150), (long_, 60)]  # ~110 MB in all
+    p = tmp_path / "shift.fq"
+    order = []
+    with open(p, "wb") as f:
+        for recs, reps in blocks:
+            data = _text(recs)
+            for _ in range(reps):
+                f.write(data)
+            order.append((recs, reps * len(recs)))
+    rd = api.FastqReader(str(p))
+    seq = []  # (template, index) of every record in file order, generated lazily
+    def expected(i):
+        for recs, cnt in order:
+            if i < cnt:
+                return recs[i % len(recs)]
+            i -= cnt
+        raise IndexError
+    n = 0
+    total = sum(c for _, c in order)
+    while True:
+        b = rd.next(batch)
+        if b is None:
+            break
+        labels, bases, offs, quals = b
+        k = len(labels)
+        lens = np.diff(offs).astype(np.int64)
+        for j in list(range(0, k, 4099)) + [k - 1]:
+            lab, s, q = expected(n + j)
+            assert labels[j].encode() == lab and lens[j] == len(s)
+            assert bases[int(offs[j]):int(offs[j + 1])].tobytes() == s
+            assert quals[int(offs[j]):int(offs[j + 1])].tobytes() == q
+        n += k
+    assert n == total
+    os.remove(p)
