@@ -168,8 +168,8 @@ int urmapx_ctx_gather_microbench(urmapx_ctx *, uint64_t n_loads, double *loads_p
 
 /* ---- index construction (host side; the command line's -make_ufi) ---- */
 /* cmd_make_ufi (ufindexio.cpp:117-179): FASTA -> .ufi, byte-identical to the reference's for the same slot count.
- * slots is mandatory here (the reference's default picks the first entry >= file_size/0.6 of its built-in prime
- * table, primes.h, which is data this library does not carry). */
+ * slots is mandatory here; the command line applies the reference's default, GetPrime(file_size / 0.6)
+ * (prime.cpp:11-21), when -slots is absent. */
 int urmapx_make_ufi(const char *fasta_path, const char *ufi_path, uint32_t word_length, uint32_t max_ix, uint64_t slots);
 /* UFIndex::MakeIndex (ufindex.cpp:83-151) on an already concatenated upper-case sequence store; blob: 5*slots bytes. */
 int urmapx_build_slots(const uint8_t *seqdata, uint32_t seqdata_size, uint32_t word_length, uint32_t max_ix,

@@ -198,20 +198,35 @@ def test_cli_make_ufi_is_byte_identical(gold_ufi, tmp_path):
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
     assert r.returncode == 0, r.stderr.decode()
     assert filecmp.cmp(out, gold_ufi, shallow=False)
-    # without -slots: the first prime >= FASTA bytes / 0.6 (ufindexio.cpp:138-150 takes it from a prime ladder instead);
-    # the index must be what the oracle's builder makes for that slot count
+    # without -slots: GetPrime(file size / 0.6) (ufindexio.cpp:138-150, prime.cpp:11-21) -- the fixture was written by
+    # the reference with its default slot count, so the default-sized index must be that file too
     r = subprocess.run([exe, "-make_ufi", os.path.join(GOLD, "g.fa"), "-output", out], stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, timeout=60)
     assert r.returncode == 0, r.stderr.decode()
-    w2, maxix2, sds2, slots2 = ol.ufi_header(out)
-    size = os.path.getsize(os.path.join(GOLD, "g.fa"))
-    assert slots2 >= int(size / 0.6) and all(slots2 % p for p in range(2, int(slots2 ** 0.5) + 1))
-    assert all(any(c % p == 0 for p in range(2, int(c ** 0.5) + 1)) for c in range(int(size / 0.6), slots2))
-    idx = ol.Index.build(os.path.join(GOLD, "g.fa"), slots2, 24, 32)
-    ref2 = os.path.join(tmp_path, "oracle_default.ufi")
-    idx.save(ref2)
-    assert filecmp.cmp(out, ref2, shallow=False)
+    assert filecmp.cmp(out, gold_ufi, shallow=False)
     # a missing input file is a loud error, exit status 1 (myutils.cpp:915)
     r = subprocess.run([exe, "-make_ufi", os.path.join(tmp_path, "nope.fa"), "-output", out], stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, timeout=60)
     assert r.returncode == 1
+
+
+@pytest.mark.skipif(not ol.have_ref(), reason="reference binary oracle/_ref/urmap not built")
+@pytest.mark.parametrize("nbases", [1200, 30011, 171717, 999983])
+def test_cli_default_slot_count_equals_reference_binary(tmp_path, nbases):
+    """GetPrime's ladder (prime.cpp:11-21) is regenerated, not stored: same default slot count as the reference binary
+    for FASTA files of several sizes (also with -veryfast: MaxIx 3, ufindexio.cpp:133-136)."""
+    import subprocess
+    from urmap_amd import synth
+    exe = os.path.join(ROOT, "urmap_amd", "urmap")
+    if not os.path.exists(exe):
+        pytest.skip("CLI not built")
+    d = str(tmp_path)
+    g = synth.make_genome(nbases, [nbases - nbases // 3, nbases // 3], repeat_frac=0.2, n_families=3)
+    synth.write_fasta(os.path.join(d, "x.fa"), g)
+    for extra in ([], ["-veryfast"]):
+        ol.run_ref(["-make_ufi", "x.fa", "-output", "ref.ufi"] + extra, cwd=d)
+        r = subprocess.run([exe, "-make_ufi", os.path.join(d, "x.fa"), "-output", os.path.join(d, "mine.ufi")] + extra,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+        assert r.returncode == 0, r.stderr.decode()
+        assert ol.ufi_header(os.path.join(d, "mine.ufi")) == ol.ufi_header(os.path.join(d, "ref.ufi"))
+        assert filecmp.cmp(os.path.join(d, "mine.ufi"), os.path.join(d, "ref.ufi"), shallow=False)

@@ -426,22 +426,33 @@ static bool is_prime64(uint64_t n) {
 	return true;
 }
 
+// GetPrime (prime.cpp:11-21) walks a ladder of 410 primes and returns the first one >= n.  The ladder is regular:
+// rung k is the first prime >= t_k with t_0 = 100 and t_(k+1) = trunc(t_k / 0.95) in double arithmetic (every rung of
+// the reference's table follows it; tests/test_abi_cpu.py holds the spot checks), so it is generated, not stored.
+// Returns 0 past the last rung, where the reference dies.
+static uint64_t get_prime(uint64_t n) {
+	uint64_t t = 100;
+	for (int k = 0; k < 410; ++k) {
+		uint64_t p = t;
+		while (!is_prime64(p)) ++p;
+		if (p >= n) return p;
+		t = (uint64_t)((double)t / 0.95);
+	}
+	return 0;
+}
+
 static int cmd_make_ufi(const Opts &o) {
 	if (o.output.empty()) die("-output option required");
 	uint64_t slots = o.slots;
 	if (slots == 0) {
-		// cmd_make_ufi (ufindexio.cpp:138-150): slots = GetPrime(file size / load factor 0.6).  The reference's GetPrime
-		// picks from a built-in ladder of primes (primes.h), which is data this build does not carry; the first prime
-		// >= the same bound is used instead, so the default-sized index is valid (and maps identically to an index the
-		// reference builds with -slots set to this number) but is not byte-identical to the reference's default.
+		// cmd_make_ufi (ufindexio.cpp:138-150): slots = GetPrime(file size / load factor 0.6)
 		FILE *f = fopen(o.make_ufi.c_str(), "rb");
 		if (!f) die("Cannot open %s", o.make_ufi.c_str());
 		fseeko(f, 0, SEEK_END);
 		const int64_t size = (int64_t)ftello(f);
 		fclose(f);
-		slots = (uint64_t)((double)size / 0.6);
-		while (!is_prime64(slots)) ++slots;
-		fprintf(stderr, "urmap: -slots not given, using %llu (first prime >= FASTA bytes / 0.6)\n", (unsigned long long)slots);
+		slots = get_prime((uint64_t)(int64_t)((double)size / 0.6));
+		if (slots == 0) die("GetPrime(%.3g) overflow", (double)size / 0.6);
 	}
 	unsigned maxix = o.maxix ? o.maxix : (o.veryfast ? 3u : 32u);
 	check(urmapx_make_ufi(o.make_ufi.c_str(), o.output.c_str(), o.wordlength, maxix, slots), "make_ufi");
