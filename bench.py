@@ -5,7 +5,11 @@ A "step" is one pass of the hot path (seed+probe kernel, then search/extend kern
 reads that is already resident in HBM, against an index that is resident in HBM.  One process per GPU;
 the index is replicated, reads are sharded by rank, there is no collective on the data path.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
+`python bench.py --gpus N` with no launcher around it starts its own N ranks (child processes through
+torch.distributed.run, before this process touches the GPU); under the driver's launcher it is one of the ranks.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`, plus
+`other_workloads` (paired-end and 250 bp single-end on the same resident index) and `e2e` (FASTQ file -> SAM file).
 """
 from __future__ import annotations
 
@@ -22,6 +26,17 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+CODE_VERSION = "r2"    # committed PMC profiles carry the code version they were taken on (pmc_traffic)
+
+# work per read of the reference on the survey's 40 Mbp planning genome (instrumented build)
+SURVEY_WORK_PER_READ = {
+    "se150": {"n_getblob": 207, "n_rowcalls": 110, "n_rowhop": 229, "n_extend": 187, "n_extbases": 5228, "n_alignhsp": 0.66,
+              "n_viterbi": 0.59, "n_dpcells": 1296},
+    "se250": {"n_getblob": 454, "n_rowcalls": 170, "n_rowhop": 266, "n_extend": 373, "n_extbases": 13153, "n_alignhsp": 3.5,
+              "n_viterbi": 4.3, "n_dpcells": 18416},
+    "pe150": {"n_getblob": 183, "n_rowcalls": 61, "n_rowhop": 141, "n_extend": 124, "n_extbases": 5169, "n_viterbi": 0.37,
+              "n_dpcells": 581},
+}
 
 
 def parse_args():
@@ -36,34 +51,74 @@ def parse_args():
     ap.add_argument("--indel", type=float, default=0.001)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-workloads", action="store_true", help="skip the PE and 250 bp runs on the same index")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the FASTQ file -> SAM file run")
     ap.add_argument("--mode", choices=("se", "pe"), default="se", help="pe: 2x150 read pairs through State2::Search4 (config 3; not the headline metric)")
     return ap.parse_args()
 
 
+def _is_prime(n):
+    if n < 2:
+        return False
+    small = (2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37)
+    for p in small:
+        if n % p == 0:
+            return n == p
+    d, r = n - 1, 0
+    while d % 2 == 0:
+        d //= 2
+        r += 1
+    for a in small:  # deterministic Miller-Rabin for 64-bit integers
+        x = pow(a, d, n)
+        if x in (1, n - 1):
+            continue
+        for _ in range(r - 1):
+            x = x * x % n
+            if x == n - 1:
+                break
+        else:
+            return False
+    return True
+
+
 def next_prime(n):
-    def is_p(x):
-        if x % 2 == 0:
-            return x == 2
-        i = 3
-        while i * i <= x:
-            if x % i == 0:
-                return False
-            i += 2
-        return True
-    while not is_p(n):
+    while not _is_prime(n):
         n += 1
     return n
+
+
+def get_prime(n):
+    """GetPrime (prime.cpp:11-21): first rung >= n of the reference's ladder of 410 primes; rung k is the first prime >=
+    t_k, t_0 = 100, t_(k+1) = trunc(t_k / 0.95) in double arithmetic (same rule the command line uses, urmap_main.cpp)."""
+    t = 100
+    for _ in range(410):
+        p = next_prime(t)
+        if p >= n:
+            return p
+        t = int(float(t) / 0.95)
+    raise ValueError("GetPrime overflow")
+
+
+def default_slot_count(seq_lengths, labels, width=60):
+    """cmd_make_ufi's default (ufindexio.cpp:138-150): GetPrime(FASTA file size in bytes / load factor 0.6), for the
+    FASTA file this genome would be (">label\n" + lines of `width` bases)."""
+    size = 0
+    for L, lab in zip(seq_lengths, labels):
+        L = int(L)
+        size += 1 + len(lab) + 1 + L + (L + width - 1) // width
+    return get_prime(int(float(size) / 0.6)), size
 
 
 HG38_LENGTHS_MBP = [248.96, 242.19, 198.30, 190.21, 181.54, 170.81, 159.35, 145.14, 138.39, 133.80, 135.09, 133.28,
                     114.36, 107.04, 101.99, 90.34, 83.26, 80.37, 58.62, 64.44, 46.71, 50.82, 156.04, 57.23]
 
 
-def make_genome_torch(torch, seed, total_bp, device, repeat_frac=0.3, n_frac=0.02, n_families=200):
+def make_genome_torch(torch, seed, total_bp, device, repeat_frac=0.5, n_frac=0.05, max_div=0.20):
     """Concatenated upper-case sequence store as -make_ufi lays it out (ufindex.cpp:462-511): 24 sequences with
-    hg38's chromosome length proportions, joined by 32 '-' bytes; `repeat_frac` of the bases overwritten by copies
-    of `n_families` repeat families (0..15 % divergence per copy), `n_frac` in runs of N.  Built on the GPU,
-    returned as a device uint8 tensor plus the directory."""
+    hg38's chromosome length proportions, joined by 32 '-' bytes.  SURVEY.md 8(d) input 2: ~`repeat_frac` of the bases
+    are copies of repeat families whose copy numbers are log-uniform in 10..1e5 (family length 300..6000, each copy
+    0..`max_div` diverged from the consensus, either strand), `n_frac` of the bases lie in runs of N.  Built on the GPU;
+    returns the device uint8 tensor, the directory and what was laid down."""
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     scale = total_bp / (sum(HG38_LENGTHS_MBP) * 1e6)
@@ -74,37 +129,47 @@ def make_genome_torch(torch, seed, total_bp, device, repeat_frac=0.3, n_frac=0.0
         off += L + (32 if i + 1 != len(lens) else 0)
     size = off
     lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=device)
+    comp = torch.tensor(list(b"TGCA"), dtype=torch.uint8, device=device)
     seq = torch.empty(size, dtype=torch.uint8, device=device)
     step = 1 << 28
     for lo in range(0, size, step):
         hi = min(size, lo + step)
         seq[lo:hi] = lut[torch.randint(0, 4, (hi - lo,), generator=g, device=device)]
-    # repeat families, vectorised per family
     lens_t = torch.tensor(lens, dtype=torch.int64, device=device)
     offs_t = torch.tensor(offsets, dtype=torch.int64, device=device)
     cum = torch.cumsum(lens_t, 0)
-    fam_len = torch.randint(300, 6000, (n_families,), generator=g, device="cpu" if False else device).tolist()
-    copies_total = int(total_bp * repeat_frac / (sum(fam_len) / n_families))
-    per_fam = max(1, copies_total // n_families)
-    for fl in fam_len:
-        fam = lut[torch.randint(0, 4, (fl,), generator=g, device=device)]
-        # uniform start over the concatenated sequences, kept inside one sequence
-        u = (torch.rand(per_fam, generator=g, device=device, dtype=torch.float64) * float(cum[-1])).long()
-        si = torch.searchsorted(cum, u, right=True).clamp(max=len(lens) - 1)
-        p = u - (cum[si] - lens_t[si])
-        p = torch.minimum(p, (lens_t[si] - fl - 1).clamp(min=0))
-        ok = lens_t[si] > fl + 1
-        start = (offs_t[si] + p)[ok]
-        n = int(start.numel())
-        if n == 0:
-            continue
-        copy = fam[None, :].expand(n, fl).clone()
-        div = torch.rand(n, 1, generator=g, device=device) * 0.15
-        mut = torch.rand(n, fl, generator=g, device=device) < div
-        rnd = lut[torch.randint(0, 4, (n, fl), generator=g, device=device)]
-        copy = torch.where(mut, rnd, copy)
-        idx = (start[:, None] + torch.arange(fl, device=device)[None, :]).reshape(-1)
-        seq[idx] = copy.reshape(-1)
+    budget = int(total_bp * repeat_frac)
+    laid, fams = 0, []
+    hostg = np.random.Generator(np.random.PCG64(seed))
+    while laid < budget and len(fams) < 4000:
+        fl = int(hostg.integers(300, 6000))
+        copies = int(round(10 ** hostg.uniform(1.0, 5.0)))
+        copies = max(1, min(copies, (budget - laid) // fl + 1, max(10, int(0.2 * budget) // fl)))
+        fam_idx = torch.randint(0, 4, (fl,), generator=g, device=device)
+        done = 0
+        while done < copies:  # copies of one family, a slab at a time
+            n = min(copies - done, max(1, (1 << 26) // fl))
+            u = (torch.rand(n, generator=g, device=device, dtype=torch.float64) * float(cum[-1])).long()
+            si = torch.searchsorted(cum, u, right=True).clamp(max=len(lens) - 1)
+            p = u - (cum[si] - lens_t[si])
+            p = torch.minimum(p, (lens_t[si] - fl - 1).clamp(min=0))
+            ok = lens_t[si] > fl + 1
+            start = (offs_t[si] + p)[ok]
+            m = int(start.numel())
+            done += n
+            if m == 0:
+                continue
+            div = torch.rand(m, 1, generator=g, device=device) * max_div
+            mut = torch.rand(m, fl, generator=g, device=device) < div
+            rnd = torch.randint(0, 4, (m, fl), generator=g, device=device)
+            idx4 = torch.where(mut, rnd, fam_idx[None, :].expand(m, fl))
+            minus = torch.rand(m, 1, generator=g, device=device) < 0.5
+            copy = torch.where(minus, comp[idx4.flip(1)], lut[idx4])
+            pos = (start[:, None] + torch.arange(fl, device=device)[None, :]).reshape(-1)
+            seq[pos] = copy.reshape(-1)
+            del div, mut, rnd, idx4, copy, pos
+        laid += copies * fl
+        fams.append((fl, copies))
     # N runs
     n_left = int(total_bp * n_frac)
     rl_all = torch.randint(100, 50000, (max(1, n_left // 25000 + 8),), generator=g, device=device).tolist()
@@ -122,7 +187,30 @@ def make_genome_torch(torch, seed, total_bp, device, repeat_frac=0.3, n_frac=0.0
     for i in range(len(lens) - 1):
         seq[offsets[i] + lens[i]: offsets[i] + lens[i] + 32] = ord("-")
     labels = [f"chr{i + 1}" for i in range(22)] + ["chrX", "chrY"]
-    return seq, np.array(lens, np.uint32), np.array(offsets, np.uint32), labels
+    cn = sorted(c for _, c in fams)
+    desc = {"repeat_families": len(fams), "repeat_bases_laid": int(laid), "copy_number_min": cn[0] if cn else 0,
+            "copy_number_median": cn[len(cn) // 2] if cn else 0, "copy_number_max": cn[-1] if cn else 0,
+            "max_divergence": max_div, "n_frac": n_frac}
+    return seq, np.array(lens, np.uint32), np.array(offsets, np.uint32), labels, desc
+
+
+def _read_starts(torch, g, d_seq, seq_lengths, seq_offsets, n, span, device):
+    """n window starts, uniform over the sequences; a window that holds an N (an assembly gap: no sequencer reads come
+    from there) is drawn again once."""
+    ns = len(seq_lengths)
+    lens_all = torch.tensor(seq_lengths.astype(np.int64), device=device)
+    offs_all = torch.tensor(seq_offsets.astype(np.int64), device=device)
+
+    def draw(k):
+        si = torch.randint(0, ns, (k,), generator=g, device=device)
+        return offs_all[si] + (torch.rand(k, generator=g, device=device, dtype=torch.float64) * (lens_all[si] - span - 2).clamp(min=1).double()).long()
+    start = draw(n)
+    probe = torch.tensor([0, span // 2, span - 1], device=device)
+    bad = (d_seq[(start[:, None] + probe[None, :]).reshape(-1)].reshape(n, 3) == ord("N")).any(1)
+    nb = int(bad.sum())
+    if nb:
+        start[bad] = draw(nb)
+    return start
 
 
 def make_reads_torch(torch, seed, d_seq, seq_lengths, seq_offsets, n, L, sub, indel, device):
@@ -130,11 +218,7 @@ def make_reads_torch(torch, seed, d_seq, seq_lengths, seq_offsets, n, L, sub, in
     probability indel*L, half reverse-complemented.  Returns uint8 tensor [n*L]."""
     g = torch.Generator(device=device)
     g.manual_seed(seed)
-    ns = len(seq_lengths)
-    si = torch.randint(0, ns, (n,), generator=g, device=device)
-    lens = torch.tensor(seq_lengths.astype(np.int64), device=device)[si]
-    offs = torch.tensor(seq_offsets.astype(np.int64), device=device)[si]
-    start = offs + (torch.rand(n, generator=g, device=device, dtype=torch.float64) * (lens - L - 2).double()).long()
+    start = _read_starts(torch, g, d_seq, seq_lengths, seq_offsets, n, L + 2, device)
     ar = torch.arange(L, device=device)
     # one indel per affected read: deletion (skip a base) or insertion (repeat index, then randomise the base)
     u = torch.rand(n, generator=g, device=device)
@@ -165,12 +249,8 @@ def make_pairs_torch(torch, seed, d_seq, seq_lengths, seq_offsets, npairs, L, su
     """npairs FR pairs (insert ~ N(300, 50) clipped to [L+20, 600]), mates interleaved: uint8 tensor [2*npairs*L]."""
     g = torch.Generator(device=device)
     g.manual_seed(seed)
-    ns = len(seq_lengths)
-    si = torch.randint(0, ns, (npairs,), generator=g, device=device)
-    lens = torch.tensor(seq_lengths.astype(np.int64), device=device)[si]
-    offs = torch.tensor(seq_offsets.astype(np.int64), device=device)[si]
     ins = (300 + 50 * torch.randn(npairs, generator=g, device=device)).long().clamp(L + 20, 600)
-    start = offs + (torch.rand(npairs, generator=g, device=device, dtype=torch.float64) * (lens - 700).clamp(min=1).double()).long()
+    start = _read_starts(torch, g, d_seq, seq_lengths, seq_offsets, npairs, 700, device)
     ar = torch.arange(L, device=device)
     a = d_seq[(start[:, None] + ar[None, :]).reshape(-1)].reshape(npairs, L)
     b = d_seq[((start + ins - L)[:, None] + ar[None, :]).reshape(-1)].reshape(npairs, L)
@@ -192,18 +272,22 @@ def make_pairs_torch(torch, seed, d_seq, seq_lengths, seq_offsets, npairs, L, su
     return torch.stack([r1, r2], dim=1).reshape(-1).contiguous()
 
 
-def pmc_traffic(kernel, reads_per_launch, total_bp, read_len=150):
-    """HBM read bytes per launch of `kernel` from the committed rocprofv3 --pmc FETCH_SIZE pass of this same
-    workload (profiles/r1/pmc_fetch_hg38scale_*.json; bench.py cannot collect PMCs itself).  None when no
-    profile of this workload (genome size, read length, kernel) is committed."""
+def pmc_traffic(kernel, reads_per_launch, total_bp, read_len=150, mode="se", code_version=CODE_VERSION):
+    """HBM read bytes per launch of `kernel` from the committed rocprofv3 --pmc FETCH_SIZE pass of this same workload
+    (profiles/r*/pmc_fetch_*.json; bench.py cannot collect PMCs itself).  A profile counts only if it names the same
+    mode (se / pe), read length, genome size and code version; None otherwise -- no claim from a stale profile."""
     import glob
     best = None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_fetch_hg38scale_*.json"))):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_fetch_*.json"))):
         try:
             d = json.load(open(path))
         except (OSError, ValueError):
             continue
-        if abs(total_bp - 3.1e9) > 1e8 or kernel not in d.get("kernels", {}) or d.get("read_len", 150) != read_len:
+        if not isinstance(d, dict) or kernel not in d.get("kernels", {}):
+            continue
+        if d.get("mode", "se") != mode or d.get("read_len", 150) != read_len or d.get("code_version") != code_version:
+            continue
+        if abs(d.get("genome_bp", 3.1e9) - total_bp) > 0.02 * total_bp:
             continue
         best = d["kernels"][kernel]["hbm_read_bytes_per_launch"] * reads_per_launch / d["reads_per_launch"]
     return None if best is None else round(best)
@@ -221,27 +305,206 @@ def metric_name(pe, read_len):
         return "reads/s mapped, 150 bp SE vs hg38, at 1/2/4/8 MI355X; SAM bit-identical"
 
 
+def host_cores():
+    """CPUs this process may actually use (affinity and cgroup quota; the GPU boxes show 256 logical CPUs but grant 16)."""
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            cores = max(1, min(cores, int(int(q) / int(per))))
+    except (OSError, ValueError):
+        pass
+    return cores
+
+
+def place_index(R, torch, api, device, d_seq, slots, seq_lengths, seq_offsets, labels):
+    """The slot table is built by the product's -make_ufi code on the host of rank 0 (UFIndex::MakeIndex is order
+    dependent), outside the timed region, and ends up replicated in every rank's HBM: over RCCL (a broadcast of the
+    resident arrays from rank 0's GPU -- setup only, nothing on the data path) when every rank has its own GPU, through
+    a file in /dev/shm when ranks share a device.  Returns (index, blob_np, seq_np, d_seq, seconds)."""
+    t0 = time.time()
+    how = "host build + upload"
+    blob_np = seq_np = None
+    size = int(d_seq.numel())
+    cache = os.environ.get("URMAP_BENCH_INDEX_CACHE")  # directory (e.g. /dev/shm/x): reuse the built table between runs
+    cpre = os.path.join(cache, f"idx_{CODE_VERSION}_{size}_{slots}") if cache else None
+    if R.rank == 0:
+        if cpre and os.path.exists(cpre + "_blob.npy"):
+            blob_np = np.load(cpre + "_blob.npy", mmap_mode="r")
+            seq_np = np.load(cpre + "_seq.npy")
+            d_seq = torch.from_numpy(seq_np).to(device)  # the genome the cached table was built from
+            how = "cached table"
+        else:
+            seq_np = d_seq.cpu().numpy()
+            blob_np = api.build_slots(seq_np, slots)
+            if cpre:
+                os.makedirs(cache, exist_ok=True)
+                np.save(cpre + "_seq.npy", seq_np)
+                np.save(cpre + "_blob.npy", blob_np)
+    t_build = time.time() - t0
+    t0 = time.time()
+    if R.world == 1:
+        index = api.Index.wrap_host(24, 32, slots, blob_np, seq_np, seq_lengths, seq_offsets, labels).upload(R.device_index)
+    elif R.backend == "nccl":
+        how += " on rank 0, RCCL broadcast of the resident arrays"
+        d_blob = torch.empty(5 * slots + 8, dtype=torch.uint8, device=device)
+        d_seqpad = torch.zeros(size + 4096, dtype=torch.uint8, device=device)
+        if R.rank == 0:
+            with warnings.catch_warnings():  # a cached table is mapped read-only; it is only copied to the device
+                warnings.simplefilter("ignore", UserWarning)
+                step = 1 << 30
+                for lo in range(0, 5 * slots, step):
+                    hi = min(5 * slots, lo + step)
+                    d_blob[lo:hi] = torch.from_numpy(np.asarray(blob_np[lo:hi])).to(device)
+            d_blob[5 * slots:] = 0
+            d_seqpad[:size] = d_seq
+        R.broadcast_bytes(torch, d_blob)
+        R.broadcast_bytes(torch, d_seqpad)
+        d_seq = d_seqpad[:size]
+        index = api.Index.wrap_device(R.device_index, 24, 32, slots, d_blob.data_ptr(), d_seqpad.data_ptr(), size,
+                                      seq_lengths, seq_offsets, labels, keep=(d_blob, d_seqpad))
+    else:
+        how += " on rank 0, shared through a file"
+        shm_dir = "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"
+        shm = os.path.join(shm_dir, f"urmap_bench_{os.environ.get('MASTER_PORT', 'solo')}_{size}")
+        if R.rank == 0:
+            np.save(shm + "_blob.npy", blob_np)
+            np.save(shm + "_seq.npy", seq_np)
+        R.barrier()
+        if R.rank != 0:
+            blob_r = np.load(shm + "_blob.npy", mmap_mode="r")
+            seq_r = np.load(shm + "_seq.npy", mmap_mode="r")
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore", UserWarning)
+                d_seq = torch.from_numpy(np.ascontiguousarray(seq_r)).to(device)
+            index = api.Index.wrap_host(24, 32, slots, blob_r, seq_r, seq_lengths, seq_offsets, labels).upload(R.device_index)
+        else:
+            index = api.Index.wrap_host(24, 32, slots, blob_np, seq_np, seq_lengths, seq_offsets, labels).upload(R.device_index)
+        R.barrier()
+        if R.rank == 0:
+            for suf in ("_blob.npy", "_seq.npy"):
+                try:
+                    os.remove(shm + suf)
+                except OSError:
+                    pass
+    return index, blob_np, seq_np, d_seq, {"make_ufi_host": round(t_build, 1), "upload": round(time.time() - t0, 1), "how": how}
+
+
+class Workload:
+    """One synthetic read set resident in HBM + the output arrays of a step."""
+
+    def __init__(self, torch, api, device, d_seq, seq_lengths, seq_offsets, pe, L, sub, indel, nb, n_batches, seed):
+        self.pe, self.L, self.nb, self.api = pe, L, nb, api
+        self.d_offs = (torch.arange(nb + 1, device=device, dtype=torch.int64) * L).contiguous()
+        self.batches = []
+        for b in range(n_batches):
+            if pe:
+                self.batches.append(make_pairs_torch(torch, seed + b, d_seq, seq_lengths, seq_offsets, nb // 2, L, sub, 1.5 * sub, device))
+            else:
+                self.batches.append(make_reads_torch(torch, seed + b, d_seq, seq_lengths, seq_offsets, nb, L, sub, indel, device))
+        self.d_results = torch.zeros(nb * api.RESULT_DTYPE.itemsize, dtype=torch.uint8, device=device)
+        self.d_pathops = torch.zeros(nb * api.MAX_PATH_OPS, dtype=torch.int16, device=device)
+        self.d_used = torch.zeros(1, dtype=torch.int32, device=device)
+        self.last = None
+
+    def step(self, mapper, b):
+        self.last = self.batches[b % len(self.batches)]
+        f = mapper.map_pe_device if self.pe else mapper.map_se_device
+        f(self.last.data_ptr(), self.d_offs.data_ptr(), self.nb // 2 if self.pe else self.nb, self.nb * self.L, self.L,
+          self.d_results.data_ptr(), self.d_pathops.data_ptr(), self.d_used.data_ptr())
+
+    def timed(self, mapper, steps, warmup, barrier=None):
+        """W untimed steps, then K timed ones -> (seconds, mean kernel ms [probe, search])"""
+        for w in range(warmup):
+            self.step(mapper, w)
+        mapper.sync()
+        if barrier:
+            barrier()
+        kms = np.zeros(2)
+        t0 = time.perf_counter()
+        for k in range(steps):
+            self.step(mapper, warmup + k)
+            mapper.sync()
+            kms += mapper.last_kernel_ms()
+        if barrier:
+            barrier()
+        return time.perf_counter() - t0, kms / max(1, steps)
+
+    def check(self, oi, sample_n, threads):
+        """The last step's results against the oracle on its first sample_n reads: every field SAM is made of (position,
+        strand, scores, MAPQ, the alignment path) -> (parity dict, oracle counters per read, oracle seconds)."""
+        api, L = self.api, self.L
+        sample_n = int(min(self.nb, sample_n)) & ~1
+        hb = self.last[: sample_n * L].cpu().numpy()
+        ho = (np.arange(sample_n + 1, dtype=np.uint64) * L)
+        t1 = time.perf_counter()
+        ores, opaths, cnt = oi.map_pe(hb, ho, threads=threads) if self.pe else oi.map_se(hb, ho, threads=threads)
+        t_cpu = time.perf_counter() - t1
+        g = np.frombuffer(self.d_results.cpu().numpy().tobytes(), dtype=api.RESULT_DTYPE)[:sample_n]
+        used = int(self.d_used.cpu().item())
+        gops = self.d_pathops[:used].cpu().numpy().view(np.uint16)
+        diffs = {"status_nonzero": int((g["status"] != 0).sum())}
+        ok = diffs["status_nonzero"] == 0
+        for name in ("dbpos", "seq_index", "coord", "score", "second", "mapq"):
+            nd = int((g[name].astype(np.int64) != ores[name].astype(np.int64)).sum())
+            diffs[name] = nd
+            ok = ok and nd == 0
+        mapped = ores["dbpos"] != 0xFFFFFFFF
+        diffs["plus"] = int((g["plus"][mapped] != ores["plus"][mapped]).sum())
+        # paths: ungapped hits carry no path on either side; gapped ones are compared run for run
+        gapped = np.nonzero(mapped & ((g["path_nops"] > 0) | (ores["path_len"] > 0)))[0]
+        bad_paths = 0
+        for i in gapped:
+            o = int(g["path_off"][i])
+            if api.decode_path(gops[o:o + int(g["path_nops"][i])]) != opaths[i]:
+                bad_paths += 1
+        diffs["path"] = bad_paths
+        ok = ok and diffs["plus"] == 0 and bad_paths == 0
+        parity = {"reads_checked": int(sample_n), "bit_identical_to_oracle": bool(ok),
+                  "fields": "dbpos, seq_index, coord, plus, score, second, mapq, path (CIGAR)",
+                  "gapped_paths_checked": int(len(gapped)), "mapped_frac": round(float(mapped.mean()), 4)}
+        if not ok:
+            parity["mismatches"] = diffs
+            parity["status_values"] = [int(x) for x in np.unique(g["status"])]
+        return parity, {k: v / max(1, cnt["n_reads"]) for k, v in cnt.items()}, t_cpu
+
+
+def kernel_table(api, pe, L, nb, kms, counters, total_bp, gather_loads_s):
+    """Per-kernel roofline figures.  Algorithmic bytes per read from the reference algorithm's own access counts
+    (SURVEY.md 8d), counted by the oracle on the sample: probe kernel 5 B per GetBlob + the read; search kernel 5 B per
+    chain slot + compared reference bases + DP target bases + the result record."""
+    c = counters
+    algs = (5.0 * c["n_getblob"] + L, 5.0 * c["n_rowhop"] + c["n_extbases"] + c["n_dptarget"] + api.RESULT_DTYPE.itemsize)
+    names = ("seed_probe_kernel", "search_pe_kernel" if pe else "search_se_kernel")
+    sector_peak = 64.0 * gather_loads_s / 1e9
+    kern = []
+    for i in range(2):
+        ach = algs[i] * nb / (kms[i] * 1e-3) / 1e9 if kms[i] > 0 else 0.0
+        k = {"kernel": names[i], "avg_ms": round(float(kms[i]), 4), "alg_bytes_per_read": round(algs[i], 1),
+             "achieved_GBs": round(ach, 2), "frac": round(ach / HBM_PEAK_GBS, 5)}
+        t = pmc_traffic(names[i], nb, total_bp, L, "pe" if pe else "se")
+        k["hbm_read_bytes_per_launch_pmc"] = t
+        if t and sector_peak > 0 and kms[i] > 0:
+            k["sector_GBs"] = round(t / (kms[i] * 1e-3) / 1e9, 1)
+            k["frac_of_random_gather_peak"] = round(k["sector_GBs"] / sector_peak, 4)
+        kern.append(k)
+    return kern
+
+
 def main():
     args = parse_args()
-    rank = int(os.environ.get("RANK", 0))
-    world = int(os.environ.get("WORLD_SIZE", 1))
-    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    from urmap_amd import ranks
+    if args.gpus > 1 and not ranks.launched():
+        # plain `python bench.py --gpus N`: start the N ranks as child processes (this process never touches the GPU)
+        sys.exit(ranks.launch_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
+    R = ranks.Ranks()
+    rank, world = R.rank, R.world
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the mapping path has no CPU fallback")
-    # URMAP_BENCH_FORCE_DEVICE: testing aid -- run several ranks on one GPU (gloo for the barrier / reductions)
-    forced = os.environ.get("URMAP_BENCH_FORCE_DEVICE")
-    dev_index = int(forced) if forced is not None else local_rank
-    torch.cuda.set_device(dev_index)
+    R.init(torch)
+    dev_index = R.device_index
     device = torch.device("cuda", dev_index)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if forced is not None:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from urmap_amd import api
     api.lib()  # fail loudly if the HIP library is missing
@@ -249,154 +512,43 @@ def main():
     t_setup = time.time()
     L = args.read_len
     total_bp = int(args.genome_mbp * 1e6)
-    d_seq, seq_lengths, seq_offsets, labels = make_genome_torch(torch, 20260101, total_bp, device)
-    slots = next_prime(int(d_seq.numel() / 0.6))  # cmd_make_ufi: slots >= bytes / load_factor 0.6 (ufindexio.cpp:138-150)
+    d_seq, seq_lengths, seq_offsets, labels, genome_desc = make_genome_torch(torch, 20260101, total_bp, device)
+    slots, fasta_bytes = default_slot_count(seq_lengths, labels)
     t_gen = time.time() - t_setup
-    # The slot table is built by the product's -make_ufi code on the host (UFIndex::MakeIndex is order dependent),
-    # outside the timed region.  With several ranks, local rank 0 builds once and shares it through /dev/shm.
-    shm = f"/dev/shm/urmap_bench_{os.environ.get('MASTER_PORT', 'solo')}_{total_bp}"
-    t0 = time.time()
-    cache = os.environ.get("URMAP_BENCH_INDEX_CACHE")  # directory (e.g. /dev/shm/x): reuse the built table between runs
-    cpre = os.path.join(cache, f"idx_{total_bp}_{slots}") if cache else None
-    if world == 1 and cpre and os.path.exists(cpre + "_blob.npy"):
-        blob_np = np.load(cpre + "_blob.npy", mmap_mode="r")
-        seq_np = np.load(cpre + "_seq.npy")
-        d_seq = torch.from_numpy(seq_np).to(device)  # the genome the cached table was built from
-    elif world == 1:
-        seq_np = d_seq.cpu().numpy()
-        blob_np = api.build_slots(seq_np, slots)
-        if cpre:
-            os.makedirs(cache, exist_ok=True)
-            np.save(cpre + "_seq.npy", seq_np)
-            np.save(cpre + "_blob.npy", blob_np)
-    else:
-        if local_rank == 0:
-            seq_np = d_seq.cpu().numpy()
-            blob_np = api.build_slots(seq_np, slots)
-            np.save(shm + "_blob.npy", blob_np)
-            np.save(shm + "_seq.npy", seq_np)
-        dist.barrier()
-        if local_rank != 0:
-            blob_np = np.load(shm + "_blob.npy", mmap_mode="r")
-            seq_np = np.load(shm + "_seq.npy", mmap_mode="r")
-            with warnings.catch_warnings():  # the shared table is mapped read-only; it is only copied to the device
-                warnings.simplefilter("ignore", UserWarning)
-                d_seq = torch.from_numpy(np.ascontiguousarray(seq_np)).to(device)  # the genome the index was built from
-    t_build = time.time() - t0
-    t0 = time.time()
-    index = api.Index.wrap_host(24, 32, slots, blob_np, seq_np, seq_lengths, seq_offsets, labels).upload(dev_index)
-    t_upload = time.time() - t0
+    index, blob_np, seq_np, d_seq, t_index = place_index(R, torch, api, device, d_seq, slots, seq_lengths, seq_offsets, labels)
     mapper = api.Mapper(index, device=dev_index, method=6)
-    if world > 1:
-        dist.barrier()
-        if local_rank == 0:
-            for suf in ("_blob.npy", "_seq.npy"):
-                try:
-                    os.remove(shm + suf)
-                except OSError:
-                    pass
 
     nb = args.reads_per_step
-    n_batches = min(args.steps + args.warmup, 10)
-    batches = []
-    d_offs = (torch.arange(nb + 1, device=device, dtype=torch.int64) * L).contiguous()
     pe = args.mode == "pe"
-    for b in range(n_batches):
-        if pe:
-            batches.append(make_pairs_torch(torch, 1000 + 97 * rank + b, d_seq, seq_lengths, seq_offsets, nb // 2, L,
-                                            args.sub, 1.5 * args.sub, device))
-        else:
-            batches.append(make_reads_torch(torch, 1000 + 97 * rank + b, d_seq, seq_lengths, seq_offsets, nb, L, args.sub,
-                                            args.indel, device))
-    d_results = torch.zeros(nb * api.RESULT_DTYPE.itemsize, dtype=torch.uint8, device=device)
-    d_pathops = torch.zeros(nb * api.MAX_PATH_OPS, dtype=torch.int16, device=device)
-    d_used = torch.zeros(1, dtype=torch.int32, device=device)
+    n_batches = min(args.steps + args.warmup, 10)
+    wl = Workload(torch, api, device, d_seq, seq_lengths, seq_offsets, pe, L, args.sub, args.indel, nb, n_batches, 1000 + 97 * rank)
     torch.cuda.synchronize()
     setup_s = time.time() - t_setup
 
-    def step(b):
-        if pe:
-            mapper.map_pe_device(batches[b % n_batches].data_ptr(), d_offs.data_ptr(), nb // 2, nb * L, L,
-                                 d_results.data_ptr(), d_pathops.data_ptr(), d_used.data_ptr())
-        else:
-            mapper.map_se_device(batches[b % n_batches].data_ptr(), d_offs.data_ptr(), nb, nb * L, L,
-                                 d_results.data_ptr(), d_pathops.data_ptr(), d_used.data_ptr())
-
-    for w in range(args.warmup):
-        step(w)
-    mapper.sync()
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    barrier()
-    kms = np.zeros(2)
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(args.warmup + k)
-        mapper.sync()
-        a, b = mapper.last_kernel_ms()
-        kms += (a, b)
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], device=device if forced is None else "cpu", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    kms /= max(1, args.steps)
-    if os.environ.get("URMAPX_PHASE_STATS") and rank == 0:
-        pc = mapper.phase_cycles()
-        sub = pc[8:]
-        pc = pc[:8]
-        tot = max(1, sum(pc))
-        names = ("setup", "phase1+2", "phase3", "chain walks", "phase4", "phase5", "phase6", "output")
-        print("phase cycle shares: " + ", ".join(f"{n} {100.0 * c / tot:.1f}%" for n, c in zip(names, pc)) +
-              f"; cycles/read {tot / nb:.0f}; batch parts: " + ", ".join(f"{n} {100.0 * c / tot:.1f}%" for n, c in zip(("locate+fetch", "compare", "xdrop", "ordered"), sub)), file=sys.stderr, flush=True)
+    dt, kms = wl.timed(mapper, args.steps, args.warmup, barrier=lambda: R.barrier(torch))
+    dt = R.max_over_ranks(torch, dt)
     reads_per_s = world * args.steps * nb / dt
 
-    # ---- parity + CPU baseline on a bounded sample of the last batch (rank 0, N=1 only for the baseline) ----
-    cpu = None
-    parity = None
-    counters = None
+    out = None
     if rank == 0:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib as ol
-        last = batches[(args.warmup + args.steps - 1) % n_batches]
-        res = np.frombuffer(d_results.cpu().numpy().tobytes(), dtype=api.RESULT_DTYPE)
         oi = ol.Index.wrap(24, 32, slots, blob_np, seq_np, seq_lengths, seq_offsets, labels)
-        # host threads: the CPUs this process may actually use (affinity and cgroup quota; the GPU boxes expose 256 logical
-        # CPUs but grant 16)
-        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-        try:
-            q, per = open("/sys/fs/cgroup/cpu.max").read().split()
-            if q != "max":
-                cores = max(1, min(cores, int(int(q) / int(per))))
-        except (OSError, ValueError):
-            pass
-        probe_n = min(nb, 4000)
-        hb = last[: probe_n * L].cpu().numpy()
-        ho = (np.arange(probe_n + 1, dtype=np.uint64) * L)
-        t1 = time.perf_counter()
-        omap = (lambda bb, oo: oi.map_pe(bb, oo, threads=cores)) if pe else (lambda bb, oo: oi.map_se(bb, oo, threads=cores))
-        ores, opaths, cnt = omap(hb, ho)
-        t_probe = time.perf_counter() - t1
-        sample_n = probe_n
+        cores = host_cores()
+        # parity on the last timed batch; the CPU baseline (N = 1 only) times the oracle on the same reads
+        parity, counters, t_probe = wl.check(oi, 4000, cores)
+        cpu = None
         if world == 1 and not args.no_cpu_baseline:
-            sample_n = int(min(nb, max(probe_n, probe_n * args.cpu_seconds / max(t_probe, 1e-3)))) & ~1
-            hb = last[: sample_n * L].cpu().numpy()
-            ho = (np.arange(sample_n + 1, dtype=np.uint64) * L)
-            t1 = time.perf_counter()
-            ores, opaths, cnt = omap(hb, ho)
-            t_cpu = time.perf_counter() - t1
-            cpu_reads = sample_n
-            # more batches of the same workload until about cpu_seconds of CPU work are timed (parity uses the last batch)
+            sample_n = int(min(nb, max(4000, 4000 * args.cpu_seconds / max(t_probe, 1e-3))))
+            parity, counters, t_cpu = wl.check(oi, sample_n, cores)
+            cpu_reads = parity["reads_checked"]
+            ho = (np.arange(nb + 1, dtype=np.uint64) * L)
             extra = 0
-            while t_cpu < args.cpu_seconds * 0.6 and sample_n == nb and extra + 1 < n_batches:
-                hb2 = batches[extra][: nb * L].cpu().numpy()
+            omap = (lambda bb: oi.map_pe(bb, ho, threads=cores)) if pe else (lambda bb: oi.map_se(bb, ho, threads=cores))
+            while t_cpu < args.cpu_seconds * 0.6 and cpu_reads >= nb and extra + 1 < n_batches:
+                hb2 = wl.batches[extra][: nb * L].cpu().numpy()
                 t1 = time.perf_counter()
-                omap(hb2, ho)
+                omap(hb2)
                 t_cpu += time.perf_counter() - t1
                 cpu_reads += nb
                 extra += 1
@@ -404,48 +556,24 @@ def main():
                    "sample": f"{cpu_reads} reads of the timed batches (the last batch first), same index, "
                              f"oracle/liburmap_oracle.so (CPU restatement, SAM-identical to reference urmap) with {cores} "
                              f"OpenMP threads = the CPUs granted to this process ({os.cpu_count()} logical on the host), "
-                             f"{t_cpu:.1f} s; the reference binary itself on the same host: DESIGN.md section 5"}
-        g = res[:sample_n]
-        ok = bool((g["status"] == 0).all())
-        diffs = {"status_nonzero": int((g["status"] != 0).sum())}
-        for name in ("dbpos", "score", "second", "mapq"):
-            nd = int((g[name].astype(np.int64) != ores[name].astype(np.int64)).sum())
-            diffs[name] = nd
-            ok = ok and nd == 0
-        parity = {"reads_checked": int(sample_n), "bit_identical_to_oracle": ok,
-                  "mapped_frac": round(float((ores["dbpos"] != 0xFFFFFFFF).mean()), 4)}
-        if not ok:
-            parity["mismatches"] = diffs
-            parity["status_values"] = [int(x) for x in np.unique(g["status"])]
-        counters = {k: v / cnt["n_reads"] for k, v in cnt.items()}
+                             f"{t_cpu:.1f} s"}
+            if cores > 10:  # the reference's own default thread count is min(cores, 10) (myutils.cpp:135-139)
+                n10 = int(min(nb, max(4000, cpu_reads * 10 / cores / 3))) & ~1
+                hb = wl.last[: n10 * L].cpu().numpy()
+                h10 = (np.arange(n10 + 1, dtype=np.uint64) * L)
+                t1 = time.perf_counter()
+                (oi.map_pe if pe else oi.map_se)(hb, h10, threads=10)
+                cpu["value_10_threads"] = round(n10 / (time.perf_counter() - t1), 1)
+        elif world == 1:
+            parity, counters, _ = wl.check(oi, min(nb, 200_000), cores)
 
-    if rank == 0:
-        # algorithmic bytes per read from the reference algorithm's own access counts, counted
-        # by the oracle on the sample: probe kernel 5 B per GetBlob + the read; search kernel 5 B per chain
-        # slot + compared reference bases + DP target bases + the result record.
-        c = counters
-        alg_probe = 5.0 * c["n_getblob"] + L
-        alg_search = 5.0 * c["n_rowhop"] + c["n_extbases"] + c["n_dptarget"] + api.RESULT_DTYPE.itemsize
-        names = ("seed_probe_kernel", "search_pe_kernel" if pe else "search_se_kernel")
-        algs = (alg_probe, alg_search)
-        dom = int(np.argmax(kms))
-        kern = []
-        for i in range(2):
-            ach = algs[i] * nb / (kms[i] * 1e-3) / 1e9 if kms[i] > 0 else 0.0
-            kern.append({"kernel": names[i], "avg_ms": round(float(kms[i]), 4), "alg_bytes_per_read": round(algs[i], 1),
-                         "achieved_GBs": round(ach, 2), "frac": round(ach / HBM_PEAK_GBS, 5)})
-        # measured random-access ceiling of the resident slot table (64-byte sector per 5-byte slot read)
         try:
             gather_loads_s = mapper.gather_microbench(1 << 28)
         except Exception:
             gather_loads_s = 0.0
-        sector_peak = 64.0 * gather_loads_s / 1e9
-        traffic = [pmc_traffic(names[i], nb, total_bp, L) for i in range(2)]
-        for i in range(2):
-            kern[i]["hbm_read_bytes_per_launch_pmc"] = traffic[i]
-            if traffic[i] and sector_peak > 0 and kms[i] > 0:
-                kern[i]["sector_GBs"] = round(traffic[i] / (kms[i] * 1e-3) / 1e9, 1)
-                kern[i]["frac_of_random_gather_peak"] = round(kern[i]["sector_GBs"] / sector_peak, 4)
+        kern = kernel_table(api, pe, L, nb, kms, counters, total_bp, gather_loads_s)
+        dom = int(np.argmax(kms))
+        key = "pe150" if pe else ("se150" if L == 150 else ("se250" if L == 250 else None))
         out = {
             "metric": metric_name(pe, L),
             "value": round(reads_per_s, 1),
@@ -460,25 +588,44 @@ def main():
             "dtype": "u8/u64 (fp32 DP cells as the reference)",
             "data": "synthetic",
             "config": {"workload": f"{L} bp {'PE mates (pairs interleaved)' if pe else 'SE reads'} vs synthetic hg38-shaped {args.genome_mbp:g} Mbp genome "
-                                   f"({slots} slots, {5 * slots / 1e9:.2f} GB slot table + {len(seq_np) / 1e9:.2f} GB sequence "
-                                   f"resident in HBM); {nb} reads/step, {args.sub:g} sub, {args.indel:g} indel",
+                                   f"({slots} slots = GetPrime({fasta_bytes} FASTA bytes / 0.6), {5 * slots / 1e9:.2f} GB slot table + "
+                                   f"{len(seq_np) / 1e9:.2f} GB sequence resident in HBM); {nb} reads/step, {args.sub:g} sub, {args.indel:g} indel",
                        "reads_per_step": nb, "read_len": L, "genome_bp": int(len(seq_np)), "slots": int(slots),
-                       "setup_s": {"genome": round(t_gen, 1), "make_ufi_host": round(t_build, 1),
-                                   "upload": round(t_upload, 1), "total": round(setup_s, 1)}},
-            "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": kern[dom]["achieved_GBs"],
+                       "genome": genome_desc, "ranks": {"world": world, "backend": R.backend, "share_devices": bool(R.shared)},
+                       "setup_s": {"genome": round(t_gen, 1), **t_index, "total": round(setup_s, 1)}},
+            "roofline": {"bound": "hbm", "kernel": kern[dom]["kernel"], "achieved": kern[dom]["achieved_GBs"],
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": kern[dom]["frac"],
-                         "traffic": traffic[dom],
-                         "random_gather_peak": {"slot_reads_per_s": round(gather_loads_s), "sector_GBs": round(sector_peak, 1),
+                         "traffic": kern[dom]["hbm_read_bytes_per_launch_pmc"],
+                         "random_gather_peak": {"slot_reads_per_s": round(gather_loads_s), "sector_GBs": round(64.0 * gather_loads_s / 1e9, 1),
                                                 "note": "measured in this run: independent random 5-byte slot reads over the resident table, 64 B sector each"}},
             "kernels": kern,
             "parity": parity,
             "work_per_read": {k: round(v, 2) for k, v in counters.items()},
         }
+        if key:
+            out["work_per_read_survey"] = SURVEY_WORK_PER_READ[key]
         if cpu is not None:
             out["cpu_baseline"] = cpu
+
+        # configs 3 and 5 on the same resident index (N = 1, headline run only): fewer steps, >= 100 k reads checked
+        if world == 1 and not pe and L == 150 and not args.no_other_workloads:
+            others = {}
+            for name, (ope, oL, osub, oindel) in {"pe_2x150": (True, 150, 0.01, 0.001), "se_250_5pct": (False, 250, 0.04, 0.01)}.items():
+                t0 = time.time()
+                del wl
+                torch.cuda.empty_cache()
+                wl = Workload(torch, api, device, d_seq, seq_lengths, seq_offsets, ope, oL, osub, oindel, nb, 3, 5000)
+                odt, okms = wl.timed(mapper, 5, 1)
+                opar, ocnt, ot = wl.check(oi, min(nb, 200_000), cores)
+                okern = kernel_table(api, ope, oL, nb, okms, ocnt, total_bp, gather_loads_s)
+                others[name] = {"metric": metric_name(ope, oL), "value": round(5 * nb / odt, 1), "unit": "reads/s", "steps": 5, "warmup": 1,
+                                "ms_per_step": round(1e3 * odt / 5, 3), "kernels": okern, "parity": opar,
+                                "work_per_read": {k: round(v, 2) for k, v in ocnt.items()},
+                                "cpu_port_reads_per_s": round(opar["reads_checked"] / ot, 1), "cpu_port_threads": cores,
+                                "sub": osub, "indel": oindel, "wall_s": round(time.time() - t0, 1)}
+            out["other_workloads"] = others
         print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
+    R.close()
 
 
 if __name__ == "__main__":

@@ -95,6 +95,10 @@ int urmapx_index_wrap_device(int device, uint32_t word_length, uint32_t max_ix, 
                              urmapx_index **out);
 /* Copy slot table + sequence to HBM of `device` (once per GPU); no-op if already resident there. */
 int urmapx_index_upload(urmapx_index *, int device);
+/* A second, third... replica of an index that has its host arrays (opened or wrapped) in the HBM of another device:
+ * one replica per GPU, reads sharded across them, no exchange between devices (the reference's threads share one
+ * UFIndex, map.cpp:43-61).  The new object borrows src's host arrays: close it before src. */
+int urmapx_index_replicate(const urmapx_index *src, int device, urmapx_index **out);
 void urmapx_index_close(urmapx_index *);
 
 uint32_t urmapx_index_word_length(const urmapx_index *);

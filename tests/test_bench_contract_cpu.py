@@ -29,12 +29,39 @@ def test_defaults_are_one_gpu_and_the_headline_workload(monkeypatch):
     assert a.genome_mbp == 3100 and a.reads_per_step == 1_000_000
 
 
-def test_pmc_traffic_lookup_uses_committed_profiles():
-    t = bench.pmc_traffic("search_se_kernel", 1_000_000, 3_100_000_727)
-    assert t is not None and 1e10 < t < 1e11            # 25.5 GB per 1 M reads in profiles/r1
-    assert bench.pmc_traffic("search_se_kernel", 500_000, 3_100_000_727) == round(t / 2)
-    assert bench.pmc_traffic("search_se_kernel", 1_000_000, 800_000_000) is None   # another workload: no claim
+def test_pmc_traffic_lookup_matches_workload_and_code_version(tmp_path, monkeypatch):
+    """A committed FETCH_SIZE profile counts only for the same mode (se / pe), read length, genome size and code
+    version: round 1's lookup took the paired-end file for the single-end probe kernel and kept quoting stale code."""
+    prof = tmp_path / "profiles" / "r9"
+    prof.mkdir(parents=True)
+
+    def put(name, mode, code, probe_bytes):
+        (prof / name).write_text(json.dumps({"mode": mode, "read_len": 150, "code_version": code, "genome_bp": 3.1e9,
+                                             "reads_per_launch": 1_000_000,
+                                             "kernels": {"seed_probe_kernel": {"hbm_read_bytes_per_launch": probe_bytes}}}))
+    put("pmc_fetch_a_se.json", "se", bench.CODE_VERSION, 16.5e9)
+    put("pmc_fetch_b_pe.json", "pe", bench.CODE_VERSION, 16.2e9)
+    put("pmc_fetch_c_old.json", "se", "r0", 99e9)
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    assert bench.pmc_traffic("seed_probe_kernel", 1_000_000, 3_100_000_727, 150, "se") == round(16.5e9)
+    assert bench.pmc_traffic("seed_probe_kernel", 500_000, 3_100_000_727, 150, "pe") == round(8.1e9)
+    assert bench.pmc_traffic("seed_probe_kernel", 1_000_000, 800_000_000, 150, "se") is None   # another genome: no claim
+    assert bench.pmc_traffic("seed_probe_kernel", 1_000_000, 3_100_000_727, 250, "se") is None
     assert bench.pmc_traffic("no_such_kernel", 1_000_000, 3_100_000_727) is None
+    assert bench.pmc_traffic("seed_probe_kernel", 1_000_000, 3_100_000_727, 150, "se", code_version="r7") is None
+
+
+def test_round1_profiles_are_stale_for_this_code():
+    assert bench.pmc_traffic("search_se_kernel", 1_000_000, 3_100_000_727, 150, "se", code_version="r1-not-recorded") is None
+
+
+def test_get_prime_ladder():
+    """GetPrime (prime.cpp:11-21): the rungs the reference's table holds around the hg38 size."""
+    assert bench.get_prime(100) == 101 and bench.get_prime(102) == 107
+    assert bench.get_prime(5_250_000_000) == 5392814809
+    assert bench.get_prime(5_392_814_810) == 5676647183
+    slots, size = bench.default_slot_count([1000, 61], ["a", "bc"])
+    assert size == (3 + 1000 + 17) + (4 + 61 + 2) and slots == bench.get_prime(int(size / 0.6))
 
 
 def test_committed_bench_lines_carry_the_contract_keys():

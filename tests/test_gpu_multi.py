@@ -1,0 +1,109 @@
+"""GPU tests of the multi-device paths: read batches sharded over N mapping lanes / N ranks, one index
+replica per device, no exchange between devices.  The reference fans reads over the threads of one process the same way
+(map.cpp:58-61, seqsource.cpp:30-66).  On a box with one GPU every lane / rank is put on device 0 (URMAPX_FORCE_DEVICE
+for the command line, URMAP_RANK_DEVICES for bench.py's ranks): the code path is the N-device one, only the device
+numbers collapse."""
+import gzip
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+EXE = os.path.join(ROOT, "urmap_amd", "urmap")
+
+
+def _golden_ufi(tmp_path, name="g.ufi.gz"):
+    ufi = os.path.join(tmp_path, "g.ufi")
+    with gzip.open(os.path.join(GOLD, name), "rb") as z, open(ufi, "wb") as f:
+        f.write(z.read())
+    return ufi
+
+
+def _records(path):
+    return [l for l in open(path, "rb").read().split(b"\n") if l and not l.startswith(b"@PG")]
+
+
+def _force_env():
+    import torch
+    env = dict(os.environ)
+    if torch.cuda.device_count() < 2:
+        env["URMAPX_FORCE_DEVICE"] = "0"
+    return env
+
+
+@pytest.mark.parametrize("gpus,streams,batch", [(2, 1, 64), (2, 2, 50), (3, 2, 17)])
+def test_cli_map_on_two_devices_reproduces_reference_sam(tmp_path, gpus, streams, batch):
+    """`urmap -map ... -gpus N -streams K`: batch b -> lane b mod (N K) on device b mod N; the SAM is the reference's
+    golden SAM, in input order."""
+    ufi = _golden_ufi(tmp_path)
+    out = os.path.join(tmp_path, "out.sam")
+    r = subprocess.run([EXE, "-map", os.path.join(GOLD, "se150.fq"), "-ufi", ufi, "-samout", out, "-batch", str(batch),
+                        "-gpus", str(gpus), "-streams", str(streams)], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       timeout=300, env=_force_env())
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    assert _records(out) == [l for l in open(os.path.join(GOLD, "se150.sam"), "rb").read().split(b"\n") if l]
+    assert f"({gpus} GPUs)".encode() in r.stderr
+
+
+def test_cli_map2_on_two_devices_reproduces_reference_sam_and_tab(tmp_path):
+    ufi = _golden_ufi(tmp_path)
+    out, tab = os.path.join(tmp_path, "out.sam"), os.path.join(tmp_path, "out.tab")
+    r = subprocess.run([EXE, "-map2", os.path.join(GOLD, "pe150_1.fq"), "-reverse", os.path.join(GOLD, "pe150_2.fq"), "-ufi", ufi,
+                        "-samout", out, "-tabbedout", tab, "-batch", "60", "-gpus", "2", "-streams", "2"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=_force_env())
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    assert _records(out) == [l for l in open(os.path.join(GOLD, "pe150.sam"), "rb").read().split(b"\n") if l]
+    assert open(tab, "rb").read() == open(os.path.join(GOLD, "pe150.tab"), "rb").read()
+
+
+def test_two_index_replicas_two_contexts_through_the_library(tmp_path):
+    """urmapx_index_replicate + one context per replica: batches of the golden reads alternate between the two
+    contexts and the records equal the golden SAM."""
+    import torch
+    from urmap_amd import api
+    ufi = _golden_ufi(tmp_path)
+    second = 1 if torch.cuda.device_count() > 1 else 0
+    idx0 = api.Index.open(ufi).upload(0)
+    idx1 = idx0.replicate(second)
+    maps = [api.Mapper(idx0, device=0), api.Mapper(idx1, device=second)]
+    labels, bases, offs, quals = api.read_fastq_arrays(os.path.join(GOLD, "se150.fq"))
+    n = len(labels)
+    sam = []
+    for b, lo in enumerate(range(0, n, 37)):
+        hi = min(n, lo + 37)
+        o = offs[lo:hi + 1] - offs[lo]
+        bb = bases[int(offs[lo]):int(offs[hi])]
+        res, ops = maps[b % 2].map_se(bb, o)
+        sam.append(idx0.sam_se(res, ops, labels[lo:hi], bb, o, quals[int(offs[lo]):int(offs[hi])]))
+    got = [l for l in b"".join(sam).split(b"\n") if l]
+    want = [l for l in open(os.path.join(GOLD, "se150.sam"), "rb").read().split(b"\n") if l and not l.startswith(b"@")]
+    assert got == want
+    for m in maps:
+        m.close()
+    idx1.close()
+
+
+def test_bench_starts_its_own_two_ranks():
+    """`python bench.py --gpus 2` with no launcher around it: two child ranks, one JSON line with n_gpus 2, results of
+    rank 0's last batch bit-identical to the oracle."""
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--genome-mbp", "40", "--reads-per-step", "20000",
+                        "--steps", "2", "--warmup", "1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout.decode()[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["ranks"]["world"] == 2
+    assert d["parity"]["bit_identical_to_oracle"], d["parity"]
+    assert d["value"] > 0 and d["scaling"] == "weak"
+    import torch
+    assert d["config"]["ranks"]["backend"] == ("nccl" if torch.cuda.device_count() >= 2 else "gloo")

@@ -172,6 +172,90 @@ def test_map_se_matches_oracle(small_case, gpu, read_len, sub, indel, n):
     compare_results(gres, gops, ores, opaths)
 
 
+@pytest.fixture(scope="module")
+def dense_case(workdir):
+    """An index at load factor 0.95: free slots are rare, so collision chains need the two-step long links
+    (TALLY_LONG_MINE 253 / TALLY_LONG_OTHER 125: ufindex.cpp:256-300, walked by GetRow_Blob ufindex.cpp:905-925).  None
+    of the other fixtures contains such a slot."""
+    import os
+    import oracle_lib as ol
+    from urmap_amd import api, synth
+    g = synth.make_genome(77, [400000, 150000], repeat_frac=0.15, n_families=6, n_run_frac=0.005)
+    fa = os.path.join(workdir, "dense.fa")
+    synth.write_fasta(fa, g)
+    oi = ol.Index.build(fa, 578_041)
+    ufi = os.path.join(workdir, "dense.ufi")
+    oi.save(ufi)
+    t0 = oi.blob().reshape(-1, 5)[:, 0]
+    assert int((t0 == 253).sum()) >= 1000 and int((t0 == 125).sum()) >= 1000, "fixture lost its long links"
+    idx = api.Index.open(ufi).upload(0)
+    return {"genome": g, "ufi": ufi, "oracle_index": oi, "index": idx, "mapper": api.Mapper(idx, device=0, method=6)}
+
+
+def _long_link_hops(oi, slots, tallies, limit):
+    """Walk the chains of the first `limit` k-mers whose head is "mine" the way GetRow_Blob does and count the hops that
+    go through a long link."""
+    blob = oi.blob().reshape(-1, 5)
+    N, max_ix = oi.slot_count, oi.max_ix
+    hops = walked = 0
+    for s, t in zip(slots.tolist(), tallies.tolist()):
+        if s == 0xFFFFFFFFFFFFFFFF or not (t & 128) or t in (254, 255):
+            continue
+        walked += 1
+        k = 0
+        while True:
+            k += 1
+            t = int(blob[s, 0])
+            if k == max_ix or t == 127 or t in (254, 255):
+                break
+            if t in (253, 125):
+                pos = int(blob[s, 1:5].view("<u4")[0])
+                s = (s + (pos & 0xFFFF) + (pos >> 16)) % N
+                hops += 1
+            else:
+                s = (s + (t & 127)) % N
+        if walked >= limit:
+            break
+    return hops, walked
+
+
+@pytest.mark.parametrize("read_len,sub,indel,n", [(150, 0.01, 0.001, 3000), (250, 0.04, 0.01, 800)])
+def test_map_se_on_dense_index_walks_long_links(dense_case, read_len, sub, indel, n):
+    """Single-end parity on the dense index: the device's chain walk (walk_all) goes through TALLY_LONG_* slots."""
+    from urmap_amd import synth
+    from conftest import reads_to_arrays
+    oi = dense_case["oracle_index"]
+    reads = synth.make_reads(300 + read_len, dense_case["genome"], n, read_len=read_len, sub=sub, ins=indel / 2, dele=indel / 2,
+                             random_frac=0.02)
+    bases, offs = reads_to_arrays(reads)
+    slots, tallies, _ = dense_case["mapper"].seed_probe(bases, offs)
+    assert int((tallies == 253).sum()) > 200, "no read k-mer lands on a long-link head"
+    hops, walked = _long_link_hops(oi, slots, tallies, 20000)
+    assert hops > 300, (hops, walked)
+    ores, opaths, _ = oi.map_se(bases, offs, threads=4)
+    gres, gops = dense_case["mapper"].map_se(bases, offs)
+    compare_results(gres, gops, ores, opaths)
+    assert (ores["dbpos"] != 0xFFFFFFFF).mean() > 0.9
+
+
+def test_pe_on_dense_index_walks_long_links(dense_case, tmp_path):
+    """Paired-end twin (SearchPE_Pending's chain walks, kernels_pe.hip) on the dense index: SAM == the oracle's."""
+    import os
+    from urmap_amd import synth
+    r1, r2 = synth.make_pairs(91, dense_case["genome"], 2500, read_len=150, sub1=0.01, sub2=0.03, ins=0.001, dele=0.001)
+    f1, f2 = os.path.join(tmp_path, "r1.fq"), os.path.join(tmp_path, "r2.fq")
+    synth.write_fastq(f1, r1)
+    synth.write_fastq(f2, r2)
+    osam = os.path.join(tmp_path, "o.sam")
+    dense_case["oracle_index"].map_file_pe(f1, f2, osam, threads=4)
+    got = _map_pe_sam(dense_case["ufi"], f1, f2)
+    want = open(osam, "rb").read()
+    if got != want:
+        g, w = got.split(b"\n"), want.split(b"\n")
+        bad = [i for i in range(min(len(g), len(w))) if g[i] != w[i]]
+        raise AssertionError(f"{len(bad)} differing records of {len(w)}, first: {g[bad[0]][:200]!r} vs {w[bad[0]][:200]!r}")
+
+
 @pytest.mark.parametrize("lo,hi", [(24, 128), (24, 192), (24, 256), (24, 320)])
 def test_map_se_mixed_lengths_in_one_batch(small_case, gpu, lo, hi):
     """A batch is run by the kernel instance of its longest read: reads of every length from W up to the class limit in

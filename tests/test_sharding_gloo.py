@@ -1,53 +1,68 @@
-"""CPU, world_size 2 (gloo): the multi-GPU path is "reads sharded by rank, index replicated, no collective on
-the data path" (SURVEY.md 8e).  This checks the sharding helper partitions a read set exactly and that the
-rank-0 aggregate used for reporting sees every read once."""
+"""CPU, world_size 2 (gloo): the multi-GPU path is "read batches sharded by rank, index replicated, no collective on
+the data path" (the reference's unit is an OpenMP thread, map.cpp:58-61).  bench.py starts its own ranks
+through urmap_amd.ranks.launch_ranks when run as plain `python bench.py --gpus N`; this drives the same launcher and the
+same init / barrier / reductions / broadcast with a CPU script."""
+import json
 import os
-import socket
+import subprocess
 import sys
-
-import numpy as np
-import torch
-import torch.distributed as dist
-import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+from urmap_amd import ranks  # noqa: E402
+
+PROBE = os.path.join(ROOT, "tests", "tools", "rank_probe.py")
 
 
-def _worker(rank, world, port, n_reads, batch):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    from urmap_amd import shard
-    mine = shard.batches_for_rank(n_reads, batch, rank, world)
-    seen = torch.zeros(n_reads, dtype=torch.int32)
-    total = 0
-    for lo, hi in mine:
-        seen[lo:hi] += 1
-        total += hi - lo
-    dist.all_reduce(seen)
-    t = torch.tensor([total], dtype=torch.int64)
-    dist.all_reduce(t)
-    assert int(t.item()) == n_reads
-    assert bool((seen == 1).all())
-    # max-over-ranks timing reduction used by bench.py
-    x = torch.tensor([float(rank + 1)], dtype=torch.float64)
-    dist.all_reduce(x, op=dist.ReduceOp.MAX)
-    assert x.item() == float(world)
-    dist.destroy_process_group()
+def _launch(n, n_reads, batch):
+    env = dict(os.environ)
+    env["URMAP_RANK_DEVICES"] = "0"
+    port = ranks.free_port()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), PROBE, str(n_reads), str(batch)]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout.decode()
+    return json.loads(lines[0])
 
 
-def test_read_sharding_world2():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    mp.spawn(_worker, args=(2, port, 100003, 4096), nprocs=2, join=True)
+def test_two_ranks_cover_every_read_once_and_reduce():
+    d = _launch(2, 100003, 4096)
+    assert d["world"] == 2 and d["backend"] == "gloo"
+    assert d["total"] == 100003 and d["covered_once"] and d["broadcast_ok"]
+    assert d["slowest"] == 2.0   # max over ranks, as the bench contract times a step
+
+
+def test_launch_ranks_starts_children_and_returns_their_code(tmp_path):
+    """ranks.launch_ranks is what `python bench.py --gpus N` calls before touching the GPU."""
+    ok = tmp_path / "ok.py"
+    ok.write_text("import os, sys\nassert os.environ['WORLD_SIZE'] == '2' and os.environ['URMAP_RANK_DEVICES'] == '0'\n"
+                  "open(sys.argv[1] + os.environ['RANK'], 'w').write('x')\n")
+    assert ranks.launch_ranks(str(ok), [str(tmp_path / "seen")], 2, n_devices=0, timeout=300) == 0
+    assert (tmp_path / "seen0").exists() and (tmp_path / "seen1").exists()
+    bad = tmp_path / "bad.py"
+    bad.write_text("import sys\nsys.exit(3)\n")
+    assert ranks.launch_ranks(str(bad), [], 2, n_devices=0, timeout=300) != 0
 
 
 def test_batches_cover_everything_single_rank():
-    from urmap_amd import shard
-    b = shard.batches_for_rank(10, 4, 0, 1)
+    b = ranks.batches_for_rank(10, 4, 0, 1)
     assert b == [(0, 4), (4, 8), (8, 10)]
-    assert shard.batches_for_rank(10, 4, 1, 3) == [(4, 8)]
-    assert shard.batches_for_rank(0, 4, 0, 2) == []
+    assert ranks.batches_for_rank(10, 4, 1, 3) == [(4, 8)]
+    assert ranks.batches_for_rank(0, 4, 0, 2) == []
+
+
+def test_device_assignment_rules(monkeypatch):
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "URMAP_RANK_DEVICES", "URMAP_BENCH_FORCE_DEVICE"):
+        monkeypatch.delenv(k, raising=False)
+    assert not ranks.launched()
+    r = ranks.Ranks()
+    assert (r.rank, r.world, r.device_index, r.shared) == (0, 1, 0, False)
+    monkeypatch.setenv("RANK", "5"); monkeypatch.setenv("WORLD_SIZE", "8"); monkeypatch.setenv("LOCAL_RANK", "5")
+    assert ranks.launched()
+    r = ranks.Ranks()
+    assert (r.device_index, r.shared) == (5, False)          # one GPU per rank: RCCL
+    monkeypatch.setenv("URMAP_RANK_DEVICES", "2")
+    r = ranks.Ranks()
+    assert (r.device_index, r.shared) == (1, True)           # ranks outnumber devices: share, gloo

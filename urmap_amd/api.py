@@ -26,7 +26,7 @@ assert RESULT_DTYPE.itemsize == 28
 
 EXPORTS = (
     "urmapx_params_for_method", "urmapx_index_open", "urmapx_index_wrap_host", "urmapx_index_wrap_device",
-    "urmapx_index_upload", "urmapx_index_close", "urmapx_index_word_length", "urmapx_index_max_ix",
+    "urmapx_index_upload", "urmapx_index_replicate", "urmapx_index_close", "urmapx_index_word_length", "urmapx_index_max_ix",
     "urmapx_index_slot_count", "urmapx_index_seqdata_size", "urmapx_index_seq_count", "urmapx_index_label",
     "urmapx_index_seq_length", "urmapx_index_seq_offset", "urmapx_ctx_create", "urmapx_ctx_destroy",
     "urmapx_map_se", "urmapx_map_se_device", "urmapx_ctx_sync", "urmapx_ctx_last_kernel_ms",
@@ -73,6 +73,7 @@ def lib():
     L.urmapx_index_wrap_host.argtypes = [u32, u32, u64, vp, vp, u32, u32, vp, vp, cp, C.POINTER(vp)]
     L.urmapx_index_wrap_device.argtypes = [i32, u32, u32, u64, vp, vp, u32, u32, vp, vp, cp, C.POINTER(vp)]
     L.urmapx_index_upload.argtypes = [vp, i32]
+    L.urmapx_index_replicate.argtypes = [vp, i32, C.POINTER(vp)]
     L.urmapx_index_close.argtypes = [vp]
     L.urmapx_index_close.restype = None
     for name, rt in (("word_length", u32), ("max_ix", u32), ("slot_count", u64), ("seqdata_size", u32),
@@ -200,6 +201,12 @@ class Index:
     def upload(self, device=0):
         _check(lib().urmapx_index_upload(self.h, device), "urmapx_index_upload")
         return self
+
+    def replicate(self, device):
+        """Another replica of this index in the HBM of `device` (one per GPU; reads are sharded across them)."""
+        h = C.c_void_p()
+        _check(lib().urmapx_index_replicate(self.h, device, C.byref(h)), "urmapx_index_replicate")
+        return Index(h.value, keep=(self,))
 
     @property
     def word_length(self): return lib().urmapx_index_word_length(self.h)

@@ -1,14 +1,17 @@
 // urmap_main.cpp -- command line of the MI355X build: the reference's `urmap -map` / `-make_ufi` surface
 // (urmap_main.cpp:6-41, map.cpp:27-67, ufindexio.cpp:117-179) as a batch dispatcher over liburmapx.so.
 //
-//   urmap -map reads.fq[.gz] -ufi index.ufi -samout out.sam [-veryfast] [-threads N] [-gpu D] [-batch N]
+//   urmap -map reads.fq[.gz] -ufi index.ufi -samout out.sam [-veryfast] [-threads N] [-gpu D] [-gpus N] [-streams K] [-batch N]
 //   urmap -make_ufi genome.fa -output index.ufi [-slots N] [-wordlength W] [-maxix M] [-veryfast]
 //
 //   urmap -map2 R1.fq -reverse R2.fq -ufi index.ufi -samout out.sam [-tabbedout out.tab]   (paired-end, map2.cpp:39-90)
 //
-// Pipeline of -map: one reader thread parses FASTQ into batches, the main thread maps batch k on the GPU while
-// a writer thread formats and writes the SAM of batch k-1.  Records are written in input order (the reference's
-// order is nondeterministic with more than one thread).  Errors: message on stderr, exit status 1
+// Pipeline of -map: one reader thread parses FASTQ into batches; batch b goes to mapping lane b mod (N*K), a host
+// thread with its own mapping context on GPU D + (b mod N) (-gpus N devices, each holding its own replica of the index,
+// -streams K contexts per device so that one lane's copies overlap another's kernels); a writer thread takes the
+// batches back in input order and formats and writes their SAM.  The reference fans reads over its OpenMP threads the
+// same way (map.cpp:58-61, seqsource.cpp:30-66) but writes in completion order; here records are written
+// in input order.  No data moves between devices.  Errors: message on stderr, exit status 1
 // (myutils.cpp:915), as the reference.
 #include <fcntl.h>
 #include <omp.h>
@@ -49,7 +52,7 @@ struct Opts {
 	bool veryfast = false, quiet = false, minq_given = false;
 	unsigned threads = 0, wordlength = 24, maxix = 0, minq = 10;
 	unsigned long long slots = 0;
-	int gpu = 0;
+	int gpu = 0, gpus = 1, streams = 2;
 	unsigned batch = 1u << 18;
 };
 
@@ -76,6 +79,8 @@ static Opts parse(int argc, char **argv) {
 		else if (a == "-slots") o.slots = strtoull(val(), nullptr, 10);
 		else if (a == "-minq") { o.minq = (unsigned)atoi(val()); o.minq_given = true; }
 		else if (a == "-gpu") o.gpu = atoi(val());
+		else if (a == "-gpus") o.gpus = atoi(val());
+		else if (a == "-streams") o.streams = atoi(val());
 		else if (a == "-batch") o.batch = (unsigned)atoi(val());
 		else if (a == "-veryfast") o.veryfast = true;
 		else if (a == "-quiet") o.quiet = true;
@@ -147,14 +152,35 @@ static int cmd_map(const Opts &o, int argc, char **argv) {
 	if (paired && o.reverse.empty()) die("-reverse required");
 	if (o.ufi.empty()) die("-ufi option required");
 	const auto t0 = std::chrono::steady_clock::now();
+	if (o.gpus < 1 || o.gpus > 64) die("-gpus must be 1..64");
+	if (o.streams < 1 || o.streams > 8) die("-streams must be 1..8");
+	// URMAPX_FORCE_DEVICE=d (test aid): every lane runs on physical device d, so that the -gpus N code path can be
+	// exercised on a machine with one GPU
+	const char *forced = getenv("URMAPX_FORCE_DEVICE");
+	auto phys = [&](int g) { return forced ? atoi(forced) : o.gpu + g; };
 	urmapx_index *I = nullptr;
 	check(urmapx_index_open(o.ufi.c_str(), &I), ("Reading index " + o.ufi).c_str());
-	check(urmapx_index_upload(I, o.gpu), "Uploading index to the GPU");
 	urmapx_params P;
 	check(urmapx_params_for_method((o.veryfast && o.map2.empty()) ? 7 : 6, &P), "SetMethod");  // -map2 always uses method 6 (map2.cpp:15-16)
-	urmapx_ctx *C = nullptr;
-	check(urmapx_ctx_create(I, o.gpu, &P, &C), "Creating mapping context");
-	if (!o.map2.empty() && o.veryfast) check(urmapx_ctx_set_pe_veryfast(C, 1), "Search5");
+	// one replica of the index per device (uploaded concurrently), K mapping contexts on each
+	const int n_lanes = o.gpus * o.streams;
+	std::vector<urmapx_index *> replicas((size_t)o.gpus, nullptr);
+	{
+		std::vector<int> rcs((size_t)o.gpus, 0);
+		std::vector<std::thread> up;
+		for (int g = 0; g < o.gpus; ++g)
+			up.emplace_back([&, g] {
+				if (g == 0) { rcs[0] = urmapx_index_upload(I, phys(0)); replicas[0] = I; }
+				else rcs[(size_t)g] = urmapx_index_replicate(I, phys(g), &replicas[(size_t)g]);
+			});
+		for (auto &t : up) t.join();
+		for (int g = 0; g < o.gpus; ++g) check(rcs[(size_t)g], "Uploading index to the GPU");
+	}
+	std::vector<urmapx_ctx *> ctxs((size_t)n_lanes, nullptr);
+	for (int l = 0; l < n_lanes; ++l) {
+		check(urmapx_ctx_create(replicas[(size_t)(l % o.gpus)], phys(l % o.gpus), &P, &ctxs[(size_t)l]), "Creating mapping context");
+		if (!o.map2.empty() && o.veryfast) check(urmapx_ctx_set_pe_veryfast(ctxs[(size_t)l], 1), "Search5");
+	}
 	if (o.veryfast && urmapx_index_max_ix(I) > 3) fprintf(stderr, "\nWARNING: index not optimal for -veryfast\n");
 	// host threads for FASTQ parsing and SAM formatting (-threads; the mapping itself runs on the GPU)
 	int host_threads = o.threads ? (int)o.threads : std::min(16, std::max(1, (int)std::thread::hardware_concurrency()));
@@ -175,7 +201,8 @@ static int cmd_map(const Opts &o, int argc, char **argv) {
 	if (!o.tabbedout.empty()) {
 		ftab = fopen(o.tabbedout.c_str(), "wb");
 		if (!ftab) die("Cannot create %s", o.tabbedout.c_str());
-		if (paired) check(urmapx_ctx_set_pair_info(C, 1), "pair info");
+		if (paired)
+			for (urmapx_ctx *C : ctxs) check(urmapx_ctx_set_pair_info(C, 1), "pair info");
 	}
 	FastqReader rd, rd2;
 	std::string err;
@@ -183,7 +210,15 @@ static int cmd_map(const Opts &o, int argc, char **argv) {
 	if (paired && !rd2.open(o.reverse, err)) die("%s", err.c_str());
 	const auto t1 = std::chrono::steady_clock::now();
 
-	Channel<std::unique_ptr<Job>> parsed(3), mapped(3), recycled(16);  // finished jobs go back to the reader: their arrays are reused
+	// batch b travels through parsed[b mod lanes] -> lane thread -> mapped[b mod lanes]; the writer visits the lanes in the
+	// same round-robin order, so batches come back in input order without a reorder buffer
+	using JobChannel = Channel<std::unique_ptr<Job>>;
+	std::vector<std::unique_ptr<JobChannel>> parsed, mapped;
+	for (int l = 0; l < n_lanes; ++l) {
+		parsed.emplace_back(new JobChannel(2));
+		mapped.emplace_back(new JobChannel(1));
+	}
+	JobChannel recycled((size_t)(8 + 6 * n_lanes));  // finished jobs go back to the reader: their arrays are reused
 	double t_parse = 0, t_gpu = 0, t_format = 0, t_write = 0;  // busy seconds per stage (URMAPX_VERBOSE)
 	auto now = [] { return std::chrono::steady_clock::now(); };
 	auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
@@ -206,7 +241,7 @@ static int cmd_map(const Opts &o, int argc, char **argv) {
 	std::thread reader([&] {
 		omp_set_num_threads(paired ? std::max(1, host_threads - host_threads / 2) : host_threads);
 		FastqBatch a;
-		for (;;) {
+		for (size_t b = 0;; ++b) {
 			std::unique_ptr<Job> j;
 			if (!recycled.try_pop(j)) j = std::make_unique<Job>();
 			j->reads.clear();
@@ -233,9 +268,9 @@ static int cmd_map(const Opts &o, int argc, char **argv) {
 			t_parse += secs(tp0, now());
 			if (!e.empty()) { reader_err = e; break; }
 			if (!more) break;
-			parsed.push(std::move(j));
+			parsed[b % (size_t)n_lanes]->push(std::move(j));
 		}
-		parsed.close();
+		for (auto &c : parsed) c->close();
 		go2.close();
 	});
 	unsigned long long n_reads = 0, n_accept = 0, n_reject = 0, n_nohit = 0, n_unsupported = 0;
@@ -246,7 +281,7 @@ static int cmd_map(const Opts &o, int argc, char **argv) {
 		std::unique_ptr<Job> j;
 		std::vector<std::string> outs((size_t)host_threads);
 		struct Cnt { unsigned long long accept = 0, reject = 0, nohit = 0, unsupported = 0; };
-		while (mapped.pop(j)) {
+		for (size_t b = 0; mapped[b % (size_t)n_lanes]->pop(j); ++b) {
 			const uint32_t n = j->reads.size();
 			const uint32_t units = paired ? n / 2 : n;
 			std::vector<Cnt> cnt((size_t)host_threads);
@@ -325,26 +360,36 @@ static int cmd_map(const Opts &o, int argc, char **argv) {
 			recycled.push(std::move(j));
 		}
 	});
-	std::unique_ptr<Job> j;
-	while (parsed.pop(j)) {
-		const uint32_t n = j->reads.size();
-		j->results.resize(n);
-		j->ops.resize((size_t)n * URMAPX_MAX_PATH_OPS);
-		size_t used = 0;
-		const auto tg0 = now();
-		int rc = paired ? urmapx_map_pe(C, j->reads.bases.data(), j->reads.offs.data(), n / 2, j->results.data(), j->ops.data(),
-		                                j->ops.size(), &used)
-		                : urmapx_map_se(C, j->reads.bases.data(), j->reads.offs.data(), n, j->results.data(), j->ops.data(),
-		                                j->ops.size(), &used);
-		check(rc, paired ? "urmapx_map_pe" : "urmapx_map_se");
-		if (paired && ftab) {
-			j->info.resize(n / 2);
-			check(urmapx_ctx_get_pair_info(C, j->info.data(), n / 2), "urmapx_ctx_get_pair_info");
-		}
-		t_gpu += secs(tg0, now());
-		mapped.push(std::move(j));
-	}
-	mapped.close();
+	std::mutex gpu_time_lock;
+	std::vector<std::thread> lanes;
+	for (int l = 0; l < n_lanes; ++l)
+		lanes.emplace_back([&, l] {
+			urmapx_ctx *C = ctxs[(size_t)l];
+			std::unique_ptr<Job> j;
+			while (parsed[(size_t)l]->pop(j)) {
+				const uint32_t n = j->reads.size();
+				j->results.resize(n);
+				j->ops.resize((size_t)n * URMAPX_MAX_PATH_OPS);
+				size_t used = 0;
+				const auto tg0 = now();
+				int rc = paired ? urmapx_map_pe(C, j->reads.bases.data(), j->reads.offs.data(), n / 2, j->results.data(), j->ops.data(),
+				                                j->ops.size(), &used)
+				                : urmapx_map_se(C, j->reads.bases.data(), j->reads.offs.data(), n, j->results.data(), j->ops.data(),
+				                                j->ops.size(), &used);
+				check(rc, paired ? "urmapx_map_pe" : "urmapx_map_se");
+				if (paired && ftab) {
+					j->info.resize(n / 2);
+					check(urmapx_ctx_get_pair_info(C, j->info.data(), n / 2), "urmapx_ctx_get_pair_info");
+				}
+				{
+					std::lock_guard<std::mutex> g(gpu_time_lock);
+					t_gpu += secs(tg0, now());
+				}
+				mapped[(size_t)l]->push(std::move(j));
+			}
+			mapped[(size_t)l]->close();
+		});
+	for (auto &t : lanes) t.join();
 	reader.join();
 	if (reader2.joinable()) reader2.join();
 	writer.join();
@@ -356,8 +401,8 @@ static int cmd_map(const Opts &o, int argc, char **argv) {
 	const double load_s = std::chrono::duration<double>(t1 - t0).count();
 	const double map_s = std::chrono::duration<double>(t2 - t1).count();
 	if (getenv("URMAPX_VERBOSE"))
-		fprintf(stderr, "stage busy seconds: parse %.2f, gpu (copies + kernels) %.2f, format %.2f, write %.2f; %d host threads\n",
-		        t_parse, t_gpu, t_format, t_write, host_threads);
+		fprintf(stderr, "stage busy seconds: parse %.2f, gpu (copies + kernels, summed over %d lanes) %.2f, format %.2f, write %.2f; %d host threads\n",
+		        t_parse, n_lanes, t_gpu, t_format, t_write, host_threads);
 	if (!o.quiet) {  // State1::HitStats (state1.cpp:593-632): same lines, sub-second timers, "GPU n" where it says "n threads"
 		auto pct = [&](unsigned long long x) { return n_reads ? 100.0 * (double)x / (double)n_reads : 0.0; };
 		auto commas = [](unsigned long long x) {  // IntToStrCommas (myutils.cpp:1400-1418)
@@ -385,13 +430,15 @@ static int cmd_map(const Opts &o, int argc, char **argv) {
 		else if (map_s < 2 * 60 * 60) fprintf(stderr, "%16.1f  Minutes in mapper\n", map_s / 60.0);
 		else fprintf(stderr, "%16.1f  Hours in mapper\n", map_s / 3600.0);
 		fprintf(stderr, "%16s  Reads (%s)\n", commas(n_reads).c_str(), short_int(n_reads).c_str());
-		fprintf(stderr, "%16.0f  Reads/sec. (GPU %d)\n", map_s > 0 ? (double)n_reads / map_s : 0.0, o.gpu);
+		if (o.gpus == 1) fprintf(stderr, "%16.0f  Reads/sec. (GPU %d)\n", map_s > 0 ? (double)n_reads / map_s : 0.0, o.gpu);
+		else fprintf(stderr, "%16.0f  Reads/sec. (%d GPUs)\n", map_s > 0 ? (double)n_reads / map_s : 0.0, o.gpus);
 		fprintf(stderr, "%16s  Mapped Q>=%u (%.1f%%)\n", commas(n_accept).c_str(), minq, pct(n_accept));
 		fprintf(stderr, "%16s  Mapped Q< %u (%.1f%%)\n", commas(n_reject).c_str(), minq, pct(n_reject));
 		fprintf(stderr, "%16s  Unmapped (%.1f%%)\n\n", commas(n_nohit).c_str(), pct(n_nohit));
 		if (o.minq_given && !paired) fprintf(stderr, "\nWARNING: Option -minq not used\n\n");
 	}
-	urmapx_ctx_destroy(C);
+	for (urmapx_ctx *C : ctxs) urmapx_ctx_destroy(C);
+	for (int g = 1; g < o.gpus; ++g) urmapx_index_close(replicas[(size_t)g]);
 	urmapx_index_close(I);
 	if (n_unsupported) die("%llu reads fell outside the device path's domain (length or list overflow); their records are not valid", n_unsupported);
 	return 0;
@@ -464,8 +511,8 @@ int main(int argc, char **argv) {
 	Opts o = parse(argc, argv);
 	if (!o.map.empty() || !o.map2.empty()) return cmd_map(o, argc, argv);
 	if (!o.make_ufi.empty()) return cmd_make_ufi(o);
-	fprintf(stderr, "urmap (MI355X build)\n  urmap -map reads.fq -ufi index.ufi -samout out.sam [-veryfast] [-gpu D]\n"
-	                "  urmap -map2 R1.fq -reverse R2.fq -ufi index.ufi -samout out.sam [-tabbedout out.tab] [-gpu D]\n"
+	fprintf(stderr, "urmap (MI355X build)\n  urmap -map reads.fq -ufi index.ufi -samout out.sam [-veryfast] [-gpu D] [-gpus N] [-streams K]\n"
+	                "  urmap -map2 R1.fq -reverse R2.fq -ufi index.ufi -samout out.sam [-tabbedout out.tab] [-gpu D] [-gpus N]\n"
 	                "  urmap -make_ufi genome.fa -output index.ufi [-slots N] [-wordlength W] [-maxix M]\n");
 	return 0;
 }

@@ -231,6 +231,21 @@ int urmapx_index_upload(urmapx_index *I, int device) {
 	return upload_directory(I);
 }
 
+// One more replica of the same index on another GPU (the reference shares one UFIndex between all its threads,
+// map.cpp:43-61; here every device holds its own copy in HBM).  The new object borrows src's host arrays.
+int urmapx_index_replicate(const urmapx_index *src, int device, urmapx_index **out) {
+	if (!src || !out || !src->h_blob || !src->h_seq) return URMAPX_E_ARG;
+	*out = nullptr;
+	urmapx_index *I = new urmapx_index;
+	I->W = src->W; I->maxIx = src->maxIx; I->seqDataSize = src->seqDataSize; I->slotCount = src->slotCount;
+	I->labels = src->labels; I->seqLengths = src->seqLengths; I->seqOffsets = src->seqOffsets;
+	I->h_blob = src->h_blob; I->h_seq = src->h_seq;
+	int rc = urmapx_index_upload(I, device);
+	if (rc) { urmapx_index_close(I); return rc; }
+	*out = I;
+	return URMAPX_OK;
+}
+
 void urmapx_index_close(urmapx_index *I) {
 	if (!I) return;
 	if (I->own_dev) { (void)hipFree((void *)I->d_blob); (void)hipFree((void *)I->d_seq); }
