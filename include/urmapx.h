@@ -151,6 +151,9 @@ int urmapx_ctx_last_kernel_ms(urmapx_ctx *, float ms[2]);
  * inside the candidate batches of phases 1,2,4,5: [8] locate+fetch, [9] window compare, [10] x-drop walks, [11] ordered part.
  * Only collected when URMAPX_PHASE_STATS is set in the environment (otherwise all zero / E_ARG). */
 int urmapx_ctx_phase_cycles(urmapx_ctx *, uint64_t out[12]);
+/* Diagnostic, same switch: shader cycles / 16 spent on each of the first n reads of the last single-end call (the cost
+ * of a read is heavy-tailed; this is how the tail is looked at). */
+int urmapx_ctx_read_cycles(urmapx_ctx *, uint32_t *out, uint32_t n);
 
 /* ---- stage-level entry points (same device code the batch call runs; used by parity tests and bench) ---- */
 /* State1::SetSlotsVec (state1.cpp:396-438) + UFIndex::GetBlob (ufindex.h:184-187) for both strands of every read.

@@ -4,7 +4,7 @@
 usage: pmc_summary.py <rocprofv3 output dir> [out.json]
 Reads every *counter_collection.csv under the directory (columns Kernel_Name, Counter_Name, Counter_Value).
 """
-import csv, glob, json, os, sys
+import csv, glob, json, os, re, sys
 from collections import defaultdict
 
 
@@ -20,12 +20,12 @@ def main():
                 for short in ("search_se_kernel", "search_pe_kernel", "seed_probe_kernel", "viterbi_batch_kernel"):
                     if short in k:
                         # <NCH, true> = the second pass over reads whose lists outgrew LDS (usually an empty queue)
-                        k = short + ("_pass2" if ", true>" in full or ",true>" in full else "")
+                        k = short + ("_pass2" if re.search(r"<\d+,\s*true", full) else "") + ("_dbg" if re.search(r"<\d+,\s*(true|false),\s*true", full) else "")
                 a = acc[k][row["Counter_Name"]]
                 a[0] += float(row["Counter_Value"])
                 a[1] += 1
     out = {k: {c: {"avg": v[0] / v[1], "dispatches": v[1]} for c, v in cs.items()} for k, cs in acc.items()
-           if k.replace("_pass2", "") in ("search_se_kernel", "search_pe_kernel", "seed_probe_kernel", "viterbi_batch_kernel")}
+           if k.replace("_pass2", "").replace("_dbg", "") in ("search_se_kernel", "search_pe_kernel", "seed_probe_kernel", "viterbi_batch_kernel")}
     s = json.dumps(out, indent=1, sort_keys=True)
     if len(sys.argv) > 2:
         open(sys.argv[2], "w").write(s + "\n")

@@ -31,7 +31,7 @@ EXPORTS = (
     "urmapx_index_seq_length", "urmapx_index_seq_offset", "urmapx_ctx_create", "urmapx_ctx_destroy",
     "urmapx_map_se", "urmapx_map_se_device", "urmapx_ctx_sync", "urmapx_ctx_last_kernel_ms",
     "urmapx_seed_probe", "urmapx_viterbi_batch", "urmapx_strerror", "urmapx_device_arch",
-    "urmapx_make_ufi", "urmapx_build_slots", "urmapx_sam_se", "urmapx_sam_header_sq", "urmapx_ctx_phase_cycles", "urmapx_map_pe", "urmapx_sam_pe", "urmapx_map_pe_device", "urmapx_ctx_set_pe_veryfast",
+    "urmapx_make_ufi", "urmapx_build_slots", "urmapx_sam_se", "urmapx_sam_header_sq", "urmapx_ctx_phase_cycles", "urmapx_ctx_read_cycles", "urmapx_map_pe", "urmapx_sam_pe", "urmapx_map_pe_device", "urmapx_ctx_set_pe_veryfast",
     "urmapx_fastq_open", "urmapx_fastq_next", "urmapx_fastq_error", "urmapx_fastq_close",
     "urmapx_ctx_gather_microbench", "urmapx_ctx_set_pair_info", "urmapx_ctx_get_pair_info", "urmapx_tab_pe",
 )
@@ -100,6 +100,7 @@ def lib():
     L.urmapx_ctx_sync.argtypes = [vp]
     L.urmapx_ctx_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float * 2)]
     L.urmapx_ctx_phase_cycles.argtypes = [vp, C.POINTER(C.c_uint64 * 12)]
+    L.urmapx_ctx_read_cycles.argtypes = [vp, vp, u32]
     L.urmapx_seed_probe.argtypes = [vp, vp, vp, u32, vp, vp, vp]
     L.urmapx_viterbi_batch.argtypes = [vp, vp, vp, vp, vp, vp, u32, vp, vp, vp, vp]
     L.urmapx_make_ufi.argtypes = [cp, cp, u32, u32, u64]
@@ -383,6 +384,12 @@ class Mapper:
         out = (C.c_uint64 * 12)()
         _check(lib().urmapx_ctx_phase_cycles(self.h, C.byref(out)), "urmapx_ctx_phase_cycles")
         return [int(x) for x in out]
+
+    def read_cycles(self, n):
+        """Shader cycles each of the first n reads of the last single-end call took (URMAPX_PHASE_STATS=1)."""
+        out = np.zeros(n, dtype=np.uint32)
+        _check(lib().urmapx_ctx_read_cycles(self.h, out.ctypes.data, n), "urmapx_ctx_read_cycles")
+        return out.astype(np.int64) * 16
 
     def seed_probe(self, bases: np.ndarray, offs: np.ndarray):
         bases = np.ascontiguousarray(bases, dtype=np.uint8)

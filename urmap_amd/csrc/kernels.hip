@@ -189,7 +189,8 @@ __global__ __launch_bounds__(64) void viterbi_batch_kernel(urmapx_params P, cons
 //            are visited, in order: AddHitX / AddHSPX, penalty cap, early exits -- exactly as the reference
 // ------------------------------------------------------------------------------------------------
 static constexpr int HSP_CAP = 256;        // HSPs of a read held in LDS
-static constexpr int SEARCH_OVF_BLOCKS = 256;  // grid of the second pass (reads whose HSP list outgrew LDS)
+static constexpr int SEARCH_OVF_BLOCKS = 2048;  // grid of the second pass (reads whose HSP list outgrew LDS): these are the
+                                                // costliest reads of a batch (hundreds of AlignHSP calls each), so they get most of the chip
 static constexpr int HSP_TOTAL_CAP = 8192;  // beyond that: in the block's global scratch (the reference's list is unbounded;
                                             // 8192 > 2 strands x 127 k-mers x MaxIx 32 candidate diagonals of a 150 bp read)
 static constexpr int TICKET_CHUNK = 4;
@@ -566,7 +567,9 @@ struct SearchWave {
 #define SEARCH_WAVES_NCH4 3
 #endif
 #define SEARCH_WAVES_PER_EU(NCH) ((NCH) <= 3 ? SEARCH_WAVES_NCH3 : (NCH) == 4 ? SEARCH_WAVES_NCH4 : 2)
-template <int NCH, bool OVF>
+// DBG = true: the diagnostic instantiation (URMAPX_PHASE_STATS / URMAPX_DEBUG_STOP): per-phase cycle stamps, per-read
+// cycle counts and schedule cuts.  The production instantiation (DBG = false) contains none of that code.
+template <int NCH, bool OVF, bool DBG>
 __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel(DevIndex X, urmapx_params P, const uint8_t *__restrict__ bases,
                                                        const uint64_t *__restrict__ offs, uint32_t n, ProbeOut probe,
                                                        urmapx_result *__restrict__ results,
@@ -596,8 +599,8 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 
 	const int lane = threadIdx.x;
 	const int W = (int)X.W;
-	const int dbg_stop = stats ? (int)stats[0] : 0;  // diagnostic only (URMAPX_DEBUG_STOP)
-	const bool timing = stats && stats[1] == 0;
+	const int dbg_stop = (DBG && stats) ? (int)stats[0] : 0;  // diagnostic only (URMAPX_DEBUG_STOP)
+	const bool timing = DBG && stats && stats[1] == 0;
 	SW S(X, P, lane);
 	S.W = W;
 	S.gseq = g_seq; S.gblob = g_blob;
@@ -625,9 +628,10 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 		if (r_next == r_end) {
 			// every lane takes part in the atomic (lanes 1..63 add 0): with `if (lane == 0) atomicAdd` here the compiler's
 			// wave-level atomic rewrite turns the loop divergent and the kernel hangs or faults (seen twice)
-			r_next = uni(atomicAdd(ticket, lane == 0 ? (uint32_t)TICKET_CHUNK : 0u));
+			constexpr uint32_t CHUNK = OVF ? 1u : (uint32_t)TICKET_CHUNK;  // second pass: few, heavy reads -- one per ticket
+			r_next = uni(atomicAdd(ticket, lane == 0 ? CHUNK : 0u));
 			if (r_next >= n) break;
-			r_end = r_next + TICKET_CHUNK < n ? r_next + TICKET_CHUNK : n;
+			r_end = r_next + CHUNK < n ? r_next + CHUNK : n;
 		}
 		uint32_t r = r_next++;
 		if constexpr (OVF) r = ovf_list[1 + r];  // second pass: the reads the first pass flagged
@@ -635,6 +639,7 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 		const int QL = (int)(offs[r + 1] - off);
 
 		if (dbg_stop == 97) { if (QL == 12345) break; continue; }
+		const uint64_t t_read0 = timing ? __builtin_amdgcn_s_memtime() : 0;
 		urmapx_result res;
 		res.dbpos = 0xFFFFFFFFu; res.seq_index = 0xFFFFFFFFu; res.coord = 0xFFFFFFFFu;
 		res.score = 0; res.second = 0; res.mapq = 0; res.plus = 0; res.exit_phase = 0; res.status = 0;
@@ -905,6 +910,7 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 			}
 		}
 		if (lane == 0) results[r] = res;
+		if (timing && lane == 0) stats[64 + r] = (uint32_t)((__builtin_amdgcn_s_memtime() - t_read0) >> 4);  // per-read cost, 16-cycle units
 	}
 }
 
@@ -931,10 +937,10 @@ int search_block_count(uint32_t max_read_len, int device) {
 	if (hipGetDeviceProperties(&prop, device) != hipSuccess) return 0;
 	int per_cu = 0;
 	const int nchq = nch_for(max_read_len);
-	hipError_t e = nchq == 2   ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, search_se_kernel<2, false>, 64, 0)
-	               : nchq == 3 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, search_se_kernel<3, false>, 64, 0)
-	               : nchq == 4 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, search_se_kernel<4, false>, 64, 0)
-	                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, search_se_kernel<5, false>, 64, 0);
+	hipError_t e = nchq == 2   ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, search_se_kernel<2, false, false>, 64, 0)
+	               : nchq == 3 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, search_se_kernel<3, false, false>, 64, 0)
+	               : nchq == 4 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, search_se_kernel<4, false, false>, 64, 0)
+	                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, search_se_kernel<5, false, false>, 64, 0);
 	if (e != hipSuccess || per_cu < 1) per_cu = 8;
 	return per_cu * prop.multiProcessorCount;
 }
@@ -997,22 +1003,17 @@ hipError_t launch_search_se(const DevIndex &X, const urmapx_params &P, const uin
 		if (e != hipSuccess) return e;
 	}
 	dim3 block(64), grid((unsigned)wk.blocks);
-	if (nch == 2)
-		hipLaunchKernelGGL((search_se_kernel<2, false>), grid, block, 0, s, X, P, d_bases, d_offs, n, probe, d_results, d_path_ops,
-		                   d_path_used, wk.stats, wk.scratch, wk.scratch_stride, X.seq, X.blob, wk.ticket, wk.hsp_lds_cap,
-		                   wk.ovf_list, (uint2 *)nullptr);
-	else if (nch == 3)
-		hipLaunchKernelGGL((search_se_kernel<3, false>), grid, block, 0, s, X, P, d_bases, d_offs, n, probe, d_results, d_path_ops,
-		                   d_path_used, wk.stats, wk.scratch, wk.scratch_stride, X.seq, X.blob, wk.ticket, wk.hsp_lds_cap,
-		                   wk.ovf_list, (uint2 *)nullptr);
-	else if (nch == 4)
-		hipLaunchKernelGGL((search_se_kernel<4, false>), grid, block, 0, s, X, P, d_bases, d_offs, n, probe, d_results, d_path_ops,
-		                   d_path_used, wk.stats, wk.scratch, wk.scratch_stride, X.seq, X.blob, wk.ticket, wk.hsp_lds_cap,
-		                   wk.ovf_list, (uint2 *)nullptr);
-	else
-		hipLaunchKernelGGL((search_se_kernel<5, false>), grid, block, 0, s, X, P, d_bases, d_offs, n, probe, d_results, d_path_ops,
-		                   d_path_used, wk.stats, wk.scratch, wk.scratch_stride, X.seq, X.blob, wk.ticket, wk.hsp_lds_cap,
-		                   wk.ovf_list, (uint2 *)nullptr);
+	uint2 *const no_ovf = nullptr;
+#define URX_LAUNCH_SE(NCH_, OVF_, DBG_, GRID_, STATS_, OVFBASE_)                                                                  \
+	hipLaunchKernelGGL((search_se_kernel<NCH_, OVF_, DBG_>), GRID_, block, 0, s, X, P, d_bases, d_offs, n, probe, d_results,         \
+	                   d_path_ops, d_path_used, STATS_, wk.scratch, wk.scratch_stride, X.seq, X.blob, wk.ticket, wk.hsp_lds_cap, \
+	                   wk.ovf_list, OVFBASE_)
+	if (wk.stats && nch == 3) URX_LAUNCH_SE(3, false, true, grid, wk.stats, no_ovf);  // diagnostic instantiations: 150 / 250 bp classes
+	else if (wk.stats && nch == 4) URX_LAUNCH_SE(4, false, true, grid, wk.stats, no_ovf);
+	else if (nch == 2) URX_LAUNCH_SE(2, false, false, grid, wk.stats, no_ovf);
+	else if (nch == 3) URX_LAUNCH_SE(3, false, false, grid, wk.stats, no_ovf);
+	else if (nch == 4) URX_LAUNCH_SE(4, false, false, grid, wk.stats, no_ovf);
+	else URX_LAUNCH_SE(5, false, false, grid, wk.stats, no_ovf);
 	{
 		hipError_t e = hipGetLastError();
 		if (e != hipSuccess) return e;
@@ -1023,22 +1024,12 @@ hipError_t launch_search_se(const DevIndex &X, const urmapx_params &P, const uin
 	// and leave); it runs the same search with the list continued in global scratch
 	dim3 grid2((unsigned)(wk.blocks < SEARCH_OVF_BLOCKS ? wk.blocks : SEARCH_OVF_BLOCKS));
 	uint2 *ovf_base = reinterpret_cast<uint2 *>(wk.scratch + (size_t)wk.blocks * wk.scratch_stride);
-	if (nch == 2)
-		hipLaunchKernelGGL((search_se_kernel<2, true>), grid2, block, 0, s, X, P, d_bases, d_offs, n, probe, d_results, d_path_ops,
-		                   d_path_used, (uint32_t *)nullptr, wk.scratch, wk.scratch_stride, X.seq, X.blob, wk.ticket, wk.hsp_lds_cap,
-		                   wk.ovf_list, ovf_base);
-	else if (nch == 3)
-		hipLaunchKernelGGL((search_se_kernel<3, true>), grid2, block, 0, s, X, P, d_bases, d_offs, n, probe, d_results, d_path_ops,
-		                   d_path_used, (uint32_t *)nullptr, wk.scratch, wk.scratch_stride, X.seq, X.blob, wk.ticket, wk.hsp_lds_cap,
-		                   wk.ovf_list, ovf_base);
-	else if (nch == 4)
-		hipLaunchKernelGGL((search_se_kernel<4, true>), grid2, block, 0, s, X, P, d_bases, d_offs, n, probe, d_results, d_path_ops,
-		                   d_path_used, (uint32_t *)nullptr, wk.scratch, wk.scratch_stride, X.seq, X.blob, wk.ticket, wk.hsp_lds_cap,
-		                   wk.ovf_list, ovf_base);
-	else
-		hipLaunchKernelGGL((search_se_kernel<5, true>), grid2, block, 0, s, X, P, d_bases, d_offs, n, probe, d_results, d_path_ops,
-		                   d_path_used, (uint32_t *)nullptr, wk.scratch, wk.scratch_stride, X.seq, X.blob, wk.ticket, wk.hsp_lds_cap,
-		                   wk.ovf_list, ovf_base);
+	uint32_t *const no_stats = nullptr;
+	if (nch == 2) URX_LAUNCH_SE(2, true, false, grid2, no_stats, ovf_base);
+	else if (nch == 3) URX_LAUNCH_SE(3, true, false, grid2, no_stats, ovf_base);
+	else if (nch == 4) URX_LAUNCH_SE(4, true, false, grid2, no_stats, ovf_base);
+	else URX_LAUNCH_SE(5, true, false, grid2, no_stats, ovf_base);
+#undef URX_LAUNCH_SE
 	return hipGetLastError();
 }
 

@@ -21,7 +21,7 @@ namespace urx {
 static constexpr int PE_HIT_CAP = 64;
 static constexpr int PE_HSP_CAP = 128;       // HSPs of a mate held in LDS
 static constexpr int PE_HSP_OVF_CAP = 8064;  // per mate, in global scratch, second pass only
-static constexpr int PE_OVF_BLOCKS = 128;    // grid of the second pass
+static constexpr int PE_OVF_BLOCKS = 1024;   // grid of the second pass (the costliest pairs of a batch)
 static constexpr int PE_PAIR_CAP = 256;
 static constexpr int PE_TICKET_CHUNK = 2;
 static constexpr int PE_ROW_CAP = 32;   // UFIndex m_MaxIx of every index this build accepts
@@ -768,9 +768,10 @@ __global__ __launch_bounds__(64) void search_pe_kernel(DevIndex X, urmapx_params
 	uint32_t pr_next = 0, pr_end = 0;
 	for (;;) {
 		if (pr_next == pr_end) {
-			pr_next = uni(atomicAdd(ticket, lane == 0 ? (uint32_t)PE_TICKET_CHUNK : 0u));
+			constexpr uint32_t CHUNK = OVF ? 1u : (uint32_t)PE_TICKET_CHUNK;
+			pr_next = uni(atomicAdd(ticket, lane == 0 ? CHUNK : 0u));
 			if (pr_next >= npairs) break;
-			pr_end = pr_next + PE_TICKET_CHUNK < npairs ? pr_next + PE_TICKET_CHUNK : npairs;
+			pr_end = pr_next + CHUNK < npairs ? pr_next + CHUNK : npairs;
 		}
 		uint32_t pr = pr_next++;
 		if constexpr (OVF) pr = ovf_list[1 + pr];

@@ -102,6 +102,7 @@ struct urmapx_ctx {
 	DevBuf<urmapx_pair_info> pairinfo;
 	DevBuf<uint32_t> ovflist;  // reads queued for the search kernel's second pass
 	uint32_t pairinfo_n = 0;
+	uint32_t stats_reads = 0;  // diagnostics: reads of the last single-end call with per-read cycle counts
 	int pe_blocks[4] = {0, 0, 0, 0};
 	int blocks[4] = {0, 0, 0, 0};  // persistent grid size of the search kernel for read length classes <=192, <=320, <=256
 };
@@ -313,6 +314,14 @@ int urmapx_ctx_phase_cycles(urmapx_ctx *C, uint64_t out[12]) {
 	return URMAPX_OK;
 }
 
+// diagnostic: shader cycles / 16 each read of the last single-end call took (URMAPX_PHASE_STATS=1; 150 / 250 bp classes)
+int urmapx_ctx_read_cycles(urmapx_ctx *C, uint32_t *out, uint32_t n) {
+	if (!C || !out || !C->statsbuf.p || n > C->stats_reads) return URMAPX_E_ARG;
+	HIP_TRY(hipStreamSynchronize(C->stream));
+	HIP_TRY(hipMemcpy(out, C->statsbuf.p + 64, (size_t)n * 4, hipMemcpyDeviceToHost));
+	return URMAPX_OK;
+}
+
 int urmapx_ctx_sync(urmapx_ctx *C) {
 	if (!C) return URMAPX_E_ARG;
 	HIP_TRY(hipStreamSynchronize(C->stream));
@@ -355,14 +364,16 @@ int urmapx_map_se_device(urmapx_ctx *C, const void *d_bases, const void *d_offs,
 	if ((rc = C->scratch.ensure(wk.scratch_stride * (size_t)wk.blocks + search_scratch_tail()))) return rc;
 	if ((rc = C->ovflist.ensure((size_t)n + 1))) return rc;
 	wk.ovf_list = C->ovflist.p;
-	if ((rc = C->statsbuf.ensure(64))) return rc;
+	const char *ds = getenv("URMAPX_DEBUG_STOP");
+	const bool diag = getenv("URMAPX_PHASE_STATS") || ds;
+	if ((rc = C->statsbuf.ensure(64 + (diag ? (size_t)n : 0)))) return rc;  // diagnostics: words 64.. = cycles per read
+	C->stats_reads = diag ? n : 0;
 	wk.scratch = C->scratch.p;
 	wk.ticket = C->statsbuf.p + 62;  // words 62/63 of the diagnostics buffer are never touched by the stamps
 	if (const char *e = getenv("URMAPX_TEST_HSP_LDS_CAP")) wk.hsp_lds_cap = atoi(e);
 	// diagnostics: URMAPX_PHASE_STATS = per-phase cycle counters; URMAPX_DEBUG_STOP=N = cut the schedule after step N
 	// (results are then NOT the reference's).  Words 0/1 of the buffer: stop step, "no timing" flag.
-	const char *ds = getenv("URMAPX_DEBUG_STOP");
-	wk.stats = (getenv("URMAPX_PHASE_STATS") || ds) ? C->statsbuf.p : nullptr;
+	wk.stats = diag ? C->statsbuf.p : nullptr;
 	if (wk.stats) {
 		const uint32_t ctl[2] = {ds ? (uint32_t)atoi(ds) : 0u, getenv("URMAPX_PHASE_STATS") ? 0u : 1u};
 		HIP_TRY(hipMemcpyAsync(C->statsbuf.p, ctl, 8, hipMemcpyHostToDevice, C->stream));
