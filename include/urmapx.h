@@ -145,6 +145,14 @@ int urmapx_ctx_sync(urmapx_ctx *);
 /* Device time (ms, HIP events on the ctx stream) of the two kernels in the most recent *_device call that has
  * completed: [0] seed+probe, [1] search/extend. */
 int urmapx_ctx_last_kernel_ms(urmapx_ctx *, float ms[2]);
+/* The search part of a single-end call is six launches (Search_Lo's phases 1-5, the flank DPs of phase 6, phase 6's
+ * ordered part; then the same three for the few reads whose hit / HSP lists outgrew the first pass's): their device
+ * times in ms, in that order. */
+int urmapx_ctx_stage_ms(urmapx_ctx *, float ms[6]);
+/* Statistics of the same call, per pass: HSPs handed to the DP launch, reads they belong to, and how many of those DPs
+ * the ordered replay of AlignHSP (alignhsp.cpp:60-172) actually looked at (the rest were run for nothing: the penalty
+ * cap had fallen by the time their turn came). */
+int urmapx_ctx_dp_stats(urmapx_ctx *, uint32_t out[6]);
 
 /* Diagnostic: shader cycles spent per phase by the last search kernel, summed over wavefronts:
  * [0] setup, [1] phases 1+2, [2] phase 3, [3] chain walks, [4] phase 4, [5] phase 5, [6] phase 6, [7] output;

@@ -31,7 +31,7 @@ EXPORTS = (
     "urmapx_index_seq_length", "urmapx_index_seq_offset", "urmapx_ctx_create", "urmapx_ctx_destroy",
     "urmapx_map_se", "urmapx_map_se_device", "urmapx_ctx_sync", "urmapx_ctx_last_kernel_ms",
     "urmapx_seed_probe", "urmapx_viterbi_batch", "urmapx_strerror", "urmapx_device_arch",
-    "urmapx_make_ufi", "urmapx_build_slots", "urmapx_sam_se", "urmapx_sam_header_sq", "urmapx_ctx_phase_cycles", "urmapx_ctx_read_cycles", "urmapx_map_pe", "urmapx_sam_pe", "urmapx_map_pe_device", "urmapx_ctx_set_pe_veryfast",
+    "urmapx_make_ufi", "urmapx_build_slots", "urmapx_sam_se", "urmapx_sam_header_sq", "urmapx_ctx_phase_cycles", "urmapx_ctx_read_cycles", "urmapx_ctx_stage_ms", "urmapx_ctx_dp_stats", "urmapx_map_pe", "urmapx_sam_pe", "urmapx_map_pe_device", "urmapx_ctx_set_pe_veryfast",
     "urmapx_fastq_open", "urmapx_fastq_next", "urmapx_fastq_error", "urmapx_fastq_close",
     "urmapx_ctx_gather_microbench", "urmapx_ctx_set_pair_info", "urmapx_ctx_get_pair_info", "urmapx_tab_pe",
 )
@@ -101,6 +101,8 @@ def lib():
     L.urmapx_ctx_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float * 2)]
     L.urmapx_ctx_phase_cycles.argtypes = [vp, C.POINTER(C.c_uint64 * 12)]
     L.urmapx_ctx_read_cycles.argtypes = [vp, vp, u32]
+    L.urmapx_ctx_stage_ms.argtypes = [vp, C.POINTER(C.c_float * 6)]
+    L.urmapx_ctx_dp_stats.argtypes = [vp, C.POINTER(C.c_uint32 * 6)]
     L.urmapx_seed_probe.argtypes = [vp, vp, vp, u32, vp, vp, vp]
     L.urmapx_viterbi_batch.argtypes = [vp, vp, vp, vp, vp, vp, u32, vp, vp, vp, vp]
     L.urmapx_make_ufi.argtypes = [cp, cp, u32, u32, u64]
@@ -364,6 +366,18 @@ class Mapper:
         ms = (C.c_float * 2)()
         _check(lib().urmapx_ctx_last_kernel_ms(self.h, C.byref(ms)), "urmapx_ctx_last_kernel_ms")
         return float(ms[0]), float(ms[1])
+
+    def stage_ms(self):
+        """ms of the six search launches of the last single-end device call: main, dp, finalize, then the second pass's."""
+        ms = (C.c_float * 6)()
+        _check(lib().urmapx_ctx_stage_ms(self.h, C.byref(ms)), "urmapx_ctx_stage_ms")
+        return [float(x) for x in ms]
+
+    def dp_stats(self):
+        """per pass: (HSPs handed to the DP launch, reads parked, DPs the ordered replay needed)"""
+        out = (C.c_uint32 * 6)()
+        _check(lib().urmapx_ctx_dp_stats(self.h, C.byref(out)), "urmapx_ctx_dp_stats")
+        return [int(x) for x in out]
 
     def set_pair_info(self, on=True):
         _check(lib().urmapx_ctx_set_pair_info(self.h, int(on)), "urmapx_ctx_set_pair_info")

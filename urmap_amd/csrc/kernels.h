@@ -35,6 +35,41 @@ hipError_t launch_gather_bench(const DevIndex &X, uint32_t blocks, uint32_t iter
 hipError_t launch_seed_probe(const DevIndex &X, const uint8_t *d_bases, const uint64_t *d_offs, uint32_t n,
                              uint32_t max_read_len, ProbeOut out, hipStream_t s);
 
+// Phase 6 of Search_Lo (AlignHSP of every HSP still unaligned, search1m6.cpp:273-274) runs as launches of its own: the
+// search kernel turns each such HSP into a DpJob and parks the read's state; dp_kernel runs the two flank DPs of every
+// job (one wavefront per job: the DP outcome of an HSP does not depend on the search state, only whether it is USED
+// does); finalize_se_kernel replays AlignHSP's bookkeeping over the read's jobs in order and writes the result.  A read
+// in a repeat family has hundreds of such HSPs (the reference's list is unbounded): inside the one-wavefront-per-read
+// search kernel they were a serial tail that set the kernel's duration.
+struct DpJob {             // 32 bytes
+	uint32_t read;         // 0xFFFFFFFF = slot not in use
+	uint32_t startdb, pk;  // the HSP (SearchWave::hsp_pk packing)
+	int32_t maxpen;        // m_MaxPenalty when the job was made: the cap only falls, so what fails it then fails it later
+	// written by dp_kernel
+	uint32_t combined_tlo; // hit start if the alignment is accepted
+	int16_t left_score, right_score;  // flank scores, floored at the all-gap score (alignhsp.cpp:124-126,157-159)
+	uint8_t nops;          // runs of the whole path (left flank, the HSP's M run, right flank; merged) in the job's ops slice
+	uint8_t flags;         // DPJ_*
+	uint8_t vst_l, vst_r;  // URMAPX_ST_* bits raised by the left / right DP
+	uint8_t pad[4];
+};
+static_assert(sizeof(DpJob) == 32, "DpJob layout");
+// flank window unusable (alignhsp.cpp:104-117 / 148-150); right flank not run (penalty already over the job's cap);
+// path longer than URMAPX_MAX_PATH_OPS runs
+static constexpr uint8_t DPJ_LEFT_FAIL = 1, DPJ_RIGHT_FAIL = 2, DPJ_RIGHT_SKIPPED = 4, DPJ_PATH_LONG = 8;
+static constexpr int DP_JOB_OPS = URMAPX_MAX_PATH_OPS;  // ops slice per job
+
+struct DpWork {
+	DpJob *jobs = nullptr;          // jobs_cap entries
+	uint16_t *ops = nullptr;        // jobs_cap * DP_JOB_OPS: the accepted alignment's path per job
+	uint32_t jobs_cap = 0;
+	uint32_t *counters = nullptr;   // [0] jobs made, [1] reads parked, [2] jobs the ordered replay needed (statistics)
+	uint32_t *fin_list = nullptr;   // per parked read: read, first job, job count
+	uint32_t *state = nullptr;      // per parked read: search state (dp_state_words(ovf) words each)
+	uint32_t fin_cap = 0;
+};
+size_t dp_state_words(bool ovf);
+
 // workspace of the persistent search kernels: per-block global scratch (+ optional diagnostics buffer)
 struct SearchWork {
 	uint32_t *stats;  // optional cycle-stamp accumulator (URMAPX_PHASE_STATS), else nullptr
@@ -44,7 +79,14 @@ struct SearchWork {
 	uint32_t *ticket;       // device word: work counter of the launch (zeroed by the launcher)
 	int hsp_lds_cap = 0;    // 0 = default; test aid (URMAPX_TEST_HSP_LDS_CAP) to exercise the HSP overflow list
 	uint32_t *ovf_list = nullptr;  // device: [0] = count, [1..n] = reads queued for the second pass
+	DpWork dp[2];                  // [0] first pass, [1] second pass; jobs == nullptr: phase 6 stays inside the search kernel
+	uint8_t *dp_scratch = nullptr; // dp_kernel's wide-band scratch: dp_blocks * dp_scratch_stride bytes
+	size_t dp_scratch_stride = 0;
+	int dp_blocks = 0;
+	hipEvent_t *stage_events = nullptr;  // optional: 7 events recorded between the launches (main, dp, finalize, main2, dp2, finalize2)
 };
+size_t dp_scratch_stride(uint32_t max_read_len);
+int dp_block_count(uint32_t max_read_len, int device);
 size_t search_scratch_stride(uint32_t max_read_len);
 size_t search_scratch_tail();
 size_t search_pe_scratch_tail();

@@ -402,7 +402,7 @@ struct SearchWave {
 			if (leftTL >= leftTHi) return;
 			const uint32_t leftTLo = leftTHi - leftTL + 1;
 			if (load_window(leftTLo, (int)leftTL)) return;
-			int leftScore = (int)viterbi_wave(VP, Q, leftQL, sT, (int)leftTL, true, false, tb, TB_ROWS8, wsv, RL, vst, lane);
+			int leftScore = (int)viterbi_wave<true>(VP, Q, leftQL, sT, (int)leftTL, true, false, tb, TB_ROWS8, wsv, RL, vst, lane);
 			status |= vst;
 			// TrimLeftIs (pathinfo.cpp:153-171): the leading I run is the last run in traceback order
 			int nTrimI = 0;
@@ -425,7 +425,7 @@ struct SearchWave {
 			if (rightTHi >= TL) rightTHi = TL - 1;
 			const uint32_t rightTL = rightTHi - rightTLo + 1;
 			if (load_window(rightTLo, (int)rightTL)) return;
-			int rightScore = (int)viterbi_wave(VP, Q + rightQLo, rightQL, sT, (int)rightTL, false, true, tb, TB_ROWS8, wsv, RR, vst, lane);
+			int rightScore = (int)viterbi_wave<true>(VP, Q + rightQLo, rightQL, sT, (int)rightTL, false, true, tb, TB_ROWS8, wsv, RR, vst, lane);
 			status |= vst;
 			// TrimRightIs (pathinfo.cpp:173-190): trailing I run = first run in traceback order, never the whole path
 			if (RR.n > 1 && (ropsR[0] & 3u) == OP_I) rtrim = 1;
@@ -452,6 +452,160 @@ struct SearchWave {
 		if (ovf) { status |= URMAPX_ST_PATH_OVERFLOW; return; }
 		__syncthreads();
 		add_hit(combinedTLo, plus, totalScore, nc);
+	}
+
+	// ---- phase 6 as separate launches (kernels.h: DpJob) ----
+	static constexpr int STATE_WORDS = HITW * 64 + 16 + URMAPX_MAX_PATH_OPS / 2;
+
+	__device__ __forceinline__ bool hsp_get(int k, uint32_t &startdb, uint32_t &pk) const {
+		startdb = 0; pk = 0;
+		if (k >= hspCount) return false;
+		if (!OVF || k < hsp_lds) { startdb = hsp_db[k]; pk = hsp_pk[k]; }
+		else { const uint2 e = hsp_ovf[k - hsp_lds]; startdb = e.x; pk = e.y; }
+		return true;
+	}
+	// AlignHSP's entry tests (alignhsp.cpp:62-70): not aligned yet, and HSP.Length - HSP.Score within the penalty cap
+	__device__ __forceinline__ bool hsp_wants_dp(int k, uint32_t &startdb, uint32_t &pk) const {
+		if (!hsp_get(k, startdb, pk)) return false;
+		if (pk & (1u << 27)) return false;
+		const int len = (int)((pk >> 9) & 511u), hscore = (int)((pk >> 18) & 511u);
+		return len - hscore <= maxPen;
+	}
+
+	// One DpJob per HSP that phase 6 would align, the read's state parked for finalize_se_kernel.  false: nothing to
+	// align, or no room left in the job array / the parking lot -- the caller then runs phase 6 itself.
+	__device__ bool park_for_dp(const DpWork &dp, uint32_t r, int phase) {
+		int njobs = 0;
+		for (int base = 0; base < hspCount; base += 64) {
+			uint32_t sdb, pk;
+			njobs += __builtin_popcountll(__ballot(hsp_wants_dp(base + lane, sdb, pk)));
+		}
+		if (njobs == 0) return false;
+		uint32_t jb = 0, slot = 0;
+		if (lane == 0) jb = atomicAdd(dp.counters, (uint32_t)njobs);
+		jb = uni(jb);
+		bool room = jb < dp.jobs_cap && (uint32_t)njobs <= dp.jobs_cap - jb;
+		if (room) {
+			if (lane == 0) slot = atomicAdd(dp.counters + 1, 1u);
+			slot = uni(slot);
+			room = slot < dp.fin_cap;
+		}
+		if (!room) {  // the slots taken stay unused
+			for (uint32_t i = jb + lane; i < dp.jobs_cap && i - jb < (uint32_t)njobs; i += 64) dp.jobs[i].read = 0xFFFFFFFFu;
+			return false;
+		}
+		int w = 0;
+		for (int base = 0; base < hspCount; base += 64) {
+			uint32_t sdb, pk;
+			const bool ok = hsp_wants_dp(base + lane, sdb, pk);
+			const uint64_t m = __ballot(ok);
+			if (ok) {
+				const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+				DpJob J;
+				J.read = r; J.startdb = sdb; J.pk = pk; J.maxpen = maxPen;
+				J.combined_tlo = 0; J.left_score = 0; J.right_score = 0; J.nops = 0; J.flags = 0; J.vst_l = 0; J.vst_r = 0;
+				J.pad[0] = J.pad[1] = J.pad[2] = J.pad[3] = 0;
+				dp.jobs[jb + (uint32_t)w + rank] = J;
+			}
+			w += __builtin_popcountll(m);
+		}
+		uint32_t *st = dp.state + (size_t)slot * STATE_WORDS;
+#pragma unroll
+		for (int wd = 0; wd < HITW; ++wd) st[wd * 64 + lane] = hit_db[wd];
+		uint32_t *sc = st + HITW * 64;
+		if (lane == 0) {
+			sc[0] = (uint32_t)hitCount; sc[1] = (uint32_t)maxPen; sc[2] = (uint32_t)best; sc[3] = (uint32_t)second;
+			sc[4] = top_db; sc[5] = (haveTop ? 1u : 0u) | (top_plus ? 2u : 0u) | ((uint32_t)phase << 8);
+			sc[6] = (uint32_t)top_nops; sc[7] = status; sc[8] = (uint32_t)hspCount;
+			dp.fin_list[3 * slot] = r; dp.fin_list[3 * slot + 1] = jb; dp.fin_list[3 * slot + 2] = (uint32_t)njobs;
+		}
+		uint16_t *tops = reinterpret_cast<uint16_t *>(sc + 16);
+		for (int t = lane; t < top_nops; t += 64) tops[t] = top[t];
+		return true;
+	}
+
+	// back from the parking lot (finalize_se_kernel); returns the phase the read was in
+	__device__ int restore_state(const uint32_t *st) {
+#pragma unroll
+		for (int wd = 0; wd < HITW; ++wd) hit_db[wd] = st[wd * 64 + lane];
+		const uint32_t *sc = st + HITW * 64;
+		hitCount = (int)uni(sc[0]); maxPen = (int)uni(sc[1]); best = (int)uni(sc[2]); second = (int)uni(sc[3]);
+		top_db = uni(sc[4]);
+		const uint32_t f = uni(sc[5]);
+		haveTop = (f & 1u) != 0; top_plus = (f & 2u) != 0;
+		top_nops = (int)uni(sc[6]); status = uni(sc[7]); hspCount = (int)uni(sc[8]); bestHSP = 0;
+		const uint16_t *tops = reinterpret_cast<const uint16_t *>(sc + 16);
+		for (int t = lane; t < top_nops; t += 64) top[t] = tops[t];
+		__syncthreads();
+		return (int)(f >> 8);
+	}
+
+	// AlignHSP's bookkeeping (alignhsp.cpp:60-172) over a job whose two flank DPs dp_kernel has run: the same tests in
+	// the same order against the CURRENT penalty cap, then AddHitX.  The DP outcome itself never depended on the state.
+	__device__ bool consume_job(const DpJob &J, const uint16_t *jops) {
+		const uint32_t pk = J.pk;
+		const int startq = (int)(pk & 511u), len = (int)((pk >> 9) & 511u);
+		const int hscore = (int)((pk >> 18) & 511u);
+		const bool plus = (pk >> 28) & 1u;
+		int totalPen = len - hscore;
+		int totalScore = hscore;
+		if (totalPen > maxPen) return false;
+		uint32_t vst = 0;
+		if (startq > 0) {
+			if (J.flags & DPJ_LEFT_FAIL) return true;
+			vst |= J.vst_l;
+			status |= J.vst_l;
+			totalScore += J.left_score;
+			totalPen += startq - J.left_score;
+			if (totalPen > maxPen) return true;
+		}
+		const int rightQLo = startq + len;
+		if (rightQLo < QL) {
+			if (J.flags & (DPJ_RIGHT_FAIL | DPJ_RIGHT_SKIPPED)) return true;
+			// the right flank was run unless the penalty after the left one already exceeded the cap the job was made
+			// under -- and the cap has not risen since
+			vst |= J.vst_r;
+			status |= J.vst_r;
+			totalScore += J.right_score;
+			totalPen += (QL - rightQLo) - J.right_score;
+			if (totalPen > maxPen) return true;
+		}
+		if (vst & (URMAPX_ST_BAND_TOO_WIDE | URMAPX_ST_PATH_OVERFLOW)) return true;
+		if (J.flags & DPJ_PATH_LONG) { status |= URMAPX_ST_PATH_OVERFLOW; return true; }
+		const int nc = (int)J.nops;
+		__syncthreads();
+		for (int t = lane; t < nc; t += 64) cand[t] = jops[t];
+		__syncthreads();
+		add_hit(J.combined_tlo, plus, totalScore, nc);
+		return true;
+	}
+
+	// m_Mapq, SetMappedPos (state1.cpp:129-145) with PosToCoordL (ufindex.cpp:729-755), the top hit's path
+	__device__ void fill_result(urmapx_result &res, int phase, urmapx_path_op *__restrict__ path_ops, uint32_t *path_used) {
+		res.mapq = (uint8_t)calc_mapq();
+		res.score = (int16_t)best; res.second = (int16_t)second;
+		res.hit_count = (uint16_t)hitCount; res.exit_phase = (uint8_t)phase; res.status = (uint8_t)status;
+		if (haveTop) {
+			uint32_t lo = 0, hi = X.seqCount - 1;
+			uint32_t found = 0xFFFFFFFFu, coord = 0xFFFFFFFFu, tl = 0;
+			while (lo <= hi && hi != 0xFFFFFFFFu) {
+				uint32_t k = (lo + hi) / 2;
+				uint32_t o = X.seqOffsets[k], sl = X.seqLengths[k];
+				if (top_db >= o && top_db < o + sl) { found = k; coord = top_db - o; tl = sl; break; }
+				if (top_db > o) lo = k + 1;
+				else hi = k - 1;
+			}
+			if (found != 0xFFFFFFFFu && coord + (uint32_t)QL <= tl) {
+				res.dbpos = top_db; res.seq_index = found; res.coord = coord; res.plus = top_plus ? 1 : 0;
+				if (top_nops > 0) {
+					uint32_t po = 0;
+					if (lane == 0) po = atomicAdd(path_used, (uint32_t)top_nops);
+					po = uni(po);
+					for (int t = lane; t < top_nops; t += 64) path_ops[po + t] = top[t];
+					res.path_off = po; res.path_nops = (uint16_t)top_nops;
+				}
+			}
+		}
 	}
 
 	// search1m6.cpp:9-33
@@ -576,7 +730,8 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
                                                        urmapx_path_op *__restrict__ path_ops, uint32_t *path_used,
                                                        uint32_t *stats, uint8_t *scratch, size_t scratch_stride,
                                                        const uint8_t *__restrict__ g_seq, const uint8_t *__restrict__ g_blob,
-                                                       uint32_t *ticket, int hsp_lds_cap, uint32_t *ovf_list, uint2 *hsp_ovf_base) {
+                                                       uint32_t *ticket, int hsp_lds_cap, uint32_t *ovf_list, uint2 *hsp_ovf_base,
+                                                       DpWork dp) {
 	// stats != nullptr (URMAPX_PHASE_STATS): per-phase shader cycles are accumulated into stats (u64 each, from byte 8)
 	using SW = SearchWave<NCH, OVF>;
 	__shared__ __attribute__((aligned(16))) uint8_t sQ2[2 * SW::QMAX];  // plus strand, then reverse complement
@@ -644,6 +799,7 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 		res.dbpos = 0xFFFFFFFFu; res.seq_index = 0xFFFFFFFFu; res.coord = 0xFFFFFFFFu;
 		res.score = 0; res.second = 0; res.mapq = 0; res.plus = 0; res.exit_phase = 0; res.status = 0;
 		res.hit_count = 0; res.path_nops = 0; res.path_off = 0;
+		bool parked = false;  // phase 6 handed to dp_kernel + finalize_se_kernel, which writes the result
 		const bool badlen = QL < W || QL > SW::QMAX || W > 32 || X.maxIx > (uint32_t)ROW_CAP;
 		if (badlen) res.status = URMAPX_ST_BAD_LENGTH;
 		if (!badlen) {
@@ -720,6 +876,8 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 			if (dbg_stop == 100) break;  // setup + output only
 			if (dbg_stop && step > (dbg_stop > 410 ? 1 : dbg_stop > 400 ? 4 : dbg_stop)) break;
 			if (step == 3 || step == 6) {
+				if (step == 6 && !OVF && (S.status & (URMAPX_ST_HSP_OVERFLOW | URMAPX_ST_HIT_OVERFLOW))) break;  // the second pass maps this read again
+				if (step == 6 && dp.jobs != nullptr && S.park_for_dp(dp, r, 6)) { parked = true; break; }
 				if (step == 6 || S.bestHSP > termHSP3) {
 					for (int k = 0; k < S.hspCount; ++k) S.align_hsp(k);
 					if (step == 3 && S.best >= minScore1) done = true;
@@ -877,33 +1035,10 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 			}
 		}
 		lapc(6);
-		res.mapq = (uint8_t)S.calc_mapq();
-		res.score = (int16_t)S.best; res.second = (int16_t)S.second;
-		res.hit_count = (uint16_t)S.hitCount; res.exit_phase = (uint8_t)phase; res.status = (uint8_t)S.status;
-		// SetMappedPos (state1.cpp:129-145) with PosToCoordL (ufindex.cpp:729-755)
-		if (S.haveTop) {
-			uint32_t lo = 0, hi = X.seqCount - 1;
-			uint32_t found = 0xFFFFFFFFu, coord = 0xFFFFFFFFu, tl = 0;
-			while (lo <= hi && hi != 0xFFFFFFFFu) {
-				uint32_t k = (lo + hi) / 2;
-				uint32_t o = X.seqOffsets[k], sl = X.seqLengths[k];
-				if (S.top_db >= o && S.top_db < o + sl) { found = k; coord = S.top_db - o; tl = sl; break; }
-				if (S.top_db > o) lo = k + 1;
-				else hi = k - 1;
-			}
-			if (found != 0xFFFFFFFFu && coord + (uint32_t)QL <= tl) {
-				res.dbpos = S.top_db; res.seq_index = found; res.coord = coord; res.plus = S.top_plus ? 1 : 0;
-				if (S.top_nops > 0) {
-					uint32_t po = 0;
-					if (lane == 0) po = atomicAdd(path_used, (uint32_t)S.top_nops);
-					po = uni(po);
-					for (int t = lane; t < S.top_nops; t += 64) path_ops[po + t] = top[t];
-					res.path_off = po; res.path_nops = (uint16_t)S.top_nops;
-				}
-			}
-		}
+		if (!parked) S.fill_result(res, phase, path_ops, path_used);
 		lapc(7);
 		}  // !badlen
+		if (parked) continue;
 		if constexpr (!OVF) {
 			if (res.status & (URMAPX_ST_HSP_OVERFLOW | URMAPX_ST_HIT_OVERFLOW)) {  // queue the read for the second pass
 				if (lane == 0) ovf_list[1 + atomicAdd(ovf_list, 1u)] = r;
@@ -912,6 +1047,186 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 		if (lane == 0) results[r] = res;
 		if (timing && lane == 0) stats[64 + r] = (uint32_t)((__builtin_amdgcn_s_memtime() - t_read0) >> 4);  // per-read cost, 16-cycle units
 	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// kernel C: the flank DPs of AlignHSP (alignhsp.cpp:98-162), one wavefront per DpJob
+// ------------------------------------------------------------------------------------------------
+// Everything here depends on the HSP and the sequences only: the windows, the two banded DPs, the trimming of
+// terminal I runs, the all-gap floor, the path.  What depends on the search state -- whether the penalty cap still
+// admits the HSP when its turn comes -- is left to finalize_se_kernel.  One conservative shortcut: if the penalty
+// after the left flank already exceeds the cap the job was made under, the right flank is not run (the cap only
+// falls, so the ordered replay returns at that same test).
+template <int NCH>
+__global__ __launch_bounds__(64) void dp_kernel(DevIndex X, urmapx_params P, const uint8_t *__restrict__ bases,
+                                                const uint64_t *__restrict__ offs, DpWork dp, uint8_t *scratch,
+                                                size_t scratch_stride, const uint8_t *__restrict__ g_seq) {
+	constexpr int QMAX = 64 * NCH;
+	constexpr int TB_ROWS8 = (QMAX - 24) / 8 + 2;
+	__shared__ __attribute__((aligned(16))) uint8_t sQ[QMAX];
+	__shared__ uint8_t sT[QMAX + 64];
+	__shared__ uint32_t tb[TB_ROWS8 * 64];
+	__shared__ uint16_t ropsL[OPS_CAP], ropsR[OPS_CAP], cand[URMAPX_MAX_PATH_OPS];
+	const int lane = threadIdx.x;
+	WideScratch ws;
+	ws.carve(scratch + (size_t)blockIdx.x * scratch_stride, QMAX, QMAX + 64);
+	const VPar VP(P);
+	const int BR = 2 * (int)P.band_radius;
+	const uint32_t made = dp.counters[0];
+	const uint32_t njobs = made < dp.jobs_cap ? made : dp.jobs_cap;
+	auto load_window = [&](uint32_t tlo, int tl) {  // true: the window holds a '-' pad byte
+		bool gap = false;
+		for (int i = lane; i < tl; i += 64) {
+			const uint8_t c = g_seq[tlo + i];
+			sT[i] = c;
+			gap |= (c == '-');
+		}
+		__syncthreads();
+		return __ballot(gap) != 0;
+	};
+	for (uint32_t j = blockIdx.x; j < njobs; j += gridDim.x) {
+		const DpJob J = dp.jobs[j];
+		if (J.read == 0xFFFFFFFFu) continue;
+		const uint64_t off = offs[J.read];
+		const int QL = (int)(offs[J.read + 1] - off);
+		const uint32_t pk = J.pk, startdb = J.startdb;
+		const int startq = (int)(pk & 511u), len = (int)((pk >> 9) & 511u), hscore = (int)((pk >> 18) & 511u);
+		const bool plus = (pk >> 28) & 1u;
+		__syncthreads();
+		{
+			const uint8_t *q = bases + off;
+#pragma unroll
+			for (int c = 0; c < NCH; ++c) {
+				const int p = 64 * c + lane;
+				if (p < QL) sQ[p] = plus ? q[p] : (uint8_t)comp_char(q[QL - 1 - p]);
+			}
+		}
+		__syncthreads();
+		uint32_t flags = 0, vst_l = 0, vst_r = 0, combinedTLo = startdb;
+		int leftScore = 0, rightScore = 0, rtrim = 0;
+		int totalPen = len - hscore;
+		RevOps RL, RR;
+		RL.ops = ropsL; RR.ops = ropsR;
+		RL.begin(); RR.begin();
+		if (startq > 0) {
+			const int leftQL = startq;
+			const uint32_t leftTHi = startdb - 1;
+			const uint32_t leftTL = (uint32_t)(leftQL + BR);
+			if (startdb < (uint32_t)startq || leftTL >= leftTHi) flags |= DPJ_LEFT_FAIL;
+			else {
+				const uint32_t leftTLo = leftTHi - leftTL + 1;
+				if (load_window(leftTLo, (int)leftTL)) flags |= DPJ_LEFT_FAIL;
+				else {
+					leftScore = (int)viterbi_wave<true>(VP, sQ, leftQL, sT, (int)leftTL, true, false, tb, TB_ROWS8, ws, RL, vst_l, lane);
+					// TrimLeftIs (pathinfo.cpp:153-171): the leading I run is the last run in traceback order
+					int nTrimI = 0;
+					if (RL.n > 0) {
+						const uint32_t lastop = ropsL[RL.n - 1];
+						if ((lastop & 3u) == OP_I) { nTrimI = (int)(lastop >> 2); --RL.n; }
+					}
+					combinedTLo = leftTLo + (uint32_t)nTrimI;
+					const int allGap = P.gap_open_score + (leftQL - 1) * P.gap_ext_score;
+					if (allGap > leftScore) leftScore = allGap;
+					totalPen += leftQL - leftScore;
+				}
+			}
+		}
+		const int rightQLo = startq + len;
+		if (!(flags & DPJ_LEFT_FAIL) && rightQLo < QL) {
+			if (totalPen > J.maxpen) flags |= DPJ_RIGHT_SKIPPED;
+			else {
+				const int rightQL = QL - rightQLo;
+				const uint32_t rightTLo = startdb + (uint32_t)len;
+				uint32_t rightTHi = rightTLo + (uint32_t)rightQL + (uint32_t)BR;
+				if (rightTHi >= X.seqDataSize) rightTHi = X.seqDataSize - 1;
+				const uint32_t rightTL = rightTHi - rightTLo + 1;
+				if (load_window(rightTLo, (int)rightTL)) flags |= DPJ_RIGHT_FAIL;
+				else {
+					rightScore = (int)viterbi_wave<true>(VP, sQ + rightQLo, rightQL, sT, (int)rightTL, false, true, tb, TB_ROWS8, ws, RR, vst_r, lane);
+					// TrimRightIs (pathinfo.cpp:173-190): trailing I run = first run in traceback order, never the whole path
+					if (RR.n > 1 && (ropsR[0] & 3u) == OP_I) rtrim = 1;
+					const int allGap = P.gap_open_score + (rightQL - 1) * P.gap_ext_score;
+					if (allGap > rightScore) rightScore = allGap;
+				}
+			}
+		}
+		// path = Left || M x len || Right, run-length merged (uniform; lane 0 stores into LDS, then one coalesced copy)
+		int nc = 0;
+		if (!(flags & (DPJ_LEFT_FAIL | DPJ_RIGHT_FAIL | DPJ_RIGHT_SKIPPED))) {
+			int cop = -1, clen = 0;
+			bool ovf = false;
+			auto put = [&](int op, int l) {
+				if (l <= 0) return;
+				if (op == cop) { clen += l; return; }
+				if (clen) { if (nc < URMAPX_MAX_PATH_OPS) { if (lane == 0) cand[nc] = (uint16_t)((clen << 2) | cop); ++nc; } else ovf = true; }
+				cop = op; clen = l;
+			};
+			for (int t = RL.n - 1; t >= 0; --t) { const uint32_t o = ropsL[t]; put((int)(o & 3u), (int)(o >> 2)); }
+			put(OP_M, len);
+			for (int t = RR.n - 1; t >= rtrim; --t) { const uint32_t o = ropsR[t]; put((int)(o & 3u), (int)(o >> 2)); }
+			put(-2, 1);  // flush
+			if (ovf) { flags |= DPJ_PATH_LONG; nc = 0; }
+			__syncthreads();
+			uint16_t *out = dp.ops + (size_t)j * DP_JOB_OPS;
+			for (int t = lane; t < nc; t += 64) out[t] = cand[t];
+		}
+		if (lane == 0) {
+			DpJob *o = dp.jobs + j;
+			o->combined_tlo = combinedTLo;
+			o->left_score = (int16_t)leftScore; o->right_score = (int16_t)rightScore;
+			o->nops = (uint8_t)nc; o->flags = (uint8_t)flags; o->vst_l = (uint8_t)vst_l; o->vst_r = (uint8_t)vst_r;
+		}
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// kernel D: phase 6's ordered part for the parked reads -- the jobs of a read in HSP order through AlignHSP's tests
+// and AddHitX, then CalcMAPQ6 / SetMappedPos and the result record.  One wavefront per read.
+// ------------------------------------------------------------------------------------------------
+template <int NCH, bool OVF>
+__global__ __launch_bounds__(64) void finalize_se_kernel(DevIndex X, urmapx_params P, const uint64_t *__restrict__ offs, DpWork dp,
+                                                         urmapx_result *__restrict__ results, urmapx_path_op *__restrict__ path_ops,
+                                                         uint32_t *path_used, int hsp_lds_cap, uint32_t *ovf_list) {
+	using SW = SearchWave<NCH, OVF>;
+	__shared__ uint16_t top[URMAPX_MAX_PATH_OPS], cand[URMAPX_MAX_PATH_OPS];
+	const int lane = threadIdx.x;
+	SW S(X, P, lane);
+	S.W = (int)X.W;
+	S.top = top; S.cand = cand;
+	S.hsp_lds = (hsp_lds_cap >= 64 && hsp_lds_cap <= HSP_CAP) ? (hsp_lds_cap & ~63) : HSP_CAP;
+	S.hit_cap = (hsp_lds_cap >= 64 && hsp_lds_cap <= HSP_CAP) ? S.hsp_lds / 4 : 64;
+	S.hit_wsh = (hsp_lds_cap >= 64 && hsp_lds_cap <= HSP_CAP) ? 4 : 6;
+	const uint32_t parked = dp.counters[1] < dp.fin_cap ? dp.counters[1] : dp.fin_cap;
+	for (uint32_t e = blockIdx.x; e < parked; e += gridDim.x) {
+		const uint32_t r = dp.fin_list[3 * e], jb = dp.fin_list[3 * e + 1], nj = dp.fin_list[3 * e + 2];
+		S.QL = (int)(offs[r + 1] - offs[r]);
+		S.nwords = S.QL - (S.W - 1);
+		__syncthreads();
+		const int phase = S.restore_state(dp.state + (size_t)e * SW::STATE_WORDS);
+		uint32_t used = 0;
+		for (uint32_t k = 0; k < nj; ++k) {
+			const DpJob J = dp.jobs[jb + k];
+			used += S.consume_job(J, dp.ops + (size_t)(jb + k) * DP_JOB_OPS) ? 1u : 0u;
+		}
+		if (lane == 0 && used) atomicAdd(dp.counters + 2, used);  // statistics: jobs whose DP the ordered replay looked at
+		urmapx_result res;
+		res.dbpos = 0xFFFFFFFFu; res.seq_index = 0xFFFFFFFFu; res.coord = 0xFFFFFFFFu;
+		res.score = 0; res.second = 0; res.mapq = 0; res.plus = 0; res.exit_phase = 0; res.status = 0;
+		res.hit_count = 0; res.path_nops = 0; res.path_off = 0;
+		S.fill_result(res, phase, path_ops, path_used);
+		if constexpr (!OVF) {
+			if (res.status & (URMAPX_ST_HSP_OVERFLOW | URMAPX_ST_HIT_OVERFLOW)) {  // the hit list outgrew the first pass's: map again
+				if (lane == 0) ovf_list[1 + atomicAdd(ovf_list, 1u)] = r;
+			}
+		}
+		if (lane == 0) results[r] = res;
+	}
+}
+
+size_t dp_state_words(bool ovf) { return ovf ? (size_t)SearchWave<3, true>::STATE_WORDS : (size_t)SearchWave<3, false>::STATE_WORDS; }
+size_t dp_scratch_stride(uint32_t max_read_len) {
+	const int qmax = 64 * (max_read_len <= 128 ? 2 : max_read_len <= 192 ? 3 : max_read_len <= 256 ? 4 : 5);
+	return (WideScratch::bytes(qmax, qmax + 64) + 255) & ~(size_t)255;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1004,33 +1319,83 @@ hipError_t launch_search_se(const DevIndex &X, const urmapx_params &P, const uin
 	}
 	dim3 block(64), grid((unsigned)wk.blocks);
 	uint2 *const no_ovf = nullptr;
-#define URX_LAUNCH_SE(NCH_, OVF_, DBG_, GRID_, STATS_, OVFBASE_)                                                                  \
+	const DpWork no_dp;
+	auto stamp = [&](int i) { if (wk.stage_events) (void)hipEventRecord(wk.stage_events[i], s); };
+	for (int pass = 0; pass < 2; ++pass)
+		if (wk.dp[pass].jobs) {
+			hipError_t e = hipMemsetAsync(wk.dp[pass].counters, 0, 16, s);
+			if (e != hipSuccess) return e;
+		}
+#define URX_LAUNCH_SE(NCH_, OVF_, DBG_, GRID_, STATS_, OVFBASE_, DP_)                                                             \
 	hipLaunchKernelGGL((search_se_kernel<NCH_, OVF_, DBG_>), GRID_, block, 0, s, X, P, d_bases, d_offs, n, probe, d_results,         \
 	                   d_path_ops, d_path_used, STATS_, wk.scratch, wk.scratch_stride, X.seq, X.blob, wk.ticket, wk.hsp_lds_cap, \
-	                   wk.ovf_list, OVFBASE_)
-	if (wk.stats && nch == 3) URX_LAUNCH_SE(3, false, true, grid, wk.stats, no_ovf);  // diagnostic instantiations: 150 / 250 bp classes
-	else if (wk.stats && nch == 4) URX_LAUNCH_SE(4, false, true, grid, wk.stats, no_ovf);
-	else if (nch == 2) URX_LAUNCH_SE(2, false, false, grid, wk.stats, no_ovf);
-	else if (nch == 3) URX_LAUNCH_SE(3, false, false, grid, wk.stats, no_ovf);
-	else if (nch == 4) URX_LAUNCH_SE(4, false, false, grid, wk.stats, no_ovf);
-	else URX_LAUNCH_SE(5, false, false, grid, wk.stats, no_ovf);
+	                   wk.ovf_list, OVFBASE_, DP_)
+	// phase 6 of the reads a pass parked: their flank DPs, then the ordered part
+#define URX_LAUNCH_DP(NCH_, OVF_, PASS_)                                                                                          \
+	do {                                                                                                                          \
+		hipLaunchKernelGGL((dp_kernel<NCH_>), dim3((unsigned)wk.dp_blocks), block, 0, s, X, P, d_bases, d_offs, wk.dp[PASS_],       \
+		                   wk.dp_scratch, wk.dp_scratch_stride, X.seq);                                                           \
+		stamp(2 + 3 * PASS_);                                                                                                      \
+		hipLaunchKernelGGL((finalize_se_kernel<NCH_, OVF_>), dim3((unsigned)wk.blocks), block, 0, s, X, P, d_offs, wk.dp[PASS_],     \
+		                   d_results, d_path_ops, d_path_used, wk.hsp_lds_cap, wk.ovf_list);                                      \
+	} while (0)
+	stamp(0);
+	const bool diag = wk.stats != nullptr && (nch == 3 || nch == 4);  // diagnostic instantiations: 150 / 250 bp classes, phase 6 inline
+	if (diag && nch == 3) URX_LAUNCH_SE(3, false, true, grid, wk.stats, no_ovf, no_dp);
+	else if (diag) URX_LAUNCH_SE(4, false, true, grid, wk.stats, no_ovf, no_dp);
+	else if (nch == 2) URX_LAUNCH_SE(2, false, false, grid, wk.stats, no_ovf, wk.dp[0]);
+	else if (nch == 3) URX_LAUNCH_SE(3, false, false, grid, wk.stats, no_ovf, wk.dp[0]);
+	else if (nch == 4) URX_LAUNCH_SE(4, false, false, grid, wk.stats, no_ovf, wk.dp[0]);
+	else URX_LAUNCH_SE(5, false, false, grid, wk.stats, no_ovf, wk.dp[0]);
+	stamp(1);
+	if (wk.dp[0].jobs && !diag) {
+		if (nch == 2) URX_LAUNCH_DP(2, false, 0);
+		else if (nch == 3) URX_LAUNCH_DP(3, false, 0);
+		else if (nch == 4) URX_LAUNCH_DP(4, false, 0);
+		else URX_LAUNCH_DP(5, false, 0);
+	} else
+		stamp(2);
+	stamp(3);
 	{
 		hipError_t e = hipGetLastError();
 		if (e != hipSuccess) return e;
 		e = hipMemsetAsync(wk.ticket, 0, 4, s);
 		if (e != hipSuccess) return e;
 	}
-	// second pass over the reads whose HSP list outgrew LDS (none for almost every batch: the blocks read a zero count
-	// and leave); it runs the same search with the list continued in global scratch
+	// second pass over the reads whose HSP or hit list outgrew the first pass's (the blocks read the count and leave
+	// when it is zero): the same search with the lists continued in global scratch
 	dim3 grid2((unsigned)(wk.blocks < SEARCH_OVF_BLOCKS ? wk.blocks : SEARCH_OVF_BLOCKS));
 	uint2 *ovf_base = reinterpret_cast<uint2 *>(wk.scratch + (size_t)wk.blocks * wk.scratch_stride);
 	uint32_t *const no_stats = nullptr;
-	if (nch == 2) URX_LAUNCH_SE(2, true, false, grid2, no_stats, ovf_base);
-	else if (nch == 3) URX_LAUNCH_SE(3, true, false, grid2, no_stats, ovf_base);
-	else if (nch == 4) URX_LAUNCH_SE(4, true, false, grid2, no_stats, ovf_base);
-	else URX_LAUNCH_SE(5, true, false, grid2, no_stats, ovf_base);
+	if (nch == 2) URX_LAUNCH_SE(2, true, false, grid2, no_stats, ovf_base, wk.dp[1]);
+	else if (nch == 3) URX_LAUNCH_SE(3, true, false, grid2, no_stats, ovf_base, wk.dp[1]);
+	else if (nch == 4) URX_LAUNCH_SE(4, true, false, grid2, no_stats, ovf_base, wk.dp[1]);
+	else URX_LAUNCH_SE(5, true, false, grid2, no_stats, ovf_base, wk.dp[1]);
+	stamp(4);
+	if (wk.dp[1].jobs) {
+		if (nch == 2) URX_LAUNCH_DP(2, true, 1);
+		else if (nch == 3) URX_LAUNCH_DP(3, true, 1);
+		else if (nch == 4) URX_LAUNCH_DP(4, true, 1);
+		else URX_LAUNCH_DP(5, true, 1);
+	} else
+		stamp(5);
+	stamp(6);
 #undef URX_LAUNCH_SE
+#undef URX_LAUNCH_DP
 	return hipGetLastError();
+}
+
+int dp_block_count(uint32_t max_read_len, int device) {
+	hipDeviceProp_t prop;
+	if (hipGetDeviceProperties(&prop, device) != hipSuccess) return 0;
+	int per_cu = 0;
+	const int nchq = nch_for(max_read_len);
+	hipError_t e = nchq == 2   ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dp_kernel<2>, 64, 0)
+	               : nchq == 3 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dp_kernel<3>, 64, 0)
+	               : nchq == 4 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dp_kernel<4>, 64, 0)
+	                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dp_kernel<5>, 64, 0);
+	if (e != hipSuccess || per_cu < 1) per_cu = 8;
+	return per_cu * prop.multiProcessorCount;
 }
 
 hipError_t launch_viterbi_batch(const urmapx_params &P, const uint8_t *d_a, const uint32_t *d_aoffs,

@@ -341,7 +341,7 @@ struct Mate {
 			if (leftTL >= leftTHi) return -1;
 			const uint32_t leftTLo = leftTHi - leftTL + 1;
 			if (load_window(leftTLo, (int)leftTL)) return -1;
-			int leftScore = (int)viterbi_wave(VPar(*P), Q, leftQL, sT, (int)leftTL, true, false, tb, TB_ROWS8, ws, RL, vst, lane);
+			int leftScore = (int)viterbi_wave<true>(VPar(*P), Q, leftQL, sT, (int)leftTL, true, false, tb, TB_ROWS8, ws, RL, vst, lane);
 			status |= vst;
 			int nTrimI = 0;
 			if (RL.n > 0) {
@@ -363,7 +363,7 @@ struct Mate {
 			if (rightTHi >= TL) rightTHi = TL - 1;
 			const uint32_t rightTL = rightTHi - rightTLo + 1;
 			if (load_window(rightTLo, (int)rightTL)) return -1;
-			int rightScore = (int)viterbi_wave(VPar(*P), Q + rightQLo, rightQL, sT, (int)rightTL, false, true, tb, TB_ROWS8, ws, RR, vst, lane);
+			int rightScore = (int)viterbi_wave<true>(VPar(*P), Q + rightQLo, rightQL, sT, (int)rightTL, false, true, tb, TB_ROWS8, ws, RR, vst, lane);
 			status |= vst;
 			if (RR.n > 1 && (ropsR[0] & 3u) == OP_I) rtrim = 1;
 			int allGap = P->gap_open_score + (rightQL - 1) * P->gap_ext_score;

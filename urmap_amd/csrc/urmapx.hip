@@ -101,6 +101,10 @@ struct urmapx_ctx {
 	int pair_info_on = 0;  // -tabbedout: record urmapx_pair_info per pair
 	DevBuf<urmapx_pair_info> pairinfo;
 	DevBuf<uint32_t> ovflist;  // reads queued for the search kernel's second pass
+	DevBuf<uint8_t> dpbuf, dpscratch;  // phase 6 as its own launches: jobs, paths, parked read states (kernels.h: DpWork)
+	int dp_blocks[4] = {0, 0, 0, 0};
+	hipEvent_t stage_ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+	bool stage_valid = false;
 	uint32_t pairinfo_n = 0;
 	uint32_t stats_reads = 0;  // diagnostics: reads of the last single-end call with per-read cycle counts
 	int pe_blocks[4] = {0, 0, 0, 0};
@@ -284,6 +288,10 @@ int urmapx_ctx_create(const urmapx_index *I, int device, const urmapx_params *P,
 		e = hipEventCreate(&C->ev[i]);
 		if (e != hipSuccess) { urmapx_ctx_destroy(C); return hip_rc(e); }
 	}
+	for (int i = 0; i < 7; ++i) {
+		e = hipEventCreate(&C->stage_ev[i]);
+		if (e != hipSuccess) { urmapx_ctx_destroy(C); return hip_rc(e); }
+	}
 	*out = C;
 	return URMAPX_OK;
 }
@@ -295,6 +303,9 @@ void urmapx_ctx_destroy(urmapx_ctx *C) {
 	C->bases.release(); C->tallies.release(); C->vflags.release(); C->vstatus.release(); C->va.release(); C->vb.release();
 	C->offs.release(); C->slots.release(); C->positions.release(); C->used.release(); C->vaoffs.release(); C->vboffs.release();
 	C->results.release(); C->pathops.release(); C->vops.release(); C->vscores.release(); C->vnops.release();
+	C->dpbuf.release(); C->dpscratch.release();
+	for (int i = 0; i < 7; ++i)
+		if (C->stage_ev[i]) (void)hipEventDestroy(C->stage_ev[i]);
 	C->scratch.release(); C->vscratch.release(); C->statsbuf.release(); C->pe_scratch.release(); C->pairinfo.release(); C->ovflist.release();
 	for (int i = 0; i < 3; ++i)
 		if (C->ev[i]) (void)hipEventDestroy(C->ev[i]);
@@ -311,6 +322,26 @@ int urmapx_ctx_phase_cycles(urmapx_ctx *C, uint64_t out[12]) {
 	uint64_t buf[13];
 	HIP_TRY(hipMemcpy(buf, C->statsbuf.p, sizeof buf, hipMemcpyDeviceToHost));
 	for (int i = 0; i < 12; ++i) out[i] = buf[i + 1];
+	return URMAPX_OK;
+}
+
+// Device time (ms) of the launches of the last single-end *_device call, in order: search (first pass), its flank DPs,
+// its finalize, search (second pass over the reads whose lists outgrew the first), its DPs, its finalize.
+int urmapx_ctx_stage_ms(urmapx_ctx *C, float ms[6]) {
+	if (!C || !ms || !C->stage_valid) return URMAPX_E_ARG;
+	HIP_TRY(hipEventSynchronize(C->stage_ev[6]));
+	for (int i = 0; i < 6; ++i) HIP_TRY(hipEventElapsedTime(&ms[i], C->stage_ev[i], C->stage_ev[i + 1]));
+	return URMAPX_OK;
+}
+
+// Statistics of the last single-end *_device call: per pass {jobs made, reads parked, jobs whose DP the replay needed}
+int urmapx_ctx_dp_stats(urmapx_ctx *C, uint32_t out[6]) {
+	if (!C || !out || !C->dpbuf.p) return URMAPX_E_ARG;
+	HIP_TRY(hipStreamSynchronize(C->stream));
+	uint32_t buf[8];
+	HIP_TRY(hipMemcpy(buf, C->dpbuf.p, sizeof buf, hipMemcpyDeviceToHost));
+	for (int p = 0; p < 2; ++p)
+		for (int i = 0; i < 3; ++i) out[3 * p + i] = buf[4 * p + i];
 	return URMAPX_OK;
 }
 
@@ -378,10 +409,41 @@ int urmapx_map_se_device(urmapx_ctx *C, const void *d_bases, const void *d_offs,
 		const uint32_t ctl[2] = {ds ? (uint32_t)atoi(ds) : 0u, getenv("URMAPX_PHASE_STATS") ? 0u : 1u};
 		HIP_TRY(hipMemcpyAsync(C->statsbuf.p, ctl, 8, hipMemcpyHostToDevice, C->stream));
 	}
+	// phase 6 (AlignHSP of every remaining HSP) as launches of its own: job array, path slices, parked read states
+	if (!getenv("URMAPX_INLINE_PHASE6")) {
+		if (C->dp_blocks[cls] == 0) C->dp_blocks[cls] = dp_block_count(max_read_len, C->device);
+		if (C->dp_blocks[cls] <= 0) return URMAPX_E_NODEVICE;
+		wk.dp_blocks = C->dp_blocks[cls];
+		wk.dp_scratch_stride = dp_scratch_stride(max_read_len);
+		if ((rc = C->dpscratch.ensure(wk.dp_scratch_stride * (size_t)wk.dp_blocks))) return rc;
+		wk.dp_scratch = C->dpscratch.p;
+		const uint32_t jobs_cap[2] = {n * 16u + 4096u, n * 16u + 65536u};
+		const uint32_t fin_cap[2] = {n, n / 8u + 1024u};
+		size_t need = 64, at[2][5];
+		for (int p = 0; p < 2; ++p) {
+			at[p][0] = need; need += (size_t)jobs_cap[p] * sizeof(DpJob);
+			at[p][1] = need; need += (((size_t)jobs_cap[p] * DP_JOB_OPS * 2) + 63) & ~(size_t)63;
+			at[p][2] = need; need += (((size_t)fin_cap[p] * 12) + 63) & ~(size_t)63;
+			at[p][3] = need; need += (size_t)fin_cap[p] * dp_state_words(p == 1) * 4;
+			at[p][4] = 16 * (size_t)p;
+		}
+		if ((rc = C->dpbuf.ensure(need))) return rc;
+		for (int p = 0; p < 2; ++p) {
+			DpWork &d = wk.dp[p];
+			d.jobs = reinterpret_cast<DpJob *>(C->dpbuf.p + at[p][0]);
+			d.ops = reinterpret_cast<uint16_t *>(C->dpbuf.p + at[p][1]);
+			d.fin_list = reinterpret_cast<uint32_t *>(C->dpbuf.p + at[p][2]);
+			d.state = reinterpret_cast<uint32_t *>(C->dpbuf.p + at[p][3]);
+			d.counters = reinterpret_cast<uint32_t *>(C->dpbuf.p + at[p][4]);
+			d.jobs_cap = jobs_cap[p]; d.fin_cap = fin_cap[p];
+		}
+	}
+	wk.stage_events = C->stage_ev;
 	HIP_TRY(hipMemsetAsync(d_path_used, 0, 4, C->stream));
 	HIP_TRY(hipEventRecord(C->ev[0], C->stream));
 	HIP_TRY(launch_seed_probe(C->X, (const uint8_t *)d_bases, (const uint64_t *)d_offs, n, max_read_len, po, C->stream));
 	HIP_TRY(hipEventRecord(C->ev[1], C->stream));
+	C->stage_valid = true;
 	HIP_TRY(launch_search_se(C->X, C->params, (const uint8_t *)d_bases, (const uint64_t *)d_offs, n, max_read_len, po,
 	                         (urmapx_result *)d_results, (urmapx_path_op *)d_path_ops, (uint32_t *)d_path_used, wk, C->stream));
 	HIP_TRY(hipEventRecord(C->ev[2], C->stream));

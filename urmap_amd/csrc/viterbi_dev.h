@@ -72,6 +72,8 @@ __device__ float viterbi_wide(const VPar P, const uint8_t *A, int LA, const uint
                               const WideScratch ws, uint32_t *lds, int lds_dwords, RevOps &R, uint32_t &status, int lane);
 
 // ws.la_cap == 0: no wide-band scratch (the band must fit one wavefront).
+// B_LDS: B is an LDS array of the caller (reads around it cannot fault, so the row blocks index it without a clamp).
+template <bool B_LDS = false>
 __device__ __forceinline__ float viterbi_wave(const VPar P, const uint8_t *A, int LA, const uint8_t *B, int LB, bool Left, bool Right,
                               uint32_t *tb, int tb_rows8, const WideScratch ws, RevOps &R, uint32_t &status, int lane_in) {
 	// the lane index is recomputed here (two mbcnt) instead of using the caller's: that one is live through the whole
@@ -103,7 +105,8 @@ __device__ __forceinline__ float viterbi_wave(const VPar P, const uint8_t *A, in
 	uint32_t acc = 0;
 	const int jbase = dlo - 1 + lane - LA;  // column of this lane in row i is jbase + i
 	const bool real = lane >= 1 && lane <= ND;
-	for (int i = 0; i < LA; ++i) {
+	// one DP row, every special case spelled out (used for row 0)
+	auto row_general = [&](int i) {
 		const int j = jbase + i;
 		const bool active = real && j >= 0 && j < LB;
 		const bool semi = (j == LB) && lane >= 1 && lane <= ND + 1;
@@ -144,6 +147,76 @@ __device__ __forceinline__ float viterbi_wave(const VPar P, const uint8_t *A, in
 		}
 		acc |= bits << (4 * (i & 7));
 		if ((i & 7) == 7) { tb[(i >> 3) * 64 + lane] = acc; acc = 0; }
+	};
+	// Up to eight rows at a time, select-only (rows >= 1, so none of row 0's special cases): the same recurrences and tie rules
+	// as row_general with every lane computing every value and the lane classes (band cell / column LB / column
+	// Startj-1 / outside) applied by selects at the end.  No divergent branch, byte loads with immediate offsets, one
+	// trace dword per lane per block -- the general row costs ~100 issue slots, half of them scalar.
+	const float GOl = Left ? 0.0f : GO, GEl = Left ? 0.0f : GE;  // column 0 of a Left problem opens / extends D for free
+	const float MISf = (float)P.mismatch_score;
+	const float el = GE * flane, el1 = GE * (flane - 1.0f);
+	const uint32_t LBr = real ? (uint32_t)LB : 0u;                          // band cell iff (unsigned)j < LBr
+	const int LBs = (lane >= 1 && lane <= ND + 1) ? LB : -(1 << 20);        // column LB cell iff j == LBs
+	const uint32_t bits0c = lane == 0 ? TB_IM : 0u;                         // column Startj-1: IM once j >= 0
+	// rows i0 .. i0+n-1 (1 <= i0, all inside one trace dword: (i0 & 7) + n <= 8)
+	auto rows_upto8 = [&](int i0, int n) {
+		const int j0 = jbase + i0;
+		const uint8_t *Ap = A + i0;
+		uint32_t av[8], bv[8];
+		if constexpr (B_LDS) {
+			const uint8_t *Bp = B + j0;  // bytes outside [0, LB) are read but never used (LDS reads cannot fault)
+#pragma unroll
+			for (int k = 0; k < 8; ++k) { av[k] = Ap[k]; bv[k] = Bp[k]; }
+		} else {
+#pragma unroll
+			for (int k = 0; k < 8; ++k) { av[k] = A[min(i0 + k, LA - 1)]; bv[k] = B[min(max(j0 + k, 0), LB - 1)]; }
+		}
+		const int sh0 = 4 * (i0 & 7);
+		uint32_t word = 0;
+#pragma unroll
+		for (int k = 0; k < 8; ++k) {
+			if (k < n) {  // wave-uniform
+				const int j = j0 + k;
+				const bool act = (uint32_t)j < LBr;
+				const bool semi = j == LBs;
+				const float D = wave_shl1(Dn, NEG);
+				const float Mcur = M;
+				const float vraw = Mcur + GO;
+				const float v = act ? vraw : NEG;
+				const float Pm = wave_prefix_max(v - el);
+				const float I = wave_shr1(Pm, NEG) + el1;
+				// M state: best of M, D ('>'), I ('>')
+				uint32_t bits = D > Mcur ? TB_DM : 0u;
+				float xM = fmaxf(Mcur, D);
+				bits = I > xM ? TB_IM : bits;
+				xM = fmaxf(xM, I);
+				const float Mnew = xM + (av[k] == bv[k] ? 1.0f : MISf);
+				// D state: open ('>=' wins) or extend; free in column 0 of a Left problem
+				const bool col0 = j == 0;
+				const float md = Mcur + (col0 ? GOl : GO);
+				const float de = D + (col0 ? GEl : GE);
+				const uint32_t bMD = md >= de ? TB_MD : 0u;
+				const float Dnew = fmaxf(md, de);
+				// I state: open ('>=' wins) or extend
+				const uint32_t bMI = vraw >= I + GE ? TB_MI : 0u;
+				bits |= bMD | bMI;
+				M = act ? Mnew : (semi ? NEG : M);
+				Dn = (act || semi) ? Dnew : Dn;
+				bits = act ? bits : (semi ? bMD : (j >= 0 ? bits0c : 0u));
+				word |= bits << (4 * k);
+			}
+		}
+		acc |= word << sh0;
+		if (((i0 + n) & 7) == 0) { tb[(i0 >> 3) * 64 + lane] = acc; acc = 0; }
+	};
+	{
+		row_general(0);  // the only row with special cases of its own (free gaps of a Left problem, the origin cell)
+		int i = 1;
+		while (i < LA) {
+			const int n = min(8 - (i & 7), LA - i);
+			rows_upto8(i, n);
+			i += n;
+		}
 	}
 	// last row of the insert matrix (strict '>' there)
 	float FinalI;
@@ -173,26 +246,37 @@ __device__ __forceinline__ float viterbi_wave(const VPar P, const uint8_t *A, in
 	if (FinalI > Score) { Score = FinalI; st = OP_I; }
 	__syncthreads();
 
-	// traceback (wave-uniform; LDS reads are broadcasts)
-	// A run of M steps stays on one diagonal (= one lane) and 8 rows share a dword, so the last dword is kept:
-	// only every 8th step of a match run touches LDS.
+	// traceback (tracebackbitmem.cpp:8-75), a whole run per step: lane s looks at the s-th cell in the current direction
+	// (M: up the diagonal, D: up the column, I: left along the row), a ballot finds the cell whose trace bits end the run.
+	// The trace cell of (row, col) is nibble (row & 7) of tb[(row >> 3) * 64 + diagonal lane].
 	int i = LA, j = LB;
 	int guard = LA + LB + 2;
-	int ckey = -1;
-	uint32_t cword = 0;
 	while ((i | j) != 0 && guard-- > 0) {
-		R.emit(st, lane);
-		int ri, cj;
-		if (st == OP_M) { ri = i - 1; cj = j - 1; }
-		else if (st == OP_D) { ri = i - 1; cj = j; }
-		else { ri = i; cj = j - 1; }
-		const int l = (LA - ri + cj - dlo + 1) & 63;
-		const int key = (ri >> 3) * 64 + l;
-		if (key != ckey) { cword = uni(tb[key]); ckey = key; }
-		uint32_t t = (cword >> (4 * (ri & 7))) & 15u;
-		if (st == OP_M) { st = (t & TB_DM) ? OP_D : (t & TB_IM) ? OP_I : OP_M; --i; --j; }
-		else if (st == OP_D) { st = (t & TB_MD) ? OP_M : OP_D; --i; }
-		else { st = (t & TB_MI) ? OP_M : OP_I; --j; }
+		int n, ri, cj;
+		uint32_t stop;
+		if (st == OP_M) { n = min(i, j); ri = i - 1 - lane; cj = j - 1 - lane; stop = TB_DM | TB_IM; }
+		else if (st == OP_D) { n = i; ri = i - 1 - lane; cj = j; stop = TB_MD; }
+		else { n = j; ri = i; cj = j - 1 - lane; stop = TB_MI; }
+		if (n <= 0) break;
+		if (n > 64) n = 64;
+		uint32_t t = 0;
+		if (lane < n) {
+			const int l = (LA - ri + cj - dlo + 1) & 63;
+			t = (tb[(ri >> 3) * 64 + l] >> (4 * (ri & 7))) & 15u;
+		}
+		const uint64_t ends = __ballot(lane < n && (t & stop) != 0);
+		const int len = ends ? (int)__builtin_ctzll(ends) + 1 : n;  // the cell that ends the run is still in this state
+		R.emit_run(st, len, lane);
+		int nst = st;
+		if (ends) {
+			const uint32_t te = rdlane(t, len - 1);
+			if (st == OP_M) nst = (te & TB_DM) ? OP_D : OP_I;
+			else nst = OP_M;
+		}
+		if (st == OP_M) { i -= len; j -= len; }
+		else if (st == OP_D) i -= len;
+		else j -= len;
+		st = nst;
 	}
 	R.end(lane);
 	if (R.overflow) status |= URMAPX_ST_PATH_OVERFLOW;
