@@ -421,13 +421,18 @@ class Workload:
         if barrier:
             barrier()
         kms = np.zeros(2)
+        self.stage_ms = np.zeros(6)
         t0 = time.perf_counter()
         for k in range(steps):
             self.step(mapper, warmup + k)
             mapper.sync()
             kms += mapper.last_kernel_ms()
+            if not self.pe:
+                self.stage_ms += mapper.stage_ms()
         if barrier:
             barrier()
+        self.stage_ms /= max(1, steps)
+        self.dp_stats = None if self.pe else mapper.dp_stats()
         return time.perf_counter() - t0, kms / max(1, steps)
 
     def check(self, oi, sample_n, threads):
@@ -469,26 +474,42 @@ class Workload:
         return parity, {k: v / max(1, cnt["n_reads"]) for k, v in cnt.items()}, t_cpu
 
 
-def kernel_table(api, pe, L, nb, kms, counters, total_bp, gather_loads_s):
-    """Per-kernel roofline figures.  Algorithmic bytes per read from the reference algorithm's own access counts
+def kernel_table(api, pe, L, nb, kms, counters, total_bp, gather_loads_s, stage_ms=None):
+    """Per-launch roofline figures.  Algorithmic bytes per read from the reference algorithm's own access counts
     (SURVEY.md 8d), counted by the oracle on the sample: probe kernel 5 B per GetBlob + the read; search kernel 5 B per
-    chain slot + compared reference bases + DP target bases + the result record."""
+    chain slot + compared reference bases + the result record; DP kernel the target bases of the DP windows + the
+    query flanks they are aligned with.  Single-end: the search is six launches (main / DP / finalize, then the same
+    for the few reads whose lists outgrew the first pass's); paired-end: one search kernel."""
     c = counters
-    algs = (5.0 * c["n_getblob"] + L, 5.0 * c["n_rowhop"] + c["n_extbases"] + c["n_dptarget"] + api.RESULT_DTYPE.itemsize)
-    names = ("seed_probe_kernel", "search_pe_kernel" if pe else "search_se_kernel")
+    rows = [("seed_probe_kernel", float(kms[0]), 5.0 * c["n_getblob"] + L)]
+    if pe or stage_ms is None:
+        rows.append(("search_pe_kernel" if pe else "search_se_kernel", float(kms[1]),
+                     5.0 * c["n_rowhop"] + c["n_extbases"] + c["n_dptarget"] + api.RESULT_DTYPE.itemsize))
+    else:
+        rows.append(("search_se_kernel", float(stage_ms[0]), 5.0 * c["n_rowhop"] + c["n_extbases"] + api.RESULT_DTYPE.itemsize))
+        rows.append(("dp_kernel", float(stage_ms[1]), 2.0 * c["n_dptarget"]))
+        rows.append(("finalize_se_kernel", float(stage_ms[2]), float(api.RESULT_DTYPE.itemsize)))
+        rows.append(("second pass (search + dp + finalize over the reads whose lists outgrew the first)", float(sum(stage_ms[3:6])), 0.0))
     sector_peak = 64.0 * gather_loads_s / 1e9
     kern = []
-    for i in range(2):
-        ach = algs[i] * nb / (kms[i] * 1e-3) / 1e9 if kms[i] > 0 else 0.0
-        k = {"kernel": names[i], "avg_ms": round(float(kms[i]), 4), "alg_bytes_per_read": round(algs[i], 1),
+    for name, ms, alg in rows:
+        ach = alg * nb / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        k = {"kernel": name, "avg_ms": round(ms, 4), "alg_bytes_per_read": round(alg, 1),
              "achieved_GBs": round(ach, 2), "frac": round(ach / HBM_PEAK_GBS, 5)}
-        t = pmc_traffic(names[i], nb, total_bp, L, "pe" if pe else "se")
+        t = pmc_traffic(name, nb, total_bp, L, "pe" if pe else "se")
         k["hbm_read_bytes_per_launch_pmc"] = t
-        if t and sector_peak > 0 and kms[i] > 0:
-            k["sector_GBs"] = round(t / (kms[i] * 1e-3) / 1e9, 1)
+        if t and sector_peak > 0 and ms > 0:
+            k["sector_GBs"] = round(t / (ms * 1e-3) / 1e9, 1)
             k["frac_of_random_gather_peak"] = round(k["sector_GBs"] / sector_peak, 4)
         kern.append(k)
     return kern
+
+
+# what the SQ counters say limits each kernel (profiles/r2/pmc_sq_*.json; DESIGN.md section 5)
+KERNEL_LIMITER = {"seed_probe_kernel": "hbm random access (64 B sector per 5 B slot)",
+                  "search_se_kernel": "instruction issue + memory latency (order-dependent schedule, one wavefront per read)",
+                  "search_pe_kernel": "instruction issue + memory latency (order-dependent schedule, one wavefront per pair)",
+                  "dp_kernel": "VALU / SALU instruction issue (fp32 banded DP, no MFMA: max-plus recurrences)"}
 
 
 def main():
@@ -571,8 +592,9 @@ def main():
             gather_loads_s = mapper.gather_microbench(1 << 28)
         except Exception:
             gather_loads_s = 0.0
-        kern = kernel_table(api, pe, L, nb, kms, counters, total_bp, gather_loads_s)
-        dom = int(np.argmax(kms))
+        kern = kernel_table(api, pe, L, nb, kms, counters, total_bp, gather_loads_s, None if pe else wl.stage_ms)
+        dom = int(np.argmax([k["avg_ms"] if not k["kernel"].startswith("second pass") else 0.0 for k in kern]))
+        dp_stats = wl.dp_stats
         key = "pe150" if pe else ("se150" if L == 150 else ("se250" if L == 250 else None))
         out = {
             "metric": metric_name(pe, L),
@@ -595,6 +617,9 @@ def main():
                        "setup_s": {"genome": round(t_gen, 1), **t_index, "total": round(setup_s, 1)}},
             "roofline": {"bound": "hbm", "kernel": kern[dom]["kernel"], "achieved": kern[dom]["achieved_GBs"],
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": kern[dom]["frac"],
+                         "limiter": KERNEL_LIMITER.get(kern[dom]["kernel"], ""),
+                         "whole_step": {"alg_bytes_per_read": round(sum(k["alg_bytes_per_read"] for k in kern), 1),
+                                        "achieved_GBs": round(sum(k["alg_bytes_per_read"] for k in kern) * nb / (dt / args.steps) / 1e9, 2)},
                          "traffic": kern[dom]["hbm_read_bytes_per_launch_pmc"],
                          "random_gather_peak": {"slot_reads_per_s": round(gather_loads_s), "sector_GBs": round(64.0 * gather_loads_s / 1e9, 1),
                                                 "note": "measured in this run: independent random 5-byte slot reads over the resident table, 64 B sector each"}},
@@ -602,6 +627,9 @@ def main():
             "parity": parity,
             "work_per_read": {k: round(v, 2) for k, v in counters.items()},
         }
+        if dp_stats:
+            out["phase6"] = {"hsps_given_to_dp_kernel": dp_stats[0], "reads_with_such_hsps": dp_stats[1], "dps_the_ordered_replay_used": dp_stats[2],
+                             "second_pass": {"hsps": dp_stats[3], "reads": dp_stats[4], "used": dp_stats[5]}}
         if key:
             out["work_per_read_survey"] = SURVEY_WORK_PER_READ[key]
         if cpu is not None:
@@ -617,7 +645,7 @@ def main():
                 wl = Workload(torch, api, device, d_seq, seq_lengths, seq_offsets, ope, oL, osub, oindel, nb, 3, 5000)
                 odt, okms = wl.timed(mapper, 5, 1)
                 opar, ocnt, ot = wl.check(oi, min(nb, 200_000), cores)
-                okern = kernel_table(api, ope, oL, nb, okms, ocnt, total_bp, gather_loads_s)
+                okern = kernel_table(api, ope, oL, nb, okms, ocnt, total_bp, gather_loads_s, None if ope else wl.stage_ms)
                 others[name] = {"metric": metric_name(ope, oL), "value": round(5 * nb / odt, 1), "unit": "reads/s", "steps": 5, "warmup": 1,
                                 "ms_per_step": round(1e3 * odt / 5, 3), "kernels": okern, "parity": opar,
                                 "work_per_read": {k: round(v, 2) for k, v in ocnt.items()},

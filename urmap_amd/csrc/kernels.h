@@ -51,17 +51,24 @@ struct DpJob {             // 32 bytes
 	uint8_t nops;          // runs of the whole path (left flank, the HSP's M run, right flank; merged) in the job's ops slice
 	uint8_t flags;         // DPJ_*
 	uint8_t vst_l, vst_r;  // URMAPX_ST_* bits raised by the left / right DP
-	uint8_t pad[4];
+	uint16_t k;            // index of the job among its read's jobs (they are consumed in that order)
+	uint8_t pad[2];
 };
 static_assert(sizeof(DpJob) == 32, "DpJob layout");
 // flank window unusable (alignhsp.cpp:104-117 / 148-150); right flank not run (penalty already over the job's cap);
 // path longer than URMAPX_MAX_PATH_OPS runs
-static constexpr uint8_t DPJ_LEFT_FAIL = 1, DPJ_RIGHT_FAIL = 2, DPJ_RIGHT_SKIPPED = 4, DPJ_PATH_LONG = 8;
+static constexpr uint8_t DPJ_LEFT_FAIL = 1, DPJ_RIGHT_FAIL = 2, DPJ_RIGHT_SKIPPED = 4, DPJ_PATH_LONG = 8, DPJ_GATED = 16;
+// The jobs of a read are run in rounds of growing size, [0,2) [2,16) [16,inf) by index: after each round the ordered
+// replay consumes that round's jobs and the penalty cap it arrives at gates the next round's DPs -- most of a repeat
+// read's HSPs fail AlignHSP's first test once the first few alignments have tightened the cap.
+static constexpr int DP_ROUNDS = 3;
+static constexpr uint32_t DP_ROUND_LO[DP_ROUNDS + 1] = {0u, 2u, 16u, 0xFFFFFFFFu};
 static constexpr int DP_JOB_OPS = URMAPX_MAX_PATH_OPS;  // ops slice per job
 
 struct DpWork {
 	DpJob *jobs = nullptr;          // jobs_cap entries
 	uint16_t *ops = nullptr;        // jobs_cap * DP_JOB_OPS: the accepted alignment's path per job
+	uint16_t *kidx = nullptr;       // jobs_cap: DpJob::k again, contiguous (a round scans it 64 jobs per load)
 	uint32_t jobs_cap = 0;
 	uint32_t *counters = nullptr;   // [0] jobs made, [1] reads parked, [2] jobs the ordered replay needed (statistics)
 	uint32_t *fin_list = nullptr;   // per parked read: read, first job, job count

@@ -491,7 +491,7 @@ struct SearchWave {
 			room = slot < dp.fin_cap;
 		}
 		if (!room) {  // the slots taken stay unused
-			for (uint32_t i = jb + lane; i < dp.jobs_cap && i - jb < (uint32_t)njobs; i += 64) dp.jobs[i].read = 0xFFFFFFFFu;
+			for (uint32_t i = jb + lane; i < dp.jobs_cap && i - jb < (uint32_t)njobs; i += 64) { dp.jobs[i].read = 0xFFFFFFFFu; dp.kidx[i] = 0xFFFFu; }
 			return false;
 		}
 		int w = 0;
@@ -504,12 +504,19 @@ struct SearchWave {
 				DpJob J;
 				J.read = r; J.startdb = sdb; J.pk = pk; J.maxpen = maxPen;
 				J.combined_tlo = 0; J.left_score = 0; J.right_score = 0; J.nops = 0; J.flags = 0; J.vst_l = 0; J.vst_r = 0;
-				J.pad[0] = J.pad[1] = J.pad[2] = J.pad[3] = 0;
+				J.k = (uint16_t)((uint32_t)w + rank); J.pad[0] = J.pad[1] = 0;
 				dp.jobs[jb + (uint32_t)w + rank] = J;
+				dp.kidx[jb + (uint32_t)w + rank] = J.k;
 			}
 			w += __builtin_popcountll(m);
 		}
-		uint32_t *st = dp.state + (size_t)slot * STATE_WORDS;
+		if (njobs > 0xFFFF) status |= URMAPX_ST_HSP_OVERFLOW;  // cannot happen: the HSP list holds at most 8192
+		if (lane == 0) { dp.fin_list[3 * slot] = r; dp.fin_list[3 * slot + 1] = jb; dp.fin_list[3 * slot + 2] = (uint32_t)njobs; }
+		park_state(dp.state + (size_t)slot * STATE_WORDS, phase);
+		return true;
+	}
+
+	__device__ void park_state(uint32_t *st, int phase) {
 #pragma unroll
 		for (int wd = 0; wd < HITW; ++wd) st[wd * 64 + lane] = hit_db[wd];
 		uint32_t *sc = st + HITW * 64;
@@ -517,11 +524,9 @@ struct SearchWave {
 			sc[0] = (uint32_t)hitCount; sc[1] = (uint32_t)maxPen; sc[2] = (uint32_t)best; sc[3] = (uint32_t)second;
 			sc[4] = top_db; sc[5] = (haveTop ? 1u : 0u) | (top_plus ? 2u : 0u) | ((uint32_t)phase << 8);
 			sc[6] = (uint32_t)top_nops; sc[7] = status; sc[8] = (uint32_t)hspCount;
-			dp.fin_list[3 * slot] = r; dp.fin_list[3 * slot + 1] = jb; dp.fin_list[3 * slot + 2] = (uint32_t)njobs;
 		}
 		uint16_t *tops = reinterpret_cast<uint16_t *>(sc + 16);
 		for (int t = lane; t < top_nops; t += 64) tops[t] = top[t];
-		return true;
 	}
 
 	// back from the parking lot (finalize_se_kernel); returns the phase the read was in
@@ -550,6 +555,7 @@ struct SearchWave {
 		int totalPen = len - hscore;
 		int totalScore = hscore;
 		if (totalPen > maxPen) return false;
+		if (J.flags & DPJ_GATED) { status |= URMAPX_ST_BAND_TOO_WIDE; return false; }  // cannot happen: gated under a cap >= this one
 		uint32_t vst = 0;
 		if (startq > 0) {
 			if (J.flags & DPJ_LEFT_FAIL) return true;
@@ -1060,7 +1066,7 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 template <int NCH>
 __global__ __launch_bounds__(64) void dp_kernel(DevIndex X, urmapx_params P, const uint8_t *__restrict__ bases,
                                                 const uint64_t *__restrict__ offs, DpWork dp, uint8_t *scratch,
-                                                size_t scratch_stride, const uint8_t *__restrict__ g_seq) {
+                                                size_t scratch_stride, const uint8_t *__restrict__ g_seq, uint32_t klo, uint32_t khi) {
 	constexpr int QMAX = 64 * NCH;
 	constexpr int TB_ROWS8 = (QMAX - 24) / 8 + 2;
 	__shared__ __attribute__((aligned(16))) uint8_t sQ[QMAX];
@@ -1084,9 +1090,24 @@ __global__ __launch_bounds__(64) void dp_kernel(DevIndex X, urmapx_params P, con
 		__syncthreads();
 		return __ballot(gap) != 0;
 	};
-	for (uint32_t j = blockIdx.x; j < njobs; j += gridDim.x) {
+	// this round's jobs: those with klo <= k < khi.  The k of 64 consecutive jobs comes in with one load; the block then
+	// runs the tile's jobs of this round one after the other.
+	for (uint32_t tile = blockIdx.x * 64u; tile < njobs; tile += gridDim.x * 64u) {
+	uint32_t kk = 0xFFFFu;  // 0xFFFF: slot not in use
+	if (tile + lane < njobs) kk = dp.kidx[tile + lane];
+	uint64_t todo = __ballot(kk >= klo && kk < khi && kk != 0xFFFFu);
+	while (todo) {
+		const uint32_t j = tile + (uint32_t)__builtin_ctzll(todo);
+		todo &= todo - 1;
 		const DpJob J = dp.jobs[j];
 		if (J.read == 0xFFFFFFFFu) continue;
+		{  // AlignHSP's first test under the cap the replay has reached so far (the cap only falls)
+			const int glen = (int)((J.pk >> 9) & 511u), gscore = (int)((J.pk >> 18) & 511u);
+			if (glen - gscore > J.maxpen) {
+				if (lane == 0) dp.jobs[j].flags = DPJ_GATED;
+				continue;
+			}
+		}
 		const uint64_t off = offs[J.read];
 		const int QL = (int)(offs[J.read + 1] - off);
 		const uint32_t pk = J.pk, startdb = J.startdb;
@@ -1177,6 +1198,7 @@ __global__ __launch_bounds__(64) void dp_kernel(DevIndex X, urmapx_params P, con
 			o->nops = (uint8_t)nc; o->flags = (uint8_t)flags; o->vst_l = (uint8_t)vst_l; o->vst_r = (uint8_t)vst_r;
 		}
 	}
+	}
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1186,7 +1208,8 @@ __global__ __launch_bounds__(64) void dp_kernel(DevIndex X, urmapx_params P, con
 template <int NCH, bool OVF>
 __global__ __launch_bounds__(64) void finalize_se_kernel(DevIndex X, urmapx_params P, const uint64_t *__restrict__ offs, DpWork dp,
                                                          urmapx_result *__restrict__ results, urmapx_path_op *__restrict__ path_ops,
-                                                         uint32_t *path_used, int hsp_lds_cap, uint32_t *ovf_list) {
+                                                         uint32_t *path_used, int hsp_lds_cap, uint32_t *ovf_list, uint32_t klo,
+                                                         uint32_t khi) {
 	using SW = SearchWave<NCH, OVF>;
 	__shared__ uint16_t top[URMAPX_MAX_PATH_OPS], cand[URMAPX_MAX_PATH_OPS];
 	const int lane = threadIdx.x;
@@ -1199,16 +1222,25 @@ __global__ __launch_bounds__(64) void finalize_se_kernel(DevIndex X, urmapx_para
 	const uint32_t parked = dp.counters[1] < dp.fin_cap ? dp.counters[1] : dp.fin_cap;
 	for (uint32_t e = blockIdx.x; e < parked; e += gridDim.x) {
 		const uint32_t r = dp.fin_list[3 * e], jb = dp.fin_list[3 * e + 1], nj = dp.fin_list[3 * e + 2];
+		if (nj <= klo) continue;  // finished in an earlier round
 		S.QL = (int)(offs[r + 1] - offs[r]);
 		S.nwords = S.QL - (S.W - 1);
 		__syncthreads();
-		const int phase = S.restore_state(dp.state + (size_t)e * SW::STATE_WORDS);
+		uint32_t *const st = dp.state + (size_t)e * SW::STATE_WORDS;
+		const int phase = S.restore_state(st);
 		uint32_t used = 0;
-		for (uint32_t k = 0; k < nj; ++k) {
+		const uint32_t kend = nj < khi ? nj : khi;
+		for (uint32_t k = klo; k < kend; ++k) {
 			const DpJob J = dp.jobs[jb + k];
 			used += S.consume_job(J, dp.ops + (size_t)(jb + k) * DP_JOB_OPS) ? 1u : 0u;
 		}
 		if (lane == 0 && used) atomicAdd(dp.counters + 2, used);  // statistics: jobs whose DP the ordered replay looked at
+		if (nj > khi) {  // more rounds to come: park again, and tell the remaining jobs the cap reached so far
+			__syncthreads();
+			S.park_state(st, phase);
+			for (uint32_t k = khi + lane; k < nj; k += 64) dp.jobs[jb + k].maxpen = S.maxPen;
+			continue;
+		}
 		urmapx_result res;
 		res.dbpos = 0xFFFFFFFFu; res.seq_index = 0xFFFFFFFFu; res.coord = 0xFFFFFFFFu;
 		res.score = 0; res.second = 0; res.mapq = 0; res.plus = 0; res.exit_phase = 0; res.status = 0;
@@ -1332,13 +1364,13 @@ hipError_t launch_search_se(const DevIndex &X, const urmapx_params &P, const uin
 	                   wk.ovf_list, OVFBASE_, DP_)
 	// phase 6 of the reads a pass parked: their flank DPs, then the ordered part
 #define URX_LAUNCH_DP(NCH_, OVF_, PASS_)                                                                                          \
-	do {                                                                                                                          \
+	do { for (int rd = 0; rd < DP_ROUNDS; ++rd) {                                                                                 \
 		hipLaunchKernelGGL((dp_kernel<NCH_>), dim3((unsigned)wk.dp_blocks), block, 0, s, X, P, d_bases, d_offs, wk.dp[PASS_],       \
-		                   wk.dp_scratch, wk.dp_scratch_stride, X.seq);                                                           \
-		stamp(2 + 3 * PASS_);                                                                                                      \
+		                   wk.dp_scratch, wk.dp_scratch_stride, X.seq, DP_ROUND_LO[rd], DP_ROUND_LO[rd + 1]);                     \
+		if (rd == DP_ROUNDS - 1) stamp(2 + 3 * PASS_);                                                                             \
 		hipLaunchKernelGGL((finalize_se_kernel<NCH_, OVF_>), dim3((unsigned)wk.blocks), block, 0, s, X, P, d_offs, wk.dp[PASS_],     \
-		                   d_results, d_path_ops, d_path_used, wk.hsp_lds_cap, wk.ovf_list);                                      \
-	} while (0)
+		                   d_results, d_path_ops, d_path_used, wk.hsp_lds_cap, wk.ovf_list, DP_ROUND_LO[rd], DP_ROUND_LO[rd + 1]); \
+	} } while (0)
 	stamp(0);
 	const bool diag = wk.stats != nullptr && (nch == 3 || nch == 4);  // diagnostic instantiations: 150 / 250 bp classes, phase 6 inline
 	if (diag && nch == 3) URX_LAUNCH_SE(3, false, true, grid, wk.stats, no_ovf, no_dp);

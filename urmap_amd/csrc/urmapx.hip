@@ -419,8 +419,9 @@ int urmapx_map_se_device(urmapx_ctx *C, const void *d_bases, const void *d_offs,
 		wk.dp_scratch = C->dpscratch.p;
 		const uint32_t jobs_cap[2] = {n * 16u + 4096u, n * 16u + 65536u};
 		const uint32_t fin_cap[2] = {n, n / 8u + 1024u};
-		size_t need = 64, at[2][5];
+		size_t need = 64, at[2][6];
 		for (int p = 0; p < 2; ++p) {
+			at[p][5] = need; need += (((size_t)jobs_cap[p] * 2) + 63) & ~(size_t)63;
 			at[p][0] = need; need += (size_t)jobs_cap[p] * sizeof(DpJob);
 			at[p][1] = need; need += (((size_t)jobs_cap[p] * DP_JOB_OPS * 2) + 63) & ~(size_t)63;
 			at[p][2] = need; need += (((size_t)fin_cap[p] * 12) + 63) & ~(size_t)63;
@@ -432,6 +433,7 @@ int urmapx_map_se_device(urmapx_ctx *C, const void *d_bases, const void *d_offs,
 			DpWork &d = wk.dp[p];
 			d.jobs = reinterpret_cast<DpJob *>(C->dpbuf.p + at[p][0]);
 			d.ops = reinterpret_cast<uint16_t *>(C->dpbuf.p + at[p][1]);
+			d.kidx = reinterpret_cast<uint16_t *>(C->dpbuf.p + at[p][5]);
 			d.fin_list = reinterpret_cast<uint32_t *>(C->dpbuf.p + at[p][2]);
 			d.state = reinterpret_cast<uint32_t *>(C->dpbuf.p + at[p][3]);
 			d.counters = reinterpret_cast<uint32_t *>(C->dpbuf.p + at[p][4]);
