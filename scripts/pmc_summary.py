@@ -17,15 +17,15 @@ def main():
             for row in csv.DictReader(fh):
                 k = row["Kernel_Name"].split("(")[0]
                 full = row["Kernel_Name"]
-                for short in ("search_se_kernel", "search_pe_kernel", "seed_probe_kernel", "viterbi_batch_kernel"):
+                for short in ("search_se_kernel", "search_pe_kernel", "seed_probe_kernel", "viterbi_batch_kernel", "dp_kernel", "finalize_se_kernel"):
                     if short in k:
                         # <NCH, true> = the second pass over reads whose lists outgrew LDS (usually an empty queue)
                         k = short + ("_pass2" if re.search(r"<\d+,\s*true", full) else "") + ("_dbg" if re.search(r"<\d+,\s*(true|false),\s*true", full) else "")
                 a = acc[k][row["Counter_Name"]]
                 a[0] += float(row["Counter_Value"])
                 a[1] += 1
-    out = {k: {c: {"avg": v[0] / v[1], "dispatches": v[1]} for c, v in cs.items()} for k, cs in acc.items()
-           if k.replace("_pass2", "").replace("_dbg", "") in ("search_se_kernel", "search_pe_kernel", "seed_probe_kernel", "viterbi_batch_kernel")}
+    out = {k: {c: {"avg": v[0] / v[1], "dispatches": v[1], "sum": v[0]} for c, v in cs.items()} for k, cs in acc.items()
+           if k.replace("_pass2", "").replace("_dbg", "") in ("search_se_kernel", "search_pe_kernel", "seed_probe_kernel", "viterbi_batch_kernel", "dp_kernel", "finalize_se_kernel")}
     s = json.dumps(out, indent=1, sort_keys=True)
     if len(sys.argv) > 2:
         open(sys.argv[2], "w").write(s + "\n")
