@@ -474,6 +474,69 @@ class Workload:
         return parity, {k: v / max(1, cnt["n_reads"]) for k, v in cnt.items()}, t_cpu
 
 
+def write_fastq_fixed(path, reads_u8, n, L):
+    """n reads of length L (uint8 array [n*L]) as FASTQ with fixed-width labels r00000000.. and quality 'I'."""
+    lab = 2 + 8 + 1
+    rec = lab + L + 3 + L + 1
+    a = np.empty((n, rec), dtype=np.uint8)
+    a[:, 0] = ord("@"); a[:, 1] = ord("r")
+    idx = np.arange(n, dtype=np.int64)
+    for d in range(8):
+        a[:, 2 + d] = ((idx // 10 ** (7 - d)) % 10 + ord("0")).astype(np.uint8)
+    a[:, 10] = ord("\n")
+    a[:, lab:lab + L] = reads_u8.reshape(n, L)
+    a[:, lab + L] = ord("\n"); a[:, lab + L + 1] = ord("+"); a[:, lab + L + 2] = ord("\n")
+    a[:, lab + L + 3:lab + 2 * L + 3] = ord("I")
+    a[:, rec - 1] = ord("\n")
+    a.tofile(path)
+    return rec * n
+
+
+def run_e2e(torch, api, oi, index, device, d_seq, seq_lengths, seq_offsets, L, sub, indel, n_reads, cores):
+    """FASTQ file -> SAM file through urmapx_map_files (the command line's cmd_map) on the resident index: what a user of
+    `urmap -map` gets, index load excluded as the reference reports it.  Files live in /dev/shm (memory), so this is the
+    parse + PCIe + map + format + write pipeline, not a disk benchmark.  The first 100 k records are compared with the
+    SAM the oracle writes for the same reads."""
+    import shutil
+    import tempfile
+    base = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    d = tempfile.mkdtemp(prefix="urmap_e2e_", dir=base)
+    try:
+        reads = make_reads_torch(torch, 777, d_seq, seq_lengths, seq_offsets, n_reads, L, sub, indel, device).cpu().numpy()
+        fq, sam = os.path.join(d, "r.fq"), os.path.join(d, "out.sam")
+        fq_bytes = write_fastq_fixed(fq, reads, n_reads, L)
+        n_chk = min(n_reads, 100_000)
+        fq_head, sam_o = os.path.join(d, "head.fq"), os.path.join(d, "oracle.sam")
+        write_fastq_fixed(fq_head, reads[: n_chk * L], n_chk, L)
+        del reads
+        runs = []
+        for _ in range(2):  # the second run has its buffers and the page cache warm; both are reported
+            rep = api.map_files(index, fq, samout=sam, first_gpu=device.index, gpus=1, streams=2, cmdline="bench.py e2e")
+            runs.append(rep)
+        rep = runs[-1]
+        oi.map_file_se(fq_head, sam_o, threads=cores)
+        want = [l for l in open(sam_o, "rb").read().split(b"\n") if l and not l.startswith(b"@")]
+        got = []
+        with open(sam, "rb") as f:
+            for line in f:
+                if line.startswith(b"@"):
+                    continue
+                got.append(line.rstrip(b"\n"))
+                if len(got) == len(want):
+                    break
+        same = got == want
+        out = {"value": round(rep["reads"] / rep["seconds"], 1), "unit": "reads/s", "reads": int(rep["reads"]),
+               "seconds": round(rep["seconds"], 3), "first_run_seconds": round(runs[0]["seconds"], 3),
+               "what": f"urmapx_map_files (= urmap -map): {fq_bytes / 1e9:.2f} GB FASTQ file -> {os.path.getsize(sam) / 1e9:.2f} GB SAM file, both in /dev/shm; "
+                       f"index resident, {rep['host_threads']} host threads, {rep['lanes']} mapping contexts on one GPU",
+               "stage_busy_s": {k: round(rep[k], 3) for k in ("parse_s", "gpu_s", "format_s", "write_s")},
+               "mapped_q10_frac": round(rep["mapped_q"] / max(1, rep["reads"]), 4),
+               "sam_records_identical_to_oracle": bool(same), "sam_records_checked": len(want)}
+        return out
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def kernel_table(api, pe, L, nb, kms, counters, total_bp, gather_loads_s, stage_ms=None):
     """Per-launch roofline figures.  Algorithmic bytes per read from the reference algorithm's own access counts
     (SURVEY.md 8d), counted by the oracle on the sample: probe kernel 5 B per GetBlob + the read; search kernel 5 B per
@@ -652,6 +715,14 @@ def main():
                                 "cpu_port_reads_per_s": round(opar["reads_checked"] / ot, 1), "cpu_port_threads": cores,
                                 "sub": osub, "indel": oindel, "wall_s": round(time.time() - t0, 1)}
             out["other_workloads"] = others
+        if world == 1 and not pe and L == 150 and not args.no_e2e:
+            try:
+                del wl
+            except NameError:
+                pass
+            torch.cuda.empty_cache()
+            out["e2e"] = run_e2e(torch, api, oi, index, device, d_seq, seq_lengths, seq_offsets, L, args.sub, args.indel,
+                                 int(os.environ.get("URMAP_BENCH_E2E_READS", 4_000_000)), cores)
         print(json.dumps(out), flush=True)
     R.close()
 

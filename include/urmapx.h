@@ -222,6 +222,30 @@ int urmapx_ctx_get_pair_info(urmapx_ctx *, urmapx_pair_info *out, uint32_t npair
 size_t urmapx_tab_pe(const urmapx_index *, const urmapx_result *r1, const urmapx_result *r2, const urmapx_pair_info *info,
                      const char *label1, uint32_t len1, uint32_t len2, int sam_on, char *buf, size_t cap);
 
+/* ---- file to file: cmd_map / cmd_map2 (map.cpp:27-67, map2.cpp:39-90) as a library call ---- */
+typedef struct urmapx_map_options {
+	int first_gpu;      /* -gpu D */
+	int gpus;           /* -gpus N: devices D..D+N-1, one replica of the index on each; 0 = 1 */
+	int streams;        /* -streams K: mapping contexts per device (copies of one overlap kernels of another); 0 = 2 */
+	int host_threads;   /* -threads: FASTQ parsing and SAM formatting; 0 = min(16, hardware threads) */
+	uint32_t batch;     /* reads per batch; 0 = 262144 */
+	int veryfast;       /* -veryfast: State1 method 7 for -map, State2 method 5 for -map2 */
+	unsigned minq;      /* -minq (only -map2 reads it, map2.cpp:76) */
+	const char *cmdline; /* text after CL: in the @PG line (NULL: empty) */
+} urmapx_map_options;
+typedef struct urmapx_map_report {  /* State1::HitStats' counters (state1.cpp:593-632) and where the time went */
+	uint64_t reads, mapped_q, mapped_lowq, unmapped, unsupported;
+	double seconds;                                  /* first read parsed .. last SAM byte written (index load excluded) */
+	double parse_s, gpu_s, format_s, write_s;        /* busy seconds per stage (gpu: summed over the lanes) */
+	int host_threads, lanes;
+} urmapx_map_report;
+/* fastq2 NULL: single-end (-map); else the mates' file (-map2 ... -reverse).  samout / tabout may be NULL.  The index
+ * needs its host arrays, or to be resident on first_gpu already (then gpus must be 1).  Batch b is mapped on device
+ * b mod gpus; records are written in input order.  Returns URMAPX_E_UNSUPPORTED if reads fell outside the device
+ * domain (report->unsupported of them), URMAPX_E_FORMAT with the reference's message in err for malformed FASTQ. */
+int urmapx_map_files(urmapx_index *, const urmapx_map_options *, const char *fastq1, const char *fastq2, const char *samout,
+                     const char *tabout, urmapx_map_report *report, char *err, size_t errcap);
+
 /* ---- FASTQ input (host) ---- */
 /* Batch form of FASTQSeqSource::GetNextLo (fastqseqsource.cpp:9-116) over LineReader (linereader.cpp:14-113):
  * plain or .gz by suffix; '\r' dropped; a final unterminated line counts; blank lines only at end of file; the same

@@ -107,3 +107,25 @@ def test_bench_starts_its_own_two_ranks():
     assert d["value"] > 0 and d["scaling"] == "weak"
     import torch
     assert d["config"]["ranks"]["backend"] == ("nccl" if torch.cuda.device_count() >= 2 else "gloo")
+
+
+def test_map_files_library_call_on_a_resident_index(tmp_path):
+    """urmapx_map_files (the command line's cmd_map as a library call) on an index that is already resident: golden SAM,
+    the report's counters, and a FASTQ error coming back as a message instead of an exit."""
+    from urmap_amd import api
+    ufi = _golden_ufi(tmp_path)
+    idx = api.Index.open(ufi).upload(0)
+    out = os.path.join(tmp_path, "lib.sam")
+    rep = api.map_files(idx, os.path.join(GOLD, "se150.fq"), samout=out, batch=90, streams=2, cmdline="test")
+    assert _records(out) == [l for l in open(os.path.join(GOLD, "se150.sam"), "rb").read().split(b"\n") if l]
+    assert rep["reads"] == 400 and rep["mapped_q"] + rep["mapped_lowq"] + rep["unmapped"] == 400 and rep["lanes"] == 2
+    out2 = os.path.join(tmp_path, "lib2.sam")
+    rep2 = api.map_files(idx, os.path.join(GOLD, "pe150_1.fq"), os.path.join(GOLD, "pe150_2.fq"), samout=out2, batch=64)
+    assert _records(out2) == [l for l in open(os.path.join(GOLD, "pe150.sam"), "rb").read().split(b"\n") if l]
+    assert rep2["reads"] == 600
+    bad = os.path.join(tmp_path, "bad.fq")
+    open(bad, "w").write("@a\nACGT\n+\nII\n")
+    with pytest.raises(api.UrmapxError) as e:
+        api.map_files(idx, bad, samout=os.path.join(tmp_path, "x.sam"))
+    assert e.value.code == api.E_FORMAT
+    idx.close()

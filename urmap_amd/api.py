@@ -33,7 +33,7 @@ EXPORTS = (
     "urmapx_seed_probe", "urmapx_viterbi_batch", "urmapx_strerror", "urmapx_device_arch",
     "urmapx_make_ufi", "urmapx_build_slots", "urmapx_sam_se", "urmapx_sam_header_sq", "urmapx_ctx_phase_cycles", "urmapx_ctx_read_cycles", "urmapx_ctx_stage_ms", "urmapx_ctx_dp_stats", "urmapx_map_pe", "urmapx_sam_pe", "urmapx_map_pe_device", "urmapx_ctx_set_pe_veryfast",
     "urmapx_fastq_open", "urmapx_fastq_next", "urmapx_fastq_error", "urmapx_fastq_close",
-    "urmapx_ctx_gather_microbench", "urmapx_ctx_set_pair_info", "urmapx_ctx_get_pair_info", "urmapx_tab_pe",
+    "urmapx_ctx_gather_microbench", "urmapx_map_files", "urmapx_ctx_set_pair_info", "urmapx_ctx_get_pair_info", "urmapx_tab_pe",
 )
 
 
@@ -47,6 +47,17 @@ class Params(C.Structure):
         "mismatch_score", "gap_open_score", "gap_ext_score", "min_hsp_score_pct",
         "term_hsp_score_pct_phase3", "xdrop", "max_penalty", "xphase1", "xphase3", "xphase4")] + [
         ("band_radius", C.c_uint32)]
+
+
+class MapOptions(C.Structure):
+    _fields_ = [("first_gpu", C.c_int), ("gpus", C.c_int), ("streams", C.c_int), ("host_threads", C.c_int), ("batch", C.c_uint32),
+                ("veryfast", C.c_int), ("minq", C.c_uint), ("cmdline", C.c_char_p)]
+
+
+class MapReport(C.Structure):
+    _fields_ = [("reads", C.c_uint64), ("mapped_q", C.c_uint64), ("mapped_lowq", C.c_uint64), ("unmapped", C.c_uint64),
+                ("unsupported", C.c_uint64), ("seconds", C.c_double), ("parse_s", C.c_double), ("gpu_s", C.c_double),
+                ("format_s", C.c_double), ("write_s", C.c_double), ("host_threads", C.c_int), ("lanes", C.c_int)]
 
 
 class UrmapxError(RuntimeError):
@@ -120,6 +131,7 @@ def lib():
     L.urmapx_ctx_get_pair_info.argtypes = [vp, vp, u32]
     L.urmapx_tab_pe.restype = C.c_size_t
     L.urmapx_tab_pe.argtypes = [vp, vp, vp, vp, cp, u32, u32, i32, vp, C.c_size_t]
+    L.urmapx_map_files.argtypes = [vp, C.POINTER(MapOptions), cp, cp, cp, cp, C.POINTER(MapReport), cp, C.c_size_t]
     L.urmapx_fastq_open.argtypes = [cp, C.POINTER(vp)]
     L.urmapx_fastq_next.restype = C.c_int64
     L.urmapx_fastq_next.argtypes = [vp, u32] + [C.POINTER(vp)] * 5
@@ -294,6 +306,20 @@ class Index:
             self.close()
         except Exception:
             pass
+
+
+def map_files(index: "Index", fastq1, fastq2=None, samout=None, tabout=None, first_gpu=0, gpus=1, streams=2, host_threads=0,
+              batch=0, veryfast=False, minq=10, cmdline=None, allow_unsupported=False):
+    """urmap -map / -map2 file to file (cmd_map / cmd_map2) on an index that has its host arrays or is resident on
+    first_gpu.  -> dict of State1::HitStats' counters and stage times."""
+    o = MapOptions(first_gpu, gpus, streams, host_threads, batch, int(veryfast), minq, cmdline.encode() if cmdline else None)
+    rep = MapReport()
+    err = C.create_string_buffer(1024)
+    enc = lambda p: os.fsencode(p) if p else None
+    rc = lib().urmapx_map_files(index.h, C.byref(o), enc(fastq1), enc(fastq2), enc(samout), enc(tabout), C.byref(rep), err, len(err))
+    if rc != 0 and not (rc == E_UNSUPPORTED and allow_unsupported):
+        raise UrmapxError(rc, "urmapx_map_files: " + err.value.decode("latin-1"))
+    return {k: getattr(rep, k) for k, _ in MapReport._fields_}
 
 
 def decode_path(ops: np.ndarray) -> str:

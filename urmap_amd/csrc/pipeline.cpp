@@ -1,0 +1,416 @@
+// pipeline.cpp -- FASTQ file(s) -> SAM file through the mapping path: cmd_map / cmd_map2 (map.cpp:27-67, map2.cpp:39-90)
+// as a library call (urmapx_map_files), so that the command line and an embedding program with an index already resident
+// in HBM run the same code.
+//
+// One reader thread parses FASTQ into batches; batch b goes to mapping lane b mod (N*K), a host thread with its own
+// mapping context on GPU first_gpu + (b mod N) (N devices, each holding its own replica of the index; K contexts per
+// device so that one lane's copies overlap another's kernels); a writer thread takes the batches back in input order and
+// formats and writes their SAM with all host threads.  The reference fans reads over its OpenMP threads the same way
+// (map.cpp:58-61, seqsource.cpp:30-66) but writes in completion order; here records are written in input
+// order.  No data moves between devices.  The batch arrays that cross PCIe are page-locked once they have their size.
+#include <fcntl.h>
+#include <hip/hip_runtime_api.h>
+#include <omp.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/urmapx.h"
+#include "sam.h"
+
+using namespace urx;
+
+namespace {
+
+// Page-locks the storage of a PodVec for as long as it keeps its address (hipHostRegister); the vector tells the pin
+// before it reallocates or frees, and the next use registers the new storage.
+template <class T>
+struct Pin {
+	PodVec<T> *v = nullptr;
+	void *p = nullptr;
+	size_t n = 0;
+	static void on_free(void *ctx, void *) { static_cast<Pin *>(ctx)->drop(); }
+	void hold(PodVec<T> &vec) {
+		if (!v) { v = &vec; vec.set_pre_free(&Pin::on_free, this); }
+		void *q = vec.data();
+		const size_t bytes = vec.capacity() * sizeof(T);
+		if (q == p && bytes == n) return;
+		drop();
+		if (q && bytes && hipHostRegister(q, bytes, hipHostRegisterDefault) == hipSuccess) { p = q; n = bytes; }
+		else (void)hipGetLastError();
+	}
+	void drop() {
+		if (p) (void)hipHostUnregister(p);
+		p = nullptr; n = 0;
+	}
+	~Pin() {
+		drop();
+		if (v) v->set_pre_free(nullptr, nullptr);
+	}
+};
+
+struct Job {
+	FastqBatch reads;
+	PodVec<urmapx_result> results;
+	PodVec<urmapx_path_op> ops;
+	std::vector<urmapx_pair_info> info;  // -tabbedout
+	Pin<uint8_t> pin_bases;
+	Pin<uint64_t> pin_offs;
+	Pin<urmapx_result> pin_results;
+	Pin<urmapx_path_op> pin_ops;
+};
+
+template <class T>
+class Channel {  // bounded queue
+public:
+	explicit Channel(size_t cap) : cap_(cap) {}
+	void push(T v) {
+		std::unique_lock<std::mutex> l(m_);
+		cv_.wait(l, [&] { return q_.size() < cap_; });
+		q_.push_back(std::move(v));
+		cv_.notify_all();
+	}
+	bool pop(T &v) {
+		std::unique_lock<std::mutex> l(m_);
+		cv_.wait(l, [&] { return !q_.empty() || closed_; });
+		if (q_.empty()) return false;
+		v = std::move(q_.front());
+		q_.pop_front();
+		cv_.notify_all();
+		return true;
+	}
+	bool try_pop(T &v) {
+		std::lock_guard<std::mutex> l(m_);
+		if (q_.empty()) return false;
+		v = std::move(q_.front());
+		q_.pop_front();
+		cv_.notify_all();
+		return true;
+	}
+	void close() {
+		std::lock_guard<std::mutex> l(m_);
+		closed_ = true;
+		cv_.notify_all();
+	}
+
+private:
+	std::mutex m_;
+	std::condition_variable cv_;
+	std::deque<T> q_;
+	size_t cap_;
+	bool closed_ = false;
+};
+
+struct Failure {
+	std::atomic<bool> set{false};
+	std::mutex m;
+	int code = 0;
+	std::string msg;
+	void raise(int c, const std::string &s) {
+		std::lock_guard<std::mutex> l(m);
+		if (!set.load()) { code = c; msg = s; set.store(true); }
+	}
+};
+
+}  // namespace
+
+extern "C" int urmapx_map_files(urmapx_index *I, const urmapx_map_options *opt, const char *fastq1, const char *fastq2,
+                                const char *samout, const char *tabout, urmapx_map_report *report, char *err, size_t errcap) {
+	auto say = [&](const std::string &s) {
+		if (err && errcap) snprintf(err, errcap, "%s", s.c_str());
+	};
+	if (err && errcap) err[0] = 0;
+	if (!I || !opt || !fastq1) return URMAPX_E_ARG;
+	const bool paired = fastq2 != nullptr;
+	const int gpus = opt->gpus > 0 ? opt->gpus : 1, streams = opt->streams > 0 ? opt->streams : 2;
+	if (gpus > 64 || streams > 8) { say("gpus must be 1..64, streams 1..8"); return URMAPX_E_ARG; }
+	const uint32_t batch = opt->batch ? opt->batch : (1u << 18);
+	const unsigned minq = paired ? opt->minq : 10;  // only cmd_map2 reads -minq (map2.cpp:76); -map keeps State1::m_Minq = 10
+	// URMAPX_FORCE_DEVICE=d (test aid): every lane runs on physical device d, so that the N-device code path can be
+	// exercised on a machine with one GPU
+	const char *forced = getenv("URMAPX_FORCE_DEVICE");
+	auto phys = [&](int g) { return forced ? atoi(forced) : opt->first_gpu + g; };
+	urmapx_params P;
+	int rc = urmapx_params_for_method((opt->veryfast && !paired) ? 7 : 6, &P);  // -map2 always uses method 6 (map2.cpp:15-16)
+	if (rc) return rc;
+	// one replica of the index per device (uploaded concurrently), K mapping contexts on each
+	const int n_lanes = gpus * streams;
+	std::vector<urmapx_index *> replicas((size_t)gpus, nullptr);
+	std::vector<urmapx_ctx *> ctxs((size_t)n_lanes, nullptr);
+	auto release = [&]() {
+		for (urmapx_ctx *C : ctxs) urmapx_ctx_destroy(C);
+		for (int g = 1; g < gpus; ++g) urmapx_index_close(replicas[(size_t)g]);
+	};
+	{
+		std::vector<int> rcs((size_t)gpus, 0);
+		std::vector<std::thread> up;
+		for (int g = 0; g < gpus; ++g)
+			up.emplace_back([&, g] {
+				if (g == 0) { rcs[0] = urmapx_index_upload(I, phys(0)); replicas[0] = I; }
+				else rcs[(size_t)g] = urmapx_index_replicate(I, phys(g), &replicas[(size_t)g]);
+			});
+		for (auto &t : up) t.join();
+		for (int g = 0; g < gpus; ++g)
+			if (rcs[(size_t)g]) { say(std::string("Uploading index to the GPU: ") + urmapx_strerror(rcs[(size_t)g])); release(); return rcs[(size_t)g]; }
+	}
+	for (int l = 0; l < n_lanes; ++l) {
+		rc = urmapx_ctx_create(replicas[(size_t)(l % gpus)], phys(l % gpus), &P, &ctxs[(size_t)l]);
+		if (!rc && paired && opt->veryfast) rc = urmapx_ctx_set_pe_veryfast(ctxs[(size_t)l], 1);
+		if (!rc && paired && tabout) rc = urmapx_ctx_set_pair_info(ctxs[(size_t)l], 1);
+		if (rc) { say(std::string("Creating mapping context: ") + urmapx_strerror(rc)); release(); return rc; }
+	}
+	// host threads for FASTQ parsing and SAM formatting (the mapping itself runs on the GPU)
+	const int host_threads = opt->host_threads > 0 ? opt->host_threads : std::min(16, std::max(1, (int)std::thread::hardware_concurrency()));
+	omp_set_num_threads(host_threads);
+	int fsam = -1;
+	uint64_t sam_off = 0;
+	Failure fail;
+	if (samout) {
+		fsam = open(samout, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+		if (fsam < 0) { say(std::string("Cannot create ") + samout); release(); return URMAPX_E_IO; }
+		std::string hdr;
+		append_sam_header_text(hdr, I, opt->cmdline);
+		if (write(fsam, hdr.data(), hdr.size()) != (ssize_t)hdr.size()) { say(std::string("Cannot write ") + samout); close(fsam); release(); return URMAPX_E_IO; }
+		sam_off = hdr.size();
+	}
+	// -tabbedout (outfiles.cpp:7-12): State2::OutputTab2's line per pair; only -map2 writes it
+	FILE *ftab = nullptr;
+	if (tabout) {
+		ftab = fopen(tabout, "wb");
+		if (!ftab) { say(std::string("Cannot create ") + tabout); if (fsam >= 0) close(fsam); release(); return URMAPX_E_IO; }
+	}
+	FastqReader rd, rd2;
+	{
+		std::string e;
+		if (!rd.open(fastq1, e) || (paired && !rd2.open(fastq2, e))) {
+			say(e);
+			if (fsam >= 0) close(fsam);
+			if (ftab) fclose(ftab);
+			release();
+			return URMAPX_E_IO;
+		}
+	}
+	const auto t1 = std::chrono::steady_clock::now();
+
+	// batch b travels through parsed[b mod lanes] -> lane thread -> mapped[b mod lanes]; the writer visits the lanes in the
+	// same round-robin order, so batches come back in input order without a reorder buffer
+	using JobChannel = Channel<std::unique_ptr<Job>>;
+	std::vector<std::unique_ptr<JobChannel>> parsed, mapped;
+	for (int l = 0; l < n_lanes; ++l) {
+		parsed.emplace_back(new JobChannel(2));
+		mapped.emplace_back(new JobChannel(1));
+	}
+	JobChannel recycled((size_t)(8 + 6 * n_lanes));  // finished jobs go back to the reader: their arrays are reused
+	double t_parse = 0, t_gpu = 0, t_format = 0, t_write = 0;  // busy seconds per stage
+	auto now = [] { return std::chrono::steady_clock::now(); };
+	auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+	// -map2: the second file is parsed by its own thread while the reader parses the first
+	struct Side { FastqBatch b; std::string e; bool more = false; } side2;
+	Channel<int> go2(1), done2(1);
+	std::thread reader2;
+	if (paired)
+		reader2 = std::thread([&] {
+			omp_set_num_threads(std::max(1, host_threads / 2));  // a new thread starts from the default team size, not main's
+			int x;
+			while (go2.pop(x)) {
+				side2.b.clear();
+				side2.e.clear();
+				side2.more = rd2.next_batch(side2.b, batch / 2, side2.e);
+				done2.push(1);
+			}
+		});
+	std::thread reader([&] {
+		omp_set_num_threads(paired ? std::max(1, host_threads - host_threads / 2) : host_threads);
+		FastqBatch a;
+		for (size_t b = 0; !fail.set.load(); ++b) {
+			std::unique_ptr<Job> j;
+			if (!recycled.try_pop(j)) j = std::make_unique<Job>();
+			j->reads.clear();
+			std::string e;
+			bool more;
+			const auto tp0 = now();
+			if (!paired)
+				more = rd.next_batch(j->reads, batch, e);
+			else {  // mates interleaved: reads 2i, 2i+1 (map2.cpp:27-32 reads one record from each file under one lock)
+				go2.push(1);
+				a.clear();
+				more = rd.next_batch(a, batch / 2, e);
+				int x;
+				done2.pop(x);
+				const FastqBatch &bb = side2.b;
+				if (e.empty()) e = side2.e;
+				if (e.empty() && (more != side2.more || a.size() != bb.size())) e = std::string("Premature end of file in FASTQ") + (a.size() > bb.size() ? "2" : "1");
+				if (e.empty()) {
+					omp_set_num_threads(host_threads);
+					interleave_batches(a, bb, j->reads);
+					omp_set_num_threads(std::max(1, host_threads - host_threads / 2));
+				}
+			}
+			t_parse += secs(tp0, now());
+			if (!e.empty()) { fail.raise(URMAPX_E_FORMAT, e); break; }
+			if (!more) break;
+			parsed[b % (size_t)n_lanes]->push(std::move(j));
+		}
+		for (auto &c : parsed) c->close();
+		go2.close();
+	});
+	unsigned long long n_reads = 0, n_accept = 0, n_reject = 0, n_nohit = 0, n_unsupported = 0;
+	std::thread writer([&] {
+		omp_set_num_threads(host_threads);
+		// SAM text of a batch is formatted by all host threads, each on a contiguous range of reads (pairs), and the
+		// pieces are written at their file offsets in input order.
+		std::unique_ptr<Job> j;
+		std::vector<std::string> outs((size_t)host_threads);
+		struct Cnt { unsigned long long accept = 0, reject = 0, nohit = 0, unsupported = 0; };
+		for (size_t b = 0; mapped[b % (size_t)n_lanes]->pop(j); ++b) {
+			if (fail.set.load()) { recycled.push(std::move(j)); continue; }
+			const uint32_t n = j->reads.size();
+			const uint32_t units = paired ? n / 2 : n;
+			std::vector<Cnt> cnt((size_t)host_threads);
+			const auto tf0 = now();
+#pragma omp parallel for schedule(static, 1) num_threads(host_threads)
+			for (int t = 0; t < host_threads; ++t) {
+				std::string &out = outs[(size_t)t];
+				out.clear();
+				Cnt &c = cnt[(size_t)t];
+				const uint32_t u0 = (uint32_t)((uint64_t)units * (uint64_t)t / (uint64_t)host_threads);
+				const uint32_t u1 = (uint32_t)((uint64_t)units * (uint64_t)(t + 1) / (uint64_t)host_threads);
+				std::vector<char> pbuf;
+				for (uint32_t i = paired ? 2 * u0 : u0; i < (paired ? 2 * u1 : u1); ++i) {
+					const urmapx_result &r = j->results[i];
+					const uint64_t off = j->reads.offs[i];
+					const unsigned L = (unsigned)(j->reads.offs[i + 1] - off);
+					if (fsam >= 0 && !paired)
+						append_sam_record(out, I, r, j->ops.data(), 0, "*", 0xFFFFFFFFu, 0, j->reads.label(i),
+						                  j->reads.bases.data() + off, j->reads.quals.data() + off, L);
+					if (fsam >= 0 && paired && (i & 1) == 0) {
+						const uint64_t off2 = j->reads.offs[i + 1];
+						const unsigned L2 = (unsigned)(j->reads.offs[i + 2] - off2);
+						pbuf.resize(strlen(j->reads.label(i)) + strlen(j->reads.label(i + 1)) + 3 * (size_t)(L + L2) + 2048);
+						size_t k = urmapx_sam_pe(I, &j->results[i], &j->results[i + 1], j->ops.data(), j->reads.label(i),
+						                         j->reads.bases.data() + off, j->reads.quals.data() + off, L,
+						                         j->reads.label(i + 1), j->reads.bases.data() + off2,
+						                         j->reads.quals.data() + off2, L2, pbuf.data(), pbuf.size());
+						out.append(pbuf.data(), k);
+					}
+					// HitStats counters (output1.cpp:20-30)
+					if (r.status) ++c.unsupported;
+					if (r.dbpos == 0xFFFFFFFFu) ++c.nohit;
+					else if (r.mapq >= minq) ++c.accept;
+					else ++c.reject;
+				}
+			}
+			for (const Cnt &c : cnt) { n_accept += c.accept; n_reject += c.reject; n_nohit += c.nohit; n_unsupported += c.unsupported; }
+			n_reads += n;
+			const auto tf1 = now();
+			t_format += secs(tf0, tf1);
+			if (fsam >= 0) {
+				std::vector<uint64_t> at((size_t)host_threads + 1);
+				at[0] = sam_off;
+				for (int t = 0; t < host_threads; ++t) at[(size_t)t + 1] = at[(size_t)t] + outs[(size_t)t].size();
+				sam_off = at[(size_t)host_threads];
+#pragma omp parallel for schedule(static, 1) num_threads(host_threads)
+				for (int t = 0; t < host_threads; ++t) {
+					const std::string &out = outs[(size_t)t];
+					size_t done = 0;
+					while (done < out.size()) {
+						ssize_t w = pwrite(fsam, out.data() + done, out.size() - done, (off_t)(at[(size_t)t] + done));
+						if (w <= 0) { fail.raise(URMAPX_E_IO, std::string("Error writing ") + samout); break; }
+						done += (size_t)w;
+					}
+				}
+			}
+			if (ftab && paired) {  // tab lines: formatted by all host threads (pair ranges), written in order
+				std::vector<std::string> tabs((size_t)host_threads);
+#pragma omp parallel for schedule(static, 1) num_threads(host_threads)
+				for (int t = 0; t < host_threads; ++t) {
+					const uint32_t u0 = (uint32_t)((uint64_t)units * (uint64_t)t / (uint64_t)host_threads);
+					const uint32_t u1 = (uint32_t)((uint64_t)units * (uint64_t)(t + 1) / (uint64_t)host_threads);
+					char line[4096];
+					for (uint32_t u = u0; u < u1; ++u) {
+						const uint32_t i = 2 * u;
+						const unsigned L1 = (unsigned)(j->reads.offs[i + 1] - j->reads.offs[i]), L2 = (unsigned)(j->reads.offs[i + 2] - j->reads.offs[i + 1]);
+						const size_t k = urmapx_tab_pe(I, &j->results[i], &j->results[i + 1], &j->info[u], j->reads.label(i), L1, L2,
+						                               fsam >= 0 ? 1 : 0, line, sizeof line);
+						tabs[(size_t)t].append(line, k);
+					}
+				}
+				for (const std::string &tb : tabs)
+					if (fwrite(tb.data(), 1, tb.size(), ftab) != tb.size()) fail.raise(URMAPX_E_IO, std::string("Error writing ") + tabout);
+			}
+			t_write += secs(tf1, now());
+			recycled.push(std::move(j));
+		}
+	});
+	std::mutex gpu_time_lock;
+	std::vector<std::thread> lanes;
+	for (int l = 0; l < n_lanes; ++l)
+		lanes.emplace_back([&, l] {
+			urmapx_ctx *C = ctxs[(size_t)l];
+			(void)hipSetDevice(phys(l % gpus));
+			std::unique_ptr<Job> j;
+			while (parsed[(size_t)l]->pop(j)) {
+				const uint32_t n = j->reads.size();
+				if (!fail.set.load()) {
+					j->results.resize(n);
+					j->ops.resize((size_t)n * URMAPX_MAX_PATH_OPS);
+					// page-lock what crosses PCIe (the arrays are recycled, so this happens once per job object and size)
+					if (!getenv("URMAPX_NO_PIN")) {
+						j->pin_bases.hold(j->reads.bases);
+						j->pin_offs.hold(j->reads.offs);
+						j->pin_results.hold(j->results);
+						j->pin_ops.hold(j->ops);
+					}
+					size_t used = 0;
+					const auto tg0 = now();
+					int mrc = paired ? urmapx_map_pe(C, j->reads.bases.data(), j->reads.offs.data(), n / 2, j->results.data(), j->ops.data(),
+					                                 j->ops.size(), &used)
+					                 : urmapx_map_se(C, j->reads.bases.data(), j->reads.offs.data(), n, j->results.data(), j->ops.data(),
+					                                 j->ops.size(), &used);
+					if (mrc != URMAPX_OK && mrc != URMAPX_E_UNSUPPORTED)
+						fail.raise(mrc, std::string(paired ? "urmapx_map_pe: " : "urmapx_map_se: ") + urmapx_strerror(mrc));
+					else if (paired && ftab) {
+						j->info.resize(n / 2);
+						mrc = urmapx_ctx_get_pair_info(C, j->info.data(), n / 2);
+						if (mrc) fail.raise(mrc, std::string("urmapx_ctx_get_pair_info: ") + urmapx_strerror(mrc));
+					}
+					std::lock_guard<std::mutex> g(gpu_time_lock);
+					t_gpu += secs(tg0, now());
+				}
+				mapped[(size_t)l]->push(std::move(j));
+			}
+			mapped[(size_t)l]->close();
+		});
+	for (auto &t : lanes) t.join();
+	reader.join();
+	if (reader2.joinable()) reader2.join();
+	writer.join();
+	{  // page-locked arrays are released before their contexts go
+		std::unique_ptr<Job> j;
+		while (recycled.try_pop(j)) j.reset();
+	}
+	if (fsam >= 0) close(fsam);
+	if (ftab) fclose(ftab);
+	const auto t2 = std::chrono::steady_clock::now();
+	release();
+	if (report) {
+		report->reads = n_reads; report->mapped_q = n_accept; report->mapped_lowq = n_reject; report->unmapped = n_nohit;
+		report->unsupported = n_unsupported;
+		report->seconds = secs(t1, t2); report->parse_s = t_parse; report->gpu_s = t_gpu; report->format_s = t_format; report->write_s = t_write;
+		report->host_threads = host_threads; report->lanes = n_lanes;
+	}
+	if (fail.set.load()) { say(fail.msg); return fail.code; }
+	return n_unsupported ? URMAPX_E_UNSUPPORTED : URMAPX_OK;
+}

@@ -478,6 +478,12 @@ void append_sam_record(std::string &out, const urmapx_index *I, const urmapx_res
 }
 
 void append_sam_header(std::string &out, const urmapx_index *I, int argc, char **argv) {
+	std::string cl;
+	for (int i = 0; i < argc; ++i) { cl += argv[i]; cl.push_back(' '); }  // argv joined with trailing spaces (state1.cpp:749-751)
+	append_sam_header_text(out, I, cl.c_str());
+}
+
+void append_sam_header_text(std::string &out, const urmapx_index *I, const char *cmdline) {
 	const uint32_t n = urmapx_index_seq_count(I);
 	for (uint32_t i = 0; i < n; ++i) {
 		out += "@SQ\tSN:";
@@ -487,7 +493,7 @@ void append_sam_header(std::string &out, const urmapx_index *I, int argc, char *
 		out.push_back('\n');
 	}
 	out += "@PG\tID:urmap\tPN:urmap\tVN:1.0.mi355x\tCL:";
-	for (int i = 0; i < argc; ++i) { out += argv[i]; out.push_back(' '); }
+	if (cmdline) out += cmdline;
 	out.push_back('\n');
 }
 

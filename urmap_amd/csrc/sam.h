@@ -21,7 +21,13 @@ public:
 	PodVec() = default;
 	PodVec(const PodVec &) = delete;
 	PodVec &operator=(const PodVec &) = delete;
-	~PodVec() { free(p_); }
+	~PodVec() {
+		if (pre_free_ && p_) pre_free_(pre_free_ctx_, p_);
+		free(p_);
+	}
+	size_t capacity() const { return cap_; }
+	// called with the current storage before it is reallocated or freed (a page-locked array is unregistered first)
+	void set_pre_free(void (*fn)(void *ctx, void *ptr), void *ctx) { pre_free_ = fn; pre_free_ctx_ = ctx; }
 	T *data() { return p_; }
 	const T *data() const { return p_; }
 	size_t size() const { return n_; }
@@ -33,6 +39,7 @@ public:
 		if (n > cap_) {
 			size_t c = cap_ ? cap_ : 1024;
 			while (c < n) c *= 2;
+			if (pre_free_ && p_) pre_free_(pre_free_ctx_, p_);
 			T *q = (T *)realloc(p_, c * sizeof(T));
 			if (!q) throw std::bad_alloc();
 			p_ = q; cap_ = c;
@@ -43,6 +50,8 @@ public:
 private:
 	T *p_ = nullptr;
 	size_t n_ = 0, cap_ = 0;
+	void (*pre_free_)(void *, void *) = nullptr;
+	void *pre_free_ctx_ = nullptr;
 };
 
 struct FastqBatch {
@@ -93,5 +102,6 @@ void append_sam_record(std::string &out, const urmapx_index *I, const urmapx_res
 
 // @SQ lines + @PG (State1::WriteSAMHeader, state1.cpp:736-752)
 void append_sam_header(std::string &out, const urmapx_index *I, int argc, char **argv);
+void append_sam_header_text(std::string &out, const urmapx_index *I, const char *cmdline);
 
 }  // namespace urx
