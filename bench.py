@@ -336,7 +336,12 @@ def place_index(R, torch, api, device, d_seq, slots, seq_lengths, seq_offsets, l
             how = "cached table"
         else:
             seq_np = d_seq.cpu().numpy()
-            blob_np = api.build_slots(seq_np, slots)
+            if os.environ.get("URMAP_BENCH_HOST_BUILD"):
+                blob_np = api.build_slots(seq_np, slots)
+            else:  # the product's -make_ufi: counting passes, heads and overflow list on the GPU, ordered inserts on the host
+                how = "-make_ufi (GPU passes + ordered inserts on the host) + upload"
+                torch.cuda.synchronize()
+                blob_np = api.build_slots_gpu(R.device_index, slots, d_seq_ptr=d_seq.data_ptr(), size=size)
             if cpre:
                 os.makedirs(cache, exist_ok=True)
                 np.save(cpre + "_seq.npy", seq_np)
@@ -387,7 +392,7 @@ def place_index(R, torch, api, device, d_seq, slots, seq_lengths, seq_offsets, l
                     os.remove(shm + suf)
                 except OSError:
                     pass
-    return index, blob_np, seq_np, d_seq, {"make_ufi_host": round(t_build, 1), "upload": round(time.time() - t0, 1), "how": how}
+    return index, blob_np, seq_np, d_seq, {"make_ufi": round(t_build, 1), "upload": round(time.time() - t0, 1), "how": how}
 
 
 class Workload:

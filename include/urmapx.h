@@ -190,6 +190,14 @@ int urmapx_make_ufi(const char *fasta_path, const char *ufi_path, uint32_t word_
 int urmapx_build_slots(const uint8_t *seqdata, uint32_t seqdata_size, uint32_t word_length, uint32_t max_ix,
                        uint64_t slots, uint8_t *blob, uint32_t *truncated_out);
 
+/* The same two with the data-parallel passes on the GPU (both strands' per-slot counts, ufindex.cpp:338-408; the first
+ * indexed position of every slot; the head slots; the remaining positions as a list in genome order) and only the
+ * order-dependent inserts (UpdateSlot / FindFreeSlot, ufindex.cpp:194-322,987-1000) on the host.  Byte-identical output.
+ * d_seqdata: the sequence store already resident on `device`, or NULL (then the host array seqdata is uploaded). */
+int urmapx_make_ufi_gpu(int device, const char *fasta_path, const char *ufi_path, uint32_t word_length, uint32_t max_ix, uint64_t slots);
+int urmapx_build_slots_gpu(int device, const uint8_t *seqdata, const void *d_seqdata, uint32_t seqdata_size, uint32_t word_length,
+                           uint32_t max_ix, uint64_t slots, uint8_t *blob, uint32_t *truncated_out);
+
 /* ---- host-side text (no device involved) ---- */
 /* One SAM record of a single-end read: State1::SetSAM / SetSAM_Unmapped (setsam.cpp:12-207) with Flags = 0 as
  * State1::Output1 passes (output1.cpp:13), CIGAR per state1.cpp:707-734 + cigar.cpp.  path_ops = the batch arena.

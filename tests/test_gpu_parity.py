@@ -692,3 +692,52 @@ def test_pe_hsp_overflow_list_matches_oracle(tmp_path):
                            stderr=subprocess.PIPE, timeout=300, env=env)
         assert r.returncode == 0, r.stderr.decode()[-2000:]
         assert ol.sam_records(out) == ol.sam_records(osam), f"LDS cap {cap}"
+
+
+@pytest.mark.parametrize("name", ["g", "r"])
+def test_make_ufi_gpu_reproduces_reference_index(tmp_path, name):
+    """-make_ufi with the counting passes, head slots and overflow list made on the GPU (make_ufi_gpu.hip) and only the
+    order-dependent inserts on the host: the .ufi the reference binary wrote (tests/golden), byte for byte -- through the
+    library and through the command line (default slot count = the reference's GetPrime ladder)."""
+    import gzip
+    import os
+    import subprocess
+    import oracle_lib as ol
+    from urmap_amd import api
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gold = os.path.join(root, "tests", "golden")
+    want = gzip.open(os.path.join(gold, name + ".ufi.gz"), "rb").read()
+    ref = os.path.join(tmp_path, "ref.ufi")
+    open(ref, "wb").write(want)
+    w, maxix, _, slots = ol.ufi_header(ref)
+    out = os.path.join(tmp_path, "gpu.ufi")
+    api.make_ufi_gpu(0, os.path.join(gold, name + ".fa"), out, slots, word_length=w, max_ix=maxix)
+    assert open(out, "rb").read() == want
+    if name == "g":
+        out2 = os.path.join(tmp_path, "cli.ufi")
+        r = subprocess.run([os.path.join(root, "urmap_amd", "urmap"), "-make_ufi", os.path.join(gold, "g.fa"), "-output", out2],
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        assert r.returncode == 0 and b"building on the host" not in r.stderr, r.stderr.decode()[-1000:]
+        assert open(out2, "rb").read() == want
+
+
+@pytest.mark.parametrize("load,maxix", [(0.6, 32), (0.95, 32), (1.0, 32), (0.8, 3)])
+def test_make_ufi_gpu_matches_oracle_on_dense_tables(tmp_path, load, maxix):
+    """Slot tables at load factors up to 1.0 (long links, truncated chains) and with -veryfast's MaxIx 3, lower-case and N
+    runs in the FASTA: GPU-assisted build == the oracle's MakeIndex restatement (itself checked against the reference)."""
+    import os
+    import oracle_lib as ol
+    from urmap_amd import api, synth
+    g = synth.make_genome(int(load * 100) + maxix, [260000, 90000, 5000], repeat_frac=0.3, n_families=5, n_run_frac=0.01)
+    fa = os.path.join(tmp_path, "g.fa")
+    synth.write_fasta(fa, g, lowercase_frac=0.1)
+    slots = int(355000 / load) | 1
+    oi = ol.Index.build(fa, slots, max_ix=maxix)
+    want = os.path.join(tmp_path, "o.ufi")
+    oi.save(want)
+    out = os.path.join(tmp_path, "gpu.ufi")
+    api.make_ufi_gpu(0, fa, out, slots, max_ix=maxix)
+    assert open(out, "rb").read() == open(want, "rb").read()
+    # the array form (bench.py passes the sequence store resident on the device instead of a host array)
+    blob = api.build_slots_gpu(0, slots, seqdata=oi.seqdata().copy(), max_ix=maxix)
+    assert bytes(blob[:5 * slots]) == bytes(oi.blob())

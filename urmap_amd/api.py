@@ -31,7 +31,7 @@ EXPORTS = (
     "urmapx_index_seq_length", "urmapx_index_seq_offset", "urmapx_ctx_create", "urmapx_ctx_destroy",
     "urmapx_map_se", "urmapx_map_se_device", "urmapx_ctx_sync", "urmapx_ctx_last_kernel_ms",
     "urmapx_seed_probe", "urmapx_viterbi_batch", "urmapx_strerror", "urmapx_device_arch",
-    "urmapx_make_ufi", "urmapx_build_slots", "urmapx_sam_se", "urmapx_sam_header_sq", "urmapx_ctx_phase_cycles", "urmapx_ctx_read_cycles", "urmapx_ctx_stage_ms", "urmapx_ctx_dp_stats", "urmapx_map_pe", "urmapx_sam_pe", "urmapx_map_pe_device", "urmapx_ctx_set_pe_veryfast",
+    "urmapx_make_ufi", "urmapx_build_slots", "urmapx_make_ufi_gpu", "urmapx_build_slots_gpu", "urmapx_sam_se", "urmapx_sam_header_sq", "urmapx_ctx_phase_cycles", "urmapx_ctx_read_cycles", "urmapx_ctx_stage_ms", "urmapx_ctx_dp_stats", "urmapx_map_pe", "urmapx_sam_pe", "urmapx_map_pe_device", "urmapx_ctx_set_pe_veryfast",
     "urmapx_fastq_open", "urmapx_fastq_next", "urmapx_fastq_error", "urmapx_fastq_close",
     "urmapx_ctx_gather_microbench", "urmapx_map_files", "urmapx_ctx_set_pair_info", "urmapx_ctx_get_pair_info", "urmapx_tab_pe",
 )
@@ -118,6 +118,8 @@ def lib():
     L.urmapx_viterbi_batch.argtypes = [vp, vp, vp, vp, vp, vp, u32, vp, vp, vp, vp]
     L.urmapx_make_ufi.argtypes = [cp, cp, u32, u32, u64]
     L.urmapx_build_slots.argtypes = [vp, u32, u32, u32, u64, vp, C.POINTER(u32)]
+    L.urmapx_make_ufi_gpu.argtypes = [i32, cp, cp, u32, u32, u64]
+    L.urmapx_build_slots_gpu.argtypes = [i32, vp, vp, u32, u32, u32, u64, vp, C.POINTER(u32)]
     L.urmapx_sam_se.restype = C.c_size_t
     L.urmapx_sam_se.argtypes = [vp, vp, vp, cp, vp, vp, u32, vp, C.c_size_t]
     L.urmapx_sam_header_sq.restype = C.c_size_t
@@ -173,6 +175,25 @@ def build_slots(seqdata: np.ndarray, slots, word_length=24, max_ix=32) -> np.nda
     trunc = C.c_uint32(0)
     _check(lib().urmapx_build_slots(seqdata.ctypes.data, len(seqdata), word_length, max_ix, slots, blob.ctypes.data,
                                     C.byref(trunc)), "urmapx_build_slots")
+    return blob
+
+
+def make_ufi_gpu(device, fasta, ufi, slots, word_length=24, max_ix=32):
+    """-make_ufi with the counting passes, head slots and overflow list made on the GPU; byte-identical output."""
+    _check(lib().urmapx_make_ufi_gpu(device, os.fsencode(fasta), os.fsencode(ufi), word_length, max_ix, slots), "urmapx_make_ufi_gpu")
+
+
+def build_slots_gpu(device, slots, seqdata: np.ndarray | None = None, d_seq_ptr=None, size=None, word_length=24, max_ix=32) -> np.ndarray:
+    """UFIndex::MakeIndex -> 5*slots byte slot table; the sequence store comes from a host array or is resident on
+    `device` already (d_seq_ptr, size)."""
+    blob = np.empty(5 * slots + 8, dtype=np.uint8)
+    blob[5 * slots:] = 0
+    trunc = C.c_uint32(0)
+    if seqdata is not None:
+        seqdata = np.ascontiguousarray(seqdata, dtype=np.uint8)
+        size = len(seqdata)
+    _check(lib().urmapx_build_slots_gpu(device, seqdata.ctypes.data if seqdata is not None else None, d_seq_ptr, size, word_length,
+                                        max_ix, slots, blob.ctypes.data, C.byref(trunc)), "urmapx_build_slots_gpu")
     return blob
 
 

@@ -151,6 +151,57 @@ bool load_fasta(const char *path, std::vector<std::string> &labels, std::vector<
 
 }  // namespace
 
+// UpdateSlot for every position that is not the first indexed occurrence of its slot, in genome order (ufindex.cpp:
+// 107-148,194-322): order dependent, so one after the other.  What each insert will touch can be guessed ahead of time:
+// read-only "walkers" follow the chain of the items 16..64 places ahead, one link per visit, prefetching the next
+// link and finally the lines FindFreeSlot will scan after the chain's end.  Walkers may see a slightly stale
+// table; they only warm the cache, so the result is unaffected.
+static void insert_overflow_in_order(Table &T, const uint64_t *oslot, const uint32_t *opos, size_t novf) {
+	uint8_t *const blob = T.blob;
+	struct Walker { uint64_t slot; int phase; };
+	Walker ring[128];
+	for (auto &w : ring) w = Walker{0, 1};
+	auto wstep = [&](size_t j) {
+		Walker &w = ring[j & 127];
+		if (w.phase != 0) return;
+		uint64_t nxt = w.slot;
+		if (T.advance(nxt)) {
+			w.slot = nxt;
+			__builtin_prefetch(blob + 5 * nxt, 0);
+		} else {
+			w.phase = 1;
+			const uint64_t c = T.wrap(w.slot, 1);
+			__builtin_prefetch(&T.nplus[c], 0);
+			__builtin_prefetch(&T.nplus[c] + 64, 0);
+			__builtin_prefetch(blob + 5 * c, 1);
+			__builtin_prefetch(blob + 5 * c + 64, 1);
+			__builtin_prefetch(blob + 5 * c + 128, 1);
+		}
+	};
+	for (size_t i = 0; i < novf; ++i) {
+		if (i + 128 < novf) __builtin_prefetch(blob + 5 * oslot[i + 128], 0);
+		if (i + 64 < novf) { ring[(i + 64) & 127] = Walker{oslot[i + 64], 0}; wstep(i + 64); }
+		if (i + 48 < novf) wstep(i + 48);
+		if (i + 32 < novf) wstep(i + 32);
+		if (i + 16 < novf) wstep(i + 16);
+		T.insert(oslot[i], opos[i]);
+	}
+}
+
+// The order-dependent tail of the GPU-assisted builder (make_ufi_gpu.hip): blob holds the head slots, nplus the
+// plus-strand counts (saturated at 255), (oslot, opos) the overflow positions in genome order.
+int urx_finish_slots_host(uint8_t *blob, uint64_t slots, uint32_t max_ix, uint8_t *nplus, const uint64_t *oslot,
+                          const uint32_t *opos, size_t novf, uint32_t *truncated_out) {
+	Table T;
+	T.blob = blob; T.N = slots; T.maxIx = max_ix; T.nplus = nplus;
+	insert_overflow_in_order(T, oslot, opos, novf);
+	if (truncated_out) *truncated_out = T.truncated;
+	return URMAPX_OK;
+}
+
+namespace {
+}  // namespace
+
 // Builds the slot table for an already concatenated, upper-cased sequence store.  blob must hold 5*slots bytes.
 extern "C" int urmapx_build_slots(const uint8_t *seqdata, uint32_t size, uint32_t W, uint32_t max_ix, uint64_t slots,
                                   uint8_t *blob, uint32_t *truncated_out) {
@@ -278,37 +329,13 @@ extern "C" int urmapx_build_slots(const uint8_t *seqdata, uint32_t size, uint32_
 		std::vector<Ovf>().swap(ovf[(size_t)ch]);
 	}
 	lap("flatten overflow list");
-	// The inserts themselves must run one after the other, but what each will touch can be guessed ahead of time:
-	// read-only "walkers" follow the chain of the items 16..64 places ahead, one link per visit, prefetching the next
-	// link and finally the lines FindFreeSlot will scan after the chain's end.  Walkers may see a slightly stale
-	// table; they only warm the cache, so the result is unaffected.
-	struct Walker { uint64_t slot; int phase; };
-	Walker ring[128];
-	for (auto &w : ring) w = Walker{0, 1};
-	auto wstep = [&](size_t j) {
-		Walker &w = ring[j & 127];
-		if (w.phase != 0) return;
-		uint64_t nxt = w.slot;
-		if (T.advance(nxt)) {
-			w.slot = nxt;
-			__builtin_prefetch(blob + 5 * nxt, 0);
-		} else {
-			w.phase = 1;
-			const uint64_t c = T.wrap(w.slot, 1);
-			__builtin_prefetch(&T.nplus[c], 0);
-			__builtin_prefetch(&T.nplus[c] + 64, 0);
-			__builtin_prefetch(blob + 5 * c, 1);
-			__builtin_prefetch(blob + 5 * c + 64, 1);
-			__builtin_prefetch(blob + 5 * c + 128, 1);
-		}
-	};
-	for (size_t i = 0; i < novf; ++i) {
-		if (i + 128 < novf) __builtin_prefetch(blob + 5 * items[i + 128].slot, 0);
-		if (i + 64 < novf) { ring[(i + 64) & 127] = Walker{items[i + 64].slot, 0}; wstep(i + 64); }
-		if (i + 48 < novf) wstep(i + 48);
-		if (i + 32 < novf) wstep(i + 32);
-		if (i + 16 < novf) wstep(i + 16);
-		T.insert(items[i].slot, items[i].pos);
+	{
+		std::vector<uint64_t> oslot(novf);
+		std::vector<uint32_t> opos(novf);
+#pragma omp parallel for schedule(static)
+		for (int64_t i = 0; i < (int64_t)novf; ++i) { oslot[(size_t)i] = items[(size_t)i].slot; opos[(size_t)i] = items[(size_t)i].pos; }
+		std::vector<Ovf>().swap(items);
+		insert_overflow_in_order(T, oslot.data(), opos.data(), novf);
 	}
 	lap("sequential overflow inserts");
 	if (verbose) fprintf(stderr, "[make_ufi] %zu overflow positions, %u truncated\n", novf, T.truncated);
@@ -318,8 +345,20 @@ extern "C" int urmapx_build_slots(const uint8_t *seqdata, uint32_t size, uint32_
 	return URMAPX_OK;
 }
 
+extern "C" int urmapx_build_slots_gpu(int device, const uint8_t *seqdata, const void *d_seqdata, uint32_t size, uint32_t W,
+                                      uint32_t max_ix, uint64_t slots, uint8_t *blob, uint32_t *truncated_out);
+static int make_ufi_impl(const char *fasta_path, const char *ufi_path, uint32_t W, uint32_t max_ix, uint64_t slots, int device);
+
 // -make_ufi FASTA -output UFI [-wordlength W] [-maxix N] -slots S
 extern "C" int urmapx_make_ufi(const char *fasta_path, const char *ufi_path, uint32_t W, uint32_t max_ix, uint64_t slots) {
+	return make_ufi_impl(fasta_path, ufi_path, W, max_ix, slots, -1);
+}
+// the same with the counting passes, the head slots and the overflow list made on `device` (make_ufi_gpu.hip)
+extern "C" int urmapx_make_ufi_gpu(int device, const char *fasta_path, const char *ufi_path, uint32_t W, uint32_t max_ix, uint64_t slots) {
+	return device < 0 ? URMAPX_E_ARG : make_ufi_impl(fasta_path, ufi_path, W, max_ix, slots, device);
+}
+
+static int make_ufi_impl(const char *fasta_path, const char *ufi_path, uint32_t W, uint32_t max_ix, uint64_t slots, int device) {
 	if (!fasta_path || !ufi_path || slots == 0) return URMAPX_E_ARG;
 	std::vector<std::string> labels, seqs;
 	if (!load_fasta(fasta_path, labels, seqs)) return URMAPX_E_IO;
@@ -341,7 +380,8 @@ extern "C" int urmapx_make_ufi(const char *fasta_path, const char *ufi_path, uin
 	}
 	uint8_t *blob = (uint8_t *)malloc(5 * slots);
 	if (!blob) return URMAPX_E_NOMEM;
-	int rc = urmapx_build_slots(store.data(), (uint32_t)total, W, max_ix, slots, blob, nullptr);
+	int rc = device < 0 ? urmapx_build_slots(store.data(), (uint32_t)total, W, max_ix, slots, blob, nullptr)
+	                    : urmapx_build_slots_gpu(device, store.data(), nullptr, (uint32_t)total, W, max_ix, slots, blob, nullptr);
 	if (rc) { free(blob); return rc; }
 	FILE *f = fopen(ufi_path, "wb");
 	if (!f) { free(blob); return URMAPX_E_IO; }

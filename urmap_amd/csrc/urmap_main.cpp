@@ -2,7 +2,7 @@
 // (urmap_main.cpp:6-41, map.cpp:27-67, ufindexio.cpp:117-179) as a batch dispatcher over liburmapx.so.
 //
 //   urmap -map reads.fq[.gz] -ufi index.ufi -samout out.sam [-veryfast] [-threads N] [-gpu D] [-gpus N] [-streams K] [-batch N]
-//   urmap -make_ufi genome.fa -output index.ufi [-slots N] [-wordlength W] [-maxix M] [-veryfast]
+//   urmap -make_ufi genome.fa -output index.ufi [-slots N] [-wordlength W] [-maxix M] [-veryfast] [-gpu D | -host]
 //
 //   urmap -map2 R1.fq -reverse R2.fq -ufi index.ufi -samout out.sam [-tabbedout out.tab]   (paired-end, map2.cpp:39-90)
 //
@@ -49,7 +49,7 @@ using namespace urx;
 
 struct Opts {
 	std::string map, map2, reverse, make_ufi, ufi, samout, tabbedout, output;
-	bool veryfast = false, quiet = false, minq_given = false;
+	bool veryfast = false, quiet = false, minq_given = false, host_build = false;
 	unsigned threads = 0, wordlength = 24, maxix = 0, minq = 10;
 	unsigned long long slots = 0;
 	int gpu = 0, gpus = 1, streams = 2;
@@ -83,6 +83,7 @@ static Opts parse(int argc, char **argv) {
 		else if (a == "-streams") o.streams = atoi(val());
 		else if (a == "-batch") o.batch = (unsigned)atoi(val());
 		else if (a == "-veryfast") o.veryfast = true;
+		else if (a == "-host") o.host_build = true;
 		else if (a == "-quiet") o.quiet = true;
 		else if (a == "-log") (void)val();
 		else die("Unknown option %s", a.c_str());
@@ -221,7 +222,14 @@ static int cmd_make_ufi(const Opts &o) {
 		if (slots == 0) die("GetPrime(%.3g) overflow", (double)size / 0.6);
 	}
 	unsigned maxix = o.maxix ? o.maxix : (o.veryfast ? 3u : 32u);
-	check(urmapx_make_ufi(o.make_ufi.c_str(), o.output.c_str(), o.wordlength, maxix, slots), "make_ufi");
+	// counting passes, head slots and the overflow list on the GPU, the order-dependent inserts on the host; -host (or no
+	// usable device) builds everything on the host.  Same bytes either way.
+	int rc = o.host_build ? URMAPX_E_NODEVICE : urmapx_make_ufi_gpu(o.gpu, o.make_ufi.c_str(), o.output.c_str(), o.wordlength, maxix, slots);
+	if (rc == URMAPX_E_NODEVICE) {
+		if (!o.host_build) fprintf(stderr, "make_ufi: no usable GPU, building on the host\n");
+		rc = urmapx_make_ufi(o.make_ufi.c_str(), o.output.c_str(), o.wordlength, maxix, slots);
+	}
+	check(rc, "make_ufi");
 	return 0;
 }
 
