@@ -57,7 +57,7 @@ struct DpJob {             // 32 bytes
 static_assert(sizeof(DpJob) == 32, "DpJob layout");
 // flank window unusable (alignhsp.cpp:104-117 / 148-150); right flank not run (penalty already over the job's cap);
 // path longer than URMAPX_MAX_PATH_OPS runs
-static constexpr uint8_t DPJ_LEFT_FAIL = 1, DPJ_RIGHT_FAIL = 2, DPJ_RIGHT_SKIPPED = 4, DPJ_PATH_LONG = 8, DPJ_GATED = 16;
+static constexpr uint8_t DPJ_LEFT_FAIL = 1, DPJ_RIGHT_FAIL = 2, DPJ_RIGHT_SKIPPED = 4, DPJ_PATH_LONG = 8, DPJ_GATED = 16, DPJ_RIGHT_ABORTED = 32;
 // The jobs of a read are run in rounds of growing size, [0,2) [2,16) [16,inf) by index: after each round the ordered
 // replay consumes that round's jobs and the penalty cap it arrives at gates the next round's DPs -- most of a repeat
 // read's HSPs fail AlignHSP's first test once the first few alignments have tightened the cap.
@@ -95,7 +95,7 @@ struct SearchWork {
 size_t dp_scratch_stride(uint32_t max_read_len);
 int dp_block_count(uint32_t max_read_len, int device);
 size_t search_scratch_stride(uint32_t max_read_len);
-size_t search_scratch_tail();
+size_t search_scratch_tail(int blocks);
 size_t search_pe_scratch_tail();
 int search_block_count(uint32_t max_read_len, int device);
 size_t viterbi_batch_scratch_stride();

@@ -335,15 +335,12 @@ struct SearchWave {
 			}
 		}
 		if (hspCount >= hsp_lds) {
-			// The LDS share of the list is full (a read in a high-copy repeat).  The first-pass kernel (OVF = false) only
-			// flags the read, which is then mapped again by the OVF = true instance, whose list continues in global
-			// scratch -- so the common kernel carries none of that code.
-			if constexpr (!OVF) { status |= URMAPX_ST_HSP_OVERFLOW; return; }
-			else {
-				const int rc = hsp_overflow_add(hsp_ovf, hspCount - hsp_lds, HSP_TOTAL_CAP - HSP_CAP, diag, startdb, npk, score);
-				if (rc == 0) return;
-				if (rc == 2) { status |= URMAPX_ST_HSP_OVERFLOW; return; }
-			}
+			// The LDS share of the list is full (a read in a repeat family: 0.2 % of 150 bp reads and 2-4 % of 250 bp reads
+			// on a genome with hg38's repeat content collect more than 256 HSPs).  The list continues in this block's
+			// global scratch (the reference's list is unbounded, state1.cpp:193-228), out of line.
+			const int rc = hsp_overflow_add(hsp_ovf, hspCount - hsp_lds, HSP_TOTAL_CAP - HSP_CAP, diag, startdb, npk, score);
+			if (rc == 0) return;
+			if (rc == 2) { status |= URMAPX_ST_HSP_OVERFLOW; return; }
 		} else if (lane == 0) {
 			hsp_db[hspCount] = startdb; hsp_pk[hspCount] = npk;
 		}
@@ -367,12 +364,12 @@ struct SearchWave {
 	// alignhsp.cpp:60-172
 	__device__ void align_hsp(int k) {
 		uint32_t startdb, pk;
-		if (!OVF || k < hsp_lds) { startdb = hsp_db[k]; pk = hsp_pk[k]; }
+		if (k < hsp_lds) { startdb = hsp_db[k]; pk = hsp_pk[k]; }
 		else { const uint2 e = hsp_ovf[k - hsp_lds]; startdb = e.x; pk = e.y; }
 		if (pk & (1u << 27)) return;  // m_Aligned
 		__syncthreads();
 		if (lane == 0) {
-			if (!OVF || k < hsp_lds) hsp_pk[k] = pk | (1u << 27);
+			if (k < hsp_lds) hsp_pk[k] = pk | (1u << 27);
 			else hsp_ovf[k - hsp_lds].y = pk | (1u << 27);
 		}
 		const int startq = (int)(pk & 511u), len = (int)((pk >> 9) & 511u);
@@ -460,7 +457,7 @@ struct SearchWave {
 	__device__ __forceinline__ bool hsp_get(int k, uint32_t &startdb, uint32_t &pk) const {
 		startdb = 0; pk = 0;
 		if (k >= hspCount) return false;
-		if (!OVF || k < hsp_lds) { startdb = hsp_db[k]; pk = hsp_pk[k]; }
+		if (k < hsp_lds) { startdb = hsp_db[k]; pk = hsp_pk[k]; }
 		else { const uint2 e = hsp_ovf[k - hsp_lds]; startdb = e.x; pk = e.y; }
 		return true;
 	}
@@ -772,7 +769,7 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 		uint8_t *sc = scratch + (size_t)blockIdx.x * scratch_stride;
 		S.rowstore = reinterpret_cast<uint32_t *>(sc);
 		S.ws.carve(sc + (size_t)SW::NSEG * ROW_CAP * 64 * 4, SW::QMAX, SW::WIDE_LB);
-		S.hsp_ovf = OVF ? hsp_ovf_base + (size_t)blockIdx.x * (HSP_TOTAL_CAP - HSP_CAP) : nullptr;
+		S.hsp_ovf = hsp_ovf_base + (size_t)blockIdx.x * (HSP_TOTAL_CAP - HSP_CAP);
 		S.hsp_lds = (hsp_lds_cap >= 64 && hsp_lds_cap <= HSP_CAP) ? (hsp_lds_cap & ~63) : HSP_CAP;  // multiple of 64
 		S.hit_cap = (hsp_lds_cap >= 64 && hsp_lds_cap <= HSP_CAP) ? S.hsp_lds / 4 : 64;
 		S.hit_wsh = (hsp_lds_cap >= 64 && hsp_lds_cap <= HSP_CAP) ? 4 : 6;
@@ -1138,7 +1135,14 @@ __global__ __launch_bounds__(64) void dp_kernel(DevIndex X, urmapx_params P, con
 				const uint32_t leftTLo = leftTHi - leftTL + 1;
 				if (load_window(leftTLo, (int)leftTL)) flags |= DPJ_LEFT_FAIL;
 				else {
-					leftScore = (int)viterbi_wave<true>(VP, sQ, leftQL, sT, (int)leftTL, true, false, tb, TB_ROWS8, ws, RL, vst_l, lane);
+					// a flank score below `need` puts the penalty over the cap the job was made under (unless the all-gap floor
+					// rescues it): the DP may stop as soon as that is certain
+					const int allGap = P.gap_open_score + (leftQL - 1) * P.gap_ext_score;
+					const int need = leftQL - (J.maxpen - totalPen);
+					bool aborted = false;
+					leftScore = (int)viterbi_wave<true>(VP, sQ, leftQL, sT, (int)leftTL, true, false, tb, TB_ROWS8, ws, RL, vst_l, lane,
+					                                    (float)need, allGap < need ? &aborted : nullptr);
+					if (aborted) { leftScore = need - 1; RL.begin(); vst_l = 0; }
 					// TrimLeftIs (pathinfo.cpp:153-171): the leading I run is the last run in traceback order
 					int nTrimI = 0;
 					if (RL.n > 0) {
@@ -1146,7 +1150,6 @@ __global__ __launch_bounds__(64) void dp_kernel(DevIndex X, urmapx_params P, con
 						if ((lastop & 3u) == OP_I) { nTrimI = (int)(lastop >> 2); --RL.n; }
 					}
 					combinedTLo = leftTLo + (uint32_t)nTrimI;
-					const int allGap = P.gap_open_score + (leftQL - 1) * P.gap_ext_score;
 					if (allGap > leftScore) leftScore = allGap;
 					totalPen += leftQL - leftScore;
 				}
@@ -1163,17 +1166,21 @@ __global__ __launch_bounds__(64) void dp_kernel(DevIndex X, urmapx_params P, con
 				const uint32_t rightTL = rightTHi - rightTLo + 1;
 				if (load_window(rightTLo, (int)rightTL)) flags |= DPJ_RIGHT_FAIL;
 				else {
-					rightScore = (int)viterbi_wave<true>(VP, sQ + rightQLo, rightQL, sT, (int)rightTL, false, true, tb, TB_ROWS8, ws, RR, vst_r, lane);
+					const int allGap = P.gap_open_score + (rightQL - 1) * P.gap_ext_score;
+					const int need = rightQL - (J.maxpen - totalPen);
+					bool aborted = false;
+					rightScore = (int)viterbi_wave<true>(VP, sQ + rightQLo, rightQL, sT, (int)rightTL, false, true, tb, TB_ROWS8, ws, RR, vst_r, lane,
+					                                     (float)need, allGap < need ? &aborted : nullptr);
+					if (aborted) { rightScore = need - 1; RR.begin(); vst_r = 0; flags |= DPJ_RIGHT_ABORTED; }
 					// TrimRightIs (pathinfo.cpp:173-190): trailing I run = first run in traceback order, never the whole path
 					if (RR.n > 1 && (ropsR[0] & 3u) == OP_I) rtrim = 1;
-					const int allGap = P.gap_open_score + (rightQL - 1) * P.gap_ext_score;
 					if (allGap > rightScore) rightScore = allGap;
 				}
 			}
 		}
 		// path = Left || M x len || Right, run-length merged (uniform; lane 0 stores into LDS, then one coalesced copy)
 		int nc = 0;
-		if (!(flags & (DPJ_LEFT_FAIL | DPJ_RIGHT_FAIL | DPJ_RIGHT_SKIPPED))) {
+		if (!(flags & (DPJ_LEFT_FAIL | DPJ_RIGHT_FAIL | DPJ_RIGHT_SKIPPED | DPJ_RIGHT_ABORTED))) {
 			int cop = -1, clen = 0;
 			bool ovf = false;
 			auto put = [&](int op, int l) {
@@ -1277,7 +1284,9 @@ size_t search_scratch_stride(uint32_t max_read_len) {
 	return (hsp_ovf_offset(nch) + 255) & ~(size_t)255;
 }
 // behind the strided per-block areas: the HSP overflow lists of the second pass's blocks
-size_t search_scratch_tail() { return (size_t)SEARCH_OVF_BLOCKS * (HSP_TOTAL_CAP - HSP_CAP) * sizeof(uint2); }
+size_t search_scratch_tail(int blocks) {
+	return (size_t)(blocks > SEARCH_OVF_BLOCKS ? blocks : SEARCH_OVF_BLOCKS) * (HSP_TOTAL_CAP - HSP_CAP) * sizeof(uint2);
+}
 
 int search_block_count(uint32_t max_read_len, int device) {
 	hipDeviceProp_t prop;
@@ -1350,7 +1359,7 @@ hipError_t launch_search_se(const DevIndex &X, const urmapx_params &P, const uin
 		if (e != hipSuccess) return e;
 	}
 	dim3 block(64), grid((unsigned)wk.blocks);
-	uint2 *const no_ovf = nullptr;
+	uint2 *const no_ovf = reinterpret_cast<uint2 *>(wk.scratch + (size_t)wk.blocks * wk.scratch_stride);  // HSP lists beyond LDS
 	const DpWork no_dp;
 	auto stamp = [&](int i) { if (wk.stage_events) (void)hipEventRecord(wk.stage_events[i], s); };
 	for (int pass = 0; pass < 2; ++pass)

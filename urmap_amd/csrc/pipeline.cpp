@@ -267,18 +267,43 @@ extern "C" int urmapx_map_files(urmapx_index *I, const urmapx_map_options *opt, 
 		go2.close();
 	});
 	unsigned long long n_reads = 0, n_accept = 0, n_reject = 0, n_nohit = 0, n_unsupported = 0;
+	// SAM text of a batch is formatted by all host threads, each on a contiguous range of reads (pairs); the pieces go to
+	// the flusher thread, which writes them at their file offsets (input order) while the next batch is being formatted.
+	struct Text { std::vector<std::string> outs; std::vector<uint64_t> at; };
+	Channel<std::unique_ptr<Text>> to_flush(2), text_pool(4);
+	std::thread flusher([&] {
+		std::unique_ptr<Text> x;
+		while (to_flush.pop(x)) {
+			const auto tw0 = now();
+			if (!fail.set.load()) {
+#pragma omp parallel for schedule(static, 1) num_threads(host_threads)
+				for (int t = 0; t < host_threads; ++t) {
+					const std::string &out = x->outs[(size_t)t];
+					size_t done = 0;
+					while (done < out.size()) {
+						ssize_t w = pwrite(fsam, out.data() + done, out.size() - done, (off_t)(x->at[(size_t)t] + done));
+						if (w <= 0) { fail.raise(URMAPX_E_IO, std::string("Error writing ") + samout); break; }
+						done += (size_t)w;
+					}
+				}
+			}
+			t_write += secs(tw0, now());
+			text_pool.push(std::move(x));
+		}
+	});
 	std::thread writer([&] {
 		omp_set_num_threads(host_threads);
-		// SAM text of a batch is formatted by all host threads, each on a contiguous range of reads (pairs), and the
-		// pieces are written at their file offsets in input order.
 		std::unique_ptr<Job> j;
-		std::vector<std::string> outs((size_t)host_threads);
+		std::unique_ptr<Text> text;
 		struct Cnt { unsigned long long accept = 0, reject = 0, nohit = 0, unsupported = 0; };
 		for (size_t b = 0; mapped[b % (size_t)n_lanes]->pop(j); ++b) {
 			if (fail.set.load()) { recycled.push(std::move(j)); continue; }
 			const uint32_t n = j->reads.size();
 			const uint32_t units = paired ? n / 2 : n;
 			std::vector<Cnt> cnt((size_t)host_threads);
+			if (!text && !text_pool.try_pop(text)) text = std::make_unique<Text>();
+			text->outs.resize((size_t)host_threads);
+			std::vector<std::string> &outs = text->outs;
 			const auto tf0 = now();
 #pragma omp parallel for schedule(static, 1) num_threads(host_threads)
 			for (int t = 0; t < host_threads; ++t) {
@@ -317,20 +342,12 @@ extern "C" int urmapx_map_files(urmapx_index *I, const urmapx_map_options *opt, 
 			const auto tf1 = now();
 			t_format += secs(tf0, tf1);
 			if (fsam >= 0) {
-				std::vector<uint64_t> at((size_t)host_threads + 1);
+				std::vector<uint64_t> &at = text->at;
+				at.assign((size_t)host_threads + 1, 0);
 				at[0] = sam_off;
 				for (int t = 0; t < host_threads; ++t) at[(size_t)t + 1] = at[(size_t)t] + outs[(size_t)t].size();
 				sam_off = at[(size_t)host_threads];
-#pragma omp parallel for schedule(static, 1) num_threads(host_threads)
-				for (int t = 0; t < host_threads; ++t) {
-					const std::string &out = outs[(size_t)t];
-					size_t done = 0;
-					while (done < out.size()) {
-						ssize_t w = pwrite(fsam, out.data() + done, out.size() - done, (off_t)(at[(size_t)t] + done));
-						if (w <= 0) { fail.raise(URMAPX_E_IO, std::string("Error writing ") + samout); break; }
-						done += (size_t)w;
-					}
-				}
+				to_flush.push(std::move(text));
 			}
 			if (ftab && paired) {  // tab lines: formatted by all host threads (pair ranges), written in order
 				std::vector<std::string> tabs((size_t)host_threads);
@@ -350,9 +367,9 @@ extern "C" int urmapx_map_files(urmapx_index *I, const urmapx_map_options *opt, 
 				for (const std::string &tb : tabs)
 					if (fwrite(tb.data(), 1, tb.size(), ftab) != tb.size()) fail.raise(URMAPX_E_IO, std::string("Error writing ") + tabout);
 			}
-			t_write += secs(tf1, now());
 			recycled.push(std::move(j));
 		}
+		to_flush.close();
 	});
 	std::mutex gpu_time_lock;
 	std::vector<std::thread> lanes;
@@ -397,6 +414,7 @@ extern "C" int urmapx_map_files(urmapx_index *I, const urmapx_map_options *opt, 
 	reader.join();
 	if (reader2.joinable()) reader2.join();
 	writer.join();
+	flusher.join();
 	{  // page-locked arrays are released before their contexts go
 		std::unique_ptr<Job> j;
 		while (recycled.try_pop(j)) j.reset();

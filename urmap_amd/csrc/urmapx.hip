@@ -392,7 +392,7 @@ int urmapx_map_se_device(urmapx_ctx *C, const void *d_bases, const void *d_offs,
 	SearchWork wk;
 	wk.blocks = C->blocks[cls];
 	wk.scratch_stride = search_scratch_stride(max_read_len);
-	if ((rc = C->scratch.ensure(wk.scratch_stride * (size_t)wk.blocks + search_scratch_tail()))) return rc;
+	if ((rc = C->scratch.ensure(wk.scratch_stride * (size_t)wk.blocks + search_scratch_tail(wk.blocks)))) return rc;
 	if ((rc = C->ovflist.ensure((size_t)n + 1))) return rc;
 	wk.ovf_list = C->ovflist.p;
 	const char *ds = getenv("URMAPX_DEBUG_STOP");

@@ -73,9 +73,15 @@ __device__ float viterbi_wide(const VPar P, const uint8_t *A, int LA, const uint
 
 // ws.la_cap == 0: no wide-band scratch (the band must fit one wavefront).
 // B_LDS: B is an LDS array of the caller (reads around it cannot fault, so the row blocks index it without a clamp).
+// abort_below / aborted (optional): the caller has no use for a score below abort_below (AlignHSP drops the HSP when a
+// flank costs more penalty than the cap leaves, alignhsp.cpp:127-130,160-162).  After every block of rows the best
+// M / D value of the row plus one point per query letter still to come bounds the final score from above (gaps cost,
+// the free end gaps of Left / Right problems add nothing); once that bound is below abort_below the DP stops and sets
+// *aborted -- the result would have been discarded anyway.
 template <bool B_LDS = false>
 __device__ __forceinline__ float viterbi_wave(const VPar P, const uint8_t *A, int LA, const uint8_t *B, int LB, bool Left, bool Right,
-                              uint32_t *tb, int tb_rows8, const WideScratch ws, RevOps &R, uint32_t &status, int lane_in) {
+                              uint32_t *tb, int tb_rows8, const WideScratch ws, RevOps &R, uint32_t &status, int lane_in,
+                              float abort_below = -3.0e38f, bool *aborted = nullptr) {
 	// the lane index is recomputed here (two mbcnt) instead of using the caller's: that one is live through the whole
 	// search kernel, gets spilled in its register-hungry parts, and was then reloaded from scratch in every DP row
 	(void)lane_in;
@@ -216,6 +222,10 @@ __device__ __forceinline__ float viterbi_wave(const VPar P, const uint8_t *A, in
 			const int n = min(8 - (i & 7), LA - i);
 			rows_upto8(i, n);
 			i += n;
+			if (aborted != nullptr && i < LA) {
+				const float best = rdlane(wave_prefix_max(fmaxf(M, Dn)), 63);
+				if (best + (float)(LA - i) < abort_below) { *aborted = true; __syncthreads(); return best; }
+			}
 		}
 	}
 	// last row of the insert matrix (strict '>' there)
