@@ -497,7 +497,46 @@ def write_fastq_fixed(path, reads_u8, n, L):
     return rec * n
 
 
-def run_e2e(torch, api, oi, index, device, d_seq, seq_lengths, seq_offsets, L, sub, indel, n_reads, cores):
+def run_reference(ref_bin, oi, d, fq, fq_head, n_reads, n_head, cores, product_sam):
+    """The reference binary itself (oracle/_ref/urmap, compiled from /root/reference by oracle/Makefile; it travels with
+    the snapshot as a test tool) on this host: the index is written as a .ufi file in /dev/shm, `urmap -map` runs on the
+    whole FASTQ file and on its head, the difference of the two wall times is mapping time without the index load.  Its
+    SAM for the head must equal the product's records (as a set: the reference writes in completion order)."""
+    import subprocess
+    ufi = os.path.join(d, "idx.ufi")
+    t0 = time.time()
+    oi.save(ufi)
+    t_save = time.time() - t0
+
+    def run(fastq, out):
+        t = time.time()
+        r = subprocess.run([ref_bin, "-map", fastq, "-ufi", ufi, "-samout", out, "-threads", str(cores)],
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        if r.returncode != 0:
+            raise RuntimeError("reference urmap failed: " + r.stderr.decode()[-500:])
+        return time.time() - t
+    sam_head, sam_all = os.path.join(d, "ref_head.sam"), os.path.join(d, "ref_all.sam")
+    t_head = run(fq_head, sam_head)
+    t_all = run(fq, sam_all)
+    os.remove(sam_all)
+    os.remove(ufi)
+    want = sorted(l for l in open(sam_head, "rb").read().split(b"\n") if l and not l.startswith(b"@"))
+    got = []
+    with open(product_sam, "rb") as f:
+        for line in f:
+            if line.startswith(b"@"):
+                continue
+            got.append(line.rstrip(b"\n"))
+            if len(got) == len(want):
+                break
+    rate = (n_reads - n_head) / max(1e-9, t_all - t_head)
+    return {"reads_per_s": round(rate, 1), "threads": cores,
+            "how": f"wall({n_reads} reads) - wall({n_head} reads) = {t_all:.1f} - {t_head:.1f} s (each run loads the index from /dev/shm); "
+                   f".ufi written in {t_save:.1f} s",
+            "sam_records_identical_to_product": bool(sorted(got) == want), "sam_records_checked": len(want)}
+
+
+def run_e2e(torch, api, oi, index, device, d_seq, seq_lengths, seq_offsets, L, sub, indel, n_reads, cores, ref_bin=None):
     """FASTQ file -> SAM file through urmapx_map_files (the command line's cmd_map) on the resident index: what a user of
     `urmap -map` gets, index load excluded as the reference reports it.  Files live in /dev/shm (memory), so this is the
     parse + PCIe + map + format + write pipeline, not a disk benchmark.  The first 100 k records are compared with the
@@ -510,7 +549,7 @@ def run_e2e(torch, api, oi, index, device, d_seq, seq_lengths, seq_offsets, L, s
         reads = make_reads_torch(torch, 777, d_seq, seq_lengths, seq_offsets, n_reads, L, sub, indel, device).cpu().numpy()
         fq, sam = os.path.join(d, "r.fq"), os.path.join(d, "out.sam")
         fq_bytes = write_fastq_fixed(fq, reads, n_reads, L)
-        n_chk = min(n_reads, 100_000)
+        n_chk = min(n_reads // 4, 400_000)
         fq_head, sam_o = os.path.join(d, "head.fq"), os.path.join(d, "oracle.sam")
         write_fastq_fixed(fq_head, reads[: n_chk * L], n_chk, L)
         del reads
@@ -520,6 +559,9 @@ def run_e2e(torch, api, oi, index, device, d_seq, seq_lengths, seq_offsets, L, s
             runs.append(rep)
         rep = runs[-1]
         oi.map_file_se(fq_head, sam_o, threads=cores)
+        ref = None
+        if ref_bin and os.path.exists(ref_bin) and not os.environ.get("URMAP_BENCH_NO_REFERENCE"):
+            ref = run_reference(ref_bin, oi, d, fq, fq_head, n_reads, n_chk, cores, sam)
         want = [l for l in open(sam_o, "rb").read().split(b"\n") if l and not l.startswith(b"@")]
         got = []
         with open(sam, "rb") as f:
@@ -537,6 +579,8 @@ def run_e2e(torch, api, oi, index, device, d_seq, seq_lengths, seq_offsets, L, s
                "stage_busy_s": {k: round(rep[k], 3) for k in ("parse_s", "gpu_s", "format_s", "write_s")},
                "mapped_q10_frac": round(rep["mapped_q"] / max(1, rep["reads"]), 4),
                "sam_records_identical_to_oracle": bool(same), "sam_records_checked": len(want)}
+        if ref:
+            out["reference_binary"] = ref
         return out
     finally:
         shutil.rmtree(d, ignore_errors=True)
@@ -727,7 +771,14 @@ def main():
                 pass
             torch.cuda.empty_cache()
             out["e2e"] = run_e2e(torch, api, oi, index, device, d_seq, seq_lengths, seq_offsets, L, args.sub, args.indel,
-                                 int(os.environ.get("URMAP_BENCH_E2E_READS", 4_000_000)), cores)
+                                 int(os.environ.get("URMAP_BENCH_E2E_READS", 4_000_000)), cores, ref_bin=ol.REF_BIN)
+            rb = out["e2e"].get("reference_binary")
+            if rb and "cpu_baseline" in out:  # the reference itself, timed on this host in this run
+                out["cpu_baseline"]["port_value"] = out["cpu_baseline"]["value"]
+                out["cpu_baseline"]["value"] = rb["reads_per_s"]
+                out["cpu_baseline"]["kind"] = "reference"
+                out["cpu_baseline"]["sample"] = (f"oracle/_ref/urmap (the unmodified reference, compiled by oracle/Makefile) -map -threads {rb['threads']} on the e2e FASTQ file: "
+                                                 + rb["how"] + "; the CPU port on the same host: port_value (" + out["cpu_baseline"]["sample"] + ")")
         print(json.dumps(out), flush=True)
     R.close()
 
