@@ -96,7 +96,7 @@ size_t dp_scratch_stride(uint32_t max_read_len);
 int dp_block_count(uint32_t max_read_len, int device);
 size_t search_scratch_stride(uint32_t max_read_len);
 size_t search_scratch_tail(int blocks);
-size_t search_pe_scratch_tail();
+size_t search_pe_scratch_tail(int blocks);
 int search_block_count(uint32_t max_read_len, int device);
 size_t viterbi_batch_scratch_stride();
 

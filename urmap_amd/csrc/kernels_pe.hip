@@ -20,7 +20,7 @@ namespace urx {
 
 static constexpr int PE_HIT_CAP = 64;
 static constexpr int PE_HSP_CAP = 128;       // HSPs of a mate held in LDS
-static constexpr int PE_HSP_OVF_CAP = 8064;  // per mate, in global scratch, second pass only
+static constexpr int PE_HSP_OVF_CAP = 8064;  // per mate, in global scratch
 static constexpr int PE_OVF_BLOCKS = 1024;   // grid of the second pass (the costliest pairs of a batch)
 static constexpr int PE_PAIR_CAP = 256;
 static constexpr int PE_TICKET_CHUNK = 2;
@@ -145,17 +145,18 @@ struct Mate {
 		return idx;
 	}
 
-	// HSP k: LDS below hsp_lds; beyond it the list continues in global scratch, in the second-pass kernel only (the
-	// first pass flags the pair and queues it: see search_se_kernel).  sf = score << 2 | aligned << 1 | plus.
+	// HSP k: LDS below hsp_lds; beyond it the list continues in this block's global scratch (both passes: re-mapping the
+	// pairs with long HSP lists in a second launch cost more than carrying the code, see search_se_kernel).
+	// sf = score << 2 | aligned << 1 | plus.
 	__device__ __forceinline__ void hsp_get(int k, uint32_t &db, uint32_t &ql, uint32_t &sf) const {
-		if (!OVF || k < hsp_lds) { db = hsp_db[k]; ql = hsp_ql[k]; sf = hsp_sf[k]; }
+		if (k < hsp_lds) { db = hsp_db[k]; ql = hsp_ql[k]; sf = hsp_sf[k]; }
 		else { const uint2 e = hsp_ovf[k - hsp_lds]; db = e.x; ql = (e.y & 511u) | (((e.y >> 9) & 511u) << 16); sf = e.y >> 18; }
 	}
 	__device__ __forceinline__ void hsp_put(int k, uint32_t db, uint32_t ql, uint32_t sf) {  // one lane
-		if (!OVF || k < hsp_lds) { hsp_db[k] = db; hsp_ql[k] = ql; hsp_sf[k] = (uint16_t)sf; }
+		if (k < hsp_lds) { hsp_db[k] = db; hsp_ql[k] = ql; hsp_sf[k] = (uint16_t)sf; }
 		else hsp_ovf[k - hsp_lds] = make_uint2(db, (ql & 511u) | ((ql >> 16) << 9) | (sf << 18));
 	}
-	__device__ __forceinline__ int hsp_room() const { return OVF ? hsp_lds + PE_HSP_OVF_CAP : hsp_lds; }
+	__device__ __forceinline__ int hsp_room() const { return hsp_lds + PE_HSP_OVF_CAP; }
 	__device__ __forceinline__ int hsp_score(int k) const {
 		uint32_t db, ql, sf;
 		hsp_get(k, db, ql, sf);
@@ -702,7 +703,7 @@ __global__ __launch_bounds__(64) void search_pe_kernel(DevIndex X, urmapx_params
                                                        uint8_t *scratch, size_t scratch_stride,
                                                        const uint8_t *__restrict__ g_seq, const uint8_t *__restrict__ g_blob,
                                                        int veryfast, uint32_t *ticket, urmapx_pair_info *pair_info,
-                                                       int hsp_lds_cap, uint32_t *ovf_list, uint2 *hsp_ovf_base) {
+                                                       int hsp_lds_cap, uint32_t *ovf_list, uint2 *hsp_ovf_base, uint32_t hsp_area_blocks) {
 	using M = Mate<NCH, OVF>;
 	constexpr int QMAX = M::QMAX;
 	// LDS per block decides how many pairs a CU keeps in flight, so arrays share memory by lifetime:
@@ -748,7 +749,7 @@ __global__ __launch_bounds__(64) void search_pe_kernel(DevIndex X, urmapx_params
 		m[a].sQ[0] = sQ[2 * a]; m[a].sQ[1] = sQ[2 * a + 1];
 		m[a].sT = sT; m[a].tb = tb; m[a].ropsL = ropsL; m[a].ropsR = ropsR; m[a].cand = cand;
 		m[a].hit_nops = hit_nops[a];
-		m[a].hit_paths = OVF ? reinterpret_cast<urmapx_path_op *>(hsp_ovf_base + (size_t)gridDim.x * 2 * PE_HSP_OVF_CAP) +
+		m[a].hit_paths = OVF ? reinterpret_cast<urmapx_path_op *>(hsp_ovf_base + (size_t)hsp_area_blocks * 2 * PE_HSP_OVF_CAP) +
 		                           ((size_t)blockIdx.x * 2 + a) * PE_HIT_CAP * M::HITW * URMAPX_MAX_PATH_OPS
 		                     : reinterpret_cast<urmapx_path_op *>(sc) + (size_t)a * PE_HIT_CAP * URMAPX_MAX_PATH_OPS;
 		m[a].hit_cap = (hsp_lds_cap >= 64 && hsp_lds_cap <= PE_HSP_CAP) ? (hsp_lds_cap & ~63) / 4 : PE_HIT_CAP;
@@ -757,7 +758,7 @@ __global__ __launch_bounds__(64) void search_pe_kernel(DevIndex X, urmapx_params
 		m[a].pend[0] = pend[2 * a]; m[a].pend[1] = pend[2 * a + 1];
 		m[a].rowlen = rowlen; m[a].pre = pre; m[a].cq_db = cq_db; m[a].cq_qp = cq_qp;
 		m[a].hsp_lds = (hsp_lds_cap >= 64 && hsp_lds_cap <= PE_HSP_CAP) ? (hsp_lds_cap & ~63) : PE_HSP_CAP;
-		m[a].hsp_ovf = OVF ? hsp_ovf_base + ((size_t)blockIdx.x * 2 + a) * PE_HSP_OVF_CAP : nullptr;
+		m[a].hsp_ovf = hsp_ovf_base + ((size_t)blockIdx.x * 2 + a) * PE_HSP_OVF_CAP;
 		m[a].rowstore = reinterpret_cast<uint32_t *>(sc + pe_rowstore_offset(QMAX));
 		m[a].ws.carve(sc + (size_t)2 * PE_HIT_CAP * URMAPX_MAX_PATH_OPS * 2, QMAX, PE_SCAN_SEG + 2 * QMAX + 64);
 	}
@@ -1183,8 +1184,10 @@ size_t search_pe_scratch_stride(uint32_t max_read_len) {
 
 // behind the strided per-block areas, for the second pass's blocks: the HSP overflow lists (two mates), then the
 // hit paths of its longer hit lists
-size_t search_pe_scratch_tail() {
-	return (size_t)PE_OVF_BLOCKS * 2 * ((size_t)PE_HSP_OVF_CAP * sizeof(uint2) + (size_t)PE_HIT_CAP * 4 * URMAPX_MAX_PATH_OPS * 2);
+static uint32_t pe_hsp_area_blocks(int blocks) { return (uint32_t)(blocks > PE_OVF_BLOCKS ? blocks : PE_OVF_BLOCKS); }
+size_t search_pe_scratch_tail(int blocks) {
+	return (size_t)pe_hsp_area_blocks(blocks) * 2 * (size_t)PE_HSP_OVF_CAP * sizeof(uint2) +
+	       (size_t)PE_OVF_BLOCKS * 2 * (size_t)PE_HIT_CAP * 4 * URMAPX_MAX_PATH_OPS * 2;
 }
 
 int search_pe_block_count(uint32_t max_read_len, int device) {
@@ -1213,22 +1216,23 @@ hipError_t launch_search_pe(const DevIndex &X, const urmapx_params &P, const uin
 	}
 	dim3 block(64), grid((unsigned)wk.blocks);
 	const int nch = pe_nch_for(max_read_len);
+	uint2 *const ovf_base1 = reinterpret_cast<uint2 *>(wk.scratch + (size_t)wk.blocks * wk.scratch_stride);  // HSP lists beyond LDS
 	if (nch == 2)
 		hipLaunchKernelGGL((search_pe_kernel<2, false>), grid, block, 0, s, X, P, d_bases, d_offs, npairs, probe, d_results,
 		                   d_path_ops, d_path_used, wk.scratch, wk.scratch_stride, X.seq, X.blob, veryfast, wk.ticket, pair_info,
-		                   wk.hsp_lds_cap, wk.ovf_list, (uint2 *)nullptr);
+		                   wk.hsp_lds_cap, wk.ovf_list, ovf_base1, pe_hsp_area_blocks(wk.blocks));
 	else if (nch == 3)
 		hipLaunchKernelGGL((search_pe_kernel<3, false>), grid, block, 0, s, X, P, d_bases, d_offs, npairs, probe, d_results,
 		                   d_path_ops, d_path_used, wk.scratch, wk.scratch_stride, X.seq, X.blob, veryfast, wk.ticket, pair_info,
-		                   wk.hsp_lds_cap, wk.ovf_list, (uint2 *)nullptr);
+		                   wk.hsp_lds_cap, wk.ovf_list, ovf_base1, pe_hsp_area_blocks(wk.blocks));
 	else if (nch == 4)
 		hipLaunchKernelGGL((search_pe_kernel<4, false>), grid, block, 0, s, X, P, d_bases, d_offs, npairs, probe, d_results,
 		                   d_path_ops, d_path_used, wk.scratch, wk.scratch_stride, X.seq, X.blob, veryfast, wk.ticket, pair_info,
-		                   wk.hsp_lds_cap, wk.ovf_list, (uint2 *)nullptr);
+		                   wk.hsp_lds_cap, wk.ovf_list, ovf_base1, pe_hsp_area_blocks(wk.blocks));
 	else
 		hipLaunchKernelGGL((search_pe_kernel<5, false>), grid, block, 0, s, X, P, d_bases, d_offs, npairs, probe, d_results,
 		                   d_path_ops, d_path_used, wk.scratch, wk.scratch_stride, X.seq, X.blob, veryfast, wk.ticket, pair_info,
-		                   wk.hsp_lds_cap, wk.ovf_list, (uint2 *)nullptr);
+		                   wk.hsp_lds_cap, wk.ovf_list, ovf_base1, pe_hsp_area_blocks(wk.blocks));
 	{
 		hipError_t e = hipGetLastError();
 		if (e != hipSuccess) return e;
@@ -1241,19 +1245,19 @@ hipError_t launch_search_pe(const DevIndex &X, const urmapx_params &P, const uin
 	if (nch == 2)
 		hipLaunchKernelGGL((search_pe_kernel<2, true>), grid2, block, 0, s, X, P, d_bases, d_offs, npairs, probe, d_results,
 		                   d_path_ops, d_path_used, wk.scratch, wk.scratch_stride, X.seq, X.blob, veryfast, wk.ticket, pair_info,
-		                   wk.hsp_lds_cap, wk.ovf_list, ovf_base);
+		                   wk.hsp_lds_cap, wk.ovf_list, ovf_base, pe_hsp_area_blocks(wk.blocks));
 	else if (nch == 3)
 		hipLaunchKernelGGL((search_pe_kernel<3, true>), grid2, block, 0, s, X, P, d_bases, d_offs, npairs, probe, d_results,
 		                   d_path_ops, d_path_used, wk.scratch, wk.scratch_stride, X.seq, X.blob, veryfast, wk.ticket, pair_info,
-		                   wk.hsp_lds_cap, wk.ovf_list, ovf_base);
+		                   wk.hsp_lds_cap, wk.ovf_list, ovf_base, pe_hsp_area_blocks(wk.blocks));
 	else if (nch == 4)
 		hipLaunchKernelGGL((search_pe_kernel<4, true>), grid2, block, 0, s, X, P, d_bases, d_offs, npairs, probe, d_results,
 		                   d_path_ops, d_path_used, wk.scratch, wk.scratch_stride, X.seq, X.blob, veryfast, wk.ticket, pair_info,
-		                   wk.hsp_lds_cap, wk.ovf_list, ovf_base);
+		                   wk.hsp_lds_cap, wk.ovf_list, ovf_base, pe_hsp_area_blocks(wk.blocks));
 	else
 		hipLaunchKernelGGL((search_pe_kernel<5, true>), grid2, block, 0, s, X, P, d_bases, d_offs, npairs, probe, d_results,
 		                   d_path_ops, d_path_used, wk.scratch, wk.scratch_stride, X.seq, X.blob, veryfast, wk.ticket, pair_info,
-		                   wk.hsp_lds_cap, wk.ovf_list, ovf_base);
+		                   wk.hsp_lds_cap, wk.ovf_list, ovf_base, pe_hsp_area_blocks(wk.blocks));
 	return hipGetLastError();
 }
 
