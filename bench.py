@@ -350,8 +350,9 @@ def place_index(R, torch, api, device, d_seq, slots, seq_lengths, seq_offsets, l
     t0 = time.time()
     if R.world == 1:
         index = api.Index.wrap_host(24, 32, slots, blob_np, seq_np, seq_lengths, seq_offsets, labels).upload(R.device_index)
-    elif R.backend == "nccl":
-        how += " on rank 0, RCCL broadcast of the resident arrays"
+    elif R.backend == "nccl" or os.environ.get("URMAP_BENCH_BROADCAST"):
+        # (URMAP_BENCH_BROADCAST: test aid -- take this branch with gloo too, when ranks share a device on a one-GPU box)
+        how += f" on rank 0, {'RCCL' if R.backend == 'nccl' else R.backend} broadcast of the resident arrays"
         d_blob = torch.empty(5 * slots + 8, dtype=torch.uint8, device=device)
         d_seqpad = torch.zeros(size + 4096, dtype=torch.uint8, device=device)
         if R.rank == 0:

@@ -90,10 +90,14 @@ def test_two_index_replicas_two_contexts_through_the_library(tmp_path):
     idx1.close()
 
 
-def test_bench_starts_its_own_two_ranks():
+@pytest.mark.parametrize("broadcast", [False, True])
+def test_bench_starts_its_own_two_ranks(broadcast):
     """`python bench.py --gpus 2` with no launcher around it: two child ranks, one JSON line with n_gpus 2, results of
-    rank 0's last batch bit-identical to the oracle."""
+    rank 0's last batch bit-identical to the oracle.  broadcast: the index reaches rank 1 through the collective
+    broadcast of the resident arrays (the branch the ranks take over RCCL on a multi-GPU node) instead of a file."""
     env = dict(os.environ)
+    if broadcast:
+        env["URMAP_BENCH_BROADCAST"] = "1"
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--genome-mbp", "40", "--reads-per-step", "20000",
@@ -107,6 +111,8 @@ def test_bench_starts_its_own_two_ranks():
     assert d["value"] > 0 and d["scaling"] == "weak"
     import torch
     assert d["config"]["ranks"]["backend"] == ("nccl" if torch.cuda.device_count() >= 2 else "gloo")
+    if broadcast:
+        assert "broadcast of the resident arrays" in d["config"]["setup_s"]["how"]
 
 
 def test_map_files_library_call_on_a_resident_index(tmp_path):

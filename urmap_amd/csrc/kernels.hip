@@ -399,7 +399,14 @@ struct SearchWave {
 			if (leftTL >= leftTHi) return;
 			const uint32_t leftTLo = leftTHi - leftTL + 1;
 			if (load_window(leftTLo, (int)leftTL)) return;
-			int leftScore = (int)viterbi_wave<true>(VP, Q, leftQL, sT, (int)leftTL, true, false, tb, TB_ROWS8, wsv, RL, vst, lane);
+			// the DP stops as soon as the flank cannot stay within what the penalty cap leaves (viterbi_dev.h); the test
+			// that would discard it follows right below, so the outcome is the same
+			const int allGapL = P.gap_open_score + (leftQL - 1) * P.gap_ext_score;
+			const int needL = leftQL - (maxPen - totalPen);
+			bool abortedL = false;
+			int leftScore = (int)viterbi_wave<true>(VP, Q, leftQL, sT, (int)leftTL, true, false, tb, TB_ROWS8, wsv, RL, vst, lane,
+			                                        (float)needL, allGapL < needL ? &abortedL : nullptr);
+			if (abortedL) return;
 			status |= vst;
 			// TrimLeftIs (pathinfo.cpp:153-171): the leading I run is the last run in traceback order
 			int nTrimI = 0;
@@ -422,7 +429,12 @@ struct SearchWave {
 			if (rightTHi >= TL) rightTHi = TL - 1;
 			const uint32_t rightTL = rightTHi - rightTLo + 1;
 			if (load_window(rightTLo, (int)rightTL)) return;
-			int rightScore = (int)viterbi_wave<true>(VP, Q + rightQLo, rightQL, sT, (int)rightTL, false, true, tb, TB_ROWS8, wsv, RR, vst, lane);
+			const int allGapR = P.gap_open_score + (rightQL - 1) * P.gap_ext_score;
+			const int needR = rightQL - (maxPen - totalPen);
+			bool abortedR = false;
+			int rightScore = (int)viterbi_wave<true>(VP, Q + rightQLo, rightQL, sT, (int)rightTL, false, true, tb, TB_ROWS8, wsv, RR, vst, lane,
+			                                         (float)needR, allGapR < needR ? &abortedR : nullptr);
+			if (abortedR) return;
 			status |= vst;
 			// TrimRightIs (pathinfo.cpp:173-190): trailing I run = first run in traceback order, never the whole path
 			if (RR.n > 1 && (ropsR[0] & 3u) == OP_I) rtrim = 1;

@@ -342,7 +342,14 @@ struct Mate {
 			if (leftTL >= leftTHi) return -1;
 			const uint32_t leftTLo = leftTHi - leftTL + 1;
 			if (load_window(leftTLo, (int)leftTL)) return -1;
-			int leftScore = (int)viterbi_wave<true>(VPar(*P), Q, leftQL, sT, (int)leftTL, true, false, tb, TB_ROWS8, ws, RL, vst, lane);
+			// the DP stops as soon as the flank cannot stay within what the penalty cap leaves (viterbi_dev.h); the test
+			// that would discard it follows right below, so the outcome is the same
+			const int allGapL = P->gap_open_score + (leftQL - 1) * P->gap_ext_score;
+			const int needL = leftQL - (maxPen - totalPen);
+			bool abortedL = false;
+			int leftScore = (int)viterbi_wave<true>(VPar(*P), Q, leftQL, sT, (int)leftTL, true, false, tb, TB_ROWS8, ws, RL, vst, lane,
+			                                        (float)needL, allGapL < needL ? &abortedL : nullptr);
+			if (abortedL) return -1;
 			status |= vst;
 			int nTrimI = 0;
 			if (RL.n > 0) {
@@ -364,7 +371,12 @@ struct Mate {
 			if (rightTHi >= TL) rightTHi = TL - 1;
 			const uint32_t rightTL = rightTHi - rightTLo + 1;
 			if (load_window(rightTLo, (int)rightTL)) return -1;
-			int rightScore = (int)viterbi_wave<true>(VPar(*P), Q + rightQLo, rightQL, sT, (int)rightTL, false, true, tb, TB_ROWS8, ws, RR, vst, lane);
+			const int allGapR = P->gap_open_score + (rightQL - 1) * P->gap_ext_score;
+			const int needR = rightQL - (maxPen - totalPen);
+			bool abortedR = false;
+			int rightScore = (int)viterbi_wave<true>(VPar(*P), Q + rightQLo, rightQL, sT, (int)rightTL, false, true, tb, TB_ROWS8, ws, RR, vst, lane,
+			                                         (float)needR, allGapR < needR ? &abortedR : nullptr);
+			if (abortedR) return -1;
 			status |= vst;
 			if (RR.n > 1 && (ropsR[0] & 3u) == OP_I) rtrim = 1;
 			int allGap = P->gap_open_score + (rightQL - 1) * P->gap_ext_score;

@@ -127,7 +127,14 @@ class Ranks:
         if self.dist is None:
             return t
         for lo in range(0, t.numel(), chunk):
-            self.dist.broadcast(t[lo:lo + chunk], src=src)
+            piece = t[lo:lo + chunk]
+            if self.backend == "gloo" and piece.is_cuda:  # gloo moves bytes through the host
+                h = piece.cpu()
+                self.dist.broadcast(h, src=src)
+                if self.rank != src:
+                    piece.copy_(h)
+            else:
+                self.dist.broadcast(piece, src=src)
         return t
 
     def close(self):
