@@ -742,7 +742,8 @@ def main():
         }
         if dp_stats:
             out["phase6"] = {"hsps_given_to_dp_kernel": dp_stats[0], "reads_with_such_hsps": dp_stats[1], "dps_the_ordered_replay_used": dp_stats[2],
-                             "second_pass": {"hsps": dp_stats[3], "reads": dp_stats[4], "used": dp_stats[5]}}
+                             "dropped_by_a_round_gate_before_their_dp": dp_stats[3],
+                             "second_pass": {"hsps": dp_stats[4], "reads": dp_stats[5], "used": dp_stats[6], "gated": dp_stats[7]}}
         if key:
             out["work_per_read_survey"] = SURVEY_WORK_PER_READ[key]
         if cpu is not None:

@@ -149,10 +149,10 @@ int urmapx_ctx_last_kernel_ms(urmapx_ctx *, float ms[2]);
  * ordered part; then the same three for the few reads whose hit / HSP lists outgrew the first pass's): their device
  * times in ms, in that order. */
 int urmapx_ctx_stage_ms(urmapx_ctx *, float ms[6]);
-/* Statistics of the same call, per pass: HSPs handed to the DP launch, reads they belong to, and how many of those DPs
- * the ordered replay of AlignHSP (alignhsp.cpp:60-172) actually looked at (the rest were run for nothing: the penalty
- * cap had fallen by the time their turn came). */
-int urmapx_ctx_dp_stats(urmapx_ctx *, uint32_t out[6]);
+/* Statistics of the same call, per pass (4 numbers each): HSPs handed to the DP launches, reads they belong to, how many
+ * of those DPs the ordered replay of AlignHSP (alignhsp.cpp:60-172) looked at, and how many were dropped before their DP
+ * because the penalty cap had fallen far enough by their round. */
+int urmapx_ctx_dp_stats(urmapx_ctx *, uint32_t out[8]);
 
 /* Diagnostic: shader cycles spent per phase by the last search kernel, summed over wavefronts:
  * [0] setup, [1] phases 1+2, [2] phase 3, [3] chain walks, [4] phase 4, [5] phase 5, [6] phase 6, [7] output;

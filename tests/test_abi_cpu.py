@@ -230,3 +230,26 @@ def test_cli_default_slot_count_equals_reference_binary(tmp_path, nbases):
         assert r.returncode == 0, r.stderr.decode()
         assert ol.ufi_header(os.path.join(d, "mine.ufi")) == ol.ufi_header(os.path.join(d, "ref.ufi"))
         assert filecmp.cmp(os.path.join(d, "mine.ufi"), os.path.join(d, "ref.ufi"), shallow=False)
+
+
+def test_file_to_file_call_and_gpu_builder_fail_loudly_without_a_device(gold_ufi, tmp_path):
+    """No GPU here: urmapx_map_files must come back with URMAPX_E_NODEVICE and a message (not exit, not fall back to any
+    CPU mapping), urmapx_make_ufi_gpu likewise; the command line's -make_ufi says that it builds on the host and
+    writes the reference's bytes."""
+    import subprocess
+    idx = api.Index.open(gold_ufi)
+    with pytest.raises(api.UrmapxError) as e:
+        api.map_files(idx, os.path.join(GOLD, "se150.fq"), samout=os.path.join(tmp_path, "x.sam"))
+    assert e.value.code == api.E_NODEVICE and "Uploading index" in str(e.value)
+    with pytest.raises(api.UrmapxError) as e2:
+        api.make_ufi_gpu(0, os.path.join(GOLD, "g.fa"), os.path.join(tmp_path, "x.ufi"), 100003)
+    assert e2.value.code == api.E_NODEVICE
+    out = os.path.join(tmp_path, "cli.ufi")
+    r = subprocess.run([os.path.join(ROOT, "urmap_amd", "urmap"), "-make_ufi", os.path.join(GOLD, "g.fa"), "-output", out],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()[-500:]
+    assert b"building on the host" in r.stderr
+    assert filecmp.cmp(out, gold_ufi, shallow=False)
+    r = subprocess.run([os.path.join(ROOT, "urmap_amd", "urmap"), "-map", os.path.join(GOLD, "se150.fq"), "-ufi", gold_ufi,
+                        "-samout", os.path.join(tmp_path, "y.sam")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 1 and b"Fatal error" in r.stderr and b"Uploading index" in r.stderr

@@ -113,7 +113,7 @@ def lib():
     L.urmapx_ctx_phase_cycles.argtypes = [vp, C.POINTER(C.c_uint64 * 12)]
     L.urmapx_ctx_read_cycles.argtypes = [vp, vp, u32]
     L.urmapx_ctx_stage_ms.argtypes = [vp, C.POINTER(C.c_float * 6)]
-    L.urmapx_ctx_dp_stats.argtypes = [vp, C.POINTER(C.c_uint32 * 6)]
+    L.urmapx_ctx_dp_stats.argtypes = [vp, C.POINTER(C.c_uint32 * 8)]
     L.urmapx_seed_probe.argtypes = [vp, vp, vp, u32, vp, vp, vp]
     L.urmapx_viterbi_batch.argtypes = [vp, vp, vp, vp, vp, vp, u32, vp, vp, vp, vp]
     L.urmapx_make_ufi.argtypes = [cp, cp, u32, u32, u64]
@@ -421,8 +421,8 @@ class Mapper:
         return [float(x) for x in ms]
 
     def dp_stats(self):
-        """per pass: (HSPs handed to the DP launch, reads parked, DPs the ordered replay needed)"""
-        out = (C.c_uint32 * 6)()
+        """per pass: (HSPs handed to the DP launches, reads parked, DPs the ordered replay looked at, jobs gated before their DP)"""
+        out = (C.c_uint32 * 8)()
         _check(lib().urmapx_ctx_dp_stats(self.h, C.byref(out)), "urmapx_ctx_dp_stats")
         return [int(x) for x in out]
 

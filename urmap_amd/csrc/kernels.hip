@@ -1099,6 +1099,7 @@ __global__ __launch_bounds__(64) void dp_kernel(DevIndex X, urmapx_params P, con
 		__syncthreads();
 		return __ballot(gap) != 0;
 	};
+	uint32_t n_gated = 0;  // statistics
 	// this round's jobs: those with klo <= k < khi.  The k of 64 consecutive jobs comes in with one load; the block then
 	// runs the tile's jobs of this round one after the other.
 	for (uint32_t tile = blockIdx.x * 64u; tile < njobs; tile += gridDim.x * 64u) {
@@ -1114,6 +1115,7 @@ __global__ __launch_bounds__(64) void dp_kernel(DevIndex X, urmapx_params P, con
 			const int glen = (int)((J.pk >> 9) & 511u), gscore = (int)((J.pk >> 18) & 511u);
 			if (glen - gscore > J.maxpen) {
 				if (lane == 0) dp.jobs[j].flags = DPJ_GATED;
+				++n_gated;
 				continue;
 			}
 		}
@@ -1218,6 +1220,7 @@ __global__ __launch_bounds__(64) void dp_kernel(DevIndex X, urmapx_params P, con
 		}
 	}
 	}
+	if (lane == 0 && n_gated) atomicAdd(dp.counters + 3, n_gated);
 }
 
 // ------------------------------------------------------------------------------------------------

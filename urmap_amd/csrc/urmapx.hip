@@ -335,13 +335,13 @@ int urmapx_ctx_stage_ms(urmapx_ctx *C, float ms[6]) {
 }
 
 // Statistics of the last single-end *_device call: per pass {jobs made, reads parked, jobs whose DP the replay needed}
-int urmapx_ctx_dp_stats(urmapx_ctx *C, uint32_t out[6]) {
+int urmapx_ctx_dp_stats(urmapx_ctx *C, uint32_t out[8]) {
 	if (!C || !out || !C->dpbuf.p) return URMAPX_E_ARG;
 	HIP_TRY(hipStreamSynchronize(C->stream));
 	uint32_t buf[8];
 	HIP_TRY(hipMemcpy(buf, C->dpbuf.p, sizeof buf, hipMemcpyDeviceToHost));
 	for (int p = 0; p < 2; ++p)
-		for (int i = 0; i < 3; ++i) out[3 * p + i] = buf[4 * p + i];
+		for (int i = 0; i < 4; ++i) out[4 * p + i] = buf[4 * p + i];
 	return URMAPX_OK;
 }
 
