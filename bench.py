@@ -53,6 +53,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-workloads", action="store_true", help="skip the PE and 250 bp runs on the same index")
     ap.add_argument("--no-e2e", action="store_true", help="skip the FASTQ file -> SAM file run")
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("URMAP_BENCH_STREAMS", 1)),
+                    help="mapping contexts (HIP streams) a batch is split over, as urmap -streams does; 1 keeps the launches of a step back to back so that their times add up to the step (2: +6 %% at 150 bp, +20 %% at 250 bp, launches overlap)")
     ap.add_argument("--mode", choices=("se", "pe"), default="se", help="pe: 2x150 read pairs through State2::Search4 (config 3; not the headline metric)")
     return ap.parse_args()
 
@@ -397,49 +399,77 @@ def place_index(R, torch, api, device, d_seq, slots, seq_lengths, seq_offsets, l
 
 
 class Workload:
-    """One synthetic read set resident in HBM + the output arrays of a step."""
+    """One synthetic read set resident in HBM + the output arrays of a step.  A batch is mapped the way the command line
+    maps it: split over `streams` mapping contexts of the device (urmap -streams K, default 2), each with its own HIP
+    stream, so that one context's probe / DP / finalize launches overlap the other's search kernel."""
 
-    def __init__(self, torch, api, device, d_seq, seq_lengths, seq_offsets, pe, L, sub, indel, nb, n_batches, seed):
-        self.pe, self.L, self.nb, self.api = pe, L, nb, api
-        self.d_offs = (torch.arange(nb + 1, device=device, dtype=torch.int64) * L).contiguous()
+    def __init__(self, torch, api, device, d_seq, seq_lengths, seq_offsets, pe, L, sub, indel, nb, n_batches, seed, streams=1):
+        self.pe, self.L, self.nb, self.api, self.torch = pe, L, nb, api, torch
         self.batches = []
         for b in range(n_batches):
             if pe:
                 self.batches.append(make_pairs_torch(torch, seed + b, d_seq, seq_lengths, seq_offsets, nb // 2, L, sub, 1.5 * sub, device))
             else:
                 self.batches.append(make_reads_torch(torch, seed + b, d_seq, seq_lengths, seq_offsets, nb, L, sub, indel, device))
-        self.d_results = torch.zeros(nb * api.RESULT_DTYPE.itemsize, dtype=torch.uint8, device=device)
-        self.d_pathops = torch.zeros(nb * api.MAX_PATH_OPS, dtype=torch.int16, device=device)
-        self.d_used = torch.zeros(1, dtype=torch.int32, device=device)
+        # contiguous parts of the batch, one per context (pairs stay together)
+        unit = 2 if pe else 1
+        cuts = [((nb // unit) * k // streams) * unit for k in range(streams + 1)]
+        self.parts = []
+        for k in range(streams):
+            n = cuts[k + 1] - cuts[k]
+            self.parts.append({"lo": cuts[k], "n": n,
+                               "d_offs": (torch.arange(n + 1, device=device, dtype=torch.int64) * L).contiguous(),
+                               "d_results": torch.zeros(n * api.RESULT_DTYPE.itemsize, dtype=torch.uint8, device=device),
+                               "d_pathops": torch.zeros(n * api.MAX_PATH_OPS, dtype=torch.int16, device=device),
+                               "d_used": torch.zeros(1, dtype=torch.int32, device=device)})
         self.last = None
 
-    def step(self, mapper, b):
+    def step(self, mappers, b):
         self.last = self.batches[b % len(self.batches)]
-        f = mapper.map_pe_device if self.pe else mapper.map_se_device
-        f(self.last.data_ptr(), self.d_offs.data_ptr(), self.nb // 2 if self.pe else self.nb, self.nb * self.L, self.L,
-          self.d_results.data_ptr(), self.d_pathops.data_ptr(), self.d_used.data_ptr())
+        for m, p in zip(mappers, self.parts):
+            f = m.map_pe_device if self.pe else m.map_se_device
+            f(self.last.data_ptr() + p["lo"] * self.L, p["d_offs"].data_ptr(), p["n"] // 2 if self.pe else p["n"], p["n"] * self.L, self.L,
+              p["d_results"].data_ptr(), p["d_pathops"].data_ptr(), p["d_used"].data_ptr())
 
-    def timed(self, mapper, steps, warmup, barrier=None):
-        """W untimed steps, then K timed ones -> (seconds, mean kernel ms [probe, search])"""
+    def timed(self, mappers, steps, warmup, barrier=None):
+        """W untimed steps, then K timed ones -> (seconds, mean ms per launch [probe, search]); stage_ms / dp_stats too"""
+        mappers = list(mappers)[: len(self.parts)]
         for w in range(warmup):
-            self.step(mapper, w)
-        mapper.sync()
+            self.step(mappers, w)
+        for m in mappers:
+            m.sync()
         if barrier:
             barrier()
         kms = np.zeros(2)
         self.stage_ms = np.zeros(6)
         t0 = time.perf_counter()
         for k in range(steps):
-            self.step(mapper, warmup + k)
-            mapper.sync()
-            kms += mapper.last_kernel_ms()
-            if not self.pe:
-                self.stage_ms += mapper.stage_ms()
+            self.step(mappers, warmup + k)
+            for m in mappers:
+                m.sync()
+            for m in mappers:
+                kms += np.array(m.last_kernel_ms()) / len(mappers)
+                if not self.pe:
+                    self.stage_ms += np.array(m.stage_ms()) / len(mappers)
         if barrier:
             barrier()
         self.stage_ms /= max(1, steps)
-        self.dp_stats = None if self.pe else mapper.dp_stats()
+        self.dp_stats = None if self.pe else [int(x) for x in np.sum([m.dp_stats() for m in mappers], axis=0)]
         return time.perf_counter() - t0, kms / max(1, steps)
+
+    def results(self):
+        """results of the last step, parts joined, path offsets made to index one joined path arena"""
+        api = self.api
+        res, ops, base = [], [], 0
+        for p in self.parts:
+            g = np.frombuffer(p["d_results"].cpu().numpy().tobytes(), dtype=api.RESULT_DTYPE).copy()
+            used = int(p["d_used"].cpu().item())
+            o = p["d_pathops"][:used].cpu().numpy().view(np.uint16)
+            g["path_off"] += np.uint32(base)
+            base += used
+            res.append(g)
+            ops.append(o)
+        return np.concatenate(res), np.concatenate(ops) if ops else np.zeros(0, np.uint16)
 
     def check(self, oi, sample_n, threads):
         """The last step's results against the oracle on its first sample_n reads: every field SAM is made of (position,
@@ -451,9 +481,8 @@ class Workload:
         t1 = time.perf_counter()
         ores, opaths, cnt = oi.map_pe(hb, ho, threads=threads) if self.pe else oi.map_se(hb, ho, threads=threads)
         t_cpu = time.perf_counter() - t1
-        g = np.frombuffer(self.d_results.cpu().numpy().tobytes(), dtype=api.RESULT_DTYPE)[:sample_n]
-        used = int(self.d_used.cpu().item())
-        gops = self.d_pathops[:used].cpu().numpy().view(np.uint16)
+        g, gops = self.results()
+        g = g[:sample_n]
         diffs = {"status_nonzero": int((g["status"] != 0).sum())}
         ok = diffs["status_nonzero"] == 0
         for name in ("dbpos", "seq_index", "coord", "score", "second", "mapq"):
@@ -650,16 +679,18 @@ def main():
     slots, fasta_bytes = default_slot_count(seq_lengths, labels)
     t_gen = time.time() - t_setup
     index, blob_np, seq_np, d_seq, t_index = place_index(R, torch, api, device, d_seq, slots, seq_lengths, seq_offsets, labels)
-    mapper = api.Mapper(index, device=dev_index, method=6)
+    mappers = [api.Mapper(index, device=dev_index, method=6) for _ in range(max(1, args.streams))]
+    mapper = mappers[0]
 
     nb = args.reads_per_step
     pe = args.mode == "pe"
     n_batches = min(args.steps + args.warmup, 10)
-    wl = Workload(torch, api, device, d_seq, seq_lengths, seq_offsets, pe, L, args.sub, args.indel, nb, n_batches, 1000 + 97 * rank)
+    wl = Workload(torch, api, device, d_seq, seq_lengths, seq_offsets, pe, L, args.sub, args.indel, nb, n_batches, 1000 + 97 * rank,
+                  streams=len(mappers))
     torch.cuda.synchronize()
     setup_s = time.time() - t_setup
 
-    dt, kms = wl.timed(mapper, args.steps, args.warmup, barrier=lambda: R.barrier(torch))
+    dt, kms = wl.timed(mappers, args.steps, args.warmup, barrier=lambda: R.barrier(torch))
     dt = R.max_over_ranks(torch, dt)
     reads_per_s = world * args.steps * nb / dt
 
@@ -705,7 +736,8 @@ def main():
             gather_loads_s = mapper.gather_microbench(1 << 28)
         except Exception:
             gather_loads_s = 0.0
-        kern = kernel_table(api, pe, L, nb, kms, counters, total_bp, gather_loads_s, None if pe else wl.stage_ms)
+        npl = nb // len(mappers)  # reads per launch: the batch is split over the contexts
+        kern = kernel_table(api, pe, L, npl, kms, counters, total_bp, gather_loads_s, None if pe else wl.stage_ms)
         dom = int(np.argmax([k["avg_ms"] if not k["kernel"].startswith("second pass") else 0.0 for k in kern]))
         dp_stats = wl.dp_stats
         key = "pe150" if pe else ("se150" if L == 150 else ("se250" if L == 250 else None))
@@ -725,7 +757,8 @@ def main():
             "config": {"workload": f"{L} bp {'PE mates (pairs interleaved)' if pe else 'SE reads'} vs synthetic hg38-shaped {args.genome_mbp:g} Mbp genome "
                                    f"({slots} slots = GetPrime({fasta_bytes} FASTA bytes / 0.6), {5 * slots / 1e9:.2f} GB slot table + "
                                    f"{len(seq_np) / 1e9:.2f} GB sequence resident in HBM); {nb} reads/step, {args.sub:g} sub, {args.indel:g} indel",
-                       "reads_per_step": nb, "read_len": L, "genome_bp": int(len(seq_np)), "slots": int(slots),
+                       "reads_per_step": nb, "streams": len(mappers), "reads_per_launch": nb // len(mappers),
+                       "read_len": L, "genome_bp": int(len(seq_np)), "slots": int(slots),
                        "genome": genome_desc, "ranks": {"world": world, "backend": R.backend, "share_devices": bool(R.shared)},
                        "setup_s": {"genome": round(t_gen, 1), **t_index, "total": round(setup_s, 1)}},
             "roofline": {"bound": "hbm", "kernel": kern[dom]["kernel"], "achieved": kern[dom]["achieved_GBs"],
@@ -737,6 +770,9 @@ def main():
                          "random_gather_peak": {"slot_reads_per_s": round(gather_loads_s), "sector_GBs": round(64.0 * gather_loads_s / 1e9, 1),
                                                 "note": "measured in this run: independent random 5-byte slot reads over the resident table, 64 B sector each"}},
             "kernels": kern,
+            "kernels_note": (f"a step = {len(mappers)} contexts x {nb // len(mappers)} reads on HIP streams of their own (urmap -streams {len(mappers)}): "
+                             "avg_ms is per launch and launches of different contexts overlap, so the rows add up to more than ms_per_step"
+                             if len(mappers) > 1 else "one context: the rows add up to ms_per_step"),
             "parity": parity,
             "work_per_read": {k: round(v, 2) for k, v in counters.items()},
         }
@@ -756,10 +792,10 @@ def main():
                 t0 = time.time()
                 del wl
                 torch.cuda.empty_cache()
-                wl = Workload(torch, api, device, d_seq, seq_lengths, seq_offsets, ope, oL, osub, oindel, nb, 3, 5000)
-                odt, okms = wl.timed(mapper, 5, 1)
+                wl = Workload(torch, api, device, d_seq, seq_lengths, seq_offsets, ope, oL, osub, oindel, nb, 3, 5000, streams=len(mappers))
+                odt, okms = wl.timed(mappers, 5, 1)
                 opar, ocnt, ot = wl.check(oi, min(nb, 200_000), cores)
-                okern = kernel_table(api, ope, oL, nb, okms, ocnt, total_bp, gather_loads_s, None if ope else wl.stage_ms)
+                okern = kernel_table(api, ope, oL, npl, okms, ocnt, total_bp, gather_loads_s, None if ope else wl.stage_ms)
                 others[name] = {"metric": metric_name(ope, oL), "value": round(5 * nb / odt, 1), "unit": "reads/s", "steps": 5, "warmup": 1,
                                 "ms_per_step": round(1e3 * odt / 5, 3), "kernels": okern, "parity": opar,
                                 "work_per_read": {k: round(v, 2) for k, v in ocnt.items()},

@@ -21,10 +21,10 @@ slots, _ = bench.default_slot_count(lens, labels)
 index, blob_np, seq_np, d_seq, tm = bench.place_index(R, torch, api, dev, d_seq, slots, lens, offs, labels)
 m = api.Mapper(index, device=0)
 wl = bench.Workload(torch, api, dev, d_seq, lens, offs, True, 150, 0.01, 0.001, n, 3, 4242)
-for s in (0, 1, 2, 3, 4, 5, 0):
+for s in (0, 1, 2, 3, 41, 42, 43, 4, 5, 0):
     if s:
         os.environ["URMAPX_DEBUG_STOP_PE"] = str(s)
     else:
         os.environ.pop("URMAPX_DEBUG_STOP_PE", None)
-    dt, kms = wl.timed(m, 3, 1)
+    dt, kms = wl.timed([m], 3, 1)
     print(f"stop {s}: probe {kms[0]:.2f} ms, search {kms[1]:.2f} ms", flush=True)

@@ -28,7 +28,7 @@ slots, _ = bench.default_slot_count(lens, labels)
 index, blob_np, seq_np, d_seq, tm = bench.place_index(R, torch, api, dev, d_seq, slots, lens, offs, labels)
 m = api.Mapper(index, device=0)
 wl = bench.Workload(torch, api, dev, d_seq, lens, offs, False, L, sub, indel, n, 2, 4242)
-dt, kms = wl.timed(m, 2, 1)
+dt, kms = wl.timed([m], 2, 1)
 print(f"genome {mbp} Mbp {desc}\nL={L} sub={sub} indel={indel} n={n}: kernels ms {kms}, {2 * n / dt:.0f} reads/s")
 pc = m.phase_cycles()
 sub8, pc = pc[8:], pc[:8]

@@ -29,7 +29,7 @@ wl = bench.Workload(torch, api, dev, d_seq, lens, offs, False, L, sub, indel, n,
 print(f"genome {mbp} Mbp, L={L} sub={sub} indel={indel} n={n}")
 os.environ.pop("URMAPX_PHASE_STATS", None)
 os.environ.pop("URMAPX_DEBUG_STOP", None)
-dt, kms = wl.timed(m, 3, 1)
+dt, kms = wl.timed([m], 3, 1)
 print(f"production kernel: probe {kms[0]:.2f} ms, search {kms[1]:.2f} ms; stages (main, dp, finalize, main2, dp2, finalize2) " + ", ".join(f"{x:.2f}" for x in m.stage_ms()) + f"; dp stats {m.dp_stats()}")
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 if os.environ.get("SWEEP_CHECK"):
@@ -39,5 +39,5 @@ if os.environ.get("SWEEP_CHECK"):
     print("parity", par)
 for s in stops:
     os.environ["URMAPX_DEBUG_STOP"] = str(s)
-    dt, kms = wl.timed(m, 3, 1)
+    dt, kms = wl.timed([m], 3, 1)
     print(f"stop {s:4d}: search {kms[1]:8.2f} ms")

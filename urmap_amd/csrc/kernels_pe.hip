@@ -89,7 +89,8 @@ struct Mate {
 	}
 	uint32_t *hsp_db, *hsp_ql;  // LDS [PE_HSP_CAP]
 	uint16_t *hsp_sf;
-	uint2 *hsp_ovf;   // OVF pass only: HSPs hsp_lds.. in global scratch as {db, startq | len << 9 | sf << 18}
+	uint2 *hsp_ovf;   // HSPs hsp_lds.. in global scratch as {db, startq | len << 9 | sf << 18}
+	int dbg_cut = 0;  // diagnostic only (URMAPX_DEBUG_STOP_PE 41 / 42 / 43): leave search_pending after that part
 	int hsp_lds;      // HSPs kept in LDS (PE_HSP_CAP; a test aid lowers it)
 	uint8_t *pend[2];     // LDS [QMAX] each: pending query positions (stored in a byte, state1.h:86-87)
 	uint8_t *rowlen;      // LDS [2 * QMAX]: row length of every pending position, [strand][i]
@@ -466,6 +467,7 @@ struct Mate {
 			for (int k = 0; k < hspCount; ++k) align_hsp(k);
 			if (best >= minScore1) { mapq = calc_mapq(); return; }
 		}
+		if (dbg_cut == 41) { mapq = calc_mapq(); return; }
 		const int minhsp = (int)((uint32_t)P->min_hsp_score_pct * (uint32_t)QL / 100.0);
 		const uint64_t N = X->slotCount;
 		const int maxIx = (int)X->maxIx;
@@ -505,6 +507,7 @@ struct Mate {
 			}
 		}
 		__syncthreads();
+		if (dbg_cut == 42) { mapq = calc_mapq(); return; }
 		// 2. the four groups in the reference's order.  Candidates that survive the hit-diagonal filter are compacted, in
 		// order, into a 128-entry LDS queue (reference position, query position | plus << 15), so that the gather below
 		// always runs on full batches even though most (round, strand, chunk) groups hold only a few row entries.
@@ -603,6 +606,7 @@ struct Mate {
 			}
 		}
 		drain(true);
+		if (dbg_cut == 43) { mapq = calc_mapq(); return; }
 		const int bmin = max(best, bestHSP) - 8;
 		for (int k = 0; k < hspCount; ++k) {
 			if (hsp_score(k) < bmin) continue;
@@ -771,6 +775,7 @@ __global__ __launch_bounds__(64) void search_pe_kernel(DevIndex X, urmapx_params
 		m[a].rowlen = rowlen; m[a].pre = pre; m[a].cq_db = cq_db; m[a].cq_qp = cq_qp;
 		m[a].hsp_lds = (hsp_lds_cap >= 64 && hsp_lds_cap <= PE_HSP_CAP) ? (hsp_lds_cap & ~63) : PE_HSP_CAP;
 		m[a].hsp_ovf = hsp_ovf_base + ((size_t)blockIdx.x * 2 + a) * PE_HSP_OVF_CAP;
+		m[a].dbg_cut = dbg_stop;
 		m[a].rowstore = reinterpret_cast<uint32_t *>(sc + pe_rowstore_offset(QMAX));
 		m[a].ws.carve(sc + (size_t)2 * PE_HIT_CAP * URMAPX_MAX_PATH_OPS * 2, QMAX, PE_SCAN_SEG + 2 * QMAX + 64);
 	}
@@ -1059,7 +1064,7 @@ __global__ __launch_bounds__(64) void search_pe_kernel(DevIndex X, urmapx_params
 		if (!done) {
 			m[0].search_pending();
 			m[1].search_pending();
-			if (dbg_stop == 4) goto pe_output;
+			if (dbg_stop == 4 || (dbg_stop >= 41 && dbg_stop <= 43)) goto pe_output;
 			// FindPairs (state2.cpp:20-85), ScanPair if there is none (state2.cpp:87-137), FindPairs again
 			for (int attempt = 0; attempt < 2; ++attempt) {
 				npairs_found = 0; bestPairScore = -1; secondPairScore = -1; bestPairIndex = -1; secondPairIndex = -1;
