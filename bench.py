@@ -434,6 +434,7 @@ class Workload:
     def timed(self, mappers, steps, warmup, barrier=None):
         """W untimed steps, then K timed ones -> (seconds, mean ms per launch [probe, search]); stage_ms / dp_stats too"""
         mappers = list(mappers)[: len(self.parts)]
+        self.torch.cuda.synchronize()  # the batches were written on torch's stream; the contexts run on streams of their own
         for w in range(warmup):
             self.step(mappers, w)
         for m in mappers:
