@@ -158,7 +158,8 @@ def test_viterbi_matches_oracle(gpu):
 
 @pytest.mark.parametrize("read_len,sub,indel,n", [(150, 0.01, 0.001, 3000), (250, 0.04, 0.01, 1500),
                                                    (100, 0.02, 0.004, 1500), (30, 0.0, 0.0, 500),
-                                                   (300, 0.03, 0.008, 1000)])  # 150/100/30: 192-base kernel class, 250: 256, 300: 320
+                                                   (300, 0.03, 0.008, 1000), (400, 0.02, 0.006, 600),
+                                                   (512, 0.03, 0.004, 400)])  # 150/100/30: 192-base kernel class, 250: 256, 300: 320, 400/512: 512
 def test_map_se_matches_oracle(small_case, gpu, read_len, sub, indel, n):
     """State1::Search end to end (search1.cpp:7-24): top hit, scores, MAPQ, path -- bit-exact."""
     from urmap_amd import synth
@@ -256,7 +257,7 @@ def test_pe_on_dense_index_walks_long_links(dense_case, tmp_path):
         raise AssertionError(f"{len(bad)} differing records of {len(w)}, first: {g[bad[0]][:200]!r} vs {w[bad[0]][:200]!r}")
 
 
-@pytest.mark.parametrize("lo,hi", [(24, 128), (24, 192), (24, 256), (24, 320)])
+@pytest.mark.parametrize("lo,hi", [(24, 128), (24, 192), (24, 256), (24, 320), (300, 512)])
 def test_map_se_mixed_lengths_in_one_batch(small_case, gpu, lo, hi):
     """A batch is run by the kernel instance of its longest read: reads of every length from W up to the class limit in
     one batch, each class limit in turn."""
@@ -298,8 +299,8 @@ def test_results_do_not_depend_on_scheduling(small_case, gpu):
 def test_bad_lengths_are_flagged(small_case, gpu):
     """Reads shorter than W or longer than the device cap are reported, not silently mis-mapped."""
     from urmap_amd import api
-    seqs = [np.frombuffer(b"ACGTACGTACGTACGT", np.uint8), np.frombuffer(b"ACGT" * 100, np.uint8)]
-    offs = np.array([0, 16, 416], dtype=np.uint64)
+    seqs = [np.frombuffer(b"ACGTACGTACGTACGT", np.uint8), np.frombuffer(b"ACGT" * 150, np.uint8)]
+    offs = np.array([0, 16, 616], dtype=np.uint64)
     with pytest.raises(api.UrmapxError) as e:
         gpu["mapper"].map_se(np.concatenate(seqs), offs)
     assert e.value.code == api.E_UNSUPPORTED

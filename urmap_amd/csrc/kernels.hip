@@ -128,7 +128,10 @@ __global__ __launch_bounds__(256) void seed_probe_kernel(DevIndex X, const uint8
 	else if (NCH >= 2 && nc == 2) probe_chunks<NCH, (NCH >= 2 ? 2 : 1)>(X, lo, hi, inv, invm, lane, QL, nwords, base2, out);
 	else if (NCH >= 3 && nc == 3) probe_chunks<NCH, (NCH >= 3 ? 3 : 1)>(X, lo, hi, inv, invm, lane, QL, nwords, base2, out);
 	else if (NCH >= 4 && nc == 4) probe_chunks<NCH, (NCH >= 4 ? 4 : 1)>(X, lo, hi, inv, invm, lane, QL, nwords, base2, out);
-	else if (NCH >= 5) probe_chunks<NCH, (NCH >= 5 ? 5 : 1)>(X, lo, hi, inv, invm, lane, QL, nwords, base2, out);
+	else if (NCH >= 5 && nc == 5) probe_chunks<NCH, (NCH >= 5 ? 5 : 1)>(X, lo, hi, inv, invm, lane, QL, nwords, base2, out);
+	else if (NCH >= 6 && nc == 6) probe_chunks<NCH, (NCH >= 6 ? 6 : 1)>(X, lo, hi, inv, invm, lane, QL, nwords, base2, out);
+	else if (NCH >= 7 && nc == 7) probe_chunks<NCH, (NCH >= 7 ? 7 : 1)>(X, lo, hi, inv, invm, lane, QL, nwords, base2, out);
+	else if (NCH >= 8) probe_chunks<NCH, (NCH >= 8 ? 8 : 1)>(X, lo, hi, inv, invm, lane, QL, nwords, base2, out);
 }
 
 
@@ -735,7 +738,7 @@ struct SearchWave {
 #ifndef SEARCH_WAVES_NCH4
 #define SEARCH_WAVES_NCH4 3
 #endif
-#define SEARCH_WAVES_PER_EU(NCH) ((NCH) <= 3 ? SEARCH_WAVES_NCH3 : (NCH) == 4 ? SEARCH_WAVES_NCH4 : 2)
+#define SEARCH_WAVES_PER_EU(NCH) ((NCH) <= 3 ? SEARCH_WAVES_NCH3 : (NCH) == 4 ? SEARCH_WAVES_NCH4 : (NCH) == 5 ? 2 : 1)
 // DBG = true: the diagnostic instantiation (URMAPX_PHASE_STATS / URMAPX_DEBUG_STOP): per-phase cycle stamps, per-read
 // cycle counts and schedule cuts.  The production instantiation (DBG = false) contains none of that code.
 template <int NCH, bool OVF, bool DBG>
@@ -1279,7 +1282,7 @@ __global__ __launch_bounds__(64) void finalize_se_kernel(DevIndex X, urmapx_para
 
 size_t dp_state_words(bool ovf) { return ovf ? (size_t)SearchWave<3, true>::STATE_WORDS : (size_t)SearchWave<3, false>::STATE_WORDS; }
 size_t dp_scratch_stride(uint32_t max_read_len) {
-	const int qmax = 64 * (max_read_len <= 128 ? 2 : max_read_len <= 192 ? 3 : max_read_len <= 256 ? 4 : 5);
+	const int qmax = 64 * (max_read_len <= 128 ? 2 : max_read_len <= 192 ? 3 : max_read_len <= 256 ? 4 : max_read_len <= 320 ? 5 : 8);
 	return (WideScratch::bytes(qmax, qmax + 64) + 255) & ~(size_t)255;
 }
 
@@ -1291,6 +1294,7 @@ static int nch_for(uint32_t max_read_len) {
 	if (max_read_len <= 192) return 3;
 	if (max_read_len <= 256) return 4;  // 250 bp reads: smaller per-read state than the 320-base class, one more wave per SIMD
 	if (max_read_len <= 320) return 5;
+	if (max_read_len <= 512) return 8;  // 1 wave per SIMD: eight mask words and 32 window loads per lane
 	return 0;
 }
 
@@ -1311,7 +1315,8 @@ int search_block_count(uint32_t max_read_len, int device) {
 	hipError_t e = nchq == 2   ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, search_se_kernel<2, false, false>, 64, 0)
 	               : nchq == 3 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, search_se_kernel<3, false, false>, 64, 0)
 	               : nchq == 4 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, search_se_kernel<4, false, false>, 64, 0)
-	                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, search_se_kernel<5, false, false>, 64, 0);
+	               : nchq == 5 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, search_se_kernel<5, false, false>, 64, 0)
+	                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, search_se_kernel<8, false, false>, 64, 0);
 	if (e != hipSuccess || per_cu < 1) per_cu = 8;
 	return per_cu * prop.multiProcessorCount;
 }
@@ -1352,7 +1357,8 @@ hipError_t launch_seed_probe(const DevIndex &X, const uint8_t *d_bases, const ui
 	if (nch == 2) hipLaunchKernelGGL(seed_probe_kernel<2>, grid, block, 0, s, X, d_bases, d_offs, n, out);
 	else if (nch == 3) hipLaunchKernelGGL(seed_probe_kernel<3>, grid, block, 0, s, X, d_bases, d_offs, n, out);
 	else if (nch == 4) hipLaunchKernelGGL(seed_probe_kernel<4>, grid, block, 0, s, X, d_bases, d_offs, n, out);
-	else hipLaunchKernelGGL(seed_probe_kernel<5>, grid, block, 0, s, X, d_bases, d_offs, n, out);
+	else if (nch == 5) hipLaunchKernelGGL(seed_probe_kernel<5>, grid, block, 0, s, X, d_bases, d_offs, n, out);
+	else hipLaunchKernelGGL(seed_probe_kernel<8>, grid, block, 0, s, X, d_bases, d_offs, n, out);
 	return hipGetLastError();
 }
 
@@ -1402,13 +1408,15 @@ hipError_t launch_search_se(const DevIndex &X, const urmapx_params &P, const uin
 	else if (nch == 2) URX_LAUNCH_SE(2, false, false, grid, wk.stats, no_ovf, wk.dp[0]);
 	else if (nch == 3) URX_LAUNCH_SE(3, false, false, grid, wk.stats, no_ovf, wk.dp[0]);
 	else if (nch == 4) URX_LAUNCH_SE(4, false, false, grid, wk.stats, no_ovf, wk.dp[0]);
-	else URX_LAUNCH_SE(5, false, false, grid, wk.stats, no_ovf, wk.dp[0]);
+	else if (nch == 5) URX_LAUNCH_SE(5, false, false, grid, wk.stats, no_ovf, wk.dp[0]);
+	else URX_LAUNCH_SE(8, false, false, grid, wk.stats, no_ovf, wk.dp[0]);
 	stamp(1);
 	if (wk.dp[0].jobs && !diag) {
 		if (nch == 2) URX_LAUNCH_DP(2, false, 0);
 		else if (nch == 3) URX_LAUNCH_DP(3, false, 0);
 		else if (nch == 4) URX_LAUNCH_DP(4, false, 0);
-		else URX_LAUNCH_DP(5, false, 0);
+		else if (nch == 5) URX_LAUNCH_DP(5, false, 0);
+		else URX_LAUNCH_DP(8, false, 0);
 	} else
 		stamp(2);
 	stamp(3);
@@ -1426,13 +1434,15 @@ hipError_t launch_search_se(const DevIndex &X, const urmapx_params &P, const uin
 	if (nch == 2) URX_LAUNCH_SE(2, true, false, grid2, no_stats, ovf_base, wk.dp[1]);
 	else if (nch == 3) URX_LAUNCH_SE(3, true, false, grid2, no_stats, ovf_base, wk.dp[1]);
 	else if (nch == 4) URX_LAUNCH_SE(4, true, false, grid2, no_stats, ovf_base, wk.dp[1]);
-	else URX_LAUNCH_SE(5, true, false, grid2, no_stats, ovf_base, wk.dp[1]);
+	else if (nch == 5) URX_LAUNCH_SE(5, true, false, grid2, no_stats, ovf_base, wk.dp[1]);
+	else URX_LAUNCH_SE(8, true, false, grid2, no_stats, ovf_base, wk.dp[1]);
 	stamp(4);
 	if (wk.dp[1].jobs) {
 		if (nch == 2) URX_LAUNCH_DP(2, true, 1);
 		else if (nch == 3) URX_LAUNCH_DP(3, true, 1);
 		else if (nch == 4) URX_LAUNCH_DP(4, true, 1);
-		else URX_LAUNCH_DP(5, true, 1);
+		else if (nch == 5) URX_LAUNCH_DP(5, true, 1);
+		else URX_LAUNCH_DP(8, true, 1);
 	} else
 		stamp(5);
 	stamp(6);
@@ -1449,7 +1459,8 @@ int dp_block_count(uint32_t max_read_len, int device) {
 	hipError_t e = nchq == 2   ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dp_kernel<2>, 64, 0)
 	               : nchq == 3 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dp_kernel<3>, 64, 0)
 	               : nchq == 4 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dp_kernel<4>, 64, 0)
-	                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dp_kernel<5>, 64, 0);
+	               : nchq == 5 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dp_kernel<5>, 64, 0)
+	                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dp_kernel<8>, 64, 0);
 	if (e != hipSuccess || per_cu < 1) per_cu = 8;
 	return per_cu * prop.multiProcessorCount;
 }

@@ -19,6 +19,7 @@ const uint32_t MAGIC3 = ('U' << 24) | ('F' << 16) | ('I' << 8) | '3';
 const uint32_t MAGIC5 = ('U' << 24) | ('F' << 16) | ('I' << 8) | '5';
 const size_t SEQ_TAIL_PAD = 4096;  // zero bytes after the sequence: windows may run past the end
 const size_t BLOB_TAIL_PAD = 8;    // the last slot is fetched with an 8-byte load
+const uint32_t MAX_QL_PE = 320;    // kernel classes of the pair kernel (pairs themselves: <= 279 bases per mate, flagged per read)
 
 int hip_rc(hipError_t e) {
 	if (e == hipSuccess) return URMAPX_OK;
@@ -102,13 +103,13 @@ struct urmapx_ctx {
 	DevBuf<urmapx_pair_info> pairinfo;
 	DevBuf<uint32_t> ovflist;  // reads queued for the search kernel's second pass
 	DevBuf<uint8_t> dpbuf, dpscratch;  // phase 6 as its own launches: jobs, paths, parked read states (kernels.h: DpWork)
-	int dp_blocks[4] = {0, 0, 0, 0};
+	int dp_blocks[5] = {0, 0, 0, 0, 0};
 	hipEvent_t stage_ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 	bool stage_valid = false;
 	uint32_t pairinfo_n = 0;
 	uint32_t stats_reads = 0;  // diagnostics: reads of the last single-end call with per-read cycle counts
 	int pe_blocks[4] = {0, 0, 0, 0};
-	int blocks[4] = {0, 0, 0, 0};  // persistent grid size of the search kernel for read length classes <=192, <=320, <=256
+	int blocks[5] = {0, 0, 0, 0, 0};  // persistent grid size of the search kernel for read length classes <=192, <=320, <=256, <=128, <=512
 };
 
 extern "C" {
@@ -383,7 +384,7 @@ int urmapx_map_se_device(urmapx_ctx *C, const void *d_bases, const void *d_offs,
 	int rc = ensure_probe(C, total_bases);
 	if (rc) return rc;
 	ProbeOut po{C->slots.p, C->tallies.p, C->positions.p};
-	const int cls = max_read_len <= 128 ? 3 : max_read_len <= 192 ? 0 : (max_read_len <= 256 ? 2 : 1);
+	const int cls = max_read_len <= 128 ? 3 : max_read_len <= 192 ? 0 : max_read_len <= 256 ? 2 : max_read_len <= 320 ? 1 : 4;
 	if (C->blocks[cls] == 0) {
 		C->blocks[cls] = search_block_count(max_read_len, C->device);
 		if (getenv("URMAPX_VERBOSE")) fprintf(stderr, "urmapx: search_se_kernel grid = %d persistent blocks (read class %d)\n", C->blocks[cls], cls);
@@ -516,7 +517,7 @@ int urmapx_ctx_set_pe_veryfast(urmapx_ctx *C, int on) {
 int urmapx_map_pe_device(urmapx_ctx *C, const void *d_bases, const void *d_offs, uint32_t npairs, uint64_t total_bases,
                          uint32_t max_read_len, void *d_results, void *d_path_ops, void *d_path_used) {
 	if (!C || (npairs && (!d_bases || !d_offs || !d_results || !d_path_ops || !d_path_used))) return URMAPX_E_ARG;
-	if (max_read_len > URMAPX_MAX_QL || npairs > 0x7FFFFFFFu) return URMAPX_E_UNSUPPORTED;
+	if (max_read_len > MAX_QL_PE || npairs > 0x7FFFFFFFu) return URMAPX_E_UNSUPPORTED;
 	HIP_TRY(hipSetDevice(C->device));
 	const uint32_t n = 2 * npairs;
 	int rc = ensure_probe(C, total_bases);
@@ -570,7 +571,7 @@ int urmapx_map_pe(urmapx_ctx *C, const uint8_t *bases, const uint64_t *offs, uin
 	const uint32_t n = 2 * npairs;
 	const uint64_t total = offs[n];
 	uint32_t mx = max_len(offs, n);
-	if (mx > URMAPX_MAX_QL) mx = URMAPX_MAX_QL;
+	if (mx > MAX_QL_PE) mx = MAX_QL_PE;
 	int rc;
 	if ((rc = C->bases.ensure(total + 64))) return rc;
 	if ((rc = C->offs.ensure((size_t)n + 1))) return rc;
