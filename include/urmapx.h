@@ -38,7 +38,7 @@ extern "C" {
 #define URMAPX_ST_BAND_TOO_WIDE 0x08 /* DP problem larger than the wide-band scratch (does not occur for reads <= URMAPX_MAX_QL) */
 #define URMAPX_ST_BAD_LENGTH 0x10    /* read shorter than the word length or longer than URMAPX_MAX_QL */
 
-#define URMAPX_MAX_QL 512     /* single-end; paired-end reads: 279 (the reference keeps pending seed positions in a byte) */
+#define URMAPX_MAX_QL 1024    /* single-end; paired-end reads: 279 (the reference keeps pending seed positions in a byte) */
 #define URMAPX_MAX_PATH_OPS 96
 
 typedef struct urmapx_index urmapx_index;

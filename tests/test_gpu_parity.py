@@ -159,7 +159,8 @@ def test_viterbi_matches_oracle(gpu):
 @pytest.mark.parametrize("read_len,sub,indel,n", [(150, 0.01, 0.001, 3000), (250, 0.04, 0.01, 1500),
                                                    (100, 0.02, 0.004, 1500), (30, 0.0, 0.0, 500),
                                                    (300, 0.03, 0.008, 1000), (400, 0.02, 0.006, 600),
-                                                   (512, 0.03, 0.004, 400)])  # 150/100/30: 192-base kernel class, 250: 256, 300: 320, 400/512: 512
+                                                   (512, 0.03, 0.004, 400), (700, 0.02, 0.004, 300),
+                                                   (1024, 0.02, 0.003, 200)])  # kernel classes: 150/100/30: 192 bases, 250: 256, 300: 320, 400/512: 512, 700/1024: 1024
 def test_map_se_matches_oracle(small_case, gpu, read_len, sub, indel, n):
     """State1::Search end to end (search1.cpp:7-24): top hit, scores, MAPQ, path -- bit-exact."""
     from urmap_amd import synth
@@ -257,7 +258,7 @@ def test_pe_on_dense_index_walks_long_links(dense_case, tmp_path):
         raise AssertionError(f"{len(bad)} differing records of {len(w)}, first: {g[bad[0]][:200]!r} vs {w[bad[0]][:200]!r}")
 
 
-@pytest.mark.parametrize("lo,hi", [(24, 128), (24, 192), (24, 256), (24, 320), (300, 512)])
+@pytest.mark.parametrize("lo,hi", [(24, 128), (24, 192), (24, 256), (24, 320), (300, 512), (500, 1024)])
 def test_map_se_mixed_lengths_in_one_batch(small_case, gpu, lo, hi):
     """A batch is run by the kernel instance of its longest read: reads of every length from W up to the class limit in
     one batch, each class limit in turn."""
@@ -299,8 +300,8 @@ def test_results_do_not_depend_on_scheduling(small_case, gpu):
 def test_bad_lengths_are_flagged(small_case, gpu):
     """Reads shorter than W or longer than the device cap are reported, not silently mis-mapped."""
     from urmap_amd import api
-    seqs = [np.frombuffer(b"ACGTACGTACGTACGT", np.uint8), np.frombuffer(b"ACGT" * 150, np.uint8)]
-    offs = np.array([0, 16, 616], dtype=np.uint64)
+    seqs = [np.frombuffer(b"ACGTACGTACGTACGT", np.uint8), np.frombuffer(b"ACGT" * 300, np.uint8)]
+    offs = np.array([0, 16, 1216], dtype=np.uint64)
     with pytest.raises(api.UrmapxError) as e:
         gpu["mapper"].map_se(np.concatenate(seqs), offs)
     assert e.value.code == api.E_UNSUPPORTED
@@ -742,3 +743,26 @@ def test_make_ufi_gpu_matches_oracle_on_dense_tables(tmp_path, load, maxix):
     # the array form (bench.py passes the sequence store resident on the device instead of a host array)
     blob = api.build_slots_gpu(0, slots, seqdata=oi.seqdata().copy(), max_ix=maxix)
     assert bytes(blob[:5 * slots]) == bytes(oi.blob())
+
+
+def test_cli_long_single_end_reads(small_case, tmp_path):
+    """600 and 1000 base reads through the command line (the 1024-base kernel class, FASTQ in, SAM with CIGAR out): the
+    oracle's SAM, record for record.  The reference's own scratch holds reads up to ~30 kb (state1.h:113); this build's
+    single-end device domain ends at 1024."""
+    import os
+    import subprocess
+    import oracle_lib as ol
+    from urmap_amd import synth
+    reads = synth.make_reads(61, small_case["genome"], 150, read_len=600, sub=0.02, ins=0.002, dele=0.002) + \
+        synth.make_reads(62, small_case["genome"], 100, read_len=1000, sub=0.01, ins=0.001, dele=0.002)
+    fq = os.path.join(tmp_path, "long.fq")
+    synth.write_fastq(fq, reads)
+    osam = os.path.join(tmp_path, "o.sam")
+    small_case["oracle_index"].map_file_se(fq, osam, threads=4)
+    out = os.path.join(tmp_path, "gpu.sam")
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "urmap_amd", "urmap")
+    r = subprocess.run([exe, "-map", fq, "-ufi", small_case["ufi"], "-samout", out, "-batch", "64"], stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    assert ol.sam_records(out) == ol.sam_records(osam)
+    assert sum(1 for l in ol.sam_records(out) if not l.startswith(b"@") and l.split(b"\t")[2] != b"*") > 200

@@ -14,7 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("URMAPX_LIB") or os.path.join(_HERE, "liburmapx.so")  # URMAPX_LIB: A/B builds
 
-MAX_QL = 512
+MAX_QL = 1024
 MAX_PATH_OPS = int(os.environ.get("URMAPX_MAX_PATH_OPS_OVERRIDE", 96))
 E_IO, E_FORMAT, E_NOMEM, E_NODEVICE, E_ARG = -1, -2, -3, -4, -5
 E_UNSUPPORTED = -6

@@ -32,7 +32,7 @@ namespace urx {
 // ------------------------------------------------------------------------------------------------
 // The k-mers of NC 64-position chunks of one read: all slot numbers first, then all 2*NC slot loads in flight
 // together, then the stores (the loads are random 64-byte sectors of a 26 GB table: their latency is the kernel).
-template <int NCH, int NC>
+template <int NCH, int NC, int C0 = 0>
 __device__ __forceinline__ void probe_chunks(const DevIndex &X, const uint64_t (&lo)[NCH + 1], const uint64_t (&hi)[NCH + 1],
                                              const uint64_t (&inv)[NCH + 1], const uint64_t (&invm)[NCH + 1], int lane,
                                              uint32_t QL, uint32_t nwords, uint64_t base2, const ProbeOut &out) {
@@ -43,13 +43,13 @@ __device__ __forceinline__ void probe_chunks(const DevIndex &X, const uint64_t (
 	bool vp[NC], vm[NC];
 #pragma unroll
 	for (int c = 0; c < NC; ++c) {
-		const uint32_t p = 64u * c + lane;
-		uint64_t flo = lo[c] >> lane, fhi = hi[c] >> lane, finv = inv[c] >> lane, finvm = invm[c] >> lane;
+		const uint32_t p = 64u * (C0 + c) + lane;
+		uint64_t flo = lo[C0 + c] >> lane, fhi = hi[C0 + c] >> lane, finv = inv[C0 + c] >> lane, finvm = invm[C0 + c] >> lane;
 		if (lane) {
-			flo |= lo[c + 1] << (64 - lane);
-			fhi |= hi[c + 1] << (64 - lane);
-			finv |= inv[c + 1] << (64 - lane);
-			finvm |= invm[c + 1] << (64 - lane);
+			flo |= lo[C0 + c + 1] << (64 - lane);
+			fhi |= hi[C0 + c + 1] << (64 - lane);
+			finv |= inv[C0 + c + 1] << (64 - lane);
+			finvm |= invm[C0 + c + 1] << (64 - lane);
 		}
 		flo &= wmask; fhi &= wmask; finv &= wmask; finvm &= wmask;
 		vp[c] = p < nwords && finv == 0;
@@ -72,7 +72,7 @@ __device__ __forceinline__ void probe_chunks(const DevIndex &X, const uint64_t (
 	}
 #pragma unroll
 	for (int c = 0; c < NC; ++c) {
-		const uint32_t p = 64u * c + lane;
+		const uint32_t p = 64u * (C0 + c) + lane;
 		if (p >= nwords) continue;
 		const uint64_t xp = (((uint64_t)rp[c][1] << 32) | rp[c][0]) >> (8u * (uint32_t)((5ull * sp[c]) & 3ull));
 		const uint64_t xm = (((uint64_t)rm[c][1] << 32) | rm[c][0]) >> (8u * (uint32_t)((5ull * sm[c]) & 3ull));
@@ -131,7 +131,11 @@ __global__ __launch_bounds__(256) void seed_probe_kernel(DevIndex X, const uint8
 	else if (NCH >= 5 && nc == 5) probe_chunks<NCH, (NCH >= 5 ? 5 : 1)>(X, lo, hi, inv, invm, lane, QL, nwords, base2, out);
 	else if (NCH >= 6 && nc == 6) probe_chunks<NCH, (NCH >= 6 ? 6 : 1)>(X, lo, hi, inv, invm, lane, QL, nwords, base2, out);
 	else if (NCH >= 7 && nc == 7) probe_chunks<NCH, (NCH >= 7 ? 7 : 1)>(X, lo, hi, inv, invm, lane, QL, nwords, base2, out);
-	else if (NCH >= 8) probe_chunks<NCH, (NCH >= 8 ? 8 : 1)>(X, lo, hi, inv, invm, lane, QL, nwords, base2, out);
+	else if (NCH >= 8 && nc <= 8) probe_chunks<NCH, (NCH >= 8 ? 8 : 1)>(X, lo, hi, inv, invm, lane, QL, nwords, base2, out);
+	else if constexpr (NCH >= 16) {  // long reads: two sweeps of eight chunks each
+		probe_chunks<NCH, 8, 0>(X, lo, hi, inv, invm, lane, QL, nwords, base2, out);
+		probe_chunks<NCH, 8, 8>(X, lo, hi, inv, invm, lane, QL, nwords, base2, out);
+	}
 }
 
 
@@ -191,6 +195,8 @@ __global__ __launch_bounds__(64) void viterbi_batch_kernel(urmapx_params P, cons
 //   consume  (order dependent, wave-uniform): only the candidates whose outcome can still change the search state
 //            are visited, in order: AddHitX / AddHSPX, penalty cap, early exits -- exactly as the reference
 // ------------------------------------------------------------------------------------------------
+// HSP record word: startq | len << 10 | score << 20 | aligned << 30 | plus << 31 (each field <= 1023)
+static constexpr uint32_t PK_MASK = 1023u, PK_LEN_SH = 10, PK_SCORE_SH = 20, PK_ALIGNED = 1u << 30, PK_PLUS_SH = 31;
 static constexpr int HSP_CAP = 256;        // HSPs of a read held in LDS
 static constexpr int SEARCH_OVF_BLOCKS = 2048;  // grid of the second pass (reads whose HSP list outgrew LDS): these are the
                                                 // costliest reads of a batch (hundreds of AlignHSP calls each), so they get most of the chip
@@ -215,11 +221,11 @@ __device__ __noinline__ int hsp_overflow_add(uint2 *ovf, int n, int cap, uint32_
 		const int i = base + lane;
 		bool eq = false;
 		uint2 e = make_uint2(0u, 0u);
-		if (i < n) { e = ovf[i]; eq = (e.x - (e.y & 511u)) == diag; }
+		if (i < n) { e = ovf[i]; eq = (e.x - (e.y & PK_MASK)) == diag; }
 		const uint64_t m = __ballot(eq);
 		if (m) {
 			const int l = __builtin_ctzll(m);
-			const int old = (int)((rdlane(e.y, l) >> 18) & 511u);
+			const int old = (int)((rdlane(e.y, l) >> PK_SCORE_SH) & PK_MASK);
 			if (score > old && lane == 0) ovf[base + l] = make_uint2(startdb, npk);
 			__syncthreads();
 			return 0;
@@ -252,7 +258,7 @@ struct SearchWave {
 	uint16_t *ropsL, *ropsR, *cand, *top;
 	uint16_t *pre;   // exclusive prefix of candidate counts, NSEG*64+1 entries
 	uint32_t *hsp_db;
-	uint32_t *hsp_pk;  // startq | len << 9 | score << 18 | aligned << 27 | plus << 28 (all <= 320: 9 bits each)
+	uint32_t *hsp_pk;  // PK_* packing: startq | len | score | aligned | plus
 	uint2 *hsp_ovf;    // global scratch of this block: HSPs hsp_lds.. as {db, pk} (reads in high-copy repeats only)
 	int hsp_lds;       // HSPs kept in LDS: HSP_CAP (a test aid lowers it to exercise the overflow path)
 	int hit_cap;       // first pass: 64 hits (the test aid lowers it along with hsp_lds)
@@ -322,16 +328,16 @@ struct SearchWave {
 	__device__ __forceinline__ void add_hsp(uint32_t startq, uint32_t startdb, bool plus, uint32_t len, int score) {
 		if (score < best - 4) return;
 		const uint32_t diag = startdb - startq;
-		const uint32_t npk = startq | (len << 9) | ((uint32_t)score << 18) | (plus ? 1u << 28 : 0u);
+		const uint32_t npk = startq | (len << PK_LEN_SH) | ((uint32_t)score << PK_SCORE_SH) | (plus ? 1u << PK_PLUS_SH : 0u);
 		const int nlds = hspCount < hsp_lds ? hspCount : hsp_lds;
 		for (int base = 0; base < nlds; base += 64) {  // the HSPs in LDS (all of them, except for reads in high-copy repeats)
 			const int i = base + lane;
 			bool eq = false;
-			if (i < nlds) eq = (hsp_db[i] - (hsp_pk[i] & 511u)) == diag;
+			if (i < nlds) eq = (hsp_db[i] - (hsp_pk[i] & PK_MASK)) == diag;
 			uint64_t m = __ballot(eq);
 			if (m) {
 				const int k = base + __builtin_ctzll(m);
-				const int old = (int)((hsp_pk[k] >> 18) & 511u);
+				const int old = (int)((hsp_pk[k] >> PK_SCORE_SH) & PK_MASK);
 				if (score > old && lane == 0) { hsp_db[k] = startdb; hsp_pk[k] = npk; }
 				__syncthreads();
 				return;
@@ -369,15 +375,15 @@ struct SearchWave {
 		uint32_t startdb, pk;
 		if (k < hsp_lds) { startdb = hsp_db[k]; pk = hsp_pk[k]; }
 		else { const uint2 e = hsp_ovf[k - hsp_lds]; startdb = e.x; pk = e.y; }
-		if (pk & (1u << 27)) return;  // m_Aligned
+		if (pk & PK_ALIGNED) return;  // m_Aligned
 		__syncthreads();
 		if (lane == 0) {
-			if (k < hsp_lds) hsp_pk[k] = pk | (1u << 27);
-			else hsp_ovf[k - hsp_lds].y = pk | (1u << 27);
+			if (k < hsp_lds) hsp_pk[k] = pk | PK_ALIGNED;
+			else hsp_ovf[k - hsp_lds].y = pk | PK_ALIGNED;
 		}
-		const int startq = (int)(pk & 511u), len = (int)((pk >> 9) & 511u);
-		const int hscore = (int)((pk >> 18) & 511u);
-		const bool plus = (pk >> 28) & 1u;
+		const int startq = (int)(pk & PK_MASK), len = (int)((pk >> PK_LEN_SH) & PK_MASK);
+		const int hscore = (int)((pk >> PK_SCORE_SH) & PK_MASK);
+		const bool plus = (pk >> PK_PLUS_SH) & 1u;
 		__syncthreads();
 		int totalPen = len - hscore;
 		int totalScore = hscore;
@@ -479,8 +485,8 @@ struct SearchWave {
 	// AlignHSP's entry tests (alignhsp.cpp:62-70): not aligned yet, and HSP.Length - HSP.Score within the penalty cap
 	__device__ __forceinline__ bool hsp_wants_dp(int k, uint32_t &startdb, uint32_t &pk) const {
 		if (!hsp_get(k, startdb, pk)) return false;
-		if (pk & (1u << 27)) return false;
-		const int len = (int)((pk >> 9) & 511u), hscore = (int)((pk >> 18) & 511u);
+		if (pk & PK_ALIGNED) return false;
+		const int len = (int)((pk >> PK_LEN_SH) & PK_MASK), hscore = (int)((pk >> PK_SCORE_SH) & PK_MASK);
 		return len - hscore <= maxPen;
 	}
 
@@ -561,9 +567,9 @@ struct SearchWave {
 	// the same order against the CURRENT penalty cap, then AddHitX.  The DP outcome itself never depended on the state.
 	__device__ bool consume_job(const DpJob &J, const uint16_t *jops) {
 		const uint32_t pk = J.pk;
-		const int startq = (int)(pk & 511u), len = (int)((pk >> 9) & 511u);
-		const int hscore = (int)((pk >> 18) & 511u);
-		const bool plus = (pk >> 28) & 1u;
+		const int startq = (int)(pk & PK_MASK), len = (int)((pk >> PK_LEN_SH) & PK_MASK);
+		const int hscore = (int)((pk >> PK_SCORE_SH) & PK_MASK);
+		const bool plus = (pk >> PK_PLUS_SH) & 1u;
 		int totalPen = len - hscore;
 		int totalScore = hscore;
 		if (totalPen > maxPen) return false;
@@ -711,6 +717,7 @@ struct SearchWave {
 			carry += rdlane(inc, 63);
 		}
 		if (lane == 0) pre[NS * 64] = (uint16_t)carry;
+		if (carry > 0xFFFF) status |= URMAPX_ST_HSP_OVERFLOW;  // only a 1024-base read whose every k-mer owns a full chain gets here
 		__syncthreads();
 		return carry;
 	}
@@ -1115,7 +1122,7 @@ __global__ __launch_bounds__(64) void dp_kernel(DevIndex X, urmapx_params P, con
 		const DpJob J = dp.jobs[j];
 		if (J.read == 0xFFFFFFFFu) continue;
 		{  // AlignHSP's first test under the cap the replay has reached so far (the cap only falls)
-			const int glen = (int)((J.pk >> 9) & 511u), gscore = (int)((J.pk >> 18) & 511u);
+			const int glen = (int)((J.pk >> PK_LEN_SH) & PK_MASK), gscore = (int)((J.pk >> PK_SCORE_SH) & PK_MASK);
 			if (glen - gscore > J.maxpen) {
 				if (lane == 0) dp.jobs[j].flags = DPJ_GATED;
 				++n_gated;
@@ -1125,8 +1132,8 @@ __global__ __launch_bounds__(64) void dp_kernel(DevIndex X, urmapx_params P, con
 		const uint64_t off = offs[J.read];
 		const int QL = (int)(offs[J.read + 1] - off);
 		const uint32_t pk = J.pk, startdb = J.startdb;
-		const int startq = (int)(pk & 511u), len = (int)((pk >> 9) & 511u), hscore = (int)((pk >> 18) & 511u);
-		const bool plus = (pk >> 28) & 1u;
+		const int startq = (int)(pk & PK_MASK), len = (int)((pk >> PK_LEN_SH) & PK_MASK), hscore = (int)((pk >> PK_SCORE_SH) & PK_MASK);
+		const bool plus = (pk >> PK_PLUS_SH) & 1u;
 		__syncthreads();
 		{
 			const uint8_t *q = bases + off;
@@ -1282,7 +1289,7 @@ __global__ __launch_bounds__(64) void finalize_se_kernel(DevIndex X, urmapx_para
 
 size_t dp_state_words(bool ovf) { return ovf ? (size_t)SearchWave<3, true>::STATE_WORDS : (size_t)SearchWave<3, false>::STATE_WORDS; }
 size_t dp_scratch_stride(uint32_t max_read_len) {
-	const int qmax = 64 * (max_read_len <= 128 ? 2 : max_read_len <= 192 ? 3 : max_read_len <= 256 ? 4 : max_read_len <= 320 ? 5 : 8);
+	const int qmax = 64 * (max_read_len <= 128 ? 2 : max_read_len <= 192 ? 3 : max_read_len <= 256 ? 4 : max_read_len <= 320 ? 5 : max_read_len <= 512 ? 8 : 16);
 	return (WideScratch::bytes(qmax, qmax + 64) + 255) & ~(size_t)255;
 }
 
@@ -1295,6 +1302,7 @@ static int nch_for(uint32_t max_read_len) {
 	if (max_read_len <= 256) return 4;  // 250 bp reads: smaller per-read state than the 320-base class, one more wave per SIMD
 	if (max_read_len <= 320) return 5;
 	if (max_read_len <= 512) return 8;  // 1 wave per SIMD: eight mask words and 32 window loads per lane
+	if (max_read_len <= 1024) return 16;
 	return 0;
 }
 
@@ -1316,7 +1324,8 @@ int search_block_count(uint32_t max_read_len, int device) {
 	               : nchq == 3 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, search_se_kernel<3, false, false>, 64, 0)
 	               : nchq == 4 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, search_se_kernel<4, false, false>, 64, 0)
 	               : nchq == 5 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, search_se_kernel<5, false, false>, 64, 0)
-	                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, search_se_kernel<8, false, false>, 64, 0);
+	               : nchq == 8 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, search_se_kernel<8, false, false>, 64, 0)
+	                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, search_se_kernel<16, false, false>, 64, 0);
 	if (e != hipSuccess || per_cu < 1) per_cu = 8;
 	return per_cu * prop.multiProcessorCount;
 }
@@ -1358,7 +1367,8 @@ hipError_t launch_seed_probe(const DevIndex &X, const uint8_t *d_bases, const ui
 	else if (nch == 3) hipLaunchKernelGGL(seed_probe_kernel<3>, grid, block, 0, s, X, d_bases, d_offs, n, out);
 	else if (nch == 4) hipLaunchKernelGGL(seed_probe_kernel<4>, grid, block, 0, s, X, d_bases, d_offs, n, out);
 	else if (nch == 5) hipLaunchKernelGGL(seed_probe_kernel<5>, grid, block, 0, s, X, d_bases, d_offs, n, out);
-	else hipLaunchKernelGGL(seed_probe_kernel<8>, grid, block, 0, s, X, d_bases, d_offs, n, out);
+	else if (nch == 8) hipLaunchKernelGGL(seed_probe_kernel<8>, grid, block, 0, s, X, d_bases, d_offs, n, out);
+	else hipLaunchKernelGGL(seed_probe_kernel<16>, grid, block, 0, s, X, d_bases, d_offs, n, out);
 	return hipGetLastError();
 }
 
@@ -1409,14 +1419,16 @@ hipError_t launch_search_se(const DevIndex &X, const urmapx_params &P, const uin
 	else if (nch == 3) URX_LAUNCH_SE(3, false, false, grid, wk.stats, no_ovf, wk.dp[0]);
 	else if (nch == 4) URX_LAUNCH_SE(4, false, false, grid, wk.stats, no_ovf, wk.dp[0]);
 	else if (nch == 5) URX_LAUNCH_SE(5, false, false, grid, wk.stats, no_ovf, wk.dp[0]);
-	else URX_LAUNCH_SE(8, false, false, grid, wk.stats, no_ovf, wk.dp[0]);
+	else if (nch == 8) URX_LAUNCH_SE(8, false, false, grid, wk.stats, no_ovf, wk.dp[0]);
+	else URX_LAUNCH_SE(16, false, false, grid, wk.stats, no_ovf, wk.dp[0]);
 	stamp(1);
 	if (wk.dp[0].jobs && !diag) {
 		if (nch == 2) URX_LAUNCH_DP(2, false, 0);
 		else if (nch == 3) URX_LAUNCH_DP(3, false, 0);
 		else if (nch == 4) URX_LAUNCH_DP(4, false, 0);
 		else if (nch == 5) URX_LAUNCH_DP(5, false, 0);
-		else URX_LAUNCH_DP(8, false, 0);
+		else if (nch == 8) URX_LAUNCH_DP(8, false, 0);
+		else URX_LAUNCH_DP(16, false, 0);
 	} else
 		stamp(2);
 	stamp(3);
@@ -1435,14 +1447,16 @@ hipError_t launch_search_se(const DevIndex &X, const urmapx_params &P, const uin
 	else if (nch == 3) URX_LAUNCH_SE(3, true, false, grid2, no_stats, ovf_base, wk.dp[1]);
 	else if (nch == 4) URX_LAUNCH_SE(4, true, false, grid2, no_stats, ovf_base, wk.dp[1]);
 	else if (nch == 5) URX_LAUNCH_SE(5, true, false, grid2, no_stats, ovf_base, wk.dp[1]);
-	else URX_LAUNCH_SE(8, true, false, grid2, no_stats, ovf_base, wk.dp[1]);
+	else if (nch == 8) URX_LAUNCH_SE(8, true, false, grid2, no_stats, ovf_base, wk.dp[1]);
+	else URX_LAUNCH_SE(16, true, false, grid2, no_stats, ovf_base, wk.dp[1]);
 	stamp(4);
 	if (wk.dp[1].jobs) {
 		if (nch == 2) URX_LAUNCH_DP(2, true, 1);
 		else if (nch == 3) URX_LAUNCH_DP(3, true, 1);
 		else if (nch == 4) URX_LAUNCH_DP(4, true, 1);
 		else if (nch == 5) URX_LAUNCH_DP(5, true, 1);
-		else URX_LAUNCH_DP(8, true, 1);
+		else if (nch == 8) URX_LAUNCH_DP(8, true, 1);
+		else URX_LAUNCH_DP(16, true, 1);
 	} else
 		stamp(5);
 	stamp(6);
@@ -1460,7 +1474,8 @@ int dp_block_count(uint32_t max_read_len, int device) {
 	               : nchq == 3 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dp_kernel<3>, 64, 0)
 	               : nchq == 4 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dp_kernel<4>, 64, 0)
 	               : nchq == 5 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dp_kernel<5>, 64, 0)
-	                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dp_kernel<8>, 64, 0);
+	               : nchq == 8 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dp_kernel<8>, 64, 0)
+	                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dp_kernel<16>, 64, 0);
 	if (e != hipSuccess || per_cu < 1) per_cu = 8;
 	return per_cu * prop.multiProcessorCount;
 }

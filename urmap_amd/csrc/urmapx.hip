@@ -103,13 +103,13 @@ struct urmapx_ctx {
 	DevBuf<urmapx_pair_info> pairinfo;
 	DevBuf<uint32_t> ovflist;  // reads queued for the search kernel's second pass
 	DevBuf<uint8_t> dpbuf, dpscratch;  // phase 6 as its own launches: jobs, paths, parked read states (kernels.h: DpWork)
-	int dp_blocks[5] = {0, 0, 0, 0, 0};
+	int dp_blocks[6] = {0, 0, 0, 0, 0, 0};
 	hipEvent_t stage_ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 	bool stage_valid = false;
 	uint32_t pairinfo_n = 0;
 	uint32_t stats_reads = 0;  // diagnostics: reads of the last single-end call with per-read cycle counts
 	int pe_blocks[4] = {0, 0, 0, 0};
-	int blocks[5] = {0, 0, 0, 0, 0};  // persistent grid size of the search kernel for read length classes <=192, <=320, <=256, <=128, <=512
+	int blocks[6] = {0, 0, 0, 0, 0, 0};  // persistent grid size of the search kernel for read length classes <=192, <=320, <=256, <=128, <=512, <=1024
 };
 
 extern "C" {
@@ -384,7 +384,7 @@ int urmapx_map_se_device(urmapx_ctx *C, const void *d_bases, const void *d_offs,
 	int rc = ensure_probe(C, total_bases);
 	if (rc) return rc;
 	ProbeOut po{C->slots.p, C->tallies.p, C->positions.p};
-	const int cls = max_read_len <= 128 ? 3 : max_read_len <= 192 ? 0 : max_read_len <= 256 ? 2 : max_read_len <= 320 ? 1 : 4;
+	const int cls = max_read_len <= 128 ? 3 : max_read_len <= 192 ? 0 : max_read_len <= 256 ? 2 : max_read_len <= 320 ? 1 : max_read_len <= 512 ? 4 : 5;
 	if (C->blocks[cls] == 0) {
 		C->blocks[cls] = search_block_count(max_read_len, C->device);
 		if (getenv("URMAPX_VERBOSE")) fprintf(stderr, "urmapx: search_se_kernel grid = %d persistent blocks (read class %d)\n", C->blocks[cls], cls);
