@@ -1,4 +1,5 @@
-# GPU tests then stage timings at 800 Mbp (150 and 250 bp) with parity on 100k reads
 R=$GRAFT_REPO_ROOT; cd $R; mkdir -p gpurun_out/r2
-timeout 1500 python3 -m pytest tests -m gpu -x -q > gpurun_out/r2/pytest_gpu.txt 2>&1; tail -15 gpurun_out/r2/pytest_gpu.txt
-bash scripts/r2_sweeps.sh
+export URMAP_BENCH_INDEX_CACHE=/dev/shm/urmap_idx
+SWEEP_CHECK=200000 python3 scripts/stop_sweep.py 3100 150 0.01 0.001 1000000 0 2>&1 | grep "production\|parity"
+SWEEP_CHECK=200000 python3 scripts/stop_sweep.py 3100 250 0.04 0.01 1000000 0 2>&1 | grep "production\|parity"
+rm -rf /dev/shm/urmap_idx

@@ -215,13 +215,60 @@ __device__ __forceinline__ float viterbi_wave(const VPar P, const uint8_t *A, in
 		acc |= word << sh0;
 		if (((i0 + n) & 7) == 0) { tb[(i0 >> 3) * 64 + lane] = acc; acc = 0; }
 	};
+	// Eight rows in the interior of the band: no lane enters (column 0) or leaves (column LB) the matrix inside the
+	// block, so every band lane is a band cell in every row and the lane classes are constants -- most rows of a long
+	// flank are of this kind (lanes enter during the first and leave during the last ~13 rows only).
+	auto rows8_interior = [&](int i0) {
+		const int j0 = jbase + i0;
+		const uint8_t *Ap = A + i0;
+		uint32_t av[8], bv[8];
+		if constexpr (B_LDS) {
+			const uint8_t *Bp = B + j0;
+#pragma unroll
+			for (int k = 0; k < 8; ++k) { av[k] = Ap[k]; bv[k] = Bp[k]; }
+		} else {
+#pragma unroll
+			for (int k = 0; k < 8; ++k) { av[k] = Ap[k]; bv[k] = B[min(max(j0 + k, 0), LB - 1)]; }
+		}
+		uint32_t word = 0;
+#pragma unroll
+		for (int k = 0; k < 8; ++k) {
+			const float D = wave_shl1(Dn, NEG);
+			const float Mcur = M;
+			const float vraw = Mcur + GO;
+			const float v = real ? vraw : NEG;
+			const float Pm = wave_prefix_max(v - el);
+			const float I = wave_shr1(Pm, NEG) + el1;
+			uint32_t bits = D > Mcur ? TB_DM : 0u;
+			float xM = fmaxf(Mcur, D);
+			bits = I > xM ? TB_IM : bits;
+			xM = fmaxf(xM, I);
+			const float Mnew = xM + (av[k] == bv[k] ? 1.0f : MISf);
+			const float de = D + GE;
+			const uint32_t bMD = vraw >= de ? TB_MD : 0u;  // md = Mcur + GO = vraw: no column-0 cell in the block
+			const float Dnew = fmaxf(vraw, de);
+			const uint32_t bMI = vraw >= I + GE ? TB_MI : 0u;
+			bits |= bMD | bMI;
+			M = real ? Mnew : M;
+			Dn = real ? Dnew : Dn;
+			word |= (real ? bits : bits0c) << (4 * k);
+		}
+		tb[(i0 >> 3) * 64 + lane] = word;
+	};
 	{
 		row_general(0);  // the only row with special cases of its own (free gaps of a Left problem, the origin cell)
 		int i = 1;
+		// interior blocks: lane 1's column >= 1 at the block's first row, lane ND+1's column < LB at its last
+		const int int_lo = LA - dlo + 1, int_hi = LB - (dlo + ND - LA) - 7;  // first rows i0 with int_lo <= i0 < int_hi qualify
 		while (i < LA) {
-			const int n = min(8 - (i & 7), LA - i);
-			rows_upto8(i, n);
-			i += n;
+			if ((i & 7) == 0 && i + 8 <= LA && i >= int_lo && i < int_hi) {
+				rows8_interior(i);
+				i += 8;
+			} else {
+				const int n = min(8 - (i & 7), LA - i);
+				rows_upto8(i, n);
+				i += n;
+			}
 			if (aborted != nullptr && i < LA) {
 				const float best = rdlane(wave_prefix_max(fmaxf(M, Dn)), 63);
 				if (best + (float)(LA - i) < abort_below) { *aborted = true; __syncthreads(); return best; }
