@@ -418,7 +418,9 @@ int urmapx_map_se_device(urmapx_ctx *C, const void *d_bases, const void *d_offs,
 		wk.dp_scratch_stride = dp_scratch_stride(max_read_len);
 		if ((rc = C->dpscratch.ensure(wk.dp_scratch_stride * (size_t)wk.dp_blocks))) return rc;
 		wk.dp_scratch = C->dpscratch.p;
-		const uint32_t jobs_cap[2] = {n * 16u + 4096u, n * 16u + 65536u};
+		const uint64_t jc = (uint64_t)n * 16u;  // ~10x what a repeat-rich genome needs; beyond it the search kernel runs phase 6 itself
+		const uint32_t jobs_cap[2] = {(uint32_t)(jc < (1ull << 30) ? jc : (1ull << 30)) + 4096u,
+		                              (uint32_t)(jc < (1ull << 30) ? jc : (1ull << 30)) + 65536u};
 		const uint32_t fin_cap[2] = {n, n / 8u + 1024u};
 		size_t need = 64, at[2][6];
 		for (int p = 0; p < 2; ++p) {
