@@ -202,7 +202,10 @@ static constexpr int SEARCH_OVF_BLOCKS = 2048;  // grid of the second pass (read
                                                 // costliest reads of a batch (hundreds of AlignHSP calls each), so they get most of the chip
 static constexpr int HSP_TOTAL_CAP = 8192;  // beyond that: in the block's global scratch (the reference's list is unbounded;
                                             // 8192 > 2 strands x 127 k-mers x MaxIx 32 candidate diagonals of a 150 bp read)
-static constexpr int TICKET_CHUNK = 4;
+#ifndef URX_TICKET_CHUNK
+#define URX_TICKET_CHUNK 4
+#endif
+static constexpr int TICKET_CHUNK = URX_TICKET_CHUNK;
 static constexpr int ROW_CAP = 32;  // UFIndex m_MaxIx of every index this build accepts
 
 // per-block global scratch: chain rows, the wide-band DP trace, then the HSP overflow list
