@@ -254,6 +254,34 @@ typedef struct urmapx_map_report {  /* State1::HitStats' counters (state1.cpp:59
 int urmapx_map_files(urmapx_index *, const urmapx_map_options *, const char *fastq1, const char *fastq2, const char *samout,
                      const char *tabout, urmapx_map_report *report, char *err, size_t errcap);
 
+/* ---- FASTQ bytes in, SAM bytes out (both text stages of -map on the device) ---- */
+/* One chunk of a FASTQ file, cut after a record's last '\n', goes to the device as it lies in the file; line ends,
+ * record checks (FASTQSeqSource::GetNextLo, fastqseqsource.cpp:9-116), State1::Search and the SAM records
+ * (State1::SetSAM / SetSAM_Unmapped with output1.cpp:13's arguments, setsam.cpp:12-207) run there and the records' text
+ * comes back in input order.  A chunk the device parser does not take as it is ('\r', blank or missing lines, a
+ * malformed record, a target label over 160 bytes) is handed back untouched with report.reason set: the caller runs it
+ * through urmapx_fastq_* / urmapx_sam_se, which reproduce the reference's handling and messages. */
+typedef struct urmapx_text urmapx_text;
+#define URMAPX_TEXT_OK 0
+#define URMAPX_TEXT_CR 1          /* a '\r' in the chunk */
+#define URMAPX_TEXT_RAGGED 2      /* line count not a multiple of four, or no '\n' at the end of the chunk */
+#define URMAPX_TEXT_BAD_RECORD 3  /* '@' missing, a byte that is not a letter, #bases != #quals, blank line */
+#define URMAPX_TEXT_LONG_NAME 4   /* target label longer than the device formatter takes */
+#define URMAPX_TEXT_SAM_CAP 5     /* sam_cap < report.sam_bytes (nothing written) */
+#define URMAPX_TEXT_TOO_LARGE 6   /* chunk over 1 GiB */
+typedef struct urmapx_text_report {
+	uint32_t records;   /* reads of the chunk */
+	uint32_t reason;    /* URMAPX_TEXT_*; non-zero: nothing was written */
+	uint64_t sam_bytes; /* bytes of SAM text (written, or needed when reason is URMAPX_TEXT_SAM_CAP) */
+	uint64_t mapped_q, mapped_lowq, unmapped, unsupported; /* State1::HitStats' counters (output1.cpp:20-30) against minq */
+} urmapx_text_report;
+/* One per mapping context; calls on it run on the context's stream (one thread at a time per context). */
+int urmapx_text_create(urmapx_ctx *, urmapx_text **out);
+void urmapx_text_destroy(urmapx_text *);
+/* fastq[fastq_bytes] and sam[sam_cap] are host arrays (page-locked ones cross PCIe without a staging copy). */
+int urmapx_text_map_se(urmapx_text *, const char *fastq, size_t fastq_bytes, unsigned minq, char *sam, size_t sam_cap,
+                       urmapx_text_report *report);
+
 /* ---- FASTQ input (host) ---- */
 /* Batch form of FASTQSeqSource::GetNextLo (fastqseqsource.cpp:9-116) over LineReader (linereader.cpp:14-113):
  * plain or .gz by suffix; '\r' dropped; a final unterminated line counts; blank lines only at end of file; the same

@@ -1,0 +1,158 @@
+"""GPU tests of the text ends of `urmap -map` on the device (urmapx_text_map_se): a chunk of FASTQ bytes in, the bytes of
+its SAM records out.  Checked against the reference's golden SAM files, against the oracle's SAM for seeded reads, and
+against the host reader + host formatter of this library on the same bytes (FASTQSeqSource::GetNextLo,
+fastqseqsource.cpp:9-116; State1::SetSAM, setsam.cpp:12-207)."""
+import gzip
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def _records(b):
+    return [l for l in b.split(b"\n") if l and not l.startswith(b"@")]
+
+
+@pytest.fixture(scope="module")
+def golden(tmp_path_factory):
+    from urmap_amd import api
+    d = tmp_path_factory.mktemp("text")
+    ufi = os.path.join(d, "g.ufi")
+    with gzip.open(os.path.join(GOLD, "g.ufi.gz"), "rb") as z, open(ufi, "wb") as f:
+        f.write(z.read())
+    idx = api.Index.open(ufi).upload(0)
+    m = api.Mapper(idx, device=0)
+    yield {"index": idx, "mapper": m}
+    m.close()
+
+
+@pytest.mark.parametrize("name", ["se150", "se250", "se_short"])
+def test_golden_fastq_bytes_to_golden_sam_bytes(golden, name):
+    from urmap_amd import api
+    fq = open(os.path.join(GOLD, name + ".fq"), "rb").read()
+    sam, rep = golden["mapper"].map_text_se(fq)
+    assert rep["reason"] == api.TEXT_OK, rep
+    want = _records(open(os.path.join(GOLD, name + ".sam"), "rb").read())
+    assert _records(sam) == want
+    assert sam.endswith(b"\n") and len(sam) == rep["sam_bytes"] and rep["records"] == len(want)
+    mapped = [l for l in want if l.split(b"\t")[2] != b"*"]
+    assert rep["unmapped"] == len(want) - len(mapped)
+    assert rep["mapped_q"] == sum(1 for l in mapped if int(l.split(b"\t")[4]) >= 10)
+    assert rep["mapped_q"] + rep["mapped_lowq"] + rep["unmapped"] == rep["records"]
+
+
+def test_chunks_cut_at_record_ends_concatenate_to_the_whole(golden):
+    fq = open(os.path.join(GOLD, "se150.fq"), "rb").read()
+    lines = fq.split(b"\n")[:-1]
+    whole, _ = golden["mapper"].map_text_se(fq)
+    parts = []
+    for lo in range(0, len(lines), 4 * 37):
+        chunk = b"\n".join(lines[lo:lo + 4 * 37]) + b"\n"
+        sam, rep = golden["mapper"].map_text_se(chunk)
+        assert rep["reason"] == 0 and rep["records"] == len(chunk.split(b"\n")) // 4
+        parts.append(sam)
+    assert b"".join(parts) == whole
+    assert golden["mapper"].map_text_se(b"")[1]["records"] == 0
+
+
+def _fastq_text(reads, labels=None):
+    out = []
+    for i, (lab, s, q) in enumerate(reads):
+        lab = labels[i] if labels else lab
+        out.append(b"@" + (lab if isinstance(lab, bytes) else lab.encode()) + b"\n" + bytes(s) + b"\n+\n" + bytes(q) + b"\n")
+    return b"".join(out)
+
+
+@pytest.mark.parametrize("read_len,sub,indel,n", [(150, 0.03, 0.01, 3000), (250, 0.04, 0.02, 1500), (64, 0.02, 0.0, 1000),
+                                                   (700, 0.03, 0.01, 300)])
+def test_seeded_reads_equal_oracle_sam_and_host_formatter(small_case, tmp_path, read_len, sub, indel, n):
+    """Gapped alignments (CIGAR from the path, dangling-M rule), both strands, labels with blanks and /1 /2 endings, lower
+    case and IUPAC letters: the device text equals the oracle's SAM file and this library's host formatter."""
+    from urmap_amd import api, synth
+    from test_gpu_parity import mutate_edge_reads
+    idx = api.Index.open(small_case["ufi"]).upload(0)
+    m = api.Mapper(idx, device=0)
+    reads = synth.make_reads(4000 + read_len, small_case["genome"], n, read_len=read_len, sub=sub, ins=indel / 2, dele=indel / 2,
+                             random_frac=0.05)
+    reads = mutate_edge_reads(reads, read_len)
+    labels = []
+    for i, (lab, _, _) in enumerate(reads):
+        lab = lab if isinstance(lab, str) else lab.decode()
+        if i % 5 == 1: lab += " extra words\there"
+        if i % 5 == 2: lab += "/1"
+        if i % 5 == 3: lab += "/2 tail"
+        if i % 5 == 4: lab = lab + "/3"
+        if i % 97 == 0: lab = "x" * 150 + lab
+        if i % 101 == 0: lab = "\tleading blank"
+        labels.append(lab)
+    fq_text = _fastq_text(reads, labels)
+    fq = os.path.join(tmp_path, "r.fq")
+    open(fq, "wb").write(fq_text)
+    sam, rep = m.map_text_se(fq_text)
+    assert rep["reason"] == api.TEXT_OK and rep["records"] == n
+    osam = os.path.join(tmp_path, "o.sam")
+    small_case["oracle_index"].map_file_se(fq, osam, threads=4)
+    assert _records(sam) == _records(open(osam, "rb").read())
+    # the host reader and formatter of the library on the same bytes
+    lab2, bases, offs, quals = api.read_fastq_arrays(fq)
+    res, ops = m.map_se(bases, offs)
+    host = idx.sam_se(res, ops, lab2, bases, offs, quals)
+    assert sam == host
+    gapped = sum(1 for l in _records(sam) if (b"I" in l.split(b"\t")[5] or b"D" in l.split(b"\t")[5]))
+    assert indel == 0 or gapped > n // 50
+    m.close()
+    idx.close()
+
+
+def test_chunks_the_device_parser_hands_back(golden):
+    """'\\r', a missing final newline, a line count that is not a multiple of four, a malformed record, a blank line: nothing is
+    written and the reason says why (the host reader then deals with the chunk the way the reference does)."""
+    from urmap_amd import api
+    m = golden["mapper"]
+    fq = open(os.path.join(GOLD, "se150.fq"), "rb").read()
+    lines = fq.split(b"\n")[:-1]
+    ok = b"\n".join(lines[:40]) + b"\n"
+    assert m.map_text_se(ok)[1]["reason"] == api.TEXT_OK
+    assert m.map_text_se(ok.replace(b"\n", b"\r\n"))[1]["reason"] == api.TEXT_CR
+    assert m.map_text_se(ok[:-1])[1]["reason"] == api.TEXT_RAGGED
+    assert m.map_text_se(b"\n".join(lines[:39]) + b"\n")[1]["reason"] == api.TEXT_RAGGED
+    bad = list(lines[:40])
+    bad[5] = bad[5][:-1] + b"1"  # a digit among the bases
+    assert m.map_text_se(b"\n".join(bad) + b"\n")[1]["reason"] == api.TEXT_BAD_RECORD
+    bad = list(lines[:40])
+    bad[7] = bad[7][:-1]  # one quality byte short
+    assert m.map_text_se(b"\n".join(bad) + b"\n")[1]["reason"] == api.TEXT_BAD_RECORD
+    bad = list(lines[:40])
+    bad[8] = b"r" + bad[8][1:]  # '@' missing
+    assert m.map_text_se(b"\n".join(bad) + b"\n")[1]["reason"] == api.TEXT_BAD_RECORD
+    bad = list(lines[:36]) + [b"", b"", b"", b""]
+    assert m.map_text_se(b"\n".join(bad) + b"\n")[1]["reason"] == api.TEXT_BAD_RECORD
+    assert m.map_text_se(b"\n" * 1000)[1]["reason"] in (api.TEXT_RAGGED, api.TEXT_BAD_RECORD)
+    sam, rep = m.map_text_se(ok, sam_cap=100)
+    assert sam is None and rep["reason"] == api.TEXT_SAM_CAP and rep["sam_bytes"] == len(m.map_text_se(ok)[0])
+
+
+def test_reads_outside_the_device_domain_are_counted(golden, tmp_path):
+    """A read longer than URMAPX_MAX_QL, one shorter than the word and an empty one: their records are the host
+    formatter's for the same flagged results, and the report counts them."""
+    from urmap_amd import api
+    m, idx = golden["mapper"], golden["index"]
+    rng = np.random.default_rng(5)
+    long_read = bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), 1500))
+    fq_text = b"@long\n" + long_read + b"\n+\n" + b"I" * 1500 + b"\n@short\nACGT\n+\nIIII\n@empty\n\n+\n\n"
+    sam, rep = m.map_text_se(fq_text)
+    assert rep["reason"] == api.TEXT_OK and rep["records"] == 3 and rep["unsupported"] >= 1
+    fq = os.path.join(tmp_path, "odd.fq")
+    open(fq, "wb").write(fq_text)
+    lab, bases, offs, quals = api.read_fastq_arrays(fq)
+    res, ops = m.map_se(bases, offs, allow_unsupported=True)
+    assert sam == idx.sam_se(res, ops, lab, bases, offs, quals)
+    assert rep["unsupported"] == int((res["status"] != 0).sum())
+    recs = sam.split(b"\n")
+    assert recs[0].split(b"\t")[0] == b"long" and recs[0].split(b"\t")[9] in (long_read,)
+    assert recs[1] == b"short\t4\t*\t0\t0\t*\t*\t0\t0\tACGT\tIIII"

@@ -33,7 +33,7 @@ EXPORTS = (
     "urmapx_seed_probe", "urmapx_viterbi_batch", "urmapx_strerror", "urmapx_device_arch",
     "urmapx_make_ufi", "urmapx_build_slots", "urmapx_make_ufi_gpu", "urmapx_build_slots_gpu", "urmapx_sam_se", "urmapx_sam_header_sq", "urmapx_ctx_phase_cycles", "urmapx_ctx_read_cycles", "urmapx_ctx_stage_ms", "urmapx_ctx_dp_stats", "urmapx_map_pe", "urmapx_sam_pe", "urmapx_map_pe_device", "urmapx_ctx_set_pe_veryfast",
     "urmapx_fastq_open", "urmapx_fastq_next", "urmapx_fastq_error", "urmapx_fastq_close",
-    "urmapx_ctx_gather_microbench", "urmapx_map_files", "urmapx_ctx_set_pair_info", "urmapx_ctx_get_pair_info", "urmapx_tab_pe",
+    "urmapx_ctx_gather_microbench", "urmapx_map_files", "urmapx_text_create", "urmapx_text_destroy", "urmapx_text_map_se", "urmapx_ctx_set_pair_info", "urmapx_ctx_get_pair_info", "urmapx_tab_pe",
 )
 
 
@@ -58,6 +58,14 @@ class MapReport(C.Structure):
     _fields_ = [("reads", C.c_uint64), ("mapped_q", C.c_uint64), ("mapped_lowq", C.c_uint64), ("unmapped", C.c_uint64),
                 ("unsupported", C.c_uint64), ("seconds", C.c_double), ("parse_s", C.c_double), ("gpu_s", C.c_double),
                 ("format_s", C.c_double), ("write_s", C.c_double), ("host_threads", C.c_int), ("lanes", C.c_int)]
+
+
+class TextReport(C.Structure):
+    _fields_ = [("records", C.c_uint32), ("reason", C.c_uint32), ("sam_bytes", C.c_uint64), ("mapped_q", C.c_uint64),
+                ("mapped_lowq", C.c_uint64), ("unmapped", C.c_uint64), ("unsupported", C.c_uint64)]
+
+
+TEXT_OK, TEXT_CR, TEXT_RAGGED, TEXT_BAD_RECORD, TEXT_LONG_NAME, TEXT_SAM_CAP, TEXT_TOO_LARGE = range(7)
 
 
 class UrmapxError(RuntimeError):
@@ -134,6 +142,10 @@ def lib():
     L.urmapx_tab_pe.restype = C.c_size_t
     L.urmapx_tab_pe.argtypes = [vp, vp, vp, vp, cp, u32, u32, i32, vp, C.c_size_t]
     L.urmapx_map_files.argtypes = [vp, C.POINTER(MapOptions), cp, cp, cp, cp, C.POINTER(MapReport), cp, C.c_size_t]
+    L.urmapx_text_create.argtypes = [vp, C.POINTER(vp)]
+    L.urmapx_text_destroy.argtypes = [vp]
+    L.urmapx_text_destroy.restype = None
+    L.urmapx_text_map_se.argtypes = [vp, vp, C.c_size_t, C.c_uint, vp, C.c_size_t, C.POINTER(TextReport)]
     L.urmapx_fastq_open.argtypes = [cp, C.POINTER(vp)]
     L.urmapx_fastq_next.restype = C.c_int64
     L.urmapx_fastq_next.argtypes = [vp, u32] + [C.POINTER(vp)] * 5
@@ -356,6 +368,8 @@ class Mapper:
         self.device = device
         self.params = params if params is not None else params_for_method(method)
         h = C.c_void_p()
+        self._text = None
+        self.h = None
         _check(lib().urmapx_ctx_create(index.h, device, C.byref(self.params), C.byref(h)), "urmapx_ctx_create")
         self.h = h
 
@@ -486,7 +500,28 @@ class Mapper:
         paths = [decode_path(ops[i * MAX_PATH_OPS: i * MAX_PATH_OPS + int(nops[i])]) for i in range(n)]
         return scores, status, paths
 
+    def map_text_se(self, fastq: bytes, minq=10, sam_cap=None):
+        """A chunk of FASTQ text (cut after a record's last newline) -> (the SAM text of its records | None, report dict).
+        None with report['reason'] != TEXT_OK: the device parser does not take the chunk as it is (see urmapx.h)."""
+        if self._text is None:
+            t = C.c_void_p()
+            _check(lib().urmapx_text_create(self.h, C.byref(t)), "urmapx_text_create")
+            self._text = t
+        src = np.frombuffer(fastq, dtype=np.uint8)
+        cap = sam_cap if sam_cap is not None else 2 * len(src) + 4096 * 64
+        out = np.empty(max(1, cap), dtype=np.uint8)
+        rep = TextReport()
+        _check(lib().urmapx_text_map_se(self._text, src.ctypes.data if len(src) else None, len(src), minq, out.ctypes.data, cap, C.byref(rep)),
+               "urmapx_text_map_se")
+        d = {k: int(getattr(rep, k)) for k, _ in TextReport._fields_}
+        if rep.reason != TEXT_OK:
+            return None, d
+        return out[: rep.sam_bytes].tobytes(), d
+
     def close(self):
+        if self._text is not None:
+            lib().urmapx_text_destroy(self._text)
+            self._text = None
         if self.h:
             lib().urmapx_ctx_destroy(self.h)
             self.h = None

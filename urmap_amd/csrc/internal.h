@@ -1,0 +1,44 @@
+// internal.h -- pieces shared by the translation units behind the C ABI (urmapx.hip, text_gpu.hip).  Not installed.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/urmapx.h"
+
+namespace urx {
+
+inline int hip_rc(hipError_t e) {
+	if (e == hipSuccess) return URMAPX_OK;
+	if (e == hipErrorOutOfMemory) return URMAPX_E_NOMEM;
+	return URMAPX_E_NODEVICE;
+}
+#define HIP_TRY(x)                                    \
+	do {                                              \
+		hipError_t e_ = (x);                          \
+		if (e_ != hipSuccess) return urx::hip_rc(e_); \
+	} while (0)
+
+// device array that only grows
+template <class T>
+struct DevBuf {
+	T *p = nullptr;
+	size_t cap = 0;
+	int ensure(size_t n) {
+		if (n <= cap) return URMAPX_OK;
+		if (p) (void)hipFree(p);
+		p = nullptr; cap = 0;
+		size_t want = n + n / 4 + 64;
+		hipError_t e = hipMalloc((void **)&p, want * sizeof(T));
+		if (e != hipSuccess) { p = nullptr; return hip_rc(e); }
+		cap = want;
+		return URMAPX_OK;
+	}
+	void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+// what text_gpu.hip needs of a mapping context (defined in urmapx.hip)
+hipStream_t ctx_stream(urmapx_ctx *);
+int ctx_device(const urmapx_ctx *);
+const urmapx_index *ctx_index(const urmapx_ctx *);
+const uint32_t *index_dev_seq_lengths(const urmapx_index *);
+
+}  // namespace urx

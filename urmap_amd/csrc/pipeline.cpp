@@ -8,7 +8,16 @@
 // formats and writes their SAM with all host threads.  The reference fans reads over its OpenMP threads the same way
 // (map.cpp:58-61, seqsource.cpp:30-66) but writes in completion order; here records are written in input
 // order.  No data moves between devices.  The batch arrays that cross PCIe are page-locked once they have their size.
+//
+// Single-end input from a plain file takes the shorter road first (text phase): the reader cuts the file into chunks at
+// record starts and reads them into page-locked buffers, a lane hands the chunk's BYTES to the device and gets the bytes
+// of its SAM records back (text_gpu.hip: line ends, record checks, search, SAM text all on the GPU), and the writer
+// copies them into the output file.  The host then only moves bytes.  A chunk the device parser does not take as it is
+// ends the text phase; the host reader continues at that chunk's first byte with the line count kept, so '\r', blank
+// lines and malformed records get the reference's handling and messages.
 #include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include <hip/hip_runtime_api.h>
 #include <omp.h>
 #include <unistd.h>
@@ -124,6 +133,127 @@ struct Failure {
 	}
 };
 
+
+// The SAM file.  Pieces are copied to their offsets by several threads: through a shared mapping of the file where that
+// works (parallel page faults; write() on one file is serialised by the inode lock), else with pwrite.
+class FileSink {
+public:
+	~FileSink() { if (fd_ >= 0) ::close(fd_); }
+	bool open(const char *path) {
+		fd_ = ::open(path, O_RDWR | O_CREAT | O_TRUNC, 0644);
+		if (fd_ < 0) return false;
+		struct stat st;
+		const char *mode = getenv("URMAPX_SAM_WRITE");  // "pwrite" | "mmap"
+		use_map_ = fstat(fd_, &st) == 0 && S_ISREG(st.st_mode) && !(mode && !strcmp(mode, "pwrite"));
+		return true;
+	}
+	bool is_open() const { return fd_ >= 0; }
+	// makes the file at least `end` bytes long (pieces below `end` can then be written from several threads at once)
+	bool reserve(uint64_t end) {
+		if (!use_map_ || end <= size_) return true;
+		if (ftruncate(fd_, (off_t)end) != 0) { use_map_ = false; return true; }
+		size_ = end;
+		return true;
+	}
+	bool write_at(const char *p, size_t n, uint64_t off, int threads) {
+		if (n == 0) return true;
+		if (threads < 1) threads = 1;
+		if (use_map_) {
+			if (off + n > size_ && ftruncate(fd_, (off_t)(off + n)) != 0) use_map_ = false;
+			else {
+				if (off + n > size_) size_ = off + n;
+				const uint64_t a = off & ~(uint64_t)4095;
+				const size_t len = (size_t)(off + n - a);
+				char *m = (char *)mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_SHARED, fd_, (off_t)a);
+				if (m == MAP_FAILED) use_map_ = false;
+				else {
+					char *dst = m + (off - a);
+#pragma omp parallel for schedule(static, 1) num_threads(threads)
+					for (int t = 0; t < threads; ++t) {
+						const size_t lo = n * (size_t)t / (size_t)threads, hi = n * (size_t)(t + 1) / (size_t)threads;
+						memcpy(dst + lo, p + lo, hi - lo);
+					}
+					munmap(m, len);
+					return true;
+				}
+			}
+		}
+		bool ok = true;
+#pragma omp parallel for schedule(static, 1) num_threads(threads)
+		for (int t = 0; t < threads; ++t) {
+			const size_t lo = n * (size_t)t / (size_t)threads, hi = n * (size_t)(t + 1) / (size_t)threads;
+			size_t done = lo;
+			while (done < hi) {
+				ssize_t w = pwrite(fd_, p + done, hi - done, (off_t)(off + done));
+				if (w <= 0) { ok = false; break; }
+				done += (size_t)w;
+			}
+		}
+		if (off + n > size_) size_ = off + n;
+		return ok;
+	}
+	bool finish(uint64_t length) {
+		if (fd_ < 0) return true;
+		bool ok = size_ == length || ftruncate(fd_, (off_t)length) == 0;
+		ok = ::close(fd_) == 0 && ok;
+		fd_ = -1;
+		return ok;
+	}
+
+private:
+	int fd_ = -1;
+	std::atomic<bool> use_map_{false};
+	std::atomic<uint64_t> size_{0};
+};
+
+// one chunk of the text phase: FASTQ bytes in, SAM bytes out, both page-locked
+struct TextJob {
+	char *in = nullptr, *out = nullptr;
+	size_t in_cap = 0, out_cap = 0, nbytes = 0;
+	uint64_t file_off = 0;
+	urmapx_text_report rep;
+	int rc = 0;
+	~TextJob() {
+		if (in) (void)hipHostFree(in);
+		if (out) (void)hipHostFree(out);
+	}
+	static bool grow(char *&p, size_t &cap, size_t want) {
+		if (want <= cap) return true;
+		if (p) (void)hipHostFree(p);
+		p = nullptr; cap = 0;
+		if (hipHostMalloc((void **)&p, want, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); p = nullptr; return false; }
+		cap = want;
+		return true;
+	}
+};
+
+// first record start at or after `from`: a line that begins with '@' whose line after next begins with '+'.  A wrong
+// guess cannot pass: the chunk in front would then hold a line count that is not a multiple of four, which the device
+// parser reports.  Returns 0 if the window [from, from + 8 MB) shows none.
+uint64_t find_record_start(int fd, uint64_t from, uint64_t fsize) {
+	std::vector<char> w;
+	for (size_t win = 1u << 16; win <= (8u << 20); win *= 4) {
+		const size_t len = (size_t)std::min<uint64_t>(win, fsize - from);
+		w.resize(len);
+		size_t got = 0;
+		while (got < len) {
+			ssize_t k = pread(fd, w.data() + got, len - got, (off_t)(from + got));
+			if (k <= 0) return 0;
+			got += (size_t)k;
+		}
+		const char *b = w.data(), *e = b + len;
+		for (const char *nl = (const char *)memchr(b, '\n', len); nl && nl + 1 < e; nl = (const char *)memchr(nl + 1, '\n', (size_t)(e - nl - 1))) {
+			if (nl[1] != '@') continue;
+			const char *n1 = (const char *)memchr(nl + 1, '\n', (size_t)(e - nl - 1));
+			const char *n2 = n1 && n1 + 1 < e ? (const char *)memchr(n1 + 1, '\n', (size_t)(e - n1 - 1)) : nullptr;
+			if (!n2 || n2 + 1 >= e) break;  // the window ends inside this record: look again with a larger one
+			if (n2[1] == '+') return from + (uint64_t)(nl + 1 - b);
+		}
+		if (len < win) return 0;  // the window reached the end of the file
+	}
+	return 0;
+}
+
 }  // namespace
 
 extern "C" int urmapx_map_files(urmapx_index *I, const urmapx_map_options *opt, const char *fastq1, const char *fastq2,
@@ -174,35 +304,176 @@ extern "C" int urmapx_map_files(urmapx_index *I, const urmapx_map_options *opt, 
 	// host threads for FASTQ parsing and SAM formatting (the mapping itself runs on the GPU)
 	const int host_threads = opt->host_threads > 0 ? opt->host_threads : std::min(16, std::max(1, (int)std::thread::hardware_concurrency()));
 	omp_set_num_threads(host_threads);
-	int fsam = -1;
+	FileSink sink;
+	const bool have_sam = samout != nullptr;
 	uint64_t sam_off = 0;
 	Failure fail;
 	if (samout) {
-		fsam = open(samout, O_WRONLY | O_CREAT | O_TRUNC, 0644);
-		if (fsam < 0) { say(std::string("Cannot create ") + samout); release(); return URMAPX_E_IO; }
+		if (!sink.open(samout)) { say(std::string("Cannot create ") + samout); release(); return URMAPX_E_IO; }
 		std::string hdr;
 		append_sam_header_text(hdr, I, opt->cmdline);
-		if (write(fsam, hdr.data(), hdr.size()) != (ssize_t)hdr.size()) { say(std::string("Cannot write ") + samout); close(fsam); release(); return URMAPX_E_IO; }
+		if (!sink.write_at(hdr.data(), hdr.size(), 0, 1)) { say(std::string("Cannot write ") + samout); release(); return URMAPX_E_IO; }
 		sam_off = hdr.size();
 	}
 	// -tabbedout (outfiles.cpp:7-12): State2::OutputTab2's line per pair; only -map2 writes it
 	FILE *ftab = nullptr;
 	if (tabout) {
 		ftab = fopen(tabout, "wb");
-		if (!ftab) { say(std::string("Cannot create ") + tabout); if (fsam >= 0) close(fsam); release(); return URMAPX_E_IO; }
+		if (!ftab) { say(std::string("Cannot create ") + tabout); release(); return URMAPX_E_IO; }
 	}
 	FastqReader rd, rd2;
 	{
 		std::string e;
 		if (!rd.open(fastq1, e) || (paired && !rd2.open(fastq2, e))) {
 			say(e);
-			if (fsam >= 0) close(fsam);
 			if (ftab) fclose(ftab);
 			release();
 			return URMAPX_E_IO;
 		}
 	}
 	const auto t1 = std::chrono::steady_clock::now();
+	unsigned long long n_reads = 0, n_accept = 0, n_reject = 0, n_nohit = 0, n_unsupported = 0;
+	double t_parse = 0, t_gpu = 0, t_format = 0, t_write = 0;  // busy seconds per stage
+	auto now = [] { return std::chrono::steady_clock::now(); };
+	auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+	std::mutex gpu_time_lock;
+
+	// ---- text phase: single-end reads from a plain file, FASTQ bytes -> device -> SAM bytes ----
+	bool host_phase = true;
+	{
+		const size_t l1 = strlen(fastq1);
+		const bool gz = l1 > 3 && !strcmp(fastq1 + l1 - 3, ".gz");
+		struct stat st;
+		int fq = -1;
+		if (!paired && have_sam && !gz && strcmp(fastq1, "-") != 0 && !getenv("URMAPX_HOST_TEXT")) fq = open(fastq1, O_RDONLY);
+		if (fq >= 0 && (fstat(fq, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size == 0)) { close(fq); fq = -1; }
+		if (fq >= 0) {
+			const uint64_t fsize = (uint64_t)st.st_size;
+			size_t chunk_bytes;  // `batch` reads at the record size the head of the file shows
+			{
+				std::vector<char> head(1u << 16);
+				const ssize_t k = pread(fq, head.data(), head.size(), 0);
+				size_t nl = 0, last = 0;
+				for (ssize_t i = 0; i < k; ++i)
+					if (head[(size_t)i] == '\n' && (++nl & 3) == 0) last = (size_t)i + 1;
+				const double rec = nl >= 4 ? (double)last / (double)(nl / 4) : 512.0;
+				chunk_bytes = (size_t)std::min(std::max(rec * (double)batch, 4096.0), 536870912.0);
+			}
+			using TextChannel = Channel<std::unique_ptr<TextJob>>;
+			std::vector<std::unique_ptr<TextChannel>> tparsed, tmapped;
+			for (int l = 0; l < n_lanes; ++l) {
+				tparsed.emplace_back(new TextChannel(1));
+				tmapped.emplace_back(new TextChannel(1));
+			}
+			const int n_jobs = 2 * n_lanes + 2;
+			TextChannel tfree((size_t)n_jobs);
+			for (int k = 0; k < n_jobs; ++k) tfree.push(std::make_unique<TextJob>());
+			std::atomic<bool> stop{false};
+			uint64_t reader_end = 0;  // first byte the reader did not hand to a lane
+			std::thread treader([&] {
+				uint64_t off = 0;
+				for (size_t b = 0; off < fsize && !stop.load() && !fail.set.load(); ++b) {
+					uint64_t end = fsize;
+					if (off + chunk_bytes < fsize) {
+						end = find_record_start(fq, off + chunk_bytes, fsize);
+						if (end == 0) break;  // no record start in sight: the host reader takes it from here
+					}
+					std::unique_ptr<TextJob> j;
+					if (!tfree.pop(j)) break;
+					if (stop.load()) break;
+					const size_t n = (size_t)(end - off);
+					const auto tp0 = now();
+					(void)hipSetDevice(phys(0));
+					if (!TextJob::grow(j->in, j->in_cap, n + n / 16 + 4096) || !TextJob::grow(j->out, j->out_cap, n + n / 2 + (1u << 20))) {
+						fail.raise(URMAPX_E_NOMEM, "Page-locked chunk buffers: out of memory");
+						break;
+					}
+					bool ok = true;
+					const int T = std::max(1, host_threads / 2);
+#pragma omp parallel for schedule(static, 1) num_threads(T)
+					for (int t = 0; t < T; ++t) {
+						const size_t lo = n * (size_t)t / (size_t)T, hi = n * (size_t)(t + 1) / (size_t)T;
+						size_t done = lo;
+						while (done < hi) {
+							ssize_t k = pread(fq, j->in + done, hi - done, (off_t)(off + done));
+							if (k <= 0) { ok = false; break; }
+							done += (size_t)k;
+						}
+					}
+					t_parse += secs(tp0, now());
+					if (!ok) { fail.raise(URMAPX_E_IO, std::string("Error reading ") + fastq1); break; }
+					j->nbytes = n; j->file_off = off;
+					tparsed[b % (size_t)n_lanes]->push(std::move(j));
+					off = end;
+				}
+				reader_end = off;
+				for (auto &c : tparsed) c->close();
+			});
+			bool handed_back = false;
+			uint64_t resume_off = 0, lines_done = 0;
+			std::thread twriter([&] {
+				omp_set_num_threads(host_threads);
+				std::unique_ptr<TextJob> j;
+				for (size_t b = 0; tmapped[b % (size_t)n_lanes]->pop(j); ++b) {
+					if (!handed_back && !fail.set.load()) {
+						if (j->rc) fail.raise(j->rc, std::string("urmapx_text_map_se: ") + urmapx_strerror(j->rc));
+						else if (j->rep.reason) { handed_back = true; stop.store(true); resume_off = j->file_off; }
+						else {
+							const auto tw0 = now();
+							if (!sink.write_at(j->out, (size_t)j->rep.sam_bytes, sam_off, std::max(1, host_threads / 2)))
+								fail.raise(URMAPX_E_IO, std::string("Error writing ") + samout);
+							sam_off += j->rep.sam_bytes;
+							t_write += secs(tw0, now());
+							n_reads += j->rep.records; n_accept += j->rep.mapped_q; n_reject += j->rep.mapped_lowq;
+							n_nohit += j->rep.unmapped; n_unsupported += j->rep.unsupported;
+							lines_done += 4ull * j->rep.records;
+						}
+					}
+					tfree.push(std::move(j));
+				}
+			});
+			std::vector<std::thread> tlanes;
+			for (int l = 0; l < n_lanes; ++l)
+				tlanes.emplace_back([&, l] {
+					(void)hipSetDevice(phys(l % gpus));
+					urmapx_text *T = nullptr;
+					const int trc = urmapx_text_create(ctxs[(size_t)l], &T);
+					if (trc) fail.raise(trc, std::string("urmapx_text_create: ") + urmapx_strerror(trc));
+					std::unique_ptr<TextJob> j;
+					while (tparsed[(size_t)l]->pop(j)) {
+						memset(&j->rep, 0, sizeof j->rep);
+						j->rc = 0;
+						if (T && !fail.set.load() && !stop.load()) {
+							const auto tg0 = now();
+							for (;;) {
+								j->rc = urmapx_text_map_se(T, j->in, j->nbytes, minq, j->out, j->out_cap, &j->rep);
+								if (j->rc || j->rep.reason != URMAPX_TEXT_SAM_CAP) break;
+								if (!TextJob::grow(j->out, j->out_cap, (size_t)j->rep.sam_bytes + (1u << 20))) { j->rc = URMAPX_E_NOMEM; break; }
+							}
+							std::lock_guard<std::mutex> g(gpu_time_lock);
+							t_gpu += secs(tg0, now());
+						} else
+							j->rep.reason = 0xFFFFu;  // not mapped: the phase is ending
+						tmapped[(size_t)l]->push(std::move(j));
+					}
+					tmapped[(size_t)l]->close();
+					urmapx_text_destroy(T);
+				});
+			for (auto &t : tlanes) t.join();
+			treader.join();
+			twriter.join();
+			{
+				std::unique_ptr<TextJob> j;
+				while (tfree.try_pop(j)) j.reset();
+			}
+			close(fq);
+			if (!handed_back) resume_off = reader_end;
+			host_phase = !fail.set.load() && resume_off < fsize;
+			if (host_phase && !rd.resume_at(resume_off, lines_done)) fail.raise(URMAPX_E_IO, std::string("Cannot continue reading ") + fastq1);
+			if (fail.set.load()) host_phase = false;
+		}
+	}
+	if (host_phase) {
 
 	// batch b travels through parsed[b mod lanes] -> lane thread -> mapped[b mod lanes]; the writer visits the lanes in the
 	// same round-robin order, so batches come back in input order without a reorder buffer
@@ -213,9 +484,6 @@ extern "C" int urmapx_map_files(urmapx_index *I, const urmapx_map_options *opt, 
 		mapped.emplace_back(new JobChannel(1));
 	}
 	JobChannel recycled((size_t)(8 + 6 * n_lanes));  // finished jobs go back to the reader: their arrays are reused
-	double t_parse = 0, t_gpu = 0, t_format = 0, t_write = 0;  // busy seconds per stage
-	auto now = [] { return std::chrono::steady_clock::now(); };
-	auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
 	// -map2: the second file is parsed by its own thread while the reader parses the first
 	struct Side { FastqBatch b; std::string e; bool more = false; } side2;
 	Channel<int> go2(1), done2(1);
@@ -266,7 +534,6 @@ extern "C" int urmapx_map_files(urmapx_index *I, const urmapx_map_options *opt, 
 		for (auto &c : parsed) c->close();
 		go2.close();
 	});
-	unsigned long long n_reads = 0, n_accept = 0, n_reject = 0, n_nohit = 0, n_unsupported = 0;
 	// SAM text of a batch is formatted by all host threads, each on a contiguous range of reads (pairs); the pieces go to
 	// the flusher thread, which writes them at their file offsets (input order) while the next batch is being formatted.
 	struct Text { std::vector<std::string> outs; std::vector<uint64_t> at; };
@@ -276,15 +543,11 @@ extern "C" int urmapx_map_files(urmapx_index *I, const urmapx_map_options *opt, 
 		while (to_flush.pop(x)) {
 			const auto tw0 = now();
 			if (!fail.set.load()) {
+				if (!sink.reserve(x->at[(size_t)host_threads])) fail.raise(URMAPX_E_IO, std::string("Error writing ") + samout);
 #pragma omp parallel for schedule(static, 1) num_threads(host_threads)
 				for (int t = 0; t < host_threads; ++t) {
 					const std::string &out = x->outs[(size_t)t];
-					size_t done = 0;
-					while (done < out.size()) {
-						ssize_t w = pwrite(fsam, out.data() + done, out.size() - done, (off_t)(x->at[(size_t)t] + done));
-						if (w <= 0) { fail.raise(URMAPX_E_IO, std::string("Error writing ") + samout); break; }
-						done += (size_t)w;
-					}
+					if (!sink.write_at(out.data(), out.size(), x->at[(size_t)t], 1)) fail.raise(URMAPX_E_IO, std::string("Error writing ") + samout);
 				}
 			}
 			t_write += secs(tw0, now());
@@ -317,10 +580,10 @@ extern "C" int urmapx_map_files(urmapx_index *I, const urmapx_map_options *opt, 
 					const urmapx_result &r = j->results[i];
 					const uint64_t off = j->reads.offs[i];
 					const unsigned L = (unsigned)(j->reads.offs[i + 1] - off);
-					if (fsam >= 0 && !paired)
+					if (have_sam && !paired)
 						append_sam_record(out, I, r, j->ops.data(), 0, "*", 0xFFFFFFFFu, 0, j->reads.label(i),
 						                  j->reads.bases.data() + off, j->reads.quals.data() + off, L);
-					if (fsam >= 0 && paired && (i & 1) == 0) {
+					if (have_sam && paired && (i & 1) == 0) {
 						const uint64_t off2 = j->reads.offs[i + 1];
 						const unsigned L2 = (unsigned)(j->reads.offs[i + 2] - off2);
 						pbuf.resize(strlen(j->reads.label(i)) + strlen(j->reads.label(i + 1)) + 3 * (size_t)(L + L2) + 2048);
@@ -341,7 +604,7 @@ extern "C" int urmapx_map_files(urmapx_index *I, const urmapx_map_options *opt, 
 			n_reads += n;
 			const auto tf1 = now();
 			t_format += secs(tf0, tf1);
-			if (fsam >= 0) {
+			if (have_sam) {
 				std::vector<uint64_t> &at = text->at;
 				at.assign((size_t)host_threads + 1, 0);
 				at[0] = sam_off;
@@ -360,7 +623,7 @@ extern "C" int urmapx_map_files(urmapx_index *I, const urmapx_map_options *opt, 
 						const uint32_t i = 2 * u;
 						const unsigned L1 = (unsigned)(j->reads.offs[i + 1] - j->reads.offs[i]), L2 = (unsigned)(j->reads.offs[i + 2] - j->reads.offs[i + 1]);
 						const size_t k = urmapx_tab_pe(I, &j->results[i], &j->results[i + 1], &j->info[u], j->reads.label(i), L1, L2,
-						                               fsam >= 0 ? 1 : 0, line, sizeof line);
+						                               have_sam ? 1 : 0, line, sizeof line);
 						tabs[(size_t)t].append(line, k);
 					}
 				}
@@ -371,7 +634,6 @@ extern "C" int urmapx_map_files(urmapx_index *I, const urmapx_map_options *opt, 
 		}
 		to_flush.close();
 	});
-	std::mutex gpu_time_lock;
 	std::vector<std::thread> lanes;
 	for (int l = 0; l < n_lanes; ++l)
 		lanes.emplace_back([&, l] {
@@ -419,7 +681,8 @@ extern "C" int urmapx_map_files(urmapx_index *I, const urmapx_map_options *opt, 
 		std::unique_ptr<Job> j;
 		while (recycled.try_pop(j)) j.reset();
 	}
-	if (fsam >= 0) close(fsam);
+	}  // host phase
+	if (have_sam && !sink.finish(sam_off)) fail.raise(URMAPX_E_IO, std::string("Error writing ") + samout);
 	if (ftab) fclose(ftab);
 	const auto t2 = std::chrono::steady_clock::now();
 	release();

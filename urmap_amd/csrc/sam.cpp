@@ -37,6 +37,13 @@ bool FastqReader::open(const std::string &path, std::string &err) {
 	return true;
 }
 
+bool FastqReader::resume_at(uint64_t offset, uint64_t lines_before) {
+	if (gz_ || !f_ || !seekable_ || have_ || line_nr_) return false;
+	file_off_ = offset;
+	line_nr_ = lines_before;
+	return true;
+}
+
 size_t FastqReader::read_some(char *dst, size_t cap) {
 	if (gz_) {
 		if (cap > (1u << 30)) cap = 1u << 30;
@@ -330,6 +337,8 @@ static struct CompInit {
 		}
 	}
 } g_comp_init;
+
+const unsigned char *complement_table() { return g_comp; }
 
 static inline void append_uint(std::string &out, uint64_t v) {
 	char tmp[24];

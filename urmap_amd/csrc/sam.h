@@ -71,6 +71,9 @@ class FastqReader {
 public:
 	~FastqReader();
 	bool open(const std::string &path, std::string &err);
+	// plain seekable files: continue at byte `offset`, which starts line number `lines_before` + 1 (the part of the file
+	// in front was consumed by the device parser)
+	bool resume_at(uint64_t offset, uint64_t lines_before);
 	// appends up to max_reads records; returns false at EOF with nothing read.  Sets err on malformed input.
 	bool next_batch(FastqBatch &B, uint32_t max_reads, std::string &err);
 	const std::string &path() const { return path_; }
@@ -99,6 +102,9 @@ std::string path_to_cigar(const urmapx_path_op *ops, unsigned nops, unsigned QL)
 void append_sam_record(std::string &out, const urmapx_index *I, const urmapx_result &r, const urmapx_path_op *ops,
                        uint32_t flags, const char *mate_label, uint32_t mate_pos, int tlen, const char *label,
                        const uint8_t *seq, const uint8_t *qual, unsigned QL);
+
+// 256-entry complement table of alpha.cpp:3005 (IUPAC, case preserving, 'u' and non-letters -> '?')
+const unsigned char *complement_table();
 
 // @SQ lines + @PG (State1::WriteSAMHeader, state1.cpp:736-752)
 void append_sam_header(std::string &out, const urmapx_index *I, int argc, char **argv);

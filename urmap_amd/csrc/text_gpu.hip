@@ -1,0 +1,511 @@
+// text_gpu.hip -- FASTQ bytes in, SAM bytes out, both ends of the mapping path on the device.
+//
+// The reference parses FASTQ one line at a time under a lock (FASTQSeqSource::GetNextLo, fastqseqsource.cpp:9-116, over
+// LineReader, linereader.cpp:54-101) and formats each record in the mapping thread (State1::SetSAM / SetSAM_Unmapped,
+// setsam.cpp:12-207; GetCIGAR / PathToCIGAR / CIGAROpsFixDanglingMs, state1.cpp:707-734, cigar.cpp:4-41,141-199).  With
+// the search on the GPU those two text stages were what bounded `urmap -map` file to file, so a
+// chunk of the FASTQ file now crosses PCIe as it lies in the file and comes back as the bytes of its SAM records:
+//
+//   raw bytes --nl_count / nl_emit--> line ends --record_kernel--> read lengths --scan--> offs
+//             --copy_bases_kernel--> bases   --urmapx_map_se_device--> results, paths
+//             --sam_kernel<0>--> record lengths --scan--> record offsets --sam_kernel<1>--> SAM text
+//
+// The device parser accepts exactly the files the reference accepts WITHOUT special handling: '\n' line ends, four
+// lines per record, '@' first, letters only, as many quality bytes as bases.  Anything else ('\r', blank lines, a
+// malformed record, a last line without '\n') makes the call hand the chunk back untouched (report.reason) and the
+// caller runs it through the host reader (sam.cpp), which reproduces the reference's handling and messages.
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "internal.h"
+#include "sam.h"
+
+using namespace urx;
+
+namespace {
+
+constexpr int NL_TILE = 16384, NL_THREADS = 256;  // 64 bytes per thread
+constexpr int SC_THREADS = 256, SC_ITEMS = 8, SC_TILE = SC_THREADS * SC_ITEMS;
+constexpr int SAM_WAVES = 4;        // wavefronts per block of the record kernels
+constexpr int HEAD_CAP = 1408;      // bytes of one record between QNAME and SEQ held in LDS (12 * 97 CIGAR + fields)
+constexpr int TNAME_MAX = 160;      // longest target label the device formatter takes
+
+struct TextHdr {  // one per call, device
+	uint32_t n_lines, n_records, flags, max_len;
+	uint32_t total_bases, sam_total, pad0, pad1;
+	unsigned long long cnt[4];  // accept, reject, nohit, unsupported
+};
+
+__device__ __forceinline__ uint32_t eq_mask(uint32_t w, uint32_t byte_x4) {  // bit 7 of every byte of w equal to the byte
+	const uint32_t x = w ^ byte_x4;
+	return ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;
+}
+
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+	const int lane = threadIdx.x & 63;
+#pragma unroll
+	for (int d = 1; d < 64; d <<= 1) {
+		const uint32_t o = __shfl_up(v, d, 64);
+		if (lane >= d) v += o;
+	}
+	return v;
+}
+
+// exclusive scan of one value per thread over a block of 256 threads; *total = block sum
+__device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t *lds4, uint32_t *total) {
+	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	const uint32_t inc = wave_incl_scan(v);
+	__syncthreads();
+	if (lane == 63) lds4[w] = inc;
+	__syncthreads();
+	uint32_t base = 0, sum = 0;
+#pragma unroll
+	for (int k = 0; k < 4; ++k) {
+		const uint32_t t = lds4[k];
+		if (k < w) base += t;
+		sum += t;
+	}
+	*total = sum;
+	return base + inc - v;
+}
+
+// ---- line ends ----
+__global__ __launch_bounds__(NL_THREADS) void nl_count_kernel(const uint4 *raw, uint32_t n_tiles, uint32_t *tile_counts, TextHdr *hdr) {
+	__shared__ uint32_t lds4[4];
+	for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+		const uint4 *p = raw + (size_t)tile * (NL_TILE / 16) + threadIdx.x * 4;
+		uint32_t c = 0, cr = 0;
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			const uint4 v = p[k];
+			c += __popc(eq_mask(v.x, 0x0A0A0A0Au)) + __popc(eq_mask(v.y, 0x0A0A0A0Au)) + __popc(eq_mask(v.z, 0x0A0A0A0Au)) + __popc(eq_mask(v.w, 0x0A0A0A0Au));
+			cr |= eq_mask(v.x, 0x0D0D0D0Du) | eq_mask(v.y, 0x0D0D0D0Du) | eq_mask(v.z, 0x0D0D0D0Du) | eq_mask(v.w, 0x0D0D0D0Du);
+		}
+		uint32_t total;
+		(void)block_excl_scan_256(c, lds4, &total);
+		if (threadIdx.x == 0) tile_counts[tile] = total;
+		if (cr) atomicOr(&hdr->flags, 1u);  // a '\r' somewhere: the host reader's business
+		__syncthreads();
+	}
+}
+
+// one block: exclusive scan of m values in place; total to *total_out
+__global__ __launch_bounds__(1024) void scan_small_kernel(uint32_t *v, const uint32_t *m_ptr, uint32_t m_div, uint32_t m_fixed, uint32_t *total_out) {
+	__shared__ uint32_t part[1024];
+	const uint32_t m = m_ptr ? (*m_ptr + m_div - 1) / m_div : m_fixed;
+	const uint32_t per = (m + 1023) / 1024;
+	const uint32_t lo = threadIdx.x * per, hi = lo + per < m ? lo + per : m;
+	uint32_t s = 0;
+	for (uint32_t i = lo; i < hi; ++i) s += v[i];
+	part[threadIdx.x] = s;
+	__syncthreads();
+	if (threadIdx.x < 64) {  // 16 partials per lane
+		uint32_t t = 0;
+		for (int k = 0; k < 16; ++k) t += part[threadIdx.x * 16 + k];
+		const uint32_t inc = wave_incl_scan(t);
+		uint32_t run = inc - t;
+		for (int k = 0; k < 16; ++k) {
+			const uint32_t x = part[threadIdx.x * 16 + k];
+			part[threadIdx.x * 16 + k] = run;
+			run += x;
+		}
+		if (threadIdx.x == 63 && total_out) *total_out = inc;
+	}
+	__syncthreads();
+	uint32_t run = part[threadIdx.x];
+	for (uint32_t i = lo; i < hi; ++i) {
+		const uint32_t x = v[i];
+		v[i] = run;
+		run += x;
+	}
+}
+
+__global__ __launch_bounds__(NL_THREADS) void nl_emit_kernel(const uint4 *raw, uint32_t n_tiles, const uint32_t *tile_offs, uint32_t *ends,
+                                                             uint32_t ends_cap, TextHdr *hdr) {
+	__shared__ uint32_t lds4[4];
+	if (blockIdx.x == 0 && threadIdx.x == 0) hdr->n_records = (hdr->n_lines < ends_cap ? hdr->n_lines : ends_cap) / 4;
+	for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+		const uint4 *p = raw + (size_t)tile * (NL_TILE / 16) + threadIdx.x * 4;
+		uint32_t w[16];
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			const uint4 v = p[k];
+			w[4 * k] = eq_mask(v.x, 0x0A0A0A0Au); w[4 * k + 1] = eq_mask(v.y, 0x0A0A0A0Au);
+			w[4 * k + 2] = eq_mask(v.z, 0x0A0A0A0Au); w[4 * k + 3] = eq_mask(v.w, 0x0A0A0A0Au);
+		}
+		uint32_t c = 0;
+#pragma unroll
+		for (int k = 0; k < 16; ++k) c += __popc(w[k]);
+		uint32_t total;
+		uint32_t at = tile_offs[tile] + block_excl_scan_256(c, lds4, &total);
+		const uint32_t pos0 = tile * (uint32_t)NL_TILE + threadIdx.x * 64u;
+		if (c) {
+#pragma unroll
+			for (int k = 0; k < 16; ++k) {
+				uint32_t m = w[k];
+				while (m) {
+					const int b = __ffs(m) - 1;  // bit 7 of byte b/8
+					m &= m - 1;
+					if (at < ends_cap) ends[at] = pos0 + 4u * k + (uint32_t)(b >> 3);
+					++at;
+				}
+			}
+		}
+		__syncthreads();
+	}
+}
+
+// ---- records ----
+__device__ __forceinline__ uint32_t line_start(const uint32_t *ends, uint32_t k) { return k ? ends[k - 1] + 1u : 0u; }
+
+// read lengths; structure of every record ('@' first, a label line that is not empty, as many quality bytes as bases)
+__global__ __launch_bounds__(256) void record_kernel(const uint8_t *raw, const uint32_t *ends, TextHdr *hdr, uint32_t *blen) {
+	const uint32_t n = hdr->n_records;
+	uint32_t mx = 0;
+	bool bad = false;
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+		const uint32_t s1 = line_start(ends, 4 * i), e1 = ends[4 * i], e2 = ends[4 * i + 1], e3 = ends[4 * i + 2], e4 = ends[4 * i + 3];
+		const uint32_t l2 = e2 - (e1 + 1), l4 = e4 - (e3 + 1);
+		if (e1 == s1 || raw[s1] != '@' || l2 != l4) bad = true;
+		blen[i] = l2;
+		mx = l2 > mx ? l2 : mx;
+	}
+	for (int d = 32; d; d >>= 1) {
+		const uint32_t o = __shfl_xor(mx, d, 64);
+		mx = o > mx ? o : mx;
+	}
+	if ((threadIdx.x & 63) == 0 && mx) atomicMax(&hdr->max_len, mx);
+	if (bad) atomicOr(&hdr->flags, 2u);
+}
+
+// tile sums of v[0, n)
+__global__ __launch_bounds__(SC_THREADS) void scan_sums_kernel(const uint32_t *v, const uint32_t *n_ptr, uint32_t *sums) {
+	__shared__ uint32_t lds4[4];
+	const uint32_t n = *n_ptr, n_tiles = (n + SC_TILE - 1) / SC_TILE;
+	for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+		const uint32_t lo = tile * SC_TILE + threadIdx.x * SC_ITEMS;
+		uint32_t s = 0;
+#pragma unroll
+		for (int k = 0; k < SC_ITEMS; ++k)
+			if (lo + k < n) s += v[lo + k];
+		uint32_t total;
+		(void)block_excl_scan_256(s, lds4, &total);
+		if (threadIdx.x == 0) sums[tile] = total;
+		__syncthreads();
+	}
+}
+
+// out[i] = exclusive prefix of v (tile offsets already scanned); out[n] = the total
+template <class OutT>
+__global__ __launch_bounds__(SC_THREADS) void scan_apply_kernel(const uint32_t *v, const uint32_t *n_ptr, const uint32_t *tile_offs, OutT *out) {
+	__shared__ uint32_t lds4[4];
+	const uint32_t n = *n_ptr, n_tiles = (n + SC_TILE - 1) / SC_TILE;
+	if (n == 0 && blockIdx.x == 0 && threadIdx.x == 0) out[0] = 0;
+	for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+		const uint32_t lo = tile * SC_TILE + threadIdx.x * SC_ITEMS;
+		uint32_t x[SC_ITEMS], s = 0;
+#pragma unroll
+		for (int k = 0; k < SC_ITEMS; ++k) {
+			x[k] = lo + k < n ? v[lo + k] : 0u;
+			s += x[k];
+		}
+		uint32_t total;
+		uint32_t run = tile_offs[tile] + block_excl_scan_256(s, lds4, &total);
+#pragma unroll
+		for (int k = 0; k < SC_ITEMS; ++k) {
+			if (lo + k < n) out[lo + k] = (OutT)run;
+			run += x[k];
+			if (lo + k + 1 == n) out[n] = (OutT)run;
+		}
+		__syncthreads();
+	}
+}
+
+// bases of every read, back to back (what the mapping kernels take); letters only (fastqseqsource.cpp:76-84)
+__global__ __launch_bounds__(256) void copy_bases_kernel(const uint8_t *raw, const uint32_t *ends, TextHdr *hdr, const uint64_t *offs, uint8_t *bases) {
+	const uint32_t n = hdr->n_records;
+	const int lane = threadIdx.x & 63;
+	const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+	bool bad = false;
+	for (uint32_t i = wave; i < n; i += n_waves) {
+		const uint32_t s2 = ends[4 * i] + 1u, L = ends[4 * i + 1] - s2;
+		uint8_t *dst = bases + offs[i];
+		for (uint32_t k = lane; k < L; k += 64) {
+			const uint8_t c = raw[s2 + k];
+			if ((uint8_t)((c | 0x20u) - 'a') >= 26u) bad = true;
+			dst[k] = c;
+		}
+	}
+	if (bad) atomicOr(&hdr->flags, 4u);
+	if (blockIdx.x == 0 && threadIdx.x == 0) hdr->total_bases = (uint32_t)offs[n];
+}
+
+// ---- SAM ----
+struct SamArgs {
+	const uint8_t *raw;
+	const uint32_t *ends;
+	const urmapx_result *results;
+	const urmapx_path_op *ops;
+	const char *tnames;          // target labels back to back
+	const uint32_t *tname_offs;  // seqCount + 1
+	const uint8_t *comp;         // 256-byte complement table (alpha.cpp:3005)
+	uint32_t seq_count;
+	uint32_t minq;
+	TextHdr *hdr;
+	uint32_t *lens;              // PASS 0 out
+	const uint32_t *rec_offs;    // PASS 1 in
+	char *sam;                   // PASS 1 out
+};
+
+__device__ __forceinline__ char *dev_put_uint(char *p, uint32_t v) {
+	char tmp[12];
+	int n = 0;
+	do { tmp[n++] = (char)('0' + v % 10u); v /= 10u; } while (v);
+	while (n) *p++ = tmp[--n];
+	return p;
+}
+
+// Lane 0 writes the fields between QNAME and SEQ of a mapped or unmapped single-end record (SetSAM with flags 0, mate
+// "*": output1.cpp:13) to `head`; returns the length, or 0 if it does not fit the device formatter.
+__device__ uint32_t build_head(const SamArgs &A, const urmapx_result &r, uint32_t QL, char *head, char *cop, uint32_t *clen) {
+	char *p = head;
+	if (r.dbpos == 0xFFFFFFFFu) {
+		const char s[] = "\t4\t*\t0\t0\t*\t*\t0\t0\t";
+		for (int i = 0; i < (int)sizeof(s) - 1; ++i) *p++ = s[i];
+		return (uint32_t)(p - head);
+	}
+	*p++ = '\t'; *p++ = '0'; *p++ = '\t';
+	if (r.seq_index >= A.seq_count) return 0;
+	const uint32_t t0 = A.tname_offs[r.seq_index], tl = A.tname_offs[r.seq_index + 1] - t0;
+	if (tl > (uint32_t)TNAME_MAX) return 0;
+	for (uint32_t i = 0; i < tl; ++i) *p++ = A.tnames[t0 + i];
+	*p++ = '\t';
+	p = dev_put_uint(p, r.coord + 1u);
+	*p++ = '\t';
+	p = dev_put_uint(p, r.mapq);
+	*p++ = '\t';
+	uint32_t nops = r.path_nops;
+	if (nops == 0) { p = dev_put_uint(p, QL); *p++ = 'M'; }
+	else {
+		if (nops > URMAPX_MAX_PATH_OPS) nops = URMAPX_MAX_PATH_OPS;
+		const urmapx_path_op *ops = A.ops + r.path_off;
+		uint32_t N = 0;
+		for (uint32_t i = 0; i < nops; ++i) {
+			const uint32_t code = ops[i] & 3u, n = ops[i] >> 2;
+			const char c = code == 0 ? 'M' : code == 1 ? 'I' : 'D';  // path D (query only) is CIGAR I and vice versa (cigar.cpp:22-25)
+			if (N && cop[N - 1] == c) clen[N - 1] += n;
+			else { cop[N] = c; clen[N] = n; ++N; }
+		}
+		uint32_t first = 0;  // CIGAROpsFixDanglingMs (cigar.cpp:141-199): head rule XOR tail rule, as in sam.cpp
+		if (N >= 3) {
+			if (cop[0] == 'M' && clen[0] <= 2 && clen[1] > 4 && cop[2] == 'M') { clen[2] += clen[0]; first = 1; }
+			else if (cop[N - 1] == 'M' && clen[N - 1] <= 2 && clen[N - 2] > 4 && cop[N - 3] == 'M') { clen[N - 3] += clen[N - 1]; --N; }
+		}
+		for (uint32_t i = first; i < N; ++i) { p = dev_put_uint(p, clen[i]); *p++ = cop[i]; }
+	}
+	const char s[] = "\t*\t0\t0\t";
+	for (int i = 0; i < (int)sizeof(s) - 1; ++i) *p++ = s[i];
+	return (uint32_t)(p - head);
+}
+
+// One wavefront per record.  PASS 0: the record's length and the HitStats counters (output1.cpp:20-30).  PASS 1: its bytes.
+template <int PASS>
+__global__ __launch_bounds__(SAM_WAVES * 64) void sam_kernel(SamArgs A) {
+	__shared__ char s_head[SAM_WAVES][HEAD_CAP];
+	__shared__ char s_cop[SAM_WAVES][URMAPX_MAX_PATH_OPS + 1];
+	__shared__ uint32_t s_clen[SAM_WAVES][URMAPX_MAX_PATH_OPS + 1];
+	__shared__ uint32_t s_hl[SAM_WAVES];
+	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	const uint32_t n = A.hdr->n_records;
+	const uint32_t wave = blockIdx.x * SAM_WAVES + w, n_waves = gridDim.x * SAM_WAVES;
+	uint32_t c_acc = 0, c_rej = 0, c_no = 0, c_uns = 0;
+	for (uint32_t i = wave; i < n; i += n_waves) {
+		const urmapx_result r = A.results[i];
+		const uint32_t s1 = line_start(A.ends, 4 * i), e1 = A.ends[4 * i], e2 = A.ends[4 * i + 1], e3 = A.ends[4 * i + 2];
+		const uint32_t QL = e2 - (e1 + 1u);
+		const uint8_t *label = A.raw + s1 + 1u;
+		uint32_t ln = e1 - s1 - 1u;
+		// QNAME: "/1" "/2" dropped, then cut at the first blank (setsam.cpp:36-46)
+		if (ln > 2 && label[ln - 2] == '/' && (label[ln - 1] == '1' || label[ln - 1] == '2')) ln -= 2;
+		uint32_t qn = ln;
+		for (uint32_t b = 0; b < ln; b += 64) {
+			const uint8_t c = b + lane < ln ? label[b + lane] : (uint8_t)'x';
+			const unsigned long long m = __ballot(c == ' ' || c == '\t');
+			if (m) { qn = b + (uint32_t)__ffsll((long long)m) - 1u; break; }
+		}
+		if (lane == 0) s_hl[w] = build_head(A, r, QL, s_head[w], s_cop[w], s_clen[w]);
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		const uint32_t hl = s_hl[w];
+		if (PASS == 0) {
+			if (lane == 0) {
+				A.lens[i] = qn + hl + 2u * QL + 2u;
+				if (hl == 0) atomicOr(&A.hdr->flags, 8u);
+				if (r.status) ++c_uns;
+				if (r.dbpos == 0xFFFFFFFFu) ++c_no;
+				else if (r.mapq >= A.minq) ++c_acc;
+				else ++c_rej;
+			}
+		} else {
+			char *out = A.sam + A.rec_offs[i];
+			for (uint32_t k = lane; k < qn; k += 64) out[k] = (char)label[k];
+			out += qn;
+			for (uint32_t k = lane; k < hl; k += 64) out[k] = s_head[w][k];
+			out += hl;
+			const uint8_t *seq = A.raw + e1 + 1u, *qual = A.raw + e3 + 1u;
+			const bool plus = r.dbpos == 0xFFFFFFFFu || r.plus;
+			if (plus) {
+				for (uint32_t k = lane; k < QL; k += 64) { out[k] = (char)seq[k]; out[QL + 1u + k] = (char)qual[k]; }
+			} else {
+				for (uint32_t k = lane; k < QL; k += 64) { out[k] = (char)A.comp[seq[QL - 1u - k]]; out[QL + 1u + k] = (char)qual[QL - 1u - k]; }
+			}
+			if (lane == 0) { out[QL] = '\t'; out[2u * QL + 1u] = '\n'; }
+		}
+		__builtin_amdgcn_wave_barrier();
+	}
+	if (PASS == 0 && lane == 0) {
+		if (c_acc) atomicAdd(&A.hdr->cnt[0], (unsigned long long)c_acc);
+		if (c_rej) atomicAdd(&A.hdr->cnt[1], (unsigned long long)c_rej);
+		if (c_no) atomicAdd(&A.hdr->cnt[2], (unsigned long long)c_no);
+		if (c_uns) atomicAdd(&A.hdr->cnt[3], (unsigned long long)c_uns);
+	}
+}
+
+}  // namespace
+
+struct urmapx_text {
+	urmapx_ctx *C = nullptr;
+	DevBuf<uint8_t> raw, bases, sam, comp;
+	DevBuf<uint32_t> tile_counts, ends, blen, sums, lens, rec_offs, used, tname_offs;
+	DevBuf<uint64_t> offs;
+	DevBuf<char> tnames;
+	DevBuf<urmapx_result> results;
+	DevBuf<urmapx_path_op> pathops;
+	DevBuf<TextHdr> hdr;
+	uint32_t seq_count = 0;
+	TextHdr *h_hdr = nullptr;  // page-locked
+};
+
+extern "C" {
+
+int urmapx_text_create(urmapx_ctx *C, urmapx_text **out) {
+	if (!C || !out) return URMAPX_E_ARG;
+	*out = nullptr;
+	HIP_TRY(hipSetDevice(ctx_device(C)));
+	urmapx_text *T = new urmapx_text;
+	T->C = C;
+	const urmapx_index *I = ctx_index(C);
+	const uint32_t n = urmapx_index_seq_count(I);
+	std::string names;
+	std::vector<uint32_t> offs(n + 1, 0);
+	for (uint32_t i = 0; i < n; ++i) { names += urmapx_index_label(I, i); offs[i + 1] = (uint32_t)names.size(); }
+	int rc = T->tnames.ensure(names.size() + 1);
+	if (!rc) rc = T->tname_offs.ensure(n + 1);
+	if (!rc) rc = T->comp.ensure(256);
+	if (!rc) rc = T->hdr.ensure(1);
+	if (!rc) rc = T->used.ensure(1);
+	hipError_t e = hipSuccess;
+	if (!rc && !names.empty()) e = hipMemcpy(T->tnames.p, names.data(), names.size(), hipMemcpyHostToDevice);
+	if (!rc && e == hipSuccess) e = hipMemcpy(T->tname_offs.p, offs.data(), (n + 1) * 4, hipMemcpyHostToDevice);
+	if (!rc && e == hipSuccess) e = hipMemcpy(T->comp.p, complement_table(), 256, hipMemcpyHostToDevice);
+	if (!rc && e == hipSuccess) e = hipHostMalloc((void **)&T->h_hdr, sizeof(TextHdr), hipHostMallocDefault);
+	if (!rc && e != hipSuccess) rc = hip_rc(e);
+	if (rc) { urmapx_text_destroy(T); return rc; }
+	T->seq_count = n;
+	*out = T;
+	return URMAPX_OK;
+}
+
+void urmapx_text_destroy(urmapx_text *T) {
+	if (!T) return;
+	(void)hipSetDevice(ctx_device(T->C));
+	(void)hipStreamSynchronize(ctx_stream(T->C));
+	T->raw.release(); T->bases.release(); T->sam.release(); T->comp.release();
+	T->tile_counts.release(); T->ends.release(); T->blen.release(); T->sums.release(); T->lens.release(); T->rec_offs.release();
+	T->used.release(); T->tname_offs.release(); T->offs.release(); T->tnames.release(); T->results.release(); T->pathops.release();
+	T->hdr.release();
+	if (T->h_hdr) (void)hipHostFree(T->h_hdr);
+	delete T;
+}
+
+int urmapx_text_map_se(urmapx_text *T, const char *fastq, size_t nbytes, unsigned minq, char *sam, size_t sam_cap, urmapx_text_report *rep) {
+	if (!T || !rep || (nbytes && !fastq)) return URMAPX_E_ARG;
+	memset(rep, 0, sizeof *rep);
+	if (nbytes == 0) return URMAPX_OK;
+	if (nbytes > (1u << 30)) { rep->reason = URMAPX_TEXT_TOO_LARGE; return URMAPX_OK; }
+	if (fastq[nbytes - 1] != '\n') { rep->reason = URMAPX_TEXT_RAGGED; return URMAPX_OK; }
+	urmapx_ctx *C = T->C;
+	HIP_TRY(hipSetDevice(ctx_device(C)));
+	hipStream_t st = ctx_stream(C);
+	const uint32_t n_tiles = (uint32_t)((nbytes + NL_TILE - 1) / NL_TILE);
+	const size_t padded = (size_t)n_tiles * NL_TILE;
+	// a record's four lines take at least five bytes ("@\n\n\n\n"); more line ends than that is not FASTQ
+	const uint32_t ends_cap = (uint32_t)(nbytes / 5 * 4 + 16);
+	const uint32_t rec_cap = ends_cap / 4 + 1;
+	int rc;
+	if ((rc = T->raw.ensure(padded + 16))) return rc;
+	if ((rc = T->tile_counts.ensure(n_tiles))) return rc;
+	if ((rc = T->ends.ensure(ends_cap))) return rc;
+	if ((rc = T->blen.ensure(rec_cap))) return rc;
+	if ((rc = T->lens.ensure(rec_cap))) return rc;
+	if ((rc = T->rec_offs.ensure((size_t)rec_cap + 1))) return rc;
+	if ((rc = T->offs.ensure((size_t)rec_cap + 1))) return rc;
+	if ((rc = T->sums.ensure(rec_cap / SC_TILE + 2))) return rc;
+	if ((rc = T->bases.ensure(nbytes + 64))) return rc;
+	TextHdr *hdr = T->hdr.p;
+	const uint8_t *raw = T->raw.p;
+	HIP_TRY(hipMemsetAsync(hdr, 0, sizeof(TextHdr), st));
+	HIP_TRY(hipMemcpyAsync(T->raw.p, fastq, nbytes, hipMemcpyHostToDevice, st));
+	if (padded + 16 > nbytes) HIP_TRY(hipMemsetAsync(T->raw.p + nbytes, 0, padded + 16 - nbytes, st));
+	const int grid = 2048;
+	hipLaunchKernelGGL(nl_count_kernel, dim3(grid), dim3(NL_THREADS), 0, st, (const uint4 *)raw, n_tiles, T->tile_counts.p, hdr);
+	hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(1024), 0, st, T->tile_counts.p, (const uint32_t *)nullptr, 1u, n_tiles, &hdr->n_lines);
+	hipLaunchKernelGGL(nl_emit_kernel, dim3(grid), dim3(NL_THREADS), 0, st, (const uint4 *)raw, n_tiles, T->tile_counts.p, T->ends.p, ends_cap, hdr);
+	hipLaunchKernelGGL(record_kernel, dim3(grid), dim3(256), 0, st, raw, T->ends.p, hdr, T->blen.p);
+	hipLaunchKernelGGL(scan_sums_kernel, dim3(grid), dim3(SC_THREADS), 0, st, T->blen.p, &hdr->n_records, T->sums.p);
+	hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(1024), 0, st, T->sums.p, &hdr->n_records, (uint32_t)SC_TILE, 0u, (uint32_t *)nullptr);
+	hipLaunchKernelGGL(scan_apply_kernel<uint64_t>, dim3(grid), dim3(SC_THREADS), 0, st, T->blen.p, &hdr->n_records, T->sums.p, T->offs.p);
+	hipLaunchKernelGGL(copy_bases_kernel, dim3(grid), dim3(256), 0, st, raw, T->ends.p, hdr, T->offs.p, T->bases.p);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipMemcpyAsync(T->h_hdr, hdr, sizeof(TextHdr), hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipStreamSynchronize(st));
+	const TextHdr h1 = *T->h_hdr;
+	if (h1.flags & 1u) { rep->reason = URMAPX_TEXT_CR; return URMAPX_OK; }
+	if (h1.n_lines > ends_cap || (h1.n_lines & 3u)) { rep->reason = URMAPX_TEXT_RAGGED; return URMAPX_OK; }
+	if (h1.flags & 6u) { rep->reason = URMAPX_TEXT_BAD_RECORD; return URMAPX_OK; }
+	const uint32_t n = h1.n_records;
+	if (n == 0) return URMAPX_OK;
+	if ((rc = T->results.ensure(n))) return rc;
+	if ((rc = T->pathops.ensure((size_t)n * URMAPX_MAX_PATH_OPS))) return rc;
+	uint32_t mx = h1.max_len > URMAPX_MAX_QL ? URMAPX_MAX_QL : h1.max_len;
+	rc = urmapx_map_se_device(C, T->bases.p, T->offs.p, n, h1.total_bases, mx, T->results.p, T->pathops.p, T->used.p);
+	if (rc) return rc;
+	SamArgs A;
+	A.raw = raw; A.ends = T->ends.p; A.results = T->results.p; A.ops = T->pathops.p; A.tnames = T->tnames.p;
+	A.tname_offs = T->tname_offs.p; A.comp = T->comp.p; A.seq_count = T->seq_count; A.minq = minq; A.hdr = hdr;
+	A.lens = T->lens.p; A.rec_offs = T->rec_offs.p; A.sam = nullptr;
+	hipLaunchKernelGGL(sam_kernel<0>, dim3(grid), dim3(SAM_WAVES * 64), 0, st, A);
+	hipLaunchKernelGGL(scan_sums_kernel, dim3(grid), dim3(SC_THREADS), 0, st, T->lens.p, &hdr->n_records, T->sums.p);
+	hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(1024), 0, st, T->sums.p, &hdr->n_records, (uint32_t)SC_TILE, 0u, &hdr->sam_total);
+	hipLaunchKernelGGL(scan_apply_kernel<uint32_t>, dim3(grid), dim3(SC_THREADS), 0, st, T->lens.p, &hdr->n_records, T->sums.p, T->rec_offs.p);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipMemcpyAsync(T->h_hdr, hdr, sizeof(TextHdr), hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipStreamSynchronize(st));
+	const TextHdr h2 = *T->h_hdr;
+	if (h2.flags & 8u) { rep->reason = URMAPX_TEXT_LONG_NAME; return URMAPX_OK; }
+	rep->sam_bytes = h2.sam_total;
+	if (h2.sam_total > sam_cap || !sam) { rep->reason = URMAPX_TEXT_SAM_CAP; return URMAPX_OK; }
+	if ((rc = T->sam.ensure((size_t)h2.sam_total + 64))) return rc;
+	A.sam = (char *)T->sam.p;
+	hipLaunchKernelGGL(sam_kernel<1>, dim3(grid), dim3(SAM_WAVES * 64), 0, st, A);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipMemcpyAsync(sam, T->sam.p, h2.sam_total, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipStreamSynchronize(st));
+	rep->records = n;
+	rep->mapped_q = h2.cnt[0]; rep->mapped_lowq = h2.cnt[1]; rep->unmapped = h2.cnt[2]; rep->unsupported = h2.cnt[3];
+	return URMAPX_OK;
+}
+
+}  // extern "C"

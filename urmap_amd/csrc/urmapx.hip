@@ -7,6 +7,7 @@
 #include <string>
 #include <vector>
 
+#include "internal.h"
 #include "kernels.h"
 
 using namespace urx;
@@ -21,35 +22,7 @@ const size_t SEQ_TAIL_PAD = 4096;  // zero bytes after the sequence: windows may
 const size_t BLOB_TAIL_PAD = 8;    // the last slot is fetched with an 8-byte load
 const uint32_t MAX_QL_PE = 320;    // kernel classes of the pair kernel (pairs themselves: <= 279 bases per mate, flagged per read)
 
-int hip_rc(hipError_t e) {
-	if (e == hipSuccess) return URMAPX_OK;
-	if (e == hipErrorOutOfMemory) return URMAPX_E_NOMEM;
-	return URMAPX_E_NODEVICE;
-}
-#define HIP_TRY(x)                         \
-	do {                                   \
-		hipError_t e_ = (x);               \
-		if (e_ != hipSuccess) return hip_rc(e_); \
-	} while (0)
-
 bool rd(FILE *f, void *p, size_t n) { return fread(p, 1, n, f) == n; }
-
-template <class T>
-struct DevBuf {
-	T *p = nullptr;
-	size_t cap = 0;
-	int ensure(size_t n) {
-		if (n <= cap) return URMAPX_OK;
-		if (p) (void)hipFree(p);
-		p = nullptr; cap = 0;
-		size_t want = n + n / 4 + 64;
-		hipError_t e = hipMalloc((void **)&p, want * sizeof(T));
-		if (e != hipSuccess) { p = nullptr; return hip_rc(e); }
-		cap = want;
-		return URMAPX_OK;
-	}
-	void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
-};
 
 }  // namespace
 
@@ -111,6 +84,13 @@ struct urmapx_ctx {
 	int pe_blocks[4] = {0, 0, 0, 0};
 	int blocks[6] = {0, 0, 0, 0, 0, 0};  // persistent grid size of the search kernel for read length classes <=192, <=320, <=256, <=128, <=512, <=1024
 };
+
+namespace urx {
+hipStream_t ctx_stream(urmapx_ctx *C) { return C->stream; }
+int ctx_device(const urmapx_ctx *C) { return C->device; }
+const urmapx_index *ctx_index(const urmapx_ctx *C) { return C->index; }
+const uint32_t *index_dev_seq_lengths(const urmapx_index *I) { return I->d_seqLengths; }
+}  // namespace urx
 
 extern "C" {
 
