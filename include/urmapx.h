@@ -254,6 +254,9 @@ typedef struct urmapx_map_report {  /* State1::HitStats' counters (state1.cpp:59
 int urmapx_map_files(urmapx_index *, const urmapx_map_options *, const char *fastq1, const char *fastq2, const char *samout,
                      const char *tabout, urmapx_map_report *report, char *err, size_t errcap);
 
+/* Page-locked chunk buffers of urmapx_map_files are kept (up to 3 GiB) for the next call in this process; this frees them. */
+void urmapx_host_pool_trim(void);
+
 /* ---- FASTQ bytes in, SAM bytes out (both text stages of -map on the device) ---- */
 /* One chunk of a FASTQ file, cut after a record's last '\n', goes to the device as it lies in the file; line ends,
  * record checks (FASTQSeqSource::GetNextLo, fastqseqsource.cpp:9-116), State1::Search and the SAM records
@@ -267,7 +270,7 @@ typedef struct urmapx_text urmapx_text;
 #define URMAPX_TEXT_RAGGED 2      /* line count not a multiple of four, or no '\n' at the end of the chunk */
 #define URMAPX_TEXT_BAD_RECORD 3  /* '@' missing, a byte that is not a letter, #bases != #quals, blank line */
 #define URMAPX_TEXT_LONG_NAME 4   /* target label longer than the device formatter takes */
-#define URMAPX_TEXT_SAM_CAP 5     /* sam_cap < report.sam_bytes (nothing written) */
+#define URMAPX_TEXT_SAM_CAP 5     /* sam_cap < report.sam_bytes: the chunk is mapped, its text waits for urmapx_text_fetch_sam */
 #define URMAPX_TEXT_TOO_LARGE 6   /* chunk over 1 GiB */
 typedef struct urmapx_text_report {
 	uint32_t records;   /* reads of the chunk */
@@ -281,6 +284,9 @@ void urmapx_text_destroy(urmapx_text *);
 /* fastq[fastq_bytes] and sam[sam_cap] are host arrays (page-locked ones cross PCIe without a staging copy). */
 int urmapx_text_map_se(urmapx_text *, const char *fastq, size_t fastq_bytes, unsigned minq, char *sam, size_t sam_cap,
                        urmapx_text_report *report);
+/* After URMAPX_TEXT_SAM_CAP: the text of the chunk just mapped into a buffer of at least report.sam_bytes (the search is
+ * not run again).  URMAPX_E_ARG if no such chunk is waiting. */
+int urmapx_text_fetch_sam(urmapx_text *, char *sam, size_t sam_cap, urmapx_text_report *report);
 
 /* ---- FASTQ input (host) ---- */
 /* Batch form of FASTQSeqSource::GetNextLo (fastqseqsource.cpp:9-116) over LineReader (linereader.cpp:14-113):

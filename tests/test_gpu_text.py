@@ -133,8 +133,15 @@ def test_chunks_the_device_parser_hands_back(golden):
     bad = list(lines[:36]) + [b"", b"", b"", b""]
     assert m.map_text_se(b"\n".join(bad) + b"\n")[1]["reason"] == api.TEXT_BAD_RECORD
     assert m.map_text_se(b"\n" * 1000)[1]["reason"] in (api.TEXT_RAGGED, api.TEXT_BAD_RECORD)
+    whole = m.map_text_se(ok)[0]
     sam, rep = m.map_text_se(ok, sam_cap=100)
-    assert sam is None and rep["reason"] == api.TEXT_SAM_CAP and rep["sam_bytes"] == len(m.map_text_se(ok)[0])
+    assert sam is None and rep["reason"] == api.TEXT_SAM_CAP and rep["sam_bytes"] == len(whole)
+    # the chunk is mapped; its text is fetched into a buffer that is large enough, without another search
+    assert m.fetch_text_sam(200)[1]["reason"] == api.TEXT_SAM_CAP
+    sam, rep = m.fetch_text_sam(len(whole))
+    assert sam == whole and rep["reason"] == api.TEXT_OK and rep["records"] == 10
+    with pytest.raises(api.UrmapxError):
+        m.fetch_text_sam(len(whole))
 
 
 def test_reads_outside_the_device_domain_are_counted(golden, tmp_path):

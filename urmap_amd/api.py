@@ -33,7 +33,7 @@ EXPORTS = (
     "urmapx_seed_probe", "urmapx_viterbi_batch", "urmapx_strerror", "urmapx_device_arch",
     "urmapx_make_ufi", "urmapx_build_slots", "urmapx_make_ufi_gpu", "urmapx_build_slots_gpu", "urmapx_sam_se", "urmapx_sam_header_sq", "urmapx_ctx_phase_cycles", "urmapx_ctx_read_cycles", "urmapx_ctx_stage_ms", "urmapx_ctx_dp_stats", "urmapx_map_pe", "urmapx_sam_pe", "urmapx_map_pe_device", "urmapx_ctx_set_pe_veryfast",
     "urmapx_fastq_open", "urmapx_fastq_next", "urmapx_fastq_error", "urmapx_fastq_close",
-    "urmapx_ctx_gather_microbench", "urmapx_map_files", "urmapx_text_create", "urmapx_text_destroy", "urmapx_text_map_se", "urmapx_ctx_set_pair_info", "urmapx_ctx_get_pair_info", "urmapx_tab_pe",
+    "urmapx_ctx_gather_microbench", "urmapx_map_files", "urmapx_host_pool_trim", "urmapx_text_create", "urmapx_text_destroy", "urmapx_text_map_se", "urmapx_text_fetch_sam", "urmapx_ctx_set_pair_info", "urmapx_ctx_get_pair_info", "urmapx_tab_pe",
 )
 
 
@@ -142,10 +142,13 @@ def lib():
     L.urmapx_tab_pe.restype = C.c_size_t
     L.urmapx_tab_pe.argtypes = [vp, vp, vp, vp, cp, u32, u32, i32, vp, C.c_size_t]
     L.urmapx_map_files.argtypes = [vp, C.POINTER(MapOptions), cp, cp, cp, cp, C.POINTER(MapReport), cp, C.c_size_t]
+    L.urmapx_host_pool_trim.argtypes = []
+    L.urmapx_host_pool_trim.restype = None
     L.urmapx_text_create.argtypes = [vp, C.POINTER(vp)]
     L.urmapx_text_destroy.argtypes = [vp]
     L.urmapx_text_destroy.restype = None
     L.urmapx_text_map_se.argtypes = [vp, vp, C.c_size_t, C.c_uint, vp, C.c_size_t, C.POINTER(TextReport)]
+    L.urmapx_text_fetch_sam.argtypes = [vp, vp, C.c_size_t, C.POINTER(TextReport)]
     L.urmapx_fastq_open.argtypes = [cp, C.POINTER(vp)]
     L.urmapx_fastq_next.restype = C.c_int64
     L.urmapx_fastq_next.argtypes = [vp, u32] + [C.POINTER(vp)] * 5
@@ -517,6 +520,14 @@ class Mapper:
         if rep.reason != TEXT_OK:
             return None, d
         return out[: rep.sam_bytes].tobytes(), d
+
+    def fetch_text_sam(self, sam_cap):
+        """After map_text_se returned TEXT_SAM_CAP: the text of that chunk (the search is not run again)."""
+        out = np.empty(max(1, sam_cap), dtype=np.uint8)
+        rep = TextReport()
+        _check(lib().urmapx_text_fetch_sam(self._text, out.ctypes.data, sam_cap, C.byref(rep)), "urmapx_text_fetch_sam")
+        d = {k: int(getattr(rep, k)) for k, _ in TextReport._fields_}
+        return (out[: rep.sam_bytes].tobytes() if rep.reason == TEXT_OK else None), d
 
     def close(self):
         if self._text is not None:

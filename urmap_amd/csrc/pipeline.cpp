@@ -122,6 +122,27 @@ private:
 	bool closed_ = false;
 };
 
+// URMAPX_PIPE_TRACE=1: every stage of every chunk with its start and end (ms since the first read), to stderr at the end
+struct Trace {
+	bool on = getenv("URMAPX_PIPE_TRACE") != nullptr;
+	std::mutex m;
+	std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+	struct Ev { const char *what; int lane; size_t job; double a, b; };
+	std::vector<Ev> evs;
+	double ms() const { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+	void add(const char *what, int lane, size_t job, double a) {
+		if (!on) return;
+		const double b = ms();
+		std::lock_guard<std::mutex> l(m);
+		evs.push_back(Ev{what, lane, job, a, b});
+	}
+	void dump() {
+		if (!on) return;
+		std::sort(evs.begin(), evs.end(), [](const Ev &x, const Ev &y) { return x.a < y.a; });
+		for (const Ev &e : evs) fprintf(stderr, "trace %-10s lane %d job %3zu  %9.2f .. %9.2f  (%7.2f ms)\n", e.what, e.lane, e.job, e.a, e.b, e.b - e.a);
+	}
+};
+
 struct Failure {
 	std::atomic<bool> set{false};
 	std::mutex m;
@@ -143,8 +164,8 @@ public:
 		fd_ = ::open(path, O_RDWR | O_CREAT | O_TRUNC, 0644);
 		if (fd_ < 0) return false;
 		struct stat st;
-		const char *mode = getenv("URMAPX_SAM_WRITE");  // "pwrite" | "mmap"
-		use_map_ = fstat(fd_, &st) == 0 && S_ISREG(st.st_mode) && !(mode && !strcmp(mode, "pwrite"));
+		const char *mode = getenv("URMAPX_SAM_WRITE");  // "pwrite" (default) | "mmap"
+		use_map_ = fstat(fd_, &st) == 0 && S_ISREG(st.st_mode) && mode && !strcmp(mode, "mmap");
 		return true;
 	}
 	bool is_open() const { return fd_ >= 0; }
@@ -206,6 +227,56 @@ private:
 	std::atomic<uint64_t> size_{0};
 };
 
+// Page-locked host buffers are kept for the next call of this process (pinning and unpinning a few hundred MB costs tens
+// of milliseconds each way, as much as mapping the chunk that travels in them); urmapx_host_pool_trim() lets go of them.
+class HostPool {
+public:
+	static HostPool &get() { static HostPool *p = new HostPool; return *p; }  // never destroyed: the runtime may be gone by then
+	char *acquire(size_t want, size_t &cap) {
+		{
+			std::lock_guard<std::mutex> l(m_);
+			size_t best = free_.size();
+			for (size_t i = 0; i < free_.size(); ++i)
+				if (free_[i].cap >= want && (best == free_.size() || free_[i].cap < free_[best].cap)) best = i;
+			if (best < free_.size() && free_[best].cap <= want + want / 2 + (8u << 20)) {
+				char *p = free_[best].p;
+				cap = free_[best].cap;
+				held_ -= cap;
+				free_.erase(free_.begin() + (long)best);
+				return p;
+			}
+		}
+		char *p = nullptr;
+		if (hipHostMalloc((void **)&p, want, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+		cap = want;
+		return p;
+	}
+	void release(char *p, size_t cap) {
+		if (!p) return;
+		{
+			std::lock_guard<std::mutex> l(m_);
+			if (held_ + cap <= kKeep) { free_.push_back(Buf{p, cap}); held_ += cap; return; }
+		}
+		(void)hipHostFree(p);
+	}
+	void trim() {
+		std::vector<Buf> v;
+		{
+			std::lock_guard<std::mutex> l(m_);
+			v.swap(free_);
+			held_ = 0;
+		}
+		for (const Buf &b : v) (void)hipHostFree(b.p);
+	}
+
+private:
+	struct Buf { char *p; size_t cap; };
+	static constexpr size_t kKeep = (size_t)3 << 30;
+	std::mutex m_;
+	std::vector<Buf> free_;
+	size_t held_ = 0;
+};
+
 // one chunk of the text phase: FASTQ bytes in, SAM bytes out, both page-locked
 struct TextJob {
 	char *in = nullptr, *out = nullptr;
@@ -214,16 +285,15 @@ struct TextJob {
 	urmapx_text_report rep;
 	int rc = 0;
 	~TextJob() {
-		if (in) (void)hipHostFree(in);
-		if (out) (void)hipHostFree(out);
+		HostPool::get().release(in, in_cap);
+		HostPool::get().release(out, out_cap);
 	}
 	static bool grow(char *&p, size_t &cap, size_t want) {
 		if (want <= cap) return true;
-		if (p) (void)hipHostFree(p);
-		p = nullptr; cap = 0;
-		if (hipHostMalloc((void **)&p, want, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); p = nullptr; return false; }
-		cap = want;
-		return true;
+		HostPool::get().release(p, cap);
+		p = HostPool::get().acquire(want, cap);
+		if (!p) cap = 0;
+		return p != nullptr;
 	}
 };
 
@@ -332,6 +402,7 @@ extern "C" int urmapx_map_files(urmapx_index *I, const urmapx_map_options *opt, 
 		}
 	}
 	const auto t1 = std::chrono::steady_clock::now();
+	Trace trace;
 	unsigned long long n_reads = 0, n_accept = 0, n_reject = 0, n_nohit = 0, n_unsupported = 0;
 	double t_parse = 0, t_gpu = 0, t_format = 0, t_write = 0;  // busy seconds per stage
 	auto now = [] { return std::chrono::steady_clock::now(); };
@@ -383,8 +454,9 @@ extern "C" int urmapx_map_files(urmapx_index *I, const urmapx_map_options *opt, 
 					if (stop.load()) break;
 					const size_t n = (size_t)(end - off);
 					const auto tp0 = now();
+					const double ta = trace.ms();
 					(void)hipSetDevice(phys(0));
-					if (!TextJob::grow(j->in, j->in_cap, n + n / 16 + 4096) || !TextJob::grow(j->out, j->out_cap, n + n / 2 + (1u << 20))) {
+					if (!TextJob::grow(j->in, j->in_cap, n + n / 16 + 4096)) {
 						fail.raise(URMAPX_E_NOMEM, "Page-locked chunk buffers: out of memory");
 						break;
 					}
@@ -401,6 +473,7 @@ extern "C" int urmapx_map_files(urmapx_index *I, const urmapx_map_options *opt, 
 						}
 					}
 					t_parse += secs(tp0, now());
+					trace.add("read", -1, b, ta);
 					if (!ok) { fail.raise(URMAPX_E_IO, std::string("Error reading ") + fastq1); break; }
 					j->nbytes = n; j->file_off = off;
 					tparsed[b % (size_t)n_lanes]->push(std::move(j));
@@ -411,6 +484,8 @@ extern "C" int urmapx_map_files(urmapx_index *I, const urmapx_map_options *opt, 
 			});
 			bool handed_back = false;
 			uint64_t resume_off = 0, lines_done = 0;
+			// write() calls on one file take turns (inode lock): more threads only add hand-overs
+			const int write_threads = getenv("URMAPX_WRITE_THREADS") ? std::max(1, atoi(getenv("URMAPX_WRITE_THREADS"))) : 1;
 			std::thread twriter([&] {
 				omp_set_num_threads(host_threads);
 				std::unique_ptr<TextJob> j;
@@ -420,10 +495,12 @@ extern "C" int urmapx_map_files(urmapx_index *I, const urmapx_map_options *opt, 
 						else if (j->rep.reason) { handed_back = true; stop.store(true); resume_off = j->file_off; }
 						else {
 							const auto tw0 = now();
-							if (!sink.write_at(j->out, (size_t)j->rep.sam_bytes, sam_off, std::max(1, host_threads / 2)))
+							const double ta = trace.ms();
+							if (!sink.write_at(j->out, (size_t)j->rep.sam_bytes, sam_off, write_threads))
 								fail.raise(URMAPX_E_IO, std::string("Error writing ") + samout);
 							sam_off += j->rep.sam_bytes;
 							t_write += secs(tw0, now());
+							trace.add("write", -1, b, ta);
 							n_reads += j->rep.records; n_accept += j->rep.mapped_q; n_reject += j->rep.mapped_lowq;
 							n_nohit += j->rep.unmapped; n_unsupported += j->rep.unsupported;
 							lines_done += 4ull * j->rep.records;
@@ -437,7 +514,11 @@ extern "C" int urmapx_map_files(urmapx_index *I, const urmapx_map_options *opt, 
 				tlanes.emplace_back([&, l] {
 					(void)hipSetDevice(phys(l % gpus));
 					urmapx_text *T = nullptr;
+					const double tc = trace.ms();
 					const int trc = urmapx_text_create(ctxs[(size_t)l], &T);
+					trace.add("create", l, 0, tc);
+					size_t nj = 0;
+					double sam_per_fastq = 1.12;
 					if (trc) fail.raise(trc, std::string("urmapx_text_create: ") + urmapx_strerror(trc));
 					std::unique_ptr<TextJob> j;
 					while (tparsed[(size_t)l]->pop(j)) {
@@ -445,26 +526,37 @@ extern "C" int urmapx_map_files(urmapx_index *I, const urmapx_map_options *opt, 
 						j->rc = 0;
 						if (T && !fail.set.load() && !stop.load()) {
 							const auto tg0 = now();
-							for (;;) {
-								j->rc = urmapx_text_map_se(T, j->in, j->nbytes, minq, j->out, j->out_cap, &j->rep);
-								if (j->rc || j->rep.reason != URMAPX_TEXT_SAM_CAP) break;
-								if (!TextJob::grow(j->out, j->out_cap, (size_t)j->rep.sam_bytes + (1u << 20))) { j->rc = URMAPX_E_NOMEM; break; }
+							const double ta = trace.ms();
+							// the SAM buffer is sized from the previous chunk's text (150-base reads: 1.09 x their FASTQ text); a chunk
+							// that needs more says so and its text is fetched into a larger one
+							if (!TextJob::grow(j->out, j->out_cap, (size_t)((double)j->nbytes * sam_per_fastq * 1.04) + (1u << 20))) j->rc = URMAPX_E_NOMEM;
+							if (!j->rc) j->rc = urmapx_text_map_se(T, j->in, j->nbytes, minq, j->out, j->out_cap, &j->rep);
+							if (!j->rc && j->rep.reason == URMAPX_TEXT_SAM_CAP) {
+								if (!TextJob::grow(j->out, j->out_cap, (size_t)j->rep.sam_bytes + j->rep.sam_bytes / 16 + (1u << 20))) j->rc = URMAPX_E_NOMEM;
+								else j->rc = urmapx_text_fetch_sam(T, j->out, j->out_cap, &j->rep);
 							}
+							if (!j->rc && !j->rep.reason && j->nbytes) sam_per_fastq = (double)j->rep.sam_bytes / (double)j->nbytes;
+							trace.add("gpu", l, (size_t)l + nj * (size_t)n_lanes, ta);
 							std::lock_guard<std::mutex> g(gpu_time_lock);
 							t_gpu += secs(tg0, now());
 						} else
 							j->rep.reason = 0xFFFFu;  // not mapped: the phase is ending
 						tmapped[(size_t)l]->push(std::move(j));
+						++nj;
 					}
 					tmapped[(size_t)l]->close();
+					const double td = trace.ms();
 					urmapx_text_destroy(T);
+					trace.add("destroy", l, 0, td);
 				});
 			for (auto &t : tlanes) t.join();
 			treader.join();
 			twriter.join();
 			{
+				const double tf = trace.ms();
 				std::unique_ptr<TextJob> j;
 				while (tfree.try_pop(j)) j.reset();
+				trace.add("unpin", -1, 0, tf);
 			}
 			close(fq);
 			if (!handed_back) resume_off = reader_end;
@@ -685,6 +777,7 @@ extern "C" int urmapx_map_files(urmapx_index *I, const urmapx_map_options *opt, 
 	if (have_sam && !sink.finish(sam_off)) fail.raise(URMAPX_E_IO, std::string("Error writing ") + samout);
 	if (ftab) fclose(ftab);
 	const auto t2 = std::chrono::steady_clock::now();
+	trace.dump();
 	release();
 	if (report) {
 		report->reads = n_reads; report->mapped_q = n_accept; report->mapped_lowq = n_reject; report->unmapped = n_nohit;
@@ -695,3 +788,5 @@ extern "C" int urmapx_map_files(urmapx_index *I, const urmapx_map_options *opt, 
 	if (fail.set.load()) { say(fail.msg); return fail.code; }
 	return n_unsupported ? URMAPX_E_UNSUPPORTED : URMAPX_OK;
 }
+
+extern "C" void urmapx_host_pool_trim(void) { HostPool::get().trim(); }

@@ -386,7 +386,27 @@ struct urmapx_text {
 	DevBuf<TextHdr> hdr;
 	uint32_t seq_count = 0;
 	TextHdr *h_hdr = nullptr;  // page-locked
+	// a chunk mapped and measured whose text has not been fetched (urmapx_text_fetch_sam)
+	bool pending = false;
+	SamArgs pending_args;
+	urmapx_text_report pending_rep;
 };
+
+static int fetch_sam(urmapx_text *T, char *sam, size_t sam_cap, urmapx_text_report *rep) {
+	*rep = T->pending_rep;
+	if (!sam || rep->sam_bytes > sam_cap) { rep->reason = URMAPX_TEXT_SAM_CAP; rep->records = 0; return URMAPX_OK; }
+	hipStream_t st = ctx_stream(T->C);
+	int rc;
+	if ((rc = T->sam.ensure((size_t)rep->sam_bytes + 64))) return rc;
+	SamArgs A = T->pending_args;
+	A.sam = (char *)T->sam.p;
+	hipLaunchKernelGGL(sam_kernel<1>, dim3(2048), dim3(SAM_WAVES * 64), 0, st, A);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipMemcpyAsync(sam, T->sam.p, rep->sam_bytes, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipStreamSynchronize(st));
+	T->pending = false;
+	return URMAPX_OK;
+}
 
 extern "C" {
 
@@ -433,6 +453,7 @@ void urmapx_text_destroy(urmapx_text *T) {
 int urmapx_text_map_se(urmapx_text *T, const char *fastq, size_t nbytes, unsigned minq, char *sam, size_t sam_cap, urmapx_text_report *rep) {
 	if (!T || !rep || (nbytes && !fastq)) return URMAPX_E_ARG;
 	memset(rep, 0, sizeof *rep);
+	T->pending = false;
 	if (nbytes == 0) return URMAPX_OK;
 	if (nbytes > (1u << 30)) { rep->reason = URMAPX_TEXT_TOO_LARGE; return URMAPX_OK; }
 	if (fastq[nbytes - 1] != '\n') { rep->reason = URMAPX_TEXT_RAGGED; return URMAPX_OK; }
@@ -495,17 +516,19 @@ int urmapx_text_map_se(urmapx_text *T, const char *fastq, size_t nbytes, unsigne
 	HIP_TRY(hipStreamSynchronize(st));
 	const TextHdr h2 = *T->h_hdr;
 	if (h2.flags & 8u) { rep->reason = URMAPX_TEXT_LONG_NAME; return URMAPX_OK; }
-	rep->sam_bytes = h2.sam_total;
-	if (h2.sam_total > sam_cap || !sam) { rep->reason = URMAPX_TEXT_SAM_CAP; return URMAPX_OK; }
-	if ((rc = T->sam.ensure((size_t)h2.sam_total + 64))) return rc;
-	A.sam = (char *)T->sam.p;
-	hipLaunchKernelGGL(sam_kernel<1>, dim3(grid), dim3(SAM_WAVES * 64), 0, st, A);
-	HIP_TRY(hipGetLastError());
-	HIP_TRY(hipMemcpyAsync(sam, T->sam.p, h2.sam_total, hipMemcpyDeviceToHost, st));
-	HIP_TRY(hipStreamSynchronize(st));
-	rep->records = n;
-	rep->mapped_q = h2.cnt[0]; rep->mapped_lowq = h2.cnt[1]; rep->unmapped = h2.cnt[2]; rep->unsupported = h2.cnt[3];
-	return URMAPX_OK;
+	T->pending = true;
+	T->pending_args = A;
+	memset(&T->pending_rep, 0, sizeof T->pending_rep);
+	T->pending_rep.records = n;
+	T->pending_rep.sam_bytes = h2.sam_total;
+	T->pending_rep.mapped_q = h2.cnt[0]; T->pending_rep.mapped_lowq = h2.cnt[1]; T->pending_rep.unmapped = h2.cnt[2]; T->pending_rep.unsupported = h2.cnt[3];
+	return fetch_sam(T, sam, sam_cap, rep);
+}
+
+int urmapx_text_fetch_sam(urmapx_text *T, char *sam, size_t sam_cap, urmapx_text_report *rep) {
+	if (!T || !rep || !T->pending) return URMAPX_E_ARG;
+	HIP_TRY(hipSetDevice(ctx_device(T->C)));
+	return fetch_sam(T, sam, sam_cap, rep);
 }
 
 }  // extern "C"
