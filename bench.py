@@ -570,7 +570,8 @@ def run_reference(ref_bin, oi, d, fq, fq_head, n_reads, n_head, cores, product_s
 def run_e2e(torch, api, oi, index, device, d_seq, seq_lengths, seq_offsets, L, sub, indel, n_reads, cores, ref_bin=None):
     """FASTQ file -> SAM file through urmapx_map_files (the command line's cmd_map) on the resident index: what a user of
     `urmap -map` gets, index load excluded as the reference reports it.  Files live in /dev/shm (memory), so this is the
-    parse + PCIe + map + format + write pipeline, not a disk benchmark.  The first 100 k records are compared with the
+    read + PCIe + parse + map + format + write pipeline, not a disk benchmark.  Chunks of the FASTQ file go to the device
+    as bytes and come back as the bytes of their SAM records (text_gpu.hip); the host reads and writes.  The first 100 k records are compared with the
     SAM the oracle writes for the same reads."""
     import shutil
     import tempfile
@@ -610,7 +611,8 @@ def run_e2e(torch, api, oi, index, device, d_seq, seq_lengths, seq_offsets, L, s
         out = {"value": round(rep["reads"] / rep["seconds"], 1), "unit": "reads/s", "reads": int(rep["reads"]),
                "seconds": round(rep["seconds"], 3), "first_run_seconds": round(runs[0]["seconds"], 3),
                "what": f"urmapx_map_files (= urmap -map): {fq_bytes / 1e9:.2f} GB FASTQ file -> {os.path.getsize(sam) / 1e9:.2f} GB SAM file, both in /dev/shm; "
-                       f"index resident, {rep['host_threads']} host threads, {rep['lanes']} mapping contexts on one GPU",
+                       f"index resident, {rep['host_threads']} host threads, {rep['lanes']} mapping contexts on one GPU; FASTQ parsing and SAM formatting on the device "
+                       f"(format_s 0 = no host formatting; write_s = one thread's pwrite into tmpfs, the stage that bounds the run)",
                "stage_busy_s": {k: round(rep[k], 3) for k in ("parse_s", "gpu_s", "format_s", "write_s")},
                "mapped_q10_frac": round(rep["mapped_q"] / max(1, rep["reads"]), 4),
                "sam_records_identical_to_oracle": bool(same), "sam_records_checked": len(want)}

@@ -163,3 +163,110 @@ def test_reads_outside_the_device_domain_are_counted(golden, tmp_path):
     recs = sam.split(b"\n")
     assert recs[0].split(b"\t")[0] == b"long" and recs[0].split(b"\t")[9] in (long_read,)
     assert recs[1] == b"short\t4\t*\t0\t0\t*\t*\t0\t0\tACGT\tIIII"
+
+
+# ---- the command line: text phase, hand-back to the host reader in the middle of a file ----
+EXE = os.path.join(ROOT, "urmap_amd", "urmap")
+
+
+def _run_cli(fq, ufi, out, batch, host_text=False, extra=()):
+    import subprocess
+    env = dict(os.environ)
+    env.pop("URMAPX_HOST_TEXT", None)
+    if host_text:
+        env["URMAPX_HOST_TEXT"] = "1"
+    return subprocess.run([EXE, "-map", fq, "-ufi", ufi, "-samout", out, "-batch", str(batch), *extra], stdout=subprocess.PIPE,
+                          stderr=subprocess.PIPE, timeout=300, env=env)
+
+
+@pytest.fixture(scope="module")
+def golden_ufi(tmp_path_factory):
+    d = tmp_path_factory.mktemp("textcli")
+    ufi = os.path.join(d, "g.ufi")
+    with gzip.open(os.path.join(GOLD, "g.ufi.gz"), "rb") as z, open(ufi, "wb") as f:
+        f.write(z.read())
+    return ufi
+
+
+def _sam_body(path):
+    return [l for l in open(path, "rb").read().split(b"\n") if l and not l.startswith(b"@PG")]
+
+
+@pytest.mark.parametrize("batch", [7, 64, 1000])
+@pytest.mark.parametrize("variant", ["plain", "crlf_second_half", "cr_in_one_record", "no_final_newline", "blank_lines_at_end",
+                                     "long_labels"])
+def test_cli_text_phase_and_host_reader_write_the_same_file(golden_ufi, tmp_path, variant, batch):
+    """Files the device parser takes whole, and files where it hands a chunk back in the middle ('\\r', a ragged end): the SAM
+    file is the reference's golden SAM either way, and equal byte for byte to what the host-reader-only pipeline writes."""
+    fq = open(os.path.join(GOLD, "se150.fq"), "rb").read()
+    lines = fq.split(b"\n")[:-1]
+    if variant == "crlf_second_half":
+        text = b"\n".join(lines[:800]) + b"\n" + b"\r\n".join(lines[800:]) + b"\r\n"
+    elif variant == "cr_in_one_record":
+        text = b"\n".join(lines[:1001]) + b"\r\n" + b"\n".join(lines[1001:]) + b"\n"
+    elif variant == "no_final_newline":
+        text = fq[:-1]
+    elif variant == "blank_lines_at_end":
+        text = fq + b"\n\n\n"
+    elif variant == "long_labels":
+        text = b"".join((l + b" " + b"z" * (i % 300) if i % 4 == 0 else l) + b"\n" for i, l in enumerate(lines))
+    else:
+        text = fq
+    src = os.path.join(tmp_path, "in.fq")
+    open(src, "wb").write(text)
+    a, b = os.path.join(tmp_path, "text.sam"), os.path.join(tmp_path, "host.sam")
+    r1 = _run_cli(src, golden_ufi, a, batch)
+    r2 = _run_cli(src, golden_ufi, b, batch, host_text=True)
+    assert r1.returncode == 0 and r2.returncode == 0, (r1.stderr.decode()[-1500:], r2.stderr.decode()[-1500:])
+    assert _sam_body(a) == _sam_body(b)
+    assert _sam_body(a) == [l for l in open(os.path.join(GOLD, "se150.sam"), "rb").read().split(b"\n") if l]
+    # the HitStats report (stderr) is the same too
+    tail = lambda r: [l for l in r.stderr.decode().splitlines() if "%" in l or "reads" in l.lower()]
+    assert tail(r1) == tail(r2)
+
+
+@pytest.mark.parametrize("batch", [5, 50])
+@pytest.mark.parametrize("damage,needle", [("digit_in_bases", "Invalid sequence letter"), ("short_qual", "Bad FASTQ record"),
+                                           ("no_at", "expected '@'"), ("blank_in_middle", "Empty line nr"),
+                                           ("truncated", "Unexpected end-of-file")])
+def test_cli_malformed_record_late_in_the_file_dies_with_the_reference_message(golden_ufi, tmp_path, damage, needle, batch):
+    """The record is in a later chunk: the device parser hands that chunk back, the host reader takes over at its first byte
+    with the line count kept, and the message (with its line number) is the one the host-only pipeline gives."""
+    fq = open(os.path.join(GOLD, "se150.fq"), "rb").read()
+    lines = fq.split(b"\n")[:-1]
+    k = 4 * 301  # first line of record 301
+    if damage == "digit_in_bases":
+        lines[k + 1] = lines[k + 1][:20] + b"7" + lines[k + 1][21:]
+    elif damage == "short_qual":
+        lines[k + 3] = lines[k + 3][:-3]
+    elif damage == "no_at":
+        lines[k] = b"r" + lines[k][1:]
+    elif damage == "blank_in_middle":
+        lines.insert(k, b"")
+    elif damage == "truncated":
+        lines = lines[: k + 2]
+    src = os.path.join(tmp_path, "bad.fq")
+    open(src, "wb").write(b"\n".join(lines) + b"\n")
+    r1 = _run_cli(src, golden_ufi, os.path.join(tmp_path, "a.sam"), batch)
+    r2 = _run_cli(src, golden_ufi, os.path.join(tmp_path, "b.sam"), batch, host_text=True)
+    assert r1.returncode == 1 and r2.returncode == 1
+    m1 = [l for l in r1.stderr.decode().splitlines() if needle in l]
+    m2 = [l for l in r2.stderr.decode().splitlines() if needle in l]
+    assert m1 and m1 == m2, (r1.stderr.decode()[-800:], r2.stderr.decode()[-800:])
+
+
+def test_map_files_reports_the_same_counters_with_and_without_the_text_phase(golden, tmp_path):
+    from urmap_amd import api
+    fq = os.path.join(GOLD, "se250.fq")
+    a, b = os.path.join(tmp_path, "a.sam"), os.path.join(tmp_path, "b.sam")
+    os.environ.pop("URMAPX_HOST_TEXT", None)
+    r1 = api.map_files(golden["index"], fq, samout=a, batch=33, streams=2, cmdline="t")
+    os.environ["URMAPX_HOST_TEXT"] = "1"
+    try:
+        r2 = api.map_files(golden["index"], fq, samout=b, batch=33, streams=2, cmdline="t")
+    finally:
+        os.environ.pop("URMAPX_HOST_TEXT", None)
+    for k in ("reads", "mapped_q", "mapped_lowq", "unmapped", "unsupported"):
+        assert r1[k] == r2[k], k
+    assert open(a, "rb").read() == open(b, "rb").read()
+    api.lib().urmapx_host_pool_trim()
