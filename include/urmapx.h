@@ -272,6 +272,7 @@ typedef struct urmapx_text urmapx_text;
 #define URMAPX_TEXT_LONG_NAME 4   /* target label longer than the device formatter takes */
 #define URMAPX_TEXT_SAM_CAP 5     /* sam_cap < report.sam_bytes: the chunk is mapped, its text waits for urmapx_text_fetch_sam */
 #define URMAPX_TEXT_TOO_LARGE 6   /* chunk over 1 GiB */
+#define URMAPX_TEXT_UNEQUAL 7     /* pairs: the two chunks do not hold the same number of records */
 typedef struct urmapx_text_report {
 	uint32_t records;   /* reads of the chunk */
 	uint32_t reason;    /* URMAPX_TEXT_*; non-zero: nothing was written */
@@ -284,6 +285,11 @@ void urmapx_text_destroy(urmapx_text *);
 /* fastq[fastq_bytes] and sam[sam_cap] are host arrays (page-locked ones cross PCIe without a staging copy). */
 int urmapx_text_map_se(urmapx_text *, const char *fastq, size_t fastq_bytes, unsigned minq, char *sam, size_t sam_cap,
                        urmapx_text_report *report);
+/* Pairs (-map2): a chunk of each mate file holding the same number of records; record 2i and 2i+1 of the text are the
+ * mates of pair i with SetSAM2's flags, RNEXT, PNEXT and TLEN (output2.cpp:18-128); report.records counts reads (2 per
+ * pair).  -tabbedout lines are not made here (urmapx_map_pe + urmapx_tab_pe). */
+int urmapx_text_map_pe(urmapx_text *, const char *fastq1, size_t fastq1_bytes, const char *fastq2, size_t fastq2_bytes,
+                       unsigned minq, char *sam, size_t sam_cap, urmapx_text_report *report);
 /* After URMAPX_TEXT_SAM_CAP: the text of the chunk just mapped into a buffer of at least report.sam_bytes (the search is
  * not run again).  URMAPX_E_ARG if no such chunk is waiting. */
 int urmapx_text_fetch_sam(urmapx_text *, char *sam, size_t sam_cap, urmapx_text_report *report);

@@ -270,3 +270,85 @@ def test_map_files_reports_the_same_counters_with_and_without_the_text_phase(gol
         assert r1[k] == r2[k], k
     assert open(a, "rb").read() == open(b, "rb").read()
     api.lib().urmapx_host_pool_trim()
+
+
+# ---- pairs ----
+@pytest.mark.parametrize("name,ufi_gz", [("pe150", "g.ufi.gz"), ("pe100_noisy", "g.ufi.gz"), ("pe120_rep", "r.ufi.gz")])
+def test_golden_mate_files_to_golden_pair_sam(tmp_path, name, ufi_gz):
+    """urmapx_text_map_pe: the bytes of the two mate files -> the reference's golden -map2 SAM (flags, RNEXT, PNEXT, TLEN
+    of SetSAM2, output2.cpp:61-128)."""
+    from urmap_amd import api
+    ufi = os.path.join(tmp_path, "x.ufi")
+    with gzip.open(os.path.join(GOLD, ufi_gz), "rb") as z, open(ufi, "wb") as f:
+        f.write(z.read())
+    idx = api.Index.open(ufi).upload(0)
+    m = api.Mapper(idx, device=0)
+    f1 = open(os.path.join(GOLD, name + "_1.fq"), "rb").read()
+    f2 = open(os.path.join(GOLD, name + "_2.fq"), "rb").read()
+    sam, rep = m.map_text_pe(f1, f2)
+    assert rep["reason"] == api.TEXT_OK, rep
+    want = _records(open(os.path.join(GOLD, name + ".sam"), "rb").read())
+    assert _records(sam) == want
+    assert rep["records"] == len(want) and rep["mapped_q"] + rep["mapped_lowq"] + rep["unmapped"] == len(want)
+    # chunks with different record counts, or a damaged mate file, are handed back
+    l2 = f2.split(b"\n")[:-1]
+    assert m.map_text_pe(f1, b"\n".join(l2[:-4]) + b"\n")[1]["reason"] == api.TEXT_UNEQUAL
+    assert m.map_text_pe(f1, f2.replace(b"\n", b"\r\n", 3))[1]["reason"] == api.TEXT_CR
+    assert m.map_text_pe(f1, b"\n".join(l2[:-1]) + b"\n")[1]["reason"] == api.TEXT_RAGGED
+    bad = list(l2)
+    bad[9] = bad[9][:-2]
+    assert m.map_text_pe(f1, b"\n".join(bad) + b"\n")[1]["reason"] == api.TEXT_BAD_RECORD
+    m.close()
+    idx.close()
+
+
+def _run_cli2(fq1, fq2, ufi, out, batch, host_text=False, extra=()):
+    import subprocess
+    env = dict(os.environ)
+    env.pop("URMAPX_HOST_TEXT", None)
+    if host_text:
+        env["URMAPX_HOST_TEXT"] = "1"
+    return subprocess.run([EXE, "-map2", fq1, "-reverse", fq2, "-ufi", ufi, "-samout", out, "-batch", str(batch), *extra],
+                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=env)
+
+
+@pytest.mark.parametrize("batch", [6, 50, 2000])
+@pytest.mark.parametrize("variant", ["plain", "crlf_in_mates_from_the_middle", "no_final_newline_in_one", "longer_labels_in_mates"])
+def test_cli_map2_text_phase_and_host_reader_write_the_same_file(golden_ufi, tmp_path, variant, batch):
+    f1 = open(os.path.join(GOLD, "pe150_1.fq"), "rb").read()
+    f2 = open(os.path.join(GOLD, "pe150_2.fq"), "rb").read()
+    l2 = f2.split(b"\n")[:-1]
+    if variant == "crlf_in_mates_from_the_middle":
+        f2 = b"\n".join(l2[:600]) + b"\n" + b"\r\n".join(l2[600:]) + b"\r\n"
+    elif variant == "no_final_newline_in_one":
+        f2 = f2[:-1]
+    elif variant == "longer_labels_in_mates":
+        f2 = b"".join((l + b" " + b"q" * (i % 211) if i % 4 == 0 else l) + b"\n" for i, l in enumerate(l2))
+    a1, a2 = os.path.join(tmp_path, "m1.fq"), os.path.join(tmp_path, "m2.fq")
+    open(a1, "wb").write(f1)
+    open(a2, "wb").write(f2)
+    a, b = os.path.join(tmp_path, "text.sam"), os.path.join(tmp_path, "host.sam")
+    r1 = _run_cli2(a1, a2, golden_ufi, a, batch)
+    r2 = _run_cli2(a1, a2, golden_ufi, b, batch, host_text=True)
+    assert r1.returncode == 0 and r2.returncode == 0, (r1.stderr.decode()[-1500:], r2.stderr.decode()[-1500:])
+    assert _sam_body(a) == _sam_body(b)
+    assert _sam_body(a) == [l for l in open(os.path.join(GOLD, "pe150.sam"), "rb").read().split(b"\n") if l]
+
+
+@pytest.mark.parametrize("batch", [10, 100])
+@pytest.mark.parametrize("which,cut", [(1, 4 * 120), (2, 4 * 120), (2, 4 * 120 + 2)])
+def test_cli_map2_unequal_mate_files_die_with_the_host_pipelines_message(golden_ufi, tmp_path, which, cut, batch):
+    f1 = open(os.path.join(GOLD, "pe150_1.fq"), "rb").read().split(b"\n")[:-1]
+    f2 = open(os.path.join(GOLD, "pe150_2.fq"), "rb").read().split(b"\n")[:-1]
+    if which == 1:
+        f1 = f1[:cut]
+    else:
+        f2 = f2[:cut]
+    a1, a2 = os.path.join(tmp_path, "m1.fq"), os.path.join(tmp_path, "m2.fq")
+    open(a1, "wb").write(b"\n".join(f1) + b"\n")
+    open(a2, "wb").write(b"\n".join(f2) + b"\n")
+    r1 = _run_cli2(a1, a2, golden_ufi, os.path.join(tmp_path, "a.sam"), batch)
+    r2 = _run_cli2(a1, a2, golden_ufi, os.path.join(tmp_path, "b.sam"), batch, host_text=True)
+    assert r1.returncode == 1 and r2.returncode == 1
+    last = lambda r: [l for l in r.stderr.decode().splitlines() if l.strip()][-1]
+    assert last(r1) == last(r2), (r1.stderr.decode()[-600:], r2.stderr.decode()[-600:])

@@ -33,7 +33,7 @@ EXPORTS = (
     "urmapx_seed_probe", "urmapx_viterbi_batch", "urmapx_strerror", "urmapx_device_arch",
     "urmapx_make_ufi", "urmapx_build_slots", "urmapx_make_ufi_gpu", "urmapx_build_slots_gpu", "urmapx_sam_se", "urmapx_sam_header_sq", "urmapx_ctx_phase_cycles", "urmapx_ctx_read_cycles", "urmapx_ctx_stage_ms", "urmapx_ctx_dp_stats", "urmapx_map_pe", "urmapx_sam_pe", "urmapx_map_pe_device", "urmapx_ctx_set_pe_veryfast",
     "urmapx_fastq_open", "urmapx_fastq_next", "urmapx_fastq_error", "urmapx_fastq_close",
-    "urmapx_ctx_gather_microbench", "urmapx_map_files", "urmapx_host_pool_trim", "urmapx_text_create", "urmapx_text_destroy", "urmapx_text_map_se", "urmapx_text_fetch_sam", "urmapx_ctx_set_pair_info", "urmapx_ctx_get_pair_info", "urmapx_tab_pe",
+    "urmapx_ctx_gather_microbench", "urmapx_map_files", "urmapx_host_pool_trim", "urmapx_text_create", "urmapx_text_destroy", "urmapx_text_map_se", "urmapx_text_map_pe", "urmapx_text_fetch_sam", "urmapx_ctx_set_pair_info", "urmapx_ctx_get_pair_info", "urmapx_tab_pe",
 )
 
 
@@ -65,7 +65,7 @@ class TextReport(C.Structure):
                 ("mapped_lowq", C.c_uint64), ("unmapped", C.c_uint64), ("unsupported", C.c_uint64)]
 
 
-TEXT_OK, TEXT_CR, TEXT_RAGGED, TEXT_BAD_RECORD, TEXT_LONG_NAME, TEXT_SAM_CAP, TEXT_TOO_LARGE = range(7)
+TEXT_OK, TEXT_CR, TEXT_RAGGED, TEXT_BAD_RECORD, TEXT_LONG_NAME, TEXT_SAM_CAP, TEXT_TOO_LARGE, TEXT_UNEQUAL = range(8)
 
 
 class UrmapxError(RuntimeError):
@@ -148,6 +148,7 @@ def lib():
     L.urmapx_text_destroy.argtypes = [vp]
     L.urmapx_text_destroy.restype = None
     L.urmapx_text_map_se.argtypes = [vp, vp, C.c_size_t, C.c_uint, vp, C.c_size_t, C.POINTER(TextReport)]
+    L.urmapx_text_map_pe.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, C.c_uint, vp, C.c_size_t, C.POINTER(TextReport)]
     L.urmapx_text_fetch_sam.argtypes = [vp, vp, C.c_size_t, C.POINTER(TextReport)]
     L.urmapx_fastq_open.argtypes = [cp, C.POINTER(vp)]
     L.urmapx_fastq_next.restype = C.c_int64
@@ -516,6 +517,23 @@ class Mapper:
         rep = TextReport()
         _check(lib().urmapx_text_map_se(self._text, src.ctypes.data if len(src) else None, len(src), minq, out.ctypes.data, cap, C.byref(rep)),
                "urmapx_text_map_se")
+        d = {k: int(getattr(rep, k)) for k, _ in TextReport._fields_}
+        if rep.reason != TEXT_OK:
+            return None, d
+        return out[: rep.sam_bytes].tobytes(), d
+
+    def map_text_pe(self, fastq1: bytes, fastq2: bytes, minq=10, sam_cap=None):
+        """Chunks of the two mate files with the same number of records -> (SAM text of the pairs | None, report dict)."""
+        if self._text is None:
+            t = C.c_void_p()
+            _check(lib().urmapx_text_create(self.h, C.byref(t)), "urmapx_text_create")
+            self._text = t
+        a, b = np.frombuffer(fastq1, dtype=np.uint8), np.frombuffer(fastq2, dtype=np.uint8)
+        cap = sam_cap if sam_cap is not None else 2 * (len(a) + len(b)) + 4096 * 64
+        out = np.empty(max(1, cap), dtype=np.uint8)
+        rep = TextReport()
+        _check(lib().urmapx_text_map_pe(self._text, a.ctypes.data if len(a) else out.ctypes.data, len(a), b.ctypes.data if len(b) else out.ctypes.data,
+                                        len(b), minq, out.ctypes.data, cap, C.byref(rep)), "urmapx_text_map_pe")
         d = {k: int(getattr(rep, k)) for k, _ in TextReport._fields_}
         if rep.reason != TEXT_OK:
             return None, d

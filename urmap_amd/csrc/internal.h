@@ -35,10 +35,12 @@ struct DevBuf {
 	void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
+// kernel classes of the pair kernel (pairs themselves: <= 279 bases per mate, flagged per read)
+constexpr uint32_t MAX_QL_PE = 320;
+
 // what text_gpu.hip needs of a mapping context (defined in urmapx.hip)
 hipStream_t ctx_stream(urmapx_ctx *);
 int ctx_device(const urmapx_ctx *);
 const urmapx_index *ctx_index(const urmapx_ctx *);
-const uint32_t *index_dev_seq_lengths(const urmapx_index *);
 
 }  // namespace urx

@@ -280,8 +280,9 @@ private:
 // one chunk of the text phase: FASTQ bytes in, SAM bytes out, both page-locked
 struct TextJob {
 	char *in = nullptr, *out = nullptr;
-	size_t in_cap = 0, out_cap = 0, nbytes = 0;
-	uint64_t file_off = 0;
+	size_t in_cap = 0, out_cap = 0, nbytes = 0, nbytes2 = 0;  // pairs: the mate file's chunk is in[...] too, at in2
+	char *in2 = nullptr;
+	uint64_t file_off = 0, file_off2 = 0;
 	urmapx_text_report rep;
 	int rc = 0;
 	~TextJob() {
@@ -409,18 +410,29 @@ extern "C" int urmapx_map_files(urmapx_index *I, const urmapx_map_options *opt, 
 	auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
 	std::mutex gpu_time_lock;
 
-	// ---- text phase: single-end reads from a plain file, FASTQ bytes -> device -> SAM bytes ----
+	// ---- text phase: reads from plain files, FASTQ bytes -> device -> SAM bytes ----
 	bool host_phase = true;
 	{
-		const size_t l1 = strlen(fastq1);
-		const bool gz = l1 > 3 && !strcmp(fastq1 + l1 - 3, ".gz");
-		struct stat st;
-		int fq = -1;
-		if (!paired && have_sam && !gz && strcmp(fastq1, "-") != 0 && !getenv("URMAPX_HOST_TEXT")) fq = open(fastq1, O_RDONLY);
-		if (fq >= 0 && (fstat(fq, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size == 0)) { close(fq); fq = -1; }
+		auto open_plain = [&](const char *path, uint64_t &size) {  // a regular file that is not .gz, else -1
+			const size_t l = strlen(path);
+			if ((l > 3 && !strcmp(path + l - 3, ".gz")) || !strcmp(path, "-")) return -1;
+			const int fd = open(path, O_RDONLY);
+			struct stat st;
+			if (fd >= 0 && (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size == 0)) { close(fd); return -1; }
+			if (fd >= 0) size = (uint64_t)st.st_size;
+			return fd;
+		};
+		uint64_t fsize = 0, fsize2 = 0;
+		int fq = -1, fq2 = -1;
+		if (have_sam && !ftab && !getenv("URMAPX_HOST_TEXT")) {  // -tabbedout lines are made on the host (urmapx_tab_pe)
+			fq = open_plain(fastq1, fsize);
+			if (fq >= 0 && paired) {
+				fq2 = open_plain(fastq2, fsize2);
+				if (fq2 < 0) { close(fq); fq = -1; }
+			}
+		}
 		if (fq >= 0) {
-			const uint64_t fsize = (uint64_t)st.st_size;
-			size_t chunk_bytes;  // `batch` reads at the record size the head of the file shows
+			size_t chunk_bytes;  // `batch` reads (pairs: batch / 2 of each file) at the record size the head of the file shows
 			{
 				std::vector<char> head(1u << 16);
 				const ssize_t k = pread(fq, head.data(), head.size(), 0);
@@ -428,7 +440,7 @@ extern "C" int urmapx_map_files(urmapx_index *I, const urmapx_map_options *opt, 
 				for (ssize_t i = 0; i < k; ++i)
 					if (head[(size_t)i] == '\n' && (++nl & 3) == 0) last = (size_t)i + 1;
 				const double rec = nl >= 4 ? (double)last / (double)(nl / 4) : 512.0;
-				chunk_bytes = (size_t)std::min(std::max(rec * (double)batch, 4096.0), 536870912.0);
+				chunk_bytes = (size_t)std::min(std::max(rec * (double)(paired ? std::max(1u, batch / 2) : batch), 4096.0), 536870912.0);
 			}
 			using TextChannel = Channel<std::unique_ptr<TextJob>>;
 			std::vector<std::unique_ptr<TextChannel>> tparsed, tmapped;
@@ -440,9 +452,44 @@ extern "C" int urmapx_map_files(urmapx_index *I, const urmapx_map_options *opt, 
 			TextChannel tfree((size_t)n_jobs);
 			for (int k = 0; k < n_jobs; ++k) tfree.push(std::make_unique<TextJob>());
 			std::atomic<bool> stop{false};
-			uint64_t reader_end = 0;  // first byte the reader did not hand to a lane
+			uint64_t reader_end = 0, reader_end2 = 0;  // first byte of each file the reader did not hand to a lane
+			const int read_threads = std::max(1, host_threads / 2);
+			// [off, off + n) of a file into dst, by several threads
+			auto read_range = [&](int fd, char *dst, uint64_t off, size_t n) {
+				bool ok = true;
+#pragma omp parallel for schedule(static, 1) num_threads(read_threads)
+				for (int t = 0; t < read_threads; ++t) {
+					const size_t lo = n * (size_t)t / (size_t)read_threads, hi = n * (size_t)(t + 1) / (size_t)read_threads;
+					size_t done = lo;
+					while (done < hi) {
+						ssize_t k = pread(fd, dst + done, hi - done, (off_t)(off + done));
+						if (k <= 0) { ok = false; break; }
+						done += (size_t)k;
+					}
+				}
+				return ok;
+			};
+			// '\n' count of each of read_threads slices of p[0, n)
+			auto count_lines = [&](const char *p, size_t n, std::vector<size_t> &per) {
+				per.assign((size_t)read_threads, 0);
+#pragma omp parallel for schedule(static, 1) num_threads(read_threads)
+				for (int t = 0; t < read_threads; ++t) {
+					const char *c = p + n * (size_t)t / (size_t)read_threads, *e = p + n * (size_t)(t + 1) / (size_t)read_threads;
+					size_t k = 0;
+					while (c < e) {
+						const char *nl = (const char *)memchr(c, '\n', (size_t)(e - c));
+						if (!nl) break;
+						++k;
+						c = nl + 1;
+					}
+					per[(size_t)t] = k;
+				}
+			};
 			std::thread treader([&] {
-				uint64_t off = 0;
+				omp_set_num_threads(read_threads);
+				uint64_t off = 0, off2 = 0;
+				double bytes2_per_byte1 = 1.0;
+				std::vector<size_t> per;
 				for (size_t b = 0; off < fsize && !stop.load() && !fail.set.load(); ++b) {
 					uint64_t end = fsize;
 					if (off + chunk_bytes < fsize) {
@@ -456,34 +503,67 @@ extern "C" int urmapx_map_files(urmapx_index *I, const urmapx_map_options *opt, 
 					const auto tp0 = now();
 					const double ta = trace.ms();
 					(void)hipSetDevice(phys(0));
-					if (!TextJob::grow(j->in, j->in_cap, n + n / 16 + 4096)) {
-						fail.raise(URMAPX_E_NOMEM, "Page-locked chunk buffers: out of memory");
-						break;
-					}
-					bool ok = true;
-					const int T = std::max(1, host_threads / 2);
-#pragma omp parallel for schedule(static, 1) num_threads(T)
-					for (int t = 0; t < T; ++t) {
-						const size_t lo = n * (size_t)t / (size_t)T, hi = n * (size_t)(t + 1) / (size_t)T;
-						size_t done = lo;
-						while (done < hi) {
-							ssize_t k = pread(fq, j->in + done, hi - done, (off_t)(off + done));
-							if (k <= 0) { ok = false; break; }
-							done += (size_t)k;
+					const size_t n_pad = (n + 4095) & ~(size_t)4095;  // the mate file's chunk starts here
+					size_t want = n + n / 16 + 4096;
+					if (paired) want = n_pad + (size_t)((double)n * bytes2_per_byte1 * 1.25) + (4u << 20);
+					if (!TextJob::grow(j->in, j->in_cap, want)) { fail.raise(URMAPX_E_NOMEM, "Page-locked chunk buffers: out of memory"); break; }
+					if (!read_range(fq, j->in, off, n)) { fail.raise(URMAPX_E_IO, std::string("Error reading ") + fastq1); break; }
+					j->nbytes = n; j->file_off = off; j->nbytes2 = 0; j->file_off2 = off2; j->in2 = nullptr;
+					if (paired) {
+						// the mate file's chunk: as many lines as this one holds
+						count_lines(j->in, n, per);
+						size_t lines = 0;
+						for (size_t k : per) lines += k;
+						char *dst = j->in + n_pad;
+						const size_t room = j->in_cap - n_pad;
+						const uint64_t left2 = fsize2 - off2;
+						size_t have = 0, n2 = 0;
+						bool found = false, give_up = false;
+						if (end == fsize) {  // last chunk: whatever the mate file still holds (the device parser says if it is not the same count)
+							if (left2 > room) give_up = true;
+							else { have = (size_t)left2; found = true; n2 = have; if (have && !read_range(fq2, dst, off2, have)) { fail.raise(URMAPX_E_IO, std::string("Error reading ") + fastq2); break; } }
 						}
+						while (!found && !give_up) {
+							size_t upto = have ? have + have / 4 + (1u << 20) : (size_t)((double)n * bytes2_per_byte1) + (1u << 16);
+							upto = (size_t)std::min<uint64_t>(std::min<uint64_t>(upto, room), left2);
+							if (upto <= have) { give_up = true; break; }  // out of room, or out of file with too few lines
+							if (!read_range(fq2, dst + have, off2 + have, upto - have)) { fail.raise(URMAPX_E_IO, std::string("Error reading ") + fastq2); give_up = true; break; }
+							have = upto;
+							count_lines(dst, have, per);
+							size_t cum = 0;
+							for (int t = 0; t < read_threads && !found; ++t) {
+								if (cum + per[(size_t)t] >= lines && lines > 0) {  // the chunk ends in this slice: walk to its last '\n'
+									const char *c = dst + have * (size_t)t / (size_t)read_threads, *e = dst + have * (size_t)(t + 1) / (size_t)read_threads;
+									size_t need = lines - cum;
+									while (need) {
+										const char *nl = (const char *)memchr(c, '\n', (size_t)(e - c));
+										c = nl + 1;
+										--need;
+									}
+									n2 = (size_t)(c - dst);
+									found = true;
+								}
+								cum += per[(size_t)t];
+							}
+							if (!found && have == left2) give_up = true;  // the mate file ends first: the host reader words that
+						}
+						if (fail.set.load()) break;
+						if (give_up) { tfree.push(std::move(j)); break; }
+						j->in2 = dst; j->nbytes2 = n2;
+						if (n && n2) bytes2_per_byte1 = (double)n2 / (double)n;
 					}
 					t_parse += secs(tp0, now());
 					trace.add("read", -1, b, ta);
-					if (!ok) { fail.raise(URMAPX_E_IO, std::string("Error reading ") + fastq1); break; }
-					j->nbytes = n; j->file_off = off;
+					const size_t adv2 = j->nbytes2;
 					tparsed[b % (size_t)n_lanes]->push(std::move(j));
 					off = end;
+					off2 += adv2;
 				}
-				reader_end = off;
+				reader_end = off; reader_end2 = off2;
 				for (auto &c : tparsed) c->close();
 			});
 			bool handed_back = false;
-			uint64_t resume_off = 0, lines_done = 0;
+			uint64_t resume_off = 0, resume_off2 = 0, lines_done = 0;  // lines_done: per file
 			// write() calls on one file take turns (inode lock): more threads only add hand-overs
 			const int write_threads = getenv("URMAPX_WRITE_THREADS") ? std::max(1, atoi(getenv("URMAPX_WRITE_THREADS"))) : 1;
 			std::thread twriter([&] {
@@ -491,8 +571,8 @@ extern "C" int urmapx_map_files(urmapx_index *I, const urmapx_map_options *opt, 
 				std::unique_ptr<TextJob> j;
 				for (size_t b = 0; tmapped[b % (size_t)n_lanes]->pop(j); ++b) {
 					if (!handed_back && !fail.set.load()) {
-						if (j->rc) fail.raise(j->rc, std::string("urmapx_text_map_se: ") + urmapx_strerror(j->rc));
-						else if (j->rep.reason) { handed_back = true; stop.store(true); resume_off = j->file_off; }
+						if (j->rc) fail.raise(j->rc, std::string(paired ? "urmapx_text_map_pe: " : "urmapx_text_map_se: ") + urmapx_strerror(j->rc));
+						else if (j->rep.reason) { handed_back = true; stop.store(true); resume_off = j->file_off; resume_off2 = j->file_off2; }
 						else {
 							const auto tw0 = now();
 							const double ta = trace.ms();
@@ -503,7 +583,7 @@ extern "C" int urmapx_map_files(urmapx_index *I, const urmapx_map_options *opt, 
 							trace.add("write", -1, b, ta);
 							n_reads += j->rep.records; n_accept += j->rep.mapped_q; n_reject += j->rep.mapped_lowq;
 							n_nohit += j->rep.unmapped; n_unsupported += j->rep.unsupported;
-							lines_done += 4ull * j->rep.records;
+							lines_done += (paired ? 2ull : 4ull) * j->rep.records;
 						}
 					}
 					tfree.push(std::move(j));
@@ -529,13 +609,16 @@ extern "C" int urmapx_map_files(urmapx_index *I, const urmapx_map_options *opt, 
 							const double ta = trace.ms();
 							// the SAM buffer is sized from the previous chunk's text (150-base reads: 1.09 x their FASTQ text); a chunk
 							// that needs more says so and its text is fetched into a larger one
-							if (!TextJob::grow(j->out, j->out_cap, (size_t)((double)j->nbytes * sam_per_fastq * 1.04) + (1u << 20))) j->rc = URMAPX_E_NOMEM;
-							if (!j->rc) j->rc = urmapx_text_map_se(T, j->in, j->nbytes, minq, j->out, j->out_cap, &j->rep);
+							const size_t fq_bytes = j->nbytes + j->nbytes2;
+							if (!TextJob::grow(j->out, j->out_cap, (size_t)((double)fq_bytes * sam_per_fastq * 1.04) + (1u << 20))) j->rc = URMAPX_E_NOMEM;
+							if (!j->rc)
+								j->rc = paired ? urmapx_text_map_pe(T, j->in, j->nbytes, j->in2, j->nbytes2, minq, j->out, j->out_cap, &j->rep)
+								               : urmapx_text_map_se(T, j->in, j->nbytes, minq, j->out, j->out_cap, &j->rep);
 							if (!j->rc && j->rep.reason == URMAPX_TEXT_SAM_CAP) {
 								if (!TextJob::grow(j->out, j->out_cap, (size_t)j->rep.sam_bytes + j->rep.sam_bytes / 16 + (1u << 20))) j->rc = URMAPX_E_NOMEM;
 								else j->rc = urmapx_text_fetch_sam(T, j->out, j->out_cap, &j->rep);
 							}
-							if (!j->rc && !j->rep.reason && j->nbytes) sam_per_fastq = (double)j->rep.sam_bytes / (double)j->nbytes;
+							if (!j->rc && !j->rep.reason && fq_bytes) sam_per_fastq = (double)j->rep.sam_bytes / (double)fq_bytes;
 							trace.add("gpu", l, (size_t)l + nj * (size_t)n_lanes, ta);
 							std::lock_guard<std::mutex> g(gpu_time_lock);
 							t_gpu += secs(tg0, now());
@@ -559,9 +642,11 @@ extern "C" int urmapx_map_files(urmapx_index *I, const urmapx_map_options *opt, 
 				trace.add("unpin", -1, 0, tf);
 			}
 			close(fq);
-			if (!handed_back) resume_off = reader_end;
-			host_phase = !fail.set.load() && resume_off < fsize;
-			if (host_phase && !rd.resume_at(resume_off, lines_done)) fail.raise(URMAPX_E_IO, std::string("Cannot continue reading ") + fastq1);
+			if (fq2 >= 0) close(fq2);
+			if (!handed_back) { resume_off = reader_end; resume_off2 = reader_end2; }
+			host_phase = !fail.set.load() && (resume_off < fsize || (paired && resume_off2 < fsize2));
+			if (host_phase && (!rd.resume_at(resume_off, lines_done) || (paired && !rd2.resume_at(resume_off2, lines_done))))
+				fail.raise(URMAPX_E_IO, std::string("Cannot continue reading ") + fastq1);
 			if (fail.set.load()) host_phase = false;
 		}
 	}

@@ -10,6 +10,10 @@
 //             --copy_bases_kernel--> bases   --urmapx_map_se_device--> results, paths
 //             --sam_kernel<0>--> record lengths --scan--> record offsets --sam_kernel<1>--> SAM text
 //
+// Paired-end (urmapx_text_map_pe): one chunk of each mate file with the same number of records; both are parsed as above,
+// the mates' bases are interleaved (reads 2i, 2i+1 = pair i, map2.cpp:27-32), State2::Search runs
+// (urmapx_map_pe_device) and each record gets SetSAM2's flags, RNEXT, PNEXT and TLEN (output2.cpp:18-128).
+//
 // The device parser accepts exactly the files the reference accepts WITHOUT special handling: '\n' line ends, four
 // lines per record, '@' first, letters only, as many quality bytes as bases.  Anything else ('\r', blank lines, a
 // malformed record, a last line without '\n') makes the call hand the chunk back untouched (report.reason) and the
@@ -28,12 +32,12 @@ namespace {
 constexpr int NL_TILE = 16384, NL_THREADS = 256;  // 64 bytes per thread
 constexpr int SC_THREADS = 256, SC_ITEMS = 8, SC_TILE = SC_THREADS * SC_ITEMS;
 constexpr int SAM_WAVES = 4;        // wavefronts per block of the record kernels
-constexpr int HEAD_CAP = 1408;      // bytes of one record between QNAME and SEQ held in LDS (12 * 97 CIGAR + fields)
+constexpr int HEAD_CAP = 1600;      // bytes of one record between QNAME and SEQ held in LDS (12 * 97 CIGAR + fields)
 constexpr int TNAME_MAX = 160;      // longest target label the device formatter takes
 
-struct TextHdr {  // one per call, device
+struct TextHdr {  // device; [0] and [1]: the chunk of each file (n_lines, n_records, flags, max_len); [0] also the call's totals
 	uint32_t n_lines, n_records, flags, max_len;
-	uint32_t total_bases, sam_total, pad0, pad1;
+	uint32_t total_bases, sam_total, n_reads, pad1;  // n_reads: records of the batch (single-end: n_records; pairs: twice that)
 	unsigned long long cnt[4];  // accept, reject, nohit, unsupported
 };
 
@@ -223,14 +227,15 @@ __global__ __launch_bounds__(SC_THREADS) void scan_apply_kernel(const uint32_t *
 }
 
 // bases of every read, back to back (what the mapping kernels take); letters only (fastqseqsource.cpp:76-84)
-__global__ __launch_bounds__(256) void copy_bases_kernel(const uint8_t *raw, const uint32_t *ends, TextHdr *hdr, const uint64_t *offs, uint8_t *bases) {
-	const uint32_t n = hdr->n_records;
+__global__ __launch_bounds__(256) void copy_bases_kernel(const uint8_t *raw, const uint32_t *ends, TextHdr *hdr, TextHdr *hdr0, const uint64_t *offs,
+                                                         uint8_t *bases, uint32_t stride, uint32_t phase) {
+	const uint32_t n = hdr0->n_reads / stride;  // pairs: the shorter of the two chunks (unequal chunks are handed back)
 	const int lane = threadIdx.x & 63;
 	const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
 	bool bad = false;
 	for (uint32_t i = wave; i < n; i += n_waves) {
 		const uint32_t s2 = ends[4 * i] + 1u, L = ends[4 * i + 1] - s2;
-		uint8_t *dst = bases + offs[i];
+		uint8_t *dst = bases + offs[(size_t)i * stride + phase];
 		for (uint32_t k = lane; k < L; k += 64) {
 			const uint8_t c = raw[s2 + k];
 			if ((uint8_t)((c | 0x20u) - 'a') >= 26u) bad = true;
@@ -238,13 +243,30 @@ __global__ __launch_bounds__(256) void copy_bases_kernel(const uint8_t *raw, con
 		}
 	}
 	if (bad) atomicOr(&hdr->flags, 4u);
-	if (blockIdx.x == 0 && threadIdx.x == 0) hdr->total_bases = (uint32_t)offs[n];
+	if (blockIdx.x == 0 && threadIdx.x == 0 && phase == 0) hdr0->total_bases = (uint32_t)offs[hdr0->n_reads];
+}
+
+// pairs: lens[2i] = length of mate 1 of pair i, lens[2i+1] = of mate 2; the two chunks must hold the same number of records
+__global__ __launch_bounds__(256) void interleave_lens_kernel(TextHdr *hdr, const uint32_t *blen0, const uint32_t *blen1, uint32_t *lens) {
+	const uint32_t n0 = hdr[0].n_records, n1 = hdr[1].n_records, n = n0 < n1 ? n0 : n1;
+	if (blockIdx.x == 0 && threadIdx.x == 0) {
+		hdr[0].n_reads = 2u * n;
+		if (n0 != n1 || hdr[0].n_lines != hdr[1].n_lines) atomicOr(&hdr[0].flags, 16u);
+		const uint32_t m0 = hdr[0].max_len, m1 = hdr[1].max_len;
+		hdr[0].max_len = m0 > m1 ? m0 : m1;
+		atomicOr(&hdr[0].flags, hdr[1].flags);
+	}
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+		lens[2 * i] = blen0[i];
+		lens[2 * i + 1] = blen1[i];
+	}
 }
 
 // ---- SAM ----
 struct SamArgs {
-	const uint8_t *raw;
-	const uint32_t *ends;
+	const uint8_t *raw[2];       // the chunk of each file (single-end: [0] only)
+	const uint32_t *ends[2];
+	uint32_t paired;             // records 2i, 2i+1 = the mates of pair i, from raw[0] and raw[1]
 	const urmapx_result *results;
 	const urmapx_path_op *ops;
 	const char *tnames;          // target labels back to back
@@ -266,16 +288,79 @@ __device__ __forceinline__ char *dev_put_uint(char *p, uint32_t v) {
 	return p;
 }
 
-// Lane 0 writes the fields between QNAME and SEQ of a mapped or unmapped single-end record (SetSAM with flags 0, mate
-// "*": output1.cpp:13) to `head`; returns the length, or 0 if it does not fit the device formatter.
-__device__ uint32_t build_head(const SamArgs &A, const urmapx_result &r, uint32_t QL, char *head, char *cop, uint32_t *clen) {
+__device__ __forceinline__ char *dev_put_int(char *p, int v) {
+	if (v < 0) { *p++ = '-'; return dev_put_uint(p, (uint32_t)(-(long long)v)); }
+	return dev_put_uint(p, (uint32_t)v);
+}
+
+// SetSAM's arguments (setsam.cpp:73-74): single-end passes 0, "*", UINT32_MAX, 0 (output1.cpp:13); pairs what SetSAM2
+// works out (output2.cpp:61-128)
+struct MateFields {
+	uint32_t flags;
+	bool mate_mapped;
+	uint32_t mate_seq_index, mate_coord;
+	int tlen;
+};
+
+__device__ __forceinline__ uint32_t paired_flags(bool first, bool revcomp, bool mate_revcomp, bool mate_unmapped) {  // output2.cpp:18-36
+	uint32_t f = first ? 0x41u : 0x81u;
+	if (revcomp) f |= 0x10u;
+	if (mate_unmapped) f |= 0x08u;
+	else if (mate_revcomp) f |= 0x20u;
+	return f;
+}
+
+// SetSAM2 (output2.cpp:61-128) for mate `second` of a pair with results r1, r2 and read lengths len1, len2
+__device__ MateFields pair_fields(const urmapx_result &r1, const urmapx_result &r2, uint32_t len1, uint32_t len2, bool second) {
+	const bool m1 = r1.dbpos != 0xFFFFFFFFu, m2 = r2.dbpos != 0xFFFFFFFFu;
+	const bool plus1 = m1 && r1.plus, plus2 = m2 && r2.plus;
+	const bool consistent = m1 && m2 && (plus1 != plus2);
+	int tlen1 = 0, tlen2 = 0;
+	bool proper = false;
+	if (m1 && m2) {
+		if (r1.coord <= r2.coord) {
+			tlen1 = (int)(r2.coord + len2) - (int)r1.coord;
+			if (tlen1 > 0 && tlen1 < 1000 && consistent) proper = true;
+			if (tlen1 > 1000) tlen1 = 0;
+			tlen2 = -tlen1;
+		} else {
+			tlen2 = (int)(r1.coord + len1) - (int)r2.coord;
+			if (tlen2 > 0 && tlen2 < 1000 && consistent) proper = true;
+			if (tlen2 > 1000) tlen2 = 0;
+			tlen1 = -tlen2;
+		}
+	}
+	const bool rc1 = m1 && !r1.plus, rc2 = m2 && !r2.plus;
+	MateFields F;
+	F.flags = second ? paired_flags(false, rc2, rc1, !m1) : paired_flags(true, rc1, rc2, !m2);
+	if (proper) F.flags |= 2u;
+	F.mate_mapped = second ? m1 : m2;
+	F.mate_seq_index = second ? r1.seq_index : r2.seq_index;
+	F.mate_coord = second ? r1.coord : r2.coord;
+	F.tlen = second ? tlen2 : tlen1;
+	return F;
+}
+
+// Lane 0 writes the fields between QNAME and SEQ of a mapped or unmapped record (SetSAM / SetSAM_Unmapped,
+// setsam.cpp:12-207) to `head`; returns the length, or 0 if it does not fit the device formatter.
+__device__ uint32_t build_head(const SamArgs &A, const urmapx_result &r, const MateFields &F, uint32_t QL, char *head, char *cop, uint32_t *clen) {
 	char *p = head;
 	if (r.dbpos == 0xFFFFFFFFu) {
-		const char s[] = "\t4\t*\t0\t0\t*\t*\t0\t0\t";
+		uint32_t flags = 0x04u;  // SetSAM_Unmapped keeps these bits of the flags it is given (setsam.cpp:14-27)
+		if (F.flags & 0x01u) flags |= 0x01u;
+		if (F.flags & 0x40u) flags |= 0x40u;
+		else if (F.flags & 0x80u) flags |= 0x80u;
+		if (F.flags & 0x08u) flags |= 0x08u;
+		else if (F.flags & 0x20u) flags |= 0x20u;
+		*p++ = '\t';
+		p = dev_put_uint(p, flags);
+		const char s[] = "\t*\t0\t0\t*\t*\t0\t0\t";
 		for (int i = 0; i < (int)sizeof(s) - 1; ++i) *p++ = s[i];
 		return (uint32_t)(p - head);
 	}
-	*p++ = '\t'; *p++ = '0'; *p++ = '\t';
+	*p++ = '\t';
+	p = dev_put_uint(p, F.flags);
+	*p++ = '\t';
 	if (r.seq_index >= A.seq_count) return 0;
 	const uint32_t t0 = A.tname_offs[r.seq_index], tl = A.tname_offs[r.seq_index + 1] - t0;
 	if (tl > (uint32_t)TNAME_MAX) return 0;
@@ -304,8 +389,26 @@ __device__ uint32_t build_head(const SamArgs &A, const urmapx_result &r, uint32_
 		}
 		for (uint32_t i = first; i < N; ++i) { p = dev_put_uint(p, clen[i]); *p++ = cop[i]; }
 	}
-	const char s[] = "\t*\t0\t0\t";
-	for (int i = 0; i < (int)sizeof(s) - 1; ++i) *p++ = s[i];
+	*p++ = '\t';
+	// RNEXT: '*' without a mapped mate, '=' if the mate's target has the same label, else that label (setsam.cpp:150-166)
+	if (!F.mate_mapped) *p++ = '*';
+	else {
+		if (F.mate_seq_index >= A.seq_count) return 0;
+		const uint32_t m0 = A.tname_offs[F.mate_seq_index], ml = A.tname_offs[F.mate_seq_index + 1] - m0;
+		if (ml > (uint32_t)TNAME_MAX) return 0;
+		bool same = ml == tl;
+		for (uint32_t i = 0; same && i < tl; ++i) same = A.tnames[t0 + i] == A.tnames[m0 + i];
+		if (ml == 0 || (ml == 1 && A.tnames[m0] == '*')) *p++ = '*';
+		else if (same) *p++ = '=';
+		else
+			for (uint32_t i = 0; i < ml; ++i) *p++ = A.tnames[m0 + i];
+	}
+	*p++ = '\t';
+	if (!F.mate_mapped || F.mate_coord == 0 || F.mate_coord == 0xFFFFFFFFu) *p++ = '0';  // position 0 prints as 0 (setsam.cpp:168-172)
+	else p = dev_put_uint(p, F.mate_coord + 1u);
+	*p++ = '\t';
+	p = dev_put_int(p, F.tlen);
+	*p++ = '\t';
 	return (uint32_t)(p - head);
 }
 
@@ -317,14 +420,17 @@ __global__ __launch_bounds__(SAM_WAVES * 64) void sam_kernel(SamArgs A) {
 	__shared__ uint32_t s_clen[SAM_WAVES][URMAPX_MAX_PATH_OPS + 1];
 	__shared__ uint32_t s_hl[SAM_WAVES];
 	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-	const uint32_t n = A.hdr->n_records;
+	const uint32_t n = A.hdr->n_reads;
 	const uint32_t wave = blockIdx.x * SAM_WAVES + w, n_waves = gridDim.x * SAM_WAVES;
 	uint32_t c_acc = 0, c_rej = 0, c_no = 0, c_uns = 0;
 	for (uint32_t i = wave; i < n; i += n_waves) {
 		const urmapx_result r = A.results[i];
-		const uint32_t s1 = line_start(A.ends, 4 * i), e1 = A.ends[4 * i], e2 = A.ends[4 * i + 1], e3 = A.ends[4 * i + 2];
+		const uint32_t side = A.paired ? (i & 1u) : 0u, rec = A.paired ? (i >> 1) : i;
+		const uint8_t *raw = A.raw[side];
+		const uint32_t *ends = A.ends[side];
+		const uint32_t s1 = line_start(ends, 4 * rec), e1 = ends[4 * rec], e2 = ends[4 * rec + 1], e3 = ends[4 * rec + 2];
 		const uint32_t QL = e2 - (e1 + 1u);
-		const uint8_t *label = A.raw + s1 + 1u;
+		const uint8_t *label = raw + s1 + 1u;
 		uint32_t ln = e1 - s1 - 1u;
 		// QNAME: "/1" "/2" dropped, then cut at the first blank (setsam.cpp:36-46)
 		if (ln > 2 && label[ln - 2] == '/' && (label[ln - 1] == '1' || label[ln - 1] == '2')) ln -= 2;
@@ -334,7 +440,15 @@ __global__ __launch_bounds__(SAM_WAVES * 64) void sam_kernel(SamArgs A) {
 			const unsigned long long m = __ballot(c == ' ' || c == '\t');
 			if (m) { qn = b + (uint32_t)__ffsll((long long)m) - 1u; break; }
 		}
-		if (lane == 0) s_hl[w] = build_head(A, r, QL, s_head[w], s_cop[w], s_clen[w]);
+		MateFields F;
+		F.flags = 0; F.mate_mapped = false; F.mate_seq_index = 0; F.mate_coord = 0xFFFFFFFFu; F.tlen = 0;
+		if (A.paired) {
+			const urmapx_result rm = A.results[i ^ 1u];
+			const uint32_t *oe = A.ends[side ^ 1u];
+			const uint32_t QLm = oe[4 * rec + 1] - (oe[4 * rec] + 1u);
+			F = side ? pair_fields(rm, r, QLm, QL, true) : pair_fields(r, rm, QL, QLm, false);
+		}
+		if (lane == 0) s_hl[w] = build_head(A, r, F, QL, s_head[w], s_cop[w], s_clen[w]);
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 		__builtin_amdgcn_wave_barrier();
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -354,7 +468,7 @@ __global__ __launch_bounds__(SAM_WAVES * 64) void sam_kernel(SamArgs A) {
 			out += qn;
 			for (uint32_t k = lane; k < hl; k += 64) out[k] = s_head[w][k];
 			out += hl;
-			const uint8_t *seq = A.raw + e1 + 1u, *qual = A.raw + e3 + 1u;
+			const uint8_t *seq = raw + e1 + 1u, *qual = raw + e3 + 1u;
 			const bool plus = r.dbpos == 0xFFFFFFFFu || r.plus;
 			if (plus) {
 				for (uint32_t k = lane; k < QL; k += 64) { out[k] = (char)seq[k]; out[QL + 1u + k] = (char)qual[k]; }
@@ -377,22 +491,52 @@ __global__ __launch_bounds__(SAM_WAVES * 64) void sam_kernel(SamArgs A) {
 
 struct urmapx_text {
 	urmapx_ctx *C = nullptr;
-	DevBuf<uint8_t> raw, bases, sam, comp;
-	DevBuf<uint32_t> tile_counts, ends, blen, sums, lens, rec_offs, used, tname_offs;
+	DevBuf<uint8_t> raw[2], bases, sam, comp;
+	DevBuf<uint32_t> tile_counts[2], ends[2], blen[2], sums, lens, rec_offs, used, tname_offs;
 	DevBuf<uint64_t> offs;
 	DevBuf<char> tnames;
 	DevBuf<urmapx_result> results;
 	DevBuf<urmapx_path_op> pathops;
-	DevBuf<TextHdr> hdr;
+	DevBuf<TextHdr> hdr;  // [2]
 	uint32_t seq_count = 0;
-	TextHdr *h_hdr = nullptr;  // page-locked
+	TextHdr *h_hdr = nullptr;  // page-locked, [2]
 	// a chunk mapped and measured whose text has not been fetched (urmapx_text_fetch_sam)
 	bool pending = false;
 	SamArgs pending_args;
 	urmapx_text_report pending_rep;
 };
 
-static int fetch_sam(urmapx_text *T, char *sam, size_t sam_cap, urmapx_text_report *rep) {
+namespace {
+
+constexpr int GRID = 2048;
+
+// H2D of one file's chunk, its line ends, its records' lengths and checks
+int parse_side(urmapx_text *T, int side, const char *fastq, size_t nbytes, uint32_t *ends_cap_out) {
+	hipStream_t st = ctx_stream(T->C);
+	const uint32_t n_tiles = (uint32_t)((nbytes + NL_TILE - 1) / NL_TILE);
+	const size_t padded = (size_t)n_tiles * NL_TILE;
+	// a record's four lines take at least five bytes ("@\n\n\n\n"); more line ends than that is not FASTQ
+	const uint32_t ends_cap = (uint32_t)(nbytes / 5 * 4 + 16);
+	const uint32_t rec_cap = ends_cap / 4 + 1;
+	int rc;
+	if ((rc = T->raw[side].ensure(padded + 16))) return rc;
+	if ((rc = T->tile_counts[side].ensure(n_tiles))) return rc;
+	if ((rc = T->ends[side].ensure(ends_cap))) return rc;
+	if ((rc = T->blen[side].ensure(rec_cap))) return rc;
+	TextHdr *hdr = T->hdr.p + side;
+	const uint8_t *raw = T->raw[side].p;
+	HIP_TRY(hipMemcpyAsync(T->raw[side].p, fastq, nbytes, hipMemcpyHostToDevice, st));
+	if (padded + 16 > nbytes) HIP_TRY(hipMemsetAsync(T->raw[side].p + nbytes, 0, padded + 16 - nbytes, st));
+	hipLaunchKernelGGL(nl_count_kernel, dim3(GRID), dim3(NL_THREADS), 0, st, (const uint4 *)raw, n_tiles, T->tile_counts[side].p, hdr);
+	hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(1024), 0, st, T->tile_counts[side].p, (const uint32_t *)nullptr, 1u, n_tiles, &hdr->n_lines);
+	hipLaunchKernelGGL(nl_emit_kernel, dim3(GRID), dim3(NL_THREADS), 0, st, (const uint4 *)raw, n_tiles, T->tile_counts[side].p, T->ends[side].p, ends_cap, hdr);
+	hipLaunchKernelGGL(record_kernel, dim3(GRID), dim3(256), 0, st, raw, T->ends[side].p, hdr, T->blen[side].p);
+	HIP_TRY(hipGetLastError());
+	*ends_cap_out = ends_cap;
+	return URMAPX_OK;
+}
+
+int fetch_sam(urmapx_text *T, char *sam, size_t sam_cap, urmapx_text_report *rep) {
 	*rep = T->pending_rep;
 	if (!sam || rep->sam_bytes > sam_cap) { rep->reason = URMAPX_TEXT_SAM_CAP; rep->records = 0; return URMAPX_OK; }
 	hipStream_t st = ctx_stream(T->C);
@@ -400,13 +544,95 @@ static int fetch_sam(urmapx_text *T, char *sam, size_t sam_cap, urmapx_text_repo
 	if ((rc = T->sam.ensure((size_t)rep->sam_bytes + 64))) return rc;
 	SamArgs A = T->pending_args;
 	A.sam = (char *)T->sam.p;
-	hipLaunchKernelGGL(sam_kernel<1>, dim3(2048), dim3(SAM_WAVES * 64), 0, st, A);
+	hipLaunchKernelGGL(sam_kernel<1>, dim3(GRID), dim3(SAM_WAVES * 64), 0, st, A);
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipMemcpyAsync(sam, T->sam.p, rep->sam_bytes, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipStreamSynchronize(st));
 	T->pending = false;
 	return URMAPX_OK;
 }
+
+// fastq2 == nullptr: single-end
+int map_text(urmapx_text *T, const char *fastq1, size_t nbytes1, const char *fastq2, size_t nbytes2, unsigned minq, char *sam, size_t sam_cap,
+             urmapx_text_report *rep) {
+	const bool paired = fastq2 != nullptr;
+	memset(rep, 0, sizeof *rep);
+	T->pending = false;
+	if (nbytes1 == 0 && (!paired || nbytes2 == 0)) return URMAPX_OK;
+	if (nbytes1 > (1u << 30) || nbytes2 > (1u << 30)) { rep->reason = URMAPX_TEXT_TOO_LARGE; return URMAPX_OK; }
+	if (nbytes1 == 0 || fastq1[nbytes1 - 1] != '\n' || (paired && (nbytes2 == 0 || fastq2[nbytes2 - 1] != '\n'))) { rep->reason = URMAPX_TEXT_RAGGED; return URMAPX_OK; }
+	urmapx_ctx *C = T->C;
+	HIP_TRY(hipSetDevice(ctx_device(C)));
+	hipStream_t st = ctx_stream(C);
+	TextHdr *hdr = T->hdr.p;
+	HIP_TRY(hipMemsetAsync(hdr, 0, 2 * sizeof(TextHdr), st));
+	uint32_t ends_cap[2] = {0, 0};
+	int rc;
+	if ((rc = parse_side(T, 0, fastq1, nbytes1, &ends_cap[0]))) return rc;
+	if (paired && (rc = parse_side(T, 1, fastq2, nbytes2, &ends_cap[1]))) return rc;
+	const size_t rec_cap = (size_t)ends_cap[0] / 4 + (size_t)ends_cap[1] / 4 + 2;
+	if ((rc = T->lens.ensure(rec_cap))) return rc;
+	if ((rc = T->rec_offs.ensure(rec_cap + 1))) return rc;
+	if ((rc = T->offs.ensure(rec_cap + 1))) return rc;
+	if ((rc = T->sums.ensure(rec_cap / SC_TILE + 2))) return rc;
+	if ((rc = T->bases.ensure(nbytes1 + nbytes2 + 64))) return rc;
+	const uint32_t *read_lens = T->blen[0].p;
+	if (paired) {
+		hipLaunchKernelGGL(interleave_lens_kernel, dim3(GRID), dim3(256), 0, st, hdr, T->blen[0].p, T->blen[1].p, T->lens.p);
+		read_lens = T->lens.p;
+	} else
+		HIP_TRY(hipMemcpyAsync(&hdr->n_reads, &hdr->n_records, 4, hipMemcpyDeviceToDevice, st));
+	hipLaunchKernelGGL(scan_sums_kernel, dim3(GRID), dim3(SC_THREADS), 0, st, read_lens, &hdr->n_reads, T->sums.p);
+	hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(1024), 0, st, T->sums.p, &hdr->n_reads, (uint32_t)SC_TILE, 0u, (uint32_t *)nullptr);
+	hipLaunchKernelGGL(scan_apply_kernel<uint64_t>, dim3(GRID), dim3(SC_THREADS), 0, st, read_lens, &hdr->n_reads, T->sums.p, T->offs.p);
+	for (int side = 0; side < (paired ? 2 : 1); ++side)
+		hipLaunchKernelGGL(copy_bases_kernel, dim3(GRID), dim3(256), 0, st, T->raw[side].p, T->ends[side].p, hdr + side, hdr, T->offs.p, T->bases.p,
+		                   paired ? 2u : 1u, (uint32_t)side);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipMemcpyAsync(T->h_hdr, hdr, 2 * sizeof(TextHdr), hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipStreamSynchronize(st));
+	const TextHdr h1 = T->h_hdr[0], h1b = T->h_hdr[1];
+	const uint32_t fl = h1.flags | (paired ? h1b.flags : 0u);
+	if (fl & 1u) { rep->reason = URMAPX_TEXT_CR; return URMAPX_OK; }
+	if (h1.n_lines > ends_cap[0] || (h1.n_lines & 3u) || (paired && (h1b.n_lines > ends_cap[1] || (h1b.n_lines & 3u)))) { rep->reason = URMAPX_TEXT_RAGGED; return URMAPX_OK; }
+	if (fl & 16u) { rep->reason = URMAPX_TEXT_UNEQUAL; return URMAPX_OK; }
+	if (fl & 6u) { rep->reason = URMAPX_TEXT_BAD_RECORD; return URMAPX_OK; }
+	const uint32_t n = h1.n_reads;
+	if (n == 0) return URMAPX_OK;
+	if ((rc = T->results.ensure(n))) return rc;
+	if ((rc = T->pathops.ensure((size_t)n * URMAPX_MAX_PATH_OPS))) return rc;
+	if (paired) {
+		const uint32_t mx = h1.max_len > MAX_QL_PE ? MAX_QL_PE : h1.max_len;
+		rc = urmapx_map_pe_device(C, T->bases.p, T->offs.p, n / 2, h1.total_bases, mx, T->results.p, T->pathops.p, T->used.p);
+	} else {
+		const uint32_t mx = h1.max_len > URMAPX_MAX_QL ? URMAPX_MAX_QL : h1.max_len;
+		rc = urmapx_map_se_device(C, T->bases.p, T->offs.p, n, h1.total_bases, mx, T->results.p, T->pathops.p, T->used.p);
+	}
+	if (rc) return rc;
+	SamArgs A;
+	A.raw[0] = T->raw[0].p; A.raw[1] = T->raw[1].p; A.ends[0] = T->ends[0].p; A.ends[1] = T->ends[1].p; A.paired = paired ? 1u : 0u;
+	A.results = T->results.p; A.ops = T->pathops.p; A.tnames = T->tnames.p;
+	A.tname_offs = T->tname_offs.p; A.comp = T->comp.p; A.seq_count = T->seq_count; A.minq = minq; A.hdr = hdr;
+	A.lens = T->lens.p; A.rec_offs = T->rec_offs.p; A.sam = nullptr;
+	hipLaunchKernelGGL(sam_kernel<0>, dim3(GRID), dim3(SAM_WAVES * 64), 0, st, A);
+	hipLaunchKernelGGL(scan_sums_kernel, dim3(GRID), dim3(SC_THREADS), 0, st, T->lens.p, &hdr->n_reads, T->sums.p);
+	hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(1024), 0, st, T->sums.p, &hdr->n_reads, (uint32_t)SC_TILE, 0u, &hdr->sam_total);
+	hipLaunchKernelGGL(scan_apply_kernel<uint32_t>, dim3(GRID), dim3(SC_THREADS), 0, st, T->lens.p, &hdr->n_reads, T->sums.p, T->rec_offs.p);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipMemcpyAsync(T->h_hdr, hdr, sizeof(TextHdr), hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipStreamSynchronize(st));
+	const TextHdr h2 = T->h_hdr[0];
+	if (h2.flags & 8u) { rep->reason = URMAPX_TEXT_LONG_NAME; return URMAPX_OK; }
+	T->pending = true;
+	T->pending_args = A;
+	memset(&T->pending_rep, 0, sizeof T->pending_rep);
+	T->pending_rep.records = n;
+	T->pending_rep.sam_bytes = h2.sam_total;
+	T->pending_rep.mapped_q = h2.cnt[0]; T->pending_rep.mapped_lowq = h2.cnt[1]; T->pending_rep.unmapped = h2.cnt[2]; T->pending_rep.unsupported = h2.cnt[3];
+	return fetch_sam(T, sam, sam_cap, rep);
+}
+
+}  // namespace
 
 extern "C" {
 
@@ -424,13 +650,13 @@ int urmapx_text_create(urmapx_ctx *C, urmapx_text **out) {
 	int rc = T->tnames.ensure(names.size() + 1);
 	if (!rc) rc = T->tname_offs.ensure(n + 1);
 	if (!rc) rc = T->comp.ensure(256);
-	if (!rc) rc = T->hdr.ensure(1);
+	if (!rc) rc = T->hdr.ensure(2);
 	if (!rc) rc = T->used.ensure(1);
 	hipError_t e = hipSuccess;
 	if (!rc && !names.empty()) e = hipMemcpy(T->tnames.p, names.data(), names.size(), hipMemcpyHostToDevice);
 	if (!rc && e == hipSuccess) e = hipMemcpy(T->tname_offs.p, offs.data(), (n + 1) * 4, hipMemcpyHostToDevice);
 	if (!rc && e == hipSuccess) e = hipMemcpy(T->comp.p, complement_table(), 256, hipMemcpyHostToDevice);
-	if (!rc && e == hipSuccess) e = hipHostMalloc((void **)&T->h_hdr, sizeof(TextHdr), hipHostMallocDefault);
+	if (!rc && e == hipSuccess) e = hipHostMalloc((void **)&T->h_hdr, 2 * sizeof(TextHdr), hipHostMallocDefault);
 	if (!rc && e != hipSuccess) rc = hip_rc(e);
 	if (rc) { urmapx_text_destroy(T); return rc; }
 	T->seq_count = n;
@@ -442,8 +668,9 @@ void urmapx_text_destroy(urmapx_text *T) {
 	if (!T) return;
 	(void)hipSetDevice(ctx_device(T->C));
 	(void)hipStreamSynchronize(ctx_stream(T->C));
-	T->raw.release(); T->bases.release(); T->sam.release(); T->comp.release();
-	T->tile_counts.release(); T->ends.release(); T->blen.release(); T->sums.release(); T->lens.release(); T->rec_offs.release();
+	for (int k = 0; k < 2; ++k) { T->raw[k].release(); T->tile_counts[k].release(); T->ends[k].release(); T->blen[k].release(); }
+	T->bases.release(); T->sam.release(); T->comp.release();
+	T->sums.release(); T->lens.release(); T->rec_offs.release();
 	T->used.release(); T->tname_offs.release(); T->offs.release(); T->tnames.release(); T->results.release(); T->pathops.release();
 	T->hdr.release();
 	if (T->h_hdr) (void)hipHostFree(T->h_hdr);
@@ -452,77 +679,13 @@ void urmapx_text_destroy(urmapx_text *T) {
 
 int urmapx_text_map_se(urmapx_text *T, const char *fastq, size_t nbytes, unsigned minq, char *sam, size_t sam_cap, urmapx_text_report *rep) {
 	if (!T || !rep || (nbytes && !fastq)) return URMAPX_E_ARG;
-	memset(rep, 0, sizeof *rep);
-	T->pending = false;
-	if (nbytes == 0) return URMAPX_OK;
-	if (nbytes > (1u << 30)) { rep->reason = URMAPX_TEXT_TOO_LARGE; return URMAPX_OK; }
-	if (fastq[nbytes - 1] != '\n') { rep->reason = URMAPX_TEXT_RAGGED; return URMAPX_OK; }
-	urmapx_ctx *C = T->C;
-	HIP_TRY(hipSetDevice(ctx_device(C)));
-	hipStream_t st = ctx_stream(C);
-	const uint32_t n_tiles = (uint32_t)((nbytes + NL_TILE - 1) / NL_TILE);
-	const size_t padded = (size_t)n_tiles * NL_TILE;
-	// a record's four lines take at least five bytes ("@\n\n\n\n"); more line ends than that is not FASTQ
-	const uint32_t ends_cap = (uint32_t)(nbytes / 5 * 4 + 16);
-	const uint32_t rec_cap = ends_cap / 4 + 1;
-	int rc;
-	if ((rc = T->raw.ensure(padded + 16))) return rc;
-	if ((rc = T->tile_counts.ensure(n_tiles))) return rc;
-	if ((rc = T->ends.ensure(ends_cap))) return rc;
-	if ((rc = T->blen.ensure(rec_cap))) return rc;
-	if ((rc = T->lens.ensure(rec_cap))) return rc;
-	if ((rc = T->rec_offs.ensure((size_t)rec_cap + 1))) return rc;
-	if ((rc = T->offs.ensure((size_t)rec_cap + 1))) return rc;
-	if ((rc = T->sums.ensure(rec_cap / SC_TILE + 2))) return rc;
-	if ((rc = T->bases.ensure(nbytes + 64))) return rc;
-	TextHdr *hdr = T->hdr.p;
-	const uint8_t *raw = T->raw.p;
-	HIP_TRY(hipMemsetAsync(hdr, 0, sizeof(TextHdr), st));
-	HIP_TRY(hipMemcpyAsync(T->raw.p, fastq, nbytes, hipMemcpyHostToDevice, st));
-	if (padded + 16 > nbytes) HIP_TRY(hipMemsetAsync(T->raw.p + nbytes, 0, padded + 16 - nbytes, st));
-	const int grid = 2048;
-	hipLaunchKernelGGL(nl_count_kernel, dim3(grid), dim3(NL_THREADS), 0, st, (const uint4 *)raw, n_tiles, T->tile_counts.p, hdr);
-	hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(1024), 0, st, T->tile_counts.p, (const uint32_t *)nullptr, 1u, n_tiles, &hdr->n_lines);
-	hipLaunchKernelGGL(nl_emit_kernel, dim3(grid), dim3(NL_THREADS), 0, st, (const uint4 *)raw, n_tiles, T->tile_counts.p, T->ends.p, ends_cap, hdr);
-	hipLaunchKernelGGL(record_kernel, dim3(grid), dim3(256), 0, st, raw, T->ends.p, hdr, T->blen.p);
-	hipLaunchKernelGGL(scan_sums_kernel, dim3(grid), dim3(SC_THREADS), 0, st, T->blen.p, &hdr->n_records, T->sums.p);
-	hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(1024), 0, st, T->sums.p, &hdr->n_records, (uint32_t)SC_TILE, 0u, (uint32_t *)nullptr);
-	hipLaunchKernelGGL(scan_apply_kernel<uint64_t>, dim3(grid), dim3(SC_THREADS), 0, st, T->blen.p, &hdr->n_records, T->sums.p, T->offs.p);
-	hipLaunchKernelGGL(copy_bases_kernel, dim3(grid), dim3(256), 0, st, raw, T->ends.p, hdr, T->offs.p, T->bases.p);
-	HIP_TRY(hipGetLastError());
-	HIP_TRY(hipMemcpyAsync(T->h_hdr, hdr, sizeof(TextHdr), hipMemcpyDeviceToHost, st));
-	HIP_TRY(hipStreamSynchronize(st));
-	const TextHdr h1 = *T->h_hdr;
-	if (h1.flags & 1u) { rep->reason = URMAPX_TEXT_CR; return URMAPX_OK; }
-	if (h1.n_lines > ends_cap || (h1.n_lines & 3u)) { rep->reason = URMAPX_TEXT_RAGGED; return URMAPX_OK; }
-	if (h1.flags & 6u) { rep->reason = URMAPX_TEXT_BAD_RECORD; return URMAPX_OK; }
-	const uint32_t n = h1.n_records;
-	if (n == 0) return URMAPX_OK;
-	if ((rc = T->results.ensure(n))) return rc;
-	if ((rc = T->pathops.ensure((size_t)n * URMAPX_MAX_PATH_OPS))) return rc;
-	uint32_t mx = h1.max_len > URMAPX_MAX_QL ? URMAPX_MAX_QL : h1.max_len;
-	rc = urmapx_map_se_device(C, T->bases.p, T->offs.p, n, h1.total_bases, mx, T->results.p, T->pathops.p, T->used.p);
-	if (rc) return rc;
-	SamArgs A;
-	A.raw = raw; A.ends = T->ends.p; A.results = T->results.p; A.ops = T->pathops.p; A.tnames = T->tnames.p;
-	A.tname_offs = T->tname_offs.p; A.comp = T->comp.p; A.seq_count = T->seq_count; A.minq = minq; A.hdr = hdr;
-	A.lens = T->lens.p; A.rec_offs = T->rec_offs.p; A.sam = nullptr;
-	hipLaunchKernelGGL(sam_kernel<0>, dim3(grid), dim3(SAM_WAVES * 64), 0, st, A);
-	hipLaunchKernelGGL(scan_sums_kernel, dim3(grid), dim3(SC_THREADS), 0, st, T->lens.p, &hdr->n_records, T->sums.p);
-	hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(1024), 0, st, T->sums.p, &hdr->n_records, (uint32_t)SC_TILE, 0u, &hdr->sam_total);
-	hipLaunchKernelGGL(scan_apply_kernel<uint32_t>, dim3(grid), dim3(SC_THREADS), 0, st, T->lens.p, &hdr->n_records, T->sums.p, T->rec_offs.p);
-	HIP_TRY(hipGetLastError());
-	HIP_TRY(hipMemcpyAsync(T->h_hdr, hdr, sizeof(TextHdr), hipMemcpyDeviceToHost, st));
-	HIP_TRY(hipStreamSynchronize(st));
-	const TextHdr h2 = *T->h_hdr;
-	if (h2.flags & 8u) { rep->reason = URMAPX_TEXT_LONG_NAME; return URMAPX_OK; }
-	T->pending = true;
-	T->pending_args = A;
-	memset(&T->pending_rep, 0, sizeof T->pending_rep);
-	T->pending_rep.records = n;
-	T->pending_rep.sam_bytes = h2.sam_total;
-	T->pending_rep.mapped_q = h2.cnt[0]; T->pending_rep.mapped_lowq = h2.cnt[1]; T->pending_rep.unmapped = h2.cnt[2]; T->pending_rep.unsupported = h2.cnt[3];
-	return fetch_sam(T, sam, sam_cap, rep);
+	return map_text(T, fastq, nbytes, nullptr, 0, minq, sam, sam_cap, rep);
+}
+
+int urmapx_text_map_pe(urmapx_text *T, const char *fastq1, size_t nbytes1, const char *fastq2, size_t nbytes2, unsigned minq, char *sam,
+                       size_t sam_cap, urmapx_text_report *rep) {
+	if (!T || !rep || !fastq1 || !fastq2) return URMAPX_E_ARG;
+	return map_text(T, fastq1, nbytes1, fastq2, nbytes2, minq, sam, sam_cap, rep);
 }
 
 int urmapx_text_fetch_sam(urmapx_text *T, char *sam, size_t sam_cap, urmapx_text_report *rep) {

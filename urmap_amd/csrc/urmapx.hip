@@ -20,7 +20,6 @@ const uint32_t MAGIC3 = ('U' << 24) | ('F' << 16) | ('I' << 8) | '3';
 const uint32_t MAGIC5 = ('U' << 24) | ('F' << 16) | ('I' << 8) | '5';
 const size_t SEQ_TAIL_PAD = 4096;  // zero bytes after the sequence: windows may run past the end
 const size_t BLOB_TAIL_PAD = 8;    // the last slot is fetched with an 8-byte load
-const uint32_t MAX_QL_PE = 320;    // kernel classes of the pair kernel (pairs themselves: <= 279 bases per mate, flagged per read)
 
 bool rd(FILE *f, void *p, size_t n) { return fread(p, 1, n, f) == n; }
 
@@ -89,7 +88,6 @@ namespace urx {
 hipStream_t ctx_stream(urmapx_ctx *C) { return C->stream; }
 int ctx_device(const urmapx_ctx *C) { return C->device; }
 const urmapx_index *ctx_index(const urmapx_ctx *C) { return C->index; }
-const uint32_t *index_dev_seq_lengths(const urmapx_index *I) { return I->d_seqLengths; }
 }  // namespace urx
 
 extern "C" {
