@@ -618,9 +618,43 @@ def run_e2e(torch, api, oi, index, device, d_seq, seq_lengths, seq_offsets, L, s
                "sam_records_identical_to_oracle": bool(same), "sam_records_checked": len(want)}
         if ref:
             out["reference_binary"] = ref
+        if not os.environ.get("URMAP_BENCH_NO_E2E_PAIRS"):
+            out["pairs"] = run_e2e_pairs(torch, api, oi, index, device, d_seq, seq_lengths, seq_offsets, L, n_reads // 2, cores, d)
         return out
     finally:
         shutil.rmtree(d, ignore_errors=True)
+
+
+def run_e2e_pairs(torch, api, oi, index, device, d_seq, seq_lengths, seq_offsets, L, npairs, cores, d):
+    """`urmap -map2`: two mate files -> SAM through urmapx_map_files (cmd_map2) on the resident index, both mate files'
+    chunks parsed and the pair records written on the device.  The head of the SAM is compared with the oracle's."""
+    pairs = make_pairs_torch(torch, 778, d_seq, seq_lengths, seq_offsets, npairs, L, 0.01, 0.02, device).cpu().numpy().reshape(npairs, 2, L)
+    fq1, fq2, sam = os.path.join(d, "m1.fq"), os.path.join(d, "m2.fq"), os.path.join(d, "pairs.sam")
+    b1 = write_fastq_fixed(fq1, np.ascontiguousarray(pairs[:, 0, :]).reshape(-1), npairs, L)
+    b2 = write_fastq_fixed(fq2, np.ascontiguousarray(pairs[:, 1, :]).reshape(-1), npairs, L)
+    n_chk = min(npairs // 4, 100_000)
+    h1, h2, sam_o = os.path.join(d, "h1.fq"), os.path.join(d, "h2.fq"), os.path.join(d, "pairs_oracle.sam")
+    write_fastq_fixed(h1, np.ascontiguousarray(pairs[:n_chk, 0, :]).reshape(-1), n_chk, L)
+    write_fastq_fixed(h2, np.ascontiguousarray(pairs[:n_chk, 1, :]).reshape(-1), n_chk, L)
+    del pairs
+    runs = [api.map_files(index, fq1, fq2, samout=sam, first_gpu=device.index, gpus=1, streams=2, cmdline="bench.py e2e pairs") for _ in range(2)]
+    rep = runs[-1]
+    oi.map_file_pe(h1, h2, sam_o, threads=cores)
+    want = [l for l in open(sam_o, "rb").read().split(b"\n") if l and not l.startswith(b"@")]
+    got = []
+    with open(sam, "rb") as f:
+        for line in f:
+            if line.startswith(b"@"):
+                continue
+            got.append(line.rstrip(b"\n"))
+            if len(got) == len(want):
+                break
+    return {"value": round(rep["reads"] / rep["seconds"], 1), "unit": "reads/s", "reads": int(rep["reads"]), "seconds": round(rep["seconds"], 3),
+            "first_run_seconds": round(runs[0]["seconds"], 3),
+            "what": f"urmapx_map_files (= urmap -map2): 2 x {b1 / 1e9:.2f} GB mate files -> {os.path.getsize(sam) / 1e9:.2f} GB SAM file in /dev/shm, "
+                    f"{(b1 + b2) / 1e9:.2f} GB of FASTQ in all; both text stages on the device",
+            "stage_busy_s": {k: round(rep[k], 3) for k in ("parse_s", "gpu_s", "format_s", "write_s")},
+            "sam_records_identical_to_oracle": bool(got == want), "sam_records_checked": len(want)}
 
 
 def kernel_table(api, pe, L, nb, kms, counters, total_bp, gather_loads_s, stage_ms=None):
