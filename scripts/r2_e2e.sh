@@ -1,8 +1,13 @@
-R=$GRAFT_REPO_ROOT; cd $R; mkdir -p gpurun_out/r2
-timeout 900 python3 -m pytest tests -m gpu -x -q -k "cli or map_files or two_devices" 2>&1 | tail -4
-URMAP_BENCH_E2E_READS=8000000 timeout 900 python3 bench.py --genome-mbp 800 --steps 3 --warmup 1 --no-cpu-baseline --no-other-workloads > gpurun_out/r2/bench_e2e.json 2> gpurun_out/r2/bench_e2e.err; echo rc=$?
+#!/bin/bash
+# default bench without the other workloads: headline + e2e (single-end and pairs), with the pipeline trace
+cd "$GRAFT_REPO_ROOT" || exit 1
+mkdir -p gpurun_out/r2
+URMAPX_PIPE_TRACE=1 timeout 2000 python3 bench.py --no-other-workloads > gpurun_out/r2/bench_e2e_pairs.json 2> gpurun_out/r2/bench_e2e_pairs.err
+echo "rc=$?"
 python3 - <<'PY'
 import json
-d=json.loads(open('gpurun_out/r2/bench_e2e.json').read().strip().splitlines()[-1])
-print(d['value'], json.dumps(d.get('e2e'),indent=1))
+d=json.loads(open("gpurun_out/r2/bench_e2e_pairs.json").read().strip().splitlines()[-1])
+e=d["e2e"]; print(d["value"]); print({k:v for k,v in e.items() if k not in ("reference_binary","pairs")}); print(e.get("pairs"))
 PY
+grep "^trace" gpurun_out/r2/bench_e2e_pairs.err | tail -56
+grep -v "^trace" gpurun_out/r2/bench_e2e_pairs.err | tail -5
