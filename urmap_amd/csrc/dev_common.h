@@ -181,12 +181,15 @@ struct BitVec {
 	}
 };
 
-// ExtendPen's two x-drop walks (extendpen.cpp:25-78) over a precomputed mismatch bit vector, one candidate per lane,
-// WITHOUT the running penalty cap (the caller compares the final penalty: it only grows along the walk).
+// ExtendPen's two x-drop walks (extendpen.cpp:25-78) over a precomputed mismatch bit vector, one candidate per lane.
+// `cap` is an UPPER BOUND of m_MaxPenalty at the candidate's turn (the cap only falls, so its value when the batch is
+// walked is one): a lane whose penalty passes it fails extendpen.cpp:43-44 / 69-70 at its turn whatever happens before,
+// so it stops walking and returns that penalty (> cap); the caller's ordered test drops it.  Lanes under the bound
+// return the full walk's result and the caller compares their penalty with the cap in order.
 // The walk visits mismatches only.  The loop over the N words is wave-uniform and unrolled; inside a word the set
 // bits are consumed one by one (x &= x - 1), so an iteration is ~20 VALU instructions with no word selection.
 template <int N>
-__device__ __forceinline__ void xdrop_walk_lane(const uint64_t (&w)[N], int qpos, int W, int QL, int mis, int xdrop,
+__device__ __forceinline__ void xdrop_walk_lane(const uint64_t (&w)[N], int qpos, int W, int QL, int mis, int xdrop, int cap,
                                                 int &bst_out, int &startpos_out, int &endpos_out, int &pen_out) {
 	// The loop bodies are written with selects only (one divergent loop, no divergent branches inside): a lane that
 	// has stopped simply carries x == 0.
@@ -211,7 +214,7 @@ __device__ __forceinline__ void xdrop_walk_lane(const uint64_t (&w)[N], int qpos
 			score = in ? s1 + mis : score;
 			pen = in ? pen - mis : pen;
 			cur = in ? m + 1 : cur;
-			const bool stop = in && (bst - score > xdrop);
+			const bool stop = in && (bst - score > xdrop || pen > cap);
 			alive = alive && !stop;
 			x = (stop || !in) ? 0ull : x;
 		}
@@ -225,7 +228,7 @@ __device__ __forceinline__ void xdrop_walk_lane(const uint64_t (&w)[N], int qpos
 	}
 	int startpos = qpos;
 	cur = startpos - 1;
-	alive = cur >= 0;
+	alive = cur >= 0 && pen <= cap;
 #pragma unroll
 	for (int c = N - 1; c >= 0; --c) {
 		uint64_t x = w[c];
@@ -243,7 +246,7 @@ __device__ __forceinline__ void xdrop_walk_lane(const uint64_t (&w)[N], int qpos
 			score = s1 + mis;
 			pen -= mis;
 			cur = m - 1;
-			const bool stop = bst - score > xdrop;
+			const bool stop = bst - score > xdrop || pen > cap;
 			alive = alive && !stop;
 			x = stop ? 0ull : x;
 		}
@@ -255,6 +258,22 @@ __device__ __forceinline__ void xdrop_walk_lane(const uint64_t (&w)[N], int qpos
 		startpos = nb ? 0 : startpos;
 	}
 	bst_out = bst; startpos_out = startpos; endpos_out = endpos; pen_out = pen;
+}
+
+// Mismatches outside the seed window [qpos, qpos + W) of a lane's bit vector.  ExtendPen never looks inside the seed
+// (extendpen.cpp:24-27), so this is the most its walks can meet: a full-length hit costs exactly -mis times this, and no
+// score along the walks exceeds QL minus this.
+template <int N>
+__device__ __forceinline__ int mismatches_outside_seed(const uint64_t (&w)[N], int qpos, int W) {
+	int pc = 0;
+#pragma unroll
+	for (int c = 0; c < N; ++c) {
+		const int lo = qpos - 64 * c, hi = lo + W;  // seed bits of this word: [lo, hi) cut to [0, 64)
+		const uint64_t below_hi = hi >= 64 ? ~0ull : (hi <= 0 ? 0ull : ((1ull << hi) - 1ull));
+		const uint64_t below_lo = lo >= 64 ? ~0ull : (lo <= 0 ? 0ull : ((1ull << lo) - 1ull));
+		pc += __builtin_popcountll(w[c] & ~(below_hi & ~below_lo));
+	}
+	return pc;
 }
 
 // inclusive prefix sum of a non-negative int over the 64 lanes (DPP, same ladder as wave_prefix_max)

@@ -1007,12 +1007,21 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 				__builtin_amdgcn_s_waitcnt(0);
 				laps(9);
 				if ((dbg_stop == 402 && step == 4) || dbg_stop == 412) { if (mm[0] == 0x123456789ull) done = true; continue; }
-				// ExtendPen's two x-drop walks (extendpen.cpp:25-78), every lane on its own bit vector, WITHOUT the
-				// running penalty cap: the accumulated penalty only grows along the walk, so the capped walk aborts
-				// iff the uncapped walk's final penalty exceeds the cap -- which is checked in order below.
+				// ExtendPen's two x-drop walks (extendpen.cpp:25-78), every lane on its own bit vector.  The accumulated
+				// penalty only grows along the walk and the cap only falls: a lane over the cap as it stands now is over
+				// it at its turn and stops; the others finish and are compared with the cap in order below.
+				// A candidate changes the state only as a full-length hit under the cap or as an HSP scoring at least
+				// max(MinHSPScore, best - 4) (extendpen.cpp:79-95, state1.cpp:555).  With n mismatches outside its seed
+				// the first costs -mis * n and no score of the second exceeds QL - n: lanes that can be neither do not walk.
 				int e_kind = 0, e_bst = 0, e_start = 0, e_end = 0, e_pen = 0;
+				bool worth = false;
 				if (c_ok) {
-					xdrop_walk_lane<NCH>(mm, (int)c_qpos, W, QL, P.mismatch_score, P.xdrop, e_bst, e_start, e_end, e_pen);
+					const int nmis = mismatches_outside_seed<NCH>(mm, (int)c_qpos, W);
+					const int floor2 = minhsp > S.best - 4 ? minhsp : S.best - 4;
+					worth = -P.mismatch_score * nmis <= S.maxPen || QL - nmis >= floor2;
+				}
+				if (worth) {
+					xdrop_walk_lane<NCH>(mm, (int)c_qpos, W, QL, P.mismatch_score, P.xdrop, S.maxPen, e_bst, e_start, e_end, e_pen);
 					if (e_start == 0 && e_end == QL - 1) e_kind = 1;
 					else if (e_bst >= minhsp) e_kind = 2;
 				}

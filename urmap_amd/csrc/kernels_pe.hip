@@ -532,9 +532,14 @@ struct Mate {
 				if (ok) {
 					uint64_t mm[NCH];
 					lane_mismatch_mask<NCH>(gseq, dblo, c_plus ? sQ[0] : sQ[1], QL, mm);
-					xdrop_walk_lane<NCH>(mm, (int)c_q, W, QL, P->mismatch_score, P->xdrop, e_bst, e_sp, e_ep, e_pen);
-					if (e_sp == 0 && e_ep == QL - 1) e_kind = 1;
-					else if (e_bst >= minhsp) e_kind = 2;
+					// lanes that can be neither a hit under the cap nor an HSP that counts do not walk (see search_se_kernel)
+					const int nmis = mismatches_outside_seed<NCH>(mm, (int)c_q, W);
+					const int floor2 = minhsp > best - 4 ? minhsp : best - 4;
+					if (-P->mismatch_score * nmis <= maxPen || QL - nmis >= floor2) {
+						xdrop_walk_lane<NCH>(mm, (int)c_q, W, QL, P->mismatch_score, P->xdrop, maxPen, e_bst, e_sp, e_ep, e_pen);
+						if (e_sp == 0 && e_ep == QL - 1) e_kind = 1;
+						else if (e_bst >= minhsp) e_kind = 2;
+					}
 				}
 				// ordered part (see search_se_kernel): candidates that cannot change the state are dropped, up front and
 				// after every change
@@ -921,7 +926,7 @@ __global__ __launch_bounds__(64) void search_pe_kernel(DevIndex X, urmapx_params
 						uint64_t mm[NCH];
 						lane_mismatch_mask<NCH>(g_seq, db - q, sQ[2 * a + (plus ? 0 : 1)], QL, mm);
 						int bst, sp, ep;
-						xdrop_walk_lane<NCH>(mm, (int)q, W, QL, P.mismatch_score, P.xdrop, bst, sp, ep, pen);
+						xdrop_walk_lane<NCH>(mm, (int)q, W, QL, P.mismatch_score, P.xdrop, P.max_penalty, bst, sp, ep, pen);  // cached for any later cap: bounded by the initial one
 						const uint32_t kind = (sp == 0 && ep == QL - 1) ? 1u : (bst >= minhsp ? 2u : 0u);
 						res = (kind << 27) | ((uint32_t)ep << 18) | ((uint32_t)sp << 9) | (uint32_t)bst;
 					}
