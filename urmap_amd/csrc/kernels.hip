@@ -1094,8 +1094,16 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 // admits the HSP when its turn comes -- is left to finalize_se_kernel.  One conservative shortcut: if the penalty
 // after the left flank already exceeds the cap the job was made under, the right flank is not run (the cap only
 // falls, so the ordered replay returns at that same test).
+#ifndef URX_DP_WAVES
+#define URX_DP_WAVES 0  // build-time knob: register budget of dp_kernel as waves per SIMD (0 = the compiler's choice, 5)
+#endif
+#if URX_DP_WAVES
+#define URX_DP_ATTR __attribute__((amdgpu_waves_per_eu(URX_DP_WAVES, URX_DP_WAVES)))
+#else
+#define URX_DP_ATTR
+#endif
 template <int NCH>
-__global__ __launch_bounds__(64) void dp_kernel(DevIndex X, urmapx_params P, const uint8_t *__restrict__ bases,
+__global__ __launch_bounds__(64) URX_DP_ATTR void dp_kernel(DevIndex X, urmapx_params P, const uint8_t *__restrict__ bases,
                                                 const uint64_t *__restrict__ offs, DpWork dp, uint8_t *scratch,
                                                 size_t scratch_stride, const uint8_t *__restrict__ g_seq, uint32_t klo, uint32_t khi) {
 	constexpr int QMAX = 64 * NCH;
