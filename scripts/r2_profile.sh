@@ -17,5 +17,8 @@ $T rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_AN
 python3 $R/scripts/pmc_summary.py /tmp/ps $O/pmc_sq_se.json > /dev/null
 $T rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_WAVES -d /tmp/ps2 -o ps --output-format csv -- python3 $R/bench.py $A > $O/bench_se_pmcsq2.json 2> $O/ps2.err
 python3 $R/scripts/pmc_summary.py /tmp/ps2 $O/pmc_sq2_se.json > /dev/null
+# 6: the file-to-file leg (text kernels of text_gpu.hip among the mapping kernels) under the kernel trace
+URMAP_BENCH_NO_REFERENCE=1 $T rocprofv3 --kernel-trace --stats -d /tmp/kt2 -o kt --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-workloads > $O/bench_e2e_ktrace.json 2> $O/kt2.err
+cp $(find /tmp/kt2 -name "*kernel_stats.csv" | head -1) $O/kernel_stats_e2e.csv
 rm -rf /dev/shm/urmap_idx
 ls -la $O | head -30
