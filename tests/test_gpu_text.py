@@ -353,3 +353,49 @@ def test_cli_map2_unequal_mate_files_die_with_the_host_pipelines_message(golden_
     assert r1.returncode == 1 and r2.returncode == 1
     last = lambda r: [l for l in r.stderr.decode().splitlines() if l.strip()][-1]
     assert last(r1) == last(r2), (r1.stderr.decode()[-600:], r2.stderr.decode()[-600:])
+
+
+def test_short_reads_outgrow_the_sam_buffer_and_are_fetched_again(small_case, tmp_path):
+    """32-base reads: the SAM text is 1.5 x the FASTQ text, more than the lane's buffer for the chunk (sized for 1.12 x +
+    1 MB), so the chunk's text is fetched a second time into a larger buffer without another search
+    (urmapx_text_fetch_sam).  Same bytes as the host-only pipeline."""
+    from urmap_amd import synth
+    reads = synth.make_reads(77, small_case["genome"], 150_000, read_len=32, sub=0.01, ins=0.0, dele=0.0, random_frac=0.05)
+    fq = os.path.join(tmp_path, "short.fq")
+    synth.write_fastq(fq, reads)
+    assert os.path.getsize(fq) > 8_000_000
+    a, b = os.path.join(tmp_path, "text.sam"), os.path.join(tmp_path, "host.sam")
+    r1 = _run_cli(fq, small_case["ufi"], a, 1 << 20)
+    r2 = _run_cli(fq, small_case["ufi"], b, 1 << 20, host_text=True)
+    assert r1.returncode == 0 and r2.returncode == 0, (r1.stderr.decode()[-800:], r2.stderr.decode()[-800:])
+    assert os.path.getsize(a) > 1.3 * os.path.getsize(fq)
+    assert _sam_body(a) == _sam_body(b)
+
+
+def test_target_label_too_long_for_the_device_formatter_goes_to_the_host(tmp_path):
+    """A sequence label of 300 bytes: the device formatter hands the chunk back (URMAPX_TEXT_LONG_NAME), the pipeline
+    formats on the host, and the SAM is the oracle's."""
+    import oracle_lib as ol
+    from urmap_amd import api, synth
+    g = synth.make_genome(9, [50000, 20000], repeat_frac=0.2, n_families=4)
+    g = [("L" * 300, g[0][1]), g[1]]
+    fa = os.path.join(tmp_path, "g.fa")
+    synth.write_fasta(fa, g)
+    oi = ol.Index.build(fa, 131101)
+    ufi = os.path.join(tmp_path, "g.ufi")
+    oi.save(ufi)
+    reads = synth.make_reads(10, g, 500, read_len=100, sub=0.01, ins=0.0, dele=0.0)
+    fq = os.path.join(tmp_path, "r.fq")
+    synth.write_fastq(fq, reads)
+    idx = api.Index.open(ufi).upload(0)
+    m = api.Mapper(idx, device=0)
+    sam, rep = m.map_text_se(open(fq, "rb").read())
+    assert sam is None and rep["reason"] == api.TEXT_LONG_NAME
+    m.close()
+    idx.close()
+    a, osam = os.path.join(tmp_path, "text.sam"), os.path.join(tmp_path, "o.sam")
+    r1 = _run_cli(fq, ufi, a, 100)
+    assert r1.returncode == 0, r1.stderr.decode()[-800:]
+    oi.map_file_se(fq, osam, threads=2)
+    assert _records(open(a, "rb").read()) == _records(open(osam, "rb").read())
+    assert any(b"L" * 300 in l for l in _records(open(a, "rb").read()))
