@@ -368,7 +368,7 @@ def test_short_reads_outgrow_the_sam_buffer_and_are_fetched_again(small_case, tm
     r1 = _run_cli(fq, small_case["ufi"], a, 1 << 20)
     r2 = _run_cli(fq, small_case["ufi"], b, 1 << 20, host_text=True)
     assert r1.returncode == 0 and r2.returncode == 0, (r1.stderr.decode()[-800:], r2.stderr.decode()[-800:])
-    assert os.path.getsize(a) > 1.3 * os.path.getsize(fq)
+    assert os.path.getsize(a) > 1.12 * 1.04 * os.path.getsize(fq) + (1 << 20)  # more than the first buffer holds
     assert _sam_body(a) == _sam_body(b)
 
 
