@@ -70,6 +70,7 @@ struct DpWork {
 	uint16_t *ops = nullptr;        // jobs_cap * DP_JOB_OPS: the accepted alignment's path per job
 	uint16_t *kidx = nullptr;       // jobs_cap: DpJob::k again, contiguous (a round scans it 64 jobs per load)
 	uint32_t jobs_cap = 0;
+	uint32_t *tickets = nullptr;    // one work counter per round of dp_kernel (zeroed with the counters)
 	uint32_t *counters = nullptr;   // [0] jobs made, [1] reads parked, [2] jobs the ordered replay needed, [3] jobs a round's gate dropped before their DP (statistics)
 	uint32_t *fin_list = nullptr;   // per parked read: read, first job, job count
 	uint32_t *state = nullptr;      // per parked read: search state (dp_state_words(ovf) words each)

@@ -1105,7 +1105,8 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 template <int NCH>
 __global__ __launch_bounds__(64) URX_DP_ATTR void dp_kernel(DevIndex X, urmapx_params P, const uint8_t *__restrict__ bases,
                                                 const uint64_t *__restrict__ offs, DpWork dp, uint8_t *scratch,
-                                                size_t scratch_stride, const uint8_t *__restrict__ g_seq, uint32_t klo, uint32_t khi) {
+                                                size_t scratch_stride, const uint8_t *__restrict__ g_seq, uint32_t klo, uint32_t khi,
+                                                uint32_t *ticket) {
 	constexpr int QMAX = 64 * NCH;
 	constexpr int TB_ROWS8 = (QMAX - 24) / 8 + 2;
 	__shared__ __attribute__((aligned(16))) uint8_t sQ[QMAX];
@@ -1130,11 +1131,18 @@ __global__ __launch_bounds__(64) URX_DP_ATTR void dp_kernel(DevIndex X, urmapx_p
 		return __ballot(gap) != 0;
 	};
 	uint32_t n_gated = 0;  // statistics
-	// this round's jobs: those with klo <= k < khi.  The k of 64 consecutive jobs comes in with one load; the block then
-	// runs the tile's jobs of this round one after the other.
-	for (uint32_t tile = blockIdx.x * 64u; tile < njobs; tile += gridDim.x * 64u) {
+	// this round's jobs: those with klo <= k < khi.  Blocks take tiles of DP_TILE consecutive jobs from the round's work
+	// counter (a read in a repeat family owns hundreds of consecutive jobs of the last round and none of the first: a
+	// fixed tile-to-block map left blocks idle while others still had a dozen DPs to run); the k of a tile's jobs comes in
+	// with one load and the block runs those of this round one after the other.
+	constexpr uint32_t DP_TILE = 16;
+	for (;;) {
+	uint32_t tile = 0;
+	if (lane == 0) tile = atomicAdd(ticket, DP_TILE);
+	tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)tile);
+	if (tile >= njobs) break;
 	uint32_t kk = 0xFFFFu;  // 0xFFFF: slot not in use
-	if (tile + lane < njobs) kk = dp.kidx[tile + lane];
+	if (lane < (int)DP_TILE && tile + lane < njobs) kk = dp.kidx[tile + lane];
 	uint64_t todo = __ballot(kk >= klo && kk < khi && kk != 0xFFFFu);
 	while (todo) {
 		const uint32_t j = tile + (uint32_t)__builtin_ctzll(todo);
@@ -1416,6 +1424,7 @@ hipError_t launch_search_se(const DevIndex &X, const urmapx_params &P, const uin
 	for (int pass = 0; pass < 2; ++pass)
 		if (wk.dp[pass].jobs) {
 			hipError_t e = hipMemsetAsync(wk.dp[pass].counters, 0, 16, s);
+			if (e == hipSuccess) e = hipMemsetAsync(wk.dp[pass].tickets, 0, 16, s);
 			if (e != hipSuccess) return e;
 		}
 #define URX_LAUNCH_SE(NCH_, OVF_, DBG_, GRID_, STATS_, OVFBASE_, DP_)                                                             \
@@ -1426,7 +1435,8 @@ hipError_t launch_search_se(const DevIndex &X, const urmapx_params &P, const uin
 #define URX_LAUNCH_DP(NCH_, OVF_, PASS_)                                                                                          \
 	do { for (int rd = 0; rd < DP_ROUNDS; ++rd) {                                                                                 \
 		hipLaunchKernelGGL((dp_kernel<NCH_>), dim3((unsigned)wk.dp_blocks), block, 0, s, X, P, d_bases, d_offs, wk.dp[PASS_],       \
-		                   wk.dp_scratch, wk.dp_scratch_stride, X.seq, DP_ROUND_LO[rd], DP_ROUND_LO[rd + 1]);                     \
+		                   wk.dp_scratch, wk.dp_scratch_stride, X.seq, DP_ROUND_LO[rd], DP_ROUND_LO[rd + 1],                      \
+		                   wk.dp[PASS_].tickets + rd);                                                                           \
 		if (rd == DP_ROUNDS - 1) stamp(2 + 3 * PASS_);                                                                             \
 		hipLaunchKernelGGL((finalize_se_kernel<NCH_, OVF_>), dim3((unsigned)wk.blocks), block, 0, s, X, P, d_offs, wk.dp[PASS_],     \
 		                   d_results, d_path_ops, d_path_used, wk.hsp_lds_cap, wk.ovf_list, DP_ROUND_LO[rd], DP_ROUND_LO[rd + 1]); \

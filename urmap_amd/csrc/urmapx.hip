@@ -418,6 +418,7 @@ int urmapx_map_se_device(urmapx_ctx *C, const void *d_bases, const void *d_offs,
 			d.fin_list = reinterpret_cast<uint32_t *>(C->dpbuf.p + at[p][2]);
 			d.state = reinterpret_cast<uint32_t *>(C->dpbuf.p + at[p][3]);
 			d.counters = reinterpret_cast<uint32_t *>(C->dpbuf.p + at[p][4]);
+			d.tickets = reinterpret_cast<uint32_t *>(C->dpbuf.p + 32 + 16 * (size_t)p);  // bytes 32..63 of the buffer's 64-byte head
 			d.jobs_cap = jobs_cap[p]; d.fin_cap = fin_cap[p];
 		}
 	}
