@@ -1135,7 +1135,10 @@ __global__ __launch_bounds__(64) URX_DP_ATTR void dp_kernel(DevIndex X, urmapx_p
 	// counter (a read in a repeat family owns hundreds of consecutive jobs of the last round and none of the first: a
 	// fixed tile-to-block map left blocks idle while others still had a dozen DPs to run); the k of a tile's jobs comes in
 	// with one load and the block runs those of this round one after the other.
-	constexpr uint32_t DP_TILE = 16;
+#ifndef URX_DP_TILE
+#define URX_DP_TILE 16
+#endif
+	constexpr uint32_t DP_TILE = URX_DP_TILE;
 	for (;;) {
 	uint32_t tile = 0;
 	if (lane == 0) tile = atomicAdd(ticket, DP_TILE);
