@@ -3,7 +3,7 @@
 cd "$GRAFT_REPO_ROOT" || exit 1
 export URMAP_BENCH_INDEX_CACHE=/dev/shm/urmap_idx
 for flags in "$@"; do
-  (cd urmap_amd/csrc && touch kernels.hip && make -j16 EXTRA="$flags" > /dev/null 2>&1)
+  (cd urmap_amd/csrc && touch kernels.hip kernels.h && make -j16 EXTRA="$flags" > /dev/null 2>&1)
   python3 bench.py --no-e2e --no-cpu-baseline --steps 10 --warmup 2 2>/dev/null | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])

@@ -61,8 +61,13 @@ static constexpr uint8_t DPJ_LEFT_FAIL = 1, DPJ_RIGHT_FAIL = 2, DPJ_RIGHT_SKIPPE
 // The jobs of a read are run in rounds of growing size, [0,2) [2,16) [16,inf) by index: after each round the ordered
 // replay consumes that round's jobs and the penalty cap it arrives at gates the next round's DPs -- most of a repeat
 // read's HSPs fail AlignHSP's first test once the first few alignments have tightened the cap.
+#ifdef URX_DP_ROUNDS4  // build-time experiment: a finer first round
+static constexpr int DP_ROUNDS = 4;
+static constexpr uint32_t DP_ROUND_LO[DP_ROUNDS + 1] = {0u, 1u, 4u, 16u, 0xFFFFFFFFu};
+#else
 static constexpr int DP_ROUNDS = 3;
 static constexpr uint32_t DP_ROUND_LO[DP_ROUNDS + 1] = {0u, 2u, 16u, 0xFFFFFFFFu};
+#endif
 static constexpr int DP_JOB_OPS = URMAPX_MAX_PATH_OPS;  // ops slice per job
 
 struct DpWork {
