@@ -64,6 +64,9 @@ static constexpr uint8_t DPJ_LEFT_FAIL = 1, DPJ_RIGHT_FAIL = 2, DPJ_RIGHT_SKIPPE
 #ifdef URX_DP_ROUNDS4  // build-time experiment: a finer first round
 static constexpr int DP_ROUNDS = 4;
 static constexpr uint32_t DP_ROUND_LO[DP_ROUNDS + 1] = {0u, 1u, 4u, 16u, 0xFFFFFFFFu};
+#elif defined(URX_DP_ROUNDS2)
+static constexpr int DP_ROUNDS = 2;
+static constexpr uint32_t DP_ROUND_LO[DP_ROUNDS + 1] = {0u, URX_DP_ROUNDS2, 0xFFFFFFFFu};
 #else
 static constexpr int DP_ROUNDS = 3;
 static constexpr uint32_t DP_ROUND_LO[DP_ROUNDS + 1] = {0u, 2u, 16u, 0xFFFFFFFFu};
