@@ -399,3 +399,25 @@ def test_target_label_too_long_for_the_device_formatter_goes_to_the_host(tmp_pat
     oi.map_file_se(fq, osam, threads=2)
     assert _records(open(a, "rb").read()) == _records(open(osam, "rb").read())
     assert any(b"L" * 300 in l for l in _records(open(a, "rb").read()))
+
+
+@pytest.mark.parametrize("batch", [20000, 80000])
+def test_cli_map2_mate_file_with_much_longer_records(small_case, tmp_path, batch):
+    """The second mate file's records are five times as long as the first's (a long comment after each label): the mate
+    chunk outgrows the buffer sized from the first file and the reader moves to a larger one, mid-file (batch 20000) and
+    on the last chunk (batch 80000).  Same SAM as the host-only pipeline."""
+    from urmap_amd import synth
+    r1, r2 = synth.make_pairs(5, small_case["genome"], 20000, read_len=100)
+    f1, f2 = os.path.join(tmp_path, "m1.fq"), os.path.join(tmp_path, "m2.fq")
+    synth.write_fastq(f1, r1)
+    with open(f2, "wb") as f:
+        for lab, s, q in r2:
+            lab = lab if isinstance(lab, bytes) else lab.encode()
+            f.write(b"@" + lab + b" " + b"c" * 1000 + b"\n" + bytes(s) + b"\n+\n" + bytes(q) + b"\n")
+    assert os.path.getsize(f2) > 4 * os.path.getsize(f1)
+    a, b = os.path.join(tmp_path, "text.sam"), os.path.join(tmp_path, "host.sam")
+    ra = _run_cli2(f1, f2, small_case["ufi"], a, batch)
+    rb = _run_cli2(f1, f2, small_case["ufi"], b, batch, host_text=True)
+    assert ra.returncode == 0 and rb.returncode == 0, (ra.stderr.decode()[-800:], rb.stderr.decode()[-800:])
+    assert _sam_body(a) == _sam_body(b)
+    assert len(_sam_body(a)) > 40000

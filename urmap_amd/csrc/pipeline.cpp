@@ -515,18 +515,35 @@ extern "C" int urmapx_map_files(urmapx_index *I, const urmapx_map_options *opt, 
 						size_t lines = 0;
 						for (size_t k : per) lines += k;
 						char *dst = j->in + n_pad;
-						const size_t room = j->in_cap - n_pad;
+						size_t room = j->in_cap - n_pad;
 						const uint64_t left2 = fsize2 - off2;
 						size_t have = 0, n2 = 0;
 						bool found = false, give_up = false;
+						// the mate chunk outgrew the buffer (its records are longer than the first file's were so far): a larger
+						// one, with what has been read
+						auto more_room = [&](size_t need_room) {
+							size_t ncap = 0;
+							char *nb = HostPool::get().acquire(n_pad + need_room + (4u << 20), ncap);
+							if (!nb) return false;
+							memcpy(nb, j->in, n);
+							if (have) memcpy(nb + n_pad, dst, have);
+							HostPool::get().release(j->in, j->in_cap);
+							j->in = nb; j->in_cap = ncap;
+							dst = nb + n_pad; room = ncap - n_pad;
+							return true;
+						};
 						if (end == fsize) {  // last chunk: whatever the mate file still holds (the device parser says if it is not the same count)
-							if (left2 > room) give_up = true;
+							if (left2 > room && (left2 > 8ull * n + (64u << 20) || !more_room((size_t)left2))) give_up = true;
 							else { have = (size_t)left2; found = true; n2 = have; if (have && !read_range(fq2, dst, off2, have)) { fail.raise(URMAPX_E_IO, std::string("Error reading ") + fastq2); break; } }
 						}
 						while (!found && !give_up) {
 							size_t upto = have ? have + have / 4 + (1u << 20) : (size_t)((double)n * bytes2_per_byte1) + (1u << 16);
 							upto = (size_t)std::min<uint64_t>(std::min<uint64_t>(upto, room), left2);
-							if (upto <= have) { give_up = true; break; }  // out of room, or out of file with too few lines
+							if (upto <= have) {
+								if (have < left2 && room < 8 * n + (64u << 20) && more_room(2 * room)) continue;  // out of room, not out of file
+								give_up = true;  // out of file with too few lines (the host reader words that), or a chunk beyond reason
+								break;
+							}
 							if (!read_range(fq2, dst + have, off2 + have, upto - have)) { fail.raise(URMAPX_E_IO, std::string("Error reading ") + fastq2); give_up = true; break; }
 							have = upto;
 							count_lines(dst, have, per);
