@@ -78,7 +78,7 @@ struct DpWork {
 	uint16_t *ops = nullptr;        // jobs_cap * DP_JOB_OPS: the accepted alignment's path per job
 	uint16_t *kidx = nullptr;       // jobs_cap: DpJob::k again, contiguous (a round scans it 64 jobs per load)
 	uint32_t jobs_cap = 0;
-	uint32_t *tickets = nullptr;    // one work counter per round of dp_kernel (zeroed with the counters)
+	uint32_t *tickets = nullptr;    // work counters of dp_kernel's rounds, zeroed with the counters
 	uint32_t *counters = nullptr;   // [0] jobs made, [1] reads parked, [2] jobs the ordered replay needed, [3] jobs a round's gate dropped before their DP (statistics)
 	uint32_t *fin_list = nullptr;   // per parked read: read, first job, job count
 	uint32_t *state = nullptr;      // per parked read: search state (dp_state_words(ovf) words each)
@@ -99,10 +99,12 @@ struct SearchWork {
 	uint8_t *dp_scratch = nullptr; // dp_kernel's wide-band scratch: dp_blocks * dp_scratch_stride bytes
 	size_t dp_scratch_stride = 0;
 	int dp_blocks = 0;
+	int fin_blocks = 0;            // grid of finalize_se_kernel (0: the search kernel's)
 	hipEvent_t *stage_events = nullptr;  // optional: 7 events recorded between the launches (main, dp, finalize, main2, dp2, finalize2)
 };
 size_t dp_scratch_stride(uint32_t max_read_len);
 int dp_block_count(uint32_t max_read_len, int device);
+int fin_block_count(uint32_t max_read_len, int device);
 size_t search_scratch_stride(uint32_t max_read_len);
 size_t search_scratch_tail(int blocks);
 size_t search_pe_scratch_tail(int blocks);

@@ -1283,6 +1283,8 @@ __global__ __launch_bounds__(64) void finalize_se_kernel(DevIndex X, urmapx_para
 	S.hit_cap = (hsp_lds_cap >= 64 && hsp_lds_cap <= HSP_CAP) ? S.hsp_lds / 4 : 64;
 	S.hit_wsh = (hsp_lds_cap >= 64 && hsp_lds_cap <= HSP_CAP) ? 4 : 6;
 	const uint32_t parked = dp.counters[1] < dp.fin_cap ? dp.counters[1] : dp.fin_cap;
+	// parked reads go to blocks round-robin: the costly ones (repeat families: hundreds of jobs) were parked last, next
+	// to each other, and a block that took a run of them from a work counter made the launch 0.8 ms longer
 	for (uint32_t e = blockIdx.x; e < parked; e += gridDim.x) {
 		const uint32_t r = dp.fin_list[3 * e], jb = dp.fin_list[3 * e + 1], nj = dp.fin_list[3 * e + 2];
 		if (nj <= klo) continue;  // finished in an earlier round
@@ -1427,7 +1429,7 @@ hipError_t launch_search_se(const DevIndex &X, const urmapx_params &P, const uin
 	for (int pass = 0; pass < 2; ++pass)
 		if (wk.dp[pass].jobs) {
 			hipError_t e = hipMemsetAsync(wk.dp[pass].counters, 0, 16, s);
-			if (e == hipSuccess) e = hipMemsetAsync(wk.dp[pass].tickets, 0, 16, s);
+			if (e == hipSuccess) e = hipMemsetAsync(wk.dp[pass].tickets, 0, 32, s);
 			if (e != hipSuccess) return e;
 		}
 #define URX_LAUNCH_SE(NCH_, OVF_, DBG_, GRID_, STATS_, OVFBASE_, DP_)                                                             \
@@ -1441,8 +1443,9 @@ hipError_t launch_search_se(const DevIndex &X, const urmapx_params &P, const uin
 		                   wk.dp_scratch, wk.dp_scratch_stride, X.seq, DP_ROUND_LO[rd], DP_ROUND_LO[rd + 1],                      \
 		                   wk.dp[PASS_].tickets + rd);                                                                           \
 		if (rd == DP_ROUNDS - 1) stamp(2 + 3 * PASS_);                                                                             \
-		hipLaunchKernelGGL((finalize_se_kernel<NCH_, OVF_>), dim3((unsigned)wk.blocks), block, 0, s, X, P, d_offs, wk.dp[PASS_],     \
-		                   d_results, d_path_ops, d_path_used, wk.hsp_lds_cap, wk.ovf_list, DP_ROUND_LO[rd], DP_ROUND_LO[rd + 1]); \
+		hipLaunchKernelGGL((finalize_se_kernel<NCH_, OVF_>), dim3((unsigned)(wk.fin_blocks > 0 ? wk.fin_blocks : wk.blocks)), block, \
+		                   0, s, X, P, d_offs, wk.dp[PASS_], d_results, d_path_ops, d_path_used, wk.hsp_lds_cap, wk.ovf_list,        \
+		                   DP_ROUND_LO[rd], DP_ROUND_LO[rd + 1]);                                                                  \
 	} } while (0)
 	stamp(0);
 	const bool diag = wk.stats != nullptr && (nch == 3 || nch == 4);  // diagnostic instantiations: 150 / 250 bp classes, phase 6 inline
@@ -1510,6 +1513,22 @@ int dp_block_count(uint32_t max_read_len, int device) {
 	               : nchq == 8 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dp_kernel<8>, 64, 0)
 	                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dp_kernel<16>, 64, 0);
 	if (e != hipSuccess || per_cu < 1) per_cu = 8;
+	return per_cu * prop.multiProcessorCount;
+}
+
+// finalize_se_kernel waits on memory (state in, jobs, state out): as many waves as fit
+int fin_block_count(uint32_t max_read_len, int device) {
+	hipDeviceProp_t prop;
+	if (hipGetDeviceProperties(&prop, device) != hipSuccess) return 0;
+	int per_cu = 0;
+	const int nchq = nch_for(max_read_len);
+	hipError_t e = nchq == 2   ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, finalize_se_kernel<2, false>, 64, 0)
+	               : nchq == 3 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, finalize_se_kernel<3, false>, 64, 0)
+	               : nchq == 4 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, finalize_se_kernel<4, false>, 64, 0)
+	               : nchq == 5 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, finalize_se_kernel<5, false>, 64, 0)
+	               : nchq == 8 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, finalize_se_kernel<8, false>, 64, 0)
+	                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, finalize_se_kernel<16, false>, 64, 0);
+	if (e != hipSuccess || per_cu < 1) per_cu = 16;
 	return per_cu * prop.multiProcessorCount;
 }
 

@@ -76,6 +76,7 @@ struct urmapx_ctx {
 	DevBuf<uint32_t> ovflist;  // reads queued for the search kernel's second pass
 	DevBuf<uint8_t> dpbuf, dpscratch;  // phase 6 as its own launches: jobs, paths, parked read states (kernels.h: DpWork)
 	int dp_blocks[6] = {0, 0, 0, 0, 0, 0};
+	int fin_blocks[6] = {0, 0, 0, 0, 0, 0};
 	hipEvent_t stage_ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 	bool stage_valid = false;
 	uint32_t pairinfo_n = 0;
@@ -393,6 +394,8 @@ int urmapx_map_se_device(urmapx_ctx *C, const void *d_bases, const void *d_offs,
 		if (C->dp_blocks[cls] == 0) C->dp_blocks[cls] = dp_block_count(max_read_len, C->device);
 		if (C->dp_blocks[cls] <= 0) return URMAPX_E_NODEVICE;
 		wk.dp_blocks = C->dp_blocks[cls];
+		if (C->fin_blocks[cls] == 0) C->fin_blocks[cls] = fin_block_count(max_read_len, C->device);
+		wk.fin_blocks = C->fin_blocks[cls] > 0 ? C->fin_blocks[cls] : 0;
 		wk.dp_scratch_stride = dp_scratch_stride(max_read_len);
 		if ((rc = C->dpscratch.ensure(wk.dp_scratch_stride * (size_t)wk.dp_blocks))) return rc;
 		wk.dp_scratch = C->dpscratch.p;
@@ -400,7 +403,7 @@ int urmapx_map_se_device(urmapx_ctx *C, const void *d_bases, const void *d_offs,
 		const uint32_t jobs_cap[2] = {(uint32_t)(jc < (1ull << 30) ? jc : (1ull << 30)) + 4096u,
 		                              (uint32_t)(jc < (1ull << 30) ? jc : (1ull << 30)) + 65536u};
 		const uint32_t fin_cap[2] = {n, n / 8u + 1024u};
-		size_t need = 64, at[2][6];
+		size_t need = 128, at[2][6];  // head: counters (2 x 16 bytes), then the work counters (2 x 32 bytes)
 		for (int p = 0; p < 2; ++p) {
 			at[p][5] = need; need += (((size_t)jobs_cap[p] * 2) + 63) & ~(size_t)63;
 			at[p][0] = need; need += (size_t)jobs_cap[p] * sizeof(DpJob);
@@ -418,7 +421,7 @@ int urmapx_map_se_device(urmapx_ctx *C, const void *d_bases, const void *d_offs,
 			d.fin_list = reinterpret_cast<uint32_t *>(C->dpbuf.p + at[p][2]);
 			d.state = reinterpret_cast<uint32_t *>(C->dpbuf.p + at[p][3]);
 			d.counters = reinterpret_cast<uint32_t *>(C->dpbuf.p + at[p][4]);
-			d.tickets = reinterpret_cast<uint32_t *>(C->dpbuf.p + 32 + 16 * (size_t)p);  // bytes 32..63 of the buffer's 64-byte head
+			d.tickets = reinterpret_cast<uint32_t *>(C->dpbuf.p + 64 + 32 * (size_t)p);
 			d.jobs_cap = jobs_cap[p]; d.fin_cap = fin_cap[p];
 		}
 	}
