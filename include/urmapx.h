@@ -273,6 +273,7 @@ typedef struct urmapx_text urmapx_text;
 #define URMAPX_TEXT_SAM_CAP 5     /* sam_cap < report.sam_bytes: the chunk is mapped, its text waits for urmapx_text_fetch_sam */
 #define URMAPX_TEXT_TOO_LARGE 6   /* chunk over 1 GiB */
 #define URMAPX_TEXT_UNEQUAL 7     /* pairs: the two chunks do not hold the same number of records */
+#define URMAPX_TEXT_INTERNAL 8    /* the device formatter's two passes disagreed on a record length (never expected): text not used */
 typedef struct urmapx_text_report {
 	uint32_t records;   /* reads of the chunk */
 	uint32_t reason;    /* URMAPX_TEXT_*; non-zero: nothing was written */

@@ -65,7 +65,7 @@ class TextReport(C.Structure):
                 ("mapped_lowq", C.c_uint64), ("unmapped", C.c_uint64), ("unsupported", C.c_uint64)]
 
 
-TEXT_OK, TEXT_CR, TEXT_RAGGED, TEXT_BAD_RECORD, TEXT_LONG_NAME, TEXT_SAM_CAP, TEXT_TOO_LARGE, TEXT_UNEQUAL = range(8)
+TEXT_OK, TEXT_CR, TEXT_RAGGED, TEXT_BAD_RECORD, TEXT_LONG_NAME, TEXT_SAM_CAP, TEXT_TOO_LARGE, TEXT_UNEQUAL, TEXT_INTERNAL = range(9)
 
 
 class UrmapxError(RuntimeError):

@@ -8,7 +8,7 @@
 //
 //   raw bytes --nl_count / nl_emit--> line ends --record_kernel--> read lengths --scan--> offs
 //             --copy_bases_kernel--> bases   --urmapx_map_se_device--> results, paths
-//             --sam_kernel<0>--> record lengths --scan--> record offsets --sam_kernel<1>--> SAM text
+//             --sam_len_kernel--> record lengths --scan--> record offsets --sam_kernel--> SAM text
 //
 // Paired-end (urmapx_text_map_pe): one chunk of each mate file with the same number of records; both are parsed as above,
 // the mates' bases are interleaved (reads 2i, 2i+1 = pair i, map2.cpp:27-32), State2::Search runs
@@ -412,8 +412,150 @@ __device__ uint32_t build_head(const SamArgs &A, const urmapx_result &r, const M
 	return (uint32_t)(p - head);
 }
 
-// One wavefront per record.  PASS 0: the record's length and the HitStats counters (output1.cpp:20-30).  PASS 1: its bytes.
-template <int PASS>
+__device__ __forceinline__ uint32_t dev_digits(uint32_t v) {
+	return v < 10u ? 1u : v < 100u ? 2u : v < 1000u ? 3u : v < 10000u ? 4u : v < 100000u ? 5u : v < 1000000u ? 6u : v < 10000000u ? 7u
+	     : v < 100000000u ? 8u : v < 1000000000u ? 9u : 10u;
+}
+
+// Length of what build_head writes, without writing it (the same tests in the same order; 0 = does not fit).  The CIGAR
+// runs are merged as they stream by; the dangling-M rule needs the first three and the last three merged runs only.
+__device__ uint32_t head_length(const SamArgs &A, const urmapx_result &r, const MateFields &F, uint32_t QL) {
+	if (r.dbpos == 0xFFFFFFFFu) {
+		uint32_t flags = 0x04u;
+		if (F.flags & 0x01u) flags |= 0x01u;
+		if (F.flags & 0x40u) flags |= 0x40u;
+		else if (F.flags & 0x80u) flags |= 0x80u;
+		if (F.flags & 0x08u) flags |= 0x08u;
+		else if (F.flags & 0x20u) flags |= 0x20u;
+		return 1u + dev_digits(flags) + 17u;
+	}
+	if (r.seq_index >= A.seq_count) return 0;
+	const uint32_t t0 = A.tname_offs[r.seq_index], tl = A.tname_offs[r.seq_index + 1] - t0;
+	if (tl > (uint32_t)TNAME_MAX) return 0;
+	uint32_t n = 1u + dev_digits(F.flags) + 1u + tl + 1u + dev_digits(r.coord + 1u) + 1u + dev_digits(r.mapq) + 1u;
+	uint32_t nops = r.path_nops;
+	if (nops == 0) n += dev_digits(QL) + 1u;
+	else {
+		if (nops > URMAPX_MAX_PATH_OPS) nops = URMAPX_MAX_PATH_OPS;
+		const urmapx_path_op *ops = A.ops + r.path_off;
+		uint32_t N = 0, chars = 0;
+		char fo[3] = {0, 0, 0}, lo[3] = {0, 0, 0};  // first three / last three merged runs (lo[2] = the last)
+		uint32_t fl[3] = {0, 0, 0}, ll[3] = {0, 0, 0};
+		char cur = 0;
+		uint32_t curlen = 0;
+		bool have = false;
+		auto close_run = [&]() {
+			if (N < 3) { fo[N] = cur; fl[N] = curlen; }
+			lo[0] = lo[1]; ll[0] = ll[1]; lo[1] = lo[2]; ll[1] = ll[2]; lo[2] = cur; ll[2] = curlen;
+			chars += dev_digits(curlen) + 1u;
+			++N;
+		};
+		for (uint32_t i = 0; i < nops; ++i) {
+			const uint32_t code = ops[i] & 3u, len = ops[i] >> 2;
+			const char c = code == 0 ? 'M' : code == 1 ? 'I' : 'D';
+			if (have && cur == c) curlen += len;
+			else {
+				if (have) close_run();
+				cur = c; curlen = len; have = true;
+			}
+		}
+		close_run();
+		if (N >= 3) {
+			if (fo[0] == 'M' && fl[0] <= 2 && fl[1] > 4 && fo[2] == 'M') {
+				chars -= dev_digits(fl[0]) + 1u;
+				chars += dev_digits(fl[2] + fl[0]) - dev_digits(fl[2]);
+			} else if (lo[2] == 'M' && ll[2] <= 2 && ll[1] > 4 && lo[0] == 'M') {
+				chars -= dev_digits(ll[2]) + 1u;
+				chars += dev_digits(ll[0] + ll[2]) - dev_digits(ll[0]);
+			}
+		}
+		n += chars;
+	}
+	n += 1u;  // the tab after CIGAR
+	if (!F.mate_mapped) n += 1u;
+	else {
+		if (F.mate_seq_index >= A.seq_count) return 0;
+		const uint32_t m0 = A.tname_offs[F.mate_seq_index], ml = A.tname_offs[F.mate_seq_index + 1] - m0;
+		if (ml > (uint32_t)TNAME_MAX) return 0;
+		bool same = ml == tl;
+		for (uint32_t i = 0; same && i < tl; ++i) same = A.tnames[t0 + i] == A.tnames[m0 + i];
+		if (ml == 0 || (ml == 1 && A.tnames[m0] == '*')) n += 1u;
+		else if (same) n += 1u;
+		else n += ml;
+	}
+	n += 1u;
+	if (!F.mate_mapped || F.mate_coord == 0 || F.mate_coord == 0xFFFFFFFFu) n += 1u;
+	else n += dev_digits(F.mate_coord + 1u);
+	n += 1u;
+	n += F.tlen < 0 ? 1u + dev_digits((uint32_t)(-(long long)F.tlen)) : dev_digits((uint32_t)F.tlen);
+	n += 1u;
+	return n;
+}
+
+// what a record has besides its result: where its lines are, QNAME length ("/1" "/2" dropped, cut at the first blank:
+// setsam.cpp:36-46), SetSAM's mate arguments
+struct RecView {
+	const uint8_t *raw;
+	uint32_t s1, e1, e3, QL;
+	MateFields F;
+};
+__device__ __forceinline__ RecView record_view(const SamArgs &A, uint32_t i, const urmapx_result &r) {
+	RecView V;
+	const uint32_t side = A.paired ? (i & 1u) : 0u, rec = A.paired ? (i >> 1) : i;
+	V.raw = A.raw[side];
+	const uint32_t *ends = A.ends[side];
+	V.s1 = line_start(ends, 4 * rec); V.e1 = ends[4 * rec];
+	const uint32_t e2 = ends[4 * rec + 1];
+	V.e3 = ends[4 * rec + 2];
+	V.QL = e2 - (V.e1 + 1u);
+	V.F.flags = 0; V.F.mate_mapped = false; V.F.mate_seq_index = 0; V.F.mate_coord = 0xFFFFFFFFu; V.F.tlen = 0;
+	if (A.paired) {
+		const urmapx_result rm = A.results[i ^ 1u];
+		const uint32_t *oe = A.ends[side ^ 1u];
+		const uint32_t QLm = oe[4 * rec + 1] - (oe[4 * rec] + 1u);
+		V.F = side ? pair_fields(rm, r, QLm, V.QL, true) : pair_fields(r, rm, V.QL, QLm, false);
+	}
+	return V;
+}
+
+// Record lengths and the HitStats counters (output1.cpp:20-30), one THREAD per record: nothing is written but a number,
+// so the serial part of a record (the head between QNAME and SEQ) runs for 64 records at a time.
+__global__ __launch_bounds__(256) void sam_len_kernel(SamArgs A) {
+	const uint32_t n = A.hdr->n_reads;
+	uint32_t c_acc = 0, c_rej = 0, c_no = 0, c_uns = 0;
+	bool bad = false;
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+		const urmapx_result r = A.results[i];
+		const RecView V = record_view(A, i, r);
+		const uint8_t *label = V.raw + V.s1 + 1u;
+		uint32_t ln = V.e1 - V.s1 - 1u;
+		if (ln > 2 && label[ln - 2] == '/' && (label[ln - 1] == '1' || label[ln - 1] == '2')) ln -= 2;
+		uint32_t qn = 0;
+		while (qn < ln && label[qn] != ' ' && label[qn] != '\t') ++qn;
+		const uint32_t hl = head_length(A, r, V.F, V.QL);
+		A.lens[i] = qn + hl + 2u * V.QL + 2u;
+		if (hl == 0) bad = true;
+		if (r.status) ++c_uns;
+		if (r.dbpos == 0xFFFFFFFFu) ++c_no;
+		else if (r.mapq >= A.minq) ++c_acc;
+		else ++c_rej;
+	}
+	if (bad) atomicOr(&A.hdr->flags, 8u);
+	for (int d = 32; d; d >>= 1) {
+		c_acc += __shfl_xor(c_acc, d, 64); c_rej += __shfl_xor(c_rej, d, 64);
+		c_no += __shfl_xor(c_no, d, 64); c_uns += __shfl_xor(c_uns, d, 64);
+	}
+	if ((threadIdx.x & 63) == 0) {
+		if (c_acc) atomicAdd(&A.hdr->cnt[0], (unsigned long long)c_acc);
+		if (c_rej) atomicAdd(&A.hdr->cnt[1], (unsigned long long)c_rej);
+		if (c_no) atomicAdd(&A.hdr->cnt[2], (unsigned long long)c_no);
+		if (c_uns) atomicAdd(&A.hdr->cnt[3], (unsigned long long)c_uns);
+	}
+}
+
+// The records' bytes, one wavefront per record: QNAME, the head built by lane 0 in LDS, SEQ and QUAL copied by the 64
+// lanes (reverse-complemented / reversed for a minus-strand hit).  The length it arrives at must be the one
+// sam_len_kernel reserved; if not, the chunk is flagged and handed back (flag 32).
 __global__ __launch_bounds__(SAM_WAVES * 64) void sam_kernel(SamArgs A) {
 	__shared__ char s_head[SAM_WAVES][HEAD_CAP];
 	__shared__ char s_cop[SAM_WAVES][URMAPX_MAX_PATH_OPS + 1];
@@ -422,17 +564,12 @@ __global__ __launch_bounds__(SAM_WAVES * 64) void sam_kernel(SamArgs A) {
 	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 	const uint32_t n = A.hdr->n_reads;
 	const uint32_t wave = blockIdx.x * SAM_WAVES + w, n_waves = gridDim.x * SAM_WAVES;
-	uint32_t c_acc = 0, c_rej = 0, c_no = 0, c_uns = 0;
 	for (uint32_t i = wave; i < n; i += n_waves) {
 		const urmapx_result r = A.results[i];
-		const uint32_t side = A.paired ? (i & 1u) : 0u, rec = A.paired ? (i >> 1) : i;
-		const uint8_t *raw = A.raw[side];
-		const uint32_t *ends = A.ends[side];
-		const uint32_t s1 = line_start(ends, 4 * rec), e1 = ends[4 * rec], e2 = ends[4 * rec + 1], e3 = ends[4 * rec + 2];
-		const uint32_t QL = e2 - (e1 + 1u);
-		const uint8_t *label = raw + s1 + 1u;
-		uint32_t ln = e1 - s1 - 1u;
-		// QNAME: "/1" "/2" dropped, then cut at the first blank (setsam.cpp:36-46)
+		const RecView V = record_view(A, i, r);
+		const uint32_t QL = V.QL;
+		const uint8_t *label = V.raw + V.s1 + 1u;
+		uint32_t ln = V.e1 - V.s1 - 1u;
 		if (ln > 2 && label[ln - 2] == '/' && (label[ln - 1] == '1' || label[ln - 1] == '2')) ln -= 2;
 		uint32_t qn = ln;
 		for (uint32_t b = 0; b < ln; b += 64) {
@@ -440,50 +577,29 @@ __global__ __launch_bounds__(SAM_WAVES * 64) void sam_kernel(SamArgs A) {
 			const unsigned long long m = __ballot(c == ' ' || c == '\t');
 			if (m) { qn = b + (uint32_t)__ffsll((long long)m) - 1u; break; }
 		}
-		MateFields F;
-		F.flags = 0; F.mate_mapped = false; F.mate_seq_index = 0; F.mate_coord = 0xFFFFFFFFu; F.tlen = 0;
-		if (A.paired) {
-			const urmapx_result rm = A.results[i ^ 1u];
-			const uint32_t *oe = A.ends[side ^ 1u];
-			const uint32_t QLm = oe[4 * rec + 1] - (oe[4 * rec] + 1u);
-			F = side ? pair_fields(rm, r, QLm, QL, true) : pair_fields(r, rm, QL, QLm, false);
-		}
-		if (lane == 0) s_hl[w] = build_head(A, r, F, QL, s_head[w], s_cop[w], s_clen[w]);
+		if (lane == 0) s_hl[w] = build_head(A, r, V.F, QL, s_head[w], s_cop[w], s_clen[w]);
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 		__builtin_amdgcn_wave_barrier();
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 		const uint32_t hl = s_hl[w];
-		if (PASS == 0) {
-			if (lane == 0) {
-				A.lens[i] = qn + hl + 2u * QL + 2u;
-				if (hl == 0) atomicOr(&A.hdr->flags, 8u);
-				if (r.status) ++c_uns;
-				if (r.dbpos == 0xFFFFFFFFu) ++c_no;
-				else if (r.mapq >= A.minq) ++c_acc;
-				else ++c_rej;
-			}
-		} else {
-			char *out = A.sam + A.rec_offs[i];
-			for (uint32_t k = lane; k < qn; k += 64) out[k] = (char)label[k];
-			out += qn;
-			for (uint32_t k = lane; k < hl; k += 64) out[k] = s_head[w][k];
-			out += hl;
-			const uint8_t *seq = raw + e1 + 1u, *qual = raw + e3 + 1u;
-			const bool plus = r.dbpos == 0xFFFFFFFFu || r.plus;
-			if (plus) {
-				for (uint32_t k = lane; k < QL; k += 64) { out[k] = (char)seq[k]; out[QL + 1u + k] = (char)qual[k]; }
-			} else {
-				for (uint32_t k = lane; k < QL; k += 64) { out[k] = (char)A.comp[seq[QL - 1u - k]]; out[QL + 1u + k] = (char)qual[QL - 1u - k]; }
-			}
-			if (lane == 0) { out[QL] = '\t'; out[2u * QL + 1u] = '\n'; }
+		if (qn + hl + 2u * QL + 2u != A.lens[i]) {  // never: the two kernels count the same bytes
+			if (lane == 0) atomicOr(&A.hdr->flags, 32u);
+			continue;
 		}
+		char *out = A.sam + A.rec_offs[i];
+		for (uint32_t k = lane; k < qn; k += 64) out[k] = (char)label[k];
+		out += qn;
+		for (uint32_t k = lane; k < hl; k += 64) out[k] = s_head[w][k];
+		out += hl;
+		const uint8_t *seq = V.raw + V.e1 + 1u, *qual = V.raw + V.e3 + 1u;
+		const bool plus = r.dbpos == 0xFFFFFFFFu || r.plus;
+		if (plus) {
+			for (uint32_t k = lane; k < QL; k += 64) { out[k] = (char)seq[k]; out[QL + 1u + k] = (char)qual[k]; }
+		} else {
+			for (uint32_t k = lane; k < QL; k += 64) { out[k] = (char)A.comp[seq[QL - 1u - k]]; out[QL + 1u + k] = (char)qual[QL - 1u - k]; }
+		}
+		if (lane == 0) { out[QL] = '\t'; out[2u * QL + 1u] = '\n'; }
 		__builtin_amdgcn_wave_barrier();
-	}
-	if (PASS == 0 && lane == 0) {
-		if (c_acc) atomicAdd(&A.hdr->cnt[0], (unsigned long long)c_acc);
-		if (c_rej) atomicAdd(&A.hdr->cnt[1], (unsigned long long)c_rej);
-		if (c_no) atomicAdd(&A.hdr->cnt[2], (unsigned long long)c_no);
-		if (c_uns) atomicAdd(&A.hdr->cnt[3], (unsigned long long)c_uns);
 	}
 }
 
@@ -544,11 +660,16 @@ int fetch_sam(urmapx_text *T, char *sam, size_t sam_cap, urmapx_text_report *rep
 	if ((rc = T->sam.ensure((size_t)rep->sam_bytes + 64))) return rc;
 	SamArgs A = T->pending_args;
 	A.sam = (char *)T->sam.p;
-	hipLaunchKernelGGL(sam_kernel<1>, dim3(GRID), dim3(SAM_WAVES * 64), 0, st, A);
+	hipLaunchKernelGGL(sam_kernel, dim3(GRID), dim3(SAM_WAVES * 64), 0, st, A);
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipMemcpyAsync(sam, T->sam.p, rep->sam_bytes, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(T->h_hdr, T->hdr.p, sizeof(TextHdr), hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipStreamSynchronize(st));
 	T->pending = false;
+	if (T->h_hdr[0].flags & 32u) {  // the two record kernels disagreed on a length: the text is not trusted
+		rep->reason = URMAPX_TEXT_INTERNAL;
+		rep->records = 0;
+	}
 	return URMAPX_OK;
 }
 
@@ -614,7 +735,7 @@ int map_text(urmapx_text *T, const char *fastq1, size_t nbytes1, const char *fas
 	A.results = T->results.p; A.ops = T->pathops.p; A.tnames = T->tnames.p;
 	A.tname_offs = T->tname_offs.p; A.comp = T->comp.p; A.seq_count = T->seq_count; A.minq = minq; A.hdr = hdr;
 	A.lens = T->lens.p; A.rec_offs = T->rec_offs.p; A.sam = nullptr;
-	hipLaunchKernelGGL(sam_kernel<0>, dim3(GRID), dim3(SAM_WAVES * 64), 0, st, A);
+	hipLaunchKernelGGL(sam_len_kernel, dim3(GRID), dim3(256), 0, st, A);
 	hipLaunchKernelGGL(scan_sums_kernel, dim3(GRID), dim3(SC_THREADS), 0, st, T->lens.p, &hdr->n_reads, T->sums.p);
 	hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(1024), 0, st, T->sums.p, &hdr->n_reads, (uint32_t)SC_TILE, 0u, &hdr->sam_total);
 	hipLaunchKernelGGL(scan_apply_kernel<uint32_t>, dim3(GRID), dim3(SC_THREADS), 0, st, T->lens.p, &hdr->n_reads, T->sums.p, T->rec_offs.p);
