@@ -427,7 +427,7 @@ __device__ uint32_t head_length(const SamArgs &A, const urmapx_result &r, const 
 		else if (F.flags & 0x80u) flags |= 0x80u;
 		if (F.flags & 0x08u) flags |= 0x08u;
 		else if (F.flags & 0x20u) flags |= 0x20u;
-		return 1u + dev_digits(flags) + 17u;
+		return 1u + dev_digits(flags) + (uint32_t)(sizeof("\t*\t0\t0\t*\t*\t0\t0\t") - 1);
 	}
 	if (r.seq_index >= A.seq_count) return 0;
 	const uint32_t t0 = A.tname_offs[r.seq_index], tl = A.tname_offs[r.seq_index + 1] - t0;
