@@ -8,6 +8,8 @@
 #include <cstdio>
 #include <cstring>
 #include <vector>
+#include <thread>
+#include <atomic>
 #include <cstdlib>
 using namespace std;
 static double now(){return chrono::duration<double>(chrono::steady_clock::now().time_since_epoch()).count();}
@@ -24,6 +26,11 @@ int main(int argc,char**argv){
     } else if(mode==1){ // parallel pwrite
       #pragma omp parallel for num_threads(T) schedule(static,1)
       for(int t=0;t<T;++t){ size_t lo=chunk*t/T,hi=chunk*(t+1)/T; pwrite(fd,buf.data()+lo,hi-lo,off+lo);}
+    } else if(mode==3){ // a second thread allocates the file's pages ahead (fallocate in 32 MB pieces), this one writes
+      static std::thread *pre=nullptr; static std::atomic<uint64_t> ahead{0};
+      if(!pre){ uint64_t total=(uint64_t)chunk*nchunks; pre=new std::thread([=]{ for(uint64_t o=0;o<total;o+=(32u<<20)){ fallocate(fd,0,o,32u<<20); ahead.store(o+(32u<<20)); } }); }
+      pwrite(fd,buf.data(),chunk,off);
+      if(c==nchunks-1){ pre->join(); }
     } else { // mmap
       ftruncate(fd,off+chunk);
       uint64_t a=off&~4095ull; size_t len=off+chunk-a;
