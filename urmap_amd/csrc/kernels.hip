@@ -239,6 +239,13 @@ __device__ __noinline__ int hsp_overflow_add(uint2 *ovf, int n, int cap, uint32_
 	return 1;
 }
 
+#ifndef URX_SE_HITW1
+#define URX_SE_HITW1 1
+#endif
+// hit-list words (64 hits each) of the first pass.  5 of 1 M reads of a repeat-rich genome end with more than 64 hits and
+// are mapped again by a launch of their own (0.9 ms); with two words they stay in the first pass, which then runs 1.6 ms
+// longer (such a read is its tail): one word it stays.  The pair kernel keeps two (kernels_pe.hip: -1.5 ms).
+static constexpr int SE_HITW1 = URX_SE_HITW1;
 template <int NCH, bool OVF>
 struct SearchWave {
 	static constexpr int QMAX = 64 * NCH;
@@ -270,7 +277,7 @@ struct SearchWave {
 	WideScratch ws;
 	// hits: entry k lives on lane k & 63 of word k >> 6.  One word (64 hits) in the first-pass kernel; the second pass
 	// (reads that outgrew a list) has HITW words = 512 hits.
-	static constexpr int HITW = OVF ? 8 : 1;
+	static constexpr int HITW = OVF ? 8 : SE_HITW1;
 	uint32_t hit_db[HITW];
 	// hits per word: 64 (2^6).  The test aid that lowers the first pass's caps also lowers this to 16 in the second pass,
 	// so that a fixture with a few dozen hits per read runs through several words.
@@ -796,7 +803,7 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 		S.ws.carve(sc + (size_t)SW::NSEG * ROW_CAP * 64 * 4, SW::QMAX, SW::WIDE_LB);
 		S.hsp_ovf = hsp_ovf_base + (size_t)blockIdx.x * (HSP_TOTAL_CAP - HSP_CAP);
 		S.hsp_lds = (hsp_lds_cap >= 64 && hsp_lds_cap <= HSP_CAP) ? (hsp_lds_cap & ~63) : HSP_CAP;  // multiple of 64
-		S.hit_cap = (hsp_lds_cap >= 64 && hsp_lds_cap <= HSP_CAP) ? S.hsp_lds / 4 : 64;
+		S.hit_cap = (hsp_lds_cap >= 64 && hsp_lds_cap <= HSP_CAP) ? S.hsp_lds / 4 : 64 * SE_HITW1;
 		S.hit_wsh = (hsp_lds_cap >= 64 && hsp_lds_cap <= HSP_CAP) ? 4 : 6;
 	}
 
@@ -1280,7 +1287,7 @@ __global__ __launch_bounds__(64) void finalize_se_kernel(DevIndex X, urmapx_para
 	S.W = (int)X.W;
 	S.top = top; S.cand = cand;
 	S.hsp_lds = (hsp_lds_cap >= 64 && hsp_lds_cap <= HSP_CAP) ? (hsp_lds_cap & ~63) : HSP_CAP;
-	S.hit_cap = (hsp_lds_cap >= 64 && hsp_lds_cap <= HSP_CAP) ? S.hsp_lds / 4 : 64;
+	S.hit_cap = (hsp_lds_cap >= 64 && hsp_lds_cap <= HSP_CAP) ? S.hsp_lds / 4 : 64 * SE_HITW1;
 	S.hit_wsh = (hsp_lds_cap >= 64 && hsp_lds_cap <= HSP_CAP) ? 4 : 6;
 	const uint32_t parked = dp.counters[1] < dp.fin_cap ? dp.counters[1] : dp.fin_cap;
 	// parked reads go to blocks round-robin: the costly ones (repeat families: hundreds of jobs) were parked last, next

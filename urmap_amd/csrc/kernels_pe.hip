@@ -19,6 +19,7 @@
 namespace urx {
 
 static constexpr int PE_HIT_CAP = 64;
+static constexpr int PE_HITW1 = 2;     // hit-list words (64 hits each) of the first pass: 19 of 1 M reads end with 65..83 hits, none with more than 128
 static constexpr int PE_HSP_CAP = 128;       // HSPs of a mate held in LDS
 static constexpr int PE_HSP_OVF_CAP = 8064;  // per mate, in global scratch
 static constexpr int PE_OVF_BLOCKS = 1024;   // grid of the second pass (the costliest pairs of a batch)
@@ -31,7 +32,7 @@ static constexpr int MAX_TL = 1000;
 
 // per-block global scratch: hit paths of both mates, the wide-band Viterbi scratch, then the pending rows
 __host__ __device__ inline size_t pe_rowstore_offset(int qmax) {
-	size_t b = (size_t)2 * PE_HIT_CAP * URMAPX_MAX_PATH_OPS * 2 + WideScratch::bytes(qmax, PE_SCAN_SEG + 2 * qmax + 64);
+	size_t b = (size_t)2 * PE_HIT_CAP * PE_HITW1 * URMAPX_MAX_PATH_OPS * 2 + WideScratch::bytes(qmax, PE_SCAN_SEG + 2 * qmax + 64);
 	return (b + 15) & ~(size_t)15;
 }
 
@@ -60,7 +61,7 @@ struct Mate {
 	// lists
 	// hits: entry k lives on lane k & 63 of word k >> 6 (one word = 64 hits in the first-pass kernel, HITW words in the
 	// second pass over pairs that outgrew a list)
-	static constexpr int HITW = OVF ? 4 : 1;
+	static constexpr int HITW = OVF ? 4 : PE_HITW1;
 	uint32_t hit_db[HITW];
 	uint32_t hit_sp[HITW];  // score << 1 | plus
 	int hit_cap;            // first pass: PE_HIT_CAP (a test aid lowers it)
@@ -772,8 +773,8 @@ __global__ __launch_bounds__(64) void search_pe_kernel(DevIndex X, urmapx_params
 		m[a].hit_nops = hit_nops[a];
 		m[a].hit_paths = OVF ? reinterpret_cast<urmapx_path_op *>(hsp_ovf_base + (size_t)hsp_area_blocks * 2 * PE_HSP_OVF_CAP) +
 		                           ((size_t)blockIdx.x * 2 + a) * PE_HIT_CAP * M::HITW * URMAPX_MAX_PATH_OPS
-		                     : reinterpret_cast<urmapx_path_op *>(sc) + (size_t)a * PE_HIT_CAP * URMAPX_MAX_PATH_OPS;
-		m[a].hit_cap = (hsp_lds_cap >= 64 && hsp_lds_cap <= PE_HSP_CAP) ? (hsp_lds_cap & ~63) / 4 : PE_HIT_CAP;
+		                     : reinterpret_cast<urmapx_path_op *>(sc) + (size_t)a * PE_HIT_CAP * PE_HITW1 * URMAPX_MAX_PATH_OPS;
+		m[a].hit_cap = (hsp_lds_cap >= 64 && hsp_lds_cap <= PE_HSP_CAP) ? (hsp_lds_cap & ~63) / 4 : PE_HIT_CAP * PE_HITW1;
 		m[a].hit_wsh = (hsp_lds_cap >= 64 && hsp_lds_cap <= PE_HSP_CAP) ? 4 : 6;
 		m[a].hsp_db = hsp_db[a]; m[a].hsp_ql = hsp_ql[a]; m[a].hsp_sf = hsp_sf[a];
 		m[a].pend[0] = pend[2 * a]; m[a].pend[1] = pend[2 * a + 1];
@@ -782,7 +783,7 @@ __global__ __launch_bounds__(64) void search_pe_kernel(DevIndex X, urmapx_params
 		m[a].hsp_ovf = hsp_ovf_base + ((size_t)blockIdx.x * 2 + a) * PE_HSP_OVF_CAP;
 		m[a].dbg_cut = dbg_stop;
 		m[a].rowstore = reinterpret_cast<uint32_t *>(sc + pe_rowstore_offset(QMAX));
-		m[a].ws.carve(sc + (size_t)2 * PE_HIT_CAP * URMAPX_MAX_PATH_OPS * 2, QMAX, PE_SCAN_SEG + 2 * QMAX + 64);
+		m[a].ws.carve(sc + (size_t)2 * PE_HIT_CAP * PE_HITW1 * URMAPX_MAX_PATH_OPS * 2, QMAX, PE_SCAN_SEG + 2 * QMAX + 64);
 	}
 
 	// pairs are handed out by a ticket counter (heavy-tailed cost per pair: the rescue DP), PE_TICKET_CHUNK per ticket
