@@ -421,3 +421,19 @@ def test_cli_map2_mate_file_with_much_longer_records(small_case, tmp_path, batch
     assert ra.returncode == 0 and rb.returncode == 0, (ra.stderr.decode()[-800:], rb.stderr.decode()[-800:])
     assert _sam_body(a) == _sam_body(b)
     assert len(_sam_body(a)) > 40000
+
+
+@pytest.mark.parametrize("host_text", [False, True])
+def test_cli_samout_to_a_pipe(golden_ufi, tmp_path, host_text):
+    """`-samout /dev/stdout | cat`: the SAM file is a pipe; records go out in order with write() (the reference writes its
+    SAM through stdio, so pipes work there: outfiles.cpp:7-12)."""
+    import subprocess
+    env = dict(os.environ)
+    env.pop("URMAPX_HOST_TEXT", None)
+    if host_text:
+        env["URMAPX_HOST_TEXT"] = "1"
+    out = os.path.join(tmp_path, "piped.sam")
+    cmd = f"'{EXE}' -map '{os.path.join(GOLD, 'se150.fq')}' -ufi '{golden_ufi}' -samout /dev/stdout -batch 50 2> '{tmp_path}/err.txt' | cat > '{out}'"
+    r = subprocess.run(["bash", "-c", "set -o pipefail; " + cmd], timeout=300, env=env)
+    assert r.returncode == 0, open(os.path.join(tmp_path, "err.txt")).read()[-800:]
+    assert _sam_body(out) == [l for l in open(os.path.join(GOLD, "se150.sam"), "rb").read().split(b"\n") if l]

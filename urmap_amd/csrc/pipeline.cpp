@@ -161,14 +161,19 @@ class FileSink {
 public:
 	~FileSink() { if (fd_ >= 0) ::close(fd_); }
 	bool open(const char *path) {
-		fd_ = ::open(path, O_RDWR | O_CREAT | O_TRUNC, 0644);
+		const char *mode = getenv("URMAPX_SAM_WRITE");  // "pwrite" (default) | "mmap"
+		const bool want_map = mode && !strcmp(mode, "mmap");
+		fd_ = ::open(path, (want_map ? O_RDWR : O_WRONLY) | O_CREAT | O_TRUNC, 0644);
+		if (fd_ < 0 && want_map) fd_ = ::open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
 		if (fd_ < 0) return false;
 		struct stat st;
-		const char *mode = getenv("URMAPX_SAM_WRITE");  // "pwrite" (default) | "mmap"
-		use_map_ = fstat(fd_, &st) == 0 && S_ISREG(st.st_mode) && mode && !strcmp(mode, "mmap");
+		const bool regular = fstat(fd_, &st) == 0 && S_ISREG(st.st_mode);
+		sequential_ = !regular;  // a pipe, a FIFO, a terminal (-samout /dev/stdout | ...): bytes go out in order with write()
+		use_map_ = regular && want_map;
 		return true;
 	}
 	bool is_open() const { return fd_ >= 0; }
+	bool seekable() const { return !sequential_; }
 	// makes the file at least `end` bytes long (pieces below `end` can then be written from several threads at once)
 	bool reserve(uint64_t end) {
 		if (!use_map_ || end <= size_) return true;
@@ -179,6 +184,17 @@ public:
 	bool write_at(const char *p, size_t n, uint64_t off, int threads) {
 		if (n == 0) return true;
 		if (threads < 1) threads = 1;
+		if (sequential_) {  // the callers hand pieces over in file order when seekable() is false
+			if (off != size_) return false;
+			size_t done = 0;
+			while (done < n) {
+				ssize_t w = ::write(fd_, p + done, n - done);
+				if (w <= 0) return false;
+				done += (size_t)w;
+			}
+			size_ = off + n;
+			return true;
+		}
 		if (use_map_) {
 			if (off + n > size_ && ftruncate(fd_, (off_t)(off + n)) != 0) use_map_ = false;
 			else {
@@ -215,7 +231,7 @@ public:
 	}
 	bool finish(uint64_t length) {
 		if (fd_ < 0) return true;
-		bool ok = size_ == length || ftruncate(fd_, (off_t)length) == 0;
+		bool ok = sequential_ || size_ == length || ftruncate(fd_, (off_t)length) == 0;
 		ok = ::close(fd_) == 0 && ok;
 		fd_ = -1;
 		return ok;
@@ -223,6 +239,7 @@ public:
 
 private:
 	int fd_ = -1;
+	bool sequential_ = false;
 	std::atomic<bool> use_map_{false};
 	std::atomic<uint64_t> size_{0};
 };
@@ -738,10 +755,17 @@ extern "C" int urmapx_map_files(urmapx_index *I, const urmapx_map_options *opt, 
 			const auto tw0 = now();
 			if (!fail.set.load()) {
 				if (!sink.reserve(x->at[(size_t)host_threads])) fail.raise(URMAPX_E_IO, std::string("Error writing ") + samout);
+				if (!sink.seekable()) {  // a pipe: the pieces one after the other
+					for (int t = 0; t < host_threads; ++t) {
+						const std::string &out = x->outs[(size_t)t];
+						if (!sink.write_at(out.data(), out.size(), x->at[(size_t)t], 1)) { fail.raise(URMAPX_E_IO, std::string("Error writing ") + samout); break; }
+					}
+				} else {
 #pragma omp parallel for schedule(static, 1) num_threads(host_threads)
 				for (int t = 0; t < host_threads; ++t) {
 					const std::string &out = x->outs[(size_t)t];
 					if (!sink.write_at(out.data(), out.size(), x->at[(size_t)t], 1)) fail.raise(URMAPX_E_IO, std::string("Error writing ") + samout);
+				}
 				}
 			}
 			t_write += secs(tw0, now());
