@@ -568,6 +568,7 @@ def run_reference(ref_bin, oi, d, fq, fq_head, n_reads, n_head, cores, product_s
 
 
 E2E_STREAMS = int(os.environ.get("URMAP_BENCH_E2E_STREAMS", 2))  # mapping contexts (lanes) of the file-to-file runs
+E2E_BATCH = int(os.environ.get("URMAP_BENCH_E2E_BATCH", 0))      # reads per chunk (0: the library's default, 262144)
 
 
 def run_e2e(torch, api, oi, index, device, d_seq, seq_lengths, seq_offsets, L, sub, indel, n_reads, cores, ref_bin=None):
@@ -590,7 +591,7 @@ def run_e2e(torch, api, oi, index, device, d_seq, seq_lengths, seq_offsets, L, s
         del reads
         runs = []
         for _ in range(2):  # the second run has its buffers and the page cache warm; both are reported
-            rep = api.map_files(index, fq, samout=sam, first_gpu=device.index, gpus=1, streams=E2E_STREAMS, cmdline="bench.py e2e")
+            rep = api.map_files(index, fq, samout=sam, first_gpu=device.index, gpus=1, streams=E2E_STREAMS, batch=E2E_BATCH, cmdline="bench.py e2e")
             runs.append(rep)
         rep = runs[-1]
         oi.map_file_se(fq_head, sam_o, threads=cores)
@@ -640,7 +641,7 @@ def run_e2e_pairs(torch, api, oi, index, device, d_seq, seq_lengths, seq_offsets
     write_fastq_fixed(h1, np.ascontiguousarray(pairs[:n_chk, 0, :]).reshape(-1), n_chk, L)
     write_fastq_fixed(h2, np.ascontiguousarray(pairs[:n_chk, 1, :]).reshape(-1), n_chk, L)
     del pairs
-    runs = [api.map_files(index, fq1, fq2, samout=sam, first_gpu=device.index, gpus=1, streams=E2E_STREAMS, cmdline="bench.py e2e pairs") for _ in range(2)]
+    runs = [api.map_files(index, fq1, fq2, samout=sam, first_gpu=device.index, gpus=1, streams=E2E_STREAMS, batch=E2E_BATCH, cmdline="bench.py e2e pairs") for _ in range(2)]
     rep = runs[-1]
     oi.map_file_pe(h1, h2, sam_o, threads=cores)
     want = [l for l in open(sam_o, "rb").read().split(b"\n") if l and not l.startswith(b"@")]
