@@ -317,7 +317,7 @@ struct TextJob {
 
 // first record start at or after `from`: a line that begins with '@' whose line after next begins with '+'.  A wrong
 // guess cannot pass: the chunk in front would then hold a line count that is not a multiple of four, which the device
-// parser reports.  Returns 0 if the window [from, from + 8 MB) shows none.
+// parser reports.  Returns 0 if the window [from, from + 4 MB) shows none.
 uint64_t find_record_start(int fd, uint64_t from, uint64_t fsize) {
 	std::vector<char> w;
 	for (size_t win = 1u << 16; win <= (8u << 20); win *= 4) {
