@@ -344,4 +344,110 @@ __device__ __forceinline__ void lane_mismatch_mask(const uint8_t *__restrict__ s
 	}
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// packed copy of m_SeqData for ExtendPen's byte compares (extendpen.cpp:29-78): four bit planes per 32 bases
+// ------------------------------------------------------------------------------------------------
+// Every byte gets a 4-bit code that is injective on the bytes a genome and a read are made of (ACGTN in either case,
+// the '-' pad between sequences); all other bytes share one code on the reference side (15) and another on the read
+// side (14).  For a read without "other" bytes -- checked once per read -- code equality IS byte equality: a coded read
+// byte never equals a reference byte outside the list, whatever that byte is.  Reads with other bytes (IUPAC codes
+// beyond N, 'u') compare ASCII windows as before (lane_mismatch_mask).
+// Layout: block b = bases 32b .. 32b+31 = one uint4 {plane 0, 1, 2, 3}, bit i of plane k = bit k of the code of base
+// 32b+i: a read's window is 16 bytes per 32 bases, contiguous, and the mismatch bits of 32 positions are
+// (t0^q0)|(t1^q1)|(t2^q2)|(t3^q3) after a funnel shift of each plane.
+static constexpr uint32_t SEQ_CODE_QOTHER = 14u, SEQ_CODE_TOTHER = 15u;
+__device__ __forceinline__ uint32_t seq_code(uint32_t c, uint32_t other) {
+	const uint32_t u = c & 0xDFu;
+	uint32_t k = u == 'A' ? 0u : u == 'C' ? 1u : u == 'G' ? 2u : u == 'T' ? 3u : u == 'N' ? 4u : 16u;
+	k += (c & 0x20u) ? 5u : 0u;  // lower case: 5..9
+	return k < 10u ? k : (c == '-' ? 10u : other);
+}
+
+// Mismatch bit vector of a whole read against the packed reference window starting at base dblo, computed by ONE lane:
+// bit p = (query[p] != seq[dblo+p]), p < QL.  qpl = the query strand's planes in LDS (block j = positions 32j..32j+31).
+template <int NCH>
+__device__ __forceinline__ void lane_mismatch_planes(const uint4 *__restrict__ seqp, uint32_t dblo, const uint4 *qpl, int QL,
+                                                     uint64_t (&mm)[NCH]) {
+	const uint32_t sh = dblo & 31u;
+	const uint4 *p = seqp + (dblo >> 5);
+	uint4 t[2 * NCH + 1];
+#pragma unroll
+	for (int j = 0; j <= 2 * NCH; ++j)
+		if (j == 0 || 32 * (j - 1) < QL) t[j] = p[j];  // wave-uniform: the whole wavefront works on one read
+#pragma unroll
+	for (int c = 0; c < NCH; ++c) {
+		uint32_t w2[2] = {0u, 0u};
+#pragma unroll
+		for (int h = 0; h < 2; ++h) {
+			const int j = 2 * c + h;
+			if (32 * j < QL) {
+				const uint4 q = qpl[j];
+				const uint32_t a0 = __builtin_amdgcn_alignbit(t[j + 1].x, t[j].x, sh);
+				const uint32_t a1 = __builtin_amdgcn_alignbit(t[j + 1].y, t[j].y, sh);
+				const uint32_t a2 = __builtin_amdgcn_alignbit(t[j + 1].z, t[j].z, sh);
+				const uint32_t a3 = __builtin_amdgcn_alignbit(t[j + 1].w, t[j].w, sh);
+				w2[h] = (a0 ^ q.x) | (a1 ^ q.y) | (a2 ^ q.z) | (a3 ^ q.w);
+			}
+		}
+		uint64_t w = ((uint64_t)w2[1] << 32) | w2[0];
+		const int rem = QL - 64 * c;
+		if (rem <= 0) w = 0;
+		else if (rem < 64) w &= ((1ull << rem) - 1ull);
+		mm[c] = w;
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// LDS-DMA: a gather that lands in LDS without passing through registers
+// ------------------------------------------------------------------------------------------------
+// global_load_lds_dword: every lane names its own source dword, lane l's data lands at lds_dst + 4*l (lds_dst = a
+// wave-uniform LDS byte address in M0).  The statement is not counted by the compiler's s_waitcnt bookkeeping: the
+// caller waits with wait_vm0() before it reads the destination.  Loads return in order, so any wait the compiler places
+// for a younger load of its own also covers these.
+__device__ __forceinline__ void glds_dword(const void *gsrc, uint32_t lds_dst) {
+	unsigned keep;
+	asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+	             : "=&s"(keep)
+	             : "v"(gsrc), "s"(lds_dst)
+	             : "memory");
+}
+__device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+template <class T>
+__device__ __forceinline__ uint32_t lds_addr(const T *p) {  // the LDS aperture is 4 GB aligned: the low half of a flat address is the LDS offset
+	return uni((uint32_t)(uintptr_t)p);
+}
+// 16 zero bytes: what lanes without a k-mer gather instead of a slot (tally 0 = TALLY_FREE)
+static __device__ uint32_t g_zero16[4];
+
+// The slots of the k-mers that start in one 64-position chunk of a read, both strands (State1::SetSlotsVec,
+// state1.cpp:396-438, with murmur64 / WordToSlot, ufindex.h:50-65): lane l cuts the W letters of the k-mer starting at
+// position 64c + l out of the read's ballot planes (bit p of lo / hi = letter bits of base p, inv / invm = base p cannot
+// be part of a plus- / minus-strand k-mer), c0 = the chunk's words, c1 = the next chunk's.  sp = plus-strand slot at that
+// position; sm = slot of the reverse-complement k-mer over the same bases (minus-strand position nwords-1-p).
+__device__ __forceinline__ void kmer_slots(const DevIndex &X, uint64_t lo0, uint64_t hi0, uint64_t inv0, uint64_t invm0, uint64_t lo1,
+                                           uint64_t hi1, uint64_t inv1, uint64_t invm1, int lane, uint32_t p, uint32_t nwords,
+                                           uint64_t &sp, uint64_t &sm, bool &vp, bool &vm) {
+	const uint32_t W = X.W;
+	const uint64_t wmask = (W >= 32) ? 0xFFFFFFFFull : ((1ull << W) - 1ull);
+	uint64_t flo = lo0 >> lane, fhi = hi0 >> lane, finv = inv0 >> lane, finvm = invm0 >> lane;
+	if (lane) {
+		flo |= lo1 << (64 - lane);
+		fhi |= hi1 << (64 - lane);
+		finv |= inv1 << (64 - lane);
+		finvm |= invm1 << (64 - lane);
+	}
+	flo &= wmask; fhi &= wmask; finv &= wmask; finvm &= wmask;
+	vp = p < nwords && finv == 0;
+	vm = p < nwords && finvm == 0;
+	// plus strand word at query position p: first base is the most significant letter
+	const uint64_t rlo = __brevll(flo) >> (64 - W), rhi = __brevll(fhi) >> (64 - W);
+	const uint64_t wp = spread32(rlo) | (spread32(rhi) << 1);
+	// reverse-complement word covering the same bases: letters complemented, order already reversed
+	const uint64_t wm = spread32(~flo & wmask) | (spread32(~fhi & wmask) << 1);
+	sp = mod_slots(murmur64(wp & X.shiftMask), X.slotCount, X.slotMagic);
+	sm = mod_slots(murmur64(wm & X.shiftMask), X.slotCount, X.slotMagic);
+}
+
 }  // namespace urx

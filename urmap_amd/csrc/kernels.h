@@ -11,6 +11,7 @@ namespace urx {
 struct DevIndex {
 	const uint8_t *blob;        // 5*slotCount bytes (+8 pad): {tally u8, pos u32 LE} per slot
 	const uint8_t *seq;         // seqDataSize ASCII bytes (+4096 zero pad)
+	const uint4 *seqp;          // the same bytes as 4-bit codes in bit planes, one uint4 per 32 bases (dev_common.h); device-built
 	uint64_t slotCount;
 	uint64_t slotMagic;         // floor(2^64 / slotCount): Barrett reciprocal for h % slotCount
 	uint64_t shiftMask;
@@ -111,9 +112,15 @@ size_t search_pe_scratch_tail(int blocks);
 int search_block_count(uint32_t max_read_len, int device);
 size_t viterbi_batch_scratch_stride();
 
+// single-end batch: the search kernel hashes and probes each read's k-mers itself (the slots of the next read are
+// gathered straight into LDS while the current one is searched); no probe launch, no probe arrays
 hipError_t launch_search_se(const DevIndex &X, const urmapx_params &P, const uint8_t *d_bases, const uint64_t *d_offs,
-                            uint32_t n, uint32_t max_read_len, ProbeOut probe, urmapx_result *d_results,
+                            uint32_t n, uint32_t max_read_len, urmapx_result *d_results,
                             urmapx_path_op *d_path_ops, uint32_t *d_path_used, const SearchWork &wk, hipStream_t s);
+
+// packed copy of the sequence store (4 bit planes per 32 bases): blocks = packed_seq_blocks(seqDataSize) uint4's
+size_t packed_seq_blocks(uint32_t seq_data_size);
+hipError_t launch_pack_seq(const uint8_t *d_seq, uint32_t seq_data_size, uint4 *d_out, hipStream_t s);
 
 // paired-end (kernels_pe.hip): reads 2i and 2i+1 of the batch are the two mates of pair i
 size_t search_pe_scratch_stride(uint32_t max_read_len);

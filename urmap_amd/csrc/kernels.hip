@@ -37,31 +37,13 @@ __device__ __forceinline__ void probe_chunks(const DevIndex &X, const uint64_t (
                                              const uint64_t (&inv)[NCH + 1], const uint64_t (&invm)[NCH + 1], int lane,
                                              uint32_t QL, uint32_t nwords, uint64_t base2, const ProbeOut &out) {
 	const uint32_t W = X.W;
-	const uint64_t wmask = (W >= 32) ? 0xFFFFFFFFull : ((1ull << W) - 1ull);
 	uint64_t sp[NC], sm[NC];
 	uint32_t rp[NC][2], rm[NC][2];
 	bool vp[NC], vm[NC];
 #pragma unroll
-	for (int c = 0; c < NC; ++c) {
-		const uint32_t p = 64u * (C0 + c) + lane;
-		uint64_t flo = lo[C0 + c] >> lane, fhi = hi[C0 + c] >> lane, finv = inv[C0 + c] >> lane, finvm = invm[C0 + c] >> lane;
-		if (lane) {
-			flo |= lo[C0 + c + 1] << (64 - lane);
-			fhi |= hi[C0 + c + 1] << (64 - lane);
-			finv |= inv[C0 + c + 1] << (64 - lane);
-			finvm |= invm[C0 + c + 1] << (64 - lane);
-		}
-		flo &= wmask; fhi &= wmask; finv &= wmask; finvm &= wmask;
-		vp[c] = p < nwords && finv == 0;
-		vm[c] = p < nwords && finvm == 0;
-		// plus strand word at query position p: first base is the most significant letter
-		const uint64_t rlo = __brevll(flo) >> (64 - W), rhi = __brevll(fhi) >> (64 - W);
-		const uint64_t wp = spread32(rlo) | (spread32(rhi) << 1);
-		// reverse-complement word covering the same bases: letters complemented, order already reversed
-		const uint64_t wm = spread32(~flo & wmask) | (spread32(~fhi & wmask) << 1);
-		sp[c] = mod_slots(murmur64(wp & X.shiftMask), X.slotCount, X.slotMagic);
-		sm[c] = mod_slots(murmur64(wm & X.shiftMask), X.slotCount, X.slotMagic);
-	}
+	for (int c = 0; c < NC; ++c)
+		kmer_slots(X, lo[C0 + c], hi[C0 + c], inv[C0 + c], invm[C0 + c], lo[C0 + c + 1], hi[C0 + c + 1], inv[C0 + c + 1],
+		           invm[C0 + c + 1], lane, 64u * (C0 + c) + lane, nwords, sp[c], sm[c], vp[c], vm[c]);
 #pragma unroll
 	for (int c = 0; c < NC; ++c) {  // lanes without a valid word fetch slot 0 (one cached sector) and drop it
 		const uint64_t ap = vp[c] ? 5ull * sp[c] : 0ull, am = vm[c] ? 5ull * sm[c] : 0ull;
@@ -208,11 +190,14 @@ static constexpr int HSP_TOTAL_CAP = 8192;  // beyond that: in the block's globa
 static constexpr int TICKET_CHUNK = URX_TICKET_CHUNK;
 static constexpr int ROW_CAP = 32;  // UFIndex m_MaxIx of every index this build accepts
 
-// per-block global scratch: chain rows, the wide-band DP trace, then the HSP overflow list
-__host__ __device__ inline size_t hsp_ovf_offset(int nch) {
+// per-block global scratch of the search kernel: chain rows, the wide-band DP's rows and trace, the banded DP's trace cells
+__host__ __device__ inline size_t search_tb_offset(int nch) {
 	const int qmax = 64 * nch;
 	size_t b = (size_t)2 * nch * ROW_CAP * 64 * 4 + WideScratch::bytes(qmax, qmax + 64);
-	return (b + 15) & ~(size_t)15;
+	return (b + 255) & ~(size_t)255;
+}
+__host__ __device__ inline size_t search_scratch_bytes(int nch) {
+	return search_tb_offset(nch) + (size_t)((64 * nch - 24) / 8 + 2) * 64 * 4;
 }
 
 // AddHSPX over the part of a read's HSP list that lives in global scratch (reads in high-copy repeats only).  Kept out
@@ -662,31 +647,88 @@ struct SearchWave {
 		return mapq;
 	}
 
+	// ---- this read's k-mer slots, as the LDS-DMA gathers of probe_issue left them ----
+	// entry e = strand * NCH*64 + i, i = the PLUS-strand position of the k-mer's bases: the minus-strand k-mer at minus
+	// position q covers the same bases as the plus-strand k-mer at nwords-1-q.  pr_lo / pr_hi = the two aligned dwords
+	// around the 5-byte slot, pr_sl = the low half of the slot number (its two low bits say where the slot starts in
+	// them: 5*slot = slot mod 4), pr_hb = bit 32 of the slot numbers of a chunk as one ballot word per [strand][chunk].
+	// A position without a k-mer gathered zeros: tally 0 = TALLY_FREE.
+	uint32_t *pr_lo, *pr_hi, *pr_sl;
+	uint64_t *pr_hb;
+	__device__ __forceinline__ void probe_get(int s, int q, uint32_t &tally, uint32_t &pos) const {
+		const int e = s * NCH * 64 + (s ? nwords - 1 - q : q);
+		const uint32_t lo = pr_lo[e], hi = pr_hi[e], sl = pr_sl[e];
+		const uint64_t v = (((uint64_t)hi << 32) | lo) >> (8u * (sl & 3u));
+		tally = (uint32_t)(v & 0xFFu);
+		pos = (uint32_t)(v >> 8);
+	}
+
+	// State1::SetSlotsVec + GetBlob for the NEXT read while this one is searched: nq = that read's bytes in LDS, QLn its
+	// length.  Per 64-position chunk: letter ballots, the 2 x 64 slot numbers (kmer_slots), then four LDS-DMA gathers --
+	// the two dwords of every slot go from the 27 GB table straight into pr_lo / pr_hi, no register holds them, and the
+	// wavefront goes on with the current read.  The caller has made sure nobody still reads the pr_* arrays.
+	__device__ __forceinline__ void probe_issue(const uint8_t *nq, int QLn) {
+		const uint32_t nwn = (uint32_t)(QLn - (W - 1));
+		auto planes = [&](int c, uint64_t &lo, uint64_t &hi, uint64_t &inv, uint64_t &invm) {
+			const int p = 64 * c + lane;
+			const uint32_t ch = p < QLn ? nq[p] : 0u;
+			const uint32_t L = p < QLn ? letter_of(ch) : 4u;
+			lo = __ballot(L & 1u);
+			hi = __ballot((L >> 1) & 1u);
+			inv = __ballot(L > 3u);
+			invm = __ballot(L > 3u || ch == 'u');  // lower-case 'u' complements to '?' (alpha.cpp:3005)
+		};
+		uint64_t lo0, hi0, inv0, invm0;
+		planes(0, lo0, hi0, inv0, invm0);
+		wait_lgkm0();  // every earlier LDS read of the pr_* arrays has returned
+#pragma unroll
+		for (int c = 0; c < NCH; ++c) {
+			if (64u * c < nwn) {  // wave-uniform: chunks that hold a k-mer start
+				uint64_t lo1 = 0, hi1 = 0, inv1 = ~0ull, invm1 = ~0ull;
+				if (c + 1 < NCH && 64 * (c + 1) < QLn) planes(c + 1, lo1, hi1, inv1, invm1);
+				uint64_t sp, sm;
+				bool vp, vm;
+				kmer_slots(X, lo0, hi0, inv0, invm0, lo1, hi1, inv1, invm1, lane, 64u * c + lane, nwn, sp, sm, vp, vm);
+				pr_sl[c * 64 + lane] = vp ? (uint32_t)sp : 0u;
+				pr_sl[(NCH + c) * 64 + lane] = vm ? (uint32_t)sm : 0u;
+				const uint64_t hbp = __ballot(vp && ((sp >> 32) & 1ull)), hbm = __ballot(vm && ((sm >> 32) & 1ull));
+				if (lane == 0) { pr_hb[c] = hbp; pr_hb[NCH + c] = hbm; }
+				const uint8_t *zero = reinterpret_cast<const uint8_t *>(g_zero16);
+				const uint8_t *ap = vp ? gblob + ((5ull * sp) & ~3ull) : zero;
+				const uint8_t *am = vm ? gblob + ((5ull * sm) & ~3ull) : zero;
+				glds_dword(ap, lds_addr(pr_lo + c * 64));
+				glds_dword(ap + 4, lds_addr(pr_hi + c * 64));
+				glds_dword(am, lds_addr(pr_lo + (NCH + c) * 64));
+				glds_dword(am + 4, lds_addr(pr_hi + (NCH + c) * 64));
+				lo0 = lo1; hi0 = hi1; inv0 = inv1; invm0 = invm1;
+			}
+		}
+	}
+
 	// UFIndex::GetRow_Blob (ufindex.cpp:883-943) for all collision chains of the read at once: lane = query position
 	// mod 64, the 2*NCH [strand][chunk] segments advance in lock step so that up to 2*NCH dependent slot loads per lane
-	// are in flight; positions go to rowstore[seg][k][lane], row lengths to rl[seg].
-	__device__ __forceinline__ void walk_all(const ProbeOut &probe, uint64_t base2, int (&rl)[NSEG]) {
-		uint64_t sl[NSEG];
-		uint32_t T[NSEG], ps[NSEG];
-		bool act[NSEG];
-		const uint64_t N = X.slotCount;
-		const int maxIx = (int)X.maxIx;
+	// are in flight; positions go to rowstore[seg][k][lane], row lengths to rl[seg].  In two parts: the chain heads come
+	// out of the pr_* arrays (which the next read's probe may then overwrite), the hops out of the slot table.
+	__device__ __forceinline__ void walk_heads(uint64_t (&sl)[NSEG], uint32_t (&T)[NSEG], uint32_t (&ps)[NSEG], bool (&act)[NSEG]) const {
 #pragma unroll
 		for (int g = 0; g < NSEG; ++g) {
 			const int s2 = g / NCH, c = g % NCH;
 			const int p = 64 * c + lane;
-			T[g] = 0; ps[g] = 0; sl[g] = 0; rl[g] = 0;
-			if (p < nwords) {
-				const uint64_t idx = base2 + (uint64_t)s2 * QL + p;
-				T[g] = probe.tallies[idx];
-				ps[g] = probe.positions[idx];
-			}
+			T[g] = 0; ps[g] = 0; sl[g] = 0;
+			if (p < nwords) probe_get(s2, p, T[g], ps[g]);
 			act[g] = (T[g] & TALLY_MY_BIT) != 0 && T[g] != TALLY_BOTH1;
-			if (act[g]) sl[g] = probe.slots[base2 + (uint64_t)s2 * QL + p];
+			if (act[g]) {
+				const int i = s2 ? nwords - 1 - p : p;
+				sl[g] = (uint64_t)pr_sl[s2 * NCH * 64 + i] | (((pr_hb[s2 * NCH + (i >> 6)] >> (i & 63)) & 1ull) << 32);
+			}
 		}
+	}
+	__device__ __forceinline__ void walk_run(uint64_t (&sl)[NSEG], uint32_t (&T)[NSEG], uint32_t (&ps)[NSEG], bool (&act)[NSEG], int (&rl)[NSEG]) {
+		const uint64_t N = X.slotCount;
+		const int maxIx = (int)X.maxIx;
 		bool any = false;
 #pragma unroll
-		for (int g = 0; g < NSEG; ++g) any |= act[g];
+		for (int g = 0; g < NSEG; ++g) { rl[g] = 0; any |= act[g]; }
 		while (any) {
 #pragma unroll
 			for (int g = 0; g < NSEG; ++g) {
@@ -745,9 +787,9 @@ struct SearchWave {
 	}
 };
 
-// waves per SIMD the register allocation aims at.  Reads <= 192: 4 (128 VGPRs, ~30 registers spilled to scratch in
+// waves per SIMD the register allocation aims at.  Reads <= 192: 4 (128 VGPRs, some registers spilled to scratch in
 // cold paths; LDS per block is kept under 10 KB for the same 16 blocks per CU) -- measured 10 % faster than 3 waves
-// with no spills.  Reads <= 320: 2 (the five-word bit vectors and 20 window loads in flight do not fit fewer
+// with no spills.  Reads <= 320: 2 (the five-word bit vectors and the window loads in flight do not fit fewer
 // registers without hundreds of spills).
 #ifndef SEARCH_WAVES_NCH3
 #define SEARCH_WAVES_NCH3 4
@@ -756,23 +798,35 @@ struct SearchWave {
 #define SEARCH_WAVES_NCH4 3
 #endif
 #define SEARCH_WAVES_PER_EU(NCH) ((NCH) <= 3 ? SEARCH_WAVES_NCH3 : (NCH) == 4 ? SEARCH_WAVES_NCH4 : (NCH) == 5 ? 2 : 1)
+// The kernel is a software pipeline over the reads a block takes from the ticket counter.  While read i is searched,
+//   * the bytes of read i+1 arrive in LDS (one LDS-DMA load issued right after read i's own bytes were taken out), and
+//   * between phases 3 and 4 -- when the chain heads of read i are in registers and its slot entries are dead -- the
+//     k-mers of read i+1 are hashed and their 2 x (QL-W+1) slots gathered straight into LDS (probe_issue): the loads
+//     are in flight behind the chain walk and the phase-4/5 window gathers of read i and have landed when read i+1
+//     begins.  There is no probe launch and no probe array in HBM: what used to be 13 bytes written and read back per
+//     k-mer stays in 12 bytes of LDS.
 // DBG = true: the diagnostic instantiation (URMAPX_PHASE_STATS / URMAPX_DEBUG_STOP): per-phase cycle stamps, per-read
-// cycle counts and schedule cuts.  The production instantiation (DBG = false) contains none of that code.
+// cycle counts and schedule cuts (stop after step 1 / 3 / 4; 100 = setup and output only; 104 = up to the chain walks).
+// The production instantiation (DBG = false) contains none of that code.
 template <int NCH, bool OVF, bool DBG>
 __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel(DevIndex X, urmapx_params P, const uint8_t *__restrict__ bases,
-                                                       const uint64_t *__restrict__ offs, uint32_t n, ProbeOut probe,
+                                                       const uint64_t *__restrict__ offs, uint32_t n,
                                                        urmapx_result *__restrict__ results,
                                                        urmapx_path_op *__restrict__ path_ops, uint32_t *path_used,
                                                        uint32_t *stats, uint8_t *scratch, size_t scratch_stride,
                                                        const uint8_t *__restrict__ g_seq, const uint8_t *__restrict__ g_blob,
+                                                       const uint4 *__restrict__ g_seqp,
                                                        uint32_t *ticket, int hsp_lds_cap, uint32_t *ovf_list, uint2 *hsp_ovf_base,
                                                        DpWork dp) {
 	// stats != nullptr (URMAPX_PHASE_STATS): per-phase shader cycles are accumulated into stats (u64 each, from byte 8)
 	using SW = SearchWave<NCH, OVF>;
+	constexpr int NQ_BYTES = ((SW::QMAX + 4 + 255) / 256) * 256;  // the next read's bytes from a 4-byte aligned address on, in 256-byte DMA pieces
 	__shared__ __attribute__((aligned(16))) uint8_t sQ2[2 * SW::QMAX];  // plus strand, then reverse complement
 	uint8_t *const sQp = sQ2, *const sQm = sQ2 + SW::QMAX;
-	const uint8_t *__restrict__ const seq = g_seq;
-	__shared__ uint32_t tb[SW::TB_ROWS8 * 64];
+	__shared__ __attribute__((aligned(16))) uint4 qpl[2 * 2 * NCH];     // both strands as bit planes (dev_common.h): [strand][block of 32]
+	__shared__ __attribute__((aligned(16))) uint8_t nextQ[NQ_BYTES];
+	__shared__ uint32_t pr_lo[SW::NSEG * 64], pr_hi[SW::NSEG * 64], pr_sl[SW::NSEG * 64];
+	__shared__ uint64_t pr_hb[SW::NSEG];
 	__shared__ uint16_t top[URMAPX_MAX_PATH_OPS];
 	__shared__ uint16_t pre[2 * SW::NSEG * 64 + 2];
 	// the flank run buffers and the candidate path live only inside align_hsp, the candidate prefix array only inside a
@@ -781,11 +835,9 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 	uint16_t *const ropsL = pre, *const ropsR = pre + OPS_CAP, *const cand = pre + 2 * OPS_CAP;
 	uint8_t *const sT = reinterpret_cast<uint8_t *>(pre + 2 * OPS_CAP + URMAPX_MAX_PATH_OPS);  // AlignHSP's target window
 	__shared__ uint32_t hsp_db[HSP_CAP], hsp_pk[HSP_CAP];
-	// candidate queue (ring): reference position, query position | plus << 14 | second phase << 15.  It is alive inside a
-	// gather step only, like the BOTH1 seed positions (xp): both sit on the DP trace buffer, which AlignHSP owns.
-	static_assert(2 * SW::QMAX + 128 + 64 <= SW::TB_ROWS8 * 64, "alias");
-	uint32_t *const cq_db = tb + 2 * SW::QMAX;
-	uint16_t *const cq_qp = reinterpret_cast<uint16_t *>(tb + 2 * SW::QMAX + 128);
+	// candidate queue (ring): reference position, query position | plus << 14 | second phase << 15
+	__shared__ uint32_t cq_db[128];
+	__shared__ uint16_t cq_qp[128];
 
 	const int lane = threadIdx.x;
 	const int W = (int)X.W;
@@ -794,18 +846,24 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 	SW S(X, P, lane);
 	S.W = W;
 	S.gseq = g_seq; S.gblob = g_blob;
-	S.sQ[0] = sQp; S.sQ[1] = sQm; S.sT = sT; S.tb = tb;
+	S.sQ[0] = sQp; S.sQ[1] = sQm; S.sT = sT;
 	S.ropsL = ropsL; S.ropsR = ropsR; S.cand = cand; S.top = top; S.pre = pre;
 	S.hsp_db = hsp_db; S.hsp_pk = hsp_pk;
+	S.pr_lo = pr_lo; S.pr_hi = pr_hi; S.pr_sl = pr_sl; S.pr_hb = pr_hb;
 	{
 		uint8_t *sc = scratch + (size_t)blockIdx.x * scratch_stride;
 		S.rowstore = reinterpret_cast<uint32_t *>(sc);
 		S.ws.carve(sc + (size_t)SW::NSEG * ROW_CAP * 64 * 4, SW::QMAX, SW::WIDE_LB);
+		// the trace cells of phase 3's banded DP live in this block's global scratch (phase 6 has kernels of its own with
+		// the trace in LDS): 6 KB of LDS per block went to the slot entries instead
+		S.tb = reinterpret_cast<uint32_t *>(sc + search_tb_offset(NCH));
 		S.hsp_ovf = hsp_ovf_base + (size_t)blockIdx.x * (HSP_TOTAL_CAP - HSP_CAP);
 		S.hsp_lds = (hsp_lds_cap >= 64 && hsp_lds_cap <= HSP_CAP) ? (hsp_lds_cap & ~63) : HSP_CAP;  // multiple of 64
 		S.hit_cap = (hsp_lds_cap >= 64 && hsp_lds_cap <= HSP_CAP) ? S.hsp_lds / 4 : 64 * SE_HITW1;
 		S.hit_wsh = (hsp_lds_cap >= 64 && hsp_lds_cap <= HSP_CAP) ? 4 : 6;
 	}
+	const bool geom_ok = W <= 32 && X.maxIx <= (uint32_t)ROW_CAP;
+	auto len_ok = [&](int ql) { return geom_ok && ql >= W && ql <= SW::QMAX; };
 
 	// Reads are handed out by a ticket counter, not by a fixed stride: the cost of a read is heavy-tailed (a read in a
 	// repeat family aligns up to 256 HSPs in phase 6), and with a fixed assignment the blocks that draw such reads
@@ -814,80 +872,58 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 	// reads takes 11.4 ms), which would cap the kernel not far above its current rate.
 	if constexpr (OVF) n = ovf_list[0];  // how many reads the first pass flagged (usually none)
 	uint32_t r_next = 0, r_end = 0;
-	for (;;) {
+	auto take = [&](uint32_t &ri) -> bool {  // the next read of this block; false: the batch is used up
 		if (r_next == r_end) {
 			// every lane takes part in the atomic (lanes 1..63 add 0): with `if (lane == 0) atomicAdd` here the compiler's
 			// wave-level atomic rewrite turns the loop divergent and the kernel hangs or faults (seen twice)
 			constexpr uint32_t CHUNK = OVF ? 1u : (uint32_t)TICKET_CHUNK;  // second pass: few, heavy reads -- one per ticket
 			r_next = uni(atomicAdd(ticket, lane == 0 ? CHUNK : 0u));
-			if (r_next >= n) break;
+			if (r_next >= n) { r_end = r_next; return false; }
 			r_end = r_next + CHUNK < n ? r_next + CHUNK : n;
 		}
-		uint32_t r = r_next++;
-		if constexpr (OVF) r = ovf_list[1 + r];  // second pass: the reads the first pass flagged
-		const uint64_t off = offs[r];
-		const int QL = (int)(offs[r + 1] - off);
+		ri = r_next++;
+		if constexpr (OVF) ri = ovf_list[1 + ri];  // second pass: the reads the first pass flagged
+		return true;
+	};
+	// a read's bytes into nextQ by LDS-DMA: whole dwords from the 4-byte aligned address at or below its first byte
+	// (loads inside the last dword of a buffer stay inside its allocation)
+	auto fetch_bytes = [&](uint64_t o, int ql) {
+		const uintptr_t a = reinterpret_cast<uintptr_t>(bases + o);
+		const uint8_t *src = reinterpret_cast<const uint8_t *>(a & ~(uintptr_t)3);
+		const int nb = (int)(a & 3) + ql;
+#pragma unroll
+		for (int k = 0; k < NQ_BYTES / 256; ++k)
+			if (256 * k < nb) {
+				const int ob = 256 * k + 4 * lane;
+				glds_dword(src + (ob < nb ? ob : 0), lds_addr(nextQ + 256 * k));
+			}
+	};
 
-		if (dbg_stop == 97) { if (QL == 12345) break; continue; }
+	bool have_cur = false;
+	uint32_t r = 0;
+	uint64_t off = 0;
+	int QL = 0;
+	for (;;) {
+		uint32_t rn = 0;
+		const bool have_next = take(rn);
+		uint64_t noff = 0;
+		int nQL = 0;
+		if (have_next) { noff = offs[rn]; nQL = (int)(offs[rn + 1] - noff); }
+		const bool next_ok = have_next && len_ok(nQL);
+		const int nmis = (int)(reinterpret_cast<uintptr_t>(bases + noff) & 3);
+		const bool cur_ok = have_cur && len_ok(QL);
+
 		const uint64_t t_read0 = timing ? __builtin_amdgcn_s_memtime() : 0;
 		urmapx_result res;
 		res.dbpos = 0xFFFFFFFFu; res.seq_index = 0xFFFFFFFFu; res.coord = 0xFFFFFFFFu;
 		res.score = 0; res.second = 0; res.mapq = 0; res.plus = 0; res.exit_phase = 0; res.status = 0;
 		res.hit_count = 0; res.path_nops = 0; res.path_off = 0;
 		bool parked = false;  // phase 6 handed to dp_kernel + finalize_se_kernel, which writes the result
-		const bool badlen = QL < W || QL > SW::QMAX || W > 32 || X.maxIx > (uint32_t)ROW_CAP;
-		if (badlen) res.status = URMAPX_ST_BAD_LENGTH;
-		if (!badlen) {
-		S.QL = QL;
-		const int nwords = QL - (W - 1);
-		S.nwords = nwords;
-#pragma unroll
-		for (int w = 0; w < SW::HITW; ++w) S.hit_db[w] = 0;
-		S.hitCount = 0; S.hspCount = 0;
-		S.maxPen = P.max_penalty; S.best = 0; S.second = 0; S.bestHSP = 0;
-		S.haveTop = false; S.top_db = 0; S.top_plus = false; S.top_nops = 0; S.status = 0;
-
-		// query bytes of both strands into LDS
-		__syncthreads();
-		const uint8_t *q = bases + off;
-#pragma unroll
-		for (int c = 0; c < NCH; ++c) {
-			int p = 64 * c + lane;
-			if (p < QL) {
-				sQp[p] = q[p];
-				sQm[p] = (uint8_t)comp_char(q[QL - 1 - p]);
-			}
-		}
-		__syncthreads();
-
-		// BOTH1 seed positions of this read by [strand][query position] in LDS (tb is idle outside align_hsp); every
-		// other k-mer gets the sentinel.  Chain heads are re-read from the probe output when the walk starts.
-		if (dbg_stop == 98) continue;
-		const uint64_t base2 = 2ull * off;
-		uint32_t *xp = reinterpret_cast<uint32_t *>(tb);
-#pragma unroll
-		for (int s = 0; s < 2; ++s) {
-#pragma unroll
-			for (int c = 0; c < NCH; ++c) {
-				const int p = 64 * c + lane;
-				uint32_t v = 0xFFFFFFFFu;
-				if (p < nwords) {
-					const uint64_t idx = base2 + (uint64_t)s * QL + p;
-					if (probe.tallies[idx] == TALLY_BOTH1) v = probe.positions[idx];
-				}
-				xp[s * SW::QMAX + p] = v;
-			}
-		}
-		__syncthreads();
-
-		if (dbg_stop == 99) continue;
-		const int minScore1 = QL + P.xphase1 * P.mismatch_score;
-		const int minScore3 = QL + P.xphase3 * P.mismatch_score;
-		const int minScore4 = QL + P.xphase4 * P.mismatch_score;
-		const int termHSP3 = (QL * P.term_hsp_score_pct_phase3) / 100;
-		const int minhsp = (int)((uint32_t)P.min_hsp_score_pct * (uint32_t)QL / 100.0);
+		if (have_cur && !cur_ok) res.status = URMAPX_ST_BAD_LENGTH;
+		bool fetched = false;
+		bool q_other = false;
 		int phase = 1;
-		bool done = false;
+		bool done = !cur_ok;
 		uint64_t tstamp = timing ? __builtin_amdgcn_s_memtime() : 0;
 		auto lapc = [&](int slot) {
 			if (!timing) return;
@@ -895,21 +931,95 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 			if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long *>(stats) + 1 + slot, (unsigned long long)(now - tstamp));
 			tstamp = now;
 		};
-		lapc(0);
+		if (cur_ok) {
+			S.QL = QL;
+			S.nwords = QL - (W - 1);
+#pragma unroll
+			for (int w = 0; w < SW::HITW; ++w) S.hit_db[w] = 0;
+			S.hitCount = 0; S.hspCount = 0;
+			S.maxPen = P.max_penalty; S.best = 0; S.second = 0; S.bestHSP = 0;
+			S.haveTop = false; S.top_db = 0; S.top_plus = false; S.top_nops = 0; S.status = 0;
+
+			// this read's bytes and slot entries have landed (issued while the previous read was searched)
+			wait_vm0();
+			__syncthreads();
+			const int mis = (int)(reinterpret_cast<uintptr_t>(bases + off) & 3);
+#pragma unroll
+			for (int c = 0; c < NCH; ++c) {
+				const int p = 64 * c + lane;
+				if (p < QL) {
+					const uint8_t ch = nextQ[mis + p];
+					sQp[p] = ch;
+					sQm[QL - 1 - p] = (uint8_t)comp_char(ch);
+				}
+			}
+			__syncthreads();
+			// both strands as bit planes of 4-bit codes (dev_common.h); a read holding a byte outside the code list
+			// compares ASCII windows instead
+			uint64_t oth = 0;
+#pragma unroll
+			for (int s = 0; s < 2; ++s) {
+#pragma unroll
+				for (int c = 0; c < NCH; ++c) {
+					if (64 * c < QL) {
+						const int p = 64 * c + lane;
+						const uint32_t code = p < QL ? seq_code(sQ2[s * SW::QMAX + p], SEQ_CODE_QOTHER) : 0u;
+						const uint64_t b0 = __ballot(code & 1u), b1 = __ballot(code & 2u), b2 = __ballot(code & 4u), b3 = __ballot(code & 8u);
+						oth |= __ballot(code == SEQ_CODE_QOTHER);
+						if (lane < 2) {
+							const int shh = 32 * lane;
+							qpl[s * 2 * NCH + 2 * c + lane] = make_uint4((uint32_t)(b0 >> shh), (uint32_t)(b1 >> shh), (uint32_t)(b2 >> shh), (uint32_t)(b3 >> shh));
+						}
+					}
+				}
+			}
+			q_other = oth != 0;
+			__syncthreads();
+			// nextQ is free again: the bytes of the read after this one
+			if (next_ok) { wait_lgkm0(); fetch_bytes(noff, nQL); fetched = true; }
+			lapc(0);
+		}
+		const int nwords = QL - (W - 1);
+		const int minScore1 = QL + P.xphase1 * P.mismatch_score;
+		const int minScore3 = QL + P.xphase3 * P.mismatch_score;
+		const int minScore4 = QL + P.xphase4 * P.mismatch_score;
+		const int termHSP3 = (QL * P.term_hsp_score_pct_phase3) / 100;
+		const int minhsp = (int)((uint32_t)P.min_hsp_score_pct * (uint32_t)(QL > 0 ? QL : 0) / 100.0);
 
 		// The six phases of Search_Lo as ONE loop, so that the gather/consume code and the DP code exist once
 		// (the kernel has to stay inside the instruction cache):
 		//   1, 2  BOTH1 seeds on / off the stride W      3  AlignHSP if the best HSP is long enough
-		//   4, 5  chain rows of length <= 2 / > 2        6  AlignHSP
+		//   5     (not a phase) chain heads out of LDS, the NEXT read's probe, then the chain walks
+		//   4, 5' chain rows of length <= 2 / > 2        6  AlignHSP
 		// Phases 1+2 and 4+5 each form ONE candidate list (gathered together, so that batches stay full); the ordered
-		// part applies the phase boundary (exit test after phase 4) when it crosses it.
+		// part applies the phase boundary (exit test after phase 4) when it crosses it.  A read that is done early, or
+		// has a bad length, still passes through step 5 for the next read's probe.
 		int rl[SW::NSEG];
 #pragma unroll
 		for (int g = 0; g < SW::NSEG; ++g) rl[g] = 0;
-		for (int step = 1; step <= 6 && !done; step += (step == 1 ? 2 : (step == 3 ? 1 : 2))) {  // 1 (=1+2), 3, 4 (=4+5), 6
+		for (int step = cur_ok ? 1 : 5;;) {
+			if (DBG && dbg_stop && step != 5 && (dbg_stop == 100 || (dbg_stop < 100 && step > dbg_stop))) { done = true; step = 5; }
+			if (step == 5) {
+				const bool go = !done;
+				uint64_t wsl[SW::NSEG];
+				uint32_t wT[SW::NSEG], wps[SW::NSEG];
+				bool wact[SW::NSEG];
+				if (go) S.walk_heads(wsl, wT, wps, wact);
+				if (next_ok) {
+					if (!fetched) fetch_bytes(noff, nQL);
+					wait_vm0();
+					__syncthreads();
+					S.probe_issue(nextQ + nmis, nQL);
+				}
+				if (!go) break;
+				S.walk_run(wsl, wT, wps, wact, rl);
+				__syncthreads();
+				lapc(3);
+				if (DBG && dbg_stop == 104) { done = true; break; }
+				step = 4;
+				continue;
+			}
 			phase = step;
-			if (dbg_stop == 100) break;  // setup + output only
-			if (dbg_stop && step > (dbg_stop > 410 ? 1 : dbg_stop > 400 ? 4 : dbg_stop)) break;
 			if (step == 3 || step == 6) {
 				if (step == 6 && !OVF && (S.status & (URMAPX_ST_HSP_OVERFLOW | URMAPX_ST_HIT_OVERFLOW))) break;  // the second pass maps this read again
 				if (step == 6 && dp.jobs != nullptr && S.park_for_dp(dp, r, 6)) { parked = true; break; }
@@ -918,6 +1028,8 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 					if (step == 3 && S.best >= minScore1) done = true;
 				}
 				lapc(step == 3 ? 2 : 6);
+				if (step == 6) break;
+				step = 5;
 				continue;
 			}
 			int cnt[2 * SW::NSEG];
@@ -927,16 +1039,18 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 #pragma unroll
 				for (int c = 0; c < NCH; ++c) {
 					const int p = 64 * c + lane;
-					const int nb1 = (xp[p] != 0xFFFFFFFFu ? 1 : 0) + (xp[SW::QMAX + p] != 0xFFFFFFFFu ? 1 : 0);
+					int nb1 = 0;
+					if (p < nwords) {
+						uint32_t t0, p0, t1, p1;
+						S.probe_get(0, p, t0, p0);
+						S.probe_get(1, p, t1, p1);
+						nb1 = (t0 == TALLY_BOTH1 ? 1 : 0) + (t1 == TALLY_BOTH1 ? 1 : 0);
+					}
 					const bool onStride = (p % W) == 0;
 					cnt[c] = onStride ? nb1 : 0;
 					cnt[NCH + c] = onStride ? 0 : nb1;
 				}
-			} else {  // walk every collision chain once; segments [0, NSEG): rows <= 2 (phase 4), [NSEG, 2 NSEG): rows > 2 (phase 5)
-				S.walk_all(probe, base2, rl);
-				__syncthreads();
-				lapc(3);
-				if (dbg_stop == 104) break;
+			} else {  // segments [0, NSEG): rows <= 2 (phase 4), [NSEG, 2 NSEG): rows > 2 (phase 5)
 #pragma unroll
 				for (int g = 0; g < SW::NSEG; ++g) {
 					cnt[g] = rl[g] <= 2 ? rl[g] : 0;
@@ -968,8 +1082,10 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 						if (step == 1) {  // BOTH1 seeds: plus-strand seed first, then minus (search1m6.cpp:69-108)
 							if (row >= NCH * 64) row -= NCH * 64;
 							s_qpos = (uint32_t)row;
-							const uint32_t pp = xp[row], pm = xp[SW::QMAX + row];
-							if (k == 0 && pp != 0xFFFFFFFFu) { s_plus = true; s_db = pp; }
+							uint32_t tp, pp, tm, pm;
+							S.probe_get(0, row, tp, pp);
+							S.probe_get(1, row, tm, pm);
+							if (k == 0 && tp == TALLY_BOTH1) { s_plus = true; s_db = pp; }
 							else { s_plus = false; s_db = pm; }
 						} else {  // chain rows: [strand][chunk][k][lane]
 							int seg = row >> 6;
@@ -1006,14 +1122,15 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 				qhead = (qhead + nb) & 127; qcount -= nb;
 				__syncthreads();
 				laps(8);
-				if ((dbg_stop == 401 && step == 4) || dbg_stop == 411) continue;
 				uint64_t mm[NCH];
 #pragma unroll
 				for (int c = 0; c < NCH; ++c) mm[c] = 0;
-				if (c_ok) lane_mismatch_mask<NCH>(seq, c_db - c_qpos, sQ2 + (c_plus ? 0 : SW::QMAX), QL, mm);
-				__builtin_amdgcn_s_waitcnt(0);
+				if (q_other) {  // wave-uniform: a read with bytes outside the code list (IUPAC beyond N, 'u')
+					if (c_ok) lane_mismatch_mask<NCH>(g_seq, c_db - c_qpos, sQ2 + (c_plus ? 0 : SW::QMAX), QL, mm);
+				} else {
+					if (c_ok) lane_mismatch_planes<NCH>(g_seqp, c_db - c_qpos, qpl + (c_plus ? 0 : 2 * NCH), QL, mm);
+				}
 				laps(9);
-				if ((dbg_stop == 402 && step == 4) || dbg_stop == 412) { if (mm[0] == 0x123456789ull) done = true; continue; }
 				// ExtendPen's two x-drop walks (extendpen.cpp:25-78), every lane on its own bit vector.  The accumulated
 				// penalty only grows along the walk and the cap only falls: a lane over the cap as it stands now is over
 				// it at its turn and stops; the others finish and are compared with the cap in order below.
@@ -1033,7 +1150,6 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 					else if (e_bst >= minhsp) e_kind = 2;
 				}
 				laps(10);
-				if ((dbg_stop == 403 && step == 4) || dbg_stop == 413) { if (__ballot(e_bst == 12345)) done = true; continue; }
 				// order-dependent part: only candidates that can change the state, in the reference's order.  Lanes that
 				// cannot change it are dropped, up front and again after every change: the penalty cap only falls, the best
 				// score only rises and hits are only added, so a candidate failing extendpen.cpp:15-17, extendpen.cpp:43-44
@@ -1071,25 +1187,33 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 				laps(11);
 			}
 
-			if (step == 1) { lapc(1); if (!done) phase = 2; }
-			if (step == 4) {
-				lapc(4);
-				if (!done && !crossed && S.best >= minScore3) done = true;  // no state-changing phase-5 candidate was met
-				if (!done) { phase = 5; if (S.best >= minScore4) done = true; }
+			if (step == 1) {
+				lapc(1);
+				if (!done) phase = 2;
+				step = done ? 5 : 3;
+				continue;
 			}
+			// step == 4
+			lapc(4);
+			if (!done && !crossed && S.best >= minScore3) done = true;  // no state-changing phase-5 candidate was met
+			if (!done) { phase = 5; if (S.best >= minScore4) done = true; }
+			if (done) break;
+			step = 6;
 		}
 		lapc(6);
-		if (!parked) S.fill_result(res, phase, path_ops, path_used);
+		if (cur_ok && !parked) S.fill_result(res, phase, path_ops, path_used);
 		lapc(7);
-		}  // !badlen
-		if (parked) continue;
-		if constexpr (!OVF) {
-			if (res.status & (URMAPX_ST_HSP_OVERFLOW | URMAPX_ST_HIT_OVERFLOW)) {  // queue the read for the second pass
-				if (lane == 0) ovf_list[1 + atomicAdd(ovf_list, 1u)] = r;
+		if (have_cur && !parked) {
+			if constexpr (!OVF) {
+				if (res.status & (URMAPX_ST_HSP_OVERFLOW | URMAPX_ST_HIT_OVERFLOW)) {  // queue the read for the second pass
+					if (lane == 0) ovf_list[1 + atomicAdd(ovf_list, 1u)] = r;
+				}
 			}
+			if (lane == 0) results[r] = res;
+			if (timing && lane == 0) stats[64 + r] = (uint32_t)((__builtin_amdgcn_s_memtime() - t_read0) >> 4);  // per-read cost, 16-cycle units
 		}
-		if (lane == 0) results[r] = res;
-		if (timing && lane == 0) stats[64 + r] = (uint32_t)((__builtin_amdgcn_s_memtime() - t_read0) >> 4);  // per-read cost, 16-cycle units
+		if (!have_next) break;
+		have_cur = true; r = rn; off = noff; QL = nQL;
 	}
 }
 
@@ -1348,7 +1472,7 @@ static int nch_for(uint32_t max_read_len) {
 
 size_t search_scratch_stride(uint32_t max_read_len) {
 	const int nch = nch_for(max_read_len);
-	return (hsp_ovf_offset(nch) + 255) & ~(size_t)255;
+	return (search_scratch_bytes(nch) + 255) & ~(size_t)255;
 }
 // behind the strided per-block areas: the HSP overflow lists of the second pass's blocks
 size_t search_scratch_tail(int blocks) {
@@ -1368,6 +1492,39 @@ int search_block_count(uint32_t max_read_len, int device) {
 	                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, search_se_kernel<16, false, false>, 64, 0);
 	if (e != hipSuccess || per_cu < 1) per_cu = 8;
 	return per_cu * prop.multiProcessorCount;
+}
+
+// ------------------------------------------------------------------------------------------------
+// the packed copy of the sequence store (dev_common.h: seq_code, lane_mismatch_planes), built once per index on the device
+// ------------------------------------------------------------------------------------------------
+// One wavefront per 64 bases at a time: lane = base, four ballots = the four planes of two 32-base blocks.  Bytes
+// beyond the stored sequence (the reference reads past its end; the store is zero-padded) get the
+// "other byte" code, like any byte outside the code list.
+__global__ __launch_bounds__(256) void pack_seq_kernel(const uint8_t *__restrict__ seq, uint64_t nbytes, uint4 *__restrict__ out,
+                                                       uint64_t nblocks) {
+	const int lane = threadIdx.x & 63;
+	const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+	const uint64_t nwaves = (uint64_t)gridDim.x * (blockDim.x >> 6);
+	uint32_t *o32 = reinterpret_cast<uint32_t *>(out);
+	for (uint64_t w = wave; 2 * w < nblocks; w += nwaves) {
+		const uint64_t i = 64 * w + lane;
+		const uint32_t code = i < nbytes ? seq_code(seq[i], SEQ_CODE_TOTHER) : SEQ_CODE_TOTHER;
+		const uint64_t b0 = __ballot(code & 1u), b1 = __ballot(code & 2u), b2 = __ballot(code & 4u), b3 = __ballot(code & 8u);
+		if (lane < 8 && 2 * w + (lane >> 2) < nblocks) {  // lanes 0..3: block 2w's planes, 4..7: block 2w+1's
+			const int k = lane & 3;
+			const uint64_t b = k == 0 ? b0 : k == 1 ? b1 : k == 2 ? b2 : b3;
+			o32[8 * w + lane] = (uint32_t)(b >> (32 * (lane >> 2)));
+		}
+	}
+}
+
+// blocks of 32 bases: the stored bytes, the 4096-byte zero pad behind them, and the blocks a window load runs past its last base
+size_t packed_seq_blocks(uint32_t seq_data_size) { return ((size_t)seq_data_size + 4096 + 31) / 32 + 40; }
+
+hipError_t launch_pack_seq(const uint8_t *d_seq, uint32_t seq_data_size, uint4 *d_out, hipStream_t s) {
+	const uint64_t nblocks = packed_seq_blocks(seq_data_size);
+	hipLaunchKernelGGL(pack_seq_kernel, dim3(8192), dim3(256), 0, s, d_seq, (uint64_t)seq_data_size, d_out, nblocks);
+	return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1413,7 +1570,7 @@ hipError_t launch_seed_probe(const DevIndex &X, const uint8_t *d_bases, const ui
 }
 
 hipError_t launch_search_se(const DevIndex &X, const urmapx_params &P, const uint8_t *d_bases, const uint64_t *d_offs,
-                            uint32_t n, uint32_t max_read_len, ProbeOut probe, urmapx_result *d_results,
+                            uint32_t n, uint32_t max_read_len, urmapx_result *d_results,
                             urmapx_path_op *d_path_ops, uint32_t *d_path_used, const SearchWork &wk, hipStream_t s) {
 	if (n == 0) return hipSuccess;
 	const int nch = nch_for(max_read_len);
@@ -1440,9 +1597,9 @@ hipError_t launch_search_se(const DevIndex &X, const urmapx_params &P, const uin
 			if (e != hipSuccess) return e;
 		}
 #define URX_LAUNCH_SE(NCH_, OVF_, DBG_, GRID_, STATS_, OVFBASE_, DP_)                                                             \
-	hipLaunchKernelGGL((search_se_kernel<NCH_, OVF_, DBG_>), GRID_, block, 0, s, X, P, d_bases, d_offs, n, probe, d_results,         \
-	                   d_path_ops, d_path_used, STATS_, wk.scratch, wk.scratch_stride, X.seq, X.blob, wk.ticket, wk.hsp_lds_cap, \
-	                   wk.ovf_list, OVFBASE_, DP_)
+	hipLaunchKernelGGL((search_se_kernel<NCH_, OVF_, DBG_>), GRID_, block, 0, s, X, P, d_bases, d_offs, n, d_results,                \
+	                   d_path_ops, d_path_used, STATS_, wk.scratch, wk.scratch_stride, X.seq, X.blob, X.seqp, wk.ticket,         \
+	                   wk.hsp_lds_cap, wk.ovf_list, OVFBASE_, DP_)
 	// phase 6 of the reads a pass parked: their flank DPs, then the ordered part
 #define URX_LAUNCH_DP(NCH_, OVF_, PASS_)                                                                                          \
 	do { for (int rd = 0; rd < DP_ROUNDS; ++rd) {                                                                                 \

@@ -36,12 +36,13 @@ struct urmapx_index {
 	// device copy
 	int device = -1;
 	const uint8_t *d_blob = nullptr, *d_seq = nullptr;
+	uint4 *d_seqp = nullptr;  // packed copy of d_seq (4 bit planes per 32 bases), always owned, built on the device
 	bool own_dev = false;
 	uint32_t *d_seqLengths = nullptr, *d_seqOffsets = nullptr;
 
 	DevIndex view() const {
 		DevIndex X;
-		X.blob = d_blob; X.seq = d_seq; X.slotCount = slotCount;
+		X.blob = d_blob; X.seq = d_seq; X.seqp = d_seqp; X.slotCount = slotCount;
 		X.slotMagic = (uint64_t)((((unsigned __int128)1) << 64) / slotCount);
 		X.shiftMask = (W >= 32) ? ~0ull : ((1ull << (2 * W)) - 1ull);
 		X.W = W; X.maxIx = maxIx; X.seqDataSize = seqDataSize; X.seqCount = (uint32_t)labels.size();
@@ -172,7 +173,17 @@ int urmapx_index_wrap_host(uint32_t W, uint32_t max_ix, uint64_t slot_count, con
 	return URMAPX_OK;
 }
 
+// ExtendPen's windows are read from a packed copy of the sequence store (0.5 byte per base, dev_common.h)
+static int build_packed_seq(urmapx_index *I) {
+	HIP_TRY(hipMalloc((void **)&I->d_seqp, packed_seq_blocks(I->seqDataSize) * sizeof(uint4)));
+	HIP_TRY(launch_pack_seq(I->d_seq, I->seqDataSize, I->d_seqp, nullptr));
+	HIP_TRY(hipDeviceSynchronize());
+	return URMAPX_OK;
+}
+
 static int upload_directory(urmapx_index *I) {
+	int rc = build_packed_seq(I);
+	if (rc) return rc;
 	size_t n = I->labels.size();
 	HIP_TRY(hipMalloc((void **)&I->d_seqLengths, (n + 1) * 4));
 	HIP_TRY(hipMalloc((void **)&I->d_seqOffsets, (n + 1) * 4));
@@ -234,6 +245,7 @@ int urmapx_index_replicate(const urmapx_index *src, int device, urmapx_index **o
 void urmapx_index_close(urmapx_index *I) {
 	if (!I) return;
 	if (I->own_dev) { (void)hipFree((void *)I->d_blob); (void)hipFree((void *)I->d_seq); }
+	if (I->d_seqp) (void)hipFree(I->d_seqp);
 	if (I->d_seqLengths) (void)hipFree(I->d_seqLengths);
 	if (I->d_seqOffsets) (void)hipFree(I->d_seqOffsets);
 	free(I->own_blob);
@@ -360,9 +372,8 @@ int urmapx_map_se_device(urmapx_ctx *C, const void *d_bases, const void *d_offs,
 	if (!C || (n && (!d_bases || !d_offs || !d_results || !d_path_ops || !d_path_used))) return URMAPX_E_ARG;
 	if (max_read_len > URMAPX_MAX_QL) return URMAPX_E_UNSUPPORTED;
 	HIP_TRY(hipSetDevice(C->device));
-	int rc = ensure_probe(C, total_bases);
-	if (rc) return rc;
-	ProbeOut po{C->slots.p, C->tallies.p, C->positions.p};
+	(void)total_bases;
+	int rc;
 	const int cls = max_read_len <= 128 ? 3 : max_read_len <= 192 ? 0 : max_read_len <= 256 ? 2 : max_read_len <= 320 ? 1 : max_read_len <= 512 ? 4 : 5;
 	if (C->blocks[cls] == 0) {
 		C->blocks[cls] = search_block_count(max_read_len, C->device);
@@ -427,11 +438,11 @@ int urmapx_map_se_device(urmapx_ctx *C, const void *d_bases, const void *d_offs,
 	}
 	wk.stage_events = C->stage_ev;
 	HIP_TRY(hipMemsetAsync(d_path_used, 0, 4, C->stream));
+	// seed + probe run inside the search kernel (kernels.hip): ev[0]..ev[1] brackets nothing for a single-end batch
 	HIP_TRY(hipEventRecord(C->ev[0], C->stream));
-	HIP_TRY(launch_seed_probe(C->X, (const uint8_t *)d_bases, (const uint64_t *)d_offs, n, max_read_len, po, C->stream));
 	HIP_TRY(hipEventRecord(C->ev[1], C->stream));
 	C->stage_valid = true;
-	HIP_TRY(launch_search_se(C->X, C->params, (const uint8_t *)d_bases, (const uint64_t *)d_offs, n, max_read_len, po,
+	HIP_TRY(launch_search_se(C->X, C->params, (const uint8_t *)d_bases, (const uint64_t *)d_offs, n, max_read_len,
 	                         (urmapx_result *)d_results, (urmapx_path_op *)d_path_ops, (uint32_t *)d_path_used, wk, C->stream));
 	HIP_TRY(hipEventRecord(C->ev[2], C->stream));
 	C->ev_valid = true;
