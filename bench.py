@@ -26,7 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-CODE_VERSION = "r2"    # committed PMC profiles carry the code version they were taken on (pmc_traffic)
+CODE_VERSION = "r3"    # committed PMC profiles carry the code version they were taken on (pmc_traffic)
 
 # work per read of the reference on the survey's 40 Mbp planning genome (instrumented build)
 SURVEY_WORK_PER_READ = {
@@ -668,12 +668,15 @@ def kernel_table(api, pe, L, nb, kms, counters, total_bp, gather_loads_s, stage_
     query flanks they are aligned with.  Single-end: the search is six launches (main / DP / finalize, then the same
     for the few reads whose lists outgrew the first pass's); paired-end: one search kernel."""
     c = counters
-    rows = [("seed_probe_kernel", float(kms[0]), 5.0 * c["n_getblob"] + L)]
+    probe_bytes = 5.0 * c["n_getblob"] + L
     if pe or stage_ms is None:
+        rows = [("seed_probe_kernel", float(kms[0]), probe_bytes)]
         rows.append(("search_pe_kernel" if pe else "search_se_kernel", float(kms[1]),
                      5.0 * c["n_rowhop"] + c["n_extbases"] + c["n_dptarget"] + api.RESULT_DTYPE.itemsize))
     else:
-        rows.append(("search_se_kernel", float(stage_ms[0]), 5.0 * c["n_rowhop"] + c["n_extbases"] + api.RESULT_DTYPE.itemsize))
+        # single-end: seed + probe run inside the search kernel (the next read's slots are gathered into LDS while the
+        # current read is searched), so its algorithmic bytes are both stages'
+        rows = [("search_se_kernel", float(stage_ms[0]), probe_bytes + 5.0 * c["n_rowhop"] + c["n_extbases"] + api.RESULT_DTYPE.itemsize)]
         rows.append(("dp_kernel", float(stage_ms[1]), 2.0 * c["n_dptarget"]))
         rows.append(("finalize_se_kernel", float(stage_ms[2]), float(api.RESULT_DTYPE.itemsize)))
         rows.append(("second pass (search + dp + finalize over the reads whose lists outgrew the first)", float(sum(stage_ms[3:6])), 0.0))

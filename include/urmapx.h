@@ -195,6 +195,11 @@ int urmapx_build_slots(const uint8_t *seqdata, uint32_t seqdata_size, uint32_t w
  * order-dependent inserts (UpdateSlot / FindFreeSlot, ufindex.cpp:194-322,987-1000) on the host.  Byte-identical output.
  * d_seqdata: the sequence store already resident on `device`, or NULL (then the host array seqdata is uploaded). */
 int urmapx_make_ufi_gpu(int device, const char *fasta_path, const char *ufi_path, uint32_t word_length, uint32_t max_ix, uint64_t slots);
+/* Either builder (device < 0: host) with cmd_make_ufi's label option: by default sequence labels are cut at the first
+ * white space (ufindexio.cpp:123-128); URMAPX_UFI_KEEP_LABELS = the reference's -notrunclabels. */
+#define URMAPX_UFI_KEEP_LABELS 1u
+int urmapx_make_ufi_opts(int device, const char *fasta_path, const char *ufi_path, uint32_t word_length, uint32_t max_ix,
+                         uint64_t slots, unsigned flags);
 int urmapx_build_slots_gpu(int device, const uint8_t *seqdata, const void *d_seqdata, uint32_t seqdata_size, uint32_t word_length,
                            uint32_t max_ix, uint64_t slots, uint8_t *blob, uint32_t *truncated_out);
 

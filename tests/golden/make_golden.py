@@ -13,6 +13,9 @@ outputs are what the reference itself wrote:
                                                    -samout A.sam -tabbedout A.tab`
   r.fa, r.ufi.gz, pe120_rep_*               repeat-rich second genome: pairs with a second-best pair (see make_repeat_set)
 
+  ufi_opts.json   sha256 / slot count / labels of the reference's .ufi for -make_ufi option sets (-load_factor, -veryfast,
+                  -notrunclabels); python make_golden.py ufiopts regenerates only this file
+
   hitstats.json   the count lines of the reference's end-of-run report (State1::HitStats, state1.cpp:593-632) for the
                   sets above, incl. -minq 3 runs (python make_golden.py hitstats regenerates only this file)
 
@@ -109,6 +112,32 @@ def make_hitstats(tmp):
         f.write("\n")
 
 
+UFI_OPT_CASES = [  # (key, FASTA, options): -make_ufi options beyond -slots (ufindexio.cpp:117-150)
+    ("load_factor_0.3", "g.fa", ["-load_factor", "0.3"]),
+    ("load_factor_0.9_veryfast", "g.fa", ["-load_factor", "0.9", "-veryfast"]),
+    ("notrunclabels", "g.fa", ["-notrunclabels", "-slots", "100003"]),
+    ("trunclabels_default", "g.fa", ["-slots", "100003"]),
+]
+
+
+def make_ufi_opts(tmp):
+    """ufi_opts.json: for each option set, the sha256 of the .ufi the reference wrote, its slot count and its labels."""
+    import hashlib
+    import json
+    out = {}
+    shutil.copy(os.path.join(HERE, "g.fa"), os.path.join(tmp, "g.fa"))
+    for key, fa, opts in UFI_OPT_CASES:
+        ol.run_ref(["-make_ufi", fa, "-output", "o.ufi"] + opts, cwd=tmp)
+        p = os.path.join(tmp, "o.ufi")
+        w, maxix, sds, slots = ol.ufi_header(p)
+        idx = ol.Index.load(p)
+        out[key] = {"options": opts, "sha256": hashlib.sha256(open(p, "rb").read()).hexdigest(), "slots": int(slots), "max_ix": int(maxix),
+                    "labels": [d[0] for d in idx.directory()]}
+    with open(os.path.join(HERE, "ufi_opts.json"), "w") as f:
+        json.dump(out, f, indent=1)
+        f.write("\n")
+
+
 def main():
     assert ol.have_ref(), "build oracle/_ref/urmap first (make -C oracle ref)"
     tmp = os.path.join(HERE, "_tmp")
@@ -159,6 +188,7 @@ def main():
         shutil.copy(os.path.join(tmp, name + ".tab"), os.path.join(HERE, name + ".tab"))
     make_repeat_set(tmp)
     make_hitstats(tmp)
+    make_ufi_opts(tmp)
     shutil.rmtree(tmp)
     print("golden fixtures written to", HERE)
 
@@ -168,6 +198,11 @@ if __name__ == "__main__":
         _tmp = os.path.join(HERE, "_tmp")
         os.makedirs(_tmp, exist_ok=True)
         make_hitstats(_tmp)
+        shutil.rmtree(_tmp)
+    elif sys.argv[1:] == ["ufiopts"]:
+        _tmp = os.path.join(HERE, "_tmp")
+        os.makedirs(_tmp, exist_ok=True)
+        make_ufi_opts(_tmp)
         shutil.rmtree(_tmp)
     else:
         main()

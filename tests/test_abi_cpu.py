@@ -253,3 +253,25 @@ def test_file_to_file_call_and_gpu_builder_fail_loudly_without_a_device(gold_ufi
     r = subprocess.run([os.path.join(ROOT, "urmap_amd", "urmap"), "-map", os.path.join(GOLD, "se150.fq"), "-ufi", gold_ufi,
                         "-samout", os.path.join(tmp_path, "y.sam")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert r.returncode == 1 and b"Fatal error" in r.stderr and b"Uploading index" in r.stderr
+
+
+@pytest.mark.parametrize("key", ["load_factor_0.3", "load_factor_0.9_veryfast", "notrunclabels", "trunclabels_default"])
+def test_cli_make_ufi_options_reproduce_reference_index(tmp_path, key):
+    """cmd_make_ufi's options beyond -slots (ufindexio.cpp:117-150): -load_factor (slots = GetPrime(int64(size / LF))),
+    -veryfast (MaxIx 3), -notrunclabels (whole label lines).  tests/golden/ufi_opts.json holds what the reference binary
+    wrote for g.fa (make_golden.py ufiopts); the host builder (-host, no GPU needed) must write the same bytes."""
+    import hashlib
+    import json
+    import subprocess
+    case = json.load(open(os.path.join(GOLD, "ufi_opts.json")))[key]
+    out = os.path.join(tmp_path, "o.ufi")
+    log = os.path.join(tmp_path, "make.log")
+    r = subprocess.run([os.path.join(ROOT, "urmap_amd", "urmap"), "-make_ufi", os.path.join(GOLD, "g.fa"), "-output", out, "-host",
+                        "-log", log] + case["options"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    w, maxix, sds, slots = ol.ufi_header(out)
+    assert (slots, maxix) == (case["slots"], case["max_ix"])
+    assert [d[0] for d in ol.Index.load(out).directory()] == case["labels"]
+    assert hashlib.sha256(open(out, "rb").read()).hexdigest() == case["sha256"]
+    text = open(log).read()  # -log FILE: command line, start and finish stamps (myutils.cpp)
+    assert "-make_ufi" in text and "Started " in text and "Finished " in text and "Elapsed time " in text

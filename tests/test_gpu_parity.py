@@ -766,3 +766,35 @@ def test_cli_long_single_end_reads(small_case, tmp_path):
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     assert ol.sam_records(out) == ol.sam_records(osam)
     assert sum(1 for l in ol.sam_records(out) if not l.startswith(b"@") and l.split(b"\t")[2] != b"*") > 200
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("quiet", [False, True])
+def test_cli_log_file_holds_rps_and_the_report(tmp_path, quiet):
+    """-log FILE (State1::HitStats, state1.cpp:593-632): `@rps=` goes to the log only (Log), the report to the terminal
+    and the log (ProgressLog); -quiet silences the terminal, not the log.  -trunclabels is accepted and changes nothing
+    for -map (SetSAM cuts the read label itself)."""
+    import gzip
+    import json
+    import os
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gold = os.path.join(root, "tests", "golden")
+    ufi = os.path.join(tmp_path, "g.ufi")
+    with gzip.open(os.path.join(gold, "g.ufi.gz"), "rb") as z, open(ufi, "wb") as f:
+        f.write(z.read())
+    out, log = os.path.join(tmp_path, "o.sam"), os.path.join(tmp_path, "run.log")
+    r = subprocess.run([os.path.join(root, "urmap_amd", "urmap"), "-map", os.path.join(gold, "se150.fq"), "-ufi", ufi, "-samout", out,
+                        "-log", log, "-trunclabels"] + (["-quiet"] if quiet else []), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    text = open(log).read()
+    assert re.search(r"^@rps=\d+\.\d$", text, re.M), text
+    assert "-map" in text.split("\n")[1] and "Started " in text and "Finished " in text
+    want = json.load(open(os.path.join(gold, "hitstats.json")))["se150"]
+    keep = ("  Reads (", "  Mapped Q>=", "  Mapped Q< ", "  Unmapped (")
+    assert [ln for ln in text.split("\n") if any(k in ln for k in keep)] == want
+    err = r.stderr.decode()
+    assert ("Mapped Q>=" in err) == (not quiet) and "@rps=" not in err
+    got = [l for l in open(out, "rb").read().split(b"\n") if l and not l.startswith(b"@PG")]
+    assert got == [l for l in open(os.path.join(gold, "se150.sam"), "rb").read().split(b"\n") if l]

@@ -112,7 +112,7 @@ inline int comp_code_of(uint8_t c) {  // complement letter; lower-case 'u' has n
 	return k < 0 ? -1 : 3 - k;
 }
 
-bool load_fasta(const char *path, std::vector<std::string> &labels, std::vector<std::string> &seqs) {
+bool load_fasta(const char *path, std::vector<std::string> &labels, std::vector<std::string> &seqs, bool trunc_labels) {
 	FILE *f = fopen(path, "rb");
 	if (!f) return false;
 	std::vector<char> buf(1 << 22);
@@ -125,6 +125,7 @@ bool load_fasta(const char *path, std::vector<std::string> &labels, std::vector<
 		if (!l.empty() && l[0] == '>') {
 			end_rec();
 			size_t e = 1;
+			if (!trunc_labels) e = l.size();  // -notrunclabels (ufindexio.cpp:123-128, fastaseqsource.cpp:31)
 			while (e < l.size() && !isspace((unsigned char)l[e])) ++e;  // -make_ufi truncates labels at white space
 			labels.push_back(l.substr(1, e - 1));
 			seqs.emplace_back();
@@ -347,7 +348,7 @@ extern "C" int urmapx_build_slots(const uint8_t *seqdata, uint32_t size, uint32_
 
 extern "C" int urmapx_build_slots_gpu(int device, const uint8_t *seqdata, const void *d_seqdata, uint32_t size, uint32_t W,
                                       uint32_t max_ix, uint64_t slots, uint8_t *blob, uint32_t *truncated_out);
-static int make_ufi_impl(const char *fasta_path, const char *ufi_path, uint32_t W, uint32_t max_ix, uint64_t slots, int device);
+static int make_ufi_impl(const char *fasta_path, const char *ufi_path, uint32_t W, uint32_t max_ix, uint64_t slots, int device, unsigned flags = 0);
 
 // -make_ufi FASTA -output UFI [-wordlength W] [-maxix N] -slots S
 extern "C" int urmapx_make_ufi(const char *fasta_path, const char *ufi_path, uint32_t W, uint32_t max_ix, uint64_t slots) {
@@ -358,10 +359,16 @@ extern "C" int urmapx_make_ufi_gpu(int device, const char *fasta_path, const cha
 	return device < 0 ? URMAPX_E_ARG : make_ufi_impl(fasta_path, ufi_path, W, max_ix, slots, device);
 }
 
-static int make_ufi_impl(const char *fasta_path, const char *ufi_path, uint32_t W, uint32_t max_ix, uint64_t slots, int device) {
+// device < 0: host builder; flags: URMAPX_UFI_*
+extern "C" int urmapx_make_ufi_opts(int device, const char *fasta_path, const char *ufi_path, uint32_t W, uint32_t max_ix, uint64_t slots,
+                                    unsigned flags) {
+	return make_ufi_impl(fasta_path, ufi_path, W, max_ix, slots, device, flags);
+}
+
+static int make_ufi_impl(const char *fasta_path, const char *ufi_path, uint32_t W, uint32_t max_ix, uint64_t slots, int device, unsigned flags) {
 	if (!fasta_path || !ufi_path || slots == 0) return URMAPX_E_ARG;
 	std::vector<std::string> labels, seqs;
-	if (!load_fasta(fasta_path, labels, seqs)) return URMAPX_E_IO;
+	if (!load_fasta(fasta_path, labels, seqs, !(flags & URMAPX_UFI_KEEP_LABELS))) return URMAPX_E_IO;
 	if (seqs.empty()) return URMAPX_E_FORMAT;
 	std::vector<uint32_t> lens, offs;
 	uint64_t total = 0;

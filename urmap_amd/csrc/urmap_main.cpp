@@ -25,6 +25,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <deque>
 #include <memory>
 #include <mutex>
@@ -48,8 +49,9 @@ using namespace urx;
 }
 
 struct Opts {
-	std::string map, map2, reverse, make_ufi, ufi, samout, tabbedout, output;
-	bool veryfast = false, quiet = false, minq_given = false, host_build = false;
+	std::string map, map2, reverse, make_ufi, ufi, samout, tabbedout, output, log;
+	bool veryfast = false, quiet = false, minq_given = false, host_build = false, notrunclabels = false;
+	double load_factor = 0.6;  // myopts.h: FLT_OPT(load_factor, 0.6, ...)
 	unsigned threads = 0, wordlength = 24, maxix = 0, minq = 10;
 	unsigned long long slots = 0;
 	int gpu = 0, gpus = 1, streams = 2;
@@ -85,10 +87,43 @@ static Opts parse(int argc, char **argv) {
 		else if (a == "-veryfast") o.veryfast = true;
 		else if (a == "-host") o.host_build = true;
 		else if (a == "-quiet") o.quiet = true;
-		else if (a == "-log") (void)val();
+		else if (a == "-log") o.log = val();
+		else if (a == "-load_factor") o.load_factor = atof(val());
+		else if (a == "-trunclabels") {}  // -map: SetSAM cuts the read label at the first blank whatever this says (setsam.cpp); -make_ufi: the default
+		else if (a == "-notrunclabels") o.notrunclabels = true;
 		else die("Unknown option %s", a.c_str());
 	}
 	return o;
+}
+
+// -log FILE (myutils.cpp: the log file every command opens): program line, command line, start time; whatever the
+// command Log()s; finish time.  HitStats writes "@rps=" and the report to it (state1.cpp:593-632).
+static FILE *g_log = nullptr;
+static std::chrono::steady_clock::time_point g_t0;
+static void log_open(const Opts &o, int argc, char **argv) {
+	if (o.log.empty()) return;
+	g_log = fopen(o.log.c_str(), "w");
+	if (!g_log) die("Cannot open log file '%s'", o.log.c_str());
+	g_t0 = std::chrono::steady_clock::now();
+	fprintf(g_log, "urmap (MI355X build)\n");
+	for (int i = 0; i < argc; ++i) fprintf(g_log, "%s ", argv[i]);
+	const time_t t = time(nullptr);
+	fprintf(g_log, "\nStarted %s", asctime(localtime(&t)));
+}
+static void log_close() {
+	if (!g_log) return;
+	const time_t t = time(nullptr);
+	const unsigned secs = (unsigned)std::chrono::duration<double>(std::chrono::steady_clock::now() - g_t0).count();
+	fprintf(g_log, "\nFinished %s", asctime(localtime(&t)));
+	fprintf(g_log, "Elapsed time %02u:%02u\n", secs / 60, secs % 60);
+	fclose(g_log);
+	g_log = nullptr;
+}
+// ProgressLog (myutils.cpp): the same text to the terminal and to the log file
+static void progress_log(bool quiet, const char *fmt, ...) {
+	va_list ap;
+	if (!quiet) { va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap); }
+	if (g_log) { va_start(ap, fmt); vfprintf(g_log, fmt, ap); va_end(ap); }
 }
 
 static void check(int rc, const char *what) {
@@ -124,7 +159,9 @@ static int cmd_map(const Opts &o, int argc, char **argv) {
 	if (getenv("URMAPX_VERBOSE"))
 		fprintf(stderr, "stage busy seconds: parse %.2f, gpu (copies + kernels, summed over %d lanes) %.2f, format %.2f, write %.2f; %d host threads\n",
 		        rep.parse_s, rep.lanes, rep.gpu_s, rep.format_s, rep.write_s, rep.host_threads);
-	if (!o.quiet) {  // State1::HitStats (state1.cpp:593-632): same lines, sub-second timers, "GPU n" where it says "n threads"
+	if (g_log) fprintf(g_log, "@rps=%.1f\n", map_s > 0 ? (double)n_reads / map_s : 0.0);  // Log("@rps=..."), state1.cpp:607
+	if (!o.quiet || g_log) {  // State1::HitStats (state1.cpp:593-632): same lines, sub-second timers, "GPU n" where it says "n threads"; ProgressLog = terminal + log file
+		const bool q = o.quiet;
 		auto pct = [&](unsigned long long x) { return n_reads ? 100.0 * (double)x / (double)n_reads : 0.0; };
 		auto commas = [](unsigned long long x) {  // IntToStrCommas (myutils.cpp:1400-1418)
 			std::string d = std::to_string(x), r;
@@ -146,17 +183,17 @@ static int cmd_map(const Opts &o, int argc, char **argv) {
 			else snprintf(b, sizeof b, "%.3g", d);
 			return std::string(b);
 		};
-		fprintf(stderr, "\n%16.1f  Seconds to load index\n", load_s);
-		if (map_s < 180) fprintf(stderr, "%16.1f  Seconds in mapper\n", map_s);
-		else if (map_s < 2 * 60 * 60) fprintf(stderr, "%16.1f  Minutes in mapper\n", map_s / 60.0);
-		else fprintf(stderr, "%16.1f  Hours in mapper\n", map_s / 3600.0);
-		fprintf(stderr, "%16s  Reads (%s)\n", commas(n_reads).c_str(), short_int(n_reads).c_str());
-		if (o.gpus == 1) fprintf(stderr, "%16.0f  Reads/sec. (GPU %d)\n", map_s > 0 ? (double)n_reads / map_s : 0.0, o.gpu);
-		else fprintf(stderr, "%16.0f  Reads/sec. (%d GPUs)\n", map_s > 0 ? (double)n_reads / map_s : 0.0, o.gpus);
-		fprintf(stderr, "%16s  Mapped Q>=%u (%.1f%%)\n", commas(n_accept).c_str(), minq, pct(n_accept));
-		fprintf(stderr, "%16s  Mapped Q< %u (%.1f%%)\n", commas(n_reject).c_str(), minq, pct(n_reject));
-		fprintf(stderr, "%16s  Unmapped (%.1f%%)\n\n", commas(n_nohit).c_str(), pct(n_nohit));
-		if (o.minq_given && !paired) fprintf(stderr, "\nWARNING: Option -minq not used\n\n");
+		progress_log(q, "\n%16.1f  Seconds to load index\n", load_s);
+		if (map_s < 180) progress_log(q, "%16.1f  Seconds in mapper\n", map_s);
+		else if (map_s < 2 * 60 * 60) progress_log(q, "%16.1f  Minutes in mapper\n", map_s / 60.0);
+		else progress_log(q, "%16.1f  Hours in mapper\n", map_s / 3600.0);
+		progress_log(q, "%16s  Reads (%s)\n", commas(n_reads).c_str(), short_int(n_reads).c_str());
+		if (o.gpus == 1) progress_log(q, "%16.0f  Reads/sec. (GPU %d)\n", map_s > 0 ? (double)n_reads / map_s : 0.0, o.gpu);
+		else progress_log(q, "%16.0f  Reads/sec. (%d GPUs)\n", map_s > 0 ? (double)n_reads / map_s : 0.0, o.gpus);
+		progress_log(q, "%16s  Mapped Q>=%u (%.1f%%)\n", commas(n_accept).c_str(), minq, pct(n_accept));
+		progress_log(q, "%16s  Mapped Q< %u (%.1f%%)\n", commas(n_reject).c_str(), minq, pct(n_reject));
+		progress_log(q, "%16s  Unmapped (%.1f%%)\n\n", commas(n_nohit).c_str(), pct(n_nohit));
+		if (o.minq_given && !paired) progress_log(q, "\nWARNING: Option -minq not used\n\n");
 	}
 	urmapx_index_close(I);
 	const unsigned long long n_unsupported = rep.unsupported;
@@ -218,16 +255,18 @@ static int cmd_make_ufi(const Opts &o) {
 		fseeko(f, 0, SEEK_END);
 		const int64_t size = (int64_t)ftello(f);
 		fclose(f);
-		slots = get_prime((uint64_t)(int64_t)((double)size / 0.6));
-		if (slots == 0) die("GetPrime(%.3g) overflow", (double)size / 0.6);
+		if (!(o.load_factor > 0)) die("-load_factor must be positive");
+		slots = get_prime((uint64_t)(int64_t)((double)size / o.load_factor));  // int64(GenomeSize/LoadFactor), ufindexio.cpp:146
+		if (slots == 0) die("GetPrime(%.3g) overflow", (double)size / o.load_factor);
 	}
 	unsigned maxix = o.maxix ? o.maxix : (o.veryfast ? 3u : 32u);
 	// counting passes, head slots and the overflow list on the GPU, the order-dependent inserts on the host; -host (or no
 	// usable device) builds everything on the host.  Same bytes either way.
-	int rc = o.host_build ? URMAPX_E_NODEVICE : urmapx_make_ufi_gpu(o.gpu, o.make_ufi.c_str(), o.output.c_str(), o.wordlength, maxix, slots);
-	if (rc == URMAPX_E_NODEVICE) {
-		if (!o.host_build) fprintf(stderr, "make_ufi: no usable GPU, building on the host\n");
-		rc = urmapx_make_ufi(o.make_ufi.c_str(), o.output.c_str(), o.wordlength, maxix, slots);
+	const unsigned flags = o.notrunclabels ? URMAPX_UFI_KEEP_LABELS : 0u;
+	int rc = o.host_build ? URMAPX_E_NODEVICE : urmapx_make_ufi_opts(o.gpu, o.make_ufi.c_str(), o.output.c_str(), o.wordlength, maxix, slots, flags);
+	if (rc == URMAPX_E_NODEVICE || (rc == URMAPX_E_NOMEM && !o.host_build)) {  // the GPU passes need ~17 bytes per slot of HBM
+		if (!o.host_build) fprintf(stderr, "make_ufi: %s, building on the host\n", rc == URMAPX_E_NOMEM ? "not enough GPU memory for the counting passes" : "no usable GPU");
+		rc = urmapx_make_ufi_opts(-1, o.make_ufi.c_str(), o.output.c_str(), o.wordlength, maxix, slots, flags);
 	}
 	check(rc, "make_ufi");
 	return 0;
@@ -236,8 +275,9 @@ static int cmd_make_ufi(const Opts &o) {
 int main(int argc, char **argv) {
 	setenv("OMP_WAIT_POLICY", "passive", 0);  // idle pool threads sleep: three pipeline stages share the cores
 	Opts o = parse(argc, argv);
-	if (!o.map.empty() || !o.map2.empty()) return cmd_map(o, argc, argv);
-	if (!o.make_ufi.empty()) return cmd_make_ufi(o);
+	log_open(o, argc, argv);
+	if (!o.map.empty() || !o.map2.empty()) { const int rc = cmd_map(o, argc, argv); log_close(); return rc; }
+	if (!o.make_ufi.empty()) { const int rc = cmd_make_ufi(o); log_close(); return rc; }
 	fprintf(stderr, "urmap (MI355X build)\n  urmap -map reads.fq -ufi index.ufi -samout out.sam [-veryfast] [-gpu D] [-gpus N] [-streams K]\n"
 	                "  urmap -map2 R1.fq -reverse R2.fq -ufi index.ufi -samout out.sam [-tabbedout out.tab] [-gpu D] [-gpus N]\n"
 	                "  urmap -make_ufi genome.fa -output index.ufi [-slots N] [-wordlength W] [-maxix M]\n");
