@@ -105,10 +105,15 @@ __device__ __forceinline__ uint64_t mod_slots(uint64_t h, uint64_t d, uint64_t m
 	return r;
 }
 
-// (a + b) mod N for a < N, small b
+// (a + b) mod N for a < N, b < 2^16 (a chain step).  No `%`: a 64-bit remainder is a 150-instruction software
+// routine on this target and was inlined at every one of the chain walk's 18 call sites (15 KB of a kernel that has
+// to stay near the instruction cache's 64 KB).  One conditional subtraction (two selects, no branch) is exact for a
+// table of >= 2^16 slots; smaller tables (test indexes) take the loop behind a wave-uniform branch.
 __device__ __forceinline__ uint64_t addmod(uint64_t a, uint64_t b, uint64_t N) {
 	uint64_t x = a + b;
-	if (x >= N) { x -= N; if (x >= N) x %= N; }
+	x = x >= N ? x - N : x;
+	if (N < 65536ull)
+		while (x >= N) x -= N;
 	return x;
 }
 

@@ -20,6 +20,8 @@
 //
 // DP scores are kept in fp32 exactly as the reference does (small integers and a -9e9f "minus infinity" that
 // absorbs small addends), so every tie and every trace bit is reproduced without re-deriving integer sentinels.
+#include <cstdlib>
+
 #include "kernels.h"
 
 #include "dev_common.h"
@@ -395,57 +397,61 @@ struct SearchWave {
 		const WideScratch wsv = ws;
 		uint32_t vst = 0;
 
-		if (startq > 0) {
-			if (startdb < (uint32_t)startq) return;
-			const int leftQL = startq;
-			const uint32_t leftTHi = startdb - 1;
-			const uint32_t leftTL = (uint32_t)(leftQL + BR);
-			if (leftTL >= leftTHi) return;
-			const uint32_t leftTLo = leftTHi - leftTL + 1;
-			if (load_window(leftTLo, (int)leftTL)) return;
+		// the two flanks through ONE copy of the banded DP (the kernel's code has to stay near the instruction cache's size)
+		const int rightQLo = startq + len;
+#pragma unroll 1
+		for (int side = 0; side < 2; ++side) {
+			const bool left = side == 0;
+			int fql;
+			uint32_t tlo, tl;
+			const uint8_t *fq;
+			if (left) {
+				if (startq <= 0) continue;
+				if (startdb < (uint32_t)startq) return;
+				fql = startq;
+				const uint32_t leftTHi = startdb - 1;
+				tl = (uint32_t)(fql + BR);
+				if (tl >= leftTHi) return;
+				tlo = leftTHi - tl + 1;
+				fq = Q;
+			} else {
+				if (rightQLo >= QL) continue;
+				fql = QL - rightQLo;
+				tlo = startdb + (uint32_t)len;
+				uint32_t thi = tlo + (uint32_t)fql + (uint32_t)BR;
+				if (thi >= TL) thi = TL - 1;
+				tl = thi - tlo + 1;
+				fq = Q + rightQLo;
+			}
+			if (load_window(tlo, (int)tl)) return;
 			// the DP stops as soon as the flank cannot stay within what the penalty cap leaves (viterbi_dev.h); the test
 			// that would discard it follows right below, so the outcome is the same
-			const int allGapL = P.gap_open_score + (leftQL - 1) * P.gap_ext_score;
-			const int needL = leftQL - (maxPen - totalPen);
-			bool abortedL = false;
-			int leftScore = (int)viterbi_wave<true>(VP, Q, leftQL, sT, (int)leftTL, true, false, tb, TB_ROWS8, wsv, RL, vst, lane,
-			                                        (float)needL, allGapL < needL ? &abortedL : nullptr);
-			if (abortedL) return;
+			const int allGap = P.gap_open_score + (fql - 1) * P.gap_ext_score;
+			const int need = fql - (maxPen - totalPen);
+			bool aborted = false;
+			RevOps R;
+			R.ops = left ? ropsL : ropsR;
+			int score = (int)viterbi_wave<true>(VP, fq, fql, sT, (int)tl, left, !left, tb, TB_ROWS8, wsv, R, vst, lane, (float)need,
+			                                    allGap < need ? &aborted : nullptr);
+			if (aborted) return;
 			status |= vst;
-			// TrimLeftIs (pathinfo.cpp:153-171): the leading I run is the last run in traceback order
-			int nTrimI = 0;
-			if (RL.n > 0) {
-				uint32_t lastop = ropsL[RL.n - 1];
-				if ((lastop & 3u) == OP_I) { nTrimI = (int)(lastop >> 2); --RL.n; }
+			if (left) {
+				RL.n = R.n;
+				// TrimLeftIs (pathinfo.cpp:153-171): the leading I run is the last run in traceback order
+				int nTrimI = 0;
+				if (RL.n > 0) {
+					uint32_t lastop = ropsL[RL.n - 1];
+					if ((lastop & 3u) == OP_I) { nTrimI = (int)(lastop >> 2); --RL.n; }
+				}
+				combinedTLo = tlo + (uint32_t)nTrimI;
+			} else {
+				RR.n = R.n;
+				// TrimRightIs (pathinfo.cpp:173-190): trailing I run = first run in traceback order, never the whole path
+				if (RR.n > 1 && (ropsR[0] & 3u) == OP_I) rtrim = 1;
 			}
-			combinedTLo = leftTLo + (uint32_t)nTrimI;
-			int allGap = P.gap_open_score + (leftQL - 1) * P.gap_ext_score;
-			if (allGap > leftScore) leftScore = allGap;
-			totalScore += leftScore;
-			totalPen += leftQL - leftScore;
-			if (totalPen > maxPen) return;
-		}
-		const int rightQLo = startq + len;
-		if (rightQLo < QL) {
-			const int rightQL = QL - rightQLo;
-			const uint32_t rightTLo = startdb + (uint32_t)len;
-			uint32_t rightTHi = rightTLo + (uint32_t)rightQL + (uint32_t)BR;
-			if (rightTHi >= TL) rightTHi = TL - 1;
-			const uint32_t rightTL = rightTHi - rightTLo + 1;
-			if (load_window(rightTLo, (int)rightTL)) return;
-			const int allGapR = P.gap_open_score + (rightQL - 1) * P.gap_ext_score;
-			const int needR = rightQL - (maxPen - totalPen);
-			bool abortedR = false;
-			int rightScore = (int)viterbi_wave<true>(VP, Q + rightQLo, rightQL, sT, (int)rightTL, false, true, tb, TB_ROWS8, wsv, RR, vst, lane,
-			                                         (float)needR, allGapR < needR ? &abortedR : nullptr);
-			if (abortedR) return;
-			status |= vst;
-			// TrimRightIs (pathinfo.cpp:173-190): trailing I run = first run in traceback order, never the whole path
-			if (RR.n > 1 && (ropsR[0] & 3u) == OP_I) rtrim = 1;
-			int allGap = P.gap_open_score + (rightQL - 1) * P.gap_ext_score;
-			if (allGap > rightScore) rightScore = allGap;
-			totalScore += rightScore;
-			totalPen += rightQL - rightScore;
+			if (allGap > score) score = allGap;
+			totalScore += score;
+			totalPen += fql - score;
 			if (totalPen > maxPen) return;
 		}
 		if (vst & (URMAPX_ST_BAND_TOO_WIDE | URMAPX_ST_PATH_OVERFLOW)) return;
@@ -647,7 +653,7 @@ struct SearchWave {
 		return mapq;
 	}
 
-	// ---- this read's k-mer slots, as the LDS-DMA gathers of probe_issue left them ----
+	// ---- this read's k-mer slots, as the LDS-DMA gathers of probe_gather left them ----
 	// entry e = strand * NCH*64 + i, i = the PLUS-strand position of the k-mer's bases: the minus-strand k-mer at minus
 	// position q covers the same bases as the plus-strand k-mer at nwords-1-q.  pr_lo / pr_hi = the two aligned dwords
 	// around the 5-byte slot, pr_sl = the low half of the slot number (its two low bits say where the slot starts in
@@ -663,11 +669,16 @@ struct SearchWave {
 		pos = (uint32_t)(v >> 8);
 	}
 
-	// State1::SetSlotsVec + GetBlob for the NEXT read while this one is searched: nq = that read's bytes in LDS, QLn its
-	// length.  Per 64-position chunk: letter ballots, the 2 x 64 slot numbers (kmer_slots), then four LDS-DMA gathers --
-	// the two dwords of every slot go from the 27 GB table straight into pr_lo / pr_hi, no register holds them, and the
-	// wavefront goes on with the current read.  The caller has made sure nobody still reads the pr_* arrays.
-	__device__ __forceinline__ void probe_issue(const uint8_t *nq, int QLn) {
+	// State1::SetSlotsVec + GetBlob for the NEXT read while this one is searched, in two parts so that the hashing's
+	// registers and the current read's chain heads are never alive together:
+	//   probe_hash    nq = that read's bytes in LDS, QLn its length.  Per 64-position chunk: letter ballots, the 2 x 64
+	//                 slot numbers (kmer_slots); their low halves go to stage_sl[group][lane], bit 32 and "has a k-mer"
+	//                 as ballots to stage_b[2 * group + 0 / 1] -- LDS that is idle between two gather steps
+	//   probe_gather  (the current read's chain heads are in registers now, its pr_* entries dead) copies the staged
+	//                 slot numbers to pr_sl / pr_hb and issues two LDS-DMA gathers per group: the two dwords of every
+	//                 slot go from the 27 GB table straight into pr_lo / pr_hi, no register holds them, and the
+	//                 wavefront goes on with the current read
+	__device__ __forceinline__ void probe_hash(const uint8_t *nq, int QLn, uint32_t *stage_sl, uint64_t *stage_b) {
 		const uint32_t nwn = (uint32_t)(QLn - (W - 1));
 		auto planes = [&](int c, uint64_t &lo, uint64_t &hi, uint64_t &inv, uint64_t &invm) {
 			const int p = 64 * c + lane;
@@ -680,7 +691,6 @@ struct SearchWave {
 		};
 		uint64_t lo0, hi0, inv0, invm0;
 		planes(0, lo0, hi0, inv0, invm0);
-		wait_lgkm0();  // every earlier LDS read of the pr_* arrays has returned
 #pragma unroll
 		for (int c = 0; c < NCH; ++c) {
 			if (64u * c < nwn) {  // wave-uniform: chunks that hold a k-mer start
@@ -689,18 +699,33 @@ struct SearchWave {
 				uint64_t sp, sm;
 				bool vp, vm;
 				kmer_slots(X, lo0, hi0, inv0, invm0, lo1, hi1, inv1, invm1, lane, 64u * c + lane, nwn, sp, sm, vp, vm);
-				pr_sl[c * 64 + lane] = vp ? (uint32_t)sp : 0u;
-				pr_sl[(NCH + c) * 64 + lane] = vm ? (uint32_t)sm : 0u;
+				stage_sl[c * 64 + lane] = (uint32_t)sp;
+				stage_sl[(NCH + c) * 64 + lane] = (uint32_t)sm;
 				const uint64_t hbp = __ballot(vp && ((sp >> 32) & 1ull)), hbm = __ballot(vm && ((sm >> 32) & 1ull));
-				if (lane == 0) { pr_hb[c] = hbp; pr_hb[NCH + c] = hbm; }
-				const uint8_t *zero = reinterpret_cast<const uint8_t *>(g_zero16);
-				const uint8_t *ap = vp ? gblob + ((5ull * sp) & ~3ull) : zero;
-				const uint8_t *am = vm ? gblob + ((5ull * sm) & ~3ull) : zero;
-				glds_dword(ap, lds_addr(pr_lo + c * 64));
-				glds_dword(ap + 4, lds_addr(pr_hi + c * 64));
-				glds_dword(am, lds_addr(pr_lo + (NCH + c) * 64));
-				glds_dword(am + 4, lds_addr(pr_hi + (NCH + c) * 64));
+				const uint64_t okp = __ballot(vp), okm = __ballot(vm);
+				if (lane == 0) {
+					stage_b[2 * c] = hbp; stage_b[2 * c + 1] = okp;
+					stage_b[2 * (NCH + c)] = hbm; stage_b[2 * (NCH + c) + 1] = okm;
+				}
 				lo0 = lo1; hi0 = hi1; inv0 = inv1; invm0 = invm1;
+			}
+		}
+	}
+	__device__ __forceinline__ void probe_gather(int QLn, const uint32_t *stage_sl, const uint64_t *stage_b) {
+		const uint32_t nwn = (uint32_t)(QLn - (W - 1));
+		wait_lgkm0();  // every earlier LDS read of the pr_* arrays has returned
+#pragma unroll
+		for (int g = 0; g < NSEG; ++g) {
+			if (64u * (g % NCH) < nwn) {
+				const uint64_t hb = stage_b[2 * g], ok = stage_b[2 * g + 1];
+				const bool v = (ok >> lane) & 1ull;
+				const uint32_t sl = stage_sl[g * 64 + lane];
+				const uint64_t slot = (uint64_t)sl | (((hb >> lane) & 1ull) << 32);
+				pr_sl[g * 64 + lane] = v ? sl : 0u;
+				if (lane == 0) pr_hb[g] = hb;
+				const uint8_t *ap = v ? gblob + ((5ull * slot) & ~3ull) : reinterpret_cast<const uint8_t *>(g_zero16);
+				glds_dword(ap, lds_addr(pr_lo + g * 64));
+				glds_dword(ap + 4, lds_addr(pr_hi + g * 64));
 			}
 		}
 	}
@@ -801,7 +826,7 @@ struct SearchWave {
 // The kernel is a software pipeline over the reads a block takes from the ticket counter.  While read i is searched,
 //   * the bytes of read i+1 arrive in LDS (one LDS-DMA load issued right after read i's own bytes were taken out), and
 //   * between phases 3 and 4 -- when the chain heads of read i are in registers and its slot entries are dead -- the
-//     k-mers of read i+1 are hashed and their 2 x (QL-W+1) slots gathered straight into LDS (probe_issue): the loads
+//     k-mers of read i+1 are hashed and their 2 x (QL-W+1) slots gathered straight into LDS (probe_hash, probe_gather): the loads
 //     are in flight behind the chain walk and the phase-4/5 window gathers of read i and have landed when read i+1
 //     begins.  There is no probe launch and no probe array in HBM: what used to be 13 bytes written and read back per
 //     k-mer stays in 12 bytes of LDS.
@@ -828,7 +853,7 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 	__shared__ uint32_t pr_lo[SW::NSEG * 64], pr_hi[SW::NSEG * 64], pr_sl[SW::NSEG * 64];
 	__shared__ uint64_t pr_hb[SW::NSEG];
 	__shared__ uint16_t top[URMAPX_MAX_PATH_OPS];
-	__shared__ uint16_t pre[2 * SW::NSEG * 64 + 2];
+	__shared__ __attribute__((aligned(8))) uint16_t pre[2 * SW::NSEG * 64 + 2];
 	// the flank run buffers and the candidate path live only inside align_hsp, the candidate prefix array only inside a
 	// gather step: they share memory (LDS per block decides how many reads a CU keeps in flight)
 	static_assert(2 * OPS_CAP + URMAPX_MAX_PATH_OPS + (SW::QMAX + 64) / 2 <= 2 * SW::NSEG * 64 + 2, "alias");
@@ -836,8 +861,12 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 	uint8_t *const sT = reinterpret_cast<uint8_t *>(pre + 2 * OPS_CAP + URMAPX_MAX_PATH_OPS);  // AlignHSP's target window
 	__shared__ uint32_t hsp_db[HSP_CAP], hsp_pk[HSP_CAP];
 	// candidate queue (ring): reference position, query position | plus << 14 | second phase << 15
-	__shared__ uint32_t cq_db[128];
+	__shared__ __attribute__((aligned(8))) uint32_t cq_db[128];
 	__shared__ uint16_t cq_qp[128];
+	// between two gather steps both are idle: the next read's slot numbers are staged there on their way to the pr_* arrays
+	static_assert(SW::NSEG * 64 * 4 <= sizeof(pre) && 2 * SW::NSEG * 8 <= sizeof(cq_db), "staging");
+	uint32_t *const stage_sl = reinterpret_cast<uint32_t *>(pre);
+	uint64_t *const stage_b = reinterpret_cast<uint64_t *>(cq_db);
 
 	const int lane = threadIdx.x;
 	const int W = (int)X.W;
@@ -998,19 +1027,25 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 #pragma unroll
 		for (int g = 0; g < SW::NSEG; ++g) rl[g] = 0;
 		for (int step = cur_ok ? 1 : 5;;) {
-			if (DBG && dbg_stop && step != 5 && (dbg_stop == 100 || (dbg_stop < 100 && step > dbg_stop))) { done = true; step = 5; }
+			if (DBG && dbg_stop && step != 5 && (dbg_stop == 100 || (dbg_stop < 100 && step > dbg_stop))) {  // diagnostic schedule cut
+				done = true;
+				if (step == 4 || step == 6) break;  // the next read's probe went out in step 5 already
+				step = 5;
+			}
 			if (step == 5) {
 				const bool go = !done;
 				uint64_t wsl[SW::NSEG];
 				uint32_t wT[SW::NSEG], wps[SW::NSEG];
 				bool wact[SW::NSEG];
-				if (go) S.walk_heads(wsl, wT, wps, wact);
 				if (next_ok) {
 					if (!fetched) fetch_bytes(noff, nQL);
 					wait_vm0();
 					__syncthreads();
-					S.probe_issue(nextQ + nmis, nQL);
+					S.probe_hash(nextQ + nmis, nQL, stage_sl, stage_b);
+					__syncthreads();
 				}
+				if (go) S.walk_heads(wsl, wT, wps, wact);
+				if (next_ok) S.probe_gather(nQL, stage_sl, stage_b);
 				if (!go) break;
 				S.walk_run(wsl, wT, wps, wact, rl);
 				__syncthreads();
@@ -1531,25 +1566,81 @@ hipError_t launch_pack_seq(const uint8_t *d_seq, uint32_t seq_data_size, uint4 *
 // measurement aid: random 5-byte slot gathers over the resident slot table, nothing else -- the ceiling any probe of
 // this table can reach on this device (one 64-byte sector per slot, 6 % of the slots straddle two)
 // ------------------------------------------------------------------------------------------------
+// MODE 0: one 8-byte load per slot (what load_slot does); 1: two 4-byte loads per slot; 2: two 4-byte LDS-DMA loads per
+// slot (what the search kernel's probe_gather does); 3: one 12-byte LDS-DMA load per slot; 4: one 16-byte load per slot.
+// The slot rate of each mode says whether random access is priced per sector or per request.
+template <int MODE>
 __global__ __launch_bounds__(256) void gather_bench_kernel(const uint8_t *__restrict__ blob, uint64_t slot_count,
                                                            uint64_t magic, uint32_t iters, uint32_t *sink) {
+	__shared__ uint32_t dst[MODE == 2 ? 4 * 8 * 2 * 64 : (MODE == 3 ? 4 * 8 * 3 * 64 : 1)];
 	uint64_t x = murmur64(((uint64_t)blockIdx.x << 20) + threadIdx.x + 1);
 	uint32_t acc = 0;
+	const int wv = threadIdx.x >> 6;
 	for (uint32_t i = 0; i < iters; ++i) {
-		uint32_t t[8], p[8];
+		if constexpr (MODE == 0) {
+			uint32_t t[8], p[8];
 #pragma unroll
-		for (int u = 0; u < 8; ++u) {
-			x = murmur64(x + 0x9E3779B97F4A7C15ull);
-			load_slot(blob, mod_slots(x, slot_count, magic), t[u], p[u]);
+			for (int u = 0; u < 8; ++u) {
+				x = murmur64(x + 0x9E3779B97F4A7C15ull);
+				load_slot(blob, mod_slots(x, slot_count, magic), t[u], p[u]);
+			}
+#pragma unroll
+			for (int u = 0; u < 8; ++u) acc += t[u] ^ p[u];
+		} else if constexpr (MODE == 1) {
+			uint32_t lo[8], hi[8];
+			const uint32_t *a[8];
+#pragma unroll
+			for (int u = 0; u < 8; ++u) {
+				x = murmur64(x + 0x9E3779B97F4A7C15ull);
+				a[u] = reinterpret_cast<const uint32_t *>(blob + ((5ull * mod_slots(x, slot_count, magic)) & ~3ull));
+			}
+#pragma unroll
+			for (int u = 0; u < 8; ++u) {
+				asm volatile("global_load_dword %0, %2, off\n\tglobal_load_dword %1, %2, off offset:4" : "=&v"(lo[u]), "=&v"(hi[u]) : "v"(a[u]) : "memory");
+			}
+			asm volatile("s_waitcnt vmcnt(0)" : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(lo[4]), "+v"(lo[5]), "+v"(lo[6]), "+v"(lo[7]),
+			             "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]), "+v"(hi[3]), "+v"(hi[4]), "+v"(hi[5]), "+v"(hi[6]), "+v"(hi[7])::"memory");
+#pragma unroll
+			for (int u = 0; u < 8; ++u) acc += lo[u] ^ hi[u];
+		} else if constexpr (MODE == 2 || MODE == 3) {
+			constexpr int PER = MODE == 2 ? 2 : 3;
+#pragma unroll
+			for (int u = 0; u < 8; ++u) {
+				x = murmur64(x + 0x9E3779B97F4A7C15ull);
+				const uint8_t *a = blob + ((5ull * mod_slots(x, slot_count, magic)) & ~3ull);
+				if constexpr (MODE == 2) {
+					glds_dword(a, lds_addr(dst + ((wv * 8 + u) * PER + 0) * 64));
+					glds_dword(a + 4, lds_addr(dst + ((wv * 8 + u) * PER + 1) * 64));
+				} else {
+					unsigned keep;
+					asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx3 %1, off\n\ts_mov_b32 m0, %0"
+					             : "=&s"(keep) : "v"(a), "s"(lds_addr(dst + (wv * 8 + u) * PER * 64)) : "memory");
+				}
+			}
+			wait_vm0();
+			acc += dst[(wv * 8 * PER) * 64 + (threadIdx.x & 63) + (i & 7) * 64];
+		} else {
+			uint4 v[8];
+#pragma unroll
+			for (int u = 0; u < 8; ++u) {
+				x = murmur64(x + 0x9E3779B97F4A7C15ull);
+				v[u] = *reinterpret_cast<const uint4 *>(blob + ((5ull * mod_slots(x, slot_count, magic)) & ~15ull));
+			}
+#pragma unroll
+			for (int u = 0; u < 8; ++u) acc += v[u].x ^ v[u].w;
 		}
-#pragma unroll
-		for (int u = 0; u < 8; ++u) acc += t[u] ^ p[u];
 	}
 	if (acc == 0x12345678u) *sink = acc;  // never true in practice; keeps the loads alive
 }
 
 hipError_t launch_gather_bench(const DevIndex &X, uint32_t blocks, uint32_t iters, uint32_t *d_sink, hipStream_t s) {
-	hipLaunchKernelGGL(gather_bench_kernel, dim3(blocks), dim3(256), 0, s, X.blob, X.slotCount, X.slotMagic, iters, d_sink);
+	const char *e = getenv("URMAPX_GATHER_MODE");  // measurement aid only
+	const int mode = e ? atoi(e) : 0;
+	if (mode == 1) hipLaunchKernelGGL(gather_bench_kernel<1>, dim3(blocks), dim3(256), 0, s, X.blob, X.slotCount, X.slotMagic, iters, d_sink);
+	else if (mode == 2) hipLaunchKernelGGL(gather_bench_kernel<2>, dim3(blocks), dim3(256), 0, s, X.blob, X.slotCount, X.slotMagic, iters, d_sink);
+	else if (mode == 3) hipLaunchKernelGGL(gather_bench_kernel<3>, dim3(blocks), dim3(256), 0, s, X.blob, X.slotCount, X.slotMagic, iters, d_sink);
+	else if (mode == 4) hipLaunchKernelGGL(gather_bench_kernel<4>, dim3(blocks), dim3(256), 0, s, X.blob, X.slotCount, X.slotMagic, iters, d_sink);
+	else hipLaunchKernelGGL(gather_bench_kernel<0>, dim3(blocks), dim3(256), 0, s, X.blob, X.slotCount, X.slotMagic, iters, d_sink);
 	return hipGetLastError();
 }
 
