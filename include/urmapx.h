@@ -32,13 +32,18 @@ extern "C" {
 #define URMAPX_E_UNSUPPORTED (-6) /* input outside the device path's domain (see status bits) */
 
 /* per-read status bits (urmapx_result.status); non-zero => that read's result is not valid */
-#define URMAPX_ST_HIT_OVERFLOW 0x01 /* more live hits than the device lists hold (512 single-end, 256 per mate paired-end) */
-#define URMAPX_ST_HSP_OVERFLOW 0x02 /* more HSPs than the device lists hold (8192 per read) */
-#define URMAPX_ST_PATH_OVERFLOW 0x04 /* alignment path longer than URMAPX_MAX_PATH_OPS runs */
-#define URMAPX_ST_BAND_TOO_WIDE 0x08 /* DP problem larger than the wide-band scratch (does not occur for reads <= URMAPX_MAX_QL) */
-#define URMAPX_ST_BAD_LENGTH 0x10    /* read shorter than the word length or longer than URMAPX_MAX_QL */
+/* Single-end: a read the fast kernels flag is mapped again by the general kernel (lists in global memory), so these
+ * remain only beyond ITS limits: 65536 live hits, 65536..262144 HSPs, a batch's path arena full, a flank window clipped
+ * by the end of the sequence store with a band beyond 1100 columns, a read shorter than the word length (the reference
+ * underflows there) or longer than URMAPX_MAX_QL_SLOW.  Paired-end: 256 hits per mate, 8192 HSPs per mate, 96 runs. */
+#define URMAPX_ST_HIT_OVERFLOW 0x01 /* more live hits than the device lists hold */
+#define URMAPX_ST_HSP_OVERFLOW 0x02 /* more HSPs than the device lists hold */
+#define URMAPX_ST_PATH_OVERFLOW 0x04 /* alignment path longer than the path storage */
+#define URMAPX_ST_BAND_TOO_WIDE 0x08 /* DP problem larger than the wide-band scratch */
+#define URMAPX_ST_BAD_LENGTH 0x10    /* read shorter than the word length or longer than the kernels take */
 
-#define URMAPX_MAX_QL 1024    /* single-end; paired-end reads: 279 (the reference keeps pending seed positions in a byte) */
+#define URMAPX_MAX_QL 1024    /* single-end reads the fast kernels take; paired-end reads: 279 (the reference keeps pending seed positions in a byte) */
+#define URMAPX_MAX_QL_SLOW 16000 /* single-end reads the general kernel takes (lists in global memory; the reference's own scratch ends near 30 kb, state1.h:113) */
 #define URMAPX_MAX_PATH_OPS 96
 
 typedef struct urmapx_index urmapx_index;

@@ -298,7 +298,8 @@ def test_results_do_not_depend_on_scheduling(small_case, gpu):
 
 
 def test_bad_lengths_are_flagged(small_case, gpu):
-    """Reads shorter than W or longer than the device cap are reported, not silently mis-mapped."""
+    """Reads shorter than W (the reference underflows there) are reported, not silently mis-mapped; a read longer than the
+    fast kernels' 1024 bases goes to the general kernel and is mapped (tests/test_gpu_slow.py compares those with the oracle)."""
     from urmap_amd import api
     seqs = [np.frombuffer(b"ACGTACGTACGTACGT", np.uint8), np.frombuffer(b"ACGT" * 300, np.uint8)]
     offs = np.array([0, 16, 1216], dtype=np.uint64)
@@ -306,7 +307,7 @@ def test_bad_lengths_are_flagged(small_case, gpu):
         gpu["mapper"].map_se(np.concatenate(seqs), offs)
     assert e.value.code == api.E_UNSUPPORTED
     res, _ = gpu["mapper"].map_se(np.concatenate(seqs), offs, allow_unsupported=True)
-    assert (res["status"] == 0x10).all()
+    assert res["status"][0] == 0x10 and res["status"][1] == 0
 
 
 @pytest.mark.parametrize("name", ["se150", "se250", "se_short"])

@@ -118,6 +118,13 @@ hipError_t launch_search_se(const DevIndex &X, const urmapx_params &P, const uin
                             uint32_t n, uint32_t max_read_len, urmapx_result *d_results,
                             urmapx_path_op *d_path_ops, uint32_t *d_path_used, const SearchWork &wk, hipStream_t s);
 
+// the general search (kernels_slow.hip) over the reads the fast passes left flagged: any length up to qcap, lists in global
+// scratch (blocks * slow_scratch_stride(qcap) bytes); list: n + 1 words, ticket: one word
+size_t slow_scratch_stride(uint32_t qcap);
+hipError_t launch_search_se_slow(const DevIndex &X, const urmapx_params &P, const uint8_t *d_bases, const uint64_t *d_offs, uint32_t n,
+                                 uint32_t qcap, urmapx_result *d_results, urmapx_path_op *d_path_ops, uint32_t *d_path_used,
+                                 uint32_t path_cap, uint8_t *scratch, int blocks, uint32_t *list, uint32_t *ticket, hipStream_t s);
+
 // packed copy of the sequence store (4 bit planes per 32 bases): blocks = packed_seq_blocks(seqDataSize) uint4's
 size_t packed_seq_blocks(uint32_t seq_data_size);
 hipError_t launch_pack_seq(const uint8_t *d_seq, uint32_t seq_data_size, uint4 *d_out, hipStream_t s);

@@ -726,7 +726,7 @@ int map_text(urmapx_text *T, const char *fastq1, size_t nbytes1, const char *fas
 		const uint32_t mx = h1.max_len > MAX_QL_PE ? MAX_QL_PE : h1.max_len;
 		rc = urmapx_map_pe_device(C, T->bases.p, T->offs.p, n / 2, h1.total_bases, mx, T->results.p, T->pathops.p, T->used.p);
 	} else {
-		const uint32_t mx = h1.max_len > URMAPX_MAX_QL ? URMAPX_MAX_QL : h1.max_len;
+		const uint32_t mx = h1.max_len > URMAPX_MAX_QL_SLOW ? URMAPX_MAX_QL_SLOW : h1.max_len;
 		rc = urmapx_map_se_device(C, T->bases.p, T->offs.p, n, h1.total_bases, mx, T->results.p, T->pathops.p, T->used.p);
 	}
 	if (rc) return rc;

@@ -76,6 +76,8 @@ struct urmapx_ctx {
 	DevBuf<urmapx_pair_info> pairinfo;
 	DevBuf<uint32_t> ovflist;  // reads queued for the search kernel's second pass
 	DevBuf<uint8_t> dpbuf, dpscratch;  // phase 6 as its own launches: jobs, paths, parked read states (kernels.h: DpWork)
+	DevBuf<uint8_t> slowscratch;       // the general kernel's per-block lists (kernels_slow.hip)
+	DevBuf<uint32_t> slowlist;
 	int dp_blocks[6] = {0, 0, 0, 0, 0, 0};
 	int fin_blocks[6] = {0, 0, 0, 0, 0, 0};
 	hipEvent_t stage_ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -295,7 +297,7 @@ void urmapx_ctx_destroy(urmapx_ctx *C) {
 	C->bases.release(); C->tallies.release(); C->vflags.release(); C->vstatus.release(); C->va.release(); C->vb.release();
 	C->offs.release(); C->slots.release(); C->positions.release(); C->used.release(); C->vaoffs.release(); C->vboffs.release();
 	C->results.release(); C->pathops.release(); C->vops.release(); C->vscores.release(); C->vnops.release();
-	C->dpbuf.release(); C->dpscratch.release();
+	C->dpbuf.release(); C->dpscratch.release(); C->slowscratch.release(); C->slowlist.release();
 	for (int i = 0; i < 7; ++i)
 		if (C->stage_ev[i]) (void)hipEventDestroy(C->stage_ev[i]);
 	C->scratch.release(); C->vscratch.release(); C->statsbuf.release(); C->pe_scratch.release(); C->pairinfo.release(); C->ovflist.release();
@@ -370,10 +372,14 @@ static int ensure_probe(urmapx_ctx *C, uint64_t total_bases) {
 int urmapx_map_se_device(urmapx_ctx *C, const void *d_bases, const void *d_offs, uint32_t n, uint64_t total_bases,
                          uint32_t max_read_len, void *d_results, void *d_path_ops, void *d_path_used) {
 	if (!C || (n && (!d_bases || !d_offs || !d_results || !d_path_ops || !d_path_used))) return URMAPX_E_ARG;
-	if (max_read_len > URMAPX_MAX_QL) return URMAPX_E_UNSUPPORTED;
+	if (max_read_len > URMAPX_MAX_QL_SLOW) return URMAPX_E_UNSUPPORTED;
 	HIP_TRY(hipSetDevice(C->device));
 	(void)total_bases;
 	int rc;
+	// the fast kernels are sized for the batch's longest read up to URMAPX_MAX_QL; longer reads (and whatever else the
+	// fast passes flag) go to the general kernel afterwards
+	const uint32_t slow_qcap = max_read_len < URMAPX_MAX_QL ? URMAPX_MAX_QL : max_read_len;
+	if (max_read_len > URMAPX_MAX_QL) max_read_len = URMAPX_MAX_QL;
 	const int cls = max_read_len <= 128 ? 3 : max_read_len <= 192 ? 0 : max_read_len <= 256 ? 2 : max_read_len <= 320 ? 1 : max_read_len <= 512 ? 4 : 5;
 	if (C->blocks[cls] == 0) {
 		C->blocks[cls] = search_block_count(max_read_len, C->device);
@@ -444,6 +450,16 @@ int urmapx_map_se_device(urmapx_ctx *C, const void *d_bases, const void *d_offs,
 	C->stage_valid = true;
 	HIP_TRY(launch_search_se(C->X, C->params, (const uint8_t *)d_bases, (const uint64_t *)d_offs, n, max_read_len,
 	                         (urmapx_result *)d_results, (urmapx_path_op *)d_path_ops, (uint32_t *)d_path_used, wk, C->stream));
+	{  // reads outside the fast kernels' domain: the general kernel (it finds its work list on the device; usually empty)
+		const int sblocks = slow_qcap <= URMAPX_MAX_QL ? 128 : 64;
+		if ((rc = C->slowscratch.ensure(slow_scratch_stride(slow_qcap) * (size_t)sblocks))) return rc;
+		if ((rc = C->slowlist.ensure((size_t)n + 2))) return rc;
+		const uint64_t pcap = (uint64_t)n * URMAPX_MAX_PATH_OPS;
+		HIP_TRY(launch_search_se_slow(C->X, C->params, (const uint8_t *)d_bases, (const uint64_t *)d_offs, n, slow_qcap,
+		                              (urmapx_result *)d_results, (urmapx_path_op *)d_path_ops, (uint32_t *)d_path_used,
+		                              (uint32_t)(pcap > 0xFFFFFFFFull ? 0xFFFFFFFFull : pcap), C->slowscratch.p, sblocks, C->slowlist.p + 1,
+		                              C->slowlist.p, C->stream));
+	}
 	HIP_TRY(hipEventRecord(C->ev[2], C->stream));
 	C->ev_valid = true;
 	return URMAPX_OK;
@@ -463,8 +479,8 @@ int urmapx_map_se(urmapx_ctx *C, const uint8_t *bases, const uint64_t *offs, uin
 	HIP_TRY(hipSetDevice(C->device));
 	const uint64_t total = offs[n];
 	uint32_t mx = max_len(offs, n);
-	// reads longer than the device domain are flagged per read by the kernel; size the kernel for the cap
-	if (mx > URMAPX_MAX_QL) mx = URMAPX_MAX_QL;
+	// reads longer than the device domain are flagged per read by the kernel; size the kernels for the cap
+	if (mx > URMAPX_MAX_QL_SLOW) mx = URMAPX_MAX_QL_SLOW;
 	int rc;
 	if ((rc = C->bases.ensure(total + 64))) return rc;
 	if ((rc = C->offs.ensure((size_t)n + 1))) return rc;

@@ -33,13 +33,14 @@ struct VPar {
 };
 
 struct RevOps {  // run-length path, traceback order (last column first)
-	uint16_t *ops;  // LDS, OPS_CAP entries
+	uint16_t *ops;  // cap entries (LDS in the fast kernels, global scratch in the general one)
+	int cap = OPS_CAP;
 	int n;
 	int cur_op, cur_len;
 	bool overflow;
 	__device__ __forceinline__ void begin() { n = 0; cur_op = -1; cur_len = 0; overflow = false; }
 	__device__ __forceinline__ void push_run(int op, int len, int lane) {
-		if (n < OPS_CAP) {
+		if (n < cap) {
 			if (lane == 0) ops[n] = (uint16_t)((len << 2) | op);
 			++n;
 		} else
