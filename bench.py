@@ -442,7 +442,7 @@ class Workload:
         if barrier:
             barrier()
         kms = np.zeros(2)
-        self.stage_ms = np.zeros(6)
+        self.stage_ms = np.zeros(7)
         t0 = time.perf_counter()
         for k in range(steps):
             self.step(mappers, warmup + k)
@@ -680,6 +680,7 @@ def kernel_table(api, pe, L, nb, kms, counters, total_bp, gather_loads_s, stage_
         rows.append(("dp_kernel", float(stage_ms[1]), 2.0 * c["n_dptarget"]))
         rows.append(("finalize_se_kernel", float(stage_ms[2]), float(api.RESULT_DTYPE.itemsize)))
         rows.append(("second pass (search + dp + finalize over the reads whose lists outgrew the first)", float(sum(stage_ms[3:6])), 0.0))
+        rows.append(("general kernel (reads outside the fast kernels' domain; usually none)", float(stage_ms[6]), 0.0))
     sector_peak = 64.0 * gather_loads_s / 1e9
     kern = []
     for name, ms, alg in rows:
@@ -786,7 +787,7 @@ def main():
             gather_loads_s = 0.0
         npl = nb // len(mappers)  # reads per launch: the batch is split over the contexts
         kern = kernel_table(api, pe, L, npl, kms, counters, total_bp, gather_loads_s, None if pe else wl.stage_ms)
-        dom = int(np.argmax([k["avg_ms"] if not k["kernel"].startswith("second pass") else 0.0 for k in kern]))
+        dom = int(np.argmax([k["avg_ms"] if not k["kernel"].startswith(("second pass", "general kernel")) else 0.0 for k in kern]))
         dp_stats = wl.dp_stats
         key = "pe150" if pe else ("se150" if L == 150 else ("se250" if L == 250 else None))
         out = {

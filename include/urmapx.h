@@ -150,10 +150,11 @@ int urmapx_ctx_sync(urmapx_ctx *);
 /* Device time (ms, HIP events on the ctx stream) of the two kernels in the most recent *_device call that has
  * completed: [0] seed+probe, [1] search/extend. */
 int urmapx_ctx_last_kernel_ms(urmapx_ctx *, float ms[2]);
-/* The search part of a single-end call is six launches (Search_Lo's phases 1-5, the flank DPs of phase 6, phase 6's
- * ordered part; then the same three for the few reads whose hit / HSP lists outgrew the first pass's): their device
- * times in ms, in that order. */
-int urmapx_ctx_stage_ms(urmapx_ctx *, float ms[6]);
+/* A single-end call is: the search kernel (seed + probe + Search_Lo's phases 1-5), the flank-DP launches of phase 6, phase
+ * 6's ordered part (finalize); the same three for the few reads whose hit / HSP lists outgrew the first pass's; the
+ * general kernel over whatever both passes left flagged.  Device times in ms: [0] search, [1] its DP launches summed,
+ * [2] its finalize launches summed, [3..5] the second pass likewise, [6] the general kernel. */
+int urmapx_ctx_stage_ms(urmapx_ctx *, float ms[7]);
 /* Statistics of the same call, per pass (4 numbers each): HSPs handed to the DP launches, reads they belong to, how many
  * of those DPs the ordered replay of AlignHSP (alignhsp.cpp:60-172) looked at, and how many were dropped before their DP
  * because the penalty cap had fallen far enough by their round. */

@@ -1014,6 +1014,7 @@ struct Searcher {
 
 	// extendscan.cpp:51-187: no overlap test, and the leftward loop never adds to Pen (quirk)
 	unsigned ExtendScan(uint32_t SeedPosQ, uint32_t SeedPosDB, bool Plus) {
+		++C.n_extscan;
 		if (SeedPosDB < SeedPosQ) return UINT_MAX;
 		uint32_t DBLo = SeedPosDB - SeedPosQ;
 		const byte *QSeq = Plus ? Q : QRC.data();
@@ -1074,11 +1075,13 @@ struct Searcher {
 	void Scan(uint32_t DBPos, unsigned DBSegLength, bool Plus, bool DoVit) {
 		int SavedMaxPenalty = MaxPenalty;
 		unsigned SavedHitCount = HitCount;
+		++C.n_scan;
 		MaxPenalty = 130;
 		ScanSlots(DBPos, DBSegLength, Plus);
 		MaxPenalty = SavedMaxPenalty;
-		if (HitCount > SavedHitCount) return;
+		if (HitCount > SavedHitCount) { C.n_scan_hits += HitCount - SavedHitCount; return; }
 		if (!DoVit) return;
+		++C.n_scan_vit;
 		const byte *Qs = Plus ? Q : QRC.data();
 		std::string Path;
 		++C.n_viterbi; C.n_dptarget += DBSegLength;
@@ -1089,6 +1092,7 @@ struct Searcher {
 			Path.erase(0, nI);
 			while (Path.size() > 1 && Path.back() == 'I') Path.pop_back();
 			AddHitX(DBPos + nI, Plus, int(Score), Path);
+			C.n_scan_hits += HitCount - SavedHitCount;
 		}
 	}
 
@@ -1640,6 +1644,7 @@ extern "C" int uo_map_pe_info(const uo_index *X, const uo_params *Pin, const uin
 			const uint64_t o0 = offs[2 * i], o1 = offs[2 * i + 1], o2 = offs[2 * i + 2];
 			S.Search4(bases + o0, unsigned(o1 - o0), bases + o1, unsigned(o2 - o1), veryfast != 0);
 			Searcher *M[2] = {&S.F, &S.R};
+			for (int a = 0; a < 2; ++a) { M[a]->C.n_dpcells += M[a]->dp.Cells; M[a]->dp.Cells = 0; }
 			if (info) {
 				uo_pair_info &pi = info[i];
 				const int second[2] = {S.SecondF, S.SecondR};

@@ -30,7 +30,7 @@ print(f"genome {mbp} Mbp, L={L} sub={sub} indel={indel} n={n}")
 os.environ.pop("URMAPX_PHASE_STATS", None)
 os.environ.pop("URMAPX_DEBUG_STOP", None)
 dt, kms = wl.timed([m], 3, 1)
-print(f"production kernel: probe {kms[0]:.2f} ms, search {kms[1]:.2f} ms; stages (main, dp, finalize, main2, dp2, finalize2) " + ", ".join(f"{x:.2f}" for x in m.stage_ms()) + f"; dp stats {m.dp_stats()}")
+print(f"production kernel: probe {kms[0]:.2f} ms, search {kms[1]:.2f} ms; stages (main, dp, finalize, main2, dp2, finalize2, general) " + ", ".join(f"{x:.2f}" for x in m.stage_ms()) + f"; dp stats {m.dp_stats()}")
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 if os.environ.get("SWEEP_CHECK"):
     import oracle_lib as ol

@@ -37,7 +37,7 @@ PAIR_INFO_DTYPE = np.dtype([("top_db", "<u4", 2), ("second_db", "<u4", 2), ("top
 assert PAIR_INFO_DTYPE.itemsize == 28
 
 COUNTER_NAMES = ("n_reads", "n_getblob", "n_rowcalls", "n_rowhop", "n_extend", "n_extbases",
-                 "n_alignhsp", "n_viterbi", "n_dpcells", "n_dptarget", "n_qbases")
+                 "n_alignhsp", "n_viterbi", "n_dpcells", "n_dptarget", "n_qbases", "n_scan", "n_extscan", "n_scan_vit", "n_scan_hits")
 
 
 class Counters(C.Structure):

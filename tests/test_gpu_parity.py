@@ -799,3 +799,75 @@ def test_cli_log_file_holds_rps_and_the_report(tmp_path, quiet):
     assert ("Mapped Q>=" in err) == (not quiet) and "@rps=" not in err
     got = [l for l in open(out, "rb").read().split(b"\n") if l and not l.startswith(b"@PG")]
     assert got == [l for l in open(os.path.join(gold, "se150.sam"), "rb").read().split(b"\n") if l]
+
+
+@pytest.fixture(scope="module")
+def rescue_case(tmp_path_factory):
+    """Pairs whose second mate lies in an exact 60-copy repeat (every k-mer of it is dropped by the index: more than MaxIx
+    occurrences) next to a unique first mate: the only way to place the second mate is State2::ScanPair (state2.cpp:87-137)
+    -> Scan / ScanSlots / ExtendScan (scan.cpp:14-39, scanslots.cpp:7-62, extendscan.cpp:51-187).  A third of the repeat
+    mates have a substitution in each of the SCANK probe k-mers (query positions 0, 27, 54, 81), so ScanSlots finds nothing
+    and the whole-read Viterbi rescue places them."""
+    import os
+    import oracle_lib as ol
+    from urmap_amd import synth
+    d = str(tmp_path_factory.mktemp("rescue"))
+    rng = np.random.default_rng(5)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    rnd = lambda n: acgt[rng.integers(0, 4, n)]
+    sub = lambda b: acgt[(int(np.where(acgt == b)[0][0]) + 1) % 4]
+    rep = rnd(400)
+    parts, starts = [], []
+    for j in range(60):
+        starts.append(sum(len(p) for p in parts))
+        parts += [rnd(600), rep.copy(), rnd(300)]
+    genome = [("chrR", np.concatenate(parts)), ("chrO", rnd(40000))]
+    fa = os.path.join(d, "r.fa")
+    synth.write_fasta(fa, genome)
+    idx = ol.Index.build(fa, 524309)
+    ufi = os.path.join(d, "r.ufi")
+    idx.save(ufi)
+    seq = genome[0][1]
+    reads = []
+    for j in range(60):
+        s = starts[j]
+        f = seq[s + 300:s + 450].copy()
+        lo = s + 600 + 50 + (j % 5) * 10
+        r = synth.revcomp(seq[lo:lo + 150])
+        if j % 3 == 0:
+            for p in (10, 35, 60, 90, 139, 114, 89, 59):  # every probe k-mer of either strand's coordinates
+                r[p] = sub(r[p])
+        else:
+            for t in range(j % 4):
+                r[120 + 7 * t] = sub(r[120 + 7 * t])
+        if j % 2:
+            f, r = r, f
+        q = np.full(150, ord("I"), np.uint8)
+        reads += [(f"p{j}/1", f, q), (f"p{j}/2", r, q)]
+    return {"dir": d, "ufi": ufi, "oracle_index": idx, "reads": reads}
+
+
+@pytest.mark.gpu
+def test_pe_rescue_scan_produces_hits(rescue_case):
+    """a21: the rescue path must PRODUCE hits on the device, not merely run: the oracle's counters say how many
+    hits Scan added (through ExtendScan and through the whole-read Viterbi), and every mate's result equals the oracle's."""
+    from conftest import reads_to_arrays
+    from urmap_amd import api
+    c = rescue_case
+    bases, offs = reads_to_arrays(c["reads"])
+    ores, opaths, cnt = c["oracle_index"].map_pe(bases, offs)
+    assert cnt["n_scan"] >= 60 and cnt["n_extscan"] >= 100 and cnt["n_scan_vit"] >= 15 and cnt["n_scan_hits"] >= 55, cnt
+    assert cnt["n_dpcells"] > 0  # the pair path's DP cells are counted too
+    assert (ores["dbpos"] != 0xFFFFFFFF).sum() >= 115
+    m = api.Mapper(api.Index.open(c["ufi"]).upload(0), device=0)
+    g, gops = m.map_pe(bases, offs)
+    assert (g["status"] == 0).all()
+    for name in ("dbpos", "seq_index", "coord", "score", "second", "mapq"):
+        assert (g[name].astype(np.int64) == ores[name].astype(np.int64)).all(), name
+    mapped = ores["dbpos"] != 0xFFFFFFFF
+    assert (g["plus"][mapped] == ores["plus"][mapped]).all()
+    gapped = 0
+    for i in np.nonzero(mapped)[0]:
+        o = int(g["path_off"][i])
+        assert api.decode_path(gops[o:o + int(g["path_nops"][i])]) == opaths[i], i
+        gapped += int(g["path_nops"][i]) > 0

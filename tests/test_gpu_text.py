@@ -437,3 +437,39 @@ def test_cli_samout_to_a_pipe(golden_ufi, tmp_path, host_text):
     r = subprocess.run(["bash", "-c", "set -o pipefail; " + cmd], timeout=300, env=env)
     assert r.returncode == 0, open(os.path.join(tmp_path, "err.txt")).read()[-800:]
     assert _sam_body(out) == [l for l in open(os.path.join(GOLD, "se150.sam"), "rb").read().split(b"\n") if l]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("paired", [False, True])
+def test_cli_veryfast_through_the_device_text_path(small_case, tmp_path, paired):
+    """`urmap -map ... -veryfast` (State1 method 7, state1.cpp:166-179) and `-map2 ... -veryfast` (State2::Search5, band
+    radius 4, map2.cpp:17-21,47-49) with FASTQ bytes parsed and SAM bytes written on the device (pipeline.cpp switches the
+    lanes' parameters), against the oracle's SAM; the host text stages must give the same file."""
+    import subprocess
+    import oracle_lib as ol
+    from urmap_amd import synth
+    exe = os.path.join(ROOT, "urmap_amd", "urmap")
+    osam, sam = os.path.join(tmp_path, "o.sam"), os.path.join(tmp_path, "g.sam")
+    if paired:
+        r1, r2 = synth.make_pairs(515, small_case["genome"], 1500, read_len=150, sub1=0.02, sub2=0.04, ins=0.003, dele=0.003)
+        f1, f2 = os.path.join(tmp_path, "r1.fq"), os.path.join(tmp_path, "r2.fq")
+        synth.write_fastq(f1, r1)
+        synth.write_fastq(f2, r2)
+        small_case["oracle_index"].map_file_pe(f1, f2, osam, threads=4, veryfast=True)
+        args = ["-map2", f1, "-reverse", f2, "-ufi", small_case["ufi"]]
+    else:
+        ufi = os.path.join(tmp_path, "vf.ufi")
+        oi = ol.Index.build(small_case["fasta"], 524309, max_ix=3)  # the index -make_ufi -veryfast writes (MaxIx 3)
+        oi.save(ufi)
+        fq = os.path.join(tmp_path, "r.fq")
+        synth.write_fastq(fq, synth.make_reads(516, small_case["genome"], 3000, read_len=150, sub=0.02, ins=0.002, dele=0.002, random_frac=0.03))
+        oi.map_file_se(fq, osam, method=7, threads=4)
+        args = ["-map", fq, "-ufi", ufi]
+    want = [l for l in open(osam, "rb").read().split(b"\n") if l and not l.startswith(b"@")]
+    assert sum(1 for l in want if l.split(b"\t")[2] != b"*") > len(want) * 0.8
+    for env in ({}, {"URMAPX_HOST_TEXT": "1"}):
+        r = subprocess.run([exe] + args + ["-samout", sam, "-veryfast", "-batch", "512"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300,
+                           env={**os.environ, **env})
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        got = [l for l in open(sam, "rb").read().split(b"\n") if l and not l.startswith(b"@")]
+        assert got == want, env

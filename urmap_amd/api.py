@@ -120,7 +120,7 @@ def lib():
     L.urmapx_ctx_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float * 2)]
     L.urmapx_ctx_phase_cycles.argtypes = [vp, C.POINTER(C.c_uint64 * 12)]
     L.urmapx_ctx_read_cycles.argtypes = [vp, vp, u32]
-    L.urmapx_ctx_stage_ms.argtypes = [vp, C.POINTER(C.c_float * 6)]
+    L.urmapx_ctx_stage_ms.argtypes = [vp, C.POINTER(C.c_float * 7)]
     L.urmapx_ctx_dp_stats.argtypes = [vp, C.POINTER(C.c_uint32 * 8)]
     L.urmapx_seed_probe.argtypes = [vp, vp, vp, u32, vp, vp, vp]
     L.urmapx_viterbi_batch.argtypes = [vp, vp, vp, vp, vp, vp, u32, vp, vp, vp, vp]
@@ -433,8 +433,9 @@ class Mapper:
         return float(ms[0]), float(ms[1])
 
     def stage_ms(self):
-        """ms of the six search launches of the last single-end device call: main, dp, finalize, then the second pass's."""
-        ms = (C.c_float * 6)()
+        """ms of the launches of the last single-end device call: search, its DP launches (summed), its finalize launches
+        (summed), the same three for the second pass, the general kernel over what both left flagged."""
+        ms = (C.c_float * 7)()
         _check(lib().urmapx_ctx_stage_ms(self.h, C.byref(ms)), "urmapx_ctx_stage_ms")
         return [float(x) for x in ms]
 

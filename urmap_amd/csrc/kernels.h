@@ -73,6 +73,7 @@ static constexpr int DP_ROUNDS = 3;
 static constexpr uint32_t DP_ROUND_LO[DP_ROUNDS + 1] = {0u, 2u, 16u, 0xFFFFFFFFu};
 #endif
 static constexpr int DP_JOB_OPS = URMAPX_MAX_PATH_OPS;  // ops slice per job
+static constexpr int STAGE_EVENTS = 4 + 4 * DP_ROUNDS;   // SearchWork::stage_events
 
 struct DpWork {
 	DpJob *jobs = nullptr;          // jobs_cap entries
@@ -101,7 +102,7 @@ struct SearchWork {
 	size_t dp_scratch_stride = 0;
 	int dp_blocks = 0;
 	int fin_blocks = 0;            // grid of finalize_se_kernel (0: the search kernel's)
-	hipEvent_t *stage_events = nullptr;  // optional: 7 events recorded between the launches (main, dp, finalize, main2, dp2, finalize2)
+	hipEvent_t *stage_events = nullptr;  // optional, STAGE_EVENTS of them: start, search end, {dp end, finalize end} x DP_ROUNDS, second search end, {dp end, finalize end} x DP_ROUNDS; the caller records the last one after the general kernel
 };
 size_t dp_scratch_stride(uint32_t max_read_len);
 int dp_block_count(uint32_t max_read_len, int device);

@@ -1697,10 +1697,11 @@ hipError_t launch_search_se(const DevIndex &X, const urmapx_params &P, const uin
 		hipLaunchKernelGGL((dp_kernel<NCH_>), dim3((unsigned)wk.dp_blocks), block, 0, s, X, P, d_bases, d_offs, wk.dp[PASS_],       \
 		                   wk.dp_scratch, wk.dp_scratch_stride, X.seq, DP_ROUND_LO[rd], DP_ROUND_LO[rd + 1],                      \
 		                   wk.dp[PASS_].tickets + rd);                                                                           \
-		if (rd == DP_ROUNDS - 1) stamp(2 + 3 * PASS_);                                                                             \
+		stamp(2 + (2 * DP_ROUNDS + 1) * PASS_ + 2 * rd);                                                                            \
 		hipLaunchKernelGGL((finalize_se_kernel<NCH_, OVF_>), dim3((unsigned)(wk.fin_blocks > 0 ? wk.fin_blocks : wk.blocks)), block, \
 		                   0, s, X, P, d_offs, wk.dp[PASS_], d_results, d_path_ops, d_path_used, wk.hsp_lds_cap, wk.ovf_list,        \
 		                   DP_ROUND_LO[rd], DP_ROUND_LO[rd + 1]);                                                                  \
+		stamp(3 + (2 * DP_ROUNDS + 1) * PASS_ + 2 * rd);                                                                            \
 	} } while (0)
 	stamp(0);
 	const bool diag = wk.stats != nullptr && (nch == 3 || nch == 4);  // diagnostic instantiations: 150 / 250 bp classes, phase 6 inline
@@ -1721,8 +1722,7 @@ hipError_t launch_search_se(const DevIndex &X, const urmapx_params &P, const uin
 		else if (nch == 8) URX_LAUNCH_DP(8, false, 0);
 		else URX_LAUNCH_DP(16, false, 0);
 	} else
-		stamp(2);
-	stamp(3);
+		for (int i = 0; i < 2 * DP_ROUNDS; ++i) stamp(2 + i);
 	{
 		hipError_t e = hipGetLastError();
 		if (e != hipSuccess) return e;
@@ -1740,7 +1740,7 @@ hipError_t launch_search_se(const DevIndex &X, const urmapx_params &P, const uin
 	else if (nch == 5) URX_LAUNCH_SE(5, true, false, grid2, no_stats, ovf_base, wk.dp[1]);
 	else if (nch == 8) URX_LAUNCH_SE(8, true, false, grid2, no_stats, ovf_base, wk.dp[1]);
 	else URX_LAUNCH_SE(16, true, false, grid2, no_stats, ovf_base, wk.dp[1]);
-	stamp(4);
+	stamp(2 + 2 * DP_ROUNDS);
 	if (wk.dp[1].jobs) {
 		if (nch == 2) URX_LAUNCH_DP(2, true, 1);
 		else if (nch == 3) URX_LAUNCH_DP(3, true, 1);
@@ -1749,8 +1749,7 @@ hipError_t launch_search_se(const DevIndex &X, const urmapx_params &P, const uin
 		else if (nch == 8) URX_LAUNCH_DP(8, true, 1);
 		else URX_LAUNCH_DP(16, true, 1);
 	} else
-		stamp(5);
-	stamp(6);
+		for (int i = 0; i < 2 * DP_ROUNDS; ++i) stamp(3 + 2 * DP_ROUNDS + i);
 #undef URX_LAUNCH_SE
 #undef URX_LAUNCH_DP
 	return hipGetLastError();

@@ -80,7 +80,7 @@ struct urmapx_ctx {
 	DevBuf<uint32_t> slowlist;
 	int dp_blocks[6] = {0, 0, 0, 0, 0, 0};
 	int fin_blocks[6] = {0, 0, 0, 0, 0, 0};
-	hipEvent_t stage_ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+	hipEvent_t stage_ev[STAGE_EVENTS] = {};
 	bool stage_valid = false;
 	uint32_t pairinfo_n = 0;
 	uint32_t stats_reads = 0;  // diagnostics: reads of the last single-end call with per-read cycle counts
@@ -282,7 +282,7 @@ int urmapx_ctx_create(const urmapx_index *I, int device, const urmapx_params *P,
 		e = hipEventCreate(&C->ev[i]);
 		if (e != hipSuccess) { urmapx_ctx_destroy(C); return hip_rc(e); }
 	}
-	for (int i = 0; i < 7; ++i) {
+	for (int i = 0; i < STAGE_EVENTS; ++i) {
 		e = hipEventCreate(&C->stage_ev[i]);
 		if (e != hipSuccess) { urmapx_ctx_destroy(C); return hip_rc(e); }
 	}
@@ -298,7 +298,7 @@ void urmapx_ctx_destroy(urmapx_ctx *C) {
 	C->offs.release(); C->slots.release(); C->positions.release(); C->used.release(); C->vaoffs.release(); C->vboffs.release();
 	C->results.release(); C->pathops.release(); C->vops.release(); C->vscores.release(); C->vnops.release();
 	C->dpbuf.release(); C->dpscratch.release(); C->slowscratch.release(); C->slowlist.release();
-	for (int i = 0; i < 7; ++i)
+	for (int i = 0; i < STAGE_EVENTS; ++i)
 		if (C->stage_ev[i]) (void)hipEventDestroy(C->stage_ev[i]);
 	C->scratch.release(); C->vscratch.release(); C->statsbuf.release(); C->pe_scratch.release(); C->pairinfo.release(); C->ovflist.release();
 	for (int i = 0; i < 3; ++i)
@@ -319,12 +319,24 @@ int urmapx_ctx_phase_cycles(urmapx_ctx *C, uint64_t out[12]) {
 	return URMAPX_OK;
 }
 
-// Device time (ms) of the launches of the last single-end *_device call, in order: search (first pass), its flank DPs,
-// its finalize, search (second pass over the reads whose lists outgrew the first), its DPs, its finalize.
-int urmapx_ctx_stage_ms(urmapx_ctx *C, float ms[6]) {
+// Device time (ms) of the launches of the last single-end *_device call: [0] search (first pass), [1] its flank-DP
+// launches summed, [2] its finalize launches summed, [3..5] the same for the second pass over the reads whose lists
+// outgrew the first, [6] the general kernel over what both passes left flagged (collect + search_se_slow_kernel).
+int urmapx_ctx_stage_ms(urmapx_ctx *C, float ms[7]) {
 	if (!C || !ms || !C->stage_valid) return URMAPX_E_ARG;
-	HIP_TRY(hipEventSynchronize(C->stage_ev[6]));
-	for (int i = 0; i < 6; ++i) HIP_TRY(hipEventElapsedTime(&ms[i], C->stage_ev[i], C->stage_ev[i + 1]));
+	HIP_TRY(hipEventSynchronize(C->stage_ev[STAGE_EVENTS - 1]));
+	auto span = [&](int a, int b, float &out) -> hipError_t { float t = 0; hipError_t e = hipEventElapsedTime(&t, C->stage_ev[a], C->stage_ev[b]); out += t; return e; };
+	for (int i = 0; i < 7; ++i) ms[i] = 0;
+	HIP_TRY(span(0, 1, ms[0]));
+	for (int p = 0; p < 2; ++p) {
+		const int b = 1 + (2 * DP_ROUNDS + 1) * p;  // the event before this pass's first dp launch
+		for (int rd = 0; rd < DP_ROUNDS; ++rd) {
+			HIP_TRY(span(b + 2 * rd, b + 2 * rd + 1, ms[1 + 3 * p]));
+			HIP_TRY(span(b + 2 * rd + 1, b + 2 * rd + 2, ms[2 + 3 * p]));
+		}
+	}
+	HIP_TRY(span(1 + 2 * DP_ROUNDS, 2 + 2 * DP_ROUNDS, ms[3]));
+	HIP_TRY(span(STAGE_EVENTS - 2, STAGE_EVENTS - 1, ms[6]));
 	return URMAPX_OK;
 }
 
@@ -460,6 +472,7 @@ int urmapx_map_se_device(urmapx_ctx *C, const void *d_bases, const void *d_offs,
 		                              (uint32_t)(pcap > 0xFFFFFFFFull ? 0xFFFFFFFFull : pcap), C->slowscratch.p, sblocks, C->slowlist.p + 1,
 		                              C->slowlist.p, C->stream));
 	}
+	HIP_TRY(hipEventRecord(C->stage_ev[STAGE_EVENTS - 1], C->stream));
 	HIP_TRY(hipEventRecord(C->ev[2], C->stream));
 	C->ev_valid = true;
 	return URMAPX_OK;
