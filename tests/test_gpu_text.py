@@ -473,3 +473,118 @@ def test_cli_veryfast_through_the_device_text_path(small_case, tmp_path, paired)
         assert r.returncode == 0, r.stderr.decode()[-2000:]
         got = [l for l in open(sam, "rb").read().split(b"\n") if l and not l.startswith(b"@")]
         assert got == want, env
+
+
+def _bgzf(data: bytes, block=60000) -> bytes:
+    """BGZF (the bgzip / htslib container): gzip members of <= 64 KB, each with a 'BC' extra field holding its size - 1."""
+    import struct
+    import zlib
+    out = bytearray()
+    for i in list(range(0, len(data), block)) + [len(data)]:  # the last, empty block is BGZF's end-of-file marker
+        raw = data[i:i + block] if i < len(data) else b""
+        c = zlib.compressobj(6, zlib.DEFLATED, -15)
+        comp = c.compress(raw) + c.flush()
+        bsize = 18 + len(comp) + 8
+        out += b"\x1f\x8b\x08\x04" + b"\0\0\0\0" + b"\0\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, bsize - 1)
+        out += comp + struct.pack("<II", zlib.crc32(raw) & 0xFFFFFFFF, len(raw))
+    return bytes(out)
+
+
+def _run_cli(args, env=None):
+    import subprocess
+    r = subprocess.run([os.path.join(ROOT, "urmap_amd", "urmap")] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300,
+                       env={**os.environ, "URMAPX_VERBOSE": "1", **(env or {})})
+    return r.returncode, r.stderr.decode()
+
+
+def _file_records(path):
+    return [l for l in open(path, "rb").read().split(b"\n") if l and not l.startswith(b"@")]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["gzip", "members", "bgzf"])
+def test_cli_gz_input_takes_the_device_text_path(small_case, tmp_path, kind):
+    """.gz FASTQ (linereader.cpp:14-113 reads it through zlib): chunks are cut out of the inflated stream and go to the device
+    as bytes -- no host parsing, no host formatting (format 0.00 in the stage report), the oracle's records, at several chunk
+    sizes; one gzip member, several members back to back, and a BGZF file (blocks inflated in parallel)."""
+    from urmap_amd import synth
+    reads = synth.make_reads(811, small_case["genome"], 6000, read_len=150, sub=0.02, ins=0.002, dele=0.002, random_frac=0.02)
+    fq, osam, sam = (os.path.join(tmp_path, n) for n in ("r.fq", "o.sam", "g.sam"))
+    synth.write_fastq(fq, reads)
+    small_case["oracle_index"].map_file_se(fq, osam, threads=4)
+    data = open(fq, "rb").read()
+    gz = os.path.join(tmp_path, "r.fq.gz")
+    if kind == "gzip":
+        open(gz, "wb").write(gzip.compress(data, 1))
+    elif kind == "members":
+        cuts = [0, len(data) // 3 + 17, 2 * len(data) // 3 + 5, len(data)]  # member ends fall inside records
+        open(gz, "wb").write(b"".join(gzip.compress(data[a:b], 1) for a, b in zip(cuts, cuts[1:])))
+    else:
+        open(gz, "wb").write(_bgzf(data))
+    want = _file_records(osam)
+    for batch in ("100000", "700", "64"):
+        rc, err = _run_cli(["-map", gz, "-ufi", small_case["ufi"], "-samout", sam, "-batch", batch])
+        assert rc == 0, err[-2000:]
+        assert _file_records(sam) == want, batch
+        assert "format 0.00" in err, err[-600:]  # the SAM text was written on the device
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("second", ["gz", "plain", "bgzf"])
+def test_cli_gz_pairs_take_the_device_text_path(small_case, tmp_path, second):
+    from urmap_amd import synth
+    r1, r2 = synth.make_pairs(812, small_case["genome"], 3000, read_len=150, sub1=0.02, sub2=0.03, ins=0.002, dele=0.002)
+    r2 = [(lab + " some longer label text", s, q) if k % 5 == 0 else (lab, s, q) for k, (lab, s, q) in enumerate(r2)]  # records of unequal size in the two files
+    f1, f2, osam, sam = (os.path.join(tmp_path, n) for n in ("r1.fq", "r2.fq", "o.sam", "g.sam"))
+    synth.write_fastq(f1, r1)
+    synth.write_fastq(f2, r2)
+    small_case["oracle_index"].map_file_pe(f1, f2, osam, threads=4)
+    g1 = f1 + ".gz"
+    open(g1, "wb").write(gzip.compress(open(f1, "rb").read(), 1))
+    g2 = f2
+    if second == "gz":
+        g2 = f2 + ".gz"
+        open(g2, "wb").write(gzip.compress(open(f2, "rb").read(), 1))
+    elif second == "bgzf":
+        g2 = f2 + ".gz"
+        open(g2, "wb").write(_bgzf(open(f2, "rb").read()))
+    want = _file_records(osam)
+    for batch in ("100000", "512"):
+        rc, err = _run_cli(["-map2", g1, "-reverse", g2, "-ufi", small_case["ufi"], "-samout", sam, "-batch", batch])
+        assert rc == 0, err[-2000:]
+        assert _file_records(sam) == want, batch
+        assert "format 0.00" in err, err[-600:]
+
+
+@pytest.mark.gpu
+def test_cli_gz_hand_back_and_errors(small_case, tmp_path):
+    """What the device parser does not take -- '\\r' from the middle of the stream on, a damaged record -- goes back to the
+    host reader, which finds its place in the .gz by uncompressed offset (gzseek): same SAM, same message and line number as
+    with the host text stages; a truncated .gz is an error."""
+    from urmap_amd import synth
+    reads = synth.make_reads(813, small_case["genome"], 4000, read_len=150, sub=0.02)
+    fq, osam, sam, sam2 = (os.path.join(tmp_path, n) for n in ("r.fq", "o.sam", "g.sam", "h.sam"))
+    synth.write_fastq(fq, reads)
+    small_case["oracle_index"].map_file_se(fq, osam, threads=4)
+    want = _file_records(osam)
+    data = open(fq, "rb").read()
+    half = data.index(b"\n@", len(data) // 2) + 1
+    gz = os.path.join(tmp_path, "crlf.fq.gz")
+    open(gz, "wb").write(gzip.compress(data[:half] + data[half:].replace(b"\n", b"\r\n"), 1))
+    for batch in ("100000", "300"):
+        rc, err = _run_cli(["-map", gz, "-ufi", small_case["ufi"], "-samout", sam, "-batch", batch])
+        assert rc == 0, err[-2000:]
+        assert _file_records(sam) == want
+    lines = data.split(b"\n")
+    lines[4 * 3000 + 3] = lines[4 * 3000 + 3][:-5]  # a quality line shorter than its bases, late in the file
+    bad = os.path.join(tmp_path, "bad.fq.gz")
+    open(bad, "wb").write(gzip.compress(b"\n".join(lines), 1))
+    rc1, err1 = _run_cli(["-map", bad, "-ufi", small_case["ufi"], "-samout", sam, "-batch", "500"])
+    rc2, err2 = _run_cli(["-map", bad, "-ufi", small_case["ufi"], "-samout", sam2, "-batch", "500"], env={"URMAPX_HOST_TEXT": "1"})
+    msg = lambda e: [l for l in e.split("\n") if "FASTQ" in l or "line" in l.lower()]
+    assert rc1 == 1 and rc2 == 1 and msg(err1) == msg(err2) and msg(err1), (err1[-500:], err2[-500:])
+    trunc = os.path.join(tmp_path, "trunc.fq.gz")
+    z = gzip.compress(data, 1)
+    open(trunc, "wb").write(z[: len(z) // 2])
+    rc, err = _run_cli(["-map", trunc, "-ufi", small_case["ufi"], "-samout", sam])
+    assert rc == 1, err[-500:]

@@ -21,6 +21,7 @@
 #include <hip/hip_runtime_api.h>
 #include <omp.h>
 #include <unistd.h>
+#include <zlib.h>
 
 #include <algorithm>
 #include <atomic>
@@ -342,6 +343,187 @@ uint64_t find_record_start(int fd, uint64_t from, uint64_t fsize) {
 	return 0;
 }
 
+
+// A FASTQ input read front to back as uncompressed bytes: a plain file, or a gzip file (linereader.cpp:14-113 reads .gz
+// through zlib) inflated on the fly.  gzip members are inflated one after the other by the calling thread; a BGZF file
+// (gzip members of <= 64 KB that carry their compressed size in a 'BC' extra field, the bgzip / htslib convention) is
+// inflated a batch of blocks at a time by all of the caller's OpenMP threads.
+class SeqSource {
+public:
+	~SeqSource() {
+		if (zs_init_) inflateEnd(&zs_);
+		for (z_stream &z : bz_) inflateEnd(&z);
+		if (fd_ >= 0) ::close(fd_);
+	}
+	// regular files only; gz says which kind the name promises (".gz")
+	bool open(const char *path, bool gz) {
+		fd_ = ::open(path, O_RDONLY);
+		struct stat st;
+		if (fd_ < 0 || fstat(fd_, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size == 0) return false;
+		csize_ = (uint64_t)st.st_size;
+		gz_ = gz;
+		if (!gz_) return true;
+		unsigned char h[18];
+		if (pread(fd_, h, sizeof h, 0) != (ssize_t)sizeof h || h[0] != 0x1f || h[1] != 0x8b) return false;
+		bgzf_ = (h[3] & 4) && h[12] == 'B' && h[13] == 'C' && h[14] == 2 && h[15] == 0;
+		cbuf_.resize(bgzf_ ? (32u << 20) : (4u << 20));
+		if (!bgzf_) {
+			memset(&zs_, 0, sizeof zs_);
+			if (inflateInit2(&zs_, 15 + 32) != Z_OK) return false;
+			zs_init_ = true;
+		}
+		return true;
+	}
+	bool is_gz() const { return gz_; }
+	bool is_bgzf() const { return bgzf_; }
+	bool failed() const { return bad_; }
+	uint64_t compressed_size() const { return csize_; }
+	// up to cap bytes of the uncompressed stream into dst; 0 = end of input (or failed())
+	size_t read(char *dst, size_t cap, int threads) {
+		if (cap == 0 || eof_ || bad_) return 0;
+		if (!gz_) {
+			const size_t n = (size_t)std::min<uint64_t>(cap, csize_ - cpos_);
+			if (n == 0) { eof_ = true; return 0; }
+			bool ok = true;
+			if (threads < 1) threads = 1;
+#pragma omp parallel for schedule(static, 1) num_threads(threads)
+			for (int t = 0; t < threads; ++t) {
+				const size_t lo = n * (size_t)t / (size_t)threads, hi = n * (size_t)(t + 1) / (size_t)threads;
+				size_t done = lo;
+				while (done < hi) {
+					const ssize_t k = pread(fd_, dst + done, hi - done, (off_t)(cpos_ + done));
+					if (k <= 0) { ok = false; break; }
+					done += (size_t)k;
+				}
+			}
+			if (!ok) { bad_ = true; return 0; }
+			cpos_ += n;
+			return n;
+		}
+		return bgzf_ ? read_bgzf(dst, cap, threads) : read_gzip(dst, cap);
+	}
+
+private:
+	bool refill() {  // more compressed bytes behind what cbuf_ still holds
+		if (chave_ > cbeg_ && cbeg_ > 0) memmove(cbuf_.data(), cbuf_.data() + cbeg_, chave_ - cbeg_);
+		chave_ -= cbeg_; cbeg_ = 0;
+		bool got = false;
+		while (chave_ < cbuf_.size() && cpos_ < csize_) {
+			const ssize_t k = pread(fd_, cbuf_.data() + chave_, cbuf_.size() - chave_, (off_t)cpos_);
+			if (k <= 0) { bad_ = true; return false; }
+			chave_ += (size_t)k; cpos_ += (uint64_t)k;
+			got = true;
+		}
+		return got;
+	}
+	size_t read_gzip(char *dst, size_t cap) {
+		size_t out = 0;
+		while (out < cap) {
+			if (cbeg_ == chave_ && !refill()) {
+				if (!bad_ && !member_done_) bad_ = true;  // the file ends inside a member
+				eof_ = true;
+				break;
+			}
+			zs_.next_in = cbuf_.data() + cbeg_;
+			zs_.avail_in = (uInt)(chave_ - cbeg_);
+			zs_.next_out = (Bytef *)dst + out;
+			zs_.avail_out = (uInt)std::min<size_t>(cap - out, 1u << 30);
+			const uInt out0 = zs_.avail_out;
+			const int rc = inflate(&zs_, Z_NO_FLUSH);
+			cbeg_ = chave_ - zs_.avail_in;
+			out += out0 - zs_.avail_out;
+			member_done_ = false;
+			if (rc == Z_STREAM_END) {  // the next member, if any, continues the text (gzread does the same)
+				member_done_ = true;
+				if (inflateReset(&zs_) != Z_OK) { bad_ = true; break; }
+			} else if (rc != Z_OK && rc != Z_BUF_ERROR) { bad_ = true; break; }
+		}
+		return out;
+	}
+	size_t read_bgzf(char *dst, size_t cap, int threads) {
+		struct Blk { size_t in, in_len, out, out_len; };
+		std::vector<Blk> blks;
+		size_t out = 0;
+		for (;;) {
+			if (chave_ - cbeg_ < 18 + 8 && !refill() && chave_ == cbeg_) { eof_ = true; break; }
+			if (chave_ - cbeg_ < 18 + 8) { bad_ = true; break; }
+			const uint8_t *h = cbuf_.data() + cbeg_;
+			if (h[0] != 0x1f || h[1] != 0x8b || !(h[3] & 4) || h[12] != 'B' || h[13] != 'C') { bad_ = true; break; }
+			const size_t bsize = (size_t)(h[16] | (h[17] << 8)) + 1;
+			if (bsize < 26) { bad_ = true; break; }
+			if (chave_ - cbeg_ < bsize) {
+				if (!blks.empty()) break;  // inflate what is complete first
+				if (!refill() || chave_ - cbeg_ < bsize) { bad_ = true; break; }
+				continue;
+			}
+			const uint8_t *tl = cbuf_.data() + cbeg_ + bsize - 4;
+			const size_t isize = (size_t)tl[0] | ((size_t)tl[1] << 8) | ((size_t)tl[2] << 16) | ((size_t)tl[3] << 24);
+			if (isize > 65536) { bad_ = true; break; }
+			if (out + isize > cap) break;
+			blks.push_back(Blk{cbeg_ + 18, bsize - 26, out, isize});
+			out += isize;
+			cbeg_ += bsize;
+		}
+		if (bad_) return 0;
+		if (threads < 1) threads = 1;
+		if ((int)bz_.size() < threads) {
+			const size_t old = bz_.size();
+			bz_.resize((size_t)threads);
+			for (size_t i = old; i < bz_.size(); ++i) {
+				memset(&bz_[i], 0, sizeof(z_stream));
+				if (inflateInit2(&bz_[i], -15) != Z_OK) { bad_ = true; return 0; }
+			}
+		}
+		bool ok = true;
+#pragma omp parallel for schedule(dynamic, 16) num_threads(threads)
+		for (long i = 0; i < (long)blks.size(); ++i) {
+			z_stream &z = bz_[(size_t)omp_get_thread_num()];
+			const Blk &b = blks[(size_t)i];
+			if (b.out_len == 0) continue;
+			inflateReset(&z);
+			z.next_in = cbuf_.data() + b.in; z.avail_in = (uInt)b.in_len;
+			z.next_out = (Bytef *)dst + b.out; z.avail_out = (uInt)b.out_len;
+			if (inflate(&z, Z_FINISH) != Z_STREAM_END || z.avail_out != 0) ok = false;
+		}
+		if (!ok) { bad_ = true; return 0; }
+		return out;
+	}
+	int fd_ = -1;
+	bool gz_ = false, bgzf_ = false, eof_ = false, bad_ = false, zs_init_ = false, member_done_ = true;
+	uint64_t csize_ = 0, cpos_ = 0;  // compressed (or plain) file: size, next byte to fetch
+	std::vector<uint8_t> cbuf_;
+	size_t cbeg_ = 0, chave_ = 0;
+	z_stream zs_;
+	std::vector<z_stream> bz_;
+};
+
+// start of the last record of b[0, n) whose first three lines lie inside the buffer: a line that begins with '@' whose line
+// after next begins with '+' (only label and quality lines can begin with '@', and two lines after a quality line come
+// bases).  0: none in sight (n holds less than one such record: the caller reads more).
+size_t last_record_start(const char *b, size_t n) {
+	for (size_t win = 1u << 16;; win *= 8) {
+		const size_t lo = n > win ? n - win : 0;
+		const char *p = b + lo, *e = b + n;
+		if (lo) {  // to the first line start at or behind lo
+			p = (const char *)memchr(p, '\n', (size_t)(e - p));
+			if (!p) { if (lo == 0) return 0; continue; }
+			++p;
+		}
+		size_t best = 0;
+		while (p < e) {
+			const char *n1 = (const char *)memchr(p, '\n', (size_t)(e - p));
+			if (!n1) break;
+			if (*p == '@') {
+				const char *n2 = n1 + 1 < e ? (const char *)memchr(n1 + 1, '\n', (size_t)(e - n1 - 1)) : nullptr;
+				if (n2 && n2 + 1 < e && n2[1] == '+') best = (size_t)(p - b);
+			}
+			p = n1 + 1;
+		}
+		if (best) return best;
+		if (lo == 0) return 0;
+	}
+}
+
 }  // namespace
 
 extern "C" int urmapx_map_files(urmapx_index *I, const urmapx_map_options *opt, const char *fastq1, const char *fastq2,
@@ -441,16 +623,26 @@ extern "C" int urmapx_map_files(urmapx_index *I, const urmapx_map_options *opt, 
 		};
 		uint64_t fsize = 0, fsize2 = 0;
 		int fq = -1, fq2 = -1;
+		// .gz input: the same phase with the chunks cut out of the inflated stream (SeqSource); a pipe has no way back to a
+		// chunk the device parser hands back, so it stays with the host reader
+		auto is_gz_name = [](const char *path) { const size_t l = strlen(path); return l > 3 && !strcmp(path + l - 3, ".gz"); };
+		SeqSource src1, src2;
+		bool streamed = false;
 		if (have_sam && !ftab && !getenv("URMAPX_HOST_TEXT")) {  // -tabbedout lines are made on the host (urmapx_tab_pe)
-			fq = open_plain(fastq1, fsize);
-			if (fq >= 0 && paired) {
-				fq2 = open_plain(fastq2, fsize2);
-				if (fq2 < 0) { close(fq); fq = -1; }
+			if (is_gz_name(fastq1) || (paired && is_gz_name(fastq2))) {
+				streamed = strcmp(fastq1, "-") != 0 && src1.open(fastq1, is_gz_name(fastq1)) && (!paired || (strcmp(fastq2, "-") != 0 && src2.open(fastq2, is_gz_name(fastq2))));
+			} else {
+				fq = open_plain(fastq1, fsize);
+				if (fq >= 0 && paired) {
+					fq2 = open_plain(fastq2, fsize2);
+					if (fq2 < 0) { close(fq); fq = -1; }
+				}
 			}
 		}
-		if (fq >= 0) {
-			size_t chunk_bytes;  // `batch` reads (pairs: batch / 2 of each file) at the record size the head of the file shows
-			{
+		if (fq >= 0 || streamed) {
+			size_t chunk_bytes = (size_t)std::min(330.0 * (double)(paired ? std::max(1u, batch / 2) : batch), 536870912.0);  // streamed: a 150-base record
+			// `batch` reads (pairs: batch / 2 of each file) at the record size the head of the file shows
+			if (!streamed) {
 				std::vector<char> head(1u << 16);
 				const ssize_t k = pread(fq, head.data(), head.size(), 0);
 				size_t nl = 0, last = 0;
@@ -502,11 +694,122 @@ extern "C" int urmapx_map_files(urmapx_index *I, const urmapx_map_options *opt, 
 					per[(size_t)t] = k;
 				}
 			};
+			bool stream_done = false;  // streamed input: the reader handed every byte of the input(s) to a lane
 			std::thread treader([&] {
 				omp_set_num_threads(read_threads);
 				uint64_t off = 0, off2 = 0;
 				double bytes2_per_byte1 = 1.0;
 				std::vector<size_t> per;
+				if (streamed) {
+					// chunks are cut out of the inflated stream: fill the job's buffer (what the last cut left over first),
+					// cut it at its last record start, keep the rest for the next chunk.  Offsets are those of the
+					// uncompressed text: that is where the host reader (gzseek) takes over if a chunk is handed back.
+					std::vector<char> carry, carry2;
+					bool eof1 = false, eof2 = false;
+					auto regrow = [&](TextJob &j, size_t want, size_t keep) {  // a larger page-locked buffer holding the first `keep` bytes
+						size_t ncap = 0;
+						char *nb = HostPool::get().acquire(want, ncap);
+						if (!nb) return false;
+						if (keep) memcpy(nb, j.in, keep);
+						HostPool::get().release(j.in, j.in_cap);
+						j.in = nb; j.in_cap = ncap;
+						return true;
+					};
+					for (size_t b = 0; !stop.load() && !fail.set.load(); ++b) {
+						if (eof1 && carry.empty()) { stream_done = !paired || (eof2 && carry2.empty()); break; }
+						std::unique_ptr<TextJob> j;
+						if (!tfree.pop(j)) break;
+						if (stop.load()) { tfree.push(std::move(j)); break; }
+						const auto tp0 = now();
+						const double ta = trace.ms();
+						(void)hipSetDevice(phys(0));
+						size_t area1 = chunk_bytes + chunk_bytes / 8 + carry.size() + (1u << 20);  // room for this file's chunk
+						size_t area2 = paired ? (size_t)((double)area1 * bytes2_per_byte1 * 1.25) + carry2.size() + (4u << 20) : 0;
+						if (!TextJob::grow(j->in, j->in_cap, area1 + 4096 + area2)) { fail.raise(URMAPX_E_NOMEM, "Page-locked chunk buffers: out of memory"); break; }
+						size_t n = carry.size(), cut = 0;
+						if (n) memcpy(j->in, carry.data(), n);
+						carry.clear();
+						size_t target = std::max(chunk_bytes, n + 1);
+						for (;;) {
+							while (n < target && !eof1) {
+								const size_t k = src1.read(j->in + n, std::min(area1, target + (64u << 10)) - n, read_threads);
+								if (k == 0) eof1 = true;
+								n += k;
+							}
+							if (src1.failed()) break;
+							cut = eof1 ? n : last_record_start(j->in, n);
+							if (cut || eof1) break;
+							target *= 2;  // less than one record start in the buffer: records of a size beyond reason, or not FASTQ
+							if (target > (1u << 30)) break;
+							if (target + (64u << 10) > area1) {
+								area1 = target + target / 8 + (1u << 20);
+								if (!regrow(*j, area1 + 4096 + area2, n)) { fail.raise(URMAPX_E_NOMEM, "Page-locked chunk buffers: out of memory"); break; }
+							}
+						}
+						if (fail.set.load()) break;
+						if (src1.failed()) { fail.raise(URMAPX_E_IO, std::string("Error reading gzip file ") + fastq1); break; }
+						if (cut == 0) { carry.assign(j->in, j->in + n); tfree.push(std::move(j)); break; }  // the host reader says what is wrong with it
+						carry.assign(j->in + cut, j->in + n);
+						j->nbytes = cut; j->file_off = off; j->nbytes2 = 0; j->file_off2 = off2; j->in2 = nullptr;
+						if (paired) {
+							count_lines(j->in, cut, per);
+							size_t lines = 0;
+							for (size_t k : per) lines += k;
+							const bool last = eof1 && carry.empty();  // last chunk: whatever the mate file still holds
+							size_t n_pad = (area1 + 4095) & ~(size_t)4095;
+							size_t have = carry2.size(), n2 = 0, seen = 0, scanned = 0;
+							bool found = false, give_up = false;
+							if (have > area2) { area2 = have + have / 4 + (4u << 20); if (!regrow(*j, n_pad + area2, cut)) { fail.raise(URMAPX_E_NOMEM, "Page-locked chunk buffers: out of memory"); break; } }
+							char *dst = j->in + n_pad;
+							if (have) memcpy(dst, carry2.data(), have);
+							carry2.clear();
+							for (;;) {
+								// newlines of dst[scanned, have): the chunk ends behind line number `lines`
+								const char *c = dst + scanned, *e = dst + have;
+								while (c < e && (last || seen < lines)) {
+									const char *nl = (const char *)memchr(c, '\n', (size_t)(e - c));
+									if (!nl) break;
+									++seen;
+									c = nl + 1;
+									if (!last && seen == lines) { n2 = (size_t)(c - dst); found = true; }
+								}
+								scanned = found ? have : (size_t)(c - dst);
+								if (found) break;
+								if (eof2) { if (last) { n2 = have; found = true; } else give_up = true; break; }  // the mate file ends first: the host reader words that
+								if (have == area2) {
+									if (area2 > 8 * area1 + (64u << 20)) { give_up = true; break; }
+									const size_t na = 2 * area2;
+									size_t ncap = 0;
+									char *nb = HostPool::get().acquire(n_pad + na, ncap);
+									if (!nb) { fail.raise(URMAPX_E_NOMEM, "Page-locked chunk buffers: out of memory"); give_up = true; break; }
+									memcpy(nb, j->in, cut);
+									memcpy(nb + n_pad, dst, have);
+									HostPool::get().release(j->in, j->in_cap);
+									j->in = nb; j->in_cap = ncap; area2 = na; dst = nb + n_pad;
+								}
+								const size_t want = std::min(area2 - have, std::max<size_t>(1u << 20, (size_t)((double)cut * bytes2_per_byte1) + (64u << 10) - std::min(have, (size_t)((double)cut * bytes2_per_byte1))));
+								const size_t k = src2.read(dst + have, want, read_threads);
+								if (k == 0) eof2 = true;
+								have += k;
+								if (src2.failed()) { fail.raise(URMAPX_E_IO, std::string("Error reading gzip file ") + fastq2); give_up = true; break; }
+							}
+							if (fail.set.load()) break;
+							if (give_up) { carry.insert(carry.begin(), j->in, j->in + cut); tfree.push(std::move(j)); break; }
+							carry2.assign(dst + n2, dst + have);
+							j->in2 = dst; j->nbytes2 = n2;
+							if (cut && n2) bytes2_per_byte1 = (double)n2 / (double)cut;
+						}
+						t_parse += secs(tp0, now());
+						trace.add("inflate", -1, b, ta);
+						const size_t adv = j->nbytes, adv2 = j->nbytes2;
+						tparsed[b % (size_t)n_lanes]->push(std::move(j));
+						off += adv;
+						off2 += adv2;
+					}
+					reader_end = off; reader_end2 = off2;
+					for (auto &c : tparsed) c->close();
+					return;
+				}
 				for (size_t b = 0; off < fsize && !stop.load() && !fail.set.load(); ++b) {
 					uint64_t end = fsize;
 					if (off + chunk_bytes < fsize) {
@@ -675,10 +978,10 @@ extern "C" int urmapx_map_files(urmapx_index *I, const urmapx_map_options *opt, 
 				while (tfree.try_pop(j)) j.reset();
 				trace.add("unpin", -1, 0, tf);
 			}
-			close(fq);
+			if (fq >= 0) close(fq);
 			if (fq2 >= 0) close(fq2);
 			if (!handed_back) { resume_off = reader_end; resume_off2 = reader_end2; }
-			host_phase = !fail.set.load() && (resume_off < fsize || (paired && resume_off2 < fsize2));
+			host_phase = !fail.set.load() && (streamed ? (handed_back || !stream_done) : (resume_off < fsize || (paired && resume_off2 < fsize2)));
 			if (host_phase && (!rd.resume_at(resume_off, lines_done) || (paired && !rd2.resume_at(resume_off2, lines_done))))
 				fail.raise(URMAPX_E_IO, std::string("Cannot continue reading ") + fastq1);
 			if (fail.set.load()) host_phase = false;

@@ -38,7 +38,13 @@ bool FastqReader::open(const std::string &path, std::string &err) {
 }
 
 bool FastqReader::resume_at(uint64_t offset, uint64_t lines_before) {
-	if (gz_ || !f_ || !seekable_ || have_ || line_nr_) return false;
+	if (have_ || line_nr_) return false;
+	if (gz_) {  // offset counts uncompressed bytes; zlib inflates its way there from the start of the file
+		if (gzseek((gzFile)gz_, (z_off_t)offset, SEEK_SET) < 0) return false;
+		line_nr_ = lines_before;
+		return true;
+	}
+	if (!f_ || !seekable_) return false;
 	file_off_ = offset;
 	line_nr_ = lines_before;
 	return true;
