@@ -567,11 +567,54 @@ def run_reference(ref_bin, oi, d, fq, fq_head, n_reads, n_head, cores, product_s
             "sam_records_identical_to_product": bool(sorted(got) == want), "sam_records_checked": len(want)}
 
 
+def write_ceiling_gbs(d, total=1 << 30, piece=64 << 20):
+    """What one thread's pwrite reaches on the medium the SAM file is written to (the same directory): GB/s."""
+    buf = bytes(piece)
+    path = os.path.join(d, "write_probe.bin")
+    fd = os.open(path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+    try:
+        t0 = time.perf_counter()
+        off = 0
+        while off < total:
+            off += os.pwrite(fd, buf, off)
+        dt = time.perf_counter() - t0
+    finally:
+        os.close(fd)
+        os.remove(path)
+    return total / dt / 1e9
+
+
+def bgzf_bytes(data, block=60000, level=1):
+    """BGZF container (bgzip / htslib): gzip members of <= 64 KB with their size in a 'BC' extra field."""
+    import struct
+    import zlib
+    out = bytearray()
+    for i in list(range(0, len(data), block)) + [len(data)]:
+        raw = data[i:i + block] if i < len(data) else b""
+        c = zlib.compressobj(level, zlib.DEFLATED, -15)
+        comp = c.compress(raw) + c.flush()
+        out += b"\x1f\x8b\x08\x04\0\0\0\0\0\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, 18 + len(comp) + 8 - 1)
+        out += comp + struct.pack("<II", zlib.crc32(raw) & 0xFFFFFFFF, len(raw))
+    return bytes(out)
+
+
+def e2e_bound(rep):
+    """Which stage of urmapx_map_files' pipeline the run waited for: the stage whose busy time fills the wall time."""
+    wall = max(rep["seconds"], 1e-9)
+    lanes = max(1, rep["lanes"])
+    shares = {"output file write (one pwrite stream into " + rep["medium"].decode() + ")": rep["write_s"] / wall,
+              "device lanes (copies + kernels)": rep["gpu_s"] / lanes / wall,
+              "input read / inflate": rep["parse_s"] / wall,
+              "host SAM formatting": rep["format_s"] / wall}
+    name = max(shares, key=shares.get)
+    return name, {k: round(v, 3) for k, v in shares.items()}
+
+
 E2E_STREAMS = int(os.environ.get("URMAP_BENCH_E2E_STREAMS", 2))  # mapping contexts (lanes) of the file-to-file runs
 E2E_BATCH = int(os.environ.get("URMAP_BENCH_E2E_BATCH", 0))      # reads per chunk (0: the library's default, 262144)
 
 
-def run_e2e(torch, api, oi, index, device, d_seq, seq_lengths, seq_offsets, L, sub, indel, n_reads, cores, ref_bin=None):
+def run_e2e(torch, api, oi, index, device, d_seq, seq_lengths, seq_offsets, L, sub, indel, n_reads, cores, ref_bin=None, gpus=1):
     """FASTQ file -> SAM file through urmapx_map_files (the command line's cmd_map) on the resident index: what a user of
     `urmap -map` gets, index load excluded as the reference reports it.  Files live in /dev/shm (memory), so this is the
     read + PCIe + parse + map + format + write pipeline, not a disk benchmark.  Chunks of the FASTQ file go to the device
@@ -591,12 +634,12 @@ def run_e2e(torch, api, oi, index, device, d_seq, seq_lengths, seq_offsets, L, s
         del reads
         runs = []
         for _ in range(2):  # the second run has its buffers and the page cache warm; both are reported
-            rep = api.map_files(index, fq, samout=sam, first_gpu=device.index, gpus=1, streams=E2E_STREAMS, batch=E2E_BATCH, cmdline="bench.py e2e")
+            rep = api.map_files(index, fq, samout=sam, first_gpu=device.index, gpus=gpus, streams=E2E_STREAMS, batch=E2E_BATCH, cmdline="bench.py e2e")
             runs.append(rep)
         rep = runs[-1]
         oi.map_file_se(fq_head, sam_o, threads=cores)
         ref = None
-        if ref_bin and os.path.exists(ref_bin) and not os.environ.get("URMAP_BENCH_NO_REFERENCE"):
+        if gpus == 1 and ref_bin and os.path.exists(ref_bin) and not os.environ.get("URMAP_BENCH_NO_REFERENCE"):
             try:
                 ref = run_reference(ref_bin, oi, d, fq, fq_head, n_reads, n_chk, cores, sam)
             except Exception as e:  # the baseline is reported when it can be had; the measurement does not depend on it
@@ -612,7 +655,14 @@ def run_e2e(torch, api, oi, index, device, d_seq, seq_lengths, seq_offsets, L, s
                 if len(got) == len(want):
                     break
         same = got == want
-        out = {"value": round(rep["reads"] / rep["seconds"], 1), "unit": "reads/s", "reads": int(rep["reads"]),
+        bound, shares = e2e_bound(rep)
+        ceiling = write_ceiling_gbs(d)
+        sam_gb = os.path.getsize(sam) / 1e9
+        out = {"value": round(rep["reads"] / rep["seconds"], 1), "unit": "reads/s", "reads": int(rep["reads"]), "gpus": gpus,
+               "bound": bound, "stage_share_of_wall": shares,
+               "output_medium": {"kind": rep["medium"].decode(), "one_thread_pwrite_GBs": round(ceiling, 2), "writer_threads": int(rep["write_threads"]),
+                                 "reads_per_s_at_that_ceiling": round(rep["reads"] / (sam_gb / ceiling), 1),
+                                 "note": "measured in this run: 1 GiB written with pwrite by one thread into the directory of the SAM file"},
                "seconds": round(rep["seconds"], 3), "first_run_seconds": round(runs[0]["seconds"], 3),
                "what": f"urmapx_map_files (= urmap -map): {fq_bytes / 1e9:.2f} GB FASTQ file -> {os.path.getsize(sam) / 1e9:.2f} GB SAM file, both in /dev/shm; "
                        f"index resident, {rep['host_threads']} host threads, {rep['lanes']} mapping contexts on one GPU; FASTQ parsing and SAM formatting on the device "
@@ -622,11 +672,55 @@ def run_e2e(torch, api, oi, index, device, d_seq, seq_lengths, seq_offsets, L, s
                "sam_records_identical_to_oracle": bool(same), "sam_records_checked": len(want)}
         if ref:
             out["reference_binary"] = ref
-        if not os.environ.get("URMAP_BENCH_NO_E2E_PAIRS"):
+        if gpus == 1 and not os.environ.get("URMAP_BENCH_NO_E2E_GZ"):
+            out["gz"] = run_e2e_gz(api, index, device, d, fq, n_reads, L, want)
+        if gpus == 1 and not os.environ.get("URMAP_BENCH_NO_E2E_PAIRS"):
             out["pairs"] = run_e2e_pairs(torch, api, oi, index, device, d_seq, seq_lengths, seq_offsets, L, n_reads // 2, cores, d)
         return out
     finally:
         shutil.rmtree(d, ignore_errors=True)
+
+
+def run_e2e_gz(api, index, device, d, fq, n_reads, L, want):
+    """The same FASTQ compressed: `urmap -map reads.fq.gz`.  The reader thread inflates (one gzip member: one zlib stream;
+    a BGZF file: blocks in parallel on the host threads), cuts chunks out of the inflated text and the device parses and
+    formats as for a plain file.  The first records of the SAM must be the plain run's."""
+    import subprocess
+    n_gz = min(n_reads, int(os.environ.get("URMAP_BENCH_E2E_GZ_READS", 1_000_000)))
+    rec = (2 + 8 + 1) + L + 3 + L + 1
+    with open(fq, "rb") as f:
+        data = f.read(rec * n_gz)
+    out = {}
+    for kind in ("gzip", "bgzf"):
+        gz = os.path.join(d, kind + ".fq.gz")
+        t0 = time.time()
+        if kind == "gzip":
+            with open(gz, "wb") as f:
+                subprocess.run(["gzip", "-1", "-c"], input=data, stdout=f, check=True)
+        else:
+            with open(gz, "wb") as f:
+                f.write(bgzf_bytes(data))
+        t_make = time.time() - t0
+        sam = os.path.join(d, kind + ".sam")
+        reps = [api.map_files(index, gz, samout=sam, first_gpu=device.index, gpus=1, streams=E2E_STREAMS, batch=E2E_BATCH, cmdline="bench.py e2e gz") for _ in range(2)]
+        rep = reps[-1]
+        got = []
+        with open(sam, "rb") as f:
+            for line in f:
+                if line.startswith(b"@"):
+                    continue
+                got.append(line.rstrip(b"\n"))
+                if len(got) == min(len(want), n_gz):
+                    break
+        bound, shares = e2e_bound(rep)
+        out[kind] = {"value": round(rep["reads"] / rep["seconds"], 1), "unit": "reads/s", "reads": int(rep["reads"]), "seconds": round(rep["seconds"], 3),
+                     "compressed_GB": round(os.path.getsize(gz) / 1e9, 3), "fastq_GB": round(len(data) / 1e9, 3),
+                     "inflate_GBs": round(rep["input_bytes"] / max(rep["parse_s"], 1e-9) / 1e9, 2),
+                     "text_on_device": bool(rep["text_on_device"]), "format_s": round(rep["format_s"], 3), "bound": bound, "stage_share_of_wall": shares,
+                     "sam_records_identical_to_plain_run": bool(got == want[: len(got)]), "made_in_s": round(t_make, 1)}
+        os.remove(gz)
+        os.remove(sam)
+    return out
 
 
 def run_e2e_pairs(torch, api, oi, index, device, d_seq, seq_lengths, seq_offsets, L, npairs, cores, d):
@@ -864,9 +958,28 @@ def main():
                 out["cpu_baseline"]["port_value"] = out["cpu_baseline"]["value"]
                 out["cpu_baseline"]["value"] = rb["reads_per_s"]
                 out["cpu_baseline"]["kind"] = "reference"
+                out["cpu_baseline"]["compares_with"] = ("e2e.value: both are file to file (FASTQ text in, SAM text out) on the same FASTQ file; the kernel metric `value` "
+                                                        "(reads resident in HBM, no text) compares with port_value, the CPU port on the same arrays")
                 out["cpu_baseline"]["sample"] = (f"oracle/_ref/urmap (the unmodified reference, compiled by oracle/Makefile) -map -threads {rb['threads']} on the e2e FASTQ file: "
                                                  + rb["how"] + "; the CPU port on the same host: port_value (" + out["cpu_baseline"]["sample"] + ")")
+        if world > 1 and not pe and L == 150 and not args.no_e2e:
+            # the drop-in curve: urmap -map -gpus N file to file, run by rank 0 over all N devices (each gets its own replica of
+            # the index; the other ranks wait at the barrier below) -- one writer feeds one SAM file whatever N is
+            try:
+                del wl
+            except NameError:
+                pass
+            torch.cuda.empty_cache()
+            if R.shared:
+                os.environ["URMAPX_FORCE_DEVICE"] = str(dev_index)
+            try:
+                out["e2e"] = run_e2e(torch, api, oi, index, device, d_seq, seq_lengths, seq_offsets, L, args.sub, args.indel,
+                                     int(os.environ.get("URMAP_BENCH_E2E_READS", 2_000_000 * min(world, 8))), cores, ref_bin=None, gpus=world)
+            except Exception as e:
+                out["e2e"] = {"error": str(e)[:300]}
         print(json.dumps(out), flush=True)
+    if world > 1 and not pe and L == 150 and not args.no_e2e:
+        R.barrier(torch)
     R.close()
 
 

@@ -257,6 +257,10 @@ typedef struct urmapx_map_report {  /* State1::HitStats' counters (state1.cpp:59
 	double seconds;                                  /* first read parsed .. last SAM byte written (index load excluded) */
 	double parse_s, gpu_s, format_s, write_s;        /* busy seconds per stage (gpu: summed over the lanes) */
 	int host_threads, lanes;
+	int write_threads;                               /* threads sharing one piece's pwrite (1 on tmpfs, up to 4 on a disk file system) */
+	int text_on_device;                              /* 1: FASTQ bytes went to the device and SAM bytes came back (plain or .gz files) */
+	uint64_t input_bytes;                            /* uncompressed FASTQ bytes that took that road (for .gz: parse_s is the inflater's busy time) */
+	char medium[24];                                 /* what the SAM file lives on: "tmpfs", "disk file system", "pipe", "none" */
 } urmapx_map_report;
 /* fastq2 NULL: single-end (-map); else the mates' file (-map2 ... -reverse).  samout / tabout may be NULL.  The index
  * needs its host arrays, or to be resident on first_gpu already (then gpus must be 1).  Batch b is mapped on device

@@ -90,15 +90,18 @@ def test_fastq_writer_of_the_file_to_file_run(tmp_path):
     assert txt == b"@r00000000\nACGTACGTAC\n+\nIIIIIIIIII\n@r00000001\nTTTTTGGGGG\n+\nIIIIIIIIII\n"
 
 
-def test_kernel_table_lists_the_six_launches_of_a_single_end_step():
+def test_kernel_table_lists_the_launches_of_a_single_end_step():
+    """Single-end: seed + probe run inside the search kernel (its algorithmic bytes are both stages'), then the DP launches,
+    the finalize launches, the second pass and the general kernel; paired-end keeps the probe launch."""
     class FakeApi:
         class RESULT_DTYPE:
             itemsize = 28
     c = {"n_getblob": 190.0, "n_rowhop": 220.0, "n_extbases": 5000.0, "n_dptarget": 90.0}
-    k = bench.kernel_table(FakeApi, False, 150, 1_000_000, [6.4, 30.0], c, 3.1e9, 4.6e10, stage_ms=[20.0, 8.0, 0.5, 0.5, 0.3, 0.1])
+    k = bench.kernel_table(FakeApi, False, 150, 1_000_000, [0.0, 30.0], c, 3.1e9, 4.6e10, stage_ms=[20.0, 8.0, 0.5, 0.5, 0.3, 0.1, 0.05])
     names = [x["kernel"] for x in k]
-    assert names[:4] == ["seed_probe_kernel", "search_se_kernel", "dp_kernel", "finalize_se_kernel"] and names[4].startswith("second pass")
-    assert abs(k[1]["alg_bytes_per_read"] - (5 * 220 + 5000 + 28)) < 1e-6
-    assert abs(k[1]["achieved_GBs"] - (5 * 220 + 5000 + 28) * 1e6 / 20e-3 / 1e9) < 0.01
+    assert names[:3] == ["search_se_kernel", "dp_kernel", "finalize_se_kernel"] and names[3].startswith("second pass") and names[4].startswith("general kernel")
+    alg = 5 * 190 + 150 + 5 * 220 + 5000 + 28
+    assert abs(k[0]["alg_bytes_per_read"] - alg) < 1e-6
+    assert abs(k[0]["achieved_GBs"] - alg * 1e6 / 20e-3 / 1e9) < 0.01
     kp = bench.kernel_table(FakeApi, True, 150, 1_000_000, [6.4, 47.0], c, 3.1e9, 4.6e10)
     assert [x["kernel"] for x in kp] == ["seed_probe_kernel", "search_pe_kernel"]

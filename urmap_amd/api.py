@@ -57,7 +57,8 @@ class MapOptions(C.Structure):
 class MapReport(C.Structure):
     _fields_ = [("reads", C.c_uint64), ("mapped_q", C.c_uint64), ("mapped_lowq", C.c_uint64), ("unmapped", C.c_uint64),
                 ("unsupported", C.c_uint64), ("seconds", C.c_double), ("parse_s", C.c_double), ("gpu_s", C.c_double),
-                ("format_s", C.c_double), ("write_s", C.c_double), ("host_threads", C.c_int), ("lanes", C.c_int)]
+                ("format_s", C.c_double), ("write_s", C.c_double), ("host_threads", C.c_int), ("lanes", C.c_int),
+                ("write_threads", C.c_int), ("text_on_device", C.c_int), ("input_bytes", C.c_uint64), ("medium", C.c_char * 24)]
 
 
 class TextReport(C.Structure):

@@ -18,6 +18,7 @@
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
+#include <sys/vfs.h>
 #include <hip/hip_runtime_api.h>
 #include <omp.h>
 #include <unistd.h>
@@ -175,6 +176,25 @@ public:
 	}
 	bool is_open() const { return fd_ >= 0; }
 	bool seekable() const { return !sequential_; }
+	// Threads that should share one piece's pwrite: on tmpfs (and ramfs) write() is a memcpy under the inode lock -- one
+	// thread does 5.8 GB/s, eight together 3.7 (scripts/fs_bench.cpp) -- so one; on a disk file system concurrent pwrites
+	// of disjoint ranges overlap their I/O, so a few.
+	int writer_threads(int host_threads) const {
+		if (const char *e = getenv("URMAPX_WRITE_THREADS")) return std::max(1, atoi(e));
+		if (sequential_ || fd_ < 0) return 1;
+		struct statfs fs;
+		if (fstatfs(fd_, &fs) != 0) return 1;
+		const long t = (long)fs.f_type;
+		if (t == 0x01021994L /* tmpfs */ || t == (long)0x858458f6L /* ramfs */) return 1;
+		return std::max(1, std::min(4, host_threads));
+	}
+	const char *medium() const {
+		if (sequential_) return "pipe";
+		struct statfs fs;
+		if (fd_ < 0 || fstatfs(fd_, &fs) != 0) return "file";
+		const long t = (long)fs.f_type;
+		return (t == 0x01021994L || t == (long)0x858458f6L) ? "tmpfs" : "disk file system";
+	}
 	// makes the file at least `end` bytes long (pieces below `end` can then be written from several threads at once)
 	bool reserve(uint64_t end) {
 		if (!use_map_ || end <= size_) return true;
@@ -216,14 +236,14 @@ public:
 				}
 			}
 		}
-		bool ok = true;
+		std::atomic<bool> ok{true};
 #pragma omp parallel for schedule(static, 1) num_threads(threads)
 		for (int t = 0; t < threads; ++t) {
 			const size_t lo = n * (size_t)t / (size_t)threads, hi = n * (size_t)(t + 1) / (size_t)threads;
 			size_t done = lo;
 			while (done < hi) {
 				ssize_t w = pwrite(fd_, p + done, hi - done, (off_t)(off + done));
-				if (w <= 0) { ok = false; break; }
+				if (w <= 0) { ok.store(false); break; }
 				done += (size_t)w;
 			}
 		}
@@ -384,7 +404,7 @@ public:
 		if (!gz_) {
 			const size_t n = (size_t)std::min<uint64_t>(cap, csize_ - cpos_);
 			if (n == 0) { eof_ = true; return 0; }
-			bool ok = true;
+			std::atomic<bool> ok{true};
 			if (threads < 1) threads = 1;
 #pragma omp parallel for schedule(static, 1) num_threads(threads)
 			for (int t = 0; t < threads; ++t) {
@@ -392,7 +412,7 @@ public:
 				size_t done = lo;
 				while (done < hi) {
 					const ssize_t k = pread(fd_, dst + done, hi - done, (off_t)(cpos_ + done));
-					if (k <= 0) { ok = false; break; }
+					if (k <= 0) { ok.store(false); break; }
 					done += (size_t)k;
 				}
 			}
@@ -474,7 +494,7 @@ private:
 				if (inflateInit2(&bz_[i], -15) != Z_OK) { bad_ = true; return 0; }
 			}
 		}
-		bool ok = true;
+		std::atomic<bool> ok{true};
 #pragma omp parallel for schedule(dynamic, 16) num_threads(threads)
 		for (long i = 0; i < (long)blks.size(); ++i) {
 			z_stream &z = bz_[(size_t)omp_get_thread_num()];
@@ -483,7 +503,7 @@ private:
 			inflateReset(&z);
 			z.next_in = cbuf_.data() + b.in; z.avail_in = (uInt)b.in_len;
 			z.next_out = (Bytef *)dst + b.out; z.avail_out = (uInt)b.out_len;
-			if (inflate(&z, Z_FINISH) != Z_STREAM_END || z.avail_out != 0) ok = false;
+			if (inflate(&z, Z_FINISH) != Z_STREAM_END || z.avail_out != 0) ok.store(false);
 		}
 		if (!ok) { bad_ = true; return 0; }
 		return out;
@@ -573,8 +593,14 @@ extern "C" int urmapx_map_files(urmapx_index *I, const urmapx_map_options *opt, 
 	}
 	// host threads for FASTQ parsing and SAM formatting (the mapping itself runs on the GPU)
 	const int host_threads = opt->host_threads > 0 ? opt->host_threads : std::min(16, std::max(1, (int)std::thread::hardware_concurrency()));
+	const int omp_threads_before = omp_get_max_threads();  // this is a library call: the caller's OpenMP setting comes back at the end
+	struct OmpRestore { int n; ~OmpRestore() { omp_set_num_threads(n); } } omp_restore{omp_threads_before};
 	omp_set_num_threads(host_threads);
 	FileSink sink;
+	int write_threads_used = 1;
+	bool text_on_device = false;
+	uint64_t input_bytes = 0;  // uncompressed FASTQ bytes the text phase handed to the device
+	std::string medium_name = "file";
 	const bool have_sam = samout != nullptr;
 	uint64_t sam_off = 0;
 	Failure fail;
@@ -584,6 +610,7 @@ extern "C" int urmapx_map_files(urmapx_index *I, const urmapx_map_options *opt, 
 		append_sam_header_text(hdr, I, opt->cmdline);
 		if (!sink.write_at(hdr.data(), hdr.size(), 0, 1)) { say(std::string("Cannot write ") + samout); release(); return URMAPX_E_IO; }
 		sam_off = hdr.size();
+		medium_name = sink.medium();
 	}
 	// -tabbedout (outfiles.cpp:7-12): State2::OutputTab2's line per pair; only -map2 writes it
 	FILE *ftab = nullptr;
@@ -665,18 +692,18 @@ extern "C" int urmapx_map_files(urmapx_index *I, const urmapx_map_options *opt, 
 			const int read_threads = std::max(1, host_threads / 2);
 			// [off, off + n) of a file into dst, by several threads
 			auto read_range = [&](int fd, char *dst, uint64_t off, size_t n) {
-				bool ok = true;
+				std::atomic<bool> ok{true};
 #pragma omp parallel for schedule(static, 1) num_threads(read_threads)
 				for (int t = 0; t < read_threads; ++t) {
 					const size_t lo = n * (size_t)t / (size_t)read_threads, hi = n * (size_t)(t + 1) / (size_t)read_threads;
 					size_t done = lo;
 					while (done < hi) {
 						ssize_t k = pread(fd, dst + done, hi - done, (off_t)(off + done));
-						if (k <= 0) { ok = false; break; }
+						if (k <= 0) { ok.store(false); break; }
 						done += (size_t)k;
 					}
 				}
-				return ok;
+				return ok.load();
 			};
 			// '\n' count of each of read_threads slices of p[0, n)
 			auto count_lines = [&](const char *p, size_t n, std::vector<size_t> &per) {
@@ -902,7 +929,9 @@ extern "C" int urmapx_map_files(urmapx_index *I, const urmapx_map_options *opt, 
 			bool handed_back = false;
 			uint64_t resume_off = 0, resume_off2 = 0, lines_done = 0;  // lines_done: per file
 			// write() calls on one file take turns (inode lock): more threads only add hand-overs
-			const int write_threads = getenv("URMAPX_WRITE_THREADS") ? std::max(1, atoi(getenv("URMAPX_WRITE_THREADS"))) : 1;
+			const int write_threads = sink.writer_threads(host_threads);
+			write_threads_used = write_threads;
+			text_on_device = true;
 			std::thread twriter([&] {
 				omp_set_num_threads(host_threads);
 				std::unique_ptr<TextJob> j;
@@ -921,6 +950,7 @@ extern "C" int urmapx_map_files(urmapx_index *I, const urmapx_map_options *opt, 
 							n_reads += j->rep.records; n_accept += j->rep.mapped_q; n_reject += j->rep.mapped_lowq;
 							n_nohit += j->rep.unmapped; n_unsupported += j->rep.unsupported;
 							lines_done += (paired ? 2ull : 4ull) * j->rep.records;
+							input_bytes += j->nbytes + j->nbytes2;
 						}
 					}
 					tfree.push(std::move(j));
@@ -1213,6 +1243,8 @@ extern "C" int urmapx_map_files(urmapx_index *I, const urmapx_map_options *opt, 
 		report->unsupported = n_unsupported;
 		report->seconds = secs(t1, t2); report->parse_s = t_parse; report->gpu_s = t_gpu; report->format_s = t_format; report->write_s = t_write;
 		report->host_threads = host_threads; report->lanes = n_lanes;
+		report->write_threads = write_threads_used; report->text_on_device = text_on_device ? 1 : 0; report->input_bytes = input_bytes;
+		snprintf(report->medium, sizeof report->medium, "%s", have_sam ? medium_name.c_str() : "none");
 	}
 	if (fail.set.load()) { say(fail.msg); return fail.code; }
 	return n_unsupported ? URMAPX_E_UNSUPPORTED : URMAPX_OK;
