@@ -36,6 +36,8 @@ __host__ __device__ inline size_t pe_rowstore_offset(int qmax) {
 	return (b + 15) & ~(size_t)15;
 }
 
+__host__ __device__ inline size_t pe_tb_offset(int qmax);
+
 template <int NCH, bool OVF>
 struct Mate {
 	static constexpr int QMAX = 64 * NCH;
@@ -49,13 +51,18 @@ struct Mate {
 	// this mate
 	int QL, W, nwords;
 	uint8_t *sQ[2];  // LDS: [0] read as given, [1] reverse complement
+	const uint4 *qpl[2];  // LDS: the two strands as bit planes of 4-bit codes (dev_common.h: seq_code), one uint4 per 32 bases
+	const uint4 *__restrict__ gseqp;  // packed copy of the sequence store
+	bool q_other;         // the read holds a byte outside the code list: its windows are compared as ASCII
 	uint32_t qch[2][NCH];
 	const uint64_t *pslots;  // probe output of this read (global), index strand*QL + qpos
 	const uint8_t *ptal;
 	const uint32_t *ppos;
 	// shared LDS scratch (one set per wave)
 	uint8_t *sT;
-	uint32_t *tb;
+	uint32_t *tb;         // trace cells of the banded DP: this block's global scratch
+	uint32_t *wide_lds;   // LDS rows of the wide-band DP (the rescue's whole-read Viterbi)
+	int wide_lds_dwords;
 	uint16_t *ropsL, *ropsR, *cand;
 	WideScratch ws;
 	// lists
@@ -223,6 +230,13 @@ struct Mate {
 		}
 	}
 
+	// mismatch bit vector of the whole read against the window at dblo, one candidate per lane: packed planes, or ASCII for
+	// a read with bytes outside the code list (wave-uniform choice)
+	__device__ __forceinline__ void lane_mask(uint32_t dblo, bool plus, uint64_t (&mm)[NCH]) const {
+		if (q_other) lane_mismatch_mask<NCH>(gseq, dblo, plus ? sQ[0] : sQ[1], QL, mm);
+		else lane_mismatch_planes<NCH>(gseqp, dblo, plus ? qpl[0] : qpl[1], QL, mm);
+	}
+
 	// The two x-drop walks shared by ExtendPen (extendpen.cpp:25-78) and ExtendScan (extendscan.cpp:77-133).
 	// scan = true: the leftward walk does not add to the penalty (the reference's omission, kept).
 	// Returns false if the penalty cap aborted the extension.
@@ -350,7 +364,7 @@ struct Mate {
 			const int needL = leftQL - (maxPen - totalPen);
 			bool abortedL = false;
 			int leftScore = (int)viterbi_wave<true>(VPar(*P), Q, leftQL, sT, (int)leftTL, true, false, tb, TB_ROWS8, ws, RL, vst, lane,
-			                                        (float)needL, allGapL < needL ? &abortedL : nullptr);
+			                                        (float)needL, allGapL < needL ? &abortedL : nullptr, wide_lds, wide_lds_dwords);
 			if (abortedL) return -1;
 			status |= vst;
 			int nTrimI = 0;
@@ -377,7 +391,7 @@ struct Mate {
 			const int needR = rightQL - (maxPen - totalPen);
 			bool abortedR = false;
 			int rightScore = (int)viterbi_wave<true>(VPar(*P), Q + rightQLo, rightQL, sT, (int)rightTL, false, true, tb, TB_ROWS8, ws, RR, vst, lane,
-			                                         (float)needR, allGapR < needR ? &abortedR : nullptr);
+			                                         (float)needR, allGapR < needR ? &abortedR : nullptr, wide_lds, wide_lds_dwords);
 			if (abortedR) return -1;
 			status |= vst;
 			if (RR.n > 1 && (ropsR[0] & 3u) == OP_I) rtrim = 1;
@@ -532,7 +546,7 @@ struct Mate {
 				int e_kind = 0, e_bst = 0, e_sp = 0, e_ep = 0, e_pen = 0;
 				if (ok) {
 					uint64_t mm[NCH];
-					lane_mismatch_mask<NCH>(gseq, dblo, c_plus ? sQ[0] : sQ[1], QL, mm);
+					lane_mask(dblo, c_plus, mm);
 					// lanes that can be neither a hit under the cap nor an HSP that counts do not walk (see search_se_kernel)
 					const int nmis = mismatches_outside_seed<NCH>(mm, (int)c_q, W);
 					const int floor2 = minhsp > best - 4 ? minhsp : best - 4;
@@ -700,7 +714,8 @@ struct Mate {
 		R.ops = ropsL;
 		uint32_t vst = 0;
 		// whole read against the window: a band far wider than a wavefront -> wide path (B read from global memory)
-		const float score = viterbi_wave(VPar(*P), plus ? sQ[0] : sQ[1], QL, gseq + dbpos, (int)seglen, true, true, tb, TB_ROWS8, ws, R, vst, lane);
+		const float score = viterbi_wave(VPar(*P), plus ? sQ[0] : sQ[1], QL, gseq + dbpos, (int)seglen, true, true, tb, TB_ROWS8, ws, R, vst, lane,
+		                                 -3.0e38f, nullptr, wide_lds, wide_lds_dwords);
 		status |= vst;
 		if (vst) return;
 		if ((double)score >= (double)QL / 3.0) {
@@ -717,13 +732,22 @@ struct Mate {
 	}
 };
 
+// Waves per SIMD the register allocation aims at.  The pair kernel waits on memory 70 % of its wave cycles and issues
+// instructions in 40 % of its SIMD cycles at two waves per SIMD (profiles/r3/pmc_sq_pe.json): it is bound by latency, and
+// a third wave hides more of it than the extra spills cost -- 2 waves (228 VGPRs): 40.4 ms per 1 M reads, 3 waves (168
+// VGPRs): 34.6 ms; asking for 4 (128 VGPRs) the compiler settles at 194 = 2 waves again.  LDS allows 12 blocks per CU
+// for reads <= 192 (13.2 KB each: the DP trace lives in global scratch, the seed-stage arrays share one area by lifetime).
+#ifndef URX_PE_WAVES
+#define URX_PE_WAVES(NCH) ((NCH) <= 3 ? 3 : 2)
+#endif
 template <int NCH, bool OVF>
-__global__ __launch_bounds__(64) void search_pe_kernel(DevIndex X, urmapx_params P, const uint8_t *__restrict__ bases,
+__global__ __launch_bounds__(64, URX_PE_WAVES(NCH)) void search_pe_kernel(DevIndex X, urmapx_params P, const uint8_t *__restrict__ bases,
                                                        const uint64_t *__restrict__ offs, uint32_t npairs, ProbeOut probe,
                                                        urmapx_result *__restrict__ results,
                                                        urmapx_path_op *__restrict__ path_ops, uint32_t *path_used,
                                                        uint8_t *scratch, size_t scratch_stride,
                                                        const uint8_t *__restrict__ g_seq, const uint8_t *__restrict__ g_blob,
+                                                       const uint4 *__restrict__ g_seqp,
                                                        int veryfast, uint32_t *ticket, urmapx_pair_info *pair_info,
                                                        int hsp_lds_cap, uint32_t *ovf_list, uint2 *hsp_ovf_base, uint32_t hsp_area_blocks) {
 	using M = Mate<NCH, OVF>;
@@ -734,24 +758,31 @@ __global__ __launch_bounds__(64) void search_pe_kernel(DevIndex X, urmapx_params
 	//   pending-stage row lengths and prefix                               on  seed_q
 	//   the pending stage's candidate queue, then FindPairs' pair list      on  seed_db
 	__shared__ __attribute__((aligned(16))) uint8_t sQ[4][QMAX];
-	__shared__ __attribute__((aligned(16))) uint32_t tb[M::TB_ROWS8 * 64];
+	__shared__ __attribute__((aligned(16))) uint4 qpl[4][2 * NCH];  // [mate * 2 + strand][block of 32 bases]
 	__shared__ uint16_t hit_nops[2][PE_HIT_CAP * M::HITW];
 	__shared__ uint32_t hsp_db[2][PE_HSP_CAP], hsp_ql[2][PE_HSP_CAP];
 	__shared__ uint16_t hsp_sf[2][PE_HSP_CAP];
 	__shared__ uint8_t pend[4][QMAX];
 	// Both1 seed lists of the two mates in enumeration order: qpos | plus << 15, db position
-	constexpr int SEED_CAP = 2 * QMAX;  // >= 2 * (QMAX - W + 1)
+	constexpr int SEED_CAP = 2 * (QMAX - 20);  // >= 2 * (QMAX - W + 1) for the word lengths in use (W >= 21); beyond it the pair is flagged
 	__shared__ __attribute__((aligned(16))) uint16_t seed_q[2][SEED_CAP];
 	__shared__ __attribute__((aligned(16))) uint32_t seed_db[2][SEED_CAP];
 	// cached ExtendPen outcome of every seed (see extend_pen_cached); bit 15 of seed_pen = "already extended once"
-	__shared__ __attribute__((aligned(16))) uint32_t seed_res[2][SEED_CAP];
-	__shared__ uint16_t seed_pen[2][SEED_CAP];
-	static_assert(4 * QMAX + 16 * QMAX <= sizeof(tb), "alias");
-	uint8_t (*const s_tal)[2][QMAX] = reinterpret_cast<uint8_t (*)[2][QMAX]>(tb);                 // [mate][strand][qpos]
-	uint32_t (*const s_pos)[2][QMAX] = reinterpret_cast<uint32_t (*)[2][QMAX]>(tb + QMAX);        // after the 4*QMAX tally bytes
-	static_assert((2 * OPS_CAP + URMAPX_MAX_PATH_OPS) * 2 + QMAX + 64 <= sizeof(seed_res), "alias");
-	uint16_t *const ropsL = reinterpret_cast<uint16_t *>(&seed_res[0][0]), *const ropsR = ropsL + OPS_CAP, *const cand = ropsR + OPS_CAP;
+	// one area, three lives: (1) the probe results staged for the seed enumeration (s_tal, s_pos); (2) the cached
+	// ExtendPen outcomes of the seeds (seed_res, seed_pen); (3) AlignHSP's run buffers, candidate path and target window,
+	// and behind them the per-row arrays of the wide-band DP
+	__shared__ __attribute__((aligned(16))) uint32_t seed_area[2 * SEED_CAP + SEED_CAP];
+	uint32_t (*const seed_res)[SEED_CAP] = reinterpret_cast<uint32_t (*)[SEED_CAP]>(seed_area);
+	uint16_t (*const seed_pen)[SEED_CAP] = reinterpret_cast<uint16_t (*)[SEED_CAP]>(seed_area + 2 * SEED_CAP);
+	static_assert(4 * QMAX + 16 * QMAX <= sizeof(seed_area), "alias");
+	uint8_t (*const s_tal)[2][QMAX] = reinterpret_cast<uint8_t (*)[2][QMAX]>(seed_area);                 // [mate][strand][qpos]
+	uint32_t (*const s_pos)[2][QMAX] = reinterpret_cast<uint32_t (*)[2][QMAX]>(seed_area + QMAX);        // after the 4*QMAX tally bytes
+	constexpr int ALIGN_BYTES = ((2 * OPS_CAP + URMAPX_MAX_PATH_OPS) * 2 + QMAX + 64 + 15) & ~15;
+	static_assert(ALIGN_BYTES + 3 * QMAX * 4 <= sizeof(seed_area), "alias");
+	uint16_t *const ropsL = reinterpret_cast<uint16_t *>(seed_area), *const ropsR = ropsL + OPS_CAP, *const cand = ropsR + OPS_CAP;
 	uint8_t *const sT = reinterpret_cast<uint8_t *>(cand + URMAPX_MAX_PATH_OPS);
+	uint32_t *const wide_lds = seed_area + ALIGN_BYTES / 4;
+	constexpr int WIDE_LDS_DWORDS = (int)(sizeof(seed_area) - ALIGN_BYTES) / 4;
 	static_assert(2 * QMAX + 66 * 2 <= sizeof(seed_q), "alias");
 	uint8_t *const rowlen = reinterpret_cast<uint8_t *>(&seed_q[0][0]);  // shared by the two mates: SearchPE_Pending runs on one mate at a time
 	uint16_t *const pre = reinterpret_cast<uint16_t *>(rowlen + 2 * QMAX);
@@ -769,7 +800,9 @@ __global__ __launch_bounds__(64) void search_pe_kernel(DevIndex X, urmapx_params
 	for (int a = 0; a < 2; ++a) {
 		m[a].X = &X; m[a].P = &P; m[a].gseq = g_seq; m[a].gblob = g_blob; m[a].lane = lane; m[a].W = W;
 		m[a].sQ[0] = sQ[2 * a]; m[a].sQ[1] = sQ[2 * a + 1];
-		m[a].sT = sT; m[a].tb = tb; m[a].ropsL = ropsL; m[a].ropsR = ropsR; m[a].cand = cand;
+		m[a].qpl[0] = qpl[2 * a]; m[a].qpl[1] = qpl[2 * a + 1]; m[a].gseqp = g_seqp; m[a].q_other = false;
+		m[a].sT = sT; m[a].tb = reinterpret_cast<uint32_t *>(sc + pe_tb_offset(QMAX)); m[a].wide_lds = wide_lds; m[a].wide_lds_dwords = WIDE_LDS_DWORDS;
+		m[a].ropsL = ropsL; m[a].ropsR = ropsR; m[a].cand = cand;
 		m[a].hit_nops = hit_nops[a];
 		m[a].hit_paths = OVF ? reinterpret_cast<urmapx_path_op *>(hsp_ovf_base + (size_t)hsp_area_blocks * 2 * PE_HSP_OVF_CAP) +
 		                           ((size_t)blockIdx.x * 2 + a) * PE_HIT_CAP * M::HITW * URMAPX_MAX_PATH_OPS
@@ -851,6 +884,28 @@ __global__ __launch_bounds__(64) void search_pe_kernel(DevIndex X, urmapx_params
 			m[a].mapq = 0xFFFFFFFFu; m[a].status = 0;
 		}
 		__syncthreads();
+		// both strands of both mates as bit planes (ExtendPen's windows are read from the packed sequence store)
+		for (int a = 0; a < 2; ++a) {
+			uint64_t oth = 0;
+#pragma unroll
+			for (int st = 0; st < 2; ++st) {
+#pragma unroll
+				for (int c = 0; c < NCH; ++c) {
+					if (64 * c < m[a].QL) {
+						const int p = 64 * c + lane;
+						const uint32_t code = p < m[a].QL ? seq_code(m[a].qch[st][c], SEQ_CODE_QOTHER) : 0u;
+						const uint64_t b0 = __ballot(code & 1u), b1 = __ballot(code & 2u), b2 = __ballot(code & 4u), b3 = __ballot(code & 8u);
+						oth |= __ballot(code == SEQ_CODE_QOTHER);
+						if (lane < 2) {
+							const int shh = 32 * lane;
+							qpl[2 * a + st][2 * c + lane] = make_uint4((uint32_t)(b0 >> shh), (uint32_t)(b1 >> shh), (uint32_t)(b2 >> shh), (uint32_t)(b3 >> shh));
+						}
+					}
+				}
+			}
+			m[a].q_other = oth != 0;
+		}
+		__syncthreads();
 
 		// ---- seed enumeration of both mates (GetFirstBoth1Seed / GetNextBoth1Seed) ----
 		// State independent, so it is run to the end up front; the pending lists are cut back to the point the
@@ -925,7 +980,7 @@ __global__ __launch_bounds__(64) void search_pe_kernel(DevIndex X, urmapx_params
 					const bool plus = (seed_q[a][i] & 0x8000u) != 0;
 					if (db >= q) {
 						uint64_t mm[NCH];
-						lane_mismatch_mask<NCH>(g_seq, db - q, sQ[2 * a + (plus ? 0 : 1)], QL, mm);
+						m[a].lane_mask(db - q, plus, mm);
 						int bst, sp, ep;
 						xdrop_walk_lane<NCH>(mm, (int)q, W, QL, P.mismatch_score, P.xdrop, P.max_penalty, bst, sp, ep, pen);  // cached for any later cap: bounded by the initial one
 						const uint32_t kind = (sp == 0 && ep == QL - 1) ? 1u : (bst >= minhsp ? 2u : 0u);
@@ -1199,9 +1254,13 @@ static int pe_nch_for(uint32_t max_read_len) {
 	return max_read_len <= 128 ? 2 : max_read_len <= 192 ? 3 : max_read_len <= 256 ? 4 : max_read_len <= 320 ? 5 : 0;
 }
 
+// behind the rows: the trace cells of the banded DP
+__host__ __device__ inline size_t pe_tb_offset(int qmax) {
+	return (pe_rowstore_offset(qmax) + (size_t)2 * (qmax / 64) * PE_ROW_CAP * 64 * 4 + 255) & ~(size_t)255;
+}
 size_t search_pe_scratch_stride(uint32_t max_read_len) {
 	const int qmax = 64 * pe_nch_for(max_read_len);
-	size_t b = pe_rowstore_offset(qmax) + (size_t)2 * (qmax / 64) * PE_ROW_CAP * 64 * 4;
+	size_t b = pe_tb_offset(qmax) + (size_t)(qmax / 8 + 2) * 64 * 4;
 	return (b + 255) & ~(size_t)255;
 }
 
@@ -1242,19 +1301,19 @@ hipError_t launch_search_pe(const DevIndex &X, const urmapx_params &P, const uin
 	uint2 *const ovf_base1 = reinterpret_cast<uint2 *>(wk.scratch + (size_t)wk.blocks * wk.scratch_stride);  // HSP lists beyond LDS
 	if (nch == 2)
 		hipLaunchKernelGGL((search_pe_kernel<2, false>), grid, block, 0, s, X, P, d_bases, d_offs, npairs, probe, d_results,
-		                   d_path_ops, d_path_used, wk.scratch, wk.scratch_stride, X.seq, X.blob, veryfast, wk.ticket, pair_info,
+		                   d_path_ops, d_path_used, wk.scratch, wk.scratch_stride, X.seq, X.blob, X.seqp, veryfast, wk.ticket, pair_info,
 		                   wk.hsp_lds_cap, wk.ovf_list, ovf_base1, pe_hsp_area_blocks(wk.blocks));
 	else if (nch == 3)
 		hipLaunchKernelGGL((search_pe_kernel<3, false>), grid, block, 0, s, X, P, d_bases, d_offs, npairs, probe, d_results,
-		                   d_path_ops, d_path_used, wk.scratch, wk.scratch_stride, X.seq, X.blob, veryfast, wk.ticket, pair_info,
+		                   d_path_ops, d_path_used, wk.scratch, wk.scratch_stride, X.seq, X.blob, X.seqp, veryfast, wk.ticket, pair_info,
 		                   wk.hsp_lds_cap, wk.ovf_list, ovf_base1, pe_hsp_area_blocks(wk.blocks));
 	else if (nch == 4)
 		hipLaunchKernelGGL((search_pe_kernel<4, false>), grid, block, 0, s, X, P, d_bases, d_offs, npairs, probe, d_results,
-		                   d_path_ops, d_path_used, wk.scratch, wk.scratch_stride, X.seq, X.blob, veryfast, wk.ticket, pair_info,
+		                   d_path_ops, d_path_used, wk.scratch, wk.scratch_stride, X.seq, X.blob, X.seqp, veryfast, wk.ticket, pair_info,
 		                   wk.hsp_lds_cap, wk.ovf_list, ovf_base1, pe_hsp_area_blocks(wk.blocks));
 	else
 		hipLaunchKernelGGL((search_pe_kernel<5, false>), grid, block, 0, s, X, P, d_bases, d_offs, npairs, probe, d_results,
-		                   d_path_ops, d_path_used, wk.scratch, wk.scratch_stride, X.seq, X.blob, veryfast, wk.ticket, pair_info,
+		                   d_path_ops, d_path_used, wk.scratch, wk.scratch_stride, X.seq, X.blob, X.seqp, veryfast, wk.ticket, pair_info,
 		                   wk.hsp_lds_cap, wk.ovf_list, ovf_base1, pe_hsp_area_blocks(wk.blocks));
 	{
 		hipError_t e = hipGetLastError();
@@ -1267,19 +1326,19 @@ hipError_t launch_search_pe(const DevIndex &X, const urmapx_params &P, const uin
 	uint2 *ovf_base = reinterpret_cast<uint2 *>(wk.scratch + (size_t)wk.blocks * wk.scratch_stride);
 	if (nch == 2)
 		hipLaunchKernelGGL((search_pe_kernel<2, true>), grid2, block, 0, s, X, P, d_bases, d_offs, npairs, probe, d_results,
-		                   d_path_ops, d_path_used, wk.scratch, wk.scratch_stride, X.seq, X.blob, veryfast, wk.ticket, pair_info,
+		                   d_path_ops, d_path_used, wk.scratch, wk.scratch_stride, X.seq, X.blob, X.seqp, veryfast, wk.ticket, pair_info,
 		                   wk.hsp_lds_cap, wk.ovf_list, ovf_base, pe_hsp_area_blocks(wk.blocks));
 	else if (nch == 3)
 		hipLaunchKernelGGL((search_pe_kernel<3, true>), grid2, block, 0, s, X, P, d_bases, d_offs, npairs, probe, d_results,
-		                   d_path_ops, d_path_used, wk.scratch, wk.scratch_stride, X.seq, X.blob, veryfast, wk.ticket, pair_info,
+		                   d_path_ops, d_path_used, wk.scratch, wk.scratch_stride, X.seq, X.blob, X.seqp, veryfast, wk.ticket, pair_info,
 		                   wk.hsp_lds_cap, wk.ovf_list, ovf_base, pe_hsp_area_blocks(wk.blocks));
 	else if (nch == 4)
 		hipLaunchKernelGGL((search_pe_kernel<4, true>), grid2, block, 0, s, X, P, d_bases, d_offs, npairs, probe, d_results,
-		                   d_path_ops, d_path_used, wk.scratch, wk.scratch_stride, X.seq, X.blob, veryfast, wk.ticket, pair_info,
+		                   d_path_ops, d_path_used, wk.scratch, wk.scratch_stride, X.seq, X.blob, X.seqp, veryfast, wk.ticket, pair_info,
 		                   wk.hsp_lds_cap, wk.ovf_list, ovf_base, pe_hsp_area_blocks(wk.blocks));
 	else
 		hipLaunchKernelGGL((search_pe_kernel<5, true>), grid2, block, 0, s, X, P, d_bases, d_offs, npairs, probe, d_results,
-		                   d_path_ops, d_path_used, wk.scratch, wk.scratch_stride, X.seq, X.blob, veryfast, wk.ticket, pair_info,
+		                   d_path_ops, d_path_used, wk.scratch, wk.scratch_stride, X.seq, X.blob, X.seqp, veryfast, wk.ticket, pair_info,
 		                   wk.hsp_lds_cap, wk.ovf_list, ovf_base, pe_hsp_area_blocks(wk.blocks));
 	return hipGetLastError();
 }

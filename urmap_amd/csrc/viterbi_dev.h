@@ -82,7 +82,7 @@ __device__ float viterbi_wide(const VPar P, const uint8_t *A, int LA, const uint
 template <bool B_LDS = false>
 __device__ __forceinline__ float viterbi_wave(const VPar P, const uint8_t *A, int LA, const uint8_t *B, int LB, bool Left, bool Right,
                               uint32_t *tb, int tb_rows8, const WideScratch ws, RevOps &R, uint32_t &status, int lane_in,
-                              float abort_below = -3.0e38f, bool *aborted = nullptr) {
+                              float abort_below = -3.0e38f, bool *aborted = nullptr, uint32_t *wide_lds = nullptr, int wide_lds_dwords = 0) {
 	// the lane index is recomputed here (two mbcnt) instead of using the caller's: that one is live through the whole
 	// search kernel, gets spilled in its register-hungry parts, and was then reloaded from scratch in every DP row
 	(void)lane_in;
@@ -103,7 +103,10 @@ __device__ __forceinline__ float viterbi_wave(const VPar P, const uint8_t *A, in
 	const int ND = dhi - dlo + 1;
 	// lanes: 0 = column Startj-1, 1..ND = band, ND+1 = column LB; final cells sit at lanes LB-dlo .. LB-dlo+2
 	if (ND + 2 > 64 || LB - dlo + 2 > 63 || ((LA + 1 + 7) >> 3) > tb_rows8) {
-		if (LA <= ws.la_cap && LB <= ws.lb_cap) return viterbi_wide(P, A, LA, B, LB, Left, Right, ws, tb, tb_rows8 * 64, R, status, lane);
+		// the wide path keeps three per-row arrays in LDS: the narrow path's trace buffer (idle here) unless the caller
+		// holds that in global memory and names another LDS area
+		if (LA <= ws.la_cap && LB <= ws.lb_cap)
+			return viterbi_wide(P, A, LA, B, LB, Left, Right, ws, wide_lds ? wide_lds : tb, wide_lds ? wide_lds_dwords : tb_rows8 * 64, R, status, lane);
 		status |= URMAPX_ST_BAND_TOO_WIDE;
 		return 0.0f;
 	}
