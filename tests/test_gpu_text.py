@@ -490,7 +490,7 @@ def _bgzf(data: bytes, block=60000) -> bytes:
     return bytes(out)
 
 
-def _run_cli(args, env=None):
+def _urmap(args, env=None):
     import subprocess
     r = subprocess.run([os.path.join(ROOT, "urmap_amd", "urmap")] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300,
                        env={**os.environ, "URMAPX_VERBOSE": "1", **(env or {})})
@@ -523,7 +523,7 @@ def test_cli_gz_input_takes_the_device_text_path(small_case, tmp_path, kind):
         open(gz, "wb").write(_bgzf(data))
     want = _file_records(osam)
     for batch in ("100000", "700", "64"):
-        rc, err = _run_cli(["-map", gz, "-ufi", small_case["ufi"], "-samout", sam, "-batch", batch])
+        rc, err = _urmap(["-map", gz, "-ufi", small_case["ufi"], "-samout", sam, "-batch", batch])
         assert rc == 0, err[-2000:]
         assert _file_records(sam) == want, batch
         assert "format 0.00" in err, err[-600:]  # the SAM text was written on the device
@@ -550,7 +550,7 @@ def test_cli_gz_pairs_take_the_device_text_path(small_case, tmp_path, second):
         open(g2, "wb").write(_bgzf(open(f2, "rb").read()))
     want = _file_records(osam)
     for batch in ("100000", "512"):
-        rc, err = _run_cli(["-map2", g1, "-reverse", g2, "-ufi", small_case["ufi"], "-samout", sam, "-batch", batch])
+        rc, err = _urmap(["-map2", g1, "-reverse", g2, "-ufi", small_case["ufi"], "-samout", sam, "-batch", batch])
         assert rc == 0, err[-2000:]
         assert _file_records(sam) == want, batch
         assert "format 0.00" in err, err[-600:]
@@ -572,19 +572,19 @@ def test_cli_gz_hand_back_and_errors(small_case, tmp_path):
     gz = os.path.join(tmp_path, "crlf.fq.gz")
     open(gz, "wb").write(gzip.compress(data[:half] + data[half:].replace(b"\n", b"\r\n"), 1))
     for batch in ("100000", "300"):
-        rc, err = _run_cli(["-map", gz, "-ufi", small_case["ufi"], "-samout", sam, "-batch", batch])
+        rc, err = _urmap(["-map", gz, "-ufi", small_case["ufi"], "-samout", sam, "-batch", batch])
         assert rc == 0, err[-2000:]
         assert _file_records(sam) == want
     lines = data.split(b"\n")
     lines[4 * 3000 + 3] = lines[4 * 3000 + 3][:-5]  # a quality line shorter than its bases, late in the file
     bad = os.path.join(tmp_path, "bad.fq.gz")
     open(bad, "wb").write(gzip.compress(b"\n".join(lines), 1))
-    rc1, err1 = _run_cli(["-map", bad, "-ufi", small_case["ufi"], "-samout", sam, "-batch", "500"])
-    rc2, err2 = _run_cli(["-map", bad, "-ufi", small_case["ufi"], "-samout", sam2, "-batch", "500"], env={"URMAPX_HOST_TEXT": "1"})
+    rc1, err1 = _urmap(["-map", bad, "-ufi", small_case["ufi"], "-samout", sam, "-batch", "500"])
+    rc2, err2 = _urmap(["-map", bad, "-ufi", small_case["ufi"], "-samout", sam2, "-batch", "500"], env={"URMAPX_HOST_TEXT": "1"})
     msg = lambda e: [l for l in e.split("\n") if "FASTQ" in l or "line" in l.lower()]
     assert rc1 == 1 and rc2 == 1 and msg(err1) == msg(err2) and msg(err1), (err1[-500:], err2[-500:])
     trunc = os.path.join(tmp_path, "trunc.fq.gz")
     z = gzip.compress(data, 1)
     open(trunc, "wb").write(z[: len(z) // 2])
-    rc, err = _run_cli(["-map", trunc, "-ufi", small_case["ufi"], "-samout", sam])
+    rc, err = _urmap(["-map", trunc, "-ufi", small_case["ufi"], "-samout", sam])
     assert rc == 1, err[-500:]
