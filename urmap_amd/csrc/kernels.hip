@@ -1461,9 +1461,35 @@ __global__ __launch_bounds__(64) void finalize_se_kernel(DevIndex X, urmapx_para
 		const int phase = S.restore_state(st);
 		uint32_t used = 0;
 		const uint32_t kend = nj < khi ? nj : khi;
-		for (uint32_t k = klo; k < kend; ++k) {
-			const DpJob J = dp.jobs[jb + k];
-			used += S.consume_job(J, dp.ops + (size_t)(jb + k) * DP_JOB_OPS) ? 1u : 0u;
+		// 64 jobs come in with one round of loads (one job per lane: the words the replay reads), then they are replayed
+		// in order out of registers; a job whose HSP already fails AlignHSP's first test under the cap as it stands fails
+		// it at its turn too (the cap only falls) and is not visited.  One scalar load per job, each waiting for the last,
+		// made this launch as long as the DP launches it follows for 250-base reads (10.4 of 118 ms per 1 M reads).
+		for (uint32_t k0 = klo; k0 < kend; k0 += 64) {
+			const uint32_t k = k0 + (uint32_t)lane;
+			uint32_t jpk = 0;
+			uint4 jw = make_uint4(0u, 0u, 0u, 0u);
+			if (k < kend) {
+				const uint32_t *jp = reinterpret_cast<const uint32_t *>(dp.jobs + jb + k);
+				jpk = jp[2];
+				jw = *reinterpret_cast<const uint4 *>(jp + 4);
+			}
+			const int jpen = (int)((jpk >> PK_LEN_SH) & PK_MASK) - (int)((jpk >> PK_SCORE_SH) & PK_MASK);
+			uint64_t todo = __ballot(k < kend && jpen <= S.maxPen);
+			while (todo) {
+				const int t = __builtin_ctzll(todo);
+				todo &= todo - 1;
+				DpJob J;
+				J.read = r; J.startdb = 0; J.maxpen = 0; J.k = 0; J.pad[0] = J.pad[1] = 0;
+				J.pk = rdlane(jpk, t);
+				J.combined_tlo = rdlane(jw.x, t);
+				const uint32_t sc = rdlane(jw.y, t), fl = rdlane(jw.z, t);
+				J.left_score = (int16_t)(sc & 0xFFFFu); J.right_score = (int16_t)(sc >> 16);
+				J.nops = (uint8_t)(fl & 0xFFu); J.flags = (uint8_t)((fl >> 8) & 0xFFu); J.vst_l = (uint8_t)((fl >> 16) & 0xFFu); J.vst_r = (uint8_t)(fl >> 24);
+				const int mp0 = S.maxPen;
+				used += S.consume_job(J, dp.ops + (size_t)(jb + k0 + (uint32_t)t) * DP_JOB_OPS) ? 1u : 0u;
+				if (S.maxPen != mp0) todo &= __ballot(jpen <= S.maxPen);
+			}
 		}
 		if (lane == 0 && used) atomicAdd(dp.counters + 2, used);  // statistics: jobs whose DP the ordered replay looked at
 		if (nj > khi) {  // more rounds to come: park again, and tell the remaining jobs the cap reached so far
