@@ -85,9 +85,15 @@ def test_seed_probe_matches_oracle(small_case, gpu):
             assert (gp[valid] == wp[valid]).all(), f"read {r} strand {strand}: positions differ"
 
 
-def test_viterbi_matches_oracle(gpu):
-    """State1::Viterbi + TraceBackBitMem (viterbi.cpp:11-261): score and full path, Left/Right variants."""
+@pytest.mark.parametrize("pair", [False, True])
+def test_viterbi_matches_oracle(gpu, pair, monkeypatch):
+    """State1::Viterbi + TraceBackBitMem (viterbi.cpp:11-261): score and full path, Left/Right variants.  pair: two problems
+    per wavefront through VFlank (viterbi_dev.h), the interior row blocks of both in packed int16 -- what dp_kernel runs."""
     import oracle_lib as ol
+    if pair:
+        monkeypatch.setenv("URMAPX_VITERBI_PAIR", "1")
+    else:
+        monkeypatch.delenv("URMAPX_VITERBI_PAIR", raising=False)
     rng = np.random.default_rng(5)
     pairs, flags = [], []
     for k in range(400):
@@ -118,6 +124,29 @@ def test_viterbi_matches_oracle(gpu):
         b = (tt + bytes(np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, size=lb)]))[:lb]
         pairs.append((a, b))
         flags.append(1 if k % 2 == 0 else 2)
+    # long flanks (many interior row blocks), adjacent problems of different length, heavy edits, a repeat-like target
+    for k in range(120):
+        la = int(rng.integers(60, 300))
+        core = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, size=la + 40)]
+        q = core[20:20 + la].copy() if k % 2 else core[:la].copy()
+        nm = int(rng.integers(0, max(1, la // (4 + k % 9))))
+        q[rng.integers(0, la, size=nm)] = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, size=nm)]
+        qq = list(q)
+        for _ in range(k % 4):
+            x = int(rng.integers(1, len(qq) - 1))
+            if rng.random() < 0.5:
+                del qq[x:x + int(rng.integers(1, 4))]
+            else:
+                qq[x:x] = list(np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, size=int(rng.integers(1, 4)))])
+        a = bytes(qq)
+        lb = len(a) + 24
+        if k % 2:
+            b = (core[20 - 24:20 + la + 40].tobytes())[:lb] if 20 - 24 >= 0 else core.tobytes()[:lb]
+        else:
+            b = core.tobytes()[:lb]
+        b = (b + bytes(np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, size=lb)]))[:lb]
+        pairs.append((a, b))
+        flags.append(1 if k % 2 else 2)
     # degenerate shapes
     pairs += [(b"ACGT", b""), (b"A", b"A"), (b"A", b"CCCCCCCCCCCCCCCCCCCCCCCCC"), (b"ACGTACGTAC", b"ACGTACGTAC"),
               (b"ACGTACGTAC" * 5, (b"ACGTACGTAC" * 5)[:30])]

@@ -165,6 +165,66 @@ __global__ __launch_bounds__(64) void viterbi_batch_kernel(urmapx_params P, cons
 	if (lane == 0) { scores[k] = score; status_out[k] = (uint8_t)status; nops_out[k] = (uint16_t)nout; }
 }
 
+// The same problems two per wavefront through VFlank / viterbi_pair_rows (viterbi_dev.h): the packed-int16 interior
+// blocks that dp_kernel uses, behind the same parity test (URMAPX_VITERBI_PAIR=1 selects this kernel).
+__global__ __launch_bounds__(64) void viterbi_batch_pair_kernel(urmapx_params P, const uint8_t *__restrict__ a,
+                                                                const uint32_t *__restrict__ aoffs, const uint8_t *__restrict__ b,
+                                                                const uint32_t *__restrict__ boffs, const uint8_t *__restrict__ flags,
+                                                                uint32_t n, float *scores, uint8_t *status_out, urmapx_path_op *ops_out,
+                                                                uint16_t *nops_out, uint8_t *scratch, size_t scratch_stride) {
+	constexpr int TBR = VB_MAXL / 8 + 2;
+	__shared__ uint8_t sA[2][VB_MAXL];
+	__shared__ uint8_t sB[2][VB_MAXL + 96];
+	__shared__ uint32_t tb[2][TBR * 64];
+	__shared__ uint16_t rops[2][OPS_CAP];
+	const int lane = threadIdx.x;
+	const VPar VP(P);
+	VFlank F[2];
+	bool narrow[2] = {false, false};
+	int LA[2] = {0, 0}, LB[2] = {0, 0};
+	uint32_t kk[2];
+	for (int h = 0; h < 2; ++h) {
+		kk[h] = 2 * blockIdx.x + h;
+		if (kk[h] >= n) continue;
+		const uint32_t k = kk[h];
+		LA[h] = (int)(aoffs[k + 1] - aoffs[k]); LB[h] = (int)(boffs[k + 1] - boffs[k]);
+		if (LA[h] <= VB_MAXL)
+			for (int i = lane; i < LA[h]; i += 64) sA[h][i] = a[aoffs[k] + i];
+		if (LB[h] <= VB_MAXL + 64)
+			for (int i = lane; i < LB[h]; i += 64) sB[h][16 + i] = b[boffs[k] + i];
+	}
+	__syncthreads();
+	for (int h = 0; h < 2; ++h)
+		if (kk[h] < n && LA[h] <= VB_MAXL && LB[h] <= VB_MAXL + 64)
+			narrow[h] = F[h].setup(VP, sA[h], LA[h], sB[h] + 16, LB[h], flags[kk[h]] & 1, (flags[kk[h]] >> 1) & 1, tb[h], TBR, -3.0e38f, false);
+	if (!narrow[0]) F[0].active = false;
+	if (!narrow[1]) F[1].active = false;
+	viterbi_pair_rows(F[0], F[1]);
+	for (int h = 0; h < 2; ++h) {
+		if (kk[h] >= n) continue;
+		const uint32_t k = kk[h];
+		uint32_t status = 0;
+		float score = 0.0f;
+		RevOps R;
+		R.ops = rops[h];
+		R.begin();
+		if (narrow[h]) score = F[h].finish(R, status);
+		else if (LA[h] > VB_MAXL) status = URMAPX_ST_BAND_TOO_WIDE;
+		else {  // degenerate or wide: the single-problem path
+			WideScratch ws;
+			ws.carve(scratch + (size_t)k * scratch_stride, VB_WIDE_LA, VB_WIDE_LB);
+			score = viterbi_wave(VP, sA[h], LA[h], b + boffs[k], LB[h], flags[k] & 1, (flags[k] >> 1) & 1, tb[h], TBR, ws, R, status, lane);
+		}
+		int nout = R.n;
+		if (nout > URMAPX_MAX_PATH_OPS) { status |= URMAPX_ST_PATH_OVERFLOW; nout = 0; }
+		if (status) nout = 0;
+		__syncthreads();
+		for (int t = lane; t < nout; t += 64) ops_out[(size_t)k * URMAPX_MAX_PATH_OPS + t] = rops[h][nout - 1 - t];
+		if (lane == 0) { scores[k] = score; status_out[k] = (uint8_t)status; nops_out[k] = (uint16_t)nout; }
+		__syncthreads();
+	}
+}
+
 // ------------------------------------------------------------------------------------------------
 // kernel B: per-read search.  One wavefront per read.
 //
@@ -495,10 +555,21 @@ struct SearchWave {
 	// align, or no room left in the job array / the parking lot -- the caller then runs phase 6 itself.
 	__device__ bool park_for_dp(const DpWork &dp, uint32_t r, int phase) {
 		int njobs = 0;
+		bool clipped = false;
 		for (int base = 0; base < hspCount; base += 64) {
 			uint32_t sdb, pk;
-			njobs += __builtin_popcountll(__ballot(hsp_wants_dp(base + lane, sdb, pk)));
+			const bool want = hsp_wants_dp(base + lane, sdb, pk);
+			njobs += __builtin_popcountll(__ballot(want));
+			// a right flank window that the end of the sequence store cuts short (alignhsp.cpp:143-145) makes a band wider than
+			// a wavefront: dp_kernel runs its DPs two to a wavefront in packed int16 and has no wide path -- such a read (it lies
+			// within a read length of the end of the last sequence) keeps its phase 6 in this kernel
+			clipped |= want && (uint64_t)(sdb - (pk & PK_MASK)) + (uint64_t)QL + 2ull * P.band_radius >= (uint64_t)X.seqDataSize;
 		}
+#ifdef URX_DP_PAIR
+		if (__ballot(clipped) != 0) return false;
+#else
+		(void)clipped;
+#endif
 		if (njobs == 0) return false;
 		uint32_t jb = 0, slot = 0;
 		if (lane == 0) jb = atomicAdd(dp.counters, (uint32_t)njobs);
@@ -1268,6 +1339,220 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 #else
 #define URX_DP_ATTR
 #endif
+// URX_DP_PAIR (build-time, off): the round-3 prototype that runs the jobs two to a wavefront with every row >= 1 of
+// both in packed int16 (viterbi_dev.h: VFlank, viterbi_pair_rows).  Bit-identical to the fp32 kernel on every parity test
+// and bench check -- and slower: 6.8 instead of 4.1 ms per 1 M 150-base reads, 77 instead of 37 ms per 1 M 250-base reads
+// (DESIGN.md section 3.4 has the instruction counts).  Kept for the A/B; tests/test_gpu_parity.py runs the packed rows
+// through viterbi_batch_pair_kernel either way.
+#ifdef URX_DP_PAIR
+template <int NCH>
+__global__ __launch_bounds__(64) URX_DP_ATTR void dp_kernel(DevIndex X, urmapx_params P, const uint8_t *__restrict__ bases,
+                                                const uint64_t *__restrict__ offs, DpWork dp, uint8_t *scratch,
+                                                size_t scratch_stride, const uint8_t *__restrict__ g_seq, uint32_t klo, uint32_t khi,
+                                                uint32_t *ticket) {
+	constexpr int QMAX = 64 * NCH;
+	constexpr int TB_ROWS8 = (QMAX - 24) / 8 + 2;
+	// two jobs at a time (viterbi_dev.h: VFlank, viterbi_pair_rows): each has its query strand, target window, trace buffer
+	// and run buffers; the windows sit behind the queries so that the bytes read around a window are LDS
+	__shared__ __attribute__((aligned(16))) uint8_t sQ[2][QMAX];
+	__shared__ uint8_t sT[2][QMAX + 64 + 32];
+	__shared__ uint32_t tb[2][TB_ROWS8 * 64];
+	__shared__ uint16_t ropsL[2][OPS_CAP], ropsR[2][OPS_CAP], cand[URMAPX_MAX_PATH_OPS];
+	const int lane = threadIdx.x;
+	WideScratch ws;
+	ws.carve(scratch + (size_t)blockIdx.x * scratch_stride, QMAX, QMAX + 64);
+	const VPar VP(P);
+	const int BR = 2 * (int)P.band_radius;
+	const uint32_t made = dp.counters[0];
+	const uint32_t njobs = made < dp.jobs_cap ? made : dp.jobs_cap;
+	auto load_window = [&](uint8_t *dst, uint32_t tlo, int tl) {  // true: the window holds a '-' pad byte
+		bool gap = false;
+		for (int i = lane; i < tl; i += 64) {
+			const uint8_t c = g_seq[tlo + i];
+			dst[i] = c;
+			gap |= (c == '-');
+		}
+		__syncthreads();
+		return __ballot(gap) != 0;
+	};
+	uint32_t n_gated = 0;  // statistics
+	// this round's jobs: those with klo <= k < khi.  Blocks take tiles of DP_TILE consecutive jobs from the round's work
+	// counter (a read in a repeat family owns hundreds of consecutive jobs of the last round and none of the first: a
+	// fixed tile-to-block map left blocks idle while others still had a dozen DPs to run); the k of a tile's jobs comes in
+	// with one load and the block runs those of this round two at a time.
+#ifndef URX_DP_TILE
+#define URX_DP_TILE 32  // 8: 8.6 ms, 16: 5.7, 32: 5.3, 48: 5.6, 64: 5.9 per 1 M 150-base reads (the counter is one address for all blocks)
+#endif
+	constexpr uint32_t DP_TILE = URX_DP_TILE;
+	for (;;) {
+	uint32_t tile = 0;
+	if (lane == 0) tile = atomicAdd(ticket, DP_TILE);
+	tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)tile);
+	if (tile >= njobs) break;
+	uint32_t kk = 0xFFFFu;  // 0xFFFF: slot not in use
+	if (lane < (int)DP_TILE && tile + lane < njobs) kk = dp.kidx[tile + lane];
+	uint64_t todo = __ballot(kk >= klo && kk < khi && kk != 0xFFFFu);
+	while (todo) {
+		// ---- up to two jobs that pass AlignHSP's first test under the cap the replay has reached so far ----
+		struct JobState {
+			uint32_t j, startdb, pk, flags, vst_l, vst_r, combinedTLo;
+			int maxpen, QL, startq, len, leftScore, rightScore, rtrim, totalPen, nL, nR;
+			bool plus;
+		} js[2];
+		// (every index into js / F below is a compile-time constant after unrolling: a run-time index would put both
+		// problems' state into scratch memory -- the first version of this loop ran five times slower for it)
+		auto take_job = [&](JobState &S, uint8_t *sq) -> bool {
+			while (todo) {
+				const uint32_t j = tile + (uint32_t)__builtin_ctzll(todo);
+				todo &= todo - 1;
+				const DpJob J = dp.jobs[j];
+				if (J.read == 0xFFFFFFFFu) continue;
+				const int glen = (int)((J.pk >> PK_LEN_SH) & PK_MASK), gscore = (int)((J.pk >> PK_SCORE_SH) & PK_MASK);
+				if (glen - gscore > J.maxpen) {  // the cap only falls
+					if (lane == 0) dp.jobs[j].flags = DPJ_GATED;
+					++n_gated;
+					continue;
+				}
+				S.j = j; S.startdb = J.startdb; S.pk = J.pk; S.maxpen = J.maxpen;
+				const uint64_t off = offs[J.read];
+				S.QL = (int)(offs[J.read + 1] - off);
+				S.startq = (int)(J.pk & PK_MASK); S.len = glen;
+				S.plus = (J.pk >> PK_PLUS_SH) & 1u;
+				S.flags = 0; S.vst_l = 0; S.vst_r = 0; S.combinedTLo = J.startdb;
+				S.leftScore = 0; S.rightScore = 0; S.rtrim = 0; S.totalPen = glen - gscore; S.nL = 0; S.nR = 0;
+				__syncthreads();
+				const uint8_t *q = bases + off;
+#pragma unroll
+				for (int c = 0; c < NCH; ++c) {
+					const int p = 64 * c + lane;
+					if (p < S.QL) sq[p] = S.plus ? q[p] : (uint8_t)comp_char(q[S.QL - 1 - p]);
+				}
+				return true;
+			}
+			return false;
+		};
+		bool have[2];
+		have[0] = take_job(js[0], sQ[0]);
+		have[1] = have[0] && take_job(js[1], sQ[1]);
+		if (!have[0]) break;
+		__syncthreads();
+		// ---- the left flanks of both jobs, then the right flanks (the right one's budget depends on the left one's outcome) ----
+#pragma unroll 1
+		for (int side = 0; side < 2; ++side) {
+			const bool left = side == 0;
+			VFlank F[2];
+			bool run[2] = {false, false}, narrow[2] = {false, false};
+			int fql[2] = {0, 0}, allGap[2] = {0, 0}, need[2] = {0, 0};
+			uint32_t tlo[2] = {0, 0}, tl[2] = {0, 0};
+#pragma unroll
+			for (int h = 0; h < 2; ++h) {
+				F[h].active = false;
+				if (!have[h]) continue;
+				JobState &S = js[h];
+				if (left) {
+					if (S.startq <= 0) continue;
+					fql[h] = S.startq;
+					const uint32_t leftTHi = S.startdb - 1;
+					tl[h] = (uint32_t)(fql[h] + BR);
+					if (S.startdb < (uint32_t)S.startq || tl[h] >= leftTHi) { S.flags |= DPJ_LEFT_FAIL; continue; }
+					tlo[h] = leftTHi - tl[h] + 1;
+				} else {
+					const int rightQLo = S.startq + S.len;
+					if ((S.flags & DPJ_LEFT_FAIL) || rightQLo >= S.QL) continue;
+					if (S.totalPen > S.maxpen) { S.flags |= DPJ_RIGHT_SKIPPED; continue; }
+					fql[h] = S.QL - rightQLo;
+					tlo[h] = S.startdb + (uint32_t)S.len;
+					uint32_t thi = tlo[h] + (uint32_t)fql[h] + (uint32_t)BR;
+					if (thi >= X.seqDataSize) thi = X.seqDataSize - 1;
+					tl[h] = thi - tlo[h] + 1;
+				}
+				if (load_window(sT[h] + 32, tlo[h], (int)tl[h])) { S.flags |= left ? DPJ_LEFT_FAIL : DPJ_RIGHT_FAIL; continue; }
+				// a flank score below `need` puts the penalty over the cap the job was made under (unless the all-gap floor
+				// rescues it): the DP may stop as soon as that is certain
+				allGap[h] = P.gap_open_score + (fql[h] - 1) * P.gap_ext_score;
+				need[h] = fql[h] - (S.maxpen - S.totalPen);
+				run[h] = true;
+				narrow[h] = F[h].setup(VP, left ? sQ[h] : sQ[h] + (S.startq + S.len), fql[h], sT[h] + 32, (int)tl[h], left, !left, tb[h], TB_ROWS8,
+				                       (float)need[h], allGap[h] < need[h]);
+				if (!narrow[h]) F[h].active = false;
+			}
+			viterbi_pair_rows(F[0], F[1]);
+#pragma unroll
+			for (int h = 0; h < 2; ++h) {
+				if (!run[h]) continue;
+				JobState &S = js[h];
+				RevOps R;
+				R.ops = left ? ropsL[h] : ropsR[h];
+				uint32_t vst = 0;
+				int score;
+				bool aborted = false;
+				if (narrow[h]) {
+					score = (int)F[h].finish(R, vst);
+					aborted = F[h].aborted;
+				} else {  // cannot happen: the search kernel keeps reads with a clipped flank window to itself (park_for_dp)
+					score = 0; R.begin(); vst = URMAPX_ST_BAND_TOO_WIDE;
+				}
+				if (aborted) { score = need[h] - 1; R.begin(); vst = 0; if (!left) S.flags |= DPJ_RIGHT_ABORTED; }
+				if (left) {
+					S.vst_l = vst;
+					S.nL = R.n;
+					// TrimLeftIs (pathinfo.cpp:153-171): the leading I run is the last run in traceback order
+					int nTrimI = 0;
+					if (S.nL > 0) {
+						const uint32_t lastop = ropsL[h][S.nL - 1];
+						if ((lastop & 3u) == OP_I) { nTrimI = (int)(lastop >> 2); --S.nL; }
+					}
+					S.combinedTLo = tlo[h] + (uint32_t)nTrimI;
+					if (allGap[h] > score) score = allGap[h];
+					S.leftScore = score;
+					S.totalPen += fql[h] - score;
+				} else {
+					S.vst_r = vst;
+					S.nR = R.n;
+					// TrimRightIs (pathinfo.cpp:173-190): trailing I run = first run in traceback order, never the whole path
+					if (S.nR > 1 && (ropsR[h][0] & 3u) == OP_I) S.rtrim = 1;
+					if (allGap[h] > score) score = allGap[h];
+					S.rightScore = score;
+				}
+			}
+		}
+		// ---- per job: path = Left || M x len || Right, run-length merged (uniform; lane 0 stores into LDS, then one coalesced copy) ----
+#pragma unroll
+		for (int h = 0; h < 2; ++h) {
+			if (!have[h]) continue;
+			JobState &S = js[h];
+			int nc = 0;
+			if (!(S.flags & (DPJ_LEFT_FAIL | DPJ_RIGHT_FAIL | DPJ_RIGHT_SKIPPED | DPJ_RIGHT_ABORTED))) {
+				int cop = -1, clen = 0;
+				bool ovf = false;
+				auto put = [&](int op, int l) {
+					if (l <= 0) return;
+					if (op == cop) { clen += l; return; }
+					if (clen) { if (nc < URMAPX_MAX_PATH_OPS) { if (lane == 0) cand[nc] = (uint16_t)((clen << 2) | cop); ++nc; } else ovf = true; }
+					cop = op; clen = l;
+				};
+				for (int t = S.nL - 1; t >= 0; --t) { const uint32_t o = ropsL[h][t]; put((int)(o & 3u), (int)(o >> 2)); }
+				put(OP_M, S.len);
+				for (int t = S.nR - 1; t >= S.rtrim; --t) { const uint32_t o = ropsR[h][t]; put((int)(o & 3u), (int)(o >> 2)); }
+				put(-2, 1);  // flush
+				if (ovf) { S.flags |= DPJ_PATH_LONG; nc = 0; }
+				__syncthreads();
+				uint16_t *out = dp.ops + (size_t)S.j * DP_JOB_OPS;
+				for (int t = lane; t < nc; t += 64) out[t] = cand[t];
+				__syncthreads();
+			}
+			if (lane == 0) {
+				DpJob *o = dp.jobs + S.j;
+				o->combined_tlo = S.combinedTLo;
+				o->left_score = (int16_t)S.leftScore; o->right_score = (int16_t)S.rightScore;
+				o->nops = (uint8_t)nc; o->flags = (uint8_t)S.flags; o->vst_l = (uint8_t)S.vst_l; o->vst_r = (uint8_t)S.vst_r;
+			}
+		}
+	}
+	}
+	if (lane == 0 && n_gated) atomicAdd(dp.counters + 3, n_gated);
+}
+#else
 template <int NCH>
 __global__ __launch_bounds__(64) URX_DP_ATTR void dp_kernel(DevIndex X, urmapx_params P, const uint8_t *__restrict__ bases,
                                                 const uint64_t *__restrict__ offs, DpWork dp, uint8_t *scratch,
@@ -1429,6 +1714,7 @@ __global__ __launch_bounds__(64) URX_DP_ATTR void dp_kernel(DevIndex X, urmapx_p
 	}
 	if (lane == 0 && n_gated) atomicAdd(dp.counters + 3, n_gated);
 }
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // kernel D: phase 6's ordered part for the parked reads -- the jobs of a read in HSP order through AlignHSP's tests
@@ -1817,8 +2103,12 @@ hipError_t launch_viterbi_batch(const urmapx_params &P, const uint8_t *d_a, cons
                                 float *d_scores, uint8_t *d_status, urmapx_path_op *d_ops, uint16_t *d_nops,
                                 uint8_t *d_scratch, hipStream_t s) {
 	if (n == 0) return hipSuccess;
-	hipLaunchKernelGGL(viterbi_batch_kernel, dim3(n), dim3(64), 0, s, P, d_a, d_aoffs, d_b, d_boffs, d_flags, n, d_scores,
-	                   d_status, d_ops, d_nops, d_scratch, viterbi_batch_scratch_stride());
+	if (getenv("URMAPX_VITERBI_PAIR"))  // test aid: two problems per wavefront, packed-int16 interior blocks
+		hipLaunchKernelGGL(viterbi_batch_pair_kernel, dim3((n + 1) / 2), dim3(64), 0, s, P, d_a, d_aoffs, d_b, d_boffs, d_flags, n, d_scores,
+		                   d_status, d_ops, d_nops, d_scratch, viterbi_batch_scratch_stride());
+	else
+		hipLaunchKernelGGL(viterbi_batch_kernel, dim3(n), dim3(64), 0, s, P, d_a, d_aoffs, d_b, d_boffs, d_flags, n, d_scores,
+		                   d_status, d_ops, d_nops, d_scratch, viterbi_batch_scratch_stride());
 	return hipGetLastError();
 }
 

@@ -345,6 +345,329 @@ __device__ __forceinline__ float viterbi_wave(const VPar P, const uint8_t *A, in
 	return Score;
 }
 
+// ------------------------------------------------------------------------------------------------
+// two banded problems in one wavefront: the row blocks in the interior of both bands run in packed int16
+// ------------------------------------------------------------------------------------------------
+// VFlank is viterbi_wave's narrow path as a resumable object: row 0, edge row blocks, interior row blocks, the last
+// insert row and the traceback are separate steps, so that a caller can advance two problems side by side
+// (viterbi_pair_rows).  Where both stand before eight rows in the interior of their bands -- every band lane is a band
+// cell in every row: most rows of a long flank -- the eight rows of BOTH problems are computed by ONE instruction stream
+// on packed 16-bit integers (v_pk_add_i16 / v_pk_max_i16; one problem per register half), ~31 instructions per row and
+// problem instead of 61.  Exactness: DP values are small integers (|x| <= 6 * 320), -9e9 becomes -32768 and every add is
+// saturating, so a dead cell stays far below any live one and every comparison between live values is the comparison
+// fp32 makes; a `>` / `>=` between two dead values may come out differently (fp32 absorbs small addends into -9e9, int16
+// lets them drift by +1 per row), but a dead cell is never on the path the traceback follows.  At the end of a block
+// the state goes back to fp32 with everything below -16000 mapped to -9e9 again, so the rows in fp32 around it -- row 0,
+// the band's edges, the last insert row -- see exactly the state the all-fp32 sweep leaves.
+typedef short vshort2 __attribute__((ext_vector_type(2)));
+typedef unsigned short vushort2 __attribute__((ext_vector_type(2)));
+
+struct VFlank {
+	// problem
+	const uint8_t *A, *B;  // LDS: query flank, target window (bytes around B may be read, never used)
+	int LA, LB;
+	bool Left, Right;
+	uint32_t *tb;          // LDS, tb_rows8 * 64 dwords
+	// geometry
+	int dlo, ND, jbase, int_lo, int_hi;
+	bool real;
+	uint32_t LBr;
+	int LBs;
+	uint32_t bits0c;
+	// state
+	float M, Dn;
+	uint32_t acc;
+	int i;                 // next row
+	bool active;           // rows still to do
+	bool aborted;
+	float abort_below;
+	bool may_abort;
+	// constants
+	float GO, GE, GOl, GEl, MISf, flane, el, el1;
+	int lane;
+
+	// false: not a narrow problem with rows to sweep (degenerate, or a band wider than the wavefront): the caller runs
+	// viterbi_wave on it instead
+	__device__ __forceinline__ bool setup(const VPar P, const uint8_t *A_, int LA_, const uint8_t *B_, int LB_, bool Left_, bool Right_,
+	                                      uint32_t *tb_, int tb_rows8, float abort_below_, bool may_abort_) {
+		lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+		A = A_; B = B_; LA = LA_; LB = LB_; Left = Left_; Right = Right_; tb = tb_;
+		active = false; aborted = false; abort_below = abort_below_; may_abort = may_abort_;
+		if (LA == 0 || LB == 0) return false;
+		const int Rad = P.band_radius;
+		dlo = min(LA, LB);
+		int dhi = max(LA, LB);
+		dlo = dlo > Rad ? dlo - Rad : 1;
+		dhi += Rad;
+		if (dhi > LA + LB - 1) dhi = LA + LB - 1;
+		ND = dhi - dlo + 1;
+		if (ND + 2 > 64 || LB - dlo + 2 > 63 || ((LA + 1 + 7) >> 3) > tb_rows8) return false;
+		GO = (float)P.gap_open_score; GE = (float)P.gap_ext_score;
+		GOl = Left ? 0.0f : GO; GEl = Left ? 0.0f : GE;
+		MISf = (float)P.mismatch_score;
+		flane = (float)lane;
+		el = GE * flane; el1 = GE * (flane - 1.0f);
+		jbase = dlo - 1 + lane - LA;
+		real = lane >= 1 && lane <= ND;
+		LBr = real ? (uint32_t)LB : 0u;
+		LBs = (lane >= 1 && lane <= ND + 1) ? LB : -(1 << 20);
+		bits0c = lane == 0 ? TB_IM : 0u;
+		int_lo = LA - dlo + 1;
+		int_hi = LB - (dlo + ND - LA) - 7;
+		M = NEG; Dn = NEG; acc = 0; i = 0;
+		active = true;
+		return true;
+	}
+
+	// row 0: the only row with special cases of its own (free gaps of a Left problem, the origin cell)
+	__device__ __forceinline__ void row0() {
+		const int j = jbase;
+		const bool act = real && j >= 0 && j < LB;
+		const bool semi = (j == LB) && lane >= 1 && lane <= ND + 1;
+		const float OpenA = Left ? 0.0f : GO;
+		const float ExtA = Left ? 0.0f : GE;
+		float Mcur = M;
+		if (j == 0) Mcur = 0.0f;
+		const float D = wave_shl1(Dn, NEG);
+		const uint32_t a = A[0];
+		const uint32_t b = act ? B[j] : 0u;
+		const float v = act ? (Mcur + OpenA) : NEG;
+		const float u = v - ExtA * flane;
+		const float Pm = wave_prefix_max(u);
+		const float I = wave_shr1(Pm, NEG) + ExtA * (flane - 1.0f);
+		uint32_t bits = 0;
+		if (act) {
+			float xM = Mcur;
+			if (D > xM) { xM = D; bits = TB_DM; }
+			if (I > xM) { xM = I; bits = TB_IM; }
+			M = xM + (a == b ? 1.0f : MISf);
+			const bool freeB = (j == 0 && Left);
+			const float md = Mcur + (freeB ? 0.0f : GO);
+			float Dnew = D + (freeB ? 0.0f : GE);
+			if (md >= Dnew) { Dnew = md; bits |= TB_MD; }
+			Dn = Dnew;
+			const float mi = Mcur + OpenA;
+			const float Ie = I + ExtA;
+			if (mi >= Ie) bits |= TB_MI;
+		} else if (semi) {
+			const float md = Mcur + GO;
+			float Dnew = D + GE;
+			if (md >= Dnew) { Dnew = md; bits = TB_MD; }
+			Dn = Dnew;
+			M = NEG;
+		} else if (lane == 0 && j >= 0) {
+			bits = TB_IM;
+		}
+		acc |= bits;
+		i = 1;
+		if (i >= LA) active = false;
+	}
+
+	// last row of the insert matrix, final state, traceback (viterbi_wave's tail); returns the score
+	__device__ __forceinline__ float finish(RevOps &R, uint32_t &status) {
+		R.begin();
+		if (aborted) return 0.0f;
+		float FinalI;
+		{
+			const int jf = dlo - 1 + lane;
+			const bool validf = jf < LB;
+			const float GapOp = Right ? 0.0f : GO, GapEx = Right ? 0.0f : GE;
+			const float Mlast = (lane == 0) ? NEG : M;
+			const float v = validf ? (Mlast + GapOp) : NEG;
+			const float u = v - GapEx * flane;
+			const float Pm = wave_prefix_max(u);
+			const float Ibefore = wave_shr1(Pm, NEG) + GapEx * (flane - 1.0f);
+			const float Ie = Ibefore + GapEx;
+			const uint32_t bits = (validf && v > Ie) ? TB_MI : 0u;
+			const float Iafter = fmaxf(v, Ie);
+			acc |= bits << (4 * (LA & 7));
+			tb[(LA >> 3) * 64 + lane] = acc;
+			FinalI = rdlane(Iafter, LB - dlo);
+		}
+		const float FinalM = rdlane(M, LB - dlo + 1);
+		const float FinalD = rdlane(Dn, LB - dlo + 2);
+		float Score = FinalM;
+		int st = OP_M;
+		if (FinalD > Score) { Score = FinalD; st = OP_D; }
+		if (FinalI > Score) { Score = FinalI; st = OP_I; }
+		__syncthreads();
+		int ii = LA, j = LB;
+		int guard = LA + LB + 2;
+		while ((ii | j) != 0 && guard-- > 0) {
+			int n, ri, cj;
+			uint32_t stop;
+			if (st == OP_M) { n = min(ii, j); ri = ii - 1 - lane; cj = j - 1 - lane; stop = TB_DM | TB_IM; }
+			else if (st == OP_D) { n = ii; ri = ii - 1 - lane; cj = j; stop = TB_MD; }
+			else { n = j; ri = ii; cj = j - 1 - lane; stop = TB_MI; }
+			if (n <= 0) break;
+			if (n > 64) n = 64;
+			uint32_t t = 0;
+			if (lane < n) {
+				const int l = (LA - ri + cj - dlo + 1) & 63;
+				t = (tb[(ri >> 3) * 64 + l] >> (4 * (ri & 7))) & 15u;
+			}
+			const uint64_t ends = __ballot(lane < n && (t & stop) != 0);
+			const int len = ends ? (int)__builtin_ctzll(ends) + 1 : n;
+			R.emit_run(st, len, lane);
+			int nst = st;
+			if (ends) {
+				const uint32_t te = rdlane(t, len - 1);
+				if (st == OP_M) nst = (te & TB_DM) ? OP_D : OP_I;
+				else nst = OP_M;
+			}
+			if (st == OP_M) { ii -= len; j -= len; }
+			else if (st == OP_D) ii -= len;
+			else j -= len;
+			st = nst;
+		}
+		R.end(lane);
+		if (R.overflow) status |= URMAPX_ST_PATH_OVERFLOW;
+		__syncthreads();
+		return Score;
+	}
+};
+
+__device__ __forceinline__ vshort2 pk_s2(uint32_t x) { return __builtin_bit_cast(vshort2, x); }
+__device__ __forceinline__ uint32_t pk_u(vshort2 x) { return __builtin_bit_cast(uint32_t, x); }
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ vshort2 pk_dpp(vshort2 v, vshort2 fill) {
+	return pk_s2((uint32_t)__builtin_amdgcn_update_dpp((int)pk_u(fill), (int)pk_u(v), CTRL, ROWMASK, 0xF, false));
+}
+// 0xFFFF in each half where a < b (signed): the saturated difference's sign, spread over the half
+__device__ __forceinline__ uint32_t pk_ltm(vshort2 a, vshort2 b) {
+	return pk_u(__builtin_elementwise_sub_sat(a, b) >> (vshort2)((short)15));
+}
+// 0xFFFF in each half where the half of x is zero
+__device__ __forceinline__ uint32_t pk_zerom(uint32_t x) {
+	const vushort2 t = __builtin_elementwise_min(__builtin_bit_cast(vushort2, x), (vushort2)((unsigned short)1));
+	return __builtin_bit_cast(uint32_t, t - (vushort2)((unsigned short)1));
+}
+__device__ __forceinline__ uint32_t pk_sel(uint32_t m, uint32_t a, uint32_t b) { return (a & m) | (b & ~m); }  // v_bfi_b32
+__device__ __forceinline__ int f2pk(float x) { return x < -30000.0f ? -32768 : (int)x; }
+__device__ __forceinline__ float pk2f(int x) { return x < -16000 ? NEG : (float)x; }
+__device__ __forceinline__ uint32_t pk_pair(int lo, int hi) { return ((uint32_t)lo & 0xFFFFu) | ((uint32_t)hi << 16); }
+
+// Rows 1 .. LA-1 of two problems (either may be inactive), all of them in packed int16: the two problems advance row by
+// row together (both start at row 1, so their eight-row trace blocks stay aligned); a problem that is out of rows, or whose
+// score can no longer reach what its caller needs, freezes in its register half while the other goes on.  The lane
+// classes of viterbi_wave's select-only rows (band cell / column LB / column 0 / outside) become 16-bit masks per half.
+__device__ __forceinline__ void viterbi_pair_rows(VFlank &a, VFlank &b) {
+	if (a.active) a.row0();
+	if (b.active) b.row0();
+	if (!a.active && !b.active) return;
+	const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+	const bool ua = a.active, ub = b.active;  // problems that have rows beyond row 0
+	const VFlank &g = ua ? a : b;             // scoring constants are the same for both
+	const vshort2 NEG2 = (vshort2)((short)-32768);
+	const uint32_t GO2 = pk_pair((int)g.GO, (int)g.GO), GE2 = pk_pair((int)g.GE, (int)g.GE);
+	const uint32_t GOl2 = pk_pair(ua ? (int)a.GOl : 0, ub ? (int)b.GOl : 0), GEl2 = pk_pair(ua ? (int)a.GEl : 0, ub ? (int)b.GEl : 0);
+	const vshort2 ONE2 = (vshort2)((short)1);
+	const vshort2 MISM1 = (vshort2)((short)((int)g.MISf - 1));
+	const vshort2 el2 = (vshort2)((short)((int)g.GE * lane)), el12 = (vshort2)((short)((int)g.GE * (lane - 1)));
+	const uint32_t realm = ((ua && a.real) ? 0x0000FFFFu : 0u) | ((ub && b.real) ? 0xFFFF0000u : 0u);
+	const uint32_t semil = ((ua && lane >= 1 && lane <= a.ND + 1) ? 0x0000FFFFu : 0u) | ((ub && lane >= 1 && lane <= b.ND + 1) ? 0xFFFF0000u : 0u);
+	const uint32_t b0c = lane == 0 ? (uint32_t)(TB_IM | (TB_IM << 16)) : 0u;
+	const vshort2 LB2 = pk_s2(pk_pair(ua ? a.LB : 0, ub ? b.LB : 0));
+	const int LAa = ua ? a.LA : 0, LAb = ub ? b.LA : 0;
+	vshort2 M = pk_s2(pk_pair(ua ? f2pk(a.M) : -32768, ub ? f2pk(b.M) : -32768));
+	vshort2 Dn = pk_s2(pk_pair(ua ? f2pk(a.Dn) : -32768, ub ? f2pk(b.Dn) : -32768));
+	uint32_t accA = ua ? a.acc : 0u, accB = ub ? b.acc : 0u;
+	bool liveA = ua, liveB = ub;
+	int i = 1;
+	while (liveA || liveB) {
+		const int i0 = i;
+		const int lim = max(liveA ? LAa : 0, liveB ? LAb : 0);
+		const int n = min(8 - (i0 & 7), lim - i0);
+		const uint8_t *Aa = (ua ? a.A : b.A) + i0, *Ab = (ub ? b.A : a.A) + i0;
+		const uint8_t *Ba = (ua ? a.B + a.jbase : b.B + b.jbase) + i0, *Bb = (ub ? b.B + b.jbase : a.B + a.jbase) + i0;
+		uint32_t av[8], bv[8];
+#pragma unroll
+		for (int k = 0; k < 8; ++k) {
+			av[k] = (uint32_t)Aa[k] | ((uint32_t)Ab[k] << 16);
+			bv[k] = (uint32_t)Ba[k] | ((uint32_t)Bb[k] << 16);
+		}
+		const uint32_t j0 = pk_pair((ua ? a.jbase : 0) + i0, (ub ? b.jbase : 0) + i0);
+		uint32_t word = 0;   // both problems' trace nibbles of this block: problem A in the low halves ... see below
+		uint32_t wa = 0, wb = 0;
+#pragma unroll
+		for (int k = 0; k < 8; ++k) {
+			if (k < n) {  // wave-uniform
+				// rows a problem does not have any more (or that lie behind its abort) change nothing in its half
+				const uint32_t rowm = ((liveA && i0 + k < LAa) ? 0x0000FFFFu : 0u) | ((liveB && i0 + k < LAb) ? 0xFFFF0000u : 0u);
+				const vshort2 jv = pk_s2(j0 + (uint32_t)k * 0x00010001u);
+				const uint32_t ge0 = ~pk_ltm(jv, (vshort2)((short)0));
+				const uint32_t actm = realm & ge0 & pk_ltm(jv, LB2) & rowm;
+				const uint32_t semim = semil & pk_zerom(pk_u(jv) ^ pk_u(LB2)) & rowm;
+				const uint32_t col0m = pk_zerom(pk_u(jv));
+				const vshort2 D = pk_dpp<0x130, 0xF>(Dn, NEG2);
+				const vshort2 Mcur = M;
+				const vshort2 vraw = __builtin_elementwise_add_sat(Mcur, pk_s2(GO2));
+				const vshort2 v = pk_s2(pk_sel(actm, pk_u(vraw), pk_u(NEG2)));
+				vshort2 Pm = __builtin_elementwise_sub_sat(v, el2);
+				Pm = __builtin_elementwise_max(Pm, pk_dpp<0x111, 0xF>(Pm, NEG2));
+				Pm = __builtin_elementwise_max(Pm, pk_dpp<0x112, 0xF>(Pm, NEG2));
+				Pm = __builtin_elementwise_max(Pm, pk_dpp<0x114, 0xF>(Pm, NEG2));
+				Pm = __builtin_elementwise_max(Pm, pk_dpp<0x118, 0xF>(Pm, NEG2));
+				Pm = __builtin_elementwise_max(Pm, pk_dpp<0x142, 0xA>(Pm, NEG2));
+				Pm = __builtin_elementwise_max(Pm, pk_dpp<0x143, 0xC>(Pm, NEG2));
+				const vshort2 I = __builtin_elementwise_add_sat(pk_dpp<0x138, 0xF>(Pm, NEG2), el12);
+				// M state: best of M, D ('>'), I ('>')
+				const uint32_t dm = pk_ltm(Mcur, D) & 0x00010001u;
+				vshort2 xM = __builtin_elementwise_max(Mcur, D);
+				const uint32_t im = pk_ltm(xM, I) & 0x00010001u;
+				xM = __builtin_elementwise_max(xM, I);
+				const vshort2 nz = __builtin_bit_cast(vshort2, __builtin_elementwise_min(__builtin_bit_cast(vushort2, av[k] ^ bv[k]), (vushort2)((unsigned short)1)));
+				const vshort2 Mnew = __builtin_elementwise_add_sat(xM, nz * MISM1 + ONE2);
+				// D state: open ('>=' wins) or extend; free in column 0 of a Left problem
+				const vshort2 md = __builtin_elementwise_add_sat(Mcur, pk_s2(pk_sel(col0m, GOl2, GO2)));
+				const vshort2 de = __builtin_elementwise_add_sat(D, pk_s2(pk_sel(col0m, GEl2, GE2)));
+				const uint32_t bMD = (~pk_ltm(md, de)) & 0x00040004u;
+				const vshort2 Dnew = __builtin_elementwise_max(md, de);
+				// I state: open ('>=' wins) or extend
+				const uint32_t bMI = (~pk_ltm(vraw, __builtin_elementwise_add_sat(I, pk_s2(GE2)))) & 0x00080008u;
+				uint32_t bits = (dm & ~im) | (im << 1) | bMD | bMI;
+				M = pk_s2(pk_sel(actm, pk_u(Mnew), pk_sel(semim, pk_u(NEG2), pk_u(M))));
+				Dn = pk_s2(pk_sel(actm | semim, pk_u(Dnew), pk_u(Dn)));
+				bits = pk_sel(actm, bits, pk_sel(semim, bMD, b0c & ge0 & rowm));
+				wa |= (bits & 0xFu) << (4 * k);
+				wb |= ((bits >> 16) & 0xFu) << (4 * k);
+			}
+		}
+		(void)word;
+		const int sh0 = 4 * (i0 & 7);
+		accA |= wa << sh0;
+		accB |= wb << sh0;
+		i = i0 + n;
+		// a problem's block is complete when its rows reach the next multiple of eight (else finish() stores the last, partial one)
+		if (liveA) {
+			const int na = min(8 - (i0 & 7), LAa - i0);
+			if (((i0 + na) & 7) == 0) { a.tb[(i0 >> 3) * 64 + lane] = accA; accA = 0; }
+			if (i >= LAa) liveA = false;
+		}
+		if (liveB) {
+			const int nb = min(8 - (i0 & 7), LAb - i0);
+			if (((i0 + nb) & 7) == 0) { b.tb[(i0 >> 3) * 64 + lane] = accB; accB = 0; }
+			if (i >= LAb) liveB = false;
+		}
+		// can the final score still reach what the caller needs?  (best value of the row plus one point per query letter to come)
+		if ((liveA && a.may_abort) || (liveB && b.may_abort)) {
+			vshort2 t = __builtin_elementwise_max(M, Dn);
+			t = __builtin_elementwise_max(t, pk_dpp<0x111, 0xF>(t, NEG2));
+			t = __builtin_elementwise_max(t, pk_dpp<0x112, 0xF>(t, NEG2));
+			t = __builtin_elementwise_max(t, pk_dpp<0x114, 0xF>(t, NEG2));
+			t = __builtin_elementwise_max(t, pk_dpp<0x118, 0xF>(t, NEG2));
+			t = __builtin_elementwise_max(t, pk_dpp<0x142, 0xA>(t, NEG2));
+			t = __builtin_elementwise_max(t, pk_dpp<0x143, 0xC>(t, NEG2));
+			const uint32_t top = rdlane(pk_u(t), 63);
+			if (liveA && a.may_abort && pk2f((int)(short)(top & 0xFFFFu)) + (float)(LAa - i) < a.abort_below) { a.aborted = true; liveA = false; }
+			if (liveB && b.may_abort && pk2f((int)(short)(top >> 16)) + (float)(LAb - i) < b.abort_below) { b.aborted = true; liveB = false; }
+		}
+	}
+	const uint32_t m2 = pk_u(M), d2 = pk_u(Dn);
+	if (ua) { a.M = pk2f((int)(short)(m2 & 0xFFFFu)); a.Dn = pk2f((int)(short)(d2 & 0xFFFFu)); a.acc = accA; a.active = false; }
+	if (ub) { b.M = pk2f((int)(short)(m2 >> 16)); b.Dn = pk2f((int)(short)(d2 >> 16)); b.acc = accB; b.active = false; }
+}
+
 // Wide-band fallback (band wider than one wavefront: a flank window clipped at the end of the sequence store,
 // or the paired-end rescue's whole-read DP against a 1 kb window).  Same recurrences and tie rules.  The matrix is
 // swept in vertical strips of 64 columns, lane = column: a column's M and D values stay in that lane's registers
