@@ -760,12 +760,16 @@ def kernel_table(api, pe, L, nb, kms, counters, total_bp, gather_loads_s, stage_
     (SURVEY.md 8d), counted by the oracle on the sample: probe kernel 5 B per GetBlob + the read; search kernel 5 B per
     chain slot + compared reference bases + the result record; DP kernel the target bases of the DP windows + the
     query flanks they are aligned with.  Single-end: the search is six launches (main / DP / finalize, then the same
-    for the few reads whose lists outgrew the first pass's); paired-end: one search kernel."""
+    for the few reads whose lists outgrew the first pass's); paired-end: one search kernel (seed + probe inside)."""
     c = counters
     probe_bytes = 5.0 * c["n_getblob"] + L
-    if pe or stage_ms is None:
+    if pe:
+        # paired-end: seed + probe of a pair's mates run at the start of that pair inside the search kernel (round 3)
+        rows = [("search_pe_kernel", float(kms[1]),
+                 probe_bytes + 5.0 * c["n_rowhop"] + c["n_extbases"] + c["n_dptarget"] + api.RESULT_DTYPE.itemsize)]
+    elif stage_ms is None:
         rows = [("seed_probe_kernel", float(kms[0]), probe_bytes)]
-        rows.append(("search_pe_kernel" if pe else "search_se_kernel", float(kms[1]),
+        rows.append(("search_se_kernel", float(kms[1]),
                      5.0 * c["n_rowhop"] + c["n_extbases"] + c["n_dptarget"] + api.RESULT_DTYPE.itemsize))
     else:
         # single-end: seed + probe run inside the search kernel (the next read's slots are gathered into LDS while the

@@ -92,7 +92,7 @@ def test_fastq_writer_of_the_file_to_file_run(tmp_path):
 
 def test_kernel_table_lists_the_launches_of_a_single_end_step():
     """Single-end: seed + probe run inside the search kernel (its algorithmic bytes are both stages'), then the DP launches,
-    the finalize launches, the second pass and the general kernel; paired-end keeps the probe launch."""
+    the finalize launches, the second pass and the general kernel; paired-end is one search kernel with the probe inside."""
     class FakeApi:
         class RESULT_DTYPE:
             itemsize = 28
@@ -104,4 +104,5 @@ def test_kernel_table_lists_the_launches_of_a_single_end_step():
     assert abs(k[0]["alg_bytes_per_read"] - alg) < 1e-6
     assert abs(k[0]["achieved_GBs"] - alg * 1e6 / 20e-3 / 1e9) < 0.01
     kp = bench.kernel_table(FakeApi, True, 150, 1_000_000, [6.4, 47.0], c, 3.1e9, 4.6e10)
-    assert [x["kernel"] for x in kp] == ["seed_probe_kernel", "search_pe_kernel"]
+    assert [x["kernel"] for x in kp] == ["search_pe_kernel"]   # seed + probe run inside it since round 3
+    assert abs(kp[0]["alg_bytes_per_read"] - (alg + 90)) < 1e-6

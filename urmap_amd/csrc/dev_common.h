@@ -426,6 +426,14 @@ __device__ __forceinline__ uint32_t lds_addr(const T *p) {  // the LDS aperture 
 // 16 zero bytes: what lanes without a k-mer gather instead of a slot (tally 0 = TALLY_FREE)
 static __device__ uint32_t g_zero16[4];
 
+// Barrier of a one-wavefront block that orders LDS traffic only: __syncthreads() also waits for every global load and
+// store in flight (s_waitcnt vmcnt(0)), which is a memory round trip where stores were just issued.
+__device__ __forceinline__ void lds_sync() {
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+	__builtin_amdgcn_s_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 // The slots of the k-mers that start in one 64-position chunk of a read, both strands (State1::SetSlotsVec,
 // state1.cpp:396-438, with murmur64 / WordToSlot, ufindex.h:50-65): lane l cuts the W letters of the k-mer starting at
 // position 64c + l out of the read's ballot planes (bit p of lo / hi = letter bits of base p, inv / invm = base p cannot

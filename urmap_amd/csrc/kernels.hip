@@ -25,6 +25,7 @@
 #include "kernels.h"
 
 #include "dev_common.h"
+#include "probe_dev.h"
 #include "viterbi_dev.h"
 
 namespace urx {
@@ -32,45 +33,6 @@ namespace urx {
 // ------------------------------------------------------------------------------------------------
 // kernel A: seed + probe
 // ------------------------------------------------------------------------------------------------
-// The k-mers of NC 64-position chunks of one read: all slot numbers first, then all 2*NC slot loads in flight
-// together, then the stores (the loads are random 64-byte sectors of a 26 GB table: their latency is the kernel).
-template <int NCH, int NC, int C0 = 0>
-__device__ __forceinline__ void probe_chunks(const DevIndex &X, const uint64_t (&lo)[NCH + 1], const uint64_t (&hi)[NCH + 1],
-                                             const uint64_t (&inv)[NCH + 1], const uint64_t (&invm)[NCH + 1], int lane,
-                                             uint32_t QL, uint32_t nwords, uint64_t base2, const ProbeOut &out) {
-	const uint32_t W = X.W;
-	uint64_t sp[NC], sm[NC];
-	uint32_t rp[NC][2], rm[NC][2];
-	bool vp[NC], vm[NC];
-#pragma unroll
-	for (int c = 0; c < NC; ++c)
-		kmer_slots(X, lo[C0 + c], hi[C0 + c], inv[C0 + c], invm[C0 + c], lo[C0 + c + 1], hi[C0 + c + 1], inv[C0 + c + 1],
-		           invm[C0 + c + 1], lane, 64u * (C0 + c) + lane, nwords, sp[c], sm[c], vp[c], vm[c]);
-#pragma unroll
-	for (int c = 0; c < NC; ++c) {  // lanes without a valid word fetch slot 0 (one cached sector) and drop it
-		const uint64_t ap = vp[c] ? 5ull * sp[c] : 0ull, am = vm[c] ? 5ull * sm[c] : 0ull;
-		const uint32_t *qp = reinterpret_cast<const uint32_t *>(X.blob + (ap & ~3ull));
-		const uint32_t *qm = reinterpret_cast<const uint32_t *>(X.blob + (am & ~3ull));
-		rp[c][0] = qp[0]; rp[c][1] = qp[1];
-		rm[c][0] = qm[0]; rm[c][1] = qm[1];
-	}
-#pragma unroll
-	for (int c = 0; c < NC; ++c) {
-		const uint32_t p = 64u * (C0 + c) + lane;
-		if (p >= nwords) continue;
-		const uint64_t xp = (((uint64_t)rp[c][1] << 32) | rp[c][0]) >> (8u * (uint32_t)((5ull * sp[c]) & 3ull));
-		const uint64_t xm = (((uint64_t)rm[c][1] << 32) | rm[c][0]) >> (8u * (uint32_t)((5ull * sm[c]) & 3ull));
-		const uint64_t ip = base2 + p;
-		const uint64_t im = base2 + QL + (QL - W - p);
-		out.slots[ip] = vp[c] ? sp[c] : ~0ull;
-		out.tallies[ip] = vp[c] ? (uint8_t)(xp & 0xFF) : (uint8_t)TALLY_FREE;
-		out.positions[ip] = vp[c] ? (uint32_t)(xp >> 8) : 0xFFFFFFFFu;
-		out.slots[im] = vm[c] ? sm[c] : ~0ull;
-		out.tallies[im] = vm[c] ? (uint8_t)(xm & 0xFF) : (uint8_t)TALLY_FREE;
-		out.positions[im] = vm[c] ? (uint32_t)(xm >> 8) : 0xFFFFFFFFu;
-	}
-}
-
 template <int NCH>
 __global__ __launch_bounds__(256) void seed_probe_kernel(DevIndex X, const uint8_t *__restrict__ bases,
                                                          const uint64_t *__restrict__ offs, uint32_t n, ProbeOut out) {
@@ -82,44 +44,7 @@ __global__ __launch_bounds__(256) void seed_probe_kernel(DevIndex X, const uint8
 	const uint32_t W = X.W;
 	if (QL < W || QL > 64u * NCH) return;
 	const uint8_t *q = bases + off;
-
-	// ballot planes: bit p of lo/hi = letter bits of base p, inv = base p is not ACGTU (or beyond the read)
-	// invm: as inv for the reverse-complement strand -- lower-case 'u' complements to '?' (alpha.cpp:3005)
-	uint64_t lo[NCH + 1], hi[NCH + 1], inv[NCH + 1], invm[NCH + 1];
-	uint32_t chv[NCH];
-#pragma unroll
-	for (int c = 0; c < NCH; ++c) {  // every chunk's bytes are requested before the first is looked at
-		const uint32_t p = 64u * c + lane;
-		chv[c] = q[p < QL ? p : QL - 1];
-	}
-#pragma unroll
-	for (int c = 0; c < NCH; ++c) {
-		const uint32_t p = 64u * c + lane;
-		const uint32_t ch = p < QL ? chv[c] : 0u;
-		const uint32_t L = p < QL ? letter_of(ch) : 4u;
-		lo[c] = __ballot(L & 1u);
-		hi[c] = __ballot((L >> 1) & 1u);
-		inv[c] = __ballot(L > 3u);
-		invm[c] = __ballot(L > 3u || ch == 'u');
-	}
-	lo[NCH] = hi[NCH] = 0;
-	inv[NCH] = invm[NCH] = ~0ull;
-
-	const uint32_t nwords = QL - (W - 1);
-	const uint64_t base2 = 2ull * off;
-	const uint32_t nc = (nwords + 63u) >> 6;  // chunks that hold a k-mer start (same for the whole wave)
-	if (nc <= 1) probe_chunks<NCH, 1>(X, lo, hi, inv, invm, lane, QL, nwords, base2, out);
-	else if (NCH >= 2 && nc == 2) probe_chunks<NCH, (NCH >= 2 ? 2 : 1)>(X, lo, hi, inv, invm, lane, QL, nwords, base2, out);
-	else if (NCH >= 3 && nc == 3) probe_chunks<NCH, (NCH >= 3 ? 3 : 1)>(X, lo, hi, inv, invm, lane, QL, nwords, base2, out);
-	else if (NCH >= 4 && nc == 4) probe_chunks<NCH, (NCH >= 4 ? 4 : 1)>(X, lo, hi, inv, invm, lane, QL, nwords, base2, out);
-	else if (NCH >= 5 && nc == 5) probe_chunks<NCH, (NCH >= 5 ? 5 : 1)>(X, lo, hi, inv, invm, lane, QL, nwords, base2, out);
-	else if (NCH >= 6 && nc == 6) probe_chunks<NCH, (NCH >= 6 ? 6 : 1)>(X, lo, hi, inv, invm, lane, QL, nwords, base2, out);
-	else if (NCH >= 7 && nc == 7) probe_chunks<NCH, (NCH >= 7 ? 7 : 1)>(X, lo, hi, inv, invm, lane, QL, nwords, base2, out);
-	else if (NCH >= 8 && nc <= 8) probe_chunks<NCH, (NCH >= 8 ? 8 : 1)>(X, lo, hi, inv, invm, lane, QL, nwords, base2, out);
-	else if constexpr (NCH >= 16) {  // long reads: two sweeps of eight chunks each
-		probe_chunks<NCH, 8, 0>(X, lo, hi, inv, invm, lane, QL, nwords, base2, out);
-		probe_chunks<NCH, 8, 8>(X, lo, hi, inv, invm, lane, QL, nwords, base2, out);
-	}
+	probe_read<NCH>(X, q, QL, off, lane, out);
 }
 
 

@@ -14,6 +14,7 @@
 // Scan / ScanSlots / ExtendScan / AddHSPScan (scan.cpp:14-39, scanslots.cpp:7-62, extendscan.cpp:8-187),
 // AdjustTopHitsAndMapqs (search2.cpp:8-57), CalcMAPQ6 (search1m6.cpp:9-33), SetMappedPos (state1.cpp:129-145).
 #include "dev_common.h"
+#include "probe_dev.h"
 #include "viterbi_dev.h"
 
 namespace urx {
@@ -849,7 +850,15 @@ __global__ __launch_bounds__(64, URX_PE_WAVES(NCH)) void search_pe_kernel(DevInd
 			for (int a = 0; a < 2; ++a) { res[a].status = URMAPX_ST_BAD_LENGTH; if (lane == 0) results[2 * pr + a] = res[a]; }
 			continue;
 		}
-		__syncthreads();
+		// seed + probe of both mates (round 3: no launch of its own -- this kernel waits on latency with half of its issue
+		// slots idle, so the hashing is free and the 2 x 254 slot gathers overlap the other pairs of the CU).  The entries go
+		// to the batch's probe arrays exactly as seed_probe_kernel writes them; the overflow pass reads the first pass's.
+		lds_sync();
+		if constexpr (!OVF) {
+			const uint64_t poff[2] = {offs[2 * pr], offs[2 * pr + 1]};
+			const uint32_t pql[2] = {(uint32_t)m[0].QL, (uint32_t)m[1].QL};
+			probe_pair<NCH, QMAX>(X, bases, poff, pql, lane, probe, s_tal, s_pos);
+		}
 		// ---- InitPE x2 (state1.cpp:95-127) ----
 		for (int a = 0; a < 2; ++a) {
 			const uint8_t *q = bases + offs[2 * pr + a];
@@ -864,15 +873,17 @@ __global__ __launch_bounds__(64, URX_PE_WAVES(NCH)) void search_pe_kernel(DevInd
 				}
 				m[a].qch[0][c] = cp; m[a].qch[1][c] = cm;
 			}
+			if constexpr (OVF) {  // the first pass staged its own probe results (probe_pair); this pass reads what it wrote
 #pragma unroll
-			for (int st = 0; st < 2; ++st) {
+				for (int st = 0; st < 2; ++st) {
 #pragma unroll
-				for (int c = 0; c < NCH; ++c) {
-					const int p = 64 * c + lane;
-					if (p < QL) {
-						const bool in = p < m[a].nwords;
-						s_tal[a][st][p] = in ? m[a].ptal[(size_t)st * QL + p] : (uint8_t)0;
-						s_pos[a][st][p] = in ? m[a].ppos[(size_t)st * QL + p] : 0xFFFFFFFFu;
+					for (int c = 0; c < NCH; ++c) {
+						const int p = 64 * c + lane;
+						if (p < QL) {
+							const bool in = p < m[a].nwords;
+							s_tal[a][st][p] = in ? m[a].ptal[(size_t)st * QL + p] : (uint8_t)0;
+							s_pos[a][st][p] = in ? m[a].ppos[(size_t)st * QL + p] : 0xFFFFFFFFu;
+						}
 					}
 				}
 			}
@@ -883,7 +894,7 @@ __global__ __launch_bounds__(64, URX_PE_WAVES(NCH)) void search_pe_kernel(DevInd
 			m[a].maxPen = P.max_penalty; m[a].best = 0; m[a].second = 0; m[a].bestHSP = 0;
 			m[a].mapq = 0xFFFFFFFFu; m[a].status = 0;
 		}
-		__syncthreads();
+		lds_sync();
 		// both strands of both mates as bit planes (ExtendPen's windows are read from the packed sequence store)
 		for (int a = 0; a < 2; ++a) {
 			uint64_t oth = 0;
@@ -905,7 +916,7 @@ __global__ __launch_bounds__(64, URX_PE_WAVES(NCH)) void search_pe_kernel(DevInd
 			}
 			m[a].q_other = oth != 0;
 		}
-		__syncthreads();
+		lds_sync();
 
 		// ---- seed enumeration of both mates (GetFirstBoth1Seed / GetNextBoth1Seed) ----
 		// State independent, so it is run to the end up front; the pending lists are cut back to the point the

@@ -543,7 +543,6 @@ int urmapx_map_pe_device(urmapx_ctx *C, const void *d_bases, const void *d_offs,
 	if (!C || (npairs && (!d_bases || !d_offs || !d_results || !d_path_ops || !d_path_used))) return URMAPX_E_ARG;
 	if (max_read_len > MAX_QL_PE || npairs > 0x7FFFFFFFu) return URMAPX_E_UNSUPPORTED;
 	HIP_TRY(hipSetDevice(C->device));
-	const uint32_t n = 2 * npairs;
 	int rc = ensure_probe(C, total_bases);
 	if (rc) return rc;
 	const int cls = max_read_len <= 128 ? 3 : max_read_len <= 192 ? 0 : (max_read_len <= 256 ? 2 : 1);
@@ -564,8 +563,8 @@ int urmapx_map_pe_device(urmapx_ctx *C, const void *d_bases, const void *d_offs,
 	HIP_TRY(hipMemsetAsync(d_path_used, 0, 4, C->stream));
 	// positions the probe kernel does not write (qpos > L-W) must read as "no k-mer"
 	HIP_TRY(hipMemsetAsync(C->tallies.p, 0, 2 * total_bases, C->stream));
+	// seed + probe run inside search_pe_kernel (round 3); the two stamps bracket nothing and stay for urmapx_ctx_stage_ms
 	HIP_TRY(hipEventRecord(C->ev[0], C->stream));
-	HIP_TRY(launch_seed_probe(C->X, (const uint8_t *)d_bases, (const uint64_t *)d_offs, n, max_read_len, po, C->stream));
 	HIP_TRY(hipEventRecord(C->ev[1], C->stream));
 	urmapx_params Ppe = C->params;
 	if (C->pe_veryfast) Ppe.band_radius = 4;  // map2.cpp:17-21
