@@ -433,6 +433,13 @@ __device__ __forceinline__ void lds_sync() {
 	__builtin_amdgcn_s_barrier();
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
+// The search kernels' blocks are one wavefront.  URX_LDS_SYNC (build flag, measurement only) makes every barrier of theirs
+// LDS-only; the default keeps __syncthreads() wherever lanes exchange data through global scratch.
+#ifdef URX_LDS_SYNC
+#define URX_SYNC() lds_sync()
+#else
+#define URX_SYNC() __syncthreads()
+#endif
 
 // The slots of the k-mers that start in one 64-position chunk of a read, both strands (State1::SetSlotsVec,
 // state1.cpp:396-438, with murmur64 / WordToSlot, ufindex.h:50-65): lane l cuts the W letters of the k-mer starting at

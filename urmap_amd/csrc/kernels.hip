@@ -77,7 +77,7 @@ __global__ __launch_bounds__(64) void viterbi_batch_kernel(urmapx_params P, cons
 		status = URMAPX_ST_BAND_TOO_WIDE;
 	else {
 		for (int i = lane; i < LA; i += 64) sA[i] = a[aoffs[k] + i];
-		__syncthreads();
+		URX_SYNC();
 		WideScratch ws;
 		ws.carve(scratch + (size_t)k * scratch_stride, VB_WIDE_LA, VB_WIDE_LB);
 		score = viterbi_wave(VPar(P), sA, LA, b + boffs[k], LB, flags[k] & 1, (flags[k] >> 1) & 1, tb, VB_MAXL / 8 + 2, ws, R,
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(64) void viterbi_batch_pair_kernel(urmapx_params P,
 		if (LB[h] <= VB_MAXL + 64)
 			for (int i = lane; i < LB[h]; i += 64) sB[h][16 + i] = b[boffs[k] + i];
 	}
-	__syncthreads();
+	URX_SYNC();
 	for (int h = 0; h < 2; ++h)
 		if (kk[h] < n && LA[h] <= VB_MAXL && LB[h] <= VB_MAXL + 64)
 			narrow[h] = F[h].setup(VP, sA[h], LA[h], sB[h] + 16, LB[h], flags[kk[h]] & 1, (flags[kk[h]] >> 1) & 1, tb[h], TBR, -3.0e38f, false);
@@ -143,10 +143,10 @@ __global__ __launch_bounds__(64) void viterbi_batch_pair_kernel(urmapx_params P,
 		int nout = R.n;
 		if (nout > URMAPX_MAX_PATH_OPS) { status |= URMAPX_ST_PATH_OVERFLOW; nout = 0; }
 		if (status) nout = 0;
-		__syncthreads();
+		URX_SYNC();
 		for (int t = lane; t < nout; t += 64) ops_out[(size_t)k * URMAPX_MAX_PATH_OPS + t] = rops[h][nout - 1 - t];
 		if (lane == 0) { scores[k] = score; status_out[k] = (uint8_t)status; nops_out[k] = (uint16_t)nout; }
-		__syncthreads();
+		URX_SYNC();
 	}
 }
 
@@ -202,7 +202,7 @@ __device__ __noinline__ int hsp_overflow_add(uint2 *ovf, int n, int cap, uint32_
 			const int l = __builtin_ctzll(m);
 			const int old = (int)((rdlane(e.y, l) >> PK_SCORE_SH) & PK_MASK);
 			if (score > old && lane == 0) ovf[base + l] = make_uint2(startdb, npk);
-			__syncthreads();
+			URX_SYNC();
 			return 0;
 		}
 	}
@@ -301,7 +301,7 @@ struct SearchWave {
 			haveTop = true; top_db = db; top_plus = plus; top_nops = cand_nops;
 			if (cand_nops) {
 				for (int t = lane; t < cand_nops; t += 64) top[t] = cand[t];
-				__syncthreads();
+				URX_SYNC();
 			}
 		}
 	}
@@ -321,7 +321,7 @@ struct SearchWave {
 				const int k = base + __builtin_ctzll(m);
 				const int old = (int)((hsp_pk[k] >> PK_SCORE_SH) & PK_MASK);
 				if (score > old && lane == 0) { hsp_db[k] = startdb; hsp_pk[k] = npk; }
-				__syncthreads();
+				URX_SYNC();
 				return;
 			}
 		}
@@ -335,7 +335,7 @@ struct SearchWave {
 		} else if (lane == 0) {
 			hsp_db[hspCount] = startdb; hsp_pk[hspCount] = npk;
 		}
-		__syncthreads();
+		URX_SYNC();
 		++hspCount;
 		if (score > bestHSP) bestHSP = score;
 	}
@@ -348,7 +348,7 @@ struct SearchWave {
 			sT[i] = c;
 			gap |= (c == '-');
 		}
-		__syncthreads();
+		URX_SYNC();
 		return __ballot(gap) != 0;
 	}
 
@@ -358,7 +358,7 @@ struct SearchWave {
 		if (k < hsp_lds) { startdb = hsp_db[k]; pk = hsp_pk[k]; }
 		else { const uint2 e = hsp_ovf[k - hsp_lds]; startdb = e.x; pk = e.y; }
 		if (pk & PK_ALIGNED) return;  // m_Aligned
-		__syncthreads();
+		URX_SYNC();
 		if (lane == 0) {
 			if (k < hsp_lds) hsp_pk[k] = pk | PK_ALIGNED;
 			else hsp_ovf[k - hsp_lds].y = pk | PK_ALIGNED;
@@ -366,7 +366,7 @@ struct SearchWave {
 		const int startq = (int)(pk & PK_MASK), len = (int)((pk >> PK_LEN_SH) & PK_MASK);
 		const int hscore = (int)((pk >> PK_SCORE_SH) & PK_MASK);
 		const bool plus = (pk >> PK_PLUS_SH) & 1u;
-		__syncthreads();
+		URX_SYNC();
 		int totalPen = len - hscore;
 		int totalScore = hscore;
 		if (totalPen > maxPen) return;
@@ -454,7 +454,7 @@ struct SearchWave {
 		for (int t = RR.n - 1; t >= rtrim; --t) { uint32_t o = ropsR[t]; put((int)(o & 3u), (int)(o >> 2)); }
 		put(-2, 1);  // flush
 		if (ovf) { status |= URMAPX_ST_PATH_OVERFLOW; return; }
-		__syncthreads();
+		URX_SYNC();
 		add_hit(combinedTLo, plus, totalScore, nc);
 	}
 
@@ -556,7 +556,7 @@ struct SearchWave {
 		top_nops = (int)uni(sc[6]); status = uni(sc[7]); hspCount = (int)uni(sc[8]); bestHSP = 0;
 		const uint16_t *tops = reinterpret_cast<const uint16_t *>(sc + 16);
 		for (int t = lane; t < top_nops; t += 64) top[t] = tops[t];
-		__syncthreads();
+		URX_SYNC();
 		return (int)(f >> 8);
 	}
 
@@ -594,9 +594,9 @@ struct SearchWave {
 		if (vst & (URMAPX_ST_BAND_TOO_WIDE | URMAPX_ST_PATH_OVERFLOW)) return true;
 		if (J.flags & DPJ_PATH_LONG) { status |= URMAPX_ST_PATH_OVERFLOW; return true; }
 		const int nc = (int)J.nops;
-		__syncthreads();
+		URX_SYNC();
 		for (int t = lane; t < nc; t += 64) cand[t] = jops[t];
-		__syncthreads();
+		URX_SYNC();
 		add_hit(J.combined_tlo, plus, totalScore, nc);
 		return true;
 	}
@@ -791,7 +791,7 @@ struct SearchWave {
 		}
 		if (lane == 0) pre[NS * 64] = (uint16_t)carry;
 		if (carry > 0xFFFF) status |= URMAPX_ST_HSP_OVERFLOW;  // only a 1024-base read whose every k-mer owns a full chain gets here
-		__syncthreads();
+		URX_SYNC();
 		return carry;
 	}
 
@@ -967,7 +967,7 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 
 			// this read's bytes and slot entries have landed (issued while the previous read was searched)
 			wait_vm0();
-			__syncthreads();
+			URX_SYNC();
 			const int mis = (int)(reinterpret_cast<uintptr_t>(bases + off) & 3);
 #pragma unroll
 			for (int c = 0; c < NCH; ++c) {
@@ -978,7 +978,7 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 					sQm[QL - 1 - p] = (uint8_t)comp_char(ch);
 				}
 			}
-			__syncthreads();
+			URX_SYNC();
 			// both strands as bit planes of 4-bit codes (dev_common.h); a read holding a byte outside the code list
 			// compares ASCII windows instead
 			uint64_t oth = 0;
@@ -999,7 +999,7 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 				}
 			}
 			q_other = oth != 0;
-			__syncthreads();
+			URX_SYNC();
 			// nextQ is free again: the bytes of the read after this one
 			if (next_ok) { wait_lgkm0(); fetch_bytes(noff, nQL); fetched = true; }
 			lapc(0);
@@ -1036,15 +1036,15 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 				if (next_ok) {
 					if (!fetched) fetch_bytes(noff, nQL);
 					wait_vm0();
-					__syncthreads();
+					URX_SYNC();
 					S.probe_hash(nextQ + nmis, nQL, stage_sl, stage_b);
-					__syncthreads();
+					URX_SYNC();
 				}
 				if (go) S.walk_heads(wsl, wT, wps, wact);
 				if (next_ok) S.probe_gather(nQL, stage_sl, stage_b);
 				if (!go) break;
 				S.walk_run(wsl, wT, wps, wact, rl);
-				__syncthreads();
+				URX_SYNC();
 				lapc(3);
 				if (DBG && dbg_stop == 104) { done = true; break; }
 				step = 4;
@@ -1138,7 +1138,7 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 					qcount += __builtin_popcountll(m);
 					scanned += 64;
 				}
-				__syncthreads();
+				URX_SYNC();
 				const int nb = qcount < 64 ? qcount : 64;
 				if (nb == 0) break;
 				uint32_t c_qpos = 0, c_db = 0;
@@ -1151,7 +1151,7 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 					c_qpos = qp & 0x3FFFu; c_plus = (qp & 0x4000u) != 0; c_second = (qp & 0x8000u) != 0;
 				}
 				qhead = (qhead + nb) & 127; qcount -= nb;
-				__syncthreads();
+				URX_SYNC();
 				laps(8);
 				uint64_t mm[NCH];
 #pragma unroll
@@ -1297,7 +1297,7 @@ __global__ __launch_bounds__(64) URX_DP_ATTR void dp_kernel(DevIndex X, urmapx_p
 			dst[i] = c;
 			gap |= (c == '-');
 		}
-		__syncthreads();
+		URX_SYNC();
 		return __ballot(gap) != 0;
 	};
 	uint32_t n_gated = 0;  // statistics
@@ -1345,7 +1345,7 @@ __global__ __launch_bounds__(64) URX_DP_ATTR void dp_kernel(DevIndex X, urmapx_p
 				S.plus = (J.pk >> PK_PLUS_SH) & 1u;
 				S.flags = 0; S.vst_l = 0; S.vst_r = 0; S.combinedTLo = J.startdb;
 				S.leftScore = 0; S.rightScore = 0; S.rtrim = 0; S.totalPen = glen - gscore; S.nL = 0; S.nR = 0;
-				__syncthreads();
+				URX_SYNC();
 				const uint8_t *q = bases + off;
 #pragma unroll
 				for (int c = 0; c < NCH; ++c) {
@@ -1360,7 +1360,7 @@ __global__ __launch_bounds__(64) URX_DP_ATTR void dp_kernel(DevIndex X, urmapx_p
 		have[0] = take_job(js[0], sQ[0]);
 		have[1] = have[0] && take_job(js[1], sQ[1]);
 		if (!have[0]) break;
-		__syncthreads();
+		URX_SYNC();
 		// ---- the left flanks of both jobs, then the right flanks (the right one's budget depends on the left one's outcome) ----
 #pragma unroll 1
 		for (int side = 0; side < 2; ++side) {
@@ -1461,10 +1461,10 @@ __global__ __launch_bounds__(64) URX_DP_ATTR void dp_kernel(DevIndex X, urmapx_p
 				for (int t = S.nR - 1; t >= S.rtrim; --t) { const uint32_t o = ropsR[h][t]; put((int)(o & 3u), (int)(o >> 2)); }
 				put(-2, 1);  // flush
 				if (ovf) { S.flags |= DPJ_PATH_LONG; nc = 0; }
-				__syncthreads();
+				URX_SYNC();
 				uint16_t *out = dp.ops + (size_t)S.j * DP_JOB_OPS;
 				for (int t = lane; t < nc; t += 64) out[t] = cand[t];
-				__syncthreads();
+				URX_SYNC();
 			}
 			if (lane == 0) {
 				DpJob *o = dp.jobs + S.j;
@@ -1503,7 +1503,7 @@ __global__ __launch_bounds__(64) URX_DP_ATTR void dp_kernel(DevIndex X, urmapx_p
 			sT[i] = c;
 			gap |= (c == '-');
 		}
-		__syncthreads();
+		URX_SYNC();
 		return __ballot(gap) != 0;
 	};
 	uint32_t n_gated = 0;  // statistics
@@ -1541,7 +1541,7 @@ __global__ __launch_bounds__(64) URX_DP_ATTR void dp_kernel(DevIndex X, urmapx_p
 		const uint32_t pk = J.pk, startdb = J.startdb;
 		const int startq = (int)(pk & PK_MASK), len = (int)((pk >> PK_LEN_SH) & PK_MASK), hscore = (int)((pk >> PK_SCORE_SH) & PK_MASK);
 		const bool plus = (pk >> PK_PLUS_SH) & 1u;
-		__syncthreads();
+		URX_SYNC();
 		{
 			const uint8_t *q = bases + off;
 #pragma unroll
@@ -1550,7 +1550,7 @@ __global__ __launch_bounds__(64) URX_DP_ATTR void dp_kernel(DevIndex X, urmapx_p
 				if (p < QL) sQ[p] = plus ? q[p] : (uint8_t)comp_char(q[QL - 1 - p]);
 			}
 		}
-		__syncthreads();
+		URX_SYNC();
 		uint32_t flags = 0, vst_l = 0, vst_r = 0, combinedTLo = startdb;
 		int leftScore = 0, rightScore = 0, rtrim = 0;
 		int totalPen = len - hscore;
@@ -1625,7 +1625,7 @@ __global__ __launch_bounds__(64) URX_DP_ATTR void dp_kernel(DevIndex X, urmapx_p
 			for (int t = RR.n - 1; t >= rtrim; --t) { const uint32_t o = ropsR[t]; put((int)(o & 3u), (int)(o >> 2)); }
 			put(-2, 1);  // flush
 			if (ovf) { flags |= DPJ_PATH_LONG; nc = 0; }
-			__syncthreads();
+			URX_SYNC();
 			uint16_t *out = dp.ops + (size_t)j * DP_JOB_OPS;
 			for (int t = lane; t < nc; t += 64) out[t] = cand[t];
 		}
@@ -1667,7 +1667,7 @@ __global__ __launch_bounds__(64) void finalize_se_kernel(DevIndex X, urmapx_para
 		if (nj <= klo) continue;  // finished in an earlier round
 		S.QL = (int)(offs[r + 1] - offs[r]);
 		S.nwords = S.QL - (S.W - 1);
-		__syncthreads();
+		URX_SYNC();
 		uint32_t *const st = dp.state + (size_t)e * SW::STATE_WORDS;
 		const int phase = S.restore_state(st);
 		uint32_t used = 0;
@@ -1704,7 +1704,7 @@ __global__ __launch_bounds__(64) void finalize_se_kernel(DevIndex X, urmapx_para
 		}
 		if (lane == 0 && used) atomicAdd(dp.counters + 2, used);  // statistics: jobs whose DP the ordered replay looked at
 		if (nj > khi) {  // more rounds to come: park again, and tell the remaining jobs the cap reached so far
-			__syncthreads();
+			URX_SYNC();
 			S.park_state(st, phase);
 			for (uint32_t k = khi + lane; k < nj; k += 64) dp.jobs[jb + k].maxpen = S.maxPen;
 			continue;

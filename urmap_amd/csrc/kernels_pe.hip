@@ -150,7 +150,7 @@ struct Mate {
 			if (lane < wl() && (w << wsh()) + lane == idx) { hit_db[w] = db; hit_sp[w] = ((uint32_t)score << 1) | (plus ? 1u : 0u); }
 		if (lane == 0) hit_nops[idx] = (uint16_t)cand_nops;
 		for (int t = lane; t < cand_nops; t += 64) hit_paths[(size_t)idx * URMAPX_MAX_PATH_OPS + t] = cand[t];
-		__syncthreads();
+		URX_SYNC();
 		++hitCount;
 		return idx;
 	}
@@ -189,7 +189,7 @@ struct Mate {
 	}
 	__device__ __forceinline__ void put_hsp(int k, uint32_t startq, uint32_t startdb, bool plus, uint32_t len, int score) {
 		if (lane == 0) hsp_put(k, startdb, startq | (len << 16), (uint32_t)((score << 2) | (plus ? 1 : 0)));
-		__syncthreads();
+		URX_SYNC();
 	}
 	// state1.cpp:553-591
 	__device__ __forceinline__ void add_hsp(uint32_t startq, uint32_t startdb, bool plus, uint32_t len, int score) {
@@ -324,7 +324,7 @@ struct Mate {
 			sT[i] = c;
 			gap |= (c == '-');
 		}
-		__syncthreads();
+		URX_SYNC();
 		return __ballot(gap) != 0;
 	}
 
@@ -333,12 +333,12 @@ struct Mate {
 		uint32_t startdb, ql, sf;
 		hsp_get(k, startdb, ql, sf);
 		if (sf & 2u) return -1;
-		__syncthreads();
+		URX_SYNC();
 		if (lane == 0) hsp_put(k, startdb, ql, sf | 2u);
 		const int startq = (int)(ql & 0xFFFFu), len = (int)(ql >> 16);
 		const int hscore = (int)(sf >> 2);
 		const bool plus = sf & 1u;
-		__syncthreads();
+		URX_SYNC();
 		int totalPen = len - hscore;
 		int totalScore = hscore;
 		if (totalPen > maxPen) return -1;
@@ -416,7 +416,7 @@ struct Mate {
 		for (int t = RR.n - 1; t >= rtrim; --t) { uint32_t o = ropsR[t]; put((int)(o & 3u), (int)(o >> 2)); }
 		put(-2, 1);
 		if (ovf) { status |= URMAPX_ST_PATH_OVERFLOW; return -1; }
-		__syncthreads();
+		URX_SYNC();
 		return add_hit(combinedTLo, plus, totalScore, nc);
 	}
 
@@ -522,7 +522,7 @@ struct Mate {
 				if (i < pendCount[s]) rowlen[s * QMAX + i] = (uint8_t)K;
 			}
 		}
-		__syncthreads();
+		URX_SYNC();
 		if (dbg_cut == 42) { mapq = calc_mapq(); return; }
 		// 2. the four groups in the reference's order.  Candidates that survive the hit-diagonal filter are compacted, in
 		// order, into a 128-entry LDS queue (reference position, query position | plus << 15), so that the gather below
@@ -530,7 +530,7 @@ struct Mate {
 		int qhead = 0, qcount = 0;
 		auto drain = [&](bool all) {
 			while (qcount >= 64 || (all && qcount > 0)) {
-				__syncthreads();
+				URX_SYNC();
 				const int nb = qcount < 64 ? qcount : 64;
 				uint32_t c_q = 0, c_db = 0;
 				bool c_plus = true;
@@ -542,7 +542,7 @@ struct Mate {
 					c_q = qp & 0x7FFFu; c_plus = (qp & 0x8000u) != 0;
 				}
 				qhead = (qhead + nb) & 127; qcount -= nb;
-				__syncthreads();
+				URX_SYNC();
 				const uint32_t dblo = c_db - c_q;
 				int e_kind = 0, e_bst = 0, e_sp = 0, e_ep = 0, e_pen = 0;
 				if (ok) {
@@ -592,10 +592,10 @@ struct Mate {
 					const int inc = wave_prefix_sum(cnt);
 					const int total = rdlane(inc, 63);
 					if (total == 0) continue;
-					__syncthreads();
+					URX_SYNC();
 					pre[lane] = (uint16_t)(inc - cnt);
 					if (lane == 0) pre[64] = (uint16_t)total;
-					__syncthreads();
+					URX_SYNC();
 					const uint32_t *rs0 = rowstore + ((size_t)(s * NCH + (base >> 6)) * PE_ROW_CAP) * 64;
 					for (int gb = 0; gb < total; gb += 64) {
 						const int g = gb + lane;
@@ -725,9 +725,9 @@ struct Mate {
 			if (n > 1 && (ropsL[0] & 3u) == OP_I) r0 = 1;                                     // TrimRightIs
 			const int nc = n - r0;
 			if (nc > URMAPX_MAX_PATH_OPS) { status |= URMAPX_ST_PATH_OVERFLOW; return; }
-			__syncthreads();
+			URX_SYNC();
 			for (int t = lane; t < nc; t += 64) cand[t] = ropsL[n - 1 - t];
-			__syncthreads();
+			URX_SYNC();
 			add_hit(dbpos + (uint32_t)nI, plus, (int)score, nc);
 		}
 	}
@@ -976,7 +976,7 @@ __global__ __launch_bounds__(64, URX_PE_WAVES(NCH)) void search_pe_kernel(DevInd
 			nseed[a] = ns;
 			m[a].pendCount[0] = np; m[a].pendCount[1] = nm;
 		}
-		__syncthreads();
+		URX_SYNC();
 
 		// ---- seed gather: the ExtendPen outcome of every seed, one seed per lane ----
 		for (int a = 0; a < 2; ++a) {
@@ -1002,7 +1002,7 @@ __global__ __launch_bounds__(64, URX_PE_WAVES(NCH)) void search_pe_kernel(DevInd
 				}
 			}
 		}
-		__syncthreads();
+		URX_SYNC();
 		if (dbg_stop == 1) continue;
 		// ExtendPen on seed i of mate a, in order (state changing), through the cache
 		auto extend_seed = [&](int a, int i) -> int {
@@ -1010,9 +1010,9 @@ __global__ __launch_bounds__(64, URX_PE_WAVES(NCH)) void search_pe_kernel(DevInd
 			const uint32_t pn = seed_pen[a][i];
 			const int r = m[a].extend_pen_cached(sq & 0x7FFFu, seed_db[a][i], (sq & 0x8000u) != 0, seed_res[a][i], (int)(pn & 0x7FFFu));
 			if ((pn & 0x8000u) == 0) {
-				__syncthreads();
+				URX_SYNC();
 				if (lane == 0) seed_pen[a][i] = (uint16_t)(pn | 0x8000u);
-				__syncthreads();
+				URX_SYNC();
 			}
 			return r;
 		};
@@ -1166,7 +1166,7 @@ __global__ __launch_bounds__(64, URX_PE_WAVES(NCH)) void search_pe_kernel(DevInd
 						++npairs_found;
 					}
 				}
-				__syncthreads();
+				URX_SYNC();
 				if (npairs_found > 0 || attempt == 1) break;
 				// ScanPair
 				const bool dovitF = (int)m[0].mapq >= 10 && dbg_stop != 5, dovitR = (int)m[1].mapq >= 10 && dbg_stop != 5;  // 5: diagnostic, no rescue DP

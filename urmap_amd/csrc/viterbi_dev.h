@@ -275,7 +275,7 @@ __device__ __forceinline__ float viterbi_wave(const VPar P, const uint8_t *A, in
 			}
 			if (aborted != nullptr && i < LA) {
 				const float best = rdlane(wave_prefix_max(fmaxf(M, Dn)), 63);
-				if (best + (float)(LA - i) < abort_below) { *aborted = true; __syncthreads(); return best; }
+				if (best + (float)(LA - i) < abort_below) { *aborted = true; URX_SYNC(); return best; }
 			}
 		}
 	}
@@ -305,7 +305,7 @@ __device__ __forceinline__ float viterbi_wave(const VPar P, const uint8_t *A, in
 	int st = OP_M;
 	if (FinalD > Score) { Score = FinalD; st = OP_D; }
 	if (FinalI > Score) { Score = FinalI; st = OP_I; }
-	__syncthreads();
+	URX_SYNC();
 
 	// traceback (tracebackbitmem.cpp:8-75), a whole run per step: lane s looks at the s-th cell in the current direction
 	// (M: up the diagonal, D: up the column, I: left along the row), a ballot finds the cell whose trace bits end the run.
@@ -341,7 +341,7 @@ __device__ __forceinline__ float viterbi_wave(const VPar P, const uint8_t *A, in
 	}
 	R.end(lane);
 	if (R.overflow) status |= URMAPX_ST_PATH_OVERFLOW;
-	__syncthreads();
+	URX_SYNC();
 	return Score;
 }
 
@@ -490,7 +490,7 @@ struct VFlank {
 		int st = OP_M;
 		if (FinalD > Score) { Score = FinalD; st = OP_D; }
 		if (FinalI > Score) { Score = FinalI; st = OP_I; }
-		__syncthreads();
+		URX_SYNC();
 		int ii = LA, j = LB;
 		int guard = LA + LB + 2;
 		while ((ii | j) != 0 && guard-- > 0) {
@@ -522,7 +522,7 @@ struct VFlank {
 		}
 		R.end(lane);
 		if (R.overflow) status |= URMAPX_ST_PATH_OVERFLOW;
-		__syncthreads();
+		URX_SYNC();
 		return Score;
 	}
 };
@@ -700,7 +700,7 @@ __device__ float viterbi_wide(const VPar P, const uint8_t *A, int LA, const uint
 	range_j(LA - 1, StartjL, EndjL);
 	const float GapOp = Right ? 0.0f : GO, GapEx = Right ? 0.0f : GE;
 	float FinalI = NEG, FinalM = NEG, carryF = NEG, MleftF = NEG;
-	__syncthreads();
+	URX_SYNC();
 	const int nstrips = (LB + 63) >> 6;
 	for (int s = 0; s < nstrips; ++s) {
 		const int j = 64 * s + lane;
@@ -773,7 +773,7 @@ __device__ float viterbi_wide(const VPar P, const uint8_t *A, int LA, const uint
 			if (((LB - 1) >> 6) == s) FinalM = rdlane(Mreg, (LB - 1) & 63);
 		}
 	}
-	__syncthreads();
+	URX_SYNC();
 	// column LB (D only): a recurrence down the rows over the per-row M values collected above
 	float FinalD = NEG;
 	for (int i = 0; i < LA; ++i) {
@@ -792,7 +792,7 @@ __device__ float viterbi_wide(const VPar P, const uint8_t *A, int LA, const uint
 	if (FinalD > Score) { Score = FinalD; st = OP_D; }
 	if (FinalI > Score) { Score = FinalI; st = OP_I; }
 	__threadfence_block();
-	__syncthreads();
+	URX_SYNC();
 	// traceback: 64 cells of the current run direction per step
 	int i = LA, j = LB;
 	int guard = LA + LB + 2;
@@ -824,7 +824,7 @@ __device__ float viterbi_wide(const VPar P, const uint8_t *A, int LA, const uint
 	}
 	R.end(lane);
 	if (R.overflow) status |= URMAPX_ST_PATH_OVERFLOW;
-	__syncthreads();
+	URX_SYNC();
 	return Score;
 }
 
