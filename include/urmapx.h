@@ -42,7 +42,7 @@ extern "C" {
 #define URMAPX_ST_BAND_TOO_WIDE 0x08 /* DP problem larger than the wide-band scratch */
 #define URMAPX_ST_BAD_LENGTH 0x10    /* read shorter than the word length or longer than the kernels take */
 
-#define URMAPX_MAX_QL 1024    /* single-end reads the fast kernels take; paired-end reads: 279 (the reference keeps pending seed positions in a byte) */
+#define URMAPX_MAX_QL 1024    /* single-end reads the fast kernels take.  Paired-end mates: at most 320 bases AND at most 256 k-mer starts (QL - W + 1 <= 256: the reference keeps pending seed positions in a byte, state1.h:86-87), i.e. 279 bases at the default word length 24 */
 #define URMAPX_MAX_QL_SLOW 16000 /* single-end reads the general kernel takes (lists in global memory; the reference's own scratch ends near 30 kb, state1.h:113) */
 #define URMAPX_MAX_PATH_OPS 96
 
@@ -286,7 +286,7 @@ typedef struct urmapx_text urmapx_text;
 #define URMAPX_TEXT_BAD_RECORD 3  /* '@' missing, a byte that is not a letter, #bases != #quals, blank line */
 #define URMAPX_TEXT_LONG_NAME 4   /* target label longer than the device formatter takes */
 #define URMAPX_TEXT_SAM_CAP 5     /* sam_cap < report.sam_bytes: the chunk is mapped, its text waits for urmapx_text_fetch_sam */
-#define URMAPX_TEXT_TOO_LARGE 6   /* chunk over 1 GiB */
+#define URMAPX_TEXT_TOO_LARGE 6   /* chunk over 1 GiB, or its SAM text over 4 GiB */
 #define URMAPX_TEXT_UNEQUAL 7     /* pairs: the two chunks do not hold the same number of records */
 #define URMAPX_TEXT_INTERNAL 8    /* the device formatter's two passes disagreed on a record length (never expected): text not used */
 typedef struct urmapx_text_report {

@@ -588,3 +588,33 @@ def test_cli_gz_hand_back_and_errors(small_case, tmp_path):
     open(trunc, "wb").write(z[: len(z) // 2])
     rc, err = _urmap(["-map", trunc, "-ufi", small_case["ufi"], "-samout", sam])
     assert rc == 1, err[-500:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("allocs", ["0", "1", "5"])
+@pytest.mark.parametrize("kind", ["plain", "gz", "pairs"])
+def test_cli_text_phase_without_pinned_memory_falls_back_to_the_host(small_case, tmp_path, kind, allocs):
+    """No page-locked memory for a chunk (memlock limit, little host memory) ends the device text phase, not the run: the
+    host reader and formatter continue from that chunk and the SAM is the same (URMAPX_TEST_PINNED_ALLOCS makes
+    the (N+1)-th fresh page-locked allocation of the process fail: N = 0 before the first chunk, later ones mid-file)."""
+    from urmap_amd import synth
+    f1, f2, osam, sam = (os.path.join(tmp_path, n) for n in ("r1.fq", "r2.fq", "o.sam", "g.sam"))
+    if kind == "pairs":
+        r1, r2 = synth.make_pairs(815, small_case["genome"], 2500, read_len=150, sub1=0.02, sub2=0.03, ins=0.002, dele=0.002)
+        synth.write_fastq(f1, r1)
+        synth.write_fastq(f2, r2)
+        small_case["oracle_index"].map_file_pe(f1, f2, osam, threads=4)
+        args = ["-map2", f1, "-reverse", f2]
+    else:
+        synth.write_fastq(f1, synth.make_reads(814, small_case["genome"], 5000, read_len=150, sub=0.02, ins=0.002, dele=0.002))
+        small_case["oracle_index"].map_file_se(f1, osam, threads=4)
+        if kind == "gz":
+            open(f1 + ".gz", "wb").write(gzip.compress(open(f1, "rb").read(), 1))
+            args = ["-map", f1 + ".gz"]
+        else:
+            args = ["-map", f1]
+    want = _file_records(osam)
+    for batch in ("100000", "600"):
+        rc, err = _urmap(args + ["-ufi", small_case["ufi"], "-samout", sam, "-batch", batch], env={"URMAPX_TEST_PINNED_ALLOCS": allocs})
+        assert rc == 0, err[-2000:]
+        assert _file_records(sam) == want, (batch, err[-600:])

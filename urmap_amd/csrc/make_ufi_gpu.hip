@@ -173,9 +173,13 @@ extern "C" int urmapx_build_slots_gpu(int device, const uint8_t *seqdata, const 
 	if ((!seqdata && !d_seqdata) || !blob || slots == 0 || W < 1 || W > 32 || size == 0) return URMAPX_E_ARG;
 	const bool verbose = getenv("URMAPX_VERBOSE") != nullptr;
 	TRY(hipSetDevice(device));
-	hipEvent_t ev0, ev1;
-	TRY(hipEventCreate(&ev0));
-	TRY(hipEventCreate(&ev1));
+	struct Events {  // destroyed on every return path
+		hipEvent_t a = nullptr, b = nullptr;
+		~Events() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+	} evs;
+	TRY(hipEventCreate(&evs.a));
+	TRY(hipEventCreate(&evs.b));
+	const hipEvent_t ev0 = evs.a, ev1 = evs.b;
 	DevMem mem;
 	uint8_t *d_seq = nullptr;
 	if (d_seqdata) d_seq = (uint8_t *)d_seqdata;
@@ -221,8 +225,6 @@ extern "C" int urmapx_build_slots_gpu(int device, const uint8_t *seqdata, const 
 	TRY(hipEventSynchronize(ev1));
 	float ms = 0;
 	(void)hipEventElapsedTime(&ms, ev0, ev1);
-	(void)hipEventDestroy(ev0);
-	(void)hipEventDestroy(ev1);
 	if (verbose) fprintf(stderr, "[make_ufi gpu] device passes %.2f s, %llu overflow positions\n", ms * 1e-3, (unsigned long long)novf);
 	// back to the host: the table with its heads, the plus counts, the overflow list
 	struct HostBuf {  // not zero-filled: each is overwritten at once

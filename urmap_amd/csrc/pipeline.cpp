@@ -285,6 +285,9 @@ public:
 			}
 		}
 		char *p = nullptr;
+		if (const char *e = getenv("URMAPX_TEST_PINNED_ALLOCS")) {  // tests: the (N+1)-th fresh allocation of the process fails
+			if (fresh_.fetch_add(1) >= (uint64_t)atoll(e)) return nullptr;
+		}
 		if (hipHostMalloc((void **)&p, want, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
 		cap = want;
 		return p;
@@ -313,6 +316,7 @@ private:
 	std::mutex m_;
 	std::vector<Buf> free_;
 	size_t held_ = 0;
+	std::atomic<uint64_t> fresh_{0};
 };
 
 // one chunk of the text phase: FASTQ bytes in, SAM bytes out, both page-locked
@@ -721,6 +725,9 @@ extern "C" int urmapx_map_files(urmapx_index *I, const urmapx_map_options *opt, 
 					per[(size_t)t] = k;
 				}
 			};
+			// No page-locked memory for a chunk (memlock limit, little host memory), or none on the device for the text kernels:
+			// the text phase ends there and the host reader / formatter, which need neither, continue from that chunk.
+			std::atomic<bool> text_nomem{false};
 			bool stream_done = false;  // streamed input: the reader handed every byte of the input(s) to a lane
 			std::thread treader([&] {
 				omp_set_num_threads(read_threads);
@@ -742,7 +749,7 @@ extern "C" int urmapx_map_files(urmapx_index *I, const urmapx_map_options *opt, 
 						j.in = nb; j.in_cap = ncap;
 						return true;
 					};
-					for (size_t b = 0; !stop.load() && !fail.set.load(); ++b) {
+					for (size_t b = 0; !stop.load() && !fail.set.load() && !text_nomem.load(); ++b) {
 						if (eof1 && carry.empty()) { stream_done = !paired || (eof2 && carry2.empty()); break; }
 						std::unique_ptr<TextJob> j;
 						if (!tfree.pop(j)) break;
@@ -752,7 +759,7 @@ extern "C" int urmapx_map_files(urmapx_index *I, const urmapx_map_options *opt, 
 						(void)hipSetDevice(phys(0));
 						size_t area1 = chunk_bytes + chunk_bytes / 8 + carry.size() + (1u << 20);  // room for this file's chunk
 						size_t area2 = paired ? (size_t)((double)area1 * bytes2_per_byte1 * 1.25) + carry2.size() + (4u << 20) : 0;
-						if (!TextJob::grow(j->in, j->in_cap, area1 + 4096 + area2)) { fail.raise(URMAPX_E_NOMEM, "Page-locked chunk buffers: out of memory"); break; }
+						if (!TextJob::grow(j->in, j->in_cap, area1 + 4096 + area2)) { text_nomem.store(true); break; }
 						size_t n = carry.size(), cut = 0;
 						if (n) memcpy(j->in, carry.data(), n);
 						carry.clear();
@@ -770,10 +777,10 @@ extern "C" int urmapx_map_files(urmapx_index *I, const urmapx_map_options *opt, 
 							if (target > (1u << 30)) break;
 							if (target + (64u << 10) > area1) {
 								area1 = target + target / 8 + (1u << 20);
-								if (!regrow(*j, area1 + 4096 + area2, n)) { fail.raise(URMAPX_E_NOMEM, "Page-locked chunk buffers: out of memory"); break; }
+								if (!regrow(*j, area1 + 4096 + area2, n)) { text_nomem.store(true); break; }
 							}
 						}
-						if (fail.set.load()) break;
+						if (fail.set.load() || text_nomem.load()) break;
 						if (src1.failed()) { fail.raise(URMAPX_E_IO, std::string("Error reading gzip file ") + fastq1); break; }
 						if (cut == 0) { carry.assign(j->in, j->in + n); tfree.push(std::move(j)); break; }  // the host reader says what is wrong with it
 						carry.assign(j->in + cut, j->in + n);
@@ -786,7 +793,7 @@ extern "C" int urmapx_map_files(urmapx_index *I, const urmapx_map_options *opt, 
 							size_t n_pad = (area1 + 4095) & ~(size_t)4095;
 							size_t have = carry2.size(), n2 = 0, seen = 0, scanned = 0;
 							bool found = false, give_up = false;
-							if (have > area2) { area2 = have + have / 4 + (4u << 20); if (!regrow(*j, n_pad + area2, cut)) { fail.raise(URMAPX_E_NOMEM, "Page-locked chunk buffers: out of memory"); break; } }
+							if (have > area2) { area2 = have + have / 4 + (4u << 20); if (!regrow(*j, n_pad + area2, cut)) { text_nomem.store(true); break; } }
 							char *dst = j->in + n_pad;
 							if (have) memcpy(dst, carry2.data(), have);
 							carry2.clear();
@@ -808,7 +815,7 @@ extern "C" int urmapx_map_files(urmapx_index *I, const urmapx_map_options *opt, 
 									const size_t na = 2 * area2;
 									size_t ncap = 0;
 									char *nb = HostPool::get().acquire(n_pad + na, ncap);
-									if (!nb) { fail.raise(URMAPX_E_NOMEM, "Page-locked chunk buffers: out of memory"); give_up = true; break; }
+									if (!nb) { text_nomem.store(true); give_up = true; break; }
 									memcpy(nb, j->in, cut);
 									memcpy(nb + n_pad, dst, have);
 									HostPool::get().release(j->in, j->in_cap);
@@ -820,7 +827,7 @@ extern "C" int urmapx_map_files(urmapx_index *I, const urmapx_map_options *opt, 
 								have += k;
 								if (src2.failed()) { fail.raise(URMAPX_E_IO, std::string("Error reading gzip file ") + fastq2); give_up = true; break; }
 							}
-							if (fail.set.load()) break;
+							if (fail.set.load() || text_nomem.load()) break;
 							if (give_up) { carry.insert(carry.begin(), j->in, j->in + cut); tfree.push(std::move(j)); break; }
 							carry2.assign(dst + n2, dst + have);
 							j->in2 = dst; j->nbytes2 = n2;
@@ -837,7 +844,7 @@ extern "C" int urmapx_map_files(urmapx_index *I, const urmapx_map_options *opt, 
 					for (auto &c : tparsed) c->close();
 					return;
 				}
-				for (size_t b = 0; off < fsize && !stop.load() && !fail.set.load(); ++b) {
+				for (size_t b = 0; off < fsize && !stop.load() && !fail.set.load() && !text_nomem.load(); ++b) {
 					uint64_t end = fsize;
 					if (off + chunk_bytes < fsize) {
 						end = find_record_start(fq, off + chunk_bytes, fsize);
@@ -853,7 +860,7 @@ extern "C" int urmapx_map_files(urmapx_index *I, const urmapx_map_options *opt, 
 					const size_t n_pad = (n + 4095) & ~(size_t)4095;  // the mate file's chunk starts here
 					size_t want = n + n / 16 + 4096;
 					if (paired) want = n_pad + (size_t)((double)n * bytes2_per_byte1 * 1.25) + (4u << 20);
-					if (!TextJob::grow(j->in, j->in_cap, want)) { fail.raise(URMAPX_E_NOMEM, "Page-locked chunk buffers: out of memory"); break; }
+					if (!TextJob::grow(j->in, j->in_cap, want)) { text_nomem.store(true); break; }
 					if (!read_range(fq, j->in, off, n)) { fail.raise(URMAPX_E_IO, std::string("Error reading ") + fastq1); break; }
 					j->nbytes = n; j->file_off = off; j->nbytes2 = 0; j->file_off2 = off2; j->in2 = nullptr;
 					if (paired) {
@@ -911,7 +918,7 @@ extern "C" int urmapx_map_files(urmapx_index *I, const urmapx_map_options *opt, 
 							}
 							if (!found && have == left2) give_up = true;  // the mate file ends first: the host reader words that
 						}
-						if (fail.set.load()) break;
+						if (fail.set.load() || text_nomem.load()) break;
 						if (give_up) { tfree.push(std::move(j)); break; }
 						j->in2 = dst; j->nbytes2 = n2;
 						if (n && n2) bytes2_per_byte1 = (double)n2 / (double)n;
@@ -937,6 +944,7 @@ extern "C" int urmapx_map_files(urmapx_index *I, const urmapx_map_options *opt, 
 				std::unique_ptr<TextJob> j;
 				for (size_t b = 0; tmapped[b % (size_t)n_lanes]->pop(j); ++b) {
 					if (!handed_back && !fail.set.load()) {
+						if (j->rc == URMAPX_E_NOMEM) { j->rc = 0; j->rep.reason = 0xFFFEu; text_nomem.store(true); }
 						if (j->rc) fail.raise(j->rc, std::string(paired ? "urmapx_text_map_pe: " : "urmapx_text_map_se: ") + urmapx_strerror(j->rc));
 						else if (j->rep.reason) { handed_back = true; stop.store(true); resume_off = j->file_off; resume_off2 = j->file_off2; }
 						else {
@@ -966,7 +974,8 @@ extern "C" int urmapx_map_files(urmapx_index *I, const urmapx_map_options *opt, 
 					trace.add("create", l, 0, tc);
 					size_t nj = 0;
 					double sam_per_fastq = 1.12;
-					if (trc) fail.raise(trc, std::string("urmapx_text_create: ") + urmapx_strerror(trc));
+					if (trc == URMAPX_E_NOMEM) text_nomem.store(true);  // T stays null: this lane's chunks go back unmapped
+					else if (trc) fail.raise(trc, std::string("urmapx_text_create: ") + urmapx_strerror(trc));
 					std::unique_ptr<TextJob> j;
 					while (tparsed[(size_t)l]->pop(j)) {
 						memset(&j->rep, 0, sizeof j->rep);

@@ -95,15 +95,23 @@ __global__ __launch_bounds__(NL_THREADS) void nl_count_kernel(const uint4 *raw, 
 }
 
 // one block: exclusive scan of m values in place; total to *total_out
-__global__ __launch_bounds__(1024) void scan_small_kernel(uint32_t *v, const uint32_t *m_ptr, uint32_t m_div, uint32_t m_fixed, uint32_t *total_out) {
+// (offsets are 32 bit: a total that does not fit sets bit 6 of *wrap_flags, and the caller refuses the chunk)
+__global__ __launch_bounds__(1024) void scan_small_kernel(uint32_t *v, const uint32_t *m_ptr, uint32_t m_div, uint32_t m_fixed, uint32_t *total_out,
+                                                          uint32_t *wrap_flags = nullptr) {
 	__shared__ uint32_t part[1024];
+	__shared__ unsigned long long tot64;
 	const uint32_t m = m_ptr ? (*m_ptr + m_div - 1) / m_div : m_fixed;
 	const uint32_t per = (m + 1023) / 1024;
 	const uint32_t lo = threadIdx.x * per, hi = lo + per < m ? lo + per : m;
-	uint32_t s = 0;
-	for (uint32_t i = lo; i < hi; ++i) s += v[i];
-	part[threadIdx.x] = s;
+	if (threadIdx.x == 0) tot64 = 0;
 	__syncthreads();
+	uint32_t s = 0;
+	unsigned long long s64 = 0;
+	for (uint32_t i = lo; i < hi; ++i) { s += v[i]; s64 += v[i]; }
+	part[threadIdx.x] = s;
+	if (wrap_flags && s64) atomicAdd(&tot64, s64);
+	__syncthreads();
+	if (wrap_flags && threadIdx.x == 0 && tot64 > 0xFFFFFFFFull) atomicOr(wrap_flags, 64u);
 	if (threadIdx.x < 64) {  // 16 partials per lane
 		uint32_t t = 0;
 		for (int k = 0; k < 16; ++k) t += part[threadIdx.x * 16 + k];
@@ -737,13 +745,14 @@ int map_text(urmapx_text *T, const char *fastq1, size_t nbytes1, const char *fas
 	A.lens = T->lens.p; A.rec_offs = T->rec_offs.p; A.sam = nullptr;
 	hipLaunchKernelGGL(sam_len_kernel, dim3(GRID), dim3(256), 0, st, A);
 	hipLaunchKernelGGL(scan_sums_kernel, dim3(GRID), dim3(SC_THREADS), 0, st, T->lens.p, &hdr->n_reads, T->sums.p);
-	hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(1024), 0, st, T->sums.p, &hdr->n_reads, (uint32_t)SC_TILE, 0u, &hdr->sam_total);
+	hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(1024), 0, st, T->sums.p, &hdr->n_reads, (uint32_t)SC_TILE, 0u, &hdr->sam_total, &hdr->flags);
 	hipLaunchKernelGGL(scan_apply_kernel<uint32_t>, dim3(GRID), dim3(SC_THREADS), 0, st, T->lens.p, &hdr->n_reads, T->sums.p, T->rec_offs.p);
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipMemcpyAsync(T->h_hdr, hdr, sizeof(TextHdr), hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipStreamSynchronize(st));
 	const TextHdr h2 = T->h_hdr[0];
 	if (h2.flags & 8u) { rep->reason = URMAPX_TEXT_LONG_NAME; return URMAPX_OK; }
+	if (h2.flags & 64u) { rep->reason = URMAPX_TEXT_TOO_LARGE; return URMAPX_OK; }  // the chunk's SAM text is over 4 GiB (record offsets are 32 bit)
 	T->pending = true;
 	T->pending_args = A;
 	memset(&T->pending_rep, 0, sizeof T->pending_rep);
