@@ -618,3 +618,118 @@ def test_cli_text_phase_without_pinned_memory_falls_back_to_the_host(small_case,
         rc, err = _urmap(args + ["-ufi", small_case["ufi"], "-samout", sam, "-batch", batch], env={"URMAPX_TEST_PINNED_ALLOCS": allocs})
         assert rc == 0, err[-2000:]
         assert _file_records(sam) == want, (batch, err[-600:])
+
+
+def _urmap_piped(args, feeds, env=None):
+    """Runs urmap with FIFOs: feeds = {placeholder: bytes}; every placeholder in args is replaced by a FIFO that a thread
+    fills.  A placeholder "-" feeds standard input through a pipe instead."""
+    import subprocess
+    import tempfile
+    import threading
+    d = tempfile.mkdtemp()
+    argv, threads, stdin_data = [], [], None
+    for a in args:
+        if a in feeds and a != "-":
+            path = os.path.join(d, a.strip("{}") + ".fq")
+            os.mkfifo(path)
+
+            def fill(path=path, data=feeds[a]):
+                with open(path, "wb") as f:
+                    try:
+                        f.write(data)
+                    except BrokenPipeError:
+                        pass
+            threads.append(threading.Thread(target=fill))
+            argv.append(path)
+        else:
+            if a == "-" and "-" in feeds:
+                stdin_data = feeds["-"]
+            argv.append(a)
+    p = subprocess.Popen([os.path.join(ROOT, "urmap_amd", "urmap")] + argv, stdin=subprocess.PIPE if stdin_data is not None else subprocess.DEVNULL,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, env={**os.environ, "URMAPX_VERBOSE": "1", **(env or {})})
+    for t in threads:
+        t.start()
+    out, err = p.communicate(stdin_data, timeout=300)
+    for t in threads:
+        t.join()
+    return p.returncode, err.decode()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("how", ["stdin", "fifo"])
+def test_cli_piped_input_takes_the_device_text_path(small_case, tmp_path, how):
+    """A pipe (FIFO or standard input; myutils.cpp:426-446 opens "-" as stdin) is streamed to the device like a .gz file:
+    no host parsing or formatting ("format 0.00"), the oracle's records, at several chunk sizes."""
+    from urmap_amd import synth
+    reads = synth.make_reads(821, small_case["genome"], 6000, read_len=150, sub=0.02, ins=0.002, dele=0.002, random_frac=0.02)
+    fq, osam, sam = (os.path.join(tmp_path, n) for n in ("r.fq", "o.sam", "g.sam"))
+    synth.write_fastq(fq, reads)
+    small_case["oracle_index"].map_file_se(fq, osam, threads=4)
+    data = open(fq, "rb").read()
+    want = _file_records(osam)
+    name = "-" if how == "stdin" else "{a}"
+    for batch in ("100000", "700", "64"):
+        rc, err = _urmap_piped(["-map", name, "-ufi", small_case["ufi"], "-samout", sam, "-batch", batch], {name: data})
+        assert rc == 0, err[-2000:]
+        assert _file_records(sam) == want, batch
+        assert "format 0.00" in err, err[-600:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("second", ["fifo", "plain", "gz"])
+def test_cli_piped_pairs(small_case, tmp_path, second):
+    from urmap_amd import synth
+    r1, r2 = synth.make_pairs(822, small_case["genome"], 3000, read_len=150, sub1=0.02, sub2=0.03, ins=0.002, dele=0.002)
+    r2 = [(lab + " a longer label", s, q) if k % 7 == 0 else (lab, s, q) for k, (lab, s, q) in enumerate(r2)]
+    f1, f2, osam, sam = (os.path.join(tmp_path, n) for n in ("r1.fq", "r2.fq", "o.sam", "g.sam"))
+    synth.write_fastq(f1, r1)
+    synth.write_fastq(f2, r2)
+    small_case["oracle_index"].map_file_pe(f1, f2, osam, threads=4)
+    want = _file_records(osam)
+    feeds = {"{a}": open(f1, "rb").read()}
+    name2 = f2
+    if second == "fifo":
+        feeds["{b}"] = open(f2, "rb").read()
+        name2 = "{b}"
+    elif second == "gz":
+        name2 = f2 + ".gz"
+        open(name2, "wb").write(gzip.compress(open(f2, "rb").read(), 1))
+    for batch in ("100000", "512"):
+        rc, err = _urmap_piped(["-map2", "{a}", "-reverse", name2, "-ufi", small_case["ufi"], "-samout", sam, "-batch", batch], feeds)
+        assert rc == 0, err[-2000:]
+        assert _file_records(sam) == want, batch
+        assert "format 0.00" in err, err[-600:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("damage", ["crlf_from_the_middle", "no_final_newline", "bad_record", "blank_lines_at_the_end"])
+def test_cli_piped_input_hand_back(small_case, tmp_path, damage):
+    """What the device parser hands back cannot be re-read from a pipe: the bytes of that chunk and of every chunk read
+    behind it go to the host reader in front of the rest of the pipe.  Same SAM / same message as the host-only run."""
+    from urmap_amd import synth
+    reads = synth.make_reads(823, small_case["genome"], 4000, read_len=150, sub=0.02, ins=0.002, dele=0.002)
+    fq, sam, hsam = (os.path.join(tmp_path, n) for n in ("r.fq", "g.sam", "h.sam"))
+    synth.write_fastq(fq, reads)
+    data = open(fq, "rb").read()
+    lines = data.split(b"\n")
+    if damage == "crlf_from_the_middle":
+        k = 4 * 2500
+        data = b"\n".join(lines[:k]) + b"\n" + b"\r\n".join(lines[k:])
+    elif damage == "no_final_newline":
+        data = data[:-1]
+    elif damage == "bad_record":
+        lines[4 * 3100 + 2] = b"-"
+        data = b"\n".join(lines)
+    else:
+        data = data + b"\n\n\n"
+    open(fq, "wb").write(data)
+    rc0, err0 = _urmap(["-map", fq, "-ufi", small_case["ufi"], "-samout", hsam], env={"URMAPX_HOST_TEXT": "1"})
+    for batch in ("100000", "900", "64"):
+        rc, err = _urmap_piped(["-map", "{a}", "-ufi", small_case["ufi"], "-samout", sam, "-batch", batch], {"{a}": data})
+        assert rc == rc0, (batch, err[-1500:])
+        if rc0 == 0:
+            assert _file_records(sam) == _file_records(hsam), batch
+        else:  # the reference's Die text with the line number; the file name differs (a FIFO), the rest does not
+            msg0 = [l for l in err0.splitlines() if "ine " in l and "r.fq" in l]
+            msg = [l for l in err.splitlines() if "ine " in l and "a.fq" in l]
+            assert msg0 and msg and msg[0].replace("a.fq", "r.fq").split("r.fq")[-1] == msg0[0].split("r.fq")[-1], (err0[-400:], err[-400:])

@@ -377,8 +377,14 @@ public:
 	~SeqSource() {
 		if (zs_init_) inflateEnd(&zs_);
 		for (z_stream &z : bz_) inflateEnd(&z);
-		if (fd_ >= 0) ::close(fd_);
+		if (fd_ >= 0 && own_) ::close(fd_);
 	}
+	// a descriptor that cannot seek (FIFO, standard input), owned by the caller: plain FASTQ text read front to back
+	bool open_pipe(int fd) {
+		fd_ = fd; own_ = false; pipe_ = true; gz_ = false;
+		return fd >= 0;
+	}
+	bool is_pipe() const { return pipe_; }
 	// regular files only; gz says which kind the name promises (".gz")
 	bool open(const char *path, bool gz) {
 		fd_ = ::open(path, O_RDONLY);
@@ -405,6 +411,16 @@ public:
 	// up to cap bytes of the uncompressed stream into dst; 0 = end of input (or failed())
 	size_t read(char *dst, size_t cap, int threads) {
 		if (cap == 0 || eof_ || bad_) return 0;
+		if (pipe_) {
+			size_t done = 0;
+			while (done < cap) {
+				const ssize_t k = ::read(fd_, dst + done, cap - done);
+				if (k < 0) { if (errno == EINTR) continue; bad_ = true; break; }
+				if (k == 0) { eof_ = true; break; }
+				done += (size_t)k;
+			}
+			return done;
+		}
 		if (!gz_) {
 			const size_t n = (size_t)std::min<uint64_t>(cap, csize_ - cpos_);
 			if (n == 0) { eof_ = true; return 0; }
@@ -513,7 +529,7 @@ private:
 		return out;
 	}
 	int fd_ = -1;
-	bool gz_ = false, bgzf_ = false, eof_ = false, bad_ = false, zs_init_ = false, member_done_ = true;
+	bool gz_ = false, bgzf_ = false, eof_ = false, bad_ = false, zs_init_ = false, member_done_ = true, pipe_ = false, own_ = true;
 	uint64_t csize_ = 0, cpos_ = 0;  // compressed (or plain) file: size, next byte to fetch
 	std::vector<uint8_t> cbuf_;
 	size_t cbeg_ = 0, chave_ = 0;
@@ -654,14 +670,19 @@ extern "C" int urmapx_map_files(urmapx_index *I, const urmapx_map_options *opt, 
 		};
 		uint64_t fsize = 0, fsize2 = 0;
 		int fq = -1, fq2 = -1;
-		// .gz input: the same phase with the chunks cut out of the inflated stream (SeqSource); a pipe has no way back to a
-		// chunk the device parser hands back, so it stays with the host reader
+		// .gz input: the same phase with the chunks cut out of the inflated stream (SeqSource).  A pipe (FIFO, standard input)
+		// is streamed the same way; it has no way back to a chunk the device parser hands back, so the bytes of that chunk
+		// and of everything read behind it are kept and given to the host reader in front of the rest of the pipe.
 		auto is_gz_name = [](const char *path) { const size_t l = strlen(path); return l > 3 && !strcmp(path + l - 3, ".gz"); };
 		SeqSource src1, src2;
 		bool streamed = false;
 		if (have_sam && !ftab && !getenv("URMAPX_HOST_TEXT")) {  // -tabbedout lines are made on the host (urmapx_tab_pe)
-			if (is_gz_name(fastq1) || (paired && is_gz_name(fastq2))) {
-				streamed = strcmp(fastq1, "-") != 0 && src1.open(fastq1, is_gz_name(fastq1)) && (!paired || (strcmp(fastq2, "-") != 0 && src2.open(fastq2, is_gz_name(fastq2))));
+			auto open_src = [&](SeqSource &src, FastqReader &r, const char *path) {
+				if (r.is_pipe()) return src.open_pipe(r.fd());
+				return strcmp(path, "-") != 0 && src.open(path, is_gz_name(path));
+			};
+			if (is_gz_name(fastq1) || (paired && is_gz_name(fastq2)) || rd.is_pipe() || (paired && rd2.is_pipe())) {
+				streamed = open_src(src1, rd, fastq1) && (!paired || open_src(src2, rd2, fastq2));
 			} else {
 				fq = open_plain(fastq1, fsize);
 				if (fq >= 0 && paired) {
@@ -729,6 +750,9 @@ extern "C" int urmapx_map_files(urmapx_index *I, const urmapx_map_options *opt, 
 			// the text phase ends there and the host reader / formatter, which need neither, continue from that chunk.
 			std::atomic<bool> text_nomem{false};
 			bool stream_done = false;  // streamed input: the reader handed every byte of the input(s) to a lane
+			// streamed input: bytes read from each source and not handed to a lane yet (behind the last cut; a whole buffer the
+			// reader gave up on).  Pipes: they go to the host reader in front of the rest of the pipe, behind pipe_back.
+			std::vector<char> carry, carry2, pipe_back, pipe_back2;
 			std::thread treader([&] {
 				omp_set_num_threads(read_threads);
 				uint64_t off = 0, off2 = 0;
@@ -738,7 +762,6 @@ extern "C" int urmapx_map_files(urmapx_index *I, const urmapx_map_options *opt, 
 					// chunks are cut out of the inflated stream: fill the job's buffer (what the last cut left over first),
 					// cut it at its last record start, keep the rest for the next chunk.  Offsets are those of the
 					// uncompressed text: that is where the host reader (gzseek) takes over if a chunk is handed back.
-					std::vector<char> carry, carry2;
 					bool eof1 = false, eof2 = false;
 					auto regrow = [&](TextJob &j, size_t want, size_t keep) {  // a larger page-locked buffer holding the first `keep` bytes
 						size_t ncap = 0;
@@ -780,8 +803,8 @@ extern "C" int urmapx_map_files(urmapx_index *I, const urmapx_map_options *opt, 
 								if (!regrow(*j, area1 + 4096 + area2, n)) { text_nomem.store(true); break; }
 							}
 						}
-						if (fail.set.load() || text_nomem.load()) break;
-						if (src1.failed()) { fail.raise(URMAPX_E_IO, std::string("Error reading gzip file ") + fastq1); break; }
+						if (fail.set.load() || text_nomem.load()) { carry.assign(j->in, j->in + n); break; }
+						if (src1.failed()) { fail.raise(URMAPX_E_IO, std::string(src1.is_pipe() ? "Error reading " : "Error reading gzip file ") + fastq1); break; }
 						if (cut == 0) { carry.assign(j->in, j->in + n); tfree.push(std::move(j)); break; }  // the host reader says what is wrong with it
 						carry.assign(j->in + cut, j->in + n);
 						j->nbytes = cut; j->file_off = off; j->nbytes2 = 0; j->file_off2 = off2; j->in2 = nullptr;
@@ -793,7 +816,10 @@ extern "C" int urmapx_map_files(urmapx_index *I, const urmapx_map_options *opt, 
 							size_t n_pad = (area1 + 4095) & ~(size_t)4095;
 							size_t have = carry2.size(), n2 = 0, seen = 0, scanned = 0;
 							bool found = false, give_up = false;
-							if (have > area2) { area2 = have + have / 4 + (4u << 20); if (!regrow(*j, n_pad + area2, cut)) { text_nomem.store(true); break; } }
+							if (have > area2) {
+								area2 = have + have / 4 + (4u << 20);
+								if (!regrow(*j, n_pad + area2, cut)) { text_nomem.store(true); carry.insert(carry.begin(), j->in, j->in + cut); break; }
+							}
 							char *dst = j->in + n_pad;
 							if (have) memcpy(dst, carry2.data(), have);
 							carry2.clear();
@@ -825,10 +851,14 @@ extern "C" int urmapx_map_files(urmapx_index *I, const urmapx_map_options *opt, 
 								const size_t k = src2.read(dst + have, want, read_threads);
 								if (k == 0) eof2 = true;
 								have += k;
-								if (src2.failed()) { fail.raise(URMAPX_E_IO, std::string("Error reading gzip file ") + fastq2); give_up = true; break; }
+								if (src2.failed()) { fail.raise(URMAPX_E_IO, std::string(src2.is_pipe() ? "Error reading " : "Error reading gzip file ") + fastq2); give_up = true; break; }
 							}
-							if (fail.set.load() || text_nomem.load()) break;
-							if (give_up) { carry.insert(carry.begin(), j->in, j->in + cut); tfree.push(std::move(j)); break; }
+							if (give_up || fail.set.load() || text_nomem.load()) {  // this chunk stays with the reader: both files' bytes back into the carries
+								carry.insert(carry.begin(), j->in, j->in + cut);
+								carry2.assign(dst, dst + have);
+								tfree.push(std::move(j));
+								break;
+							}
 							carry2.assign(dst + n2, dst + have);
 							j->in2 = dst; j->nbytes2 = n2;
 							if (cut && n2) bytes2_per_byte1 = (double)n2 / (double)cut;
@@ -947,19 +977,23 @@ extern "C" int urmapx_map_files(urmapx_index *I, const urmapx_map_options *opt, 
 						if (j->rc == URMAPX_E_NOMEM) { j->rc = 0; j->rep.reason = 0xFFFEu; text_nomem.store(true); }
 						if (j->rc) fail.raise(j->rc, std::string(paired ? "urmapx_text_map_pe: " : "urmapx_text_map_se: ") + urmapx_strerror(j->rc));
 						else if (j->rep.reason) { handed_back = true; stop.store(true); resume_off = j->file_off; resume_off2 = j->file_off2; }
-						else {
-							const auto tw0 = now();
-							const double ta = trace.ms();
-							if (!sink.write_at(j->out, (size_t)j->rep.sam_bytes, sam_off, write_threads))
-								fail.raise(URMAPX_E_IO, std::string("Error writing ") + samout);
-							sam_off += j->rep.sam_bytes;
-							t_write += secs(tw0, now());
-							trace.add("write", -1, b, ta);
-							n_reads += j->rep.records; n_accept += j->rep.mapped_q; n_reject += j->rep.mapped_lowq;
-							n_nohit += j->rep.unmapped; n_unsupported += j->rep.unsupported;
-							lines_done += (paired ? 2ull : 4ull) * j->rep.records;
-							input_bytes += j->nbytes + j->nbytes2;
-						}
+					}
+					if (handed_back && streamed) {  // pipes: this chunk's bytes and those of every chunk behind it, in order
+						if (src1.is_pipe()) pipe_back.insert(pipe_back.end(), j->in, j->in + j->nbytes);
+						if (paired && src2.is_pipe() && j->in2) pipe_back2.insert(pipe_back2.end(), j->in2, j->in2 + j->nbytes2);
+					}
+					if (!handed_back && !fail.set.load()) {
+						const auto tw0 = now();
+						const double ta = trace.ms();
+						if (!sink.write_at(j->out, (size_t)j->rep.sam_bytes, sam_off, write_threads))
+							fail.raise(URMAPX_E_IO, std::string("Error writing ") + samout);
+						sam_off += j->rep.sam_bytes;
+						t_write += secs(tw0, now());
+						trace.add("write", -1, b, ta);
+						n_reads += j->rep.records; n_accept += j->rep.mapped_q; n_reject += j->rep.mapped_lowq;
+						n_nohit += j->rep.unmapped; n_unsupported += j->rep.unsupported;
+						lines_done += (paired ? 2ull : 4ull) * j->rep.records;
+						input_bytes += j->nbytes + j->nbytes2;
 					}
 					tfree.push(std::move(j));
 				}
@@ -1021,8 +1055,16 @@ extern "C" int urmapx_map_files(urmapx_index *I, const urmapx_map_options *opt, 
 			if (fq2 >= 0) close(fq2);
 			if (!handed_back) { resume_off = reader_end; resume_off2 = reader_end2; }
 			host_phase = !fail.set.load() && (streamed ? (handed_back || !stream_done) : (resume_off < fsize || (paired && resume_off2 < fsize2)));
-			if (host_phase && (!rd.resume_at(resume_off, lines_done) || (paired && !rd2.resume_at(resume_off2, lines_done))))
-				fail.raise(URMAPX_E_IO, std::string("Cannot continue reading ") + fastq1);
+			if (host_phase) {
+				// a seekable source continues at its (uncompressed) offset; a pipe with the bytes taken from it and not mapped
+				auto resume = [&](FastqReader &r, SeqSource &src, uint64_t at, std::vector<char> &back, std::vector<char> &rest) {
+					if (!streamed || !src.is_pipe()) return r.resume_at(at, lines_done);
+					back.insert(back.end(), rest.begin(), rest.end());
+					return r.resume_with_prefix(std::move(back), lines_done);
+				};
+				if (!resume(rd, src1, resume_off, pipe_back, carry) || (paired && !resume(rd2, src2, resume_off2, pipe_back2, carry2)))
+					fail.raise(URMAPX_E_IO, std::string("Cannot continue reading ") + fastq1);
+			}
 			if (fail.set.load()) host_phase = false;
 		}
 	}

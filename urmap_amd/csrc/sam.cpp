@@ -50,7 +50,24 @@ bool FastqReader::resume_at(uint64_t offset, uint64_t lines_before) {
 	return true;
 }
 
+bool FastqReader::resume_with_prefix(std::vector<char> &&prefix, uint64_t lines_before) {
+	if (have_ || line_nr_ || !f_) return false;
+	prefix_ = std::move(prefix);
+	prefix_pos_ = 0;
+	line_nr_ = lines_before;
+	return true;
+}
+
+int FastqReader::fd() const { return f_ ? fileno(f_) : -1; }
+
 size_t FastqReader::read_some(char *dst, size_t cap) {
+	if (prefix_pos_ < prefix_.size()) {
+		const size_t n = std::min(cap, prefix_.size() - prefix_pos_);
+		memcpy(dst, prefix_.data() + prefix_pos_, n);
+		prefix_pos_ += n;
+		if (prefix_pos_ == prefix_.size()) { std::vector<char>().swap(prefix_); prefix_pos_ = 0; }
+		return n;
+	}
 	if (gz_) {
 		if (cap > (1u << 30)) cap = 1u << 30;
 		int n = gzread((gzFile)gz_, dst, (unsigned)cap);

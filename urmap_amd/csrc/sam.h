@@ -74,6 +74,11 @@ public:
 	// plain seekable files: continue at byte `offset`, which starts line number `lines_before` + 1 (the part of the file
 	// in front was consumed by the device parser)
 	bool resume_at(uint64_t offset, uint64_t lines_before);
+	// pipes: continue with `prefix` (bytes another reader of the same descriptor took from it and gives back) and then
+	// whatever the descriptor still holds; the prefix starts line number `lines_before` + 1
+	bool resume_with_prefix(std::vector<char> &&prefix, uint64_t lines_before);
+	bool is_pipe() const { return f_ && !seekable_; }  // plain input that cannot seek (a FIFO, standard input)
+	int fd() const;
 	// appends up to max_reads records; returns false at EOF with nothing read.  Sets err on malformed input.
 	bool next_batch(FastqBatch &B, uint32_t max_reads, std::string &err);
 	const std::string &path() const { return path_; }
@@ -90,6 +95,8 @@ private:
 	bool eof_ = false, finished_ = false, seekable_ = true;
 	uint64_t line_nr_ = 0;  // lines consumed so far
 	std::vector<size_t> ends_;  // scratch: end offset of every line of the batch
+	std::vector<char> prefix_;  // resume_with_prefix: read before the descriptor
+	size_t prefix_pos_ = 0;
 };
 
 // mates interleaved (reads 2i, 2i+1 = pair i), all host threads
