@@ -303,12 +303,19 @@ int urmapx_text_map_se(urmapx_text *, const char *fastq, size_t fastq_bytes, uns
                        urmapx_text_report *report);
 /* Pairs (-map2): a chunk of each mate file holding the same number of records; record 2i and 2i+1 of the text are the
  * mates of pair i with SetSAM2's flags, RNEXT, PNEXT and TLEN (output2.cpp:18-128); report.records counts reads (2 per
- * pair).  -tabbedout lines are not made here (urmapx_map_pe + urmapx_tab_pe). */
+ * pair).  -tabbedout lines: urmapx_text_fetch_pairs + urmapx_tab_pe. */
 int urmapx_text_map_pe(urmapx_text *, const char *fastq1, size_t fastq1_bytes, const char *fastq2, size_t fastq2_bytes,
                        unsigned minq, char *sam, size_t sam_cap, urmapx_text_report *report);
 /* After URMAPX_TEXT_SAM_CAP: the text of the chunk just mapped into a buffer of at least report.sam_bytes (the search is
  * not run again).  URMAPX_E_ARG if no such chunk is waiting. */
 int urmapx_text_fetch_sam(urmapx_text *, char *sam, size_t sam_cap, urmapx_text_report *report);
+/* After urmapx_text_map_pe mapped a chunk (reason 0 or URMAPX_TEXT_SAM_CAP) on a context with urmapx_ctx_set_pair_info
+ * on: what State2::OutputTab2 (outputtab2.cpp:85-120) needs for the chunk's -tabbedout lines, which the host formats with
+ * urmapx_tab_pe -- the 2 * npairs results, the npairs pair records, the offset of the '\n' of every line of the FIRST
+ * file's chunk (4 * npairs: pair i's label is the text between the '@' that starts line 4i and line_ends1[4i], its first
+ * mate's length line_ends1[4i+1] - line_ends1[4i] - 1) and the second mates' lengths.  npairs must be report.records / 2. */
+int urmapx_text_fetch_pairs(urmapx_text *, uint32_t npairs, urmapx_result *results, urmapx_pair_info *info, uint32_t *line_ends1,
+                            uint32_t *lens2);
 
 /* ---- FASTQ input (host) ---- */
 /* Batch form of FASTQSeqSource::GetNextLo (fastqseqsource.cpp:9-116) over LineReader (linereader.cpp:14-113):

@@ -733,3 +733,59 @@ def test_cli_piped_input_hand_back(small_case, tmp_path, damage):
             msg0 = [l for l in err0.splitlines() if "ine " in l and "r.fq" in l]
             msg = [l for l in err.splitlines() if "ine " in l and "a.fq" in l]
             assert msg0 and msg and msg[0].replace("a.fq", "r.fq").split("r.fq")[-1] == msg0[0].split("r.fq")[-1], (err0[-400:], err[-400:])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,ufi_gz", [("pe150", "g.ufi.gz"), ("pe120_rep", "r.ufi.gz")])
+@pytest.mark.parametrize("form", ["plain", "gz", "fifo"])
+def test_cli_map2_tabbedout_with_the_device_text_path(tmp_path, name, ufi_gz, form):
+    """-tabbedout no longer sends a -map2 run to the host text stages: the SAM text is made on the device, the tab lines
+    by host threads from the chunk's results and pair records (urmapx_text_fetch_pairs).  Reference's golden .tab and
+    .sam, at several chunk sizes; the stage report shows that the device wrote the SAM."""
+    gold = os.path.join(ROOT, "tests", "golden")
+    ufi = os.path.join(tmp_path, "x.ufi")
+    with gzip.open(os.path.join(gold, ufi_gz), "rb") as z, open(ufi, "wb") as f:
+        f.write(z.read())
+    d1, d2 = (open(os.path.join(gold, f"{name}_{k}.fq"), "rb").read() for k in (1, 2))
+    sam, tab = os.path.join(tmp_path, "out.sam"), os.path.join(tmp_path, "out.tab")
+    want_tab = open(os.path.join(gold, name + ".tab"), "rb").read()
+    want_sam = [l for l in open(os.path.join(gold, name + ".sam"), "rb").read().split(b"\n") if l]
+    for batch in ("100000", "128", "30"):
+        if form == "fifo":
+            rc, err = _urmap_piped(["-map2", "{a}", "-reverse", "{b}", "-ufi", ufi, "-samout", sam, "-tabbedout", tab, "-batch", batch], {"{a}": d1, "{b}": d2})
+        else:
+            f1, f2 = os.path.join(tmp_path, "r1.fq"), os.path.join(tmp_path, "r2.fq")
+            if form == "gz":
+                f1, f2 = f1 + ".gz", f2 + ".gz"
+                open(f1, "wb").write(gzip.compress(d1, 1))
+                open(f2, "wb").write(_bgzf(d2))
+            else:
+                open(f1, "wb").write(d1)
+                open(f2, "wb").write(d2)
+            rc, err = _urmap(["-map2", f1, "-reverse", f2, "-ufi", ufi, "-samout", sam, "-tabbedout", tab, "-batch", batch])
+        assert rc == 0, err[-2000:]
+        assert open(tab, "rb").read() == want_tab, batch
+        assert [l for l in open(sam, "rb").read().split(b"\n") if l and not l.startswith(b"@PG")] == want_sam, batch
+        assert "text on device: 1" in err, err[-600:]
+
+
+@pytest.mark.gpu
+def test_cli_map2_tabbedout_hand_back_mid_file(tmp_path):
+    """A CRLF part of the first mate file hands the rest of the run to the host stages: the tab file continues seamlessly."""
+    gold = os.path.join(ROOT, "tests", "golden")
+    ufi = os.path.join(tmp_path, "x.ufi")
+    with gzip.open(os.path.join(gold, "r.ufi.gz"), "rb") as z, open(ufi, "wb") as f:
+        f.write(z.read())
+    d1, d2 = (open(os.path.join(gold, f"pe120_rep_{k}.fq"), "rb").read() for k in (1, 2))
+    l1 = d1.split(b"\n")
+    k = 4 * (len(l1) // 8)
+    d1 = b"\n".join(l1[:k]) + b"\n" + b"\r\n".join(l1[k:])
+    f1, f2 = os.path.join(tmp_path, "r1.fq"), os.path.join(tmp_path, "r2.fq")
+    open(f1, "wb").write(d1)
+    open(f2, "wb").write(d2)
+    sam, tab = os.path.join(tmp_path, "out.sam"), os.path.join(tmp_path, "out.tab")
+    want_tab = open(os.path.join(gold, "pe120_rep.tab"), "rb").read()
+    for batch in ("100000", "64"):
+        rc, err = _urmap(["-map2", f1, "-reverse", f2, "-ufi", ufi, "-samout", sam, "-tabbedout", tab, "-batch", batch])
+        assert rc == 0, err[-2000:]
+        assert open(tab, "rb").read() == want_tab, batch

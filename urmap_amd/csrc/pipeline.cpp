@@ -327,6 +327,11 @@ struct TextJob {
 	uint64_t file_off = 0, file_off2 = 0;
 	urmapx_text_report rep;
 	int rc = 0;
+	// -tabbedout: the chunk's lines, formatted by the lane's host threads from what urmapx_text_fetch_pairs brings back
+	std::string tab;
+	std::vector<urmapx_result> tab_res;
+	std::vector<urmapx_pair_info> tab_info;
+	std::vector<uint32_t> tab_ends, tab_lens2;
 	~TextJob() {
 		HostPool::get().release(in, in_cap);
 		HostPool::get().release(out, out_cap);
@@ -676,7 +681,9 @@ extern "C" int urmapx_map_files(urmapx_index *I, const urmapx_map_options *opt, 
 		auto is_gz_name = [](const char *path) { const size_t l = strlen(path); return l > 3 && !strcmp(path + l - 3, ".gz"); };
 		SeqSource src1, src2;
 		bool streamed = false;
-		if (have_sam && !ftab && !getenv("URMAPX_HOST_TEXT")) {  // -tabbedout lines are made on the host (urmapx_tab_pe)
+		// -tabbedout (pairs only): the SAM text is made on the device all the same; the lines of the tab file are formatted by
+		// host threads from the chunk's results and pair records (urmapx_text_fetch_pairs), with the labels read in place
+		if (have_sam && (!ftab || paired) && !getenv("URMAPX_HOST_TEXT")) {
 			auto open_src = [&](SeqSource &src, FastqReader &r, const char *path) {
 				if (r.is_pipe()) return src.open_pipe(r.fd());
 				return strcmp(path, "-") != 0 && src.open(path, is_gz_name(path));
@@ -988,6 +995,8 @@ extern "C" int urmapx_map_files(urmapx_index *I, const urmapx_map_options *opt, 
 						if (!sink.write_at(j->out, (size_t)j->rep.sam_bytes, sam_off, write_threads))
 							fail.raise(URMAPX_E_IO, std::string("Error writing ") + samout);
 						sam_off += j->rep.sam_bytes;
+						if (ftab && !j->tab.empty() && fwrite(j->tab.data(), 1, j->tab.size(), ftab) != j->tab.size())
+							fail.raise(URMAPX_E_IO, std::string("Error writing ") + tabout);
 						t_write += secs(tw0, now());
 						trace.add("write", -1, b, ta);
 						n_reads += j->rep.records; n_accept += j->rep.mapped_q; n_reject += j->rep.mapped_lowq;
@@ -1029,6 +1038,32 @@ extern "C" int urmapx_map_files(urmapx_index *I, const urmapx_map_options *opt, 
 								else j->rc = urmapx_text_fetch_sam(T, j->out, j->out_cap, &j->rep);
 							}
 							if (!j->rc && !j->rep.reason && fq_bytes) sam_per_fastq = (double)j->rep.sam_bytes / (double)fq_bytes;
+							j->tab.clear();
+							if (!j->rc && !j->rep.reason && ftab && j->rep.records) {
+								const uint32_t np = j->rep.records / 2;
+								j->tab_res.resize((size_t)2 * np); j->tab_info.resize(np); j->tab_ends.resize((size_t)4 * np); j->tab_lens2.resize(np);
+								j->rc = urmapx_text_fetch_pairs(T, np, j->tab_res.data(), j->tab_info.data(), j->tab_ends.data(), j->tab_lens2.data());
+								if (!j->rc) {
+									const auto tf0 = now();
+									const int TT = std::max(1, host_threads / n_lanes);
+									std::vector<std::string> part((size_t)TT);
+#pragma omp parallel for schedule(static, 1) num_threads(TT)
+									for (int t = 0; t < TT; ++t) {
+										std::string &o = part[(size_t)t];
+										const uint32_t lo = (uint32_t)((uint64_t)np * (uint64_t)t / (uint64_t)TT), hi = (uint32_t)((uint64_t)np * (uint64_t)(t + 1) / (uint64_t)TT);
+										o.reserve((size_t)(hi - lo) * 72);
+										for (uint32_t u = lo; u < hi; ++u) {
+											const uint32_t *e = j->tab_ends.data() + (size_t)4 * u;
+											const uint32_t s0 = (u ? e[-1] + 1u : 0u) + 1u;  // behind the '@'
+											append_tab_pe(o, I, &j->tab_res[(size_t)2 * u], &j->tab_res[(size_t)2 * u + 1], &j->tab_info[u], j->in + s0, e[0] - s0,
+											              e[1] - e[0] - 1u, j->tab_lens2[u], have_sam ? 1 : 0);
+										}
+									}
+									for (const std::string &o : part) j->tab += o;
+									std::lock_guard<std::mutex> g(gpu_time_lock);
+									t_format += secs(tf0, now());
+								}
+							}
 							trace.add("gpu", l, (size_t)l + nj * (size_t)n_lanes, ta);
 							std::lock_guard<std::mutex> g(gpu_time_lock);
 							t_gpu += secs(tg0, now());

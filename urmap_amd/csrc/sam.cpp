@@ -597,10 +597,9 @@ unsigned template_length(const TabHit &h1, const TabHit &h2, uint32_t len1, uint
 }
 }  // namespace
 
-extern "C" size_t urmapx_tab_pe(const urmapx_index *I, const urmapx_result *r1, const urmapx_result *r2,
-                                const urmapx_pair_info *info, const char *label1, uint32_t len1, uint32_t len2, int sam_on,
-                                char *buf, size_t cap) {
-	if (!I || !r1 || !r2 || !info || !label1 || !buf) return 0;
+namespace urx {
+void append_tab_pe(std::string &out, const urmapx_index *I, const urmapx_result *r1, const urmapx_result *r2, const urmapx_pair_info *info,
+                   const char *label1, size_t n, uint32_t len1, uint32_t len2, int sam_on) {
 	const urmapx_result *r[2] = {r1, r2};
 	TabHit top[2], sec[2];
 	for (int a = 0; a < 2; ++a) {
@@ -610,8 +609,7 @@ extern "C" size_t urmapx_tab_pe(const urmapx_index *I, const urmapx_result *r1, 
 		sec[a].has = info->second_db[a] != 0xFFFFFFFFu;
 		sec[a].db = info->second_db[a]; sec[a].plus = info->second_plus[a] != 0; sec[a].score = info->second_score[a];
 	}
-	std::string out;
-	size_t n = strlen(label1);  // GetPairLabel, state1.cpp:762-778
+	// GetPairLabel, state1.cpp:762-778
 	if (n > 2 && label1[n - 2] == '/' && (label1[n - 1] == '1' || label1[n - 1] == '2')) n -= 2;
 	for (size_t i = 0; i < n && !isspace((unsigned char)label1[i]); ++i) out.push_back(label1[i]);
 	out.push_back('\t');
@@ -635,6 +633,15 @@ extern "C" size_t urmapx_tab_pe(const urmapx_index *I, const urmapx_result *r1, 
 		out.push_back(';');
 	}
 	out.push_back('\n');
+}
+}  // namespace urx
+
+extern "C" size_t urmapx_tab_pe(const urmapx_index *I, const urmapx_result *r1, const urmapx_result *r2,
+                                const urmapx_pair_info *info, const char *label1, uint32_t len1, uint32_t len2, int sam_on,
+                                char *buf, size_t cap) {
+	if (!I || !r1 || !r2 || !info || !label1 || !buf) return 0;
+	std::string out;
+	urx::append_tab_pe(out, I, r1, r2, info, label1, strlen(label1), len1, len2, sam_on);
 	if (out.size() > cap) return 0;
 	memcpy(buf, out.data(), out.size());
 	return out.size();

@@ -110,6 +110,10 @@ void append_sam_record(std::string &out, const urmapx_index *I, const urmapx_res
                        uint32_t flags, const char *mate_label, uint32_t mate_pos, int tlen, const char *label,
                        const uint8_t *seq, const uint8_t *qual, unsigned QL);
 
+// One -tabbedout line (State2::OutputTab2, outputtab2.cpp:85-120); label1 = the first mate's label, n bytes, no '@'
+void append_tab_pe(std::string &out, const urmapx_index *I, const urmapx_result *r1, const urmapx_result *r2, const urmapx_pair_info *info,
+                   const char *label1, size_t n, uint32_t len1, uint32_t len2, int sam_on);
+
 // 256-entry complement table of alpha.cpp:3005 (IUPAC, case preserving, 'u' and non-letters -> '?')
 const unsigned char *complement_table();
 

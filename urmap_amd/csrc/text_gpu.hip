@@ -625,6 +625,7 @@ struct urmapx_text {
 	uint32_t seq_count = 0;
 	TextHdr *h_hdr = nullptr;  // page-locked, [2]
 	// a chunk mapped and measured whose text has not been fetched (urmapx_text_fetch_sam)
+	uint32_t last_pairs = 0;  // pairs of the last chunk urmapx_text_map_pe mapped (urmapx_text_fetch_pairs)
 	bool pending = false;
 	SamArgs pending_args;
 	urmapx_text_report pending_rep;
@@ -738,6 +739,7 @@ int map_text(urmapx_text *T, const char *fastq1, size_t nbytes1, const char *fas
 		rc = urmapx_map_se_device(C, T->bases.p, T->offs.p, n, h1.total_bases, mx, T->results.p, T->pathops.p, T->used.p);
 	}
 	if (rc) return rc;
+	T->last_pairs = paired ? n / 2 : 0;
 	SamArgs A;
 	A.raw[0] = T->raw[0].p; A.raw[1] = T->raw[1].p; A.ends[0] = T->ends[0].p; A.ends[1] = T->ends[1].p; A.paired = paired ? 1u : 0u;
 	A.results = T->results.p; A.ops = T->pathops.p; A.tnames = T->tnames.p;
@@ -822,6 +824,17 @@ int urmapx_text_fetch_sam(urmapx_text *T, char *sam, size_t sam_cap, urmapx_text
 	if (!T || !rep || !T->pending) return URMAPX_E_ARG;
 	HIP_TRY(hipSetDevice(ctx_device(T->C)));
 	return fetch_sam(T, sam, sam_cap, rep);
+}
+
+int urmapx_text_fetch_pairs(urmapx_text *T, uint32_t npairs, urmapx_result *results, urmapx_pair_info *info, uint32_t *line_ends1, uint32_t *lens2) {
+	if (!T || !results || !info || !line_ends1 || !lens2) return URMAPX_E_ARG;
+	if (T->last_pairs == 0 || T->last_pairs != npairs) return URMAPX_E_ARG;
+	HIP_TRY(hipSetDevice(ctx_device(T->C)));
+	hipStream_t st = ctx_stream(T->C);
+	HIP_TRY(hipMemcpyAsync(results, T->results.p, (size_t)2 * npairs * sizeof(urmapx_result), hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(line_ends1, T->ends[0].p, (size_t)4 * npairs * 4, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(lens2, T->blen[1].p, (size_t)npairs * 4, hipMemcpyDeviceToHost, st));
+	return urmapx_ctx_get_pair_info(T->C, info, npairs);  // synchronises the stream
 }
 
 }  // extern "C"
