@@ -35,7 +35,7 @@ extern "C" {
 /* Single-end: a read the fast kernels flag is mapped again by the general kernel (lists in global memory), so these
  * remain only beyond ITS limits: 65536 live hits, 65536..262144 HSPs, a batch's path arena full, a flank window clipped
  * by the end of the sequence store with a band beyond 1100 columns, a read shorter than the word length (the reference
- * underflows there) or longer than URMAPX_MAX_QL_SLOW.  Paired-end: 256 hits per mate, 8192 HSPs per mate, 96 runs. */
+ * underflows there) or longer than URMAPX_MAX_QL_SLOW.  Paired-end: 1024 hits per mate (third pass), 8192 HSPs per mate, 96 runs. */
 #define URMAPX_ST_HIT_OVERFLOW 0x01 /* more live hits than the device lists hold */
 #define URMAPX_ST_HSP_OVERFLOW 0x02 /* more HSPs than the device lists hold */
 #define URMAPX_ST_PATH_OVERFLOW 0x04 /* alignment path longer than the path storage */

@@ -121,3 +121,94 @@ def test_cli_maps_what_the_fast_kernels_flag(many_hits_case, small_case, tmp_pat
                 assert r.returncode == 0, r.stderr.decode()[-2000:]
                 got = [l for l in open(sam, "rb").read().split(b"\n") if l and not l.startswith(b"@")]
                 assert got == want
+
+
+def _compare_pe(g, gops, ores, opaths):
+    assert (g["status"] == 0).all(), np.unique(g["status"])
+    for name in ("dbpos", "seq_index", "coord", "score", "second", "mapq"):
+        assert (g[name].astype(np.int64) == ores[name].astype(np.int64)).all(), name
+    mapped = ores["dbpos"] != 0xFFFFFFFF
+    assert (g["plus"][mapped] == ores["plus"][mapped]).all()
+    for i in np.nonzero(mapped)[0]:
+        o = int(g["path_off"][i])
+        assert api.decode_path(gops[o:o + int(g["path_nops"][i])]) == opaths[i], i
+
+
+def test_pairs_with_more_than_256_hits_per_mate(many_hits_case):
+    """A mate with more than 256 live hits outgrows the pair kernel's second pass; a third pass with lists of 1024 hits per
+    mate maps it (the reference's lists have no bound, state1.cpp:193-228).  FindPairs sees hundreds x hundreds of hits:
+    the best and second-best pair are tracked without a pair list (state2.cpp:20-85 keeps one of unbounded length)."""
+    c = many_hits_case
+    R = [x[1] for x in c["reads"]]  # six cuts of the consensus; the odd-numbered ones are stored reverse-complemented
+    q = np.full(150, ord("I"), np.uint8)
+    mates = [(R[0], synth.revcomp(R[4])), (R[2], synth.revcomp(R[0])), (synth.revcomp(R[1]), R[3]), (synth.revcomp(R[5]), synth.revcomp(R[2]))]
+    pairs = []
+    for k, (m1, m2) in enumerate(mates):
+        pairs += [(f"c{k}/1", m1.copy(), q), (f"c{k}/2", m2.copy(), q)]
+    r1, r2 = synth.make_pairs(17, c["genome"], 30, read_len=150, sub1=0.01, sub2=0.02)  # ordinary pairs in the same batch
+    pairs += [x for ab in zip(r1, r2) for x in ab]
+    bases, offs = reads_to_arrays(pairs)
+    ores, opaths, _ = c["oracle_index"].map_pe(bases, offs)
+    assert (ores["hit_count"] > 256).sum() >= 4, ores["hit_count"]  # the fixture does what it was built for
+    m = api.Mapper(api.Index.open(c["ufi"]).upload(0), device=0)
+    g, gops = m.map_pe(bases, offs)
+    _compare_pe(g, gops, ores, opaths)
+
+
+@pytest.fixture(scope="module")
+def satellite_case(tmp_path_factory):
+    """VERDICT r2 item 3's fixture, literally: 2 000 tandem copies of a 171-base monomer, each copy <= 2 % diverged, between
+    random flanks.  (An index drops every k-mer with more than 32 occurrences, so reads from it end with a few dozen hits.)"""
+    d = str(tmp_path_factory.mktemp("satellite"))
+    rng = np.random.default_rng(171)
+    rnd = lambda n: ACGT[rng.integers(0, 4, n)]
+    mono = rnd(171)
+    copies = []
+    for _ in range(2000):
+        m = mono.copy()
+        for p in rng.choice(171, int(rng.integers(0, 4)), replace=False):  # 0..3 substitutions = <= 1.75 %
+            m[p] = _sub(rng, m[p])
+        copies.append(m)
+    genome = [("chrS", np.concatenate([rnd(20000)] + copies + [rnd(20000)])), ("chrO", rnd(60000))]
+    fa = os.path.join(d, "s.fa")
+    synth.write_fasta(fa, genome)
+    idx = ol.Index.build(fa, 2097169)
+    ufi = os.path.join(d, "s.ufi")
+    idx.save(ufi)
+    return {"dir": d, "ufi": ufi, "oracle_index": idx, "genome": genome}
+
+
+def test_tandem_satellite_single_and_paired(satellite_case):
+    c = satellite_case
+    sat = [("chrS", c["genome"][0][1][20000 - 300:20000 + 171 * 2000 + 300])]
+    reads = synth.make_reads(61, sat, 300, read_len=150, sub=0.01, ins=0.001, dele=0.001) + synth.make_reads(62, c["genome"], 100, read_len=150, sub=0.02)
+    bases, offs = reads_to_arrays(reads)
+    ores, opaths, _ = c["oracle_index"].map_se(bases, offs)
+    m = api.Mapper(api.Index.open(c["ufi"]).upload(0), device=0)
+    g, gops = m.map_se(bases, offs)
+    _compare(g, gops, ores, opaths)
+    r1, r2 = synth.make_pairs(63, sat, 200, read_len=150, sub1=0.01, sub2=0.02, ins=0.001, dele=0.001)
+    pairs = [x for ab in zip(r1, r2) for x in ab]
+    bases, offs = reads_to_arrays(pairs)
+    ores, opaths, _ = c["oracle_index"].map_pe(bases, offs)
+    g, gops = m.map_pe(bases, offs)
+    _compare_pe(g, gops, ores, opaths)
+
+
+def test_cli_map2_on_pairs_with_hundreds_of_hits(many_hits_case, tmp_path):
+    c = many_hits_case
+    r = [c["reads"][k][1] if k % 2 == 0 else synth.revcomp(c["reads"][k][1]) for k in (0, 2, 3)]
+    q = np.full(150, ord("I"), np.uint8)
+    r1 = [(f"c{k}", x.copy(), q) for k, x in enumerate(r)] + synth.make_reads(8, c["genome"], 40, read_len=150, sub=0.02)
+    r2 = [(f"c{k}", synth.revcomp(x), q) for k, x in enumerate(r)] + synth.make_reads(9, c["genome"], 40, read_len=150, sub=0.02)
+    f1, f2, sam, osam = (os.path.join(tmp_path, n) for n in ("r1.fq", "r2.fq", "out.sam", "oracle.sam"))
+    synth.write_fastq(f1, r1)
+    synth.write_fastq(f2, r2)
+    c["oracle_index"].map_file_pe(f1, f2, osam)
+    want = [l for l in open(osam, "rb").read().split(b"\n") if l and not l.startswith(b"@")]
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "urmap_amd", "urmap")
+    for env in ({}, {"URMAPX_HOST_TEXT": "1"}):
+        rr = subprocess.run([exe, "-map2", f1, "-reverse", f2, "-ufi", c["ufi"], "-samout", sam], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                            timeout=300, env={**os.environ, **env})
+        assert rr.returncode == 0, rr.stderr.decode()[-2000:]
+        assert [l for l in open(sam, "rb").read().split(b"\n") if l and not l.startswith(b"@")] == want

@@ -24,7 +24,7 @@ static constexpr int PE_HITW1 = 2;     // hit-list words (64 hits each) of the f
 static constexpr int PE_HSP_CAP = 128;       // HSPs of a mate held in LDS
 static constexpr int PE_HSP_OVF_CAP = 8064;  // per mate, in global scratch
 static constexpr int PE_OVF_BLOCKS = 1024;   // grid of the second pass (the costliest pairs of a batch)
-static constexpr int PE_PAIR_CAP = 256;
+static constexpr int PE_T2_BLOCKS = 64;      // grid of the third pass (pairs with more than 256 hits on a mate)
 static constexpr int PE_TICKET_CHUNK = 2;
 static constexpr int PE_ROW_CAP = 32;   // UFIndex m_MaxIx of every index this build accepts
 static constexpr int PE_SCAN_SEG = 1024;  // SCAN_DB_SEG_LENGTH, state2.cpp:92
@@ -39,8 +39,14 @@ __host__ __device__ inline size_t pe_rowstore_offset(int qmax) {
 
 __host__ __device__ inline size_t pe_tb_offset(int qmax);
 
-template <int NCH, bool OVF>
+// TIER: 0 = first pass (hit lists of PE_HITW1 x 64 per mate), 1 = second pass over the pairs that outgrew a list (4 x 64
+// hits, HSP lists continued in global memory), 2 = third pass over the pairs that outgrew those (PE_HITW2 x 64 = 1024
+// hits per mate: the reference's list has no bound, state1.cpp:193-228; this pass exists so that a pair in a satellite
+// is mapped, not flagged -- it runs a handful of pairs per run and is not tuned)
+static constexpr int PE_HITW2 = 16;
+template <int NCH, int TIER>
 struct Mate {
+	static constexpr bool OVF = TIER > 0;
 	static constexpr int QMAX = 64 * NCH;
 	static constexpr int TB_ROWS8 = QMAX / 8 + 2;
 	// wave constants
@@ -69,7 +75,7 @@ struct Mate {
 	// lists
 	// hits: entry k lives on lane k & 63 of word k >> 6 (one word = 64 hits in the first-pass kernel, HITW words in the
 	// second pass over pairs that outgrew a list)
-	static constexpr int HITW = OVF ? 4 : PE_HITW1;
+	static constexpr int HITW = TIER == 0 ? PE_HITW1 : TIER == 1 ? 4 : PE_HITW2;
 	uint32_t hit_db[HITW];
 	uint32_t hit_sp[HITW];  // score << 1 | plus
 	int hit_cap;            // first pass: PE_HIT_CAP (a test aid lowers it)
@@ -741,8 +747,8 @@ struct Mate {
 #ifndef URX_PE_WAVES
 #define URX_PE_WAVES(NCH) ((NCH) <= 3 ? 3 : 2)
 #endif
-template <int NCH, bool OVF>
-__global__ __launch_bounds__(64, URX_PE_WAVES(NCH)) void search_pe_kernel(DevIndex X, urmapx_params P, const uint8_t *__restrict__ bases,
+template <int NCH, int TIER>
+__global__ __launch_bounds__(64, TIER == 2 ? 1 : URX_PE_WAVES(NCH)) void search_pe_kernel(DevIndex X, urmapx_params P, const uint8_t *__restrict__ bases,
                                                        const uint64_t *__restrict__ offs, uint32_t npairs, ProbeOut probe,
                                                        urmapx_result *__restrict__ results,
                                                        urmapx_path_op *__restrict__ path_ops, uint32_t *path_used,
@@ -750,14 +756,15 @@ __global__ __launch_bounds__(64, URX_PE_WAVES(NCH)) void search_pe_kernel(DevInd
                                                        const uint8_t *__restrict__ g_seq, const uint8_t *__restrict__ g_blob,
                                                        const uint4 *__restrict__ g_seqp,
                                                        int veryfast, uint32_t *ticket, urmapx_pair_info *pair_info,
-                                                       int hsp_lds_cap, uint32_t *ovf_list, uint2 *hsp_ovf_base, uint32_t hsp_area_blocks) {
-	using M = Mate<NCH, OVF>;
+                                                       int hsp_lds_cap, uint32_t *ovf_list, uint32_t *ovf_next, uint2 *hsp_ovf_base, uint32_t hsp_area_blocks) {
+	constexpr bool OVF = TIER > 0;
+	using M = Mate<NCH, TIER>;
 	constexpr int QMAX = M::QMAX;
 	// LDS per block decides how many pairs a CU keeps in flight, so arrays share memory by lifetime:
 	//   probe results staged for the seed enumeration (s_tal, s_pos)       on  the DP trace buffer (idle until AlignHSP)
 	//   flank run buffers, candidate path, target window (AlignHSP / Scan)  on  seed_res  (seeds are dead by then)
 	//   pending-stage row lengths and prefix                               on  seed_q
-	//   the pending stage's candidate queue, then FindPairs' pair list      on  seed_db
+	//   the pending stage's candidate queue                                 on  seed_db
 	__shared__ __attribute__((aligned(16))) uint8_t sQ[4][QMAX];
 	__shared__ __attribute__((aligned(16))) uint4 qpl[4][2 * NCH];  // [mate * 2 + strand][block of 32 bases]
 	__shared__ uint16_t hit_nops[2][PE_HIT_CAP * M::HITW];
@@ -787,9 +794,8 @@ __global__ __launch_bounds__(64, URX_PE_WAVES(NCH)) void search_pe_kernel(DevInd
 	static_assert(2 * QMAX + 66 * 2 <= sizeof(seed_q), "alias");
 	uint8_t *const rowlen = reinterpret_cast<uint8_t *>(&seed_q[0][0]);  // shared by the two mates: SearchPE_Pending runs on one mate at a time
 	uint16_t *const pre = reinterpret_cast<uint16_t *>(rowlen + 2 * QMAX);
-	static_assert(2 * PE_PAIR_CAP * 2 <= sizeof(seed_db) && 128 * 6 <= sizeof(seed_db), "alias");
-	uint16_t *const pair_f = reinterpret_cast<uint16_t *>(&seed_db[0][0]), *const pair_r = pair_f + PE_PAIR_CAP;
-	uint32_t *const cq_db = &seed_db[0][0];  // pending stage only: before FindPairs fills the pair list
+	static_assert(128 * 6 <= sizeof(seed_db), "alias");
+	uint32_t *const cq_db = &seed_db[0][0];  // pending stage only
 	uint16_t *const cq_qp = reinterpret_cast<uint16_t *>(cq_db + 128);
 
 	const int lane = threadIdx.x;
@@ -806,6 +812,7 @@ __global__ __launch_bounds__(64, URX_PE_WAVES(NCH)) void search_pe_kernel(DevInd
 		m[a].ropsL = ropsL; m[a].ropsR = ropsR; m[a].cand = cand;
 		m[a].hit_nops = hit_nops[a];
 		m[a].hit_paths = OVF ? reinterpret_cast<urmapx_path_op *>(hsp_ovf_base + (size_t)hsp_area_blocks * 2 * PE_HSP_OVF_CAP) +
+		                           (TIER == 2 ? (size_t)PE_OVF_BLOCKS * 2 * PE_HIT_CAP * 4 * URMAPX_MAX_PATH_OPS : (size_t)0) +
 		                           ((size_t)blockIdx.x * 2 + a) * PE_HIT_CAP * M::HITW * URMAPX_MAX_PATH_OPS
 		                     : reinterpret_cast<urmapx_path_op *>(sc) + (size_t)a * PE_HIT_CAP * PE_HITW1 * URMAPX_MAX_PATH_OPS;
 		m[a].hit_cap = (hsp_lds_cap >= 64 && hsp_lds_cap <= PE_HSP_CAP) ? (hsp_lds_cap & ~63) / 4 : PE_HIT_CAP * PE_HITW1;
@@ -1106,6 +1113,9 @@ __global__ __launch_bounds__(64, URX_PE_WAVES(NCH)) void search_pe_kernel(DevInd
 			}
 		}
 		int npairs_found = 0, bestPairScore = -1, secondPairScore = -1, bestPairIndex = -1, secondPairIndex = -1;
+		// the reference keeps every pair (state2.cpp:20-85) and looks only at the best and the second best afterwards: their
+		// hit indexes are kept as the indexes change hands, so the pair list needs no storage (and has no capacity)
+		int bestF = -1, bestR = -1, secF = -1, secR = -1;
 		int secondHit[2] = {-1, -1};  // m_SecondHit of the mates (set by AdjustTopHitsAndMapqs only)
 		if (dbg_stop == 2) done = true;
 		if (!done) {
@@ -1140,6 +1150,7 @@ __global__ __launch_bounds__(64, URX_PE_WAVES(NCH)) void search_pe_kernel(DevInd
 			// FindPairs (state2.cpp:20-85), ScanPair if there is none (state2.cpp:87-137), FindPairs again
 			for (int attempt = 0; attempt < 2; ++attempt) {
 				npairs_found = 0; bestPairScore = -1; secondPairScore = -1; bestPairIndex = -1; secondPairIndex = -1;
+				bestF = bestR = secF = secR = -1;
 				for (int i = 0; i < m[0].hitCount; ++i) {
 					const uint32_t spf = m[0].hsp_of(i);
 					const int sf = (int)(spf >> 1);
@@ -1155,14 +1166,10 @@ __global__ __launch_bounds__(64, URX_PE_WAVES(NCH)) void search_pe_kernel(DevInd
 						if ((spf & 1u) == (spr & 1u)) continue;
 						const int total = sf + sr;
 						if (total > bestPairScore) {
-							secondPairIndex = bestPairIndex; secondPairScore = bestPairScore;
-							bestPairScore = total; bestPairIndex = npairs_found;
-						} else if (total == bestPairScore) { secondPairIndex = npairs_found; secondPairScore = bestPairScore; }
-						else if (total > secondPairScore) { secondPairIndex = bestPairIndex; secondPairScore = total; }  // sic, state2.cpp:74
-						if (npairs_found < PE_PAIR_CAP) {
-							if (lane == 0) { pair_f[npairs_found] = (uint16_t)i; pair_r[npairs_found] = (uint16_t)j; }
-						} else
-							m[0].status |= URMAPX_ST_HIT_OVERFLOW;
+							secondPairIndex = bestPairIndex; secondPairScore = bestPairScore; secF = bestF; secR = bestR;
+							bestPairScore = total; bestPairIndex = npairs_found; bestF = i; bestR = j;
+						} else if (total == bestPairScore) { secondPairIndex = npairs_found; secondPairScore = bestPairScore; secF = i; secR = j; }
+						else if (total > secondPairScore) { secondPairIndex = bestPairIndex; secondPairScore = total; secF = bestF; secR = bestR; }  // sic, state2.cpp:74
 						++npairs_found;
 					}
 				}
@@ -1198,8 +1205,8 @@ __global__ __launch_bounds__(64, URX_PE_WAVES(NCH)) void search_pe_kernel(DevInd
 				if (mq > 40) mq = 40;
 				if (mq > m[0].mapq) m[0].mapq = mq;
 				if (mq > m[1].mapq) m[1].mapq = mq;
-				if (bestPairIndex >= 0 && bestPairIndex < PE_PAIR_CAP) { m[0].topHit = pair_f[bestPairIndex]; m[1].topHit = pair_r[bestPairIndex]; }
-				if (secondPairIndex >= 0 && secondPairIndex < PE_PAIR_CAP) { secondHit[0] = pair_f[secondPairIndex]; secondHit[1] = pair_r[secondPairIndex]; }
+				if (bestPairIndex >= 0) { m[0].topHit = bestF; m[1].topHit = bestR; }
+				if (secondPairIndex >= 0) { secondHit[0] = secF; secondHit[1] = secR; }
 			}
 		}
 
@@ -1253,9 +1260,13 @@ __global__ __launch_bounds__(64, URX_PE_WAVES(NCH)) void search_pe_kernel(DevInd
 			}
 			if (lane == 0) results[2 * pr + a] = R;
 		}
-		if constexpr (!OVF) {
+		if constexpr (TIER == 0) {
 			if ((m[0].status | m[1].status) & (URMAPX_ST_HSP_OVERFLOW | URMAPX_ST_HIT_OVERFLOW)) {  // queue the pair for the second pass
-				if (lane == 0) ovf_list[1 + atomicAdd(ovf_list, 1u)] = pr;
+				if (lane == 0) ovf_next[1 + atomicAdd(ovf_next, 1u)] = pr;
+			}
+		} else if constexpr (TIER == 1) {
+			if ((m[0].status | m[1].status) & URMAPX_ST_HIT_OVERFLOW) {  // more than 256 hits on a mate: the third pass
+				if (lane == 0) ovf_next[1 + atomicAdd(ovf_next, 1u)] = pr;
 			}
 		}
 	}
@@ -1280,7 +1291,8 @@ size_t search_pe_scratch_stride(uint32_t max_read_len) {
 static uint32_t pe_hsp_area_blocks(int blocks) { return (uint32_t)(blocks > PE_OVF_BLOCKS ? blocks : PE_OVF_BLOCKS); }
 size_t search_pe_scratch_tail(int blocks) {
 	return (size_t)pe_hsp_area_blocks(blocks) * 2 * (size_t)PE_HSP_OVF_CAP * sizeof(uint2) +
-	       (size_t)PE_OVF_BLOCKS * 2 * (size_t)PE_HIT_CAP * 4 * URMAPX_MAX_PATH_OPS * 2;
+	       (size_t)PE_OVF_BLOCKS * 2 * (size_t)PE_HIT_CAP * 4 * URMAPX_MAX_PATH_OPS * 2 +
+	       (size_t)PE_T2_BLOCKS * 2 * (size_t)PE_HIT_CAP * PE_HITW2 * URMAPX_MAX_PATH_OPS * 2;
 }
 
 int search_pe_block_count(uint32_t max_read_len, int device) {
@@ -1288,10 +1300,10 @@ int search_pe_block_count(uint32_t max_read_len, int device) {
 	if (hipGetDeviceProperties(&prop, device) != hipSuccess) return 0;
 	int per_cu = 0;
 	const int nchq = pe_nch_for(max_read_len);
-	hipError_t e = nchq == 2   ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, search_pe_kernel<2, false>, 64, 0)
-	               : nchq == 3 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, search_pe_kernel<3, false>, 64, 0)
-	               : nchq == 4 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, search_pe_kernel<4, false>, 64, 0)
-	                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, search_pe_kernel<5, false>, 64, 0);
+	hipError_t e = nchq == 2   ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, search_pe_kernel<2, 0>, 64, 0)
+	               : nchq == 3 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, search_pe_kernel<3, 0>, 64, 0)
+	               : nchq == 4 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, search_pe_kernel<4, 0>, 64, 0)
+	                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, search_pe_kernel<5, 0>, 64, 0);
 	if (e != hipSuccess || per_cu < 1) per_cu = 4;
 	return per_cu * prop.multiProcessorCount;
 }
@@ -1301,56 +1313,41 @@ hipError_t launch_search_pe(const DevIndex &X, const urmapx_params &P, const uin
                             urmapx_path_op *d_path_ops, uint32_t *d_path_used, const SearchWork &wk, int veryfast,
                             urmapx_pair_info *pair_info, hipStream_t s) {
 	if (npairs == 0) return hipSuccess;
+	uint32_t *const ovf_list2 = wk.ovf_list + (size_t)npairs + 1;  // the third pass's work list (wk.ovf_list holds 2 * (npairs + 1) words)
 	{
 		hipError_t e = hipMemsetAsync(wk.ticket, 0, 4, s);
 		if (e != hipSuccess) return e;
 		e = hipMemsetAsync(wk.ovf_list, 0, 4, s);
 		if (e != hipSuccess) return e;
+		e = hipMemsetAsync(ovf_list2, 0, 4, s);
+		if (e != hipSuccess) return e;
 	}
-	dim3 block(64), grid((unsigned)wk.blocks);
+	dim3 block(64);
 	const int nch = pe_nch_for(max_read_len);
-	uint2 *const ovf_base1 = reinterpret_cast<uint2 *>(wk.scratch + (size_t)wk.blocks * wk.scratch_stride);  // HSP lists beyond LDS
-	if (nch == 2)
-		hipLaunchKernelGGL((search_pe_kernel<2, false>), grid, block, 0, s, X, P, d_bases, d_offs, npairs, probe, d_results,
-		                   d_path_ops, d_path_used, wk.scratch, wk.scratch_stride, X.seq, X.blob, X.seqp, veryfast, wk.ticket, pair_info,
-		                   wk.hsp_lds_cap, wk.ovf_list, ovf_base1, pe_hsp_area_blocks(wk.blocks));
-	else if (nch == 3)
-		hipLaunchKernelGGL((search_pe_kernel<3, false>), grid, block, 0, s, X, P, d_bases, d_offs, npairs, probe, d_results,
-		                   d_path_ops, d_path_used, wk.scratch, wk.scratch_stride, X.seq, X.blob, X.seqp, veryfast, wk.ticket, pair_info,
-		                   wk.hsp_lds_cap, wk.ovf_list, ovf_base1, pe_hsp_area_blocks(wk.blocks));
-	else if (nch == 4)
-		hipLaunchKernelGGL((search_pe_kernel<4, false>), grid, block, 0, s, X, P, d_bases, d_offs, npairs, probe, d_results,
-		                   d_path_ops, d_path_used, wk.scratch, wk.scratch_stride, X.seq, X.blob, X.seqp, veryfast, wk.ticket, pair_info,
-		                   wk.hsp_lds_cap, wk.ovf_list, ovf_base1, pe_hsp_area_blocks(wk.blocks));
-	else
-		hipLaunchKernelGGL((search_pe_kernel<5, false>), grid, block, 0, s, X, P, d_bases, d_offs, npairs, probe, d_results,
-		                   d_path_ops, d_path_used, wk.scratch, wk.scratch_stride, X.seq, X.blob, X.seqp, veryfast, wk.ticket, pair_info,
-		                   wk.hsp_lds_cap, wk.ovf_list, ovf_base1, pe_hsp_area_blocks(wk.blocks));
-	{
-		hipError_t e = hipGetLastError();
-		if (e != hipSuccess) return e;
-		e = hipMemsetAsync(wk.ticket, 0, 4, s);
-		if (e != hipSuccess) return e;
-	}
-	// second pass over the pairs whose HSP lists outgrew LDS (see launch_search_se)
-	dim3 grid2((unsigned)(wk.blocks < PE_OVF_BLOCKS ? wk.blocks : PE_OVF_BLOCKS));
-	uint2 *ovf_base = reinterpret_cast<uint2 *>(wk.scratch + (size_t)wk.blocks * wk.scratch_stride);
-	if (nch == 2)
-		hipLaunchKernelGGL((search_pe_kernel<2, true>), grid2, block, 0, s, X, P, d_bases, d_offs, npairs, probe, d_results,
-		                   d_path_ops, d_path_used, wk.scratch, wk.scratch_stride, X.seq, X.blob, X.seqp, veryfast, wk.ticket, pair_info,
-		                   wk.hsp_lds_cap, wk.ovf_list, ovf_base, pe_hsp_area_blocks(wk.blocks));
-	else if (nch == 3)
-		hipLaunchKernelGGL((search_pe_kernel<3, true>), grid2, block, 0, s, X, P, d_bases, d_offs, npairs, probe, d_results,
-		                   d_path_ops, d_path_used, wk.scratch, wk.scratch_stride, X.seq, X.blob, X.seqp, veryfast, wk.ticket, pair_info,
-		                   wk.hsp_lds_cap, wk.ovf_list, ovf_base, pe_hsp_area_blocks(wk.blocks));
-	else if (nch == 4)
-		hipLaunchKernelGGL((search_pe_kernel<4, true>), grid2, block, 0, s, X, P, d_bases, d_offs, npairs, probe, d_results,
-		                   d_path_ops, d_path_used, wk.scratch, wk.scratch_stride, X.seq, X.blob, X.seqp, veryfast, wk.ticket, pair_info,
-		                   wk.hsp_lds_cap, wk.ovf_list, ovf_base, pe_hsp_area_blocks(wk.blocks));
-	else
-		hipLaunchKernelGGL((search_pe_kernel<5, true>), grid2, block, 0, s, X, P, d_bases, d_offs, npairs, probe, d_results,
-		                   d_path_ops, d_path_used, wk.scratch, wk.scratch_stride, X.seq, X.blob, X.seqp, veryfast, wk.ticket, pair_info,
-		                   wk.hsp_lds_cap, wk.ovf_list, ovf_base, pe_hsp_area_blocks(wk.blocks));
+	uint2 *const ovf_base = reinterpret_cast<uint2 *>(wk.scratch + (size_t)wk.blocks * wk.scratch_stride);  // HSP lists beyond LDS
+#define URX_LAUNCH_PE(NCH_, TIER_, GRID_, IN_, OUT_)                                                                          \
+	hipLaunchKernelGGL((search_pe_kernel<NCH_, TIER_>), GRID_, block, 0, s, X, P, d_bases, d_offs, npairs, probe, d_results,      \
+	                   d_path_ops, d_path_used, wk.scratch, wk.scratch_stride, X.seq, X.blob, X.seqp, veryfast, wk.ticket,        \
+	                   pair_info, wk.hsp_lds_cap, IN_, OUT_, ovf_base, pe_hsp_area_blocks(wk.blocks))
+#define URX_LAUNCH_PE_TIER(TIER_, GRID_, IN_, OUT_)                                                                            \
+	do {                                                                                                                        \
+		if (nch == 2) URX_LAUNCH_PE(2, TIER_, GRID_, IN_, OUT_);                                                                  \
+		else if (nch == 3) URX_LAUNCH_PE(3, TIER_, GRID_, IN_, OUT_);                                                             \
+		else if (nch == 4) URX_LAUNCH_PE(4, TIER_, GRID_, IN_, OUT_);                                                             \
+		else URX_LAUNCH_PE(5, TIER_, GRID_, IN_, OUT_);                                                                           \
+		hipError_t e_ = hipGetLastError();                                                                                        \
+		if (e_ != hipSuccess) return e_;                                                                                          \
+		e_ = hipMemsetAsync(wk.ticket, 0, 4, s);                                                                                  \
+		if (e_ != hipSuccess) return e_;                                                                                          \
+	} while (0)
+	uint32_t *const none = nullptr;
+	URX_LAUNCH_PE_TIER(0, dim3((unsigned)wk.blocks), none, wk.ovf_list);
+	// second pass over the pairs whose HSP or hit lists outgrew the first pass's (see launch_search_se); third pass over
+	// the pairs with more than 256 hits on a mate.  Both find their work lists on the device and usually leave at once.
+	URX_LAUNCH_PE_TIER(1, dim3((unsigned)(wk.blocks < PE_OVF_BLOCKS ? wk.blocks : PE_OVF_BLOCKS)), wk.ovf_list, ovf_list2);
+	URX_LAUNCH_PE_TIER(2, dim3((unsigned)(wk.blocks < PE_T2_BLOCKS ? wk.blocks : PE_T2_BLOCKS)), ovf_list2, none);
+#undef URX_LAUNCH_PE_TIER
+#undef URX_LAUNCH_PE
 	return hipGetLastError();
 }
 

@@ -552,7 +552,7 @@ int urmapx_map_pe_device(urmapx_ctx *C, const void *d_bases, const void *d_offs,
 	wk.blocks = C->pe_blocks[cls];
 	wk.scratch_stride = search_pe_scratch_stride(max_read_len);
 	if ((rc = C->pe_scratch.ensure(wk.scratch_stride * (size_t)wk.blocks + search_pe_scratch_tail(wk.blocks)))) return rc;
-	if ((rc = C->ovflist.ensure((size_t)npairs + 1))) return rc;
+	if ((rc = C->ovflist.ensure(2 * ((size_t)npairs + 1)))) return rc;  // work lists of the second and third pass
 	wk.ovf_list = C->ovflist.p;
 	if (const char *e = getenv("URMAPX_TEST_HSP_LDS_CAP")) wk.hsp_lds_cap = atoi(e);
 	wk.scratch = C->pe_scratch.p;
