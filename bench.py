@@ -504,6 +504,10 @@ class Workload:
         parity = {"reads_checked": int(sample_n), "bit_identical_to_oracle": bool(ok),
                   "fields": "dbpos, seq_index, coord, plus, score, second, mapq, path (CIGAR)",
                   "gapped_paths_checked": int(len(gapped)), "mapped_frac": round(float(mapped.mean()), 4)}
+        if not self.pe:  # the phase of Search_Lo a read left in (search1m6.cpp:35-277): what share of the batch each phase sees
+            h = np.bincount(ores["exit_phase"].astype(np.int64), minlength=7)[:7]
+            parity["exit_phase_frac"] = [round(float(x) / max(1, sample_n), 4) for x in h]
+            parity["exit_phase_equal"] = bool((g["exit_phase"] == ores["exit_phase"]).all())
         if not ok:
             parity["mismatches"] = diffs
             parity["status_values"] = [int(x) for x in np.unique(g["status"])]
