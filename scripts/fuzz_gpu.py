@@ -25,8 +25,11 @@ oi = ol.Index.wrap(24, 32, slots, blob_np, seq_np, lens, offs, labels)
 cores = bench.host_cores()
 bad = 0
 cases = [(False, 150, 0.01, 0.001), (False, 150, 0.03, 0.01), (False, 100, 0.02, 0.004), (False, 250, 0.04, 0.01), (False, 250, 0.01, 0.002),
-         (False, 300, 0.03, 0.008), (False, 64, 0.01, 0.0), (True, 150, 0.01, 0.001), (True, 100, 0.03, 0.005), (True, 250, 0.02, 0.004)]
+         (False, 300, 0.03, 0.008), (False, 64, 0.01, 0.0), (True, 150, 0.01, 0.001), (True, 100, 0.03, 0.005), (True, 250, 0.02, 0.004),
+         (False, 500, 0.02, 0.004), (False, 1000, 0.01, 0.002), (True, 270, 0.03, 0.006)]  # round 3: the 512 / 1024-base kernel classes, the longest pairs
+n_all = n
 for ci, (pe, L, sub, indel) in enumerate(cases):
+    n = n_all if L <= 300 else n_all // 4
     for streams in ((1, 2) if ci < 2 else (1,)):
         wl = bench.Workload(torch, api, dev, d_seq, lens, offs, pe, L, sub, indel, n, 1, 9000 + 31 * ci, streams=streams)
         dt, kms = wl.timed(ms[:streams], 1, 0)
