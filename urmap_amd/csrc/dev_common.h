@@ -426,6 +426,22 @@ __device__ __forceinline__ uint32_t lds_addr(const T *p) {  // the LDS aperture 
 // 16 zero bytes: what lanes without a k-mer gather instead of a slot (tally 0 = TALLY_FREE)
 static __device__ uint32_t g_zero16[4];
 
+// A wave-uniform int the optimiser must treat as new from here on.  The search kernels derive dozens of lane masks
+// and conditions from a read's length; LLVM hoists them all to the top of the read (they are loop invariant), where they
+// outnumber the 102 SGPRs of a wave several times over, get spilled into VGPR lanes and come back through v_readlane +
+// s_nop at every use.  Re-deriving them where they are used is one v_cmp; so the length is "refreshed" at the top of the
+// hot loops (measured: search kernel 24.4 -> 22.4 ms per 1 M reads with two such points).
+// the same for the lane number: values derived from it (lane + 64 c, LDS addresses, lane masks) are one instruction to make
+// and a scratch reload (a memory round trip) to keep
+__device__ __forceinline__ int fresh_lane(int x) {
+	asm volatile("" : "+v"(x));
+	return x;
+}
+__device__ __forceinline__ int fresh_uniform(int x) {
+	asm volatile("" : "+v"(x));
+	return __builtin_amdgcn_readfirstlane(x);
+}
+
 // Barrier of a one-wavefront block that orders LDS traffic only: __syncthreads() also waits for every global load and
 // store in flight (s_waitcnt vmcnt(0)), which is a memory round trip where stores were just issued.
 __device__ __forceinline__ void lds_sync() {

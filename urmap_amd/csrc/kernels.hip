@@ -229,7 +229,7 @@ struct SearchWave {
 
 	const DevIndex &X;
 	const urmapx_params &P;
-	const int lane;
+	int lane;  // not const: the search kernel refreshes it at the top of its hot loops (fresh_lane)
 	const uint8_t *__restrict__ gseq;   // = X.seq / X.blob, passed as plain kernel arguments so that the
 	const uint8_t *__restrict__ gblob;  // compiler emits global_load (not flat) and can keep many loads in flight
 	int QL, W, nwords;
@@ -864,7 +864,7 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 	uint32_t *const stage_sl = reinterpret_cast<uint32_t *>(pre);
 	uint64_t *const stage_b = reinterpret_cast<uint64_t *>(cq_db);
 
-	const int lane = threadIdx.x;
+	int lane = threadIdx.x;
 	const int W = (int)X.W;
 	const int dbg_stop = (DBG && stats) ? (int)stats[0] : 0;  // diagnostic only (URMAPX_DEBUG_STOP)
 	const bool timing = DBG && stats && stats[1] == 0;
@@ -1004,7 +1004,7 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 			if (next_ok) { wait_lgkm0(); fetch_bytes(noff, nQL); fetched = true; }
 			lapc(0);
 		}
-		const int nwords = QL - (W - 1);
+		int nwords = QL - (W - 1);
 		const int minScore1 = QL + P.xphase1 * P.mismatch_score;
 		const int minScore3 = QL + P.xphase3 * P.mismatch_score;
 		const int minScore4 = QL + P.xphase4 * P.mismatch_score;
@@ -1023,6 +1023,9 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 #pragma unroll
 		for (int g = 0; g < SW::NSEG; ++g) rl[g] = 0;
 		for (int step = cur_ok ? 1 : 5;;) {
+			QL = fresh_uniform(QL);  // see dev_common.h: keeps the length-dependent masks out of the SGPR spill lanes
+			S.QL = QL; nwords = QL - (W - 1); S.nwords = nwords;
+			lane = fresh_lane(lane); S.lane = lane;
 			if (DBG && dbg_stop && step != 5 && (dbg_stop == 100 || (dbg_stop < 100 && step > dbg_stop))) {  // diagnostic schedule cut
 				done = true;
 				if (step == 4 || step == 6) break;  // the next read's probe went out in step 5 already
@@ -1096,6 +1099,9 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 			// compacted, in order, into a small LDS queue; gather/consume then always run on full batches.
 			int scanned = 0, qhead = 0, qcount = 0;
 			while (!done && (scanned < total || qcount > 0)) {
+				QL = fresh_uniform(QL);
+				S.QL = QL; nwords = QL - (W - 1); S.nwords = nwords;
+				lane = fresh_lane(lane); S.lane = lane;
 				uint64_t tsub = timing ? __builtin_amdgcn_s_memtime() : 0;
 				auto laps = [&](int slot) {
 					if (!timing) return;
@@ -1763,6 +1769,8 @@ int search_block_count(uint32_t max_read_len, int device) {
 	               : nchq == 8 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, search_se_kernel<8, false, false>, 64, 0)
 	                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, search_se_kernel<16, false, false>, 64, 0);
 	if (e != hipSuccess || per_cu < 1) per_cu = 8;
+	// measurement aid: fewer resident waves with the same code (is the kernel bound by issue or by latency? DESIGN.md 5.0)
+	if (const char *t = getenv("URMAPX_TEST_BLOCKS_PER_CU")) { const int v = atoi(t); if (v >= 1 && v < per_cu) per_cu = v; }
 	return per_cu * prop.multiProcessorCount;
 }
 
