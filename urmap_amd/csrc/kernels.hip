@@ -282,6 +282,7 @@ struct SearchWave {
 	// state1.cpp:508-551.  path (if any) is in `cand` with cand_nops runs.
 	__device__ __forceinline__ void add_hit(uint32_t db, bool plus, int score, int cand_nops) {
 		if (score < 10) return;
+		const int lane = fresh_lane(this->lane);  // dev_common.h: lane-derived values are remade here, not carried (and spilled) from the top of the kernel
 		if (overlaps_hit(db)) return;
 		int mp = (QL - score) - 2 * P.mismatch_score;
 		if (mp < maxPen) maxPen = mp;
@@ -309,6 +310,7 @@ struct SearchWave {
 	// state1.cpp:553-591
 	__device__ __forceinline__ void add_hsp(uint32_t startq, uint32_t startdb, bool plus, uint32_t len, int score) {
 		if (score < best - 4) return;
+		const int lane = fresh_lane(this->lane);  // dev_common.h: lane-derived values are remade here, not carried (and spilled) from the top of the kernel
 		const uint32_t diag = startdb - startq;
 		const uint32_t npk = startq | (len << PK_LEN_SH) | ((uint32_t)score << PK_SCORE_SH) | (plus ? 1u << PK_PLUS_SH : 0u);
 		const int nlds = hspCount < hsp_lds ? hspCount : hsp_lds;
@@ -479,6 +481,7 @@ struct SearchWave {
 	// One DpJob per HSP that phase 6 would align, the read's state parked for finalize_se_kernel.  false: nothing to
 	// align, or no room left in the job array / the parking lot -- the caller then runs phase 6 itself.
 	__device__ bool park_for_dp(const DpWork &dp, uint32_t r, int phase) {
+		const int lane = fresh_lane(this->lane);  // dev_common.h: lane-derived values are remade here, not carried (and spilled) from the top of the kernel
 		int njobs = 0;
 		bool clipped = false;
 		for (int base = 0; base < hspCount; base += 64) {
@@ -603,6 +606,7 @@ struct SearchWave {
 
 	// m_Mapq, SetMappedPos (state1.cpp:129-145) with PosToCoordL (ufindex.cpp:729-755), the top hit's path
 	__device__ void fill_result(urmapx_result &res, int phase, urmapx_path_op *__restrict__ path_ops, uint32_t *path_used) {
+		const int lane = fresh_lane(this->lane);  // dev_common.h: lane-derived values are remade here, not carried (and spilled) from the top of the kernel
 		res.mapq = (uint8_t)calc_mapq();
 		res.score = (int16_t)best; res.second = (int16_t)second;
 		res.hit_count = (uint16_t)hitCount; res.exit_phase = (uint8_t)phase; res.status = (uint8_t)status;
@@ -675,6 +679,8 @@ struct SearchWave {
 	//                 slot go from the 27 GB table straight into pr_lo / pr_hi, no register holds them, and the
 	//                 wavefront goes on with the current read
 	__device__ __forceinline__ void probe_hash(const uint8_t *nq, int QLn, uint32_t *stage_sl, uint64_t *stage_b) {
+		const int lane = fresh_lane(this->lane);  // dev_common.h: lane-derived values are remade here, not carried (and spilled) from the top of the kernel
+		QLn = fresh_uniform(QLn);
 		const uint32_t nwn = (uint32_t)(QLn - (W - 1));
 		auto planes = [&](int c, uint64_t &lo, uint64_t &hi, uint64_t &inv, uint64_t &invm) {
 			const int p = 64 * c + lane;
@@ -708,6 +714,8 @@ struct SearchWave {
 		}
 	}
 	__device__ __forceinline__ void probe_gather(int QLn, const uint32_t *stage_sl, const uint64_t *stage_b) {
+		const int lane = fresh_lane(this->lane);  // dev_common.h: lane-derived values are remade here, not carried (and spilled) from the top of the kernel
+		QLn = fresh_uniform(QLn);
 		const uint32_t nwn = (uint32_t)(QLn - (W - 1));
 		wait_lgkm0();  // every earlier LDS read of the pr_* arrays has returned
 #pragma unroll
@@ -731,6 +739,7 @@ struct SearchWave {
 	// are in flight; positions go to rowstore[seg][k][lane], row lengths to rl[seg].  In two parts: the chain heads come
 	// out of the pr_* arrays (which the next read's probe may then overwrite), the hops out of the slot table.
 	__device__ __forceinline__ void walk_heads(uint64_t (&sl)[NSEG], uint32_t (&T)[NSEG], uint32_t (&ps)[NSEG], bool (&act)[NSEG]) const {
+		const int lane = fresh_lane(this->lane);  // dev_common.h: lane-derived values are remade here, not carried (and spilled) from the top of the kernel
 #pragma unroll
 		for (int g = 0; g < NSEG; ++g) {
 			const int s2 = g / NCH, c = g % NCH;
@@ -751,6 +760,7 @@ struct SearchWave {
 #pragma unroll
 		for (int g = 0; g < NSEG; ++g) { rl[g] = 0; any |= act[g]; }
 		while (any) {
+			const int lane = fresh_lane(this->lane);  // dev_common.h: lane-derived values are remade here, not carried (and spilled) from the top of the kernel
 #pragma unroll
 			for (int g = 0; g < NSEG; ++g) {
 				if (!act[g]) continue;
@@ -1195,6 +1205,7 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 				uint64_t todo = __ballot(e_kind != 0 && e_pen <= S.maxPen && !(e_kind == 2 && e_bst < S.best - 4) &&
 				                         !S.overlaps_any_hit(my_dblo));
 				while (todo) {
+					lane = fresh_lane(lane); S.lane = lane;
 					const int t = __builtin_ctzll(todo);
 					todo &= todo - 1;
 					if (rdlane((uint32_t)c_second, t) != 0 && !crossed) {  // first candidate of the second phase of this list
