@@ -183,9 +183,12 @@ __host__ __device__ inline size_t search_tb_offset(int nch) {
 	size_t b = (size_t)2 * nch * ROW_CAP * 64 * 4 + WideScratch::bytes(qmax, qmax + 64);
 	return (b + 255) & ~(size_t)255;
 }
-__host__ __device__ inline size_t search_scratch_bytes(int nch) {
-	return search_tb_offset(nch) + (size_t)((64 * nch - 24) / 8 + 2) * 64 * 4;
+// behind the trace cells: hits 65..128 of a first-pass read (SE_HIT_TAIL words)
+static constexpr int SE_HIT_TAIL = 64;
+__host__ __device__ inline size_t search_tail_offset(int nch) {
+	return (search_tb_offset(nch) + (size_t)((64 * nch - 24) / 8 + 2) * 64 * 4 + 255) & ~(size_t)255;
 }
+__host__ __device__ inline size_t search_scratch_bytes(int nch) { return search_tail_offset(nch) + (size_t)SE_HIT_TAIL * 4; }
 
 // AddHSPX over the part of a read's HSP list that lives in global scratch (reads in high-copy repeats only).  Kept out
 // of line so that its registers do not count against the search loop's.  0: same diagonal found (entry updated if the
@@ -251,6 +254,12 @@ struct SearchWave {
 	// (reads that outgrew a list) has HITW words = 512 hits.
 	static constexpr int HITW = OVF ? 8 : SE_HITW1;
 	uint32_t hit_db[HITW];
+	// First pass only: hits 65..128 live in global memory (this block's scratch while the read is searched, the read's
+	// parked state afterwards) and are looked at only by a read that has them -- 5 reads in a million on the hg38-scale
+	// genome, which used to cost every batch a second pass of ~1 ms.  The register word stays one.
+	static constexpr int TAIL = OVF ? 0 : SE_HIT_TAIL;
+	uint32_t *hit_tail;
+	__device__ __forceinline__ bool has_tail() const { return !OVF && hitCount > 64 * SE_HITW1; }
 	// hits per word: 64 (2^6).  The test aid that lowers the first pass's caps also lowers this to 16 in the second pass,
 	// so that a fixture with a few dozen hits per read runs through several words.
 	int hit_wsh;
@@ -267,6 +276,7 @@ struct SearchWave {
 		bool eq = false;
 #pragma unroll
 		for (int w = 0; w < HITW; ++w) eq |= lane < wl() && (w << wsh()) + lane < hitCount && (hit_db[w] >> 6) == (db >> 6);
+		if (has_tail()) eq |= lane < hitCount - 64 * SE_HITW1 && (hit_tail[lane] >> 6) == (db >> 6);
 		return __ballot(eq) != 0;
 	}
 
@@ -276,6 +286,11 @@ struct SearchWave {
 #pragma unroll
 		for (int w = 0; w < HITW; ++w)
 			for (int k = 0; k < wl() && (w << wsh()) + k < hitCount; ++k) ov |= (rdlane(hit_db[w], k) >> 6) == (db >> 6);
+		if (has_tail()) {
+			const int nt = hitCount - 64 * SE_HITW1;
+			const uint32_t t = lane < nt ? hit_tail[lane] : 0u;
+			for (int k = 0; k < nt; ++k) ov |= (rdlane(t, k) >> 6) == (db >> 6);
+		}
 		return ov;
 	}
 
@@ -293,10 +308,16 @@ struct SearchWave {
 			if (score < best - SECONDARY_HIT_MAX_DELTA) return;
 			if (score > second) second = score;
 		}
-		if (hitCount >= (OVF ? HITW << wsh() : hit_cap)) { status |= URMAPX_ST_HIT_OVERFLOW; return; }
+		// the first pass's capacity: its register word(s) + the tail (a test aid lowers hit_cap below a word: no tail then)
+		if (hitCount >= (OVF ? HITW << wsh() : (hit_cap == 64 * SE_HITW1 ? hit_cap + TAIL : hit_cap))) { status |= URMAPX_ST_HIT_OVERFLOW; return; }
+		if (!OVF && hitCount >= 64 * SE_HITW1) {
+			if (lane == 0) hit_tail[hitCount - 64 * SE_HITW1] = db;
+			URX_SYNC();  // the other lanes read it (overlaps_hit / overlaps_any_hit)
+		} else {
 #pragma unroll
-		for (int w = 0; w < HITW; ++w)
-			if (lane < wl() && (w << wsh()) + lane == hitCount) hit_db[w] = db;
+			for (int w = 0; w < HITW; ++w)
+				if (lane < wl() && (w << wsh()) + lane == hitCount) hit_db[w] = db;
+		}
 		++hitCount;
 		if (newTop) {
 			haveTop = true; top_db = db; top_plus = plus; top_nops = cand_nops;
@@ -461,7 +482,7 @@ struct SearchWave {
 	}
 
 	// ---- phase 6 as separate launches (kernels.h: DpJob) ----
-	static constexpr int STATE_WORDS = HITW * 64 + 16 + URMAPX_MAX_PATH_OPS / 2;
+	static constexpr int STATE_WORDS = HITW * 64 + TAIL + 16 + URMAPX_MAX_PATH_OPS / 2;  // hit words, hit tail, scalars, the top hit's path
 
 	__device__ __forceinline__ bool hsp_get(int k, uint32_t &startdb, uint32_t &pk) const {
 		startdb = 0; pk = 0;
@@ -537,7 +558,8 @@ struct SearchWave {
 	__device__ void park_state(uint32_t *st, int phase) {
 #pragma unroll
 		for (int wd = 0; wd < HITW; ++wd) st[wd * 64 + lane] = hit_db[wd];
-		uint32_t *sc = st + HITW * 64;
+		if (has_tail() && hit_tail != st + HITW * 64 && lane < hitCount - 64 * SE_HITW1) st[HITW * 64 + lane] = hit_tail[lane];
+		uint32_t *sc = st + HITW * 64 + TAIL;
 		if (lane == 0) {
 			sc[0] = (uint32_t)hitCount; sc[1] = (uint32_t)maxPen; sc[2] = (uint32_t)best; sc[3] = (uint32_t)second;
 			sc[4] = top_db; sc[5] = (haveTop ? 1u : 0u) | (top_plus ? 2u : 0u) | ((uint32_t)phase << 8);
@@ -548,10 +570,11 @@ struct SearchWave {
 	}
 
 	// back from the parking lot (finalize_se_kernel); returns the phase the read was in
-	__device__ int restore_state(const uint32_t *st) {
+	__device__ int restore_state(uint32_t *st) {
 #pragma unroll
 		for (int wd = 0; wd < HITW; ++wd) hit_db[wd] = st[wd * 64 + lane];
-		const uint32_t *sc = st + HITW * 64;
+		hit_tail = st + HITW * 64;  // in place: the replay appends to it there
+		const uint32_t *sc = st + HITW * 64 + TAIL;
 		hitCount = (int)uni(sc[0]); maxPen = (int)uni(sc[1]); best = (int)uni(sc[2]); second = (int)uni(sc[3]);
 		top_db = uni(sc[4]);
 		const uint32_t f = uni(sc[5]);
@@ -892,6 +915,7 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 		// the trace cells of phase 3's banded DP live in this block's global scratch (phase 6 has kernels of its own with
 		// the trace in LDS): 6 KB of LDS per block went to the slot entries instead
 		S.tb = reinterpret_cast<uint32_t *>(sc + search_tb_offset(NCH));
+		S.hit_tail = reinterpret_cast<uint32_t *>(sc + search_tail_offset(NCH));
 		S.hsp_ovf = hsp_ovf_base + (size_t)blockIdx.x * (HSP_TOTAL_CAP - HSP_CAP);
 		S.hsp_lds = (hsp_lds_cap >= 64 && hsp_lds_cap <= HSP_CAP) ? (hsp_lds_cap & ~63) : HSP_CAP;  // multiple of 64
 		S.hit_cap = (hsp_lds_cap >= 64 && hsp_lds_cap <= HSP_CAP) ? S.hsp_lds / 4 : 64 * SE_HITW1;

@@ -1305,6 +1305,7 @@ int search_pe_block_count(uint32_t max_read_len, int device) {
 	               : nchq == 4 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, search_pe_kernel<4, 0>, 64, 0)
 	                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, search_pe_kernel<5, 0>, 64, 0);
 	if (e != hipSuccess || per_cu < 1) per_cu = 4;
+	if (const char *t = getenv("URMAPX_TEST_BLOCKS_PER_CU")) { const int v = atoi(t); if (v >= 1 && v < per_cu) per_cu = v; }  // measurement aid (see search_block_count)
 	return per_cu * prop.multiProcessorCount;
 }
 

@@ -323,7 +323,8 @@ int urmapx_ctx_phase_cycles(urmapx_ctx *C, uint64_t out[12]) {
 // launches summed, [2] its finalize launches summed, [3..5] the same for the second pass over the reads whose lists
 // outgrew the first, [6] the general kernel over what both passes left flagged (collect + search_se_slow_kernel).
 int urmapx_ctx_stage_ms(urmapx_ctx *C, float ms[7]) {
-	if (!C || !ms || !C->stage_valid) return URMAPX_E_ARG;
+	if (!C || !ms) return URMAPX_E_ARG;
+	if (!C->stage_valid) { for (int i = 0; i < 7; ++i) ms[i] = 0; return URMAPX_OK; }  // no stamps were taken
 	HIP_TRY(hipEventSynchronize(C->stage_ev[STAGE_EVENTS - 1]));
 	auto span = [&](int a, int b, float &out) -> hipError_t { float t = 0; hipError_t e = hipEventElapsedTime(&t, C->stage_ev[a], C->stage_ev[b]); out += t; return e; };
 	for (int i = 0; i < 7; ++i) ms[i] = 0;
@@ -454,12 +455,15 @@ int urmapx_map_se_device(urmapx_ctx *C, const void *d_bases, const void *d_offs,
 			d.jobs_cap = jobs_cap[p]; d.fin_cap = fin_cap[p];
 		}
 	}
-	wk.stage_events = C->stage_ev;
+	// stage stamps: one event per launch group (urmapx_ctx_stage_ms); URMAPX_NO_STAGE_STAMPS=1 leaves them out (measurement
+	// of what the stamps themselves cost: DESIGN.md 5.0)
+	const bool stamps = getenv("URMAPX_NO_STAGE_STAMPS") == nullptr;
+	wk.stage_events = stamps ? C->stage_ev : nullptr;
 	HIP_TRY(hipMemsetAsync(d_path_used, 0, 4, C->stream));
 	// seed + probe run inside the search kernel (kernels.hip): ev[0]..ev[1] brackets nothing for a single-end batch
 	HIP_TRY(hipEventRecord(C->ev[0], C->stream));
 	HIP_TRY(hipEventRecord(C->ev[1], C->stream));
-	C->stage_valid = true;
+	C->stage_valid = stamps;
 	HIP_TRY(launch_search_se(C->X, C->params, (const uint8_t *)d_bases, (const uint64_t *)d_offs, n, max_read_len,
 	                         (urmapx_result *)d_results, (urmapx_path_op *)d_path_ops, (uint32_t *)d_path_used, wk, C->stream));
 	{  // reads outside the fast kernels' domain: the general kernel (it finds its work list on the device; usually empty)
@@ -472,7 +476,7 @@ int urmapx_map_se_device(urmapx_ctx *C, const void *d_bases, const void *d_offs,
 		                              (uint32_t)(pcap > 0xFFFFFFFFull ? 0xFFFFFFFFull : pcap), C->slowscratch.p, sblocks, C->slowlist.p + 1,
 		                              C->slowlist.p, C->stream));
 	}
-	HIP_TRY(hipEventRecord(C->stage_ev[STAGE_EVENTS - 1], C->stream));
+	if (stamps) HIP_TRY(hipEventRecord(C->stage_ev[STAGE_EVENTS - 1], C->stream));
 	HIP_TRY(hipEventRecord(C->ev[2], C->stream));
 	C->ev_valid = true;
 	return URMAPX_OK;
