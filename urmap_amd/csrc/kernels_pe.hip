@@ -54,7 +54,9 @@ struct Mate {
 	const urmapx_params *P;
 	const uint8_t *__restrict__ gseq;
 	const uint8_t *__restrict__ gblob;
-	int lane;
+	// `lane` is not a member: the objects of this struct live in private memory (the pairing loop picks a mate at run time), and
+	// a member is a scratch load wherever it is used; the work-item id is a register
+#define lane ((int)threadIdx.x)
 	// this mate
 	int QL, W, nwords;
 	uint8_t *sQ[2];  // LDS: [0] read as given, [1] reverse complement
@@ -738,6 +740,7 @@ struct Mate {
 		}
 	}
 };
+#undef lane
 
 // Waves per SIMD the register allocation aims at.  The pair kernel waits on memory 70 % of its wave cycles and issues
 // instructions in 40 % of its SIMD cycles at two waves per SIMD (profiles/r3/pmc_sq_pe.json): it is bound by latency, and
@@ -805,7 +808,7 @@ __global__ __launch_bounds__(64, TIER == 2 ? 1 : URX_PE_WAVES(NCH)) void search_
 	uint8_t *sc = scratch + (size_t)blockIdx.x * scratch_stride;
 	M m[2];
 	for (int a = 0; a < 2; ++a) {
-		m[a].X = &X; m[a].P = &P; m[a].gseq = g_seq; m[a].gblob = g_blob; m[a].lane = lane; m[a].W = W;
+		m[a].X = &X; m[a].P = &P; m[a].gseq = g_seq; m[a].gblob = g_blob; m[a].W = W;
 		m[a].sQ[0] = sQ[2 * a]; m[a].sQ[1] = sQ[2 * a + 1];
 		m[a].qpl[0] = qpl[2 * a]; m[a].qpl[1] = qpl[2 * a + 1]; m[a].gseqp = g_seqp; m[a].q_other = false;
 		m[a].sT = sT; m[a].tb = reinterpret_cast<uint32_t *>(sc + pe_tb_offset(QMAX)); m[a].wide_lds = wide_lds; m[a].wide_lds_dwords = WIDE_LDS_DWORDS;
