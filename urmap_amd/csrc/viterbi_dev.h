@@ -105,8 +105,13 @@ __device__ __forceinline__ float viterbi_wave(const VPar P, const uint8_t *A, in
 	if (ND + 2 > 64 || LB - dlo + 2 > 63 || ((LA + 1 + 7) >> 3) > tb_rows8) {
 		// the wide path keeps three per-row arrays in LDS: the narrow path's trace buffer (idle here) unless the caller
 		// holds that in global memory and names another LDS area
-		if (LA <= ws.la_cap && LB <= ws.lb_cap)
-			return viterbi_wide(P, A, LA, B, LB, Left, Right, ws, wide_lds ? wide_lds : tb, wide_lds ? wide_lds_dwords : tb_rows8 * 64, R, status, lane);
+		if (LA <= ws.la_cap && LB <= ws.lb_cap) {
+			// the count, not the pointer, says whether there is an LDS area, and the two kinds of row storage are never one
+			// pointer variable: a generic pointer that is LDS on one path and global on the other (or its null test) trips the
+			// gfx950 backend once the LDS address is a known constant ("Illegal instruction ... src_shared_base")
+			if (wide_lds_dwords > 0) return viterbi_wide(P, A, LA, B, LB, Left, Right, ws, wide_lds, wide_lds_dwords, R, status, lane);
+			return viterbi_wide(P, A, LA, B, LB, Left, Right, ws, tb, tb_rows8 * 64, R, status, lane);
+		}
 		status |= URMAPX_ST_BAND_TOO_WIDE;
 		return 0.0f;
 	}
