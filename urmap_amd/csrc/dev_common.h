@@ -426,6 +426,12 @@ __device__ __forceinline__ uint32_t lds_addr(const T *p) {  // the LDS aperture 
 // 16 zero bytes: what lanes without a k-mer gather instead of a slot (tally 0 = TALLY_FREE)
 static __device__ uint32_t g_zero16[4];
 
+// An LDS array named by an LDS pointer: 32 bit, accessed with ds_* instructions.  (A plain pointer that the compiler cannot
+// trace back to its LDS array -- one loaded from memory -- is a 64-bit generic pointer and every access a flat_* instruction.)
+template <class T> using lds_ptr = __attribute__((address_space(3))) T *;
+template <class T> __device__ __forceinline__ lds_ptr<T> to_lds(T *p) { return (lds_ptr<T>)p; }
+template <class T> __device__ __forceinline__ T *from_lds(lds_ptr<T> p) { return (T *)p; }
+
 // A wave-uniform int the optimiser must treat as new from here on.  The search kernels derive dozens of lane masks
 // and conditions from a read's length; LLVM hoists them all to the top of the read (they are loop invariant), where they
 // outnumber the 102 SGPRs of a wave several times over, get spilled into VGPR lanes and come back through v_readlane +

@@ -81,7 +81,7 @@ struct Mate {
 	uint32_t hit_db[HITW];
 	uint32_t hit_sp[HITW];  // score << 1 | plus
 	int hit_cap;            // first pass: PE_HIT_CAP (a test aid lowers it)
-	uint16_t *hit_nops;   // LDS [PE_HIT_CAP * HITW]
+	lds_ptr<uint16_t> hit_nops;   // LDS [PE_HIT_CAP * HITW]
 	urmapx_path_op *hit_paths;  // global [PE_HIT_CAP * HITW][URMAPX_MAX_PATH_OPS]
 	// hits per word: 64 (2^6); lowered to 16 in the second pass by the test aid that lowers the first pass's caps, so that
 	// a fixture with a few dozen hits per mate runs through several words
@@ -104,16 +104,18 @@ struct Mate {
 			if ((i >> wsh()) == w) v = rdlane(hit_sp[w], l);
 		return v;
 	}
-	uint32_t *hsp_db, *hsp_ql;  // LDS [PE_HSP_CAP]
-	uint16_t *hsp_sf;
+	// LDS arrays are named by LDS pointers (32 bit, `ds_*` instructions): a generic pointer loaded from this struct (which lives
+	// in private memory) is 64 bit and every access through it a `flat_*` instruction
+	lds_ptr<uint32_t> hsp_db, hsp_ql;  // LDS [PE_HSP_CAP]
+	lds_ptr<uint16_t> hsp_sf;
 	uint2 *hsp_ovf;   // HSPs hsp_lds.. in global scratch as {db, startq | len << 9 | sf << 18}
 	int dbg_cut = 0;  // diagnostic only (URMAPX_DEBUG_STOP_PE 41 / 42 / 43): leave search_pending after that part
 	int hsp_lds;      // HSPs kept in LDS (PE_HSP_CAP; a test aid lowers it)
-	uint8_t *pend[2];     // LDS [QMAX] each: pending query positions (stored in a byte, state1.h:86-87)
-	uint8_t *rowlen;      // LDS [2 * QMAX]: row length of every pending position, [strand][i]
-	uint16_t *pre;        // LDS [65]
-	uint32_t *cq_db;      // LDS [128]: candidate queue of the pending stage (ring)
-	uint16_t *cq_qp;      // LDS [128]
+	lds_ptr<uint8_t> pend[2];     // LDS [QMAX] each: pending query positions (stored in a byte, state1.h:86-87)
+	lds_ptr<uint8_t> rowlen;      // LDS [2 * QMAX]: row length of every pending position, [strand][i]
+	lds_ptr<uint16_t> pre;        // LDS [65]
+	lds_ptr<uint32_t> cq_db;      // LDS [128]: candidate queue of the pending stage (ring)
+	lds_ptr<uint16_t> cq_qp;      // LDS [128]
 	uint32_t *rowstore;   // global, this block: [strand][chunk][k][lane]
 	int pendCount[2];
 	int hitCount, hspCount, topHit;
@@ -813,16 +815,16 @@ __global__ __launch_bounds__(64, TIER == 2 ? 1 : URX_PE_WAVES(NCH)) void search_
 		m[a].qpl[0] = qpl[2 * a]; m[a].qpl[1] = qpl[2 * a + 1]; m[a].gseqp = g_seqp; m[a].q_other = false;
 		m[a].sT = sT; m[a].tb = reinterpret_cast<uint32_t *>(sc + pe_tb_offset(QMAX)); m[a].wide_lds = wide_lds; m[a].wide_lds_dwords = WIDE_LDS_DWORDS;
 		m[a].ropsL = ropsL; m[a].ropsR = ropsR; m[a].cand = cand;
-		m[a].hit_nops = hit_nops[a];
+		m[a].hit_nops = to_lds(&hit_nops[a][0]);
 		m[a].hit_paths = OVF ? reinterpret_cast<urmapx_path_op *>(hsp_ovf_base + (size_t)hsp_area_blocks * 2 * PE_HSP_OVF_CAP) +
 		                           (TIER == 2 ? (size_t)PE_OVF_BLOCKS * 2 * PE_HIT_CAP * 4 * URMAPX_MAX_PATH_OPS : (size_t)0) +
 		                           ((size_t)blockIdx.x * 2 + a) * PE_HIT_CAP * M::HITW * URMAPX_MAX_PATH_OPS
 		                     : reinterpret_cast<urmapx_path_op *>(sc) + (size_t)a * PE_HIT_CAP * PE_HITW1 * URMAPX_MAX_PATH_OPS;
 		m[a].hit_cap = (hsp_lds_cap >= 64 && hsp_lds_cap <= PE_HSP_CAP) ? (hsp_lds_cap & ~63) / 4 : PE_HIT_CAP * PE_HITW1;
 		m[a].hit_wsh = (hsp_lds_cap >= 64 && hsp_lds_cap <= PE_HSP_CAP) ? 4 : 6;
-		m[a].hsp_db = hsp_db[a]; m[a].hsp_ql = hsp_ql[a]; m[a].hsp_sf = hsp_sf[a];
-		m[a].pend[0] = pend[2 * a]; m[a].pend[1] = pend[2 * a + 1];
-		m[a].rowlen = rowlen; m[a].pre = pre; m[a].cq_db = cq_db; m[a].cq_qp = cq_qp;
+		m[a].hsp_db = to_lds(&hsp_db[a][0]); m[a].hsp_ql = to_lds(&hsp_ql[a][0]); m[a].hsp_sf = to_lds(&hsp_sf[a][0]);
+		m[a].pend[0] = to_lds(&pend[2 * a][0]); m[a].pend[1] = to_lds(&pend[2 * a + 1][0]);
+		m[a].rowlen = to_lds(rowlen); m[a].pre = to_lds(pre); m[a].cq_db = to_lds(cq_db); m[a].cq_qp = to_lds(cq_qp);
 		m[a].hsp_lds = (hsp_lds_cap >= 64 && hsp_lds_cap <= PE_HSP_CAP) ? (hsp_lds_cap & ~63) : PE_HSP_CAP;
 		m[a].hsp_ovf = hsp_ovf_base + ((size_t)blockIdx.x * 2 + a) * PE_HSP_OVF_CAP;
 		m[a].dbg_cut = dbg_stop;
