@@ -59,8 +59,8 @@ struct Mate {
 #define lane ((int)threadIdx.x)
 	// this mate
 	int QL, W, nwords;
-	uint8_t *sQ[2];  // LDS: [0] read as given, [1] reverse complement
-	const uint4 *qpl[2];  // LDS: the two strands as bit planes of 4-bit codes (dev_common.h: seq_code), one uint4 per 32 bases
+	lds_ptr<uint8_t> sQ[2];  // LDS: [0] read as given, [1] reverse complement
+	lds_ptr<const uint4> qpl[2];  // LDS: the two strands as bit planes of 4-bit codes (dev_common.h: seq_code), one uint4 per 32 bases
 	const uint4 *__restrict__ gseqp;  // packed copy of the sequence store
 	bool q_other;         // the read holds a byte outside the code list: its windows are compared as ASCII
 	uint32_t qch[2][NCH];
@@ -68,11 +68,11 @@ struct Mate {
 	const uint8_t *ptal;
 	const uint32_t *ppos;
 	// shared LDS scratch (one set per wave)
-	uint8_t *sT;
+	lds_ptr<uint8_t> sT;
 	uint32_t *tb;         // trace cells of the banded DP: this block's global scratch
-	uint32_t *wide_lds;   // LDS rows of the wide-band DP (the rescue's whole-read Viterbi)
+	lds_ptr<uint32_t> wide_lds;   // LDS rows of the wide-band DP (the rescue's whole-read Viterbi)
 	int wide_lds_dwords;
-	uint16_t *ropsL, *ropsR, *cand;
+	lds_ptr<uint16_t> ropsL, ropsR, cand;
 	WideScratch ws;
 	// lists
 	// hits: entry k lives on lane k & 63 of word k >> 6 (one word = 64 hits in the first-pass kernel, HITW words in the
@@ -244,8 +244,8 @@ struct Mate {
 	// mismatch bit vector of the whole read against the window at dblo, one candidate per lane: packed planes, or ASCII for
 	// a read with bytes outside the code list (wave-uniform choice)
 	__device__ __forceinline__ void lane_mask(uint32_t dblo, bool plus, uint64_t (&mm)[NCH]) const {
-		if (q_other) lane_mismatch_mask<NCH>(gseq, dblo, plus ? sQ[0] : sQ[1], QL, mm);
-		else lane_mismatch_planes<NCH>(gseqp, dblo, plus ? qpl[0] : qpl[1], QL, mm);
+		if (q_other) lane_mismatch_mask<NCH>(gseq, dblo, from_lds(plus ? sQ[0] : sQ[1]), QL, mm);
+		else lane_mismatch_planes<NCH>(gseqp, dblo, from_lds(plus ? qpl[0] : qpl[1]), QL, mm);
 	}
 
 	// The two x-drop walks shared by ExtendPen (extendpen.cpp:25-78) and ExtendScan (extendscan.cpp:77-133).
@@ -355,9 +355,9 @@ struct Mate {
 		const int BR = 2 * (int)P->band_radius;
 		const uint32_t TL = X->seqDataSize;
 		uint32_t combinedTLo = startdb;
-		const uint8_t *Q = plus ? sQ[0] : sQ[1];
+		const uint8_t *Q = from_lds(plus ? sQ[0] : sQ[1]);
 		RevOps RL, RR;
-		RL.ops = ropsL; RR.ops = ropsR;
+		RL.ops = from_lds(ropsL); RR.ops = from_lds(ropsR);
 		RL.begin(); RR.begin();
 		int rtrim = 0;
 		uint32_t vst = 0;
@@ -374,8 +374,8 @@ struct Mate {
 			const int allGapL = P->gap_open_score + (leftQL - 1) * P->gap_ext_score;
 			const int needL = leftQL - (maxPen - totalPen);
 			bool abortedL = false;
-			int leftScore = (int)viterbi_wave<true>(VPar(*P), Q, leftQL, sT, (int)leftTL, true, false, tb, TB_ROWS8, ws, RL, vst, lane,
-			                                        (float)needL, allGapL < needL ? &abortedL : nullptr, wide_lds, wide_lds_dwords);
+			int leftScore = (int)viterbi_wave<true>(VPar(*P), Q, leftQL, from_lds(sT), (int)leftTL, true, false, tb, TB_ROWS8, ws, RL, vst, lane,
+			                                        (float)needL, allGapL < needL ? &abortedL : nullptr, from_lds(wide_lds), wide_lds_dwords);
 			if (abortedL) return -1;
 			status |= vst;
 			int nTrimI = 0;
@@ -401,8 +401,8 @@ struct Mate {
 			const int allGapR = P->gap_open_score + (rightQL - 1) * P->gap_ext_score;
 			const int needR = rightQL - (maxPen - totalPen);
 			bool abortedR = false;
-			int rightScore = (int)viterbi_wave<true>(VPar(*P), Q + rightQLo, rightQL, sT, (int)rightTL, false, true, tb, TB_ROWS8, ws, RR, vst, lane,
-			                                         (float)needR, allGapR < needR ? &abortedR : nullptr, wide_lds, wide_lds_dwords);
+			int rightScore = (int)viterbi_wave<true>(VPar(*P), Q + rightQLo, rightQL, from_lds(sT), (int)rightTL, false, true, tb, TB_ROWS8, ws, RR, vst, lane,
+			                                         (float)needR, allGapR < needR ? &abortedR : nullptr, from_lds(wide_lds), wide_lds_dwords);
 			if (abortedR) return -1;
 			status |= vst;
 			if (RR.n > 1 && (ropsR[0] & 3u) == OP_I) rtrim = 1;
@@ -722,11 +722,11 @@ struct Mate {
 		if (hitCount > savedHits) return;
 		if (!dovit) return;
 		RevOps R;
-		R.ops = ropsL;
+		R.ops = from_lds(ropsL);
 		uint32_t vst = 0;
 		// whole read against the window: a band far wider than a wavefront -> wide path (B read from global memory)
-		const float score = viterbi_wave(VPar(*P), plus ? sQ[0] : sQ[1], QL, gseq + dbpos, (int)seglen, true, true, tb, TB_ROWS8, ws, R, vst, lane,
-		                                 -3.0e38f, nullptr, wide_lds, wide_lds_dwords);
+		const float score = viterbi_wave(VPar(*P), from_lds(plus ? sQ[0] : sQ[1]), QL, gseq + dbpos, (int)seglen, true, true, tb, TB_ROWS8, ws, R, vst, lane,
+		                                 -3.0e38f, nullptr, from_lds(wide_lds), wide_lds_dwords);
 		status |= vst;
 		if (vst) return;
 		if ((double)score >= (double)QL / 3.0) {
@@ -811,10 +811,10 @@ __global__ __launch_bounds__(64, TIER == 2 ? 1 : URX_PE_WAVES(NCH)) void search_
 	M m[2];
 	for (int a = 0; a < 2; ++a) {
 		m[a].X = &X; m[a].P = &P; m[a].gseq = g_seq; m[a].gblob = g_blob; m[a].W = W;
-		m[a].sQ[0] = sQ[2 * a]; m[a].sQ[1] = sQ[2 * a + 1];
-		m[a].qpl[0] = qpl[2 * a]; m[a].qpl[1] = qpl[2 * a + 1]; m[a].gseqp = g_seqp; m[a].q_other = false;
-		m[a].sT = sT; m[a].tb = reinterpret_cast<uint32_t *>(sc + pe_tb_offset(QMAX)); m[a].wide_lds = wide_lds; m[a].wide_lds_dwords = WIDE_LDS_DWORDS;
-		m[a].ropsL = ropsL; m[a].ropsR = ropsR; m[a].cand = cand;
+		m[a].sQ[0] = to_lds(&sQ[2 * a][0]); m[a].sQ[1] = to_lds(&sQ[2 * a + 1][0]);
+		m[a].qpl[0] = to_lds((const uint4 *)&qpl[2 * a][0]); m[a].qpl[1] = to_lds((const uint4 *)&qpl[2 * a + 1][0]); m[a].gseqp = g_seqp; m[a].q_other = false;
+		m[a].sT = to_lds(sT); m[a].tb = reinterpret_cast<uint32_t *>(sc + pe_tb_offset(QMAX)); m[a].wide_lds = to_lds(wide_lds); m[a].wide_lds_dwords = WIDE_LDS_DWORDS;
+		m[a].ropsL = to_lds(ropsL); m[a].ropsR = to_lds(ropsR); m[a].cand = to_lds(cand);
 		m[a].hit_nops = to_lds(&hit_nops[a][0]);
 		m[a].hit_paths = OVF ? reinterpret_cast<urmapx_path_op *>(hsp_ovf_base + (size_t)hsp_area_blocks * 2 * PE_HSP_OVF_CAP) +
 		                           (TIER == 2 ? (size_t)PE_OVF_BLOCKS * 2 * PE_HIT_CAP * 4 * URMAPX_MAX_PATH_OPS : (size_t)0) +
