@@ -44,6 +44,17 @@ __host__ __device__ inline size_t pe_tb_offset(int qmax);
 // hits per mate: the reference's list has no bound, state1.cpp:193-228; this pass exists so that a pair in a satellite
 // is mapped, not flagged -- it runs a handful of pairs per run and is not tuned)
 static constexpr int PE_HITW2 = 16;
+// The wave-uniform state of a mate that changes as the pair is searched.  It lives in LDS, not in the Mate object: the Mate
+// objects are in private memory (the pairing loop picks a mate at run time), where every access is a scratch load or
+// store -- a memory round trip for a counter.  Through `hot` it is a ds_read / ds_write (all lanes, same address).
+struct MateHot {
+	int QL, nwords;
+	int pendCount[2];
+	int hitCount, hspCount, topHit;
+	int maxPen, best, second, bestHSP;
+	uint32_t mapq;
+	uint32_t status;
+};
 template <int NCH, int TIER>
 struct Mate {
 	static constexpr bool OVF = TIER > 0;
@@ -58,7 +69,20 @@ struct Mate {
 	// a member is a scratch load wherever it is used; the work-item id is a register
 #define lane ((int)threadIdx.x)
 	// this mate
-	int QL, W, nwords;
+	int W;
+	lds_ptr<MateHot> hot;
+#define QL (hot->QL)
+#define nwords (hot->nwords)
+#define pendCount (hot->pendCount)
+#define hitCount (hot->hitCount)
+#define hspCount (hot->hspCount)
+#define topHit (hot->topHit)
+#define maxPen (hot->maxPen)
+#define best (hot->best)
+#define second (hot->second)
+#define bestHSP (hot->bestHSP)
+#define mapq (hot->mapq)
+#define status (hot->status)
 	lds_ptr<uint8_t> sQ[2];  // LDS: [0] read as given, [1] reverse complement
 	lds_ptr<const uint4> qpl[2];  // LDS: the two strands as bit planes of 4-bit codes (dev_common.h: seq_code), one uint4 per 32 bases
 	const uint4 *__restrict__ gseqp;  // packed copy of the sequence store
@@ -81,7 +105,7 @@ struct Mate {
 	uint32_t hit_db[HITW];
 	uint32_t hit_sp[HITW];  // score << 1 | plus
 	int hit_cap;            // first pass: PE_HIT_CAP (a test aid lowers it)
-	lds_ptr<uint16_t> hit_nops;   // LDS [PE_HIT_CAP * HITW]
+	lds_ptr<uint8_t> hit_nops;   // LDS [PE_HIT_CAP * HITW]: runs of a hit's path (<= URMAPX_MAX_PATH_OPS = 96)
 	urmapx_path_op *hit_paths;  // global [PE_HIT_CAP * HITW][URMAPX_MAX_PATH_OPS]
 	// hits per word: 64 (2^6); lowered to 16 in the second pass by the test aid that lowers the first pass's caps, so that
 	// a fixture with a few dozen hits per mate runs through several words
@@ -117,11 +141,6 @@ struct Mate {
 	lds_ptr<uint32_t> cq_db;      // LDS [128]: candidate queue of the pending stage (ring)
 	lds_ptr<uint16_t> cq_qp;      // LDS [128]
 	uint32_t *rowstore;   // global, this block: [strand][chunk][k][lane]
-	int pendCount[2];
-	int hitCount, hspCount, topHit;
-	int maxPen, best, second, bestHSP;
-	uint32_t mapq;
-	uint32_t status;
 
 	__device__ __forceinline__ bool overlaps_hit(uint32_t db) const {
 		bool eq = false;
@@ -158,7 +177,7 @@ struct Mate {
 #pragma unroll
 		for (int w = 0; w < HITW; ++w)
 			if (lane < wl() && (w << wsh()) + lane == idx) { hit_db[w] = db; hit_sp[w] = ((uint32_t)score << 1) | (plus ? 1u : 0u); }
-		if (lane == 0) hit_nops[idx] = (uint16_t)cand_nops;
+		if (lane == 0) hit_nops[idx] = (uint8_t)cand_nops;
 		for (int t = lane; t < cand_nops; t += 64) hit_paths[(size_t)idx * URMAPX_MAX_PATH_OPS + t] = cand[t];
 		URX_SYNC();
 		++hitCount;
@@ -743,6 +762,18 @@ struct Mate {
 	}
 };
 #undef lane
+#undef QL
+#undef nwords
+#undef pendCount
+#undef hitCount
+#undef hspCount
+#undef topHit
+#undef maxPen
+#undef best
+#undef second
+#undef bestHSP
+#undef mapq
+#undef status
 
 // Waves per SIMD the register allocation aims at.  The pair kernel waits on memory 70 % of its wave cycles and issues
 // instructions in 40 % of its SIMD cycles at two waves per SIMD (profiles/r3/pmc_sq_pe.json): it is bound by latency, and
@@ -772,7 +803,9 @@ __global__ __launch_bounds__(64, TIER == 2 ? 1 : URX_PE_WAVES(NCH)) void search_
 	//   the pending stage's candidate queue                                 on  seed_db
 	__shared__ __attribute__((aligned(16))) uint8_t sQ[4][QMAX];
 	__shared__ __attribute__((aligned(16))) uint4 qpl[4][2 * NCH];  // [mate * 2 + strand][block of 32 bases]
-	__shared__ uint16_t hit_nops[2][PE_HIT_CAP * M::HITW];
+	static_assert(URMAPX_MAX_PATH_OPS <= 255, "hit_nops is a byte");
+	__shared__ uint8_t hit_nops[2][PE_HIT_CAP * M::HITW];
+	__shared__ MateHot hot[2];
 	__shared__ uint32_t hsp_db[2][PE_HSP_CAP], hsp_ql[2][PE_HSP_CAP];
 	__shared__ uint16_t hsp_sf[2][PE_HSP_CAP];
 	__shared__ uint8_t pend[4][QMAX];
@@ -815,7 +848,7 @@ __global__ __launch_bounds__(64, TIER == 2 ? 1 : URX_PE_WAVES(NCH)) void search_
 		m[a].qpl[0] = to_lds((const uint4 *)&qpl[2 * a][0]); m[a].qpl[1] = to_lds((const uint4 *)&qpl[2 * a + 1][0]); m[a].gseqp = g_seqp; m[a].q_other = false;
 		m[a].sT = to_lds(sT); m[a].tb = reinterpret_cast<uint32_t *>(sc + pe_tb_offset(QMAX)); m[a].wide_lds = to_lds(wide_lds); m[a].wide_lds_dwords = WIDE_LDS_DWORDS;
 		m[a].ropsL = to_lds(ropsL); m[a].ropsR = to_lds(ropsR); m[a].cand = to_lds(cand);
-		m[a].hit_nops = to_lds(&hit_nops[a][0]);
+		m[a].hit_nops = to_lds(&hit_nops[a][0]); m[a].hot = to_lds(&hot[a]);
 		m[a].hit_paths = OVF ? reinterpret_cast<urmapx_path_op *>(hsp_ovf_base + (size_t)hsp_area_blocks * 2 * PE_HSP_OVF_CAP) +
 		                           (TIER == 2 ? (size_t)PE_OVF_BLOCKS * 2 * PE_HIT_CAP * 4 * URMAPX_MAX_PATH_OPS : (size_t)0) +
 		                           ((size_t)blockIdx.x * 2 + a) * PE_HIT_CAP * M::HITW * URMAPX_MAX_PATH_OPS
@@ -855,7 +888,7 @@ __global__ __launch_bounds__(64, TIER == 2 ? 1 : URX_PE_WAVES(NCH)) void search_
 			res[a].score = 0; res[a].second = 0; res[a].mapq = 0; res[a].plus = 0; res[a].exit_phase = 0; res[a].status = 0;
 			res[a].hit_count = 0; res[a].path_nops = 0; res[a].path_off = 0;
 			if (QL < W || QL > QMAX || W > 32 || X.maxIx > 32 || QL - (W - 1) > 256) bad = true;  // pending positions are bytes
-			m[a].QL = QL; m[a].nwords = QL - (W - 1);
+			hot[a].QL = QL; hot[a].nwords = QL - (W - 1);
 			m[a].pslots = probe.slots + 2 * off; m[a].ptal = probe.tallies + 2 * off; m[a].ppos = probe.positions + 2 * off;
 		}
 		if (bad) {
@@ -868,13 +901,13 @@ __global__ __launch_bounds__(64, TIER == 2 ? 1 : URX_PE_WAVES(NCH)) void search_
 		lds_sync();
 		if constexpr (!OVF) {
 			const uint64_t poff[2] = {offs[2 * pr], offs[2 * pr + 1]};
-			const uint32_t pql[2] = {(uint32_t)m[0].QL, (uint32_t)m[1].QL};
+			const uint32_t pql[2] = {(uint32_t)hot[0].QL, (uint32_t)hot[1].QL};
 			probe_pair<NCH, QMAX>(X, bases, poff, pql, lane, probe, s_tal, s_pos);
 		}
 		// ---- InitPE x2 (state1.cpp:95-127) ----
 		for (int a = 0; a < 2; ++a) {
 			const uint8_t *q = bases + offs[2 * pr + a];
-			const int QL = m[a].QL;
+			const int QL = hot[a].QL;
 #pragma unroll
 			for (int c = 0; c < NCH; ++c) {
 				const int p = 64 * c + lane;
@@ -892,7 +925,7 @@ __global__ __launch_bounds__(64, TIER == 2 ? 1 : URX_PE_WAVES(NCH)) void search_
 					for (int c = 0; c < NCH; ++c) {
 						const int p = 64 * c + lane;
 						if (p < QL) {
-							const bool in = p < m[a].nwords;
+							const bool in = p < hot[a].nwords;
 							s_tal[a][st][p] = in ? m[a].ptal[(size_t)st * QL + p] : (uint8_t)0;
 							s_pos[a][st][p] = in ? m[a].ppos[(size_t)st * QL + p] : 0xFFFFFFFFu;
 						}
@@ -901,10 +934,10 @@ __global__ __launch_bounds__(64, TIER == 2 ? 1 : URX_PE_WAVES(NCH)) void search_
 			}
 #pragma unroll
 			for (int w = 0; w < M::HITW; ++w) { m[a].hit_db[w] = 0; m[a].hit_sp[w] = 0; }
-			m[a].pendCount[0] = m[a].pendCount[1] = 0;
-			m[a].hitCount = 0; m[a].hspCount = 0; m[a].topHit = -1;
-			m[a].maxPen = P.max_penalty; m[a].best = 0; m[a].second = 0; m[a].bestHSP = 0;
-			m[a].mapq = 0xFFFFFFFFu; m[a].status = 0;
+			hot[a].pendCount[0] = hot[a].pendCount[1] = 0;
+			hot[a].hitCount = 0; hot[a].hspCount = 0; hot[a].topHit = -1;
+			hot[a].maxPen = P.max_penalty; hot[a].best = 0; hot[a].second = 0; hot[a].bestHSP = 0;
+			hot[a].mapq = 0xFFFFFFFFu; hot[a].status = 0;
 		}
 		lds_sync();
 		// both strands of both mates as bit planes (ExtendPen's windows are read from the packed sequence store)
@@ -914,9 +947,9 @@ __global__ __launch_bounds__(64, TIER == 2 ? 1 : URX_PE_WAVES(NCH)) void search_
 			for (int st = 0; st < 2; ++st) {
 #pragma unroll
 				for (int c = 0; c < NCH; ++c) {
-					if (64 * c < m[a].QL) {
+					if (64 * c < hot[a].QL) {
 						const int p = 64 * c + lane;
-						const uint32_t code = p < m[a].QL ? seq_code(m[a].qch[st][c], SEQ_CODE_QOTHER) : 0u;
+						const uint32_t code = p < hot[a].QL ? seq_code(m[a].qch[st][c], SEQ_CODE_QOTHER) : 0u;
 						const uint64_t b0 = __ballot(code & 1u), b1 = __ballot(code & 2u), b2 = __ballot(code & 4u), b3 = __ballot(code & 8u);
 						oth |= __ballot(code == SEQ_CODE_QOTHER);
 						if (lane < 2) {
@@ -938,7 +971,7 @@ __global__ __launch_bounds__(64, TIER == 2 ? 1 : URX_PE_WAVES(NCH)) void search_
 		// the last seed returned" (getseed.cpp:60-66,118-124), and because a skipped seed has that very diagonal, it is
 		// the same as "skip a seed on the diagonal of the previous BOTH1 candidate": a neighbour comparison.
 		for (int a = 0; a < 2; ++a) {
-			const int QWC = m[a].nwords;
+			const int QWC = hot[a].nwords;
 			int ns = 0, np = 0, nm = 0;
 			bool have = false;
 			uint32_t lastDiag = 0;
@@ -984,15 +1017,15 @@ __global__ __launch_bounds__(64, TIER == 2 ? 1 : URX_PE_WAVES(NCH)) void search_
 					lastDiag = (uint32_t)__shfl((int)lastHere, 63 - __builtin_clzll(anyc));
 				}
 			}
-			if (ns > SEED_CAP) { ns = SEED_CAP; m[a].status |= URMAPX_ST_HSP_OVERFLOW; }
+			if (ns > SEED_CAP) { ns = SEED_CAP; hot[a].status |= URMAPX_ST_HSP_OVERFLOW; }
 			nseed[a] = ns;
-			m[a].pendCount[0] = np; m[a].pendCount[1] = nm;
+			hot[a].pendCount[0] = np; hot[a].pendCount[1] = nm;
 		}
 		URX_SYNC();
 
 		// ---- seed gather: the ExtendPen outcome of every seed, one seed per lane ----
 		for (int a = 0; a < 2; ++a) {
-			const int QL = m[a].QL;
+			const int QL = hot[a].QL;
 			const int minhsp = (int)((uint32_t)P.min_hsp_score_pct * (uint32_t)QL / 100.0);
 			for (int base = 0; base < nseed[a]; base += 64) {
 				const int i = base + lane;
@@ -1048,13 +1081,13 @@ __global__ __launch_bounds__(64, TIER == 2 ? 1 : URX_PE_WAVES(NCH)) void search_
 				const uint32_t pn = seed_pen[a][i], res = seed_res[a][i];
 				const uint32_t q = seed_q[a][i] & 0x7FFFu, db = seed_db[a][i];
 				if ((pn & 0x8000u) && ((seed_q[a][i] & 0x8000u) != 0) == plus_req)
-					st = db < q || (res >> 27) != 1u || (int)(pn & 0x7FFFu) > m[a].maxPen || m[a].overlaps_any_hit(db - q);
+					st = db < q || (res >> 27) != 1u || (int)(pn & 0x7FFFu) > hot[a].maxPen || m[a].overlaps_any_hit(db - q);
 			}
 			return __ballot(st);
 		};
 
 		// ---- Search4 pairing loop (search2m4.cpp:71-143) ----
-		const int QLf = m[0].QL, QLr = m[1].QL;
+		const int QLf = hot[0].QL, QLr = hot[1].QL;
 		const int64_t QL2 = (int64_t)((QLf + QLr) / 2);
 		const int termPair = QLf + QLr + 5 * P.mismatch_score;
 		bool done = false;
@@ -1090,7 +1123,7 @@ __global__ __launch_bounds__(64, TIER == 2 ? 1 : URX_PE_WAVES(NCH)) void search_
 							const int rs = extend_seed_as(1, i, !plusf);
 							if (rs <= 0) continue;
 							if (fs + rs < termPair) continue;
-							m[0].mapq = 40; m[1].mapq = 40; done = true;
+							hot[0].mapq = 40; hot[1].mapq = 40; done = true;
 						}
 					}
 				}
@@ -1111,7 +1144,7 @@ __global__ __launch_bounds__(64, TIER == 2 ? 1 : URX_PE_WAVES(NCH)) void search_
 							const int rs = extend_seed(1, t);
 							if (rs <= 0) continue;
 							if (fs + rs < termPair) continue;
-							m[0].mapq = 40; m[1].mapq = 40; done = true;
+							hot[0].mapq = 40; hot[1].mapq = 40; done = true;
 						}
 					}
 				}
@@ -1141,10 +1174,10 @@ __global__ __launch_bounds__(64, TIER == 2 ? 1 : URX_PE_WAVES(NCH)) void search_
 				m[0].search_pending();
 				m[1].search_pending();
 				done = true;
-			} else if (m[0].best >= (QLf * 9) / 10 && m[1].best >= (QLr * 9) / 10 && m[0].topHit >= 0 && m[1].topHit >= 0) {
-				int64_t d = (int64_t)m[0].hdb(m[0].topHit) - (int64_t)m[1].hdb(m[1].topHit);
+			} else if (hot[0].best >= (QLf * 9) / 10 && hot[1].best >= (QLr * 9) / 10 && hot[0].topHit >= 0 && hot[1].topHit >= 0) {
+				int64_t d = (int64_t)m[0].hdb(hot[0].topHit) - (int64_t)m[1].hdb(hot[1].topHit);
 				if (d < 0) d = -d;
-				if (d + QL2 <= MAX_TL) { m[0].mapq = 40; m[1].mapq = 40; done = true; }
+				if (d + QL2 <= MAX_TL) { hot[0].mapq = 40; hot[1].mapq = 40; done = true; }
 			}
 		}
 		if (dbg_stop == 3) done = true;
@@ -1156,15 +1189,15 @@ __global__ __launch_bounds__(64, TIER == 2 ? 1 : URX_PE_WAVES(NCH)) void search_
 			for (int attempt = 0; attempt < 2; ++attempt) {
 				npairs_found = 0; bestPairScore = -1; secondPairScore = -1; bestPairIndex = -1; secondPairIndex = -1;
 				bestF = bestR = secF = secR = -1;
-				for (int i = 0; i < m[0].hitCount; ++i) {
+				for (int i = 0; i < hot[0].hitCount; ++i) {
 					const uint32_t spf = m[0].hsp_of(i);
 					const int sf = (int)(spf >> 1);
-					if (sf < m[0].second - 12) continue;
+					if (sf < hot[0].second - 12) continue;
 					const int64_t dbf = (int64_t)m[0].hdb(i);
-					for (int j = 0; j < m[1].hitCount; ++j) {
+					for (int j = 0; j < hot[1].hitCount; ++j) {
 						const uint32_t spr = m[1].hsp_of(j);
 						const int sr = (int)(spr >> 1);
-						if (sr < m[1].second - 12) continue;
+						if (sr < hot[1].second - 12) continue;
 						int64_t d = dbf - (int64_t)m[1].hdb(j);
 						if (d < 0) d = -d;
 						if (d + QL2 > 1000) continue;
@@ -1181,25 +1214,25 @@ __global__ __launch_bounds__(64, TIER == 2 ? 1 : URX_PE_WAVES(NCH)) void search_
 				URX_SYNC();
 				if (npairs_found > 0 || attempt == 1) break;
 				// ScanPair
-				const bool dovitF = (int)m[0].mapq >= 10 && dbg_stop != 5, dovitR = (int)m[1].mapq >= 10 && dbg_stop != 5;  // 5: diagnostic, no rescue DP
-				const int hcf = m[0].hitCount, hcr = m[1].hitCount;
+				const bool dovitF = (int)hot[0].mapq >= 10 && dbg_stop != 5, dovitR = (int)hot[1].mapq >= 10 && dbg_stop != 5;  // 5: diagnostic, no rescue DP
+				const int hcf = hot[0].hitCount, hcr = hot[1].hitCount;
 				for (int i = 0; i < hcf; ++i) {
 					const uint32_t sp = m[0].hsp_of(i);
-					if ((int)(sp >> 1) < m[0].second) continue;
+					if ((int)(sp >> 1) < hot[0].second) continue;
 					const uint32_t db = m[0].hdb(i);
 					if (sp & 1u) m[1].scan(db, PE_SCAN_SEG, false, dovitF);
 					else if (db >= (uint32_t)PE_SCAN_SEG) m[1].scan(db - PE_SCAN_SEG, PE_SCAN_SEG + 2 * (uint32_t)QLf, true, dovitF);
 				}
 				for (int j = 0; j < hcr; ++j) {
 					const uint32_t sp = m[1].hsp_of(j);
-					if ((int)(sp >> 1) < m[1].second) continue;
+					if ((int)(sp >> 1) < hot[1].second) continue;
 					const uint32_t db = m[1].hdb(j);
 					if (sp & 1u) m[0].scan(db, PE_SCAN_SEG, false, dovitR);
 					else if (db >= (uint32_t)PE_SCAN_SEG) m[0].scan(db - PE_SCAN_SEG, PE_SCAN_SEG + 2 * (uint32_t)QLf, true, dovitR);
 				}
 			}
 			// AdjustTopHitsAndMapqs (search2.cpp:8-57)
-			if (npairs_found == 0) { m[0].mapq /= 2; m[1].mapq /= 2; }
+			if (npairs_found == 0) { hot[0].mapq /= 2; hot[1].mapq /= 2; }
 			else {
 				const double fract = (double)bestPairScore / (double)(QLf + QLr);
 				double drop = (double)(bestPairScore - secondPairScore);
@@ -1208,9 +1241,9 @@ __global__ __launch_bounds__(64, TIER == 2 ? 1 : URX_PE_WAVES(NCH)) void search_
 				x = x * fract;
 				uint32_t mq = (uint32_t)x;
 				if (mq > 40) mq = 40;
-				if (mq > m[0].mapq) m[0].mapq = mq;
-				if (mq > m[1].mapq) m[1].mapq = mq;
-				if (bestPairIndex >= 0) { m[0].topHit = bestF; m[1].topHit = bestR; }
+				if (mq > hot[0].mapq) hot[0].mapq = mq;
+				if (mq > hot[1].mapq) hot[1].mapq = mq;
+				if (bestPairIndex >= 0) { hot[0].topHit = bestF; hot[1].topHit = bestR; }
 				if (secondPairIndex >= 0) { secondHit[0] = secF; secondHit[1] = secR; }
 			}
 		}
@@ -1221,9 +1254,9 @@ __global__ __launch_bounds__(64, TIER == 2 ? 1 : URX_PE_WAVES(NCH)) void search_
 			for (int a = 0; a < 2; ++a) {
 				pi.top_db[a] = 0xFFFFFFFFu; pi.second_db[a] = 0xFFFFFFFFu;
 				pi.top_score[a] = 0; pi.second_score[a] = 0; pi.top_plus[a] = 0; pi.second_plus[a] = 0;
-				if (m[a].topHit >= 0) {
-					const uint32_t sp = m[a].hsp_of(m[a].topHit);
-					pi.top_db[a] = m[a].hdb(m[a].topHit); pi.top_score[a] = (int16_t)(sp >> 1); pi.top_plus[a] = (uint8_t)(sp & 1u);
+				if (hot[a].topHit >= 0) {
+					const uint32_t sp = m[a].hsp_of(hot[a].topHit);
+					pi.top_db[a] = m[a].hdb(hot[a].topHit); pi.top_score[a] = (int16_t)(sp >> 1); pi.top_plus[a] = (uint8_t)(sp & 1u);
 				}
 				if (secondHit[a] >= 0) {
 					const uint32_t sp = m[a].hsp_of(secondHit[a]);
@@ -1235,12 +1268,12 @@ __global__ __launch_bounds__(64, TIER == 2 ? 1 : URX_PE_WAVES(NCH)) void search_
 		// ---- per-mate output: SetMappedPos (state1.cpp:129-145) ----
 		for (int a = 0; a < 2; ++a) {
 			urmapx_result &R = res[a];
-			R.mapq = (uint8_t)(m[a].mapq > 255 ? 255 : m[a].mapq);
-			R.second = (int16_t)m[a].second; R.hit_count = (uint16_t)m[a].hitCount; R.status = (uint8_t)(m[a].status | m[1 - a].status);
+			R.mapq = (uint8_t)(hot[a].mapq > 255 ? 255 : hot[a].mapq);
+			R.second = (int16_t)hot[a].second; R.hit_count = (uint16_t)hot[a].hitCount; R.status = (uint8_t)(hot[a].status | hot[1 - a].status);
 			R.exit_phase = done ? 1 : 2;
-			if (m[a].topHit >= 0) {
-				const uint32_t db = m[a].hdb(m[a].topHit);
-				const uint32_t sp = m[a].hsp_of(m[a].topHit);
+			if (hot[a].topHit >= 0) {
+				const uint32_t db = m[a].hdb(hot[a].topHit);
+				const uint32_t sp = m[a].hsp_of(hot[a].topHit);
 				R.score = (int16_t)(sp >> 1);
 				uint32_t lo = 0, hi = X.seqCount - 1;
 				uint32_t found = 0xFFFFFFFFu, coord = 0xFFFFFFFFu, tl = 0;
@@ -1251,14 +1284,14 @@ __global__ __launch_bounds__(64, TIER == 2 ? 1 : URX_PE_WAVES(NCH)) void search_
 					if (db > o) lo = k + 1;
 					else hi = k - 1;
 				}
-				if (found != 0xFFFFFFFFu && coord + (uint32_t)m[a].QL <= tl) {
+				if (found != 0xFFFFFFFFu && coord + (uint32_t)hot[a].QL <= tl) {
 					R.dbpos = db; R.seq_index = found; R.coord = coord; R.plus = (uint8_t)(sp & 1u);
-					const int nops = m[a].hit_nops[m[a].topHit];
+					const int nops = m[a].hit_nops[hot[a].topHit];
 					if (nops > 0) {
 						uint32_t po = 0;
 						if (lane == 0) po = atomicAdd(path_used, (uint32_t)nops);
 						po = uni(po);
-						for (int t = lane; t < nops; t += 64) path_ops[po + t] = m[a].hit_paths[(size_t)m[a].topHit * URMAPX_MAX_PATH_OPS + t];
+						for (int t = lane; t < nops; t += 64) path_ops[po + t] = m[a].hit_paths[(size_t)hot[a].topHit * URMAPX_MAX_PATH_OPS + t];
 						R.path_off = po; R.path_nops = (uint16_t)nops;
 					}
 				}
@@ -1266,11 +1299,11 @@ __global__ __launch_bounds__(64, TIER == 2 ? 1 : URX_PE_WAVES(NCH)) void search_
 			if (lane == 0) results[2 * pr + a] = R;
 		}
 		if constexpr (TIER == 0) {
-			if ((m[0].status | m[1].status) & (URMAPX_ST_HSP_OVERFLOW | URMAPX_ST_HIT_OVERFLOW)) {  // queue the pair for the second pass
+			if ((hot[0].status | hot[1].status) & (URMAPX_ST_HSP_OVERFLOW | URMAPX_ST_HIT_OVERFLOW)) {  // queue the pair for the second pass
 				if (lane == 0) ovf_next[1 + atomicAdd(ovf_next, 1u)] = pr;
 			}
 		} else if constexpr (TIER == 1) {
-			if ((m[0].status | m[1].status) & URMAPX_ST_HIT_OVERFLOW) {  // more than 256 hits on a mate: the third pass
+			if ((hot[0].status | hot[1].status) & URMAPX_ST_HIT_OVERFLOW) {  // more than 256 hits on a mate: the third pass
 				if (lane == 0) ovf_next[1 + atomicAdd(ovf_next, 1u)] = pr;
 			}
 		}
