@@ -54,6 +54,9 @@ struct MateHot {
 	int maxPen, best, second, bestHSP;
 	uint32_t mapq;
 	uint32_t status;
+	// set once per kernel or per pair, read everywhere
+	int W, wide_lds_dwords, hit_cap, hit_wsh, hsp_lds, dbg_cut;
+	bool q_other;  // the read holds a byte outside the code list: its windows are compared as ASCII
 };
 template <int NCH, int TIER>
 struct Mate {
@@ -69,8 +72,14 @@ struct Mate {
 	// a member is a scratch load wherever it is used; the work-item id is a register
 #define lane ((int)threadIdx.x)
 	// this mate
-	int W;
 	lds_ptr<MateHot> hot;
+#define W (hot->W)
+#define wide_lds_dwords (hot->wide_lds_dwords)
+#define hit_cap (hot->hit_cap)
+#define hit_wsh (hot->hit_wsh)
+#define hsp_lds (hot->hsp_lds)
+#define dbg_cut (hot->dbg_cut)
+#define q_other (hot->q_other)
 #define QL (hot->QL)
 #define nwords (hot->nwords)
 #define pendCount (hot->pendCount)
@@ -86,7 +95,6 @@ struct Mate {
 	lds_ptr<uint8_t> sQ[2];  // LDS: [0] read as given, [1] reverse complement
 	lds_ptr<const uint4> qpl[2];  // LDS: the two strands as bit planes of 4-bit codes (dev_common.h: seq_code), one uint4 per 32 bases
 	const uint4 *__restrict__ gseqp;  // packed copy of the sequence store
-	bool q_other;         // the read holds a byte outside the code list: its windows are compared as ASCII
 	uint32_t qch[2][NCH];
 	const uint64_t *pslots;  // probe output of this read (global), index strand*QL + qpos
 	const uint8_t *ptal;
@@ -95,7 +103,6 @@ struct Mate {
 	lds_ptr<uint8_t> sT;
 	uint32_t *tb;         // trace cells of the banded DP: this block's global scratch
 	lds_ptr<uint32_t> wide_lds;   // LDS rows of the wide-band DP (the rescue's whole-read Viterbi)
-	int wide_lds_dwords;
 	lds_ptr<uint16_t> ropsL, ropsR, cand;
 	WideScratch ws;
 	// lists
@@ -104,12 +111,12 @@ struct Mate {
 	static constexpr int HITW = TIER == 0 ? PE_HITW1 : TIER == 1 ? 4 : PE_HITW2;
 	uint32_t hit_db[HITW];
 	uint32_t hit_sp[HITW];  // score << 1 | plus
-	int hit_cap;            // first pass: PE_HIT_CAP (a test aid lowers it)
+	// hit_cap (MateHot): first pass: PE_HIT_CAP (a test aid lowers it)
 	lds_ptr<uint8_t> hit_nops;   // LDS [PE_HIT_CAP * HITW]: runs of a hit's path (<= URMAPX_MAX_PATH_OPS = 96)
 	urmapx_path_op *hit_paths;  // global [PE_HIT_CAP * HITW][URMAPX_MAX_PATH_OPS]
 	// hits per word: 64 (2^6); lowered to 16 in the second pass by the test aid that lowers the first pass's caps, so that
 	// a fixture with a few dozen hits per mate runs through several words
-	int hit_wsh;
+	// hit_wsh (MateHot)
 	__device__ __forceinline__ int wsh() const { return OVF ? hit_wsh : 6; }
 	__device__ __forceinline__ int wl() const { return 1 << wsh(); }
 	__device__ __forceinline__ uint32_t hdb(int i) const {  // i wave-uniform
@@ -133,8 +140,8 @@ struct Mate {
 	lds_ptr<uint32_t> hsp_db, hsp_ql;  // LDS [PE_HSP_CAP]
 	lds_ptr<uint16_t> hsp_sf;
 	uint2 *hsp_ovf;   // HSPs hsp_lds.. in global scratch as {db, startq | len << 9 | sf << 18}
-	int dbg_cut = 0;  // diagnostic only (URMAPX_DEBUG_STOP_PE 41 / 42 / 43): leave search_pending after that part
-	int hsp_lds;      // HSPs kept in LDS (PE_HSP_CAP; a test aid lowers it)
+	// dbg_cut (MateHot): diagnostic only (URMAPX_DEBUG_STOP_PE 41 / 42 / 43): leave search_pending after that part
+	// hsp_lds (MateHot): HSPs kept in LDS (PE_HSP_CAP; a test aid lowers it)
 	lds_ptr<uint8_t> pend[2];     // LDS [QMAX] each: pending query positions (stored in a byte, state1.h:86-87)
 	lds_ptr<uint8_t> rowlen;      // LDS [2 * QMAX]: row length of every pending position, [strand][i]
 	lds_ptr<uint16_t> pre;        // LDS [65]
@@ -774,6 +781,13 @@ struct Mate {
 #undef bestHSP
 #undef mapq
 #undef status
+#undef W
+#undef wide_lds_dwords
+#undef hit_cap
+#undef hit_wsh
+#undef hsp_lds
+#undef dbg_cut
+#undef q_other
 
 // Waves per SIMD the register allocation aims at.  The pair kernel waits on memory 70 % of its wave cycles and issues
 // instructions in 40 % of its SIMD cycles at two waves per SIMD (profiles/r3/pmc_sq_pe.json): it is bound by latency, and
@@ -843,24 +857,24 @@ __global__ __launch_bounds__(64, TIER == 2 ? 1 : URX_PE_WAVES(NCH)) void search_
 	uint8_t *sc = scratch + (size_t)blockIdx.x * scratch_stride;
 	M m[2];
 	for (int a = 0; a < 2; ++a) {
-		m[a].X = &X; m[a].P = &P; m[a].gseq = g_seq; m[a].gblob = g_blob; m[a].W = W;
+		m[a].X = &X; m[a].P = &P; m[a].gseq = g_seq; m[a].gblob = g_blob; hot[a].W = W;
 		m[a].sQ[0] = to_lds(&sQ[2 * a][0]); m[a].sQ[1] = to_lds(&sQ[2 * a + 1][0]);
-		m[a].qpl[0] = to_lds((const uint4 *)&qpl[2 * a][0]); m[a].qpl[1] = to_lds((const uint4 *)&qpl[2 * a + 1][0]); m[a].gseqp = g_seqp; m[a].q_other = false;
-		m[a].sT = to_lds(sT); m[a].tb = reinterpret_cast<uint32_t *>(sc + pe_tb_offset(QMAX)); m[a].wide_lds = to_lds(wide_lds); m[a].wide_lds_dwords = WIDE_LDS_DWORDS;
+		m[a].qpl[0] = to_lds((const uint4 *)&qpl[2 * a][0]); m[a].qpl[1] = to_lds((const uint4 *)&qpl[2 * a + 1][0]); m[a].gseqp = g_seqp; hot[a].q_other = false;
+		m[a].sT = to_lds(sT); m[a].tb = reinterpret_cast<uint32_t *>(sc + pe_tb_offset(QMAX)); m[a].wide_lds = to_lds(wide_lds); hot[a].wide_lds_dwords = WIDE_LDS_DWORDS;
 		m[a].ropsL = to_lds(ropsL); m[a].ropsR = to_lds(ropsR); m[a].cand = to_lds(cand);
 		m[a].hit_nops = to_lds(&hit_nops[a][0]); m[a].hot = to_lds(&hot[a]);
 		m[a].hit_paths = OVF ? reinterpret_cast<urmapx_path_op *>(hsp_ovf_base + (size_t)hsp_area_blocks * 2 * PE_HSP_OVF_CAP) +
 		                           (TIER == 2 ? (size_t)PE_OVF_BLOCKS * 2 * PE_HIT_CAP * 4 * URMAPX_MAX_PATH_OPS : (size_t)0) +
 		                           ((size_t)blockIdx.x * 2 + a) * PE_HIT_CAP * M::HITW * URMAPX_MAX_PATH_OPS
 		                     : reinterpret_cast<urmapx_path_op *>(sc) + (size_t)a * PE_HIT_CAP * PE_HITW1 * URMAPX_MAX_PATH_OPS;
-		m[a].hit_cap = (hsp_lds_cap >= 64 && hsp_lds_cap <= PE_HSP_CAP) ? (hsp_lds_cap & ~63) / 4 : PE_HIT_CAP * PE_HITW1;
-		m[a].hit_wsh = (hsp_lds_cap >= 64 && hsp_lds_cap <= PE_HSP_CAP) ? 4 : 6;
+		hot[a].hit_cap = (hsp_lds_cap >= 64 && hsp_lds_cap <= PE_HSP_CAP) ? (hsp_lds_cap & ~63) / 4 : PE_HIT_CAP * PE_HITW1;
+		hot[a].hit_wsh = (hsp_lds_cap >= 64 && hsp_lds_cap <= PE_HSP_CAP) ? 4 : 6;
 		m[a].hsp_db = to_lds(&hsp_db[a][0]); m[a].hsp_ql = to_lds(&hsp_ql[a][0]); m[a].hsp_sf = to_lds(&hsp_sf[a][0]);
 		m[a].pend[0] = to_lds(&pend[2 * a][0]); m[a].pend[1] = to_lds(&pend[2 * a + 1][0]);
 		m[a].rowlen = to_lds(rowlen); m[a].pre = to_lds(pre); m[a].cq_db = to_lds(cq_db); m[a].cq_qp = to_lds(cq_qp);
-		m[a].hsp_lds = (hsp_lds_cap >= 64 && hsp_lds_cap <= PE_HSP_CAP) ? (hsp_lds_cap & ~63) : PE_HSP_CAP;
+		hot[a].hsp_lds = (hsp_lds_cap >= 64 && hsp_lds_cap <= PE_HSP_CAP) ? (hsp_lds_cap & ~63) : PE_HSP_CAP;
 		m[a].hsp_ovf = hsp_ovf_base + ((size_t)blockIdx.x * 2 + a) * PE_HSP_OVF_CAP;
-		m[a].dbg_cut = dbg_stop;
+		hot[a].dbg_cut = dbg_stop;
 		m[a].rowstore = reinterpret_cast<uint32_t *>(sc + pe_rowstore_offset(QMAX));
 		m[a].ws.carve(sc + (size_t)2 * PE_HIT_CAP * PE_HITW1 * URMAPX_MAX_PATH_OPS * 2, QMAX, PE_SCAN_SEG + 2 * QMAX + 64);
 	}
@@ -959,7 +973,7 @@ __global__ __launch_bounds__(64, TIER == 2 ? 1 : URX_PE_WAVES(NCH)) void search_
 					}
 				}
 			}
-			m[a].q_other = oth != 0;
+			hot[a].q_other = oth != 0;
 		}
 		lds_sync();
 
