@@ -57,6 +57,8 @@ struct MateHot {
 	// set once per kernel or per pair, read everywhere
 	int W, wide_lds_dwords, hit_cap, hit_wsh, hsp_lds, dbg_cut;
 	bool q_other;  // the read holds a byte outside the code list: its windows are compared as ASCII
+	uint2 *hsp_ovf;             // this mate's HSP list beyond LDS, global
+	urmapx_path_op *hit_paths;  // its hits' paths, global
 };
 template <int NCH, int TIER>
 struct Mate {
@@ -80,6 +82,8 @@ struct Mate {
 #define hsp_lds (hot->hsp_lds)
 #define dbg_cut (hot->dbg_cut)
 #define q_other (hot->q_other)
+#define hsp_ovf (hot->hsp_ovf)
+#define hit_paths (hot->hit_paths)
 #define QL (hot->QL)
 #define nwords (hot->nwords)
 #define pendCount (hot->pendCount)
@@ -113,7 +117,7 @@ struct Mate {
 	uint32_t hit_sp[HITW];  // score << 1 | plus
 	// hit_cap (MateHot): first pass: PE_HIT_CAP (a test aid lowers it)
 	lds_ptr<uint8_t> hit_nops;   // LDS [PE_HIT_CAP * HITW]: runs of a hit's path (<= URMAPX_MAX_PATH_OPS = 96)
-	urmapx_path_op *hit_paths;  // global [PE_HIT_CAP * HITW][URMAPX_MAX_PATH_OPS]
+	// hit_paths (MateHot): global [PE_HIT_CAP * HITW][URMAPX_MAX_PATH_OPS]
 	// hits per word: 64 (2^6); lowered to 16 in the second pass by the test aid that lowers the first pass's caps, so that
 	// a fixture with a few dozen hits per mate runs through several words
 	// hit_wsh (MateHot)
@@ -139,7 +143,7 @@ struct Mate {
 	// in private memory) is 64 bit and every access through it a `flat_*` instruction
 	lds_ptr<uint32_t> hsp_db, hsp_ql;  // LDS [PE_HSP_CAP]
 	lds_ptr<uint16_t> hsp_sf;
-	uint2 *hsp_ovf;   // HSPs hsp_lds.. in global scratch as {db, startq | len << 9 | sf << 18}
+	// hsp_ovf (MateHot): HSPs hsp_lds.. in global scratch as {db, startq | len << 9 | sf << 18}
 	// dbg_cut (MateHot): diagnostic only (URMAPX_DEBUG_STOP_PE 41 / 42 / 43): leave search_pending after that part
 	// hsp_lds (MateHot): HSPs kept in LDS (PE_HSP_CAP; a test aid lowers it)
 	lds_ptr<uint8_t> pend[2];     // LDS [QMAX] each: pending query positions (stored in a byte, state1.h:86-87)
@@ -788,6 +792,8 @@ struct Mate {
 #undef hsp_lds
 #undef dbg_cut
 #undef q_other
+#undef hsp_ovf
+#undef hit_paths
 
 // Waves per SIMD the register allocation aims at.  The pair kernel waits on memory 70 % of its wave cycles and issues
 // instructions in 40 % of its SIMD cycles at two waves per SIMD (profiles/r3/pmc_sq_pe.json): it is bound by latency, and
@@ -863,7 +869,7 @@ __global__ __launch_bounds__(64, TIER == 2 ? 1 : URX_PE_WAVES(NCH)) void search_
 		m[a].sT = to_lds(sT); m[a].tb = reinterpret_cast<uint32_t *>(sc + pe_tb_offset(QMAX)); m[a].wide_lds = to_lds(wide_lds); hot[a].wide_lds_dwords = WIDE_LDS_DWORDS;
 		m[a].ropsL = to_lds(ropsL); m[a].ropsR = to_lds(ropsR); m[a].cand = to_lds(cand);
 		m[a].hit_nops = to_lds(&hit_nops[a][0]); m[a].hot = to_lds(&hot[a]);
-		m[a].hit_paths = OVF ? reinterpret_cast<urmapx_path_op *>(hsp_ovf_base + (size_t)hsp_area_blocks * 2 * PE_HSP_OVF_CAP) +
+		hot[a].hit_paths = OVF ? reinterpret_cast<urmapx_path_op *>(hsp_ovf_base + (size_t)hsp_area_blocks * 2 * PE_HSP_OVF_CAP) +
 		                           (TIER == 2 ? (size_t)PE_OVF_BLOCKS * 2 * PE_HIT_CAP * 4 * URMAPX_MAX_PATH_OPS : (size_t)0) +
 		                           ((size_t)blockIdx.x * 2 + a) * PE_HIT_CAP * M::HITW * URMAPX_MAX_PATH_OPS
 		                     : reinterpret_cast<urmapx_path_op *>(sc) + (size_t)a * PE_HIT_CAP * PE_HITW1 * URMAPX_MAX_PATH_OPS;
@@ -873,7 +879,7 @@ __global__ __launch_bounds__(64, TIER == 2 ? 1 : URX_PE_WAVES(NCH)) void search_
 		m[a].pend[0] = to_lds(&pend[2 * a][0]); m[a].pend[1] = to_lds(&pend[2 * a + 1][0]);
 		m[a].rowlen = to_lds(rowlen); m[a].pre = to_lds(pre); m[a].cq_db = to_lds(cq_db); m[a].cq_qp = to_lds(cq_qp);
 		hot[a].hsp_lds = (hsp_lds_cap >= 64 && hsp_lds_cap <= PE_HSP_CAP) ? (hsp_lds_cap & ~63) : PE_HSP_CAP;
-		m[a].hsp_ovf = hsp_ovf_base + ((size_t)blockIdx.x * 2 + a) * PE_HSP_OVF_CAP;
+		hot[a].hsp_ovf = hsp_ovf_base + ((size_t)blockIdx.x * 2 + a) * PE_HSP_OVF_CAP;
 		hot[a].dbg_cut = dbg_stop;
 		m[a].rowstore = reinterpret_cast<uint32_t *>(sc + pe_rowstore_offset(QMAX));
 		m[a].ws.carve(sc + (size_t)2 * PE_HIT_CAP * PE_HITW1 * URMAPX_MAX_PATH_OPS * 2, QMAX, PE_SCAN_SEG + 2 * QMAX + 64);
@@ -1305,7 +1311,7 @@ __global__ __launch_bounds__(64, TIER == 2 ? 1 : URX_PE_WAVES(NCH)) void search_
 						uint32_t po = 0;
 						if (lane == 0) po = atomicAdd(path_used, (uint32_t)nops);
 						po = uni(po);
-						for (int t = lane; t < nops; t += 64) path_ops[po + t] = m[a].hit_paths[(size_t)hot[a].topHit * URMAPX_MAX_PATH_OPS + t];
+						for (int t = lane; t < nops; t += 64) path_ops[po + t] = hot[a].hit_paths[(size_t)hot[a].topHit * URMAPX_MAX_PATH_OPS + t];
 						R.path_off = po; R.path_nops = (uint16_t)nops;
 					}
 				}
