@@ -134,7 +134,7 @@ hipError_t launch_pack_seq(const uint8_t *d_seq, uint32_t seq_data_size, uint4 *
 size_t search_pe_scratch_stride(uint32_t max_read_len);
 int search_pe_block_count(uint32_t max_read_len, int device);
 hipError_t launch_search_pe(const DevIndex &X, const urmapx_params &P, const uint8_t *d_bases, const uint64_t *d_offs,
-                            uint32_t npairs, uint32_t max_read_len, ProbeOut probe, urmapx_result *d_results,
+                            uint32_t npairs, uint32_t max_read_len, urmapx_result *d_results,
                             urmapx_path_op *d_path_ops, uint32_t *d_path_used, const SearchWork &wk, int veryfast,
                             urmapx_pair_info *pair_info, hipStream_t s);
 

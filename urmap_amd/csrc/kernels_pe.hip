@@ -60,21 +60,42 @@ struct MateHot {
 	uint2 *hsp_ovf;             // this mate's HSP list beyond LDS, global
 	urmapx_path_op *hit_paths;  // its hits' paths, global
 };
+// Everything a mate owns, as ONE LDS object per mate.  Round 4: a Mate is now a handful of pointers held in registers -- the
+// pointer to this object is the only thing that differs between the two mates, so `the mate picked at run time` is an address
+// computation, not an array of objects in private memory (where every member access was a scratch load: 331 scratch
+// instructions per pair in round 3).  The hit list lives here too (it was four per-lane words per mate in private memory).
+static constexpr int pe_hitw(int tier) { return tier == 0 ? PE_HITW1 : tier == 1 ? 4 : PE_HITW2; }
+template <int NCH, int TIER>
+struct MateLds {
+	static constexpr int QMAX = 64 * NCH;
+	static constexpr int HITS = 64 * pe_hitw(TIER);
+	MateHot hot;
+	__attribute__((aligned(16))) uint4 qpl[2][2 * NCH];  // the two strands as bit planes of 4-bit codes (dev_common.h: seq_code), one uint4 per 32 bases
+	__attribute__((aligned(16))) uint8_t sQ[2][QMAX];     // [0] read as given, [1] reverse complement
+	uint32_t hit_db[HITS];
+	uint16_t hit_sp[HITS];   // score << 1 | plus
+	uint8_t hit_nops[HITS];  // runs of a hit's path (<= URMAPX_MAX_PATH_OPS = 96)
+	uint32_t hsp_db[PE_HSP_CAP], hsp_ql[PE_HSP_CAP];
+	uint16_t hsp_sf[PE_HSP_CAP];
+	uint8_t pend[2][QMAX];   // pending query positions (stored in a byte, state1.h:86-87)
+	uint64_t kpl[4][NCH + 1];  // letter planes of the read (probe_dev.h: probe_pair, slot_from_planes)
+};
 template <int NCH, int TIER>
 struct Mate {
 	static constexpr bool OVF = TIER > 0;
 	static constexpr int QMAX = 64 * NCH;
 	static constexpr int TB_ROWS8 = QMAX / 8 + 2;
-	// wave constants
+	static constexpr int HITW = pe_hitw(TIER);
+	// wave constants (the same in both mates' objects: registers)
 	const DevIndex *X;
 	const urmapx_params *P;
 	const uint8_t *__restrict__ gseq;
 	const uint8_t *__restrict__ gblob;
-	// `lane` is not a member: the objects of this struct live in private memory (the pairing loop picks a mate at run time), and
-	// a member is a scratch load wherever it is used; the work-item id is a register
+	const uint4 *__restrict__ gseqp;  // packed copy of the sequence store
 #define lane ((int)threadIdx.x)
-	// this mate
-	lds_ptr<MateHot> hot;
+	// this mate: everything it owns is behind this one LDS pointer
+	lds_ptr<MateLds<NCH, TIER>> L;
+#define hot (&L->hot)
 #define W (hot->W)
 #define wide_lds_dwords (hot->wide_lds_dwords)
 #define hit_cap (hot->hit_cap)
@@ -96,57 +117,30 @@ struct Mate {
 #define bestHSP (hot->bestHSP)
 #define mapq (hot->mapq)
 #define status (hot->status)
-	lds_ptr<uint8_t> sQ[2];  // LDS: [0] read as given, [1] reverse complement
-	lds_ptr<const uint4> qpl[2];  // LDS: the two strands as bit planes of 4-bit codes (dev_common.h: seq_code), one uint4 per 32 bases
-	const uint4 *__restrict__ gseqp;  // packed copy of the sequence store
-	uint32_t qch[2][NCH];
-	const uint64_t *pslots;  // probe output of this read (global), index strand*QL + qpos
-	const uint8_t *ptal;
-	const uint32_t *ppos;
+#define sQ (L->sQ)
+#define qpl (L->qpl)
+#define hit_db (L->hit_db)
+#define hit_sp (L->hit_sp)
+#define hit_nops (L->hit_nops)
+#define hsp_db (L->hsp_db)
+#define hsp_ql (L->hsp_ql)
+#define hsp_sf (L->hsp_sf)
+#define pend (L->pend)
 	// shared LDS scratch (one set per wave)
 	lds_ptr<uint8_t> sT;
 	uint32_t *tb;         // trace cells of the banded DP: this block's global scratch
 	lds_ptr<uint32_t> wide_lds;   // LDS rows of the wide-band DP (the rescue's whole-read Viterbi)
 	lds_ptr<uint16_t> ropsL, ropsR, cand;
 	WideScratch ws;
-	// lists
-	// hits: entry k lives on lane k & 63 of word k >> 6 (one word = 64 hits in the first-pass kernel, HITW words in the
-	// second pass over pairs that outgrew a list)
-	static constexpr int HITW = TIER == 0 ? PE_HITW1 : TIER == 1 ? 4 : PE_HITW2;
-	uint32_t hit_db[HITW];
-	uint32_t hit_sp[HITW];  // score << 1 | plus
-	// hit_cap (MateHot): first pass: PE_HIT_CAP (a test aid lowers it)
-	lds_ptr<uint8_t> hit_nops;   // LDS [PE_HIT_CAP * HITW]: runs of a hit's path (<= URMAPX_MAX_PATH_OPS = 96)
-	// hit_paths (MateHot): global [PE_HIT_CAP * HITW][URMAPX_MAX_PATH_OPS]
-	// hits per word: 64 (2^6); lowered to 16 in the second pass by the test aid that lowers the first pass's caps, so that
-	// a fixture with a few dozen hits per mate runs through several words
-	// hit_wsh (MateHot)
-	__device__ __forceinline__ int wsh() const { return OVF ? hit_wsh : 6; }
-	__device__ __forceinline__ int wl() const { return 1 << wsh(); }
-	__device__ __forceinline__ uint32_t hdb(int i) const {  // i wave-uniform
-		const int l = i & (wl() - 1);
-		uint32_t v = rdlane(hit_db[0], l);
-#pragma unroll
-		for (int w = 1; w < HITW; ++w)
-			if ((i >> wsh()) == w) v = rdlane(hit_db[w], l);
-		return v;
-	}
-	__device__ __forceinline__ uint32_t hsp_of(int i) const {
-		const int l = i & (wl() - 1);
-		uint32_t v = rdlane(hit_sp[0], l);
-#pragma unroll
-		for (int w = 1; w < HITW; ++w)
-			if ((i >> wsh()) == w) v = rdlane(hit_sp[w], l);
-		return v;
-	}
-	// LDS arrays are named by LDS pointers (32 bit, `ds_*` instructions): a generic pointer loaded from this struct (which lives
-	// in private memory) is 64 bit and every access through it a `flat_*` instruction
-	lds_ptr<uint32_t> hsp_db, hsp_ql;  // LDS [PE_HSP_CAP]
-	lds_ptr<uint16_t> hsp_sf;
-	// hsp_ovf (MateHot): HSPs hsp_lds.. in global scratch as {db, startq | len << 9 | sf << 18}
+	// hit k: hit_db[k], hit_sp[k], hit_nops[k] in LDS; its path in hit_paths (global) [k][URMAPX_MAX_PATH_OPS]
+	// capacity: first pass hit_cap (PE_HITW1 x 64; a test aid lowers it); later passes HITW << hit_wsh (HITW x 64; the test
+	// aid that lowers the first pass's caps makes it HITW x 16 in the second pass, so that a fixture with a few dozen hits
+	// per mate reaches the third)
+	__device__ __forceinline__ int hits_room() const { return OVF ? HITW << hit_wsh : hit_cap; }
+	__device__ __forceinline__ uint32_t hdb(int i) const { return hit_db[i]; }      // i wave-uniform
+	__device__ __forceinline__ uint32_t hsp_of(int i) const { return hit_sp[i]; }
+	// HSPs: LDS [PE_HSP_CAP] (hsp_db, hsp_ql, hsp_sf); beyond hsp_lds in global scratch as {db, startq | len << 9 | sf << 18}
 	// dbg_cut (MateHot): diagnostic only (URMAPX_DEBUG_STOP_PE 41 / 42 / 43): leave search_pending after that part
-	// hsp_lds (MateHot): HSPs kept in LDS (PE_HSP_CAP; a test aid lowers it)
-	lds_ptr<uint8_t> pend[2];     // LDS [QMAX] each: pending query positions (stored in a byte, state1.h:86-87)
 	lds_ptr<uint8_t> rowlen;      // LDS [2 * QMAX]: row length of every pending position, [strand][i]
 	lds_ptr<uint16_t> pre;        // LDS [65]
 	lds_ptr<uint32_t> cq_db;      // LDS [128]: candidate queue of the pending stage (ring)
@@ -155,17 +149,16 @@ struct Mate {
 
 	__device__ __forceinline__ bool overlaps_hit(uint32_t db) const {
 		bool eq = false;
-#pragma unroll
-		for (int w = 0; w < HITW; ++w) eq |= lane < wl() && (w << wsh()) + lane < hitCount && (hit_db[w] >> 6) == (db >> 6);
+		const int n = hitCount;
+		for (int b = 0; b < n; b += 64) eq |= b + lane < n && (hit_db[b + lane] >> 6) == (db >> 6);
 		return __ballot(eq) != 0;
 	}
 
 	// per-lane form of OverlapsHit
 	__device__ __forceinline__ bool overlaps_any_hit(uint32_t db) const {
 		bool ov = false;
-#pragma unroll
-		for (int w = 0; w < HITW; ++w)
-			for (int k = 0; k < wl() && (w << wsh()) + k < hitCount; ++k) ov |= (rdlane(hit_db[w], k) >> 6) == (db >> 6);
+		const int n = hitCount;
+		for (int k = 0; k < n; ++k) ov |= (hit_db[k] >> 6) == (db >> 6);  // one address for all lanes: an LDS broadcast
 		return ov;
 	}
 
@@ -184,11 +177,8 @@ struct Mate {
 			else if (score > second) second = score;
 		}
 		if (!keep) return -1;
-		if (hitCount >= (OVF ? HITW << wsh() : hit_cap)) { status |= URMAPX_ST_HIT_OVERFLOW; if (topHit == idx) topHit = -1; return -1; }
-#pragma unroll
-		for (int w = 0; w < HITW; ++w)
-			if (lane < wl() && (w << wsh()) + lane == idx) { hit_db[w] = db; hit_sp[w] = ((uint32_t)score << 1) | (plus ? 1u : 0u); }
-		if (lane == 0) hit_nops[idx] = (uint8_t)cand_nops;
+		if (hitCount >= hits_room()) { status |= URMAPX_ST_HIT_OVERFLOW; if (topHit == idx) topHit = -1; return -1; }
+		if (lane == 0) { hit_db[idx] = db; hit_sp[idx] = (uint16_t)(((uint32_t)score << 1) | (plus ? 1u : 0u)); hit_nops[idx] = (uint8_t)cand_nops; }
 		for (int t = lane; t < cand_nops; t += 64) hit_paths[(size_t)idx * URMAPX_MAX_PATH_OPS + t] = cand[t];
 		URX_SYNC();
 		++hitCount;
@@ -266,7 +256,7 @@ struct Mate {
 		for (int c = 0; c < NCH; ++c) {
 			const int p = 64 * c + lane;
 			bool ne = false;
-			if (p < QL) ne = ((uint32_t)t[p] != qch[s][c]);
+			if (p < QL) ne = ((uint32_t)t[p] != (uint32_t)sQ[s][p]);
 			mm.w[c] = __ballot(ne);
 		}
 	}
@@ -274,8 +264,8 @@ struct Mate {
 	// mismatch bit vector of the whole read against the window at dblo, one candidate per lane: packed planes, or ASCII for
 	// a read with bytes outside the code list (wave-uniform choice)
 	__device__ __forceinline__ void lane_mask(uint32_t dblo, bool plus, uint64_t (&mm)[NCH]) const {
-		if (q_other) lane_mismatch_mask<NCH>(gseq, dblo, from_lds(plus ? sQ[0] : sQ[1]), QL, mm);
-		else lane_mismatch_planes<NCH>(gseqp, dblo, from_lds(plus ? qpl[0] : qpl[1]), QL, mm);
+		if (q_other) lane_mismatch_mask<NCH>(gseq, dblo, from_lds(&sQ[plus ? 0 : 1][0]), QL, mm);
+		else lane_mismatch_planes<NCH>(gseqp, dblo, from_lds((lds_ptr<const uint4>)&qpl[plus ? 0 : 1][0]), QL, mm);
 	}
 
 	// The two x-drop walks shared by ExtendPen (extendpen.cpp:25-78) and ExtendScan (extendscan.cpp:77-133).
@@ -385,61 +375,66 @@ struct Mate {
 		const int BR = 2 * (int)P->band_radius;
 		const uint32_t TL = X->seqDataSize;
 		uint32_t combinedTLo = startdb;
-		const uint8_t *Q = from_lds(plus ? sQ[0] : sQ[1]);
-		RevOps RL, RR;
-		RL.ops = from_lds(ropsL); RR.ops = from_lds(ropsR);
-		RL.begin(); RR.begin();
+		const uint8_t *Q = from_lds(&sQ[plus ? 0 : 1][0]);
+		int nL = 0, nR = 0;
 		int rtrim = 0;
 		uint32_t vst = 0;
-		if (startq > 0) {
-			if (startdb < (uint32_t)startq) return -1;
-			const int leftQL = startq;
-			const uint32_t leftTHi = startdb - 1;
-			const uint32_t leftTL = (uint32_t)(leftQL + BR);
-			if (leftTL >= leftTHi) return -1;
-			const uint32_t leftTLo = leftTHi - leftTL + 1;
-			if (load_window(leftTLo, (int)leftTL)) return -1;
+		const VPar VP(*P);
+		// the two flanks through ONE copy of the banded DP (as search_se_kernel: the code has to stay near the instruction cache's size)
+		const int rightQLo = startq + len;
+#pragma unroll 1
+		for (int side = 0; side < 2; ++side) {
+			const bool left = side == 0;
+			int fql;
+			uint32_t tlo, tl;
+			const uint8_t *fq;
+			if (left) {
+				if (startq <= 0) continue;
+				if (startdb < (uint32_t)startq) return -1;
+				fql = startq;
+				const uint32_t leftTHi = startdb - 1;
+				tl = (uint32_t)(fql + BR);
+				if (tl >= leftTHi) return -1;
+				tlo = leftTHi - tl + 1;
+				fq = Q;
+			} else {
+				if (rightQLo >= QL) continue;
+				fql = QL - rightQLo;
+				tlo = startdb + (uint32_t)len;
+				uint32_t thi = tlo + (uint32_t)fql + (uint32_t)BR;
+				if (thi >= TL) thi = TL - 1;
+				tl = thi - tlo + 1;
+				fq = Q + rightQLo;
+			}
+			if (load_window(tlo, (int)tl)) return -1;
 			// the DP stops as soon as the flank cannot stay within what the penalty cap leaves (viterbi_dev.h); the test
 			// that would discard it follows right below, so the outcome is the same
-			const int allGapL = P->gap_open_score + (leftQL - 1) * P->gap_ext_score;
-			const int needL = leftQL - (maxPen - totalPen);
-			bool abortedL = false;
-			int leftScore = (int)viterbi_wave<true>(VPar(*P), Q, leftQL, from_lds(sT), (int)leftTL, true, false, tb, TB_ROWS8, ws, RL, vst, lane,
-			                                        (float)needL, allGapL < needL ? &abortedL : nullptr, from_lds(wide_lds), wide_lds_dwords);
-			if (abortedL) return -1;
+			const int allGap = P->gap_open_score + (fql - 1) * P->gap_ext_score;
+			const int need = fql - (maxPen - totalPen);
+			bool aborted = false;
+			RevOps R;
+			R.ops = from_lds(left ? ropsL : ropsR);
+			int score = (int)viterbi_wave<true>(VP, fq, fql, from_lds(sT), (int)tl, left, !left, tb, TB_ROWS8, ws, R, vst, lane, (float)need,
+			                                    allGap < need ? &aborted : nullptr, from_lds(wide_lds), wide_lds_dwords);
+			if (aborted) return -1;
 			status |= vst;
-			int nTrimI = 0;
-			if (RL.n > 0) {
-				uint32_t lastop = ropsL[RL.n - 1];
-				if ((lastop & 3u) == OP_I) { nTrimI = (int)(lastop >> 2); --RL.n; }
+			if (left) {
+				nL = R.n;
+				// TrimLeftIs (pathinfo.cpp:153-171): the leading I run is the last run in traceback order
+				int nTrimI = 0;
+				if (nL > 0) {
+					uint32_t lastop = ropsL[nL - 1];
+					if ((lastop & 3u) == OP_I) { nTrimI = (int)(lastop >> 2); --nL; }
+				}
+				combinedTLo = tlo + (uint32_t)nTrimI;
+			} else {
+				nR = R.n;
+				// TrimRightIs (pathinfo.cpp:173-190): trailing I run = first run in traceback order, never the whole path
+				if (nR > 1 && (ropsR[0] & 3u) == OP_I) rtrim = 1;
 			}
-			combinedTLo = leftTLo + (uint32_t)nTrimI;
-			int allGap = P->gap_open_score + (leftQL - 1) * P->gap_ext_score;
-			if (allGap > leftScore) leftScore = allGap;
-			totalScore += leftScore;
-			totalPen += leftQL - leftScore;
-			if (totalPen > maxPen) return -1;
-		}
-		const int rightQLo = startq + len;
-		if (rightQLo < QL) {
-			const int rightQL = QL - rightQLo;
-			const uint32_t rightTLo = startdb + (uint32_t)len;
-			uint32_t rightTHi = rightTLo + (uint32_t)rightQL + (uint32_t)BR;
-			if (rightTHi >= TL) rightTHi = TL - 1;
-			const uint32_t rightTL = rightTHi - rightTLo + 1;
-			if (load_window(rightTLo, (int)rightTL)) return -1;
-			const int allGapR = P->gap_open_score + (rightQL - 1) * P->gap_ext_score;
-			const int needR = rightQL - (maxPen - totalPen);
-			bool abortedR = false;
-			int rightScore = (int)viterbi_wave<true>(VPar(*P), Q + rightQLo, rightQL, from_lds(sT), (int)rightTL, false, true, tb, TB_ROWS8, ws, RR, vst, lane,
-			                                         (float)needR, allGapR < needR ? &abortedR : nullptr, from_lds(wide_lds), wide_lds_dwords);
-			if (abortedR) return -1;
-			status |= vst;
-			if (RR.n > 1 && (ropsR[0] & 3u) == OP_I) rtrim = 1;
-			int allGap = P->gap_open_score + (rightQL - 1) * P->gap_ext_score;
-			if (allGap > rightScore) rightScore = allGap;
-			totalScore += rightScore;
-			totalPen += rightQL - rightScore;
+			if (allGap > score) score = allGap;
+			totalScore += score;
+			totalPen += fql - score;
 			if (totalPen > maxPen) return -1;
 		}
 		if (status & (URMAPX_ST_BAND_TOO_WIDE | URMAPX_ST_PATH_OVERFLOW)) return -1;
@@ -451,9 +446,9 @@ struct Mate {
 			if (clen) { if (nc < URMAPX_MAX_PATH_OPS) { if (lane == 0) cand[nc] = (uint16_t)((clen << 2) | cop); ++nc; } else ovf = true; }
 			cop = op; clen = l;
 		};
-		for (int t = RL.n - 1; t >= 0; --t) { uint32_t o = ropsL[t]; put((int)(o & 3u), (int)(o >> 2)); }
+		for (int t = nL - 1; t >= 0; --t) { uint32_t o = ropsL[t]; put((int)(o & 3u), (int)(o >> 2)); }
 		put(OP_M, len);
-		for (int t = RR.n - 1; t >= rtrim; --t) { uint32_t o = ropsR[t]; put((int)(o & 3u), (int)(o >> 2)); }
+		for (int t = nR - 1; t >= rtrim; --t) { uint32_t o = ropsR[t]; put((int)(o & 3u), (int)(o >> 2)); }
 		put(-2, 1);
 		if (ovf) { status |= URMAPX_ST_PATH_OVERFLOW; return -1; }
 		URX_SYNC();
@@ -514,16 +509,32 @@ struct Mate {
 	// strand, the chains of 64 pending positions are walked at once (one chain per lane), and each (round, strand,
 	// chunk) group of row entries goes through the same gather / ordered-consume split as search_se_kernel: outcome of
 	// the uncapped x-drop walk per lane, then only the state-changing candidates in the reference's order.
-	__device__ void search_pending() {
+	// (round 4: inlined at its one call site -- as a function of its own it took `this` as a pointer, i.e. the Mate object in
+	// private memory and every pointer in it a scratch load; AlignHSP has one call site in here, a loop that runs once for
+	// the phase-3 alignments (if the best HSP is long enough) and once for the final ones)
+	__device__ __forceinline__ void search_pending() {
 		maxPen = P->max_penalty;
 		const int minScore1 = QL + P->xphase1 * P->mismatch_score;
 		const int termHSP3 = (QL * P->term_hsp_score_pct_phase3) / 100;
 		if (best >= minScore1) { mapq = calc_mapq(); return; }
-		if (bestHSP >= termHSP3) {
-			for (int k = 0; k < hspCount; ++k) align_hsp(k);
-			if (best >= minScore1) { mapq = calc_mapq(); return; }
+#pragma unroll 1
+		for (int stage = bestHSP >= termHSP3 ? 0 : 1; stage < 2; ++stage) {
+			if (stage == 1) {
+				if (dbg_cut == 41) break;
+				if (!pending_rows()) break;  // diagnostic cut
+			}
+			const int bmin = stage == 0 ? -0x7FFFFFFF : max(best, bestHSP) - 8;
+			for (int k = 0; k < hspCount; ++k) {
+				if (stage == 1 && hsp_score(k) < bmin) continue;
+				align_hsp(k);
+			}
+			if (stage == 0 && best >= minScore1) break;
 		}
-		if (dbg_cut == 41) { mapq = calc_mapq(); return; }
+		mapq = calc_mapq();
+	}
+
+	// the chain walks and ExtendPen calls of SearchPE_Pending (search1pepend.cpp:46-116); false: a diagnostic cut says stop
+	__device__ __forceinline__ bool pending_rows() {
 		const int minhsp = (int)((uint32_t)P->min_hsp_score_pct * (uint32_t)QL / 100.0);
 		const uint64_t N = X->slotCount;
 		const int maxIx = (int)X->maxIx;
@@ -537,8 +548,10 @@ struct Mate {
 				uint64_t slot2 = 0;
 				uint32_t T = 0, pos = 0;
 				if (act) {
-					const size_t idx = (size_t)s * QL + pend[s][i];
-					slot2 = pslots[idx]; T = ptal[idx]; pos = ppos[idx];
+					// the head's slot number from the read's letter planes, its tally and position from the table again (round 3
+					// read all three from probe arrays in HBM that every pair had written)
+					slot2 = slot_from_planes<NCH + 1>(*X, (lds_ptr<const uint64_t>)&L->kpl[0][0], (uint32_t)nwords, s, pend[s][i]);
+					load_slot(gblob, slot2, T, pos);
 					act = (T & TALLY_MY_BIT) != 0;  // GetRow_Blob returns 0 for a slot that is not "mine"
 				}
 				while (__ballot(act)) {
@@ -563,7 +576,7 @@ struct Mate {
 			}
 		}
 		URX_SYNC();
-		if (dbg_cut == 42) { mapq = calc_mapq(); return; }
+		if (dbg_cut == 42) return false;
 		// 2. the four groups in the reference's order.  Candidates that survive the hit-diagonal filter are compacted, in
 		// order, into a 128-entry LDS queue (reference position, query position | plus << 15), so that the gather below
 		// always runs on full batches even though most (round, strand, chunk) groups hold only a few row entries.
@@ -667,13 +680,7 @@ struct Mate {
 			}
 		}
 		drain(true);
-		if (dbg_cut == 43) { mapq = calc_mapq(); return; }
-		const int bmin = max(best, bestHSP) - 8;
-		for (int k = 0; k < hspCount; ++k) {
-			if (hsp_score(k) < bmin) continue;
-			align_hsp(k);
-		}
-		mapq = calc_mapq();
+		return dbg_cut != 43;
 	}
 
 	// extendscan.cpp:51-187
@@ -691,7 +698,7 @@ struct Mate {
 	}
 
 	// scanslots.cpp:7-62: every window k-mer against the read's slots at the first SCANK prime-stride positions
-	__device__ void scan_slots(uint32_t dblo, uint32_t seglen, bool plus) {
+	__device__ __forceinline__ void scan_slots(uint32_t dblo, uint32_t seglen, bool plus) {
 		if (QL <= 4 * W) return;
 		const int s = plus ? 0 : 1;
 		uint64_t qslot[SCANK];
@@ -699,7 +706,7 @@ struct Mate {
 #pragma unroll
 		for (uint32_t k = 0; k < SCANK; ++k) {
 			qposk[k] = (k * PRIME_STRIDE) % (uint32_t)nwords;
-			qslot[k] = uni64(pslots[(size_t)s * QL + qposk[k]]);
+			qslot[k] = uni64(slot_from_planes<NCH + 1>(*X, (lds_ptr<const uint64_t>)&L->kpl[0][0], (uint32_t)nwords, s, qposk[k]));
 		}
 		const uint64_t wmask = X->shiftMask;
 		const uint64_t wbits = (W >= 32) ? 0xFFFFFFFFull : ((1ull << W) - 1ull);
@@ -743,7 +750,7 @@ struct Mate {
 	}
 
 	// scan.cpp:14-39
-	__device__ void scan(uint32_t dbpos, uint32_t seglen, bool plus, bool dovit) {
+	__device__ __forceinline__ void scan(uint32_t dbpos, uint32_t seglen, bool plus, bool dovit) {
 		const int savedMaxPen = maxPen;
 		const int savedHits = hitCount;
 		maxPen = 130;
@@ -755,7 +762,7 @@ struct Mate {
 		R.ops = from_lds(ropsL);
 		uint32_t vst = 0;
 		// whole read against the window: a band far wider than a wavefront -> wide path (B read from global memory)
-		const float score = viterbi_wave(VPar(*P), from_lds(plus ? sQ[0] : sQ[1]), QL, gseq + dbpos, (int)seglen, true, true, tb, TB_ROWS8, ws, R, vst, lane,
+		const float score = viterbi_wave(VPar(*P), from_lds(&sQ[plus ? 0 : 1][0]), QL, gseq + dbpos, (int)seglen, true, true, tb, TB_ROWS8, ws, R, vst, lane,
 		                                 -3.0e38f, nullptr, from_lds(wide_lds), wide_lds_dwords);
 		status |= vst;
 		if (vst) return;
@@ -794,6 +801,16 @@ struct Mate {
 #undef q_other
 #undef hsp_ovf
 #undef hit_paths
+#undef hot
+#undef sQ
+#undef qpl
+#undef hit_db
+#undef hit_sp
+#undef hit_nops
+#undef hsp_db
+#undef hsp_ql
+#undef hsp_sf
+#undef pend
 
 // Waves per SIMD the register allocation aims at.  The pair kernel waits on memory 70 % of its wave cycles and issues
 // instructions in 40 % of its SIMD cycles at two waves per SIMD (profiles/r3/pmc_sq_pe.json): it is bound by latency, and
@@ -805,7 +822,7 @@ struct Mate {
 #endif
 template <int NCH, int TIER>
 __global__ __launch_bounds__(64, TIER == 2 ? 1 : URX_PE_WAVES(NCH)) void search_pe_kernel(DevIndex X, urmapx_params P, const uint8_t *__restrict__ bases,
-                                                       const uint64_t *__restrict__ offs, uint32_t npairs, ProbeOut probe,
+                                                       const uint64_t *__restrict__ offs, uint32_t npairs,
                                                        urmapx_result *__restrict__ results,
                                                        urmapx_path_op *__restrict__ path_ops, uint32_t *path_used,
                                                        uint8_t *scratch, size_t scratch_stride,
@@ -821,23 +838,21 @@ __global__ __launch_bounds__(64, TIER == 2 ? 1 : URX_PE_WAVES(NCH)) void search_
 	//   flank run buffers, candidate path, target window (AlignHSP / Scan)  on  seed_res  (seeds are dead by then)
 	//   pending-stage row lengths and prefix                               on  seed_q
 	//   the pending stage's candidate queue                                 on  seed_db
-	__shared__ __attribute__((aligned(16))) uint8_t sQ[4][QMAX];
-	__shared__ __attribute__((aligned(16))) uint4 qpl[4][2 * NCH];  // [mate * 2 + strand][block of 32 bases]
+	__shared__ MateLds<NCH, TIER> ml[2];
 	static_assert(URMAPX_MAX_PATH_OPS <= 255, "hit_nops is a byte");
-	__shared__ uint8_t hit_nops[2][PE_HIT_CAP * M::HITW];
-	__shared__ MateHot hot[2];
-	__shared__ uint32_t hsp_db[2][PE_HSP_CAP], hsp_ql[2][PE_HSP_CAP];
-	__shared__ uint16_t hsp_sf[2][PE_HSP_CAP];
-	__shared__ uint8_t pend[4][QMAX];
 	// Both1 seed lists of the two mates in enumeration order: qpos | plus << 15, db position
-	constexpr int SEED_CAP = 2 * (QMAX - 20);  // >= 2 * (QMAX - W + 1) for the word lengths in use (W >= 21); beyond it the pair is flagged
+	// later passes: 2 * (QMAX - 20) >= 2 * (QMAX - W + 1) for the word lengths in use (W >= 21).  First pass: QMAX -- a mate returns a
+	// seed only where the diagonal changes (getseed.cpp:60-66), a handful per read; a pair with more goes to the second pass
+	// (LDS per block decides how many pairs a CU keeps in flight)
+	constexpr int SEED_CAP = TIER == 0 ? QMAX : 2 * (QMAX - 20);
 	__shared__ __attribute__((aligned(16))) uint16_t seed_q[2][SEED_CAP];
 	__shared__ __attribute__((aligned(16))) uint32_t seed_db[2][SEED_CAP];
 	// cached ExtendPen outcome of every seed (see extend_pen_cached); bit 15 of seed_pen = "already extended once"
 	// one area, three lives: (1) the probe results staged for the seed enumeration (s_tal, s_pos); (2) the cached
 	// ExtendPen outcomes of the seeds (seed_res, seed_pen); (3) AlignHSP's run buffers, candidate path and target window,
 	// and behind them the per-row arrays of the wide-band DP
-	__shared__ __attribute__((aligned(16))) uint32_t seed_area[2 * SEED_CAP + SEED_CAP];
+	constexpr int SEED_AREA_DWORDS = 3 * SEED_CAP > 5 * QMAX ? 3 * SEED_CAP : 5 * QMAX;
+	__shared__ __attribute__((aligned(16))) uint32_t seed_area[SEED_AREA_DWORDS];
 	uint32_t (*const seed_res)[SEED_CAP] = reinterpret_cast<uint32_t (*)[SEED_CAP]>(seed_area);
 	uint16_t (*const seed_pen)[SEED_CAP] = reinterpret_cast<uint16_t (*)[SEED_CAP]>(seed_area + 2 * SEED_CAP);
 	static_assert(4 * QMAX + 16 * QMAX <= sizeof(seed_area), "alias");
@@ -861,28 +876,29 @@ __global__ __launch_bounds__(64, TIER == 2 ? 1 : URX_PE_WAVES(NCH)) void search_
 	const int dbg_stop = veryfast >> 8;  // diagnostic only (URMAPX_DEBUG_STOP_PE): results are NOT the reference's
 	veryfast &= 1;
 	uint8_t *sc = scratch + (size_t)blockIdx.x * scratch_stride;
-	M m[2];
+	// A Mate is the shared pointers below plus the LDS address of the mate's own object: `mate(a)` with a run-time a is an
+	// address computation (round 3 kept an array of two objects, which the run-time index forced into private memory)
+	M mshared;
+	mshared.X = &X; mshared.P = &P; mshared.gseq = g_seq; mshared.gblob = g_blob; mshared.gseqp = g_seqp;
+	mshared.sT = to_lds(sT); mshared.tb = reinterpret_cast<uint32_t *>(sc + pe_tb_offset(QMAX)); mshared.wide_lds = to_lds(wide_lds);
+	mshared.ropsL = to_lds(ropsL); mshared.ropsR = to_lds(ropsR); mshared.cand = to_lds(cand);
+	mshared.rowlen = to_lds(rowlen); mshared.pre = to_lds(pre); mshared.cq_db = to_lds(cq_db); mshared.cq_qp = to_lds(cq_qp);
+	mshared.rowstore = reinterpret_cast<uint32_t *>(sc + pe_rowstore_offset(QMAX));
+	mshared.ws.carve(sc + (size_t)2 * PE_HIT_CAP * PE_HITW1 * URMAPX_MAX_PATH_OPS * 2, QMAX, PE_SCAN_SEG + 2 * QMAX + 64);
+	mshared.L = to_lds(&ml[0]);
+	auto mate = [&](int a) -> M { M r = mshared; r.L = to_lds(&ml[a]); return r; };
+#define hot(a) ml[a].hot
 	for (int a = 0; a < 2; ++a) {
-		m[a].X = &X; m[a].P = &P; m[a].gseq = g_seq; m[a].gblob = g_blob; hot[a].W = W;
-		m[a].sQ[0] = to_lds(&sQ[2 * a][0]); m[a].sQ[1] = to_lds(&sQ[2 * a + 1][0]);
-		m[a].qpl[0] = to_lds((const uint4 *)&qpl[2 * a][0]); m[a].qpl[1] = to_lds((const uint4 *)&qpl[2 * a + 1][0]); m[a].gseqp = g_seqp; hot[a].q_other = false;
-		m[a].sT = to_lds(sT); m[a].tb = reinterpret_cast<uint32_t *>(sc + pe_tb_offset(QMAX)); m[a].wide_lds = to_lds(wide_lds); hot[a].wide_lds_dwords = WIDE_LDS_DWORDS;
-		m[a].ropsL = to_lds(ropsL); m[a].ropsR = to_lds(ropsR); m[a].cand = to_lds(cand);
-		m[a].hit_nops = to_lds(&hit_nops[a][0]); m[a].hot = to_lds(&hot[a]);
-		hot[a].hit_paths = OVF ? reinterpret_cast<urmapx_path_op *>(hsp_ovf_base + (size_t)hsp_area_blocks * 2 * PE_HSP_OVF_CAP) +
+		hot(a).W = W; hot(a).q_other = false; hot(a).wide_lds_dwords = WIDE_LDS_DWORDS;
+		hot(a).hit_paths = OVF ? reinterpret_cast<urmapx_path_op *>(hsp_ovf_base + (size_t)hsp_area_blocks * 2 * PE_HSP_OVF_CAP) +
 		                           (TIER == 2 ? (size_t)PE_OVF_BLOCKS * 2 * PE_HIT_CAP * 4 * URMAPX_MAX_PATH_OPS : (size_t)0) +
 		                           ((size_t)blockIdx.x * 2 + a) * PE_HIT_CAP * M::HITW * URMAPX_MAX_PATH_OPS
 		                     : reinterpret_cast<urmapx_path_op *>(sc) + (size_t)a * PE_HIT_CAP * PE_HITW1 * URMAPX_MAX_PATH_OPS;
-		hot[a].hit_cap = (hsp_lds_cap >= 64 && hsp_lds_cap <= PE_HSP_CAP) ? (hsp_lds_cap & ~63) / 4 : PE_HIT_CAP * PE_HITW1;
-		hot[a].hit_wsh = (hsp_lds_cap >= 64 && hsp_lds_cap <= PE_HSP_CAP) ? 4 : 6;
-		m[a].hsp_db = to_lds(&hsp_db[a][0]); m[a].hsp_ql = to_lds(&hsp_ql[a][0]); m[a].hsp_sf = to_lds(&hsp_sf[a][0]);
-		m[a].pend[0] = to_lds(&pend[2 * a][0]); m[a].pend[1] = to_lds(&pend[2 * a + 1][0]);
-		m[a].rowlen = to_lds(rowlen); m[a].pre = to_lds(pre); m[a].cq_db = to_lds(cq_db); m[a].cq_qp = to_lds(cq_qp);
-		hot[a].hsp_lds = (hsp_lds_cap >= 64 && hsp_lds_cap <= PE_HSP_CAP) ? (hsp_lds_cap & ~63) : PE_HSP_CAP;
-		hot[a].hsp_ovf = hsp_ovf_base + ((size_t)blockIdx.x * 2 + a) * PE_HSP_OVF_CAP;
-		hot[a].dbg_cut = dbg_stop;
-		m[a].rowstore = reinterpret_cast<uint32_t *>(sc + pe_rowstore_offset(QMAX));
-		m[a].ws.carve(sc + (size_t)2 * PE_HIT_CAP * PE_HITW1 * URMAPX_MAX_PATH_OPS * 2, QMAX, PE_SCAN_SEG + 2 * QMAX + 64);
+		hot(a).hit_cap = (hsp_lds_cap >= 64 && hsp_lds_cap <= PE_HSP_CAP) ? (hsp_lds_cap & ~63) / 4 : PE_HIT_CAP * PE_HITW1;
+		hot(a).hit_wsh = (hsp_lds_cap >= 64 && hsp_lds_cap <= PE_HSP_CAP) ? 4 : 6;
+		hot(a).hsp_lds = (hsp_lds_cap >= 64 && hsp_lds_cap <= PE_HSP_CAP) ? (hsp_lds_cap & ~63) : PE_HSP_CAP;
+		hot(a).hsp_ovf = hsp_ovf_base + ((size_t)blockIdx.x * 2 + a) * PE_HSP_OVF_CAP;
+		hot(a).dbg_cut = dbg_stop;
 	}
 
 	// pairs are handed out by a ticket counter (heavy-tailed cost per pair: the rescue DP), PE_TICKET_CHUNK per ticket
@@ -908,78 +924,64 @@ __global__ __launch_bounds__(64, TIER == 2 ? 1 : URX_PE_WAVES(NCH)) void search_
 			res[a].score = 0; res[a].second = 0; res[a].mapq = 0; res[a].plus = 0; res[a].exit_phase = 0; res[a].status = 0;
 			res[a].hit_count = 0; res[a].path_nops = 0; res[a].path_off = 0;
 			if (QL < W || QL > QMAX || W > 32 || X.maxIx > 32 || QL - (W - 1) > 256) bad = true;  // pending positions are bytes
-			hot[a].QL = QL; hot[a].nwords = QL - (W - 1);
-			m[a].pslots = probe.slots + 2 * off; m[a].ptal = probe.tallies + 2 * off; m[a].ppos = probe.positions + 2 * off;
+			hot(a).QL = QL; hot(a).nwords = QL - (W - 1);
 		}
 		if (bad) {
 			for (int a = 0; a < 2; ++a) { res[a].status = URMAPX_ST_BAD_LENGTH; if (lane == 0) results[2 * pr + a] = res[a]; }
 			continue;
 		}
 		// seed + probe of both mates (round 3: no launch of its own -- this kernel waits on latency with half of its issue
-		// slots idle, so the hashing is free and the 2 x 254 slot gathers overlap the other pairs of the CU).  The entries go
-		// to the batch's probe arrays exactly as seed_probe_kernel writes them; the overflow pass reads the first pass's.
+		// slots idle, so the hashing is free and the 2 x 254 slot gathers overlap the other pairs of the CU).  Round 4: the
+		// entries go to LDS only, in every pass (the later passes used to read what the first had written to HBM).
 		lds_sync();
-		if constexpr (!OVF) {
+		{
 			const uint64_t poff[2] = {offs[2 * pr], offs[2 * pr + 1]};
-			const uint32_t pql[2] = {(uint32_t)hot[0].QL, (uint32_t)hot[1].QL};
-			probe_pair<NCH, QMAX>(X, bases, poff, pql, lane, probe, s_tal, s_pos);
+			const uint32_t pql[2] = {(uint32_t)hot(0).QL, (uint32_t)hot(1).QL};
+			probe_pair<NCH, QMAX>(X, bases, poff, pql, lane, s_tal, s_pos, to_lds(&ml[0].kpl[0][0]), to_lds(&ml[1].kpl[0][0]));
 		}
 		// ---- InitPE x2 (state1.cpp:95-127) ----
+		uint32_t qch[2][2][NCH];  // this lane's bytes of the two mates, both strands (locals: every index below is a constant after unrolling)
+#pragma unroll
 		for (int a = 0; a < 2; ++a) {
 			const uint8_t *q = bases + offs[2 * pr + a];
-			const int QL = hot[a].QL;
+			const int QL = hot(a).QL;
 #pragma unroll
 			for (int c = 0; c < NCH; ++c) {
 				const int p = 64 * c + lane;
 				uint32_t cp = 0, cm = 0;
 				if (p < QL) {
 					cp = q[p]; cm = comp_char(q[QL - 1 - p]);
-					m[a].sQ[0][p] = (uint8_t)cp; m[a].sQ[1][p] = (uint8_t)cm;
+					ml[a].sQ[0][p] = (uint8_t)cp; ml[a].sQ[1][p] = (uint8_t)cm;
 				}
-				m[a].qch[0][c] = cp; m[a].qch[1][c] = cm;
+				qch[a][0][c] = cp; qch[a][1][c] = cm;
 			}
-			if constexpr (OVF) {  // the first pass staged its own probe results (probe_pair); this pass reads what it wrote
-#pragma unroll
-				for (int st = 0; st < 2; ++st) {
-#pragma unroll
-					for (int c = 0; c < NCH; ++c) {
-						const int p = 64 * c + lane;
-						if (p < QL) {
-							const bool in = p < hot[a].nwords;
-							s_tal[a][st][p] = in ? m[a].ptal[(size_t)st * QL + p] : (uint8_t)0;
-							s_pos[a][st][p] = in ? m[a].ppos[(size_t)st * QL + p] : 0xFFFFFFFFu;
-						}
-					}
-				}
-			}
-#pragma unroll
-			for (int w = 0; w < M::HITW; ++w) { m[a].hit_db[w] = 0; m[a].hit_sp[w] = 0; }
-			hot[a].pendCount[0] = hot[a].pendCount[1] = 0;
-			hot[a].hitCount = 0; hot[a].hspCount = 0; hot[a].topHit = -1;
-			hot[a].maxPen = P.max_penalty; hot[a].best = 0; hot[a].second = 0; hot[a].bestHSP = 0;
-			hot[a].mapq = 0xFFFFFFFFu; hot[a].status = 0;
+			hot(a).pendCount[0] = hot(a).pendCount[1] = 0;
+			hot(a).hitCount = 0; hot(a).hspCount = 0; hot(a).topHit = -1;
+			hot(a).maxPen = P.max_penalty; hot(a).best = 0; hot(a).second = 0; hot(a).bestHSP = 0;
+			hot(a).mapq = 0xFFFFFFFFu; hot(a).status = 0;
 		}
 		lds_sync();
 		// both strands of both mates as bit planes (ExtendPen's windows are read from the packed sequence store)
+#pragma unroll
 		for (int a = 0; a < 2; ++a) {
 			uint64_t oth = 0;
 #pragma unroll
 			for (int st = 0; st < 2; ++st) {
 #pragma unroll
 				for (int c = 0; c < NCH; ++c) {
-					if (64 * c < hot[a].QL) {
+					if (64 * c < hot(a).QL) {
 						const int p = 64 * c + lane;
-						const uint32_t code = p < hot[a].QL ? seq_code(m[a].qch[st][c], SEQ_CODE_QOTHER) : 0u;
+						const uint32_t code = p < hot(a).QL ? seq_code(qch[a][st][c], SEQ_CODE_QOTHER) : 0u;
 						const uint64_t b0 = __ballot(code & 1u), b1 = __ballot(code & 2u), b2 = __ballot(code & 4u), b3 = __ballot(code & 8u);
 						oth |= __ballot(code == SEQ_CODE_QOTHER);
 						if (lane < 2) {
 							const int shh = 32 * lane;
-							qpl[2 * a + st][2 * c + lane] = make_uint4((uint32_t)(b0 >> shh), (uint32_t)(b1 >> shh), (uint32_t)(b2 >> shh), (uint32_t)(b3 >> shh));
+							ml[a].qpl[st][2 * c + lane] = make_uint4((uint32_t)(b0 >> shh), (uint32_t)(b1 >> shh), (uint32_t)(b2 >> shh), (uint32_t)(b3 >> shh));
 						}
 					}
 				}
 			}
-			hot[a].q_other = oth != 0;
+			hot(a).q_other = oth != 0;
 		}
 		lds_sync();
 
@@ -991,7 +993,7 @@ __global__ __launch_bounds__(64, TIER == 2 ? 1 : URX_PE_WAVES(NCH)) void search_
 		// the last seed returned" (getseed.cpp:60-66,118-124), and because a skipped seed has that very diagonal, it is
 		// the same as "skip a seed on the diagonal of the previous BOTH1 candidate": a neighbour comparison.
 		for (int a = 0; a < 2; ++a) {
-			const int QWC = hot[a].nwords;
+			const int QWC = hot(a).nwords;
 			int ns = 0, np = 0, nm = 0;
 			bool have = false;
 			uint32_t lastDiag = 0;
@@ -1022,8 +1024,8 @@ __global__ __launch_bounds__(64, TIER == 2 ? 1 : URX_PE_WAVES(NCH)) void search_
 				const bool pendM = (Tm & TALLY_MY_BIT) != 0 && ((!candM && !retP) || (candM && !retM && retP));
 				const uint64_t mp = __ballot(pendP), mmn = __ballot(pendM);
 				const uint64_t lt = (1ull << lane) - 1ull;
-				if (pendP) m[a].pend[0][np + __builtin_popcountll(mp & lt)] = (uint8_t)qpos;
-				if (pendM) m[a].pend[1][nm + __builtin_popcountll(mmn & lt)] = (uint8_t)qpos;
+				if (pendP) ml[a].pend[0][np + __builtin_popcountll(mp & lt)] = (uint8_t)qpos;
+				if (pendM) ml[a].pend[1][nm + __builtin_popcountll(mmn & lt)] = (uint8_t)qpos;
 				np += __builtin_popcountll(mp); nm += __builtin_popcountll(mmn);
 				const int nret = (retP ? 1 : 0) + (retM ? 1 : 0);
 				const int inc = wave_prefix_sum(nret);
@@ -1037,15 +1039,15 @@ __global__ __launch_bounds__(64, TIER == 2 ? 1 : URX_PE_WAVES(NCH)) void search_
 					lastDiag = (uint32_t)__shfl((int)lastHere, 63 - __builtin_clzll(anyc));
 				}
 			}
-			if (ns > SEED_CAP) { ns = SEED_CAP; hot[a].status |= URMAPX_ST_HSP_OVERFLOW; }
+			if (ns > SEED_CAP) { ns = SEED_CAP; hot(a).status |= URMAPX_ST_HSP_OVERFLOW; }
 			nseed[a] = ns;
-			hot[a].pendCount[0] = np; hot[a].pendCount[1] = nm;
+			hot(a).pendCount[0] = np; hot(a).pendCount[1] = nm;
 		}
 		URX_SYNC();
 
 		// ---- seed gather: the ExtendPen outcome of every seed, one seed per lane ----
 		for (int a = 0; a < 2; ++a) {
-			const int QL = hot[a].QL;
+			const int QL = hot(a).QL;
 			const int minhsp = (int)((uint32_t)P.min_hsp_score_pct * (uint32_t)QL / 100.0);
 			for (int base = 0; base < nseed[a]; base += 64) {
 				const int i = base + lane;
@@ -1056,7 +1058,7 @@ __global__ __launch_bounds__(64, TIER == 2 ? 1 : URX_PE_WAVES(NCH)) void search_
 					const bool plus = (seed_q[a][i] & 0x8000u) != 0;
 					if (db >= q) {
 						uint64_t mm[NCH];
-						m[a].lane_mask(db - q, plus, mm);
+						mate(a).lane_mask(db - q, plus, mm);
 						int bst, sp, ep;
 						xdrop_walk_lane<NCH>(mm, (int)q, W, QL, P.mismatch_score, P.xdrop, P.max_penalty, bst, sp, ep, pen);  // cached for any later cap: bounded by the initial one
 						const uint32_t kind = (sp == 0 && ep == QL - 1) ? 1u : (bst >= minhsp ? 2u : 0u);
@@ -1073,7 +1075,7 @@ __global__ __launch_bounds__(64, TIER == 2 ? 1 : URX_PE_WAVES(NCH)) void search_
 		auto extend_seed = [&](int a, int i) -> int {
 			const uint32_t sq = seed_q[a][i];
 			const uint32_t pn = seed_pen[a][i];
-			const int r = m[a].extend_pen_cached(sq & 0x7FFFu, seed_db[a][i], (sq & 0x8000u) != 0, seed_res[a][i], (int)(pn & 0x7FFFu));
+			const int r = mate(a).extend_pen_cached(sq & 0x7FFFu, seed_db[a][i], (sq & 0x8000u) != 0, seed_res[a][i], (int)(pn & 0x7FFFu));
 			if ((pn & 0x8000u) == 0) {
 				URX_SYNC();
 				if (lane == 0) seed_pen[a][i] = (uint16_t)(pn | 0x8000u);
@@ -1087,7 +1089,7 @@ __global__ __launch_bounds__(64, TIER == 2 ? 1 : URX_PE_WAVES(NCH)) void search_
 		auto extend_seed_as = [&](int a, int i, bool plus_req) -> int {
 			const uint32_t sq = seed_q[a][i];
 			if (((sq & 0x8000u) != 0) == plus_req) return extend_seed(a, i);
-			return m[a].extend_pen(sq & 0x7FFFu, seed_db[a][i], plus_req);
+			return mate(a).extend_pen(sq & 0x7FFFu, seed_db[a][i], plus_req);
 		};
 		// Lanes = seeds base.. of mate a: true where a repeated ExtendPen on that seed is certain to return <= 0 without
 		// changing anything: it has been extended before, and it is not a full-length hit, or its penalty exceeds the
@@ -1101,13 +1103,13 @@ __global__ __launch_bounds__(64, TIER == 2 ? 1 : URX_PE_WAVES(NCH)) void search_
 				const uint32_t pn = seed_pen[a][i], res = seed_res[a][i];
 				const uint32_t q = seed_q[a][i] & 0x7FFFu, db = seed_db[a][i];
 				if ((pn & 0x8000u) && ((seed_q[a][i] & 0x8000u) != 0) == plus_req)
-					st = db < q || (res >> 27) != 1u || (int)(pn & 0x7FFFu) > hot[a].maxPen || m[a].overlaps_any_hit(db - q);
+					st = db < q || (res >> 27) != 1u || (int)(pn & 0x7FFFu) > hot(a).maxPen || mate(a).overlaps_any_hit(db - q);
 			}
 			return __ballot(st);
 		};
 
 		// ---- Search4 pairing loop (search2m4.cpp:71-143) ----
-		const int QLf = hot[0].QL, QLr = hot[1].QL;
+		const int QLf = hot(0).QL, QLr = hot(1).QL;
 		const int64_t QL2 = (int64_t)((QLf + QLr) / 2);
 		const int termPair = QLf + QLr + 5 * P.mismatch_score;
 		bool done = false;
@@ -1143,7 +1145,7 @@ __global__ __launch_bounds__(64, TIER == 2 ? 1 : URX_PE_WAVES(NCH)) void search_
 							const int rs = extend_seed_as(1, i, !plusf);
 							if (rs <= 0) continue;
 							if (fs + rs < termPair) continue;
-							hot[0].mapq = 40; hot[1].mapq = 40; done = true;
+							hot(0).mapq = 40; hot(1).mapq = 40; done = true;
 						}
 					}
 				}
@@ -1164,7 +1166,7 @@ __global__ __launch_bounds__(64, TIER == 2 ? 1 : URX_PE_WAVES(NCH)) void search_
 							const int rs = extend_seed(1, t);
 							if (rs <= 0) continue;
 							if (fs + rs < termPair) continue;
-							hot[0].mapq = 40; hot[1].mapq = 40; done = true;
+							hot(0).mapq = 40; hot(1).mapq = 40; done = true;
 						}
 					}
 				}
@@ -1176,6 +1178,7 @@ __global__ __launch_bounds__(64, TIER == 2 ? 1 : URX_PE_WAVES(NCH)) void search_
 		int bestF = -1, bestR = -1, secF = -1, secR = -1;
 		int secondHit[2] = {-1, -1};  // m_SecondHit of the mates (set by AdjustTopHitsAndMapqs only)
 		if (dbg_stop == 2) done = true;
+		bool vf_pending = false;
 		if (!done) {
 			// all collected seeds, each mate (search2m4.cpp:145-158)
 			// (a seed extended before changes nothing when extended again, see settled(); only the others are visited)
@@ -1191,34 +1194,36 @@ __global__ __launch_bounds__(64, TIER == 2 ? 1 : URX_PE_WAVES(NCH)) void search_
 				}
 			if (veryfast) {
 				// Search5 (search2m5.cpp:112-127): no 90 % shortcut and no pair stage; each mate finishes on its own
-				m[0].search_pending();
-				m[1].search_pending();
-				done = true;
-			} else if (hot[0].best >= (QLf * 9) / 10 && hot[1].best >= (QLr * 9) / 10 && hot[0].topHit >= 0 && hot[1].topHit >= 0) {
-				int64_t d = (int64_t)m[0].hdb(hot[0].topHit) - (int64_t)m[1].hdb(hot[1].topHit);
+				vf_pending = true;
+			} else if (hot(0).best >= (QLf * 9) / 10 && hot(1).best >= (QLr * 9) / 10 && hot(0).topHit >= 0 && hot(1).topHit >= 0) {
+				int64_t d = (int64_t)mate(0).hdb(hot(0).topHit) - (int64_t)mate(1).hdb(hot(1).topHit);
 				if (d < 0) d = -d;
-				if (d + QL2 <= MAX_TL) { hot[0].mapq = 40; hot[1].mapq = 40; done = true; }
+				if (d + QL2 <= MAX_TL) { hot(0).mapq = 40; hot(1).mapq = 40; done = true; }
 			}
 		}
-		if (dbg_stop == 3) done = true;
+		if (dbg_stop == 3 && !vf_pending) done = true;
 		if (!done) {
-			m[0].search_pending();
-			m[1].search_pending();
+			// SearchPE_Pending of the forward mate, then of the reverse mate: one copy of the code, the mate is an LDS address
+#pragma unroll 1
+			for (int a = 0; a < 2; ++a) mate(a).search_pending();
+		}
+		if (vf_pending) done = true;
+		if (!done) {
 			if (dbg_stop == 4 || (dbg_stop >= 41 && dbg_stop <= 43)) goto pe_output;
 			// FindPairs (state2.cpp:20-85), ScanPair if there is none (state2.cpp:87-137), FindPairs again
 			for (int attempt = 0; attempt < 2; ++attempt) {
 				npairs_found = 0; bestPairScore = -1; secondPairScore = -1; bestPairIndex = -1; secondPairIndex = -1;
 				bestF = bestR = secF = secR = -1;
-				for (int i = 0; i < hot[0].hitCount; ++i) {
-					const uint32_t spf = m[0].hsp_of(i);
+				for (int i = 0; i < hot(0).hitCount; ++i) {
+					const uint32_t spf = mate(0).hsp_of(i);
 					const int sf = (int)(spf >> 1);
-					if (sf < hot[0].second - 12) continue;
-					const int64_t dbf = (int64_t)m[0].hdb(i);
-					for (int j = 0; j < hot[1].hitCount; ++j) {
-						const uint32_t spr = m[1].hsp_of(j);
+					if (sf < hot(0).second - 12) continue;
+					const int64_t dbf = (int64_t)mate(0).hdb(i);
+					for (int j = 0; j < hot(1).hitCount; ++j) {
+						const uint32_t spr = mate(1).hsp_of(j);
 						const int sr = (int)(spr >> 1);
-						if (sr < hot[1].second - 12) continue;
-						int64_t d = dbf - (int64_t)m[1].hdb(j);
+						if (sr < hot(1).second - 12) continue;
+						int64_t d = dbf - (int64_t)mate(1).hdb(j);
 						if (d < 0) d = -d;
 						if (d + QL2 > 1000) continue;
 						if ((spf & 1u) == (spr & 1u)) continue;
@@ -1234,25 +1239,31 @@ __global__ __launch_bounds__(64, TIER == 2 ? 1 : URX_PE_WAVES(NCH)) void search_
 				URX_SYNC();
 				if (npairs_found > 0 || attempt == 1) break;
 				// ScanPair
-				const bool dovitF = (int)hot[0].mapq >= 10 && dbg_stop != 5, dovitR = (int)hot[1].mapq >= 10 && dbg_stop != 5;  // 5: diagnostic, no rescue DP
-				const int hcf = hot[0].hitCount, hcr = hot[1].hitCount;
-				for (int i = 0; i < hcf; ++i) {
-					const uint32_t sp = m[0].hsp_of(i);
-					if ((int)(sp >> 1) < hot[0].second) continue;
-					const uint32_t db = m[0].hdb(i);
-					if (sp & 1u) m[1].scan(db, PE_SCAN_SEG, false, dovitF);
-					else if (db >= (uint32_t)PE_SCAN_SEG) m[1].scan(db - PE_SCAN_SEG, PE_SCAN_SEG + 2 * (uint32_t)QLf, true, dovitF);
-				}
-				for (int j = 0; j < hcr; ++j) {
-					const uint32_t sp = m[1].hsp_of(j);
-					if ((int)(sp >> 1) < hot[1].second) continue;
-					const uint32_t db = m[1].hdb(j);
-					if (sp & 1u) m[0].scan(db, PE_SCAN_SEG, false, dovitR);
-					else if (db >= (uint32_t)PE_SCAN_SEG) m[0].scan(db - PE_SCAN_SEG, PE_SCAN_SEG + 2 * (uint32_t)QLf, true, dovitR);
+				const bool dovitF = (int)hot(0).mapq >= 10 && dbg_stop != 5, dovitR = (int)hot(1).mapq >= 10 && dbg_stop != 5;  // 5: diagnostic, no rescue DP
+				const int hcf = hot(0).hitCount, hcr = hot(1).hitCount;
+				// the forward mate's hits scanned for on the reverse mate, then the other way round (state2.cpp:100-136; both use
+				// the FORWARD read's length for the minus-strand segment, as the reference does): one call site, so Scan and
+				// everything under it exists once
+#pragma unroll 1
+				for (int dir = 0; dir < 2; ++dir) {
+					const int hc = dir == 0 ? hcf : hcr;
+					const bool dovit = dir == 0 ? dovitF : dovitR;
+					for (int i = 0; i < hc; ++i) {
+						const uint32_t sp = mate(dir).hsp_of(i);
+						if ((int)(sp >> 1) < hot(dir).second) continue;
+						const uint32_t db = mate(dir).hdb(i);
+						uint32_t sdb = db, slen = PE_SCAN_SEG;
+						bool splus = false;
+						if ((sp & 1u) == 0) {
+							if (db < (uint32_t)PE_SCAN_SEG) continue;
+							sdb = db - PE_SCAN_SEG; slen = PE_SCAN_SEG + 2 * (uint32_t)QLf; splus = true;
+						}
+						mate(1 - dir).scan(sdb, slen, splus, dovit);
+					}
 				}
 			}
 			// AdjustTopHitsAndMapqs (search2.cpp:8-57)
-			if (npairs_found == 0) { hot[0].mapq /= 2; hot[1].mapq /= 2; }
+			if (npairs_found == 0) { hot(0).mapq /= 2; hot(1).mapq /= 2; }
 			else {
 				const double fract = (double)bestPairScore / (double)(QLf + QLr);
 				double drop = (double)(bestPairScore - secondPairScore);
@@ -1261,9 +1272,9 @@ __global__ __launch_bounds__(64, TIER == 2 ? 1 : URX_PE_WAVES(NCH)) void search_
 				x = x * fract;
 				uint32_t mq = (uint32_t)x;
 				if (mq > 40) mq = 40;
-				if (mq > hot[0].mapq) hot[0].mapq = mq;
-				if (mq > hot[1].mapq) hot[1].mapq = mq;
-				if (bestPairIndex >= 0) { hot[0].topHit = bestF; hot[1].topHit = bestR; }
+				if (mq > hot(0).mapq) hot(0).mapq = mq;
+				if (mq > hot(1).mapq) hot(1).mapq = mq;
+				if (bestPairIndex >= 0) { hot(0).topHit = bestF; hot(1).topHit = bestR; }
 				if (secondPairIndex >= 0) { secondHit[0] = secF; secondHit[1] = secR; }
 			}
 		}
@@ -1274,13 +1285,13 @@ __global__ __launch_bounds__(64, TIER == 2 ? 1 : URX_PE_WAVES(NCH)) void search_
 			for (int a = 0; a < 2; ++a) {
 				pi.top_db[a] = 0xFFFFFFFFu; pi.second_db[a] = 0xFFFFFFFFu;
 				pi.top_score[a] = 0; pi.second_score[a] = 0; pi.top_plus[a] = 0; pi.second_plus[a] = 0;
-				if (hot[a].topHit >= 0) {
-					const uint32_t sp = m[a].hsp_of(hot[a].topHit);
-					pi.top_db[a] = m[a].hdb(hot[a].topHit); pi.top_score[a] = (int16_t)(sp >> 1); pi.top_plus[a] = (uint8_t)(sp & 1u);
+				if (hot(a).topHit >= 0) {
+					const uint32_t sp = mate(a).hsp_of(hot(a).topHit);
+					pi.top_db[a] = mate(a).hdb(hot(a).topHit); pi.top_score[a] = (int16_t)(sp >> 1); pi.top_plus[a] = (uint8_t)(sp & 1u);
 				}
 				if (secondHit[a] >= 0) {
-					const uint32_t sp = m[a].hsp_of(secondHit[a]);
-					pi.second_db[a] = m[a].hdb(secondHit[a]); pi.second_score[a] = (int16_t)(sp >> 1); pi.second_plus[a] = (uint8_t)(sp & 1u);
+					const uint32_t sp = mate(a).hsp_of(secondHit[a]);
+					pi.second_db[a] = mate(a).hdb(secondHit[a]); pi.second_score[a] = (int16_t)(sp >> 1); pi.second_plus[a] = (uint8_t)(sp & 1u);
 				}
 			}
 			if (lane == 0) pair_info[pr] = pi;
@@ -1288,12 +1299,12 @@ __global__ __launch_bounds__(64, TIER == 2 ? 1 : URX_PE_WAVES(NCH)) void search_
 		// ---- per-mate output: SetMappedPos (state1.cpp:129-145) ----
 		for (int a = 0; a < 2; ++a) {
 			urmapx_result &R = res[a];
-			R.mapq = (uint8_t)(hot[a].mapq > 255 ? 255 : hot[a].mapq);
-			R.second = (int16_t)hot[a].second; R.hit_count = (uint16_t)hot[a].hitCount; R.status = (uint8_t)(hot[a].status | hot[1 - a].status);
+			R.mapq = (uint8_t)(hot(a).mapq > 255 ? 255 : hot(a).mapq);
+			R.second = (int16_t)hot(a).second; R.hit_count = (uint16_t)hot(a).hitCount; R.status = (uint8_t)(hot(a).status | hot(1 - a).status);
 			R.exit_phase = done ? 1 : 2;
-			if (hot[a].topHit >= 0) {
-				const uint32_t db = m[a].hdb(hot[a].topHit);
-				const uint32_t sp = m[a].hsp_of(hot[a].topHit);
+			if (hot(a).topHit >= 0) {
+				const uint32_t db = mate(a).hdb(hot(a).topHit);
+				const uint32_t sp = mate(a).hsp_of(hot(a).topHit);
 				R.score = (int16_t)(sp >> 1);
 				uint32_t lo = 0, hi = X.seqCount - 1;
 				uint32_t found = 0xFFFFFFFFu, coord = 0xFFFFFFFFu, tl = 0;
@@ -1304,14 +1315,14 @@ __global__ __launch_bounds__(64, TIER == 2 ? 1 : URX_PE_WAVES(NCH)) void search_
 					if (db > o) lo = k + 1;
 					else hi = k - 1;
 				}
-				if (found != 0xFFFFFFFFu && coord + (uint32_t)hot[a].QL <= tl) {
+				if (found != 0xFFFFFFFFu && coord + (uint32_t)hot(a).QL <= tl) {
 					R.dbpos = db; R.seq_index = found; R.coord = coord; R.plus = (uint8_t)(sp & 1u);
-					const int nops = m[a].hit_nops[hot[a].topHit];
+					const int nops = ml[a].hit_nops[hot(a).topHit];
 					if (nops > 0) {
 						uint32_t po = 0;
 						if (lane == 0) po = atomicAdd(path_used, (uint32_t)nops);
 						po = uni(po);
-						for (int t = lane; t < nops; t += 64) path_ops[po + t] = hot[a].hit_paths[(size_t)hot[a].topHit * URMAPX_MAX_PATH_OPS + t];
+						for (int t = lane; t < nops; t += 64) path_ops[po + t] = hot(a).hit_paths[(size_t)hot(a).topHit * URMAPX_MAX_PATH_OPS + t];
 						R.path_off = po; R.path_nops = (uint16_t)nops;
 					}
 				}
@@ -1319,16 +1330,18 @@ __global__ __launch_bounds__(64, TIER == 2 ? 1 : URX_PE_WAVES(NCH)) void search_
 			if (lane == 0) results[2 * pr + a] = R;
 		}
 		if constexpr (TIER == 0) {
-			if ((hot[0].status | hot[1].status) & (URMAPX_ST_HSP_OVERFLOW | URMAPX_ST_HIT_OVERFLOW)) {  // queue the pair for the second pass
+			if ((hot(0).status | hot(1).status) & (URMAPX_ST_HSP_OVERFLOW | URMAPX_ST_HIT_OVERFLOW)) {  // queue the pair for the second pass
 				if (lane == 0) ovf_next[1 + atomicAdd(ovf_next, 1u)] = pr;
 			}
 		} else if constexpr (TIER == 1) {
-			if ((hot[0].status | hot[1].status) & URMAPX_ST_HIT_OVERFLOW) {  // more than 256 hits on a mate: the third pass
+			if ((hot(0).status | hot(1).status) & URMAPX_ST_HIT_OVERFLOW) {  // more than 256 hits on a mate: the third pass
 				if (lane == 0) ovf_next[1 + atomicAdd(ovf_next, 1u)] = pr;
 			}
 		}
 	}
 }
+
+#undef hot
 
 static int pe_nch_for(uint32_t max_read_len) {
 	return max_read_len <= 128 ? 2 : max_read_len <= 192 ? 3 : max_read_len <= 256 ? 4 : max_read_len <= 320 ? 5 : 0;
@@ -1368,7 +1381,7 @@ int search_pe_block_count(uint32_t max_read_len, int device) {
 }
 
 hipError_t launch_search_pe(const DevIndex &X, const urmapx_params &P, const uint8_t *d_bases, const uint64_t *d_offs,
-                            uint32_t npairs, uint32_t max_read_len, ProbeOut probe, urmapx_result *d_results,
+                            uint32_t npairs, uint32_t max_read_len, urmapx_result *d_results,
                             urmapx_path_op *d_path_ops, uint32_t *d_path_used, const SearchWork &wk, int veryfast,
                             urmapx_pair_info *pair_info, hipStream_t s) {
 	if (npairs == 0) return hipSuccess;
@@ -1385,7 +1398,7 @@ hipError_t launch_search_pe(const DevIndex &X, const urmapx_params &P, const uin
 	const int nch = pe_nch_for(max_read_len);
 	uint2 *const ovf_base = reinterpret_cast<uint2 *>(wk.scratch + (size_t)wk.blocks * wk.scratch_stride);  // HSP lists beyond LDS
 #define URX_LAUNCH_PE(NCH_, TIER_, GRID_, IN_, OUT_)                                                                          \
-	hipLaunchKernelGGL((search_pe_kernel<NCH_, TIER_>), GRID_, block, 0, s, X, P, d_bases, d_offs, npairs, probe, d_results,      \
+	hipLaunchKernelGGL((search_pe_kernel<NCH_, TIER_>), GRID_, block, 0, s, X, P, d_bases, d_offs, npairs, d_results,      \
 	                   d_path_ops, d_path_used, wk.scratch, wk.scratch_stride, X.seq, X.blob, X.seqp, veryfast, wk.ticket,        \
 	                   pair_info, wk.hsp_lds_cap, IN_, OUT_, ovf_base, pe_hsp_area_blocks(wk.blocks))
 #define URX_LAUNCH_PE_TIER(TIER_, GRID_, IN_, OUT_)                                                                            \

@@ -94,12 +94,18 @@ __device__ __forceinline__ void probe_read(const DevIndex &X, const uint8_t *__r
 
 // Both mates of a pair by one wavefront, as search_pe_kernel wants them at the start of a pair: the bytes of the two mates
 // are requested together, then all slot numbers are hashed, then every slot load of the pair is in flight at once (one
-// memory round trip for the pair instead of one per mate), and the entries go to the batch's probe arrays (read again by
-// the pending stage, much later) AND straight into the kernel's LDS staging tables s_tal / s_pos ([mate][strand][qpos];
-// 0 / 0xFFFFFFFF beyond the last k-mer start), so nothing waits for the stores.
+// memory round trip for the pair instead of one per mate), and the entries go straight into the kernel's LDS staging
+// tables s_tal / s_pos ([mate][strand][qpos]; 0 / 0xFFFFFFFF beyond the last k-mer start).
+// Round 4: nothing is written to HBM.  (Round 3 also stored slot / tally / position of every k-mer in the batch's probe
+// arrays -- 13 B x 2 x 254 per pair, a third of the kernel's WRITE_SIZE -- for the pending stage and the rescue scan, which
+// run long after the staging tables have been reused.)  What those stages need is the slot NUMBER of a few k-mers, and that
+// is a function of the read: the letter planes of the two mates are kept in LDS (kpl[mate][plane][chunk]: low bit, high
+// bit, not-a-letter, not-a-letter on the minus strand; 32 B per 64 bases) and slot_from_planes() re-derives a slot where it
+// is needed; its tally and position are read from the table again (the first hop of the chain walk).
 template <int NCH, int QMAX>
 __device__ __forceinline__ void probe_pair(const DevIndex &X, const uint8_t *__restrict__ bases, const uint64_t (&off)[2], const uint32_t (&QL)[2],
-                                           int lane, const ProbeOut &out, uint8_t (*__restrict__ s_tal)[2][QMAX], uint32_t (*__restrict__ s_pos)[2][QMAX]) {
+                                           int lane, uint8_t (*__restrict__ s_tal)[2][QMAX], uint32_t (*__restrict__ s_pos)[2][QMAX],
+                                           lds_ptr<uint64_t> kpl0, lds_ptr<uint64_t> kpl1) {
 	const uint32_t W = X.W;
 	uint32_t chv[2][NCH];
 #pragma unroll
@@ -124,6 +130,11 @@ __device__ __forceinline__ void probe_pair(const DevIndex &X, const uint8_t *__r
 		}
 		lo[a][NCH] = hi[a][NCH] = 0;
 		inv[a][NCH] = invm[a][NCH] = ~0ull;
+		if (lane == 0) {
+			const lds_ptr<uint64_t> k = a ? kpl1 : kpl0;
+#pragma unroll
+			for (int c = 0; c <= NCH; ++c) { k[c] = lo[a][c]; k[(NCH + 1) + c] = hi[a][c]; k[2 * (NCH + 1) + c] = inv[a][c]; k[3 * (NCH + 1) + c] = invm[a][c]; }
+		}
 	}
 	uint64_t sp[2][NCH], sm[2][NCH];
 	uint32_t rp[2][NCH][2], rm[2][NCH][2];
@@ -157,7 +168,6 @@ __device__ __forceinline__ void probe_pair(const DevIndex &X, const uint8_t *__r
 #pragma unroll
 	for (int a = 0; a < 2; ++a) {
 		const uint32_t nwords = QL[a] - (W - 1);
-		const uint64_t base2 = 2ull * off[a];
 #pragma unroll
 		for (int c = 0; c < NCH; ++c) {
 			const uint32_t p = 64u * c + lane;
@@ -165,15 +175,8 @@ __device__ __forceinline__ void probe_pair(const DevIndex &X, const uint8_t *__r
 				const uint64_t xp = (((uint64_t)rp[a][c][1] << 32) | rp[a][c][0]) >> (8u * (uint32_t)((5ull * sp[a][c]) & 3ull));
 				const uint64_t xm = (((uint64_t)rm[a][c][1] << 32) | rm[a][c][0]) >> (8u * (uint32_t)((5ull * sm[a][c]) & 3ull));
 				const uint32_t pm = QL[a] - W - p;  // minus-strand position of the k-mer over the same bases
-				const uint64_t ip = base2 + p, im = base2 + QL[a] + pm;
 				const uint8_t tp = vp[a][c] ? (uint8_t)(xp & 0xFF) : (uint8_t)TALLY_FREE, tm = vm[a][c] ? (uint8_t)(xm & 0xFF) : (uint8_t)TALLY_FREE;
 				const uint32_t pp = vp[a][c] ? (uint32_t)(xp >> 8) : 0xFFFFFFFFu, pmn = vm[a][c] ? (uint32_t)(xm >> 8) : 0xFFFFFFFFu;
-				out.slots[ip] = vp[a][c] ? sp[a][c] : ~0ull;
-				out.tallies[ip] = tp;
-				out.positions[ip] = pp;
-				out.slots[im] = vm[a][c] ? sm[a][c] : ~0ull;
-				out.tallies[im] = tm;
-				out.positions[im] = pmn;
 				s_tal[a][0][p] = tp; s_pos[a][0][p] = pp;
 				s_tal[a][1][pm] = tm; s_pos[a][1][pm] = pmn;
 			} else if (p < QL[a]) {
@@ -182,6 +185,30 @@ __device__ __forceinline__ void probe_pair(const DevIndex &X, const uint8_t *__r
 			}
 		}
 	}
+}
+
+// The slot of the k-mer at query position q of strand s (0 plus, 1 minus) of a read whose letter planes probe_pair left in
+// LDS (kpl: [plane][NCHP1] words, planes lo / hi / inv / invm), each lane its own (s, q).  ~0 where there is no k-mer
+// (a letter outside ACGTU in it, or q beyond the last k-mer start) -- State1::SetSlotsVec's UINT64_MAX (state1.cpp:396-438).
+template <int NCHP1>
+__device__ __forceinline__ uint64_t slot_from_planes(const DevIndex &X, lds_ptr<const uint64_t> kpl, uint32_t nwords, int s, uint32_t q) {
+	const uint32_t W = X.W;
+	if (q >= nwords) return ~0ull;
+	const uint32_t p = s ? nwords - 1u - q : q;  // the plus-strand position of the k-mer's first base
+	const uint32_t c = p >> 6, sh = p & 63u;
+	const uint64_t wmask = (W >= 32) ? 0xFFFFFFFFull : ((1ull << W) - 1ull);
+	auto cut = [&](int plane) -> uint64_t {
+		const uint64_t w0 = kpl[plane * NCHP1 + c], w1 = kpl[plane * NCHP1 + c + 1];  // c + 1 <= NCH: the last word is the pad
+		uint64_t f = w0 >> sh;
+		if (sh) f |= w1 << (64u - sh);
+		return f & wmask;
+	};
+	const uint64_t flo = cut(0), fhi = cut(1), fbad = cut(s ? 3 : 2);
+	if (fbad) return ~0ull;
+	uint64_t w;
+	if (s == 0) w = spread32(__brevll(flo) >> (64 - W)) | (spread32(__brevll(fhi) >> (64 - W)) << 1);
+	else w = spread32(~flo & wmask) | (spread32(~fhi & wmask) << 1);
+	return mod_slots(murmur64(w & X.shiftMask), X.slotCount, X.slotMagic);
 }
 
 }  // namespace urx

@@ -463,7 +463,7 @@ int urmapx_map_se_device(urmapx_ctx *C, const void *d_bases, const void *d_offs,
 	// seed + probe run inside the search kernel (kernels.hip): ev[0]..ev[1] brackets nothing for a single-end batch
 	HIP_TRY(hipEventRecord(C->ev[0], C->stream));
 	HIP_TRY(hipEventRecord(C->ev[1], C->stream));
-	C->stage_valid = stamps;
+	C->stage_valid = stamps && n > 0;  // an empty batch records no stage events (launch_search_se returns at once)
 	HIP_TRY(launch_search_se(C->X, C->params, (const uint8_t *)d_bases, (const uint64_t *)d_offs, n, max_read_len,
 	                         (urmapx_result *)d_results, (urmapx_path_op *)d_path_ops, (uint32_t *)d_path_used, wk, C->stream));
 	{  // reads outside the fast kernels' domain: the general kernel (it finds its work list on the device; usually empty)
@@ -547,8 +547,9 @@ int urmapx_map_pe_device(urmapx_ctx *C, const void *d_bases, const void *d_offs,
 	if (!C || (npairs && (!d_bases || !d_offs || !d_results || !d_path_ops || !d_path_used))) return URMAPX_E_ARG;
 	if (max_read_len > MAX_QL_PE || npairs > 0x7FFFFFFFu) return URMAPX_E_UNSUPPORTED;
 	HIP_TRY(hipSetDevice(C->device));
-	int rc = ensure_probe(C, total_bases);
-	if (rc) return rc;
+	int rc;
+	(void)total_bases;
+	C->stage_valid = false;  // the stage stamps are a single-end batch's: none of an earlier batch may be reported for this one
 	const int cls = max_read_len <= 128 ? 3 : max_read_len <= 192 ? 0 : (max_read_len <= 256 ? 2 : 1);
 	if (C->pe_blocks[cls] == 0) C->pe_blocks[cls] = search_pe_block_count(max_read_len, C->device);
 	if (C->pe_blocks[cls] <= 0) return URMAPX_E_NODEVICE;
@@ -563,11 +564,9 @@ int urmapx_map_pe_device(urmapx_ctx *C, const void *d_bases, const void *d_offs,
 	wk.stats = nullptr;
 	if ((rc = C->statsbuf.ensure(64))) return rc;
 	wk.ticket = C->statsbuf.p + 62;
-	ProbeOut po{C->slots.p, C->tallies.p, C->positions.p};
 	HIP_TRY(hipMemsetAsync(d_path_used, 0, 4, C->stream));
-	// positions the probe kernel does not write (qpos > L-W) must read as "no k-mer"
-	HIP_TRY(hipMemsetAsync(C->tallies.p, 0, 2 * total_bases, C->stream));
-	// seed + probe run inside search_pe_kernel (round 3); the two stamps bracket nothing and stay for urmapx_ctx_stage_ms
+	// seed + probe run inside search_pe_kernel (round 3; round 4: without probe arrays in HBM); the two stamps bracket
+	// nothing and stay for urmapx_ctx_stage_ms
 	HIP_TRY(hipEventRecord(C->ev[0], C->stream));
 	HIP_TRY(hipEventRecord(C->ev[1], C->stream));
 	urmapx_params Ppe = C->params;
@@ -578,7 +577,7 @@ int urmapx_map_pe_device(urmapx_ctx *C, const void *d_bases, const void *d_offs,
 		d_info = C->pairinfo.p;
 		C->pairinfo_n = npairs;
 	}
-	HIP_TRY(launch_search_pe(C->X, Ppe, (const uint8_t *)d_bases, (const uint64_t *)d_offs, npairs, max_read_len, po,
+	HIP_TRY(launch_search_pe(C->X, Ppe, (const uint8_t *)d_bases, (const uint64_t *)d_offs, npairs, max_read_len,
 	                         (urmapx_result *)d_results, (urmapx_path_op *)d_path_ops, (uint32_t *)d_path_used, wk,
 	                         C->pe_veryfast | (getenv("URMAPX_DEBUG_STOP_PE") ? atoi(getenv("URMAPX_DEBUG_STOP_PE")) << 8 : 0), d_info, C->stream));  // bits 8..: diagnostic schedule cut
 	HIP_TRY(hipEventRecord(C->ev[2], C->stream));
