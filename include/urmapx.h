@@ -35,7 +35,8 @@ extern "C" {
 /* Single-end: a read the fast kernels flag is mapped again by the general kernel (lists in global memory), so these
  * remain only beyond ITS limits: 65536 live hits, 65536..262144 HSPs, a batch's path arena full, a flank window clipped
  * by the end of the sequence store with a band beyond 1100 columns, a read shorter than the word length (the reference
- * underflows there) or longer than URMAPX_MAX_QL_SLOW.  Paired-end: 1024 hits per mate (third pass), 8192 HSPs per mate, 96 runs. */
+ * underflows there) or longer than URMAPX_MAX_QL_SLOW (where the reference stops with an assertion).  Paired-end: none either since
+ * round 4 (the general pair kernel, kernels_pe_slow.hip), except mates beyond the reference's own byte-sized pending positions. */
 #define URMAPX_ST_HIT_OVERFLOW 0x01 /* more live hits than the device lists hold */
 #define URMAPX_ST_HSP_OVERFLOW 0x02 /* more HSPs than the device lists hold */
 #define URMAPX_ST_PATH_OVERFLOW 0x04 /* alignment path longer than the path storage */
@@ -43,7 +44,7 @@ extern "C" {
 #define URMAPX_ST_BAD_LENGTH 0x10    /* read shorter than the word length or longer than the kernels take */
 
 #define URMAPX_MAX_QL 1024    /* single-end reads the fast kernels take.  Paired-end mates: at most 320 bases AND at most 256 k-mer starts (QL - W + 1 <= 256: the reference keeps pending seed positions in a byte, state1.h:86-87), i.e. 279 bases at the default word length 24 */
-#define URMAPX_MAX_QL_SLOW 16000 /* single-end reads the general kernel takes (lists in global memory; the reference's own scratch ends near 30 kb, state1.h:113) */
+#define URMAPX_MAX_QL_SLOW 30836 /* single-end reads the general kernel takes (lists in global memory): the reference's own limit -- its per-read scratch is a 1 MB bump allocator (state1.h:113,208-213) that a read of 30 837 bases overruns ("assert failed: m_AllocBuffOffset <= m_AllocBuffSize", measured with the reference binary) */
 #define URMAPX_MAX_PATH_OPS 96
 
 typedef struct urmapx_index urmapx_index;
@@ -251,6 +252,14 @@ typedef struct urmapx_map_options {
 	int veryfast;       /* -veryfast: State1 method 7 for -map, State2 method 5 for -map2 */
 	unsigned minq;      /* -minq (only -map2 reads it, map2.cpp:76) */
 	const char *cmdline; /* text after CL: in the @PG line (NULL: empty) */
+	/* round 4 (0 = the reference's behaviour: one SAM file) */
+	int sam_shards;     /* -samshards N: the SAM text goes to N files samout.0 .. samout.N-1, shard s = the records of the s-th
+	                     * N-th of the input (cut at a record), written by its own pipeline (reader, lanes, writer) on its own
+	                     * share of the devices; the header is in shard 0, so `cat samout.0 .. samout.N-1` is byte for byte what one
+	                     * file would hold.  Plain (seekable, not .gz) input only: other input goes to shard 0 whole, the other
+	                     * shards stay empty.  -tabbedout is split the same way (tabout.0 ..).  N must divide gpus or be a multiple of it */
+	int discard_sam;    /* measurement: the SAM text is made and copied to the host, then dropped instead of written (report.medium
+	                     * "discarded"): what the device lanes sustain when the output medium is not in the way */
 } urmapx_map_options;
 typedef struct urmapx_map_report {  /* State1::HitStats' counters (state1.cpp:593-632) and where the time went */
 	uint64_t reads, mapped_q, mapped_lowq, unmapped, unsupported;
@@ -260,7 +269,12 @@ typedef struct urmapx_map_report {  /* State1::HitStats' counters (state1.cpp:59
 	int write_threads;                               /* threads sharing one piece's pwrite (1 on tmpfs, up to 4 on a disk file system) */
 	int text_on_device;                              /* 1: FASTQ bytes went to the device and SAM bytes came back (plain or .gz files) */
 	uint64_t input_bytes;                            /* uncompressed FASTQ bytes that took that road (for .gz: parse_s is the inflater's busy time) */
-	char medium[24];                                 /* what the SAM file lives on: "tmpfs", "disk file system", "pipe", "none" */
+	char medium[24];                                 /* what the SAM file lives on: "tmpfs", "disk file system", "pipe", "none", "discarded" */
+	/* round 4: where a device lane's time goes (seconds summed over the chunks of all lanes, from events on the lanes' streams;
+	 * text phase only): FASTQ bytes to the device, line ends / record checks / base copy, the mapping kernels, SAM lengths + text,
+	 * SAM bytes back */
+	double dev_h2d_s, dev_parse_s, dev_map_s, dev_format_s, dev_d2h_s;
+	int shards;                                      /* SAM files written (1 unless sam_shards) */
 } urmapx_map_report;
 /* fastq2 NULL: single-end (-map); else the mates' file (-map2 ... -reverse).  samout / tabout may be NULL.  The index
  * needs its host arrays, or to be resident on first_gpu already (then gpus must be 1).  Batch b is mapped on device
@@ -294,6 +308,7 @@ typedef struct urmapx_text_report {
 	uint32_t reason;    /* URMAPX_TEXT_*; non-zero: nothing was written */
 	uint64_t sam_bytes; /* bytes of SAM text (written, or needed when reason is URMAPX_TEXT_SAM_CAP) */
 	uint64_t mapped_q, mapped_lowq, unmapped, unsupported; /* State1::HitStats' counters (output1.cpp:20-30) against minq */
+	float ms_h2d, ms_parse, ms_map, ms_format, ms_d2h;     /* the chunk on its stream, by events: copy in, parse, map, SAM text, copy out */
 } urmapx_text_report;
 /* One per mapping context; calls on it run on the context's stream (one thread at a time per context). */
 int urmapx_text_create(urmapx_ctx *, urmapx_text **out);

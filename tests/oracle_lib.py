@@ -181,15 +181,15 @@ class Index:
         k = lib().uo_get_row(self.h, int(slot), pv.ctypes.data)
         return pv[:k].copy()
 
-    def map_se(self, bases: np.ndarray, offs: np.ndarray, method=6, threads=1):
-        """-> (results structured array, list of path strings, counters dict)"""
+    def map_se(self, bases: np.ndarray, offs: np.ndarray, method=6, threads=1, p=None):
+        """-> (results structured array, list of path strings, counters dict); p: parameters other than the method's"""
         bases = np.ascontiguousarray(bases, dtype=np.uint8)
         offs = np.ascontiguousarray(offs, dtype=np.uint64)
         n = len(offs) - 1
         res = np.zeros(n, dtype=RESULT_DTYPE)
         arena = C.c_void_p()
         cnt = Counters()
-        p = params(method)
+        p = p if p is not None else params(method)
         rc = lib().uo_map_se(self.h, C.byref(p), bases.ctypes.data, offs.ctypes.data, n, threads,
                              res.ctypes.data, C.byref(arena), C.byref(cnt))
         assert rc == 0
@@ -197,7 +197,7 @@ class Index:
         lib().uo_free(arena)
         return res, paths, cnt.asdict()
 
-    def map_pe(self, bases: np.ndarray, offs: np.ndarray, threads=1, veryfast=False):
+    def map_pe(self, bases: np.ndarray, offs: np.ndarray, threads=1, veryfast=False, p=None):
         """pairs interleaved (reads 2i, 2i+1) -> (results[2*npairs], paths, counters)"""
         bases = np.ascontiguousarray(bases, dtype=np.uint8)
         offs = np.ascontiguousarray(offs, dtype=np.uint64)
@@ -205,7 +205,7 @@ class Index:
         res = np.zeros(n, dtype=RESULT_DTYPE)
         arena = C.c_void_p()
         cnt = Counters()
-        p = params(6)
+        p = p if p is not None else params(6)
         rc = lib().uo_map_pe_opts(self.h, C.byref(p), bases.ctypes.data, offs.ctypes.data, n // 2, threads, int(veryfast),
                                   res.ctypes.data, C.byref(arena), C.byref(cnt))
         assert rc == 0

@@ -135,3 +135,77 @@ def test_map_files_library_call_on_a_resident_index(tmp_path):
         api.map_files(idx, bad, samout=os.path.join(tmp_path, "x.sam"))
     assert e.value.code == api.E_FORMAT
     idx.close()
+
+
+def _cat(paths):
+    return b"".join(open(p, "rb").read() for p in paths)
+
+
+@pytest.mark.parametrize("gpus,shards,batch,host_text", [(2, 2, 64, False), (1, 3, 40, False), (2, 4, 33, False), (2, 2, 64, True)])
+def test_cli_samshards_concatenate_to_the_one_file(tmp_path, gpus, shards, batch, host_text):
+    """`-samout out.sam -samshards N` (round 4): N pipelines side by side, each over its part of the input with its own SAM
+    file and writer; `cat out.sam.0 .. out.sam.N-1` is byte for byte the file a run without -samshards writes (which is the
+    reference's golden SAM).  The reference appends every record to one file under one lock (output1.cpp:10-16)."""
+    ufi = _golden_ufi(tmp_path)
+    one, out = os.path.join(tmp_path, "one.sam"), os.path.join(tmp_path, "out.sam")
+    env = _force_env()
+    if host_text:
+        env["URMAPX_HOST_TEXT"] = "1"
+    base = [EXE, "-map", os.path.join(GOLD, "se150.fq"), "-ufi", ufi, "-batch", str(batch), "-gpus", str(gpus), "-streams", "2"]
+    r1 = subprocess.run(base + ["-samout", one], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=env)
+    assert r1.returncode == 0, r1.stderr.decode()[-2000:]
+    r2 = subprocess.run(base + ["-samout", out, "-samshards", str(shards)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=env)
+    assert r2.returncode == 0, r2.stderr.decode()[-2000:]
+    parts = [f"{out}.{s}" for s in range(shards)]
+    assert all(os.path.exists(p) for p in parts) and not os.path.exists(out)
+    strip_pg = lambda b: b"\n".join(l for l in b.split(b"\n") if not l.startswith(b"@PG"))  # the command lines differ by the option itself
+    assert strip_pg(_cat(parts)) == strip_pg(open(one, "rb").read())
+    assert sum(os.path.getsize(p) > 0 for p in parts) >= min(shards, 2)  # the work really was split
+    assert _records(one) == [l for l in open(os.path.join(GOLD, "se150.sam"), "rb").read().split(b"\n") if l]
+    # the report counts every shard's reads
+    reads = [l for l in r2.stderr.decode().split("\n") if "Reads (" in l]
+    assert reads and reads == [l for l in r1.stderr.decode().split("\n") if "Reads (" in l]
+
+
+def test_cli_samshards_pairs_and_tab(tmp_path):
+    ufi = _golden_ufi(tmp_path)
+    out, tab = os.path.join(tmp_path, "out.sam"), os.path.join(tmp_path, "out.tab")
+    r = subprocess.run([EXE, "-map2", os.path.join(GOLD, "pe150_1.fq"), "-reverse", os.path.join(GOLD, "pe150_2.fq"), "-ufi", ufi,
+                        "-samout", out, "-tabbedout", tab, "-batch", "60", "-gpus", "2", "-streams", "1", "-samshards", "2"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=_force_env())
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    sam = _cat([out + ".0", out + ".1"])
+    assert os.path.getsize(out + ".1") > 0
+    assert [l for l in sam.split(b"\n") if l and not l.startswith(b"@PG")] == [l for l in open(os.path.join(GOLD, "pe150.sam"), "rb").read().split(b"\n") if l]
+    assert _cat([tab + ".0", tab + ".1"]) == open(os.path.join(GOLD, "pe150.tab"), "rb").read()
+
+
+def test_cli_samshards_of_input_that_cannot_be_cut(tmp_path):
+    """.gz input has no record boundary to seek to: everything goes to shard 0, the other shards are empty files -- `cat` of the
+    shards is still the one file."""
+    ufi = _golden_ufi(tmp_path)
+    gz = os.path.join(tmp_path, "r.fq.gz")
+    with open(os.path.join(GOLD, "se150.fq"), "rb") as f, gzip.open(gz, "wb") as z:
+        z.write(f.read())
+    out = os.path.join(tmp_path, "out.sam")
+    r = subprocess.run([EXE, "-map", gz, "-ufi", ufi, "-samout", out, "-samshards", "2", "-gpus", "2"], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       timeout=300, env=_force_env())
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    assert os.path.getsize(out + ".1") == 0
+    assert _records(out + ".0") == [l for l in open(os.path.join(GOLD, "se150.sam"), "rb").read().split(b"\n") if l]
+
+
+def test_map_files_discard_and_device_stage_times(tmp_path):
+    """urmapx_map_options.discard_sam: the text is made, copied back and dropped (what the device lanes sustain without an
+    output medium); the report splits a lane's stream time into copy in / parse / map / SAM text / copy out."""
+    from urmap_amd import api
+    ufi = _golden_ufi(tmp_path)
+    idx = api.Index.open(ufi).upload(0)
+    out = os.path.join(tmp_path, "never.sam")
+    rep = api.map_files(idx, os.path.join(GOLD, "se150.fq"), samout=out, batch=90, streams=2, cmdline="test", discard_sam=True)
+    assert not os.path.exists(out)
+    assert rep["medium"] == b"discarded" and rep["reads"] > 0 and rep["text_on_device"] == 1
+    stages = [rep[k] for k in ("dev_h2d_s", "dev_parse_s", "dev_map_s", "dev_format_s", "dev_d2h_s")]
+    assert all(x > 0 for x in stages) and sum(stages) <= rep["gpu_s"] * 1.05 + 1e-3, (stages, rep["gpu_s"])
+    rep2 = api.map_files(idx, os.path.join(GOLD, "se150.fq"), samout=out, batch=90, streams=2, cmdline="test")
+    assert {k: rep[k] for k in ("reads", "mapped_q", "mapped_lowq", "unmapped")} == {k: rep2[k] for k in ("reads", "mapped_q", "mapped_lowq", "unmapped")}

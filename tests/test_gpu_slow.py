@@ -79,13 +79,13 @@ def test_reads_with_more_than_512_hits(many_hits_case):
     _compare(g, gops, ores, opaths)
 
 
-@pytest.mark.parametrize("lens", [(1500, 2048, 3000), (8192,), (12000, 16000, 1025)])
+@pytest.mark.parametrize("lens", [(1500, 2048, 3000), (8192,), (12000, 16000, 1025), (25000, 30836)])  # 30 836: the reference's own limit (state1.h:113)
 def test_long_single_end_reads(small_case, lens):
     genome = small_case["genome"]
     reads = []
     for k, L in enumerate(lens):
         # the penalty cap is absolute (MAX_PENALTY 100, state1.cpp:152-179): a long read maps only if it is nearly exact
-        reads += synth.make_reads(900 + k, genome, 3, read_len=L, sub=0.002, ins=0.0002, dele=0.0002, label_prefix=f"L{L}_")
+        reads += synth.make_reads(900 + k, genome, 3, read_len=L, sub=min(0.002, 15.0 / L), ins=min(0.0002, 1.5 / L), dele=min(0.0002, 1.5 / L), label_prefix=f"L{L}_")
     reads += synth.make_reads(77, genome, 40, read_len=150, sub=0.02, ins=0.002, dele=0.002)  # a mixed batch
     bases, offs = reads_to_arrays(reads)
     ores, opaths, _ = small_case["oracle_index"].map_se(bases, offs)
@@ -96,7 +96,7 @@ def test_long_single_end_reads(small_case, lens):
 
 
 def test_reads_beyond_the_general_kernel_are_flagged_not_mismapped(small_case):
-    reads = synth.make_reads(5, small_case["genome"], 2, read_len=16001, sub=0.01) + synth.make_reads(6, small_case["genome"], 5, read_len=150)
+    reads = synth.make_reads(5, small_case["genome"], 2, read_len=30837, sub=0.01) + synth.make_reads(6, small_case["genome"], 5, read_len=150)
     bases, offs = reads_to_arrays(reads)
     m = api.Mapper(api.Index.open(small_case["ufi"]).upload(0), device=0)
     g, _ = m.map_se(bases, offs, allow_unsupported=True)

@@ -51,19 +51,22 @@ class Params(C.Structure):
 
 class MapOptions(C.Structure):
     _fields_ = [("first_gpu", C.c_int), ("gpus", C.c_int), ("streams", C.c_int), ("host_threads", C.c_int), ("batch", C.c_uint32),
-                ("veryfast", C.c_int), ("minq", C.c_uint), ("cmdline", C.c_char_p)]
+                ("veryfast", C.c_int), ("minq", C.c_uint), ("cmdline", C.c_char_p), ("sam_shards", C.c_int), ("discard_sam", C.c_int)]
 
 
 class MapReport(C.Structure):
     _fields_ = [("reads", C.c_uint64), ("mapped_q", C.c_uint64), ("mapped_lowq", C.c_uint64), ("unmapped", C.c_uint64),
                 ("unsupported", C.c_uint64), ("seconds", C.c_double), ("parse_s", C.c_double), ("gpu_s", C.c_double),
                 ("format_s", C.c_double), ("write_s", C.c_double), ("host_threads", C.c_int), ("lanes", C.c_int),
-                ("write_threads", C.c_int), ("text_on_device", C.c_int), ("input_bytes", C.c_uint64), ("medium", C.c_char * 24)]
+                ("write_threads", C.c_int), ("text_on_device", C.c_int), ("input_bytes", C.c_uint64), ("medium", C.c_char * 24),
+                ("dev_h2d_s", C.c_double), ("dev_parse_s", C.c_double), ("dev_map_s", C.c_double), ("dev_format_s", C.c_double),
+                ("dev_d2h_s", C.c_double), ("shards", C.c_int)]
 
 
 class TextReport(C.Structure):
     _fields_ = [("records", C.c_uint32), ("reason", C.c_uint32), ("sam_bytes", C.c_uint64), ("mapped_q", C.c_uint64),
-                ("mapped_lowq", C.c_uint64), ("unmapped", C.c_uint64), ("unsupported", C.c_uint64)]
+                ("mapped_lowq", C.c_uint64), ("unmapped", C.c_uint64), ("unsupported", C.c_uint64),
+                ("ms_h2d", C.c_float), ("ms_parse", C.c_float), ("ms_map", C.c_float), ("ms_format", C.c_float), ("ms_d2h", C.c_float)]
 
 
 TEXT_OK, TEXT_CR, TEXT_RAGGED, TEXT_BAD_RECORD, TEXT_LONG_NAME, TEXT_SAM_CAP, TEXT_TOO_LARGE, TEXT_UNEQUAL, TEXT_INTERNAL = range(9)
@@ -347,10 +350,11 @@ class Index:
 
 
 def map_files(index: "Index", fastq1, fastq2=None, samout=None, tabout=None, first_gpu=0, gpus=1, streams=2, host_threads=0,
-              batch=0, veryfast=False, minq=10, cmdline=None, allow_unsupported=False):
+              batch=0, veryfast=False, minq=10, cmdline=None, allow_unsupported=False, sam_shards=0, discard_sam=False):
     """urmap -map / -map2 file to file (cmd_map / cmd_map2) on an index that has its host arrays or is resident on
     first_gpu.  -> dict of State1::HitStats' counters and stage times."""
-    o = MapOptions(first_gpu, gpus, streams, host_threads, batch, int(veryfast), minq, cmdline.encode() if cmdline else None)
+    o = MapOptions(first_gpu, gpus, streams, host_threads, batch, int(veryfast), minq, cmdline.encode() if cmdline else None,
+                   int(sam_shards), int(discard_sam))
     rep = MapReport()
     err = C.create_string_buffer(1024)
     enc = lambda p: os.fsencode(p) if p else None

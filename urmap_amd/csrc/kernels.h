@@ -138,6 +138,14 @@ hipError_t launch_search_pe(const DevIndex &X, const urmapx_params &P, const uin
                             urmapx_path_op *d_path_ops, uint32_t *d_path_used, const SearchWork &wk, int veryfast,
                             urmapx_pair_info *pair_info, hipStream_t s);
 
+// the general pair search (kernels_pe_slow.hip) over the pairs the fast passes left flagged: lists in global scratch
+// (blocks * pe_slow_scratch_stride() bytes); list: npairs + 1 words, ticket: one word
+size_t pe_slow_scratch_stride();
+hipError_t launch_search_pe_slow(const DevIndex &X, const urmapx_params &P, const uint8_t *d_bases, const uint64_t *d_offs, uint32_t npairs,
+                                 urmapx_result *d_results, urmapx_path_op *d_path_ops, uint32_t *d_path_used, uint32_t path_cap,
+                                 uint8_t *scratch, int blocks, uint32_t *list, uint32_t *ticket, int veryfast, urmapx_pair_info *pair_info,
+                                 int all_pairs, hipStream_t s);
+
 hipError_t launch_viterbi_batch(const urmapx_params &P, const uint8_t *d_a, const uint32_t *d_aoffs,
                                 const uint8_t *d_b, const uint32_t *d_boffs, const uint8_t *d_flags, uint32_t n,
                                 float *d_scores, uint8_t *d_status, urmapx_path_op *d_ops, uint16_t *d_nops,

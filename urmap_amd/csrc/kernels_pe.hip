@@ -538,41 +538,64 @@ struct Mate {
 		const int minhsp = (int)((uint32_t)P->min_hsp_score_pct * (uint32_t)QL / 100.0);
 		const uint64_t N = X->slotCount;
 		const int maxIx = (int)X->maxIx;
-		// 1. all chains: rowstore[strand][chunk][k][lane], row length in rowlen[strand][i]
-		for (int s = 0; s < 2; ++s) {
-			for (int base = 0; base < pendCount[s]; base += 64) {
-				const int i = base + lane;
-				uint32_t *rs = rowstore + ((size_t)(s * NCH + (base >> 6)) * PE_ROW_CAP) * 64 + lane;
-				int K = 0;
-				bool act = i < pendCount[s];
-				uint64_t slot2 = 0;
-				uint32_t T = 0, pos = 0;
-				if (act) {
-					// the head's slot number from the read's letter planes, its tally and position from the table again (round 3
-					// read all three from probe arrays in HBM that every pair had written)
-					slot2 = slot_from_planes<NCH + 1>(*X, (lds_ptr<const uint64_t>)&L->kpl[0][0], (uint32_t)nwords, s, pend[s][i]);
-					load_slot(gblob, slot2, T, pos);
-					act = (T & TALLY_MY_BIT) != 0;  // GetRow_Blob returns 0 for a slot that is not "mine"
+		// 1. all chains: rowstore[strand][chunk][k][lane], row length in rowlen[strand][i].  The [strand][chunk] groups advance
+		// in lock step (as search_se_kernel's walk_run): one dependent slot load per hop for all of the mate's chains, where
+		// round 3 walked the plus strand's chains to their ends before it started on the minus strand's
+		{
+			constexpr int NG = 2 * NCH;
+			uint64_t wsl[NG];
+			uint32_t wT[NG], wps[NG];
+			int wK[NG];
+			bool wact[NG];
+			bool any = false;
+#pragma unroll
+			for (int g = 0; g < NG; ++g) {
+				const int st = g / NCH, i = 64 * (g % NCH) + lane;
+				wK[g] = 0; wsl[g] = 0; wT[g] = 0; wps[g] = 0;
+				wact[g] = i < pendCount[st];
+				// the head's slot number from the read's letter planes (round 3 read slot, tally and position from probe arrays in
+				// HBM that every pair had written); its tally and position from the table again
+				if (wact[g]) wsl[g] = slot_from_planes<NCH + 1>(*X, (lds_ptr<const uint64_t>)&L->kpl[0][0], (uint32_t)nwords, st, pend[st][i]);
+			}
+#pragma unroll
+			for (int g = 0; g < NG; ++g)
+				if (wact[g]) load_slot(gblob, wsl[g], wT[g], wps[g]);
+#pragma unroll
+			for (int g = 0; g < NG; ++g) {
+				wact[g] = wact[g] && (wT[g] & TALLY_MY_BIT) != 0;  // GetRow_Blob returns 0 for a slot that is not "mine"
+				any |= wact[g];
+			}
+			while (__ballot(any)) {
+#pragma unroll
+				for (int g = 0; g < NG; ++g) {
+					if (!wact[g]) continue;
+					uint32_t *rs = rowstore + ((size_t)g * PE_ROW_CAP) * 64 + lane;
+					rs[wK[g] * 64] = wps[g];
+					++wK[g];
+					const uint32_t t = wT[g];
+					if (wK[g] == maxIx || wK[g] >= PE_ROW_CAP) wact[g] = false;
+					else if (t == TALLY_PLUS1 || t == TALLY_BOTH1) { wK[g] = 1; wact[g] = false; }
+					else if (t == TALLY_END) wact[g] = false;
+					else if (t == TALLY_LONG_MINE || t == TALLY_LONG_OTHER) {
+						const uint64_t slotA = addmod(wsl[g], wps[g] & 0xFFFFu, N);
+						wsl[g] = addmod(slotA, wps[g] >> 16, N);
+						uint32_t tA, pA;
+						load_slot(gblob, slotA, tA, pA);
+						rs[(wK[g] - 1) * 64] = pA;
+					} else
+						wsl[g] = addmod(wsl[g], t & TALLY_NEXT_MASK, N);
 				}
-				while (__ballot(act)) {
-					if (act) {
-						rs[K * 64] = pos;
-						++K;
-						if (K == maxIx || K >= PE_ROW_CAP) act = false;
-						else if (T == TALLY_PLUS1 || T == TALLY_BOTH1) { K = 1; act = false; }
-						else if (T == TALLY_END) act = false;
-						else if (T == TALLY_LONG_MINE || T == TALLY_LONG_OTHER) {
-							const uint64_t slotA = addmod(slot2, pos & 0xFFFFu, N);
-							slot2 = addmod(slotA, pos >> 16, N);
-							uint32_t tA, pA;
-							load_slot(gblob, slotA, tA, pA);
-							rs[(K - 1) * 64] = pA;
-						} else
-							slot2 = addmod(slot2, T & TALLY_NEXT_MASK, N);
-						if (act) load_slot(gblob, slot2, T, pos);
-					}
+				any = false;
+#pragma unroll
+				for (int g = 0; g < NG; ++g) {
+					if (wact[g]) load_slot(gblob, wsl[g], wT[g], wps[g]);
+					any |= wact[g];
 				}
-				if (i < pendCount[s]) rowlen[s * QMAX + i] = (uint8_t)K;
+			}
+#pragma unroll
+			for (int g = 0; g < NG; ++g) {
+				const int st = g / NCH, i = 64 * (g % NCH) + lane;
+				if (i < pendCount[st]) rowlen[st * QMAX + i] = (uint8_t)wK[g];
 			}
 		}
 		URX_SYNC();

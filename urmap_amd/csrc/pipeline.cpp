@@ -162,6 +162,8 @@ struct Failure {
 class FileSink {
 public:
 	~FileSink() { if (fd_ >= 0) ::close(fd_); }
+	// measurement (urmapx_map_options.discard_sam): the text is taken and dropped
+	void open_discard() { discard_ = true; }
 	bool open(const char *path) {
 		const char *mode = getenv("URMAPX_SAM_WRITE");  // "pwrite" (default) | "mmap"
 		const bool want_map = mode && !strcmp(mode, "mmap");
@@ -180,6 +182,7 @@ public:
 	// thread does 5.8 GB/s, eight together 3.7 (scripts/fs_bench.cpp) -- so one; on a disk file system concurrent pwrites
 	// of disjoint ranges overlap their I/O, so a few.
 	int writer_threads(int host_threads) const {
+		if (discard_) return 1;
 		if (const char *e = getenv("URMAPX_WRITE_THREADS")) return std::max(1, atoi(e));
 		if (sequential_ || fd_ < 0) return 1;
 		struct statfs fs;
@@ -189,6 +192,7 @@ public:
 		return std::max(1, std::min(4, host_threads));
 	}
 	const char *medium() const {
+		if (discard_) return "discarded";
 		if (sequential_) return "pipe";
 		struct statfs fs;
 		if (fd_ < 0 || fstatfs(fd_, &fs) != 0) return "file";
@@ -203,7 +207,7 @@ public:
 		return true;
 	}
 	bool write_at(const char *p, size_t n, uint64_t off, int threads) {
-		if (n == 0) return true;
+		if (n == 0 || discard_) return true;
 		if (threads < 1) threads = 1;
 		if (sequential_) {  // the callers hand pieces over in file order when seekable() is false
 			if (off != size_) return false;
@@ -251,7 +255,7 @@ public:
 		return ok;
 	}
 	bool finish(uint64_t length) {
-		if (fd_ < 0) return true;
+		if (fd_ < 0 || discard_) return true;
 		bool ok = sequential_ || size_ == length || ftruncate(fd_, (off_t)length) == 0;
 		ok = ::close(fd_) == 0 && ok;
 		fd_ = -1;
@@ -260,7 +264,7 @@ public:
 
 private:
 	int fd_ = -1;
-	bool sequential_ = false;
+	bool sequential_ = false, discard_ = false;
 	std::atomic<bool> use_map_{false};
 	std::atomic<uint64_t> size_{0};
 };
@@ -571,8 +575,66 @@ size_t last_record_start(const char *b, size_t n) {
 
 }  // namespace
 
-extern "C" int urmapx_map_files(urmapx_index *I, const urmapx_map_options *opt, const char *fastq1, const char *fastq2,
-                                const char *samout, const char *tabout, urmapx_map_report *report, char *err, size_t errcap) {
+namespace {
+// One shard of a sharded run (urmapx_map_options.sam_shards): the records of bytes [lo, hi) of the (plain, seekable) input
+// file(s), cut at record starts; the SAM header only in the first shard.
+struct InputRange {
+	bool on = false;
+	uint64_t lo[2] = {0, 0}, hi[2] = {0, 0};
+	uint64_t lines_before = 0;  // lines of each file in front of lo (they name the line in the reader's messages)
+	bool header = true;
+};
+
+// number of '\n' in bytes [from, to) of fd, by all threads
+uint64_t count_newlines(int fd, uint64_t from, uint64_t to, int threads) {
+	if (to <= from) return 0;
+	const uint64_t piece = 8u << 20;
+	const uint64_t np = (to - from + piece - 1) / piece;
+	uint64_t total = 0;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads) reduction(+ : total)
+	for (int64_t k = 0; k < (int64_t)np; ++k) {
+		std::vector<char> buf((size_t)piece);
+		const uint64_t a = from + (uint64_t)k * piece, b = std::min(to, a + piece);
+		size_t have = 0;
+		while (a + have < b) {
+			const ssize_t r = pread(fd, buf.data() + have, (size_t)(b - a - have), (off_t)(a + have));
+			if (r <= 0) break;
+			have += (size_t)r;
+		}
+		const char *c = buf.data(), *e = c + have;
+		uint64_t n = 0;
+		while (c < e) {
+			const char *nl = (const char *)memchr(c, '\n', (size_t)(e - c));
+			if (!nl) break;
+			++n;
+			c = nl + 1;
+		}
+		total += n;
+	}
+	return total;
+}
+
+// offset of the byte behind the `lines`-th '\n' of fd at or after `from` (`fsize` if the file has fewer)
+uint64_t skip_lines(int fd, uint64_t from, uint64_t fsize, uint64_t lines) {
+	std::vector<char> buf(8u << 20);
+	uint64_t at = from;
+	while (lines && at < fsize) {
+		const ssize_t r = pread(fd, buf.data(), (size_t)std::min<uint64_t>(buf.size(), fsize - at), (off_t)at);
+		if (r <= 0) return fsize;
+		const char *c = buf.data(), *e = c + r;
+		while (lines && c < e) {
+			const char *nl = (const char *)memchr(c, '\n', (size_t)(e - c));
+			if (!nl) { c = e; break; }
+			--lines;
+			c = nl + 1;
+		}
+		at += (uint64_t)(c - buf.data());
+	}
+	return lines ? fsize : at;
+}
+
+int map_files_impl(urmapx_index *I, const urmapx_map_options *opt, const InputRange &range, const char *fastq1, const char *fastq2,
+                   const char *samout, const char *tabout, urmapx_map_report *report, char *err, size_t errcap) {
 	auto say = [&](const std::string &s) {
 		if (err && errcap) snprintf(err, errcap, "%s", s.c_str());
 	};
@@ -630,11 +692,14 @@ extern "C" int urmapx_map_files(urmapx_index *I, const urmapx_map_options *opt, 
 	uint64_t sam_off = 0;
 	Failure fail;
 	if (samout) {
-		if (!sink.open(samout)) { say(std::string("Cannot create ") + samout); release(); return URMAPX_E_IO; }
-		std::string hdr;
-		append_sam_header_text(hdr, I, opt->cmdline);
-		if (!sink.write_at(hdr.data(), hdr.size(), 0, 1)) { say(std::string("Cannot write ") + samout); release(); return URMAPX_E_IO; }
-		sam_off = hdr.size();
+		if (opt->discard_sam) sink.open_discard();
+		else if (!sink.open(samout)) { say(std::string("Cannot create ") + samout); release(); return URMAPX_E_IO; }
+		if (range.header) {
+			std::string hdr;
+			append_sam_header_text(hdr, I, opt->cmdline);
+			if (!sink.write_at(hdr.data(), hdr.size(), 0, 1)) { say(std::string("Cannot write ") + samout); release(); return URMAPX_E_IO; }
+			sam_off = hdr.size();
+		}
 		medium_name = sink.medium();
 	}
 	// -tabbedout (outfiles.cpp:7-12): State2::OutputTab2's line per pair; only -map2 writes it
@@ -653,10 +718,21 @@ extern "C" int urmapx_map_files(urmapx_index *I, const urmapx_map_options *opt, 
 			return URMAPX_E_IO;
 		}
 	}
+	if (range.on) {  // the host reader, should it be needed, starts and stops where the shard does
+		if (!rd.resume_at(range.lo[0], range.lines_before) || (paired && !rd2.resume_at(range.lo[1], range.lines_before))) {
+			say(std::string("Cannot read a part of ") + fastq1);
+			if (ftab) fclose(ftab);
+			release();
+			return URMAPX_E_IO;
+		}
+		rd.set_limit(range.hi[0]);
+		if (paired) rd2.set_limit(range.hi[1]);
+	}
 	const auto t1 = std::chrono::steady_clock::now();
 	Trace trace;
 	unsigned long long n_reads = 0, n_accept = 0, n_reject = 0, n_nohit = 0, n_unsupported = 0;
 	double t_parse = 0, t_gpu = 0, t_format = 0, t_write = 0;  // busy seconds per stage
+	double dev_ms[5] = {0, 0, 0, 0, 0};  // a lane's stream time by events: copy in, parse, map, SAM text, copy out (text phase)
 	auto now = [] { return std::chrono::steady_clock::now(); };
 	auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
 	std::mutex gpu_time_lock;
@@ -696,6 +772,7 @@ extern "C" int urmapx_map_files(urmapx_index *I, const urmapx_map_options *opt, 
 					fq2 = open_plain(fastq2, fsize2);
 					if (fq2 < 0) { close(fq); fq = -1; }
 				}
+				if (fq >= 0 && range.on) { fsize = range.hi[0]; fsize2 = range.hi[1]; }  // a shard: its part of the file(s) is the file
 			}
 		}
 		if (fq >= 0 || streamed) {
@@ -762,7 +839,7 @@ extern "C" int urmapx_map_files(urmapx_index *I, const urmapx_map_options *opt, 
 			std::vector<char> carry, carry2, pipe_back, pipe_back2;
 			std::thread treader([&] {
 				omp_set_num_threads(read_threads);
-				uint64_t off = 0, off2 = 0;
+				uint64_t off = range.on ? range.lo[0] : 0, off2 = range.on ? range.lo[1] : 0;
 				double bytes2_per_byte1 = 1.0;
 				std::vector<size_t> per;
 				if (streamed) {
@@ -971,7 +1048,7 @@ extern "C" int urmapx_map_files(urmapx_index *I, const urmapx_map_options *opt, 
 				for (auto &c : tparsed) c->close();
 			});
 			bool handed_back = false;
-			uint64_t resume_off = 0, resume_off2 = 0, lines_done = 0;  // lines_done: per file
+			uint64_t resume_off = 0, resume_off2 = 0, lines_done = range.on ? range.lines_before : 0;  // lines_done: per file
 			// write() calls on one file take turns (inode lock): more threads only add hand-overs
 			const int write_threads = sink.writer_threads(host_threads);
 			write_threads_used = write_threads;
@@ -1001,6 +1078,7 @@ extern "C" int urmapx_map_files(urmapx_index *I, const urmapx_map_options *opt, 
 						trace.add("write", -1, b, ta);
 						n_reads += j->rep.records; n_accept += j->rep.mapped_q; n_reject += j->rep.mapped_lowq;
 						n_nohit += j->rep.unmapped; n_unsupported += j->rep.unsupported;
+						dev_ms[0] += j->rep.ms_h2d; dev_ms[1] += j->rep.ms_parse; dev_ms[2] += j->rep.ms_map; dev_ms[3] += j->rep.ms_format; dev_ms[4] += j->rep.ms_d2h;
 						lines_done += (paired ? 2ull : 4ull) * j->rep.records;
 						input_bytes += j->nbytes + j->nbytes2;
 					}
@@ -1093,7 +1171,7 @@ extern "C" int urmapx_map_files(urmapx_index *I, const urmapx_map_options *opt, 
 			if (host_phase) {
 				// a seekable source continues at its (uncompressed) offset; a pipe with the bytes taken from it and not mapped
 				auto resume = [&](FastqReader &r, SeqSource &src, uint64_t at, std::vector<char> &back, std::vector<char> &rest) {
-					if (!streamed || !src.is_pipe()) return r.resume_at(at, lines_done);
+					if (!streamed || !src.is_pipe()) return r.resume_at(at, lines_done);  // (a shard's reader: positioned again, same rules)
 					back.insert(back.end(), rest.begin(), rest.end());
 					return r.resume_with_prefix(std::move(back), lines_done);
 				};
@@ -1331,9 +1409,141 @@ extern "C" int urmapx_map_files(urmapx_index *I, const urmapx_map_options *opt, 
 		report->host_threads = host_threads; report->lanes = n_lanes;
 		report->write_threads = write_threads_used; report->text_on_device = text_on_device ? 1 : 0; report->input_bytes = input_bytes;
 		snprintf(report->medium, sizeof report->medium, "%s", have_sam ? medium_name.c_str() : "none");
+		report->dev_h2d_s = dev_ms[0] * 1e-3; report->dev_parse_s = dev_ms[1] * 1e-3; report->dev_map_s = dev_ms[2] * 1e-3;
+		report->dev_format_s = dev_ms[3] * 1e-3; report->dev_d2h_s = dev_ms[4] * 1e-3;
+		report->shards = 1;
 	}
 	if (fail.set.load()) { say(fail.msg); return fail.code; }
 	return n_unsupported ? URMAPX_E_UNSUPPORTED : URMAPX_OK;
+}
+
+}  // namespace
+
+// cmd_map / cmd_map2 as a library call; with sam_shards > 1 as that many pipelines side by side, each over its part of the
+// input with its own SAM file, devices and writer (the reference appends every record to one file under one lock,
+// output1.cpp:10-16: one output stream is what bounds a run on several GPUs)
+extern "C" int urmapx_map_files(urmapx_index *I, const urmapx_map_options *opt, const char *fastq1, const char *fastq2,
+                                const char *samout, const char *tabout, urmapx_map_report *report, char *err, size_t errcap) {
+	if (err && errcap) err[0] = 0;
+	if (!I || !opt || !fastq1) return URMAPX_E_ARG;
+	const int shards = opt->sam_shards > 1 ? opt->sam_shards : 1;
+	if (shards == 1 || !samout) return map_files_impl(I, opt, InputRange(), fastq1, fastq2, samout, tabout, report, err, errcap);
+	auto say = [&](const std::string &s) {
+		if (err && errcap) snprintf(err, errcap, "%s", s.c_str());
+	};
+	const bool paired = fastq2 != nullptr;
+	const int gpus = opt->gpus > 0 ? opt->gpus : 1;
+	if (shards > 64 || (gpus % shards != 0 && shards % gpus != 0)) { say("-samshards must divide -gpus or be a multiple of it"); return URMAPX_E_ARG; }
+	const int host_threads = opt->host_threads > 0 ? opt->host_threads : std::min(16, std::max(1, (int)std::thread::hardware_concurrency()));
+	// plain seekable files are cut; anything else (.gz, a pipe) goes to shard 0 whole
+	auto plain_size = [](const char *path, int &fd) -> uint64_t {
+		fd = -1;
+		const size_t l = strlen(path);
+		if ((l > 3 && !strcmp(path + l - 3, ".gz")) || !strcmp(path, "-")) return 0;
+		fd = open(path, O_RDONLY);
+		struct stat st;
+		if (fd >= 0 && (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size == 0)) { close(fd); fd = -1; }
+		return fd >= 0 ? (uint64_t)st.st_size : 0;
+	};
+	int fd1 = -1, fd2 = -1;
+	const uint64_t fsize1 = plain_size(fastq1, fd1), fsize2 = paired ? plain_size(fastq2, fd2) : 0;
+	const bool cut = fd1 >= 0 && (!paired || fd2 >= 0) && !getenv("URMAPX_HOST_TEXT_NO_SHARDS");
+	std::vector<InputRange> ranges((size_t)shards);
+	{
+		// shard s starts at the first record start at or behind byte fsize * s / shards of the first file -- and, for pairs, at
+		// the same line of the second file
+		std::vector<uint64_t> at((size_t)shards + 1, 0), at2((size_t)shards + 1, 0), lines((size_t)shards + 1, 0);
+		at[(size_t)shards] = fsize1; at2[(size_t)shards] = fsize2;
+		if (cut) {
+			for (int s = 1; s < shards; ++s) {
+				const uint64_t nominal = fsize1 / (uint64_t)shards * (uint64_t)s;
+				uint64_t a = nominal > at[(size_t)s - 1] ? find_record_start(fd1, nominal, fsize1) : at[(size_t)s - 1];
+				if (a == 0 || a < at[(size_t)s - 1]) a = fsize1;  // no record start in sight: the shard in front takes the rest
+				at[(size_t)s] = a;
+			}
+			for (int s = 1; s <= shards; ++s) lines[(size_t)s] = lines[(size_t)s - 1] + count_newlines(fd1, at[(size_t)s - 1], at[(size_t)s], host_threads);
+			if (paired)
+				for (int s = 1; s < shards; ++s) at2[(size_t)s] = skip_lines(fd2, at2[(size_t)s - 1], fsize2, lines[(size_t)s] - lines[(size_t)s - 1]);
+		}
+		for (int s = 0; s < shards; ++s) {
+			InputRange &r = ranges[(size_t)s];
+			r.header = s == 0;
+			r.on = cut;
+			r.lo[0] = at[(size_t)s]; r.hi[0] = at[(size_t)s + 1]; r.lo[1] = at2[(size_t)s]; r.hi[1] = at2[(size_t)s + 1];
+			r.lines_before = lines[(size_t)s];
+		}
+		if (paired && cut) ranges[(size_t)shards - 1].hi[1] = fsize2;
+	}
+	if (fd1 >= 0) close(fd1);
+	if (fd2 >= 0) close(fd2);
+	// devices: shard s takes gpus / shards of them, or shares device s mod gpus
+	const char *forced = getenv("URMAPX_FORCE_DEVICE");
+	auto phys = [&](int g) { return forced ? atoi(forced) : opt->first_gpu + g; };
+	const int per = gpus >= shards ? gpus / shards : 1;
+	// one replica of the index on the first device of every shard (a shard with several devices makes the others' itself)
+	std::vector<urmapx_index *> replicas((size_t)gpus, nullptr);
+	int rc = urmapx_index_upload(I, phys(0));
+	replicas[0] = I;
+	for (int g = per; g < gpus && !rc; g += per) rc = urmapx_index_replicate(I, phys(g), &replicas[(size_t)g]);
+	auto release = [&]() { for (int g = 1; g < gpus; ++g) urmapx_index_close(replicas[(size_t)g]); };
+	if (rc) { say(std::string("Uploading index to the GPU: ") + urmapx_strerror(rc)); release(); return rc; }
+	std::vector<urmapx_map_report> reps((size_t)shards);
+	std::vector<int> rcs((size_t)shards, 0);
+	std::vector<std::string> errs((size_t)shards);
+	std::vector<std::thread> th;
+	const auto t0 = std::chrono::steady_clock::now();
+	for (int s = 0; s < shards; ++s)
+		th.emplace_back([&, s] {
+			urmapx_map_options o = *opt;
+			o.sam_shards = 0;
+			o.gpus = per;
+			const int g0 = gpus >= shards ? s * per : s % gpus;
+			o.first_gpu = opt->first_gpu + g0;
+			o.host_threads = std::max(2, host_threads / shards);
+			const std::string sam = std::string(samout) + "." + std::to_string(s);
+			const std::string tab = tabout ? std::string(tabout) + "." + std::to_string(s) : std::string();
+			char e[512];
+			e[0] = 0;
+			memset(&reps[(size_t)s], 0, sizeof reps[(size_t)s]);
+			const InputRange &r = ranges[(size_t)s];
+			if (!cut && s > 0) {  // input that cannot be cut: the other shards are empty files (`cat` of the shards is still the one file)
+				FILE *f = fopen(sam.c_str(), "wb");
+				if (f) fclose(f);
+				if (tabout) { f = fopen(tab.c_str(), "wb"); if (f) fclose(f); }
+				return;
+			}
+			if (cut && r.lo[0] >= r.hi[0]) {  // nothing left for this shard (fewer records than shards)
+				FILE *f = fopen(sam.c_str(), "wb");
+				if (f) fclose(f);
+				if (tabout) { f = fopen(tab.c_str(), "wb"); if (f) fclose(f); }
+				return;
+			}
+			rcs[(size_t)s] = map_files_impl(replicas[(size_t)g0], &o, r, fastq1, fastq2, sam.c_str(), tabout ? tab.c_str() : nullptr, &reps[(size_t)s], e, sizeof e);
+			errs[(size_t)s] = e;
+		});
+	for (auto &t : th) t.join();
+	const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+	release();
+	int out_rc = URMAPX_OK;
+	for (int s = 0; s < shards; ++s)
+		if (rcs[(size_t)s] && rcs[(size_t)s] != URMAPX_E_UNSUPPORTED && out_rc == URMAPX_OK) { out_rc = rcs[(size_t)s]; say(errs[(size_t)s]); }
+	if (report) {
+		memset(report, 0, sizeof *report);
+		for (const urmapx_map_report &r : reps) {
+			report->reads += r.reads; report->mapped_q += r.mapped_q; report->mapped_lowq += r.mapped_lowq; report->unmapped += r.unmapped;
+			report->unsupported += r.unsupported; report->parse_s += r.parse_s; report->gpu_s += r.gpu_s; report->format_s += r.format_s;
+			report->write_s += r.write_s; report->lanes += r.lanes; report->host_threads += r.host_threads; report->input_bytes += r.input_bytes;
+			report->dev_h2d_s += r.dev_h2d_s; report->dev_parse_s += r.dev_parse_s; report->dev_map_s += r.dev_map_s;
+			report->dev_format_s += r.dev_format_s; report->dev_d2h_s += r.dev_d2h_s;
+			report->write_threads = std::max(report->write_threads, r.write_threads);
+			report->text_on_device |= r.text_on_device;
+			if (r.medium[0]) memcpy(report->medium, r.medium, sizeof report->medium);
+		}
+		report->seconds = wall;
+		report->shards = shards;
+	}
+	if (out_rc != URMAPX_OK) return out_rc;
+	return report && report->unsupported ? URMAPX_E_UNSUPPORTED : URMAPX_OK;
 }
 
 extern "C" void urmapx_host_pool_trim(void) { HostPool::get().trim(); }

@@ -38,7 +38,7 @@ bool FastqReader::open(const std::string &path, std::string &err) {
 }
 
 bool FastqReader::resume_at(uint64_t offset, uint64_t lines_before) {
-	if (have_ || line_nr_) return false;
+	if (have_ || started_) return false;
 	if (gz_) {  // offset counts uncompressed bytes; zlib inflates its way there from the start of the file
 		if (gzseek((gzFile)gz_, (z_off_t)offset, SEEK_SET) < 0) return false;
 		line_nr_ = lines_before;
@@ -51,7 +51,7 @@ bool FastqReader::resume_at(uint64_t offset, uint64_t lines_before) {
 }
 
 bool FastqReader::resume_with_prefix(std::vector<char> &&prefix, uint64_t lines_before) {
-	if (have_ || line_nr_ || !f_) return false;
+	if (have_ || started_ || !f_) return false;
 	prefix_ = std::move(prefix);
 	prefix_pos_ = 0;
 	line_nr_ = lines_before;
@@ -85,6 +85,8 @@ size_t FastqReader::read_some(char *dst, size_t cap) {
 		}
 		return done;
 	}
+	if (file_off_ >= limit_) return 0;
+	if (cap > limit_ - file_off_) cap = (size_t)(limit_ - file_off_);
 	const int T = cap >= (8u << 20) ? omp_get_max_threads() : 1;
 	std::vector<size_t> got((size_t)T, 0);
 #pragma omp parallel for schedule(static, 1) num_threads(T)
@@ -147,6 +149,7 @@ inline void line_copy(char *dst, const char *s, const char *e) {
 bool FastqReader::next_batch(FastqBatch &B, uint32_t max_reads, std::string &err) {
 	if (B.offs.empty()) { B.offs.resize(1); B.offs[0] = 0; }
 	if (finished_ || max_reads == 0) return false;
+	started_ = true;
 	// 1. line ends of up to max_reads records (a final unterminated line counts)
 	const size_t want = 4 * (size_t)max_reads;
 	ends_.clear();
@@ -392,14 +395,24 @@ static inline char *put_bytes(char *p, const void *src, size_t n) {
 	memcpy(p, src, n);
 	return p + n;
 }
-static constexpr size_t CIGAR_MAX_CHARS = 12 * (size_t)(URMAPX_MAX_PATH_OPS + 1);
+// the longest CIGAR text of a path of nops runs: up to 10 digits and a letter per run ("QL M" when there is none)
+static inline size_t cigar_max_chars(unsigned nops) { return 11 * ((size_t)nops + 1) + 16; }
 
+// Any number of runs (the general kernels' paths are as long as the read): the runs are merged as they come (path D, query
+// only, is CIGAR I and vice versa); the dangling-M rule needs the first three and the last three merged runs only.
 static char *put_cigar(char *p, const urmapx_path_op *ops, unsigned nops, unsigned QL) {
 	if (nops == 0) { p = put_uint(p, QL); *p++ = 'M'; return p; }
-	char op[URMAPX_MAX_PATH_OPS + 1];
-	unsigned len[URMAPX_MAX_PATH_OPS + 1];
+	char op_fixed[URMAPX_MAX_PATH_OPS + 1];
+	unsigned len_fixed[URMAPX_MAX_PATH_OPS + 1];
+	std::vector<char> op_big;
+	std::vector<unsigned> len_big;
+	char *op = op_fixed;
+	unsigned *len = len_fixed;
+	if (nops > URMAPX_MAX_PATH_OPS) {
+		op_big.resize((size_t)nops + 1); len_big.resize((size_t)nops + 1);
+		op = op_big.data(); len = len_big.data();
+	}
 	unsigned N = 0;
-	if (nops > URMAPX_MAX_PATH_OPS) nops = URMAPX_MAX_PATH_OPS;
 	for (unsigned i = 0; i < nops; ++i) {
 		unsigned code = ops[i] & 3u, n = ops[i] >> 2;
 		char c = code == 0 ? 'M' : code == 1 ? 'I' : 'D';  // path D (query only) is CIGAR I and vice versa
@@ -424,8 +437,8 @@ static char *put_cigar(char *p, const urmapx_path_op *ops, unsigned nops, unsign
 }
 
 std::string path_to_cigar(const urmapx_path_op *ops, unsigned nops, unsigned QL) {
-	char buf[CIGAR_MAX_CHARS + 16];
-	return std::string(buf, (size_t)(put_cigar(buf, ops, nops, QL) - buf));
+	std::vector<char> buf(cigar_max_chars(nops));
+	return std::string(buf.data(), (size_t)(put_cigar(buf.data(), ops, nops, QL) - buf.data()));
 }
 
 static size_t qname_len(const char *label) {
@@ -471,7 +484,7 @@ void append_sam_record(std::string &out, const urmapx_index *I, const urmapx_res
 	if (r.dbpos == 0xFFFFFFFFu) { append_unmapped(out, flags, label, seq, qual, QL); return; }
 	const char *tlabel = urmapx_index_label(I, r.seq_index);
 	const size_t ql = qname_len(label), tl = strlen(tlabel), ml = mate_label ? strlen(mate_label) : 0;
-	char *const buf = record_scratch(ql + tl + ml + 2 * (size_t)QL + CIGAR_MAX_CHARS + 128), *p = buf;
+	char *const buf = record_scratch(ql + tl + ml + 2 * (size_t)QL + cigar_max_chars(r.path_nops) + 128), *p = buf;
 	p = put_bytes(p, label, ql);
 	*p++ = '\t';
 	p = put_uint(p, flags);

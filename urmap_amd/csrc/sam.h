@@ -74,6 +74,8 @@ public:
 	// plain seekable files: continue at byte `offset`, which starts line number `lines_before` + 1 (the part of the file
 	// in front was consumed by the device parser)
 	bool resume_at(uint64_t offset, uint64_t lines_before);
+	// plain seekable files: the reader stops at byte `end` as if the file ended there (one shard of a sharded run)
+	void set_limit(uint64_t end) { limit_ = end; }
 	// pipes: continue with `prefix` (bytes another reader of the same descriptor took from it and gives back) and then
 	// whatever the descriptor still holds; the prefix starts line number `lines_before` + 1
 	bool resume_with_prefix(std::vector<char> &&prefix, uint64_t lines_before);
@@ -92,7 +94,9 @@ private:
 	size_t beg_ = 0, have_ = 0;  // unconsumed input = buf_[beg_, have_)
 	double bytes_per_line_ = 160;  // running estimate, sizes the reads and the scan windows
 	uint64_t file_off_ = 0;  // plain files: next byte to read
+	uint64_t limit_ = ~0ull;  // plain files: first byte not to read
 	bool eof_ = false, finished_ = false, seekable_ = true;
+	bool started_ = false;  // next_batch has been called: the reader cannot be positioned any more
 	uint64_t line_nr_ = 0;  // lines consumed so far
 	std::vector<size_t> ends_;  // scratch: end offset of every line of the batch
 	std::vector<char> prefix_;  // resume_with_prefix: read before the descriptor

@@ -32,6 +32,9 @@ namespace {
 constexpr int NL_TILE = 16384, NL_THREADS = 256;  // 64 bytes per thread
 constexpr int SC_THREADS = 256, SC_ITEMS = 8, SC_TILE = SC_THREADS * SC_ITEMS;
 constexpr int SAM_WAVES = 4;        // wavefronts per block of the record kernels
+// an LDS array named by an LDS pointer (32 bit, ds_* instructions), as in dev_common.h
+template <class T> using lds_ptr = __attribute__((address_space(3))) T *;
+template <class T> __device__ __forceinline__ lds_ptr<T> to_lds(T *p) { return (lds_ptr<T>)p; }
 constexpr int HEAD_CAP = 1600;      // bytes of one record between QNAME and SEQ held in LDS (12 * 97 CIGAR + fields)
 constexpr int TNAME_MAX = 160;      // longest target label the device formatter takes
 
@@ -288,17 +291,31 @@ struct SamArgs {
 	char *sam;                   // PASS 1 out
 };
 
-__device__ __forceinline__ char *dev_put_uint(char *p, uint32_t v) {
+// Where the head of a record is written: LDS (HeadLds) or, for a head longer than the LDS buffer, straight into the output
+// (HeadGlobal).  Two types, two instantiations of build_head: a generic pointer that is LDS on one path and global on the
+// other makes the compiler cast the LDS address, and the cast of LDS offset 0 is a null pointer.
+struct HeadLds {
+	lds_ptr<char> base;
+	uint32_t n;
+	__device__ __forceinline__ void put(char c) { base[n++] = c; }
+};
+struct HeadGlobal {
+	char *base;
+	uint32_t n;
+	__device__ __forceinline__ void put(char c) { base[n++] = c; }
+};
+template <class W>
+__device__ __forceinline__ void dev_put_uint(W &w, uint32_t v) {
 	char tmp[12];
 	int n = 0;
 	do { tmp[n++] = (char)('0' + v % 10u); v /= 10u; } while (v);
-	while (n) *p++ = tmp[--n];
-	return p;
+	while (n) w.put(tmp[--n]);
 }
 
-__device__ __forceinline__ char *dev_put_int(char *p, int v) {
-	if (v < 0) { *p++ = '-'; return dev_put_uint(p, (uint32_t)(-(long long)v)); }
-	return dev_put_uint(p, (uint32_t)v);
+template <class W>
+__device__ __forceinline__ void dev_put_int(W &w, int v) {
+	if (v < 0) { w.put('-'); dev_put_uint(w, (uint32_t)(-(long long)v)); return; }
+	dev_put_uint(w, (uint32_t)v);
 }
 
 // SetSAM's arguments (setsam.cpp:73-74): single-end passes 0, "*", UINT32_MAX, 0 (output1.cpp:13); pairs what SetSAM2
@@ -351,8 +368,43 @@ __device__ MateFields pair_fields(const urmapx_result &r1, const urmapx_result &
 
 // Lane 0 writes the fields between QNAME and SEQ of a mapped or unmapped record (SetSAM / SetSAM_Unmapped,
 // setsam.cpp:12-207) to `head`; returns the length, or 0 if it does not fit the device formatter.
-__device__ uint32_t build_head(const SamArgs &A, const urmapx_result &r, const MateFields &F, uint32_t QL, char *head, char *cop, uint32_t *clen) {
-	char *p = head;
+// The merged CIGAR runs of a path, seen from both ends: N of them, the first three (fo / fl) and the last three (lo / ll, [2] = the
+// last), and the characters they print as.
+struct CigarEnds {
+	uint32_t N, chars;
+	char fo[3], lo[3];
+	uint32_t fl[3], ll[3];
+};
+__device__ __forceinline__ uint32_t dev_digits(uint32_t v) {
+	return v < 10u ? 1u : v < 100u ? 2u : v < 1000u ? 3u : v < 10000u ? 4u : v < 100000u ? 5u : v < 1000000u ? 6u : v < 10000000u ? 7u
+	     : v < 100000000u ? 8u : v < 1000000000u ? 9u : 10u;
+}
+__device__ void cigar_ends(const urmapx_path_op *ops, uint32_t nops, CigarEnds &E) {
+	E.N = 0; E.chars = 0;
+	for (int t = 0; t < 3; ++t) { E.fo[t] = 0; E.lo[t] = 0; E.fl[t] = 0; E.ll[t] = 0; }
+	char cur = 0;
+	uint32_t curlen = 0;
+	bool have = false;
+	auto close_run = [&]() {
+		if (E.N < 3) { E.fo[E.N] = cur; E.fl[E.N] = curlen; }
+		E.lo[0] = E.lo[1]; E.ll[0] = E.ll[1]; E.lo[1] = E.lo[2]; E.ll[1] = E.ll[2]; E.lo[2] = cur; E.ll[2] = curlen;
+		E.chars += dev_digits(curlen) + 1u;
+		++E.N;
+	};
+	for (uint32_t i = 0; i < nops; ++i) {
+		const uint32_t code = ops[i] & 3u, len = ops[i] >> 2;
+		const char c = code == 0 ? 'M' : code == 1 ? 'I' : 'D';
+		if (have && cur == c) curlen += len;
+		else {
+			if (have) close_run();
+			cur = c; curlen = len; have = true;
+		}
+	}
+	if (have) close_run();
+}
+
+template <class W>
+__device__ uint32_t build_head(const SamArgs &A, const urmapx_result &r, const MateFields &F, uint32_t QL, W &w) {
 	if (r.dbpos == 0xFFFFFFFFu) {
 		uint32_t flags = 0x04u;  // SetSAM_Unmapped keeps these bits of the flags it is given (setsam.cpp:14-27)
 		if (F.flags & 0x01u) flags |= 0x01u;
@@ -360,70 +412,81 @@ __device__ uint32_t build_head(const SamArgs &A, const urmapx_result &r, const M
 		else if (F.flags & 0x80u) flags |= 0x80u;
 		if (F.flags & 0x08u) flags |= 0x08u;
 		else if (F.flags & 0x20u) flags |= 0x20u;
-		*p++ = '\t';
-		p = dev_put_uint(p, flags);
+		w.put('\t');
+		dev_put_uint(w, flags);
 		const char s[] = "\t*\t0\t0\t*\t*\t0\t0\t";
-		for (int i = 0; i < (int)sizeof(s) - 1; ++i) *p++ = s[i];
-		return (uint32_t)(p - head);
+		for (int i = 0; i < (int)sizeof(s) - 1; ++i) w.put(s[i]);
+		return w.n;
 	}
-	*p++ = '\t';
-	p = dev_put_uint(p, F.flags);
-	*p++ = '\t';
+	w.put('\t');
+	dev_put_uint(w, F.flags);
+	w.put('\t');
 	if (r.seq_index >= A.seq_count) return 0;
 	const uint32_t t0 = A.tname_offs[r.seq_index], tl = A.tname_offs[r.seq_index + 1] - t0;
 	if (tl > (uint32_t)TNAME_MAX) return 0;
-	for (uint32_t i = 0; i < tl; ++i) *p++ = A.tnames[t0 + i];
-	*p++ = '\t';
-	p = dev_put_uint(p, r.coord + 1u);
-	*p++ = '\t';
-	p = dev_put_uint(p, r.mapq);
-	*p++ = '\t';
-	uint32_t nops = r.path_nops;
-	if (nops == 0) { p = dev_put_uint(p, QL); *p++ = 'M'; }
+	for (uint32_t i = 0; i < tl; ++i) w.put(A.tnames[t0 + i]);
+	w.put('\t');
+	dev_put_uint(w, r.coord + 1u);
+	w.put('\t');
+	dev_put_uint(w, r.mapq);
+	w.put('\t');
+	const uint32_t nops = r.path_nops;
+	if (nops == 0) { dev_put_uint(w, QL); w.put('M'); }
 	else {
-		if (nops > URMAPX_MAX_PATH_OPS) nops = URMAPX_MAX_PATH_OPS;
+		// Any number of runs (the general kernels' paths are as long as the read): the runs are merged as they stream by, twice --
+		// once for what CIGAROpsFixDanglingMs (cigar.cpp:141-199) needs to know (how many merged runs, the first three, the last
+		// three: head rule XOR tail rule, as in sam.cpp), once to write them.
 		const urmapx_path_op *ops = A.ops + r.path_off;
-		uint32_t N = 0;
+		CigarEnds E;
+		cigar_ends(ops, nops, E);
+		const bool head_rule = E.N >= 3 && E.fo[0] == 'M' && E.fl[0] <= 2 && E.fl[1] > 4 && E.fo[2] == 'M';
+		const bool tail_rule = !head_rule && E.N >= 3 && E.lo[2] == 'M' && E.ll[2] <= 2 && E.ll[1] > 4 && E.lo[0] == 'M';
+		uint32_t k = 0;  // index of the merged run being closed
+		char cur = 0;
+		uint32_t curlen = 0;
+		bool have = false;
+		auto close_run = [&]() {
+			uint32_t len = curlen;
+			bool skip = false;
+			if (head_rule) { if (k == 0) skip = true; else if (k == 2) len += E.fl[0]; }
+			if (tail_rule) { if (k == E.N - 1) skip = true; else if (k == E.N - 3) len += E.ll[2]; }
+			if (!skip) { dev_put_uint(w, len); w.put(cur); }
+			++k;
+		};
 		for (uint32_t i = 0; i < nops; ++i) {
-			const uint32_t code = ops[i] & 3u, n = ops[i] >> 2;
+			const uint32_t code = ops[i] & 3u, len = ops[i] >> 2;
 			const char c = code == 0 ? 'M' : code == 1 ? 'I' : 'D';  // path D (query only) is CIGAR I and vice versa (cigar.cpp:22-25)
-			if (N && cop[N - 1] == c) clen[N - 1] += n;
-			else { cop[N] = c; clen[N] = n; ++N; }
+			if (have && cur == c) curlen += len;
+			else {
+				if (have) close_run();
+				cur = c; curlen = len; have = true;
+			}
 		}
-		uint32_t first = 0;  // CIGAROpsFixDanglingMs (cigar.cpp:141-199): head rule XOR tail rule, as in sam.cpp
-		if (N >= 3) {
-			if (cop[0] == 'M' && clen[0] <= 2 && clen[1] > 4 && cop[2] == 'M') { clen[2] += clen[0]; first = 1; }
-			else if (cop[N - 1] == 'M' && clen[N - 1] <= 2 && clen[N - 2] > 4 && cop[N - 3] == 'M') { clen[N - 3] += clen[N - 1]; --N; }
-		}
-		for (uint32_t i = first; i < N; ++i) { p = dev_put_uint(p, clen[i]); *p++ = cop[i]; }
+		close_run();
 	}
-	*p++ = '\t';
+	w.put('\t');
 	// RNEXT: '*' without a mapped mate, '=' if the mate's target has the same label, else that label (setsam.cpp:150-166)
-	if (!F.mate_mapped) *p++ = '*';
+	if (!F.mate_mapped) w.put('*');
 	else {
 		if (F.mate_seq_index >= A.seq_count) return 0;
 		const uint32_t m0 = A.tname_offs[F.mate_seq_index], ml = A.tname_offs[F.mate_seq_index + 1] - m0;
 		if (ml > (uint32_t)TNAME_MAX) return 0;
 		bool same = ml == tl;
 		for (uint32_t i = 0; same && i < tl; ++i) same = A.tnames[t0 + i] == A.tnames[m0 + i];
-		if (ml == 0 || (ml == 1 && A.tnames[m0] == '*')) *p++ = '*';
-		else if (same) *p++ = '=';
+		if (ml == 0 || (ml == 1 && A.tnames[m0] == '*')) w.put('*');
+		else if (same) w.put('=');
 		else
-			for (uint32_t i = 0; i < ml; ++i) *p++ = A.tnames[m0 + i];
+			for (uint32_t i = 0; i < ml; ++i) w.put(A.tnames[m0 + i]);
 	}
-	*p++ = '\t';
-	if (!F.mate_mapped || F.mate_coord == 0 || F.mate_coord == 0xFFFFFFFFu) *p++ = '0';  // position 0 prints as 0 (setsam.cpp:168-172)
-	else p = dev_put_uint(p, F.mate_coord + 1u);
-	*p++ = '\t';
-	p = dev_put_int(p, F.tlen);
-	*p++ = '\t';
-	return (uint32_t)(p - head);
+	w.put('\t');
+	if (!F.mate_mapped || F.mate_coord == 0 || F.mate_coord == 0xFFFFFFFFu) w.put('0');  // position 0 prints as 0 (setsam.cpp:168-172)
+	else dev_put_uint(w, F.mate_coord + 1u);
+	w.put('\t');
+	dev_put_int(w, F.tlen);
+	w.put('\t');
+	return w.n;
 }
 
-__device__ __forceinline__ uint32_t dev_digits(uint32_t v) {
-	return v < 10u ? 1u : v < 100u ? 2u : v < 1000u ? 3u : v < 10000u ? 4u : v < 100000u ? 5u : v < 1000000u ? 6u : v < 10000000u ? 7u
-	     : v < 100000000u ? 8u : v < 1000000000u ? 9u : 10u;
-}
 
 // Length of what build_head writes, without writing it (the same tests in the same order; 0 = does not fit).  The CIGAR
 // runs are merged as they stream by; the dangling-M rule needs the first three and the last three merged runs only.
@@ -441,40 +504,20 @@ __device__ uint32_t head_length(const SamArgs &A, const urmapx_result &r, const 
 	const uint32_t t0 = A.tname_offs[r.seq_index], tl = A.tname_offs[r.seq_index + 1] - t0;
 	if (tl > (uint32_t)TNAME_MAX) return 0;
 	uint32_t n = 1u + dev_digits(F.flags) + 1u + tl + 1u + dev_digits(r.coord + 1u) + 1u + dev_digits(r.mapq) + 1u;
-	uint32_t nops = r.path_nops;
+	const uint32_t nops = r.path_nops;
 	if (nops == 0) n += dev_digits(QL) + 1u;
 	else {
-		if (nops > URMAPX_MAX_PATH_OPS) nops = URMAPX_MAX_PATH_OPS;
 		const urmapx_path_op *ops = A.ops + r.path_off;
-		uint32_t N = 0, chars = 0;
-		char fo[3] = {0, 0, 0}, lo[3] = {0, 0, 0};  // first three / last three merged runs (lo[2] = the last)
-		uint32_t fl[3] = {0, 0, 0}, ll[3] = {0, 0, 0};
-		char cur = 0;
-		uint32_t curlen = 0;
-		bool have = false;
-		auto close_run = [&]() {
-			if (N < 3) { fo[N] = cur; fl[N] = curlen; }
-			lo[0] = lo[1]; ll[0] = ll[1]; lo[1] = lo[2]; ll[1] = ll[2]; lo[2] = cur; ll[2] = curlen;
-			chars += dev_digits(curlen) + 1u;
-			++N;
-		};
-		for (uint32_t i = 0; i < nops; ++i) {
-			const uint32_t code = ops[i] & 3u, len = ops[i] >> 2;
-			const char c = code == 0 ? 'M' : code == 1 ? 'I' : 'D';
-			if (have && cur == c) curlen += len;
-			else {
-				if (have) close_run();
-				cur = c; curlen = len; have = true;
-			}
-		}
-		close_run();
-		if (N >= 3) {
-			if (fo[0] == 'M' && fl[0] <= 2 && fl[1] > 4 && fo[2] == 'M') {
-				chars -= dev_digits(fl[0]) + 1u;
-				chars += dev_digits(fl[2] + fl[0]) - dev_digits(fl[2]);
-			} else if (lo[2] == 'M' && ll[2] <= 2 && ll[1] > 4 && lo[0] == 'M') {
-				chars -= dev_digits(ll[2]) + 1u;
-				chars += dev_digits(ll[0] + ll[2]) - dev_digits(ll[0]);
+		CigarEnds E;
+		cigar_ends(ops, nops, E);
+		uint32_t chars = E.chars;
+		if (E.N >= 3) {
+			if (E.fo[0] == 'M' && E.fl[0] <= 2 && E.fl[1] > 4 && E.fo[2] == 'M') {
+				chars -= dev_digits(E.fl[0]) + 1u;
+				chars += dev_digits(E.fl[2] + E.fl[0]) - dev_digits(E.fl[2]);
+			} else if (E.lo[2] == 'M' && E.ll[2] <= 2 && E.ll[1] > 4 && E.lo[0] == 'M') {
+				chars -= dev_digits(E.ll[2]) + 1u;
+				chars += dev_digits(E.ll[0] + E.ll[2]) - dev_digits(E.ll[0]);
 			}
 		}
 		n += chars;
@@ -566,8 +609,6 @@ __global__ __launch_bounds__(256) void sam_len_kernel(SamArgs A) {
 // sam_len_kernel reserved; if not, the chunk is flagged and handed back (flag 32).
 __global__ __launch_bounds__(SAM_WAVES * 64) void sam_kernel(SamArgs A) {
 	__shared__ char s_head[SAM_WAVES][HEAD_CAP];
-	__shared__ char s_cop[SAM_WAVES][URMAPX_MAX_PATH_OPS + 1];
-	__shared__ uint32_t s_clen[SAM_WAVES][URMAPX_MAX_PATH_OPS + 1];
 	__shared__ uint32_t s_hl[SAM_WAVES];
 	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 	const uint32_t n = A.hdr->n_reads;
@@ -585,19 +626,30 @@ __global__ __launch_bounds__(SAM_WAVES * 64) void sam_kernel(SamArgs A) {
 			const unsigned long long m = __ballot(c == ' ' || c == '\t');
 			if (m) { qn = b + (uint32_t)__ffsll((long long)m) - 1u; break; }
 		}
-		if (lane == 0) s_hl[w] = build_head(A, r, V.F, QL, s_head[w], s_cop[w], s_clen[w]);
+		// the head goes through LDS unless it is longer than that (a CIGAR of hundreds of runs, from the general kernels): then
+		// lane 0 writes it where it belongs -- the reserved length says which before anything is written
+		const uint32_t reserved = A.lens[i];
+		const bool direct = reserved > qn + 2u * QL + 2u + (uint32_t)HEAD_CAP - 64u;
+		char *out = A.sam + A.rec_offs[i];
+		if (lane == 0) {
+			if (direct) { HeadGlobal hw{out + qn, 0u}; s_hl[w] = build_head(A, r, V.F, QL, hw); }
+			else { HeadLds hw{to_lds(&s_head[w][0]), 0u}; s_hl[w] = build_head(A, r, V.F, QL, hw); }
+		}
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 		__builtin_amdgcn_wave_barrier();
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 		const uint32_t hl = s_hl[w];
-		if (qn + hl + 2u * QL + 2u != A.lens[i]) {  // never: the two kernels count the same bytes
+		if (qn + hl + 2u * QL + 2u != reserved) {  // never: the two kernels count the same bytes
 			if (lane == 0) atomicOr(&A.hdr->flags, 32u);
+#ifdef URX_DEBUG_TEXT
+			if (lane == 0) printf("sam_kernel mismatch: rec %u qn %u hl %u QL %u reserved %u direct %d nops %u dbpos %u\n", i, qn, hl, QL, reserved, (int)direct, (unsigned)r.path_nops, r.dbpos);
+#endif
 			continue;
 		}
-		char *out = A.sam + A.rec_offs[i];
 		for (uint32_t k = lane; k < qn; k += 64) out[k] = (char)label[k];
 		out += qn;
-		for (uint32_t k = lane; k < hl; k += 64) out[k] = s_head[w][k];
+		if (!direct)
+			for (uint32_t k = lane; k < hl; k += 64) out[k] = s_head[w][k];
 		out += hl;
 		const uint8_t *seq = V.raw + V.e1 + 1u, *qual = V.raw + V.e3 + 1u;
 		const bool plus = r.dbpos == 0xFFFFFFFFu || r.plus;
@@ -624,6 +676,11 @@ struct urmapx_text {
 	DevBuf<TextHdr> hdr;  // [2]
 	uint32_t seq_count = 0;
 	TextHdr *h_hdr = nullptr;  // page-locked, [2]
+	// where the chunk's time on the stream goes (urmapx_text_report.ms_*): start, after each side's H2D [1..2], before the
+	// mapping kernels [3], after them [4], before the copy back [5], after it [6]
+	hipEvent_t ev[7] = {};
+	bool ev_ok = false;
+	int ev_sides = 1;
 	// a chunk mapped and measured whose text has not been fetched (urmapx_text_fetch_sam)
 	uint32_t last_pairs = 0;  // pairs of the last chunk urmapx_text_map_pe mapped (urmapx_text_fetch_pairs)
 	bool pending = false;
@@ -650,7 +707,9 @@ int parse_side(urmapx_text *T, int side, const char *fastq, size_t nbytes, uint3
 	if ((rc = T->blen[side].ensure(rec_cap))) return rc;
 	TextHdr *hdr = T->hdr.p + side;
 	const uint8_t *raw = T->raw[side].p;
+	if (T->ev_ok && side == 0) HIP_TRY(hipEventRecord(T->ev[0], st));
 	HIP_TRY(hipMemcpyAsync(T->raw[side].p, fastq, nbytes, hipMemcpyHostToDevice, st));
+	if (T->ev_ok) HIP_TRY(hipEventRecord(T->ev[1 + side], st));
 	if (padded + 16 > nbytes) HIP_TRY(hipMemsetAsync(T->raw[side].p + nbytes, 0, padded + 16 - nbytes, st));
 	hipLaunchKernelGGL(nl_count_kernel, dim3(GRID), dim3(NL_THREADS), 0, st, (const uint4 *)raw, n_tiles, T->tile_counts[side].p, hdr);
 	hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(1024), 0, st, T->tile_counts[side].p, (const uint32_t *)nullptr, 1u, n_tiles, &hdr->n_lines);
@@ -671,9 +730,21 @@ int fetch_sam(urmapx_text *T, char *sam, size_t sam_cap, urmapx_text_report *rep
 	A.sam = (char *)T->sam.p;
 	hipLaunchKernelGGL(sam_kernel, dim3(GRID), dim3(SAM_WAVES * 64), 0, st, A);
 	HIP_TRY(hipGetLastError());
+	if (T->ev_ok) HIP_TRY(hipEventRecord(T->ev[5], st));
 	HIP_TRY(hipMemcpyAsync(sam, T->sam.p, rep->sam_bytes, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipMemcpyAsync(T->h_hdr, T->hdr.p, sizeof(TextHdr), hipMemcpyDeviceToHost, st));
+	if (T->ev_ok) HIP_TRY(hipEventRecord(T->ev[6], st));
 	HIP_TRY(hipStreamSynchronize(st));
+	if (T->ev_ok) {  // (the parse share holds the second side's H2D of a pair chunk's other file only as far as it is not copy)
+		float a = 0, b = 0, c = 0, d = 0, e = 0, f = 0;
+		(void)hipEventElapsedTime(&a, T->ev[0], T->ev[1]);
+		if (T->ev_sides == 2) (void)hipEventElapsedTime(&f, T->ev[1], T->ev[2]);  // side 0's parse kernels + side 1's copy
+		(void)hipEventElapsedTime(&b, T->ev[T->ev_sides], T->ev[3]);
+		(void)hipEventElapsedTime(&c, T->ev[3], T->ev[4]);
+		(void)hipEventElapsedTime(&d, T->ev[4], T->ev[5]);
+		(void)hipEventElapsedTime(&e, T->ev[5], T->ev[6]);
+		rep->ms_h2d = a; rep->ms_parse = b + f; rep->ms_map = c; rep->ms_format = d; rep->ms_d2h = e;
+	}
 	T->pending = false;
 	if (T->h_hdr[0].flags & 32u) {  // the two record kernels disagreed on a length: the text is not trusted
 		rep->reason = URMAPX_TEXT_INTERNAL;
@@ -731,6 +802,7 @@ int map_text(urmapx_text *T, const char *fastq1, size_t nbytes1, const char *fas
 	if (n == 0) return URMAPX_OK;
 	if ((rc = T->results.ensure(n))) return rc;
 	if ((rc = T->pathops.ensure((size_t)n * URMAPX_MAX_PATH_OPS))) return rc;
+	if (T->ev_ok) HIP_TRY(hipEventRecord(T->ev[3], st));
 	if (paired) {
 		const uint32_t mx = h1.max_len > MAX_QL_PE ? MAX_QL_PE : h1.max_len;
 		rc = urmapx_map_pe_device(C, T->bases.p, T->offs.p, n / 2, h1.total_bases, mx, T->results.p, T->pathops.p, T->used.p);
@@ -739,6 +811,8 @@ int map_text(urmapx_text *T, const char *fastq1, size_t nbytes1, const char *fas
 		rc = urmapx_map_se_device(C, T->bases.p, T->offs.p, n, h1.total_bases, mx, T->results.p, T->pathops.p, T->used.p);
 	}
 	if (rc) return rc;
+	if (T->ev_ok) HIP_TRY(hipEventRecord(T->ev[4], st));
+	T->ev_sides = paired ? 2 : 1;
 	T->last_pairs = paired ? n / 2 : 0;
 	SamArgs A;
 	A.raw[0] = T->raw[0].p; A.raw[1] = T->raw[1].p; A.ends[0] = T->ends[0].p; A.ends[1] = T->ends[1].p; A.paired = paired ? 1u : 0u;
@@ -791,6 +865,9 @@ int urmapx_text_create(urmapx_ctx *C, urmapx_text **out) {
 	if (!rc && e == hipSuccess) e = hipHostMalloc((void **)&T->h_hdr, 2 * sizeof(TextHdr), hipHostMallocDefault);
 	if (!rc && e != hipSuccess) rc = hip_rc(e);
 	if (rc) { urmapx_text_destroy(T); return rc; }
+	T->ev_ok = true;
+	for (hipEvent_t &x : T->ev)
+		if (hipEventCreate(&x) != hipSuccess) { T->ev_ok = false; x = nullptr; }
 	T->seq_count = n;
 	*out = T;
 	return URMAPX_OK;
@@ -806,6 +883,8 @@ void urmapx_text_destroy(urmapx_text *T) {
 	T->used.release(); T->tname_offs.release(); T->offs.release(); T->tnames.release(); T->results.release(); T->pathops.release();
 	T->hdr.release();
 	if (T->h_hdr) (void)hipHostFree(T->h_hdr);
+	for (hipEvent_t x : T->ev)
+		if (x) (void)hipEventDestroy(x);
 	delete T;
 }
 

@@ -54,7 +54,7 @@ struct Opts {
 	double load_factor = 0.6;  // myopts.h: FLT_OPT(load_factor, 0.6, ...)
 	unsigned threads = 0, wordlength = 24, maxix = 0, minq = 10;
 	unsigned long long slots = 0;
-	int gpu = 0, gpus = 1, streams = 2;
+	int gpu = 0, gpus = 1, streams = 2, samshards = 0;
 	unsigned batch = 1u << 18;
 };
 
@@ -83,6 +83,7 @@ static Opts parse(int argc, char **argv) {
 		else if (a == "-gpu") o.gpu = atoi(val());
 		else if (a == "-gpus") o.gpus = atoi(val());
 		else if (a == "-streams") o.streams = atoi(val());
+		else if (a == "-samshards") o.samshards = atoi(val());
 		else if (a == "-batch") o.batch = (unsigned)atoi(val());
 		else if (a == "-veryfast") o.veryfast = true;
 		else if (a == "-host") o.host_build = true;
@@ -137,6 +138,7 @@ static int cmd_map(const Opts &o, int argc, char **argv) {
 	if (o.ufi.empty()) die("-ufi option required");
 	if (o.gpus < 1 || o.gpus > 64) die("-gpus must be 1..64");
 	if (o.streams < 1 || o.streams > 8) die("-streams must be 1..8");
+	if (o.samshards < 0 || o.samshards > 64) die("-samshards must be 0..64");
 	const auto t0 = std::chrono::steady_clock::now();
 	urmapx_index *I = nullptr;
 	check(urmapx_index_open(o.ufi.c_str(), &I), ("Reading index " + o.ufi).c_str());
@@ -145,6 +147,8 @@ static int cmd_map(const Opts &o, int argc, char **argv) {
 	std::string cl;
 	for (int i = 0; i < argc; ++i) { cl += argv[i]; cl.push_back(' '); }  // argv joined with trailing spaces (state1.cpp:749-751)
 	urmapx_map_options mo;
+	memset(&mo, 0, sizeof mo);
+	mo.sam_shards = o.samshards;  // -samout out.sam -samshards N: out.sam.0 .. out.sam.N-1, `cat` of them = the one file
 	mo.first_gpu = o.gpu; mo.gpus = o.gpus; mo.streams = o.streams; mo.host_threads = (int)o.threads; mo.batch = o.batch;
 	mo.veryfast = o.veryfast ? 1 : 0; mo.minq = o.minq; mo.cmdline = cl.c_str();
 	urmapx_map_report rep;
@@ -278,7 +282,7 @@ int main(int argc, char **argv) {
 	log_open(o, argc, argv);
 	if (!o.map.empty() || !o.map2.empty()) { const int rc = cmd_map(o, argc, argv); log_close(); return rc; }
 	if (!o.make_ufi.empty()) { const int rc = cmd_make_ufi(o); log_close(); return rc; }
-	fprintf(stderr, "urmap (MI355X build)\n  urmap -map reads.fq -ufi index.ufi -samout out.sam [-veryfast] [-gpu D] [-gpus N] [-streams K]\n"
+	fprintf(stderr, "urmap (MI355X build)\n  urmap -map reads.fq -ufi index.ufi -samout out.sam [-veryfast] [-gpu D] [-gpus N] [-streams K] [-samshards N]\n"
 	                "  urmap -map2 R1.fq -reverse R2.fq -ufi index.ufi -samout out.sam [-tabbedout out.tab] [-gpu D] [-gpus N]\n"
 	                "  urmap -make_ufi genome.fa -output index.ufi [-slots N] [-wordlength W] [-maxix M]\n");
 	return 0;

@@ -374,6 +374,8 @@ int urmapx_ctx_last_kernel_ms(urmapx_ctx *C, float ms[2]) {
 	return URMAPX_OK;
 }
 
+static constexpr int PE_SLOW_BLOCKS = 32;  // grid of the general pair kernel (9.5 MB of lists per block)
+
 static int ensure_probe(urmapx_ctx *C, uint64_t total_bases) {
 	int rc;
 	if ((rc = C->slots.ensure(2 * total_bases + 64))) return rc;
@@ -464,12 +466,14 @@ int urmapx_map_se_device(urmapx_ctx *C, const void *d_bases, const void *d_offs,
 	HIP_TRY(hipEventRecord(C->ev[0], C->stream));
 	HIP_TRY(hipEventRecord(C->ev[1], C->stream));
 	C->stage_valid = stamps && n > 0;  // an empty batch records no stage events (launch_search_se returns at once)
+	// the general kernel's lists are sized before anything is enqueued: growing them (hipMalloc / hipFree) between the two
+	// launches would stall the stream in the middle of a batch
+	const int sblocks = slow_qcap <= URMAPX_MAX_QL ? 128 : 64;
+	if ((rc = C->slowscratch.ensure(slow_scratch_stride(slow_qcap) * (size_t)sblocks))) return rc;
+	if ((rc = C->slowlist.ensure((size_t)n + 2))) return rc;
 	HIP_TRY(launch_search_se(C->X, C->params, (const uint8_t *)d_bases, (const uint64_t *)d_offs, n, max_read_len,
 	                         (urmapx_result *)d_results, (urmapx_path_op *)d_path_ops, (uint32_t *)d_path_used, wk, C->stream));
 	{  // reads outside the fast kernels' domain: the general kernel (it finds its work list on the device; usually empty)
-		const int sblocks = slow_qcap <= URMAPX_MAX_QL ? 128 : 64;
-		if ((rc = C->slowscratch.ensure(slow_scratch_stride(slow_qcap) * (size_t)sblocks))) return rc;
-		if ((rc = C->slowlist.ensure((size_t)n + 2))) return rc;
 		const uint64_t pcap = (uint64_t)n * URMAPX_MAX_PATH_OPS;
 		HIP_TRY(launch_search_se_slow(C->X, C->params, (const uint8_t *)d_bases, (const uint64_t *)d_offs, n, slow_qcap,
 		                              (urmapx_result *)d_results, (urmapx_path_op *)d_path_ops, (uint32_t *)d_path_used,
@@ -558,6 +562,8 @@ int urmapx_map_pe_device(urmapx_ctx *C, const void *d_bases, const void *d_offs,
 	wk.scratch_stride = search_pe_scratch_stride(max_read_len);
 	if ((rc = C->pe_scratch.ensure(wk.scratch_stride * (size_t)wk.blocks + search_pe_scratch_tail(wk.blocks)))) return rc;
 	if ((rc = C->ovflist.ensure(2 * ((size_t)npairs + 1)))) return rc;  // work lists of the second and third pass
+	if ((rc = C->slowscratch.ensure(pe_slow_scratch_stride() * (size_t)PE_SLOW_BLOCKS))) return rc;  // the general pair kernel's lists
+	if ((rc = C->slowlist.ensure((size_t)npairs + 2))) return rc;
 	wk.ovf_list = C->ovflist.p;
 	if (const char *e = getenv("URMAPX_TEST_HSP_LDS_CAP")) wk.hsp_lds_cap = atoi(e);
 	wk.scratch = C->pe_scratch.p;
@@ -580,6 +586,13 @@ int urmapx_map_pe_device(urmapx_ctx *C, const void *d_bases, const void *d_offs,
 	HIP_TRY(launch_search_pe(C->X, Ppe, (const uint8_t *)d_bases, (const uint64_t *)d_offs, npairs, max_read_len,
 	                         (urmapx_result *)d_results, (urmapx_path_op *)d_path_ops, (uint32_t *)d_path_used, wk,
 	                         C->pe_veryfast | (getenv("URMAPX_DEBUG_STOP_PE") ? atoi(getenv("URMAPX_DEBUG_STOP_PE")) << 8 : 0), d_info, C->stream));  // bits 8..: diagnostic schedule cut
+	{  // pairs outside the fast passes' domain: the general pair kernel (it finds its work list on the device; usually empty)
+		const uint64_t pcap = (uint64_t)npairs * 2 * URMAPX_MAX_PATH_OPS;
+		HIP_TRY(launch_search_pe_slow(C->X, Ppe, (const uint8_t *)d_bases, (const uint64_t *)d_offs, npairs, (urmapx_result *)d_results,
+		                              (urmapx_path_op *)d_path_ops, (uint32_t *)d_path_used, (uint32_t)(pcap > 0xFFFFFFFFull ? 0xFFFFFFFFull : pcap),
+		                              C->slowscratch.p, PE_SLOW_BLOCKS, C->slowlist.p + 1, C->slowlist.p, C->pe_veryfast, d_info,
+		                              getenv("URMAPX_TEST_PE_GENERAL") != nullptr, C->stream));  // test aid: every pair through the general kernel
+	}
 	HIP_TRY(hipEventRecord(C->ev[2], C->stream));
 	C->ev_valid = true;
 	return URMAPX_OK;

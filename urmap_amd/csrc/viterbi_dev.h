@@ -40,11 +40,16 @@ struct RevOps {  // run-length path, traceback order (last column first)
 	bool overflow;
 	__device__ __forceinline__ void begin() { n = 0; cur_op = -1; cur_len = 0; overflow = false; }
 	__device__ __forceinline__ void push_run(int op, int len, int lane) {
-		if (n < cap) {
-			if (lane == 0) ops[n] = (uint16_t)((len << 2) | op);
-			++n;
-		} else
-			overflow = true;
+		// 14 bits of length: a longer run (the general kernel's reads beyond 16 383 bases) becomes several runs of one kind
+		do {
+			const int piece = len > 16383 ? 16383 : len;
+			if (n < cap) {
+				if (lane == 0) ops[n] = (uint16_t)((piece << 2) | op);
+				++n;
+			} else
+				overflow = true;
+			len -= piece;
+		} while (len > 0);
 	}
 	__device__ __forceinline__ void emit(int op, int lane) {
 		if (op == cur_op) ++cur_len;
