@@ -350,6 +350,7 @@ def place_index(R, torch, api, device, d_seq, slots, seq_lengths, seq_offsets, l
                 np.save(cpre + "_blob.npy", blob_np)
     t_build = time.time() - t0
     t0 = time.time()
+    broadcast_s = None
     if R.world == 1:
         index = api.Index.wrap_host(24, 32, slots, blob_np, seq_np, seq_lengths, seq_offsets, labels).upload(R.device_index)
     elif R.backend == "nccl" or os.environ.get("URMAP_BENCH_BROADCAST"):
@@ -366,8 +367,11 @@ def place_index(R, torch, api, device, d_seq, slots, seq_lengths, seq_offsets, l
                     d_blob[lo:hi] = torch.from_numpy(np.asarray(blob_np[lo:hi])).to(device)
             d_blob[5 * slots:] = 0
             d_seqpad[:size] = d_seq
+        t_b = time.time()
         R.broadcast_bytes(torch, d_blob)
         R.broadcast_bytes(torch, d_seqpad)
+        torch.cuda.synchronize()
+        broadcast_s = time.time() - t_b
         d_seq = d_seqpad[:size]
         index = api.Index.wrap_device(R.device_index, 24, 32, slots, d_blob.data_ptr(), d_seqpad.data_ptr(), size,
                                       seq_lengths, seq_offsets, labels, keep=(d_blob, d_seqpad))
@@ -395,7 +399,13 @@ def place_index(R, torch, api, device, d_seq, slots, seq_lengths, seq_offsets, l
                     os.remove(shm + suf)
                 except OSError:
                     pass
-    return index, blob_np, seq_np, d_seq, {"make_ufi": round(t_build, 1), "upload": round(time.time() - t0, 1), "how": how}
+    info = {"make_ufi": round(t_build, 1), "upload": round(time.time() - t0, 1), "how": how,
+            # what every rank holds in HBM for the index: slot table + sequence + its packed copy (4 bit planes per 32 bases)
+            "index_bytes_per_rank": int(5 * slots + 8 + size + 4096 + 16 * ((size + 31) // 32 + 1))}
+    if broadcast_s is not None:
+        info["broadcast_s"] = round(broadcast_s, 2)
+        info["broadcast_pieces"] = int((5 * slots + 8 + (1 << 30) - 1) >> 30) + int((size + 4096 + (1 << 30) - 1) >> 30)
+    return index, blob_np, seq_np, d_seq, info
 
 
 class Workload:
@@ -602,6 +612,20 @@ def bgzf_bytes(data, block=60000, level=1):
     return bytes(out)
 
 
+def files_equal_concat(one, parts, block=64 << 20):
+    """`cat parts` == the file `one`, byte for byte"""
+    with open(one, "rb") as f:
+        for p in parts:
+            with open(p, "rb") as g:
+                while True:
+                    b = g.read(block)
+                    if not b:
+                        break
+                    if f.read(len(b)) != b:
+                        return False
+        return f.read(1) == b""
+
+
 def e2e_bound(rep):
     """Which stage of urmapx_map_files' pipeline the run waited for: the stage whose busy time fills the wall time."""
     wall = max(rep["seconds"], 1e-9)
@@ -660,6 +684,31 @@ def run_e2e(torch, api, oi, index, device, d_seq, seq_lengths, seq_offsets, L, s
                     break
         same = got == want
         bound, shares = e2e_bound(rep)
+        # the same run with the SAM text dropped after it has reached the host: what the device lanes sustain when the output
+        # medium is out of the way, and where a lane's time goes (events on the lanes' streams)
+        null_rep = [api.map_files(index, fq, samout=sam + ".null", first_gpu=device.index, gpus=gpus, streams=E2E_STREAMS, batch=E2E_BATCH,
+                                  cmdline="bench.py e2e", discard_sam=True) for _ in range(2)][-1]
+        lanes = max(1, null_rep["lanes"])
+        null_sink = {"value": round(null_rep["reads"] / null_rep["seconds"], 1), "unit": "reads/s", "seconds": round(null_rep["seconds"], 3),
+                     "lanes": lanes, "lane_busy_s_summed": round(null_rep["gpu_s"], 3),
+                     "stream_time_s_summed_over_lanes": {k[4:-2]: round(null_rep[k], 3) for k in ("dev_h2d_s", "dev_parse_s", "dev_map_s", "dev_format_s", "dev_d2h_s")},
+                     "note": "urmapx_map_files with discard_sam: FASTQ bytes to the device, SAM bytes back to the host, nothing written; "
+                             "stream times from HIP events per chunk (copy in, line ends + record checks + base copy, mapping kernels, SAM lengths + text, copy out), "
+                             "summed over the chunks of all lanes: divide by `lanes` for the wall share"}
+        # one SAM file per pipeline (urmap -samshards N): N readers, lanes and writers side by side; `cat` of the shards must be the one file
+        n_shards = gpus if gpus > 1 else 2
+        for p in [sam + f".sh.{k}" for k in range(n_shards)]:
+            if os.path.exists(p):
+                os.remove(p)
+        sh_rep = [api.map_files(index, fq, samout=sam + ".sh", first_gpu=device.index, gpus=gpus, streams=E2E_STREAMS, batch=E2E_BATCH,
+                                cmdline="bench.py e2e", sam_shards=n_shards) for _ in range(2)][-1]
+        sharded = {"value": round(sh_rep["reads"] / sh_rep["seconds"], 1), "unit": "reads/s", "seconds": round(sh_rep["seconds"], 3), "shards": n_shards,
+                   "vs_one_file": round((sh_rep["reads"] / sh_rep["seconds"]) / (rep["reads"] / rep["seconds"]), 3),
+                   "cat_of_shards_equals_the_one_file": files_equal_concat(sam, [sam + f".sh.{k}" for k in range(n_shards)]),
+                   "note": f"urmap -samout out.sam -samshards {n_shards}: shard s = the s-th part of the input (cut at a record), its own reader, "
+                           f"lanes and writer{'' if gpus > 1 else ' (here: two pipelines on the one GPU)'}; header in shard 0"}
+        for k in range(n_shards):
+            os.remove(sam + f".sh.{k}")
         ceiling = write_ceiling_gbs(d)
         sam_gb = os.path.getsize(sam) / 1e9
         out = {"value": round(rep["reads"] / rep["seconds"], 1), "unit": "reads/s", "reads": int(rep["reads"]), "gpus": gpus,
@@ -673,7 +722,8 @@ def run_e2e(torch, api, oi, index, device, d_seq, seq_lengths, seq_offsets, L, s
                        f"(format_s 0 = no host formatting; write_s = one thread's pwrite into tmpfs, the stage that bounds the run)",
                "stage_busy_s": {k: round(rep[k], 3) for k in ("parse_s", "gpu_s", "format_s", "write_s")},
                "mapped_q10_frac": round(rep["mapped_q"] / max(1, rep["reads"]), 4),
-               "sam_records_identical_to_oracle": bool(same), "sam_records_checked": len(want)}
+               "sam_records_identical_to_oracle": bool(same), "sam_records_checked": len(want),
+               "null_sink": null_sink, "sharded": sharded}
         if ref:
             out["reference_binary"] = ref
         if gpus == 1 and not os.environ.get("URMAP_BENCH_NO_E2E_GZ"):
@@ -910,9 +960,14 @@ def main():
                                    f"{len(seq_np) / 1e9:.2f} GB sequence resident in HBM); {nb} reads/step, {args.sub:g} sub, {args.indel:g} indel",
                        "reads_per_step": nb, "streams": len(mappers), "reads_per_launch": nb // len(mappers),
                        "read_len": L, "genome_bp": int(len(seq_np)), "slots": int(slots),
-                       "genome": genome_desc, "ranks": {"world": world, "backend": R.backend, "share_devices": bool(R.shared)},
+                       "genome": genome_desc, "ranks": {"world": world, "backend": R.backend, "share_devices": bool(R.shared),
+                                 "index_bytes_per_rank": t_index.get("index_bytes_per_rank"), "broadcast_s": t_index.get("broadcast_s"),
+                                 "broadcast_pieces": t_index.get("broadcast_pieces")},
                        "setup_s": {"genome": round(t_gen, 1), **t_index, "total": round(setup_s, 1)}},
-            "roofline": {"bound": "hbm", "kernel": kern[dom]["kernel"], "achieved": kern[dom]["achieved_GBs"],
+            # bound: the limiter the counters show (profiles/r4: the waves of the search kernels wait on memory LATENCY more than half
+            # of their cycles and issue in most of the rest; traffic is a few percent of the HBM peak) -- `peak` stays the HBM peak the
+            # contract prices against, `frac` = algorithmic bytes / time / peak
+            "roofline": {"bound": "latency+issue", "bound_in_contract_terms": "hbm", "peak_kind": "hbm", "kernel": kern[dom]["kernel"], "achieved": kern[dom]["achieved_GBs"],
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": kern[dom]["frac"],
                          "limiter": KERNEL_LIMITER.get(kern[dom]["kernel"], ""),
                          "whole_step": {"alg_bytes_per_read": round(sum(k["alg_bytes_per_read"] for k in kern), 1),
@@ -952,6 +1007,11 @@ def main():
                                 "work_per_read": {k: round(v, 2) for k, v in ocnt.items()},
                                 "cpu_port_reads_per_s": round(opar["reads_checked"] / ot, 1), "cpu_port_threads": cores,
                                 "sub": osub, "indel": oindel, "wall_s": round(time.time() - t0, 1)}
+                if wl.dp_stats:
+                    ds = wl.dp_stats
+                    others[name]["phase6"] = {"hsps_given_to_dp_kernel": ds[0], "reads_with_such_hsps": ds[1], "dps_the_ordered_replay_used": ds[2],
+                                              "dropped_by_a_round_gate_before_their_dp": ds[3],
+                                              "second_pass": {"hsps": ds[4], "reads": ds[5], "used": ds[6], "gated": ds[7]}}
             out["other_workloads"] = others
         if world == 1 and not pe and L == 150 and not args.no_e2e:
             try:
@@ -981,7 +1041,12 @@ def main():
             if R.shared:
                 os.environ["URMAPX_FORCE_DEVICE"] = str(dev_index)
             try:
-                out["e2e"] = run_e2e(torch, api, oi, index, device, d_seq, seq_lengths, seq_offsets, L, args.sub, args.indel,
+                e2e_index = index
+                if R.backend == "nccl" or os.environ.get("URMAP_BENCH_BROADCAST"):
+                    # the ranks' replicas came over the broadcast and live in THEIR processes; rank 0's file-to-file run over all devices
+                    # uploads its own from the host arrays (urmapx_index_replicate)
+                    e2e_index = api.Index.wrap_host(24, 32, slots, blob_np, seq_np, seq_lengths, seq_offsets, labels).upload(dev_index)
+                out["e2e"] = run_e2e(torch, api, oi, e2e_index, device, d_seq, seq_lengths, seq_offsets, L, args.sub, args.indel,
                                      int(os.environ.get("URMAP_BENCH_E2E_READS", 2_000_000 * min(world, 8))), cores, ref_bin=None, gpus=world)
             except Exception as e:
                 out["e2e"] = {"error": str(e)[:300]}
