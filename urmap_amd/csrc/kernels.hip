@@ -1713,10 +1713,14 @@ __global__ __launch_bounds__(64) void finalize_se_kernel(DevIndex X, urmapx_para
 		const int phase = S.restore_state(st);
 		uint32_t used = 0;
 		const uint32_t kend = nj < khi ? nj : khi;
-		// 64 jobs come in with one round of loads (one job per lane: the words the replay reads), then they are replayed
-		// in order out of registers; a job whose HSP already fails AlignHSP's first test under the cap as it stands fails
-		// it at its turn too (the cap only falls) and is not visited.  One scalar load per job, each waiting for the last,
-		// made this launch as long as the DP launches it follows for 250-base reads (10.4 of 118 ms per 1 M reads).
+		// 64 jobs come in with one round of loads (one job per lane: the words the replay reads).  Round 4: every lane then runs
+		// AlignHSP's tests on its own job against the state as it stands -- the penalty after the HSP, after the left flank,
+		// after the right flank against the cap (alignhsp.cpp:62-70,127-130,160-162), the score against best - 12
+		// (state1.cpp:530-536).  The cap only falls and the best score only rises, so a job that fails one of them now fails
+		// it at its turn too and changes nothing: only the jobs that pass go through the ordered replay (consume_job, which
+		// repeats the tests at the job's turn), and the set is filtered again after every change.  A read in a repeat family
+		// brings hundreds of jobs of which a handful end in a hit; replaying them one by one made this launch 9.7 of 105 ms per
+		// 1 M 250-base reads.  (Jobs that raise a status bit -- a DP that outgrew its buffers -- always take the ordered road.)
 		for (uint32_t k0 = klo; k0 < kend; k0 += 64) {
 			const uint32_t k = k0 + (uint32_t)lane;
 			uint32_t jpk = 0;
@@ -1726,8 +1730,21 @@ __global__ __launch_bounds__(64) void finalize_se_kernel(DevIndex X, urmapx_para
 				jpk = jp[2];
 				jw = *reinterpret_cast<const uint4 *>(jp + 4);
 			}
-			const int jpen = (int)((jpk >> PK_LEN_SH) & PK_MASK) - (int)((jpk >> PK_SCORE_SH) & PK_MASK);
-			uint64_t todo = __ballot(k < kend && jpen <= S.maxPen);
+			const int jstartq = (int)(jpk & PK_MASK), jlen = (int)((jpk >> PK_LEN_SH) & PK_MASK), jhs = (int)((jpk >> PK_SCORE_SH) & PK_MASK);
+			const int jpen = jlen - jhs;
+			const int jls = (int)(int16_t)(jw.y & 0xFFFFu), jrs = (int)(int16_t)(jw.y >> 16);
+			const uint32_t jfl = (jw.z >> 8) & 0xFFu;
+			const bool has_l = jstartq > 0, has_r = jstartq + jlen < S.QL;
+			const bool raises = (jw.z >> 16) != 0u || (jfl & (DPJ_GATED | DPJ_PATH_LONG)) != 0u;  // vst_l / vst_r / flags that set a status bit
+			const bool dead = (has_l && (jfl & DPJ_LEFT_FAIL)) || (has_r && (jfl & (DPJ_RIGHT_FAIL | DPJ_RIGHT_SKIPPED)));
+			const int pen1 = jpen + (has_l ? jstartq - jls : 0);
+			const int pen2 = pen1 + (has_r ? (S.QL - (jstartq + jlen)) - jrs : 0);
+			const int jscore = jhs + (has_l ? jls : 0) + (has_r ? jrs : 0);
+			auto viable = [&]() {
+				return k < kend && jpen <= S.maxPen && (raises || (!dead && pen1 <= S.maxPen && pen2 <= S.maxPen && jscore >= S.best - SECONDARY_HIT_MAX_DELTA && jscore >= 10));
+			};
+			used += (uint32_t)__builtin_popcountll(__ballot(k < kend && jpen <= S.maxPen));
+			uint64_t todo = __ballot(viable());
 			while (todo) {
 				const int t = __builtin_ctzll(todo);
 				todo &= todo - 1;
@@ -1738,9 +1755,9 @@ __global__ __launch_bounds__(64) void finalize_se_kernel(DevIndex X, urmapx_para
 				const uint32_t sc = rdlane(jw.y, t), fl = rdlane(jw.z, t);
 				J.left_score = (int16_t)(sc & 0xFFFFu); J.right_score = (int16_t)(sc >> 16);
 				J.nops = (uint8_t)(fl & 0xFFu); J.flags = (uint8_t)((fl >> 8) & 0xFFu); J.vst_l = (uint8_t)((fl >> 16) & 0xFFu); J.vst_r = (uint8_t)(fl >> 24);
-				const int mp0 = S.maxPen;
-				used += S.consume_job(J, dp.ops + (size_t)(jb + k0 + (uint32_t)t) * DP_JOB_OPS) ? 1u : 0u;
-				if (S.maxPen != mp0) todo &= __ballot(jpen <= S.maxPen);
+				const int mp0 = S.maxPen, b0 = S.best;
+				S.consume_job(J, dp.ops + (size_t)(jb + k0 + (uint32_t)t) * DP_JOB_OPS);
+				if (S.maxPen != mp0 || S.best != b0) todo &= __ballot(viable());
 			}
 		}
 		if (lane == 0 && used) atomicAdd(dp.counters + 2, used);  // statistics: jobs whose DP the ordered replay looked at

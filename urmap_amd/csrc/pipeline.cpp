@@ -579,6 +579,9 @@ namespace {
 // One shard of a sharded run (urmapx_map_options.sam_shards): the records of bytes [lo, hi) of the (plain, seekable) input
 // file(s), cut at record starts; the SAM header only in the first shard.
 struct InputRange {
+	// out: when this pipeline's clock started (contexts made, files open) and stopped, on the steady clock -- the wall time of a
+	// sharded run is first start .. last stop, with the set-up outside as in a run of one pipeline
+	mutable double t_begin = 0, t_end = 0;
 	bool on = false;
 	uint64_t lo[2] = {0, 0}, hi[2] = {0, 0};
 	uint64_t lines_before = 0;  // lines of each file in front of lo (they name the line in the reader's messages)
@@ -1400,6 +1403,8 @@ int map_files_impl(urmapx_index *I, const urmapx_map_options *opt, const InputRa
 	if (have_sam && !sink.finish(sam_off)) fail.raise(URMAPX_E_IO, std::string("Error writing ") + samout);
 	if (ftab) fclose(ftab);
 	const auto t2 = std::chrono::steady_clock::now();
+	range.t_begin = std::chrono::duration<double>(t1.time_since_epoch()).count();
+	range.t_end = std::chrono::duration<double>(t2.time_since_epoch()).count();
 	trace.dump();
 	release();
 	if (report) {
@@ -1522,7 +1527,13 @@ extern "C" int urmapx_map_files(urmapx_index *I, const urmapx_map_options *opt, 
 			errs[(size_t)s] = e;
 		});
 	for (auto &t : th) t.join();
-	const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+	double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+	{
+		double b = 0, e = 0;
+		for (const InputRange &r : ranges)
+			if (r.t_end > 0) { b = b == 0 ? r.t_begin : std::min(b, r.t_begin); e = std::max(e, r.t_end); }
+		if (e > b) wall = e - b;
+	}
 	release();
 	int out_rc = URMAPX_OK;
 	for (int s = 0; s < shards; ++s)
