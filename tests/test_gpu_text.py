@@ -502,7 +502,7 @@ def _file_records(path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind", ["gzip", "members", "bgzf"])
+@pytest.mark.parametrize("kind", ["gzip", "members", "bgzf", "padded"])
 def test_cli_gz_input_takes_the_device_text_path(small_case, tmp_path, kind):
     """.gz FASTQ (linereader.cpp:14-113 reads it through zlib): chunks are cut out of the inflated stream and go to the device
     as bytes -- no host parsing, no host formatting (format 0.00 in the stage report), the oracle's records, at several chunk
@@ -519,6 +519,8 @@ def test_cli_gz_input_takes_the_device_text_path(small_case, tmp_path, kind):
     elif kind == "members":
         cuts = [0, len(data) // 3 + 17, 2 * len(data) // 3 + 5, len(data)]  # member ends fall inside records
         open(gz, "wb").write(b"".join(gzip.compress(data[a:b], 1) for a, b in zip(cuts, cuts[1:])))
+    elif kind == "padded":  # zero padding behind the last member: zlib's gzread (the reference, the host reader) ignores it
+        open(gz, "wb").write(gzip.compress(data[: len(data) // 2], 1) + gzip.compress(data[len(data) // 2:], 1) + b"\0" * 1024)
     else:
         open(gz, "wb").write(_bgzf(data))
     want = _file_records(osam)

@@ -494,9 +494,9 @@ __global__ __launch_bounds__(64) void search_pe_slow_kernel(DevIndex X, urmapx_p
 					const uint32_t nops = S.hit_pn[S.topHit];
 					if (nops > 0) {
 						uint32_t po = 0;
-						if (lane == 0) po = atomicAdd(path_used, nops);
+						if (lane == 0) po = reserve_path(path_used, nops, path_cap);  // room is taken only if the path fits
 						po = uni(po);
-						if (po + nops <= path_cap && nops <= 0xFFFFu) {
+						if (po != 0xFFFFFFFFu && nops <= 0xFFFFu) {
 							const uint16_t *src = S.parena + S.hit_poff[S.topHit];
 							for (uint32_t t = lane; t < nops; t += 64) path_ops[po + t] = src[t];
 							O.path_off = po; O.path_nops = (uint16_t)nops;

@@ -97,9 +97,10 @@ __global__ __launch_bounds__(64) void search_se_slow_kernel(DevIndex X, urmapx_p
 				res.dbpos = S.top_db; res.seq_index = found; res.coord = coord; res.plus = S.top_plus ? 1 : 0;
 				if (S.top_nops > 0) {
 					uint32_t po = 0;
-					if (lane == 0) po = atomicAdd(path_used, (uint32_t)S.top_nops);
+					// room is taken only if the path fits (a count past the arena's end made the host reject the whole batch)
+					if (lane == 0) po = reserve_path(path_used, (uint32_t)S.top_nops, path_cap);
 					po = uni(po);
-					if (po + (uint32_t)S.top_nops <= path_cap && S.top_nops <= 0xFFFF) {
+					if (po != 0xFFFFFFFFu && S.top_nops <= 0xFFFF) {
 						for (int t = lane; t < S.top_nops; t += 64) path_ops[po + t] = S.top[t];
 						res.path_off = po; res.path_nops = (uint16_t)S.top_nops;
 					} else

@@ -473,6 +473,12 @@ private:
 				eof_ = true;
 				break;
 			}
+			if (member_done_ && seen_member_) {
+				// behind a complete member: another member continues the text; anything else (zero padding, trailing garbage) ends
+				// the input, as zlib's gzread treats it (gz_look) -- the reference and the host reader read such a file to its end
+				if (chave_ - cbeg_ < 2) (void)refill();
+				if (chave_ - cbeg_ < 2 || cbuf_[cbeg_] != 0x1f || cbuf_[cbeg_ + 1] != 0x8b) { eof_ = true; break; }
+			}
 			zs_.next_in = cbuf_.data() + cbeg_;
 			zs_.avail_in = (uInt)(chave_ - cbeg_);
 			zs_.next_out = (Bytef *)dst + out;
@@ -483,7 +489,7 @@ private:
 			out += out0 - zs_.avail_out;
 			member_done_ = false;
 			if (rc == Z_STREAM_END) {  // the next member, if any, continues the text (gzread does the same)
-				member_done_ = true;
+				member_done_ = true; seen_member_ = true;
 				if (inflateReset(&zs_) != Z_OK) { bad_ = true; break; }
 			} else if (rc != Z_OK && rc != Z_BUF_ERROR) { bad_ = true; break; }
 		}
@@ -538,7 +544,7 @@ private:
 		return out;
 	}
 	int fd_ = -1;
-	bool gz_ = false, bgzf_ = false, eof_ = false, bad_ = false, zs_init_ = false, member_done_ = true, pipe_ = false, own_ = true;
+	bool gz_ = false, bgzf_ = false, eof_ = false, bad_ = false, zs_init_ = false, member_done_ = true, seen_member_ = false, pipe_ = false, own_ = true;
 	uint64_t csize_ = 0, cpos_ = 0;  // compressed (or plain) file: size, next byte to fetch
 	std::vector<uint8_t> cbuf_;
 	size_t cbeg_ = 0, chave_ = 0;

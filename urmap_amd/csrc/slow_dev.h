@@ -13,6 +13,17 @@ static constexpr uint32_t SLOW_HITCAP = 65536;     // live hits of one read (a t
 static constexpr uint32_t SLOW_WIDE_CAP = 1100;    // wide-band DP (flank window clipped at the end of the sequence store)
 static constexpr int SLOW_ROW_CAP = 32;            // UFIndex m_MaxIx of every index this build accepts
 
+// n entries of a batch's path arena, or 0xFFFFFFFF if they do not fit (the counter then stays where it was)
+__device__ inline uint32_t reserve_path(uint32_t *used, uint32_t n, uint32_t cap) {
+	uint32_t cur = *used;
+	for (;;) {
+		if (cur > cap || n > cap - cur) return 0xFFFFFFFFu;
+		const uint32_t seen = atomicCAS(used, cur, cur + n);
+		if (seen == cur) return cur;
+		cur = seen;
+	}
+}
+
 struct SlowLayout {
 	size_t q, slots, tal, pos, hit_db, hsp_db, hsp_q, hsp_len, hsp_score, hsp_fl, todo, rows, ropsL, ropsR, cand, top, tb, ws, total;
 	uint32_t qcap, hspcap, pathcap;
