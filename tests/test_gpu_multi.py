@@ -115,6 +115,29 @@ def test_bench_starts_its_own_two_ranks(broadcast):
         assert "broadcast of the resident arrays" in d["config"]["setup_s"]["how"]
 
 
+def test_broadcast_of_a_table_larger_than_one_piece():
+    """The 8-GPU launch's index placement on a box with one GPU: rank 0 builds the table, the other rank
+    waits in the collective, the resident arrays travel in 1 GiB pieces (ranks.broadcast_bytes) -- here at 1.2 Gbp (11.6 GB
+    of index, 12 pieces; URMAP_TEST_FULLSCALE=1: the 3.1 Gbp genome of the bench, 31.6 GB, 29 pieces).  The line carries
+    what a rank holds and how long the broadcast took; both ranks map their own reads bit-identically."""
+    mbp = 3100 if os.environ.get("URMAP_TEST_FULLSCALE") else 1200
+    env = dict(os.environ)
+    env["URMAP_BENCH_BROADCAST"] = "1"
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--genome-mbp", str(mbp), "--reads-per-step", "200000",
+                        "--steps", "2", "--warmup", "1", "--no-e2e"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500, env=env)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    d = json.loads([l for l in r.stdout.decode().splitlines() if l.startswith("{")][-1])
+    rk = d["config"]["ranks"]
+    assert d["n_gpus"] == 2 and rk["world"] == 2 and d["parity"]["bit_identical_to_oracle"], d["parity"]
+    slots, bp = d["config"]["slots"], d["config"]["genome_bp"]
+    assert rk["index_bytes_per_rank"] >= 5 * slots + bp + bp // 2  # slot table + sequence + its packed copy
+    assert rk["broadcast_pieces"] == (5 * slots + 8 + (1 << 30) - 1) // (1 << 30) + (bp + 4096 + (1 << 30) - 1) // (1 << 30) >= (29 if mbp == 3100 else 12)
+    assert rk["broadcast_s"] > 0
+    assert "broadcast of the resident arrays" in d["config"]["setup_s"]["how"]
+
+
 def test_map_files_library_call_on_a_resident_index(tmp_path):
     """urmapx_map_files (the command line's cmd_map as a library call) on an index that is already resident: golden SAM,
     the report's counters, and a FASTQ error coming back as a message instead of an exit."""

@@ -90,12 +90,16 @@ class Ranks:
         if self.world > 1:
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            # the other ranks sit in the first collective while rank 0 builds the index (24 s at hg38 scale, more on a slow host):
+            # the wait is bounded explicitly, not by a backend's default
+            import datetime
+            limit = datetime.timedelta(seconds=int(os.environ.get("URMAP_RANK_TIMEOUT_S", 1800)))
             if self.shared or not self.want_gpu:
                 self.backend = "gloo"
-                dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
+                dist.init_process_group("gloo", rank=self.rank, world_size=self.world, timeout=limit)
             else:
                 self.backend = "nccl"  # = RCCL on ROCm
-                dist.init_process_group("nccl", rank=self.rank, world_size=self.world,
+                dist.init_process_group("nccl", rank=self.rank, world_size=self.world, timeout=limit,
                                         device_id=torch.device("cuda", self.device_index))
             self.dist = dist
         return self
