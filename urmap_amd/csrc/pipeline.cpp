@@ -1508,6 +1508,8 @@ extern "C" int urmapx_map_files(urmapx_index *I, const urmapx_map_options *opt, 
 			urmapx_map_options o = *opt;
 			o.sam_shards = 0;
 			o.gpus = per;
+			// pipelines that share a device share its lanes too: K contexts per device in all, as in a run of one pipeline
+			if (shards > gpus) o.streams = std::max(1, (opt->streams > 0 ? opt->streams : 2) * gpus / shards);
 			const int g0 = gpus >= shards ? s * per : s % gpus;
 			o.first_gpu = opt->first_gpu + g0;
 			o.host_threads = std::max(2, host_threads / shards);
