@@ -401,7 +401,9 @@ def place_index(R, torch, api, device, d_seq, slots, seq_lengths, seq_offsets, l
                     pass
     info = {"make_ufi": round(t_build, 1), "upload": round(time.time() - t0, 1), "how": how,
             # what every rank holds in HBM for the index: slot table + sequence + its packed copy (4 bit planes per 32 bases)
-            "index_bytes_per_rank": int(5 * slots + 8 + size + 4096 + 16 * ((size + 31) // 32 + 1))}
+            # + every chain head's row laid out beside the table (chain_rows.hip: 4 B per slot + 4 B per chained position)
+            "index_bytes_per_rank": int(5 * slots + 8 + size + 4096 + 16 * ((size + 31) // 32 + 1)) + int(index.chain_row_bytes()),
+            "chain_row_bytes": int(index.chain_row_bytes())}
     if broadcast_s is not None:
         info["broadcast_s"] = round(broadcast_s, 2)
         info["broadcast_pieces"] = int((5 * slots + 8 + (1 << 30) - 1) >> 30) + int((size + 4096 + (1 << 30) - 1) >> 30)

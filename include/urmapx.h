@@ -107,6 +107,8 @@ int urmapx_index_upload(urmapx_index *, int device);
 int urmapx_index_replicate(const urmapx_index *src, int device, urmapx_index **out);
 void urmapx_index_close(urmapx_index *);
 
+/* bytes of GetRow_Blob's rows laid out beside the resident slot table (chain_rows.hip); 0 if they were not built */
+uint64_t urmapx_index_chain_row_bytes(const urmapx_index *);
 uint32_t urmapx_index_word_length(const urmapx_index *);
 uint32_t urmapx_index_max_ix(const urmapx_index *);
 uint64_t urmapx_index_slot_count(const urmapx_index *);

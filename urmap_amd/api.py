@@ -26,7 +26,7 @@ assert RESULT_DTYPE.itemsize == 28
 
 EXPORTS = (
     "urmapx_params_for_method", "urmapx_index_open", "urmapx_index_wrap_host", "urmapx_index_wrap_device",
-    "urmapx_index_upload", "urmapx_index_replicate", "urmapx_index_close", "urmapx_index_word_length", "urmapx_index_max_ix",
+    "urmapx_index_upload", "urmapx_index_replicate", "urmapx_index_close", "urmapx_index_chain_row_bytes", "urmapx_index_word_length", "urmapx_index_max_ix",
     "urmapx_index_slot_count", "urmapx_index_seqdata_size", "urmapx_index_seq_count", "urmapx_index_label",
     "urmapx_index_seq_length", "urmapx_index_seq_offset", "urmapx_ctx_create", "urmapx_ctx_destroy",
     "urmapx_map_se", "urmapx_map_se_device", "urmapx_ctx_sync", "urmapx_ctx_last_kernel_ms",
@@ -100,7 +100,7 @@ def lib():
     L.urmapx_index_close.argtypes = [vp]
     L.urmapx_index_close.restype = None
     for name, rt in (("word_length", u32), ("max_ix", u32), ("slot_count", u64), ("seqdata_size", u32),
-                     ("seq_count", u32)):
+                     ("seq_count", u32), ("chain_row_bytes", u64)):
         f = getattr(L, "urmapx_index_" + name)
         f.restype = rt
         f.argtypes = [vp]
@@ -263,6 +263,8 @@ class Index:
         h = C.c_void_p()
         _check(lib().urmapx_index_replicate(self.h, device, C.byref(h)), "urmapx_index_replicate")
         return Index(h.value, keep=(self,))
+
+    def chain_row_bytes(self): return int(lib().urmapx_index_chain_row_bytes(self.h))
 
     @property
     def word_length(self): return lib().urmapx_index_word_length(self.h)

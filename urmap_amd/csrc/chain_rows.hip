@@ -1,0 +1,140 @@
+// chain_rows.hip -- UFIndex::GetRow_Blob's rows (ufindex.cpp:883-943) laid out once per index, on the device, when the slot
+// table reaches HBM (round 4).
+//
+// A k-mer's collision chain is a linked list through the slot table: GetRow_Blob follows up to MaxIx - 1 dependent links, each
+// a random 5-byte read of a 27 GB table.  One of a read's 254 k-mers nearly always heads a long chain, so the search kernel's
+// chain walk is a dependent sequence of a dozen memory round trips per read and 17 % of its vector instructions (the 64-bit
+// slot arithmetic of every hop).  The table is read-only: every head's row can be written down once.
+//   rowinfo[slot]   u32: row length (low byte) | offset of the row inside its group of 1024 slots << 8; 0 where the slot
+//                   heads no chain (not "mine", or a single-entry PLUS1 / BOTH1 slot, whose row is its own position)
+//   rowbase[group]  u64: where the rows of the group's heads begin in `rows`
+//   rows            u32: the positions, row after row, in slot order
+// A kernel then needs the head's info word (one random read), the group base (a 40 MB array that lives in L2 / MALL) and the
+// row itself, contiguous: two dependent round trips whatever the chain's length.  34 GB at hg38 scale (21.6 info + 12 rows),
+// built in under a second; an index whose rows do not fit the device keeps the hop-by-hop walk (DevIndex::rowinfo == nullptr).
+#include "kernels.h"
+
+#include "dev_common.h"
+
+#include <vector>
+
+namespace urx {
+
+static constexpr int CR_GROUP = 1024;
+static constexpr int CR_ROW_CAP = 32;  // UFIndex m_MaxIx of every index this build accepts
+
+// GetRow_Blob from a head slot whose tally says "mine, with a next link" -- the walk of SearchWave::walk_run, one thread per
+// chain.  out != nullptr: the positions are written; returns the row length.
+__device__ __forceinline__ int chain_row(const uint8_t *__restrict__ blob, uint64_t N, int maxIx, uint64_t slot, uint32_t T, uint32_t pos,
+                                         uint32_t *out) {
+	int K = 0;
+	for (;;) {
+		if (out) out[K] = pos;
+		++K;
+		if (K == maxIx || K >= CR_ROW_CAP) return K;
+		if (T == TALLY_PLUS1 || T == TALLY_BOTH1) return 1;
+		if (T == TALLY_END) return K;
+		if (T == TALLY_LONG_MINE || T == TALLY_LONG_OTHER) {
+			const uint64_t slotA = addmod(slot, pos & 0xFFFFu, N);
+			slot = addmod(slotA, pos >> 16, N);
+			uint32_t tA, pA;
+			load_slot(blob, slotA, tA, pA);
+			if (out) out[K - 1] = pA;
+		} else
+			slot = addmod(slot, T & TALLY_NEXT_MASK, N);
+		load_slot(blob, slot, T, pos);
+	}
+}
+
+__device__ __forceinline__ bool heads_a_row(uint32_t T) { return (T & TALLY_MY_BIT) != 0 && T != TALLY_BOTH1 && T != TALLY_PLUS1; }
+
+// pass 1: row length of every slot, and their sum per group of 1024 slots
+__global__ __launch_bounds__(CR_GROUP) void rows_len_kernel(const uint8_t *__restrict__ blob, uint64_t N, int maxIx, uint32_t *__restrict__ info,
+                                                            uint32_t *__restrict__ groupsum, uint32_t groups) {
+	__shared__ uint32_t wsum[CR_GROUP / 64];
+	// (a launch holds fewer than 2^32 work-items and the table has more slots than that: the blocks loop over the groups)
+	for (uint32_t g = blockIdx.x; g < groups; g += gridDim.x) {
+		const uint64_t s = (uint64_t)g * CR_GROUP + threadIdx.x;
+		uint32_t len = 0;
+		if (s < N) {
+			uint32_t T, pos;
+			load_slot(blob, s, T, pos);
+			if (heads_a_row(T)) len = (uint32_t)chain_row(blob, N, maxIx, s, T, pos, nullptr);
+			info[s] = len;
+		}
+		uint32_t v = len;
+		for (int d = 32; d; d >>= 1) v += __shfl_xor(v, d, 64);
+		__syncthreads();
+		if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = v;
+		__syncthreads();
+		if (threadIdx.x == 0) {
+			uint32_t t = 0;
+			for (int w = 0; w < CR_GROUP / 64; ++w) t += wsum[w];
+			groupsum[g] = t;
+		}
+	}
+}
+
+// pass 2: the info words and the rows
+__global__ __launch_bounds__(CR_GROUP) void rows_fill_kernel(const uint8_t *__restrict__ blob, uint64_t N, int maxIx, uint32_t *__restrict__ info,
+                                                             const uint64_t *__restrict__ rowbase, uint32_t *__restrict__ rows, uint32_t groups) {
+	__shared__ uint32_t wsum[CR_GROUP / 64];
+	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	for (uint32_t g = blockIdx.x; g < groups; g += gridDim.x) {
+		const uint64_t s = (uint64_t)g * CR_GROUP + threadIdx.x;
+		const uint32_t len = s < N ? info[s] : 0u;
+		uint32_t inc = len;  // inclusive prefix inside the wavefront
+		for (int d = 1; d < 64; d <<= 1) {
+			const uint32_t up = __shfl_up(inc, d, 64);
+			if (lane >= d) inc += up;
+		}
+		__syncthreads();
+		if (lane == 63) wsum[w] = inc;
+		__syncthreads();
+		uint32_t before = 0;
+		for (int k = 0; k < w; ++k) before += wsum[k];
+		const uint32_t off = before + inc - len;
+		if (s < N && len) {
+			info[s] = (off << 8) | len;
+			uint32_t T, pos;
+			load_slot(blob, s, T, pos);
+			(void)chain_row(blob, N, maxIx, s, T, pos, rows + rowbase[g] + off);
+		}
+	}
+}
+
+// device arrays of the layout; all three null on return if maxIx is beyond the kernels' row capacity or memory is short
+hipError_t build_chain_rows(const uint8_t *d_blob, uint64_t slot_count, uint32_t max_ix, uint32_t **d_info, uint64_t **d_base, uint32_t **d_rows,
+                            uint64_t *total_rows) {
+	*d_info = nullptr; *d_base = nullptr; *d_rows = nullptr; *total_rows = 0;
+	if (max_ix > (uint32_t)CR_ROW_CAP || max_ix < 1 || slot_count == 0) return hipSuccess;
+	const uint64_t groups = (slot_count + CR_GROUP - 1) / CR_GROUP;
+	if (groups > 0x7FFFFFFFull) return hipSuccess;
+	uint32_t *info = nullptr, *gsum = nullptr, *rows = nullptr;
+	uint64_t *base = nullptr;
+	auto drop = [&]() { (void)hipFree(info); (void)hipFree(gsum); (void)hipFree(base); (void)hipFree(rows); (void)hipGetLastError(); };
+	if (hipMalloc((void **)&info, slot_count * 4) != hipSuccess || hipMalloc((void **)&gsum, groups * 4) != hipSuccess ||
+	    hipMalloc((void **)&base, groups * 8) != hipSuccess) { drop(); return hipSuccess; }  // no room: the kernels walk hop by hop
+	const unsigned grid = (unsigned)(groups < (1u << 20) ? groups : (1u << 20));
+	hipLaunchKernelGGL(rows_len_kernel, dim3(grid), dim3(CR_GROUP), 0, nullptr, d_blob, slot_count, (int)max_ix, info, gsum, (uint32_t)groups);
+	hipError_t e = hipGetLastError();
+	std::vector<uint32_t> hs(groups);
+	if (e == hipSuccess) e = hipMemcpy(hs.data(), gsum, groups * 4, hipMemcpyDeviceToHost);
+	if (e != hipSuccess) { drop(); return e; }
+	std::vector<uint64_t> hb(groups);
+	uint64_t total = 0;
+	for (uint64_t g = 0; g < groups; ++g) { hb[g] = total; total += hs[g]; }
+	(void)hipFree(gsum); gsum = nullptr;
+	if (hipMalloc((void **)&rows, (total + 64) * 4) != hipSuccess) { drop(); return hipSuccess; }
+	e = hipMemcpy(base, hb.data(), groups * 8, hipMemcpyHostToDevice);
+	if (e == hipSuccess) {
+		hipLaunchKernelGGL(rows_fill_kernel, dim3(grid), dim3(CR_GROUP), 0, nullptr, d_blob, slot_count, (int)max_ix, info, base, rows, (uint32_t)groups);
+		e = hipGetLastError();
+	}
+	if (e == hipSuccess) e = hipDeviceSynchronize();
+	if (e != hipSuccess) { drop(); return e; }
+	*d_info = info; *d_base = base; *d_rows = rows; *total_rows = total;
+	return hipSuccess;
+}
+
+}  // namespace urx

@@ -21,6 +21,10 @@ struct DevIndex {
 	uint32_t seqCount;
 	const uint32_t *seqLengths; // device
 	const uint32_t *seqOffsets; // device
+	// GetRow_Blob's rows laid out once per index (chain_rows.hip); rowinfo == nullptr: not built, the kernels walk hop by hop
+	const uint32_t *rowinfo;    // per slot: row length | offset inside the slot's group of 1024 << 8
+	const uint64_t *rowbase;    // per group of 1024 slots: where its rows begin
+	const uint32_t *rows;       // positions, row after row
 };
 
 // per-k-mer output of the seed+probe stage, SoA; index = 2*offs[r] + strand*L + qpos
@@ -145,6 +149,10 @@ hipError_t launch_search_pe_slow(const DevIndex &X, const urmapx_params &P, cons
                                  urmapx_result *d_results, urmapx_path_op *d_path_ops, uint32_t *d_path_used, uint32_t path_cap,
                                  uint8_t *scratch, int blocks, uint32_t *list, uint32_t *ticket, int veryfast, urmapx_pair_info *pair_info,
                                  int all_pairs, hipStream_t s);
+
+// chain_rows.hip: the rows of every chain head of a resident slot table (all three null if they cannot be had)
+hipError_t build_chain_rows(const uint8_t *d_blob, uint64_t slot_count, uint32_t max_ix, uint32_t **d_info, uint64_t **d_base, uint32_t **d_rows,
+                            uint64_t *total_rows);
 
 hipError_t launch_viterbi_batch(const urmapx_params &P, const uint8_t *d_a, const uint32_t *d_aoffs,
                                 const uint8_t *d_b, const uint32_t *d_boffs, const uint8_t *d_flags, uint32_t n,

@@ -813,6 +813,41 @@ struct SearchWave {
 		}
 	}
 
+	// Round 4: the rows are not walked, they are LOOKED UP in the layout chain_rows.hip wrote when the index reached the device
+	// (DevIndex::rowinfo): the head's info word (one random read) gives the row's length and, with its group's base (a 40 MB
+	// array: L2 / MALL), where the row lies in DevIndex::rows.  Nothing is copied: rowstore[g][lane] keeps the row's index in
+	// `rows` (0xFFFFFFFF for a PLUS1 head, whose row is its own position, kept in rowstore[NSEG + g][lane]) and the candidate
+	// stage reads rows[index + k].  walk_run costs ~25 instructions per hop (64-bit slot arithmetic, the 5-byte unpack) for the
+	// longest of the read's chains; this costs one round trip and a dozen instructions per group.
+	__device__ __forceinline__ void rows_fetch(uint64_t (&sl)[NSEG], uint32_t (&T)[NSEG], uint32_t (&ps)[NSEG], bool (&act)[NSEG], int (&rl)[NSEG]) {
+		const int lane = fresh_lane(this->lane);
+		uint32_t info[NSEG];
+#pragma unroll
+		for (int g = 0; g < NSEG; ++g) {
+			info[g] = 0;
+			if (act[g] && T[g] != TALLY_PLUS1) info[g] = X.rowinfo[sl[g]];
+		}
+#pragma unroll
+		for (int g = 0; g < NSEG; ++g) {
+			rl[g] = 0;
+			if (act[g]) {
+				if (T[g] == TALLY_PLUS1) {
+					rl[g] = 1;
+					rowstore[(size_t)g * 64 + lane] = 0xFFFFFFFFu;
+					rowstore[(size_t)(NSEG + g) * 64 + lane] = ps[g];
+				} else {
+					rl[g] = (int)(info[g] & 0xFFu);
+					rowstore[(size_t)g * 64 + lane] = (uint32_t)(X.rowbase[sl[g] >> 10] + (info[g] >> 8));
+				}
+			}
+		}
+	}
+	// row entry k of the chain of lane l in group seg (ROWS kernels)
+	__device__ __forceinline__ uint32_t row_entry(int seg, int k, int l) const {
+		const uint32_t at = rowstore[(size_t)seg * 64 + l];
+		return at == 0xFFFFFFFFu ? rowstore[(size_t)(NSEG + seg) * 64 + l] : X.rows[(size_t)at + (uint32_t)k];
+	}
+
 	// exclusive prefix over NS segments of per-lane counts -> pre[]; returns the total
 	template <int NS>
 	__device__ __forceinline__ int scan_counts(const int (&cnt)[NS]) {
@@ -863,7 +898,8 @@ struct SearchWave {
 // DBG = true: the diagnostic instantiation (URMAPX_PHASE_STATS / URMAPX_DEBUG_STOP): per-phase cycle stamps, per-read
 // cycle counts and schedule cuts (stop after step 1 / 3 / 4; 100 = setup and output only; 104 = up to the chain walks).
 // The production instantiation (DBG = false) contains none of that code.
-template <int NCH, bool OVF, bool DBG>
+// ROWS: the chain rows come out of the layout built with the index (rows_fetch) instead of being walked hop by hop
+template <int NCH, bool OVF, bool DBG, bool ROWS = false>
 __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel(DevIndex X, urmapx_params P, const uint8_t *__restrict__ bases,
                                                        const uint64_t *__restrict__ offs, uint32_t n,
                                                        urmapx_result *__restrict__ results,
@@ -1081,7 +1117,8 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 				if (go) S.walk_heads(wsl, wT, wps, wact);
 				if (next_ok) S.probe_gather(nQL, stage_sl, stage_b);
 				if (!go) break;
-				S.walk_run(wsl, wT, wps, wact, rl);
+				if constexpr (ROWS) S.rows_fetch(wsl, wT, wps, wact, rl);
+				else S.walk_run(wsl, wT, wps, wact, rl);
 				URX_SYNC();
 				lapc(3);
 				if (DBG && dbg_stop == 104) { done = true; break; }
@@ -1165,7 +1202,8 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 							if (seg >= SW::NSEG) seg -= SW::NSEG;
 							s_plus = seg < NCH;
 							s_qpos = (uint32_t)((seg - (s_plus ? 0 : NCH)) * 64 + l);
-							s_db = S.rowstore[((size_t)seg * ROW_CAP + k) * 64 + l];
+							if constexpr (ROWS) s_db = S.row_entry(seg, k, l);
+							else s_db = S.rowstore[((size_t)seg * ROW_CAP + k) * 64 + l];
 						}
 						ok = s_db >= s_qpos;  // extendpen.cpp:12-13
 					}
@@ -1989,6 +2027,10 @@ hipError_t launch_search_se(const DevIndex &X, const urmapx_params &P, const uin
 	hipLaunchKernelGGL((search_se_kernel<NCH_, OVF_, DBG_>), GRID_, block, 0, s, X, P, d_bases, d_offs, n, d_results,                \
 	                   d_path_ops, d_path_used, STATS_, wk.scratch, wk.scratch_stride, X.seq, X.blob, X.seqp, wk.ticket,         \
 	                   wk.hsp_lds_cap, wk.ovf_list, OVFBASE_, DP_)
+#define URX_LAUNCH_SE_ROWS(NCH_, GRID_, STATS_, OVFBASE_, DP_)                                                                      \
+	hipLaunchKernelGGL((search_se_kernel<NCH_, false, false, true>), GRID_, block, 0, s, X, P, d_bases, d_offs, n, d_results,          \
+	                   d_path_ops, d_path_used, STATS_, wk.scratch, wk.scratch_stride, X.seq, X.blob, X.seqp, wk.ticket,         \
+	                   wk.hsp_lds_cap, wk.ovf_list, OVFBASE_, DP_)
 	// phase 6 of the reads a pass parked: their flank DPs, then the ordered part
 #define URX_LAUNCH_DP(NCH_, OVF_, PASS_)                                                                                          \
 	do { for (int rd = 0; rd < DP_ROUNDS; ++rd) {                                                                                 \
@@ -2005,6 +2047,12 @@ hipError_t launch_search_se(const DevIndex &X, const urmapx_params &P, const uin
 	const bool diag = wk.stats != nullptr && (nch == 3 || nch == 4);  // diagnostic instantiations: 150 / 250 bp classes, phase 6 inline
 	if (diag && nch == 3) URX_LAUNCH_SE(3, false, true, grid, wk.stats, no_ovf, no_dp);
 	else if (diag) URX_LAUNCH_SE(4, false, true, grid, wk.stats, no_ovf, no_dp);
+	else if (nch == 2 && X.rowinfo) URX_LAUNCH_SE_ROWS(2, grid, wk.stats, no_ovf, wk.dp[0]);  // the chain rows are looked up in the layout built with the index
+	else if (nch == 3 && X.rowinfo) URX_LAUNCH_SE_ROWS(3, grid, wk.stats, no_ovf, wk.dp[0]);
+	else if (nch == 4 && X.rowinfo) URX_LAUNCH_SE_ROWS(4, grid, wk.stats, no_ovf, wk.dp[0]);
+	else if (nch == 5 && X.rowinfo) URX_LAUNCH_SE_ROWS(5, grid, wk.stats, no_ovf, wk.dp[0]);
+	else if (nch == 8 && X.rowinfo) URX_LAUNCH_SE_ROWS(8, grid, wk.stats, no_ovf, wk.dp[0]);
+	else if (nch == 16 && X.rowinfo) URX_LAUNCH_SE_ROWS(16, grid, wk.stats, no_ovf, wk.dp[0]);
 	else if (nch == 2) URX_LAUNCH_SE(2, false, false, grid, wk.stats, no_ovf, wk.dp[0]);
 	else if (nch == 3) URX_LAUNCH_SE(3, false, false, grid, wk.stats, no_ovf, wk.dp[0]);
 	else if (nch == 4) URX_LAUNCH_SE(4, false, false, grid, wk.stats, no_ovf, wk.dp[0]);
@@ -2049,6 +2097,7 @@ hipError_t launch_search_se(const DevIndex &X, const urmapx_params &P, const uin
 	} else
 		for (int i = 0; i < 2 * DP_ROUNDS; ++i) stamp(3 + 2 * DP_ROUNDS + i);
 #undef URX_LAUNCH_SE
+#undef URX_LAUNCH_SE_ROWS
 #undef URX_LAUNCH_DP
 	return hipGetLastError();
 }

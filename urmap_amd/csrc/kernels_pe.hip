@@ -565,6 +565,31 @@ struct Mate {
 				wact[g] = wact[g] && (wT[g] & TALLY_MY_BIT) != 0;  // GetRow_Blob returns 0 for a slot that is not "mine"
 				any |= wact[g];
 			}
+			const bool lookup = X->rowinfo != nullptr;
+			if (lookup) {
+				// the rows are looked up in the layout built with the index (chain_rows.hip; search_se_kernel's rows_fetch): the head's
+				// info word gives the row's length and where it lies in X->rows; rowstore[g][lane] keeps that index (0xFFFFFFFF for a
+				// single-entry head, whose row is its own position in rowstore[NG + g][lane]) and the candidate stage reads it there
+				uint32_t info[NG];
+#pragma unroll
+				for (int g = 0; g < NG; ++g) {
+					info[g] = 0;
+					if (wact[g] && wT[g] != TALLY_PLUS1 && wT[g] != TALLY_BOTH1) info[g] = X->rowinfo[wsl[g]];
+				}
+#pragma unroll
+				for (int g = 0; g < NG; ++g) {
+					if (!wact[g]) continue;
+					if (wT[g] == TALLY_PLUS1 || wT[g] == TALLY_BOTH1) {
+						wK[g] = 1;
+						rowstore[(size_t)g * 64 + lane] = 0xFFFFFFFFu;
+						rowstore[(size_t)(NG + g) * 64 + lane] = wps[g];
+					} else {
+						wK[g] = (int)(info[g] & 0xFFu);
+						rowstore[(size_t)g * 64 + lane] = (uint32_t)(X->rowbase[wsl[g] >> 10] + (info[g] >> 8));
+					}
+				}
+				any = false;
+			}
 			while (__ballot(any)) {
 #pragma unroll
 				for (int g = 0; g < NG; ++g) {
@@ -686,7 +711,12 @@ struct Mate {
 							}
 							const int k = g - (int)pre[lo];
 							c_q = pend[s][base + lo];
-							c_db = rs0[k * 64 + lo];
+							if (X->rowinfo) {
+								const int g = s * NCH + (base >> 6);
+								const uint32_t at = rowstore[(size_t)g * 64 + lo];
+								c_db = at == 0xFFFFFFFFu ? rowstore[(size_t)(2 * NCH + g) * 64 + lo] : X->rows[(size_t)at + (uint32_t)k];
+							} else
+								c_db = rs0[k * 64 + lo];
 							ok = c_db >= c_q;
 						}
 						ok = ok && !overlaps_any_hit(c_db - c_q);

@@ -37,6 +37,10 @@ struct urmapx_index {
 	int device = -1;
 	const uint8_t *d_blob = nullptr, *d_seq = nullptr;
 	uint4 *d_seqp = nullptr;  // packed copy of d_seq (4 bit planes per 32 bases), always owned, built on the device
+	// GetRow_Blob's rows laid out once (chain_rows.hip), always owned, built on the device; null: not built
+	uint32_t *d_rowinfo = nullptr, *d_rows = nullptr;
+	uint64_t *d_rowbase = nullptr;
+	uint64_t n_rows = 0;
 	bool own_dev = false;
 	uint32_t *d_seqLengths = nullptr, *d_seqOffsets = nullptr;
 
@@ -47,6 +51,7 @@ struct urmapx_index {
 		X.shiftMask = (W >= 32) ? ~0ull : ((1ull << (2 * W)) - 1ull);
 		X.W = W; X.maxIx = maxIx; X.seqDataSize = seqDataSize; X.seqCount = (uint32_t)labels.size();
 		X.seqLengths = d_seqLengths; X.seqOffsets = d_seqOffsets;
+		X.rowinfo = d_rowinfo; X.rowbase = d_rowbase; X.rows = d_rows;
 		return X;
 	}
 };
@@ -186,6 +191,15 @@ static int build_packed_seq(urmapx_index *I) {
 static int upload_directory(urmapx_index *I) {
 	int rc = build_packed_seq(I);
 	if (rc) return rc;
+	// every chain head's row, contiguous (chain_rows.hip): 4 bytes per slot + 4 per indexed position.  URMAPX_NO_CHAIN_ROWS=1
+	// (measurement, tests): the kernels walk the chains hop by hop, as they do when the rows do not fit the device
+	if (!getenv("URMAPX_NO_CHAIN_ROWS")) {
+		const hipError_t e = build_chain_rows(I->d_blob, I->slotCount, I->maxIx, &I->d_rowinfo, &I->d_rowbase, &I->d_rows, &I->n_rows);
+		if (getenv("URMAPX_VERBOSE"))
+			fprintf(stderr, "urmapx: chain rows %s: %llu positions in rows, %.2f GB (hip: %s)\n", I->d_rowinfo ? "built" : "NOT built",
+			        (unsigned long long)I->n_rows, I->d_rowinfo ? (4.0 * (double)I->slotCount + 4.0 * (double)I->n_rows) / 1e9 : 0.0, hipGetErrorString(e));
+		HIP_TRY(e);
+	}
 	size_t n = I->labels.size();
 	HIP_TRY(hipMalloc((void **)&I->d_seqLengths, (n + 1) * 4));
 	HIP_TRY(hipMalloc((void **)&I->d_seqOffsets, (n + 1) * 4));
@@ -248,6 +262,9 @@ void urmapx_index_close(urmapx_index *I) {
 	if (!I) return;
 	if (I->own_dev) { (void)hipFree((void *)I->d_blob); (void)hipFree((void *)I->d_seq); }
 	if (I->d_seqp) (void)hipFree(I->d_seqp);
+	if (I->d_rowinfo) (void)hipFree(I->d_rowinfo);
+	if (I->d_rowbase) (void)hipFree(I->d_rowbase);
+	if (I->d_rows) (void)hipFree(I->d_rows);
 	if (I->d_seqLengths) (void)hipFree(I->d_seqLengths);
 	if (I->d_seqOffsets) (void)hipFree(I->d_seqOffsets);
 	free(I->own_blob);
@@ -255,6 +272,10 @@ void urmapx_index_close(urmapx_index *I) {
 	delete I;
 }
 
+// bytes of the chain-row layout resident with the index (0: not built -- URMAPX_NO_CHAIN_ROWS, MaxIx over 32, or no room)
+uint64_t urmapx_index_chain_row_bytes(const urmapx_index *I) {
+	return I && I->d_rowinfo ? 4ull * I->slotCount + 4ull * (I->n_rows + 64) + 8ull * ((I->slotCount + 1023) / 1024) : 0ull;
+}
 uint32_t urmapx_index_word_length(const urmapx_index *I) { return I->W; }
 uint32_t urmapx_index_max_ix(const urmapx_index *I) { return I->maxIx; }
 uint64_t urmapx_index_slot_count(const urmapx_index *I) { return I->slotCount; }
