@@ -900,3 +900,37 @@ def test_pe_rescue_scan_produces_hits(rescue_case):
         o = int(g["path_off"][i])
         assert api.decode_path(gops[o:o + int(g["path_nops"][i])]) == opaths[i], i
         gapped += int(g["path_nops"][i]) > 0
+
+
+@pytest.mark.gpu
+def test_chain_rows_on_and_off_give_the_oracle(dense_case, tmp_path, monkeypatch):
+    """chain_rows.hip: GetRow_Blob's rows (ufindex.cpp:883-943) laid out beside the resident table; the search kernels look a
+    row up instead of walking the chain.  On the dense index (thousands of long-link slots, truncated chains): the layout is
+    built by default, both settings give the oracle's results for single reads and pairs."""
+    from conftest import reads_to_arrays
+    from urmap_amd import api, synth
+    c = dense_case
+    reads = synth.make_reads(4711, c["genome"], 2500, read_len=150, sub=0.01, ins=0.001, dele=0.001)
+    bases, offs = reads_to_arrays(reads)
+    ores, opaths, _ = c["oracle_index"].map_se(bases, offs, threads=4)
+    r1, r2 = synth.make_pairs(4712, c["genome"], 1200, read_len=150, sub1=0.01, sub2=0.02, ins=0.001, dele=0.001)
+    pairs = [x for ab in zip(r1, r2) for x in ab]
+    pb, po = reads_to_arrays(pairs)
+    pres, ppaths, _ = c["oracle_index"].map_pe(pb, po, threads=4)
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("URMAPX_NO_CHAIN_ROWS", "1")
+        idx = api.Index.open(c["ufi"]).upload(0)
+        assert (idx.chain_row_bytes() == 0) == off
+        m = api.Mapper(idx, device=0)
+        g, gops = m.map_se(bases, offs)
+        for name in ("dbpos", "seq_index", "coord", "score", "second", "mapq", "exit_phase", "hit_count"):
+            assert (g[name].astype(np.int64) == ores[name].astype(np.int64)).all(), (off, name)
+        for i in np.nonzero(ores["dbpos"] != 0xFFFFFFFF)[0]:
+            o = int(g["path_off"][i])
+            assert api.decode_path(gops[o:o + int(g["path_nops"][i])]) == opaths[i]
+        g, gops = m.map_pe(pb, po)
+        for name in ("dbpos", "seq_index", "coord", "score", "second", "mapq"):
+            assert (g[name].astype(np.int64) == pres[name].astype(np.int64)).all(), (off, name)
+        m.close()
+        idx.close()
