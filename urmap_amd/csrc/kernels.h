@@ -86,7 +86,7 @@ struct DpWork {
 	uint32_t jobs_cap = 0;
 	uint32_t *tickets = nullptr;    // work counters of dp_kernel's rounds, zeroed with the counters
 	uint32_t *counters = nullptr;   // [0] jobs made, [1] reads parked, [2] jobs the ordered replay needed, [3] jobs a round's gate dropped before their DP (statistics)
-	uint32_t *fin_list = nullptr;   // per parked read: read, first job, job count
+	uint32_t *fin_list = nullptr;   // per parked read: read, first job, job count, read length (16 bytes, one load)
 	uint32_t *state = nullptr;      // per parked read: search state (dp_state_words(ovf) words each)
 	uint32_t fin_cap = 0;
 };

@@ -551,7 +551,7 @@ struct SearchWave {
 			w += __builtin_popcountll(m);
 		}
 		if (njobs > 0xFFFF) status |= URMAPX_ST_HSP_OVERFLOW;  // cannot happen: the HSP list holds at most 8192
-		if (lane == 0) { dp.fin_list[3 * slot] = r; dp.fin_list[3 * slot + 1] = jb; dp.fin_list[3 * slot + 2] = (uint32_t)njobs; }
+		if (lane == 0) *reinterpret_cast<uint4 *>(dp.fin_list + 4 * (size_t)slot) = make_uint4(r, jb, (uint32_t)njobs, (uint32_t)QL);
 		park_state(dp.state + (size_t)slot * STATE_WORDS, phase);
 		return true;
 	}
@@ -576,13 +576,19 @@ struct SearchWave {
 		for (int wd = 0; wd < HITW; ++wd) hit_db[wd] = st[wd * 64 + lane];
 		hit_tail = st + HITW * 64;  // in place: the replay appends to it there
 		const uint32_t *sc = st + HITW * 64 + TAIL;
+		// the top hit's path comes in with the same round of loads as the scalars (its length is one of them: waiting for it
+		// first made the path a round trip of its own; finalize_se_kernel is a chain of such trips and little else)
+		static_assert(URMAPX_MAX_PATH_OPS <= 128, "two path ops per lane");
+		const uint16_t *tops = reinterpret_cast<const uint16_t *>(sc + 16);
+		const uint16_t t0 = tops[lane];
+		const uint16_t t1 = lane + 64 < URMAPX_MAX_PATH_OPS ? tops[lane + 64] : (uint16_t)0;
 		hitCount = (int)uni(sc[0]); maxPen = (int)uni(sc[1]); best = (int)uni(sc[2]); second = (int)uni(sc[3]);
 		top_db = uni(sc[4]);
 		const uint32_t f = uni(sc[5]);
 		haveTop = (f & 1u) != 0; top_plus = (f & 2u) != 0;
 		top_nops = (int)uni(sc[6]); status = uni(sc[7]); hspCount = (int)uni(sc[8]); bestHSP = 0;
-		const uint16_t *tops = reinterpret_cast<const uint16_t *>(sc + 16);
-		for (int t = lane; t < top_nops; t += 64) top[t] = tops[t];
+		top[lane] = t0;
+		if (lane + 64 < URMAPX_MAX_PATH_OPS) top[lane + 64] = t1;
 		URX_SYNC();
 		return (int)(f >> 8);
 	}
@@ -1587,6 +1593,10 @@ __global__ __launch_bounds__(64) URX_DP_ATTR void dp_kernel(DevIndex X, urmapx_p
 		return __ballot(gap) != 0;
 	};
 	uint32_t n_gated = 0;  // statistics
+	uint32_t q_read = 0xFFFFFFFFu;  // the read (and strand) whose bases sQ holds
+	bool q_plus = false;
+	uint64_t q_off = 0;
+	int q_len = 0;
 	// this round's jobs: those with klo <= k < khi.  Blocks take tiles of DP_TILE consecutive jobs from the round's work
 	// counter (a read in a repeat family owns hundreds of consecutive jobs of the last round and none of the first: a
 	// fixed tile-to-block map left blocks idle while others still had a dozen DPs to run); the k of a tile's jobs comes in
@@ -1616,21 +1626,26 @@ __global__ __launch_bounds__(64) URX_DP_ATTR void dp_kernel(DevIndex X, urmapx_p
 				continue;
 			}
 		}
-		const uint64_t off = offs[J.read];
-		const int QL = (int)(offs[J.read + 1] - off);
 		const uint32_t pk = J.pk, startdb = J.startdb;
 		const int startq = (int)(pk & PK_MASK), len = (int)((pk >> PK_LEN_SH) & PK_MASK), hscore = (int)((pk >> PK_SCORE_SH) & PK_MASK);
 		const bool plus = (pk >> PK_PLUS_SH) & 1u;
+		// the jobs of a tile are consecutive HSPs, mostly of one read: its bases (one strand) stay in LDS from job to job
 		URX_SYNC();
-		{
-			const uint8_t *q = bases + off;
+		if (J.read != q_read || plus != q_plus) {
+			if (J.read != q_read) {
+				q_off = offs[J.read];
+				q_len = (int)(offs[J.read + 1] - q_off);
+			}
+			const uint8_t *q = bases + q_off;
 #pragma unroll
 			for (int c = 0; c < NCH; ++c) {
 				const int p = 64 * c + lane;
-				if (p < QL) sQ[p] = plus ? q[p] : (uint8_t)comp_char(q[QL - 1 - p]);
+				if (p < q_len) sQ[p] = plus ? q[p] : (uint8_t)comp_char(q[q_len - 1 - p]);
 			}
+			q_read = J.read; q_plus = plus;
+			URX_SYNC();
 		}
-		URX_SYNC();
+		const int QL = q_len;
 		uint32_t flags = 0, vst_l = 0, vst_r = 0, combinedTLo = startdb;
 		int leftScore = 0, rightScore = 0, rtrim = 0;
 		int totalPen = len - hscore;
@@ -1725,8 +1740,16 @@ __global__ __launch_bounds__(64) URX_DP_ATTR void dp_kernel(DevIndex X, urmapx_p
 // kernel D: phase 6's ordered part for the parked reads -- the jobs of a read in HSP order through AlignHSP's tests
 // and AddHitX, then CalcMAPQ6 / SetMappedPos and the result record.  One wavefront per read.
 // ------------------------------------------------------------------------------------------------
+#ifndef URX_FIN_WAVES
+#define URX_FIN_WAVES 8  // register budget of finalize_se_kernel as waves per SIMD: 51 VGPRs, no spill; the kernel waits on memory and wants waves (0 = the compiler's choice: 85 VGPRs, 5 waves)
+#endif
+#if URX_FIN_WAVES
+#define URX_FIN_ATTR __attribute__((amdgpu_waves_per_eu(URX_FIN_WAVES, URX_FIN_WAVES)))
+#else
+#define URX_FIN_ATTR
+#endif
 template <int NCH, bool OVF>
-__global__ __launch_bounds__(64) void finalize_se_kernel(DevIndex X, urmapx_params P, const uint64_t *__restrict__ offs, DpWork dp,
+__global__ __launch_bounds__(64) URX_FIN_ATTR void finalize_se_kernel(DevIndex X, urmapx_params P, const uint64_t *__restrict__ offs, DpWork dp,
                                                          urmapx_result *__restrict__ results, urmapx_path_op *__restrict__ path_ops,
                                                          uint32_t *path_used, int hsp_lds_cap, uint32_t *ovf_list, uint32_t klo,
                                                          uint32_t khi) {
@@ -1742,16 +1765,31 @@ __global__ __launch_bounds__(64) void finalize_se_kernel(DevIndex X, urmapx_para
 	const uint32_t parked = dp.counters[1] < dp.fin_cap ? dp.counters[1] : dp.fin_cap;
 	// parked reads go to blocks round-robin: the costly ones (repeat families: hundreds of jobs) were parked last, next
 	// to each other, and a block that took a run of them from a work counter made the launch 0.8 ms longer
+	// A read-round is a chain of memory round trips and little else (SQ_WAIT_ANY 97 % of the wave cycles), so
+	// the chain is kept short: the list entry (read, first job, job count, read length: one 16-byte load) of the block's NEXT
+	// read is asked for before this one is replayed, and the parked state, the top path and the first 64 jobs of a read
+	// leave in one round of loads.
+	const uint4 *const fin = reinterpret_cast<const uint4 *>(dp.fin_list);
+	uint4 ent = make_uint4(0u, 0u, 0u, 0u);
+	if (blockIdx.x < parked) ent = fin[blockIdx.x];
 	for (uint32_t e = blockIdx.x; e < parked; e += gridDim.x) {
-		const uint32_t r = dp.fin_list[3 * e], jb = dp.fin_list[3 * e + 1], nj = dp.fin_list[3 * e + 2];
+		const uint32_t r = uni(ent.x), jb = uni(ent.y), nj = uni(ent.z);
+		S.QL = (int)uni(ent.w);
+		if (e + gridDim.x < parked) ent = fin[e + gridDim.x];
 		if (nj <= klo) continue;  // finished in an earlier round
-		S.QL = (int)(offs[r + 1] - offs[r]);
 		S.nwords = S.QL - (S.W - 1);
+		const uint32_t kend = nj < khi ? nj : khi;
+		uint32_t jpk0 = 0;
+		uint4 jw0 = make_uint4(0u, 0u, 0u, 0u);
+		if (klo + (uint32_t)lane < kend) {
+			const uint32_t *jp = reinterpret_cast<const uint32_t *>(dp.jobs + jb + klo + (uint32_t)lane);
+			jpk0 = jp[2];
+			jw0 = *reinterpret_cast<const uint4 *>(jp + 4);
+		}
 		URX_SYNC();
 		uint32_t *const st = dp.state + (size_t)e * SW::STATE_WORDS;
 		const int phase = S.restore_state(st);
 		uint32_t used = 0;
-		const uint32_t kend = nj < khi ? nj : khi;
 		// 64 jobs come in with one round of loads (one job per lane: the words the replay reads).  Round 4: every lane then runs
 		// AlignHSP's tests on its own job against the state as it stands -- the penalty after the HSP, after the left flank,
 		// after the right flank against the cap (alignhsp.cpp:62-70,127-130,160-162), the score against best - 12
@@ -1762,12 +1800,15 @@ __global__ __launch_bounds__(64) void finalize_se_kernel(DevIndex X, urmapx_para
 		// 1 M 250-base reads.  (Jobs that raise a status bit -- a DP that outgrew its buffers -- always take the ordered road.)
 		for (uint32_t k0 = klo; k0 < kend; k0 += 64) {
 			const uint32_t k = k0 + (uint32_t)lane;
-			uint32_t jpk = 0;
-			uint4 jw = make_uint4(0u, 0u, 0u, 0u);
-			if (k < kend) {
-				const uint32_t *jp = reinterpret_cast<const uint32_t *>(dp.jobs + jb + k);
-				jpk = jp[2];
-				jw = *reinterpret_cast<const uint4 *>(jp + 4);
+			const uint32_t jpk = jpk0;
+			const uint4 jw = jw0;
+			// the next 64 jobs are asked for before these are replayed (a read in a repeat family brings thousands: one wave, one
+			// round trip per 64 of them otherwise)
+			jpk0 = 0; jw0 = make_uint4(0u, 0u, 0u, 0u);
+			if (k + 64u < kend) {
+				const uint32_t *jp = reinterpret_cast<const uint32_t *>(dp.jobs + jb + k + 64u);
+				jpk0 = jp[2];
+				jw0 = *reinterpret_cast<const uint4 *>(jp + 4);
 			}
 			const int jstartq = (int)(jpk & PK_MASK), jlen = (int)((jpk >> PK_LEN_SH) & PK_MASK), jhs = (int)((jpk >> PK_SCORE_SH) & PK_MASK);
 			const int jpen = jlen - jhs;

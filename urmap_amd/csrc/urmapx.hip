@@ -461,7 +461,7 @@ int urmapx_map_se_device(urmapx_ctx *C, const void *d_bases, const void *d_offs,
 			at[p][5] = need; need += (((size_t)jobs_cap[p] * 2) + 63) & ~(size_t)63;
 			at[p][0] = need; need += (size_t)jobs_cap[p] * sizeof(DpJob);
 			at[p][1] = need; need += (((size_t)jobs_cap[p] * DP_JOB_OPS * 2) + 63) & ~(size_t)63;
-			at[p][2] = need; need += (((size_t)fin_cap[p] * 12) + 63) & ~(size_t)63;
+			at[p][2] = need; need += (((size_t)fin_cap[p] * 16) + 63) & ~(size_t)63;
 			at[p][3] = need; need += (size_t)fin_cap[p] * dp_state_words(p == 1) * 4;
 			at[p][4] = 16 * (size_t)p;
 		}

@@ -84,6 +84,12 @@ __device__ float viterbi_wide(const VPar P, const uint8_t *A, int LA, const uint
 // M / D value of the row plus one point per query letter still to come bounds the final score from above (gaps cost,
 // the free end gaps of Left / Right problems add nothing); once that bound is below abort_below the DP stops and sets
 // *aborted -- the result would have been discarded anyway.
+#ifndef URX_VIT_RB
+#define URX_VIT_RB 4  // rows per block of viterbi_wave (4 or 8)
+#endif
+#ifndef URX_ABORT_FINE
+#define URX_ABORT_FINE 32
+#endif
 template <bool B_LDS = false>
 __device__ __forceinline__ float viterbi_wave(const VPar P, const uint8_t *A, int LA, const uint8_t *B, int LB, bool Left, bool Right,
                               uint32_t *tb, int tb_rows8, const WideScratch ws, RevOps &R, uint32_t &status, int lane_in,
@@ -174,27 +180,34 @@ __device__ __forceinline__ float viterbi_wave(const VPar P, const uint8_t *A, in
 	// trace dword per lane per block -- the general row costs ~100 issue slots, half of them scalar.
 	const float GOl = Left ? 0.0f : GO, GEl = Left ? 0.0f : GE;  // column 0 of a Left problem opens / extends D for free
 	const float MISf = (float)P.mismatch_score;
+	const float ONEl = real ? 1.0f : NEG, MISl = real ? MISf : NEG;  // letter scores of this lane in the interior of the band
 	const float el = GE * flane, el1 = GE * (flane - 1.0f);
 	const uint32_t LBr = real ? (uint32_t)LB : 0u;                          // band cell iff (unsigned)j < LBr
 	const int LBs = (lane >= 1 && lane <= ND + 1) ? LB : -(1 << 20);        // column LB cell iff j == LBs
 	const uint32_t bits0c = lane == 0 ? TB_IM : 0u;                         // column Startj-1: IM once j >= 0
-	// rows i0 .. i0+n-1 (1 <= i0, all inside one trace dword: (i0 & 7) + n <= 8)
-	auto rows_upto8 = [&](int i0, int n) {
+	// Rows come in blocks of RB = 4 (URX_VIT_RB; 8 until round 4): a trace dword holds eight rows, so two blocks fill one.  With
+	// four the blocks at the band's edges are shorter (a block is "interior" only if no lane enters or leaves the matrix in ANY
+	// of its rows: up to 3 + 3 rows lost to alignment instead of 7 + 7 -- on a 60-row flank 32 rows take the cheap road
+	// instead of 24) and dp_kernel can look at its stop test twice as often.
+	constexpr int RB = URX_VIT_RB;
+	static_assert(RB == 4 || RB == 8, "a trace dword holds eight rows");
+	// rows i0 .. i0+n-1 (1 <= i0, all inside one block: (i0 & (RB-1)) + n <= RB)
+	auto rows_upto = [&](int i0, int n) {
 		const int j0 = jbase + i0;
 		const uint8_t *Ap = A + i0;
-		uint32_t av[8], bv[8];
+		uint32_t av[RB], bv[RB];
 		if constexpr (B_LDS) {
 			const uint8_t *Bp = B + j0;  // bytes outside [0, LB) are read but never used (LDS reads cannot fault)
 #pragma unroll
-			for (int k = 0; k < 8; ++k) { av[k] = Ap[k]; bv[k] = Bp[k]; }
+			for (int k = 0; k < RB; ++k) { av[k] = Ap[k]; bv[k] = Bp[k]; }
 		} else {
 #pragma unroll
-			for (int k = 0; k < 8; ++k) { av[k] = A[min(i0 + k, LA - 1)]; bv[k] = B[min(max(j0 + k, 0), LB - 1)]; }
+			for (int k = 0; k < RB; ++k) { av[k] = A[min(i0 + k, LA - 1)]; bv[k] = B[min(max(j0 + k, 0), LB - 1)]; }
 		}
 		const int sh0 = 4 * (i0 & 7);
 		uint32_t word = 0;
 #pragma unroll
-		for (int k = 0; k < 8; ++k) {
+		for (int k = 0; k < RB; ++k) {
 			if (k < n) {  // wave-uniform
 				const int j = j0 + k;
 				const bool act = (uint32_t)j < LBr;
@@ -202,26 +215,28 @@ __device__ __forceinline__ float viterbi_wave(const VPar P, const uint8_t *A, in
 				const float D = wave_shl1(Dn, NEG);
 				const float Mcur = M;
 				const float vraw = Mcur + GO;
-				const float v = act ? vraw : NEG;
-				const float Pm = wave_prefix_max(v - el);
+				// (a cell outside the matrix is kept dead by its letter score -- rows_interior has the argument; here the set
+				// of such cells changes with the row: lanes enter at column 0 and leave behind column LB.  A lane left of
+				// column 0 has a dead M, so its v is dead without a mask; its D is never read by a cell of the matrix, nor is
+				// anything of a lane right of column LB; the column LB cell itself computes D like any other and gets a dead M.)
+				const float Pm = wave_prefix_max(vraw - el);
 				const float I = wave_shr1(Pm, NEG) + el1;
 				// M state: best of M, D ('>'), I ('>')
 				uint32_t bits = D > Mcur ? TB_DM : 0u;
 				float xM = fmaxf(Mcur, D);
 				bits = I > xM ? TB_IM : bits;
 				xM = fmaxf(xM, I);
-				const float Mnew = xM + (av[k] == bv[k] ? 1.0f : MISf);
+				const float sc = av[k] == bv[k] ? 1.0f : MISf;
+				M = xM + (act ? sc : NEG);
 				// D state: open ('>=' wins) or extend; free in column 0 of a Left problem
 				const bool col0 = j == 0;
 				const float md = Mcur + (col0 ? GOl : GO);
 				const float de = D + (col0 ? GEl : GE);
 				const uint32_t bMD = md >= de ? TB_MD : 0u;
-				const float Dnew = fmaxf(md, de);
+				Dn = fmaxf(md, de);
 				// I state: open ('>=' wins) or extend
 				const uint32_t bMI = vraw >= I + GE ? TB_MI : 0u;
 				bits |= bMD | bMI;
-				M = act ? Mnew : (semi ? NEG : M);
-				Dn = (act || semi) ? Dnew : Dn;
 				bits = act ? bits : (semi ? bMD : (j >= 0 ? bits0c : 0u));
 				word |= bits << (4 * k);
 			}
@@ -229,62 +244,69 @@ __device__ __forceinline__ float viterbi_wave(const VPar P, const uint8_t *A, in
 		acc |= word << sh0;
 		if (((i0 + n) & 7) == 0) { tb[(i0 >> 3) * 64 + lane] = acc; acc = 0; }
 	};
-	// Eight rows in the interior of the band: no lane enters (column 0) or leaves (column LB) the matrix inside the
+	// A block of rows in the interior of the band: no lane enters (column 0) or leaves (column LB) the matrix inside the
 	// block, so every band lane is a band cell in every row and the lane classes are constants -- most rows of a long
 	// flank are of this kind (lanes enter during the first and leave during the last ~13 rows only).
-	auto rows8_interior = [&](int i0) {
+	auto rows_interior = [&](int i0) {
 		const int j0 = jbase + i0;
 		const uint8_t *Ap = A + i0;
-		uint32_t av[8], bv[8];
+		uint32_t av[RB], bv[RB];
 		if constexpr (B_LDS) {
 			const uint8_t *Bp = B + j0;
 #pragma unroll
-			for (int k = 0; k < 8; ++k) { av[k] = Ap[k]; bv[k] = Bp[k]; }
+			for (int k = 0; k < RB; ++k) { av[k] = Ap[k]; bv[k] = Bp[k]; }
 		} else {
 #pragma unroll
-			for (int k = 0; k < 8; ++k) { av[k] = Ap[k]; bv[k] = B[min(max(j0 + k, 0), LB - 1)]; }
+			for (int k = 0; k < RB; ++k) { av[k] = Ap[k]; bv[k] = B[min(max(j0 + k, 0), LB - 1)]; }
 		}
 		uint32_t word = 0;
+		// The lanes outside the band (lane 0 = column Startj-1, lanes beyond ND) are kept dead by their letter score, not by
+		// selects: a cell's new M is max(M, D, I) + score, and -9e9 as the score of both outcomes leaves -9e9 (or less) there
+		// whatever D and I were -- a dead M opens dead gaps (v, and with it the I of every lane to the right, needs no mask),
+		// and nobody reads the D of such a lane: lane 0's would go to lane -1, and beyond the band D stays dead from lane 63
+		// inwards by induction.  Three selects fewer per cell row.
 #pragma unroll
-		for (int k = 0; k < 8; ++k) {
+		for (int k = 0; k < RB; ++k) {
 			const float D = wave_shl1(Dn, NEG);
 			const float Mcur = M;
 			const float vraw = Mcur + GO;
-			const float v = real ? vraw : NEG;
-			const float Pm = wave_prefix_max(v - el);
+			const float Pm = wave_prefix_max(vraw - el);
 			const float I = wave_shr1(Pm, NEG) + el1;
 			uint32_t bits = D > Mcur ? TB_DM : 0u;
 			float xM = fmaxf(Mcur, D);
 			bits = I > xM ? TB_IM : bits;
 			xM = fmaxf(xM, I);
-			const float Mnew = xM + (av[k] == bv[k] ? 1.0f : MISf);
+			M = xM + (av[k] == bv[k] ? ONEl : MISl);
 			const float de = D + GE;
 			const uint32_t bMD = vraw >= de ? TB_MD : 0u;  // md = Mcur + GO = vraw: no column-0 cell in the block
-			const float Dnew = fmaxf(vraw, de);
+			Dn = fmaxf(vraw, de);
 			const uint32_t bMI = vraw >= I + GE ? TB_MI : 0u;
 			bits |= bMD | bMI;
-			M = real ? Mnew : M;
-			Dn = real ? Dnew : Dn;
 			word |= (real ? bits : bits0c) << (4 * k);
 		}
-		tb[(i0 >> 3) * 64 + lane] = word;
+		if constexpr (RB == 8) tb[(i0 >> 3) * 64 + lane] = word;
+		else {
+			acc |= word << (4 * (i0 & 7));
+			if (((i0 + RB) & 7) == 0) { tb[(i0 >> 3) * 64 + lane] = acc; acc = 0; }
+		}
 	};
 	{
 		row_general(0);  // the only row with special cases of its own (free gaps of a Left problem, the origin cell)
 		int i = 1;
 		// interior blocks: lane 1's column >= 1 at the block's first row, lane ND+1's column < LB at its last
-		const int int_lo = LA - dlo + 1, int_hi = LB - (dlo + ND - LA) - 7;  // first rows i0 with int_lo <= i0 < int_hi qualify
+		const int int_lo = LA - dlo + 1, int_hi = LB - (dlo + ND - LA) - (RB - 1);  // first rows i0 with int_lo <= i0 < int_hi qualify
 		while (i < LA) {
-			if ((i & 7) == 0 && i + 8 <= LA && i >= int_lo && i < int_hi) {
-				rows8_interior(i);
-				i += 8;
+			if ((i & (RB - 1)) == 0 && i + RB <= LA && i >= int_lo && i < int_hi) {
+				rows_interior(i);
+				i += RB;
 			} else {
-				const int n = min(8 - (i & 7), LA - i);
-				rows_upto8(i, n);
+				const int n = min(RB - (i & (RB - 1)), LA - i);
+				rows_upto(i, n);
 				i += n;
 			}
-			if (aborted != nullptr && i < LA) {
-				const float best = rdlane(wave_prefix_max(fmaxf(M, Dn)), 63);
+			// the stop test after every block of the first URX_ABORT_FINE rows, after every second one from there on
+			if (aborted != nullptr && i < LA && (RB == 8 || i < URX_ABORT_FINE || (i & 7) == 0)) {
+				const float best = rdlane(wave_prefix_max(lane >= 1 ? fmaxf(M, Dn) : NEG), 63);  // (lane 0's D is not a cell's)
 				if (best + (float)(LA - i) < abort_below) { *aborted = true; URX_SYNC(); return best; }
 			}
 		}
