@@ -455,6 +455,7 @@ class Workload:
             barrier()
         kms = np.zeros(2)
         self.stage_ms = np.zeros(7)
+        self.round_ms = None
         t0 = time.perf_counter()
         for k in range(steps):
             self.step(mappers, warmup + k)
@@ -464,6 +465,8 @@ class Workload:
                 kms += np.array(m.last_kernel_ms()) / len(mappers)
                 if not self.pe:
                     self.stage_ms += np.array(m.stage_ms()) / len(mappers)
+                    rm = np.array(m.round_ms()) / len(mappers) / max(1, steps)
+                    self.round_ms = rm if self.round_ms is None else self.round_ms + rm
         if barrier:
             barrier()
         self.stage_ms /= max(1, steps)
@@ -988,6 +991,9 @@ def main():
             out["phase6"] = {"hsps_given_to_dp_kernel": dp_stats[0], "reads_with_such_hsps": dp_stats[1], "dps_the_ordered_replay_used": dp_stats[2],
                              "dropped_by_a_round_gate_before_their_dp": dp_stats[3],
                              "second_pass": {"hsps": dp_stats[4], "reads": dp_stats[5], "used": dp_stats[6], "gated": dp_stats[7]}}
+            if wl.round_ms is not None:
+                out["phase6"]["launch_ms_by_round"] = {"rounds": "HSPs [0,2), [2,16), [16,...) of a read", "dp_kernel": [round(float(x[0]), 3) for x in wl.round_ms],
+                                                       "finalize_se_kernel": [round(float(x[1]), 3) for x in wl.round_ms]}
         if key:
             out["work_per_read_survey"] = SURVEY_WORK_PER_READ[key]
         if cpu is not None:
@@ -1014,6 +1020,9 @@ def main():
                     others[name]["phase6"] = {"hsps_given_to_dp_kernel": ds[0], "reads_with_such_hsps": ds[1], "dps_the_ordered_replay_used": ds[2],
                                               "dropped_by_a_round_gate_before_their_dp": ds[3],
                                               "second_pass": {"hsps": ds[4], "reads": ds[5], "used": ds[6], "gated": ds[7]}}
+                    if wl.round_ms is not None:
+                        others[name]["phase6"]["launch_ms_by_round"] = {"dp_kernel": [round(float(x[0]), 3) for x in wl.round_ms],
+                                                                        "finalize_se_kernel": [round(float(x[1]), 3) for x in wl.round_ms]}
             out["other_workloads"] = others
         if world == 1 and not pe and L == 150 and not args.no_e2e:
             try:

@@ -158,6 +158,9 @@ int urmapx_ctx_last_kernel_ms(urmapx_ctx *, float ms[2]);
  * general kernel over whatever both passes left flagged.  Device times in ms: [0] search, [1] its DP launches summed,
  * [2] its finalize launches summed, [3..5] the second pass likewise, [6] the general kernel. */
 int urmapx_ctx_stage_ms(urmapx_ctx *, float ms[7]);
+/* The same call's phase-6 launches one by one (first pass): ms[2*r] = the DP launch of round r, ms[2*r+1] = the finalize
+ * launch behind it; *rounds = how many rounds there are (3: HSPs [0,2), [2,16), [16,...) of a read). */
+int urmapx_ctx_round_ms(urmapx_ctx *, float ms[16], int *rounds);
 /* Statistics of the same call, per pass (4 numbers each): HSPs handed to the DP launches, reads they belong to, how many
  * of those DPs the ordered replay of AlignHSP (alignhsp.cpp:60-172) looked at, and how many were dropped before their DP
  * because the penalty cap had fallen far enough by their round. */

@@ -362,6 +362,17 @@ int urmapx_ctx_stage_ms(urmapx_ctx *C, float ms[7]) {
 	return URMAPX_OK;
 }
 
+int urmapx_ctx_round_ms(urmapx_ctx *C, float ms[16], int *rounds) {
+	if (!C || !ms || !rounds) return URMAPX_E_ARG;
+	static_assert(2 * DP_ROUNDS <= 16, "ms[16]");
+	for (int i = 0; i < 16; ++i) ms[i] = 0;
+	*rounds = DP_ROUNDS;
+	if (!C->stage_valid) return URMAPX_OK;
+	HIP_TRY(hipEventSynchronize(C->stage_ev[STAGE_EVENTS - 1]));
+	for (int i = 0; i < 2 * DP_ROUNDS; ++i) HIP_TRY(hipEventElapsedTime(&ms[i], C->stage_ev[1 + i], C->stage_ev[2 + i]));
+	return URMAPX_OK;
+}
+
 // Statistics of the last single-end *_device call: per pass {jobs made, reads parked, jobs whose DP the replay needed}
 int urmapx_ctx_dp_stats(urmapx_ctx *C, uint32_t out[8]) {
 	if (!C || !out || !C->dpbuf.p) return URMAPX_E_ARG;

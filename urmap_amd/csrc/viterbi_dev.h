@@ -85,7 +85,7 @@ __device__ float viterbi_wide(const VPar P, const uint8_t *A, int LA, const uint
 // the free end gaps of Left / Right problems add nothing); once that bound is below abort_below the DP stops and sets
 // *aborted -- the result would have been discarded anyway.
 #ifndef URX_VIT_RB
-#define URX_VIT_RB 4  // rows per block of viterbi_wave (4 or 8)
+#define URX_VIT_RB 8  // rows per block of viterbi_wave (8; 4 measured slower)
 #endif
 #ifndef URX_ABORT_FINE
 #define URX_ABORT_FINE 32
