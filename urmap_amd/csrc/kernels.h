@@ -84,7 +84,8 @@ struct DpWork {
 	uint16_t *ops = nullptr;        // jobs_cap * DP_JOB_OPS: the accepted alignment's path per job
 	uint16_t *kidx = nullptr;       // jobs_cap: DpJob::k again, contiguous (a round scans it 64 jobs per load)
 	uint32_t jobs_cap = 0;
-	uint32_t *tickets = nullptr;    // work counters of dp_kernel's rounds, zeroed with the counters
+	uint32_t *tickets = nullptr;    // [rd] work counter of dp_kernel's round rd, [4 + rd] length of the round's job list; zeroed with the counters
+	uint32_t *round_list = nullptr; // DP_ROUNDS x jobs_cap: the jobs (indices) of each round, dealt out by dp_round_lists_kernel after the search
 	uint32_t *counters = nullptr;   // [0] jobs made, [1] reads parked, [2] jobs the ordered replay needed, [3] jobs a round's gate dropped before their DP (statistics)
 	uint32_t *fin_list = nullptr;   // per parked read: read, first job, job count, read length (16 bytes, one load)
 	uint32_t *state = nullptr;      // per parked read: search state (dp_state_words(ovf) words each)

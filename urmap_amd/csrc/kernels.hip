@@ -637,6 +637,16 @@ struct SearchWave {
 	// m_Mapq, SetMappedPos (state1.cpp:129-145) with PosToCoordL (ufindex.cpp:729-755), the top hit's path
 	__device__ void fill_result(urmapx_result &res, int phase, urmapx_path_op *__restrict__ path_ops, uint32_t *path_used) {
 		const int lane = fresh_lane(this->lane);  // dev_common.h: lane-derived values are remade here, not carried (and spilled) from the top of the kernel
+		if (fill_result_core(res, phase)) {
+			uint32_t po = 0;
+			if (lane == 0) po = atomicAdd(path_used, (uint32_t)top_nops);
+			po = uni(po);
+			for (int t = lane; t < top_nops; t += 64) path_ops[po + t] = top[t];
+			res.path_off = po; res.path_nops = (uint16_t)top_nops;
+		}
+	}
+	// everything of the result but the place of the top hit's path; true: there is a path (top[0 .. top_nops)) to be placed
+	__device__ bool fill_result_core(urmapx_result &res, int phase) {
 		res.mapq = (uint8_t)calc_mapq();
 		res.score = (int16_t)best; res.second = (int16_t)second;
 		res.hit_count = (uint16_t)hitCount; res.exit_phase = (uint8_t)phase; res.status = (uint8_t)status;
@@ -652,15 +662,10 @@ struct SearchWave {
 			}
 			if (found != 0xFFFFFFFFu && coord + (uint32_t)QL <= tl) {
 				res.dbpos = top_db; res.seq_index = found; res.coord = coord; res.plus = top_plus ? 1 : 0;
-				if (top_nops > 0) {
-					uint32_t po = 0;
-					if (lane == 0) po = atomicAdd(path_used, (uint32_t)top_nops);
-					po = uni(po);
-					for (int t = lane; t < top_nops; t += 64) path_ops[po + t] = top[t];
-					res.path_off = po; res.path_nops = (uint16_t)top_nops;
-				}
+				return top_nops > 0;
 			}
 		}
+		return false;
 	}
 
 	// search1m6.cpp:9-33
@@ -1335,6 +1340,53 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 }
 
 // ------------------------------------------------------------------------------------------------
+// the jobs of each round as a list: one pass over the k of every job the search kernel made
+// ------------------------------------------------------------------------------------------------
+// A block takes 4096 consecutive jobs, counts those of each round in LDS, reserves room in the round's list with ONE
+// atomic per round (the lists' order does not matter: it only decides which wavefront runs a job) and writes the indices;
+// a thread's 16 jobs are consecutive, so the jobs of a read stay together in the list (dp_kernel keeps a read's bases in LDS).
+__global__ __launch_bounds__(256) void dp_round_lists_kernel(DpWork dp) {
+	constexpr int PER = 16;
+	__shared__ uint32_t cnt[DP_ROUNDS], base[DP_ROUNDS];
+	const uint32_t made = dp.counters[0];
+	const uint32_t njobs = made < dp.jobs_cap ? made : dp.jobs_cap;
+	for (uint32_t c0 = blockIdx.x * 256u * PER; c0 < njobs; c0 += gridDim.x * 256u * PER) {
+		if (threadIdx.x < DP_ROUNDS) cnt[threadIdx.x] = 0;
+		__syncthreads();
+		const uint32_t j0 = c0 + threadIdx.x * PER;
+		uint16_t kk[PER];
+		if (j0 + PER <= njobs) {
+			const uint4 a = *reinterpret_cast<const uint4 *>(dp.kidx + j0), b = *reinterpret_cast<const uint4 *>(dp.kidx + j0 + 8);
+			const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+			for (int i = 0; i < PER; ++i) kk[i] = (uint16_t)(w[i >> 1] >> (16 * (i & 1)));
+		} else {
+#pragma unroll
+			for (int i = 0; i < PER; ++i) kk[i] = j0 + i < njobs ? dp.kidx[j0 + i] : (uint16_t)0xFFFFu;
+		}
+		uint32_t my[DP_ROUNDS], pos[DP_ROUNDS];
+#pragma unroll
+		for (int rd = 0; rd < DP_ROUNDS; ++rd) {
+			my[rd] = 0;
+#pragma unroll
+			for (int i = 0; i < PER; ++i) my[rd] += (kk[i] != 0xFFFFu && kk[i] >= DP_ROUND_LO[rd] && kk[i] < DP_ROUND_LO[rd + 1]) ? 1u : 0u;
+			pos[rd] = my[rd] ? atomicAdd(&cnt[rd], my[rd]) : 0u;
+		}
+		__syncthreads();
+		if (threadIdx.x < DP_ROUNDS) base[threadIdx.x] = cnt[threadIdx.x] ? atomicAdd(dp.tickets + 4 + threadIdx.x, cnt[threadIdx.x]) : 0u;
+		__syncthreads();
+#pragma unroll
+		for (int rd = 0; rd < DP_ROUNDS; ++rd) {
+			uint32_t *out = dp.round_list + (size_t)rd * dp.jobs_cap + base[rd] + pos[rd];
+#pragma unroll
+			for (int i = 0; i < PER; ++i)
+				if (kk[i] != 0xFFFFu && kk[i] >= DP_ROUND_LO[rd] && kk[i] < DP_ROUND_LO[rd + 1]) *out++ = j0 + (uint32_t)i;
+		}
+		__syncthreads();
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
 // kernel C: the flank DPs of AlignHSP (alignhsp.cpp:98-162), one wavefront per DpJob
 // ------------------------------------------------------------------------------------------------
 // Everything here depends on the HSP and the sequences only: the windows, the two banded DPs, the trimming of
@@ -1360,7 +1412,7 @@ template <int NCH>
 __global__ __launch_bounds__(64) URX_DP_ATTR void dp_kernel(DevIndex X, urmapx_params P, const uint8_t *__restrict__ bases,
                                                 const uint64_t *__restrict__ offs, DpWork dp, uint8_t *scratch,
                                                 size_t scratch_stride, const uint8_t *__restrict__ g_seq, uint32_t klo, uint32_t khi,
-                                                uint32_t *ticket) {
+                                                uint32_t *ticket, const uint32_t *__restrict__ list, const uint32_t *list_count) {
 	constexpr int QMAX = 64 * NCH;
 	constexpr int TB_ROWS8 = (QMAX - 24) / 8 + 2;
 	// two jobs at a time (viterbi_dev.h: VFlank, viterbi_pair_rows): each has its query strand, target window, trace buffer
@@ -1568,7 +1620,7 @@ template <int NCH>
 __global__ __launch_bounds__(64) URX_DP_ATTR void dp_kernel(DevIndex X, urmapx_params P, const uint8_t *__restrict__ bases,
                                                 const uint64_t *__restrict__ offs, DpWork dp, uint8_t *scratch,
                                                 size_t scratch_stride, const uint8_t *__restrict__ g_seq, uint32_t klo, uint32_t khi,
-                                                uint32_t *ticket) {
+                                                uint32_t *ticket, const uint32_t *__restrict__ list, const uint32_t *list_count) {
 	constexpr int QMAX = 64 * NCH;
 	constexpr int TB_ROWS8 = (QMAX - 24) / 8 + 2;
 	__shared__ __attribute__((aligned(16))) uint8_t sQ[QMAX];
@@ -1597,24 +1649,29 @@ __global__ __launch_bounds__(64) URX_DP_ATTR void dp_kernel(DevIndex X, urmapx_p
 	bool q_plus = false;
 	uint64_t q_off = 0;
 	int q_len = 0;
-	// this round's jobs: those with klo <= k < khi.  Blocks take tiles of DP_TILE consecutive jobs from the round's work
-	// counter (a read in a repeat family owns hundreds of consecutive jobs of the last round and none of the first: a
-	// fixed tile-to-block map left blocks idle while others still had a dozen DPs to run); the k of a tile's jobs comes in
-	// with one load and the block runs those of this round one after the other.
+	// this round's jobs: the list dp_round_lists_kernel made of those with klo <= k < khi.  Blocks take tiles of DP_TILE list
+	// entries from the round's work counter (a read in a repeat family owns hundreds of consecutive jobs of the last round
+	// and none of the first: a fixed tile-to-block map left blocks idle while others still had a dozen DPs to run).
+	// Until round 4 a tile was 32 consecutive jobs of the whole array, of which those of the round were picked by their k:
+	// every round paid one ticket per 32 jobs MADE, and tickets are atomics on one address, which retire at 88 M/s on this
+	// device whatever else the machine does -- 0.41 M tickets = 4.7 ms per round for 1 M 250-base reads, of which the first
+	// two rounds had 7 % and 30 % of the jobs to run (7.5 ms each).
 #ifndef URX_DP_TILE
-#define URX_DP_TILE 32  // 8: 8.6 ms, 16: 5.7, 32: 5.3, 48: 5.6, 64: 5.9 per 1 M 150-base reads (the counter is one address for all blocks)
+#define URX_DP_TILE 16
 #endif
 	constexpr uint32_t DP_TILE = URX_DP_TILE;
+	(void)klo; (void)khi; (void)njobs;
+	const uint32_t nlist = *list_count < dp.jobs_cap ? *list_count : dp.jobs_cap;
 	for (;;) {
 	uint32_t tile = 0;
 	if (lane == 0) tile = atomicAdd(ticket, DP_TILE);
 	tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)tile);
-	if (tile >= njobs) break;
-	uint32_t kk = 0xFFFFu;  // 0xFFFF: slot not in use
-	if (lane < (int)DP_TILE && tile + lane < njobs) kk = dp.kidx[tile + lane];
-	uint64_t todo = __ballot(kk >= klo && kk < khi && kk != 0xFFFFu);
+	if (tile >= nlist) break;
+	uint32_t jl = 0xFFFFFFFFu;
+	if (lane < (int)DP_TILE && tile + lane < nlist) jl = list[tile + lane];
+	uint64_t todo = __ballot(jl != 0xFFFFFFFFu);
 	while (todo) {
-		const uint32_t j = tile + (uint32_t)__builtin_ctzll(todo);
+		const uint32_t j = rdlane(jl, __builtin_ctzll(todo));
 		todo &= todo - 1;
 		const DpJob J = dp.jobs[j];
 		if (J.read == 0xFFFFFFFFu) continue;
@@ -1755,7 +1812,31 @@ __global__ __launch_bounds__(64) URX_FIN_ATTR void finalize_se_kernel(DevIndex X
                                                          uint32_t khi) {
 	using SW = SearchWave<NCH, OVF>;
 	__shared__ uint16_t top[URMAPX_MAX_PATH_OPS], cand[URMAPX_MAX_PATH_OPS];
+	// The paths of the reads a block finishes wait in LDS and go to the arena many at a time: room in the arena is an atomic
+	// on ONE address, those retire at 88 M/s on this device whatever else it does, and one per finished read was what the
+	// finalize launches took once the statistics counter was out of the way (0.3 M reads done in the first round of 1 M
+	// 250-base reads: 3.2 ms).  The arena stays dense; the result records of those reads wait with their paths and are written at the flush.
+	constexpr int PBUF_OPS = 1024, PEND = 64;
+	__shared__ uint16_t pbuf[PBUF_OPS];
+	__shared__ uint32_t pend_r[PEND];
+	__shared__ urmapx_result pend_res[PEND];  // path_off = the offset inside pbuf until the flush
+	int pb_used = 0, pb_n = 0;
 	const int lane = threadIdx.x;
+	auto flush_paths = [&]() {
+		if (pb_n == 0) return;
+		URX_SYNC();
+		uint32_t po = 0;
+		if (lane == 0) po = atomicAdd(path_used, (uint32_t)pb_used);
+		po = uni(po);
+		for (int t = lane; t < pb_used; t += 64) path_ops[po + t] = pbuf[t];
+		if (lane < pb_n) {
+			urmapx_result rr = pend_res[lane];
+			rr.path_off += po;
+			results[pend_r[lane]] = rr;
+		}
+		URX_SYNC();
+		pb_used = 0; pb_n = 0;
+	};
 	SW S(X, P, lane);
 	S.W = (int)X.W;
 	S.top = top; S.cand = cand;
@@ -1770,6 +1851,7 @@ __global__ __launch_bounds__(64) URX_FIN_ATTR void finalize_se_kernel(DevIndex X
 	// read is asked for before this one is replayed, and the parked state, the top path and the first 64 jobs of a read
 	// leave in one round of loads.
 	const uint4 *const fin = reinterpret_cast<const uint4 *>(dp.fin_list);
+	uint32_t used_block = 0;
 	uint4 ent = make_uint4(0u, 0u, 0u, 0u);
 	if (blockIdx.x < parked) ent = fin[blockIdx.x];
 	for (uint32_t e = blockIdx.x; e < parked; e += gridDim.x) {
@@ -1840,7 +1922,7 @@ __global__ __launch_bounds__(64) URX_FIN_ATTR void finalize_se_kernel(DevIndex X
 				if (S.maxPen != mp0 || S.best != b0) todo &= __ballot(viable());
 			}
 		}
-		if (lane == 0 && used) atomicAdd(dp.counters + 2, used);  // statistics: jobs whose DP the ordered replay looked at
+		used_block += used;  // statistics: jobs whose DP the ordered replay looked at
 		if (nj > khi) {  // more rounds to come: park again, and tell the remaining jobs the cap reached so far
 			URX_SYNC();
 			S.park_state(st, phase);
@@ -1851,14 +1933,25 @@ __global__ __launch_bounds__(64) URX_FIN_ATTR void finalize_se_kernel(DevIndex X
 		res.dbpos = 0xFFFFFFFFu; res.seq_index = 0xFFFFFFFFu; res.coord = 0xFFFFFFFFu;
 		res.score = 0; res.second = 0; res.mapq = 0; res.plus = 0; res.exit_phase = 0; res.status = 0;
 		res.hit_count = 0; res.path_nops = 0; res.path_off = 0;
-		S.fill_result(res, phase, path_ops, path_used);
+		if (S.fill_result_core(res, phase)) {
+			if (pb_used + S.top_nops > PBUF_OPS || pb_n == PEND) flush_paths();
+			URX_SYNC();
+			for (int t = lane; t < S.top_nops; t += 64) pbuf[pb_used + t] = top[t];
+			res.path_nops = (uint16_t)S.top_nops;
+			res.path_off = (uint32_t)pb_used;  // inside pbuf; the flush adds the place of the buffer in the arena
+			if (lane == 0) { pend_r[pb_n] = r; pend_res[pb_n] = res; }
+			pb_used += S.top_nops; ++pb_n;
+		} else if (lane == 0) results[r] = res;
 		if constexpr (!OVF) {
 			if (res.status & (URMAPX_ST_HSP_OVERFLOW | URMAPX_ST_HIT_OVERFLOW)) {  // the hit list outgrew the first pass's: map again
 				if (lane == 0) ovf_list[1 + atomicAdd(ovf_list, 1u)] = r;
 			}
 		}
-		if (lane == 0) results[r] = res;
 	}
+	flush_paths();
+	// one atomic per block, not per read: atomics on one address retire at 88 M/s on this device, and one per parked read was
+	// what the first finalize launch of a batch took (0.5 M reads: 5.7 ms)
+	if (lane == 0 && used_block) atomicAdd(dp.counters + 2, used_block);
 }
 
 size_t dp_state_words(bool ovf) { return ovf ? (size_t)SearchWave<3, true>::STATE_WORDS : (size_t)SearchWave<3, false>::STATE_WORDS; }
@@ -2074,10 +2167,12 @@ hipError_t launch_search_se(const DevIndex &X, const urmapx_params &P, const uin
 	                   wk.hsp_lds_cap, wk.ovf_list, OVFBASE_, DP_)
 	// phase 6 of the reads a pass parked: their flank DPs, then the ordered part
 #define URX_LAUNCH_DP(NCH_, OVF_, PASS_)                                                                                          \
-	do { for (int rd = 0; rd < DP_ROUNDS; ++rd) {                                                                                 \
+	do { hipLaunchKernelGGL(dp_round_lists_kernel, dim3(2048), dim3(256), 0, s, wk.dp[PASS_]);                                      \
+	for (int rd = 0; rd < DP_ROUNDS; ++rd) {                                                                                      \
 		hipLaunchKernelGGL((dp_kernel<NCH_>), dim3((unsigned)wk.dp_blocks), block, 0, s, X, P, d_bases, d_offs, wk.dp[PASS_],       \
 		                   wk.dp_scratch, wk.dp_scratch_stride, X.seq, DP_ROUND_LO[rd], DP_ROUND_LO[rd + 1],                      \
-		                   wk.dp[PASS_].tickets + rd);                                                                           \
+		                   wk.dp[PASS_].tickets + rd, wk.dp[PASS_].round_list + (size_t)rd * wk.dp[PASS_].jobs_cap,               \
+		                   wk.dp[PASS_].tickets + 4 + rd);                                                                       \
 		stamp(2 + (2 * DP_ROUNDS + 1) * PASS_ + 2 * rd);                                                                            \
 		hipLaunchKernelGGL((finalize_se_kernel<NCH_, OVF_>), dim3((unsigned)(wk.fin_blocks > 0 ? wk.fin_blocks : wk.blocks)), block, \
 		                   0, s, X, P, d_offs, wk.dp[PASS_], d_results, d_path_ops, d_path_used, wk.hsp_lds_cap, wk.ovf_list,        \

@@ -467,7 +467,8 @@ int urmapx_map_se_device(urmapx_ctx *C, const void *d_bases, const void *d_offs,
 		const uint32_t jobs_cap[2] = {(uint32_t)(jc < (1ull << 30) ? jc : (1ull << 30)) + 4096u,
 		                              (uint32_t)(jc < (1ull << 30) ? jc : (1ull << 30)) + 65536u};
 		const uint32_t fin_cap[2] = {n, n / 8u + 1024u};
-		size_t need = 128, at[2][6];  // head: counters (2 x 16 bytes), then the work counters (2 x 32 bytes)
+		static_assert(4 + DP_ROUNDS <= 8, "tickets: 32 bytes per pass");
+		size_t need = 128, at[2][7];  // head: counters (2 x 16 bytes), then the work counters (2 x 32 bytes)
 		for (int p = 0; p < 2; ++p) {
 			at[p][5] = need; need += (((size_t)jobs_cap[p] * 2) + 63) & ~(size_t)63;
 			at[p][0] = need; need += (size_t)jobs_cap[p] * sizeof(DpJob);
@@ -475,6 +476,7 @@ int urmapx_map_se_device(urmapx_ctx *C, const void *d_bases, const void *d_offs,
 			at[p][2] = need; need += (((size_t)fin_cap[p] * 16) + 63) & ~(size_t)63;
 			at[p][3] = need; need += (size_t)fin_cap[p] * dp_state_words(p == 1) * 4;
 			at[p][4] = 16 * (size_t)p;
+			at[p][6] = need; need += (((size_t)jobs_cap[p] * 4 * DP_ROUNDS) + 63) & ~(size_t)63;
 		}
 		if ((rc = C->dpbuf.ensure(need))) return rc;
 		for (int p = 0; p < 2; ++p) {
@@ -482,6 +484,7 @@ int urmapx_map_se_device(urmapx_ctx *C, const void *d_bases, const void *d_offs,
 			d.jobs = reinterpret_cast<DpJob *>(C->dpbuf.p + at[p][0]);
 			d.ops = reinterpret_cast<uint16_t *>(C->dpbuf.p + at[p][1]);
 			d.kidx = reinterpret_cast<uint16_t *>(C->dpbuf.p + at[p][5]);
+			d.round_list = reinterpret_cast<uint32_t *>(C->dpbuf.p + at[p][6]);
 			d.fin_list = reinterpret_cast<uint32_t *>(C->dpbuf.p + at[p][2]);
 			d.state = reinterpret_cast<uint32_t *>(C->dpbuf.p + at[p][3]);
 			d.counters = reinterpret_cast<uint32_t *>(C->dpbuf.p + at[p][4]);
