@@ -934,3 +934,33 @@ def test_chain_rows_on_and_off_give_the_oracle(dense_case, tmp_path, monkeypatch
             assert (g[name].astype(np.int64) == pres[name].astype(np.int64)).all(), (off, name)
         m.close()
         idx.close()
+
+
+@pytest.mark.gpu
+def test_phase6_launches_path_arena_dense_and_round_times(dense_case):
+    """Phase 6 as launches of its own (kernels.hip: dp_round_lists_kernel, dp_kernel, finalize_se_kernel): reads of a genome with
+    repeat families park with many HSPs each.  The results are the oracle's; the path arena is dense (finalize_se_kernel hands the
+    paths of the reads a block finishes to the arena many at a time: every gapped read's runs are there exactly once, nothing
+    between them); the launches are timed one by one (urmapx_ctx_round_ms) and add up to the stage times."""
+    from urmap_amd import synth
+    from conftest import reads_to_arrays
+    reads = synth.make_reads(4242, dense_case["genome"], 4000, read_len=250, sub=0.04, ins=0.005, dele=0.005, random_frac=0.02)
+    bases, offs = reads_to_arrays(reads)
+    ores, opaths, _ = dense_case["oracle_index"].map_se(bases, offs, threads=4)
+    m = dense_case["mapper"]
+    gres, gops = m.map_se(bases, offs)
+    compare_results(gres, gops, ores, opaths)
+    st = m.dp_stats()
+    assert st[0] > 2 * st[1] > 0, st  # jobs were made, several per parked read
+    nops = gres["path_nops"].astype(np.int64)
+    have = nops > 0
+    order = np.argsort(gres["path_off"][have])
+    o, l = gres["path_off"][have][order].astype(np.int64), nops[have][order]
+    assert (o[1:] >= o[:-1] + l[:-1]).all() and o[-1] + l[-1] <= len(gops)  # no two paths share a run
+    # nothing in the arena but paths -- except what a read mapped again by the second pass left behind from its first
+    assert int(nops.sum()) >= len(gops) - 96 * max(8, len(reads) // 100), (int(nops.sum()), len(gops))
+    rounds = m.round_ms()
+    stage = m.stage_ms()
+    assert len(rounds) == 3 and all(d >= 0 and f >= 0 for d, f in rounds)
+    assert abs(sum(d for d, _ in rounds) - stage[1]) < 0.05 + 0.02 * stage[1]
+    assert abs(sum(f for _, f in rounds) - stage[2]) < 0.05 + 0.02 * stage[2]

@@ -66,16 +66,15 @@ static constexpr uint8_t DPJ_LEFT_FAIL = 1, DPJ_RIGHT_FAIL = 2, DPJ_RIGHT_SKIPPE
 // The jobs of a read are run in rounds of growing size, [0,2) [2,16) [16,inf) by index: after each round the ordered
 // replay consumes that round's jobs and the penalty cap it arrives at gates the next round's DPs -- most of a repeat
 // read's HSPs fail AlignHSP's first test once the first few alignments have tightened the cap.
-#ifdef URX_DP_ROUNDS4  // build-time experiment: a finer first round
-static constexpr int DP_ROUNDS = 4;
-static constexpr uint32_t DP_ROUND_LO[DP_ROUNDS + 1] = {0u, 1u, 4u, 16u, 0xFFFFFFFFu};
-#elif defined(URX_DP_ROUNDS2)
-static constexpr int DP_ROUNDS = 2;
-static constexpr uint32_t DP_ROUND_LO[DP_ROUNDS + 1] = {0u, URX_DP_ROUNDS2, 0xFFFFFFFFu};
+#ifdef URX_DP_NROUNDS  // build-time experiment: -DURX_DP_NROUNDS=4 -DURX_DP_BOUNDS=0u,1u,4u,16u (up to 8 rounds)
+static constexpr int DP_ROUNDS = URX_DP_NROUNDS;
+static constexpr uint32_t DP_ROUND_LO[DP_ROUNDS + 1] = {URX_DP_BOUNDS, 0xFFFFFFFFu};
 #else
 static constexpr int DP_ROUNDS = 3;
 static constexpr uint32_t DP_ROUND_LO[DP_ROUNDS + 1] = {0u, 2u, 16u, 0xFFFFFFFFu};
 #endif
+static constexpr int DP_TICKET_WORDS = 16;  // per pass: [rd] work counter of round rd, [8 + rd] length of its job list
+static_assert(DP_ROUNDS <= 8, "DP_TICKET_WORDS");
 static constexpr int DP_JOB_OPS = URMAPX_MAX_PATH_OPS;  // ops slice per job
 static constexpr int STAGE_EVENTS = 4 + 4 * DP_ROUNDS;   // SearchWork::stage_events
 
@@ -84,7 +83,7 @@ struct DpWork {
 	uint16_t *ops = nullptr;        // jobs_cap * DP_JOB_OPS: the accepted alignment's path per job
 	uint16_t *kidx = nullptr;       // jobs_cap: DpJob::k again, contiguous (a round scans it 64 jobs per load)
 	uint32_t jobs_cap = 0;
-	uint32_t *tickets = nullptr;    // [rd] work counter of dp_kernel's round rd, [4 + rd] length of the round's job list; zeroed with the counters
+	uint32_t *tickets = nullptr;    // [rd] work counter of dp_kernel's round rd, [8 + rd] length of the round's job list; zeroed with the counters
 	uint32_t *round_list = nullptr; // DP_ROUNDS x jobs_cap: the jobs (indices) of each round, dealt out by dp_round_lists_kernel after the search
 	uint32_t *counters = nullptr;   // [0] jobs made, [1] reads parked, [2] jobs the ordered replay needed, [3] jobs a round's gate dropped before their DP (statistics)
 	uint32_t *fin_list = nullptr;   // per parked read: read, first job, job count, read length (16 bytes, one load)

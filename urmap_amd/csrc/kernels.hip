@@ -1373,7 +1373,7 @@ __global__ __launch_bounds__(256) void dp_round_lists_kernel(DpWork dp) {
 			pos[rd] = my[rd] ? atomicAdd(&cnt[rd], my[rd]) : 0u;
 		}
 		__syncthreads();
-		if (threadIdx.x < DP_ROUNDS) base[threadIdx.x] = cnt[threadIdx.x] ? atomicAdd(dp.tickets + 4 + threadIdx.x, cnt[threadIdx.x]) : 0u;
+		if (threadIdx.x < DP_ROUNDS) base[threadIdx.x] = cnt[threadIdx.x] ? atomicAdd(dp.tickets + 8 + threadIdx.x, cnt[threadIdx.x]) : 0u;
 		__syncthreads();
 #pragma unroll
 		for (int rd = 0; rd < DP_ROUNDS; ++rd) {
@@ -2154,7 +2154,7 @@ hipError_t launch_search_se(const DevIndex &X, const urmapx_params &P, const uin
 	for (int pass = 0; pass < 2; ++pass)
 		if (wk.dp[pass].jobs) {
 			hipError_t e = hipMemsetAsync(wk.dp[pass].counters, 0, 16, s);
-			if (e == hipSuccess) e = hipMemsetAsync(wk.dp[pass].tickets, 0, 32, s);
+			if (e == hipSuccess) e = hipMemsetAsync(wk.dp[pass].tickets, 0, 4 * DP_TICKET_WORDS, s);
 			if (e != hipSuccess) return e;
 		}
 #define URX_LAUNCH_SE(NCH_, OVF_, DBG_, GRID_, STATS_, OVFBASE_, DP_)                                                             \
@@ -2167,14 +2167,17 @@ hipError_t launch_search_se(const DevIndex &X, const urmapx_params &P, const uin
 	                   wk.hsp_lds_cap, wk.ovf_list, OVFBASE_, DP_)
 	// phase 6 of the reads a pass parked: their flank DPs, then the ordered part
 #define URX_LAUNCH_DP(NCH_, OVF_, PASS_)                                                                                          \
-	do { hipLaunchKernelGGL(dp_round_lists_kernel, dim3(2048), dim3(256), 0, s, wk.dp[PASS_]);                                      \
+	do { /* the second pass is a few reads with many jobs each, usually none at all: smaller grids for the launches that go by reads */ \
+	const unsigned dpg = (unsigned)wk.dp_blocks;                                                                                  \
+	const unsigned fing = (unsigned)(wk.fin_blocks > 0 ? wk.fin_blocks : wk.blocks), fing2 = PASS_ && fing > 1024u ? 1024u : fing;  \
+	hipLaunchKernelGGL(dp_round_lists_kernel, dim3(PASS_ ? 128 : 2048), dim3(256), 0, s, wk.dp[PASS_]);                           \
 	for (int rd = 0; rd < DP_ROUNDS; ++rd) {                                                                                      \
-		hipLaunchKernelGGL((dp_kernel<NCH_>), dim3((unsigned)wk.dp_blocks), block, 0, s, X, P, d_bases, d_offs, wk.dp[PASS_],       \
+		hipLaunchKernelGGL((dp_kernel<NCH_>), dim3(dpg), block, 0, s, X, P, d_bases, d_offs, wk.dp[PASS_],                        \
 		                   wk.dp_scratch, wk.dp_scratch_stride, X.seq, DP_ROUND_LO[rd], DP_ROUND_LO[rd + 1],                      \
 		                   wk.dp[PASS_].tickets + rd, wk.dp[PASS_].round_list + (size_t)rd * wk.dp[PASS_].jobs_cap,               \
-		                   wk.dp[PASS_].tickets + 4 + rd);                                                                       \
+		                   wk.dp[PASS_].tickets + 8 + rd);                                                                       \
 		stamp(2 + (2 * DP_ROUNDS + 1) * PASS_ + 2 * rd);                                                                            \
-		hipLaunchKernelGGL((finalize_se_kernel<NCH_, OVF_>), dim3((unsigned)(wk.fin_blocks > 0 ? wk.fin_blocks : wk.blocks)), block, \
+		hipLaunchKernelGGL((finalize_se_kernel<NCH_, OVF_>), dim3(fing2), block,                                                  \
 		                   0, s, X, P, d_offs, wk.dp[PASS_], d_results, d_path_ops, d_path_used, wk.hsp_lds_cap, wk.ovf_list,        \
 		                   DP_ROUND_LO[rd], DP_ROUND_LO[rd + 1]);                                                                  \
 		stamp(3 + (2 * DP_ROUNDS + 1) * PASS_ + 2 * rd);                                                                            \

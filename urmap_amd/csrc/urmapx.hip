@@ -467,8 +467,7 @@ int urmapx_map_se_device(urmapx_ctx *C, const void *d_bases, const void *d_offs,
 		const uint32_t jobs_cap[2] = {(uint32_t)(jc < (1ull << 30) ? jc : (1ull << 30)) + 4096u,
 		                              (uint32_t)(jc < (1ull << 30) ? jc : (1ull << 30)) + 65536u};
 		const uint32_t fin_cap[2] = {n, n / 8u + 1024u};
-		static_assert(4 + DP_ROUNDS <= 8, "tickets: 32 bytes per pass");
-		size_t need = 128, at[2][7];  // head: counters (2 x 16 bytes), then the work counters (2 x 32 bytes)
+		size_t need = 256, at[2][7];  // head: counters (2 x 16 bytes), then the work counters and list lengths (2 x 64 bytes from byte 64)
 		for (int p = 0; p < 2; ++p) {
 			at[p][5] = need; need += (((size_t)jobs_cap[p] * 2) + 63) & ~(size_t)63;
 			at[p][0] = need; need += (size_t)jobs_cap[p] * sizeof(DpJob);
@@ -488,7 +487,7 @@ int urmapx_map_se_device(urmapx_ctx *C, const void *d_bases, const void *d_offs,
 			d.fin_list = reinterpret_cast<uint32_t *>(C->dpbuf.p + at[p][2]);
 			d.state = reinterpret_cast<uint32_t *>(C->dpbuf.p + at[p][3]);
 			d.counters = reinterpret_cast<uint32_t *>(C->dpbuf.p + at[p][4]);
-			d.tickets = reinterpret_cast<uint32_t *>(C->dpbuf.p + 64 + 32 * (size_t)p);
+			d.tickets = reinterpret_cast<uint32_t *>(C->dpbuf.p + 64 + 4 * DP_TICKET_WORDS * (size_t)p);
 			d.jobs_cap = jobs_cap[p]; d.fin_cap = fin_cap[p];
 		}
 	}
