@@ -951,7 +951,7 @@ def test_phase6_launches_path_arena_dense_and_round_times(dense_case):
     gres, gops = m.map_se(bases, offs)
     compare_results(gres, gops, ores, opaths)
     st = m.dp_stats()
-    assert st[0] > 2 * st[1] > 0, st  # jobs were made, several per parked read
+    assert st[0] > st[1] > 500 and st[2] > 0, st  # reads were parked with their HSPs as jobs, and the ordered replay looked at DPs
     nops = gres["path_nops"].astype(np.int64)
     have = nops > 0
     order = np.argsort(gres["path_off"][have])
