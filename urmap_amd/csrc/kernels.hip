@@ -977,7 +977,10 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 	// finish long after the rest.
 	// TICKET_CHUNK reads per ticket: same-address atomics retire at ~88 M/s on this device (a bare ticket loop over 1 M
 	// reads takes 11.4 ms), which would cap the kernel not far above its current rate.
-	if constexpr (OVF) n = ovf_list[0];  // how many reads the first pass flagged (usually none)
+	if constexpr (OVF) {
+		n = ovf_list[0];  // how many reads the first pass flagged (usually none: then no block asks the ticket counter)
+		if (n == 0) return;
+	}
 	uint32_t r_next = 0, r_end = 0;
 	auto take = [&](uint32_t &ri) -> bool {  // the next read of this block; false: the batch is used up
 		if (r_next == r_end) {
@@ -1662,10 +1665,17 @@ __global__ __launch_bounds__(64) URX_DP_ATTR void dp_kernel(DevIndex X, urmapx_p
 	constexpr uint32_t DP_TILE = URX_DP_TILE;
 	(void)klo; (void)khi; (void)njobs;
 	const uint32_t nlist = *list_count < dp.jobs_cap ? *list_count : dp.jobs_cap;
-	for (;;) {
-	uint32_t tile = 0;
-	if (lane == 0) tile = atomicAdd(ticket, DP_TILE);
-	tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)tile);
+	// A block's first tile is its own (tile blockIdx.x), the ticket counter deals the tiles behind the grid's first sweep: a
+	// launch with nothing to do -- the second pass's three, every batch -- used to cost one ticket per block, 5 888 atomics on one
+	// address = 68 us each; a block that sees the list used up behind its tile does not ask again.
+	uint32_t tile = blockIdx.x * DP_TILE;
+	for (bool first = true;; first = false) {
+	if (!first) {
+		if (tile + DP_TILE >= nlist && tile >= gridDim.x * DP_TILE) break;  // this block took the list's last tile from the counter
+		uint32_t t0 = 0;
+		if (lane == 0) t0 = atomicAdd(ticket, DP_TILE);
+		tile = gridDim.x * DP_TILE + (uint32_t)__builtin_amdgcn_readfirstlane((int)t0);
+	}
 	if (tile >= nlist) break;
 	uint32_t jl = 0xFFFFFFFFu;
 	if (lane < (int)DP_TILE && tile + lane < nlist) jl = list[tile + lane];
@@ -2136,7 +2146,7 @@ hipError_t launch_search_se(const DevIndex &X, const urmapx_params &P, const uin
 	if (n == 0) return hipSuccess;
 	const int nch = nch_for(max_read_len);
 	{
-		hipError_t e = hipMemsetAsync(wk.ticket, 0, 4, s);
+		hipError_t e = hipMemsetAsync(wk.ticket, 0, 8, s);  // two words: the first pass's ticket counter and the second pass's
 		if (e != hipSuccess) return e;
 	}
 	if (wk.stats) {
@@ -2151,16 +2161,22 @@ hipError_t launch_search_se(const DevIndex &X, const urmapx_params &P, const uin
 	uint2 *const no_ovf = reinterpret_cast<uint2 *>(wk.scratch + (size_t)wk.blocks * wk.scratch_stride);  // HSP lists beyond LDS
 	const DpWork no_dp;
 	auto stamp = [&](int i) { if (wk.stage_events) (void)hipEventRecord(wk.stage_events[i], s); };
-	for (int pass = 0; pass < 2; ++pass)
-		if (wk.dp[pass].jobs) {
-			hipError_t e = hipMemsetAsync(wk.dp[pass].counters, 0, 16, s);
-			if (e == hipSuccess) e = hipMemsetAsync(wk.dp[pass].tickets, 0, 4 * DP_TICKET_WORDS, s);
-			if (e != hipSuccess) return e;
-		}
+	if (wk.dp[0].jobs && wk.dp[1].jobs && wk.dp[1].counters == wk.dp[0].counters + 4 && wk.dp[0].tickets == wk.dp[0].counters + 16 &&
+	    wk.dp[1].tickets == wk.dp[0].tickets + DP_TICKET_WORDS) {
+		// both passes' counters and work counters are one block of the work buffer's head (urmapx.hip): one fill, not four
+		hipError_t e = hipMemsetAsync(wk.dp[0].counters, 0, 64 + 2 * 4 * DP_TICKET_WORDS, s);
+		if (e != hipSuccess) return e;
+	} else
+		for (int pass = 0; pass < 2; ++pass)
+			if (wk.dp[pass].jobs) {
+				hipError_t e = hipMemsetAsync(wk.dp[pass].counters, 0, 16, s);
+				if (e == hipSuccess) e = hipMemsetAsync(wk.dp[pass].tickets, 0, 4 * DP_TICKET_WORDS, s);
+				if (e != hipSuccess) return e;
+			}
 #define URX_LAUNCH_SE(NCH_, OVF_, DBG_, GRID_, STATS_, OVFBASE_, DP_)                                                             \
 	hipLaunchKernelGGL((search_se_kernel<NCH_, OVF_, DBG_>), GRID_, block, 0, s, X, P, d_bases, d_offs, n, d_results,                \
-	                   d_path_ops, d_path_used, STATS_, wk.scratch, wk.scratch_stride, X.seq, X.blob, X.seqp, wk.ticket,         \
-	                   wk.hsp_lds_cap, wk.ovf_list, OVFBASE_, DP_)
+	                   d_path_ops, d_path_used, STATS_, wk.scratch, wk.scratch_stride, X.seq, X.blob, X.seqp,                    \
+	                   wk.ticket + ((OVF_) ? 1 : 0), wk.hsp_lds_cap, wk.ovf_list, OVFBASE_, DP_)
 #define URX_LAUNCH_SE_ROWS(NCH_, GRID_, STATS_, OVFBASE_, DP_)                                                                      \
 	hipLaunchKernelGGL((search_se_kernel<NCH_, false, false, true>), GRID_, block, 0, s, X, P, d_bases, d_offs, n, d_results,          \
 	                   d_path_ops, d_path_used, STATS_, wk.scratch, wk.scratch_stride, X.seq, X.blob, X.seqp, wk.ticket,         \
@@ -2210,8 +2226,6 @@ hipError_t launch_search_se(const DevIndex &X, const urmapx_params &P, const uin
 		for (int i = 0; i < 2 * DP_ROUNDS; ++i) stamp(2 + i);
 	{
 		hipError_t e = hipGetLastError();
-		if (e != hipSuccess) return e;
-		e = hipMemsetAsync(wk.ticket, 0, 4, s);
 		if (e != hipSuccess) return e;
 	}
 	// second pass over the reads whose HSP or hit list outgrew the first pass's (the blocks read the count and leave
