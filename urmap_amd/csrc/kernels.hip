@@ -1662,6 +1662,9 @@ __global__ __launch_bounds__(64) URX_DP_ATTR void dp_kernel(DevIndex X, urmapx_p
 #ifndef URX_DP_TILE
 #define URX_DP_TILE 16
 #endif
+#ifndef URX_DP_EDGE2
+#define URX_DP_EDGE2 true  // viterbi_dev.h: edge rows with the tests of their edge only
+#endif
 	constexpr uint32_t DP_TILE = URX_DP_TILE;
 	(void)klo; (void)khi; (void)njobs;
 	const uint32_t nlist = *list_count < dp.jobs_cap ? *list_count : dp.jobs_cap;
@@ -1733,7 +1736,7 @@ __global__ __launch_bounds__(64) URX_DP_ATTR void dp_kernel(DevIndex X, urmapx_p
 					const int allGap = P.gap_open_score + (leftQL - 1) * P.gap_ext_score;
 					const int need = leftQL - (J.maxpen - totalPen);
 					bool aborted = false;
-					leftScore = (int)viterbi_wave<true>(VP, sQ, leftQL, sT, (int)leftTL, true, false, tb, TB_ROWS8, ws, RL, vst_l, lane,
+					leftScore = (int)viterbi_wave<true, URX_DP_EDGE2>(VP, sQ, leftQL, sT, (int)leftTL, true, false, tb, TB_ROWS8, ws, RL, vst_l, lane,
 					                                    (float)need, allGap < need ? &aborted : nullptr);
 					if (aborted) { leftScore = need - 1; RL.begin(); vst_l = 0; }
 					// TrimLeftIs (pathinfo.cpp:153-171): the leading I run is the last run in traceback order
@@ -1762,7 +1765,7 @@ __global__ __launch_bounds__(64) URX_DP_ATTR void dp_kernel(DevIndex X, urmapx_p
 					const int allGap = P.gap_open_score + (rightQL - 1) * P.gap_ext_score;
 					const int need = rightQL - (J.maxpen - totalPen);
 					bool aborted = false;
-					rightScore = (int)viterbi_wave<true>(VP, sQ + rightQLo, rightQL, sT, (int)rightTL, false, true, tb, TB_ROWS8, ws, RR, vst_r, lane,
+					rightScore = (int)viterbi_wave<true, URX_DP_EDGE2>(VP, sQ + rightQLo, rightQL, sT, (int)rightTL, false, true, tb, TB_ROWS8, ws, RR, vst_r, lane,
 					                                     (float)need, allGap < need ? &aborted : nullptr);
 					if (aborted) { rightScore = need - 1; RR.begin(); vst_r = 0; flags |= DPJ_RIGHT_ABORTED; }
 					// TrimRightIs (pathinfo.cpp:173-190): trailing I run = first run in traceback order, never the whole path

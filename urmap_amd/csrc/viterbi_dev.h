@@ -1,5 +1,6 @@
 // viterbi_dev.h -- banded Viterbi + traceback on one wavefront; see kernels.hip for the overview.
 #pragma once
+#include <type_traits>
 #include "dev_common.h"
 
 namespace urx {
@@ -90,7 +91,7 @@ __device__ float viterbi_wide(const VPar P, const uint8_t *A, int LA, const uint
 #ifndef URX_ABORT_FINE
 #define URX_ABORT_FINE 32
 #endif
-template <bool B_LDS = false>
+template <bool B_LDS = false, bool EDGE2 = false>
 __device__ __forceinline__ float viterbi_wave(const VPar P, const uint8_t *A, int LA, const uint8_t *B, int LB, bool Left, bool Right,
                               uint32_t *tb, int tb_rows8, const WideScratch ws, RevOps &R, uint32_t &status, int lane_in,
                               float abort_below = -3.0e38f, bool *aborted = nullptr, uint32_t *wide_lds = nullptr, int wide_lds_dwords = 0) {
@@ -185,10 +186,10 @@ __device__ __forceinline__ float viterbi_wave(const VPar P, const uint8_t *A, in
 	const uint32_t LBr = real ? (uint32_t)LB : 0u;                          // band cell iff (unsigned)j < LBr
 	const int LBs = (lane >= 1 && lane <= ND + 1) ? LB : -(1 << 20);        // column LB cell iff j == LBs
 	const uint32_t bits0c = lane == 0 ? TB_IM : 0u;                         // column Startj-1: IM once j >= 0
-	// Rows come in blocks of RB = 4 (URX_VIT_RB; 8 until round 4): a trace dword holds eight rows, so two blocks fill one.  With
-	// four the blocks at the band's edges are shorter (a block is "interior" only if no lane enters or leaves the matrix in ANY
-	// of its rows: up to 3 + 3 rows lost to alignment instead of 7 + 7 -- on a 60-row flank 32 rows take the cheap road
-	// instead of 24) and dp_kernel can look at its stop test twice as often.
+	// Rows come in blocks of RB = 8 (URX_VIT_RB), the rows of one trace dword.  Blocks of 4 were measured in round 4: the
+	// blocks at the band's edges are shorter (a block is "interior" only if no lane enters or leaves the matrix in ANY of its
+	// rows: up to 3 + 3 rows lost to alignment instead of 7 + 7) and dp_kernel can look at its stop test twice as often -- and
+	// the shorter unrolled bodies schedule worse by more than that.
 	constexpr int RB = URX_VIT_RB;
 	static_assert(RB == 4 || RB == 8, "a trace dword holds eight rows");
 	// rows i0 .. i0+n-1 (1 <= i0, all inside one block: (i0 & (RB-1)) + n <= RB)
@@ -238,6 +239,67 @@ __device__ __forceinline__ float viterbi_wave(const VPar P, const uint8_t *A, in
 				const uint32_t bMI = vraw >= I + GE ? TB_MI : 0u;
 				bits |= bMD | bMI;
 				bits = act ? bits : (semi ? bMD : (j >= 0 ? bits0c : 0u));
+				word |= bits << (4 * k);
+			}
+		}
+		acc |= word << sh0;
+		if (((i0 + n) & 7) == 0) { tb[(i0 >> 3) * 64 + lane] = acc; acc = 0; }
+	};
+	// EDGE2 (dp_kernel): the rows at the band's two edges with the tests of THEIR edge only.  Top (no cell of the block at or
+	// beyond column LB): a band lane is in the matrix from the row it reaches column 0 -- one compare of the row number with a
+	// lane constant; column 0 is that row itself; lane 0's trace cell turns IM at row int_lo, a wave-uniform test.  Bottom (every
+	// band lane at column >= 1, lane 0 at column >= 0): a band lane leaves at the row it reaches column LB -- the same compare
+	// with another constant -- and is the column-LB cell in exactly that row; no column-0 cell, so D opens from M + GO as in the
+	// interior.  rows_upto spends 9-11 instructions per row on lane classes, these 4-7.
+	const int enter_i = -jbase;                                                       // the row in which this lane sits at column 0
+	const int enter_real = real ? enter_i : 0x7FFFFFFF;                              // band cell (top) iff i >= enter_real
+	const int exit_real = real ? LB - jbase : (int)0x80000000;                       // band cell (bottom) iff i < exit_real
+	const int exit_semi = (lane >= 1 && lane <= ND + 1) ? LB - jbase : (int)0x80000000;  // column-LB cell iff i == exit_semi
+	auto rows_edge = [&](auto top_tag, int i0, int n, int int_lo_) {
+		constexpr bool TOP = decltype(top_tag)::value;
+		const int j0 = jbase + i0;
+		const uint8_t *Ap = A + i0;
+		uint32_t av[RB], bv[RB];
+		if constexpr (B_LDS) {
+			const uint8_t *Bp = B + j0;
+#pragma unroll
+			for (int k = 0; k < RB; ++k) { av[k] = Ap[k]; bv[k] = Bp[k]; }
+		} else {
+#pragma unroll
+			for (int k = 0; k < RB; ++k) { av[k] = A[min(i0 + k, LA - 1)]; bv[k] = B[min(max(j0 + k, 0), LB - 1)]; }
+		}
+		const int sh0 = 4 * (i0 & 7);
+		uint32_t word = 0;
+#pragma unroll
+		for (int k = 0; k < RB; ++k) {
+			if (k < n) {  // wave-uniform
+				const int i = i0 + k;
+				const bool act = TOP ? (enter_real <= i) : (i < exit_real);
+				const float D = wave_shl1(Dn, NEG);
+				const float Mcur = M;
+				const float vraw = Mcur + GO;
+				const float Pm = wave_prefix_max(vraw - el);
+				const float I = wave_shr1(Pm, NEG) + el1;
+				uint32_t bits = D > Mcur ? TB_DM : 0u;
+				float xM = fmaxf(Mcur, D);
+				bits = I > xM ? TB_IM : bits;
+				xM = fmaxf(xM, I);
+				const float sc = av[k] == bv[k] ? 1.0f : MISf;
+				M = xM + (act ? sc : NEG);
+				float md = vraw, de = D + GE;
+				if constexpr (TOP) {
+					if (Left) {  // compile-time at dp_kernel's call sites: column 0 of a Left problem opens / extends D for free
+						const bool col0 = enter_i == i;
+						md = Mcur + (col0 ? GOl : GO);
+						de = D + (col0 ? GEl : GE);
+					}
+				}
+				const uint32_t bMD = md >= de ? TB_MD : 0u;
+				Dn = fmaxf(md, de);
+				const uint32_t bMI = vraw >= I + GE ? TB_MI : 0u;
+				bits |= bMD | bMI;
+				if constexpr (TOP) bits = act ? bits : (i >= int_lo_ ? bits0c : 0u);
+				else bits = act ? bits : (exit_semi == i ? bMD : bits0c);
 				word |= bits << (4 * k);
 			}
 		}
@@ -301,7 +363,9 @@ __device__ __forceinline__ float viterbi_wave(const VPar P, const uint8_t *A, in
 				i += RB;
 			} else {
 				const int n = min(RB - (i & (RB - 1)), LA - i);
-				rows_upto(i, n);
+				if (EDGE2 && i + n - 1 < int_hi + (RB - 1)) rows_edge(std::true_type{}, i, n, int_lo);  // nothing at or beyond column LB
+				else if (EDGE2 && i >= int_lo) rows_edge(std::false_type{}, i, n, int_lo);
+				else rows_upto(i, n);
 				i += n;
 			}
 			// the stop test after every block of the first URX_ABORT_FINE rows, after every second one from there on
