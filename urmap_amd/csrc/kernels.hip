@@ -1663,7 +1663,7 @@ __global__ __launch_bounds__(64) URX_DP_ATTR void dp_kernel(DevIndex X, urmapx_p
 #define URX_DP_TILE 16
 #endif
 #ifndef URX_DP_EDGE2
-#define URX_DP_EDGE2 true  // viterbi_dev.h: edge rows with the tests of their edge only
+#define URX_DP_EDGE2 false  // viterbi_dev.h: edge rows with the tests of their edge only -- bit-identical, 10 % fewer instructions per edge row and no faster: off
 #endif
 	constexpr uint32_t DP_TILE = URX_DP_TILE;
 	(void)klo; (void)khi; (void)njobs;
