@@ -1628,7 +1628,12 @@ __global__ __launch_bounds__(64) URX_DP_ATTR void dp_kernel(DevIndex X, urmapx_p
 	constexpr int TB_ROWS8 = (QMAX - 24) / 8 + 2;
 	__shared__ __attribute__((aligned(16))) uint8_t sQ[QMAX];
 	__shared__ uint8_t sT[QMAX + 64];
+#if URX_DP_TB_GLOBAL  // build-time experiment: the trace cells in the block's global scratch, LDS per block 7 -> 1.2 KB
+	uint32_t *const tb = reinterpret_cast<uint32_t *>(scratch + (size_t)blockIdx.x * scratch_stride +
+	                                                  ((WideScratch::bytes(QMAX, QMAX + 64) + 255) & ~(size_t)255));
+#else
 	__shared__ uint32_t tb[TB_ROWS8 * 64];
+#endif
 	__shared__ uint16_t ropsL[OPS_CAP], ropsR[OPS_CAP], cand[URMAPX_MAX_PATH_OPS];
 	const int lane = threadIdx.x;
 	WideScratch ws;
@@ -1661,6 +1666,9 @@ __global__ __launch_bounds__(64) URX_DP_ATTR void dp_kernel(DevIndex X, urmapx_p
 	// two rounds had 7 % and 30 % of the jobs to run (7.5 ms each).
 #ifndef URX_DP_TILE
 #define URX_DP_TILE 16
+#endif
+#ifndef URX_DP_TB_GLOBAL
+#define URX_DP_TB_GLOBAL 0
 #endif
 #ifndef URX_DP_EDGE2
 #define URX_DP_EDGE2 false  // viterbi_dev.h: edge rows with the tests of their edge only -- bit-identical, 10 % fewer instructions per edge row and no faster: off
@@ -1970,7 +1978,9 @@ __global__ __launch_bounds__(64) URX_FIN_ATTR void finalize_se_kernel(DevIndex X
 size_t dp_state_words(bool ovf) { return ovf ? (size_t)SearchWave<3, true>::STATE_WORDS : (size_t)SearchWave<3, false>::STATE_WORDS; }
 size_t dp_scratch_stride(uint32_t max_read_len) {
 	const int qmax = 64 * (max_read_len <= 128 ? 2 : max_read_len <= 192 ? 3 : max_read_len <= 256 ? 4 : max_read_len <= 320 ? 5 : max_read_len <= 512 ? 8 : 16);
-	return (WideScratch::bytes(qmax, qmax + 64) + 255) & ~(size_t)255;
+	// the wide-band rows and trace bytes, then room for the narrow band's trace cells (URX_DP_TB_GLOBAL: dp_kernel keeps them here
+	// instead of in LDS)
+	return ((WideScratch::bytes(qmax, qmax + 64) + 255) & ~(size_t)255) + (size_t)((qmax - 24) / 8 + 2) * 256;
 }
 
 // ------------------------------------------------------------------------------------------------
