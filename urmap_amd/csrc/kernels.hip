@@ -1631,8 +1631,15 @@ __global__ __launch_bounds__(64) URX_DP_ATTR void dp_kernel(DevIndex X, urmapx_p
 #if URX_DP_TB_GLOBAL  // build-time experiment: the trace cells in the block's global scratch, LDS per block 7 -> 1.2 KB
 	uint32_t *const tb = reinterpret_cast<uint32_t *>(scratch + (size_t)blockIdx.x * scratch_stride +
 	                                                  ((WideScratch::bytes(QMAX, QMAX + 64) + 255) & ~(size_t)255));
+	__shared__ uint32_t wlds[3 * QMAX];  // the wide path's three per-row arrays (it used the idle trace buffer when that was LDS)
+#define URX_DP_WLDS , wlds, 3 * QMAX
+#elif defined(URX_DP_WLDS_TEST)  // debugging aid: the trace buffer in LDS as shipped, the wide path's rows in an array of their own
+	__shared__ uint32_t tb[TB_ROWS8 * 64];
+	__shared__ uint32_t wlds[URX_DP_WLDS_TEST * QMAX];
+#define URX_DP_WLDS , wlds, URX_DP_WLDS_TEST * QMAX
 #else
 	__shared__ uint32_t tb[TB_ROWS8 * 64];
+#define URX_DP_WLDS
 #endif
 	__shared__ uint16_t ropsL[OPS_CAP], ropsR[OPS_CAP], cand[URMAPX_MAX_PATH_OPS];
 	const int lane = threadIdx.x;
@@ -1730,6 +1737,10 @@ __global__ __launch_bounds__(64) URX_DP_ATTR void dp_kernel(DevIndex X, urmapx_p
 		RevOps RL, RR;
 		RL.ops = ropsL; RR.ops = ropsR;
 		RL.begin(); RR.begin();
+#if defined(URX_DP_WLDS_TEST) && defined(URX_DP_WLDS_FILL)
+		for (int t = lane; t < URX_DP_WLDS_TEST * QMAX; t += 64) wlds[t] = URX_DP_WLDS_FILL;
+		URX_SYNC();
+#endif
 		if (startq > 0) {
 			const int leftQL = startq;
 			const uint32_t leftTHi = startdb - 1;
@@ -1745,7 +1756,7 @@ __global__ __launch_bounds__(64) URX_DP_ATTR void dp_kernel(DevIndex X, urmapx_p
 					const int need = leftQL - (J.maxpen - totalPen);
 					bool aborted = false;
 					leftScore = (int)viterbi_wave<true, URX_DP_EDGE2>(VP, sQ, leftQL, sT, (int)leftTL, true, false, tb, TB_ROWS8, ws, RL, vst_l, lane,
-					                                    (float)need, allGap < need ? &aborted : nullptr);
+					                                    (float)need, allGap < need ? &aborted : nullptr URX_DP_WLDS);
 					if (aborted) { leftScore = need - 1; RL.begin(); vst_l = 0; }
 					// TrimLeftIs (pathinfo.cpp:153-171): the leading I run is the last run in traceback order
 					int nTrimI = 0;
@@ -1774,7 +1785,7 @@ __global__ __launch_bounds__(64) URX_DP_ATTR void dp_kernel(DevIndex X, urmapx_p
 					const int need = rightQL - (J.maxpen - totalPen);
 					bool aborted = false;
 					rightScore = (int)viterbi_wave<true, URX_DP_EDGE2>(VP, sQ + rightQLo, rightQL, sT, (int)rightTL, false, true, tb, TB_ROWS8, ws, RR, vst_r, lane,
-					                                     (float)need, allGap < need ? &aborted : nullptr);
+					                                     (float)need, allGap < need ? &aborted : nullptr URX_DP_WLDS);
 					if (aborted) { rightScore = need - 1; RR.begin(); vst_r = 0; flags |= DPJ_RIGHT_ABORTED; }
 					// TrimRightIs (pathinfo.cpp:173-190): trailing I run = first run in traceback order, never the whole path
 					if (RR.n > 1 && (ropsR[0] & 3u) == OP_I) rtrim = 1;

@@ -507,7 +507,7 @@ int urmapx_map_se_device(urmapx_ctx *C, const void *d_bases, const void *d_offs,
 	if ((rc = C->slowlist.ensure((size_t)n + 2))) return rc;
 	HIP_TRY(launch_search_se(C->X, C->params, (const uint8_t *)d_bases, (const uint64_t *)d_offs, n, max_read_len,
 	                         (urmapx_result *)d_results, (urmapx_path_op *)d_path_ops, (uint32_t *)d_path_used, wk, C->stream));
-	{  // reads outside the fast kernels' domain: the general kernel (it finds its work list on the device; usually empty)
+	if (!getenv("URMAPX_TEST_NO_GENERAL")) {  // reads outside the fast kernels' domain: the general kernel (it finds its work list on the device; usually empty).  The test aid leaves such reads flagged: which reads do the fast kernels hand over?
 		const uint64_t pcap = (uint64_t)n * URMAPX_MAX_PATH_OPS;
 		HIP_TRY(launch_search_se_slow(C->X, C->params, (const uint8_t *)d_bases, (const uint64_t *)d_offs, n, slow_qcap,
 		                              (urmapx_result *)d_results, (urmapx_path_op *)d_path_ops, (uint32_t *)d_path_used,
