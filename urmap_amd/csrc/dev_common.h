@@ -43,19 +43,22 @@ __device__ __forceinline__ float dpp_f(float v, float fill) {
 // compiler's form costs five instructions per step (constant fill, nop, v_mov_dpp, a canonicalising max, the max):
 // with dst = src1 = the value itself a lane whose DPP source does not exist is simply not written (bound_ctrl:0) and
 // keeps its value.  s_nop 1 = the two wait states a DPP read needs after the VALU write of the same register.
+#ifndef URX_DPP_NOP
+#define URX_DPP_NOP "s_nop 1\n\t"  // build-time knob (debugging): the wait between the steps
+#endif
 __device__ __forceinline__ float wave_prefix_max(float v) {
 	asm volatile(
-	    "s_nop 1\n\t"
+	    URX_DPP_NOP
 	    "v_max_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-	    "s_nop 1\n\t"
+	    URX_DPP_NOP
 	    "v_max_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
-	    "s_nop 1\n\t"
+	    URX_DPP_NOP
 	    "v_max_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
-	    "s_nop 1\n\t"
+	    URX_DPP_NOP
 	    "v_max_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
-	    "s_nop 1\n\t"
+	    URX_DPP_NOP
 	    "v_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-	    "s_nop 1\n\t"
+	    URX_DPP_NOP
 	    "v_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
 	    "s_nop 1"
 	    : "+v"(v));

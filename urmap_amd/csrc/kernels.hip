@@ -1619,6 +1619,12 @@ __global__ __launch_bounds__(64) URX_DP_ATTR void dp_kernel(DevIndex X, urmapx_p
 	if (lane == 0 && n_gated) atomicAdd(dp.counters + 3, n_gated);
 }
 #else
+// URX_DP_TB_GLOBAL (default 1): the trace cells of the narrow band live in the block's global scratch, not in LDS.  They were what held
+// this kernel to 5.75 waves per SIMD for 150-base reads and to 4.25 for 250-base reads (9.2 KB of LDS per block); the stores are one
+// dword per lane per eight rows and the traceback reads a few dozen cells.  250 bases: 31.5 -> 27.7 ms per 1 M reads, 150: 3.06 -> 2.94.
+#ifndef URX_DP_TB_GLOBAL
+#define URX_DP_TB_GLOBAL 1
+#endif
 template <int NCH>
 __global__ __launch_bounds__(64) URX_DP_ATTR void dp_kernel(DevIndex X, urmapx_params P, const uint8_t *__restrict__ bases,
                                                 const uint64_t *__restrict__ offs, DpWork dp, uint8_t *scratch,
@@ -1626,9 +1632,14 @@ __global__ __launch_bounds__(64) URX_DP_ATTR void dp_kernel(DevIndex X, urmapx_p
                                                 uint32_t *ticket, const uint32_t *__restrict__ list, const uint32_t *list_count) {
 	constexpr int QMAX = 64 * NCH;
 	constexpr int TB_ROWS8 = (QMAX - 24) / 8 + 2;
-	__shared__ __attribute__((aligned(16))) uint8_t sQ[QMAX];
-	__shared__ uint8_t sT[QMAX + 64];
-#if URX_DP_TB_GLOBAL  // build-time experiment: the trace cells in the block's global scratch, LDS per block 7 -> 1.2 KB
+	// ONE array for the read and the window behind it: the DP's row blocks read the window's bytes as base + immediate offset with
+	// base = sT + (column of the block's first row), which is negative by up to band_radius + 1 for the lanes left of column 0 --
+	// harmless as long as sT does not start at LDS offset 0: there the negative base wraps and base + offset is out of range for
+	// bytes that ARE in the matrix (they read as 0).  Two separate arrays left the order to the compiler, and it happened to put sQ
+	// first; adding any other LDS array to this kernel changed that and one tiny flank's score with it.
+	__shared__ __attribute__((aligned(16))) uint8_t sQT[QMAX + QMAX + 64];
+	uint8_t *const sQ = sQT, *const sT = sQT + QMAX;
+#if URX_DP_TB_GLOBAL  // the trace cells in the block's global scratch: LDS per block 7 -> 1.2 KB (+ the wide path's rows)
 	uint32_t *const tb = reinterpret_cast<uint32_t *>(scratch + (size_t)blockIdx.x * scratch_stride +
 	                                                  ((WideScratch::bytes(QMAX, QMAX + 64) + 255) & ~(size_t)255));
 	__shared__ uint32_t wlds[3 * QMAX];  // the wide path's three per-row arrays (it used the idle trace buffer when that was LDS)
@@ -1675,7 +1686,7 @@ __global__ __launch_bounds__(64) URX_DP_ATTR void dp_kernel(DevIndex X, urmapx_p
 #define URX_DP_TILE 16
 #endif
 #ifndef URX_DP_TB_GLOBAL
-#define URX_DP_TB_GLOBAL 0
+#define URX_DP_TB_GLOBAL 1
 #endif
 #ifndef URX_DP_EDGE2
 #define URX_DP_EDGE2 false  // viterbi_dev.h: edge rows with the tests of their edge only -- bit-identical, 10 % fewer instructions per edge row and no faster: off

@@ -79,7 +79,10 @@ __device__ float viterbi_wide(const VPar P, const uint8_t *A, int LA, const uint
                               const WideScratch ws, uint32_t *lds, int lds_dwords, RevOps &R, uint32_t &status, int lane);
 
 // ws.la_cap == 0: no wide-band scratch (the band must fit one wavefront).
-// B_LDS: B is an LDS array of the caller (reads around it cannot fault, so the row blocks index it without a clamp).
+// B_LDS: B is an LDS array of the caller (reads around it cannot fault, so the row blocks index it without a clamp).  The caller
+// keeps at least band_radius + 1 bytes of its LDS IN FRONT of B (B inside a larger array, never a variable of its own that the
+// compiler may place at LDS offset 0): the blocks address B[j0 + k] as base (B + j0) + immediate k with j0 down to -(band_radius + 1),
+// and a base below zero wraps -- base + k is then out of range, and reads 0, even where j0 + k is a column of the matrix.
 // abort_below / aborted (optional): the caller has no use for a score below abort_below (AlignHSP drops the HSP when a
 // flank costs more penalty than the cap leaves, alignhsp.cpp:127-130,160-162).  After every block of rows the best
 // M / D value of the row plus one point per query letter still to come bounds the final score from above (gaps cost,
