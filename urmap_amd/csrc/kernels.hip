@@ -1642,8 +1642,12 @@ __global__ __launch_bounds__(64) URX_DP_ATTR void dp_kernel(DevIndex X, urmapx_p
 #if URX_DP_TB_GLOBAL  // the trace cells in the block's global scratch: LDS per block 7 -> 1.2 KB (+ the wide path's rows)
 	uint32_t *const tb = reinterpret_cast<uint32_t *>(scratch + (size_t)blockIdx.x * scratch_stride +
 	                                                  ((WideScratch::bytes(QMAX, QMAX + 64) + 255) & ~(size_t)255));
+#ifdef URX_DP_NO_WLDS  // debugging aid: the wide path's rows in the global trace buffer too (what search_se_kernel's inline DP does)
+#define URX_DP_WLDS
+#else
 	__shared__ uint32_t wlds[3 * QMAX];  // the wide path's three per-row arrays (it used the idle trace buffer when that was LDS)
 #define URX_DP_WLDS , wlds, 3 * QMAX
+#endif
 #elif defined(URX_DP_WLDS_TEST)  // debugging aid: the trace buffer in LDS as shipped, the wide path's rows in an array of their own
 	__shared__ uint32_t tb[TB_ROWS8 * 64];
 	__shared__ uint32_t wlds[URX_DP_WLDS_TEST * QMAX];
