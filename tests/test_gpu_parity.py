@@ -964,3 +964,41 @@ def test_phase6_launches_path_arena_dense_and_round_times(dense_case):
     assert len(rounds) == 3 and all(d >= 0 and f >= 0 for d, f in rounds)
     assert abs(sum(d for d, _ in rounds) - stage[1]) < 0.05 + 0.02 * stage[1]
     assert abs(sum(f for _, f in rounds) - stage[2]) < 0.05 + 0.02 * stage[2]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lo,hi", [(60, 128), (130, 192), (200, 256)])
+def test_short_flanks_with_a_gap_next_to_the_read_ends(small_case, gpu, lo, hi):
+    """A one-base insertion or deletion 6..20 bases from an end of the read: the ungapped extension stops at it and AlignHSP's flank
+    DP runs on a handful of rows, most of its lanes left of column 0 or right of column LB.  The row blocks address the window's
+    bytes as base + immediate with a base below the window's start for those lanes; dp_kernel once depended on what the compiler
+    had placed in front of the window in LDS (one 14-row flank in the whole suite met it)."""
+    from urmap_amd import synth
+    from conftest import reads_to_arrays
+    rng = np.random.default_rng(1000 + hi)
+    reads = []
+    for si, (name, seq) in enumerate(small_case["genome"]):
+        for _ in range(400):
+            L = int(rng.integers(lo, hi + 1))
+            p0 = int(rng.integers(0, len(seq) - L - 4))
+            frag = seq[p0:p0 + L + 2].copy()
+            if (frag == ord("N")).any():
+                continue
+            p = int(rng.integers(6, 21))
+            if rng.random() < 0.5:
+                p = L - p
+            if rng.random() < 0.5:
+                r = np.delete(frag, p)[:L]  # a base of the reference the read does not have
+            else:
+                r = np.insert(frag, p, synth.ACGT[(int(np.where(synth.ACGT == (frag[p] & 0xDF))[0][0]) + 1) % 4])[:L]
+            if rng.random() < 0.3:  # and a substitution somewhere else
+                q = int(rng.integers(0, L))
+                r[q] = synth.ACGT[(int(np.where(synth.ACGT == (r[q] & 0xDF))[0][0]) + 2) % 4]
+            if rng.random() < 0.5:
+                r = synth.revcomp(r)
+            reads.append((f"e{len(reads)}", np.ascontiguousarray(r), np.full(len(r), ord("I"), np.uint8)))
+    bases, offs = reads_to_arrays(reads)
+    ores, opaths, _ = small_case["oracle_index"].map_se(bases, offs, threads=4)
+    assert sum(("I" in p or "D" in p) for p in opaths) > len(reads) // 3  # the gaps are aligned, not clipped away
+    gres, gops = gpu["mapper"].map_se(bases, offs)
+    compare_results(gres, gops, ores, opaths)
