@@ -54,7 +54,7 @@ def parse_args():
     ap.add_argument("--no-other-workloads", action="store_true", help="skip the PE and 250 bp runs on the same index")
     ap.add_argument("--no-e2e", action="store_true", help="skip the FASTQ file -> SAM file run")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("URMAP_BENCH_STREAMS", 1)),
-                    help="mapping contexts (HIP streams) a batch is split over, as urmap -streams does; 1 keeps the launches of a step back to back so that their times add up to the step (2: +6 %% at 150 bp, +20 %% at 250 bp, launches overlap)")
+                    help="mapping contexts (HIP streams) a batch is split over, as urmap -streams does; 1 keeps the launches of a step back to back so that their times add up to the step (2: -2 %% at 150 bp, +5 %% at 250 bp since round 4 made phase 6 cheap; launches overlap)")
     ap.add_argument("--mode", choices=("se", "pe"), default="se", help="pe: 2x150 read pairs through State2::Search4 (config 3; not the headline metric)")
     return ap.parse_args()
 
