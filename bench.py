@@ -885,6 +885,11 @@ def main():
     slots, fasta_bytes = default_slot_count(seq_lengths, labels)
     t_gen = time.time() - t_setup
     index, blob_np, seq_np, d_seq, t_index = place_index(R, torch, api, device, d_seq, slots, seq_lengths, seq_offsets, labels)
+    # UFIndex::Validate (ufindex.cpp:611-658) as a device pass over THIS rank's resident replica, before anything is timed: every
+    # stored position re-hashed to its head slot, every chain followed, every used slot on exactly one chain
+    index_ok, vrep = index.validate()
+    if not index_ok:
+        raise SystemExit(f"bench.py: rank {rank}: the resident index does not validate: {vrep}")
     mappers = [api.Mapper(index, device=dev_index, method=6) for _ in range(max(1, args.streams))]
     mapper = mappers[0]
 
@@ -968,6 +973,11 @@ def main():
                        "genome": genome_desc, "ranks": {"world": world, "backend": R.backend, "share_devices": bool(R.shared),
                                  "index_bytes_per_rank": t_index.get("index_bytes_per_rank"), "broadcast_s": t_index.get("broadcast_s"),
                                  "broadcast_pieces": t_index.get("broadcast_pieces")},
+                       "index_validated": bool(index_ok),
+                       "index_validation": {"what": "UFIndex::Validate (ufindex.cpp:611-658) as one device pass over the resident table, every rank its own replica: "
+                                                    "each stored position re-hashed to its head slot, each chain followed link by link, each used slot on exactly one chain",
+                                            "slots": int(vrep["slots"]), "used_slots": int(vrep["used"]), "rows": int(vrep["heads"]),
+                                            "positions_rehashed": int(vrep["positions"]), "seconds": round(vrep["seconds"], 3)},
                        "setup_s": {"genome": round(t_gen, 1), **t_index, "total": round(setup_s, 1)}},
             # bound: the limiter the counters show (profiles/r4: the waves of the search kernels wait on memory LATENCY more than half
             # of their cycles and issue in most of the rest; traffic is a few percent of the HBM peak) -- `peak` stays the HBM peak the

@@ -109,6 +109,27 @@ void urmapx_index_close(urmapx_index *);
 
 /* bytes of GetRow_Blob's rows laid out beside the resident slot table (chain_rows.hip); 0 if they were not built */
 uint64_t urmapx_index_chain_row_bytes(const urmapx_index *);
+/* UFIndex::Validate / cmd_ufi_validate (ufindex.cpp:611-658, ufistats.cpp:141-147) as one pass over the RESIDENT table (the
+ * index must have been uploaded or wrapped on a device): every slot whose tally says "mine" heads a row; the row is collected
+ * link by link as GetRow_Validate does (ufindex.cpp:834-881: head "mine", later links "other", the middle slot of a long link
+ * TALLY_NEXT_LONG_OTHER, at most MaxIx entries), every position must lie inside the sequence store and the word that starts
+ * there must hash back to the head slot (the reference dies with "WordToSlot != Slot").  Beyond the reference's test, every
+ * slot that is not free must lie on exactly one head's chain (reached == used).  Returns URMAPX_OK for a valid table,
+ * URMAPX_E_FORMAT if any check failed (the report says which), URMAPX_E_ARG if the index is not resident. */
+typedef struct urmapx_validate_report {
+	uint64_t slots;          /* slots of the table */
+	uint64_t heads;          /* slots that head a row (tally "mine") */
+	uint64_t positions;      /* stored positions re-hashed */
+	uint64_t used;           /* slots that are not TALLY_FREE */
+	uint64_t reached;        /* slots the walks passed through (chain links and the middle slots of long links) */
+	uint64_t bad_hash;       /* positions whose word does not hash to the head slot */
+	uint64_t bad_pos;        /* positions outside the sequence store */
+	uint64_t bad_link;       /* mine / other bits, long-link middle slots or steps that break the chain rules */
+	uint64_t bad_len;        /* rows longer than MaxIx */
+	uint64_t first_bad_slot; /* lowest head slot with a failure; UINT64_MAX: none */
+	double seconds;          /* the pass on the device */
+} urmapx_validate_report;
+int urmapx_index_validate(const urmapx_index *, urmapx_validate_report *out);
 uint32_t urmapx_index_word_length(const urmapx_index *);
 uint32_t urmapx_index_max_ix(const urmapx_index *);
 uint64_t urmapx_index_slot_count(const urmapx_index *);

@@ -1,0 +1,63 @@
+"""Guards the shipped kernels' register allocation against the toolchain: the search kernels' speed rests
+on how many waves fit a SIMD and on how little they spill, and a compiler bump or a changed flag can move both silently.
+
+The figures are read out of the gfx950 code objects inside the built liburmapx.so (tests/tools/kernel_meta.py: the
+NT_AMDGPU_METADATA notes), i.e. of the binary that runs on the GPU box -- nothing is recompiled.  Ceilings are what the
+round's profiled build has (profiles/r5/kernel_resources.txt), with no slack on occupancy and a little on spill counts."""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
+SO = os.path.join(ROOT, "urmap_amd", "liburmapx.so")
+
+# kernel: (min waves per SIMD, max VGPRs, max spilled VGPRs, max spilled SGPRs, max scratch bytes per lane, max LDS bytes)
+CEILINGS = {
+    "search_se_kernel<3, false, false, true>": (4, 128, 62, 240, 160, 10048),    # 150-base reads, the headline kernel
+    "search_se_kernel<4, false, false, true>": (3, 168, 14, 257, 48, 12560),     # 250-base reads
+    "search_se_kernel<2, false, false, true>": (4, 128, 33, 221, 112, 7792),     # reads of up to 128 bases
+    "search_pe_kernel<3, 0>": (3, 168, 11, 275, 52, 12864),                      # 2 x 150 pairs
+    "dp_kernel<3>": (6, 80, 0, 57, 8, 3456),
+    "dp_kernel<4>": (6, 80, 0, 57, 8, 4352),
+    "finalize_se_kernel<3, false>": (8, 64, 0, 23, 0, 4480),
+    "finalize_se_kernel<4, false>": (8, 64, 0, 23, 0, 4480),
+    "seed_probe_kernel<3>": (8, 64, 0, 0, 0, 0),
+    "validate_kernel": (8, 64, 0, 0, 0, 64),
+}
+
+
+@pytest.fixture(scope="module")
+def table():
+    import kernel_meta
+    if not os.path.exists(SO):
+        pytest.fail(f"{SO} is missing: run __graft_entry__.build() first")
+    return kernel_meta.kernel_table(SO)
+
+
+@pytest.mark.parametrize("kernel", sorted(CEILINGS))
+def test_shipped_kernel_stays_inside_its_recorded_resources(table, kernel):
+    assert kernel in table, f"{kernel} is not in liburmapx.so; it holds: {sorted(k for k in table if k.split('<')[0] == kernel.split('<')[0])}"
+    waves, vgpr, vspill, sspill, scratch, lds = CEILINGS[kernel]
+    r = table[kernel]
+    assert r["waves_per_simd"] >= waves, (kernel, r)
+    assert r["vgpr"] + r["agpr"] <= vgpr, (kernel, r)
+    assert r["vgpr_spill"] <= vspill, (kernel, r)
+    assert r["sgpr_spill"] <= sspill, (kernel, r)
+    assert r["scratch"] <= scratch, (kernel, r)
+    assert r["lds"] <= lds, (kernel, r)
+
+
+def test_every_kernel_of_the_library_is_a_wave64_gfx950_kernel(table):
+    assert len(table) >= 60
+    for k, r in table.items():
+        assert r["max_threads"] % 64 == 0 or r["max_threads"] <= 64, (k, r)
+
+
+def test_lds_per_block_allows_the_occupancy_the_registers_allow(table):
+    """160 KB of LDS per CU, 4 SIMDs: blocks of one wave need waves_per_simd * 4 * lds <= 160 KB"""
+    for k in ("search_se_kernel<3, false, false, true>", "search_pe_kernel<3, 0>", "search_se_kernel<4, false, false, true>"):
+        r = table[k]
+        assert r["max_threads"] == 64
+        assert r["waves_per_simd"] * 4 * r["lds"] <= 160 * 1024, (k, r)

@@ -26,7 +26,7 @@ assert RESULT_DTYPE.itemsize == 28
 
 EXPORTS = (
     "urmapx_params_for_method", "urmapx_index_open", "urmapx_index_wrap_host", "urmapx_index_wrap_device",
-    "urmapx_index_upload", "urmapx_index_replicate", "urmapx_index_close", "urmapx_index_chain_row_bytes", "urmapx_index_word_length", "urmapx_index_max_ix",
+    "urmapx_index_upload", "urmapx_index_replicate", "urmapx_index_close", "urmapx_index_chain_row_bytes", "urmapx_index_validate", "urmapx_index_word_length", "urmapx_index_max_ix",
     "urmapx_index_slot_count", "urmapx_index_seqdata_size", "urmapx_index_seq_count", "urmapx_index_label",
     "urmapx_index_seq_length", "urmapx_index_seq_offset", "urmapx_ctx_create", "urmapx_ctx_destroy",
     "urmapx_map_se", "urmapx_map_se_device", "urmapx_ctx_sync", "urmapx_ctx_last_kernel_ms",
@@ -61,6 +61,11 @@ class MapReport(C.Structure):
                 ("write_threads", C.c_int), ("text_on_device", C.c_int), ("input_bytes", C.c_uint64), ("medium", C.c_char * 24),
                 ("dev_h2d_s", C.c_double), ("dev_parse_s", C.c_double), ("dev_map_s", C.c_double), ("dev_format_s", C.c_double),
                 ("dev_d2h_s", C.c_double), ("shards", C.c_int)]
+
+
+class ValidateReport(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("slots", "heads", "positions", "used", "reached", "bad_hash", "bad_pos", "bad_link", "bad_len",
+                                          "first_bad_slot")] + [("seconds", C.c_double)]
 
 
 class TextReport(C.Structure):
@@ -104,6 +109,7 @@ def lib():
         f = getattr(L, "urmapx_index_" + name)
         f.restype = rt
         f.argtypes = [vp]
+    L.urmapx_index_validate.argtypes = [vp, C.POINTER(ValidateReport)]
     L.urmapx_index_label.restype = cp
     L.urmapx_index_label.argtypes = [vp, u32]
     L.urmapx_index_seq_length.restype = u32
@@ -266,6 +272,14 @@ class Index:
         return Index(h.value, keep=(self,))
 
     def chain_row_bytes(self): return int(lib().urmapx_index_chain_row_bytes(self.h))
+
+    def validate(self):
+        """UFIndex::Validate (ufindex.cpp:611-658) as one device pass over the resident table -> (ok, report dict)."""
+        r = ValidateReport()
+        rc = lib().urmapx_index_validate(self.h, C.byref(r))
+        if rc not in (0, E_FORMAT):
+            raise UrmapxError(rc, "urmapx_index_validate")
+        return rc == 0, {n: getattr(r, n) for n, _ in ValidateReport._fields_}
 
     @property
     def word_length(self): return lib().urmapx_index_word_length(self.h)

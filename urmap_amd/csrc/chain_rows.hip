@@ -137,4 +137,117 @@ hipError_t build_chain_rows(const uint8_t *d_blob, uint64_t slot_count, uint32_t
 	return hipSuccess;
 }
 
+
+// ---- UFIndex::Validate (ufindex.cpp:611-658) over a resident table ----
+// ValidateSlot for every slot, one thread per slot: a slot whose tally says "mine" heads a row; GetRow_Validate
+// (ufindex.cpp:834-881) collects the row's positions link by link (the head must be "mine", every later link "other", a long
+// link's middle slot TALLY_NEXT_LONG_OTHER, at most MaxIx entries), every position must lie inside the sequence store and the
+// word that starts there (GetWord, ufindex.cpp:68-81) must hash back to the head slot (WordToSlot, ufindex.h:60-65).  Beyond
+// the reference's test: the slots the walks pass through are counted, and every slot that is not free must lie on exactly one
+// head's chain -- `reached` == `used` (a table with a lost or doubly linked slot fails that, whatever its positions hash to).
+struct ValidateCounters {  // u64 each; mirrors urmapx_validate_report from `heads` on
+	unsigned long long heads, positions, used, reached, bad_hash, bad_pos, bad_link, bad_len, first_bad_slot;
+};
+static constexpr int VC_WORDS = 9;
+
+__device__ __forceinline__ uint64_t word_at(const uint8_t *__restrict__ seq, uint32_t pos, uint32_t W) {  // GetWord
+	uint64_t w = 0;
+	for (uint32_t i = 0; i < W; ++i) {
+		const uint32_t L = letter_of(seq[(size_t)pos + i]);
+		if (L > 3u) return ~0ull;
+		w = (w << 2) | L;
+	}
+	return w;
+}
+
+__global__ __launch_bounds__(256) void validate_kernel(DevIndex X, unsigned long long *__restrict__ out, uint32_t groups) {
+	__shared__ unsigned long long acc[VC_WORDS - 1];
+	if (threadIdx.x < VC_WORDS - 1) acc[threadIdx.x] = 0;
+	__syncthreads();
+	unsigned long long heads = 0, positions = 0, used = 0, reached = 0, bad_hash = 0, bad_pos = 0, bad_link = 0, bad_len = 0;
+	unsigned long long first_bad = ~0ull;
+	const uint64_t N = X.slotCount;
+	for (uint32_t g = blockIdx.x; g < groups; g += gridDim.x) {
+		const uint64_t head = (uint64_t)g * 256 + threadIdx.x;
+		if (head >= N) continue;
+		uint32_t T, pos;
+		load_slot(X.blob, head, T, pos);
+		if (T != TALLY_FREE) ++used;
+		if ((T & TALLY_MY_BIT) == 0) continue;  // TallyOther: GetRow_Validate returns 0
+		++heads;
+		uint64_t slot = head;
+		uint32_t K = 0;
+		bool bad = false;
+		for (;;) {
+			++reached;
+			uint32_t p = pos;
+			const bool single = T == TALLY_PLUS1 || T == TALLY_BOTH1;
+			const bool is_long = T == TALLY_LONG_MINE || T == TALLY_LONG_OTHER;
+			++K;
+			uint64_t next = slot;
+			bool stop = single || K == X.maxIx;
+			if (single && slot != head) { ++bad_link; bad = true; }
+			if (!stop) {
+				if ((slot == head) != ((T & TALLY_MY_BIT) != 0)) { ++bad_link; bad = true; }
+				if (T == TALLY_END) stop = true;
+				else if (is_long) {
+					const uint64_t slotA = addmod(slot, pos & 0xFFFFu, N);
+					next = addmod(slotA, pos >> 16, N);
+					uint32_t tA, pA;
+					load_slot(X.blob, slotA, tA, pA);
+					p = pA;
+					++reached;
+					if (tA != TALLY_LONG_OTHER) { ++bad_link; bad = true; }
+				} else {
+					const uint32_t step = T & TALLY_NEXT_MASK;
+					if (step == 0 || step > 124u) { ++bad_link; bad = true; stop = true; }  // TALLY_FREE in a chain
+					next = addmod(slot, step, N);
+				}
+			}  // (K == MaxIx on a long link: GetRow_Validate returns before it resolves the link, PosVec[K-1] stays the step word)
+			++positions;
+			if (p >= X.seqDataSize) { ++bad_pos; bad = true; }
+			else if (mod_slots(murmur64(word_at(X.seq, p, X.W)), N, X.slotMagic) != head) { ++bad_hash; bad = true; }
+			if (stop) break;
+			if (K >= 256u) { ++bad_len; bad = true; break; }  // only with a header whose MaxIx is 0 or beyond what a tally can count
+			slot = next;
+			load_slot(X.blob, slot, T, pos);
+		}
+		if (K > X.maxIx) { ++bad_len; bad = true; }
+		if (bad && head < first_bad) first_bad = head;
+	}
+	atomicAdd(&acc[0], heads); atomicAdd(&acc[1], positions); atomicAdd(&acc[2], used); atomicAdd(&acc[3], reached);
+	atomicAdd(&acc[4], bad_hash); atomicAdd(&acc[5], bad_pos); atomicAdd(&acc[6], bad_link); atomicAdd(&acc[7], bad_len);
+	if (first_bad != ~0ull) atomicMin(out + 8, first_bad);
+	__syncthreads();
+	if (threadIdx.x < VC_WORDS - 1 && acc[threadIdx.x]) atomicAdd(out + threadIdx.x, acc[threadIdx.x]);
+}
+
+// out[9]: heads, positions, used, reached, bad_hash, bad_pos, bad_link, bad_len, first_bad_slot (all ones: none)
+hipError_t validate_index(const DevIndex &X, uint64_t out[9], float *ms) {
+	unsigned long long *d = nullptr;
+	hipError_t e = hipMalloc((void **)&d, VC_WORDS * 8);
+	if (e != hipSuccess) return e;
+	unsigned long long init[VC_WORDS] = {0, 0, 0, 0, 0, 0, 0, 0, ~0ull};
+	e = hipMemcpy(d, init, sizeof init, hipMemcpyHostToDevice);
+	const uint64_t groups = (X.slotCount + 255) / 256;
+	hipEvent_t a = nullptr, b = nullptr;
+	if (e == hipSuccess) e = hipEventCreate(&a);
+	if (e == hipSuccess) e = hipEventCreate(&b);
+	if (e == hipSuccess && groups <= 0xFFFFFFFFull) {
+		(void)hipEventRecord(a, nullptr);
+		// (more slots than a launch has work-items: the blocks loop over the groups)
+		hipLaunchKernelGGL(validate_kernel, dim3((unsigned)(groups < 65536 ? groups : 65536)), dim3(256), 0, nullptr, X, d, (uint32_t)groups);
+		e = hipGetLastError();
+		(void)hipEventRecord(b, nullptr);
+	} else if (e == hipSuccess)
+		e = hipErrorInvalidValue;
+	if (e == hipSuccess) e = hipMemcpy(init, d, sizeof init, hipMemcpyDeviceToHost);
+	if (e == hipSuccess && ms) (void)hipEventElapsedTime(ms, a, b);
+	for (int i = 0; i < VC_WORDS; ++i) out[i] = init[i];
+	if (a) (void)hipEventDestroy(a);
+	if (b) (void)hipEventDestroy(b);
+	(void)hipFree(d);
+	return e;
+}
+
 }  // namespace urx

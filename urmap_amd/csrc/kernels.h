@@ -154,6 +154,10 @@ hipError_t launch_search_pe_slow(const DevIndex &X, const urmapx_params &P, cons
 hipError_t build_chain_rows(const uint8_t *d_blob, uint64_t slot_count, uint32_t max_ix, uint32_t **d_info, uint64_t **d_base, uint32_t **d_rows,
                             uint64_t *total_rows);
 
+// UFIndex::Validate (ufindex.cpp:611-658) over the resident table: out[9] = heads, positions, used slots, slots reached by the
+// walks, bad hashes, bad positions, bad links, bad row lengths, first bad head slot (all ones: none); ms: the pass on the device
+hipError_t validate_index(const DevIndex &X, uint64_t out[9], float *ms);
+
 hipError_t launch_viterbi_batch(const urmapx_params &P, const uint8_t *d_a, const uint32_t *d_aoffs,
                                 const uint8_t *d_b, const uint32_t *d_boffs, const uint8_t *d_flags, uint32_t n,
                                 float *d_scores, uint8_t *d_status, urmapx_path_op *d_ops, uint16_t *d_nops,

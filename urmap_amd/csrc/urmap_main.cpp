@@ -5,6 +5,7 @@
 //   urmap -make_ufi genome.fa -output index.ufi [-slots N] [-wordlength W] [-maxix M] [-veryfast] [-gpu D | -host]
 //
 //   urmap -map2 R1.fq -reverse R2.fq -ufi index.ufi -samout out.sam [-tabbedout out.tab]   (paired-end, map2.cpp:39-90)
+//   urmap -ufi_validate index.ufi [-gpu D]                                                   (ufistats.cpp:141-147, on the device)
 //
 // Pipeline of -map: one reader thread parses FASTQ into batches; batch b goes to mapping lane b mod (N*K), a host
 // thread with its own mapping context on GPU D + (b mod N) (-gpus N devices, each holding its own replica of the index,
@@ -49,7 +50,7 @@ using namespace urx;
 }
 
 struct Opts {
-	std::string map, map2, reverse, make_ufi, ufi, samout, tabbedout, output, log;
+	std::string map, map2, reverse, make_ufi, ufi, ufi_validate, samout, tabbedout, output, log;
 	bool veryfast = false, quiet = false, minq_given = false, host_build = false, notrunclabels = false;
 	double load_factor = 0.6;  // myopts.h: FLT_OPT(load_factor, 0.6, ...)
 	unsigned threads = 0, wordlength = 24, maxix = 0, minq = 10;
@@ -72,6 +73,7 @@ static Opts parse(int argc, char **argv) {
 		else if (a == "-reverse") o.reverse = val();
 		else if (a == "-make_ufi") o.make_ufi = val();
 		else if (a == "-ufi") o.ufi = val();
+		else if (a == "-ufi_validate") o.ufi_validate = val();
 		else if (a == "-samout") o.samout = val();
 		else if (a == "-tabbedout") o.tabbedout = val();
 		else if (a == "-output") o.output = val();
@@ -276,14 +278,39 @@ static int cmd_make_ufi(const Opts &o) {
 	return 0;
 }
 
+// cmd_ufi_validate (ufistats.cpp:141-147): FromFile + UFIndex::Validate (ufindex.cpp:611-658), the pass itself on the device
+static int cmd_ufi_validate(const Opts &o) {
+	urmapx_index *I = nullptr;
+	check(urmapx_index_open(o.ufi_validate.c_str(), &I), ("Reading index " + o.ufi_validate).c_str());
+	setenv("URMAPX_NO_CHAIN_ROWS", "1", 0);  // the pass reads the table itself; the derived row layout is not needed for it
+	check(urmapx_index_upload(I, o.gpu), "index upload");
+	urmapx_validate_report r;
+	const int rc = urmapx_index_validate(I, &r);
+	if (rc != URMAPX_OK && rc != URMAPX_E_FORMAT) check(rc, "ufi_validate");
+	progress_log(o.quiet, "%llu slots, %llu used, %llu rows, %llu positions re-hashed in %.3f s (GPU %d)\n", (unsigned long long)r.slots,
+	             (unsigned long long)r.used, (unsigned long long)r.heads, (unsigned long long)r.positions, r.seconds, o.gpu);
+	urmapx_index_close(I);
+	if (rc == URMAPX_E_FORMAT) {
+		// the reference stops at the first failing slot with "WordToSlot != Slot" (ufindex.cpp:642) or a failed assertion
+		const char *what = r.bad_hash ? "WordToSlot != Slot" : r.bad_pos ? "Pos >= SeqDataSize" : r.bad_link ? "broken chain link" :
+		                   r.bad_len ? "row longer than MaxIx" : "used slots not all on a chain";
+		die("%s: first bad slot 0x%llx (%llu hash, %llu position, %llu link, %llu length failures; %llu slots used, %llu reached)", what,
+		    (unsigned long long)r.first_bad_slot, (unsigned long long)r.bad_hash, (unsigned long long)r.bad_pos, (unsigned long long)r.bad_link,
+		    (unsigned long long)r.bad_len, (unsigned long long)r.used, (unsigned long long)r.reached);
+	}
+	return 0;
+}
+
 int main(int argc, char **argv) {
 	setenv("OMP_WAIT_POLICY", "passive", 0);  // idle pool threads sleep: three pipeline stages share the cores
 	Opts o = parse(argc, argv);
 	log_open(o, argc, argv);
 	if (!o.map.empty() || !o.map2.empty()) { const int rc = cmd_map(o, argc, argv); log_close(); return rc; }
 	if (!o.make_ufi.empty()) { const int rc = cmd_make_ufi(o); log_close(); return rc; }
+	if (!o.ufi_validate.empty()) { const int rc = cmd_ufi_validate(o); log_close(); return rc; }
 	fprintf(stderr, "urmap (MI355X build)\n  urmap -map reads.fq -ufi index.ufi -samout out.sam [-veryfast] [-gpu D] [-gpus N] [-streams K] [-samshards N]\n"
 	                "  urmap -map2 R1.fq -reverse R2.fq -ufi index.ufi -samout out.sam [-tabbedout out.tab] [-gpu D] [-gpus N]\n"
-	                "  urmap -make_ufi genome.fa -output index.ufi [-slots N] [-wordlength W] [-maxix M]\n");
+	                "  urmap -make_ufi genome.fa -output index.ufi [-slots N] [-wordlength W] [-maxix M]\n"
+	                "  urmap -ufi_validate index.ufi [-gpu D]\n");
 	return 0;
 }

@@ -276,6 +276,22 @@ void urmapx_index_close(urmapx_index *I) {
 uint64_t urmapx_index_chain_row_bytes(const urmapx_index *I) {
 	return I && I->d_rowinfo ? 4ull * I->slotCount + 4ull * (I->n_rows + 64) + 8ull * ((I->slotCount + 1023) / 1024) : 0ull;
 }
+int urmapx_index_validate(const urmapx_index *I, urmapx_validate_report *out) {
+	if (!I || !out) return URMAPX_E_ARG;
+	memset(out, 0, sizeof *out);
+	out->first_bad_slot = ~0ull;
+	if (!I->d_blob || !I->d_seq || I->device < 0) return URMAPX_E_ARG;  // urmapx_index_upload first
+	HIP_TRY(hipSetDevice(I->device));
+	uint64_t v[9];
+	float ms = 0.f;
+	HIP_TRY(validate_index(I->view(), v, &ms));
+	out->slots = I->slotCount;
+	out->heads = v[0]; out->positions = v[1]; out->used = v[2]; out->reached = v[3];
+	out->bad_hash = v[4]; out->bad_pos = v[5]; out->bad_link = v[6]; out->bad_len = v[7]; out->first_bad_slot = v[8];
+	out->seconds = ms * 1e-3;
+	const bool ok = !v[4] && !v[5] && !v[6] && !v[7] && v[2] == v[3];
+	return ok ? URMAPX_OK : URMAPX_E_FORMAT;
+}
 uint32_t urmapx_index_word_length(const urmapx_index *I) { return I->W; }
 uint32_t urmapx_index_max_ix(const urmapx_index *I) { return I->maxIx; }
 uint64_t urmapx_index_slot_count(const urmapx_index *I) { return I->slotCount; }
