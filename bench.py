@@ -26,7 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-CODE_VERSION = "r4"    # committed PMC profiles carry the code version they were taken on (pmc_traffic)
+CODE_VERSION = "r5"    # committed PMC profiles carry the code version they were taken on (pmc_traffic)
 
 # work per read of the reference on the survey's 40 Mbp planning genome (instrumented build)
 SURVEY_WORK_PER_READ = {
@@ -274,13 +274,14 @@ def make_pairs_torch(torch, seed, d_seq, seq_lengths, seq_offsets, npairs, L, su
     return torch.stack([r1, r2], dim=1).reshape(-1).contiguous()
 
 
-def pmc_traffic(kernel, reads_per_launch, total_bp, read_len=150, mode="se", code_version=CODE_VERSION):
-    """HBM read bytes per launch of `kernel` from the committed rocprofv3 --pmc FETCH_SIZE pass of this same workload
-    (profiles/r*/pmc_fetch_*.json; bench.py cannot collect PMCs itself).  A profile counts only if it names the same
-    mode (se / pe), read length, genome size and code version; None otherwise -- no claim from a stale profile."""
+def pmc_traffic(kernel, reads_per_launch, total_bp, read_len=150, mode="se", code_version=CODE_VERSION, what="fetch"):
+    """HBM read (what="fetch") or written (what="write") bytes per launch of `kernel` from the committed rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE pass of this same workload (profiles/r*/pmc_fetch_*.json, pmc_write_*.json; bench.py cannot collect PMCs itself).  A
+    profile counts only if it names the same mode (se / pe), read length, genome size and code version; None otherwise -- no claim
+    from a stale profile."""
     import glob
     best = None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_fetch_*.json"))):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"pmc_{what}_*.json"))):
         try:
             d = json.load(open(path))
         except (OSError, ValueError):
@@ -291,7 +292,7 @@ def pmc_traffic(kernel, reads_per_launch, total_bp, read_len=150, mode="se", cod
             continue
         if abs(d.get("genome_bp", 3.1e9) - total_bp) > 0.02 * total_bp:
             continue
-        best = d["kernels"][kernel]["hbm_read_bytes_per_launch"] * reads_per_launch / d["reads_per_launch"]
+        best = d["kernels"][kernel]["hbm_read_bytes_per_launch" if what == "fetch" else "hbm_write_bytes_per_launch"] * reads_per_launch / d["reads_per_launch"]
     return None if best is None else round(best)
 
 
@@ -456,6 +457,7 @@ class Workload:
         kms = np.zeros(2)
         self.stage_ms = np.zeros(7)
         self.round_ms = None
+        self.p3_ms, self.p3_stats = np.zeros(3), np.zeros(2)
         t0 = time.perf_counter()
         for k in range(steps):
             self.step(mappers, warmup + k)
@@ -467,6 +469,9 @@ class Workload:
                     self.stage_ms += np.array(m.stage_ms()) / len(mappers)
                     rm = np.array(m.round_ms()) / len(mappers) / max(1, steps)
                     self.round_ms = rm if self.round_ms is None else self.round_ms + rm
+                    p3m, p3s = m.phase3()
+                    self.p3_ms += np.array(p3m) / len(mappers) / max(1, steps)
+                    self.p3_stats += np.array(p3s, dtype=np.float64) / max(1, steps)
         if barrier:
             barrier()
         self.stage_ms /= max(1, steps)
@@ -644,7 +649,7 @@ def e2e_bound(rep):
 
 
 E2E_STREAMS = int(os.environ.get("URMAP_BENCH_E2E_STREAMS", 2))  # mapping contexts (lanes) of the file-to-file runs
-E2E_BATCH = int(os.environ.get("URMAP_BENCH_E2E_BATCH", 0))      # reads per chunk (0: the library's default, 262144)
+E2E_BATCH = int(os.environ.get("URMAP_BENCH_E2E_BATCH", 0))      # reads per chunk (0: the library chooses: 262 144 .. 1 M by the size of the file)
 
 
 def run_e2e(torch, api, oi, index, device, d_seq, seq_lengths, seq_offsets, L, sub, indel, n_reads, cores, ref_bin=None, gpus=1):
@@ -814,7 +819,7 @@ def run_e2e_pairs(torch, api, oi, index, device, d_seq, seq_lengths, seq_offsets
             "sam_records_identical_to_oracle": bool(got == want), "sam_records_checked": len(want)}
 
 
-def kernel_table(api, pe, L, nb, kms, counters, total_bp, gather_loads_s, stage_ms=None):
+def kernel_table(api, pe, L, nb, kms, counters, total_bp, gather_loads_s, stage_ms=None, p3_ms=None):
     """Per-launch roofline figures.  Algorithmic bytes per read from the reference algorithm's own access counts
     (SURVEY.md 8d), counted by the oracle on the sample: probe kernel 5 B per GetBlob + the read; search kernel 5 B per
     chain slot + compared reference bases + the result record; DP kernel the target bases of the DP windows + the
@@ -833,8 +838,11 @@ def kernel_table(api, pe, L, nb, kms, counters, total_bp, gather_loads_s, stage_
     else:
         # single-end: seed + probe run inside the search kernel (the next read's slots are gathered into LDS while the
         # current read is searched), so its algorithmic bytes are both stages'
-        rows = [("search_se_kernel", float(stage_ms[0]), probe_bytes + 5.0 * c["n_rowhop"] + c["n_extbases"] + api.RESULT_DTYPE.itemsize)]
-        rows.append(("dp_kernel", float(stage_ms[1]), 2.0 * c["n_dptarget"]))
+        # round 5: with phase 3 parked the search stage is two launches of search_se_kernel (every read; then the reads parked at phase 3)
+        # with phase 3's dp_kernel launch between them -- the search row is the two search launches, the DP row every dp_kernel launch
+        p3_dp = float(p3_ms[1]) if p3_ms is not None and p3_ms[0] > 0 else 0.0
+        rows = [("search_se_kernel", float(stage_ms[0]) - p3_dp, probe_bytes + 5.0 * c["n_rowhop"] + c["n_extbases"] + api.RESULT_DTYPE.itemsize)]
+        rows.append(("dp_kernel", float(stage_ms[1]) + p3_dp, 2.0 * c["n_dptarget"]))
         rows.append(("finalize_se_kernel", float(stage_ms[2]), float(api.RESULT_DTYPE.itemsize)))
         rows.append(("second pass (search + dp + finalize over the reads whose lists outgrew the first)", float(sum(stage_ms[3:6])), 0.0))
         rows.append(("general kernel (reads outside the fast kernels' domain; usually none)", float(stage_ms[6]), 0.0))
@@ -846,6 +854,12 @@ def kernel_table(api, pe, L, nb, kms, counters, total_bp, gather_loads_s, stage_
              "achieved_GBs": round(ach, 2), "frac": round(ach / HBM_PEAK_GBS, 5)}
         t = pmc_traffic(name, nb, total_bp, L, "pe" if pe else "se")
         k["hbm_read_bytes_per_launch_pmc"] = t
+        k["hbm_write_bytes_per_launch_pmc"] = pmc_traffic(name, nb, total_bp, L, "pe" if pe else "se", what="write")
+        if name == "search_se_kernel" and p3_ms is not None and p3_ms[0] > 0:
+            k["launches"] = {"first (seed + probe + phases 1-2 of every read; phases 4-5 of the reads with nothing to align in phase 3)": round(float(p3_ms[0]), 4),
+                             "second (the reads parked at phase 3: replay of AlignHSP's bookkeeping, phases 4-5)": round(float(p3_ms[2]), 4)}
+        if name == "dp_kernel" and p3_dp > 0:
+            k["launches"] = {"phase 3's flank DPs": round(p3_dp, 4), "phase 6's (three rounds)": round(float(stage_ms[1]), 4)}
         if t and sector_peak > 0 and ms > 0:
             k["sector_GBs"] = round(t / (ms * 1e-3) / 1e9, 1)
             k["frac_of_random_gather_peak"] = round(k["sector_GBs"] / sector_peak, 4)
@@ -948,7 +962,7 @@ def main():
         except Exception:
             gather_loads_s = 0.0
         npl = nb // len(mappers)  # reads per launch: the batch is split over the contexts
-        kern = kernel_table(api, pe, L, npl, kms, counters, total_bp, gather_loads_s, None if pe else wl.stage_ms)
+        kern = kernel_table(api, pe, L, npl, kms, counters, total_bp, gather_loads_s, None if pe else wl.stage_ms, None if pe else wl.p3_ms)
         dom = int(np.argmax([k["avg_ms"] if not k["kernel"].startswith(("second pass", "general kernel")) else 0.0 for k in kern]))
         dp_stats = wl.dp_stats
         key = "pe150" if pe else ("se150" if L == 150 else ("se250" if L == 250 else None))
@@ -988,6 +1002,7 @@ def main():
                          "whole_step": {"alg_bytes_per_read": round(sum(k["alg_bytes_per_read"] for k in kern), 1),
                                         "achieved_GBs": round(sum(k["alg_bytes_per_read"] for k in kern) * nb / (dt / args.steps) / 1e9, 2)},
                          "traffic": kern[dom]["hbm_read_bytes_per_launch_pmc"],
+                         "write_bytes": kern[dom]["hbm_write_bytes_per_launch_pmc"],
                          "random_gather_peak": {"slot_reads_per_s": round(gather_loads_s), "sector_GBs": round(64.0 * gather_loads_s / 1e9, 1),
                                                 "note": "measured in this run: independent random 5-byte slot reads over the resident table, 64 B sector each"}},
             "kernels": kern,
@@ -1004,6 +1019,31 @@ def main():
             if wl.round_ms is not None:
                 out["phase6"]["launch_ms_by_round"] = {"rounds": "HSPs [0,2), [2,16), [16,...) of a read", "dp_kernel": [round(float(x[0]), 3) for x in wl.round_ms],
                                                        "finalize_se_kernel": [round(float(x[1]), 3) for x in wl.round_ms]}
+        if not pe and wl.p3_ms[0] > 0:
+            out["phase3"] = {"what": "Search_Lo's phase 3 (AlignHSP when the best HSP of phases 1-2 is long, search1m6.cpp:162-171) parked like phase 6: DpJobs for dp_kernel, "
+                                     "the read resumed by a second launch of the search kernel from its parked state",
+                             "reads_parked": int(round(wl.p3_stats[1])), "hsps_given_to_dp_kernel": int(round(wl.p3_stats[0])),
+                             "launch_ms": {"search_first": round(float(wl.p3_ms[0]), 3), "dp_kernel": round(float(wl.p3_ms[1]), 3), "search_second": round(float(wl.p3_ms[2]), 3)}}
+        if not pe and world == 1:
+            # The probe stage alone (north_star: "rocprof HBM GB/s on the probe kernel reported against peak"): seed_probe_kernel launched on
+            # its own over the last timed batch, OUTSIDE the timed region -- inside a mapping call the probe is a stage of search_se_kernel
+            try:
+                p0 = wl.parts[0]
+                pms = [mapper.seed_probe_device(wl.last.data_ptr() + p0["lo"] * L, p0["d_offs"].data_ptr(), p0["n"], p0["n"] * L, L) for _ in range(3)][-1]
+                palg = 5.0 * counters["n_getblob"] + L
+                ptraffic = pmc_traffic("seed_probe_kernel", p0["n"], total_bp, L, "se")
+                kmers = 2 * (L - 24 + 1)
+                sect = kmers * 64.0 * 1.0625 + L  # one 64 B sector per k-mer, 6 % of the slots straddle two
+                out["probe_only"] = {"kernel": "seed_probe_kernel", "ms": round(pms, 4), "reads": int(p0["n"]), "alg_bytes_per_read": round(palg, 1),
+                                     "achieved_GBs": round(palg * p0["n"] / (pms * 1e-3) / 1e9, 1), "frac_of_hbm_peak": round(palg * p0["n"] / (pms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                                     "sector_bytes_per_read_model": round(sect, 1), "sector_GBs_model": round(sect * p0["n"] / (pms * 1e-3) / 1e9, 1),
+                                     "hbm_read_bytes_per_launch_pmc": ptraffic,
+                                     "sector_GBs_pmc": round(ptraffic / (pms * 1e-3) / 1e9, 1) if ptraffic else None,
+                                     "frac_of_random_gather_peak": round((ptraffic if ptraffic else sect * p0["n"]) / (pms * 1e-3) / 1e9 / max(1e-9, 64.0 * gather_loads_s / 1e9), 4),
+                                     "note": "launched standalone outside the timed region: SetSlotsVec + GetBlob for every k-mer of both strands, slots / tallies / positions written to HBM "
+                                             "(13 B per k-mer, which the fused kernel keeps in LDS)"}
+            except Exception as e:
+                out["probe_only"] = {"error": str(e)[:200]}
         if key:
             out["work_per_read_survey"] = SURVEY_WORK_PER_READ[key]
         if cpu is not None:
@@ -1017,11 +1057,12 @@ def main():
                 del wl
                 torch.cuda.empty_cache()
                 wl = Workload(torch, api, device, d_seq, seq_lengths, seq_offsets, ope, oL, osub, oindel, nb, 3, 5000, streams=len(mappers))
-                odt, okms = wl.timed(mappers, 5, 1)
+                osteps, owarm = 10, 2
+                odt, okms = wl.timed(mappers, osteps, owarm)
                 opar, ocnt, ot = wl.check(oi, min(nb, 200_000), cores)
-                okern = kernel_table(api, ope, oL, npl, okms, ocnt, total_bp, gather_loads_s, None if ope else wl.stage_ms)
-                others[name] = {"metric": metric_name(ope, oL), "value": round(5 * nb / odt, 1), "unit": "reads/s", "steps": 5, "warmup": 1,
-                                "ms_per_step": round(1e3 * odt / 5, 3), "kernels": okern, "parity": opar,
+                okern = kernel_table(api, ope, oL, npl, okms, ocnt, total_bp, gather_loads_s, None if ope else wl.stage_ms, None if ope else wl.p3_ms)
+                others[name] = {"metric": metric_name(ope, oL), "value": round(osteps * nb / odt, 1), "unit": "reads/s", "steps": osteps, "warmup": owarm,
+                                "ms_per_step": round(1e3 * odt / osteps, 3), "kernels": okern, "parity": opar,
                                 "work_per_read": {k: round(v, 2) for k, v in ocnt.items()},
                                 "cpu_port_reads_per_s": round(opar["reads_checked"] / ot, 1), "cpu_port_threads": cores,
                                 "sub": osub, "indel": oindel, "wall_s": round(time.time() - t0, 1)}
@@ -1033,6 +1074,10 @@ def main():
                     if wl.round_ms is not None:
                         others[name]["phase6"]["launch_ms_by_round"] = {"dp_kernel": [round(float(x[0]), 3) for x in wl.round_ms],
                                                                         "finalize_se_kernel": [round(float(x[1]), 3) for x in wl.round_ms]}
+                if not ope and wl.p3_ms[0] > 0:
+                    others[name]["phase3"] = {"reads_parked": int(round(wl.p3_stats[1])), "hsps_given_to_dp_kernel": int(round(wl.p3_stats[0])),
+                                              "launch_ms": {"search_first": round(float(wl.p3_ms[0]), 3), "dp_kernel": round(float(wl.p3_ms[1]), 3),
+                                                            "search_second": round(float(wl.p3_ms[2]), 3)}}
             out["other_workloads"] = others
         if world == 1 and not pe and L == 150 and not args.no_e2e:
             try:
@@ -1041,7 +1086,7 @@ def main():
                 pass
             torch.cuda.empty_cache()
             out["e2e"] = run_e2e(torch, api, oi, index, device, d_seq, seq_lengths, seq_offsets, L, args.sub, args.indel,
-                                 int(os.environ.get("URMAP_BENCH_E2E_READS", 4_000_000)), cores, ref_bin=ol.REF_BIN)
+                                 int(os.environ.get("URMAP_BENCH_E2E_READS", 10_000_000)), cores, ref_bin=ol.REF_BIN)  # BASELINE config 2: 10 M reads
             rb = out["e2e"].get("reference_binary")
             if rb and "cpu_baseline" in out:  # the reference itself, timed on this host in this run
                 out["cpu_baseline"]["port_value"] = out["cpu_baseline"]["value"]

@@ -182,6 +182,14 @@ int urmapx_ctx_stage_ms(urmapx_ctx *, float ms[7]);
 /* The same call's phase-6 launches one by one (first pass): ms[2*r] = the DP launch of round r, ms[2*r+1] = the finalize
  * launch behind it; *rounds = how many rounds there are (3: HSPs [0,2), [2,16), [16,...) of a read). */
 int urmapx_ctx_round_ms(urmapx_ctx *, float ms[16], int *rounds);
+/* Round 5: phase 3 of Search_Lo (AlignHSP when the best HSP of phases 1-2 is long, search1m6.cpp:162-171) is parked like phase 6:
+ * the search stage ([0] above) is then three launches -- ms[0] the first search launch (seed + probe + phases 1-2 for every read,
+ * phases 4-5 for the reads with nothing to align in phase 3), ms[1] phase 3's flank-DP launch, ms[2] the search launch over the reads
+ * parked at phase 3 (replay of AlignHSP's bookkeeping, phases 4-5).  stats[0] = DpJobs made for phase 3, stats[1] = reads parked there.
+ * All zero when phase 3 ran inside the search kernel, which is the DEFAULT: measured at hg38 scale the three launches take 6 % longer than
+ * the one.  URMAPX_PARK_PHASE3=1 in the environment turns the parking on (reads of up to 320 bases, an index with the
+ * row layout). */
+int urmapx_ctx_phase3(urmapx_ctx *, float ms[3], uint32_t stats[2]);
 /* Statistics of the same call, per pass (4 numbers each): HSPs handed to the DP launches, reads they belong to, how many
  * of those DPs the ordered replay of AlignHSP (alignhsp.cpp:60-172) looked at, and how many were dropped before their DP
  * because the penalty cap had fallen far enough by their round. */
@@ -208,6 +216,12 @@ int urmapx_seed_probe(urmapx_ctx *, const uint8_t *bases, const uint64_t *offs, 
 int urmapx_viterbi_batch(urmapx_ctx *, const uint8_t *a, const uint32_t *a_offs, const uint8_t *b,
                          const uint32_t *b_offs, const uint8_t *flags, uint32_t n, float *scores, uint8_t *status,
                          urmapx_path_op *ops, uint16_t *nops);
+
+/* The same stage over reads already resident in HBM of the ctx's device, nothing copied back (measurement: the probe launch alone,
+ * *ms = its time on the ctx stream; inside urmapx_map_se* the probe is a stage of the search kernel).  Results stay in the context's
+ * probe arrays. */
+int urmapx_seed_probe_device(urmapx_ctx *, const void *d_bases, const void *d_offs, uint32_t n, uint64_t total_bases,
+                             uint32_t max_read_len, float *ms);
 
 /* Measurement aid (no reference counterpart): n_loads independent random 5-byte slot reads over the resident slot
  * table and nothing else -- the random-access ceiling of this table on this device, which bench.py reports next to
@@ -282,8 +296,10 @@ typedef struct urmapx_map_options {
 	int sam_shards;     /* -samshards N: the SAM text goes to N files samout.0 .. samout.N-1, shard s = the records of the s-th
 	                     * N-th of the input (cut at a record), written by its own pipeline (reader, lanes, writer) on its own
 	                     * share of the devices; the header is in shard 0, so `cat samout.0 .. samout.N-1` is byte for byte what one
-	                     * file would hold.  Plain (seekable, not .gz) input only: other input goes to shard 0 whole, the other
-	                     * shards stay empty.  -tabbedout is split the same way (tabout.0 ..).  N must divide gpus or be a multiple of it */
+	                     * file would hold.  Plain (seekable, not .gz) input only: other input is mapped by ONE
+	                     * pipeline over all the devices into shard 0, the other shards stay empty.  -tabbedout is split the same way
+	                     * (tabout.0 ..).  Needs samout (URMAPX_E_ARG without); N in 1..64 must divide gpus or be a multiple of it.  A failed
+	                     * run removes the shard files it wrote */
 	int discard_sam;    /* measurement: the SAM text is made and copied to the host, then dropped instead of written (report.medium
 	                     * "discarded"): what the device lanes sustain when the output medium is not in the way */
 } urmapx_map_options;
@@ -301,6 +317,8 @@ typedef struct urmapx_map_report {  /* State1::HitStats' counters (state1.cpp:59
 	 * SAM bytes back */
 	double dev_h2d_s, dev_parse_s, dev_map_s, dev_format_s, dev_d2h_s;
 	int shards;                                      /* SAM files written (1 unless sam_shards) */
+	double shard_scan_s;                             /* sam_shards: seconds spent cutting the input at record starts (pairs: counting the lines that
+	                                                  * place the cuts of the mates' file); inside `seconds` */
 } urmapx_map_report;
 /* fastq2 NULL: single-end (-map); else the mates' file (-map2 ... -reverse).  samout / tabout may be NULL.  The index
  * needs its host arrays, or to be resident on first_gpu already (then gpus must be 1).  Batch b is mapped on device
@@ -371,6 +389,16 @@ int64_t urmapx_fastq_next(urmapx_fastq *, uint32_t max_reads, const uint8_t **ba
                           const uint64_t **offs, const char **label_data, const uint64_t **label_offs);
 const char *urmapx_fastq_error(const urmapx_fastq *);
 void urmapx_fastq_close(urmapx_fastq *);
+
+/* ---- .gz input (host) ---- */
+/* The reference reads .gz files through zlib, one stream on one thread (linereader.cpp:54-113, gzipfileio.cpp).  urmapx_map_files
+ * cuts a gzip stream into segments that several threads inflate side by side (urmap_amd/csrc/pgzip.h: each finds a deflate block
+ * start behind its cut, decodes with the 32 KB in front of it unknown, the references into that window are filled in once the
+ * segment in front is done; every member's CRC-32 and length are checked as zlib does).  This entry point runs that reader alone:
+ * gz_path inflated to out_path, the bytes `gzip -dc` writes.  threads <= 0: all.  stats (optional): bytes written, bytes that
+ * came by the parallel road, bytes that came through zlib (small files, one thread, input the parallel decoder hands over).
+ * URMAPX_E_FORMAT: not gzip, truncated, or corrupt (what was decoded before the damage is in out_path, as with zlib). */
+int urmapx_gunzip_file(const char *gz_path, const char *out_path, int threads, uint64_t stats[3]);
 
 const char *urmapx_strerror(int code);
 /* "gfx950" etc. of the ctx's device; NULL without a device */

@@ -3,7 +3,7 @@ on how many waves fit a SIMD and on how little they spill, and a compiler bump o
 
 The figures are read out of the gfx950 code objects inside the built liburmapx.so (tests/tools/kernel_meta.py: the
 NT_AMDGPU_METADATA notes), i.e. of the binary that runs on the GPU box -- nothing is recompiled.  Ceilings are what the
-round's profiled build has (profiles/r5/kernel_resources.txt), with no slack on occupancy and a little on spill counts."""
+round's profiled build has (profiles/r5/kernel_resources.txt), with no slack on occupancy and about 5 % on spill counts."""
 import os
 import sys
 
@@ -15,14 +15,16 @@ SO = os.path.join(ROOT, "urmap_amd", "liburmapx.so")
 
 # kernel: (min waves per SIMD, max VGPRs, max spilled VGPRs, max spilled SGPRs, max scratch bytes per lane, max LDS bytes)
 CEILINGS = {
-    "search_se_kernel<3, false, false, true>": (4, 128, 62, 240, 160, 10048),    # 150-base reads, the headline kernel
-    "search_se_kernel<4, false, false, true>": (3, 168, 14, 257, 48, 12560),     # 250-base reads
-    "search_se_kernel<2, false, false, true>": (4, 128, 33, 221, 112, 7792),     # reads of up to 128 bases
-    "search_pe_kernel<3, 0>": (3, 168, 11, 275, 52, 12864),                      # 2 x 150 pairs
-    "dp_kernel<3>": (6, 80, 0, 57, 8, 3456),
-    "dp_kernel<4>": (6, 80, 0, 57, 8, 4352),
-    "finalize_se_kernel<3, false>": (8, 64, 0, 23, 0, 4480),
-    "finalize_se_kernel<4, false>": (8, 64, 0, 23, 0, 4480),
+    "search_se_kernel<3, false, false, true, 0>": (4, 128, 66, 255, 168, 10048),  # 150-base reads, the headline kernel (phase 3 inline)
+    "search_se_kernel<4, false, false, true, 0>": (3, 168, 14, 272, 48, 12560),   # 250-base reads
+    "search_se_kernel<2, false, false, true, 0>": (4, 128, 30, 236, 112, 7792),   # reads of up to 128 bases
+    "search_se_kernel<3, false, false, true, 1>": (4, 128, 12, 260, 48, 10048),   # URMAPX_PARK_PHASE3=1: first launch (no banded DP inside)
+    "search_se_kernel<3, false, false, true, 2>": (4, 120, 0, 150, 0, 10048),     # ... second launch (the reads parked at phase 3)
+    "search_pe_kernel<3, 0>": (3, 168, 12, 296, 52, 12864),                       # 2 x 150 pairs
+    "dp_kernel<3>": (6, 80, 0, 65, 8, 3456),
+    "dp_kernel<4>": (6, 80, 0, 65, 8, 4352),
+    "finalize_se_kernel<3, false>": (8, 64, 0, 24, 0, 4480),
+    "finalize_se_kernel<4, false>": (8, 64, 0, 24, 0, 4480),
     "seed_probe_kernel<3>": (8, 64, 0, 0, 0, 0),
     "validate_kernel": (8, 64, 0, 0, 0, 64),
 }
@@ -57,7 +59,7 @@ def test_every_kernel_of_the_library_is_a_wave64_gfx950_kernel(table):
 
 def test_lds_per_block_allows_the_occupancy_the_registers_allow(table):
     """160 KB of LDS per CU, 4 SIMDs: blocks of one wave need waves_per_simd * 4 * lds <= 160 KB"""
-    for k in ("search_se_kernel<3, false, false, true>", "search_pe_kernel<3, 0>", "search_se_kernel<4, false, false, true>"):
+    for k in ("search_se_kernel<3, false, false, true, 0>", "search_pe_kernel<3, 0>", "search_se_kernel<4, false, false, true, 0>"):
         r = table[k]
         assert r["max_threads"] == 64
         assert r["waves_per_simd"] * 4 * r["lds"] <= 160 * 1024, (k, r)

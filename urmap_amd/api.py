@@ -30,9 +30,9 @@ EXPORTS = (
     "urmapx_index_slot_count", "urmapx_index_seqdata_size", "urmapx_index_seq_count", "urmapx_index_label",
     "urmapx_index_seq_length", "urmapx_index_seq_offset", "urmapx_ctx_create", "urmapx_ctx_destroy",
     "urmapx_map_se", "urmapx_map_se_device", "urmapx_ctx_sync", "urmapx_ctx_last_kernel_ms",
-    "urmapx_seed_probe", "urmapx_viterbi_batch", "urmapx_strerror", "urmapx_device_arch",
-    "urmapx_make_ufi", "urmapx_make_ufi_opts", "urmapx_build_slots", "urmapx_make_ufi_gpu", "urmapx_build_slots_gpu", "urmapx_sam_se", "urmapx_sam_header_sq", "urmapx_ctx_phase_cycles", "urmapx_ctx_read_cycles", "urmapx_ctx_stage_ms", "urmapx_ctx_round_ms", "urmapx_ctx_dp_stats", "urmapx_map_pe", "urmapx_sam_pe", "urmapx_map_pe_device", "urmapx_ctx_set_pe_veryfast",
-    "urmapx_fastq_open", "urmapx_fastq_next", "urmapx_fastq_error", "urmapx_fastq_close",
+    "urmapx_seed_probe", "urmapx_seed_probe_device", "urmapx_viterbi_batch", "urmapx_strerror", "urmapx_device_arch",
+    "urmapx_make_ufi", "urmapx_make_ufi_opts", "urmapx_build_slots", "urmapx_make_ufi_gpu", "urmapx_build_slots_gpu", "urmapx_sam_se", "urmapx_sam_header_sq", "urmapx_ctx_phase_cycles", "urmapx_ctx_read_cycles", "urmapx_ctx_stage_ms", "urmapx_ctx_phase3", "urmapx_ctx_round_ms", "urmapx_ctx_dp_stats", "urmapx_map_pe", "urmapx_sam_pe", "urmapx_map_pe_device", "urmapx_ctx_set_pe_veryfast",
+    "urmapx_gunzip_file", "urmapx_fastq_open", "urmapx_fastq_next", "urmapx_fastq_error", "urmapx_fastq_close",
     "urmapx_ctx_gather_microbench", "urmapx_map_files", "urmapx_host_pool_trim", "urmapx_text_create", "urmapx_text_destroy", "urmapx_text_map_se", "urmapx_text_map_pe", "urmapx_text_fetch_sam", "urmapx_text_fetch_pairs", "urmapx_ctx_set_pair_info", "urmapx_ctx_get_pair_info", "urmapx_tab_pe",
 )
 
@@ -60,7 +60,7 @@ class MapReport(C.Structure):
                 ("format_s", C.c_double), ("write_s", C.c_double), ("host_threads", C.c_int), ("lanes", C.c_int),
                 ("write_threads", C.c_int), ("text_on_device", C.c_int), ("input_bytes", C.c_uint64), ("medium", C.c_char * 24),
                 ("dev_h2d_s", C.c_double), ("dev_parse_s", C.c_double), ("dev_map_s", C.c_double), ("dev_format_s", C.c_double),
-                ("dev_d2h_s", C.c_double), ("shards", C.c_int)]
+                ("dev_d2h_s", C.c_double), ("shards", C.c_int), ("shard_scan_s", C.c_double)]
 
 
 class ValidateReport(C.Structure):
@@ -130,7 +130,9 @@ def lib():
     L.urmapx_ctx_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float * 2)]
     L.urmapx_ctx_phase_cycles.argtypes = [vp, C.POINTER(C.c_uint64 * 12)]
     L.urmapx_ctx_read_cycles.argtypes = [vp, vp, u32]
+    L.urmapx_seed_probe_device.argtypes = [vp, vp, vp, u32, u64, u32, C.POINTER(C.c_float)]
     L.urmapx_ctx_stage_ms.argtypes = [vp, C.POINTER(C.c_float * 7)]
+    L.urmapx_ctx_phase3.argtypes = [vp, C.POINTER(C.c_float * 3), C.POINTER(C.c_uint32 * 2)]
     L.urmapx_ctx_round_ms.argtypes = [vp, C.POINTER(C.c_float * 16), C.POINTER(C.c_int)]
     L.urmapx_ctx_dp_stats.argtypes = [vp, C.POINTER(C.c_uint32 * 8)]
     L.urmapx_seed_probe.argtypes = [vp, vp, vp, u32, vp, vp, vp]
@@ -366,6 +368,15 @@ class Index:
             pass
 
 
+def gunzip_file(gz_path, out_path, threads=0):
+    """the .gz reader of urmapx_map_files alone (pgzip.h) -> (bytes written, by the parallel road, through zlib)"""
+    L = lib()
+    L.urmapx_gunzip_file.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.POINTER(C.c_uint64 * 3)]
+    st = (C.c_uint64 * 3)()
+    _check(L.urmapx_gunzip_file(os.fsencode(gz_path), os.fsencode(out_path), threads, C.byref(st)), f"urmapx_gunzip_file({gz_path})")
+    return int(st[0]), int(st[1]), int(st[2])
+
+
 def map_files(index: "Index", fastq1, fastq2=None, samout=None, tabout=None, first_gpu=0, gpus=1, streams=2, host_threads=0,
               batch=0, veryfast=False, minq=10, cmdline=None, allow_unsupported=False, sam_shards=0, discard_sam=False):
     """urmap -map / -map2 file to file (cmd_map / cmd_map2) on an index that has its host arrays or is resident on
@@ -460,6 +471,20 @@ class Mapper:
         ms = (C.c_float * 7)()
         _check(lib().urmapx_ctx_stage_ms(self.h, C.byref(ms)), "urmapx_ctx_stage_ms")
         return [float(x) for x in ms]
+
+    def seed_probe_device(self, d_bases_ptr, d_offs_ptr, n, total_bases, max_read_len):
+        """the probe launch alone over reads resident in HBM -> its ms on the context's stream"""
+        ms = C.c_float(0)
+        _check(lib().urmapx_seed_probe_device(self.h, d_bases_ptr, d_offs_ptr, n, total_bases, max_read_len, C.byref(ms)), "urmapx_seed_probe_device")
+        return float(ms.value)
+
+    def phase3(self):
+        """The search stage of the last single-end device call when phase 3 is parked (round 5): ms of the first search launch, of
+        phase 3's DP launch and of the launch over the reads parked at phase 3; DpJobs made for phase 3, reads parked there."""
+        ms = (C.c_float * 3)()
+        st = (C.c_uint32 * 2)()
+        _check(lib().urmapx_ctx_phase3(self.h, C.byref(ms), C.byref(st)), "urmapx_ctx_phase3")
+        return [float(x) for x in ms], [int(x) for x in st]
 
     def round_ms(self):
         """ms of the first pass's phase-6 launches one by one: [(dp, finalize) per round]"""

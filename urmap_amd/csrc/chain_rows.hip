@@ -125,6 +125,9 @@ hipError_t build_chain_rows(const uint8_t *d_blob, uint64_t slot_count, uint32_t
 	uint64_t total = 0;
 	for (uint64_t g = 0; g < groups; ++g) { hb[g] = total; total += hs[g]; }
 	(void)hipFree(gsum); gsum = nullptr;
+	// a row's place is kept as a 32-bit index into `rows` with 0xFFFFFFFF as the "single entry" mark (SearchWave::rows_fetch); no
+	// index the reference can build gets there (positions are 32 bit, each stored once), but nothing else enforced it
+	if (total >= 0xFFFFFFFFull) { drop(); return hipSuccess; }
 	if (hipMalloc((void **)&rows, (total + 64) * 4) != hipSuccess) { drop(); return hipSuccess; }
 	e = hipMemcpy(base, hb.data(), groups * 8, hipMemcpyHostToDevice);
 	if (e == hipSuccess) {

@@ -76,7 +76,12 @@ static constexpr uint32_t DP_ROUND_LO[DP_ROUNDS + 1] = {0u, 2u, 16u, 0xFFFFFFFFu
 static constexpr int DP_TICKET_WORDS = 16;  // per pass: [rd] work counter of round rd, [8 + rd] length of its job list
 static_assert(DP_ROUNDS <= 8, "DP_TICKET_WORDS");
 static constexpr int DP_JOB_OPS = URMAPX_MAX_PATH_OPS;  // ops slice per job
-static constexpr int STAGE_EVENTS = 4 + 4 * DP_ROUNDS;   // SearchWork::stage_events
+// SearchWork::stage_events: [0] start, [1] search end (with phase 3 parked: the end of the resume launch), {dp end, finalize end} x DP_ROUNDS,
+// second search end, {dp end, finalize end} x DP_ROUNDS, [STAGE_LAST] after the general kernel (recorded by the caller); then the two stamps
+// inside the search stage when phase 3 is parked: [STAGE_P3_MAIN] end of the first search launch, [STAGE_P3_DP] end of phase 3's DP launch
+static constexpr int STAGE_LAST = 3 + 4 * DP_ROUNDS;
+static constexpr int STAGE_P3_MAIN = STAGE_LAST + 1, STAGE_P3_DP = STAGE_LAST + 2;
+static constexpr int STAGE_EVENTS = STAGE_LAST + 3;
 
 struct DpWork {
 	DpJob *jobs = nullptr;          // jobs_cap entries
@@ -91,6 +96,7 @@ struct DpWork {
 	uint32_t fin_cap = 0;
 };
 size_t dp_state_words(bool ovf);
+size_t p3_state_words(uint32_t max_read_len);
 
 // workspace of the persistent search kernels: per-block global scratch (+ optional diagnostics buffer)
 struct SearchWork {
@@ -99,14 +105,20 @@ struct SearchWork {
 	size_t scratch_stride;  // search_scratch_stride(max_read_len)
 	int blocks;             // search_block_count(max_read_len, device)
 	uint32_t *ticket;       // device word: work counter of the launch (zeroed by the launcher)
+	uint32_t *ticket3 = nullptr;  // one more word: work counter of the launch over the reads parked at phase 3
 	int hsp_lds_cap = 0;    // 0 = default; test aid (URMAPX_TEST_HSP_LDS_CAP) to exercise the HSP overflow list
 	uint32_t *ovf_list = nullptr;  // device: [0] = count, [1..n] = reads queued for the second pass
 	DpWork dp[2];                  // [0] first pass, [1] second pass; jobs == nullptr: phase 6 stays inside the search kernel
+	// Round 5: phase 3 (AlignHSP when the best HSP of phases 1-2 is long, search1m6.cpp:162-171) parked the same way: the first
+	// launch ends a read there, dp_kernel runs the flank DPs, and a second launch of the search kernel (PART 2) takes the read up
+	// again -- replay of AlignHSP's bookkeeping, then phases 4-6 -- from its parked state: hits, scalars, top path, the HSP list and
+	// the read's slot entries (p3_state_words(nch) words per read).  jobs == nullptr: phase 3 stays inside the search kernel.
+	DpWork dp3;
 	uint8_t *dp_scratch = nullptr; // dp_kernel's wide-band scratch: dp_blocks * dp_scratch_stride bytes
 	size_t dp_scratch_stride = 0;
 	int dp_blocks = 0;
 	int fin_blocks = 0;            // grid of finalize_se_kernel (0: the search kernel's)
-	hipEvent_t *stage_events = nullptr;  // optional, STAGE_EVENTS of them: start, search end, {dp end, finalize end} x DP_ROUNDS, second search end, {dp end, finalize end} x DP_ROUNDS; the caller records the last one after the general kernel
+	hipEvent_t *stage_events = nullptr;  // optional, STAGE_EVENTS of them (see STAGE_LAST above)
 };
 size_t dp_scratch_stride(uint32_t max_read_len);
 int dp_block_count(uint32_t max_read_len, int device);

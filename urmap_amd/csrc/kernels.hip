@@ -500,9 +500,18 @@ struct SearchWave {
 		return len - hscore <= maxPen;
 	}
 
-	// One DpJob per HSP that phase 6 would align, the read's state parked for finalize_se_kernel.  false: nothing to
-	// align, or no room left in the job array / the parking lot -- the caller then runs phase 6 itself.
-	__device__ bool park_for_dp(const DpWork &dp, uint32_t r, int phase) {
+	// Round 5: a read parked at PHASE 3 takes more with it than one parked at phase 6 -- it has phases 4-6 still to run: behind the
+	// STATE_WORDS of park_state lie its HSP list (P3_HSP entries at most: the HSPs of phases 1-2 come from unique seeds, a handful per
+	// read) and its slot entries (the pr_* arrays: what the probe gathered for it), so that the second launch neither hashes nor
+	// probes again.
+	static constexpr int P3_HSP = 128;
+	static constexpr int P3_WORDS = STATE_WORDS + 2 * P3_HSP + 3 * NSEG * 64 + 2 * NSEG;
+
+	// One DpJob per HSP that phase 6 (P3: phase 3) would align, the read's state parked for finalize_se_kernel (P3: for the
+	// search kernel's second launch).  1: parked; 0: nothing to align; -1: no room left in the job array / the parking lot (P3:
+	// or an HSP list beyond what a parked read carries) -- the caller then runs the phase itself, or hands the read to the second pass.
+	template <bool P3 = false>
+	__device__ int park_for_dp(const DpWork &dp, uint32_t r, int phase) {
 		const int lane = fresh_lane(this->lane);  // dev_common.h: lane-derived values are remade here, not carried (and spilled) from the top of the kernel
 		int njobs = 0;
 		bool clipped = false;
@@ -516,11 +525,12 @@ struct SearchWave {
 			clipped |= want && (uint64_t)(sdb - (pk & PK_MASK)) + (uint64_t)QL + 2ull * P.band_radius >= (uint64_t)X.seqDataSize;
 		}
 #ifdef URX_DP_PAIR
-		if (__ballot(clipped) != 0) return false;
+		if (__ballot(clipped) != 0) return -1;
 #else
 		(void)clipped;
 #endif
-		if (njobs == 0) return false;
+		if (njobs == 0) return 0;
+		if (P3 && (hspCount > hsp_lds || hspCount > P3_HSP)) return -1;
 		uint32_t jb = 0, slot = 0;
 		if (lane == 0) jb = atomicAdd(dp.counters, (uint32_t)njobs);
 		jb = uni(jb);
@@ -532,7 +542,7 @@ struct SearchWave {
 		}
 		if (!room) {  // the slots taken stay unused
 			for (uint32_t i = jb + lane; i < dp.jobs_cap && i - jb < (uint32_t)njobs; i += 64) { dp.jobs[i].read = 0xFFFFFFFFu; dp.kidx[i] = 0xFFFFu; }
-			return false;
+			return -1;
 		}
 		int w = 0;
 		for (int base = 0; base < hspCount; base += 64) {
@@ -552,8 +562,55 @@ struct SearchWave {
 		}
 		if (njobs > 0xFFFF) status |= URMAPX_ST_HSP_OVERFLOW;  // cannot happen: the HSP list holds at most 8192
 		if (lane == 0) *reinterpret_cast<uint4 *>(dp.fin_list + 4 * (size_t)slot) = make_uint4(r, jb, (uint32_t)njobs, (uint32_t)QL);
-		park_state(dp.state + (size_t)slot * STATE_WORDS, phase);
-		return true;
+		uint32_t *const st = dp.state + (size_t)slot * (P3 ? P3_WORDS : STATE_WORDS);
+		park_state(st, phase);
+		if constexpr (P3) {
+			// AlignHSP marks an HSP aligned before it tests it (alignhsp.cpp:62-70): every HSP of the list is, after phase 3
+			uint32_t *const hx = st + STATE_WORDS;
+			for (int i = lane; i < hspCount; i += 64) { hx[i] = hsp_db[i]; hx[P3_HSP + i] = hsp_pk[i] | PK_ALIGNED; }
+			uint32_t *const px = hx + 2 * P3_HSP;
+#pragma unroll
+			for (int g = 0; g < NSEG; ++g)
+				if (64 * (g % NCH) < nwords) {
+					px[g * 64 + lane] = pr_lo[g * 64 + lane];
+					px[(NSEG + g) * 64 + lane] = pr_hi[g * 64 + lane];
+					px[(2 * NSEG + g) * 64 + lane] = pr_sl[g * 64 + lane];
+				}
+			if (lane < NSEG) reinterpret_cast<uint64_t *>(px + 3 * NSEG * 64)[lane] = pr_hb[lane];
+		}
+		return 1;
+	}
+
+	// phase 3 found nothing to align: its HSPs are marked all the same (alignhsp.cpp:62-70 sets m_Aligned before the penalty test)
+	__device__ __forceinline__ void mark_all_aligned() {
+		const int nl = hspCount < hsp_lds ? hspCount : hsp_lds;
+		for (int i = lane; i < nl; i += 64) hsp_pk[i] |= PK_ALIGNED;
+		for (int i = hsp_lds + lane; i < hspCount; i += 64) hsp_ovf[i - hsp_lds].y |= PK_ALIGNED;
+		URX_SYNC();
+	}
+
+	// A read parked at phase 3 comes back (search kernel, PART 2): slot entries by LDS-DMA (contiguous rows of 64 words), the
+	// state of restore_state, the HSP list.  Returns the phase it was parked in (3).
+	__device__ int resume3(uint32_t *st) {
+		const int lane = fresh_lane(this->lane);
+		const uint32_t *const hx = st + STATE_WORDS;
+		const uint32_t *const px = hx + 2 * P3_HSP;
+		wait_lgkm0();  // every earlier LDS read of the pr_* arrays has returned
+#pragma unroll
+		for (int g = 0; g < NSEG; ++g)
+			if (64 * (g % NCH) < nwords) {
+				glds_dword(px + g * 64 + lane, lds_addr(pr_lo + g * 64));
+				glds_dword(px + (NSEG + g) * 64 + lane, lds_addr(pr_hi + g * 64));
+				glds_dword(px + (2 * NSEG + g) * 64 + lane, lds_addr(pr_sl + g * 64));
+			}
+		uint64_t hb = 0;
+		if (lane < NSEG) hb = reinterpret_cast<const uint64_t *>(px + 3 * NSEG * 64)[lane];
+		const int phase = restore_state(st);
+		for (int i = lane; i < hspCount; i += 64) { hsp_db[i] = hx[i]; hsp_pk[i] = hx[P3_HSP + i]; }
+		if (lane < NSEG) pr_hb[lane] = hb;
+		wait_vm0();
+		URX_SYNC();
+		return phase;
 	}
 
 	__device__ void park_state(uint32_t *st, int phase) {
@@ -759,7 +816,11 @@ struct SearchWave {
 				const uint64_t hb = stage_b[2 * g], ok = stage_b[2 * g + 1];
 				const bool v = (ok >> lane) & 1ull;
 				const uint32_t sl = stage_sl[g * 64 + lane];
+#ifdef URX_FAULT_SLOT32  // fault injection for the test suite's own check (profiles/r5/fault_slot32.txt): the slot number cut to 32 bits
+				const uint64_t slot = (uint64_t)sl; (void)hb;
+#else
 				const uint64_t slot = (uint64_t)sl | (((hb >> lane) & 1ull) << 32);
+#endif
 				pr_sl[g * 64 + lane] = v ? sl : 0u;
 				if (lane == 0) pr_hb[g] = hb;
 				const uint8_t *ap = v ? gblob + ((5ull * slot) & ~3ull) : reinterpret_cast<const uint8_t *>(g_zero16);
@@ -910,7 +971,12 @@ struct SearchWave {
 // cycle counts and schedule cuts (stop after step 1 / 3 / 4; 100 = setup and output only; 104 = up to the chain walks).
 // The production instantiation (DBG = false) contains none of that code.
 // ROWS: the chain rows come out of the layout built with the index (rows_fetch) instead of being walked hop by hop
-template <int NCH, bool OVF, bool DBG, bool ROWS = false>
+// PART (round 5): 0 = the whole of phases 1-5 with phase 3's alignments inline (the second pass, the diagnostic build, indexes
+// without the row layout); 1 = the same, but a read whose phase 3 has something to align is PARKED there (DpJobs for dp_kernel,
+// state for PART 2) and a read that finds no room for its phase-6 jobs goes to the second pass -- no banded DP in this kernel;
+// 2 = the second launch: the reads PART 1 parked at phase 3, from the replay of AlignHSP's bookkeeping over their jobs onwards
+// (phases 4-5, then parked for phase 6 like any other read).  n = the batch's reads (PART 2: read from dp3's counter).
+template <int NCH, bool OVF, bool DBG, bool ROWS = false, int PART = 0>
 __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel(DevIndex X, urmapx_params P, const uint8_t *__restrict__ bases,
                                                        const uint64_t *__restrict__ offs, uint32_t n,
                                                        urmapx_result *__restrict__ results,
@@ -919,7 +985,8 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
                                                        const uint8_t *__restrict__ g_seq, const uint8_t *__restrict__ g_blob,
                                                        const uint4 *__restrict__ g_seqp,
                                                        uint32_t *ticket, int hsp_lds_cap, uint32_t *ovf_list, uint2 *hsp_ovf_base,
-                                                       DpWork dp) {
+                                                       DpWork dp, DpWork dp3) {
+	static_assert(PART == 0 || (!OVF && !DBG), "phase 3 is parked by the production first pass only");
 	// stats != nullptr (URMAPX_PHASE_STATS): per-phase shader cycles are accumulated into stats (u64 each, from byte 8)
 	using SW = SearchWave<NCH, OVF>;
 	constexpr int NQ_BYTES = ((SW::QMAX + 4 + 255) / 256) * 256;  // the next read's bytes from a 4-byte aligned address on, in 256-byte DMA pieces
@@ -936,6 +1003,8 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 	static_assert(2 * OPS_CAP + URMAPX_MAX_PATH_OPS + (SW::QMAX + 64) / 2 <= 2 * SW::NSEG * 64 + 2, "alias");
 	uint16_t *const ropsL = pre, *const ropsR = pre + OPS_CAP, *const cand = pre + 2 * OPS_CAP;
 	uint8_t *const sT = reinterpret_cast<uint8_t *>(pre + 2 * OPS_CAP + URMAPX_MAX_PATH_OPS);  // AlignHSP's target window
+	// viterbi_wave<B_LDS> wants band_radius + 1 bytes of this block's LDS in front of the window (viterbi_dev.h): it lies inside `pre`
+	static_assert((2 * OPS_CAP + URMAPX_MAX_PATH_OPS) * 2 >= 64, "AlignHSP's window must not start near LDS offset 0");
 	__shared__ uint32_t hsp_db[HSP_CAP], hsp_pk[HSP_CAP];
 	// candidate queue (ring): reference position, query position | plus << 14 | second phase << 15
 	__shared__ __attribute__((aligned(8))) uint32_t cq_db[128];
@@ -981,6 +1050,11 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 		n = ovf_list[0];  // how many reads the first pass flagged (usually none: then no block asks the ticket counter)
 		if (n == 0) return;
 	}
+	if constexpr (PART == 2) {
+		n = dp3.counters[1] < dp3.fin_cap ? dp3.counters[1] : dp3.fin_cap;  // the reads the first launch parked at phase 3
+		if (n == 0) return;
+	}
+	const uint4 *const fin3 = reinterpret_cast<const uint4 *>(dp3.fin_list);
 	uint32_t r_next = 0, r_end = 0;
 	auto take = [&](uint32_t &ri) -> bool {  // the next read of this block; false: the batch is used up
 		if (r_next == r_end) {
@@ -1013,12 +1087,20 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 	uint32_t r = 0;
 	uint64_t off = 0;
 	int QL = 0;
+	uint32_t p3_e = 0, p3_jb = 0, p3_nj = 0;  // PART 2: this read's place in the parking lot, its phase-3 jobs
 	for (;;) {
 		uint32_t rn = 0;
 		const bool have_next = take(rn);
 		uint64_t noff = 0;
 		int nQL = 0;
-		if (have_next) { noff = offs[rn]; nQL = (int)(offs[rn + 1] - noff); }
+		uint32_t n_e = 0, n_jb = 0, n_nj = 0;
+		if constexpr (PART == 2) {
+			if (have_next) {
+				const uint4 ent = fin3[rn];
+				n_e = rn; rn = uni(ent.x); n_jb = uni(ent.y); n_nj = uni(ent.z);
+				noff = offs[rn]; nQL = (int)uni(ent.w);
+			}
+		} else if (have_next) { noff = offs[rn]; nQL = (int)(offs[rn + 1] - noff); }
 		const bool next_ok = have_next && len_ok(nQL);
 		const int nmis = (int)(reinterpret_cast<uintptr_t>(bases + noff) & 3);
 		const bool cur_ok = have_cur && len_ok(QL);
@@ -1090,6 +1172,35 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 			lapc(0);
 		}
 		int nwords = QL - (W - 1);
+		if constexpr (PART == 2) {
+			if (cur_ok) {
+				// back from the parking lot: state, HSP list and slot entries, then AlignHSP's bookkeeping (alignhsp.cpp:60-172) over the
+				// jobs dp_kernel ran, in HSP order against the cap as it falls -- what finalize_se_kernel does for phase 6
+				phase = S.resume3(dp3.state + (size_t)p3_e * SW::P3_WORDS);
+				for (uint32_t k0 = 0; k0 < p3_nj; k0 += 64) {
+					const uint32_t k = k0 + (uint32_t)lane;
+					uint32_t jpk = 0;
+					uint4 jw = make_uint4(0u, 0u, 0u, 0u);
+					if (k < p3_nj) {
+						const uint32_t *jp = reinterpret_cast<const uint32_t *>(dp3.jobs + p3_jb + k);
+						jpk = jp[2];
+						jw = *reinterpret_cast<const uint4 *>(jp + 4);
+					}
+					const int nt = (int)(p3_nj - k0 < 64u ? p3_nj - k0 : 64u);
+					for (int t = 0; t < nt; ++t) {
+						DpJob J;
+						J.read = r; J.startdb = 0; J.maxpen = 0; J.k = 0; J.pad[0] = J.pad[1] = 0;
+						J.pk = rdlane(jpk, t);
+						J.combined_tlo = rdlane(jw.x, t);
+						const uint32_t sc = rdlane(jw.y, t), fl = rdlane(jw.z, t);
+						J.left_score = (int16_t)(sc & 0xFFFFu); J.right_score = (int16_t)(sc >> 16);
+						J.nops = (uint8_t)(fl & 0xFFu); J.flags = (uint8_t)((fl >> 8) & 0xFFu); J.vst_l = (uint8_t)((fl >> 16) & 0xFFu); J.vst_r = (uint8_t)(fl >> 24);
+						S.consume_job(J, dp3.ops + (size_t)(p3_jb + k0 + (uint32_t)t) * DP_JOB_OPS);
+					}
+				}
+				if (S.best >= QL + P.xphase1 * P.mismatch_score) done = true;  // search1m6.cpp:170-171
+			}
+		}
 		const int minScore1 = QL + P.xphase1 * P.mismatch_score;
 		const int minScore3 = QL + P.xphase3 * P.mismatch_score;
 		const int minScore4 = QL + P.xphase4 * P.mismatch_score;
@@ -1107,7 +1218,7 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 		int rl[SW::NSEG];
 #pragma unroll
 		for (int g = 0; g < SW::NSEG; ++g) rl[g] = 0;
-		for (int step = cur_ok ? 1 : 5;;) {
+		for (int step = (cur_ok && PART != 2) ? 1 : 5;;) {
 			QL = fresh_uniform(QL);  // see dev_common.h: keeps the length-dependent masks out of the SGPR spill lanes
 			S.QL = QL; nwords = QL - (W - 1); S.nwords = nwords;
 			lane = fresh_lane(lane); S.lane = lane;
@@ -1121,7 +1232,7 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 				uint64_t wsl[SW::NSEG];
 				uint32_t wT[SW::NSEG], wps[SW::NSEG];
 				bool wact[SW::NSEG];
-				if (next_ok) {
+				if (PART != 2 && next_ok) {  // (PART 2: the next read's slot entries come out of its parked state)
 					if (!fetched) fetch_bytes(noff, nQL);
 					wait_vm0();
 					URX_SYNC();
@@ -1129,7 +1240,8 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 					URX_SYNC();
 				}
 				if (go) S.walk_heads(wsl, wT, wps, wact);
-				if (next_ok) S.probe_gather(nQL, stage_sl, stage_b);
+				if (PART != 2 && next_ok) S.probe_gather(nQL, stage_sl, stage_b);
+				if (PART == 2 && next_ok && !fetched) { fetch_bytes(noff, nQL); fetched = true; }
 				if (!go) break;
 				if constexpr (ROWS) S.rows_fetch(wsl, wT, wps, wact, rl);
 				else S.walk_run(wsl, wT, wps, wact, rl);
@@ -1141,8 +1253,28 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 			}
 			phase = step;
 			if (step == 3 || step == 6) {
+				if constexpr (PART != 0) {
+					// no banded DP in this kernel: the alignments of phase 3 and of phase 6 are DpJobs.  A read whose lists have
+					// outgrown the first pass's is mapped again by the second pass whatever happens here.
+					if (S.status & (URMAPX_ST_HSP_OVERFLOW | URMAPX_ST_HIT_OVERFLOW)) {
+						if (step == 6) break;
+						done = true;
+					} else if (step == 6) {
+						const int rc = S.template park_for_dp<false>(dp, r, 6);
+						if (rc > 0) parked = true;
+						else if (rc < 0) S.status |= URMAPX_ST_HSP_OVERFLOW;  // no room for its jobs: the second pass (which aligns inline) maps it
+						break;
+					} else if (S.bestHSP > termHSP3) {
+						const int rc = S.template park_for_dp<true>(dp3, r, 3);
+						if (rc > 0) { parked = true; done = true; }
+						else if (rc < 0) { S.status |= URMAPX_ST_HSP_OVERFLOW; done = true; }
+						else S.mark_all_aligned();
+					}
+					step = 5;
+					continue;
+				} else {
 				if (step == 6 && !OVF && (S.status & (URMAPX_ST_HSP_OVERFLOW | URMAPX_ST_HIT_OVERFLOW))) break;  // the second pass maps this read again
-				if (step == 6 && dp.jobs != nullptr && S.park_for_dp(dp, r, 6)) { parked = true; break; }
+				if (step == 6 && dp.jobs != nullptr && S.park_for_dp(dp, r, 6) > 0) { parked = true; break; }
 				if (step == 6 || S.bestHSP > termHSP3) {
 					for (int k = 0; k < S.hspCount; ++k) S.align_hsp(k);
 					if (step == 3 && S.best >= minScore1) done = true;
@@ -1151,6 +1283,7 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 				if (step == 6) break;
 				step = 5;
 				continue;
+				}
 			}
 			int cnt[2 * SW::NSEG];
 #pragma unroll
@@ -1339,6 +1472,7 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 		}
 		if (!have_next) break;
 		have_cur = true; r = rn; off = noff; QL = nQL;
+		p3_e = n_e; p3_jb = n_jb; p3_nj = n_nj;
 	}
 }
 
@@ -1639,6 +1773,7 @@ __global__ __launch_bounds__(64) URX_DP_ATTR void dp_kernel(DevIndex X, urmapx_p
 	// first; adding any other LDS array to this kernel changed that and one tiny flank's score with it.
 	__shared__ __attribute__((aligned(16))) uint8_t sQT[QMAX + QMAX + 64];
 	uint8_t *const sQ = sQT, *const sT = sQT + QMAX;
+	static_assert(QMAX >= 64, "the window lies band_radius + 1 bytes or more inside sQT (viterbi_dev.h: B_LDS)");
 #if URX_DP_TB_GLOBAL  // the trace cells in the block's global scratch: LDS per block 7 -> 1.2 KB (+ the wide path's rows)
 	uint32_t *const tb = reinterpret_cast<uint32_t *>(scratch + (size_t)blockIdx.x * scratch_stride +
 	                                                  ((WideScratch::bytes(QMAX, QMAX + 64) + 255) & ~(size_t)255));
@@ -1711,7 +1846,7 @@ __global__ __launch_bounds__(64) URX_DP_ATTR void dp_kernel(DevIndex X, urmapx_p
 	}
 	if (tile >= nlist) break;
 	uint32_t jl = 0xFFFFFFFFu;
-	if (lane < (int)DP_TILE && tile + lane < nlist) jl = list[tile + lane];
+	if (lane < (int)DP_TILE && tile + lane < nlist) jl = list ? list[tile + lane] : tile + (uint32_t)lane;  // no list: every job made (phase 3's)
 	uint64_t todo = __ballot(jl != 0xFFFFFFFFu);
 	while (todo) {
 		const uint32_t j = rdlane(jl, __builtin_ctzll(todo));
@@ -2002,6 +2137,11 @@ __global__ __launch_bounds__(64) URX_FIN_ATTR void finalize_se_kernel(DevIndex X
 }
 
 size_t dp_state_words(bool ovf) { return ovf ? (size_t)SearchWave<3, true>::STATE_WORDS : (size_t)SearchWave<3, false>::STATE_WORDS; }
+// words of a read parked at phase 3 (0: this read-length class keeps phase 3 inline)
+size_t p3_state_words(uint32_t max_read_len) {
+	return max_read_len <= 128 ? (size_t)SearchWave<2, false>::P3_WORDS : max_read_len <= 192 ? (size_t)SearchWave<3, false>::P3_WORDS :
+	       max_read_len <= 256 ? (size_t)SearchWave<4, false>::P3_WORDS : max_read_len <= 320 ? (size_t)SearchWave<5, false>::P3_WORDS : 0;
+}
 size_t dp_scratch_stride(uint32_t max_read_len) {
 	const int qmax = 64 * (max_read_len <= 128 ? 2 : max_read_len <= 192 ? 3 : max_read_len <= 256 ? 4 : max_read_len <= 320 ? 5 : max_read_len <= 512 ? 8 : 16);
 	// the wide-band rows and trace bytes, then room for the narrow band's trace cells (URX_DP_TB_GLOBAL: dp_kernel keeps them here
@@ -2036,10 +2176,10 @@ int search_block_count(uint32_t max_read_len, int device) {
 	if (hipGetDeviceProperties(&prop, device) != hipSuccess) return 0;
 	int per_cu = 0;
 	const int nchq = nch_for(max_read_len);
-	hipError_t e = nchq == 2   ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, search_se_kernel<2, false, false>, 64, 0)
-	               : nchq == 3 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, search_se_kernel<3, false, false>, 64, 0)
-	               : nchq == 4 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, search_se_kernel<4, false, false>, 64, 0)
-	               : nchq == 5 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, search_se_kernel<5, false, false>, 64, 0)
+	hipError_t e = nchq == 2   ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, search_se_kernel<2, false, false, true>, 64, 0)
+	               : nchq == 3 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, search_se_kernel<3, false, false, true>, 64, 0)
+	               : nchq == 4 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, search_se_kernel<4, false, false, true>, 64, 0)
+	               : nchq == 5 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, search_se_kernel<5, false, false, true>, 64, 0)
 	               : nchq == 8 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, search_se_kernel<8, false, false>, 64, 0)
 	                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, search_se_kernel<16, false, false>, 64, 0);
 	if (e != hipSuccess || per_cu < 1) per_cu = 8;
@@ -2186,6 +2326,7 @@ hipError_t launch_search_se(const DevIndex &X, const urmapx_params &P, const uin
 	const int nch = nch_for(max_read_len);
 	{
 		hipError_t e = hipMemsetAsync(wk.ticket, 0, 8, s);  // two words: the first pass's ticket counter and the second pass's
+		if (e == hipSuccess && wk.ticket3) e = hipMemsetAsync(wk.ticket3, 0, 4, s);  // the work counter of the launch over the reads parked at phase 3
 		if (e != hipSuccess) return e;
 	}
 	if (wk.stats) {
@@ -2202,8 +2343,13 @@ hipError_t launch_search_se(const DevIndex &X, const urmapx_params &P, const uin
 	auto stamp = [&](int i) { if (wk.stage_events) (void)hipEventRecord(wk.stage_events[i], s); };
 	if (wk.dp[0].jobs && wk.dp[1].jobs && wk.dp[1].counters == wk.dp[0].counters + 4 && wk.dp[0].tickets == wk.dp[0].counters + 16 &&
 	    wk.dp[1].tickets == wk.dp[0].tickets + DP_TICKET_WORDS) {
-		// both passes' counters and work counters are one block of the work buffer's head (urmapx.hip): one fill, not four
-		hipError_t e = hipMemsetAsync(wk.dp[0].counters, 0, 64 + 2 * 4 * DP_TICKET_WORDS, s);
+		// both passes' counters and work counters (and phase 3's behind them) are one block of the work buffer's head (urmapx.hip): one fill
+		const bool with3 = wk.dp3.jobs && wk.dp3.counters == wk.dp[0].counters + 8 && wk.dp3.tickets == wk.dp[0].tickets + 2 * DP_TICKET_WORDS;
+		hipError_t e = hipMemsetAsync(wk.dp[0].counters, 0, 64 + (with3 ? 3 : 2) * 4 * DP_TICKET_WORDS, s);
+		if (e == hipSuccess && wk.dp3.jobs && !with3) {
+			e = hipMemsetAsync(wk.dp3.counters, 0, 16, s);
+			if (e == hipSuccess) e = hipMemsetAsync(wk.dp3.tickets, 0, 4 * DP_TICKET_WORDS, s);
+		}
 		if (e != hipSuccess) return e;
 	} else
 		for (int pass = 0; pass < 2; ++pass)
@@ -2215,11 +2361,27 @@ hipError_t launch_search_se(const DevIndex &X, const urmapx_params &P, const uin
 #define URX_LAUNCH_SE(NCH_, OVF_, DBG_, GRID_, STATS_, OVFBASE_, DP_)                                                             \
 	hipLaunchKernelGGL((search_se_kernel<NCH_, OVF_, DBG_>), GRID_, block, 0, s, X, P, d_bases, d_offs, n, d_results,                \
 	                   d_path_ops, d_path_used, STATS_, wk.scratch, wk.scratch_stride, X.seq, X.blob, X.seqp,                    \
-	                   wk.ticket + ((OVF_) ? 1 : 0), wk.hsp_lds_cap, wk.ovf_list, OVFBASE_, DP_)
+	                   wk.ticket + ((OVF_) ? 1 : 0), wk.hsp_lds_cap, wk.ovf_list, OVFBASE_, DP_, no_dp)
 #define URX_LAUNCH_SE_ROWS(NCH_, GRID_, STATS_, OVFBASE_, DP_)                                                                      \
 	hipLaunchKernelGGL((search_se_kernel<NCH_, false, false, true>), GRID_, block, 0, s, X, P, d_bases, d_offs, n, d_results,          \
 	                   d_path_ops, d_path_used, STATS_, wk.scratch, wk.scratch_stride, X.seq, X.blob, X.seqp, wk.ticket,         \
-	                   wk.hsp_lds_cap, wk.ovf_list, OVFBASE_, DP_)
+	                   wk.hsp_lds_cap, wk.ovf_list, OVFBASE_, DP_, no_dp)
+	// phase 3 parked (round 5): the first launch (PART 1: no banded DP inside), phase 3's flank DPs (every job made, no round lists),
+	// the second launch over the reads parked there (PART 2; wk.ticket + 2: a work counter of its own)
+#define URX_LAUNCH_SE_P3(NCH_)                                                                                                      \
+	do {                                                                                                                            \
+	hipLaunchKernelGGL((search_se_kernel<NCH_, false, false, true, 1>), grid, block, 0, s, X, P, d_bases, d_offs, n, d_results,       \
+	                   d_path_ops, d_path_used, no_stats3, wk.scratch, wk.scratch_stride, X.seq, X.blob, X.seqp, wk.ticket,          \
+	                   wk.hsp_lds_cap, wk.ovf_list, no_ovf, wk.dp[0], wk.dp3);                                                       \
+	stamp(STAGE_P3_MAIN);                                                                                                           \
+	hipLaunchKernelGGL((dp_kernel<NCH_>), dim3((unsigned)wk.dp_blocks), block, 0, s, X, P, d_bases, d_offs, wk.dp3,                   \
+	                   wk.dp_scratch, wk.dp_scratch_stride, X.seq, 0u, 0xFFFFFFFFu, wk.dp3.tickets, (const uint32_t *)nullptr,       \
+	                   wk.dp3.counters);                                                                                             \
+	stamp(STAGE_P3_DP);                                                                                                             \
+	hipLaunchKernelGGL((search_se_kernel<NCH_, false, false, true, 2>), grid, block, 0, s, X, P, d_bases, d_offs, n, d_results,       \
+	                   d_path_ops, d_path_used, no_stats3, wk.scratch, wk.scratch_stride, X.seq, X.blob, X.seqp, wk.ticket3,         \
+	                   wk.hsp_lds_cap, wk.ovf_list, no_ovf, wk.dp[0], wk.dp3);                                                       \
+	} while (0)
 	// phase 6 of the reads a pass parked: their flank DPs, then the ordered part
 #define URX_LAUNCH_DP(NCH_, OVF_, PASS_)                                                                                          \
 	do { /* the second pass is a few reads with many jobs each, usually none at all: smaller grids for the launches that go by reads */ \
@@ -2239,7 +2401,14 @@ hipError_t launch_search_se(const DevIndex &X, const urmapx_params &P, const uin
 	} } while (0)
 	stamp(0);
 	const bool diag = wk.stats != nullptr && (nch == 3 || nch == 4);  // diagnostic instantiations: 150 / 250 bp classes, phase 6 inline
-	if (diag && nch == 3) URX_LAUNCH_SE(3, false, true, grid, wk.stats, no_ovf, no_dp);
+	uint32_t *const no_stats3 = nullptr;
+	// phase 3 parked: reads of up to 320 bases on an index with the row layout, phase 6 as launches of its own (the default)
+	const bool p3 = !diag && wk.dp3.jobs && wk.dp[0].jobs && wk.dp_blocks > 0 && X.rowinfo && nch <= 5 && wk.stats == nullptr;
+	if (p3 && nch == 2) URX_LAUNCH_SE_P3(2);
+	else if (p3 && nch == 3) URX_LAUNCH_SE_P3(3);
+	else if (p3 && nch == 4) URX_LAUNCH_SE_P3(4);
+	else if (p3) URX_LAUNCH_SE_P3(5);
+	else if (diag && nch == 3) URX_LAUNCH_SE(3, false, true, grid, wk.stats, no_ovf, no_dp);
 	else if (diag) URX_LAUNCH_SE(4, false, true, grid, wk.stats, no_ovf, no_dp);
 	else if (nch == 2 && X.rowinfo) URX_LAUNCH_SE_ROWS(2, grid, wk.stats, no_ovf, wk.dp[0]);  // the chain rows are looked up in the layout built with the index
 	else if (nch == 3 && X.rowinfo) URX_LAUNCH_SE_ROWS(3, grid, wk.stats, no_ovf, wk.dp[0]);
@@ -2253,6 +2422,7 @@ hipError_t launch_search_se(const DevIndex &X, const urmapx_params &P, const uin
 	else if (nch == 5) URX_LAUNCH_SE(5, false, false, grid, wk.stats, no_ovf, wk.dp[0]);
 	else if (nch == 8) URX_LAUNCH_SE(8, false, false, grid, wk.stats, no_ovf, wk.dp[0]);
 	else URX_LAUNCH_SE(16, false, false, grid, wk.stats, no_ovf, wk.dp[0]);
+	if (!p3) { stamp(STAGE_P3_MAIN); stamp(STAGE_P3_DP); }
 	stamp(1);
 	if (wk.dp[0].jobs && !diag) {
 		if (nch == 2) URX_LAUNCH_DP(2, false, 0);
@@ -2290,6 +2460,7 @@ hipError_t launch_search_se(const DevIndex &X, const urmapx_params &P, const uin
 		for (int i = 0; i < 2 * DP_ROUNDS; ++i) stamp(3 + 2 * DP_ROUNDS + i);
 #undef URX_LAUNCH_SE
 #undef URX_LAUNCH_SE_ROWS
+#undef URX_LAUNCH_SE_P3
 #undef URX_LAUNCH_DP
 	return hipGetLastError();
 }

@@ -915,6 +915,7 @@ __global__ __launch_bounds__(64, TIER == 2 ? 1 : URX_PE_WAVES(NCH)) void search_
 	static_assert(ALIGN_BYTES + 3 * QMAX * 4 <= sizeof(seed_area), "alias");
 	uint16_t *const ropsL = reinterpret_cast<uint16_t *>(seed_area), *const ropsR = ropsL + OPS_CAP, *const cand = ropsR + OPS_CAP;
 	uint8_t *const sT = reinterpret_cast<uint8_t *>(cand + URMAPX_MAX_PATH_OPS);
+	static_assert((2 * OPS_CAP + URMAPX_MAX_PATH_OPS) * 2 >= 64, "AlignHSP's window lies band_radius + 1 bytes or more inside seed_area (viterbi_dev.h: B_LDS)");
 	uint32_t *const wide_lds = seed_area + ALIGN_BYTES / 4;
 	constexpr int WIDE_LDS_DWORDS = (int)(sizeof(seed_area) - ALIGN_BYTES) / 4;
 	static_assert(2 * QMAX + 66 * 2 <= sizeof(seed_q), "alias");

@@ -16,6 +16,7 @@
 // ends the text phase; the host reader continues at that chunk's first byte with the line count kept, so '\r', blank
 // lines and malformed records get the reference's handling and messages.
 #include <fcntl.h>
+#include <functional>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <sys/vfs.h>
@@ -23,6 +24,8 @@
 #include <omp.h>
 #include <unistd.h>
 #include <zlib.h>
+
+#include "pgzip.h"
 
 #include <algorithm>
 #include <atomic>
@@ -378,13 +381,12 @@ uint64_t find_record_start(int fd, uint64_t from, uint64_t fsize) {
 
 
 // A FASTQ input read front to back as uncompressed bytes: a plain file, or a gzip file (linereader.cpp:14-113 reads .gz
-// through zlib) inflated on the fly.  gzip members are inflated one after the other by the calling thread; a BGZF file
-// (gzip members of <= 64 KB that carry their compressed size in a 'BC' extra field, the bgzip / htslib convention) is
-// inflated a batch of blocks at a time by all of the caller's OpenMP threads.
+// through zlib) inflated on the fly.  A plain gzip stream is cut into segments that the caller's OpenMP threads inflate side by
+// side (pgzip.h, round 5; one zlib stream on one thread until then); a BGZF file (gzip members of <= 64 KB that carry their
+// compressed size in a 'BC' extra field, the bgzip / htslib convention) is inflated a batch of blocks at a time by the same threads.
 class SeqSource {
 public:
 	~SeqSource() {
-		if (zs_init_) inflateEnd(&zs_);
 		for (z_stream &z : bz_) inflateEnd(&z);
 		if (fd_ >= 0 && own_) ::close(fd_);
 	}
@@ -405,12 +407,8 @@ public:
 		unsigned char h[18];
 		if (pread(fd_, h, sizeof h, 0) != (ssize_t)sizeof h || h[0] != 0x1f || h[1] != 0x8b) return false;
 		bgzf_ = (h[3] & 4) && h[12] == 'B' && h[13] == 'C' && h[14] == 2 && h[15] == 0;
-		cbuf_.resize(bgzf_ ? (32u << 20) : (4u << 20));
-		if (!bgzf_) {
-			memset(&zs_, 0, sizeof zs_);
-			if (inflateInit2(&zs_, 15 + 32) != Z_OK) return false;
-			zs_init_ = true;
-		}
+		if (bgzf_) cbuf_.resize(32u << 20);
+		else if (!pg_.open(fd_, csize_)) return false;  // plain gzip: segments of the one stream inflated side by side (pgzip.h)
 		return true;
 	}
 	bool is_gz() const { return gz_; }
@@ -449,8 +447,15 @@ public:
 			cpos_ += n;
 			return n;
 		}
-		return bgzf_ ? read_bgzf(dst, cap, threads) : read_gzip(dst, cap);
+		if (bgzf_) return read_bgzf(dst, cap, threads);
+		const size_t k = pg_.read(dst, cap, gz_threads_ > 0 ? gz_threads_ : threads);
+		if (pg_.failed()) bad_ = true;
+		if (k == 0) eof_ = true;
+		return k;
 	}
+	// plain gzip: the inflater is what the run waits for -- it may use more threads than the readers of a plain file get
+	void set_gz_threads(int t) { gz_threads_ = t; }
+	uint64_t gz_parallel_bytes() const { return pg_.parallel_bytes(); }
 
 private:
 	bool refill() {  // more compressed bytes behind what cbuf_ still holds
@@ -464,36 +469,6 @@ private:
 			got = true;
 		}
 		return got;
-	}
-	size_t read_gzip(char *dst, size_t cap) {
-		size_t out = 0;
-		while (out < cap) {
-			if (cbeg_ == chave_ && !refill()) {
-				if (!bad_ && !member_done_) bad_ = true;  // the file ends inside a member
-				eof_ = true;
-				break;
-			}
-			if (member_done_ && seen_member_) {
-				// behind a complete member: another member continues the text; anything else (zero padding, trailing garbage) ends
-				// the input, as zlib's gzread treats it (gz_look) -- the reference and the host reader read such a file to its end
-				if (chave_ - cbeg_ < 2) (void)refill();
-				if (chave_ - cbeg_ < 2 || cbuf_[cbeg_] != 0x1f || cbuf_[cbeg_ + 1] != 0x8b) { eof_ = true; break; }
-			}
-			zs_.next_in = cbuf_.data() + cbeg_;
-			zs_.avail_in = (uInt)(chave_ - cbeg_);
-			zs_.next_out = (Bytef *)dst + out;
-			zs_.avail_out = (uInt)std::min<size_t>(cap - out, 1u << 30);
-			const uInt out0 = zs_.avail_out;
-			const int rc = inflate(&zs_, Z_NO_FLUSH);
-			cbeg_ = chave_ - zs_.avail_in;
-			out += out0 - zs_.avail_out;
-			member_done_ = false;
-			if (rc == Z_STREAM_END) {  // the next member, if any, continues the text (gzread does the same)
-				member_done_ = true; seen_member_ = true;
-				if (inflateReset(&zs_) != Z_OK) { bad_ = true; break; }
-			} else if (rc != Z_OK && rc != Z_BUF_ERROR) { bad_ = true; break; }
-		}
-		return out;
 	}
 	size_t read_bgzf(char *dst, size_t cap, int threads) {
 		struct Blk { size_t in, in_len, out, out_len; };
@@ -544,11 +519,12 @@ private:
 		return out;
 	}
 	int fd_ = -1;
-	bool gz_ = false, bgzf_ = false, eof_ = false, bad_ = false, zs_init_ = false, member_done_ = true, seen_member_ = false, pipe_ = false, own_ = true;
+	bool gz_ = false, bgzf_ = false, eof_ = false, bad_ = false, pipe_ = false, own_ = true;
 	uint64_t csize_ = 0, cpos_ = 0;  // compressed (or plain) file: size, next byte to fetch
 	std::vector<uint8_t> cbuf_;
 	size_t cbeg_ = 0, chave_ = 0;
-	z_stream zs_;
+	ParallelGunzip pg_;
+	int gz_threads_ = 0;
 	std::vector<z_stream> bz_;
 };
 
@@ -591,18 +567,24 @@ struct InputRange {
 	bool on = false;
 	uint64_t lo[2] = {0, 0}, hi[2] = {0, 0};
 	uint64_t lines_before = 0;  // lines of each file in front of lo (they name the line in the reader's messages)
+	// single-end shards: the lines in front of lo are counted only if a message needs a line number (lines_before stays 0 until then)
+	std::function<uint64_t()> lazy_lines;
 	bool header = true;
 };
 
 // number of '\n' in bytes [from, to) of fd, by all threads
-uint64_t count_newlines(int fd, uint64_t from, uint64_t to, int threads) {
+// per_piece (optional): the count of every 8 MB piece, for line_offsets below
+uint64_t count_newlines(int fd, uint64_t from, uint64_t to, int threads, std::vector<uint64_t> *per_piece = nullptr) {
 	if (to <= from) return 0;
 	const uint64_t piece = 8u << 20;
 	const uint64_t np = (to - from + piece - 1) / piece;
+	if (per_piece) per_piece->assign((size_t)np, 0);
 	uint64_t total = 0;
-#pragma omp parallel for schedule(dynamic, 1) num_threads(threads) reduction(+ : total)
+#pragma omp parallel num_threads(threads) reduction(+ : total)
+	{
+	std::vector<char> buf((size_t)std::min<uint64_t>(piece, to - from));  // one buffer per thread, not per piece
+#pragma omp for schedule(dynamic, 1)
 	for (int64_t k = 0; k < (int64_t)np; ++k) {
-		std::vector<char> buf((size_t)piece);
 		const uint64_t a = from + (uint64_t)k * piece, b = std::min(to, a + piece);
 		size_t have = 0;
 		while (a + have < b) {
@@ -619,6 +601,8 @@ uint64_t count_newlines(int fd, uint64_t from, uint64_t to, int threads) {
 			c = nl + 1;
 		}
 		total += n;
+		if (per_piece) (*per_piece)[(size_t)k] = n;
+	}
 	}
 	return total;
 }
@@ -640,6 +624,24 @@ uint64_t skip_lines(int fd, uint64_t from, uint64_t fsize, uint64_t lines) {
 		at += (uint64_t)(c - buf.data());
 	}
 	return lines ? fsize : at;
+}
+
+// offsets of the bytes behind the targets[i]-th '\n' of fd (`fsize` where the file has fewer), targets ascending: the pieces' line
+// counts by all threads, then one scan inside the piece each target falls in (the mates' file of a sharded paired run used to be
+// walked by one thread from its start to the last cut)
+std::vector<uint64_t> line_offsets(int fd, uint64_t fsize, const std::vector<uint64_t> &targets, int threads) {
+	std::vector<uint64_t> per, out(targets.size(), fsize);
+	count_newlines(fd, 0, fsize, threads, &per);
+	const uint64_t piece = 8u << 20;
+	uint64_t before = 0;
+	size_t k = 0;
+	for (size_t i = 0; i < targets.size(); ++i) {
+		if (targets[i] == 0) { out[i] = 0; continue; }
+		while (k < per.size() && before + per[k] < targets[i]) before += per[k++];
+		if (k == per.size()) break;  // fewer lines than asked for: fsize
+		out[i] = skip_lines(fd, (uint64_t)k * piece, fsize, targets[i] - before);
+	}
+	return out;
 }
 
 int map_files_impl(urmapx_index *I, const urmapx_map_options *opt, const InputRange &range, const char *fastq1, const char *fastq2,
@@ -736,6 +738,7 @@ int map_files_impl(urmapx_index *I, const urmapx_map_options *opt, const InputRa
 		}
 		rd.set_limit(range.hi[0]);
 		if (paired) rd2.set_limit(range.hi[1]);
+		if (range.lazy_lines) rd.set_lazy_line_base(range.lazy_lines);
 	}
 	const auto t1 = std::chrono::steady_clock::now();
 	Trace trace;
@@ -775,6 +778,8 @@ int map_files_impl(urmapx_index *I, const urmapx_map_options *opt, const InputRa
 			};
 			if (is_gz_name(fastq1) || (paired && is_gz_name(fastq2)) || rd.is_pipe() || (paired && rd2.is_pipe())) {
 				streamed = open_src(src1, rd, fastq1) && (!paired || open_src(src2, rd2, fastq2));
+				src1.set_gz_threads(host_threads);  // a plain gzip stream: the inflater is what the run waits for
+				src2.set_gz_threads(host_threads);
 			} else {
 				fq = open_plain(fastq1, fsize);
 				if (fq >= 0 && paired) {
@@ -786,6 +791,12 @@ int map_files_impl(urmapx_index *I, const urmapx_map_options *opt, const InputRa
 		}
 		if (fq >= 0 || streamed) {
 			size_t chunk_bytes = (size_t)std::min(330.0 * (double)(paired ? std::max(1u, batch / 2) : batch), 536870912.0);  // streamed: a 150-base record
+			if (streamed && !opt->batch && src1.is_gz()) {
+				// no -batch given: larger chunks for a large file, as for plain input below (FASTQ text is 4-5 times its gzip size)
+				const double est = 4.0 * (double)src1.compressed_size() / 330.0 * (paired ? 2.0 : 1.0);
+				const double reads = std::min(1048576.0, std::max((double)batch, est / (4.0 * (double)n_lanes)));
+				chunk_bytes = (size_t)std::min(330.0 * (paired ? std::max(1.0, reads / 2) : reads), 536870912.0);
+			}
 			// `batch` reads (pairs: batch / 2 of each file) at the record size the head of the file shows
 			if (!streamed) {
 				std::vector<char> head(1u << 16);
@@ -794,7 +805,15 @@ int map_files_impl(urmapx_index *I, const urmapx_map_options *opt, const InputRa
 				for (ssize_t i = 0; i < k; ++i)
 					if (head[(size_t)i] == '\n' && (++nl & 3) == 0) last = (size_t)i + 1;
 				const double rec = nl >= 4 ? (double)last / (double)(nl / 4) : 512.0;
-				chunk_bytes = (size_t)std::min(std::max(rec * (double)(paired ? std::max(1u, batch / 2) : batch), 4096.0), 536870912.0);
+				double reads_per_chunk = (double)batch;
+				if (!opt->batch) {
+					// no -batch given: a chunk pays 3-4 ms of fixed cost on the device (launch tails, the second pass's empty launches) --
+					// two thirds of a 262 144-read chunk's mapping time at 46 M reads/s -- so a large file is cut into larger chunks, up to
+					// 1 M reads, as long as every lane still gets four of them (the lanes overlap each other's copies)
+					const double est = (double)(fsize - (range.on ? range.lo[0] : 0)) / rec * (paired ? 2.0 : 1.0);
+					reads_per_chunk = std::min(1048576.0, std::max((double)batch, est / (4.0 * (double)n_lanes)));
+				}
+				chunk_bytes = (size_t)std::min(std::max(rec * (paired ? std::max(1.0, reads_per_chunk / 2) : reads_per_chunk), 4096.0), 536870912.0);
 			}
 			using TextChannel = Channel<std::unique_ptr<TextJob>>;
 			std::vector<std::unique_ptr<TextChannel>> tparsed, tmapped;
@@ -1438,13 +1457,15 @@ extern "C" int urmapx_map_files(urmapx_index *I, const urmapx_map_options *opt, 
 	if (err && errcap) err[0] = 0;
 	if (!I || !opt || !fastq1) return URMAPX_E_ARG;
 	const int shards = opt->sam_shards > 1 ? opt->sam_shards : 1;
-	if (shards == 1 || !samout) return map_files_impl(I, opt, InputRange(), fastq1, fastq2, samout, tabout, report, err, errcap);
+	if (shards == 1) return map_files_impl(I, opt, InputRange(), fastq1, fastq2, samout, tabout, report, err, errcap);
 	auto say = [&](const std::string &s) {
 		if (err && errcap) snprintf(err, errcap, "%s", s.c_str());
 	};
 	const bool paired = fastq2 != nullptr;
 	const int gpus = opt->gpus > 0 ? opt->gpus : 1;
-	if (shards > 64 || (gpus % shards != 0 && shards % gpus != 0)) { say("-samshards must divide -gpus or be a multiple of it"); return URMAPX_E_ARG; }
+	if (!samout) { say("-samshards needs -samout (the shards are named after it)"); return URMAPX_E_ARG; }
+	if (shards > 64) { say("-samshards must be 1..64"); return URMAPX_E_ARG; }
+	if (gpus % shards != 0 && shards % gpus != 0) { say("-samshards must divide -gpus or be a multiple of it"); return URMAPX_E_ARG; }
 	const int host_threads = opt->host_threads > 0 ? opt->host_threads : std::min(16, std::max(1, (int)std::thread::hardware_concurrency()));
 	// plain seekable files are cut; anything else (.gz, a pipe) goes to shard 0 whole
 	auto plain_size = [](const char *path, int &fd) -> uint64_t {
@@ -1460,6 +1481,9 @@ extern "C" int urmapx_map_files(urmapx_index *I, const urmapx_map_options *opt, 
 	const uint64_t fsize1 = plain_size(fastq1, fd1), fsize2 = paired ? plain_size(fastq2, fd2) : 0;
 	const bool cut = fd1 >= 0 && (!paired || fd2 >= 0) && !getenv("URMAPX_HOST_TEXT_NO_SHARDS");
 	std::vector<InputRange> ranges((size_t)shards);
+	// the cutting (and, for pairs, the line counts that place the cuts of the mates' file) belongs to the run: it is inside
+	// report->seconds and reported as shard_scan_s
+	const auto t_scan0 = std::chrono::steady_clock::now();
 	{
 		// shard s starts at the first record start at or behind byte fsize * s / shards of the first file -- and, for pairs, at
 		// the same line of the second file
@@ -1472,9 +1496,11 @@ extern "C" int urmapx_map_files(urmapx_index *I, const urmapx_map_options *opt, 
 				if (a == 0 || a < at[(size_t)s - 1]) a = fsize1;  // no record start in sight: the shard in front takes the rest
 				at[(size_t)s] = a;
 			}
-			for (int s = 1; s <= shards; ++s) lines[(size_t)s] = lines[(size_t)s - 1] + count_newlines(fd1, at[(size_t)s - 1], at[(size_t)s], host_threads);
-			if (paired)
-				for (int s = 1; s < shards; ++s) at2[(size_t)s] = skip_lines(fd2, at2[(size_t)s - 1], fsize2, lines[(size_t)s] - lines[(size_t)s - 1]);
+			if (paired) {  // the mates' file is cut at the same LINES: the first file's parts are counted, the second's offsets looked up
+				for (int s = 1; s < shards; ++s) lines[(size_t)s] = lines[(size_t)s - 1] + count_newlines(fd1, at[(size_t)s - 1], at[(size_t)s], host_threads);
+				const std::vector<uint64_t> o2 = line_offsets(fd2, fsize2, std::vector<uint64_t>(lines.begin() + 1, lines.begin() + shards), host_threads);
+				for (int s = 1; s < shards; ++s) at2[(size_t)s] = o2[(size_t)s - 1];
+			}
 		}
 		for (int s = 0; s < shards; ++s) {
 			InputRange &r = ranges[(size_t)s];
@@ -1482,11 +1508,44 @@ extern "C" int urmapx_map_files(urmapx_index *I, const urmapx_map_options *opt, 
 			r.on = cut;
 			r.lo[0] = at[(size_t)s]; r.hi[0] = at[(size_t)s + 1]; r.lo[1] = at2[(size_t)s]; r.hi[1] = at2[(size_t)s + 1];
 			r.lines_before = lines[(size_t)s];
+			if (cut && !paired && s > 0) {
+				// single-end: nothing needs the line counts but a message about a malformed record -- the shard's reader counts then
+				const std::string path = fastq1;
+				const uint64_t upto = at[(size_t)s];
+				r.lazy_lines = [path, upto, host_threads]() -> uint64_t {
+					const int fd = open(path.c_str(), O_RDONLY);
+					if (fd < 0) return 0;
+					const uint64_t n = count_newlines(fd, 0, upto, host_threads);
+					close(fd);
+					return n;
+				};
+			}
 		}
 		if (paired && cut) ranges[(size_t)shards - 1].hi[1] = fsize2;
 	}
 	if (fd1 >= 0) close(fd1);
 	if (fd2 >= 0) close(fd2);
+	const double scan_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_scan0).count();
+	auto empty_shards_from = [&](int s0) {
+		for (int s = s0; s < shards; ++s) {
+			FILE *f = fopen((std::string(samout) + "." + std::to_string(s)).c_str(), "wb");
+			if (f) fclose(f);
+			if (tabout) { f = fopen((std::string(tabout) + "." + std::to_string(s)).c_str(), "wb"); if (f) fclose(f); }
+		}
+	};
+	if (!cut) {
+		// Input that cannot be cut (.gz, BGZF, a pipe): ONE pipeline with all the devices and lanes the caller gave writes shard 0, the
+		// other shards are empty files -- `cat` of the shards is still the one file.  (Until round 4 shard 0 ran on gpus / shards of
+		// the devices: `-gpus 8 -samshards 8 reads.fq.gz` mapped the whole file on one GPU.)
+		urmapx_map_options o = *opt;
+		o.sam_shards = 0;
+		const std::string sam0 = std::string(samout) + ".0", tab0 = tabout ? std::string(tabout) + ".0" : std::string();
+		const int rc1 = map_files_impl(I, &o, InputRange(), fastq1, fastq2, sam0.c_str(), tabout ? tab0.c_str() : nullptr, report, err, errcap);
+		if (rc1 == URMAPX_OK || rc1 == URMAPX_E_UNSUPPORTED) empty_shards_from(1);
+		else { remove(sam0.c_str()); if (tabout) remove(tab0.c_str()); }
+		if (report) report->shards = shards;
+		return rc1;
+	}
 	// devices: shard s takes gpus / shards of them, or shares device s mod gpus
 	const char *forced = getenv("URMAPX_FORCE_DEVICE");
 	auto phys = [&](int g) { return forced ? atoi(forced) : opt->first_gpu + g; };
@@ -1519,13 +1578,7 @@ extern "C" int urmapx_map_files(urmapx_index *I, const urmapx_map_options *opt, 
 			e[0] = 0;
 			memset(&reps[(size_t)s], 0, sizeof reps[(size_t)s]);
 			const InputRange &r = ranges[(size_t)s];
-			if (!cut && s > 0) {  // input that cannot be cut: the other shards are empty files (`cat` of the shards is still the one file)
-				FILE *f = fopen(sam.c_str(), "wb");
-				if (f) fclose(f);
-				if (tabout) { f = fopen(tab.c_str(), "wb"); if (f) fclose(f); }
-				return;
-			}
-			if (cut && r.lo[0] >= r.hi[0]) {  // nothing left for this shard (fewer records than shards)
+			if (r.lo[0] >= r.hi[0]) {  // nothing left for this shard (fewer records than shards)
 				FILE *f = fopen(sam.c_str(), "wb");
 				if (f) fclose(f);
 				if (tabout) { f = fopen(tab.c_str(), "wb"); if (f) fclose(f); }
@@ -1542,10 +1595,16 @@ extern "C" int urmapx_map_files(urmapx_index *I, const urmapx_map_options *opt, 
 			if (r.t_end > 0) { b = b == 0 ? r.t_begin : std::min(b, r.t_begin); e = std::max(e, r.t_end); }
 		if (e > b) wall = e - b;
 	}
+	wall += scan_s;
 	release();
 	int out_rc = URMAPX_OK;
 	for (int s = 0; s < shards; ++s)
 		if (rcs[(size_t)s] && rcs[(size_t)s] != URMAPX_E_UNSUPPORTED && out_rc == URMAPX_OK) { out_rc = rcs[(size_t)s]; say(errs[(size_t)s]); }
+	if (out_rc != URMAPX_OK)  // a failed run leaves no partial shard files behind (the first error is the one reported)
+		for (int s = 0; s < shards; ++s) {
+			remove((std::string(samout) + "." + std::to_string(s)).c_str());
+			if (tabout) remove((std::string(tabout) + "." + std::to_string(s)).c_str());
+		}
 	if (report) {
 		memset(report, 0, sizeof *report);
 		for (const urmapx_map_report &r : reps) {
@@ -1560,6 +1619,7 @@ extern "C" int urmapx_map_files(urmapx_index *I, const urmapx_map_options *opt, 
 		}
 		report->seconds = wall;
 		report->shards = shards;
+		report->shard_scan_s = scan_s;
 	}
 	if (out_rc != URMAPX_OK) return out_rc;
 	return report && report->unsupported ? URMAPX_E_UNSUPPORTED : URMAPX_OK;

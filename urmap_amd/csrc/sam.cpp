@@ -290,11 +290,12 @@ bool FastqReader::next_batch(FastqBatch &B, uint32_t max_reads, std::string &err
 				pos = beg_ = 0;
 				if (have_ == 0) eof_ = true;
 			}
-			if (!only_blank) { err = "Empty line nr " + std::to_string(line_nr_ + blanks) + " in FASTQ file '" + path_ + "'"; return false; }
+			if (!only_blank) { line_base(); err = "Empty line nr " + std::to_string(line_nr_ + blanks) + " in FASTQ file '" + path_ + "'"; return false; }
 			finished_ = true;
 			have_ = beg_ = 0;
 			return nrec > 0;
 		}
+		line_base();  // a message follows: now the lines in front of a shard are worth counting
 		const uint64_t ln = line_nr_ + 1;
 		if (l1[0] != '@') { err = "Bad line " + std::to_string(ln) + " in FASTQ file '" + path_ + "': expected '@'"; return false; }
 		if (k + 1 >= nlines) { err = "Unexpected end-of-file in FASTQ file " + path_; return false; }

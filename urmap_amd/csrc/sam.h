@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <new>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -76,6 +77,9 @@ public:
 	bool resume_at(uint64_t offset, uint64_t lines_before);
 	// plain seekable files: the reader stops at byte `end` as if the file ended there (one shard of a sharded run)
 	void set_limit(uint64_t end) { limit_ = end; }
+	// one shard of a single-end sharded run: the lines of the file in front of the shard are not counted unless a message needs
+	// a line number -- `base` is asked then, once, and its answer added to the line numbers counted from the shard's start
+	void set_lazy_line_base(std::function<uint64_t()> base) { line_base_ = std::move(base); }
 	// pipes: continue with `prefix` (bytes another reader of the same descriptor took from it and gives back) and then
 	// whatever the descriptor still holds; the prefix starts line number `lines_before` + 1
 	bool resume_with_prefix(std::vector<char> &&prefix, uint64_t lines_before);
@@ -98,6 +102,8 @@ private:
 	bool eof_ = false, finished_ = false, seekable_ = true;
 	bool started_ = false;  // next_batch has been called: the reader cannot be positioned any more
 	uint64_t line_nr_ = 0;  // lines consumed so far
+	std::function<uint64_t()> line_base_;  // see set_lazy_line_base
+	uint64_t line_base() { if (line_base_) { line_nr_ += line_base_(); line_base_ = nullptr; } return 0; }
 	std::vector<size_t> ends_;  // scratch: end offset of every line of the batch
 	std::vector<char> prefix_;  // resume_with_prefix: read before the descriptor
 	size_t prefix_pos_ = 0;

@@ -1,6 +1,7 @@
 // urmapx.hip -- C ABI (include/urmapx.h) over the gfx950 kernels.  Host side only: .ufi parsing
 // (UFIndex::FromFile, ufindexio.cpp:51-115), device upload, workspace management, batch calls.
 // There is no CPU compute path in this library.
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -199,6 +200,13 @@ static int upload_directory(urmapx_index *I) {
 			fprintf(stderr, "urmapx: chain rows %s: %llu positions in rows, %.2f GB (hip: %s)\n", I->d_rowinfo ? "built" : "NOT built",
 			        (unsigned long long)I->n_rows, I->d_rowinfo ? (4.0 * (double)I->slotCount + 4.0 * (double)I->n_rows) / 1e9 : 0.0, hipGetErrorString(e));
 		HIP_TRY(e);
+		//  a replica without the layout maps 15 % slower with the same results: say so once, whoever asked for the upload
+		static bool warned = false;
+		if (!I->d_rowinfo && !warned) {
+			warned = true;
+			fprintf(stderr, "urmapx: the chain-row layout of the index was not built on device %d (no room for it, or MaxIx over 32): "
+			                "collision chains are walked link by link\n", I->device);
+		}
 	}
 	size_t n = I->labels.size();
 	HIP_TRY(hipMalloc((void **)&I->d_seqLengths, (n + 1) * 4));
@@ -362,7 +370,7 @@ int urmapx_ctx_phase_cycles(urmapx_ctx *C, uint64_t out[12]) {
 int urmapx_ctx_stage_ms(urmapx_ctx *C, float ms[7]) {
 	if (!C || !ms) return URMAPX_E_ARG;
 	if (!C->stage_valid) { for (int i = 0; i < 7; ++i) ms[i] = 0; return URMAPX_OK; }  // no stamps were taken
-	HIP_TRY(hipEventSynchronize(C->stage_ev[STAGE_EVENTS - 1]));
+	HIP_TRY(hipEventSynchronize(C->stage_ev[STAGE_LAST]));
 	auto span = [&](int a, int b, float &out) -> hipError_t { float t = 0; hipError_t e = hipEventElapsedTime(&t, C->stage_ev[a], C->stage_ev[b]); out += t; return e; };
 	for (int i = 0; i < 7; ++i) ms[i] = 0;
 	HIP_TRY(span(0, 1, ms[0]));
@@ -374,7 +382,25 @@ int urmapx_ctx_stage_ms(urmapx_ctx *C, float ms[7]) {
 		}
 	}
 	HIP_TRY(span(1 + 2 * DP_ROUNDS, 2 + 2 * DP_ROUNDS, ms[3]));
-	HIP_TRY(span(STAGE_EVENTS - 2, STAGE_EVENTS - 1, ms[6]));
+	HIP_TRY(span(STAGE_LAST - 1, STAGE_LAST, ms[6]));
+	return URMAPX_OK;
+}
+
+// Round 5: with phase 3 parked the search stage ([0] of urmapx_ctx_stage_ms) is three launches: ms[0] the first search launch,
+// ms[1] phase 3's flank-DP launch, ms[2] the search launch over the reads parked at phase 3; stats[0] = DpJobs made for phase 3,
+// stats[1] = reads parked there.  All zero when phase 3 ran inside the search kernel.
+int urmapx_ctx_phase3(urmapx_ctx *C, float ms[3], uint32_t stats[2]) {
+	if (!C || !ms || !stats) return URMAPX_E_ARG;
+	ms[0] = ms[1] = ms[2] = 0; stats[0] = stats[1] = 0;
+	if (!C->stage_valid || !C->dpbuf.p) return URMAPX_OK;
+	HIP_TRY(hipEventSynchronize(C->stage_ev[STAGE_LAST]));
+	HIP_TRY(hipEventElapsedTime(&ms[0], C->stage_ev[0], C->stage_ev[STAGE_P3_MAIN]));
+	HIP_TRY(hipEventElapsedTime(&ms[1], C->stage_ev[STAGE_P3_MAIN], C->stage_ev[STAGE_P3_DP]));
+	HIP_TRY(hipEventElapsedTime(&ms[2], C->stage_ev[STAGE_P3_DP], C->stage_ev[1]));
+	uint32_t buf[2];
+	HIP_TRY(hipMemcpy(buf, C->dpbuf.p + 32, sizeof buf, hipMemcpyDeviceToHost));
+	stats[0] = buf[0]; stats[1] = buf[1];
+	if (buf[1] == 0 && buf[0] == 0 && ms[1] < 1e-3f && ms[2] < 1e-3f) { ms[0] = 0; }
 	return URMAPX_OK;
 }
 
@@ -384,7 +410,7 @@ int urmapx_ctx_round_ms(urmapx_ctx *C, float ms[16], int *rounds) {
 	for (int i = 0; i < 16; ++i) ms[i] = 0;
 	*rounds = DP_ROUNDS;
 	if (!C->stage_valid) return URMAPX_OK;
-	HIP_TRY(hipEventSynchronize(C->stage_ev[STAGE_EVENTS - 1]));
+	HIP_TRY(hipEventSynchronize(C->stage_ev[STAGE_LAST]));
 	for (int i = 0; i < 2 * DP_ROUNDS; ++i) HIP_TRY(hipEventElapsedTime(&ms[i], C->stage_ev[1 + i], C->stage_ev[2 + i]));
 	return URMAPX_OK;
 }
@@ -461,6 +487,7 @@ int urmapx_map_se_device(urmapx_ctx *C, const void *d_bases, const void *d_offs,
 	C->stats_reads = diag ? n : 0;
 	wk.scratch = C->scratch.p;
 	wk.ticket = C->statsbuf.p + 62;  // words 62/63 of the diagnostics buffer are never touched by the stamps
+	wk.ticket3 = C->statsbuf.p + 58; // nor is word 58 (60 is the gather microbenchmark's sink)
 	if (const char *e = getenv("URMAPX_TEST_HSP_LDS_CAP")) wk.hsp_lds_cap = atoi(e);
 	// diagnostics: URMAPX_PHASE_STATS = per-phase cycle counters; URMAPX_DEBUG_STOP=N = cut the schedule after step N
 	// (results are then NOT the reference's).  Words 0/1 of the buffer: stop step, "no timing" flag.
@@ -493,7 +520,36 @@ int urmapx_map_se_device(urmapx_ctx *C, const void *d_bases, const void *d_offs,
 			at[p][4] = 16 * (size_t)p;
 			at[p][6] = need; need += (((size_t)jobs_cap[p] * 4 * DP_ROUNDS) + 63) & ~(size_t)63;
 		}
+		// phase 3 parked (kernels.h: SearchWork::dp3): jobs, their path slices, the parking lot with its larger records.
+		// Off by default: measured on the hg38-scale bench it LOSES 6 % at 150 bases and 4 % at 250 (the first launch gets 1.9 ms
+		// shorter, phase 3's DP launch and the second search launch cost 3.3 ms).  URMAPX_PARK_PHASE3=1 turns it on (tests, measurement).
+		const char *park3 = getenv("URMAPX_PARK_PHASE3");
+		const size_t p3w = (park3 && atoi(park3) > 0) ? p3_state_words(max_read_len) : 0;
+		uint32_t jobs_cap3 = (uint32_t)((uint64_t)n * 2u < (1ull << 30) ? (uint64_t)n * 2u : (1ull << 30)) + 4096u;
+		uint32_t fin_cap3 = n;
+		// test aids: a job array / parking lot too small for the batch -- reads that find no room are mapped by the second pass
+		if (const char *e = getenv("URMAPX_TEST_P3_JOBS_CAP")) jobs_cap3 = (uint32_t)atoi(e) + 1u;
+		if (const char *e = getenv("URMAPX_TEST_P3_FIN_CAP")) fin_cap3 = std::min<uint32_t>(n, (uint32_t)atoi(e));
+		size_t at3[5] = {0, 0, 0, 0, 0};
+		if (p3w) {
+			at3[4] = need; need += (((size_t)jobs_cap3 * 2) + 63) & ~(size_t)63;
+			at3[0] = need; need += (size_t)jobs_cap3 * sizeof(DpJob);
+			at3[1] = need; need += (((size_t)jobs_cap3 * DP_JOB_OPS * 2) + 63) & ~(size_t)63;
+			at3[2] = need; need += (((size_t)fin_cap3 * 16) + 63) & ~(size_t)63;
+			at3[3] = need; need += (size_t)fin_cap3 * p3w * 4;
+		}
 		if ((rc = C->dpbuf.ensure(need))) return rc;
+		if (p3w) {
+			DpWork &d = wk.dp3;
+			d.jobs = reinterpret_cast<DpJob *>(C->dpbuf.p + at3[0]);
+			d.ops = reinterpret_cast<uint16_t *>(C->dpbuf.p + at3[1]);
+			d.kidx = reinterpret_cast<uint16_t *>(C->dpbuf.p + at3[4]);
+			d.fin_list = reinterpret_cast<uint32_t *>(C->dpbuf.p + at3[2]);
+			d.state = reinterpret_cast<uint32_t *>(C->dpbuf.p + at3[3]);
+			d.counters = reinterpret_cast<uint32_t *>(C->dpbuf.p + 32);
+			d.tickets = reinterpret_cast<uint32_t *>(C->dpbuf.p + 64 + 4 * DP_TICKET_WORDS * (size_t)2);
+			d.jobs_cap = jobs_cap3; d.fin_cap = fin_cap3;
+		}
 		for (int p = 0; p < 2; ++p) {
 			DpWork &d = wk.dp[p];
 			d.jobs = reinterpret_cast<DpJob *>(C->dpbuf.p + at[p][0]);
@@ -530,7 +586,7 @@ int urmapx_map_se_device(urmapx_ctx *C, const void *d_bases, const void *d_offs,
 		                              (uint32_t)(pcap > 0xFFFFFFFFull ? 0xFFFFFFFFull : pcap), C->slowscratch.p, sblocks, C->slowlist.p + 1,
 		                              C->slowlist.p, C->stream));
 	}
-	if (stamps) HIP_TRY(hipEventRecord(C->stage_ev[STAGE_EVENTS - 1], C->stream));
+	if (stamps) HIP_TRY(hipEventRecord(C->stage_ev[STAGE_LAST], C->stream));
 	HIP_TRY(hipEventRecord(C->ev[2], C->stream));
 	C->ev_valid = true;
 	return URMAPX_OK;
@@ -707,6 +763,32 @@ int urmapx_seed_probe(urmapx_ctx *C, const uint8_t *bases, const uint64_t *offs,
 	HIP_TRY(hipMemcpyAsync(positions, C->positions.p, 2 * total * 4, hipMemcpyDeviceToHost, C->stream));
 	HIP_TRY(hipStreamSynchronize(C->stream));
 	return URMAPX_OK;
+}
+
+// The probe stage alone over reads resident in HBM (measurement: the figure the task's north_star names, "rocprof HBM GB/s on the
+// probe kernel against peak"; inside a mapping call the probe is a stage of the search kernel).  Slots, tallies and positions go
+// to the context's probe arrays as in urmapx_seed_probe; *ms = the launch on the context's stream, by events.
+int urmapx_seed_probe_device(urmapx_ctx *C, const void *d_bases, const void *d_offs, uint32_t n, uint64_t total_bases, uint32_t max_read_len,
+                             float *ms) {
+	if (!C || !ms || (n && (!d_bases || !d_offs))) return URMAPX_E_ARG;
+	*ms = 0;
+	if (n == 0) return URMAPX_OK;
+	if (max_read_len > URMAPX_MAX_QL) return URMAPX_E_UNSUPPORTED;
+	HIP_TRY(hipSetDevice(C->device));
+	int rc;
+	if ((rc = ensure_probe(C, total_bases))) return rc;
+	ProbeOut po{C->slots.p, C->tallies.p, C->positions.p};
+	hipEvent_t e0, e1;
+	HIP_TRY(hipEventCreate(&e0));
+	HIP_TRY(hipEventCreate(&e1));
+	HIP_TRY(hipEventRecord(e0, C->stream));
+	hipError_t e = launch_seed_probe(C->X, (const uint8_t *)d_bases, (const uint64_t *)d_offs, n, max_read_len, po, C->stream);
+	if (e == hipSuccess) e = hipEventRecord(e1, C->stream);
+	if (e == hipSuccess) e = hipEventSynchronize(e1);
+	if (e == hipSuccess) e = hipEventElapsedTime(ms, e0, e1);
+	(void)hipEventDestroy(e0);
+	(void)hipEventDestroy(e1);
+	return hip_rc(e);
 }
 
 // measurement aid for the roofline: see include/urmapx.h

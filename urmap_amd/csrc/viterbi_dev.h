@@ -111,6 +111,15 @@ __device__ __forceinline__ float viterbi_wave(const VPar P, const uint8_t *A, in
 		return (float)(P.gap_open_score + (LA - 1) * P.gap_ext_score);
 	}
 	const int Rad = P.band_radius;
+	if constexpr (B_LDS) {
+		// The contract above, enforced where it used to be a convention: a window within band_radius + 1 bytes of LDS
+		// offset 0 would read zeros for columns that ARE in the matrix and score wrongly in silence; here the read is flagged
+		// (URMAPX_ST_BAND_TOO_WIDE -> not a valid result, every parity test fails).  One scalar compare per DP.
+		if ((uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)B) < (uint32_t)Rad + 1u) {
+			status |= URMAPX_ST_BAND_TOO_WIDE;
+			return 0.0f;
+		}
+	}
 	int dlo = min(LA, LB), dhi = max(LA, LB);
 	dlo = dlo > Rad ? dlo - Rad : 1;
 	dhi += Rad;
