@@ -472,6 +472,7 @@ class Workload:
                     p3m, p3s = m.phase3()
                     self.p3_ms += np.array(p3m) / len(mappers) / max(1, steps)
                     self.p3_stats += np.array(p3s, dtype=np.float64) / max(1, steps)
+        self.own_s = time.perf_counter() - t0  # this rank's K steps, before it waits for the others
         if barrier:
             barrier()
         self.stage_ms /= max(1, steps)
@@ -732,6 +733,7 @@ def run_e2e(torch, api, oi, index, device, d_seq, seq_lengths, seq_offsets, L, s
                        f"(format_s 0 = no host formatting; write_s = one thread's pwrite into tmpfs, the stage that bounds the run)",
                "stage_busy_s": {k: round(rep[k], 3) for k in ("parse_s", "gpu_s", "format_s", "write_s")},
                "mapped_q10_frac": round(rep["mapped_q"] / max(1, rep["reads"]), 4),
+               "placement": rep["placement"].decode(),  # NUMA node of each device's PCI function = where its lane threads ran (@any: not pinned)
                "sam_records_identical_to_oracle": bool(same), "sam_records_checked": len(want),
                "null_sink": null_sink, "sharded": sharded}
         if ref:
@@ -750,7 +752,7 @@ def run_e2e_gz(api, index, device, d, fq, n_reads, L, want):
     a BGZF file: blocks in parallel on the host threads), cuts chunks out of the inflated text and the device parses and
     formats as for a plain file.  The first records of the SAM must be the plain run's."""
     import subprocess
-    n_gz = min(n_reads, int(os.environ.get("URMAP_BENCH_E2E_GZ_READS", 1_000_000)))
+    n_gz = min(n_reads, int(os.environ.get("URMAP_BENCH_E2E_GZ_READS", 2_000_000)))
     rec = (2 + 8 + 1) + L + 3 + L + 1
     with open(fq, "rb") as f:
         data = f.read(rec * n_gz)
@@ -916,6 +918,8 @@ def main():
     setup_s = time.time() - t_setup
 
     dt, kms = wl.timed(mappers, args.steps, args.warmup, barrier=lambda: R.barrier(torch))
+    # every rank's own numbers, for the N > 1 line: its steps between the two barriers, its set-up (genome, index placement, batches)
+    per_rank = R.all_gather_floats(torch, [wl.own_s, setup_s, t_index.get("make_ufi", 0.0), t_index.get("upload", 0.0), t_index.get("broadcast_s") or 0.0])
     dt = R.max_over_ranks(torch, dt)
     reads_per_s = world * args.steps * nb / dt
 
@@ -993,6 +997,14 @@ def main():
                                             "slots": int(vrep["slots"]), "used_slots": int(vrep["used"]), "rows": int(vrep["heads"]),
                                             "positions_rehashed": int(vrep["positions"]), "seconds": round(vrep["seconds"], 3)},
                        "setup_s": {"genome": round(t_gen, 1), **t_index, "total": round(setup_s, 1)}},
+            # N > 1: what each rank did between the barriers (value is priced on the slowest) and how long it took to get ready
+            "per_rank": {"ms_per_step": [round(1e3 * r[0] / args.steps, 3) for r in per_rank],
+                         "ms_per_step_min": round(1e3 * min(r[0] for r in per_rank) / args.steps, 3),
+                         "ms_per_step_max": round(1e3 * max(r[0] for r in per_rank) / args.steps, 3),
+                         "slowest_rank": int(np.argmax([r[0] for r in per_rank])),
+                         "setup_s": [round(r[1], 1) for r in per_rank],
+                         "setup_parts_s": {"make_ufi (rank 0 builds, the others wait in the collective)": [round(r[2], 1) for r in per_rank],
+                                           "upload / broadcast": [round(max(r[3], r[4]), 1) for r in per_rank]}},
             # bound: the limiter the counters show (profiles/r4: the waves of the search kernels wait on memory LATENCY more than half
             # of their cycles and issue in most of the rest; traffic is a few percent of the HBM peak) -- `peak` stays the HBM peak the
             # contract prices against, `frac` = algorithmic bytes / time / peak

@@ -288,7 +288,7 @@ typedef struct urmapx_map_options {
 	int gpus;           /* -gpus N: devices D..D+N-1, one replica of the index on each; 0 = 1 */
 	int streams;        /* -streams K: mapping contexts per device (copies of one overlap kernels of another); 0 = 2 */
 	int host_threads;   /* -threads: FASTQ parsing and SAM formatting; 0 = min(16, hardware threads) */
-	uint32_t batch;     /* reads per batch; 0 = 262144 */
+	uint32_t batch;     /* reads per batch; 0 = the library chooses: 262 144, up to 524 288 for files large enough to give every lane four chunks */
 	int veryfast;       /* -veryfast: State1 method 7 for -map, State2 method 5 for -map2 */
 	unsigned minq;      /* -minq (only -map2 reads it, map2.cpp:76) */
 	const char *cmdline; /* text after CL: in the @PG line (NULL: empty) */
@@ -317,6 +317,10 @@ typedef struct urmapx_map_report {  /* State1::HitStats' counters (state1.cpp:59
 	 * SAM bytes back */
 	double dev_h2d_s, dev_parse_s, dev_map_s, dev_format_s, dev_d2h_s;
 	int shards;                                      /* SAM files written (1 unless sam_shards) */
+	char placement[256];                             /* where the run's threads were put: "gpu0@node1 gpu1@node1; reader+writer@node1" per pipeline
+	                                                  * (shards separated by " | "); @any = not pinned (no NUMA node known for the device).  A lane's
+	                                                  * host thread runs on the CPUs of its device's NUMA node; reader and writer too when all devices
+	                                                  * of the pipeline share one node */
 	double shard_scan_s;                             /* sam_shards: seconds spent cutting the input at record starts (pairs: counting the lines that
 	                                                  * place the cuts of the mates' file); inside `seconds` */
 } urmapx_map_report;
@@ -327,7 +331,7 @@ typedef struct urmapx_map_report {  /* State1::HitStats' counters (state1.cpp:59
 int urmapx_map_files(urmapx_index *, const urmapx_map_options *, const char *fastq1, const char *fastq2, const char *samout,
                      const char *tabout, urmapx_map_report *report, char *err, size_t errcap);
 
-/* Page-locked chunk buffers of urmapx_map_files are kept (up to 3 GiB) for the next call in this process; this frees them. */
+/* Page-locked chunk buffers of urmapx_map_files are kept (up to 8 GiB) for the next call in this process; this frees them. */
 void urmapx_host_pool_trim(void);
 
 /* ---- FASTQ bytes in, SAM bytes out (both text stages of -map on the device) ---- */

@@ -21,11 +21,14 @@ def main():
                     if short in k:
                         # <NCH, true> = the second pass over reads whose lists outgrew LDS (usually an empty queue)
                         k = short + ("_pass2" if re.search(r"<\d+,\s*true", full) else "") + ("_dbg" if re.search(r"<\d+,\s*(true|false),\s*true", full) else "")
+                        m = re.search(r"<\d+,\s*(?:true|false),\s*(?:true|false),\s*(?:true|false),\s*([12])>", full)  # round 5: phase 3 parked -- first / second launch
+                        if m:
+                            k += "_part" + m.group(1)
                 a = acc[k][row["Counter_Name"]]
                 a[0] += float(row["Counter_Value"])
                 a[1] += 1
     out = {k: {c: {"avg": v[0] / v[1], "dispatches": v[1], "sum": v[0]} for c, v in cs.items()} for k, cs in acc.items()
-           if k.replace("_pass2", "").replace("_dbg", "") in ("search_se_kernel", "search_pe_kernel", "seed_probe_kernel", "viterbi_batch_kernel", "dp_kernel", "finalize_se_kernel")}
+           if k.replace("_pass2", "").replace("_dbg", "").replace("_part1", "").replace("_part2", "") in ("search_se_kernel", "search_pe_kernel", "seed_probe_kernel", "viterbi_batch_kernel", "dp_kernel", "finalize_se_kernel")}
     s = json.dumps(out, indent=1, sort_keys=True)
     if len(sys.argv) > 2:
         open(sys.argv[2], "w").write(s + "\n")

@@ -7,6 +7,7 @@ import gzip
 import json
 import os
 import subprocess
+import time
 import sys
 
 import numpy as np
@@ -115,6 +116,39 @@ def test_bench_starts_its_own_two_ranks(broadcast):
         assert "broadcast of the resident arrays" in d["config"]["setup_s"]["how"]
 
 
+def test_eight_ranks_on_the_one_device_as_the_scaling_run_launches_them():
+    """BASELINE config 4's launch (`bench.py --gpus 8`: 8 ranks, index built by rank 0 and broadcast, reads sharded by rank) on a box
+    with one GPU: all ranks share the device, the collectives go over gloo, the index takes the broadcast branch.  The line must say
+    n_gpus 8, carry every rank's own step and set-up times, rank 0's results bit-identical to the oracle, and the file-to-file leg
+    over the 8 'devices'.  Set-up per rank at this size bounds what the full-scale launch needs (printed for the record)."""
+    env = dict(os.environ)
+    env["URMAP_BENCH_BROADCAST"] = "1"
+    env["URMAP_BENCH_E2E_READS"] = "160000"
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--genome-mbp", "40", "--reads-per-step", "20000",
+                        "--steps", "2", "--warmup", "1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500, env=env)
+    wall = time.time() - t0
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout.decode()[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["config"]["ranks"]["world"] == 8 and d["scaling"] == "weak"
+    assert d["parity"]["bit_identical_to_oracle"], d["parity"]
+    assert d["config"]["index_validated"] is True
+    pr = d["per_rank"]
+    assert len(pr["ms_per_step"]) == 8 and len(pr["setup_s"]) == 8 and 0 <= pr["slowest_rank"] < 8
+    assert pr["ms_per_step_max"] == max(pr["ms_per_step"]) and pr["ms_per_step_min"] == min(pr["ms_per_step"]) > 0
+    assert d["ms_per_step"] >= pr["ms_per_step_max"] * 0.999  # the line's step time is the slowest rank's (plus the barrier)
+    assert d["value"] == pytest.approx(8 * d["steps"] * 20000 / (d["ms_per_step"] * d["steps"] * 1e-3), rel=1e-3)
+    assert "broadcast of the resident arrays" in d["config"]["setup_s"]["how"]
+    e2e = d["e2e"]
+    assert "error" not in e2e and e2e["gpus"] == 8 and e2e["sam_records_identical_to_oracle"], e2e
+    assert e2e["sharded"]["shards"] == 8 and e2e["sharded"]["cat_of_shards_equals_the_one_file"]
+    print(f"8 ranks on one device: wall {wall:.0f} s, set-up per rank {pr['setup_s']}, ms per step per rank {pr['ms_per_step']}")
+
+
 def test_broadcast_of_a_table_larger_than_one_piece():
     """The 8-GPU launch's index placement on a box with one GPU: rank 0 builds the table, the other rank
     waits in the collective, the resident arrays travel in 1 GiB pieces (ranks.broadcast_bytes) -- here at 1.2 Gbp (11.6 GB
@@ -216,6 +250,30 @@ def test_cli_samshards_of_input_that_cannot_be_cut(tmp_path):
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     assert os.path.getsize(out + ".1") == 0
     assert _records(out + ".0") == [l for l in open(os.path.join(GOLD, "se150.sam"), "rb").read().split(b"\n") if l]
+
+
+def test_lane_threads_are_placed_on_their_devices_numa_node(tmp_path, monkeypatch):
+    """urmapx_map_files pins each lane's host thread to the CPUs of its device's NUMA node (read from sysfs by PCI bus id) and says
+    where in the report.  On a box without NUMA information the devices are '@any'; with the node forced (test aid) the threads are
+    pinned for real -- same records either way."""
+    from urmap_amd import api
+    ufi = _golden_ufi(tmp_path)
+    idx = api.Index.open(ufi).upload(0)
+    want = [l for l in open(os.path.join(GOLD, "se150.sam"), "rb").read().split(b"\n") if l]
+    out = os.path.join(tmp_path, "a.sam")
+    rep = api.map_files(idx, os.path.join(GOLD, "se150.fq"), samout=out, batch=90, streams=2, cmdline="test")
+    assert rep["placement"].decode().startswith("gpu0@") and "reader+writer@" in rep["placement"].decode()
+    assert _records(out) == want
+    if os.path.exists("/sys/devices/system/node/node0/cpulist"):
+        monkeypatch.setenv("URMAPX_TEST_NUMA_NODE", "0")
+        rep = api.map_files(idx, os.path.join(GOLD, "se150.fq"), samout=out, batch=90, streams=2, cmdline="test", sam_shards=2)
+        pl = rep["placement"].decode()
+        assert pl.count("gpu0@node0") == 2 and pl.count("reader+writer@node0") == 2 and " | " in pl, pl
+        assert [l for k in range(2) for l in _records(f"{out}.{k}")] == want
+    monkeypatch.setenv("URMAPX_NO_NUMA_PIN", "1")
+    rep = api.map_files(idx, os.path.join(GOLD, "se150.fq"), samout=out, batch=90, streams=2, cmdline="test")
+    assert rep["placement"].decode() == "gpu0@any; reader+writer@any"
+    idx.close()
 
 
 def test_map_files_discard_and_device_stage_times(tmp_path):

@@ -32,6 +32,14 @@ def test_two_ranks_cover_every_read_once_and_reduce():
     assert d["world"] == 2 and d["backend"] == "gloo"
     assert d["total"] == 100003 and d["covered_once"] and d["broadcast_ok"]
     assert d["slowest"] == 2.0   # max over ranks, as the bench contract times a step
+    assert d["gathered"] == [[0.0, 10.0], [1.0, 11.0]]  # every rank's own numbers, in rank order
+
+
+def test_eight_ranks_as_the_drivers_scaling_run_launches_them():
+    """config 4's world size (8 ranks, here without devices): sharding, the reductions and the per-rank gather"""
+    d = _launch(8, 1000003, 65536)
+    assert d["world"] == 8 and d["total"] == 1000003 and d["covered_once"] and d["broadcast_ok"]
+    assert d["slowest"] == 8.0 and d["gathered"] == [[float(r), 10.0 + r] for r in range(8)]
 
 
 def test_launch_ranks_starts_children_and_returns_their_code(tmp_path):

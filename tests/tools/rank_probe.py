@@ -25,11 +25,12 @@ def main():
     R.broadcast_bytes(torch, t, chunk=1024)
     R.barrier()
     ok_bcast = bool((t == torch.arange(5000, dtype=torch.int64).to(torch.uint8)).all())
+    gathered = R.all_gather_floats(torch, [float(R.rank), 10.0 + R.rank])  # per-rank numbers of the N > 1 bench line
     flags = torch.tensor([1.0 if ok_bcast else 0.0])
     all_ok = R.sum_over_ranks(torch, float(flags.item())) == R.world
     if R.rank == 0:
         print(json.dumps({"world": R.world, "backend": R.backend, "total": total, "slowest": slowest,
-                          "covered_once": bool((seen == 1).all()), "broadcast_ok": all_ok,
+                          "covered_once": bool((seen == 1).all()), "broadcast_ok": all_ok, "gathered": gathered,
                           "device_index": R.device_index, "shared": R.shared}), flush=True)
     R.close()
 

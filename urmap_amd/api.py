@@ -60,7 +60,7 @@ class MapReport(C.Structure):
                 ("format_s", C.c_double), ("write_s", C.c_double), ("host_threads", C.c_int), ("lanes", C.c_int),
                 ("write_threads", C.c_int), ("text_on_device", C.c_int), ("input_bytes", C.c_uint64), ("medium", C.c_char * 24),
                 ("dev_h2d_s", C.c_double), ("dev_parse_s", C.c_double), ("dev_map_s", C.c_double), ("dev_format_s", C.c_double),
-                ("dev_d2h_s", C.c_double), ("shards", C.c_int), ("shard_scan_s", C.c_double)]
+                ("dev_d2h_s", C.c_double), ("shards", C.c_int), ("placement", C.c_char * 256), ("shard_scan_s", C.c_double)]
 
 
 class ValidateReport(C.Structure):

@@ -241,6 +241,9 @@ struct SegDecoder {
 		return true;
 	}
 
+	// One Huffman-coded block.  The bit buffer is libdeflate's: `bl` valid bits in `bb`, refilled without a branch by OR-ing the next
+	// eight bytes in above them (the bits of a byte that does not fit whole are OR-ed again, identically, by the next refill); after a
+	// refill 56..63 bits are valid -- more than a literal / length code, its extra bits, a distance code and its extra bits take (48).
 	template <bool CHECK>
 	bool huff_block() {
 		const uint32_t *lt = LL.t.data(), *dt = DD.t.data();
@@ -248,69 +251,99 @@ struct SegDecoder {
 		size_t n = this->n;
 		size_t cap = buf.size();
 		uint16_t *o = buf.data();
-		uint64_t checked = 0;  // CHECK: symbols seen
+		const uint8_t *in = B.p + (B.pos >> 3);
+		const uint8_t *const in_limit = B.p + (B.end >> 3);  // the buffer has 16 readable bytes behind it
+		uint64_t bb;
+		memcpy(&bb, in, 8);
+		bb >>= (B.pos & 7);
+		uint32_t bl = 64u - (uint32_t)(B.pos & 7);
+		in += 8;
+		bl -= 8; in -= 1;  // keep one byte back so that `bl` stays below 64 (56 .. 63 after a refill)
+		bb &= (bl < 64 ? (((uint64_t)1 << bl) - 1u) : ~0ull);
+#define URX_REFILL()                                  \
+	do {                                              \
+		uint64_t nx_;                                 \
+		memcpy(&nx_, in, 8);                          \
+		bb |= nx_ << bl;                              \
+		in += (63u - bl) >> 3;                        \
+		bl |= 56u;                                    \
+	} while (0)
+		bool ok = true;
 		for (;;) {
-			if (B.pos + 48 > B.end) return false;  // a symbol (15 + 5 + 15 + 13 bits) must lie inside the buffer
-			uint64_t v = B.peek();
-			uint32_t e = lt[v & lmask];
+			if (in > in_limit) { ok = false; break; }
+			URX_REFILL();
+			uint32_t e = lt[bb & lmask];
 			if (e & LINK) {
 				const int pb = (int)(e & 255u), sb = (int)((e >> 24) & 15u);
-				e = lt[((e >> 8) & 0xFFFFu) + ((v >> pb) & (((uint64_t)1 << sb) - 1u))];
+				e = lt[((e >> 8) & 0xFFFFu) + ((bb >> pb) & (((uint64_t)1 << sb) - 1u))];
 			}
-			const int l = (int)(e & 255u);
-			if (!l) return false;
-			const uint32_t sym = e >> 8;
-			B.pos += (uint64_t)l;
-			v >>= l;
+			uint32_t l = e & 255u;
+			if (!l) { ok = false; break; }
+			uint32_t sym = e >> 8;
+			bb >>= l; bl -= l;
 			if (sym < 256) {
-				if (CHECK) { if (!text_byte(sym)) return false; ++checked; continue; }
-				if (n == cap) { grow(n + 1); cap = buf.size(); o = buf.data(); }
-				o[n++] = (uint16_t)sym;
+				if (CHECK) { if (!text_byte(sym)) { ok = false; break; } }
+				else {
+					if (n + 4 > cap) { this->n = n; grow(n + 4); cap = buf.size(); o = buf.data(); }
+					o[n++] = (uint16_t)sym;
+				}
+				// up to two more literals out of the bits already in the buffer (at least 41 are left: 15 each)
+				e = lt[bb & lmask];
+				if (!(e & LINK) && (e >> 8) < 256 && (e & 255u)) {
+					sym = e >> 8;
+					if (CHECK) { if (!text_byte(sym)) { ok = false; break; } }
+					else o[n++] = (uint16_t)sym;
+					l = e & 255u; bb >>= l; bl -= l;
+					e = lt[bb & lmask];
+					if (!(e & LINK) && (e >> 8) < 256 && (e & 255u)) {
+						sym = e >> 8;
+						if (CHECK) { if (!text_byte(sym)) { ok = false; break; } }
+						else o[n++] = (uint16_t)sym;
+						l = e & 255u; bb >>= l; bl -= l;
+					}
+				}
 				continue;
 			}
 			if (sym == 256) break;
-			if (sym > 285) return false;
+			if (sym > 285) { ok = false; break; }
 			const int li = (int)sym - 257;
-			const uint32_t len = LEN_BASE[li] + (uint32_t)(v & (((uint64_t)1 << LEN_EXTRA[li]) - 1u));
-			B.pos += LEN_EXTRA[li];
-			v >>= LEN_EXTRA[li];
-			uint32_t de = dt[v & dmask];
+			const uint32_t len = LEN_BASE[li] + (uint32_t)(bb & (((uint64_t)1 << LEN_EXTRA[li]) - 1u));
+			bb >>= LEN_EXTRA[li]; bl -= LEN_EXTRA[li];
+			uint32_t de = dt[bb & dmask];
 			if (de & LINK) {
 				const int pb = (int)(de & 255u), sb = (int)((de >> 24) & 15u);
-				de = dt[((de >> 8) & 0xFFFFu) + ((v >> pb) & (((uint64_t)1 << sb) - 1u))];
+				de = dt[((de >> 8) & 0xFFFFu) + ((bb >> pb) & (((uint64_t)1 << sb) - 1u))];
 			}
-			const int dl = (int)(de & 255u);
-			if (!dl) return false;
+			const uint32_t dl = de & 255u;
+			if (!dl) { ok = false; break; }
 			const uint32_t ds = de >> 8;
-			if (ds > 29) return false;
-			B.pos += (uint64_t)dl;
-			v >>= dl;
-			const uint32_t dist = DIST_BASE[ds] + (uint32_t)(v & (((uint64_t)1 << DIST_EXTRA[ds]) - 1u));
-			B.pos += DIST_EXTRA[ds];
-			if (CHECK) { checked += len; continue; }
-			if (n + len > cap) { grow(n + len); cap = buf.size(); o = buf.data(); }
+			if (ds > 29) { ok = false; break; }
+			bb >>= dl; bl -= dl;
+			const uint32_t dist = DIST_BASE[ds] + (uint32_t)(bb & (((uint64_t)1 << DIST_EXTRA[ds]) - 1u));
+			bb >>= DIST_EXTRA[ds]; bl -= DIST_EXTRA[ds];
+			if (CHECK) continue;
+			if (n + len + 4 > cap) { this->n = n; grow(n + len + 4); cap = buf.size(); o = buf.data(); }
 			const size_t have = n - member_start;  // symbols of this member decoded here
 			if (dist <= have) {
 				const uint16_t *s = o + n - dist;
-				for (uint32_t i = 0; i < len; ++i) o[n + i] = s[i];  // (overlapping copies replicate, as deflate means them to)
+				if (dist >= len) memcpy(o + n, s, (size_t)len * 2);
+				else
+					for (uint32_t i = 0; i < len; ++i) o[n + i] = s[i];  // an overlapping copy replicates, as deflate means it to
 				n += len;
 			} else {
-				if (!from_unknown) return false;  // a reference in front of the member's start
-				// the first (dist - n) .. symbols come out of the unknown window, the rest out of this segment's own output
+				if (!from_unknown) { ok = false; break; }  // a reference in front of the member's start
+				// part (or all) of the match lies in the unknown window in front of this segment: symbols 0x8000 | k
 				for (uint32_t i = 0; i < len; ++i) {
-					const size_t back = dist;  // distance from position n + i is constant
-					if (back <= n + i) o[n + i] = o[n + i - back];
-					else {
-						const size_t k = WIN - (back - (n + i));
-						o[n + i] = (uint16_t)(0x8000u | (uint16_t)k);
-					}
+					if (dist <= n + i) o[n + i] = o[n + i - dist];
+					else o[n + i] = (uint16_t)(0x8000u | (uint16_t)(WIN - (dist - (n + i))));
 				}
 				n += len;
 			}
 		}
+#undef URX_REFILL
 		if (!CHECK) this->n = n;
-		(void)checked;
-		return true;
+		B.pos = (uint64_t)(in - B.p) * 8 - bl;
+		return ok && B.pos <= B.end;
 	}
 };
 
@@ -588,13 +621,29 @@ size_t ParallelGunzip::read(char *dst, size_t cap, int threads) {
 		const bool direct = total <= cap - done;
 		if (!direct) D.obuf.resize(total);
 		char *const otext = direct ? dst + done : D.obuf.data();
-		struct Piece { int k; size_t lo, hi; };  // pieces of 4 MB so that all threads take part whatever the number of segments
+		// pieces of at most 4 MB (all threads take part whatever the number of segments), cut at segment and member ends; a piece's
+		// symbols become bytes and its CRC-32 is taken while they are still in the cache
+		std::vector<std::pair<size_t, std::pair<uint32_t, uint32_t>>> ends;  // members that ended in this round: (offset in its text, (crc, isize))
+		for (int k = 0; k < K; ++k)
+			for (const SegDecoder::Member &m : segs[(size_t)keep[(size_t)k]].members) ends.push_back({ooff[(size_t)k] + m.out_end, {m.crc, m.isize}});
+		struct Piece { int k; size_t lo, hi; };  // symbols [lo, hi) of kept segment k
 		std::vector<Piece> pieces;
-		for (int k = 0; k < K; ++k) {
-			const size_t n = segs[(size_t)keep[(size_t)k]].n;
-			for (size_t lo = 0; lo < n; lo += 4u << 20) pieces.push_back(Piece{k, lo, std::min(n, lo + (4u << 20))});
+		{
+			size_t ei = 0;
+			for (int k = 0; k < K; ++k) {
+				const size_t n = segs[(size_t)keep[(size_t)k]].n;
+				size_t lo = 0;
+				while (lo < n) {
+					size_t hi = std::min(n, lo + (4u << 20));
+					while (ei < ends.size() && ends[ei].first <= ooff[(size_t)k] + lo) ++ei;
+					if (ei < ends.size() && ends[ei].first < ooff[(size_t)k] + hi) hi = ends[ei].first - ooff[(size_t)k];
+					pieces.push_back(Piece{k, lo, hi});
+					lo = hi;
+				}
+			}
 		}
 		std::vector<uint8_t> pok(pieces.size(), 1);
+		std::vector<uint32_t> pcrc(pieces.size(), 0);
 #pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
 		for (long pi = 0; pi < (long)pieces.size(); ++pi) {
 			const Piece &pc = pieces[(size_t)pi];
@@ -614,27 +663,14 @@ size_t ParallelGunzip::read(char *dst, size_t cap, int threads) {
 				}
 			}
 			if (!ok) pok[(size_t)pi] = 0;
+			pcrc[(size_t)pi] = (uint32_t)crc32(0L, (const Bytef *)o + pc.lo, (uInt)(pc.hi - pc.lo));
 		}
 		for (uint8_t x : pok)
 			if (!x) bad_ = true;
 		if (bad_) break;
-		// 4. CRC-32 and length of every member that ended in this round, as zlib checks them: pieces by all threads, combined in order
+		// CRC-32 and length of every member that ended in this round, as zlib checks them: the pieces' values combined in order
 		const double tr4 = omp_get_wtime();
 		{
-			std::vector<std::pair<size_t, std::pair<uint32_t, uint32_t>>> ends;  // (offset in this round's text, (crc, isize))
-			for (int k = 0; k < K; ++k)
-				for (const SegDecoder::Member &m : segs[(size_t)keep[(size_t)k]].members) ends.push_back({ooff[(size_t)k] + m.out_end, {m.crc, m.isize}});
-			std::vector<size_t> cuts;
-			cuts.push_back(0);
-			for (const Piece &pc : pieces) cuts.push_back(ooff[(size_t)pc.k] + pc.lo);
-			for (auto &e : ends) cuts.push_back(e.first);
-			cuts.push_back(total);
-			std::sort(cuts.begin(), cuts.end());
-			cuts.erase(std::unique(cuts.begin(), cuts.end()), cuts.end());
-			std::vector<uint32_t> cc(cuts.size() - 1);
-#pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
-			for (long i = 0; i < (long)cuts.size() - 1; ++i)
-				cc[(size_t)i] = (uint32_t)crc32(0L, (const Bytef *)otext + cuts[(size_t)i], (uInt)(cuts[(size_t)i + 1] - cuts[(size_t)i]));
 			size_t ei = 0;
 			auto member_ends_at = [&](size_t at) {
 				while (ei < ends.size() && ends[ei].first == at) {
@@ -644,11 +680,11 @@ size_t ParallelGunzip::read(char *dst, size_t cap, int threads) {
 				}
 			};
 			member_ends_at(0);
-			for (size_t i = 0; i + 1 < cuts.size(); ++i) {
-				const size_t len = cuts[i + 1] - cuts[i];
-				D.crc = (uint32_t)crc32_combine(D.crc, cc[i], (z_off_t)len);
+			for (size_t pi = 0; pi < pieces.size(); ++pi) {
+				const size_t len = pieces[pi].hi - pieces[pi].lo;
+				D.crc = (uint32_t)crc32_combine(D.crc, pcrc[pi], (z_off_t)len);
 				D.isize += len;
-				member_ends_at(cuts[i + 1]);
+				member_ends_at(ooff[(size_t)pieces[pi].k] + pieces[pi].hi);
 			}
 			if (bad_) break;
 		}

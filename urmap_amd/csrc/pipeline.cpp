@@ -16,6 +16,7 @@
 // ends the text phase; the host reader continues at that chunk's first byte with the line count kept, so '\r', blank
 // lines and malformed records get the reference's handling and messages.
 #include <fcntl.h>
+#include <sched.h>
 #include <functional>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -29,6 +30,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cctype>
 #include <chrono>
 #include <condition_variable>
 #include <cstdio>
@@ -319,7 +321,7 @@ public:
 
 private:
 	struct Buf { char *p; size_t cap; };
-	static constexpr size_t kKeep = (size_t)3 << 30;
+	static constexpr size_t kKeep = (size_t)8 << 30;  // 2 pipelines x 6 chunks of 524 288 reads in flight = 4.2 GB
 	std::mutex m_;
 	std::vector<Buf> free_;
 	size_t held_ = 0;
@@ -644,6 +646,56 @@ std::vector<uint64_t> line_offsets(int fd, uint64_t fsize, const std::vector<uin
 	return out;
 }
 
+// Where a device hangs: its PCI function's NUMA node (/sys/bus/pci/devices/<bus id>/numa_node) and that node's CPUs that this process
+// may use.  On an 8-GPU node the devices sit behind two sockets: a lane thread that drives device g -- it fills and drains the
+// page-locked chunk buffers that cross PCIe -- runs on g's socket, and so do the reader and the writer of a shard whose devices are
+// all there.  ok == false (no such file, node -1 as on one-socket boxes and in most VMs, or none of the node's CPUs
+// allowed): nothing is pinned.
+struct DevicePlace {
+	int node = -1;
+	cpu_set_t cpus;
+	bool ok = false;
+};
+DevicePlace place_of_device(int device) {
+	DevicePlace P;
+	CPU_ZERO(&P.cpus);
+	char bus[64] = {0};
+	if (getenv("URMAPX_NO_NUMA_PIN") || hipDeviceGetPCIBusId(bus, (int)sizeof bus, device) != hipSuccess) return P;
+	for (char *c = bus; *c; ++c) *c = (char)tolower((unsigned char)*c);
+	const char *forced = getenv("URMAPX_TEST_NUMA_NODE");  // test aid: pretend every device hangs off this node
+	if (forced) P.node = atoi(forced);
+	else {
+		FILE *f = fopen((std::string("/sys/bus/pci/devices/") + bus + "/numa_node").c_str(), "r");
+		if (!f) return P;
+		if (fscanf(f, "%d", &P.node) != 1) P.node = -1;
+		fclose(f);
+	}
+	if (P.node < 0) return P;
+	FILE *f = fopen(("/sys/devices/system/node/node" + std::to_string(P.node) + "/cpulist").c_str(), "r");
+	if (!f) return P;
+	char list[4096] = {0};
+	const bool got = fgets(list, sizeof list, f) != nullptr;
+	fclose(f);
+	if (!got) return P;
+	cpu_set_t allowed;
+	CPU_ZERO(&allowed);
+	if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) return P;
+	for (const char *c = list; *c && *c != '\n';) {  // "0-63,128-191"
+		char *e;
+		const long a = strtol(c, &e, 10);
+		long b = a;
+		if (e == c) break;
+		if (*e == '-') { c = e + 1; b = strtol(c, &e, 10); }
+		for (long k = a; k <= b && k < CPU_SETSIZE; ++k)
+			if (CPU_ISSET((int)k, &allowed)) CPU_SET((int)k, &P.cpus);
+		c = *e == ',' ? e + 1 : e;
+	}
+	P.ok = CPU_COUNT(&P.cpus) > 0;
+	return P;
+}
+// the calling thread (and the OpenMP team it starts later) onto a device's socket; false: left where it was
+bool pin_to(const DevicePlace &P) { return P.ok && sched_setaffinity(0, sizeof P.cpus, &P.cpus) == 0; }
+
 int map_files_impl(urmapx_index *I, const urmapx_map_options *opt, const InputRange &range, const char *fastq1, const char *fastq2,
                    const char *samout, const char *tabout, urmapx_map_report *report, char *err, size_t errcap) {
 	auto say = [&](const std::string &s) {
@@ -689,6 +741,16 @@ int map_files_impl(urmapx_index *I, const urmapx_map_options *opt, const InputRa
 		if (!rc && paired && tabout) rc = urmapx_ctx_set_pair_info(ctxs[(size_t)l], 1);
 		if (rc) { say(std::string("Creating mapping context: ") + urmapx_strerror(rc)); release(); return rc; }
 	}
+	// where each device hangs (NUMA node of its PCI function): lane threads run there; a pipeline whose devices share one node -- every
+	// shard of a sharded run on a two-socket node -- has its reader and writer there too
+	std::vector<DevicePlace> places((size_t)gpus);
+	for (int g = 0; g < gpus; ++g) places[(size_t)g] = place_of_device(phys(g));
+	bool one_node = places[0].ok;
+	for (int g = 1; g < gpus; ++g) one_node = one_node && places[(size_t)g].ok && places[(size_t)g].node == places[0].node;
+	std::string placement;
+	for (int g = 0; g < gpus; ++g)
+		placement += (g ? " gpu" : "gpu") + std::to_string(phys(g)) + (places[(size_t)g].ok ? "@node" + std::to_string(places[(size_t)g].node) : std::string("@any"));
+	placement += one_node ? "; reader+writer@node" + std::to_string(places[0].node) : std::string("; reader+writer@any");
 	// host threads for FASTQ parsing and SAM formatting (the mapping itself runs on the GPU)
 	const int host_threads = opt->host_threads > 0 ? opt->host_threads : std::min(16, std::max(1, (int)std::thread::hardware_concurrency()));
 	const int omp_threads_before = omp_get_max_threads();  // this is a library call: the caller's OpenMP setting comes back at the end
@@ -794,7 +856,7 @@ int map_files_impl(urmapx_index *I, const urmapx_map_options *opt, const InputRa
 			if (streamed && !opt->batch && src1.is_gz()) {
 				// no -batch given: larger chunks for a large file, as for plain input below (FASTQ text is 4-5 times its gzip size)
 				const double est = 4.0 * (double)src1.compressed_size() / 330.0 * (paired ? 2.0 : 1.0);
-				const double reads = std::min(1048576.0, std::max((double)batch, est / (4.0 * (double)n_lanes)));
+				const double reads = std::min(524288.0, std::max((double)batch, est / (4.0 * (double)n_lanes)));
 				chunk_bytes = (size_t)std::min(330.0 * (paired ? std::max(1.0, reads / 2) : reads), 536870912.0);
 			}
 			// `batch` reads (pairs: batch / 2 of each file) at the record size the head of the file shows
@@ -809,9 +871,12 @@ int map_files_impl(urmapx_index *I, const urmapx_map_options *opt, const InputRa
 				if (!opt->batch) {
 					// no -batch given: a chunk pays 3-4 ms of fixed cost on the device (launch tails, the second pass's empty launches) --
 					// two thirds of a 262 144-read chunk's mapping time at 46 M reads/s -- so a large file is cut into larger chunks, up to
-					// 1 M reads, as long as every lane still gets four of them (the lanes overlap each other's copies)
+					// 524 288 reads, as long as every lane still gets four of them (the lanes overlap each other's copies).  Measured on
+					// 10 M reads (profiles/r5/e2e_by_chunk.txt): 262 144 -> 29.2 M reads/s with the SAM text dropped, 524 288 -> 31.2 M;
+					// 1 M-read chunks need 0.7 GB of page-locked memory each, six of them outgrow the pool and the run stalls in
+					// hipHostMalloc / hipHostFree (6.5 M reads/s)
 					const double est = (double)(fsize - (range.on ? range.lo[0] : 0)) / rec * (paired ? 2.0 : 1.0);
-					reads_per_chunk = std::min(1048576.0, std::max((double)batch, est / (4.0 * (double)n_lanes)));
+					reads_per_chunk = std::min(524288.0, std::max((double)batch, est / (4.0 * (double)n_lanes)));
 				}
 				chunk_bytes = (size_t)std::min(std::max(rec * (paired ? std::max(1.0, reads_per_chunk / 2) : reads_per_chunk), 4096.0), 536870912.0);
 			}
@@ -866,6 +931,7 @@ int map_files_impl(urmapx_index *I, const urmapx_map_options *opt, const InputRa
 			// reader gave up on).  Pipes: they go to the host reader in front of the rest of the pipe, behind pipe_back.
 			std::vector<char> carry, carry2, pipe_back, pipe_back2;
 			std::thread treader([&] {
+				if (one_node) (void)pin_to(places[0]);  // the page-locked chunk buffers are first touched here
 				omp_set_num_threads(read_threads);
 				uint64_t off = range.on ? range.lo[0] : 0, off2 = range.on ? range.lo[1] : 0;
 				double bytes2_per_byte1 = 1.0;
@@ -1082,6 +1148,7 @@ int map_files_impl(urmapx_index *I, const urmapx_map_options *opt, const InputRa
 			write_threads_used = write_threads;
 			text_on_device = true;
 			std::thread twriter([&] {
+				if (one_node) (void)pin_to(places[0]);
 				omp_set_num_threads(host_threads);
 				std::unique_ptr<TextJob> j;
 				for (size_t b = 0; tmapped[b % (size_t)n_lanes]->pop(j); ++b) {
@@ -1116,6 +1183,7 @@ int map_files_impl(urmapx_index *I, const urmapx_map_options *opt, const InputRa
 			std::vector<std::thread> tlanes;
 			for (int l = 0; l < n_lanes; ++l)
 				tlanes.emplace_back([&, l] {
+					(void)pin_to(places[(size_t)(l % gpus)]);
 					(void)hipSetDevice(phys(l % gpus));
 					urmapx_text *T = nullptr;
 					const double tc = trace.ms();
@@ -1381,6 +1449,7 @@ int map_files_impl(urmapx_index *I, const urmapx_map_options *opt, const InputRa
 	for (int l = 0; l < n_lanes; ++l)
 		lanes.emplace_back([&, l] {
 			urmapx_ctx *C = ctxs[(size_t)l];
+			(void)pin_to(places[(size_t)(l % gpus)]);
 			(void)hipSetDevice(phys(l % gpus));
 			std::unique_ptr<Job> j;
 			while (parsed[(size_t)l]->pop(j)) {
@@ -1442,6 +1511,7 @@ int map_files_impl(urmapx_index *I, const urmapx_map_options *opt, const InputRa
 		report->dev_h2d_s = dev_ms[0] * 1e-3; report->dev_parse_s = dev_ms[1] * 1e-3; report->dev_map_s = dev_ms[2] * 1e-3;
 		report->dev_format_s = dev_ms[3] * 1e-3; report->dev_d2h_s = dev_ms[4] * 1e-3;
 		report->shards = 1;
+		snprintf(report->placement, sizeof report->placement, "%s", placement.c_str());
 	}
 	if (fail.set.load()) { say(fail.msg); return fail.code; }
 	return n_unsupported ? URMAPX_E_UNSUPPORTED : URMAPX_OK;
@@ -1616,6 +1686,10 @@ extern "C" int urmapx_map_files(urmapx_index *I, const urmapx_map_options *opt, 
 			report->write_threads = std::max(report->write_threads, r.write_threads);
 			report->text_on_device |= r.text_on_device;
 			if (r.medium[0]) memcpy(report->medium, r.medium, sizeof report->medium);
+			if (r.placement[0]) {
+				const size_t have = strlen(report->placement);
+				snprintf(report->placement + have, sizeof report->placement - have, "%s%s", have ? " | " : "", r.placement);
+			}
 		}
 		report->seconds = wall;
 		report->shards = shards;

@@ -165,6 +165,10 @@ static int cmd_map(const Opts &o, int argc, char **argv) {
 	if (getenv("URMAPX_VERBOSE"))
 		fprintf(stderr, "stage busy seconds: parse %.2f, gpu (copies + kernels, summed over %d lanes) %.2f, format %.2f, write %.2f; %d host threads; text on device: %d\n",
 		        rep.parse_s, rep.lanes, rep.gpu_s, rep.format_s, rep.write_s, rep.host_threads, (int)rep.text_on_device);
+	if (getenv("URMAPX_VERBOSE") || g_log) {  // where the threads ran (NUMA node of each device's PCI function; @any: not pinned)
+		if (getenv("URMAPX_VERBOSE")) fprintf(stderr, "placement: %s\n", rep.placement);
+		if (g_log) fprintf(g_log, "placement: %s\n", rep.placement);
+	}
 	if (g_log) fprintf(g_log, "@rps=%.1f\n", map_s > 0 ? (double)n_reads / map_s : 0.0);  // Log("@rps=..."), state1.cpp:607
 	if (!o.quiet || g_log) {  // State1::HitStats (state1.cpp:593-632): same lines, sub-second timers, "GPU n" where it says "n threads"; ProgressLog = terminal + log file
 		const bool q = o.quiet;

@@ -126,6 +126,16 @@ class Ranks:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return float(t.item())
 
+    def all_gather_floats(self, torch, xs):
+        """every rank's list of floats -> [[rank 0's], [rank 1's], ...] on every rank (reporting only: per-rank step and set-up times)"""
+        if self.dist is None:
+            return [[float(x) for x in xs]]
+        dev = "cpu" if self.backend == "gloo" else torch.device("cuda", self.device_index)
+        mine = torch.tensor([float(x) for x in xs], device=dev, dtype=torch.float64)
+        out = [torch.zeros_like(mine) for _ in range(self.world)]
+        self.dist.all_gather(out, mine)
+        return [[float(v) for v in t.tolist()] for t in out]
+
     def broadcast_bytes(self, torch, t, src=0, chunk=1 << 30):
         """Broadcast a 1-D uint8 tensor in place, in pieces of `chunk` bytes (a 27 GB slot table is one tensor)."""
         if self.dist is None:
