@@ -1029,7 +1029,7 @@ def main():
                              "dropped_by_a_round_gate_before_their_dp": dp_stats[3],
                              "second_pass": {"hsps": dp_stats[4], "reads": dp_stats[5], "used": dp_stats[6], "gated": dp_stats[7]}}
             if wl.round_ms is not None:
-                out["phase6"]["launch_ms_by_round"] = {"rounds": "HSPs [0,2), [2,16), [16,...) of a read", "dp_kernel": [round(float(x[0]), 3) for x in wl.round_ms],
+                out["phase6"]["launch_ms_by_round"] = {"rounds": mapper.dp_rounds(), "dp_kernel": [round(float(x[0]), 3) for x in wl.round_ms],
                                                        "finalize_se_kernel": [round(float(x[1]), 3) for x in wl.round_ms]}
         if not pe and wl.p3_ms[0] > 0:
             out["phase3"] = {"what": "Search_Lo's phase 3 (AlignHSP when the best HSP of phases 1-2 is long, search1m6.cpp:162-171) parked like phase 6: DpJobs for dp_kernel, "
@@ -1084,7 +1084,7 @@ def main():
                                               "dropped_by_a_round_gate_before_their_dp": ds[3],
                                               "second_pass": {"hsps": ds[4], "reads": ds[5], "used": ds[6], "gated": ds[7]}}
                     if wl.round_ms is not None:
-                        others[name]["phase6"]["launch_ms_by_round"] = {"dp_kernel": [round(float(x[0]), 3) for x in wl.round_ms],
+                        others[name]["phase6"]["launch_ms_by_round"] = {"rounds": mapper.dp_rounds(), "dp_kernel": [round(float(x[0]), 3) for x in wl.round_ms],
                                                                         "finalize_se_kernel": [round(float(x[1]), 3) for x in wl.round_ms]}
                 if not ope and wl.p3_ms[0] > 0:
                     others[name]["phase3"] = {"reads_parked": int(round(wl.p3_stats[1])), "hsps_given_to_dp_kernel": int(round(wl.p3_stats[0])),

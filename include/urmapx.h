@@ -180,8 +180,11 @@ int urmapx_ctx_last_kernel_ms(urmapx_ctx *, float ms[2]);
  * [2] its finalize launches summed, [3..5] the second pass likewise, [6] the general kernel. */
 int urmapx_ctx_stage_ms(urmapx_ctx *, float ms[7]);
 /* The same call's phase-6 launches one by one (first pass): ms[2*r] = the DP launch of round r, ms[2*r+1] = the finalize
- * launch behind it; *rounds = how many rounds there are (3: HSPs [0,2), [2,16), [16,...) of a read). */
+ * launch behind it; *rounds = how many rounds the call had (3 or 4: urmapx_ctx_dp_rounds). */
 int urmapx_ctx_round_ms(urmapx_ctx *, float ms[16], int *rounds);
+/* The rounds of that call: round r = the HSPs lo[r] <= k < lo[r + 1] of a read (the last round is open ended: lo[rounds] = UINT32_MAX).
+ * Reads of up to 192 bases: [0,2) [2,16) [16,..); longer reads: [0,2) [2,8) [8,32) [32,..) (round 5). */
+int urmapx_ctx_dp_rounds(urmapx_ctx *, uint32_t lo[8], int *rounds);
 /* Round 5: phase 3 of Search_Lo (AlignHSP when the best HSP of phases 1-2 is long, search1m6.cpp:162-171) is parked like phase 6:
  * the search stage ([0] above) is then three launches -- ms[0] the first search launch (seed + probe + phases 1-2 for every read,
  * phases 4-5 for the reads with nothing to align in phase 3), ms[1] phase 3's flank-DP launch, ms[2] the search launch over the reads

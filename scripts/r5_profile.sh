@@ -41,3 +41,19 @@ for f in ("pmc_fetch_${wl}_raw","pmc_write_${wl}_raw","pmc_sq_$wl","pmc_sq2_$wl"
 PY
 done
 rm -rf /dev/shm/urmap_idx
+# the single-end workload once more with phase 3 parked (URMAPX_PARK_PHASE3=1): kernel trace, FETCH_SIZE, WRITE_SIZE -- what the three launches move
+if [ -z "$NO_PARKED" ]; then
+  export URMAP_BENCH_INDEX_CACHE=/dev/shm/urmap_idx
+  python3 $R/bench.py --steps 2 --warmup 1 --no-other-workloads --no-cpu-baseline --no-e2e > /dev/null 2>&1   # (the cache was removed above: rebuilt here)
+  A="--steps 5 --warmup 1 --no-cpu-baseline --no-other-workloads --no-e2e"
+  export URMAPX_PARK_PHASE3=1
+  $T rocprofv3 --kernel-trace --stats -d /tmp/kt_p3 -o kt --output-format csv -- python3 $R/bench.py $A > $O/bench_se150_parked_ktrace.json 2> $O/kt_p3.err
+  cp $(find /tmp/kt_p3 -name "*kernel_stats.csv" | head -1) $O/kernel_stats_se150_parked.csv
+  $T rocprofv3 --pmc FETCH_SIZE -d /tmp/pf_p3 -o pf --output-format csv -- python3 $R/bench.py $A > /dev/null 2> $O/pf_p3.err
+  python3 $R/scripts/pmc_summary.py /tmp/pf_p3 $O/pmc_fetch_se150_parked_raw.json > /dev/null
+  $T rocprofv3 --pmc WRITE_SIZE -d /tmp/pw_p3 -o pw --output-format csv -- python3 $R/bench.py $A > /dev/null 2> $O/pw_p3.err
+  python3 $R/scripts/pmc_summary.py /tmp/pw_p3 $O/pmc_write_se150_parked_raw.json > /dev/null
+  unset URMAPX_PARK_PHASE3
+  rm -rf /tmp/kt_p3 /tmp/pf_p3 /tmp/pw_p3 /dev/shm/urmap_idx
+  head -8 $O/kernel_stats_se150_parked.csv | cut -c1-160
+fi

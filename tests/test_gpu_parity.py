@@ -961,9 +961,27 @@ def test_phase6_launches_path_arena_dense_and_round_times(dense_case):
     assert int(nops.sum()) >= len(gops) - 96 * max(8, len(reads) // 100), (int(nops.sum()), len(gops))
     rounds = m.round_ms()
     stage = m.stage_ms()
-    assert len(rounds) == 3 and all(d >= 0 and f >= 0 for d, f in rounds)
+    assert len(rounds) == 4 and all(d >= 0 and f >= 0 for d, f in rounds)  # 250-base reads: four rounds (kernels.h: DpBounds)
+    assert m.dp_rounds() == "HSPs [0,2), [2,8), [8,32), [32,...) of a read"
     assert abs(sum(d for d, _ in rounds) - stage[1]) < 0.05 + 0.02 * stage[1]
     assert abs(sum(f for _, f in rounds) - stage[2]) < 0.05 + 0.02 * stage[2]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bounds,n", [("0,2,16", 3), ("0,1,4,16", 4), ("0", 1), ("0,64", 2)])
+def test_phase6_round_boundaries_do_not_change_results(dense_case, monkeypatch, bounds, n):
+    """the rounds only decide WHEN a read's HSPs are aligned and which are gated before their DP; the ordered replay sees the same jobs"""
+    from urmap_amd import synth
+    from conftest import reads_to_arrays
+    reads = synth.make_reads(4243, dense_case["genome"], 1500, read_len=250, sub=0.04, ins=0.005, dele=0.005)
+    reads += synth.make_reads(4244, dense_case["genome"], 10, read_len=150, sub=0.02)  # (batch class stays the 256-base one)
+    bases, offs = reads_to_arrays(reads)
+    ores, opaths, _ = dense_case["oracle_index"].map_se(bases, offs, threads=4)
+    monkeypatch.setenv("URMAPX_DP_BOUNDS", bounds)
+    m = dense_case["mapper"]
+    gres, gops = m.map_se(bases, offs)
+    compare_results(gres, gops, ores, opaths)
+    assert len(m.round_ms()) == n
 
 
 @pytest.mark.gpu

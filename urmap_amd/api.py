@@ -31,7 +31,7 @@ EXPORTS = (
     "urmapx_index_seq_length", "urmapx_index_seq_offset", "urmapx_ctx_create", "urmapx_ctx_destroy",
     "urmapx_map_se", "urmapx_map_se_device", "urmapx_ctx_sync", "urmapx_ctx_last_kernel_ms",
     "urmapx_seed_probe", "urmapx_seed_probe_device", "urmapx_viterbi_batch", "urmapx_strerror", "urmapx_device_arch",
-    "urmapx_make_ufi", "urmapx_make_ufi_opts", "urmapx_build_slots", "urmapx_make_ufi_gpu", "urmapx_build_slots_gpu", "urmapx_sam_se", "urmapx_sam_header_sq", "urmapx_ctx_phase_cycles", "urmapx_ctx_read_cycles", "urmapx_ctx_stage_ms", "urmapx_ctx_phase3", "urmapx_ctx_round_ms", "urmapx_ctx_dp_stats", "urmapx_map_pe", "urmapx_sam_pe", "urmapx_map_pe_device", "urmapx_ctx_set_pe_veryfast",
+    "urmapx_make_ufi", "urmapx_make_ufi_opts", "urmapx_build_slots", "urmapx_make_ufi_gpu", "urmapx_build_slots_gpu", "urmapx_sam_se", "urmapx_sam_header_sq", "urmapx_ctx_phase_cycles", "urmapx_ctx_read_cycles", "urmapx_ctx_stage_ms", "urmapx_ctx_phase3", "urmapx_ctx_round_ms", "urmapx_ctx_dp_rounds", "urmapx_ctx_dp_stats", "urmapx_map_pe", "urmapx_sam_pe", "urmapx_map_pe_device", "urmapx_ctx_set_pe_veryfast",
     "urmapx_gunzip_file", "urmapx_fastq_open", "urmapx_fastq_next", "urmapx_fastq_error", "urmapx_fastq_close",
     "urmapx_ctx_gather_microbench", "urmapx_map_files", "urmapx_host_pool_trim", "urmapx_text_create", "urmapx_text_destroy", "urmapx_text_map_se", "urmapx_text_map_pe", "urmapx_text_fetch_sam", "urmapx_text_fetch_pairs", "urmapx_ctx_set_pair_info", "urmapx_ctx_get_pair_info", "urmapx_tab_pe",
 )
@@ -492,6 +492,16 @@ class Mapper:
         n = C.c_int(0)
         _check(lib().urmapx_ctx_round_ms(self.h, C.byref(ms), C.byref(n)), "urmapx_ctx_round_ms")
         return [(float(ms[2 * r]), float(ms[2 * r + 1])) for r in range(n.value)]
+
+    def dp_rounds(self):
+        """the rounds of phase 6 in the last single-end call as text: 'HSPs [0,2), [2,16), [16,...) of a read'"""
+        lo = (C.c_uint32 * 8)()
+        n = C.c_int(0)
+        L = lib()
+        L.urmapx_ctx_dp_rounds.argtypes = [C.c_void_p, C.POINTER(C.c_uint32 * 8), C.POINTER(C.c_int)]
+        _check(L.urmapx_ctx_dp_rounds(self.h, C.byref(lo), C.byref(n)), "urmapx_ctx_dp_rounds")
+        parts = [f"[{lo[r]},{lo[r + 1]})" if r + 1 < n.value else f"[{lo[r]},...)" for r in range(n.value)]
+        return "HSPs " + ", ".join(parts) + " of a read"
 
     def dp_stats(self):
         """per pass: (HSPs handed to the DP launches, reads parked, DPs the ordered replay looked at, jobs gated before their DP)"""

@@ -66,13 +66,20 @@ static constexpr uint8_t DPJ_LEFT_FAIL = 1, DPJ_RIGHT_FAIL = 2, DPJ_RIGHT_SKIPPE
 // The jobs of a read are run in rounds of growing size, [0,2) [2,16) [16,inf) by index: after each round the ordered
 // replay consumes that round's jobs and the penalty cap it arrives at gates the next round's DPs -- most of a repeat
 // read's HSPs fail AlignHSP's first test once the first few alignments have tightened the cap.
-#ifdef URX_DP_NROUNDS  // build-time experiment: -DURX_DP_NROUNDS=4 -DURX_DP_BOUNDS=0u,1u,4u,16u (up to 8 rounds)
-static constexpr int DP_ROUNDS = URX_DP_NROUNDS;
-static constexpr uint32_t DP_ROUND_LO[DP_ROUNDS + 1] = {URX_DP_BOUNDS, 0xFFFFFFFFu};
-#else
-static constexpr int DP_ROUNDS = 3;
-static constexpr uint32_t DP_ROUND_LO[DP_ROUNDS + 1] = {0u, 2u, 16u, 0xFFFFFFFFu};
-#endif
+// Round 5: the boundaries are chosen per call (SearchWork::dp_bounds): [0,2) [2,16) [16,inf) for reads of up to 192 bases, [0,2) [2,8)
+// [8,32) [32,inf) beyond (250-base reads with 5 % errors bring 13 HSPs each to phase 6: the fourth round's tighter gate is worth more
+// than its two launches cost -- measured in round 4).  DP_ROUNDS = the most rounds a call may have.
+static constexpr int DP_ROUNDS = 4;
+struct DpBounds {
+	int rounds;                    // rounds in use, 1 .. DP_ROUNDS
+	uint32_t lo[DP_ROUNDS + 1];    // round rd = jobs with lo[rd] <= k < lo[rd + 1]; lo[rounds] = 0xFFFFFFFF, unused rounds are empty
+};
+inline DpBounds dp_bounds_default(bool long_reads) {
+	DpBounds b;
+	if (long_reads) { b.rounds = 4; b.lo[0] = 0; b.lo[1] = 2; b.lo[2] = 8; b.lo[3] = 32; b.lo[4] = 0xFFFFFFFFu; }
+	else { b.rounds = 3; b.lo[0] = 0; b.lo[1] = 2; b.lo[2] = 16; b.lo[3] = 0xFFFFFFFFu; b.lo[4] = 0xFFFFFFFFu; }
+	return b;
+}
 static constexpr int DP_TICKET_WORDS = 16;  // per pass: [rd] work counter of round rd, [8 + rd] length of its job list
 static_assert(DP_ROUNDS <= 8, "DP_TICKET_WORDS");
 static constexpr int DP_JOB_OPS = URMAPX_MAX_PATH_OPS;  // ops slice per job
@@ -118,6 +125,7 @@ struct SearchWork {
 	size_t dp_scratch_stride = 0;
 	int dp_blocks = 0;
 	int fin_blocks = 0;            // grid of finalize_se_kernel (0: the search kernel's)
+	DpBounds dp_bounds = dp_bounds_default(false);  // phase 6's rounds for this call
 	hipEvent_t *stage_events = nullptr;  // optional, STAGE_EVENTS of them (see STAGE_LAST above)
 };
 size_t dp_scratch_stride(uint32_t max_read_len);

@@ -1482,7 +1482,8 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 // A block takes 4096 consecutive jobs, counts those of each round in LDS, reserves room in the round's list with ONE
 // atomic per round (the lists' order does not matter: it only decides which wavefront runs a job) and writes the indices;
 // a thread's 16 jobs are consecutive, so the jobs of a read stay together in the list (dp_kernel keeps a read's bases in LDS).
-__global__ __launch_bounds__(256) void dp_round_lists_kernel(DpWork dp) {
+__global__ __launch_bounds__(256) void dp_round_lists_kernel(DpWork dp, DpBounds bounds) {
+	const uint32_t *const DP_ROUND_LO = bounds.lo;
 	constexpr int PER = 16;
 	__shared__ uint32_t cnt[DP_ROUNDS], base[DP_ROUNDS];
 	const uint32_t made = dp.counters[0];
@@ -2387,8 +2388,10 @@ hipError_t launch_search_se(const DevIndex &X, const urmapx_params &P, const uin
 	do { /* the second pass is a few reads with many jobs each, usually none at all: smaller grids for the launches that go by reads */ \
 	const unsigned dpg = (unsigned)wk.dp_blocks;                                                                                  \
 	const unsigned fing = (unsigned)(wk.fin_blocks > 0 ? wk.fin_blocks : wk.blocks), fing2 = PASS_ && fing > 1024u ? 1024u : fing;  \
-	hipLaunchKernelGGL(dp_round_lists_kernel, dim3(PASS_ ? 128 : 2048), dim3(256), 0, s, wk.dp[PASS_]);                           \
+	const uint32_t *const DP_ROUND_LO = wk.dp_bounds.lo;                                                                          \
+	hipLaunchKernelGGL(dp_round_lists_kernel, dim3(PASS_ ? 128 : 2048), dim3(256), 0, s, wk.dp[PASS_], wk.dp_bounds);             \
 	for (int rd = 0; rd < DP_ROUNDS; ++rd) {                                                                                      \
+		if (rd >= wk.dp_bounds.rounds) { stamp(2 + (2 * DP_ROUNDS + 1) * PASS_ + 2 * rd); stamp(3 + (2 * DP_ROUNDS + 1) * PASS_ + 2 * rd); continue; } \
 		hipLaunchKernelGGL((dp_kernel<NCH_>), dim3(dpg), block, 0, s, X, P, d_bases, d_offs, wk.dp[PASS_],                        \
 		                   wk.dp_scratch, wk.dp_scratch_stride, X.seq, DP_ROUND_LO[rd], DP_ROUND_LO[rd + 1],                      \
 		                   wk.dp[PASS_].tickets + rd, wk.dp[PASS_].round_list + (size_t)rd * wk.dp[PASS_].jobs_cap,               \

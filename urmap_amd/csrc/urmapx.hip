@@ -78,6 +78,8 @@ struct urmapx_ctx {
 	DevBuf<uint32_t> statsbuf;
 	DevBuf<uint8_t> pe_scratch;
 	int pe_veryfast = 0;  // State2::m_Method 5
+	int dp_rounds_used = 3;  // rounds of phase 6 in the last single-end call (kernels.h: DpBounds)
+	uint32_t dp_bounds_used[DP_ROUNDS + 1] = {0, 2, 16, 0xFFFFFFFFu, 0xFFFFFFFFu};
 	int pair_info_on = 0;  // -tabbedout: record urmapx_pair_info per pair
 	DevBuf<urmapx_pair_info> pairinfo;
 	DevBuf<uint32_t> ovflist;  // reads queued for the search kernel's second pass
@@ -408,10 +410,18 @@ int urmapx_ctx_round_ms(urmapx_ctx *C, float ms[16], int *rounds) {
 	if (!C || !ms || !rounds) return URMAPX_E_ARG;
 	static_assert(2 * DP_ROUNDS <= 16, "ms[16]");
 	for (int i = 0; i < 16; ++i) ms[i] = 0;
-	*rounds = DP_ROUNDS;
+	*rounds = C->dp_rounds_used;
 	if (!C->stage_valid) return URMAPX_OK;
 	HIP_TRY(hipEventSynchronize(C->stage_ev[STAGE_LAST]));
-	for (int i = 0; i < 2 * DP_ROUNDS; ++i) HIP_TRY(hipEventElapsedTime(&ms[i], C->stage_ev[1 + i], C->stage_ev[2 + i]));
+	for (int i = 0; i < 2 * C->dp_rounds_used; ++i) HIP_TRY(hipEventElapsedTime(&ms[i], C->stage_ev[1 + i], C->stage_ev[2 + i]));
+	return URMAPX_OK;
+}
+
+// the round boundaries of the last single-end call: round rd = a read's HSPs lo[rd] <= k < lo[rd + 1] (the last round is open ended)
+int urmapx_ctx_dp_rounds(urmapx_ctx *C, uint32_t lo[8], int *rounds) {
+	if (!C || !lo || !rounds) return URMAPX_E_ARG;
+	*rounds = C->dp_rounds_used;
+	for (int i = 0; i < 8; ++i) lo[i] = i <= DP_ROUNDS ? C->dp_bounds_used[i] : 0xFFFFFFFFu;
 	return URMAPX_OK;
 }
 
@@ -504,6 +514,27 @@ int urmapx_map_se_device(urmapx_ctx *C, const void *d_bases, const void *d_offs,
 		if (C->fin_blocks[cls] == 0) C->fin_blocks[cls] = fin_block_count(max_read_len, C->device);
 		wk.fin_blocks = C->fin_blocks[cls] > 0 ? C->fin_blocks[cls] : 0;
 		wk.dp_scratch_stride = dp_scratch_stride(max_read_len);
+		// phase 6's rounds: three for reads of up to 192 bases, four beyond (kernels.h); URMAPX_DP_BOUNDS="0,2,8,32" (measurement) sets them
+		wk.dp_bounds = dp_bounds_default(max_read_len > 192);
+		if (const char *e = getenv("URMAPX_DP_BOUNDS")) {
+			DpBounds b;
+			b.rounds = 0;
+			for (const char *c = e; *c && b.rounds < DP_ROUNDS;) {
+				char *end;
+				const unsigned long v = strtoul(c, &end, 10);
+				if (end == c) break;
+				b.lo[b.rounds++] = (uint32_t)v;
+				c = *end == ',' ? end + 1 : end;
+			}
+			bool ok = b.rounds >= 1 && b.lo[0] == 0;
+			for (int i = 1; i < b.rounds; ++i) ok = ok && b.lo[i] > b.lo[i - 1];
+			if (ok) {
+				for (int i = b.rounds; i <= DP_ROUNDS; ++i) b.lo[i] = 0xFFFFFFFFu;
+				wk.dp_bounds = b;
+			}
+		}
+		C->dp_rounds_used = wk.dp_bounds.rounds;
+		for (int i = 0; i <= DP_ROUNDS; ++i) C->dp_bounds_used[i] = wk.dp_bounds.lo[i];
 		if ((rc = C->dpscratch.ensure(wk.dp_scratch_stride * (size_t)wk.dp_blocks))) return rc;
 		wk.dp_scratch = C->dpscratch.p;
 		const uint64_t jc = (uint64_t)n * 16u;  // ~10x what a repeat-rich genome needs; beyond it the search kernel runs phase 6 itself
