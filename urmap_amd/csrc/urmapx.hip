@@ -552,7 +552,7 @@ int urmapx_map_se_device(urmapx_ctx *C, const void *d_bases, const void *d_offs,
 			at[p][6] = need; need += (((size_t)jobs_cap[p] * 4 * DP_ROUNDS) + 63) & ~(size_t)63;
 		}
 		// phase 3 parked (kernels.h: SearchWork::dp3): jobs, their path slices, the parking lot with its larger records.
-		// Off by default: measured on the hg38-scale bench it LOSES 6 % at 150 bases and 4 % at 250 (DESIGN.md 5.0: the first launch gets 1.9 ms
+		// Off by default: measured on the hg38-scale bench it LOSES 6 % at 150 bases and 4 % at 250 (DESIGN.md 5.R5: the first launch gets 1.9 ms
 		// shorter, phase 3's DP launch and the second search launch cost 3.3 ms).  URMAPX_PARK_PHASE3=1 turns it on (tests, measurement).
 		const char *park3 = getenv("URMAPX_PARK_PHASE3");
 		const size_t p3w = (park3 && atoi(park3) > 0) ? p3_state_words(max_read_len) : 0;
