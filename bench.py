@@ -20,6 +20,12 @@ import warnings
 import sys
 import time
 
+# Idle OpenMP workers sleep instead of spinning, as the `urmap` command line sets it (urmap_main.cpp): this process is granted 16 CPUs on the
+# GPU boxes (a cgroup quota) and runs several OpenMP teams -- the oracle's, the pipeline threads' of the file-to-file legs -- whose spinning
+# workers get the whole process throttled (round 5: the file-to-file legs ran at a third of their rate in half of the runs until the
+# library made its own teams sleep; this covers the teams it does not own).  Before any OpenMP runtime is loaded.
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -1122,8 +1128,15 @@ def main():
                 e2e_index = index
                 if R.backend == "nccl" or os.environ.get("URMAP_BENCH_BROADCAST"):
                     # the ranks' replicas came over the broadcast and live in THEIR processes; rank 0's file-to-file run over all devices
-                    # uploads its own from the host arrays (urmapx_index_replicate)
+                    # uploads its own from the host arrays (urmapx_index_replicate).  Rank 0's broadcast copy and its contexts are released
+                    # first (the device held two full indexes for the length of this leg); d_seq stays: the reads are drawn from it
+                    for m in mappers:
+                        m.close()
+                    index.close()
+                    index._keep = ()  # the broadcast slot table (a torch tensor) goes with it
+                    torch.cuda.empty_cache()
                     e2e_index = api.Index.wrap_host(24, 32, slots, blob_np, seq_np, seq_lengths, seq_offsets, labels).upload(dev_index)
+                    out["config"]["ranks"]["e2e_index_chain_row_bytes"] = int(e2e_index.chain_row_bytes())
                 out["e2e"] = run_e2e(torch, api, oi, e2e_index, device, d_seq, seq_lengths, seq_offsets, L, args.sub, args.indel,
                                      int(os.environ.get("URMAP_BENCH_E2E_READS", 2_000_000 * min(world, 8))), cores, ref_bin=None, gpus=world)
             except Exception as e:

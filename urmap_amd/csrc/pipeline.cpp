@@ -693,6 +693,14 @@ DevicePlace place_of_device(int device) {
 	P.ok = CPU_COUNT(&P.cpus) > 0;
 	return P;
 }
+// Idle OpenMP workers must sleep, not spin: the reader, the writer, every lane and the caller each have a team of their own, and libomp's
+// default keeps a team's workers spinning for 200 ms behind every parallel region (KMP_BLOCKTIME).  Three or four teams of 16 spinning
+// threads on a host that grants the process 16 CPUs (a cgroup quota, as on the GPU boxes) get the whole process throttled: the lanes' host
+// threads stall between their launches and a run takes three times as long -- seen in half of the bench runs of round 5 (the command line
+// has always set OMP_WAIT_POLICY=passive for this; a library call cannot count on its caller's environment).  Per thread: it applies to the
+// teams this thread starts.
+inline void omp_workers_sleep_when_idle() { kmp_set_blocktime(0); }
+
 // the calling thread (and the OpenMP team it starts later) onto a device's socket; false: left where it was
 bool pin_to(const DevicePlace &P) { return P.ok && sched_setaffinity(0, sizeof P.cpus, &P.cpus) == 0; }
 
@@ -755,6 +763,7 @@ int map_files_impl(urmapx_index *I, const urmapx_map_options *opt, const InputRa
 	const int host_threads = opt->host_threads > 0 ? opt->host_threads : std::min(16, std::max(1, (int)std::thread::hardware_concurrency()));
 	const int omp_threads_before = omp_get_max_threads();  // this is a library call: the caller's OpenMP setting comes back at the end
 	struct OmpRestore { int n; ~OmpRestore() { omp_set_num_threads(n); } } omp_restore{omp_threads_before};
+	omp_workers_sleep_when_idle();
 	omp_set_num_threads(host_threads);
 	FileSink sink;
 	int write_threads_used = 1;
@@ -932,6 +941,7 @@ int map_files_impl(urmapx_index *I, const urmapx_map_options *opt, const InputRa
 			std::vector<char> carry, carry2, pipe_back, pipe_back2;
 			std::thread treader([&] {
 				if (one_node) (void)pin_to(places[0]);  // the page-locked chunk buffers are first touched here
+				omp_workers_sleep_when_idle();
 				omp_set_num_threads(read_threads);
 				uint64_t off = range.on ? range.lo[0] : 0, off2 = range.on ? range.lo[1] : 0;
 				double bytes2_per_byte1 = 1.0;
@@ -1149,6 +1159,7 @@ int map_files_impl(urmapx_index *I, const urmapx_map_options *opt, const InputRa
 			text_on_device = true;
 			std::thread twriter([&] {
 				if (one_node) (void)pin_to(places[0]);
+				omp_workers_sleep_when_idle();
 				omp_set_num_threads(host_threads);
 				std::unique_ptr<TextJob> j;
 				for (size_t b = 0; tmapped[b % (size_t)n_lanes]->pop(j); ++b) {
@@ -1183,6 +1194,7 @@ int map_files_impl(urmapx_index *I, const urmapx_map_options *opt, const InputRa
 			std::vector<std::thread> tlanes;
 			for (int l = 0; l < n_lanes; ++l)
 				tlanes.emplace_back([&, l] {
+					omp_workers_sleep_when_idle();
 					(void)pin_to(places[(size_t)(l % gpus)]);
 					(void)hipSetDevice(phys(l % gpus));
 					urmapx_text *T = nullptr;
@@ -1294,6 +1306,7 @@ int map_files_impl(urmapx_index *I, const urmapx_map_options *opt, const InputRa
 	std::thread reader2;
 	if (paired)
 		reader2 = std::thread([&] {
+			omp_workers_sleep_when_idle();
 			omp_set_num_threads(std::max(1, host_threads / 2));  // a new thread starts from the default team size, not main's
 			int x;
 			while (go2.pop(x)) {
@@ -1304,6 +1317,7 @@ int map_files_impl(urmapx_index *I, const urmapx_map_options *opt, const InputRa
 			}
 		});
 	std::thread reader([&] {
+		omp_workers_sleep_when_idle();
 		omp_set_num_threads(paired ? std::max(1, host_threads - host_threads / 2) : host_threads);
 		FastqBatch a;
 		for (size_t b = 0; !fail.set.load(); ++b) {
@@ -1325,8 +1339,10 @@ int map_files_impl(urmapx_index *I, const urmapx_map_options *opt, const InputRa
 				if (e.empty()) e = side2.e;
 				if (e.empty() && (more != side2.more || a.size() != bb.size())) e = std::string("Premature end of file in FASTQ") + (a.size() > bb.size() ? "2" : "1");
 				if (e.empty()) {
+					omp_workers_sleep_when_idle();
 					omp_set_num_threads(host_threads);
 					interleave_batches(a, bb, j->reads);
+					omp_workers_sleep_when_idle();
 					omp_set_num_threads(std::max(1, host_threads - host_threads / 2));
 				}
 			}
@@ -1366,6 +1382,7 @@ int map_files_impl(urmapx_index *I, const urmapx_map_options *opt, const InputRa
 		}
 	});
 	std::thread writer([&] {
+		omp_workers_sleep_when_idle();
 		omp_set_num_threads(host_threads);
 		std::unique_ptr<Job> j;
 		std::unique_ptr<Text> text;
@@ -1449,6 +1466,7 @@ int map_files_impl(urmapx_index *I, const urmapx_map_options *opt, const InputRa
 	for (int l = 0; l < n_lanes; ++l)
 		lanes.emplace_back([&, l] {
 			urmapx_ctx *C = ctxs[(size_t)l];
+			omp_workers_sleep_when_idle();
 			(void)pin_to(places[(size_t)(l % gpus)]);
 			(void)hipSetDevice(phys(l % gpus));
 			std::unique_ptr<Job> j;
