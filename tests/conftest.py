@@ -13,6 +13,19 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_finish(session):
+    """A process that uses both torch and liburmapx must let torch initialise the GPU first (the other order can
+    leave torch without a device -- "No HIP GPUs are available").  The full-scale module builds its genome with torch; whichever
+    GPU module the selection starts with, torch goes first."""
+    if any(item.get_closest_marker("gpu") is not None for item in session.items):
+        try:
+            import torch
+            if torch.cuda.is_available():
+                torch.zeros(1, device="cuda")
+        except Exception:
+            pass
+
+
 @pytest.fixture(scope="session")
 def workdir(tmp_path_factory):
     return str(tmp_path_factory.mktemp("urmap"))

@@ -5,12 +5,15 @@
 // a random 5-byte read of a 27 GB table.  One of a read's 254 k-mers nearly always heads a long chain, so the search kernel's
 // chain walk is a dependent sequence of a dozen memory round trips per read and 17 % of its vector instructions (the 64-bit
 // slot arithmetic of every hop).  The table is read-only: every head's row can be written down once.
-//   rowinfo[slot]   u32: row length (low byte) | offset of the row inside its group of 1024 slots << 8; 0 where the slot
-//                   heads no chain (not "mine", or a single-entry PLUS1 / BOTH1 slot, whose row is its own position)
+//   rowinfo[slot]   2 x u32 (round 5): .x = row length (low byte) | offset of the row inside its group of 1024 slots << 8; 0 where the
+//                   slot heads no chain (not "mine", or a single-entry PLUS1 / BOTH1 slot, whose row is its own position);
+//                   .y = the row's SECOND position: with the head's own position (which the probe has already read with the
+//                   slot) a row of two -- 70 % of the rows of an hg38-like table (0.41 G rows hold 0.99 G positions) -- needs
+//                   no read of `rows` at all, and phase 4 of the search (rows of length <= 2) none whatever the read
 //   rowbase[group]  u64: where the rows of the group's heads begin in `rows`
 //   rows            u32: the positions, row after row, in slot order
 // A kernel then needs the head's info word (one random read), the group base (a 40 MB array that lives in L2 / MALL) and the
-// row itself, contiguous: two dependent round trips whatever the chain's length.  34 GB at hg38 scale (21.6 info + 12 rows),
+// row itself, contiguous: two dependent round trips whatever the chain's length.  47 GB at hg38 scale (43.1 info + 4.0 rows),
 // built in under a second; an index whose rows do not fit the device keeps the hop-by-hop walk (DevIndex::rowinfo == nullptr).
 #include "kernels.h"
 
@@ -49,7 +52,7 @@ __device__ __forceinline__ int chain_row(const uint8_t *__restrict__ blob, uint6
 __device__ __forceinline__ bool heads_a_row(uint32_t T) { return (T & TALLY_MY_BIT) != 0 && T != TALLY_BOTH1 && T != TALLY_PLUS1; }
 
 // pass 1: row length of every slot, and their sum per group of 1024 slots
-__global__ __launch_bounds__(CR_GROUP) void rows_len_kernel(const uint8_t *__restrict__ blob, uint64_t N, int maxIx, uint32_t *__restrict__ info,
+__global__ __launch_bounds__(CR_GROUP) void rows_len_kernel(const uint8_t *__restrict__ blob, uint64_t N, int maxIx, uint2 *__restrict__ info,
                                                             uint32_t *__restrict__ groupsum, uint32_t groups) {
 	__shared__ uint32_t wsum[CR_GROUP / 64];
 	// (a launch holds fewer than 2^32 work-items and the table has more slots than that: the blocks loop over the groups)
@@ -60,7 +63,7 @@ __global__ __launch_bounds__(CR_GROUP) void rows_len_kernel(const uint8_t *__res
 			uint32_t T, pos;
 			load_slot(blob, s, T, pos);
 			if (heads_a_row(T)) len = (uint32_t)chain_row(blob, N, maxIx, s, T, pos, nullptr);
-			info[s] = len;
+			info[s] = make_uint2(len, 0u);
 		}
 		uint32_t v = len;
 		for (int d = 32; d; d >>= 1) v += __shfl_xor(v, d, 64);
@@ -76,13 +79,13 @@ __global__ __launch_bounds__(CR_GROUP) void rows_len_kernel(const uint8_t *__res
 }
 
 // pass 2: the info words and the rows
-__global__ __launch_bounds__(CR_GROUP) void rows_fill_kernel(const uint8_t *__restrict__ blob, uint64_t N, int maxIx, uint32_t *__restrict__ info,
+__global__ __launch_bounds__(CR_GROUP) void rows_fill_kernel(const uint8_t *__restrict__ blob, uint64_t N, int maxIx, uint2 *__restrict__ info,
                                                              const uint64_t *__restrict__ rowbase, uint32_t *__restrict__ rows, uint32_t groups) {
 	__shared__ uint32_t wsum[CR_GROUP / 64];
 	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 	for (uint32_t g = blockIdx.x; g < groups; g += gridDim.x) {
 		const uint64_t s = (uint64_t)g * CR_GROUP + threadIdx.x;
-		const uint32_t len = s < N ? info[s] : 0u;
+		const uint32_t len = s < N ? info[s].x : 0u;
 		uint32_t inc = len;  // inclusive prefix inside the wavefront
 		for (int d = 1; d < 64; d <<= 1) {
 			const uint32_t up = __shfl_up(inc, d, 64);
@@ -95,25 +98,27 @@ __global__ __launch_bounds__(CR_GROUP) void rows_fill_kernel(const uint8_t *__re
 		for (int k = 0; k < w; ++k) before += wsum[k];
 		const uint32_t off = before + inc - len;
 		if (s < N && len) {
-			info[s] = (off << 8) | len;
 			uint32_t T, pos;
 			load_slot(blob, s, T, pos);
-			(void)chain_row(blob, N, maxIx, s, T, pos, rows + rowbase[g] + off);
+			uint32_t *const row = rows + rowbase[g] + off;
+			(void)chain_row(blob, N, maxIx, s, T, pos, row);
+			info[s] = make_uint2((off << 8) | len, len > 1 ? row[1] : 0u);  // (this thread wrote the row: its own stores are visible to it)
 		}
 	}
 }
 
 // device arrays of the layout; all three null on return if maxIx is beyond the kernels' row capacity or memory is short
-hipError_t build_chain_rows(const uint8_t *d_blob, uint64_t slot_count, uint32_t max_ix, uint32_t **d_info, uint64_t **d_base, uint32_t **d_rows,
+hipError_t build_chain_rows(const uint8_t *d_blob, uint64_t slot_count, uint32_t max_ix, uint2 **d_info, uint64_t **d_base, uint32_t **d_rows,
                             uint64_t *total_rows) {
 	*d_info = nullptr; *d_base = nullptr; *d_rows = nullptr; *total_rows = 0;
 	if (max_ix > (uint32_t)CR_ROW_CAP || max_ix < 1 || slot_count == 0) return hipSuccess;
 	const uint64_t groups = (slot_count + CR_GROUP - 1) / CR_GROUP;
 	if (groups > 0x7FFFFFFFull) return hipSuccess;
-	uint32_t *info = nullptr, *gsum = nullptr, *rows = nullptr;
+	uint2 *info = nullptr;
+	uint32_t *gsum = nullptr, *rows = nullptr;
 	uint64_t *base = nullptr;
 	auto drop = [&]() { (void)hipFree(info); (void)hipFree(gsum); (void)hipFree(base); (void)hipFree(rows); (void)hipGetLastError(); };
-	if (hipMalloc((void **)&info, slot_count * 4) != hipSuccess || hipMalloc((void **)&gsum, groups * 4) != hipSuccess ||
+	if (hipMalloc((void **)&info, slot_count * sizeof(uint2)) != hipSuccess || hipMalloc((void **)&gsum, groups * 4) != hipSuccess ||
 	    hipMalloc((void **)&base, groups * 8) != hipSuccess) { drop(); return hipSuccess; }  // no room: the kernels walk hop by hop
 	const unsigned grid = (unsigned)(groups < (1u << 20) ? groups : (1u << 20));
 	hipLaunchKernelGGL(rows_len_kernel, dim3(grid), dim3(CR_GROUP), 0, nullptr, d_blob, slot_count, (int)max_ix, info, gsum, (uint32_t)groups);

@@ -22,7 +22,7 @@ struct DevIndex {
 	const uint32_t *seqLengths; // device
 	const uint32_t *seqOffsets; // device
 	// GetRow_Blob's rows laid out once per index (chain_rows.hip); rowinfo == nullptr: not built, the kernels walk hop by hop
-	const uint32_t *rowinfo;    // per slot: row length | offset inside the slot's group of 1024 << 8
+	const uint2 *rowinfo;       // per slot: .x = row length | offset inside the slot's group of 1024 << 8, .y = the row's second position
 	const uint64_t *rowbase;    // per group of 1024 slots: where its rows begin
 	const uint32_t *rows;       // positions, row after row
 };
@@ -171,7 +171,7 @@ hipError_t launch_search_pe_slow(const DevIndex &X, const urmapx_params &P, cons
                                  int all_pairs, hipStream_t s);
 
 // chain_rows.hip: the rows of every chain head of a resident slot table (all three null if they cannot be had)
-hipError_t build_chain_rows(const uint8_t *d_blob, uint64_t slot_count, uint32_t max_ix, uint32_t **d_info, uint64_t **d_base, uint32_t **d_rows,
+hipError_t build_chain_rows(const uint8_t *d_blob, uint64_t slot_count, uint32_t max_ix, uint2 **d_info, uint64_t **d_base, uint32_t **d_rows,
                             uint64_t *total_rows);
 
 // UFIndex::Validate (ufindex.cpp:611-658) over the resident table: out[9] = heads, positions, used slots, slots reached by the

@@ -167,7 +167,10 @@ __global__ __launch_bounds__(64) void viterbi_batch_pair_kernel(urmapx_params P,
 // ------------------------------------------------------------------------------------------------
 // HSP record word: startq | len << 10 | score << 20 | aligned << 30 | plus << 31 (each field <= 1023)
 static constexpr uint32_t PK_MASK = 1023u, PK_LEN_SH = 10, PK_SCORE_SH = 20, PK_ALIGNED = 1u << 30, PK_PLUS_SH = 31;
-static constexpr int HSP_CAP = 256;        // HSPs of a read held in LDS
+#ifndef URX_HSP_CAP
+#define URX_HSP_CAP 256  // build-time experiment (profiles/r5/ab_waves5.txt): 64 frees 1.5 KB of LDS per block
+#endif
+static constexpr int HSP_CAP = URX_HSP_CAP;        // HSPs of a read held in LDS
 static constexpr int SEARCH_OVF_BLOCKS = 2048;  // grid of the second pass (reads whose HSP list outgrew LDS): these are the
                                                 // costliest reads of a batch (hundreds of AlignHSP calls each), so they get most of the chip
 static constexpr int HSP_TOTAL_CAP = 8192;  // beyond that: in the block's global scratch (the reference's list is unbounded;
@@ -893,31 +896,41 @@ struct SearchWave {
 	// longest of the read's chains; this costs one round trip and a dozen instructions per group.
 	__device__ __forceinline__ void rows_fetch(uint64_t (&sl)[NSEG], uint32_t (&T)[NSEG], uint32_t (&ps)[NSEG], bool (&act)[NSEG], int (&rl)[NSEG]) {
 		const int lane = fresh_lane(this->lane);
-		uint32_t info[NSEG];
+		// Round 5: the info entry is two words -- the second is the row's second position.  The first position of a row is the head's
+		// own (the probe read it with the slot), so a row of two needs nothing but this entry, and phase 4 (rows of length <= 2) reads
+		// no `rows` at all: one dependent round trip and one 64-byte sector less per such row.  rowstore: [g] = the row's index in
+		// `rows` (rows of three and more), [NSEG + g] = position 0, [2 NSEG + g] = position 1.
+		uint2 info[NSEG];
+		bool longhead = false;
 #pragma unroll
 		for (int g = 0; g < NSEG; ++g) {
-			info[g] = 0;
+			info[g] = make_uint2(0u, 0u);
 			if (act[g] && T[g] != TALLY_PLUS1) info[g] = X.rowinfo[sl[g]];
+			longhead |= act[g] && T[g] == TALLY_LONG_MINE;
 		}
+		const bool any_long = __ballot(longhead) != 0;  // a head whose own slot holds a long link's steps, not a position: thousands in a table at load 0.95, a hundred at 0.6
 #pragma unroll
 		for (int g = 0; g < NSEG; ++g) {
 			rl[g] = 0;
 			if (act[g]) {
-				if (T[g] == TALLY_PLUS1) {
-					rl[g] = 1;
-					rowstore[(size_t)g * 64 + lane] = 0xFFFFFFFFu;
-					rowstore[(size_t)(NSEG + g) * 64 + lane] = ps[g];
-				} else {
-					rl[g] = (int)(info[g] & 0xFFu);
-					rowstore[(size_t)g * 64 + lane] = (uint32_t)(X.rowbase[sl[g] >> 10] + (info[g] >> 8));
+				uint32_t p0 = ps[g];
+				if (T[g] == TALLY_PLUS1) rl[g] = 1;
+				else {
+					rl[g] = (int)(info[g].x & 0xFFu);
+					uint32_t at = 0;
+					if (rl[g] > 2 || (any_long && T[g] == TALLY_LONG_MINE)) at = (uint32_t)(X.rowbase[sl[g] >> 10] + (info[g].x >> 8));
+					if (any_long && T[g] == TALLY_LONG_MINE) p0 = X.rows[at];  // position 0 of such a row lies in the link's middle slot: the layout has it
+					rowstore[(size_t)g * 64 + lane] = at;
+					rowstore[(size_t)(2 * NSEG + g) * 64 + lane] = info[g].y;
 				}
+				rowstore[(size_t)(NSEG + g) * 64 + lane] = p0;
 			}
 		}
 	}
 	// row entry k of the chain of lane l in group seg (ROWS kernels)
 	__device__ __forceinline__ uint32_t row_entry(int seg, int k, int l) const {
-		const uint32_t at = rowstore[(size_t)seg * 64 + l];
-		return at == 0xFFFFFFFFu ? rowstore[(size_t)(NSEG + seg) * 64 + l] : X.rows[(size_t)at + (uint32_t)k];
+		if (k < 2) return rowstore[(size_t)((k + 1) * NSEG + seg) * 64 + l];
+		return X.rows[(size_t)rowstore[(size_t)seg * 64 + l] + (uint32_t)k];
 	}
 
 	// exclusive prefix over NS segments of per-lane counts -> pre[]; returns the total

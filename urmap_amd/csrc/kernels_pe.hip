@@ -570,23 +570,31 @@ struct Mate {
 				// the rows are looked up in the layout built with the index (chain_rows.hip; search_se_kernel's rows_fetch): the head's
 				// info word gives the row's length and where it lies in X->rows; rowstore[g][lane] keeps that index (0xFFFFFFFF for a
 				// single-entry head, whose row is its own position in rowstore[NG + g][lane]) and the candidate stage reads it there
-				uint32_t info[NG];
+				// (round 5: the info entry carries the row's second position -- rows of two need no read of X->rows; rowstore[NG + g] =
+				// position 0, [2 NG + g] = position 1, [g] = the row's index in X->rows for rows of three and more)
+				uint2 info[NG];
+				bool longhead = false;
 #pragma unroll
 				for (int g = 0; g < NG; ++g) {
-					info[g] = 0;
+					info[g] = make_uint2(0u, 0u);
 					if (wact[g] && wT[g] != TALLY_PLUS1 && wT[g] != TALLY_BOTH1) info[g] = X->rowinfo[wsl[g]];
+					longhead |= wact[g] && wT[g] == TALLY_LONG_MINE;
 				}
+				const bool any_long = __ballot(longhead) != 0;  // a head whose own slot holds a long link's steps, not a position
 #pragma unroll
 				for (int g = 0; g < NG; ++g) {
 					if (!wact[g]) continue;
-					if (wT[g] == TALLY_PLUS1 || wT[g] == TALLY_BOTH1) {
-						wK[g] = 1;
-						rowstore[(size_t)g * 64 + lane] = 0xFFFFFFFFu;
-						rowstore[(size_t)(NG + g) * 64 + lane] = wps[g];
-					} else {
-						wK[g] = (int)(info[g] & 0xFFu);
-						rowstore[(size_t)g * 64 + lane] = (uint32_t)(X->rowbase[wsl[g] >> 10] + (info[g] >> 8));
+					uint32_t p0 = wps[g];
+					if (wT[g] == TALLY_PLUS1 || wT[g] == TALLY_BOTH1) wK[g] = 1;
+					else {
+						wK[g] = (int)(info[g].x & 0xFFu);
+						uint32_t at = 0;
+						if (wK[g] > 2 || (any_long && wT[g] == TALLY_LONG_MINE)) at = (uint32_t)(X->rowbase[wsl[g] >> 10] + (info[g].x >> 8));
+						if (any_long && wT[g] == TALLY_LONG_MINE) p0 = X->rows[at];
+						rowstore[(size_t)g * 64 + lane] = at;
+						rowstore[(size_t)(2 * NG + g) * 64 + lane] = info[g].y;
 					}
+					rowstore[(size_t)(NG + g) * 64 + lane] = p0;
 				}
 				any = false;
 			}
@@ -713,8 +721,8 @@ struct Mate {
 							c_q = pend[s][base + lo];
 							if (X->rowinfo) {
 								const int g = s * NCH + (base >> 6);
-								const uint32_t at = rowstore[(size_t)g * 64 + lo];
-								c_db = at == 0xFFFFFFFFu ? rowstore[(size_t)(2 * NCH + g) * 64 + lo] : X->rows[(size_t)at + (uint32_t)k];
+								c_db = k < 2 ? rowstore[(size_t)((k + 1) * 2 * NCH + g) * 64 + lo]
+								             : X->rows[(size_t)rowstore[(size_t)g * 64 + lo] + (uint32_t)k];
 							} else
 								c_db = rs0[k * 64 + lo];
 							ok = c_db >= c_q;

@@ -39,7 +39,8 @@ struct urmapx_index {
 	const uint8_t *d_blob = nullptr, *d_seq = nullptr;
 	uint4 *d_seqp = nullptr;  // packed copy of d_seq (4 bit planes per 32 bases), always owned, built on the device
 	// GetRow_Blob's rows laid out once (chain_rows.hip), always owned, built on the device; null: not built
-	uint32_t *d_rowinfo = nullptr, *d_rows = nullptr;
+	uint2 *d_rowinfo = nullptr;
+	uint32_t *d_rows = nullptr;
 	uint64_t *d_rowbase = nullptr;
 	uint64_t n_rows = 0;
 	bool own_dev = false;
@@ -200,7 +201,7 @@ static int upload_directory(urmapx_index *I) {
 		const hipError_t e = build_chain_rows(I->d_blob, I->slotCount, I->maxIx, &I->d_rowinfo, &I->d_rowbase, &I->d_rows, &I->n_rows);
 		if (getenv("URMAPX_VERBOSE"))
 			fprintf(stderr, "urmapx: chain rows %s: %llu positions in rows, %.2f GB (hip: %s)\n", I->d_rowinfo ? "built" : "NOT built",
-			        (unsigned long long)I->n_rows, I->d_rowinfo ? (4.0 * (double)I->slotCount + 4.0 * (double)I->n_rows) / 1e9 : 0.0, hipGetErrorString(e));
+			        (unsigned long long)I->n_rows, I->d_rowinfo ? (8.0 * (double)I->slotCount + 4.0 * (double)I->n_rows) / 1e9 : 0.0, hipGetErrorString(e));
 		HIP_TRY(e);
 		//  a replica without the layout maps 15 % slower with the same results: say so once, whoever asked for the upload
 		static bool warned = false;
@@ -284,7 +285,7 @@ void urmapx_index_close(urmapx_index *I) {
 
 // bytes of the chain-row layout resident with the index (0: not built -- URMAPX_NO_CHAIN_ROWS, MaxIx over 32, or no room)
 uint64_t urmapx_index_chain_row_bytes(const urmapx_index *I) {
-	return I && I->d_rowinfo ? 4ull * I->slotCount + 4ull * (I->n_rows + 64) + 8ull * ((I->slotCount + 1023) / 1024) : 0ull;
+	return I && I->d_rowinfo ? 8ull * I->slotCount + 4ull * (I->n_rows + 64) + 8ull * ((I->slotCount + 1023) / 1024) : 0ull;
 }
 int urmapx_index_validate(const urmapx_index *I, urmapx_validate_report *out) {
 	if (!I || !out) return URMAPX_E_ARG;
