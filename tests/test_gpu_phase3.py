@@ -13,7 +13,12 @@ pytestmark = pytest.mark.gpu
 def case(small_case):
     from urmap_amd import api, synth
     from conftest import reads_to_arrays
-    idx = api.Index.open(small_case["ufi"]).upload(0)
+    import os
+    os.environ["URMAPX_KEEP_ROWINFO"] = "1"  # the parked variant looks rows up in the info entries, which an upload otherwise drops once slot16 is built
+    try:
+        idx = api.Index.open(small_case["ufi"]).upload(0)
+    finally:
+        del os.environ["URMAPX_KEEP_ROWINFO"]
     assert idx.chain_row_bytes() > 0  # phase 3 is parked on indexes that carry the row layout
     # indels put an HSP (not a full-length hit) on most reads: phase 3 aligns it
     reads = synth.make_reads(31, small_case["genome"], 2500, read_len=150, sub=0.01, ins=0.004, dele=0.004, random_frac=0.03)

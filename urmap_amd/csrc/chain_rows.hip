@@ -146,6 +146,47 @@ hipError_t build_chain_rows(const uint8_t *d_blob, uint64_t slot_count, uint32_t
 }
 
 
+// ---- the slot table with its rows' heads inline (DevIndex::slot16) ----
+// One thread per slot, from the 5-byte table and the row layout above.
+__global__ __launch_bounds__(256) void slot16_kernel(const uint8_t *__restrict__ blob, uint64_t N, const uint2 *__restrict__ info,
+                                                     const uint64_t *__restrict__ rowbase, const uint32_t *__restrict__ rows, uint4 *__restrict__ out,
+                                                     uint32_t groups) {
+	for (uint32_t g = blockIdx.x; g < groups; g += gridDim.x) {  // (more slots than a launch has work-items)
+		const uint64_t s = (uint64_t)g * 256 + threadIdx.x;
+		if (s >= N) continue;
+		uint32_t T, pos;
+		load_slot(blob, s, T, pos);
+		uint32_t len = 0, x = 0;
+		if ((T & TALLY_MY_BIT) != 0) {
+			if (T == TALLY_BOTH1 || T == TALLY_PLUS1) len = 1;
+			else {
+				const uint2 i = info[s];
+				len = i.x & 0xFFu;
+				const uint64_t at = rowbase[s >> 10] + (i.x >> 8);
+				pos = rows[at];  // the row's first position: the slot's own, except behind a long link (its middle slot's)
+				x = len <= 2 ? i.y : (uint32_t)at;
+			}
+		}
+		out[s] = make_uint4(pos, T | (len << 8), x, 0u);
+	}
+}
+
+// null on return if there is no room for it (16 bytes per slot): the kernels then use the row layout, or walk
+hipError_t build_slot16(const uint8_t *d_blob, uint64_t slot_count, const uint2 *d_info, const uint64_t *d_base, const uint32_t *d_rows, uint4 **d_slot16) {
+	*d_slot16 = nullptr;
+	if (!d_info || !d_base || !d_rows || slot_count == 0) return hipSuccess;
+	uint4 *out = nullptr;
+	if (hipMalloc((void **)&out, (slot_count + 1) * sizeof(uint4)) != hipSuccess) { (void)hipGetLastError(); return hipSuccess; }
+	const uint64_t groups = (slot_count + 255) / 256;
+	hipLaunchKernelGGL(slot16_kernel, dim3((unsigned)(groups < (1u << 20) ? groups : (1u << 20))), dim3(256), 0, nullptr, d_blob, slot_count, d_info, d_base, d_rows,
+	                   out, (uint32_t)groups);
+	hipError_t e = hipGetLastError();
+	if (e == hipSuccess) e = hipDeviceSynchronize();
+	if (e != hipSuccess) { (void)hipFree(out); return e; }
+	*d_slot16 = out;
+	return hipSuccess;
+}
+
 // ---- UFIndex::Validate (ufindex.cpp:611-658) over a resident table ----
 // ValidateSlot for every slot, one thread per slot: a slot whose tally says "mine" heads a row; GetRow_Validate
 // (ufindex.cpp:834-881) collects the row's positions link by link (the head must be "mine", every later link "other", a long

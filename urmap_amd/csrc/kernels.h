@@ -25,6 +25,12 @@ struct DevIndex {
 	const uint2 *rowinfo;       // per slot: .x = row length | offset inside the slot's group of 1024 << 8, .y = the row's second position
 	const uint64_t *rowbase;    // per group of 1024 slots: where its rows begin
 	const uint32_t *rows;       // positions, row after row
+	// Round 5: the slot table as the search kernel wants it (chain_rows.hip: build_slot16), 16 bytes per slot, never straddling a sector:
+	//   .x = the slot's position (for a head whose own slot holds a long link's steps: the row's resolved first position)
+	//   .y = tally | row length << 8 (row length 1 for PLUS1 / BOTH1 heads, 0 for slots that head nothing)
+	//   .z = rows of two: the second position; longer rows: the row's index in `rows`
+	// One gather per k-mer then brings what the probe AND the row lookup need: no rowinfo read, no rowbase read.  nullptr: not built.
+	const uint4 *slot16;
 };
 
 // per-k-mer output of the seed+probe stage, SoA; index = 2*offs[r] + strand*L + qpos
@@ -171,6 +177,7 @@ hipError_t launch_search_pe_slow(const DevIndex &X, const urmapx_params &P, cons
                                  int all_pairs, hipStream_t s);
 
 // chain_rows.hip: the rows of every chain head of a resident slot table (all three null if they cannot be had)
+hipError_t build_slot16(const uint8_t *d_blob, uint64_t slot_count, const uint2 *d_info, const uint64_t *d_base, const uint32_t *d_rows, uint4 **d_slot16);
 hipError_t build_chain_rows(const uint8_t *d_blob, uint64_t slot_count, uint32_t max_ix, uint2 **d_info, uint64_t **d_base, uint32_t **d_rows,
                             uint64_t *total_rows);
 

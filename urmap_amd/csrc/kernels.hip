@@ -225,7 +225,10 @@ __device__ __noinline__ int hsp_overflow_add(uint2 *ovf, int n, int cap, uint32_
 // are mapped again by a launch of their own (0.9 ms); with two words they stay in the first pass, which then runs 1.6 ms
 // longer (such a read is its tail): one word it stays.  The pair kernel keeps two (kernels_pe.hip: -1.5 ms).
 static constexpr int SE_HITW1 = URX_SE_HITW1;
-template <int NCH, bool OVF>
+// LAYOUT 1 (round 5): the slot entries in LDS come out of DevIndex::slot16 -- pr_lo = the slot's position, pr_hi = tally | row length
+// << 8, pr_sl = the row's second position (rows of two) or its index in DevIndex::rows -- instead of the two dwords around the
+// 5-byte slot and the slot number's low half
+template <int NCH, bool OVF, int LAYOUT = 0>
 struct SearchWave {
 	static constexpr int QMAX = 64 * NCH;
 	// rows of the narrow DP's trace buffer: a flank is at most QMAX - W long (the HSP holds the seed), longer problems
@@ -758,6 +761,11 @@ struct SearchWave {
 	uint64_t *pr_hb;
 	__device__ __forceinline__ void probe_get(int s, int q, uint32_t &tally, uint32_t &pos) const {
 		const int e = s * NCH * 64 + (s ? nwords - 1 - q : q);
+		if constexpr (LAYOUT == 1) {
+			pos = pr_lo[e];
+			tally = pr_hi[e] & 0xFFu;
+			return;
+		}
 		const uint32_t lo = pr_lo[e], hi = pr_hi[e], sl = pr_sl[e];
 		const uint64_t v = (((uint64_t)hi << 32) | lo) >> (8u * (sl & 3u));
 		tally = (uint32_t)(v & 0xFFu);
@@ -819,6 +827,15 @@ struct SearchWave {
 				const uint64_t hb = stage_b[2 * g], ok = stage_b[2 * g + 1];
 				const bool v = (ok >> lane) & 1ull;
 				const uint32_t sl = stage_sl[g * 64 + lane];
+				if constexpr (LAYOUT == 1) {
+					// one aligned 16-byte slot of DevIndex::slot16: position, tally | row length, second position or row index
+					const uint64_t slot16 = (uint64_t)sl | (((hb >> lane) & 1ull) << 32);
+					const uint8_t *ap = v ? reinterpret_cast<const uint8_t *>(X.slot16) + 16ull * slot16 : reinterpret_cast<const uint8_t *>(g_zero16);
+					glds_dword(ap, lds_addr(pr_lo + g * 64));
+					glds_dword(ap + 4, lds_addr(pr_hi + g * 64));
+					glds_dword(ap + 8, lds_addr(pr_sl + g * 64));
+					continue;
+				}
 #ifdef URX_FAULT_SLOT32  // fault injection for the test suite's own check (profiles/r5/fault_slot32.txt): the slot number cut to 32 bits
 				const uint64_t slot = (uint64_t)sl; (void)hb;
 #else
@@ -844,6 +861,18 @@ struct SearchWave {
 			const int s2 = g / NCH, c = g % NCH;
 			const int p = 64 * c + lane;
 			T[g] = 0; ps[g] = 0; sl[g] = 0;
+			if constexpr (LAYOUT == 1) {
+				// sl carries what rows_fetch needs instead of a slot number: row length | (second position or row index) << 32
+				if (p < nwords) {
+					const int e = s2 * NCH * 64 + (s2 ? nwords - 1 - p : p);
+					const uint32_t hi = pr_hi[e];
+					ps[g] = pr_lo[e];
+					T[g] = hi & 0xFFu;
+					sl[g] = (uint64_t)((hi >> 8) & 0xFFu) | ((uint64_t)pr_sl[e] << 32);
+				}
+				act[g] = (T[g] & TALLY_MY_BIT) != 0 && T[g] != TALLY_BOTH1;
+				continue;
+			}
 			if (p < nwords) probe_get(s2, p, T[g], ps[g]);
 			act[g] = (T[g] & TALLY_MY_BIT) != 0 && T[g] != TALLY_BOTH1;
 			if (act[g]) {
@@ -900,6 +929,19 @@ struct SearchWave {
 		// own (the probe read it with the slot), so a row of two needs nothing but this entry, and phase 4 (rows of length <= 2) reads
 		// no `rows` at all: one dependent round trip and one 64-byte sector less per such row.  rowstore: [g] = the row's index in
 		// `rows` (rows of three and more), [NSEG + g] = position 0, [2 NSEG + g] = position 1.
+		if constexpr (LAYOUT == 1) {
+			// everything came with the probe (DevIndex::slot16): no read at all.  rowstore[g] = second position (rows of two) or the row's
+			// index in `rows`, [NSEG + g] = position 0
+#pragma unroll
+			for (int g = 0; g < NSEG; ++g) {
+				rl[g] = act[g] ? (int)(sl[g] & 0xFFu) : 0;
+				if (act[g]) {
+					rowstore[(size_t)g * 64 + lane] = (uint32_t)(sl[g] >> 32);
+					rowstore[(size_t)(NSEG + g) * 64 + lane] = ps[g];
+				}
+			}
+			return;
+		}
 		uint2 info[NSEG];
 		bool longhead = false;
 #pragma unroll
@@ -928,7 +970,13 @@ struct SearchWave {
 		}
 	}
 	// row entry k of the chain of lane l in group seg (ROWS kernels)
-	__device__ __forceinline__ uint32_t row_entry(int seg, int k, int l) const {
+	// short_row: the row has at most two entries (the candidate belongs to phase 4's half of the list)
+	__device__ __forceinline__ uint32_t row_entry(int seg, int k, int l, bool short_row) const {
+		if constexpr (LAYOUT == 1) {
+			if (k == 0) return rowstore[(size_t)(NSEG + seg) * 64 + l];
+			const uint32_t x = rowstore[(size_t)seg * 64 + l];
+			return short_row ? x : X.rows[(size_t)x + (uint32_t)k];
+		}
 		if (k < 2) return rowstore[(size_t)((k + 1) * NSEG + seg) * 64 + l];
 		return X.rows[(size_t)rowstore[(size_t)seg * 64 + l] + (uint32_t)k];
 	}
@@ -989,7 +1037,8 @@ struct SearchWave {
 // state for PART 2) and a read that finds no room for its phase-6 jobs goes to the second pass -- no banded DP in this kernel;
 // 2 = the second launch: the reads PART 1 parked at phase 3, from the replay of AlignHSP's bookkeeping over their jobs onwards
 // (phases 4-5, then parked for phase 6 like any other read).  n = the batch's reads (PART 2: read from dp3's counter).
-template <int NCH, bool OVF, bool DBG, bool ROWS = false, int PART = 0>
+// ROWS: 0 = chains walked hop by hop, 1 = rows looked up in the row layout (rows_fetch), 2 = everything with the probe (DevIndex::slot16)
+template <int NCH, bool OVF, bool DBG, int ROWS = 0, int PART = 0>
 __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel(DevIndex X, urmapx_params P, const uint8_t *__restrict__ bases,
                                                        const uint64_t *__restrict__ offs, uint32_t n,
                                                        urmapx_result *__restrict__ results,
@@ -999,9 +1048,9 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
                                                        const uint4 *__restrict__ g_seqp,
                                                        uint32_t *ticket, int hsp_lds_cap, uint32_t *ovf_list, uint2 *hsp_ovf_base,
                                                        DpWork dp, DpWork dp3) {
-	static_assert(PART == 0 || (!OVF && !DBG), "phase 3 is parked by the production first pass only");
+	static_assert(PART == 0 || (!OVF && !DBG && ROWS == 1), "phase 3 is parked by the production first pass only");
 	// stats != nullptr (URMAPX_PHASE_STATS): per-phase shader cycles are accumulated into stats (u64 each, from byte 8)
-	using SW = SearchWave<NCH, OVF>;
+	using SW = SearchWave<NCH, OVF, ROWS == 2 ? 1 : 0>;
 	constexpr int NQ_BYTES = ((SW::QMAX + 4 + 255) / 256) * 256;  // the next read's bytes from a 4-byte aligned address on, in 256-byte DMA pieces
 	__shared__ __attribute__((aligned(16))) uint8_t sQ2[2 * SW::QMAX];  // plus strand, then reverse complement
 	uint8_t *const sQp = sQ2, *const sQm = sQ2 + SW::QMAX;
@@ -1256,7 +1305,7 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 				if (PART != 2 && next_ok) S.probe_gather(nQL, stage_sl, stage_b);
 				if (PART == 2 && next_ok && !fetched) { fetch_bytes(noff, nQL); fetched = true; }
 				if (!go) break;
-				if constexpr (ROWS) S.rows_fetch(wsl, wT, wps, wact, rl);
+				if constexpr (ROWS != 0) S.rows_fetch(wsl, wT, wps, wact, rl);
 				else S.walk_run(wsl, wT, wps, wact, rl);
 				URX_SYNC();
 				lapc(3);
@@ -1359,10 +1408,11 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 						} else {  // chain rows: [strand][chunk][k][lane]
 							int seg = row >> 6;
 							const int l = row & 63;
+							const bool short_row = seg < SW::NSEG;  // the list's first half: rows of at most two (phase 4)
 							if (seg >= SW::NSEG) seg -= SW::NSEG;
 							s_plus = seg < NCH;
 							s_qpos = (uint32_t)((seg - (s_plus ? 0 : NCH)) * 64 + l);
-							if constexpr (ROWS) s_db = S.row_entry(seg, k, l);
+							if constexpr (ROWS != 0) s_db = S.row_entry(seg, k, l, short_row);
 							else s_db = S.rowstore[((size_t)seg * ROW_CAP + k) * 64 + l];
 						}
 						ok = s_db >= s_qpos;  // extendpen.cpp:12-13
@@ -2380,6 +2430,10 @@ hipError_t launch_search_se(const DevIndex &X, const urmapx_params &P, const uin
 	hipLaunchKernelGGL((search_se_kernel<NCH_, false, false, true>), GRID_, block, 0, s, X, P, d_bases, d_offs, n, d_results,          \
 	                   d_path_ops, d_path_used, STATS_, wk.scratch, wk.scratch_stride, X.seq, X.blob, X.seqp, wk.ticket,         \
 	                   wk.hsp_lds_cap, wk.ovf_list, OVFBASE_, DP_, no_dp)
+#define URX_LAUNCH_SE_S16(NCH_, GRID_, OVFBASE_, DP_)                                                                               \
+	hipLaunchKernelGGL((search_se_kernel<NCH_, false, false, 2>), GRID_, block, 0, s, X, P, d_bases, d_offs, n, d_results,            \
+	                   d_path_ops, d_path_used, no_stats3, wk.scratch, wk.scratch_stride, X.seq, X.blob, X.seqp, wk.ticket,          \
+	                   wk.hsp_lds_cap, wk.ovf_list, OVFBASE_, DP_, no_dp)
 	// phase 3 parked (round 5): the first launch (PART 1: no banded DP inside), phase 3's flank DPs (every job made, no round lists),
 	// the second launch over the reads parked there (PART 2; wk.ticket + 2: a work counter of its own)
 #define URX_LAUNCH_SE_P3(NCH_)                                                                                                      \
@@ -2424,6 +2478,12 @@ hipError_t launch_search_se(const DevIndex &X, const urmapx_params &P, const uin
 	else if (p3 && nch == 3) URX_LAUNCH_SE_P3(3);
 	else if (p3 && nch == 4) URX_LAUNCH_SE_P3(4);
 	else if (p3) URX_LAUNCH_SE_P3(5);
+	else if (!diag && X.slot16 && wk.stats == nullptr && nch == 2) URX_LAUNCH_SE_S16(2, grid, no_ovf, wk.dp[0]);  // slots, row lengths and second positions in one gather
+	else if (!diag && X.slot16 && wk.stats == nullptr && nch == 3) URX_LAUNCH_SE_S16(3, grid, no_ovf, wk.dp[0]);
+	else if (!diag && X.slot16 && wk.stats == nullptr && nch == 4) URX_LAUNCH_SE_S16(4, grid, no_ovf, wk.dp[0]);
+	else if (!diag && X.slot16 && wk.stats == nullptr && nch == 5) URX_LAUNCH_SE_S16(5, grid, no_ovf, wk.dp[0]);
+	else if (!diag && X.slot16 && wk.stats == nullptr && nch == 8) URX_LAUNCH_SE_S16(8, grid, no_ovf, wk.dp[0]);
+	else if (!diag && X.slot16 && wk.stats == nullptr && nch == 16) URX_LAUNCH_SE_S16(16, grid, no_ovf, wk.dp[0]);
 	else if (diag && nch == 3) URX_LAUNCH_SE(3, false, true, grid, wk.stats, no_ovf, no_dp);
 	else if (diag) URX_LAUNCH_SE(4, false, true, grid, wk.stats, no_ovf, no_dp);
 	else if (nch == 2 && X.rowinfo) URX_LAUNCH_SE_ROWS(2, grid, wk.stats, no_ovf, wk.dp[0]);  // the chain rows are looked up in the layout built with the index
@@ -2477,6 +2537,7 @@ hipError_t launch_search_se(const DevIndex &X, const urmapx_params &P, const uin
 #undef URX_LAUNCH_SE
 #undef URX_LAUNCH_SE_ROWS
 #undef URX_LAUNCH_SE_P3
+#undef URX_LAUNCH_SE_S16
 #undef URX_LAUNCH_DP
 	return hipGetLastError();
 }

@@ -557,16 +557,36 @@ struct Mate {
 				// HBM that every pair had written); its tally and position from the table again
 				if (wact[g]) wsl[g] = slot_from_planes<NCH + 1>(*X, (lds_ptr<const uint64_t>)&L->kpl[0][0], (uint32_t)nwords, st, pend[st][i]);
 			}
+			// round 5: with DevIndex::slot16 the head's slot brings its row's length and second position (or the row's index) along:
+			// one read per pending k-mer instead of slot + info entry + group base
+			const bool s16 = X->slot16 != nullptr;
+			uint32_t wx[NG];
 #pragma unroll
-			for (int g = 0; g < NG; ++g)
-				if (wact[g]) load_slot(gblob, wsl[g], wT[g], wps[g]);
+			for (int g = 0; g < NG; ++g) {
+				wx[g] = 0;
+				if (!wact[g]) continue;
+				if (s16) {
+					const uint4 v = X->slot16[wsl[g]];
+					wps[g] = v.x; wT[g] = v.y & 0xFFu; wK[g] = (int)((v.y >> 8) & 0xFFu); wx[g] = v.z;
+				} else
+					load_slot(gblob, wsl[g], wT[g], wps[g]);
+			}
 #pragma unroll
 			for (int g = 0; g < NG; ++g) {
 				wact[g] = wact[g] && (wT[g] & TALLY_MY_BIT) != 0;  // GetRow_Blob returns 0 for a slot that is not "mine"
 				any |= wact[g];
 			}
 			const bool lookup = X->rowinfo != nullptr;
-			if (lookup) {
+			if (s16) {
+				// rowstore[g] = second position (rows of two) or the row's index in X->rows, [NG + g] = position 0; wK is the row's length
+#pragma unroll
+				for (int g = 0; g < NG; ++g) {
+					if (!wact[g]) { wK[g] = 0; continue; }
+					rowstore[(size_t)g * 64 + lane] = wx[g];
+					rowstore[(size_t)(NG + g) * 64 + lane] = wps[g];
+				}
+				any = false;
+			} else if (lookup) {
 				// the rows are looked up in the layout built with the index (chain_rows.hip; search_se_kernel's rows_fetch): the head's
 				// info word gives the row's length and where it lies in X->rows; rowstore[g][lane] keeps that index (0xFFFFFFFF for a
 				// single-entry head, whose row is its own position in rowstore[NG + g][lane]) and the candidate stage reads it there
@@ -719,7 +739,14 @@ struct Mate {
 							}
 							const int k = g - (int)pre[lo];
 							c_q = pend[s][base + lo];
-							if (X->rowinfo) {
+							if (X->slot16) {
+								const int g = s * NCH + (base >> 6);
+								if (k == 0) c_db = rowstore[(size_t)(2 * NCH + g) * 64 + lo];
+								else {
+									const uint32_t x = rowstore[(size_t)g * 64 + lo];
+									c_db = round == 0 ? x : X->rows[(size_t)x + (uint32_t)k];  // round 0: rows of at most two
+								}
+							} else if (X->rowinfo) {
 								const int g = s * NCH + (base >> 6);
 								c_db = k < 2 ? rowstore[(size_t)((k + 1) * 2 * NCH + g) * 64 + lo]
 								             : X->rows[(size_t)rowstore[(size_t)g * 64 + lo] + (uint32_t)k];

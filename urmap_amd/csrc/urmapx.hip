@@ -41,6 +41,7 @@ struct urmapx_index {
 	// GetRow_Blob's rows laid out once (chain_rows.hip), always owned, built on the device; null: not built
 	uint2 *d_rowinfo = nullptr;
 	uint32_t *d_rows = nullptr;
+	uint4 *d_slot16 = nullptr;  // the slot table with the rows' heads inline (chain_rows.hip), always owned; null: not built
 	uint64_t *d_rowbase = nullptr;
 	uint64_t n_rows = 0;
 	bool own_dev = false;
@@ -53,7 +54,7 @@ struct urmapx_index {
 		X.shiftMask = (W >= 32) ? ~0ull : ((1ull << (2 * W)) - 1ull);
 		X.W = W; X.maxIx = maxIx; X.seqDataSize = seqDataSize; X.seqCount = (uint32_t)labels.size();
 		X.seqLengths = d_seqLengths; X.seqOffsets = d_seqOffsets;
-		X.rowinfo = d_rowinfo; X.rowbase = d_rowbase; X.rows = d_rows;
+		X.rowinfo = d_rowinfo; X.rowbase = d_rowbase; X.rows = d_rows; X.slot16 = d_slot16;
 		return X;
 	}
 };
@@ -200,12 +201,25 @@ static int upload_directory(urmapx_index *I) {
 	if (!getenv("URMAPX_NO_CHAIN_ROWS")) {
 		const hipError_t e = build_chain_rows(I->d_blob, I->slotCount, I->maxIx, &I->d_rowinfo, &I->d_rowbase, &I->d_rows, &I->n_rows);
 		if (getenv("URMAPX_VERBOSE"))
-			fprintf(stderr, "urmapx: chain rows %s: %llu positions in rows, %.2f GB (hip: %s)\n", I->d_rowinfo ? "built" : "NOT built",
+			fprintf(stderr, "urmapx: chain rows %s: %llu positions in rows, %.2f GB (hip: %s)\n", I->d_rows ? "built" : "NOT built",
 			        (unsigned long long)I->n_rows, I->d_rowinfo ? (8.0 * (double)I->slotCount + 4.0 * (double)I->n_rows) / 1e9 : 0.0, hipGetErrorString(e));
 		HIP_TRY(e);
+		// round 5: the 16-byte slot table for the single-end search kernel (86 GB at hg38 scale; URMAPX_NO_SLOT16=1: not built)
+		if (I->d_rowinfo && !getenv("URMAPX_NO_SLOT16")) {
+			const hipError_t e2 = build_slot16(I->d_blob, I->slotCount, I->d_rowinfo, I->d_rowbase, I->d_rows, &I->d_slot16);
+			if (getenv("URMAPX_VERBOSE")) fprintf(stderr, "urmapx: slot16 table %s (%.2f GB)\n", I->d_slot16 ? "built" : "NOT built", 16.0 * (double)I->slotCount / 1e9);
+			HIP_TRY(e2);
+			// The per-slot info entries and the group bases have done their work once slot16 holds what they said (43 GB at hg38 scale):
+			// every kernel that looks rows up reads slot16 then.  They stay for the one user that still wants them, the parked
+			// phase 3 (URMAPX_PARK_PHASE3, measurement), and on request (URMAPX_KEEP_ROWINFO).
+			if (I->d_slot16 && !getenv("URMAPX_PARK_PHASE3") && !getenv("URMAPX_KEEP_ROWINFO")) {
+				(void)hipFree(I->d_rowinfo); I->d_rowinfo = nullptr;
+				(void)hipFree(I->d_rowbase); I->d_rowbase = nullptr;
+			}
+		}
 		//  a replica without the layout maps 15 % slower with the same results: say so once, whoever asked for the upload
 		static bool warned = false;
-		if (!I->d_rowinfo && !warned) {
+		if (!I->d_rowinfo && !I->d_slot16 && !warned) {
 			warned = true;
 			fprintf(stderr, "urmapx: the chain-row layout of the index was not built on device %d (no room for it, or MaxIx over 32): "
 			                "collision chains are walked link by link\n", I->device);
@@ -273,6 +287,7 @@ void urmapx_index_close(urmapx_index *I) {
 	if (!I) return;
 	if (I->own_dev) { (void)hipFree((void *)I->d_blob); (void)hipFree((void *)I->d_seq); }
 	if (I->d_seqp) (void)hipFree(I->d_seqp);
+	if (I->d_slot16) (void)hipFree(I->d_slot16);
 	if (I->d_rowinfo) (void)hipFree(I->d_rowinfo);
 	if (I->d_rowbase) (void)hipFree(I->d_rowbase);
 	if (I->d_rows) (void)hipFree(I->d_rows);
@@ -285,7 +300,9 @@ void urmapx_index_close(urmapx_index *I) {
 
 // bytes of the chain-row layout resident with the index (0: not built -- URMAPX_NO_CHAIN_ROWS, MaxIx over 32, or no room)
 uint64_t urmapx_index_chain_row_bytes(const urmapx_index *I) {
-	return I && I->d_rowinfo ? 8ull * I->slotCount + 4ull * (I->n_rows + 64) + 8ull * ((I->slotCount + 1023) / 1024) : 0ull;
+	if (!I) return 0ull;
+	return (I->d_rowinfo ? 8ull * I->slotCount + 8ull * ((I->slotCount + 1023) / 1024) : 0ull) + (I->d_rows ? 4ull * (I->n_rows + 64) : 0ull) +
+	       (I->d_slot16 ? 16ull * (I->slotCount + 1) : 0ull);
 }
 int urmapx_index_validate(const urmapx_index *I, urmapx_validate_report *out) {
 	if (!I || !out) return URMAPX_E_ARG;
