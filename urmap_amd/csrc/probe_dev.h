@@ -156,7 +156,15 @@ __device__ __forceinline__ void probe_pair(const DevIndex &X, const uint8_t *__r
 #pragma unroll
 		for (int c = 0; c < NCH; ++c) {
 			rp[a][c][0] = rp[a][c][1] = rm[a][c][0] = rm[a][c][1] = 0;
-			if (64u * c < nwords) {  // lanes without a valid word fetch slot 0 (one cached sector) and drop it
+			if (64u * c < nwords && X.slot16) {
+				// round 5: the 16-byte slots of DevIndex::slot16 -- aligned (never two sectors), position and tally in their first two
+				// dwords without the 5-byte unpack.  (A head behind a long link shows its row's resolved first position there, not the
+				// link's steps: the seed enumeration reads positions of BOTH1 slots only.)
+				const uint2 qp = *reinterpret_cast<const uint2 *>(X.slot16 + (vp[a][c] ? sp[a][c] : 0ull));
+				const uint2 qm = *reinterpret_cast<const uint2 *>(X.slot16 + (vm[a][c] ? sm[a][c] : 0ull));
+				rp[a][c][0] = qp.x; rp[a][c][1] = qp.y;
+				rm[a][c][0] = qm.x; rm[a][c][1] = qm.y;
+			} else if (64u * c < nwords) {  // lanes without a valid word fetch slot 0 (one cached sector) and drop it
 				const uint64_t ap = vp[a][c] ? 5ull * sp[a][c] : 0ull, am = vm[a][c] ? 5ull * sm[a][c] : 0ull;
 				const uint32_t *qp = reinterpret_cast<const uint32_t *>(X.blob + (ap & ~3ull));
 				const uint32_t *qm = reinterpret_cast<const uint32_t *>(X.blob + (am & ~3ull));
@@ -172,8 +180,11 @@ __device__ __forceinline__ void probe_pair(const DevIndex &X, const uint8_t *__r
 		for (int c = 0; c < NCH; ++c) {
 			const uint32_t p = 64u * c + lane;
 			if (p < nwords) {
-				const uint64_t xp = (((uint64_t)rp[a][c][1] << 32) | rp[a][c][0]) >> (8u * (uint32_t)((5ull * sp[a][c]) & 3ull));
-				const uint64_t xm = (((uint64_t)rm[a][c][1] << 32) | rm[a][c][0]) >> (8u * (uint32_t)((5ull * sm[a][c]) & 3ull));
+				// (tally in the low byte, position above it: slot16's {position, tally | ...} is brought into the 5-byte slot's shape)
+				const uint64_t xp = X.slot16 ? (((uint64_t)rp[a][c][0] << 8) | (rp[a][c][1] & 0xFFu))
+				                             : (((uint64_t)rp[a][c][1] << 32) | rp[a][c][0]) >> (8u * (uint32_t)((5ull * sp[a][c]) & 3ull));
+				const uint64_t xm = X.slot16 ? (((uint64_t)rm[a][c][0] << 8) | (rm[a][c][1] & 0xFFu))
+				                             : (((uint64_t)rm[a][c][1] << 32) | rm[a][c][0]) >> (8u * (uint32_t)((5ull * sm[a][c]) & 3ull));
 				const uint32_t pm = QL[a] - W - p;  // minus-strand position of the k-mer over the same bases
 				const uint8_t tp = vp[a][c] ? (uint8_t)(xp & 0xFF) : (uint8_t)TALLY_FREE, tm = vm[a][c] ? (uint8_t)(xm & 0xFF) : (uint8_t)TALLY_FREE;
 				const uint32_t pp = vp[a][c] ? (uint32_t)(xp >> 8) : 0xFFFFFFFFu, pmn = vm[a][c] ? (uint32_t)(xm >> 8) : 0xFFFFFFFFu;
