@@ -659,6 +659,44 @@ E2E_STREAMS = int(os.environ.get("URMAP_BENCH_E2E_STREAMS", 2))  # mapping conte
 E2E_BATCH = int(os.environ.get("URMAP_BENCH_E2E_BATCH", 0))      # reads per chunk (0: the library chooses: 262 144 .. 1 M by the size of the file)
 
 
+def _cgroup_cpu():
+    """cpu.stat of this process's cgroup (v2): periods in which the CPU quota ran out, and for how long its threads were stopped"""
+    out = {}
+    for path in ("/sys/fs/cgroup/cpu.stat", "/sys/fs/cgroup/cpu/cpu.stat"):  # v2, v1
+        try:
+            for line in open(path):
+                k, v = line.split()
+                if k in ("nr_periods", "nr_throttled", "throttled_usec", "usage_usec"):
+                    out[k] = int(v)
+                elif k == "throttled_time":  # v1: nanoseconds
+                    out["throttled_usec"] = int(v) // 1000
+            break
+        except (OSError, ValueError):
+            continue
+    return out
+
+
+def watched(fn):
+    """fn() with what the host side did meanwhile: CPU seconds of this process, the cgroup's throttled periods / time"""
+    c0, t0, w0 = _cgroup_cpu(), os.times(), time.time()
+    rep = fn()
+    c1, t1, w1 = _cgroup_cpu(), os.times(), time.time()
+    rep["host"] = {"process_cpu_s": round((t1.user - t0.user) + (t1.system - t0.system), 3), "call_wall_s": round(w1 - w0, 3),
+                   "cgroup_throttled_periods": c1.get("nr_throttled", 0) - c0.get("nr_throttled", 0),
+                   "cgroup_throttled_ms": round((c1.get("throttled_usec", 0) - c0.get("throttled_usec", 0)) / 1e3, 1),
+                   "cgroup_cpu_s": round((c1.get("usage_usec", 0) - c0.get("usage_usec", 0)) / 1e6, 3)}
+    return rep
+
+
+def lane_view(rep):
+    """where the lanes' time went in one urmapx_map_files run (seconds summed over lanes)"""
+    return {"stream_time_s": {k[4:-2]: round(rep[k], 3) for k in ("dev_h2d_s", "dev_parse_s", "dev_map_s", "dev_format_s", "dev_d2h_s")},
+            "map_search_s": round(rep["dev_map_search_s"], 3), "map_dp_finalize_s": round(rep["dev_map_dp_s"], 3),
+            "map_enqueue_host_s": round(rep["map_enqueue_s"], 3), "lane_busy_s": round(rep["gpu_s"], 3),
+            "alloc": {"device_s": round(rep["alloc_dev_s"], 3), "device_calls": rep["alloc_dev_calls"], "pinned_s": round(rep["alloc_pinned_s"], 3), "pinned_calls": rep["alloc_pinned_calls"]},
+            "host": rep.get("host")}
+
+
 def run_e2e(torch, api, oi, index, device, d_seq, seq_lengths, seq_offsets, L, sub, indel, n_reads, cores, ref_bin=None, gpus=1):
     """FASTQ file -> SAM file through urmapx_map_files (the command line's cmd_map) on the resident index: what a user of
     `urmap -map` gets, index load excluded as the reference reports it.  Files live in /dev/shm (memory), so this is the
@@ -679,7 +717,7 @@ def run_e2e(torch, api, oi, index, device, d_seq, seq_lengths, seq_offsets, L, s
         del reads
         runs = []
         for _ in range(2):  # the second run has its buffers and the page cache warm; both are reported
-            rep = api.map_files(index, fq, samout=sam, first_gpu=device.index, gpus=gpus, streams=E2E_STREAMS, batch=E2E_BATCH, cmdline="bench.py e2e")
+            rep = watched(lambda: api.map_files(index, fq, samout=sam, first_gpu=device.index, gpus=gpus, streams=E2E_STREAMS, batch=E2E_BATCH, cmdline="bench.py e2e"))
             runs.append(rep)
         rep = runs[-1]
         oi.map_file_se(fq_head, sam_o, threads=cores)
@@ -703,12 +741,13 @@ def run_e2e(torch, api, oi, index, device, d_seq, seq_lengths, seq_offsets, L, s
         bound, shares = e2e_bound(rep)
         # the same run with the SAM text dropped after it has reached the host: what the device lanes sustain when the output
         # medium is out of the way, and where a lane's time goes (events on the lanes' streams)
-        null_rep = [api.map_files(index, fq, samout=sam + ".null", first_gpu=device.index, gpus=gpus, streams=E2E_STREAMS, batch=E2E_BATCH,
-                                  cmdline="bench.py e2e", discard_sam=True) for _ in range(2)][-1]
+        null_rep = [watched(lambda: api.map_files(index, fq, samout=sam + ".null", first_gpu=device.index, gpus=gpus, streams=E2E_STREAMS, batch=E2E_BATCH,
+                                                  cmdline="bench.py e2e", discard_sam=True)) for _ in range(2)][-1]
         lanes = max(1, null_rep["lanes"])
         null_sink = {"value": round(null_rep["reads"] / null_rep["seconds"], 1), "unit": "reads/s", "seconds": round(null_rep["seconds"], 3),
                      "lanes": lanes, "lane_busy_s_summed": round(null_rep["gpu_s"], 3),
                      "stream_time_s_summed_over_lanes": {k[4:-2]: round(null_rep[k], 3) for k in ("dev_h2d_s", "dev_parse_s", "dev_map_s", "dev_format_s", "dev_d2h_s")},
+                     "lanes_view": lane_view(null_rep),
                      "note": "urmapx_map_files with discard_sam: FASTQ bytes to the device, SAM bytes back to the host, nothing written; "
                              "stream times from HIP events per chunk (copy in, line ends + record checks + base copy, mapping kernels, SAM lengths + text, copy out), "
                              "summed over the chunks of all lanes: divide by `lanes` for the wall share"}
@@ -717,11 +756,12 @@ def run_e2e(torch, api, oi, index, device, d_seq, seq_lengths, seq_offsets, L, s
         for p in [sam + f".sh.{k}" for k in range(n_shards)]:
             if os.path.exists(p):
                 os.remove(p)
-        sh_rep = [api.map_files(index, fq, samout=sam + ".sh", first_gpu=device.index, gpus=gpus, streams=E2E_STREAMS, batch=E2E_BATCH,
-                                cmdline="bench.py e2e", sam_shards=n_shards) for _ in range(2)][-1]
+        sh_rep = [watched(lambda: api.map_files(index, fq, samout=sam + ".sh", first_gpu=device.index, gpus=gpus, streams=E2E_STREAMS, batch=E2E_BATCH,
+                                                cmdline="bench.py e2e", sam_shards=n_shards)) for _ in range(2)][-1]
         sharded = {"value": round(sh_rep["reads"] / sh_rep["seconds"], 1), "unit": "reads/s", "seconds": round(sh_rep["seconds"], 3), "shards": n_shards,
                    "vs_one_file": round((sh_rep["reads"] / sh_rep["seconds"]) / (rep["reads"] / rep["seconds"]), 3),
                    "cat_of_shards_equals_the_one_file": files_equal_concat(sam, [sam + f".sh.{k}" for k in range(n_shards)]),
+                   "lanes_view": lane_view(sh_rep),
                    "note": f"urmap -samout out.sam -samshards {n_shards}: shard s = the s-th part of the input (cut at a record), its own reader, "
                            f"lanes and writer{'' if gpus > 1 else ' (here: two pipelines on the one GPU)'}; header in shard 0"}
         for k in range(n_shards):
@@ -739,6 +779,7 @@ def run_e2e(torch, api, oi, index, device, d_seq, seq_lengths, seq_offsets, L, s
                        f"(format_s 0 = no host formatting; write_s = one thread's pwrite into tmpfs, the stage that bounds the run)",
                "stage_busy_s": {k: round(rep[k], 3) for k in ("parse_s", "gpu_s", "format_s", "write_s")},
                "mapped_q10_frac": round(rep["mapped_q"] / max(1, rep["reads"]), 4),
+               "lanes_view": lane_view(rep), "first_run_lanes_view": lane_view(runs[0]),
                "placement": rep["placement"].decode(),  # NUMA node of each device's PCI function = where its lane threads ran (@any: not pinned)
                "sam_records_identical_to_oracle": bool(same), "sam_records_checked": len(want),
                "null_sink": null_sink, "sharded": sharded}

@@ -326,6 +326,11 @@ typedef struct urmapx_map_report {  /* State1::HitStats' counters (state1.cpp:59
 	                                                  * of the pipeline share one node */
 	double shard_scan_s;                             /* sam_shards: seconds spent cutting the input at record starts (pairs: counting the lines that
 	                                                  * place the cuts of the mates' file); inside `seconds` */
+	double dev_map_search_s, dev_map_dp_s;           /* of dev_map_s (single-end): the search launches; phase 6's dp + finalize launches */
+	double map_enqueue_s;                            /* host seconds the lanes spent enqueueing mapping launches (a lane thread that is not scheduled shows here) */
+	double alloc_dev_s, alloc_pinned_s;              /* seconds all threads of the call spent in hipMalloc / hipFree of the lanes' device arrays, and in
+	                                                  * hipHostMalloc / hipHostFree of page-locked chunk buffers (kept for the next call: 0 calls when warm) */
+	uint32_t alloc_dev_calls, alloc_pinned_calls;
 } urmapx_map_report;
 /* fastq2 NULL: single-end (-map); else the mates' file (-map2 ... -reverse).  samout / tabout may be NULL.  The index
  * needs its host arrays, or to be resident on first_gpu already (then gpus must be 1).  Batch b is mapped on device
@@ -354,12 +359,15 @@ typedef struct urmapx_text urmapx_text;
 #define URMAPX_TEXT_TOO_LARGE 6   /* chunk over 1 GiB, or its SAM text over 4 GiB */
 #define URMAPX_TEXT_UNEQUAL 7     /* pairs: the two chunks do not hold the same number of records */
 #define URMAPX_TEXT_INTERNAL 8    /* the device formatter's two passes disagreed on a record length (never expected): text not used */
+#define URMAPX_TEXT_DEFERRED 9    /* urmapx_text_set_deferred: the chunk is mapped and counted, its text is on its way (urmapx_text_wait) */
 typedef struct urmapx_text_report {
 	uint32_t records;   /* reads of the chunk */
 	uint32_t reason;    /* URMAPX_TEXT_*; non-zero: nothing was written */
 	uint64_t sam_bytes; /* bytes of SAM text (written, or needed when reason is URMAPX_TEXT_SAM_CAP) */
 	uint64_t mapped_q, mapped_lowq, unmapped, unsupported; /* State1::HitStats' counters (output1.cpp:20-30) against minq */
 	float ms_h2d, ms_parse, ms_map, ms_format, ms_d2h;     /* the chunk on its stream, by events: copy in, parse, map, SAM text, copy out */
+	float ms_map_search, ms_map_dp;                        /* of ms_map (single-end): the search launch; phase 6's dp + finalize launches */
+	float ms_map_enqueue;                                  /* host time spent enqueueing the mapping launches (no wait inside: all of it is the calling thread) */
 } urmapx_text_report;
 /* One per mapping context; calls on it run on the context's stream (one thread at a time per context). */
 int urmapx_text_create(urmapx_ctx *, urmapx_text **out);
@@ -372,6 +380,15 @@ int urmapx_text_map_se(urmapx_text *, const char *fastq, size_t fastq_bytes, uns
  * pair).  -tabbedout lines: urmapx_text_fetch_pairs + urmapx_tab_pe. */
 int urmapx_text_map_pe(urmapx_text *, const char *fastq1, size_t fastq1_bytes, const char *fastq2, size_t fastq2_bytes,
                        unsigned minq, char *sam, size_t sam_cap, urmapx_text_report *report);
+/* The copy back as a stage of its own.  With deferred on, urmapx_text_map_se / _pe / _fetch_sam return once the chunk's SAM text
+ * has been made on the device and its copy to `sam` has been ENQUEUED on a second stream (report.reason URMAPX_TEXT_DEFERRED;
+ * records, sam_bytes, the counters and ms_h2d / ms_parse / ms_map* are final), so that the caller can hand the context its next
+ * chunk while the text crosses PCIe; urmapx_text_wait then waits for the OLDEST such copy and returns that chunk's final report
+ * (reason 0 or URMAPX_TEXT_INTERNAL, ms_format, ms_d2h) -- only then may `sam` be read.  At most two chunks are in flight per
+ * context: map(i), map(i+1), wait(i), map(i+2), wait(i+1) ...; a third map call before a wait returns URMAPX_E_ARG.
+ * Round 5: a lane of urmapx_map_files runs this way (the reference has no counterpart: its threads write records as they finish). */
+int urmapx_text_set_deferred(urmapx_text *, int on);
+int urmapx_text_wait(urmapx_text *, urmapx_text_report *report);
 /* After URMAPX_TEXT_SAM_CAP: the text of the chunk just mapped into a buffer of at least report.sam_bytes (the search is
  * not run again).  URMAPX_E_ARG if no such chunk is waiting. */
 int urmapx_text_fetch_sam(urmapx_text *, char *sam, size_t sam_cap, urmapx_text_report *report);

@@ -60,6 +60,52 @@ def test_chunks_cut_at_record_ends_concatenate_to_the_whole(golden):
     assert golden["mapper"].map_text_se(b"")[1]["records"] == 0
 
 
+def test_copy_back_deferred_two_chunks_in_flight(golden):
+    """urmapx_text_set_deferred: chunk i + 1 goes in before chunk i's text is waited for (what a lane of urmapx_map_files does).
+    Chunks of different sizes (the device's SAM array grows under way), one rejected chunk in between, one whose buffer is too
+    small (urmapx_text_fetch_sam, deferred too), an empty one: every chunk's bytes equal the one-at-a-time call's; a third
+    chunk before a wait is refused."""
+    import ctypes as C
+    from urmap_amd import api
+    m = golden["mapper"]
+    fq = open(os.path.join(GOLD, "se150.fq"), "rb").read()
+    lines = fq.split(b"\n")[:-1]
+    cuts = [0, 4 * 11, 4 * 12, 4 * 90, 4 * 91, 4 * 300, len(lines)]
+    chunks = [b"\n".join(lines[a:b]) + b"\n" for a, b in zip(cuts, cuts[1:]) if b > a]
+    chunks.insert(3, b"@r\r\nACGT\r\n+\r\nIIII\r\n")  # '\r': the device parser hands it back, no text is on its way for it
+    chunks.insert(5, b"")
+    want = [m.map_text_se(c) for c in chunks]
+    caps = [None] * len(chunks)
+    caps[2] = 4096  # far too small for 78 records
+    got = m.map_text_se_stream(chunks, sam_caps=caps)
+    assert len(got) == len(want)
+    for i, ((gs, gr), (ws, wr)) in enumerate(zip(got, want)):
+        assert gr["reason"] == wr["reason"], (i, gr, wr)
+        if wr["reason"] == api.TEXT_OK:
+            assert (gs or b"") == (ws or b""), i
+            assert gr["records"] == wr["records"] and gr["sam_bytes"] == wr["sam_bytes"] and gr["mapped_q"] == wr["mapped_q"]
+    assert got[3][1]["reason"] == api.TEXT_CR
+    # twice in a row, and the plain call still works afterwards
+    assert [g[0] for g in m.map_text_se_stream(chunks[:3])] == [w[0] for w in want[:3]]
+    assert m.map_text_se(chunks[0])[0] == want[0][0]
+    # a third chunk while two are in flight is refused; waiting makes room
+    L = api.lib()
+    assert L.urmapx_text_set_deferred(m._text, 1) == 0
+    bufs = [np.empty(2 * len(chunks[0]) + 4096 * 64, np.uint8) for _ in range(3)]
+    src = np.frombuffer(chunks[0], np.uint8)
+    rep = api.TextReport()
+    for k in range(2):
+        assert L.urmapx_text_map_se(m._text, src.ctypes.data, len(src), 10, bufs[k].ctypes.data, len(bufs[k]), C.byref(rep)) == 0
+        assert rep.reason == api.TEXT_DEFERRED
+    assert L.urmapx_text_map_se(m._text, src.ctypes.data, len(src), 10, bufs[2].ctypes.data, len(bufs[2]), C.byref(rep)) == api.E_ARG
+    assert L.urmapx_text_set_deferred(m._text, 0) == api.E_ARG  # not while texts are on their way
+    for k in range(2):
+        assert L.urmapx_text_wait(m._text, C.byref(rep)) == 0 and rep.reason == api.TEXT_OK
+        assert bufs[k][: rep.sam_bytes].tobytes() == want[0][0]
+    assert L.urmapx_text_wait(m._text, C.byref(rep)) == api.E_ARG  # nothing left to wait for
+    assert L.urmapx_text_set_deferred(m._text, 0) == 0
+
+
 def _fastq_text(reads, labels=None):
     out = []
     for i, (lab, s, q) in enumerate(reads):

@@ -33,7 +33,7 @@ EXPORTS = (
     "urmapx_seed_probe", "urmapx_seed_probe_device", "urmapx_viterbi_batch", "urmapx_strerror", "urmapx_device_arch",
     "urmapx_make_ufi", "urmapx_make_ufi_opts", "urmapx_build_slots", "urmapx_make_ufi_gpu", "urmapx_build_slots_gpu", "urmapx_sam_se", "urmapx_sam_header_sq", "urmapx_ctx_phase_cycles", "urmapx_ctx_read_cycles", "urmapx_ctx_stage_ms", "urmapx_ctx_phase3", "urmapx_ctx_round_ms", "urmapx_ctx_dp_rounds", "urmapx_ctx_dp_stats", "urmapx_map_pe", "urmapx_sam_pe", "urmapx_map_pe_device", "urmapx_ctx_set_pe_veryfast",
     "urmapx_gunzip_file", "urmapx_fastq_open", "urmapx_fastq_next", "urmapx_fastq_error", "urmapx_fastq_close",
-    "urmapx_ctx_gather_microbench", "urmapx_map_files", "urmapx_host_pool_trim", "urmapx_text_create", "urmapx_text_destroy", "urmapx_text_map_se", "urmapx_text_map_pe", "urmapx_text_fetch_sam", "urmapx_text_fetch_pairs", "urmapx_ctx_set_pair_info", "urmapx_ctx_get_pair_info", "urmapx_tab_pe",
+    "urmapx_ctx_gather_microbench", "urmapx_map_files", "urmapx_host_pool_trim", "urmapx_text_create", "urmapx_text_destroy", "urmapx_text_map_se", "urmapx_text_map_pe", "urmapx_text_fetch_sam", "urmapx_text_set_deferred", "urmapx_text_wait", "urmapx_text_fetch_pairs", "urmapx_ctx_set_pair_info", "urmapx_ctx_get_pair_info", "urmapx_tab_pe",
 )
 
 
@@ -60,7 +60,9 @@ class MapReport(C.Structure):
                 ("format_s", C.c_double), ("write_s", C.c_double), ("host_threads", C.c_int), ("lanes", C.c_int),
                 ("write_threads", C.c_int), ("text_on_device", C.c_int), ("input_bytes", C.c_uint64), ("medium", C.c_char * 24),
                 ("dev_h2d_s", C.c_double), ("dev_parse_s", C.c_double), ("dev_map_s", C.c_double), ("dev_format_s", C.c_double),
-                ("dev_d2h_s", C.c_double), ("shards", C.c_int), ("placement", C.c_char * 256), ("shard_scan_s", C.c_double)]
+                ("dev_d2h_s", C.c_double), ("shards", C.c_int), ("placement", C.c_char * 256), ("shard_scan_s", C.c_double),
+                ("dev_map_search_s", C.c_double), ("dev_map_dp_s", C.c_double), ("map_enqueue_s", C.c_double),
+                ("alloc_dev_s", C.c_double), ("alloc_pinned_s", C.c_double), ("alloc_dev_calls", C.c_uint32), ("alloc_pinned_calls", C.c_uint32)]
 
 
 class ValidateReport(C.Structure):
@@ -71,10 +73,11 @@ class ValidateReport(C.Structure):
 class TextReport(C.Structure):
     _fields_ = [("records", C.c_uint32), ("reason", C.c_uint32), ("sam_bytes", C.c_uint64), ("mapped_q", C.c_uint64),
                 ("mapped_lowq", C.c_uint64), ("unmapped", C.c_uint64), ("unsupported", C.c_uint64),
-                ("ms_h2d", C.c_float), ("ms_parse", C.c_float), ("ms_map", C.c_float), ("ms_format", C.c_float), ("ms_d2h", C.c_float)]
+                ("ms_h2d", C.c_float), ("ms_parse", C.c_float), ("ms_map", C.c_float), ("ms_format", C.c_float), ("ms_d2h", C.c_float),
+                ("ms_map_search", C.c_float), ("ms_map_dp", C.c_float), ("ms_map_enqueue", C.c_float)]
 
 
-TEXT_OK, TEXT_CR, TEXT_RAGGED, TEXT_BAD_RECORD, TEXT_LONG_NAME, TEXT_SAM_CAP, TEXT_TOO_LARGE, TEXT_UNEQUAL, TEXT_INTERNAL = range(9)
+TEXT_OK, TEXT_CR, TEXT_RAGGED, TEXT_BAD_RECORD, TEXT_LONG_NAME, TEXT_SAM_CAP, TEXT_TOO_LARGE, TEXT_UNEQUAL, TEXT_INTERNAL, TEXT_DEFERRED = range(10)
 
 
 class UrmapxError(RuntimeError):
@@ -163,6 +166,8 @@ def lib():
     L.urmapx_text_map_se.argtypes = [vp, vp, C.c_size_t, C.c_uint, vp, C.c_size_t, C.POINTER(TextReport)]
     L.urmapx_text_map_pe.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, C.c_uint, vp, C.c_size_t, C.POINTER(TextReport)]
     L.urmapx_text_fetch_sam.argtypes = [vp, vp, C.c_size_t, C.POINTER(TextReport)]
+    L.urmapx_text_set_deferred.argtypes = [vp, C.c_int]
+    L.urmapx_text_wait.argtypes = [vp, C.POINTER(TextReport)]
     L.urmapx_fastq_open.argtypes = [cp, C.POINTER(vp)]
     L.urmapx_fastq_next.restype = C.c_int64
     L.urmapx_fastq_next.argtypes = [vp, u32] + [C.POINTER(vp)] * 5
@@ -603,6 +608,47 @@ class Mapper:
         if rep.reason != TEXT_OK:
             return None, d
         return out[: rep.sam_bytes].tobytes(), d
+
+    def map_text_se_stream(self, chunks, minq=10, sam_caps=None):
+        """Chunks of one FASTQ file through the context with the copy back deferred (urmapx_text_set_deferred): chunk i + 1 is handed
+        over before chunk i's text is waited for, as a lane of urmapx_map_files does.  -> [(SAM text | None, report dict)] per chunk.
+        sam_caps[i] (optional): the buffer offered for chunk i; too small -> urmapx_text_fetch_sam into a larger one, deferred too."""
+        if self._text is None:
+            t = C.c_void_p()
+            _check(lib().urmapx_text_create(self.h, C.byref(t)), "urmapx_text_create")
+            self._text = t
+        _check(lib().urmapx_text_set_deferred(self._text, 1), "urmapx_text_set_deferred")
+        res, prev = [], None
+
+        def finish(item):
+            out, d0 = item
+            if d0["reason"] != TEXT_DEFERRED:
+                return (b"" if d0["reason"] == TEXT_OK else None), d0
+            rep = TextReport()
+            _check(lib().urmapx_text_wait(self._text, C.byref(rep)), "urmapx_text_wait")
+            d = {k: (int(getattr(rep, k)) if not k.startswith("ms_") else float(getattr(rep, k))) for k, _ in TextReport._fields_}
+            return (out[: rep.sam_bytes].tobytes() if rep.reason == TEXT_OK else None), d
+
+        try:
+            for i, fastq in enumerate(chunks):
+                src = np.frombuffer(fastq, dtype=np.uint8)
+                cap = sam_caps[i] if sam_caps is not None and sam_caps[i] is not None else 2 * len(src) + 4096 * 64
+                out = np.empty(max(1, cap), dtype=np.uint8)
+                rep = TextReport()
+                _check(lib().urmapx_text_map_se(self._text, src.ctypes.data if len(src) else None, len(src), minq, out.ctypes.data, cap, C.byref(rep)),
+                       "urmapx_text_map_se")
+                if rep.reason == TEXT_SAM_CAP:
+                    out = np.empty(int(rep.sam_bytes) + 64, dtype=np.uint8)
+                    _check(lib().urmapx_text_fetch_sam(self._text, out.ctypes.data, len(out), C.byref(rep)), "urmapx_text_fetch_sam")
+                d = {k: int(getattr(rep, k)) for k, _ in TextReport._fields_}
+                if prev is not None:
+                    res.append(finish(prev))
+                prev = (out, d)
+            if prev is not None:
+                res.append(finish(prev))
+        finally:
+            _check(lib().urmapx_text_set_deferred(self._text, 0), "urmapx_text_set_deferred")
+        return res
 
     def fetch_text_sam(self, sam_cap):
         """After map_text_se returned TEXT_SAM_CAP: the text of that chunk (the search is not run again)."""

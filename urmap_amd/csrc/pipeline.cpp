@@ -44,6 +44,7 @@
 #include <vector>
 
 #include "../../include/urmapx.h"
+#include "internal.h"
 #include "sam.h"
 
 using namespace urx;
@@ -297,6 +298,7 @@ public:
 		if (const char *e = getenv("URMAPX_TEST_PINNED_ALLOCS")) {  // tests: the (N+1)-th fresh allocation of the process fails
 			if (fresh_.fetch_add(1) >= (uint64_t)atoll(e)) return nullptr;
 		}
+		AllocTimer at(1);
 		if (hipHostMalloc((void **)&p, want, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
 		cap = want;
 		return p;
@@ -307,6 +309,7 @@ public:
 			std::lock_guard<std::mutex> l(m_);
 			if (held_ + cap <= kKeep) { free_.push_back(Buf{p, cap}); held_ += cap; return; }
 		}
+		AllocTimer at(1);
 		(void)hipHostFree(p);
 	}
 	void trim() {
@@ -326,6 +329,68 @@ private:
 	std::vector<Buf> free_;
 	size_t held_ = 0;
 	std::atomic<uint64_t> fresh_{0};
+};
+
+// A lane's mapping context and text stage are kept for the next urmapx_map_files call on the same index and device: their
+// device arrays (2.5-3 GB per lane: DpJobs, parked states, path arena, the chunk's text both ways) are otherwise allocated in
+// the first chunk of every call and freed at its end, and on a device that has just freed as much, hipMalloc has been measured
+// at 27 ms a call instead of 0.2 (48 of them per lane: 0.6 s in front of a 0.3 s run; profiles/r5/e2e_watch.txt).
+// urmapx_index_close destroys the lanes of its index, urmapx_host_pool_trim all of them; URMAPX_NO_LANE_POOL=1 keeps none.
+struct PooledLane {
+	const urmapx_index *I;
+	int device;
+	urmapx_params P;
+	bool veryfast, pair_info;
+	urmapx_ctx *C;
+	urmapx_text *T;
+};
+class LanePool {
+public:
+	static LanePool &get() { static LanePool *p = new LanePool; return *p; }  // never destroyed, like the page-locked pool
+	static bool enabled() {
+		if (getenv("URMAPX_NO_LANE_POOL")) return false;
+		for (char **e = environ; e && *e; ++e)
+			if (!strncmp(*e, "URMAPX_TEST_", 12) || !strncmp(*e, "URMAPX_DEBUG_", 13)) return false;  // contexts cache what such knobs decide
+		return true;
+	}
+	bool take(const urmapx_index *I, int device, const urmapx_params &P, bool veryfast, bool pair_info, urmapx_ctx *&C, urmapx_text *&T) {
+		std::lock_guard<std::mutex> l(m_);
+		for (size_t i = 0; i < v_.size(); ++i) {
+			const PooledLane &q = v_[i];
+			if (q.I == I && q.device == device && q.veryfast == veryfast && q.pair_info == pair_info && !memcmp(&q.P, &P, sizeof P)) {
+				C = q.C; T = q.T;
+				v_.erase(v_.begin() + (long)i);
+				return true;
+			}
+		}
+		return false;
+	}
+	void give(const PooledLane &q) {
+		{
+			std::lock_guard<std::mutex> l(m_);
+			if (v_.size() < kMax) { v_.push_back(q); return; }
+		}
+		destroy(q);
+	}
+	void purge(const urmapx_index *I) {
+		std::vector<PooledLane> out;
+		{
+			std::lock_guard<std::mutex> l(m_);
+			for (size_t i = 0; i < v_.size();)
+				if (!I || v_[i].I == I) { out.push_back(v_[i]); v_.erase(v_.begin() + (long)i); }
+				else ++i;
+		}
+		for (const PooledLane &q : out) destroy(q);
+	}
+	static void destroy(const PooledLane &q) {
+		if (q.T) urmapx_text_destroy(q.T);
+		if (q.C) urmapx_ctx_destroy(q.C);
+	}
+
+private:
+	static constexpr size_t kMax = 8;
+	std::mutex m_;
+	std::vector<PooledLane> v_;
 };
 
 // one chunk of the text phase: FASTQ bytes in, SAM bytes out, both page-locked
@@ -727,8 +792,20 @@ int map_files_impl(urmapx_index *I, const urmapx_map_options *opt, const InputRa
 	const int n_lanes = gpus * streams;
 	std::vector<urmapx_index *> replicas((size_t)gpus, nullptr);
 	std::vector<urmapx_ctx *> ctxs((size_t)n_lanes, nullptr);
+	std::vector<urmapx_text *> texts((size_t)n_lanes, nullptr);  // a lane's text stage: from the pool, or made by the lane's thread
+	const bool pool_lanes = LanePool::enabled();
+	const bool lane_veryfast = paired && opt->veryfast, lane_pair_info = paired && tabout != nullptr;
+	bool run_ok = false;  // set at the end of a run without failure: only then are the lanes worth keeping
 	auto release = [&]() {
-		for (urmapx_ctx *C : ctxs) urmapx_ctx_destroy(C);
+		for (int l = 0; l < n_lanes; ++l) {
+			urmapx_ctx *C = ctxs[(size_t)l];
+			urmapx_text *T = texts[(size_t)l];
+			// (a lane of the caller's own index only: the other devices' replicas are closed below.  set_deferred refuses while a text is on its way)
+			if (C && pool_lanes && run_ok && l % gpus == 0 && replicas[0] == I && (!T || urmapx_text_set_deferred(T, 0) == URMAPX_OK))
+				LanePool::get().give(PooledLane{I, phys(0), P, lane_veryfast, lane_pair_info, C, T});
+			else LanePool::destroy(PooledLane{I, 0, P, false, false, C, T});
+			ctxs[(size_t)l] = nullptr; texts[(size_t)l] = nullptr;
+		}
 		for (int g = 1; g < gpus; ++g) urmapx_index_close(replicas[(size_t)g]);
 	};
 	{
@@ -744,6 +821,7 @@ int map_files_impl(urmapx_index *I, const urmapx_map_options *opt, const InputRa
 			if (rcs[(size_t)g]) { say(std::string("Uploading index to the GPU: ") + urmapx_strerror(rcs[(size_t)g])); release(); return rcs[(size_t)g]; }
 	}
 	for (int l = 0; l < n_lanes; ++l) {
+		if (pool_lanes && l % gpus == 0 && LanePool::get().take(I, phys(0), P, lane_veryfast, lane_pair_info, ctxs[(size_t)l], texts[(size_t)l])) continue;
 		rc = urmapx_ctx_create(replicas[(size_t)(l % gpus)], phys(l % gpus), &P, &ctxs[(size_t)l]);
 		if (!rc && paired && opt->veryfast) rc = urmapx_ctx_set_pe_veryfast(ctxs[(size_t)l], 1);
 		if (!rc && paired && tabout) rc = urmapx_ctx_set_pair_info(ctxs[(size_t)l], 1);
@@ -815,7 +893,7 @@ int map_files_impl(urmapx_index *I, const urmapx_map_options *opt, const InputRa
 	Trace trace;
 	unsigned long long n_reads = 0, n_accept = 0, n_reject = 0, n_nohit = 0, n_unsupported = 0;
 	double t_parse = 0, t_gpu = 0, t_format = 0, t_write = 0;  // busy seconds per stage
-	double dev_ms[5] = {0, 0, 0, 0, 0};  // a lane's stream time by events: copy in, parse, map, SAM text, copy out (text phase)
+	double dev_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // a lane's stream time by events: copy in, parse, map, SAM text, copy out (text phase)
 	auto now = [] { return std::chrono::steady_clock::now(); };
 	auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
 	std::mutex gpu_time_lock;
@@ -895,7 +973,7 @@ int map_files_impl(urmapx_index *I, const urmapx_map_options *opt, const InputRa
 				tparsed.emplace_back(new TextChannel(1));
 				tmapped.emplace_back(new TextChannel(1));
 			}
-			const int n_jobs = 2 * n_lanes + 2;
+			const int n_jobs = 3 * n_lanes + 2;  // per lane: one waiting for it, one being mapped, one whose text is crossing PCIe; reader, writer
 			TextChannel tfree((size_t)n_jobs);
 			for (int k = 0; k < n_jobs; ++k) tfree.push(std::make_unique<TextJob>());
 			std::atomic<bool> stop{false};
@@ -1185,6 +1263,7 @@ int map_files_impl(urmapx_index *I, const urmapx_map_options *opt, const InputRa
 						n_reads += j->rep.records; n_accept += j->rep.mapped_q; n_reject += j->rep.mapped_lowq;
 						n_nohit += j->rep.unmapped; n_unsupported += j->rep.unsupported;
 						dev_ms[0] += j->rep.ms_h2d; dev_ms[1] += j->rep.ms_parse; dev_ms[2] += j->rep.ms_map; dev_ms[3] += j->rep.ms_format; dev_ms[4] += j->rep.ms_d2h;
+						dev_ms[5] += j->rep.ms_map_search; dev_ms[6] += j->rep.ms_map_dp; dev_ms[7] += j->rep.ms_map_enqueue;
 						lines_done += (paired ? 2ull : 4ull) * j->rep.records;
 						input_bytes += j->nbytes + j->nbytes2;
 					}
@@ -1197,15 +1276,32 @@ int map_files_impl(urmapx_index *I, const urmapx_map_options *opt, const InputRa
 					omp_workers_sleep_when_idle();
 					(void)pin_to(places[(size_t)(l % gpus)]);
 					(void)hipSetDevice(phys(l % gpus));
-					urmapx_text *T = nullptr;
+					urmapx_text *T = texts[(size_t)l];
 					const double tc = trace.ms();
-					const int trc = urmapx_text_create(ctxs[(size_t)l], &T);
+					const int trc = T ? URMAPX_OK : urmapx_text_create(ctxs[(size_t)l], &T);
+					texts[(size_t)l] = T;  // released with the lane's context (kept for the next call, or destroyed)
 					trace.add("create", l, 0, tc);
 					size_t nj = 0;
 					double sam_per_fastq = 1.12;
 					if (trc == URMAPX_E_NOMEM) text_nomem.store(true);  // T stays null: this lane's chunks go back unmapped
 					else if (trc) fail.raise(trc, std::string("urmapx_text_create: ") + urmapx_strerror(trc));
-					std::unique_ptr<TextJob> j;
+					// The copy back is a stage of its own (urmapx_text_set_deferred): chunk i's text crosses PCIe while the lane's stream takes
+					// chunk i + 1 in and maps it; the lane waits for chunk i's copy when chunk i + 1 has been enqueued to its end.
+					// URMAPX_NO_DEFERRED_COPY=1 (measurement): every chunk is waited for before the next is taken.
+					const bool defer = T && !getenv("URMAPX_NO_DEFERRED_COPY") && urmapx_text_set_deferred(T, 1) == URMAPX_OK;
+					auto ok_so_far = [](const TextJob &q) { return !q.rc && (q.rep.reason == 0 || q.rep.reason == URMAPX_TEXT_DEFERRED); };
+					auto hand_on = [&](std::unique_ptr<TextJob> &q) {
+						if (!q->rc && q->rep.reason == URMAPX_TEXT_DEFERRED) {
+							const auto tw0 = now();
+							const double ta = trace.ms();
+							q->rc = urmapx_text_wait(T, &q->rep);
+							trace.add("wait", l, 0, ta);
+							std::lock_guard<std::mutex> g(gpu_time_lock);
+							t_gpu += secs(tw0, now());
+						}
+						tmapped[(size_t)l]->push(std::move(q));
+					};
+					std::unique_ptr<TextJob> j, prev;
 					while (tparsed[(size_t)l]->pop(j)) {
 						memset(&j->rep, 0, sizeof j->rep);
 						j->rc = 0;
@@ -1223,9 +1319,9 @@ int map_files_impl(urmapx_index *I, const urmapx_map_options *opt, const InputRa
 								if (!TextJob::grow(j->out, j->out_cap, (size_t)j->rep.sam_bytes + j->rep.sam_bytes / 16 + (1u << 20))) j->rc = URMAPX_E_NOMEM;
 								else j->rc = urmapx_text_fetch_sam(T, j->out, j->out_cap, &j->rep);
 							}
-							if (!j->rc && !j->rep.reason && fq_bytes) sam_per_fastq = (double)j->rep.sam_bytes / (double)fq_bytes;
+							if (ok_so_far(*j) && fq_bytes && j->rep.records) sam_per_fastq = (double)j->rep.sam_bytes / (double)fq_bytes;
 							j->tab.clear();
-							if (!j->rc && !j->rep.reason && ftab && j->rep.records) {
+							if (ok_so_far(*j) && ftab && j->rep.records) {
 								const uint32_t np = j->rep.records / 2;
 								j->tab_res.resize((size_t)2 * np); j->tab_info.resize(np); j->tab_ends.resize((size_t)4 * np); j->tab_lens2.resize(np);
 								j->rc = urmapx_text_fetch_pairs(T, np, j->tab_res.data(), j->tab_info.data(), j->tab_ends.data(), j->tab_lens2.data());
@@ -1255,13 +1351,13 @@ int map_files_impl(urmapx_index *I, const urmapx_map_options *opt, const InputRa
 							t_gpu += secs(tg0, now());
 						} else
 							j->rep.reason = 0xFFFFu;  // not mapped: the phase is ending
-						tmapped[(size_t)l]->push(std::move(j));
+						if (prev) hand_on(prev);
+						if (defer) prev = std::move(j);
+						else tmapped[(size_t)l]->push(std::move(j));
 						++nj;
 					}
+					if (prev) hand_on(prev);
 					tmapped[(size_t)l]->close();
-					const double td = trace.ms();
-					urmapx_text_destroy(T);
-					trace.add("destroy", l, 0, td);
 				});
 			for (auto &t : tlanes) t.join();
 			treader.join();
@@ -1518,6 +1614,7 @@ int map_files_impl(urmapx_index *I, const urmapx_map_options *opt, const InputRa
 	range.t_begin = std::chrono::duration<double>(t1.time_since_epoch()).count();
 	range.t_end = std::chrono::duration<double>(t2.time_since_epoch()).count();
 	trace.dump();
+	run_ok = !fail.set.load();
 	release();
 	if (report) {
 		report->reads = n_reads; report->mapped_q = n_accept; report->mapped_lowq = n_reject; report->unmapped = n_nohit;
@@ -1528,6 +1625,7 @@ int map_files_impl(urmapx_index *I, const urmapx_map_options *opt, const InputRa
 		snprintf(report->medium, sizeof report->medium, "%s", have_sam ? medium_name.c_str() : "none");
 		report->dev_h2d_s = dev_ms[0] * 1e-3; report->dev_parse_s = dev_ms[1] * 1e-3; report->dev_map_s = dev_ms[2] * 1e-3;
 		report->dev_format_s = dev_ms[3] * 1e-3; report->dev_d2h_s = dev_ms[4] * 1e-3;
+		report->dev_map_search_s = dev_ms[5] * 1e-3; report->dev_map_dp_s = dev_ms[6] * 1e-3; report->map_enqueue_s = dev_ms[7] * 1e-3;
 		report->shards = 1;
 		snprintf(report->placement, sizeof report->placement, "%s", placement.c_str());
 	}
@@ -1540,8 +1638,22 @@ int map_files_impl(urmapx_index *I, const urmapx_map_options *opt, const InputRa
 // cmd_map / cmd_map2 as a library call; with sam_shards > 1 as that many pipelines side by side, each over its part of the
 // input with its own SAM file, devices and writer (the reference appends every record to one file under one lock,
 // output1.cpp:10-16: one output stream is what bounds a run on several GPUs)
+static int map_files_entry(urmapx_index *I, const urmapx_map_options *opt, const char *fastq1, const char *fastq2,
+                           const char *samout, const char *tabout, urmapx_map_report *report, char *err, size_t errcap);
 extern "C" int urmapx_map_files(urmapx_index *I, const urmapx_map_options *opt, const char *fastq1, const char *fastq2,
                                 const char *samout, const char *tabout, urmapx_map_report *report, char *err, size_t errcap) {
+	// what the call spent in allocation calls (all of its threads): device arrays of the lanes' contexts, page-locked chunk buffers
+	AllocClock &ac = alloc_clock();
+	const uint64_t ns0[2] = {ac.ns[0].load(), ac.ns[1].load()}, c0[2] = {ac.calls[0].load(), ac.calls[1].load()};
+	const int rc = map_files_entry(I, opt, fastq1, fastq2, samout, tabout, report, err, errcap);
+	if (report) {
+		report->alloc_dev_s = (double)(ac.ns[0].load() - ns0[0]) * 1e-9; report->alloc_pinned_s = (double)(ac.ns[1].load() - ns0[1]) * 1e-9;
+		report->alloc_dev_calls = (uint32_t)(ac.calls[0].load() - c0[0]); report->alloc_pinned_calls = (uint32_t)(ac.calls[1].load() - c0[1]);
+	}
+	return rc;
+}
+static int map_files_entry(urmapx_index *I, const urmapx_map_options *opt, const char *fastq1, const char *fastq2,
+                           const char *samout, const char *tabout, urmapx_map_report *report, char *err, size_t errcap) {
 	if (err && errcap) err[0] = 0;
 	if (!I || !opt || !fastq1) return URMAPX_E_ARG;
 	const int shards = opt->sam_shards > 1 ? opt->sam_shards : 1;
@@ -1701,6 +1813,7 @@ extern "C" int urmapx_map_files(urmapx_index *I, const urmapx_map_options *opt, 
 			report->write_s += r.write_s; report->lanes += r.lanes; report->host_threads += r.host_threads; report->input_bytes += r.input_bytes;
 			report->dev_h2d_s += r.dev_h2d_s; report->dev_parse_s += r.dev_parse_s; report->dev_map_s += r.dev_map_s;
 			report->dev_format_s += r.dev_format_s; report->dev_d2h_s += r.dev_d2h_s;
+			report->dev_map_search_s += r.dev_map_search_s; report->dev_map_dp_s += r.dev_map_dp_s; report->map_enqueue_s += r.map_enqueue_s;
 			report->write_threads = std::max(report->write_threads, r.write_threads);
 			report->text_on_device |= r.text_on_device;
 			if (r.medium[0]) memcpy(report->medium, r.medium, sizeof report->medium);
@@ -1717,4 +1830,10 @@ extern "C" int urmapx_map_files(urmapx_index *I, const urmapx_map_options *opt, 
 	return report && report->unsupported ? URMAPX_E_UNSUPPORTED : URMAPX_OK;
 }
 
-extern "C" void urmapx_host_pool_trim(void) { HostPool::get().trim(); }
+extern "C" void urmapx_host_pool_trim(void) {
+	LanePool::get().purge(nullptr);
+	HostPool::get().trim();
+}
+namespace urx {
+void lane_pool_purge(const urmapx_index *I) { LanePool::get().purge(I); }
+}

@@ -19,6 +19,7 @@
 // malformed record, a last line without '\n') makes the call hand the chunk back untouched (report.reason) and the
 // caller runs it through the host reader (sam.cpp), which reproduces the reference's handling and messages.
 #include <cstring>
+#include <chrono>
 #include <string>
 #include <vector>
 
@@ -287,6 +288,7 @@ struct SamArgs {
 	uint32_t minq;
 	TextHdr *hdr;
 	uint32_t *lens;              // PASS 0 out
+	uint32_t *qn;                // PASS 0 out: QNAME bytes of every record (PASS 1 does not scan the labels again)
 	const uint32_t *rec_offs;    // PASS 1 in
 	char *sam;                   // PASS 1 out
 };
@@ -585,6 +587,7 @@ __global__ __launch_bounds__(256) void sam_len_kernel(SamArgs A) {
 		while (qn < ln && label[qn] != ' ' && label[qn] != '\t') ++qn;
 		const uint32_t hl = head_length(A, r, V.F, V.QL);
 		A.lens[i] = qn + hl + 2u * V.QL + 2u;
+		A.qn[i] = qn;
 		if (hl == 0) bad = true;
 		if (r.status) ++c_uns;
 		if (r.dbpos == 0xFFFFFFFFu) ++c_no;
@@ -604,62 +607,91 @@ __global__ __launch_bounds__(256) void sam_len_kernel(SamArgs A) {
 	}
 }
 
-// The records' bytes, one wavefront per record: QNAME, the head built by lane 0 in LDS, SEQ and QUAL copied by the 64
-// lanes (reverse-complemented / reversed for a minus-strand hit).  The length it arrives at must be the one
-// sam_len_kernel reserved; if not, the chunk is flagged and handed back (flag 32).
+// The records' bytes, 64 records per wavefront at a time.  First every LANE builds the head of its own record (the fields between
+// QNAME and SEQ: a serial string of digits and tabs, 40-80 bytes) in its slice of LDS -- the one-wavefront-per-record kernel of rounds
+// 3-4 had lane 0 do this while 63 lanes waited: 3.6 ms per 1 M records, nine tenths of it that string --, then the wavefront goes
+// through its 64 records and copies QNAME, the head out of LDS, SEQ and QUAL with all lanes (reverse-complemented / reversed for a
+// minus-strand hit).  A head longer than a slice (a CIGAR of many runs, a long target label) is built as before: by lane 0 in the
+// wavefront's large LDS buffer, or, longer than that, straight into the output.  A record's length must be the one sam_len_kernel
+// reserved; if not, the chunk is flagged and handed back (flag 32).
+constexpr int HEAD_SMALL = 96;
+__device__ __forceinline__ uint32_t bcast(uint32_t v, int t) { return (uint32_t)__builtin_amdgcn_readlane((int)v, t); }
+
 __global__ __launch_bounds__(SAM_WAVES * 64) void sam_kernel(SamArgs A) {
-	__shared__ char s_head[SAM_WAVES][HEAD_CAP];
+	__shared__ char s_heads[SAM_WAVES][64 * HEAD_SMALL];
+	__shared__ char s_big[SAM_WAVES][HEAD_CAP];
 	__shared__ uint32_t s_hl[SAM_WAVES];
 	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 	const uint32_t n = A.hdr->n_reads;
 	const uint32_t wave = blockIdx.x * SAM_WAVES + w, n_waves = gridDim.x * SAM_WAVES;
-	for (uint32_t i = wave; i < n; i += n_waves) {
-		const urmapx_result r = A.results[i];
-		const RecView V = record_view(A, i, r);
-		const uint32_t QL = V.QL;
-		const uint8_t *label = V.raw + V.s1 + 1u;
-		uint32_t ln = V.e1 - V.s1 - 1u;
-		if (ln > 2 && label[ln - 2] == '/' && (label[ln - 1] == '1' || label[ln - 1] == '2')) ln -= 2;
-		uint32_t qn = ln;
-		for (uint32_t b = 0; b < ln; b += 64) {
-			const uint8_t c = b + lane < ln ? label[b + lane] : (uint8_t)'x';
-			const unsigned long long m = __ballot(c == ' ' || c == '\t');
-			if (m) { qn = b + (uint32_t)__ffsll((long long)m) - 1u; break; }
-		}
-		// the head goes through LDS unless it is longer than that (a CIGAR of hundreds of runs, from the general kernels): then
-		// lane 0 writes it where it belongs -- the reserved length says which before anything is written
-		const uint32_t reserved = A.lens[i];
-		const bool direct = reserved > qn + 2u * QL + 2u + (uint32_t)HEAD_CAP - 64u;
-		char *out = A.sam + A.rec_offs[i];
-		if (lane == 0) {
-			if (direct) { HeadGlobal hw{out + qn, 0u}; s_hl[w] = build_head(A, r, V.F, QL, hw); }
-			else { HeadLds hw{to_lds(&s_head[w][0]), 0u}; s_hl[w] = build_head(A, r, V.F, QL, hw); }
+	for (uint32_t base = wave * 64u; base < n; base += n_waves * 64u) {
+		const uint32_t i = base + (uint32_t)lane;
+		const bool valid = i < n;
+		uint32_t qn = 0, off = 0, hl = 0, want = 0, QL = 0, s1 = 0, e1 = 0, e3 = 0, fl = 0;  // fl: 1 small, 2 bad, 4 plus
+		if (valid) {
+			const urmapx_result r = A.results[i];
+			const RecView V = record_view(A, i, r);
+			qn = A.qn[i]; off = A.rec_offs[i]; QL = V.QL; s1 = V.s1; e1 = V.e1; e3 = V.e3;
+			const uint32_t reserved = A.lens[i], fixed = qn + 2u * QL + 2u;
+			want = reserved - fixed;
+			if (reserved <= fixed) fl |= 2u;  // (a head is never empty)
+			else if (want <= (uint32_t)HEAD_SMALL) {
+				HeadLds hw{to_lds(&s_heads[w][lane * HEAD_SMALL]), 0u};
+				hl = build_head(A, r, V.F, QL, hw);
+				fl |= hl == want ? 1u : 2u;
+			}
+			if (r.dbpos == 0xFFFFFFFFu || r.plus) fl |= 4u;
 		}
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 		__builtin_amdgcn_wave_barrier();
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-		const uint32_t hl = s_hl[w];
-		if (qn + hl + 2u * QL + 2u != reserved) {  // never: the two kernels count the same bytes
-			if (lane == 0) atomicOr(&A.hdr->flags, 32u);
+		const int nrec = (int)(n - base < 64u ? n - base : 64u);
+		for (int t = 0; t < nrec; ++t) {
+			const uint32_t t_fl = bcast(fl, t), t_qn = bcast(qn, t), t_QL = bcast(QL, t), t_want = bcast(want, t);
+			const uint32_t t_s1 = bcast(s1, t), t_e1 = bcast(e1, t), t_e3 = bcast(e3, t);
+			const uint32_t rec_i = base + (uint32_t)t;
+			const uint8_t *raw = A.raw[A.paired ? (rec_i & 1u) : 0u];
+			char *out = A.sam + bcast(off, t);
+			uint32_t t_hl = bcast(hl, t);
+			bool direct = false;
+			if (!(t_fl & 3u)) {  // a long head: lane 0 writes it into the large buffer or, longer than that, where it belongs
+				direct = t_want > (uint32_t)HEAD_CAP - 64u;
+				if (lane == 0) {
+					const urmapx_result r = A.results[rec_i];
+					const RecView V = record_view(A, rec_i, r);
+					if (direct) { HeadGlobal hw{out + t_qn, 0u}; s_hl[w] = build_head(A, r, V.F, t_QL, hw); }
+					else { HeadLds hw{to_lds(&s_big[w][0]), 0u}; s_hl[w] = build_head(A, r, V.F, t_QL, hw); }
+				}
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+				__builtin_amdgcn_wave_barrier();
+				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+				t_hl = s_hl[w];
+			}
+			if ((t_fl & 2u) || t_hl != t_want) {  // never: the two kernels count the same bytes
+				if (lane == 0) atomicOr(&A.hdr->flags, 32u);
 #ifdef URX_DEBUG_TEXT
-			if (lane == 0) printf("sam_kernel mismatch: rec %u qn %u hl %u QL %u reserved %u direct %d nops %u dbpos %u\n", i, qn, hl, QL, reserved, (int)direct, (unsigned)r.path_nops, r.dbpos);
+				if (lane == 0) printf("sam_kernel mismatch: rec %u qn %u hl %u want %u QL %u fl %u direct %d\n", rec_i, t_qn, t_hl, t_want, t_QL, t_fl, (int)direct);
 #endif
-			continue;
+				continue;
+			}
+			const uint8_t *label = raw + t_s1 + 1u;
+			for (uint32_t k = lane; k < t_qn; k += 64) out[k] = (char)label[k];
+			out += t_qn;
+			if (t_fl & 1u) {
+				const char *h = &s_heads[w][t * HEAD_SMALL];
+				for (uint32_t k = lane; k < t_hl; k += 64) out[k] = h[k];
+			} else if (!direct)
+				for (uint32_t k = lane; k < t_hl; k += 64) out[k] = s_big[w][k];
+			out += t_hl;
+			const uint8_t *seq = raw + t_e1 + 1u, *qual = raw + t_e3 + 1u;
+			if (t_fl & 4u) {
+				for (uint32_t k = lane; k < t_QL; k += 64) { out[k] = (char)seq[k]; out[t_QL + 1u + k] = (char)qual[k]; }
+			} else {
+				for (uint32_t k = lane; k < t_QL; k += 64) { out[k] = (char)A.comp[seq[t_QL - 1u - k]]; out[t_QL + 1u + k] = (char)qual[t_QL - 1u - k]; }
+			}
+			if (lane == 0) { out[t_QL] = '\t'; out[2u * t_QL + 1u] = '\n'; }
 		}
-		for (uint32_t k = lane; k < qn; k += 64) out[k] = (char)label[k];
-		out += qn;
-		if (!direct)
-			for (uint32_t k = lane; k < hl; k += 64) out[k] = s_head[w][k];
-		out += hl;
-		const uint8_t *seq = V.raw + V.e1 + 1u, *qual = V.raw + V.e3 + 1u;
-		const bool plus = r.dbpos == 0xFFFFFFFFu || r.plus;
-		if (plus) {
-			for (uint32_t k = lane; k < QL; k += 64) { out[k] = (char)seq[k]; out[QL + 1u + k] = (char)qual[k]; }
-		} else {
-			for (uint32_t k = lane; k < QL; k += 64) { out[k] = (char)A.comp[seq[QL - 1u - k]]; out[QL + 1u + k] = (char)qual[QL - 1u - k]; }
-		}
-		if (lane == 0) { out[QL] = '\t'; out[2u * QL + 1u] = '\n'; }
-		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_wave_barrier();  // (the next 64 heads go where these were)
 	}
 }
 
@@ -668,19 +700,29 @@ __global__ __launch_bounds__(SAM_WAVES * 64) void sam_kernel(SamArgs A) {
 struct urmapx_text {
 	urmapx_ctx *C = nullptr;
 	DevBuf<uint8_t> raw[2], bases, sam, comp;
-	DevBuf<uint32_t> tile_counts[2], ends[2], blen[2], sums, lens, rec_offs, used, tname_offs;
+	DevBuf<uint32_t> tile_counts[2], ends[2], blen[2], sums, lens, qn, rec_offs, used, tname_offs;
 	DevBuf<uint64_t> offs;
 	DevBuf<char> tnames;
 	DevBuf<urmapx_result> results;
 	DevBuf<urmapx_path_op> pathops;
 	DevBuf<TextHdr> hdr;  // [2]
 	uint32_t seq_count = 0;
-	TextHdr *h_hdr = nullptr;  // page-locked, [2]
+	TextHdr *h_hdr = nullptr;  // page-locked, [4]: [0..1] what map_text reads in between, [2 + set] the header behind a chunk's sam_kernel
 	// where the chunk's time on the stream goes (urmapx_text_report.ms_*): start, after each side's H2D [1..2], before the
 	// mapping kernels [3], after them [4], before the copy back [5], after it [6]
 	hipEvent_t ev[7] = {};
 	bool ev_ok = false;
 	int ev_sides = 1;
+	// The copy back as a stage of its own (urmapx_text_set_deferred): the text of chunk i crosses PCIe on copy_st while the main stream
+	// takes chunk i + 1 in, parses and maps it.  Two chunks are in flight at most; what belongs to a chunk's tail exists twice
+	// (set = chunk parity): the events around its sam_kernel and its copy, the header copied behind sam_kernel, its report.
+	hipStream_t copy_st = nullptr;
+	bool deferred = false;
+	hipEvent_t tail_ev[2][3] = {};  // [set]: before sam_kernel's group (= ev[4] of that chunk), before the copy, after it
+	bool tail_ok = false;
+	uint32_t chunk_no = 0;          // chunks whose tail has been enqueued
+	int waiting = 0;                // tails enqueued and not waited for (deferred mode: 0..2)
+	urmapx_text_report tail_rep[2];
 	// a chunk mapped and measured whose text has not been fetched (urmapx_text_fetch_sam)
 	uint32_t last_pairs = 0;  // pairs of the last chunk urmapx_text_map_pe mapped (urmapx_text_fetch_pairs)
 	bool pending = false;
@@ -720,37 +762,52 @@ int parse_side(urmapx_text *T, int side, const char *fastq, size_t nbytes, uint3
 	return URMAPX_OK;
 }
 
+// a chunk's tail has crossed PCIe: the times of its last two stages, the formatter's verdict
+int finish_tail(urmapx_text *T, int set, urmapx_text_report *rep) {
+	if (T->tail_ok) HIP_TRY(hipEventSynchronize(T->tail_ev[set][2]));
+	else HIP_TRY(hipStreamSynchronize(T->copy_st ? T->copy_st : ctx_stream(T->C)));
+	*rep = T->tail_rep[set];
+	if (T->tail_ok) {
+		float d = 0, e = 0;
+		(void)hipEventElapsedTime(&d, T->tail_ev[set][0], T->tail_ev[set][1]);
+		(void)hipEventElapsedTime(&e, T->tail_ev[set][1], T->tail_ev[set][2]);
+		rep->ms_format = d; rep->ms_d2h = e;
+	}
+	if (T->h_hdr[2 + set].flags & 32u) {  // the two record kernels disagreed on a length: the text is not trusted
+		rep->reason = URMAPX_TEXT_INTERNAL;
+		rep->records = 0;
+	}
+	return URMAPX_OK;
+}
+
 int fetch_sam(urmapx_text *T, char *sam, size_t sam_cap, urmapx_text_report *rep) {
 	*rep = T->pending_rep;
 	if (!sam || rep->sam_bytes > sam_cap) { rep->reason = URMAPX_TEXT_SAM_CAP; rep->records = 0; return URMAPX_OK; }
 	hipStream_t st = ctx_stream(T->C);
 	int rc;
+	const int set = (int)(T->chunk_no & 1u);
+	if (T->sam.cap < (size_t)rep->sam_bytes + 64 && T->waiting) HIP_TRY(hipStreamSynchronize(T->copy_st));  // (the array is about to be replaced under a copy)
 	if ((rc = T->sam.ensure((size_t)rep->sam_bytes + 64))) return rc;
 	SamArgs A = T->pending_args;
 	A.sam = (char *)T->sam.p;
+	// the text of the chunk before may still be on its way out of T->sam
+	if (T->deferred && T->waiting && T->tail_ok) HIP_TRY(hipStreamWaitEvent(st, T->tail_ev[set ^ 1][2], 0));
 	hipLaunchKernelGGL(sam_kernel, dim3(GRID), dim3(SAM_WAVES * 64), 0, st, A);
 	HIP_TRY(hipGetLastError());
-	if (T->ev_ok) HIP_TRY(hipEventRecord(T->ev[5], st));
-	HIP_TRY(hipMemcpyAsync(sam, T->sam.p, rep->sam_bytes, hipMemcpyDeviceToHost, st));
-	HIP_TRY(hipMemcpyAsync(T->h_hdr, T->hdr.p, sizeof(TextHdr), hipMemcpyDeviceToHost, st));
-	if (T->ev_ok) HIP_TRY(hipEventRecord(T->ev[6], st));
-	HIP_TRY(hipStreamSynchronize(st));
-	if (T->ev_ok) {  // (the parse share holds the second side's H2D of a pair chunk's other file only as far as it is not copy)
-		float a = 0, b = 0, c = 0, d = 0, e = 0, f = 0;
-		(void)hipEventElapsedTime(&a, T->ev[0], T->ev[1]);
-		if (T->ev_sides == 2) (void)hipEventElapsedTime(&f, T->ev[1], T->ev[2]);  // side 0's parse kernels + side 1's copy
-		(void)hipEventElapsedTime(&b, T->ev[T->ev_sides], T->ev[3]);
-		(void)hipEventElapsedTime(&c, T->ev[3], T->ev[4]);
-		(void)hipEventElapsedTime(&d, T->ev[4], T->ev[5]);
-		(void)hipEventElapsedTime(&e, T->ev[5], T->ev[6]);
-		rep->ms_h2d = a; rep->ms_parse = b + f; rep->ms_map = c; rep->ms_format = d; rep->ms_d2h = e;
+	HIP_TRY(hipMemcpyAsync(T->h_hdr + 2 + set, T->hdr.p, sizeof(TextHdr), hipMemcpyDeviceToHost, st));  // (on the main stream: the next chunk clears the header there)
+	if (T->tail_ok) HIP_TRY(hipEventRecord(T->tail_ev[set][1], st));
+	hipStream_t cs = T->deferred ? T->copy_st : st;
+	if (T->deferred) {
+		if (T->tail_ok) HIP_TRY(hipStreamWaitEvent(cs, T->tail_ev[set][1], 0));
+		else HIP_TRY(hipStreamSynchronize(st));
 	}
+	HIP_TRY(hipMemcpyAsync(sam, T->sam.p, rep->sam_bytes, hipMemcpyDeviceToHost, cs));
+	if (T->tail_ok) HIP_TRY(hipEventRecord(T->tail_ev[set][2], cs));
+	T->tail_rep[set] = *rep;
 	T->pending = false;
-	if (T->h_hdr[0].flags & 32u) {  // the two record kernels disagreed on a length: the text is not trusted
-		rep->reason = URMAPX_TEXT_INTERNAL;
-		rep->records = 0;
-	}
-	return URMAPX_OK;
+	++T->chunk_no;
+	if (T->deferred) { ++T->waiting; rep->reason = URMAPX_TEXT_DEFERRED; return URMAPX_OK; }
+	return finish_tail(T, set, rep);
 }
 
 // fastq2 == nullptr: single-end
@@ -758,6 +815,7 @@ int map_text(urmapx_text *T, const char *fastq1, size_t nbytes1, const char *fas
              urmapx_text_report *rep) {
 	const bool paired = fastq2 != nullptr;
 	memset(rep, 0, sizeof *rep);
+	if (T->waiting >= 2) return URMAPX_E_ARG;  // deferred mode: two chunks in flight at most (urmapx_text_wait takes the older one)
 	T->pending = false;
 	if (nbytes1 == 0 && (!paired || nbytes2 == 0)) return URMAPX_OK;
 	if (nbytes1 > (1u << 30) || nbytes2 > (1u << 30)) { rep->reason = URMAPX_TEXT_TOO_LARGE; return URMAPX_OK; }
@@ -773,6 +831,7 @@ int map_text(urmapx_text *T, const char *fastq1, size_t nbytes1, const char *fas
 	if (paired && (rc = parse_side(T, 1, fastq2, nbytes2, &ends_cap[1]))) return rc;
 	const size_t rec_cap = (size_t)ends_cap[0] / 4 + (size_t)ends_cap[1] / 4 + 2;
 	if ((rc = T->lens.ensure(rec_cap))) return rc;
+	if ((rc = T->qn.ensure(rec_cap))) return rc;
 	if ((rc = T->rec_offs.ensure(rec_cap + 1))) return rc;
 	if ((rc = T->offs.ensure(rec_cap + 1))) return rc;
 	if ((rc = T->sums.ensure(rec_cap / SC_TILE + 2))) return rc;
@@ -803,6 +862,7 @@ int map_text(urmapx_text *T, const char *fastq1, size_t nbytes1, const char *fas
 	if ((rc = T->results.ensure(n))) return rc;
 	if ((rc = T->pathops.ensure((size_t)n * URMAPX_MAX_PATH_OPS))) return rc;
 	if (T->ev_ok) HIP_TRY(hipEventRecord(T->ev[3], st));
+	const auto enq0 = std::chrono::steady_clock::now();
 	if (paired) {
 		const uint32_t mx = h1.max_len > MAX_QL_PE ? MAX_QL_PE : h1.max_len;
 		rc = urmapx_map_pe_device(C, T->bases.p, T->offs.p, n / 2, h1.total_bases, mx, T->results.p, T->pathops.p, T->used.p);
@@ -812,13 +872,15 @@ int map_text(urmapx_text *T, const char *fastq1, size_t nbytes1, const char *fas
 	}
 	if (rc) return rc;
 	if (T->ev_ok) HIP_TRY(hipEventRecord(T->ev[4], st));
+	if (T->tail_ok) HIP_TRY(hipEventRecord(T->tail_ev[T->chunk_no & 1u][0], st));
+	const float enq_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - enq0).count();
 	T->ev_sides = paired ? 2 : 1;
 	T->last_pairs = paired ? n / 2 : 0;
 	SamArgs A;
 	A.raw[0] = T->raw[0].p; A.raw[1] = T->raw[1].p; A.ends[0] = T->ends[0].p; A.ends[1] = T->ends[1].p; A.paired = paired ? 1u : 0u;
 	A.results = T->results.p; A.ops = T->pathops.p; A.tnames = T->tnames.p;
 	A.tname_offs = T->tname_offs.p; A.comp = T->comp.p; A.seq_count = T->seq_count; A.minq = minq; A.hdr = hdr;
-	A.lens = T->lens.p; A.rec_offs = T->rec_offs.p; A.sam = nullptr;
+	A.lens = T->lens.p; A.qn = T->qn.p; A.rec_offs = T->rec_offs.p; A.sam = nullptr;
 	hipLaunchKernelGGL(sam_len_kernel, dim3(GRID), dim3(256), 0, st, A);
 	hipLaunchKernelGGL(scan_sums_kernel, dim3(GRID), dim3(SC_THREADS), 0, st, T->lens.p, &hdr->n_reads, T->sums.p);
 	hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(1024), 0, st, T->sums.p, &hdr->n_reads, (uint32_t)SC_TILE, 0u, &hdr->sam_total, &hdr->flags);
@@ -833,6 +895,18 @@ int map_text(urmapx_text *T, const char *fastq1, size_t nbytes1, const char *fas
 	T->pending_args = A;
 	memset(&T->pending_rep, 0, sizeof T->pending_rep);
 	T->pending_rep.records = n;
+	T->pending_rep.ms_map_enqueue = enq_ms;
+	if (T->ev_ok) {  // everything up to the mapping is behind the synchronisation above (the parse share holds the second side's H2D of a
+		             // pair chunk's other file only as far as it is not copy)
+		float a = 0, b = 0, c = 0, f = 0;
+		(void)hipEventElapsedTime(&a, T->ev[0], T->ev[1]);
+		if (T->ev_sides == 2) (void)hipEventElapsedTime(&f, T->ev[1], T->ev[2]);  // side 0's parse kernels + side 1's copy
+		(void)hipEventElapsedTime(&b, T->ev[T->ev_sides], T->ev[3]);
+		(void)hipEventElapsedTime(&c, T->ev[3], T->ev[4]);
+		T->pending_rep.ms_h2d = a; T->pending_rep.ms_parse = b + f; T->pending_rep.ms_map = c;
+		float st7[7];
+		if (T->ev_sides == 1 && urmapx_ctx_stage_ms(T->C, st7) == URMAPX_OK) { T->pending_rep.ms_map_search = st7[0]; T->pending_rep.ms_map_dp = st7[1] + st7[2]; }
+	}
 	T->pending_rep.sam_bytes = h2.sam_total;
 	T->pending_rep.mapped_q = h2.cnt[0]; T->pending_rep.mapped_lowq = h2.cnt[1]; T->pending_rep.unmapped = h2.cnt[2]; T->pending_rep.unsupported = h2.cnt[3];
 	return fetch_sam(T, sam, sam_cap, rep);
@@ -862,12 +936,17 @@ int urmapx_text_create(urmapx_ctx *C, urmapx_text **out) {
 	if (!rc && !names.empty()) e = hipMemcpy(T->tnames.p, names.data(), names.size(), hipMemcpyHostToDevice);
 	if (!rc && e == hipSuccess) e = hipMemcpy(T->tname_offs.p, offs.data(), (n + 1) * 4, hipMemcpyHostToDevice);
 	if (!rc && e == hipSuccess) e = hipMemcpy(T->comp.p, complement_table(), 256, hipMemcpyHostToDevice);
-	if (!rc && e == hipSuccess) e = hipHostMalloc((void **)&T->h_hdr, 2 * sizeof(TextHdr), hipHostMallocDefault);
+	if (!rc && e == hipSuccess) e = hipHostMalloc((void **)&T->h_hdr, 4 * sizeof(TextHdr), hipHostMallocDefault);
+	if (!rc && e == hipSuccess) { memset(T->h_hdr, 0, 4 * sizeof(TextHdr)); e = hipStreamCreateWithFlags(&T->copy_st, hipStreamNonBlocking); }
 	if (!rc && e != hipSuccess) rc = hip_rc(e);
 	if (rc) { urmapx_text_destroy(T); return rc; }
 	T->ev_ok = true;
 	for (hipEvent_t &x : T->ev)
 		if (hipEventCreate(&x) != hipSuccess) { T->ev_ok = false; x = nullptr; }
+	T->tail_ok = true;
+	for (auto &set : T->tail_ev)
+		for (hipEvent_t &x : set)
+			if (hipEventCreate(&x) != hipSuccess) { T->tail_ok = false; x = nullptr; }
 	T->seq_count = n;
 	*out = T;
 	return URMAPX_OK;
@@ -877,9 +956,13 @@ void urmapx_text_destroy(urmapx_text *T) {
 	if (!T) return;
 	(void)hipSetDevice(ctx_device(T->C));
 	(void)hipStreamSynchronize(ctx_stream(T->C));
+	if (T->copy_st) { (void)hipStreamSynchronize(T->copy_st); (void)hipStreamDestroy(T->copy_st); }
+	for (auto &set : T->tail_ev)
+		for (hipEvent_t x : set)
+			if (x) (void)hipEventDestroy(x);
 	for (int k = 0; k < 2; ++k) { T->raw[k].release(); T->tile_counts[k].release(); T->ends[k].release(); T->blen[k].release(); }
 	T->bases.release(); T->sam.release(); T->comp.release();
-	T->sums.release(); T->lens.release(); T->rec_offs.release();
+	T->sums.release(); T->lens.release(); T->qn.release(); T->rec_offs.release();
 	T->used.release(); T->tname_offs.release(); T->offs.release(); T->tnames.release(); T->results.release(); T->pathops.release();
 	T->hdr.release();
 	if (T->h_hdr) (void)hipHostFree(T->h_hdr);
@@ -897,6 +980,20 @@ int urmapx_text_map_pe(urmapx_text *T, const char *fastq1, size_t nbytes1, const
                        size_t sam_cap, urmapx_text_report *rep) {
 	if (!T || !rep || !fastq1 || !fastq2) return URMAPX_E_ARG;
 	return map_text(T, fastq1, nbytes1, fastq2, nbytes2, minq, sam, sam_cap, rep);
+}
+
+int urmapx_text_set_deferred(urmapx_text *T, int on) {
+	if (!T || T->waiting || T->pending) return URMAPX_E_ARG;
+	T->deferred = on != 0;
+	return URMAPX_OK;
+}
+
+int urmapx_text_wait(urmapx_text *T, urmapx_text_report *rep) {
+	if (!T || !rep || T->waiting <= 0) return URMAPX_E_ARG;
+	HIP_TRY(hipSetDevice(ctx_device(T->C)));
+	const int set = (int)((T->chunk_no - (uint32_t)T->waiting) & 1u);  // the oldest tail on its way
+	--T->waiting;
+	return finish_tail(T, set, rep);
 }
 
 int urmapx_text_fetch_sam(urmapx_text *T, char *sam, size_t sam_cap, urmapx_text_report *rep) {

@@ -99,6 +99,7 @@ struct urmapx_ctx {
 };
 
 namespace urx {
+AllocClock &alloc_clock() { static AllocClock c{}; return c; }
 hipStream_t ctx_stream(urmapx_ctx *C) { return C->stream; }
 int ctx_device(const urmapx_ctx *C) { return C->device; }
 const urmapx_index *ctx_index(const urmapx_ctx *C) { return C->index; }
@@ -285,6 +286,7 @@ int urmapx_index_replicate(const urmapx_index *src, int device, urmapx_index **o
 
 void urmapx_index_close(urmapx_index *I) {
 	if (!I) return;
+	lane_pool_purge(I);  // mapping contexts urmapx_map_files kept for this index
 	if (I->own_dev) { (void)hipFree((void *)I->d_blob); (void)hipFree((void *)I->d_seq); }
 	if (I->d_seqp) (void)hipFree(I->d_seqp);
 	if (I->d_slot16) (void)hipFree(I->d_slot16);
