@@ -751,6 +751,12 @@ def run_e2e(torch, api, oi, index, device, d_seq, seq_lengths, seq_offsets, L, s
                      "note": "urmapx_map_files with discard_sam: FASTQ bytes to the device, SAM bytes back to the host, nothing written; "
                              "stream times from HIP events per chunk (copy in, line ends + record checks + base copy, mapping kernels, SAM lengths + text, copy out), "
                              "summed over the chunks of all lanes: divide by `lanes` for the wall share"}
+        if gpus == 1 and n_reads >= 4_000_000 and not E2E_BATCH:
+            # the same with chunks of 1 M reads (-batch 1048576): fewer launch tails on the device, a coarser pipeline towards the writer
+            # (the one-file and sharded rates are LOWER with it, which is why the library stops at 524 288: profiles/r5/e2e_by_chunk_after.txt)
+            big = [api.map_files(index, fq, samout=sam + ".null", first_gpu=device.index, gpus=gpus, streams=E2E_STREAMS, batch=1 << 20,
+                                 cmdline="bench.py e2e", discard_sam=True) for _ in range(2)][-1]
+            null_sink["with_1m_read_chunks"] = {"value": round(big["reads"] / big["seconds"], 1), "seconds": round(big["seconds"], 3)}
         # one SAM file per pipeline (urmap -samshards N): N readers, lanes and writers side by side; `cat` of the shards must be the one file
         n_shards = gpus if gpus > 1 else 2
         for p in [sam + f".sh.{k}" for k in range(n_shards)]:

@@ -14,3 +14,5 @@ e=d['e2e']
 print('e2e', e['value'], 'null', e['null_sink']['value'], 'sharded', e['sharded']['value'], 'gz', {k:v['value'] for k,v in e['gz'].items()}, 'pairs', e['pairs']['value'], e['placement'])
 print(d['probe_only'])
 PY
+# the kernel timeline of the file-to-file legs on the same code (scripts/e2e_timeline.py)
+[ -z "$NO_TRACE" ] && E2E_READS=4000000 bash scripts/r5_e2e_trace.sh
