@@ -751,12 +751,6 @@ def run_e2e(torch, api, oi, index, device, d_seq, seq_lengths, seq_offsets, L, s
                      "note": "urmapx_map_files with discard_sam: FASTQ bytes to the device, SAM bytes back to the host, nothing written; "
                              "stream times from HIP events per chunk (copy in, line ends + record checks + base copy, mapping kernels, SAM lengths + text, copy out), "
                              "summed over the chunks of all lanes: divide by `lanes` for the wall share"}
-        if gpus == 1 and n_reads >= 4_000_000 and not E2E_BATCH:
-            # the same with chunks of 1 M reads (-batch 1048576): fewer launch tails on the device, a coarser pipeline towards the writer
-            # (the one-file and sharded rates are LOWER with it, which is why the library stops at 524 288: profiles/r5/e2e_by_chunk_after.txt)
-            big = [api.map_files(index, fq, samout=sam + ".null", first_gpu=device.index, gpus=gpus, streams=E2E_STREAMS, batch=1 << 20,
-                                 cmdline="bench.py e2e", discard_sam=True) for _ in range(2)][-1]
-            null_sink["with_1m_read_chunks"] = {"value": round(big["reads"] / big["seconds"], 1), "seconds": round(big["seconds"], 3)}
         # one SAM file per pipeline (urmap -samshards N): N readers, lanes and writers side by side; `cat` of the shards must be the one file
         n_shards = gpus if gpus > 1 else 2
         for p in [sam + f".sh.{k}" for k in range(n_shards)]:
@@ -821,7 +815,7 @@ def run_e2e_gz(api, index, device, d, fq, n_reads, L, want):
                 f.write(bgzf_bytes(data))
         t_make = time.time() - t0
         sam = os.path.join(d, kind + ".sam")
-        reps = [api.map_files(index, gz, samout=sam, first_gpu=device.index, gpus=1, streams=E2E_STREAMS, batch=E2E_BATCH, cmdline="bench.py e2e gz") for _ in range(2)]
+        reps = [watched(lambda: api.map_files(index, gz, samout=sam, first_gpu=device.index, gpus=1, streams=E2E_STREAMS, batch=E2E_BATCH, cmdline="bench.py e2e gz")) for _ in range(2)]
         rep = reps[-1]
         got = []
         with open(sam, "rb") as f:
@@ -836,7 +830,7 @@ def run_e2e_gz(api, index, device, d, fq, n_reads, L, want):
                      "compressed_GB": round(os.path.getsize(gz) / 1e9, 3), "fastq_GB": round(len(data) / 1e9, 3),
                      "inflate_GBs": round(rep["input_bytes"] / max(rep["parse_s"], 1e-9) / 1e9, 2),
                      "text_on_device": bool(rep["text_on_device"]), "format_s": round(rep["format_s"], 3), "bound": bound, "stage_share_of_wall": shares,
-                     "sam_records_identical_to_plain_run": bool(got == want[: len(got)]), "made_in_s": round(t_make, 1)}
+                     "sam_records_identical_to_plain_run": bool(got == want[: len(got)]), "made_in_s": round(t_make, 1), "lanes_view": lane_view(rep)}
         os.remove(gz)
         os.remove(sam)
     return out
@@ -854,7 +848,7 @@ def run_e2e_pairs(torch, api, oi, index, device, d_seq, seq_lengths, seq_offsets
     write_fastq_fixed(h1, np.ascontiguousarray(pairs[:n_chk, 0, :]).reshape(-1), n_chk, L)
     write_fastq_fixed(h2, np.ascontiguousarray(pairs[:n_chk, 1, :]).reshape(-1), n_chk, L)
     del pairs
-    runs = [api.map_files(index, fq1, fq2, samout=sam, first_gpu=device.index, gpus=1, streams=E2E_STREAMS, batch=E2E_BATCH, cmdline="bench.py e2e pairs") for _ in range(2)]
+    runs = [watched(lambda: api.map_files(index, fq1, fq2, samout=sam, first_gpu=device.index, gpus=1, streams=E2E_STREAMS, batch=E2E_BATCH, cmdline="bench.py e2e pairs")) for _ in range(2)]
     rep = runs[-1]
     oi.map_file_pe(h1, h2, sam_o, threads=cores)
     want = [l for l in open(sam_o, "rb").read().split(b"\n") if l and not l.startswith(b"@")]
@@ -871,7 +865,7 @@ def run_e2e_pairs(torch, api, oi, index, device, d_seq, seq_lengths, seq_offsets
             "what": f"urmapx_map_files (= urmap -map2): 2 x {b1 / 1e9:.2f} GB mate files -> {os.path.getsize(sam) / 1e9:.2f} GB SAM file in /dev/shm, "
                     f"{(b1 + b2) / 1e9:.2f} GB of FASTQ in all; both text stages on the device",
             "stage_busy_s": {k: round(rep[k], 3) for k in ("parse_s", "gpu_s", "format_s", "write_s")},
-            "sam_records_identical_to_oracle": bool(got == want), "sam_records_checked": len(want)}
+            "sam_records_identical_to_oracle": bool(got == want), "sam_records_checked": len(want), "lanes_view": lane_view(rep)}
 
 
 def kernel_table(api, pe, L, nb, kms, counters, total_bp, gather_loads_s, stage_ms=None, p3_ms=None):

@@ -339,7 +339,7 @@ typedef struct urmapx_map_report {  /* State1::HitStats' counters (state1.cpp:59
 int urmapx_map_files(urmapx_index *, const urmapx_map_options *, const char *fastq1, const char *fastq2, const char *samout,
                      const char *tabout, urmapx_map_report *report, char *err, size_t errcap);
 
-/* Page-locked chunk buffers of urmapx_map_files are kept (up to 8 GiB) for the next call in this process; this frees them. */
+/* Page-locked chunk buffers of urmapx_map_files are kept (up to 16 GiB) for the next call in this process; this frees them. */
 void urmapx_host_pool_trim(void);
 
 /* ---- FASTQ bytes in, SAM bytes out (both text stages of -map on the device) ---- */

@@ -324,7 +324,7 @@ public:
 
 private:
 	struct Buf { char *p; size_t cap; };
-	static constexpr size_t kKeep = (size_t)8 << 30;  // 2 pipelines x 6 chunks of 524 288 reads in flight = 4.2 GB
+	static constexpr size_t kKeep = (size_t)16 << 30;  // 2 pipelines x 8 chunks of 524 288 reads in flight = 6.3 GB, and the other shapes a process maps (smaller files, mate pairs) beside them
 	std::mutex m_;
 	std::vector<Buf> free_;
 	size_t held_ = 0;
