@@ -970,6 +970,17 @@ def main():
     dt = R.max_over_ranks(torch, dt)
     reads_per_s = world * args.steps * nb / dt
 
+    leg_n = world > 1 and not pe and L == 150 and not args.no_e2e  # the N > 1 file-to-file leg: rank 0 maps over all N devices
+    if leg_n and rank != 0:
+        # this rank is done: its replica (122 GB at hg38 scale) and its contexts leave the device before rank 0 puts a replica of its
+        # own there for the file-to-file leg (two resident indexes + the 160 GB peak of a slot16 build would not fit 288 GB)
+        for m in mappers:
+            m.close()
+        index.close()
+        index._keep = ()
+        del wl
+        torch.cuda.empty_cache()
+        R.barrier(torch)
     out = None
     if rank == 0:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -1155,7 +1166,7 @@ def main():
                                                         "(reads resident in HBM, no text) compares with port_value, the CPU port on the same arrays")
                 out["cpu_baseline"]["sample"] = (f"oracle/_ref/urmap (the unmodified reference, compiled by oracle/Makefile) -map -threads {rb['threads']} on the e2e FASTQ file: "
                                                  + rb["how"] + "; the CPU port on the same host: port_value (" + out["cpu_baseline"]["sample"] + ")")
-        if world > 1 and not pe and L == 150 and not args.no_e2e:
+        if leg_n:
             # the drop-in curve: urmap -map -gpus N file to file, run by rank 0 over all N devices (each gets its own replica of
             # the index; the other ranks wait at the barrier below) -- one writer feeds one SAM file whatever N is
             try:
@@ -1163,6 +1174,7 @@ def main():
             except NameError:
                 pass
             torch.cuda.empty_cache()
+            R.barrier(torch)  # the other ranks have released their replicas and contexts
             if R.shared:
                 os.environ["URMAPX_FORCE_DEVICE"] = str(dev_index)
             try:

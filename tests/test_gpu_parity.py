@@ -913,27 +913,40 @@ def test_chain_rows_on_and_off_give_the_oracle(dense_case, tmp_path, monkeypatch
     reads = synth.make_reads(4711, c["genome"], 2500, read_len=150, sub=0.01, ins=0.001, dele=0.001)
     bases, offs = reads_to_arrays(reads)
     ores, opaths, _ = c["oracle_index"].map_se(bases, offs, threads=4)
+    long_reads = synth.make_reads(4713, c["genome"], 800, read_len=250, sub=0.03, ins=0.004, dele=0.004)  # another read-length class of the kernels
+    lb, lo = reads_to_arrays(long_reads)
+    lres, _, _ = c["oracle_index"].map_se(lb, lo, threads=4)
     r1, r2 = synth.make_pairs(4712, c["genome"], 1200, read_len=150, sub1=0.01, sub2=0.02, ins=0.001, dele=0.001)
     pairs = [x for ab in zip(r1, r2) for x in ab]
     pb, po = reads_to_arrays(pairs)
     pres, ppaths, _ = c["oracle_index"].map_pe(pb, po, threads=4)
-    for off in (False, True):
+    sizes = {}
+    for mode in ("slot16", "rows", "walk"):  # what a device with room for everything / for the rows only / for neither runs
+        off = mode == "walk"
+        if mode == "rows":
+            monkeypatch.setenv("URMAPX_NO_SLOT16", "1")  # search_se_kernel<.., ROWS 1>, the pair kernel's info-entry lookup
         if off:
+            monkeypatch.delenv("URMAPX_NO_SLOT16")
             monkeypatch.setenv("URMAPX_NO_CHAIN_ROWS", "1")
         idx = api.Index.open(c["ufi"]).upload(0)
         assert (idx.chain_row_bytes() == 0) == off
+        sizes[mode] = idx.chain_row_bytes()
         m = api.Mapper(idx, device=0)
         g, gops = m.map_se(bases, offs)
         for name in ("dbpos", "seq_index", "coord", "score", "second", "mapq", "exit_phase", "hit_count"):
-            assert (g[name].astype(np.int64) == ores[name].astype(np.int64)).all(), (off, name)
+            assert (g[name].astype(np.int64) == ores[name].astype(np.int64)).all(), (mode, name)
         for i in np.nonzero(ores["dbpos"] != 0xFFFFFFFF)[0]:
             o = int(g["path_off"][i])
             assert api.decode_path(gops[o:o + int(g["path_nops"][i])]) == opaths[i]
+        g, _ = m.map_se(lb, lo)
+        for name in ("dbpos", "seq_index", "coord", "score", "second", "mapq", "exit_phase", "hit_count"):
+            assert (g[name].astype(np.int64) == lres[name].astype(np.int64)).all(), (mode, "250", name)
         g, gops = m.map_pe(pb, po)
         for name in ("dbpos", "seq_index", "coord", "score", "second", "mapq"):
-            assert (g[name].astype(np.int64) == pres[name].astype(np.int64)).all(), (off, name)
+            assert (g[name].astype(np.int64) == pres[name].astype(np.int64)).all(), (mode, name)
         m.close()
         idx.close()
+    assert sizes["slot16"] > sizes["rows"] > 0  # (the 16-byte table is there by default, and is what URMAPX_NO_SLOT16 leaves out)
 
 
 @pytest.mark.gpu
