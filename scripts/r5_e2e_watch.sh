@@ -14,4 +14,4 @@ print("run $k:", d["value"], d["ms_per_step"], "e2e", round(e["value"]/1e6,2), "
 print("   first", e["first_run_lanes_view"]); print("   e2e  ", e["lanes_view"]); print("   null ", e["null_sink"]["lanes_view"]); print("   shard", e["sharded"]["lanes_view"])
 PY
 done
-[ -z "$NO_TRACE" ] && bash scripts/r5_e2e_trace.sh
+if [ -z "$NO_TRACE" ]; then bash scripts/r5_e2e_trace.sh; fi

@@ -15,4 +15,4 @@ print('e2e', e['value'], 'null', e['null_sink']['value'], 'sharded', e['sharded'
 print(d['probe_only'])
 PY
 # the kernel timeline of the file-to-file legs on the same code (scripts/e2e_timeline.py)
-[ -z "$NO_TRACE" ] && E2E_READS=4000000 bash scripts/r5_e2e_trace.sh
+if [ -z "$NO_TRACE" ]; then E2E_READS=4000000 bash scripts/r5_e2e_trace.sh; fi
