@@ -318,6 +318,58 @@ def test_map_files_reports_the_same_counters_with_and_without_the_text_phase(gol
     api.lib().urmapx_host_pool_trim()
 
 
+def test_lanes_are_kept_between_calls_and_go_with_their_index(small_case, tmp_path, monkeypatch):
+    """urmapx_map_files keeps its lanes' mapping contexts (LanePool, pipeline.cpp): the second call on an index allocates no device
+    array (report.alloc_dev_calls == 0), a pair run after single-end runs reuses the same contexts, the SAM is the oracle's every
+    time; urmapx_host_pool_trim and Index.close destroy the kept lanes (the next call allocates again), and so does
+    URMAPX_NO_LANE_POOL=1 for a call."""
+    from urmap_amd import api, synth
+    for k in list(os.environ):
+        if k.startswith("URMAPX_TEST_") or k.startswith("URMAPX_DEBUG_"):
+            monkeypatch.delenv(k)  # (such knobs switch the pool off: contexts cache what they decide)
+    monkeypatch.delenv("URMAPX_NO_LANE_POOL", raising=False)
+    oi = small_case["oracle_index"]
+    fq, fq2 = os.path.join(tmp_path, "a.fq"), os.path.join(tmp_path, "b.fq")
+    synth.write_fastq(fq, synth.make_reads(31, small_case["genome"], 6000, read_len=150, sub=0.01, ins=0.001, dele=0.001))
+    synth.write_fastq(fq2, synth.make_reads(32, small_case["genome"], 7000, read_len=150, sub=0.02, ins=0.002, dele=0.002))
+    r1, r2 = synth.make_pairs(33, small_case["genome"], 3000, read_len=150, sub1=0.01, sub2=0.02, ins=0.001, dele=0.001)
+    m1, m2 = os.path.join(tmp_path, "m1.fq"), os.path.join(tmp_path, "m2.fq")
+    synth.write_fastq(m1, r1)
+    synth.write_fastq(m2, r2)
+    want, want2, wantp = (os.path.join(tmp_path, n) for n in ("o1.sam", "o2.sam", "op.sam"))
+    oi.map_file_se(fq, want, threads=4)
+    oi.map_file_se(fq2, want2, threads=4)
+    oi.map_file_pe(m1, m2, wantp, threads=4)
+    body = lambda p: _records(open(p, "rb").read())
+    api.lib().urmapx_host_pool_trim()
+    idx = api.Index.open(small_case["ufi"]).upload(0)
+    out = os.path.join(tmp_path, "x.sam")
+    a = api.map_files(idx, fq, samout=out, batch=1500, streams=2, cmdline="t")
+    assert a["alloc_dev_calls"] > 0 and body(out) == body(want)
+    b = api.map_files(idx, fq, samout=out, batch=1500, streams=2, cmdline="t")
+    assert b["alloc_dev_calls"] == 0 and b["alloc_pinned_calls"] == 0 and body(out) == body(want)
+    c = api.map_files(idx, fq2, samout=out, batch=1000, streams=2, cmdline="t")  # another file in smaller chunks: nothing grows
+    assert c["alloc_dev_calls"] == 0 and body(out) == body(want2)
+    p = api.map_files(idx, m1, m2, samout=out, batch=1000, streams=2, cmdline="t")  # the pair path on the contexts the single-end runs left
+    assert body(out) == body(wantp)
+    p2 = api.map_files(idx, m1, m2, samout=out, batch=1000, streams=2, cmdline="t")
+    assert p2["alloc_dev_calls"] == 0 and body(out) == body(wantp)
+    monkeypatch.setenv("URMAPX_NO_LANE_POOL", "1")
+    d = api.map_files(idx, fq, samout=out, batch=1500, streams=2, cmdline="t")
+    assert d["alloc_dev_calls"] > 0 and body(out) == body(want)
+    monkeypatch.delenv("URMAPX_NO_LANE_POOL")
+    assert api.map_files(idx, fq, samout=out, batch=1500, streams=2, cmdline="t")["alloc_dev_calls"] == 0  # (the kept lanes were not touched)
+    api.lib().urmapx_host_pool_trim()
+    e = api.map_files(idx, fq, samout=out, batch=1500, streams=2, cmdline="t")
+    assert e["alloc_dev_calls"] > 0 and e["alloc_pinned_calls"] > 0 and body(out) == body(want)
+    idx.close()  # destroys the lanes kept for it
+    idx = api.Index.open(small_case["ufi"]).upload(0)
+    f = api.map_files(idx, fq, samout=out, batch=1500, streams=2, cmdline="t")
+    assert f["alloc_dev_calls"] > 0 and body(out) == body(want)
+    idx.close()
+    api.lib().urmapx_host_pool_trim()
+
+
 # ---- pairs ----
 @pytest.mark.parametrize("name,ufi_gz", [("pe150", "g.ufi.gz"), ("pe100_noisy", "g.ufi.gz"), ("pe120_rep", "r.ufi.gz")])
 def test_golden_mate_files_to_golden_pair_sam(tmp_path, name, ufi_gz):
