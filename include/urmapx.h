@@ -423,6 +423,9 @@ void urmapx_fastq_close(urmapx_fastq *);
  * came by the parallel road, bytes that came through zlib (small files, one thread, input the parallel decoder hands over).
  * URMAPX_E_FORMAT: not gzip, truncated, or corrupt (what was decoded before the damage is in out_path, as with zlib). */
 int urmapx_gunzip_file(const char *gz_path, const char *out_path, int threads, uint64_t stats[3]);
+/* Which of the reader's vector paths this host runs: bit 0 = symbols to bytes 32 at a time (AVX2), bit 1 = CRC-32 by carry-less
+ * multiplication (PCLMULQDQ; set only after the routine has reproduced zlib's crc32 on its self-test).  URMAPX_PGZIP_NO_SIMD=1: neither. */
+int urmapx_pgzip_simd(void);
 
 const char *urmapx_strerror(int code);
 /* "gfx950" etc. of the ctx's device; NULL without a device */

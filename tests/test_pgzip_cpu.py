@@ -117,3 +117,23 @@ def test_damaged_files_fail_as_with_zlib(tmp_path, fastq, monkeypatch):
             gzip.decompress(data)
     with pytest.raises(api.UrmapxError):
         _run(str(tmp_path), "notgz", b"@r\nACGT\n+\nIIII\n" * 10, monkeypatch=monkeypatch)
+
+
+def test_vector_paths_are_in_use_and_agree_with_the_plain_loops(tmp_path, fastq):
+    """Symbols -> bytes 32 at a time (AVX2) and CRC-32 by carry-less multiplication (PCLMULQDQ) are what runs on a host that has the
+    instructions -- the CRC routine only after reproducing zlib's crc32 on its self-test, so a wrong constant would show here as a
+    missing flag, not as a wrong checksum -- and URMAPX_PGZIP_NO_SIMD=1 (a process of its own: the choice is made once) gives the same bytes."""
+    import subprocess
+    import sys
+    from urmap_amd import api
+    flags = open("/proc/cpuinfo").read().split("flags", 1)[-1].split("\n", 1)[0].split()
+    got = api.lib().urmapx_pgzip_simd()
+    assert bool(got & 1) == ("avx2" in flags)
+    assert bool(got & 2) == ("pclmulqdq" in flags and "sse4_1" in flags)
+    gz = os.path.join(tmp_path, "v.gz")
+    open(gz, "wb").write(gzip.compress(fastq, 6))
+    code = ("import sys; sys.path.insert(0, %r); from urmap_amd import api; print(api.lib().urmapx_pgzip_simd(), api.gunzip_file(%r, %r, 8))"
+            % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), gz, gz + ".plain"))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, URMAPX_PGZIP_NO_SIMD="1", URMAPX_PGZIP_SEGMENT="65536"), capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.startswith("0 "), (r.stdout, r.stderr[-500:])
+    assert open(gz + ".plain", "rb").read() == fastq

@@ -6,6 +6,9 @@
 #include <omp.h>
 #include <unistd.h>
 #include <zlib.h>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 
 #include <algorithm>
 #include <cstdio>
@@ -25,6 +28,159 @@ const uint8_t LEN_EXTRA[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3
 const uint16_t DIST_BASE[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
 const uint8_t DIST_EXTRA[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
 const uint8_t CL_ORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+
+// A growable array whose new elements are not touched (std::vector value-initialises them: for the symbol buffers and the round's
+// text that was a pass over 0.2-0.4 GB per round on one thread -- as long as the round's decoding on sixteen).
+template <class T>
+struct RawBuf {
+	std::unique_ptr<T[]> p;
+	size_t cap = 0;
+	T *data() { return p.get(); }
+	const T *data() const { return p.get(); }
+	size_t size() const { return cap; }  // the capacity
+	T &operator[](size_t i) { return p[i]; }
+	const T &operator[](size_t i) const { return p[i]; }
+	void reserve_keep(size_t need, size_t keep) {  // room for `need` elements, the first `keep` carried over
+		if (need <= cap) return;
+		const size_t nc = std::max(need, cap + cap / 2);
+		std::unique_ptr<T[]> q(new T[nc]);
+		if (keep) memcpy(q.get(), p.get(), keep * sizeof(T));
+		p = std::move(q);
+		cap = nc;
+	}
+};
+
+void par_copy(char *d, const char *s, size_t n, int threads) {
+	constexpr size_t PIECE = 4u << 20;
+	if (n < 2 * PIECE || threads < 2) { memcpy(d, s, n); return; }
+	const long pieces = (long)((n + PIECE - 1) / PIECE);
+#pragma omp parallel for schedule(static) num_threads(threads)
+	for (long i = 0; i < pieces; ++i) {
+		const size_t lo = (size_t)i * PIECE, hi = std::min(n, lo + PIECE);
+		memcpy(d + lo, s + lo, hi - lo);
+	}
+}
+
+// ---- the two passes over a round's text that are not decoding: symbols -> bytes, CRC-32 ----
+// Both were scalar loops (a branch per symbol; zlib's table CRC) and together cost more than the decode itself once 16 threads
+// shared it (18 of a round's 40 ms on the GPU box).  With AVX2 / PCLMULQDQ (checked at run time; the plain loops otherwise):
+//  * 32 symbols at a time: if all are literals (< 256: everything but the first few hundred KB of a segment, whose copies still
+//    reach into the unknown window) they are packed to bytes with one instruction; a group with a window reference takes the old loop;
+//  * CRC-32 by carry-less multiplication: 64 bytes folded per step with the constants of the reflected polynomial 0xEDB88320
+//    (x^(512+64) mod P, x^512 mod P for the four-register step, x^(128+64), x^128 for one register: Gopal et al., "Fast CRC computation
+//    for generic polynomials using PCLMULQDQ", Intel 2009), the last 16 bytes and the tail by the table.  The routine proves itself against
+//    zlib's crc32 on its first use (several lengths and alignments); if it ever disagreed it would not be used.
+uint32_t crc_table_update(uint32_t raw, const uint8_t *p, size_t n) {  // raw: the register without the pre / post inversion
+	static uint32_t T[256];
+	static bool init = false;
+	if (!init) {
+#pragma omp critical(urx_crc_table)
+		{
+			if (!init) {
+				for (uint32_t i = 0; i < 256; ++i) {
+					uint32_t c = i;
+					for (int k = 0; k < 8; ++k) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+					T[i] = c;
+				}
+				init = true;
+			}
+		}
+	}
+	for (size_t i = 0; i < n; ++i) raw = T[(raw ^ p[i]) & 0xFFu] ^ (raw >> 8);
+	return raw;
+}
+
+#if defined(__x86_64__)
+__attribute__((target("pclmul,sse4.1"))) inline __m128i crc_fold_step(__m128i x, __m128i k, __m128i next) {
+	const __m128i lo = _mm_clmulepi64_si128(x, k, 0x00), hi = _mm_clmulepi64_si128(x, k, 0x11);
+	return _mm_xor_si128(_mm_xor_si128(lo, hi), next);
+}
+__attribute__((target("pclmul,sse4.1"))) uint32_t crc_fold_pclmul(uint32_t raw, const uint8_t *p, size_t n) {  // n >= 64, a multiple of 16
+	const __m128i k12 = _mm_set_epi64x(0x00000001c6e41596LL, 0x0000000154442bd4LL);  // high, low
+	const __m128i k34 = _mm_set_epi64x(0x00000000ccaa009eLL, 0x00000001751997d0LL);
+	__m128i x1 = _mm_loadu_si128((const __m128i *)p), x2 = _mm_loadu_si128((const __m128i *)(p + 16));
+	__m128i x3 = _mm_loadu_si128((const __m128i *)(p + 32)), x4 = _mm_loadu_si128((const __m128i *)(p + 48));
+	x1 = _mm_xor_si128(x1, _mm_cvtsi32_si128((int)raw));
+	p += 64; n -= 64;
+	while (n >= 64) {
+		x1 = crc_fold_step(x1, k12, _mm_loadu_si128((const __m128i *)p));
+		x2 = crc_fold_step(x2, k12, _mm_loadu_si128((const __m128i *)(p + 16)));
+		x3 = crc_fold_step(x3, k12, _mm_loadu_si128((const __m128i *)(p + 32)));
+		x4 = crc_fold_step(x4, k12, _mm_loadu_si128((const __m128i *)(p + 48)));
+		p += 64; n -= 64;
+	}
+	x1 = crc_fold_step(x1, k34, x2);
+	x1 = crc_fold_step(x1, k34, x3);
+	x1 = crc_fold_step(x1, k34, x4);
+	while (n >= 16) {
+		x1 = crc_fold_step(x1, k34, _mm_loadu_si128((const __m128i *)p));
+		p += 16; n -= 16;
+	}
+	uint8_t last[16];
+	_mm_storeu_si128((__m128i *)last, x1);
+	return crc_table_update(0u, last, 16);  // what is left of the message is these 16 bytes
+}
+__attribute__((target("avx2"))) size_t narrow_literals_avx2(const uint16_t *s, size_t n, char *o) {  // leading groups of 32 literals; returns how many symbols it took
+	size_t i = 0;
+	const __m256i hi = _mm256_set1_epi16((short)0xFF00);
+	for (; i + 32 <= n; i += 32) {
+		const __m256i a = _mm256_loadu_si256((const __m256i *)(s + i)), b = _mm256_loadu_si256((const __m256i *)(s + i + 16));
+		if (!_mm256_testz_si256(_mm256_or_si256(a, b), hi)) break;  // a symbol >= 256 in the group
+		const __m256i pk = _mm256_permute4x64_epi64(_mm256_packus_epi16(a, b), 0xD8);
+		_mm256_storeu_si256((__m256i *)(o + i), pk);
+	}
+	return i;
+}
+#endif
+
+bool cpu_has(const char *what) {
+#if defined(__x86_64__)
+	if (!strcmp(what, "avx2")) return __builtin_cpu_supports("avx2");
+	if (!strcmp(what, "pclmul")) return __builtin_cpu_supports("pclmul") && __builtin_cpu_supports("sse4.1");
+#endif
+	(void)what;
+	return false;
+}
+
+// zlib's crc32(0, p, n)
+int g_crc_pclmul = -1;  // -1 not tried, 0 no, 1 yes (verified against zlib)
+uint32_t crc32_of(const uint8_t *p, size_t n) {
+#if defined(__x86_64__)
+	int &usable = g_crc_pclmul;
+	if (usable < 0) {
+#pragma omp critical(urx_crc_check)
+		if (usable < 0) {
+			int ok = cpu_has("pclmul") && !getenv("URMAPX_PGZIP_NO_SIMD") ? 1 : 0;
+			if (ok) {
+				std::vector<uint8_t> t(4096 + 64);
+				uint32_t x = 12345u;
+				for (uint8_t &b : t) { x = x * 1664525u + 1013904223u; b = (uint8_t)(x >> 24); }
+				for (size_t off : {(size_t)0, (size_t)1, (size_t)7})
+					for (size_t len : {(size_t)64, (size_t)80, (size_t)127, (size_t)128, (size_t)1000, (size_t)4096}) {
+						const size_t body = len & ~(size_t)15;
+						uint32_t raw = crc_fold_pclmul(0xFFFFFFFFu, t.data() + off, body);
+						raw = crc_table_update(raw, t.data() + off + body, len - body);
+						if (~raw != (uint32_t)crc32(0L, t.data() + off, (uInt)len)) ok = 0;
+					}
+			}
+			usable = ok;
+		}
+	}
+	if (usable == 1 && n >= 64) {
+		const size_t body = n & ~(size_t)15;
+		uint32_t raw = crc_fold_pclmul(0xFFFFFFFFu, p, body);
+		raw = crc_table_update(raw, p + body, n - body);
+		return ~raw;
+	}
+#endif
+	uint32_t c = 0;
+	while (n) {  // (zlib's length is 32 bits)
+		const size_t k = std::min<size_t>(n, 1u << 30);
+		c = (uint32_t)crc32(c, p, (uInt)k);
+		p += k; n -= k;
+	}
+	return c;
+}
 
 inline uint32_t rev_bits(uint32_t c, int n) {
 	uint32_t r = 0;
@@ -163,9 +319,10 @@ inline bool text_byte(uint32_t c) { return (c >= 32 && c < 127) || c == '\n' || 
 // (k = 32767 is the byte just before it).
 struct SegDecoder {
 	Bits B;
-	std::vector<uint16_t> buf;  // out[0, n): size() is the capacity, the symbols are written through a raw pointer
+	RawBuf<uint16_t> buf;  // out[0, n): size() is the capacity, the symbols are written through a raw pointer
 	size_t n = 0;
-	void grow(size_t need) { if (need > buf.size()) buf.resize(std::max(need + (1u << 20), buf.size() * 2)); }
+	size_t hint = 0;       // symbols a segment of this run is expected to make (the first allocation: no doubling from nothing)
+	void grow(size_t need) { if (need > buf.size()) buf.reserve_keep(std::max({need + (1u << 20), buf.size() * 2, hint}), n); }
 	void reset() { n = 0; members.clear(); member_start = 0; from_unknown = true; failed = false; at_eof = false; in_stream = true; block_start = 0; }
 	struct Member { size_t out_end; uint32_t crc, isize; };  // a member ended behind out[0, out_end)
 	std::vector<Member> members;
@@ -358,8 +515,8 @@ struct ParallelGunzip::Impl {
 	std::vector<uint8_t> window;  // the last <= 32 KB of the current member's text
 	uint32_t crc = 0;             // of the current member so far
 	uint64_t isize = 0;
-	std::vector<char> obuf;       // decoded text not yet handed out
-	size_t obeg = 0;
+	RawBuf<char> obuf;            // decoded text not yet handed out: [obeg, osize)
+	size_t obeg = 0, osize = 0;
 	// zlib roads
 	z_stream zs;
 	bool zs_init = false, member_done = true, seen_member = false;
@@ -424,11 +581,11 @@ size_t ParallelGunzip::read(char *dst, size_t cap, int threads) {
 	size_t done = 0;
 	if (threads < 1) threads = 1;
 	while (done < cap && !bad_) {
-		if (D.obeg < D.obuf.size()) {  // text already decoded
-			const size_t k = std::min(cap - done, D.obuf.size() - D.obeg);
-			memcpy(dst + done, D.obuf.data() + D.obeg, k);
+		if (D.obeg < D.osize) {  // text already decoded
+			const size_t k = std::min(cap - done, D.osize - D.obeg);
+			par_copy(dst + done, D.obuf.data() + D.obeg, k, threads);
 			D.obeg += k; done += k;
-			if (D.obeg == D.obuf.size()) { D.obuf.clear(); D.obeg = 0; }
+			if (D.obeg == D.osize) { D.osize = 0; D.obeg = 0; }
 			continue;
 		}
 		if (D.eof) break;
@@ -505,7 +662,7 @@ size_t ParallelGunzip::read(char *dst, size_t cap, int threads) {
 		const bool last_round = B1 == D.csize;
 		std::vector<SegDecoder> &segs = D.segs;
 		if ((int)segs.size() < T) segs.resize((size_t)T);
-		for (SegDecoder &S : segs) S.reset();
+		for (SegDecoder &S : segs) { S.reset(); S.hint = (size_t)D.seg_bytes * 6; }  // FASTQ text deflates to a fifth or less; more grows the buffer
 		std::vector<uint64_t> start((size_t)T, ~0ull);
 		start[0] = D.cbits - B0 * 8;
 		// 1. block starts behind the cuts
@@ -619,7 +776,7 @@ size_t ParallelGunzip::read(char *dst, size_t cap, int threads) {
 		const size_t total = ooff[(size_t)K];
 		// straight into the caller's buffer when the round's text fits what is left of it (obuf is empty here); else through obuf
 		const bool direct = total <= cap - done;
-		if (!direct) D.obuf.resize(total);
+		if (!direct) { D.obuf.reserve_keep(total, 0); D.osize = total; D.obeg = 0; }
 		char *const otext = direct ? dst + done : D.obuf.data();
 		// pieces of at most 4 MB (all threads take part whatever the number of segments), cut at segment and member ends; a piece's
 		// symbols become bytes and its CRC-32 is taken while they are still in the cache
@@ -644,6 +801,8 @@ size_t ParallelGunzip::read(char *dst, size_t cap, int threads) {
 		}
 		std::vector<uint8_t> pok(pieces.size(), 1);
 		std::vector<uint32_t> pcrc(pieces.size(), 0);
+		const bool simd_narrow = cpu_has("avx2") && !getenv("URMAPX_PGZIP_NO_SIMD");
+		(void)simd_narrow;
 #pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
 		for (long pi = 0; pi < (long)pieces.size(); ++pi) {
 			const Piece &pc = pieces[(size_t)pi];
@@ -653,17 +812,26 @@ size_t ParallelGunzip::read(char *dst, size_t cap, int threads) {
 			char *o = otext + ooff[(size_t)pc.k];
 			const size_t wbase = WIN - w.size();
 			bool ok = true;
-			for (size_t i = pc.lo; i < pc.hi; ++i) {
-				const uint16_t v = s[i];
-				if (v < 256) o[i] = (char)v;
-				else {
-					const size_t kk = v & 0x7FFFu;
-					if (kk < wbase) { ok = false; o[i] = 0; }
-					else o[i] = (char)w[kk - wbase];
+			for (size_t i = pc.lo; i < pc.hi;) {
+#if defined(__x86_64__)
+				if (simd_narrow) {
+					i += narrow_literals_avx2(s + i, pc.hi - i, o + i);
+					if (i >= pc.hi) break;
+				}
+#endif
+				const size_t stop = std::min(pc.hi, i + 32);  // the group the packed pass stopped at (or, without it, the next 32 symbols)
+				for (; i < stop; ++i) {
+					const uint16_t v = s[i];
+					if (v < 256) o[i] = (char)v;
+					else {
+						const size_t kk = v & 0x7FFFu;
+						if (kk < wbase) { ok = false; o[i] = 0; }
+						else o[i] = (char)w[kk - wbase];
+					}
 				}
 			}
 			if (!ok) pok[(size_t)pi] = 0;
-			pcrc[(size_t)pi] = (uint32_t)crc32(0L, (const Bytef *)o + pc.lo, (uInt)(pc.hi - pc.lo));
+			pcrc[(size_t)pi] = crc32_of((const uint8_t *)o + pc.lo, pc.hi - pc.lo);
 		}
 		for (uint8_t x : pok)
 			if (!x) bad_ = true;
@@ -729,4 +897,9 @@ extern "C" int urmapx_gunzip_file(const char *gz_path, const char *out_path, int
 	fclose(in);
 	if (stats) { stats[0] = total; stats[1] = g.parallel_bytes(); stats[2] = g.serial_bytes(); }
 	return rc;
+}
+
+extern "C" int urmapx_pgzip_simd(void) {
+	(void)urx::crc32_of((const uint8_t *)"", 0);  // (runs the self-check)
+	return (urx::cpu_has("avx2") && !getenv("URMAPX_PGZIP_NO_SIMD") ? 1 : 0) | (urx::g_crc_pclmul == 1 ? 2 : 0);
 }
