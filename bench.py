@@ -592,7 +592,7 @@ def run_reference(ref_bin, oi, d, fq, fq_head, n_reads, n_head, cores, product_s
             if len(got) == len(want):
                 break
     rate = (n_reads - n_head) / max(1e-9, t_all - t_head)
-    return {"reads_per_s": round(rate, 1), "threads": cores,
+    return {"reads_per_s": round(rate, 1), "threads": cores, "wall_all_reads_s": round(t_all, 1), "wall_head_s": round(t_head, 1),
             "how": f"wall({n_reads} reads) - wall({n_head} reads) = {t_all:.1f} - {t_head:.1f} s (each run loads the index from /dev/shm); "
                    f".ufi written in {t_save:.1f} s",
             "sam_records_identical_to_product": bool(sorted(got) == want), "sam_records_checked": len(want)}
@@ -697,7 +697,49 @@ def lane_view(rep):
             "host": rep.get("host")}
 
 
-def run_e2e(torch, api, oi, index, device, d_seq, seq_lengths, seq_offsets, L, sub, indel, n_reads, cores, ref_bin=None, gpus=1):
+def run_cli(oi, d, fq, n_reads, want, ref):
+    """What a user of the command line gets, index load included: `urmap -map reads.fq -ufi index.ufi -samout out.sam` as a process of its
+    own (the .ufi in /dev/shm, as for the reference binary's run): wall time of the process, its own "Seconds to load index" and
+    "Seconds in mapper", with the index streamed from the file to the device (urmapx_index_open_device, what the command line does) and,
+    for comparison, read into host arrays first (URMAPX_HOST_INDEX=1: the loader of rounds 1-4).  The first records of its SAM must be the oracle's."""
+    import re
+    import subprocess
+    exe = os.path.join(ROOT, "urmap_amd", "urmap")
+    ufi, sam = os.path.join(d, "cli.ufi"), os.path.join(d, "cli.sam")
+    t0 = time.time()
+    oi.save(ufi)
+    out = {"ufi_GB": round(os.path.getsize(ufi) / 1e9, 2), "ufi_written_in_s": round(time.time() - t0, 1), "reads": n_reads}
+    for name, extra in (("index_streamed_to_the_device", {}), ("index_through_host_arrays", {"URMAPX_HOST_INDEX": "1"})):
+        env = dict(os.environ, OMP_WAIT_POLICY="passive", **extra)
+        t = time.time()
+        r = subprocess.run([exe, "-map", fq, "-ufi", ufi, "-samout", sam], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+        wall = time.time() - t
+        text = (r.stdout + r.stderr).decode("latin-1")
+        if r.returncode != 0:
+            out[name] = {"error": text[-300:]}
+            continue
+        num = lambda what: (lambda m: float(m.group(1)) if m else None)(re.search(r"([0-9.]+)\s+" + what, text))
+        got = []
+        with open(sam, "rb") as f:
+            for line in f:
+                if line.startswith(b"@"):
+                    continue
+                got.append(line.rstrip(b"\n"))
+                if len(got) == len(want):
+                    break
+        out[name] = {"wall_s": round(wall, 2), "seconds_to_load_index": num("Seconds to load index"), "seconds_in_mapper": num("Seconds in mapper"),
+                     "reads_per_s_of_wall": round(n_reads / wall, 1), "sam_records_identical_to_oracle": bool(got == want)}
+        os.remove(sam)
+    os.remove(ufi)
+    if ref and ref.get("wall_all_reads_s"):
+        out["reference_binary_wall_s"] = ref["wall_all_reads_s"]
+        w = out.get("index_streamed_to_the_device", {}).get("wall_s")
+        if w:
+            out["reference_wall_over_product_wall"] = round(ref["wall_all_reads_s"] / w, 1)
+    return out
+
+
+def run_e2e(torch, api, oi, index, device, d_seq, seq_lengths, seq_offsets, L, sub, indel, n_reads, cores, ref_bin=None, gpus=1, release_device=None):
     """FASTQ file -> SAM file through urmapx_map_files (the command line's cmd_map) on the resident index: what a user of
     `urmap -map` gets, index load excluded as the reference reports it.  Files live in /dev/shm (memory), so this is the
     read + PCIe + parse + map + format + write pipeline, not a disk benchmark.  Chunks of the FASTQ file go to the device
@@ -789,6 +831,12 @@ def run_e2e(torch, api, oi, index, device, d_seq, seq_lengths, seq_offsets, L, s
             out["gz"] = run_e2e_gz(api, index, device, d, fq, n_reads, L, want)
         if gpus == 1 and not os.environ.get("URMAP_BENCH_NO_E2E_PAIRS"):
             out["pairs"] = run_e2e_pairs(torch, api, oi, index, device, d_seq, seq_lengths, seq_offsets, L, n_reads // 2, cores, d)
+        if gpus == 1 and release_device is not None and not os.environ.get("URMAP_BENCH_NO_CLI"):
+            release_device()  # the command line's process loads an index of its own: this process's replica and contexts leave the device first
+            try:
+                out["cli"] = run_cli(oi, d, fq, n_reads, want, ref)
+            except Exception as e:
+                out["cli"] = {"error": str(e)[:300]}
         return out
     finally:
         shutil.rmtree(d, ignore_errors=True)
@@ -1155,8 +1203,15 @@ def main():
             except NameError:
                 pass
             torch.cuda.empty_cache()
+            def release_device():  # (the last leg runs the command line as a process of its own, with its own index on the device)
+                for m in mappers:
+                    m.close()
+                index.close()
+                index._keep = ()
+                torch.cuda.empty_cache()
             out["e2e"] = run_e2e(torch, api, oi, index, device, d_seq, seq_lengths, seq_offsets, L, args.sub, args.indel,
-                                 int(os.environ.get("URMAP_BENCH_E2E_READS", 10_000_000)), cores, ref_bin=ol.REF_BIN)  # BASELINE config 2: 10 M reads
+                                 int(os.environ.get("URMAP_BENCH_E2E_READS", 10_000_000)), cores, ref_bin=ol.REF_BIN,  # BASELINE config 2: 10 M reads
+                                 release_device=release_device)
             rb = out["e2e"].get("reference_binary")
             if rb and "cpu_baseline" in out:  # the reference itself, timed on this host in this run
                 out["cpu_baseline"]["port_value"] = out["cpu_baseline"]["value"]

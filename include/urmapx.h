@@ -88,6 +88,10 @@ typedef uint16_t urmapx_path_op;
 
 /* ---- index: UFIndex::FromFile (ufindexio.cpp:51-115) + the device-load path ---- */
 int urmapx_index_open(const char *ufi_path, urmapx_index **out);
+/* The same file straight into the HBM of `device` (round 5): the header is parsed on the host, the slot table and the sequence store
+ * stream from the file through page-locked buffers read by several threads, and the resident layouts are built there; no host copy
+ * of the arrays is kept (urmapx_index_replicate copies device to device from such an index).  What `urmap -map / -map2` loads with. */
+int urmapx_index_open_device(const char *ufi_path, int device, urmapx_index **out);
 /* Wrap caller-owned HOST arrays (no copy; must outlive the index).  labels = seq_count NUL-terminated strings. */
 int urmapx_index_wrap_host(uint32_t word_length, uint32_t max_ix, uint64_t slot_count, const uint8_t *blob,
                            const uint8_t *seqdata, uint32_t seqdata_size, uint32_t seq_count,

@@ -91,6 +91,52 @@ def test_two_index_replicas_two_contexts_through_the_library(tmp_path):
     idx1.close()
 
 
+def test_index_streamed_from_the_file_to_the_device_and_replicated_device_to_device(tmp_path):
+    """urmapx_index_open_device (what the command line loads with): the .ufi's arrays go from the file to the device through
+    page-locked buffers, no host copy is kept; the resident table validates like the one uploaded from host arrays, maps the
+    golden reads to the golden SAM, and urmapx_index_replicate copies it device to device (no host arrays to upload from).
+    A file cut short or with a damaged magic word is refused as urmapx_index_open refuses it."""
+    import torch
+    from urmap_amd import api
+    ufi = _golden_ufi(tmp_path)
+    second = 1 if torch.cuda.device_count() > 1 else 0
+    idx_h = api.Index.open(ufi).upload(0)
+    idx_d = api.Index.open_device(ufi, 0)
+    ok_h, rep_h = idx_h.validate()
+    ok_d, rep_d = idx_d.validate()
+    assert ok_h and ok_d
+    for k in ("slots", "heads", "positions", "used", "reached"):
+        assert rep_h[k] == rep_d[k], k
+    assert idx_d.chain_row_bytes() == idx_h.chain_row_bytes() > 0
+    idx_r = idx_d.replicate(second)
+    ok_r, rep_r = idx_r.validate()
+    assert ok_r and rep_r["positions"] == rep_h["positions"] and idx_r.chain_row_bytes() == idx_h.chain_row_bytes()
+    labels, bases, offs, quals = api.read_fastq_arrays(os.path.join(GOLD, "se150.fq"))
+    want = [l for l in open(os.path.join(GOLD, "se150.sam"), "rb").read().split(b"\n") if l and not l.startswith(b"@")]
+    for idx, dev in ((idx_d, 0), (idx_r, second)):
+        m = api.Mapper(idx, device=dev)
+        res, ops = m.map_se(bases, offs)
+        assert [l for l in idx.sam_se(res, ops, labels, bases, offs, quals).split(b"\n") if l] == want
+        m.close()
+    out = os.path.join(tmp_path, "f.sam")
+    rep = api.map_files(idx_d, os.path.join(GOLD, "se150.fq"), samout=out, gpus=2 if second else 1, streams=2, batch=50, cmdline="t")
+    assert rep["reads"] == len(want) and _records(out) == [l for l in open(os.path.join(GOLD, "se150.sam"), "rb").read().split(b"\n") if l]
+    for i in (idx_r, idx_d, idx_h):
+        i.close()
+    raw = open(ufi, "rb").read()
+    cut = os.path.join(tmp_path, "cut.ufi")
+    open(cut, "wb").write(raw[: len(raw) // 2])
+    bad = os.path.join(tmp_path, "bad.ufi")
+    open(bad, "wb").write(raw[:-4] + b"XXXX")
+    for p in (cut, bad):
+        with pytest.raises(api.UrmapxError) as e:
+            api.Index.open_device(p, 0)
+        assert e.value.code == api.E_FORMAT
+        with pytest.raises(api.UrmapxError) as e2:
+            api.Index.open(p)
+        assert e2.value.code == api.E_FORMAT
+
+
 @pytest.mark.parametrize("broadcast", [False, True])
 def test_bench_starts_its_own_two_ranks(broadcast):
     """`python bench.py --gpus 2` with no launcher around it: two child ranks, one JSON line with n_gpus 2, results of

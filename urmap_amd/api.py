@@ -33,7 +33,7 @@ EXPORTS = (
     "urmapx_seed_probe", "urmapx_seed_probe_device", "urmapx_viterbi_batch", "urmapx_strerror", "urmapx_device_arch",
     "urmapx_make_ufi", "urmapx_make_ufi_opts", "urmapx_build_slots", "urmapx_make_ufi_gpu", "urmapx_build_slots_gpu", "urmapx_sam_se", "urmapx_sam_header_sq", "urmapx_ctx_phase_cycles", "urmapx_ctx_read_cycles", "urmapx_ctx_stage_ms", "urmapx_ctx_phase3", "urmapx_ctx_round_ms", "urmapx_ctx_dp_rounds", "urmapx_ctx_dp_stats", "urmapx_map_pe", "urmapx_sam_pe", "urmapx_map_pe_device", "urmapx_ctx_set_pe_veryfast",
     "urmapx_gunzip_file", "urmapx_fastq_open", "urmapx_fastq_next", "urmapx_fastq_error", "urmapx_fastq_close",
-    "urmapx_ctx_gather_microbench", "urmapx_map_files", "urmapx_host_pool_trim", "urmapx_text_create", "urmapx_text_destroy", "urmapx_text_map_se", "urmapx_text_map_pe", "urmapx_pgzip_simd", "urmapx_text_fetch_sam", "urmapx_text_set_deferred", "urmapx_text_wait", "urmapx_text_fetch_pairs", "urmapx_ctx_set_pair_info", "urmapx_ctx_get_pair_info", "urmapx_tab_pe",
+    "urmapx_ctx_gather_microbench", "urmapx_map_files", "urmapx_host_pool_trim", "urmapx_text_create", "urmapx_text_destroy", "urmapx_text_map_se", "urmapx_text_map_pe", "urmapx_pgzip_simd", "urmapx_index_open_device", "urmapx_text_fetch_sam", "urmapx_text_set_deferred", "urmapx_text_wait", "urmapx_text_fetch_pairs", "urmapx_ctx_set_pair_info", "urmapx_ctx_get_pair_info", "urmapx_tab_pe",
 )
 
 
@@ -242,6 +242,13 @@ class Index:
     def open(cls, path):
         h = C.c_void_p()
         _check(lib().urmapx_index_open(os.fsencode(path), C.byref(h)), f"urmapx_index_open({path})")
+        return cls(h.value)
+
+    @classmethod
+    def open_device(cls, path, device=0):
+        """UFIndex::FromFile straight into the HBM of `device` (no host copy of the arrays is kept): what the command line loads with."""
+        h = C.c_void_p()
+        _check(lib().urmapx_index_open_device(os.fsencode(path), int(device), C.byref(h)), f"urmapx_index_open_device({path})")
         return cls(h.value)
 
     @classmethod

@@ -143,7 +143,13 @@ static int cmd_map(const Opts &o, int argc, char **argv) {
 	if (o.samshards < 0 || o.samshards > 64) die("-samshards must be 0..64");
 	const auto t0 = std::chrono::steady_clock::now();
 	urmapx_index *I = nullptr;
-	check(urmapx_index_open(o.ufi.c_str(), &I), ("Reading index " + o.ufi).c_str());
+	// the file streams to the first device (urmapx_index_open_device); URMAPX_HOST_INDEX=1: through host arrays as before (measurement)
+	if (getenv("URMAPX_HOST_INDEX")) check(urmapx_index_open(o.ufi.c_str(), &I), ("Reading index " + o.ufi).c_str());
+	else {
+		const int rc = urmapx_index_open_device(o.ufi.c_str(), getenv("URMAPX_FORCE_DEVICE") ? atoi(getenv("URMAPX_FORCE_DEVICE")) : o.gpu, &I);
+		if (rc == URMAPX_E_NODEVICE || rc == URMAPX_E_NOMEM) die("Uploading index to the GPU: %s", urmapx_strerror(rc));  // (the message of the upload step, as before)
+		check(rc, ("Reading index " + o.ufi).c_str());
+	}
 	if (o.veryfast && urmapx_index_max_ix(I) > 3) fprintf(stderr, "\nWARNING: index not optimal for -veryfast\n");
 	const double load_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 	std::string cl;

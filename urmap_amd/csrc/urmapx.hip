@@ -1,11 +1,16 @@
 // urmapx.hip -- C ABI (include/urmapx.h) over the gfx950 kernels.  Host side only: .ufi parsing
 // (UFIndex::FromFile, ufindexio.cpp:51-115), device upload, workspace management, batch calls.
 // There is no CPU compute path in this library.
+#include <fcntl.h>
+#include <unistd.h>
+
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "internal.h"
@@ -174,6 +179,108 @@ int urmapx_index_open(const char *path, urmapx_index **out) {
 	return URMAPX_OK;
 }
 
+static int upload_directory(urmapx_index *I);
+
+// nbytes of the file at file_off -> dev: several threads pread pieces of 128 MB into page-locked buffers, each piece goes out with
+// an asynchronous copy while the next is being read (three buffers in flight)
+static int stream_to_device(int fd, uint64_t file_off, size_t nbytes, uint8_t *dev, int threads) {
+	constexpr size_t PIECE = 128u << 20;
+	constexpr int NS = 3;
+	char *stage[NS] = {nullptr, nullptr, nullptr};
+	hipEvent_t ev[NS] = {};
+	hipStream_t st = nullptr;
+	int rc = URMAPX_OK;
+	auto cleanup = [&]() {
+		if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+		for (int k = 0; k < NS; ++k) {
+			if (stage[k]) (void)hipHostFree(stage[k]);
+			if (ev[k]) (void)hipEventDestroy(ev[k]);
+		}
+	};
+	if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { st = nullptr; cleanup(); return URMAPX_E_NODEVICE; }
+	const size_t stage_bytes = std::min(PIECE, std::max<size_t>(nbytes, 1));
+	for (int k = 0; k < NS; ++k)
+		if (hipHostMalloc((void **)&stage[k], stage_bytes, hipHostMallocDefault) != hipSuccess ||
+		    hipEventCreateWithFlags(&ev[k], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); cleanup(); return URMAPX_E_NOMEM; }
+	if (threads < 1) threads = 1;
+	size_t piece = 0;
+	for (size_t off = 0; off < nbytes && rc == URMAPX_OK; off += PIECE, ++piece) {
+		const int k = (int)(piece % NS);
+		const size_t n = std::min(PIECE, nbytes - off);
+		if (piece >= (size_t)NS && hipEventSynchronize(ev[k]) != hipSuccess) { rc = URMAPX_E_NODEVICE; break; }
+		std::atomic<bool> ok{true};
+		std::vector<std::thread> th;
+		const int T = (int)std::min<size_t>((size_t)threads, (n + (4u << 20) - 1) / (4u << 20));
+		for (int t = 0; t < T; ++t)
+			th.emplace_back([&, t] {
+				const size_t lo = n * (size_t)t / (size_t)T, hi = n * (size_t)(t + 1) / (size_t)T;
+				size_t got = lo;
+				while (got < hi) {
+					const ssize_t r = pread(fd, stage[k] + got, hi - got, (off_t)(file_off + off + got));
+					if (r <= 0) { ok.store(false); return; }
+					got += (size_t)r;
+				}
+			});
+		for (auto &x : th) x.join();
+		if (!ok.load()) { rc = URMAPX_E_FORMAT; break; }  // the file ends inside the array
+		if (hipMemcpyAsync(dev + off, stage[k], n, hipMemcpyHostToDevice, st) != hipSuccess || hipEventRecord(ev[k], st) != hipSuccess) rc = URMAPX_E_NODEVICE;
+	}
+	if (st && hipStreamSynchronize(st) != hipSuccess && rc == URMAPX_OK) rc = URMAPX_E_NODEVICE;
+	cleanup();
+	return rc;
+}
+
+// UFIndex::FromFile (ufindexio.cpp:51-115) straight into HBM.  urmapx_index_open reads the file into host arrays with one thread (27 GB at hg38
+// scale: 10-13 s) and urmapx_index_upload copies them out of pageable memory (4-5 s more); a run of `urmap -map` that maps 10 M reads in
+// half a second spent 15 s there.  Here the header is parsed as before and the two arrays stream from the file to the device through
+// page-locked buffers, read by several threads; nothing of them stays on the host (urmapx_index_replicate copies device to device then).
+int urmapx_index_open_device(const char *path, int device, urmapx_index **out) {
+	if (!path || !out) return URMAPX_E_ARG;
+	*out = nullptr;
+	FILE *f = fopen(path, "rb");
+	if (!f) return URMAPX_E_IO;
+	urmapx_index *I = new urmapx_index;
+	uint32_t u = 0, seqCount = 0;
+	bool ok = rd(f, &u, 4) && u == MAGIC1 && rd(f, &I->W, 4) && rd(f, &I->maxIx, 4) && rd(f, &I->seqDataSize, 4) &&
+	          rd(f, &I->slotCount, 8) && rd(f, &seqCount, 4);
+	for (uint32_t i = 0; ok && i < seqCount; ++i) {
+		uint32_t L, off, n;
+		ok = rd(f, &L, 4) && rd(f, &off, 4) && rd(f, &n, 4) && n < (1u << 20);
+		if (!ok) break;
+		std::string s(n, '\0');
+		ok = rd(f, &s[0], n);
+		I->seqLengths.push_back(L);
+		I->seqOffsets.push_back(off);
+		I->labels.push_back(std::string(s.c_str()));
+	}
+	ok = ok && rd(f, &u, 4) && u == MAGIC2 && I->slotCount > 0 && I->W >= 1 && I->W <= 32;
+	if (!ok) { fclose(f); delete I; return URMAPX_E_FORMAT; }
+	const uint64_t blob_off = (uint64_t)ftello(f);
+	const size_t nb = 5 * I->slotCount;
+	const uint64_t seq_off = blob_off + nb + 4;
+	// the two magic words behind the arrays, before anything is allocated
+	uint32_t m3 = 0, m5 = 0;
+	const int fd = fileno(f);
+	ok = pread(fd, &m3, 4, (off_t)(blob_off + nb)) == 4 && m3 == MAGIC3 && pread(fd, &m5, 4, (off_t)(seq_off + I->seqDataSize)) == 4 && m5 == MAGIC5;
+	if (!ok) { fclose(f); delete I; return URMAPX_E_FORMAT; }
+	hipError_t e = hipSetDevice(device);
+	uint8_t *db = nullptr, *ds = nullptr;
+	if (e == hipSuccess) e = hipMalloc((void **)&db, nb + BLOB_TAIL_PAD);
+	if (e == hipSuccess) e = hipMalloc((void **)&ds, (size_t)I->seqDataSize + SEQ_TAIL_PAD);
+	if (e != hipSuccess) { (void)hipGetLastError(); if (db) (void)hipFree(db); fclose(f); delete I; return hip_rc(e); }
+	I->d_blob = db; I->d_seq = ds; I->own_dev = true; I->device = device;
+	int rc = URMAPX_OK;
+	if (hipMemset(db + nb, 0, BLOB_TAIL_PAD) != hipSuccess || hipMemset(ds + I->seqDataSize, 0, SEQ_TAIL_PAD) != hipSuccess) rc = URMAPX_E_NODEVICE;
+	const int threads = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+	if (!rc) rc = stream_to_device(fd, blob_off, nb, db, threads);
+	if (!rc) rc = stream_to_device(fd, seq_off, I->seqDataSize, ds, threads);
+	fclose(f);
+	if (!rc) rc = upload_directory(I);
+	if (rc) { urmapx_index_close(I); return rc; }
+	*out = I;
+	return URMAPX_OK;
+}
+
 int urmapx_index_wrap_host(uint32_t W, uint32_t max_ix, uint64_t slot_count, const uint8_t *blob, const uint8_t *seqdata,
                            uint32_t seqdata_size, uint32_t seq_count, const uint32_t *seq_lengths,
                            const uint32_t *offsets, const char *labels, urmapx_index **out) {
@@ -272,13 +379,30 @@ int urmapx_index_upload(urmapx_index *I, int device) {
 // One more replica of the same index on another GPU (the reference shares one UFIndex between all its threads,
 // map.cpp:43-61; here every device holds its own copy in HBM).  The new object borrows src's host arrays.
 int urmapx_index_replicate(const urmapx_index *src, int device, urmapx_index **out) {
-	if (!src || !out || !src->h_blob || !src->h_seq) return URMAPX_E_ARG;
+	if (!src || !out || ((!src->h_blob || !src->h_seq) && (!src->d_blob || !src->d_seq))) return URMAPX_E_ARG;
 	*out = nullptr;
 	urmapx_index *I = new urmapx_index;
 	I->W = src->W; I->maxIx = src->maxIx; I->seqDataSize = src->seqDataSize; I->slotCount = src->slotCount;
 	I->labels = src->labels; I->seqLengths = src->seqLengths; I->seqOffsets = src->seqOffsets;
-	I->h_blob = src->h_blob; I->h_seq = src->h_seq;
-	int rc = urmapx_index_upload(I, device);
+	int rc;
+	if (src->h_blob && src->h_seq) {
+		I->h_blob = src->h_blob; I->h_seq = src->h_seq;
+		rc = urmapx_index_upload(I, device);
+	} else {
+		// no host copy (urmapx_index_open_device, urmapx_index_wrap_device): the table and the sequence travel device to device
+		// (xGMI between the GPUs of a node); the packed sequence, the rows and slot16 are rebuilt from them on the new device
+		const size_t nb = 5 * I->slotCount;
+		uint8_t *db = nullptr, *ds = nullptr;
+		hipError_t e = hipSetDevice(device);
+		if (e == hipSuccess) e = hipMalloc((void **)&db, nb + BLOB_TAIL_PAD);
+		if (e == hipSuccess) e = hipMalloc((void **)&ds, (size_t)I->seqDataSize + SEQ_TAIL_PAD);
+		if (e != hipSuccess) { (void)hipGetLastError(); if (db) (void)hipFree(db); delete I; return hip_rc(e); }
+		I->d_blob = db; I->d_seq = ds; I->own_dev = true; I->device = device;
+		if (e == hipSuccess) e = hipMemcpyPeer(db, device, src->d_blob, src->device, nb + BLOB_TAIL_PAD);
+		if (e == hipSuccess) e = hipMemcpyPeer(ds, device, src->d_seq, src->device, (size_t)I->seqDataSize + SEQ_TAIL_PAD);
+		if (e == hipSuccess) e = hipDeviceSynchronize();
+		rc = e == hipSuccess ? upload_directory(I) : hip_rc(e);
+	}
 	if (rc) { urmapx_index_close(I); return rc; }
 	*out = I;
 	return URMAPX_OK;
