@@ -337,7 +337,7 @@ typedef struct urmapx_map_report {  /* State1::HitStats' counters (state1.cpp:59
 	uint32_t alloc_dev_calls, alloc_pinned_calls;
 } urmapx_map_report;
 /* fastq2 NULL: single-end (-map); else the mates' file (-map2 ... -reverse).  samout / tabout may be NULL.  The index
- * needs its host arrays, or to be resident on first_gpu already (then gpus must be 1).  Batch b is mapped on device
+ * needs its host arrays, or to be resident on first_gpu already (the other devices' replicas are then copied from there).  Batch b is mapped on device
  * b mod gpus; records are written in input order.  Returns URMAPX_E_UNSUPPORTED if reads fell outside the device
  * domain (report->unsupported of them), URMAPX_E_FORMAT with the reference's message in err for malformed FASTQ. */
 int urmapx_map_files(urmapx_index *, const urmapx_map_options *, const char *fastq1, const char *fastq2, const char *samout,
