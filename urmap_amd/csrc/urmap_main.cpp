@@ -291,9 +291,15 @@ static int cmd_make_ufi(const Opts &o) {
 // cmd_ufi_validate (ufistats.cpp:141-147): FromFile + UFIndex::Validate (ufindex.cpp:611-658), the pass itself on the device
 static int cmd_ufi_validate(const Opts &o) {
 	urmapx_index *I = nullptr;
-	check(urmapx_index_open(o.ufi_validate.c_str(), &I), ("Reading index " + o.ufi_validate).c_str());
 	setenv("URMAPX_NO_CHAIN_ROWS", "1", 0);  // the pass reads the table itself; the derived row layout is not needed for it
-	check(urmapx_index_upload(I, o.gpu), "index upload");
+	if (getenv("URMAPX_HOST_INDEX")) {
+		check(urmapx_index_open(o.ufi_validate.c_str(), &I), ("Reading index " + o.ufi_validate).c_str());
+		check(urmapx_index_upload(I, o.gpu), "index upload");
+	} else {  // the file streams to the device (urmapx_index_open_device)
+		const int lrc = urmapx_index_open_device(o.ufi_validate.c_str(), o.gpu, &I);
+		if (lrc == URMAPX_E_NODEVICE || lrc == URMAPX_E_NOMEM) check(lrc, "index upload");
+		check(lrc, ("Reading index " + o.ufi_validate).c_str());
+	}
 	urmapx_validate_report r;
 	const int rc = urmapx_index_validate(I, &r);
 	if (rc != URMAPX_OK && rc != URMAPX_E_FORMAT) check(rc, "ufi_validate");
