@@ -630,6 +630,35 @@ def test_cli_gz_input_takes_the_device_text_path(small_case, tmp_path, kind):
 
 
 @pytest.mark.gpu
+def test_cli_bgzf_block_with_a_wrong_crc_is_refused(small_case, tmp_path):
+    """The reference reads BGZF through zlib's gzread, which checks every member's CRC-32; the parallel block reader inflates raw
+    deflate data and checks the trailer's CRC itself (round 5): a block whose stored CRC is off by a bit ends the run with an error,
+    as a damaged plain gzip file does; the intact file maps."""
+    from urmap_amd import synth
+    reads = synth.make_reads(812, small_case["genome"], 3000, read_len=150, sub=0.02, ins=0.002, dele=0.002)
+    fq, sam = os.path.join(tmp_path, "r.fq"), os.path.join(tmp_path, "g.sam")
+    synth.write_fastq(fq, reads)
+    good = _bgzf(open(fq, "rb").read())
+    gz = os.path.join(tmp_path, "r.fq.gz")
+    open(gz, "wb").write(good)
+    rc, err = _urmap(["-map", gz, "-ufi", small_case["ufi"], "-samout", sam])
+    assert rc == 0, err[-1000:]
+    n_ok = len(_file_records(sam))
+    assert n_ok == 3000
+    first = (good[16] | (good[17] << 8)) + 1  # size of the first block
+    bad = bytearray(good)
+    bad[first - 8] ^= 0x01  # lowest byte of the first block's CRC-32
+    open(gz, "wb").write(bytes(bad))
+    rc, err = _urmap(["-map", gz, "-ufi", small_case["ufi"], "-samout", sam])
+    assert rc != 0, err[-500:]
+    plain_bad = bytearray(gzip.compress(open(fq, "rb").read(), 1))
+    plain_bad[-8] ^= 0x01
+    open(gz, "wb").write(bytes(plain_bad))
+    rc2, err2 = _urmap(["-map", gz, "-ufi", small_case["ufi"], "-samout", sam])
+    assert rc2 != 0, err2[-500:]
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("second", ["gz", "plain", "bgzf"])
 def test_cli_gz_pairs_take_the_device_text_path(small_case, tmp_path, second):
     from urmap_amd import synth

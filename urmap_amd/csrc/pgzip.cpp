@@ -564,6 +564,8 @@ struct ParallelGunzip::Impl {
 	}
 };
 
+uint32_t crc32_fast(const uint8_t *p, size_t n) { return crc32_of(p, n); }
+
 ParallelGunzip::ParallelGunzip() : d_(new Impl) {}
 ParallelGunzip::~ParallelGunzip() {
 	if (d_->zs_init) inflateEnd(&d_->zs);

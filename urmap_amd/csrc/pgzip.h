@@ -24,6 +24,9 @@
 
 namespace urx {
 
+// zlib's crc32(0, p, n), by carry-less multiplication where the host has it (pgzip.cpp: verified against zlib at first use)
+uint32_t crc32_fast(const uint8_t *p, size_t n);
+
 class ParallelGunzip {
 public:
 	ParallelGunzip();

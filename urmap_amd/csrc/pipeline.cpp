@@ -538,7 +538,7 @@ private:
 		return got;
 	}
 	size_t read_bgzf(char *dst, size_t cap, int threads) {
-		struct Blk { size_t in, in_len, out, out_len; };
+		struct Blk { size_t in, in_len, out, out_len; uint32_t crc; };
 		std::vector<Blk> blks;
 		size_t out = 0;
 		for (;;) {
@@ -557,7 +557,8 @@ private:
 			const size_t isize = (size_t)tl[0] | ((size_t)tl[1] << 8) | ((size_t)tl[2] << 16) | ((size_t)tl[3] << 24);
 			if (isize > 65536) { bad_ = true; break; }
 			if (out + isize > cap) break;
-			blks.push_back(Blk{cbeg_ + 18, bsize - 26, out, isize});
+			const uint32_t crc = (uint32_t)tl[-4] | ((uint32_t)tl[-3] << 8) | ((uint32_t)tl[-2] << 16) | ((uint32_t)tl[-1] << 24);
+			blks.push_back(Blk{cbeg_ + 18, bsize - 26, out, isize, crc});
 			out += isize;
 			cbeg_ += bsize;
 		}
@@ -581,6 +582,8 @@ private:
 			z.next_in = cbuf_.data() + b.in; z.avail_in = (uInt)b.in_len;
 			z.next_out = (Bytef *)dst + b.out; z.avail_out = (uInt)b.out_len;
 			if (inflate(&z, Z_FINISH) != Z_STREAM_END || z.avail_out != 0) ok.store(false);
+			// the member's CRC-32, as zlib's gzread checks it for the reference (a raw inflate does not): round 5
+			else if (crc32_fast((const uint8_t *)dst + b.out, b.out_len) != b.crc) ok.store(false);
 		}
 		if (!ok) { bad_ = true; return 0; }
 		return out;
