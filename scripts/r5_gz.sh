@@ -2,12 +2,12 @@
 # GPU box: the .gz reader's phases on the host (scripts/pgzip_phases.py), then the gz / BGZF legs of bench.py twice (light runs)
 R=$GRAFT_REPO_ROOT; cd $R
 O=$R/gpurun_out/r5gz; mkdir -p $O
-python scripts/pgzip_phases.py 2000000 16 2>&1 | tail -12
-URMAPX_PGZIP_NO_SIMD=1 python scripts/pgzip_phases.py 2000000 16 2>&1 | tail -6
+[ -z "$NO_PHASES" ] && python scripts/pgzip_phases.py 2000000 16 2>&1 | tail -12
+[ -z "$NO_PHASES" ] && URMAPX_PGZIP_NO_SIMD=1 python scripts/pgzip_phases.py 2000000 16 2>&1 | tail -6
 export URMAP_BENCH_INDEX_CACHE=/dev/shm/urmap_idx URMAP_BENCH_NO_REFERENCE=1 URMAP_BENCH_NO_E2E_PAIRS=1
 for k in 1 2 3; do
   for simd in on off; do
-    if [ $simd = off ]; then export URMAPX_PGZIP_NO_SIMD=1; else unset URMAPX_PGZIP_NO_SIMD; fi
+    if [ $simd = off ]; then export ${OFFVAR:-URMAPX_PGZIP_NO_SIMD}=1; else unset ${OFFVAR:-URMAPX_PGZIP_NO_SIMD}; fi
     python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-workloads > $O/gz_${simd}_$k.json 2> $O/gz_${simd}_$k.err
     python - <<PY
 import json
