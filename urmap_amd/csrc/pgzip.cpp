@@ -536,6 +536,18 @@ struct ParallelGunzip::Impl {
 		}
 		return true;
 	}
+	bool pread_par(uint8_t *dst, size_t n, uint64_t off, int threads) const {  // a round's 42 MB: one thread's pread was 8 of its 45 ms
+		constexpr size_t PIECE = 2u << 20;
+		if (n < 4 * PIECE || threads < 2) return pread_all(dst, n, off);
+		const long pieces = (long)((n + PIECE - 1) / PIECE);
+		bool ok = true;
+#pragma omp parallel for schedule(static) num_threads(threads) reduction(&& : ok)
+		for (long i = 0; i < pieces; ++i) {
+			const size_t lo = (size_t)i * PIECE, hi = std::min(n, lo + PIECE);
+			ok = ok && pread_all(dst + lo, hi - lo, off + lo);
+		}
+		return ok;
+	}
 	bool zfill() {  // more compressed bytes; false at the end of the file (or a read error)
 		if (zbeg < zhave) return true;
 		const size_t n = (size_t)std::min<uint64_t>(zin.size(), csize - zpos);
@@ -658,7 +670,9 @@ size_t ParallelGunzip::read(char *dst, size_t cap, int threads) {
 		const uint64_t Bread = std::min<uint64_t>(D.csize, B1 + SLACK);
 		std::vector<uint8_t> &cbuf = D.cbuf;
 		if (cbuf.size() < (size_t)(Bread - B0) + 16) cbuf.resize((size_t)(Bread - B0) + 16);
-		if (!D.pread_all(cbuf.data(), (size_t)(Bread - B0), B0)) { bad_ = true; break; }
+		const double tread0 = omp_get_wtime();
+		if (!D.pread_par(cbuf.data(), (size_t)(Bread - B0), B0, threads)) { bad_ = true; break; }
+		const double tread = omp_get_wtime() - tread0;
 		memset(cbuf.data() + (Bread - B0), 0, 16);
 		const uint64_t end_bits = (Bread - B0) * 8, cut_bits = (B1 - B0) * 8;
 		const bool last_round = B1 == D.csize;
@@ -862,7 +876,7 @@ size_t ParallelGunzip::read(char *dst, size_t cap, int threads) {
 		if (direct) done += total;
 		if (getenv("URMAPX_PGZIP_VERBOSE"))
 			fprintf(stderr, "pgzip round: %d segments (%d kept), %.1f MB in, %.1f MB out; read %.3f, find %.3f, decode %.3f, mend %.3f, resolve %.3f, crc %.3f s\n", T, K,
-			        (B1 - B0) / 1e6, total / 1e6, 0.0, tr1 - tr0, tr2 - tr1, tr3 - tr2, tr4 - tr3, omp_get_wtime() - tr4);
+			        (B1 - B0) / 1e6, total / 1e6, tread, tr1 - tr0, tr2 - tr1, tr3 - tr2, tr4 - tr3, omp_get_wtime() - tr4);
 		D.window = win[(size_t)K];
 		const SegDecoder &L = segs[(size_t)keep[(size_t)K - 1]];
 		if (L.at_eof) D.eof = true;
