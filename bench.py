@@ -710,7 +710,7 @@ def run_cli(oi, d, fq, n_reads, want, ref):
     oi.save(ufi)
     out = {"ufi_GB": round(os.path.getsize(ufi) / 1e9, 2), "ufi_written_in_s": round(time.time() - t0, 1), "reads": n_reads}
     for name, extra in (("index_streamed_to_the_device", {}), ("index_through_host_arrays", {"URMAPX_HOST_INDEX": "1"})):
-        env = dict(os.environ, OMP_WAIT_POLICY="passive", **extra)
+        env = dict(os.environ, OMP_WAIT_POLICY="passive", URMAPX_VERBOSE="1", **extra)
         t = time.time()
         r = subprocess.run([exe, "-map", fq, "-ufi", ufi, "-samout", sam], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
         wall = time.time() - t
@@ -727,6 +727,9 @@ def run_cli(oi, d, fq, n_reads, want, ref):
                 got.append(line.rstrip(b"\n"))
                 if len(got) == len(want):
                     break
+        m = re.search(r"index streamed to device \d+: ([0-9.]+) GB in ([0-9.]+) s \((\d+) reader threads\), resident layouts built in ([0-9.]+) s", text)
+        if m:
+            out.setdefault("load_parts_s", {"file_to_device": float(m.group(2)), "resident_layouts": float(m.group(4)), "reader_threads": int(m.group(3))})
         out[name] = {"wall_s": round(wall, 2), "seconds_to_load_index": num("Seconds to load index"), "seconds_in_mapper": num("Seconds in mapper"),
                      "reads_per_s_of_wall": round(n_reads / wall, 1), "sam_records_identical_to_oracle": bool(got == want)}
         os.remove(sam)

@@ -272,10 +272,16 @@ int urmapx_index_open_device(const char *path, int device, urmapx_index **out) {
 	int rc = URMAPX_OK;
 	if (hipMemset(db + nb, 0, BLOB_TAIL_PAD) != hipSuccess || hipMemset(ds + I->seqDataSize, 0, SEQ_TAIL_PAD) != hipSuccess) rc = URMAPX_E_NODEVICE;
 	const int threads = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+	const auto t0 = std::chrono::steady_clock::now();
 	if (!rc) rc = stream_to_device(fd, blob_off, nb, db, threads);
 	if (!rc) rc = stream_to_device(fd, seq_off, I->seqDataSize, ds, threads);
 	fclose(f);
+	const auto t1 = std::chrono::steady_clock::now();
 	if (!rc) rc = upload_directory(I);
+	if (getenv("URMAPX_VERBOSE"))
+		fprintf(stderr, "urmapx: index streamed to device %d: %.2f GB in %.2f s (%d reader threads), resident layouts built in %.2f s\n", device,
+		        (double)(nb + I->seqDataSize) / 1e9, std::chrono::duration<double>(t1 - t0).count(), threads,
+		        std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count());
 	if (rc) { urmapx_index_close(I); return rc; }
 	*out = I;
 	return URMAPX_OK;
