@@ -709,8 +709,18 @@ def run_cli(oi, d, fq, n_reads, want, ref):
     t0 = time.time()
     oi.save(ufi)
     out = {"ufi_GB": round(os.path.getsize(ufi) / 1e9, 2), "ufi_written_in_s": round(time.time() - t0, 1), "reads": n_reads}
-    for name, extra in (("index_streamed_to_the_device", {}), ("index_through_host_arrays", {"URMAPX_HOST_INDEX": "1"})):
+    # (the first process to read the freshly written .ufi out of /dev/shm reads it at a third of the rate of the ones after it: it is kept apart)
+    variants = [("index_streamed_first_read_of_the_file", {}), ("index_through_host_arrays", {"URMAPX_HOST_INDEX": "1"}), ("index_streamed_to_the_device", {})]
+    if os.environ.get("URMAP_BENCH_CLI_THREADS"):  # measurement: the loader's reader threads
+        variants = [(f"streamed_with_{t}_reader_threads", {"URMAPX_LOAD_THREADS": t}) for t in os.environ["URMAP_BENCH_CLI_THREADS"].split(",")]
+    settle = float(os.environ.get("URMAP_BENCH_CLI_SETTLE_S", 8))
+    out["settle_s_before_each_run"] = settle
+    for name, extra in variants:
         env = dict(os.environ, OMP_WAIT_POLICY="passive", URMAPX_VERBOSE="1", **extra)
+        # The device clears memory a process has freed (122 GB here: this process's replica, then the run before), and a process that
+        # starts within seconds of that waits for it in its first allocations (measured: the same command 4-6 s instead of 2.5-4 s).
+        # A user's run starts on an idle device: each run here waits a few seconds first.
+        time.sleep(settle)
         t = time.time()
         r = subprocess.run([exe, "-map", fq, "-ufi", ufi, "-samout", sam], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
         wall = time.time() - t
@@ -729,7 +739,9 @@ def run_cli(oi, d, fq, n_reads, want, ref):
                     break
         m = re.search(r"index streamed to device \d+: ([0-9.]+) GB in ([0-9.]+) s \((\d+) reader threads\), resident layouts built in ([0-9.]+) s", text)
         if m:
-            out.setdefault("load_parts_s", {"file_to_device": float(m.group(2)), "resident_layouts": float(m.group(4)), "reader_threads": int(m.group(3))})
+            out["load_parts_s"] = {"file_to_device": float(m.group(2)), "resident_layouts": float(m.group(4)), "reader_threads": int(m.group(3))}  # (of the last streamed run)
+            if os.environ.get("URMAP_BENCH_CLI_THREADS"):
+                out.setdefault("file_to_device_s_by_threads", {})[m.group(3)] = float(m.group(2))
         out[name] = {"wall_s": round(wall, 2), "seconds_to_load_index": num("Seconds to load index"), "seconds_in_mapper": num("Seconds in mapper"),
                      "reads_per_s_of_wall": round(n_reads / wall, 1), "sam_records_identical_to_oracle": bool(got == want)}
         os.remove(sam)

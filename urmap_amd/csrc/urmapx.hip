@@ -271,7 +271,8 @@ int urmapx_index_open_device(const char *path, int device, urmapx_index **out) {
 	I->d_blob = db; I->d_seq = ds; I->own_dev = true; I->device = device;
 	int rc = URMAPX_OK;
 	if (hipMemset(db + nb, 0, BLOB_TAIL_PAD) != hipSuccess || hipMemset(ds + I->seqDataSize, 0, SEQ_TAIL_PAD) != hipSuccess) rc = URMAPX_E_NODEVICE;
-	const int threads = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+	int threads = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+	if (const char *e = getenv("URMAPX_LOAD_THREADS")) threads = std::max(1, std::min(256, atoi(e)));  // (measurement)
 	const auto t0 = std::chrono::steady_clock::now();
 	if (!rc) rc = stream_to_device(fd, blob_off, nb, db, threads);
 	if (!rc) rc = stream_to_device(fd, seq_off, I->seqDataSize, ds, threads);
