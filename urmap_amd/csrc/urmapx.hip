@@ -231,8 +231,8 @@ static int stream_to_device(int fd, uint64_t file_off, size_t nbytes, uint8_t *d
 }
 
 // UFIndex::FromFile (ufindexio.cpp:51-115) straight into HBM.  urmapx_index_open reads the file into host arrays with one thread (27 GB at hg38
-// scale: 10-13 s) and urmapx_index_upload copies them out of pageable memory (4-5 s more); a run of `urmap -map` that maps 10 M reads in
-// half a second spent 15 s there.  Here the header is parsed as before and the two arrays stream from the file to the device through
+// scale: 5.5 s out of /dev/shm) and urmapx_index_upload copies them out of pageable memory (3.3 s more); a run of `urmap -map` that maps 10 M
+// reads in 0.7 s spent 9 s there.  Here the header is parsed as before and the two arrays stream from the file to the device through
 // page-locked buffers, read by several threads; nothing of them stays on the host (urmapx_index_replicate copies device to device then).
 int urmapx_index_open_device(const char *path, int device, urmapx_index **out) {
 	if (!path || !out) return URMAPX_E_ARG;
