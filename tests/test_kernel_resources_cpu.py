@@ -29,6 +29,11 @@ CEILINGS = {
     "seed_probe_kernel<3>": (8, 64, 0, 0, 0, 0),
     "validate_kernel": (8, 64, 0, 0, 0, 64),
     "slot16_kernel": (8, 32, 0, 0, 0, 0),
+    # the text stage of the file-to-file lanes (text_gpu.hip)
+    "sam_kernel": (5, 88, 0, 100, 44, 30992),        # 64 heads per wavefront in LDS: 4 x 64 x 96 B + the 1 600-byte buffers of long heads
+    "sam_len_kernel": (8, 48, 0, 0, 0, 10256),
+    "copy_bases_kernel": (8, 32, 0, 0, 0, 0),
+    "record_kernel": (8, 32, 0, 0, 0, 0),
 }
 
 

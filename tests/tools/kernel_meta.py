@@ -71,7 +71,7 @@ def kernel_table(so_path):
     out = {}
     for mangled, nice in zip(names, demangle(names)):
         # "void urx::search_se_kernel<3, false, false, true>(urx::DevIndex, ...)" -> "search_se_kernel<3, false, false, true>"
-        nice = re.sub(r"^void\s+", "", nice)
+        nice = re.sub(r"^void\s+", "", nice).replace("(anonymous namespace)::", "")  # (before the cut at the argument list's parenthesis)
         depth, cut = 0, len(nice)
         for j, ch in enumerate(nice):
             if ch == "<":
