@@ -32,7 +32,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-CODE_VERSION = "r5"    # committed PMC profiles carry the code version they were taken on (pmc_traffic)
+CODE_VERSION = "r6"    # committed PMC profiles carry the code version they were taken on (pmc_traffic)
 
 # work per read of the reference on the survey's 40 Mbp planning genome (instrumented build)
 SURVEY_WORK_PER_READ = {
@@ -121,14 +121,49 @@ HG38_LENGTHS_MBP = [248.96, 242.19, 198.30, 190.21, 181.54, 170.81, 159.35, 145.
                     114.36, 107.04, 101.99, 90.34, 83.26, 80.37, 58.62, 64.44, 46.71, 50.82, 156.04, 57.23]
 
 
+_M64 = (1 << 64) - 1
+
+
+def _s64(x):
+    """a 64-bit pattern as the signed scalar torch's int64 arithmetic takes"""
+    x &= _M64
+    return x - (1 << 64) if x >> 63 else x
+
+
+def _mix_int(x):
+    """splitmix64's finaliser on a Python integer (the key schedule of the generator below)"""
+    x &= _M64
+    x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & _M64
+    x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & _M64
+    return x ^ (x >> 31)
+
+
+def _mix_t(torch, x):
+    """the same finaliser on an int64 tensor: multiplications wrap, `>>` is arithmetic on int64, so the vacated bits are masked off"""
+    x = (x ^ ((x >> 30) & ((1 << 34) - 1))) * _s64(0xBF58476D1CE4E5B9)
+    x = (x ^ ((x >> 27) & ((1 << 37) - 1))) * _s64(0x94D049BB133111EB)
+    return x ^ ((x >> 31) & ((1 << 33) - 1))
+
+
+def _stream_key(seed, a, b=0):
+    """key of the random stream (a, b) of generator `seed`: stream values are _mix_t(key + counter)"""
+    return _s64(_mix_int(_mix_int(seed) ^ _mix_int((a << 20) + b + 0x632BE59BD9B4E019)))
+
+
 def make_genome_torch(torch, seed, total_bp, device, repeat_frac=0.5, n_frac=0.05, max_div=0.20):
     """Concatenated upper-case sequence store as -make_ufi lays it out (ufindex.cpp:462-511): 24 sequences with
     hg38's chromosome length proportions, joined by 32 '-' bytes.  SURVEY.md 8(d) input 2: ~`repeat_frac` of the bases
     are copies of repeat families whose copy numbers are log-uniform in 10..1e5 (family length 300..6000, each copy
-    0..`max_div` diverged from the consensus, either strand), `n_frac` of the bases lie in runs of N.  Built on the GPU;
-    returns the device uint8 tensor, the directory and what was laid down."""
-    g = torch.Generator(device=device)
-    g.manual_seed(seed)
+    0..`max_div` diverged from the consensus, either strand), `n_frac` of the bases lie in runs of N.
+
+    Round 6: the store is a pure function of (seed, total_bp) -- on any device, any box, any torch.  Every random value is a
+    counter-based hash (splitmix64's finaliser over key + counter, integer arithmetic only) instead of a draw from the
+    device's generator, and copies that overlap are laid down in a DEFINED order: families in sequence, the slabs of a family
+    in sequence, the copies of a slab sorted by start with the later start winning (each copy writes up to the start of the
+    next, so one index-put never names a byte twice; rounds 1-5 scattered overlapping copies in one index-put whose order of
+    writes to a duplicate index is undefined, and every run mapped a slightly different genome).  tests/test_genome_cpu.py pins
+    the 40 Mbp store's checksum on the CPU; the same value must come out on the GPU.
+    Returns the device uint8 tensor, the directory and what was laid down."""
     scale = total_bp / (sum(HG38_LENGTHS_MBP) * 1e6)
     lens = [max(2000, int(x * 1e6 * scale)) for x in HG38_LENGTHS_MBP]
     offsets, off = [], 0
@@ -139,49 +174,63 @@ def make_genome_torch(torch, seed, total_bp, device, repeat_frac=0.5, n_frac=0.0
     lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=device)
     comp = torch.tensor(list(b"TGCA"), dtype=torch.uint8, device=device)
     seq = torch.empty(size, dtype=torch.uint8, device=device)
-    step = 1 << 28
+    step = 1 << 27
+    k_base = _stream_key(seed, 1)
     for lo in range(0, size, step):
         hi = min(size, lo + step)
-        seq[lo:hi] = lut[torch.randint(0, 4, (hi - lo,), generator=g, device=device)]
+        seq[lo:hi] = lut[(_mix_t(torch, torch.arange(lo, hi, device=device, dtype=torch.int64) + k_base) >> 40) & 3]
     lens_t = torch.tensor(lens, dtype=torch.int64, device=device)
     offs_t = torch.tensor(offsets, dtype=torch.int64, device=device)
     cum = torch.cumsum(lens_t, 0)
+    total = int(sum(lens))
     budget = int(total_bp * repeat_frac)
+    div_q = int(max_div * (1 << 24))
     laid, fams = 0, []
     hostg = np.random.Generator(np.random.PCG64(seed))
     while laid < budget and len(fams) < 4000:
         fl = int(hostg.integers(300, 6000))
         copies = int(round(10 ** hostg.uniform(1.0, 5.0)))
         copies = max(1, min(copies, (budget - laid) // fl + 1, max(10, int(0.2 * budget) // fl)))
-        fam_idx = torch.randint(0, 4, (fl,), generator=g, device=device)
+        f = len(fams)
+        ar = torch.arange(fl, device=device, dtype=torch.int64)
+        fam_idx = (_mix_t(torch, ar + _stream_key(seed, 2, f)) >> 40) & 3
+        k_copy, k_cell = _stream_key(seed, 3, f), _stream_key(seed, 4, f)
         done = 0
         while done < copies:  # copies of one family, a slab at a time
-            n = min(copies - done, max(1, (1 << 26) // fl))
-            u = (torch.rand(n, generator=g, device=device, dtype=torch.float64) * float(cum[-1])).long()
+            n = min(copies - done, max(1, (1 << 25) // fl))
+            c = torch.arange(done, done + n, device=device, dtype=torch.int64)
+            hc = _mix_t(torch, c + k_copy)                       # per copy: bits 1..62 its place, 0..23 its divergence, 24 its strand
+            u = ((hc >> 1) & ((1 << 62) - 1)) % total
             si = torch.searchsorted(cum, u, right=True).clamp(max=len(lens) - 1)
             p = u - (cum[si] - lens_t[si])
             p = torch.minimum(p, (lens_t[si] - fl - 1).clamp(min=0))
             ok = lens_t[si] > fl + 1
             start = (offs_t[si] + p)[ok]
+            c, hc = c[ok], hc[ok]
             m = int(start.numel())
             done += n
             if m == 0:
                 continue
-            div = torch.rand(m, 1, generator=g, device=device) * max_div
-            mut = torch.rand(m, fl, generator=g, device=device) < div
-            rnd = torch.randint(0, 4, (m, fl), generator=g, device=device)
-            idx4 = torch.where(mut, rnd, fam_idx[None, :].expand(m, fl))
-            minus = torch.rand(m, 1, generator=g, device=device) < 0.5
+            start, order = torch.sort(start, stable=True)
+            c, hc = c[order], hc[order]
+            nxt = torch.cat([start[1:], start[-1:] + fl])
+            keep_len = torch.minimum(nxt - start, torch.full_like(start, fl))  # a copy is written up to where the next one starts
+            thr = (((hc & 0xFFFFFF) * div_q) >> 24)[:, None]                    # this copy's divergence, 0..max_div, as a 24-bit threshold
+            hb = _mix_t(torch, c[:, None] * fl + ar[None, :] + k_cell)          # per base: bits 0..23 "mutated?", 40..41 the random base
+            idx4 = torch.where((hb & 0xFFFFFF) < thr, (hb >> 40) & 3, fam_idx[None, :].expand(m, fl))
+            minus = ((hc >> 24) & 1).bool()[:, None]
             copy = torch.where(minus, comp[idx4.flip(1)], lut[idx4])
-            pos = (start[:, None] + torch.arange(fl, device=device)[None, :]).reshape(-1)
-            seq[pos] = copy.reshape(-1)
-            del div, mut, rnd, idx4, copy, pos
+            keep = ar[None, :] < keep_len[:, None]
+            pos = (start[:, None] + ar[None, :])[keep]
+            seq[pos] = copy[keep]
+            del thr, hb, idx4, copy, pos, keep
         laid += copies * fl
         fams.append((fl, copies))
     # N runs
     n_left = int(total_bp * n_frac)
-    rl_all = torch.randint(100, 50000, (max(1, n_left // 25000 + 8),), generator=g, device=device).tolist()
-    pos_u = torch.rand(len(rl_all), generator=g, device=device, dtype=torch.float64).tolist()
+    n_draw = max(1, n_left // 25000 + 8)
+    rl_all = hostg.integers(100, 50000, n_draw).tolist()
+    pos_u = hostg.random(n_draw).tolist()
     for rl, u in zip(rl_all, pos_u):
         if n_left <= 0:
             break
@@ -196,10 +245,35 @@ def make_genome_torch(torch, seed, total_bp, device, repeat_frac=0.5, n_frac=0.0
         seq[offsets[i] + lens[i]: offsets[i] + lens[i] + 32] = ord("-")
     labels = [f"chr{i + 1}" for i in range(22)] + ["chrX", "chrY"]
     cn = sorted(c for _, c in fams)
-    desc = {"repeat_families": len(fams), "repeat_bases_laid": int(laid), "copy_number_min": cn[0] if cn else 0,
+    desc = {"generator": "bench.make_genome_torch round 6 (counter-based, device-independent)", "seed": int(seed),
+            "repeat_families": len(fams), "repeat_bases_laid": int(laid), "copy_number_min": cn[0] if cn else 0,
             "copy_number_median": cn[len(cn) // 2] if cn else 0, "copy_number_max": cn[-1] if cn else 0,
             "max_divergence": max_div, "n_frac": n_frac}
     return seq, np.array(lens, np.uint32), np.array(offsets, np.uint32), labels, desc
+
+
+def array_checksum(a):
+    """urmapx_checksum_device's value for a host byte array (numpy restatement: include/urmapx.h): the sum modulo 2^64 over the
+    little-endian 64-bit words w_i, the last zero-padded, of murmur64(w_i + (i + 1) * 0x9E3779B97F4A7C15)"""
+    a = np.ascontiguousarray(a).view(np.uint8).reshape(-1)
+    n = a.size
+    total = 0
+    step = 1 << 24
+    with np.errstate(over="ignore"):
+        for lo in range(0, n, step):
+            part = a[lo:lo + step]
+            if part.size & 7:
+                part = np.concatenate([part, np.zeros(8 - (part.size & 7), np.uint8)])
+            w = part.view("<u8").astype(np.uint64)
+            i = np.arange(lo // 8 + 1, lo // 8 + 1 + w.size, dtype=np.uint64)
+            h = w + i * np.uint64(0x9E3779B97F4A7C15)
+            h ^= h >> np.uint64(33)
+            h *= np.uint64(0xFF51AFD7ED558CCD)
+            h ^= h >> np.uint64(33)
+            h *= np.uint64(0xC4CEB9FE1A85EC53)
+            h ^= h >> np.uint64(33)
+            total = (total + int(h.sum(dtype=np.uint64))) & _M64
+    return total
 
 
 def _read_starts(torch, g, d_seq, seq_lengths, seq_offsets, n, span, device):
@@ -280,7 +354,7 @@ def make_pairs_torch(torch, seed, d_seq, seq_lengths, seq_offsets, npairs, L, su
     return torch.stack([r1, r2], dim=1).reshape(-1).contiguous()
 
 
-def pmc_traffic(kernel, reads_per_launch, total_bp, read_len=150, mode="se", code_version=CODE_VERSION, what="fetch"):
+def pmc_traffic(kernel, reads_per_launch, total_bp, read_len=150, mode="se", code_version=CODE_VERSION, what="fetch", source=None):
     """HBM read (what="fetch") or written (what="write") bytes per launch of `kernel` from the committed rocprofv3 --pmc FETCH_SIZE /
     WRITE_SIZE pass of this same workload (profiles/r*/pmc_fetch_*.json, pmc_write_*.json; bench.py cannot collect PMCs itself).  A
     profile counts only if it names the same mode (se / pe), read length, genome size and code version; None otherwise -- no claim
@@ -299,6 +373,8 @@ def pmc_traffic(kernel, reads_per_launch, total_bp, read_len=150, mode="se", cod
         if abs(d.get("genome_bp", 3.1e9) - total_bp) > 0.02 * total_bp:
             continue
         best = d["kernels"][kernel]["hbm_read_bytes_per_launch" if what == "fetch" else "hbm_write_bytes_per_launch"] * reads_per_launch / d["reads_per_launch"]
+        if source is not None:
+            source[what] = os.path.relpath(path, ROOT)
     return None if best is None else round(best)
 
 
@@ -598,6 +674,32 @@ def run_reference(ref_bin, oi, d, fq, fq_head, n_reads, n_head, cores, product_s
             "sam_records_identical_to_product": bool(sorted(got) == want), "sam_records_checked": len(want)}
 
 
+def sam_head_records(path, n):
+    """the first n records (lines that are not header lines) of a SAM file"""
+    got = []
+    with open(path, "rb") as f:
+        for line in f:
+            if line.startswith(b"@"):
+                continue
+            got.append(line.rstrip(b"\n"))
+            if len(got) == n:
+                break
+    return got
+
+
+def sam_tail_records(path, n, per_record=700):
+    """the last n records of a SAM file, read from its end (the file may be tens of GB)"""
+    size = os.path.getsize(path)
+    want = n * per_record
+    while True:
+        with open(path, "rb") as f:
+            f.seek(max(0, size - want))
+            lines = f.read().split(b"\n")[:-1]
+        if len(lines) > n or want >= size:
+            return [l for l in lines if not l.startswith(b"@")][-n:]
+        want *= 2
+
+
 def write_ceiling_gbs(d, total=1 << 30, piece=64 << 20):
     """What one thread's pwrite reaches on the medium the SAM file is written to (the same directory): GB/s."""
     buf = bytes(piece)
@@ -771,6 +873,13 @@ def run_e2e(torch, api, oi, index, device, d_seq, seq_lengths, seq_offsets, L, s
         n_chk = min(n_reads // 4, 400_000)
         fq_head, sam_o = os.path.join(d, "head.fq"), os.path.join(d, "oracle.sam")
         write_fastq_fixed(fq_head, reads[: n_chk * L], n_chk, L)
+        # the LAST n_chk reads too (chunk numbers, byte offsets and path-arena offsets are largest at the end of the file);
+        # their labels are the file's (write_fastq_fixed counts from 0: the tail file is cut out of the big one below)
+        fq_tail, sam_ot = os.path.join(d, "tail.fq"), os.path.join(d, "oracle_tail.sam")
+        rec_bytes = fq_bytes // n_reads
+        with open(fq, "rb") as f, open(fq_tail, "wb") as g:
+            f.seek((n_reads - n_chk) * rec_bytes)
+            g.write(f.read())
         del reads
         runs = []
         for _ in range(2):  # the second run has its buffers and the page cache warm; both are reported
@@ -786,15 +895,11 @@ def run_e2e(torch, api, oi, index, device, d_seq, seq_lengths, seq_offsets, L, s
                 ref = None
                 print(f"bench.py: reference binary not timed: {e}", file=sys.stderr)
         want = [l for l in open(sam_o, "rb").read().split(b"\n") if l and not l.startswith(b"@")]
-        got = []
-        with open(sam, "rb") as f:
-            for line in f:
-                if line.startswith(b"@"):
-                    continue
-                got.append(line.rstrip(b"\n"))
-                if len(got) == len(want):
-                    break
-        same = got == want
+        same = sam_head_records(sam, len(want)) == want
+        oi.map_file_se(fq_tail, sam_ot, threads=cores)
+        want_tail = [l for l in open(sam_ot, "rb").read().split(b"\n") if l and not l.startswith(b"@")]
+        same_tail = len(want_tail) == n_chk and sam_tail_records(sam, n_chk) == want_tail
+        os.remove(fq_tail); os.remove(sam_ot)
         bound, shares = e2e_bound(rep)
         # the same run with the SAM text dropped after it has reached the host: what the device lanes sustain when the output
         # medium is out of the way, and where a lane's time goes (events on the lanes' streams)
@@ -838,14 +943,16 @@ def run_e2e(torch, api, oi, index, device, d_seq, seq_lengths, seq_offsets, L, s
                "mapped_q10_frac": round(rep["mapped_q"] / max(1, rep["reads"]), 4),
                "lanes_view": lane_view(rep), "first_run_lanes_view": lane_view(runs[0]),
                "placement": rep["placement"].decode(),  # NUMA node of each device's PCI function = where its lane threads ran (@any: not pinned)
-               "sam_records_identical_to_oracle": bool(same), "sam_records_checked": len(want),
+               "sam_records_identical_to_oracle": bool(same and same_tail), "sam_records_checked": len(want) + len(want_tail),
+               "sam_slices_checked": {"head": [0, len(want)], "tail": [n_reads - len(want_tail), n_reads], "head_identical": bool(same), "tail_identical": bool(same_tail)},
                "null_sink": null_sink, "sharded": sharded}
         if ref:
             out["reference_binary"] = ref
         if gpus == 1 and not os.environ.get("URMAP_BENCH_NO_E2E_GZ"):
             out["gz"] = run_e2e_gz(api, index, device, d, fq, n_reads, L, want)
         if gpus == 1 and not os.environ.get("URMAP_BENCH_NO_E2E_PAIRS"):
-            out["pairs"] = run_e2e_pairs(torch, api, oi, index, device, d_seq, seq_lengths, seq_offsets, L, n_reads // 2, cores, d)
+            out["pairs"] = run_e2e_pairs(torch, api, oi, index, device, d_seq, seq_lengths, seq_offsets, L,
+                                         int(os.environ.get("URMAP_BENCH_E2E_PAIRS", n_reads)), cores, d)  # BASELINE config 3: 10 M PAIRS
         if gpus == 1 and release_device is not None and not os.environ.get("URMAP_BENCH_NO_CLI"):
             release_device()  # the command line's process loads an index of its own: this process's replica and contexts leave the device first
             try:
@@ -901,34 +1008,58 @@ def run_e2e_gz(api, index, device, d, fq, n_reads, L, want):
 
 def run_e2e_pairs(torch, api, oi, index, device, d_seq, seq_lengths, seq_offsets, L, npairs, cores, d):
     """`urmap -map2`: two mate files -> SAM through urmapx_map_files (cmd_map2) on the resident index, both mate files'
-    chunks parsed and the pair records written on the device.  The head of the SAM is compared with the oracle's."""
-    pairs = make_pairs_torch(torch, 778, d_seq, seq_lengths, seq_offsets, npairs, L, 0.01, 0.02, device).cpu().numpy().reshape(npairs, 2, L)
+    chunks parsed and the pair records written on the device.  BASELINE config 3: 10 M pairs.  The head AND the tail of the SAM are
+    compared with the oracle's."""
     fq1, fq2, sam = os.path.join(d, "m1.fq"), os.path.join(d, "m2.fq"), os.path.join(d, "pairs.sam")
-    b1 = write_fastq_fixed(fq1, np.ascontiguousarray(pairs[:, 0, :]).reshape(-1), npairs, L)
-    b2 = write_fastq_fixed(fq2, np.ascontiguousarray(pairs[:, 1, :]).reshape(-1), npairs, L)
     n_chk = min(npairs // 4, 100_000)
     h1, h2, sam_o = os.path.join(d, "h1.fq"), os.path.join(d, "h2.fq"), os.path.join(d, "pairs_oracle.sam")
-    write_fastq_fixed(h1, np.ascontiguousarray(pairs[:n_chk, 0, :]).reshape(-1), n_chk, L)
-    write_fastq_fixed(h2, np.ascontiguousarray(pairs[:n_chk, 1, :]).reshape(-1), n_chk, L)
-    del pairs
+    t1, t2 = os.path.join(d, "t1.fq"), os.path.join(d, "t2.fq")
+    # the pairs a slab at a time (the generator's index arrays are 8 bytes per base); the mate files are the slabs' files joined,
+    # labels counted through
+    slab, b1, b2 = 2_000_000, 0, 0
+    rec = (2 + 8 + 1) + L + 3 + L + 1
+    with open(fq1, "wb") as f1, open(fq2, "wb") as f2:
+        for lo in range(0, npairs, slab):
+            n = min(slab, npairs - lo)
+            pairs = make_pairs_torch(torch, 778 + lo // slab, d_seq, seq_lengths, seq_offsets, n, L, 0.01, 0.02, device).cpu().numpy().reshape(n, 2, L)
+            for f, side in ((f1, 0), (f2, 1)):
+                a = np.empty((n, rec), dtype=np.uint8)
+                a[:, 0] = ord("@"); a[:, 1] = ord("r")
+                idx = np.arange(lo, lo + n, dtype=np.int64)
+                for k in range(8):
+                    a[:, 2 + k] = ((idx // 10 ** (7 - k)) % 10 + ord("0")).astype(np.uint8)
+                a[:, 10] = ord("\n")
+                a[:, 11:11 + L] = pairs[:, side, :]
+                a[:, 11 + L] = ord("\n"); a[:, 12 + L] = ord("+"); a[:, 13 + L] = ord("\n")
+                a[:, 14 + L:14 + 2 * L] = ord("I")
+                a[:, rec - 1] = ord("\n")
+                a.tofile(f)
+            del pairs
+    b1 = b2 = rec * npairs
+    for src, head, tail in ((fq1, h1, t1), (fq2, h2, t2)):
+        with open(src, "rb") as f:
+            open(head, "wb").write(f.read(n_chk * rec))
+            f.seek((npairs - n_chk) * rec)
+            open(tail, "wb").write(f.read())
     runs = [watched(lambda: api.map_files(index, fq1, fq2, samout=sam, first_gpu=device.index, gpus=1, streams=E2E_STREAMS, batch=E2E_BATCH, cmdline="bench.py e2e pairs")) for _ in range(2)]
     rep = runs[-1]
     oi.map_file_pe(h1, h2, sam_o, threads=cores)
     want = [l for l in open(sam_o, "rb").read().split(b"\n") if l and not l.startswith(b"@")]
-    got = []
-    with open(sam, "rb") as f:
-        for line in f:
-            if line.startswith(b"@"):
-                continue
-            got.append(line.rstrip(b"\n"))
-            if len(got) == len(want):
-                break
-    return {"value": round(rep["reads"] / rep["seconds"], 1), "unit": "reads/s", "reads": int(rep["reads"]), "seconds": round(rep["seconds"], 3),
-            "first_run_seconds": round(runs[0]["seconds"], 3),
-            "what": f"urmapx_map_files (= urmap -map2): 2 x {b1 / 1e9:.2f} GB mate files -> {os.path.getsize(sam) / 1e9:.2f} GB SAM file in /dev/shm, "
-                    f"{(b1 + b2) / 1e9:.2f} GB of FASTQ in all; both text stages on the device",
-            "stage_busy_s": {k: round(rep[k], 3) for k in ("parse_s", "gpu_s", "format_s", "write_s")},
-            "sam_records_identical_to_oracle": bool(got == want), "sam_records_checked": len(want), "lanes_view": lane_view(rep)}
+    same = sam_head_records(sam, len(want)) == want
+    oi.map_file_pe(t1, t2, sam_o, threads=cores)
+    want_tail = [l for l in open(sam_o, "rb").read().split(b"\n") if l and not l.startswith(b"@")]
+    same_tail = len(want_tail) == 2 * n_chk and sam_tail_records(sam, 2 * n_chk) == want_tail
+    out = {"value": round(rep["reads"] / rep["seconds"], 1), "unit": "reads/s", "reads": int(rep["reads"]), "pairs": int(npairs), "seconds": round(rep["seconds"], 3),
+           "first_run_seconds": round(runs[0]["seconds"], 3),
+           "what": f"urmapx_map_files (= urmap -map2): 2 x {b1 / 1e9:.2f} GB mate files -> {os.path.getsize(sam) / 1e9:.2f} GB SAM file in /dev/shm, "
+                   f"{(b1 + b2) / 1e9:.2f} GB of FASTQ in all; both text stages on the device",
+           "stage_busy_s": {k: round(rep[k], 3) for k in ("parse_s", "gpu_s", "format_s", "write_s")},
+           "sam_records_identical_to_oracle": bool(same and same_tail), "sam_records_checked": len(want) + len(want_tail),
+           "sam_slices_checked": {"head_pairs": [0, n_chk], "tail_pairs": [npairs - n_chk, npairs], "head_identical": bool(same), "tail_identical": bool(same_tail)},
+           "lanes_view": lane_view(rep)}
+    for p in (fq1, fq2, sam, h1, h2, t1, t2, sam_o):
+        os.remove(p)
+    return out
 
 
 def kernel_table(api, pe, L, nb, kms, counters, total_bp, gather_loads_s, stage_ms=None, p3_ms=None):
@@ -964,9 +1095,11 @@ def kernel_table(api, pe, L, nb, kms, counters, total_bp, gather_loads_s, stage_
         ach = alg * nb / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         k = {"kernel": name, "avg_ms": round(ms, 4), "alg_bytes_per_read": round(alg, 1),
              "achieved_GBs": round(ach, 2), "frac": round(ach / HBM_PEAK_GBS, 5)}
-        t = pmc_traffic(name, nb, total_bp, L, "pe" if pe else "se")
+        src = {}
+        t = pmc_traffic(name, nb, total_bp, L, "pe" if pe else "se", source=src)
         k["hbm_read_bytes_per_launch_pmc"] = t
-        k["hbm_write_bytes_per_launch_pmc"] = pmc_traffic(name, nb, total_bp, L, "pe" if pe else "se", what="write")
+        k["hbm_write_bytes_per_launch_pmc"] = pmc_traffic(name, nb, total_bp, L, "pe" if pe else "se", what="write", source=src)
+        k["pmc_source"] = src or None  # the committed rocprofv3 --pmc pass the two figures are LOOKED UP in (same kernel, workload and code version), not counted in this run
         if name == "search_se_kernel" and p3_ms is not None and p3_ms[0] > 0:
             k["launches"] = {"first (seed + probe + phases 1-2 of every read; phases 4-5 of the reads with nothing to align in phase 3)": round(float(p3_ms[0]), 4),
                              "second (the reads parked at phase 3: replay of AlignHSP's bookkeeping, phases 4-5)": round(float(p3_ms[2]), 4)}
@@ -1016,6 +1149,14 @@ def main():
     index_ok, vrep = index.validate()
     if not index_ok:
         raise SystemExit(f"bench.py: rank {rank}: the resident index does not validate: {vrep}")
+    # which genome and which table this run maps against (urmapx_index_checksum over the resident arrays), next to the values recorded in the
+    # repo for this generator, seed and size (tests/golden/bench_genome.json: the store's, computed on the CPU; profiles/r6: the table's)
+    table_checksum, genome_checksum = index.checksum()
+    recorded = {}
+    try:
+        recorded = json.load(open(os.path.join(ROOT, "tests", "golden", "bench_genome.json"))).get(f"{args.genome_mbp:g}", {})
+    except (OSError, ValueError):
+        pass
     mappers = [api.Mapper(index, device=dev_index, method=6) for _ in range(max(1, args.streams))]
     mapper = mappers[0]
 
@@ -1067,7 +1208,7 @@ def main():
                 t_cpu += time.perf_counter() - t1
                 cpu_reads += nb
                 extra += 1
-            cpu = {"value": round(cpu_reads / t_cpu, 1), "unit": "reads/s", "cores": cores, "kind": "port",
+            cpu = {"value": round(cpu_reads / t_cpu, 1), "unit": "reads/s", "cores": cores, "host_logical_cpus": os.cpu_count(), "kind": "port",
                    "sample": f"{cpu_reads} reads of the timed batches (the last batch first), same index, "
                              f"oracle/liburmap_oracle.so (CPU restatement, SAM-identical to reference urmap) with {cores} "
                              f"OpenMP threads = the CPUs granted to this process ({os.cpu_count()} logical on the host), "
@@ -1109,7 +1250,13 @@ def main():
                                    f"{len(seq_np) / 1e9:.2f} GB sequence resident in HBM); {nb} reads/step, {args.sub:g} sub, {args.indel:g} indel",
                        "reads_per_step": nb, "streams": len(mappers), "reads_per_launch": nb // len(mappers),
                        "read_len": L, "genome_bp": int(len(seq_np)), "slots": int(slots),
-                       "genome": genome_desc, "ranks": {"world": world, "backend": R.backend, "share_devices": bool(R.shared),
+                       "genome": genome_desc,
+                       "genome_checksum": f"{genome_checksum:016x}", "slot_table_checksum": f"{table_checksum:016x}",
+                       "genome_checksum_recorded": recorded.get("checksum"), "slot_table_checksum_recorded": recorded.get("slot_table_checksum"),
+                       "inputs_are_the_recorded_ones": (None if not recorded.get("checksum") else
+                                                        bool(recorded["checksum"] == f"{genome_checksum:016x}" and
+                                                             recorded.get("slot_table_checksum", f"{table_checksum:016x}") == f"{table_checksum:016x}")),
+                       "ranks": {"world": world, "backend": R.backend, "share_devices": bool(R.shared),
                                  "index_bytes_per_rank": t_index.get("index_bytes_per_rank"), "broadcast_s": t_index.get("broadcast_s"),
                                  "broadcast_pieces": t_index.get("broadcast_pieces")},
                        "index_validated": bool(index_ok),
@@ -1136,6 +1283,9 @@ def main():
                                         "achieved_GBs": round(sum(k["alg_bytes_per_read"] for k in kern) * nb / (dt / args.steps) / 1e9, 2)},
                          "traffic": kern[dom]["hbm_read_bytes_per_launch_pmc"],
                          "write_bytes": kern[dom]["hbm_write_bytes_per_launch_pmc"],
+                         "traffic_source": ((kern[dom]["pmc_source"] or {}).get("fetch") and
+                                            f"looked up, not counted in this run: {kern[dom]['pmc_source'].get('fetch')} / {kern[dom]['pmc_source'].get('write')} "
+                                            f"(rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel on this workload, code version {CODE_VERSION}); null when no committed pass names this kernel and version"),
                          "random_gather_peak": {"slot_reads_per_s": round(gather_loads_s), "sector_GBs": round(64.0 * gather_loads_s / 1e9, 1),
                                                 "note": "measured in this run: independent random 5-byte slot reads over the resident table, 64 B sector each"}},
             "kernels": kern,
@@ -1261,7 +1411,7 @@ def main():
                     e2e_index = api.Index.wrap_host(24, 32, slots, blob_np, seq_np, seq_lengths, seq_offsets, labels).upload(dev_index)
                     out["config"]["ranks"]["e2e_index_chain_row_bytes"] = int(e2e_index.chain_row_bytes())
                 out["e2e"] = run_e2e(torch, api, oi, e2e_index, device, d_seq, seq_lengths, seq_offsets, L, args.sub, args.indel,
-                                     int(os.environ.get("URMAP_BENCH_E2E_READS", 2_000_000 * min(world, 8))), cores, ref_bin=None, gpus=world)
+                                     int(os.environ.get("URMAP_BENCH_E2E_READS", 12_500_000 * min(world, 8))), cores, ref_bin=None, gpus=world)  # config 4: 12.5 M reads per device
             except Exception as e:
                 out["e2e"] = {"error": str(e)[:300]}
         print(json.dumps(out), flush=True)

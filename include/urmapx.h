@@ -134,6 +134,14 @@ typedef struct urmapx_validate_report {
 	double seconds;          /* the pass on the device */
 } urmapx_validate_report;
 int urmapx_index_validate(const urmapx_index *, urmapx_validate_report *out);
+/* Which bytes is this?  Checksum of a device-resident array: the sum, modulo 2^64, over its little-endian 64-bit words w_i
+ * (i = 0, 1, ...; the last word zero-padded) of murmur64(w_i + (i + 1) * 0x9E3779B97F4A7C15) with the reference's murmur64
+ * (ufindex.h:50-58).  d_ptr must be 8-byte aligned.  A sum, so the same array gives the same value on every device and in the
+ * numpy restatement of tests/oracle_lib.py.  urmapx_index_checksum: out[0] the resident slot table (5 * slot_count bytes, the
+ * .ufi file's m_Blob), out[1] the sequence store (seqdata_size bytes, m_SeqData) -- bench.py prints both so that a run says which
+ * genome and which table it mapped against (the reference has no counterpart; its -ufi_validate checks consistency, not identity). */
+int urmapx_checksum_device(int device, const void *d_ptr, uint64_t nbytes, uint64_t *out);
+int urmapx_index_checksum(const urmapx_index *, uint64_t out[2]);
 uint32_t urmapx_index_word_length(const urmapx_index *);
 uint32_t urmapx_index_max_ix(const urmapx_index *);
 uint64_t urmapx_index_slot_count(const urmapx_index *);

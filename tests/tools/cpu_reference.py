@@ -35,7 +35,7 @@ def main():
     os.makedirs(args.dir, exist_ok=True)
     dev = torch.device("cuda", 0)
     L = 150
-    d_seq, seq_lengths, seq_offsets, labels = bench.make_genome_torch(torch, 20260101, int(args.genome_mbp * 1e6), dev)
+    d_seq, seq_lengths, seq_offsets, labels, _desc = bench.make_genome_torch(torch, 20260101, int(args.genome_mbp * 1e6), dev)
     seq_np = d_seq.cpu().numpy()
     fa, ufi, fq = (os.path.join(args.dir, x) for x in ("g.fa", "g.ufi", "r.fq"))
     e2e_cli.write_fasta(fa, seq_np, seq_lengths, seq_offsets, labels)

@@ -34,6 +34,7 @@ EXPORTS = (
     "urmapx_make_ufi", "urmapx_make_ufi_opts", "urmapx_build_slots", "urmapx_make_ufi_gpu", "urmapx_build_slots_gpu", "urmapx_sam_se", "urmapx_sam_header_sq", "urmapx_ctx_phase_cycles", "urmapx_ctx_read_cycles", "urmapx_ctx_stage_ms", "urmapx_ctx_phase3", "urmapx_ctx_round_ms", "urmapx_ctx_dp_rounds", "urmapx_ctx_dp_stats", "urmapx_map_pe", "urmapx_sam_pe", "urmapx_map_pe_device", "urmapx_ctx_set_pe_veryfast",
     "urmapx_gunzip_file", "urmapx_fastq_open", "urmapx_fastq_next", "urmapx_fastq_error", "urmapx_fastq_close",
     "urmapx_ctx_gather_microbench", "urmapx_map_files", "urmapx_host_pool_trim", "urmapx_text_create", "urmapx_text_destroy", "urmapx_text_map_se", "urmapx_text_map_pe", "urmapx_pgzip_simd", "urmapx_index_open_device", "urmapx_text_fetch_sam", "urmapx_text_set_deferred", "urmapx_text_wait", "urmapx_text_fetch_pairs", "urmapx_ctx_set_pair_info", "urmapx_ctx_get_pair_info", "urmapx_tab_pe",
+    "urmapx_checksum_device", "urmapx_index_checksum",
 )
 
 
@@ -113,6 +114,8 @@ def lib():
         f.restype = rt
         f.argtypes = [vp]
     L.urmapx_index_validate.argtypes = [vp, C.POINTER(ValidateReport)]
+    L.urmapx_checksum_device.argtypes = [i32, vp, u64, C.POINTER(u64)]
+    L.urmapx_index_checksum.argtypes = [vp, C.POINTER(u64)]
     L.urmapx_index_label.restype = cp
     L.urmapx_index_label.argtypes = [vp, u32]
     L.urmapx_index_seq_length.restype = u32
@@ -231,6 +234,13 @@ def build_slots_gpu(device, slots, seqdata: np.ndarray | None = None, d_seq_ptr=
     return blob
 
 
+def checksum_device(device, d_ptr, nbytes):
+    """urmapx_checksum_device: the checksum of `nbytes` device-resident bytes at the 8-byte-aligned address d_ptr"""
+    out = C.c_uint64(0)
+    _check(lib().urmapx_checksum_device(device, d_ptr, nbytes, C.byref(out)), "urmapx_checksum_device")
+    return int(out.value)
+
+
 class Index:
     """UFIndex (read side): parsed .ufi + its copy in HBM."""
 
@@ -294,6 +304,12 @@ class Index:
         if rc not in (0, E_FORMAT):
             raise UrmapxError(rc, "urmapx_index_validate")
         return rc == 0, {n: getattr(r, n) for n, _ in ValidateReport._fields_}
+
+    def checksum(self):
+        """(slot table, sequence store): urmapx_index_checksum over the resident arrays -- which table and which genome this is"""
+        out = (C.c_uint64 * 2)()
+        _check(lib().urmapx_index_checksum(self.h, out), "urmapx_index_checksum")
+        return int(out[0]), int(out[1])
 
     @property
     def word_length(self): return lib().urmapx_index_word_length(self.h)

@@ -299,4 +299,40 @@ hipError_t validate_index(const DevIndex &X, uint64_t out[9], float *ms) {
 	return e;
 }
 
+// Checksum of a resident byte array (urmapx_checksum_device, urmapx_index_checksum): sum over the array's little-endian 64-bit
+// words w_i (the last one zero-padded) of murmur64(w_i + (i + 1) * 0x9E3779B97F4A7C15), modulo 2^64.  A sum: the order in which the
+// threads add their parts does not matter, so one array has one value on every device and in a numpy restatement.
+__global__ void __launch_bounds__(256) checksum_kernel(const uint8_t *__restrict__ p, uint64_t nbytes, unsigned long long *out) {
+	const uint64_t words = nbytes >> 3;
+	const uint64_t *w = (const uint64_t *)p;
+	uint64_t acc = 0;
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (uint64_t)gridDim.x * blockDim.x)
+		acc += murmur64(w[i] + (i + 1) * 0x9E3779B97F4A7C15ull);
+	if (blockIdx.x == 0 && threadIdx.x == 0 && (nbytes & 7)) {
+		uint64_t t = 0;
+		for (uint64_t k = 0; k < (nbytes & 7); ++k) t |= (uint64_t)p[(words << 3) + k] << (8 * k);
+		acc += murmur64(t + (words + 1) * 0x9E3779B97F4A7C15ull);
+	}
+	for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+	if ((threadIdx.x & 63) == 0) atomicAdd(out, (unsigned long long)acc);
+}
+
+hipError_t checksum_device(const void *d_ptr, uint64_t nbytes, uint64_t *out) {
+	if (((uintptr_t)d_ptr & 7) != 0) return hipErrorInvalidValue;
+	unsigned long long *d = nullptr;
+	hipError_t e = hipMalloc((void **)&d, 8);
+	if (e != hipSuccess) return e;
+	e = hipMemset(d, 0, 8);
+	if (e == hipSuccess) {
+		const uint64_t blocks = ((nbytes >> 3) + 255) / 256;
+		hipLaunchKernelGGL(checksum_kernel, dim3((unsigned)(blocks < 1 ? 1 : blocks < 16384 ? blocks : 16384)), dim3(256), 0, nullptr, (const uint8_t *)d_ptr, nbytes, d);
+		e = hipGetLastError();
+	}
+	unsigned long long v = 0;
+	if (e == hipSuccess) e = hipMemcpy(&v, d, 8, hipMemcpyDeviceToHost);
+	*out = v;
+	(void)hipFree(d);
+	return e;
+}
+
 }  // namespace urx

@@ -185,6 +185,9 @@ hipError_t build_chain_rows(const uint8_t *d_blob, uint64_t slot_count, uint32_t
 // walks, bad hashes, bad positions, bad links, bad row lengths, first bad head slot (all ones: none); ms: the pass on the device
 hipError_t validate_index(const DevIndex &X, uint64_t out[9], float *ms);
 
+// sum of murmur64(word_i + (i + 1) * golden ratio) over the array's little-endian 64-bit words (chain_rows.hip); d_ptr 8-byte aligned
+hipError_t checksum_device(const void *d_ptr, uint64_t nbytes, uint64_t *out);
+
 hipError_t launch_viterbi_batch(const urmapx_params &P, const uint8_t *d_a, const uint32_t *d_aoffs,
                                 const uint8_t *d_b, const uint32_t *d_boffs, const uint8_t *d_flags, uint32_t n,
                                 float *d_scores, uint8_t *d_status, urmapx_path_op *d_ops, uint16_t *d_nops,

@@ -453,6 +453,20 @@ int urmapx_index_validate(const urmapx_index *I, urmapx_validate_report *out) {
 	const bool ok = !v[4] && !v[5] && !v[6] && !v[7] && v[2] == v[3];
 	return ok ? URMAPX_OK : URMAPX_E_FORMAT;
 }
+int urmapx_checksum_device(int device, const void *d_ptr, uint64_t nbytes, uint64_t *out) {
+	if (!d_ptr || !out || ((uintptr_t)d_ptr & 7)) return URMAPX_E_ARG;
+	HIP_TRY(hipSetDevice(device));
+	HIP_TRY(checksum_device(d_ptr, nbytes, out));
+	return URMAPX_OK;
+}
+int urmapx_index_checksum(const urmapx_index *I, uint64_t out[2]) {
+	if (!I || !out) return URMAPX_E_ARG;
+	if (!I->d_blob || !I->d_seq || I->device < 0) return URMAPX_E_ARG;  // urmapx_index_upload first
+	HIP_TRY(hipSetDevice(I->device));
+	HIP_TRY(checksum_device(I->d_blob, 5ull * I->slotCount, &out[0]));
+	HIP_TRY(checksum_device(I->d_seq, I->seqDataSize, &out[1]));
+	return URMAPX_OK;
+}
 uint32_t urmapx_index_word_length(const urmapx_index *I) { return I->W; }
 uint32_t urmapx_index_max_ix(const urmapx_index *I) { return I->maxIx; }
 uint64_t urmapx_index_slot_count(const urmapx_index *I) { return I->slotCount; }
