@@ -80,6 +80,7 @@ def test_the_genome_on_the_device_is_the_recorded_one(big):
     table, seq = big["index"].checksum()  # urmapx_index_checksum over the resident arrays == the numpy restatement on the host arrays
     assert seq == big["genome_checksum"] == big["bench"].array_checksum(big["seq"])
     assert table == big["bench"].array_checksum(np.asarray(big["blob"][: 5 * big["slots"]]))
+    assert f"{table:016x}" == g["slot_table_checksum"]  # the GPU-assisted builder's table == the host builder's, recorded in the build container
 
 
 def _sam_lines(path):

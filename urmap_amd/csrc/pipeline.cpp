@@ -767,7 +767,17 @@ DevicePlace place_of_device(int device) {
 // threads stall between their launches and a run takes three times as long -- seen in half of the bench runs of round 5 (the command line
 // has always set OMP_WAIT_POLICY=passive for this; a library call cannot count on its caller's environment).  Per thread: it applies to the
 // teams this thread starts.
+// kmp_set_blocktime is libomp's (the runtime hipcc links); under another OpenMP runtime -- the sanitizer builds use g++ -- idle workers
+// are the caller's business (OMP_WAIT_POLICY=passive, which the command line and bench.py set anyway).
+#ifdef KMP_VERSION_MAJOR
 inline void omp_workers_sleep_when_idle() { kmp_set_blocktime(0); }
+inline int omp_idle_blocktime() { return kmp_get_blocktime(); }
+inline void omp_set_idle_blocktime(int ms) { kmp_set_blocktime(ms); }
+#else
+inline void omp_workers_sleep_when_idle() {}
+inline int omp_idle_blocktime() { return 0; }
+inline void omp_set_idle_blocktime(int) {}
+#endif
 
 // the calling thread (and the OpenMP team it starts later) onto a device's socket; false: left where it was
 bool pin_to(const DevicePlace &P) { return P.ok && sched_setaffinity(0, sizeof P.cpus, &P.cpus) == 0; }
@@ -843,7 +853,8 @@ int map_files_impl(urmapx_index *I, const urmapx_map_options *opt, const InputRa
 	// host threads for FASTQ parsing and SAM formatting (the mapping itself runs on the GPU)
 	const int host_threads = opt->host_threads > 0 ? opt->host_threads : std::min(16, std::max(1, (int)std::thread::hardware_concurrency()));
 	const int omp_threads_before = omp_get_max_threads();  // this is a library call: the caller's OpenMP setting comes back at the end
-	struct OmpRestore { int n; ~OmpRestore() { omp_set_num_threads(n); } } omp_restore{omp_threads_before};
+	// (the calling thread's block time comes back too -- kmp_set_blocktime(0) below applies to the teams THIS thread starts later)
+	struct OmpRestore { int n, blocktime; ~OmpRestore() { omp_set_num_threads(n); omp_set_idle_blocktime(blocktime); } } omp_restore{omp_threads_before, omp_idle_blocktime()};
 	omp_workers_sleep_when_idle();
 	omp_set_num_threads(host_threads);
 	FileSink sink;
@@ -1256,7 +1267,12 @@ int map_files_impl(urmapx_index *I, const urmapx_map_options *opt, const InputRa
 					if (!handed_back && !fail.set.load()) {
 						const auto tw0 = now();
 						const double ta = trace.ms();
-						if (!sink.write_at(j->out, (size_t)j->rep.sam_bytes, sam_off, write_threads))
+#ifdef URX_FAULT_OFF32  // fault injection for the suite's own check (profiles/r6/fault_off32.txt): the writer's file offset cut to 32 bits
+						const uint64_t at = (uint32_t)sam_off;
+#else
+						const uint64_t at = sam_off;
+#endif
+						if (!sink.write_at(j->out, (size_t)j->rep.sam_bytes, at, write_threads))
 							fail.raise(URMAPX_E_IO, std::string("Error writing ") + samout);
 						sam_off += j->rep.sam_bytes;
 						if (ftab && !j->tab.empty() && fwrite(j->tab.data(), 1, j->tab.size(), ftab) != j->tab.size())

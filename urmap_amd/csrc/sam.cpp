@@ -728,12 +728,12 @@ extern "C" size_t urmapx_sam_pe(const urmapx_index *I, const urmapx_result *r1, 
 	bool proper = false;
 	if (m1 && m2) {
 		if (r1->coord <= r2->coord) {
-			tlen1 = (int)(r2->coord + len2) - (int)r1->coord;
+			tlen1 = (int)((r2->coord + len2) - r1->coord);  // (32-bit wrap-around, as the reference's int arithmetic does on a 2^31-base sequence; no signed overflow)
 			if (tlen1 > 0 && tlen1 < 1000 && consistent) proper = true;
 			if (tlen1 > 1000) tlen1 = 0;
 			tlen2 = -tlen1;
 		} else {
-			tlen2 = (int)(r1->coord + len1) - (int)r2->coord;
+			tlen2 = (int)((r1->coord + len1) - r2->coord);
 			if (tlen2 > 0 && tlen2 < 1000 && consistent) proper = true;
 			if (tlen2 > 1000) tlen2 = 0;
 			tlen1 = -tlen2;
