@@ -420,6 +420,16 @@ __device__ __forceinline__ void glds_dword(const void *gsrc, uint32_t lds_dst) {
 	             : "v"(gsrc), "s"(lds_dst)
 	             : "memory");
 }
+// L2 prefetch (round 6): the 64-byte sectors of [p, p + nbytes) are asked for by LDS-DMA dword loads whose data lands in a sink that
+// nobody reads -- no register is named, so nothing of the wave waits for them or can be overwritten by them.  The search kernels
+// issue these for the NEXT batch of candidate windows before they walk the current one: the real gather of that batch, one
+// batch-time later, finds its sectors in L2 instead of paying an HBM round trip in front of every dependent step.  (Loads return
+// in order: a touch must be issued BEHIND the loads the wave is about to wait for, never in front of them.)
+__device__ __forceinline__ void glds_touch(const uint8_t *p, int nbytes, uint32_t lds_sink) {  // nbytes wave-uniform, a multiple of 4
+	lds_sink = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_sink);  // M0 takes a scalar
+	for (int o = 0; o < nbytes; o += 64) glds_dword(p + o, lds_sink);
+	glds_dword(p + nbytes - 4, lds_sink);
+}
 __device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ void wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 template <class T>

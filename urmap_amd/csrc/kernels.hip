@@ -167,8 +167,15 @@ __global__ __launch_bounds__(64) void viterbi_batch_pair_kernel(urmapx_params P,
 // ------------------------------------------------------------------------------------------------
 // HSP record word: startq | len << 10 | score << 20 | aligned << 30 | plus << 31 (each field <= 1023)
 static constexpr uint32_t PK_MASK = 1023u, PK_LEN_SH = 10, PK_SCORE_SH = 20, PK_ALIGNED = 1u << 30, PK_PLUS_SH = 31;
+// Round 6: the windows of the next candidate batch (and a read's long rows) are touched into L2 ahead of their gathers (dev_common.h:
+// glds_touch).  The sink of those loads is 256 bytes of LDS; the HSP list in LDS gives them up (192 entries instead of 256: a read
+// with more keeps the rest in its block's global scratch, as before) so that the block stays under the 10 240 bytes that let 16 of
+// them share a CU.  URX_PREFETCH=0: the round-5 kernel (A/B builds).
+#ifndef URX_PREFETCH
+#define URX_PREFETCH 1
+#endif
 #ifndef URX_HSP_CAP
-#define URX_HSP_CAP 256  // build-time experiment (profiles/r5/ab_waves5.txt): 64 frees 1.5 KB of LDS per block
+#define URX_HSP_CAP (URX_PREFETCH ? 192 : 256)  // build-time experiment (profiles/r5/ab_waves5.txt): 64 frees 1.5 KB of LDS per block
 #endif
 static constexpr int HSP_CAP = URX_HSP_CAP;        // HSPs of a read held in LDS
 static constexpr int SEARCH_OVF_BLOCKS = 2048;  // grid of the second pass (reads whose HSP list outgrew LDS): these are the
@@ -759,6 +766,7 @@ struct SearchWave {
 	// A position without a k-mer gathered zeros: tally 0 = TALLY_FREE.
 	uint32_t *pr_lo, *pr_hi, *pr_sl;
 	uint64_t *pr_hb;
+	uint32_t pf_sink = 0;  // LDS address of the L2 touches' sink (dev_common.h: glds_touch); 0: no touches
 	__device__ __forceinline__ void probe_get(int s, int q, uint32_t &tally, uint32_t &pos) const {
 		const int e = s * NCH * 64 + (s ? nwords - 1 - q : q);
 		if constexpr (LAYOUT == 1) {
@@ -940,6 +948,22 @@ struct SearchWave {
 					rowstore[(size_t)(NSEG + g) * 64 + lane] = ps[g];
 				}
 			}
+#if URX_PREFETCH
+			// round 6: the rows of three and more (phase 5 reads their entries 1.. out of DevIndex::rows, one dependent round trip in front
+			// of every batch's window gather) are touched into L2 now, behind the next read's probe gathers: phase 4 runs in between
+			if (pf_sink) {
+				const uint32_t sink = (uint32_t)__builtin_amdgcn_readfirstlane((int)pf_sink);
+#pragma unroll
+				for (int g = 0; g < NSEG; ++g)
+					if (rl[g] > 2) {
+						const uint8_t *rp = reinterpret_cast<const uint8_t *>(X.rows + (size_t)(uint32_t)(sl[g] >> 32) + 1);
+						const int nb = 4 * (rl[g] - 1);
+						glds_dword(rp, sink);
+						glds_dword(rp + nb - 4, sink);
+						if (nb > 64) glds_dword(rp + 64, sink);
+					}
+			}
+#endif
 			return;
 		}
 		uint2 info[NSEG];
@@ -1038,6 +1062,7 @@ struct SearchWave {
 // 2 = the second launch: the reads PART 1 parked at phase 3, from the replay of AlignHSP's bookkeeping over their jobs onwards
 // (phases 4-5, then parked for phase 6 like any other read).  n = the batch's reads (PART 2: read from dp3's counter).
 // ROWS: 0 = chains walked hop by hop, 1 = rows looked up in the row layout (rows_fetch), 2 = everything with the probe (DevIndex::slot16)
+#define DBG_NOPF(DBG_) false
 template <int NCH, bool OVF, bool DBG, int ROWS = 0, int PART = 0>
 __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel(DevIndex X, urmapx_params P, const uint8_t *__restrict__ bases,
                                                        const uint64_t *__restrict__ offs, uint32_t n,
@@ -1071,6 +1096,8 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 	// candidate queue (ring): reference position, query position | plus << 14 | second phase << 15
 	__shared__ __attribute__((aligned(8))) uint32_t cq_db[128];
 	__shared__ uint16_t cq_qp[128];
+	constexpr bool PF = URX_PREFETCH != 0 && !DBG_NOPF(DBG);
+	__shared__ uint32_t pf_sink[PF ? 64 : 1];  // where the L2 touches land (glds_touch); never read
 	// between two gather steps both are idle: the next read's slot numbers are staged there on their way to the pr_* arrays
 	static_assert(SW::NSEG * 64 * 4 <= sizeof(pre) && 2 * SW::NSEG * 8 <= sizeof(cq_db), "staging");
 	uint32_t *const stage_sl = reinterpret_cast<uint32_t *>(pre);
@@ -1087,6 +1114,7 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 	S.ropsL = ropsL; S.ropsR = ropsR; S.cand = cand; S.top = top; S.pre = pre;
 	S.hsp_db = hsp_db; S.hsp_pk = hsp_pk;
 	S.pr_lo = pr_lo; S.pr_hi = pr_hi; S.pr_sl = pr_sl; S.pr_hb = pr_hb;
+	if constexpr (PF) S.pf_sink = lds_addr(pf_sink);
 	{
 		uint8_t *sc = scratch + (size_t)blockIdx.x * scratch_stride;
 		S.rowstore = reinterpret_cast<uint32_t *>(sc);
@@ -1390,7 +1418,8 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 					if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long *>(stats) + 1 + slot, (unsigned long long)(now - tsub));
 					tsub = now;
 				};
-				while (qcount < 64 && scanned < total) {
+				// (PF: the scan runs one step ahead -- up to 128 queued -- so that the batch after this one is known when its windows are touched)
+				while (qcount < (PF ? 65 : 64) && scanned < total) {
 					const int g = scanned + lane;
 					uint32_t s_qpos = 0, s_db = 0;
 					bool s_plus = true, ok = false;
@@ -1441,14 +1470,29 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 				}
 				qhead = (qhead + nb) & 127; qcount -= nb;
 				URX_SYNC();
+				bool c_live = c_ok;
+				if constexpr (PF) {
+					// scanned a step earlier than it is gathered: a candidate on the diagonal block of a hit found meanwhile returns at once
+					// in the reference (extendpen.cpp:15-17) -- it is dropped here as the scan would have dropped it
+					c_live = c_ok && !S.overlaps_any_hit(c_db - c_qpos);
+					if (__ballot(c_live) == 0) { laps(8); continue; }
+				}
 				laps(8);
 				uint64_t mm[NCH];
 #pragma unroll
 				for (int c = 0; c < NCH; ++c) mm[c] = 0;
 				if (q_other) {  // wave-uniform: a read with bytes outside the code list (IUPAC beyond N, 'u')
-					if (c_ok) lane_mismatch_mask<NCH>(g_seq, c_db - c_qpos, sQ2 + (c_plus ? 0 : SW::QMAX), QL, mm);
+					if (c_live) lane_mismatch_mask<NCH>(g_seq, c_db - c_qpos, sQ2 + (c_plus ? 0 : SW::QMAX), QL, mm);
 				} else {
-					if (c_ok) lane_mismatch_planes<NCH>(g_seqp, c_db - c_qpos, qpl + (c_plus ? 0 : 2 * NCH), QL, mm);
+					if (c_live) lane_mismatch_planes<NCH>(g_seqp, c_db - c_qpos, qpl + (c_plus ? 0 : 2 * NCH), QL, mm);
+				}
+				if constexpr (PF) {
+					// the windows of the batch AFTER this one (already in the queue) on their way into L2 while this one is walked and consumed
+					if (!q_other && lane < qcount) {
+						const int pos = (qhead + lane) & 127;
+						const uint32_t ndblo = cq_db[pos] - (uint32_t)(cq_qp[pos] & 0x3FFFu);
+						glds_touch(reinterpret_cast<const uint8_t *>(g_seqp + (ndblo >> 5)), 16 * ((QL - 1) / 32 + 2), lds_addr(pf_sink));
+					}
 				}
 				laps(9);
 				// ExtendPen's two x-drop walks (extendpen.cpp:25-78), every lane on its own bit vector.  The accumulated
@@ -1459,7 +1503,7 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 				// the first costs -mis * n and no score of the second exceeds QL - n: lanes that can be neither do not walk.
 				int e_kind = 0, e_bst = 0, e_start = 0, e_end = 0, e_pen = 0;
 				bool worth = false;
-				if (c_ok) {
+				if (c_live) {
 					const int nmis = mismatches_outside_seed<NCH>(mm, (int)c_qpos, W);
 					const int floor2 = minhsp > S.best - 4 ? minhsp : S.best - 4;
 					worth = -P.mismatch_score * nmis <= S.maxPen || QL - nmis >= floor2;
