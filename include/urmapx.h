@@ -351,7 +351,13 @@ typedef struct urmapx_map_report {  /* State1::HitStats' counters (state1.cpp:59
 int urmapx_map_files(urmapx_index *, const urmapx_map_options *, const char *fastq1, const char *fastq2, const char *samout,
                      const char *tabout, urmapx_map_report *report, char *err, size_t errcap);
 
-/* Page-locked chunk buffers of urmapx_map_files are kept (up to 16 GiB) for the next call in this process; this frees them. */
+/* What urmapx_map_files keeps for the next call of this process, and what lets go of it:
+ *   - page-locked chunk buffers, up to 16 GiB of host memory (pinning a few hundred MB costs as much as mapping the chunk in it);
+ *   - its lanes: up to 8 mapping contexts with their text stages, 2.5-3 GB of DEVICE memory each (DpJobs, parked states, path arena,
+ *     the chunk's text both ways), keyed on index, device, parameters and the URMAPX_* environment -- a lane is kept only while an
+ *     eighth of the device's memory is still free with it there, so a process that shares the device with another allocator (torch)
+ *     sees at most that much held back.
+ * urmapx_host_pool_trim() frees both; urmapx_index_close() destroys the lanes of its index; URMAPX_NO_LANE_POOL=1 keeps no lanes. */
 void urmapx_host_pool_trim(void);
 
 /* ---- FASTQ bytes in, SAM bytes out (both text stages of -map on the device) ---- */

@@ -663,14 +663,21 @@ class Mapper:
                 if rep.reason == TEXT_SAM_CAP:
                     out = np.empty(int(rep.sam_bytes) + 64, dtype=np.uint8)
                     _check(lib().urmapx_text_fetch_sam(self._text, out.ctypes.data, len(out), C.byref(rep)), "urmapx_text_fetch_sam")
-                d = {k: int(getattr(rep, k)) for k, _ in TextReport._fields_}
+                d = {k: (int(getattr(rep, k)) if not k.startswith("ms_") else float(getattr(rep, k))) for k, _ in TextReport._fields_}
                 if prev is not None:
-                    res.append(finish(prev))
+                    item, prev = prev, None
+                    res.append(finish(item))
                 prev = (out, d)
             if prev is not None:
-                res.append(finish(prev))
+                item, prev = prev, None
+                res.append(finish(item))
         finally:
-            _check(lib().urmapx_text_set_deferred(self._text, 0), "urmapx_text_set_deferred")
+            #  after an exception a chunk may still be on its way: it is waited for before the mode is switched back, and nothing
+            # is raised from here -- the exception that ended the loop is the one the caller sees
+            rep = TextReport()
+            while lib().urmapx_text_wait(self._text, C.byref(rep)) == 0:
+                pass
+            lib().urmapx_text_set_deferred(self._text, 0)
         return res
 
     def fetch_text_sam(self, sam_cap):

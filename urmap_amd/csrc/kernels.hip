@@ -172,7 +172,7 @@ static constexpr uint32_t PK_MASK = 1023u, PK_LEN_SH = 10, PK_SCORE_SH = 20, PK_
 // with more keeps the rest in its block's global scratch, as before) so that the block stays under the 10 240 bytes that let 16 of
 // them share a CU.  URX_PREFETCH=0: the round-5 kernel (A/B builds).
 #ifndef URX_PREFETCH
-#define URX_PREFETCH 1
+#define URX_PREFETCH 0  // bit 0: the next batch's windows, bit 1: a read's long rows
 #endif
 #ifndef URX_HSP_CAP
 #define URX_HSP_CAP (URX_PREFETCH ? 192 : 256)  // build-time experiment (profiles/r5/ab_waves5.txt): 64 frees 1.5 KB of LDS per block
@@ -948,7 +948,7 @@ struct SearchWave {
 					rowstore[(size_t)(NSEG + g) * 64 + lane] = ps[g];
 				}
 			}
-#if URX_PREFETCH
+#if (URX_PREFETCH & 2)
 			// round 6: the rows of three and more (phase 5 reads their entries 1.. out of DevIndex::rows, one dependent round trip in front
 			// of every batch's window gather) are touched into L2 now, behind the next read's probe gathers: phase 4 runs in between
 			if (pf_sink) {
@@ -1096,8 +1096,8 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 	// candidate queue (ring): reference position, query position | plus << 14 | second phase << 15
 	__shared__ __attribute__((aligned(8))) uint32_t cq_db[128];
 	__shared__ uint16_t cq_qp[128];
-	constexpr bool PF = URX_PREFETCH != 0 && !DBG_NOPF(DBG);
-	__shared__ uint32_t pf_sink[PF ? 64 : 1];  // where the L2 touches land (glds_touch); never read
+	constexpr bool PF = (URX_PREFETCH & 1) != 0 && !DBG_NOPF(DBG);
+	__shared__ uint32_t pf_sink[URX_PREFETCH ? 64 : 1];  // where the L2 touches land (glds_touch); never read
 	// between two gather steps both are idle: the next read's slot numbers are staged there on their way to the pr_* arrays
 	static_assert(SW::NSEG * 64 * 4 <= sizeof(pre) && 2 * SW::NSEG * 8 <= sizeof(cq_db), "staging");
 	uint32_t *const stage_sl = reinterpret_cast<uint32_t *>(pre);
@@ -1114,7 +1114,7 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 	S.ropsL = ropsL; S.ropsR = ropsR; S.cand = cand; S.top = top; S.pre = pre;
 	S.hsp_db = hsp_db; S.hsp_pk = hsp_pk;
 	S.pr_lo = pr_lo; S.pr_hi = pr_hi; S.pr_sl = pr_sl; S.pr_hb = pr_hb;
-	if constexpr (PF) S.pf_sink = lds_addr(pf_sink);
+	if constexpr ((URX_PREFETCH & 2) != 0) S.pf_sink = lds_addr(pf_sink);
 	{
 		uint8_t *sc = scratch + (size_t)blockIdx.x * scratch_stride;
 		S.rowstore = reinterpret_cast<uint32_t *>(sc);
@@ -2293,6 +2293,9 @@ int search_block_count(uint32_t max_read_len, int device) {
 	if (e != hipSuccess || per_cu < 1) per_cu = 8;
 	// measurement aid: fewer resident waves with the same code (is the kernel bound by issue or by latency? DESIGN.md 5.0)
 	if (const char *t = getenv("URMAPX_TEST_BLOCKS_PER_CU")) { const int v = atoi(t); if (v >= 1 && v < per_cu) per_cu = v; }
+	// tuning knob (round 6): the persistent search kernel leaves room on every CU -- for the launches of ANOTHER context of the device (a second
+	// lane of urmapx_map_files), which otherwise wait until this kernel's blocks exit (profiles/r6/lanes_blocks.txt)
+	if (const char *t = getenv("URMAPX_BLOCKS_PER_CU")) { const int v = atoi(t); if (v >= 1 && v < per_cu) per_cu = v; }
 	return per_cu * prop.multiProcessorCount;
 }
 

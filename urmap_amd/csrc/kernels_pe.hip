@@ -19,9 +19,16 @@
 
 namespace urx {
 
+// URX_PE_DIET (round 6): the first pass's block under 10 240 bytes of LDS so that FOUR of them fit a SIMD's share of a
+// CU (with 128 VGPRs): one word of hits per mate instead of two (a pair with more than 64 hits on a mate goes to the second pass), 64 HSPs of
+// a mate in LDS instead of 128 (the list goes on in global scratch, as before), 136 seeds per mate instead of QMAX (more: second pass).
+// 0 = the round-5 kernel (3 waves per SIMD, 168 VGPRs, 12.9 KB).  Measured: profiles/r6/ab_pe_waves4.txt.
+#ifndef URX_PE_DIET
+#define URX_PE_DIET 1
+#endif
 static constexpr int PE_HIT_CAP = 64;
-static constexpr int PE_HITW1 = 2;     // hit-list words (64 hits each) of the first pass: 19 of 1 M reads end with 65..83 hits, none with more than 128
-static constexpr int PE_HSP_CAP = 128;       // HSPs of a mate held in LDS
+static constexpr int PE_HITW1 = URX_PE_DIET ? 1 : 2;     // hit-list words (64 hits each) of the first pass: 19 of 1 M reads end with 65..83 hits, none with more than 128
+static constexpr int PE_HSP_CAP = URX_PE_DIET ? 64 : 128;       // HSPs of a mate held in LDS
 static constexpr int PE_HSP_OVF_CAP = 8064;  // per mate, in global scratch
 static constexpr int PE_OVF_BLOCKS = 1024;   // grid of the second pass (the costliest pairs of a batch)
 static constexpr int PE_T2_BLOCKS = 64;      // grid of the third pass (pairs with more than 256 hits on a mate)
@@ -906,7 +913,7 @@ struct Mate {
 // VGPRs): 34.6 ms; asking for 4 (128 VGPRs) the compiler settles at 194 = 2 waves again.  LDS allows 12 blocks per CU
 // for reads <= 192 (13.2 KB each: the DP trace lives in global scratch, the seed-stage arrays share one area by lifetime).
 #ifndef URX_PE_WAVES
-#define URX_PE_WAVES(NCH) ((NCH) <= 3 ? 3 : 2)
+#define URX_PE_WAVES(NCH) ((NCH) <= 3 ? (URX_PE_DIET ? 4 : 3) : 2)
 #endif
 template <int NCH, int TIER>
 __global__ __launch_bounds__(64, TIER == 2 ? 1 : URX_PE_WAVES(NCH)) void search_pe_kernel(DevIndex X, urmapx_params P, const uint8_t *__restrict__ bases,
@@ -932,7 +939,7 @@ __global__ __launch_bounds__(64, TIER == 2 ? 1 : URX_PE_WAVES(NCH)) void search_
 	// later passes: 2 * (QMAX - 20) >= 2 * (QMAX - W + 1) for the word lengths in use (W >= 21).  First pass: QMAX -- a mate returns a
 	// seed only where the diagonal changes (getseed.cpp:60-66), a handful per read; a pair with more goes to the second pass
 	// (LDS per block decides how many pairs a CU keeps in flight)
-	constexpr int SEED_CAP = TIER == 0 ? QMAX : 2 * (QMAX - 20);
+	constexpr int SEED_CAP = TIER == 0 ? (URX_PE_DIET && NCH <= 3 ? 136 : QMAX) : 2 * (QMAX - 20);
 	__shared__ __attribute__((aligned(16))) uint16_t seed_q[2][SEED_CAP];
 	__shared__ __attribute__((aligned(16))) uint32_t seed_db[2][SEED_CAP];
 	// cached ExtendPen outcome of every seed (see extend_pen_cached); bit 15 of seed_pen = "already extended once"

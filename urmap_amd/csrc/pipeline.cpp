@@ -343,7 +343,16 @@ struct PooledLane {
 	bool veryfast, pair_info;
 	urmapx_ctx *C;
 	urmapx_text *T;
+	uint64_t env = 0;  // what the URMAPX_* knobs were when the context was made (a context caches what they decide): reused only under the same
 };
+// every URMAPX_* variable of the environment, names and values, as one number
+uint64_t env_knobs() {
+	uint64_t h = 1469598103934665603ull;
+	for (char **e = environ; e && *e; ++e)
+		if (!strncmp(*e, "URMAPX_", 7) && strncmp(*e, "URMAPX_VERBOSE", 14) && strncmp(*e, "URMAPX_PIPE_TRACE", 17))
+			for (const char *c = *e; *c; ++c) h = (h ^ (unsigned char)*c) * 1099511628211ull;
+	return h;
+}
 class LanePool {
 public:
 	static LanePool &get() { static LanePool *p = new LanePool; return *p; }  // never destroyed, like the page-locked pool
@@ -357,7 +366,7 @@ public:
 		std::lock_guard<std::mutex> l(m_);
 		for (size_t i = 0; i < v_.size(); ++i) {
 			const PooledLane &q = v_[i];
-			if (q.I == I && q.device == device && q.veryfast == veryfast && q.pair_info == pair_info && !memcmp(&q.P, &P, sizeof P)) {
+			if (q.I == I && q.device == device && q.veryfast == veryfast && q.pair_info == pair_info && q.env == env_knobs() && !memcmp(&q.P, &P, sizeof P)) {
 				C = q.C; T = q.T;
 				v_.erase(v_.begin() + (long)i);
 				return true;
@@ -366,7 +375,11 @@ public:
 		return false;
 	}
 	void give(const PooledLane &q) {
-		{
+		// a kept lane holds 2.5-3 GB of device arrays: it stays only while the device has room to spare -- an eighth of its memory still free
+		// with the lane on it (a process that shares the device with other allocators saw the pool's memory as gone)
+		size_t free_b = 0, total_b = 0;
+		const bool roomy = hipSetDevice(q.device) == hipSuccess && hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b >= total_b / 8;
+		if (roomy) {
 			std::lock_guard<std::mutex> l(m_);
 			if (v_.size() < kMax) { v_.push_back(q); return; }
 		}
@@ -781,6 +794,14 @@ inline void omp_set_idle_blocktime(int) {}
 
 // the calling thread (and the OpenMP team it starts later) onto a device's socket; false: left where it was
 bool pin_to(const DevicePlace &P) { return P.ok && sched_setaffinity(0, sizeof P.cpus, &P.cpus) == 0; }
+// A pipeline thread that pinned itself hands its OpenMP workers back unpinned: the workers of its team inherited its
+// narrowed mask when they were made, libomp returns them to a pool the CALLER's later parallel regions draw from, and those would
+// then run on one socket.  Run by the pinned thread as its last act: every thread of its team takes the mask the caller had.
+void unpin_team(bool was_pinned, const cpu_set_t &caller_mask, int team) {
+	if (!was_pinned) return;
+#pragma omp parallel num_threads(team > 0 ? team : 1)
+	(void)sched_setaffinity(0, sizeof caller_mask, &caller_mask);
+}
 
 int map_files_impl(urmapx_index *I, const urmapx_map_options *opt, const InputRange &range, const char *fastq1, const char *fastq2,
                    const char *samout, const char *tabout, urmapx_map_report *report, char *err, size_t errcap) {
@@ -815,8 +836,8 @@ int map_files_impl(urmapx_index *I, const urmapx_map_options *opt, const InputRa
 			urmapx_text *T = texts[(size_t)l];
 			// (a lane of the caller's own index only: the other devices' replicas are closed below.  set_deferred refuses while a text is on its way)
 			if (C && pool_lanes && run_ok && l % gpus == 0 && replicas[0] == I && (!T || urmapx_text_set_deferred(T, 0) == URMAPX_OK))
-				LanePool::get().give(PooledLane{I, phys(0), P, lane_veryfast, lane_pair_info, C, T});
-			else LanePool::destroy(PooledLane{I, 0, P, false, false, C, T});
+				LanePool::get().give(PooledLane{I, phys(0), P, lane_veryfast, lane_pair_info, C, T, env_knobs()});
+			else LanePool::destroy(PooledLane{I, 0, P, false, false, C, T, 0});
 			ctxs[(size_t)l] = nullptr; texts[(size_t)l] = nullptr;
 		}
 		for (int g = 1; g < gpus; ++g) urmapx_index_close(replicas[(size_t)g]);
@@ -857,6 +878,9 @@ int map_files_impl(urmapx_index *I, const urmapx_map_options *opt, const InputRa
 	struct OmpRestore { int n, blocktime; ~OmpRestore() { omp_set_num_threads(n); omp_set_idle_blocktime(blocktime); } } omp_restore{omp_threads_before, omp_idle_blocktime()};
 	omp_workers_sleep_when_idle();
 	omp_set_num_threads(host_threads);
+	cpu_set_t caller_mask;
+	CPU_ZERO(&caller_mask);
+	(void)sched_getaffinity(0, sizeof caller_mask, &caller_mask);
 	FileSink sink;
 	int write_threads_used = 1;
 	bool text_on_device = false;
@@ -1032,7 +1056,8 @@ int map_files_impl(urmapx_index *I, const urmapx_map_options *opt, const InputRa
 			// reader gave up on).  Pipes: they go to the host reader in front of the rest of the pipe, behind pipe_back.
 			std::vector<char> carry, carry2, pipe_back, pipe_back2;
 			std::thread treader([&] {
-				if (one_node) (void)pin_to(places[0]);  // the page-locked chunk buffers are first touched here
+				const bool pinned = one_node && pin_to(places[0]);  // the page-locked chunk buffers are first touched here
+				struct Unpin { bool on; const cpu_set_t &m; int n; ~Unpin() { unpin_team(on, m, n); } } unpin{pinned, caller_mask, read_threads};
 				omp_workers_sleep_when_idle();
 				omp_set_num_threads(read_threads);
 				uint64_t off = range.on ? range.lo[0] : 0, off2 = range.on ? range.lo[1] : 0;
@@ -1154,10 +1179,24 @@ int map_files_impl(urmapx_index *I, const urmapx_map_options *opt, const InputRa
 					for (auto &c : tparsed) c->close();
 					return;
 				}
+				// Round 6: the library's own chunk size (no -batch given) is ramped.  The first chunk of a lane is a quarter of the size, its second
+				// a half: the lanes start after 40 MB have been read instead of 165 MB, and the second lane a quarter-chunk later instead of a whole
+				// one.  The last round of chunks is cut in halves again and again (down to an eighth), so that the run does not end with one lane
+				// mapping a whole chunk while the others have nothing left (10 M reads: 19 chunks of 13 ms, of which the first and the last ran
+				// beside an idle lane).  URMAPX_NO_CHUNK_RAMP=1: every chunk the same size (measurement).
+				const bool ramp = !opt->batch && !getenv("URMAPX_NO_CHUNK_RAMP");
 				for (size_t b = 0; off < fsize && !stop.load() && !fail.set.load() && !text_nomem.load(); ++b) {
 					uint64_t end = fsize;
-					if (off + chunk_bytes < fsize) {
-						end = find_record_start(fq, off + chunk_bytes, fsize);
+					size_t this_chunk = chunk_bytes;
+					if (ramp) {
+						if (b < (size_t)n_lanes) this_chunk = chunk_bytes / 4;
+						else if (b < 2 * (size_t)n_lanes) this_chunk = chunk_bytes / 2;
+						const uint64_t left = fsize - off;
+						if (left <= (uint64_t)n_lanes * chunk_bytes) this_chunk = (size_t)std::min<uint64_t>(this_chunk, std::max<uint64_t>(left / (2 * (uint64_t)n_lanes), chunk_bytes / 8));
+						this_chunk = std::max<size_t>(this_chunk, 4096);
+					}
+					if (off + this_chunk < fsize) {
+						end = find_record_start(fq, off + this_chunk, fsize);
 						if (end == 0) break;  // no record start in sight: the host reader takes it from here
 					}
 					std::unique_ptr<TextJob> j;
@@ -1250,7 +1289,8 @@ int map_files_impl(urmapx_index *I, const urmapx_map_options *opt, const InputRa
 			write_threads_used = write_threads;
 			text_on_device = true;
 			std::thread twriter([&] {
-				if (one_node) (void)pin_to(places[0]);
+				const bool pinned = one_node && pin_to(places[0]);
+				struct Unpin { bool on; const cpu_set_t &m; int n; ~Unpin() { unpin_team(on, m, n); } } unpin{pinned, caller_mask, host_threads};
 				omp_workers_sleep_when_idle();
 				omp_set_num_threads(host_threads);
 				std::unique_ptr<TextJob> j;
@@ -1293,7 +1333,8 @@ int map_files_impl(urmapx_index *I, const urmapx_map_options *opt, const InputRa
 			for (int l = 0; l < n_lanes; ++l)
 				tlanes.emplace_back([&, l] {
 					omp_workers_sleep_when_idle();
-					(void)pin_to(places[(size_t)(l % gpus)]);
+					const bool pinned = pin_to(places[(size_t)(l % gpus)]);
+					struct Unpin { bool on; const cpu_set_t &m; int n; ~Unpin() { unpin_team(on, m, n); } } unpin{pinned, caller_mask, std::max(1, host_threads / n_lanes)};
 					(void)hipSetDevice(phys(l % gpus));
 					urmapx_text *T = texts[(size_t)l];
 					const double tc = trace.ms();
@@ -1582,7 +1623,8 @@ int map_files_impl(urmapx_index *I, const urmapx_map_options *opt, const InputRa
 		lanes.emplace_back([&, l] {
 			urmapx_ctx *C = ctxs[(size_t)l];
 			omp_workers_sleep_when_idle();
-			(void)pin_to(places[(size_t)(l % gpus)]);
+			const bool pinned = pin_to(places[(size_t)(l % gpus)]);
+			struct Unpin { bool on; const cpu_set_t &m; int n; ~Unpin() { unpin_team(on, m, n); } } unpin{pinned, caller_mask, 1};
 			(void)hipSetDevice(phys(l % gpus));
 			std::unique_ptr<Job> j;
 			while (parsed[(size_t)l]->pop(j)) {

@@ -60,6 +60,7 @@ hipError_t hipHostUnregister(void *) { return hipSuccess; }
 hipError_t hipDeviceGetPCIBusId(char *, int, int) { return hipErrorInvalidDevice; }
 hipError_t hipMalloc(void **p, size_t n) { *p = malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
 hipError_t hipFree(void *p) { free(p); return hipSuccess; }
+hipError_t hipMemGetInfo(size_t *f, size_t *t) { *f = (size_t)200 << 30; *t = (size_t)288 << 30; return hipSuccess; }
 }
 
 namespace urx {

@@ -774,7 +774,12 @@ int parse_side(urmapx_text *T, int side, const char *fastq, size_t nbytes, uint3
 // a chunk's tail has crossed PCIe: the times of its last two stages, the formatter's verdict
 int finish_tail(urmapx_text *T, int set, urmapx_text_report *rep) {
 	if (T->tail_ok) HIP_TRY(hipEventSynchronize(T->tail_ev[set][2]));
-	else HIP_TRY(hipStreamSynchronize(T->copy_st ? T->copy_st : ctx_stream(T->C)));
+	else {
+		// no events (their creation failed): the header's copy went out on the main stream, the text's on the main stream too -- deferred
+		// mode is refused without events (urmapx_text_set_deferred) -- so that is the stream to wait for (copy_st was waited for, idle)
+		HIP_TRY(hipStreamSynchronize(ctx_stream(T->C)));
+		if (T->copy_st) HIP_TRY(hipStreamSynchronize(T->copy_st));
+	}
 	*rep = T->tail_rep[set];
 	if (T->tail_ok) {
 		float d = 0, e = 0;
@@ -993,6 +998,7 @@ int urmapx_text_map_pe(urmapx_text *T, const char *fastq1, size_t nbytes1, const
 
 int urmapx_text_set_deferred(urmapx_text *T, int on) {
 	if (!T || T->waiting || T->pending) return URMAPX_E_ARG;
+	if (on && !T->tail_ok) return URMAPX_E_NODEVICE;  // the second stream is ordered behind the first by events: none, no deferred copies (the caller keeps the plain mode)
 	T->deferred = on != 0;
 	return URMAPX_OK;
 }

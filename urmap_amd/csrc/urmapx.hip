@@ -720,7 +720,14 @@ int urmapx_map_se_device(urmapx_ctx *C, const void *d_bases, const void *d_offs,
 		// Off by default: measured on the hg38-scale bench it LOSES 6 % at 150 bases and 4 % at 250 (the first launch gets 1.9 ms
 		// shorter, phase 3's DP launch and the second search launch cost 3.3 ms).  URMAPX_PARK_PHASE3=1 turns it on (tests, measurement).
 		const char *park3 = getenv("URMAPX_PARK_PHASE3");
-		const size_t p3w = (park3 && atoi(park3) > 0) ? p3_state_words(max_read_len) : 0;
+		size_t p3w = (park3 && atoi(park3) > 0) ? p3_state_words(max_read_len) : 0;
+		if (p3w && !C->X.rowinfo) {
+			//  the parked variant runs on the row layout, which an index that was uploaded WITHOUT the knob has dropped once slot16
+			// was built: say so once instead of silently mapping with the inline kernel and reporting zeros
+			static std::atomic<bool> said{false};
+			if (!said.exchange(true)) fprintf(stderr, "urmapx: URMAPX_PARK_PHASE3 is set but the index was uploaded without it (its row layout is gone): phase 3 stays inline\n");
+			p3w = 0;
+		}
 		uint32_t jobs_cap3 = (uint32_t)((uint64_t)n * 2u < (1ull << 30) ? (uint64_t)n * 2u : (1ull << 30)) + 4096u;
 		uint32_t fin_cap3 = n;
 		// test aids: a job array / parking lot too small for the batch -- reads that find no room are mapped by the second pass
