@@ -37,7 +37,9 @@ try:
     del d_seq
     torch.cuda.empty_cache()
     mode = sys.argv[3] if len(sys.argv) > 3 else "blocks"
-    if mode == "ramp":  # the chunk-size ramp of the text phase against chunks of one size, alternating
+    if mode == "files":  # two and three lanes, SAM text dropped and into files
+        settings = [(2, {}), (3, {}), (2, {}), (3, {})]
+    elif mode == "ramp":  # the chunk-size ramp of the text phase against chunks of one size, alternating
         settings = [(2, {"URMAPX_NO_CHUNK_RAMP": "1"}), (2, {}), (2, {"URMAPX_NO_CHUNK_RAMP": "1"}), (2, {}), (3, {"URMAPX_NO_CHUNK_RAMP": "1"}), (3, {})]
     else:
         settings = [(st, {"URMAPX_BLOCKS_PER_CU": str(b)} if b else {}) for st in (2, 3) for b in (0, 15, 14, 12, 0)]
@@ -50,13 +52,13 @@ try:
         print(f"streams {streams} {env or 'default'}: {[round(x['reads'] / x['seconds'] / 1e6, 2) for x in reps]} M reads/s; last: wall {r['seconds']:.3f} s, "
               f"lane busy {r['gpu_s']:.3f}, stream time map {r['dev_map_s']:.3f} (search {r['dev_map_search_s']:.3f}, dp {r['dev_map_dp_s']:.3f}) parse {r['dev_parse_s']:.3f} "
               f"format {r['dev_format_s']:.3f} h2d {r['dev_h2d_s']:.3f} d2h {r['dev_d2h_s']:.3f}, alloc calls {r['alloc_dev_calls']}", flush=True)
-    if mode == "ramp":  # into a file too
-        for env in ({"URMAPX_NO_CHUNK_RAMP": "1"}, {}, {"URMAPX_NO_CHUNK_RAMP": "1"}, {}):
+    if mode in ("ramp", "files"):  # into a file too
+        for env, st in (({"URMAPX_NO_CHUNK_RAMP": "1"}, 2), ({}, 2), ({"URMAPX_NO_CHUNK_RAMP": "1"}, 2), ({}, 2)) if mode == "ramp" else (({}, 2), ({}, 3), ({}, 2), ({}, 3)):
             os.environ.pop("URMAPX_NO_CHUNK_RAMP", None)
             os.environ.update(env)
-            reps = [api.map_files(index, fq, samout=os.path.join(d, "x.sam"), first_gpu=0, gpus=1, streams=2, cmdline="lanes") for _ in range(3)]
-            print(f"one file {env or 'default'}: {[round(x['reads'] / x['seconds'] / 1e6, 2) for x in reps]} M reads/s, write_s {reps[-1]['write_s']:.3f}", flush=True)
-            reps = [api.map_files(index, fq, samout=os.path.join(d, "y.sam"), first_gpu=0, gpus=1, streams=2, cmdline="lanes", sam_shards=2) for _ in range(3)]
-            print(f"two shards {env or 'default'}: {[round(x['reads'] / x['seconds'] / 1e6, 2) for x in reps]} M reads/s", flush=True)
+            reps = [api.map_files(index, fq, samout=os.path.join(d, "x.sam"), first_gpu=0, gpus=1, streams=st, cmdline="lanes") for _ in range(3)]
+            print(f"one file streams {st} {env or 'default'}: {[round(x['reads'] / x['seconds'] / 1e6, 2) for x in reps]} M reads/s, write_s {reps[-1]['write_s']:.3f}", flush=True)
+            reps = [api.map_files(index, fq, samout=os.path.join(d, "y.sam"), first_gpu=0, gpus=1, streams=st, cmdline="lanes", sam_shards=2) for _ in range(3)]
+            print(f"two shards streams {st} {env or 'default'}: {[round(x['reads'] / x['seconds'] / 1e6, 2) for x in reps]} M reads/s", flush=True)
 finally:
     shutil.rmtree(d, ignore_errors=True)

@@ -3,7 +3,7 @@ on how many waves fit a SIMD and on how little they spill, and a compiler bump o
 
 The figures are read out of the gfx950 code objects inside the built liburmapx.so (tests/tools/kernel_meta.py: the
 NT_AMDGPU_METADATA notes), i.e. of the binary that runs on the GPU box -- nothing is recompiled.  Ceilings are what the
-round's profiled build has (profiles/r5/kernel_resources.txt), with no slack on occupancy and about 5 % on spill counts."""
+round's profiled build has (profiles/r6/kernel_resources.txt), with no slack on occupancy and about 5 % on spill counts."""
 import os
 import sys
 
@@ -21,7 +21,8 @@ CEILINGS = {
     "search_se_kernel<3, false, false, 1, 0>": (4, 128, 55, 256, 168, 10048),   # the same on an index without slot16 (row layout only)
     "search_se_kernel<3, false, false, 1, 1>": (4, 128, 16, 228, 64, 10048),    # URMAPX_PARK_PHASE3=1: first launch (no banded DP inside)
     "search_se_kernel<3, false, false, 1, 2>": (4, 120, 0, 150, 0, 10048),      # ... second launch (the reads parked at phase 3)
-    "search_pe_kernel<3, 0>": (3, 168, 16, 292, 68, 12864),                     # 2 x 150 pairs
+    "search_pe_kernel<3, 0>": (4, 128, 72, 292, 272, 10240),                    # 2 x 150 pairs; round 6: the LDS diet (kernels_pe.hip: URX_PE_DIET 2) -- FOUR waves per SIMD, 16 blocks x 10 240 B = a CU's 160 KB
+    "search_pe_kernel<2, 0>": (4, 128, 64, 292, 240, 8256),                     # pairs of reads of up to 128 bases, same diet
     "dp_kernel<3>": (6, 80, 0, 65, 8, 3456),
     "dp_kernel<4>": (6, 80, 0, 65, 8, 4352),
     "finalize_se_kernel<3, false>": (8, 64, 0, 24, 0, 4480),

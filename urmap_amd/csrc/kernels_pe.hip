@@ -19,15 +19,29 @@
 
 namespace urx {
 
-// URX_PE_DIET (round 6): the first pass's block under 10 240 bytes of LDS so that FOUR of them fit a SIMD's share of a
-// CU (with 128 VGPRs): one word of hits per mate instead of two (a pair with more than 64 hits on a mate goes to the second pass), 64 HSPs of
-// a mate in LDS instead of 128 (the list goes on in global scratch, as before), 136 seeds per mate instead of QMAX (more: second pass).
-// 0 = the round-5 kernel (3 waves per SIMD, 168 VGPRs, 12.9 KB).  Measured: profiles/r6/ab_pe_waves4.txt.
+// URX_PE_DIET (round 6): the first pass's block at 10 240 bytes of LDS, so that FOUR of them fit a SIMD's share of a CU
+// (with 128 VGPRs; the round-5 kernel: 12 864 B, 168 VGPRs, three waves).  Where the bytes come from:
+//   1  one word of hits per mate in LDS (hits 65..128 of a mate in the block's global scratch, URX_PE_TAIL; without the tail such a pair
+//      goes to the second pass), 64 HSPs of a mate in LDS instead of 128 (the list goes on in global scratch, as before), 136 seeds per mate
+//      instead of QMAX (a pair with more: second pass)
+//   2  (ships) both words of hits in LDS: 64 HSPs, 104 seeds per mate, a hit's run count in the upper bits of its score word, pending lists
+//      of QMAX - 16 positions, the pending stage's prefix array inside seed_area
+//   0  the round-5 kernel
+// Measured (profiles/r6/ab_pe_waves4.txt, ab_pe_tail.txt), ms per 1 M reads on one box: 0: 21.60, 1: 20.35-20.48, 2: 19.59-19.63.
 #ifndef URX_PE_DIET
-#define URX_PE_DIET 1
+#define URX_PE_DIET 2
 #endif
 static constexpr int PE_HIT_CAP = 64;
-static constexpr int PE_HITW1 = URX_PE_DIET ? 1 : 2;     // hit-list words (64 hits each) of the first pass: 19 of 1 M reads end with 65..83 hits, none with more than 128
+#ifndef URX_PE_TAIL
+#define URX_PE_TAIL 1  // diet 1: hits 65..128 of a mate in global scratch (0: such a pair goes to the second pass)
+#endif
+// URX_PE_DIET 2: BOTH hit words stay in LDS and the bytes come from elsewhere -- 104 seeds per mate, a hit's run count in the upper bits of
+// its score word (reads of up to 192 bases: score < 256), pending lists of QMAX - 16 positions, no tail pointer: 10 216 B
+#define URX_PE_PACK (URX_PE_DIET == 2)
+static constexpr int PE_HITW1 = (URX_PE_DIET == 1 && !URX_PE_TAIL) ? 1 : 2;     // hit-list words (64 hits each) of the first pass: 19 of 1 M reads end with 65..83 hits, none with more than 128
+// ... of which in LDS.  On the diet the second word lives in the block's global scratch (hit_tail): the 19-in-a-million pairs that reach it are
+// also the costliest of a batch, and as the second pass's whole work list they kept a launch of their own going for 1.8 ms (profiles/r6/ab_pe_waves4.txt)
+static constexpr int PE_HITW1_LDS = URX_PE_DIET == 1 ? 1 : 2;
 static constexpr int PE_HSP_CAP = URX_PE_DIET ? 64 : 128;       // HSPs of a mate held in LDS
 static constexpr int PE_HSP_OVF_CAP = 8064;  // per mate, in global scratch
 static constexpr int PE_OVF_BLOCKS = 1024;   // grid of the second pass (the costliest pairs of a batch)
@@ -45,12 +59,31 @@ __host__ __device__ inline size_t pe_rowstore_offset(int qmax) {
 }
 
 __host__ __device__ inline size_t pe_tb_offset(int qmax);
+__host__ __device__ inline size_t pe_tail_offset(int qmax);
 
 // TIER: 0 = first pass (hit lists of PE_HITW1 x 64 per mate), 1 = second pass over the pairs that outgrew a list (4 x 64
 // hits, HSP lists continued in global memory), 2 = third pass over the pairs that outgrew those (PE_HITW2 x 64 = 1024
 // hits per mate: the reference's list has no bound, state1.cpp:193-228; this pass exists so that a pair in a satellite
 // is mapped, not flagged -- it runs a handful of pairs per run and is not tuned)
 static constexpr int PE_HITW2 = 16;
+// The first pass's hits beyond its LDS word (diet): kept out of line, as search_se_kernel's hsp_overflow_add, so that the registers of a
+// path 19 pairs in a million take do not count against the loops every pair runs.  tail: [k] position, [64 + k] score << 1 | plus, [128 + k] runs.
+__device__ __noinline__ bool pe_tail_overlaps_any(const uint32_t *tail, int nt, uint32_t db) {  // wave-uniform db: one hit per lane
+	const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+	return __ballot(lane < nt && (tail[lane] >> 6) == (db >> 6)) != 0;
+}
+__device__ __noinline__ bool pe_tail_overlaps_each(const uint32_t *tail, int nt, uint32_t db) {  // a db per lane
+	bool ov = false;
+	for (int k = 0; k < nt; ++k) ov |= (tail[k] >> 6) == (db >> 6);
+	return ov;
+}
+__device__ __noinline__ uint32_t pe_tail_get(const uint32_t *tail, int at) { return tail[at]; }
+__device__ __noinline__ void pe_tail_put(uint32_t *tail, int k, uint32_t db, uint32_t sp, uint32_t nops) {
+	const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+	if (lane == 0) { tail[k] = db; tail[64 + k] = sp; tail[128 + k] = nops; }
+	__threadfence_block();
+}
+
 // The wave-uniform state of a mate that changes as the pair is searched.  It lives in LDS, not in the Mate object: the Mate
 // objects are in private memory (the pairing loop picks a mate at run time), where every access is a scratch load or
 // store -- a memory round trip for a counter.  Through `hot` it is a ds_read / ds_write (all lanes, same address).
@@ -66,12 +99,15 @@ struct MateHot {
 	bool q_other;  // the read holds a byte outside the code list: its windows are compared as ASCII
 	uint2 *hsp_ovf;             // this mate's HSP list beyond LDS, global
 	urmapx_path_op *hit_paths;  // its hits' paths, global
+#if !URX_PE_PACK
+	uint32_t *hit_tail;         // first pass on the diet: hits beyond the LDS word -- [k] position, [64 + k] score << 1 | plus, [128 + k] runs of the path; global
+#endif
 };
 // Everything a mate owns, as ONE LDS object per mate.  Round 4: a Mate is now a handful of pointers held in registers -- the
 // pointer to this object is the only thing that differs between the two mates, so `the mate picked at run time` is an address
 // computation, not an array of objects in private memory (where every member access was a scratch load: 331 scratch
 // instructions per pair in round 3).  The hit list lives here too (it was four per-lane words per mate in private memory).
-static constexpr int pe_hitw(int tier) { return tier == 0 ? PE_HITW1 : tier == 1 ? 4 : PE_HITW2; }
+static constexpr int pe_hitw(int tier) { return tier == 0 ? PE_HITW1_LDS : tier == 1 ? 4 : PE_HITW2; }
 template <int NCH, int TIER>
 struct MateLds {
 	static constexpr int QMAX = 64 * NCH;
@@ -81,10 +117,11 @@ struct MateLds {
 	__attribute__((aligned(16))) uint8_t sQ[2][QMAX];     // [0] read as given, [1] reverse complement
 	uint32_t hit_db[HITS];
 	uint16_t hit_sp[HITS];   // score << 1 | plus
-	uint8_t hit_nops[HITS];  // runs of a hit's path (<= URMAPX_MAX_PATH_OPS = 96)
+	static constexpr bool PACK = URX_PE_PACK && TIER == 0 && NCH <= 3;  // the run count rides in hit_sp (bits 9..15)
+	uint8_t hit_nops[PACK ? 4 : HITS];  // runs of a hit's path (<= URMAPX_MAX_PATH_OPS = 96)
 	uint32_t hsp_db[PE_HSP_CAP], hsp_ql[PE_HSP_CAP];
 	uint16_t hsp_sf[PE_HSP_CAP];
-	uint8_t pend[2][QMAX];   // pending query positions (stored in a byte, state1.h:86-87)
+	uint8_t pend[2][PACK ? QMAX - 16 : QMAX];   // pending query positions (stored in a byte, state1.h:86-87); at most QL - W + 1 <= QMAX - 20 of them (W >= 21)
 	uint64_t kpl[4][NCH + 1];  // letter planes of the read (probe_dev.h: probe_pair, slot_from_planes)
 };
 template <int NCH, int TIER>
@@ -112,6 +149,11 @@ struct Mate {
 #define q_other (hot->q_other)
 #define hsp_ovf (hot->hsp_ovf)
 #define hit_paths (hot->hit_paths)
+#if URX_PE_PACK
+#define hit_tail ((uint32_t *)nullptr)
+#else
+#define hit_tail (hot->hit_tail)
+#endif
 #define QL (hot->QL)
 #define nwords (hot->nwords)
 #define pendCount (hot->pendCount)
@@ -144,8 +186,18 @@ struct Mate {
 	// aid that lowers the first pass's caps makes it HITW x 16 in the second pass, so that a fixture with a few dozen hits
 	// per mate reaches the third)
 	__device__ __forceinline__ int hits_room() const { return OVF ? HITW << hit_wsh : hit_cap; }
-	__device__ __forceinline__ uint32_t hdb(int i) const { return hit_db[i]; }      // i wave-uniform
-	__device__ __forceinline__ uint32_t hsp_of(int i) const { return hit_sp[i]; }
+	static constexpr int HITS_LDS = MateLds<NCH, TIER>::HITS;
+	static constexpr bool TAIL = TIER == 0 && PE_HITW1_LDS < PE_HITW1;  // hits beyond HITS_LDS exist and live in hit_tail
+	__device__ __forceinline__ uint32_t hdb(int i) const { return (TAIL && i >= HITS_LDS) ? pe_tail_get(hit_tail, i - HITS_LDS) : hit_db[i]; }      // i wave-uniform
+	static constexpr bool PACK = MateLds<NCH, TIER>::PACK;
+	__device__ __forceinline__ uint32_t hsp_of(int i) const {
+		if constexpr (PACK) return (uint32_t)hit_sp[i] & 0x1FFu;
+		return (TAIL && i >= HITS_LDS) ? pe_tail_get(hit_tail, 64 + i - HITS_LDS) : (uint32_t)hit_sp[i];
+	}
+	__device__ __forceinline__ int hnops(int i) const {
+		if constexpr (PACK) return (int)(hit_sp[i] >> 9);
+		return (TAIL && i >= HITS_LDS) ? (int)pe_tail_get(hit_tail, 128 + i - HITS_LDS) : (int)hit_nops[i];
+	}
 	// HSPs: LDS [PE_HSP_CAP] (hsp_db, hsp_ql, hsp_sf); beyond hsp_lds in global scratch as {db, startq | len << 9 | sf << 18}
 	// dbg_cut (MateHot): diagnostic only (URMAPX_DEBUG_STOP_PE 41 / 42 / 43): leave search_pending after that part
 	lds_ptr<uint8_t> rowlen;      // LDS [2 * QMAX]: row length of every pending position, [strand][i]
@@ -157,6 +209,11 @@ struct Mate {
 	__device__ __forceinline__ bool overlaps_hit(uint32_t db) const {
 		bool eq = false;
 		const int n = hitCount;
+		if constexpr (TAIL) {
+			eq = lane < n && (hit_db[lane] >> 6) == (db >> 6);  // (HITS_LDS == 64)
+			if (__ballot(eq) != 0) return true;
+			return n > HITS_LDS && pe_tail_overlaps_any(hit_tail, n - HITS_LDS, db);
+		}
 		for (int b = 0; b < n; b += 64) eq |= b + lane < n && (hit_db[b + lane] >> 6) == (db >> 6);
 		return __ballot(eq) != 0;
 	}
@@ -165,7 +222,8 @@ struct Mate {
 	__device__ __forceinline__ bool overlaps_any_hit(uint32_t db) const {
 		bool ov = false;
 		const int n = hitCount;
-		for (int k = 0; k < n; ++k) ov |= (hit_db[k] >> 6) == (db >> 6);  // one address for all lanes: an LDS broadcast
+		for (int k = 0; k < (TAIL && n > HITS_LDS ? HITS_LDS : n); ++k) ov |= (hit_db[k] >> 6) == (db >> 6);  // one address for all lanes: an LDS broadcast
+		if (TAIL && n > HITS_LDS) ov |= pe_tail_overlaps_each(hit_tail, n - HITS_LDS, db);
 		return ov;
 	}
 
@@ -185,7 +243,12 @@ struct Mate {
 		}
 		if (!keep) return -1;
 		if (hitCount >= hits_room()) { status |= URMAPX_ST_HIT_OVERFLOW; if (topHit == idx) topHit = -1; return -1; }
-		if (lane == 0) { hit_db[idx] = db; hit_sp[idx] = (uint16_t)(((uint32_t)score << 1) | (plus ? 1u : 0u)); hit_nops[idx] = (uint8_t)cand_nops; }
+		if (TAIL && idx >= HITS_LDS) pe_tail_put(hit_tail, idx - HITS_LDS, db, ((uint32_t)score << 1) | (plus ? 1u : 0u), (uint32_t)cand_nops);
+		else if (lane == 0) {
+			hit_db[idx] = db;
+			if constexpr (PACK) hit_sp[idx] = (uint16_t)(((uint32_t)score << 1) | (plus ? 1u : 0u) | ((uint32_t)cand_nops << 9));
+			else { hit_sp[idx] = (uint16_t)(((uint32_t)score << 1) | (plus ? 1u : 0u)); hit_nops[idx] = (uint8_t)cand_nops; }
+		}
 		for (int t = lane; t < cand_nops; t += 64) hit_paths[(size_t)idx * URMAPX_MAX_PATH_OPS + t] = cand[t];
 		URX_SYNC();
 		++hitCount;
@@ -896,6 +959,7 @@ struct Mate {
 #undef q_other
 #undef hsp_ovf
 #undef hit_paths
+#undef hit_tail
 #undef hot
 #undef sQ
 #undef qpl
@@ -934,12 +998,13 @@ __global__ __launch_bounds__(64, TIER == 2 ? 1 : URX_PE_WAVES(NCH)) void search_
 	//   pending-stage row lengths and prefix                               on  seed_q
 	//   the pending stage's candidate queue                                 on  seed_db
 	__shared__ MateLds<NCH, TIER> ml[2];
-	static_assert(URMAPX_MAX_PATH_OPS <= 255, "hit_nops is a byte");
+	static_assert(URMAPX_MAX_PATH_OPS <= 127, "hit_nops is a byte (seven bits when it rides in hit_sp)");
+	static_assert(!M::TAIL || M::HITS_LDS == 64, "the tail begins at hit 64");
 	// Both1 seed lists of the two mates in enumeration order: qpos | plus << 15, db position
 	// later passes: 2 * (QMAX - 20) >= 2 * (QMAX - W + 1) for the word lengths in use (W >= 21).  First pass: QMAX -- a mate returns a
 	// seed only where the diagonal changes (getseed.cpp:60-66), a handful per read; a pair with more goes to the second pass
 	// (LDS per block decides how many pairs a CU keeps in flight)
-	constexpr int SEED_CAP = TIER == 0 ? (URX_PE_DIET && NCH <= 3 ? 136 : QMAX) : 2 * (QMAX - 20);
+	constexpr int SEED_CAP = TIER == 0 ? (URX_PE_DIET && NCH <= 3 ? (URX_PE_PACK ? 104 : 136) : QMAX) : 2 * (QMAX - 20);
 	__shared__ __attribute__((aligned(16))) uint16_t seed_q[2][SEED_CAP];
 	__shared__ __attribute__((aligned(16))) uint32_t seed_db[2][SEED_CAP];
 	// cached ExtendPen outcome of every seed (see extend_pen_cached); bit 15 of seed_pen = "already extended once"
@@ -960,9 +1025,11 @@ __global__ __launch_bounds__(64, TIER == 2 ? 1 : URX_PE_WAVES(NCH)) void search_
 	static_assert((2 * OPS_CAP + URMAPX_MAX_PATH_OPS) * 2 >= 64, "AlignHSP's window lies band_radius + 1 bytes or more inside seed_area (viterbi_dev.h: B_LDS)");
 	uint32_t *const wide_lds = seed_area + ALIGN_BYTES / 4;
 	constexpr int WIDE_LDS_DWORDS = (int)(sizeof(seed_area) - ALIGN_BYTES) / 4;
-	static_assert(2 * QMAX + 66 * 2 <= sizeof(seed_q), "alias");
+	// (diet 2: the prefix array lies at the start of seed_area instead -- the pending stage's chain rows run while AlignHSP's buffers there are idle)
+	constexpr bool PRE_IN_AREA = URX_PE_PACK && TIER == 0 && NCH <= 3;
+	static_assert(2 * QMAX + (PRE_IN_AREA ? 0 : 66 * 2) <= sizeof(seed_q), "alias");
 	uint8_t *const rowlen = reinterpret_cast<uint8_t *>(&seed_q[0][0]);  // shared by the two mates: SearchPE_Pending runs on one mate at a time
-	uint16_t *const pre = reinterpret_cast<uint16_t *>(rowlen + 2 * QMAX);
+	uint16_t *const pre = PRE_IN_AREA ? reinterpret_cast<uint16_t *>(seed_area) : reinterpret_cast<uint16_t *>(rowlen + 2 * QMAX);
 	static_assert(128 * 6 <= sizeof(seed_db), "alias");
 	uint32_t *const cq_db = &seed_db[0][0];  // pending stage only
 	uint16_t *const cq_qp = reinterpret_cast<uint16_t *>(cq_db + 128);
@@ -990,6 +1057,9 @@ __global__ __launch_bounds__(64, TIER == 2 ? 1 : URX_PE_WAVES(NCH)) void search_
 		                           (TIER == 2 ? (size_t)PE_OVF_BLOCKS * 2 * PE_HIT_CAP * 4 * URMAPX_MAX_PATH_OPS : (size_t)0) +
 		                           ((size_t)blockIdx.x * 2 + a) * PE_HIT_CAP * M::HITW * URMAPX_MAX_PATH_OPS
 		                     : reinterpret_cast<urmapx_path_op *>(sc) + (size_t)a * PE_HIT_CAP * PE_HITW1 * URMAPX_MAX_PATH_OPS;
+#if !URX_PE_PACK
+		hot(a).hit_tail = reinterpret_cast<uint32_t *>(sc + pe_tail_offset(QMAX)) + a * 192;
+#endif
 		hot(a).hit_cap = (hsp_lds_cap >= 64 && hsp_lds_cap <= PE_HSP_CAP) ? (hsp_lds_cap & ~63) / 4 : PE_HIT_CAP * PE_HITW1;
 		hot(a).hit_wsh = (hsp_lds_cap >= 64 && hsp_lds_cap <= PE_HSP_CAP) ? 4 : 6;
 		hot(a).hsp_lds = (hsp_lds_cap >= 64 && hsp_lds_cap <= PE_HSP_CAP) ? (hsp_lds_cap & ~63) : PE_HSP_CAP;
@@ -1413,7 +1483,7 @@ __global__ __launch_bounds__(64, TIER == 2 ? 1 : URX_PE_WAVES(NCH)) void search_
 				}
 				if (found != 0xFFFFFFFFu && coord + (uint32_t)hot(a).QL <= tl) {
 					R.dbpos = db; R.seq_index = found; R.coord = coord; R.plus = (uint8_t)(sp & 1u);
-					const int nops = ml[a].hit_nops[hot(a).topHit];
+					const int nops = mate(a).hnops(hot(a).topHit);
 					if (nops > 0) {
 						uint32_t po = 0;
 						if (lane == 0) po = atomicAdd(path_used, (uint32_t)nops);
@@ -1447,9 +1517,13 @@ static int pe_nch_for(uint32_t max_read_len) {
 __host__ __device__ inline size_t pe_tb_offset(int qmax) {
 	return (pe_rowstore_offset(qmax) + (size_t)2 * (qmax / 64) * PE_ROW_CAP * 64 * 4 + 255) & ~(size_t)255;
 }
+// behind the trace cells: the first pass's hits 65..128 of both mates (3 x 64 words each)
+__host__ __device__ inline size_t pe_tail_offset(int qmax) {
+	return (pe_tb_offset(qmax) + (size_t)(qmax / 8 + 2) * 64 * 4 + 255) & ~(size_t)255;
+}
 size_t search_pe_scratch_stride(uint32_t max_read_len) {
 	const int qmax = 64 * pe_nch_for(max_read_len);
-	size_t b = pe_tb_offset(qmax) + (size_t)(qmax / 8 + 2) * 64 * 4;
+	size_t b = pe_tail_offset(qmax) + (size_t)2 * 192 * 4;
 	return (b + 255) & ~(size_t)255;
 }
 
