@@ -617,13 +617,13 @@ class Workload:
         return parity, {k: v / max(1, cnt["n_reads"]) for k, v in cnt.items()}, t_cpu
 
 
-def write_fastq_fixed(path, reads_u8, n, L):
-    """n reads of length L (uint8 array [n*L]) as FASTQ with fixed-width labels r00000000.. and quality 'I'."""
+def write_fastq_fixed(path, reads_u8, n, L, first=0):
+    """n reads of length L (uint8 array [n*L]) as FASTQ with fixed-width labels r00000000.. (counted from `first`) and quality 'I'; `path` may be an open file."""
     lab = 2 + 8 + 1
     rec = lab + L + 3 + L + 1
     a = np.empty((n, rec), dtype=np.uint8)
     a[:, 0] = ord("@"); a[:, 1] = ord("r")
-    idx = np.arange(n, dtype=np.int64)
+    idx = np.arange(first, first + n, dtype=np.int64)
     for d in range(8):
         a[:, 2 + d] = ((idx // 10 ** (7 - d)) % 10 + ord("0")).astype(np.uint8)
     a[:, 10] = ord("\n")
@@ -867,12 +867,20 @@ def run_e2e(torch, api, oi, index, device, d_seq, seq_lengths, seq_offsets, L, s
     base = "/dev/shm" if os.path.isdir("/dev/shm") else None
     d = tempfile.mkdtemp(prefix="urmap_e2e_", dir=base)
     try:
-        reads = make_reads_torch(torch, 777, d_seq, seq_lengths, seq_offsets, n_reads, L, sub, indel, device).cpu().numpy()
         fq, sam = os.path.join(d, "r.fq"), os.path.join(d, "out.sam")
-        fq_bytes = write_fastq_fixed(fq, reads, n_reads, L)
+        # the reads a slab at a time (the generator's index arrays are 8 bytes per base: 100 M reads -- the N = 8 leg -- at once would not fit), labels counted through
+        slab = 2_000_000
+        with open(fq, "wb") as f:
+            for lo in range(0, n_reads, slab):
+                k = min(slab, n_reads - lo)
+                part = make_reads_torch(torch, 777 + lo // slab, d_seq, seq_lengths, seq_offsets, k, L, sub, indel, device).cpu().numpy()
+                write_fastq_fixed(f, part, k, L, first=lo)
+                del part
+        fq_bytes = os.path.getsize(fq)
         n_chk = min(n_reads // 4, 400_000)
         fq_head, sam_o = os.path.join(d, "head.fq"), os.path.join(d, "oracle.sam")
-        write_fastq_fixed(fq_head, reads[: n_chk * L], n_chk, L)
+        with open(fq, "rb") as f, open(fq_head, "wb") as g:
+            g.write(f.read(n_chk * (fq_bytes // n_reads)))
         # the LAST n_chk reads too (chunk numbers, byte offsets and path-arena offsets are largest at the end of the file);
         # their labels are the file's (write_fastq_fixed counts from 0: the tail file is cut out of the big one below)
         fq_tail, sam_ot = os.path.join(d, "tail.fq"), os.path.join(d, "oracle_tail.sam")
@@ -880,7 +888,6 @@ def run_e2e(torch, api, oi, index, device, d_seq, seq_lengths, seq_offsets, L, s
         with open(fq, "rb") as f, open(fq_tail, "wb") as g:
             f.seek((n_reads - n_chk) * rec_bytes)
             g.write(f.read())
-        del reads
         runs = []
         for _ in range(2):  # the second run has its buffers and the page cache warm; both are reported
             rep = watched(lambda: api.map_files(index, fq, samout=sam, first_gpu=device.index, gpus=gpus, streams=E2E_STREAMS, batch=E2E_BATCH, cmdline="bench.py e2e"))
@@ -903,10 +910,12 @@ def run_e2e(torch, api, oi, index, device, d_seq, seq_lengths, seq_offsets, L, s
         bound, shares = e2e_bound(rep)
         # the same run with the SAM text dropped after it has reached the host: what the device lanes sustain when the output
         # medium is out of the way, and where a lane's time goes (events on the lanes' streams)
-        null_rep = [watched(lambda: api.map_files(index, fq, samout=sam + ".null", first_gpu=device.index, gpus=gpus, streams=E2E_STREAMS, batch=E2E_BATCH,
-                                                  cmdline="bench.py e2e", discard_sam=True)) for _ in range(2)][-1]
+        null_reps = [watched(lambda: api.map_files(index, fq, samout=sam + ".null", first_gpu=device.index, gpus=gpus, streams=E2E_STREAMS, batch=E2E_BATCH,
+                                                   cmdline="bench.py e2e", discard_sam=True)) for _ in range(3)]
+        null_rep = null_reps[-1]  # (three calls, the last one reported: the first two still warm buffers and lanes up -- scripts/r6_lanes.py shows the same run after run)
         lanes = max(1, null_rep["lanes"])
         null_sink = {"value": round(null_rep["reads"] / null_rep["seconds"], 1), "unit": "reads/s", "seconds": round(null_rep["seconds"], 3),
+                     "all_runs_reads_per_s": [round(r["reads"] / r["seconds"], 1) for r in null_reps],
                      "lanes": lanes, "lane_busy_s_summed": round(null_rep["gpu_s"], 3),
                      "stream_time_s_summed_over_lanes": {k[4:-2]: round(null_rep[k], 3) for k in ("dev_h2d_s", "dev_parse_s", "dev_map_s", "dev_format_s", "dev_d2h_s")},
                      "lanes_view": lane_view(null_rep),

@@ -3,7 +3,7 @@
 # GPU's time goes between the first and the last kernel of a urmapx_map_files run (scripts/e2e_timeline.py)
 R=$GRAFT_REPO_ROOT; cd /tmp; export TMPDIR=/tmp
 O=$R/gpurun_out/r5t; mkdir -p $O
-export URMAP_BENCH_INDEX_CACHE=/dev/shm/urmap_idx URMAP_BENCH_NO_E2E_GZ=1 URMAP_BENCH_NO_E2E_PAIRS=1 URMAP_BENCH_NO_REFERENCE=1 URMAP_BENCH_E2E_READS=${E2E_READS:-4000000}
+export URMAP_BENCH_NO_CLI=1 URMAP_BENCH_INDEX_CACHE=/dev/shm/urmap_idx URMAP_BENCH_NO_E2E_GZ=1 URMAP_BENCH_NO_E2E_PAIRS=1 URMAP_BENCH_NO_REFERENCE=1 URMAP_BENCH_E2E_READS=${E2E_READS:-4000000}
 A="--steps 1 --warmup 1 --no-cpu-baseline --no-other-workloads"
 python3 $R/bench.py $A > $O/plain.json 2> $O/plain.err   # builds the cache; the legs without the profiler
 for lanes in 2 1; do
