@@ -91,6 +91,9 @@ VARIANTS = [
     ("host_text", ["-batch", 900], {"URMAPX_HOST_TEXT": "1"}),
     ("no_lane_pool", ["-batch", 900], {"URMAPX_NO_LANE_POOL": "1"}),
     ("mmap_writer", ["-batch", 900], {"URMAPX_SAM_WRITE": "mmap"}),
+    # no -batch: the library's own chunk sizes, ramped up at the start of the file and down at its end (pipeline.cpp, round 6), three lanes
+    ("ramped_chunks", ["-streams", 3], {"URMAPX_TEST_CHUNK_READS": "1600"}),
+    ("ramp_off", ["-streams", 2], {"URMAPX_TEST_CHUNK_READS": "1600", "URMAPX_NO_CHUNK_RAMP": "1"}),
 ]
 
 

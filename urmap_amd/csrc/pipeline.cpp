@@ -1002,6 +1002,7 @@ int map_files_impl(urmapx_index *I, const urmapx_map_options *opt, const InputRa
 					// hipHostMalloc / hipHostFree (6.5 M reads/s)
 					const double est = (double)(fsize - (range.on ? range.lo[0] : 0)) / rec * (paired ? 2.0 : 1.0);
 					reads_per_chunk = std::min(524288.0, std::max((double)batch, est / (4.0 * (double)n_lanes)));
+					if (const char *e = getenv("URMAPX_TEST_CHUNK_READS")) reads_per_chunk = std::max(4.0, atof(e));  // test aid: the library's own choice, small (the ramp below on a small file)
 				}
 				chunk_bytes = (size_t)std::min(std::max(rec * (paired ? std::max(1.0, reads_per_chunk / 2) : reads_per_chunk), 4096.0), 536870912.0);
 			}
@@ -1193,7 +1194,7 @@ int map_files_impl(urmapx_index *I, const urmapx_map_options *opt, const InputRa
 						else if (b < 2 * (size_t)n_lanes) this_chunk = chunk_bytes / 2;
 						const uint64_t left = fsize - off;
 						if (left <= (uint64_t)n_lanes * chunk_bytes) this_chunk = (size_t)std::min<uint64_t>(this_chunk, std::max<uint64_t>(left / (2 * (uint64_t)n_lanes), chunk_bytes / 8));
-						this_chunk = std::max<size_t>(this_chunk, 4096);
+						this_chunk = std::max<size_t>(this_chunk, 1024);
 					}
 					if (off + this_chunk < fsize) {
 						end = find_record_start(fq, off + this_chunk, fsize);
