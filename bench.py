@@ -1161,6 +1161,7 @@ def main():
     # which genome and which table this run maps against (urmapx_index_checksum over the resident arrays), next to the values recorded in the
     # repo for this generator, seed and size (tests/golden/bench_genome.json: the store's, computed on the CPU; profiles/r6: the table's)
     table_checksum, genome_checksum = index.checksum()
+    layout_checksums = index.layout_checksum()  # slot16, chain rows: derived from the table on this device at upload
     recorded = {}
     try:
         recorded = json.load(open(os.path.join(ROOT, "tests", "golden", "bench_genome.json"))).get(f"{args.genome_mbp:g}", {})
@@ -1261,6 +1262,7 @@ def main():
                        "read_len": L, "genome_bp": int(len(seq_np)), "slots": int(slots),
                        "genome": genome_desc,
                        "genome_checksum": f"{genome_checksum:016x}", "slot_table_checksum": f"{table_checksum:016x}",
+                       "slot16_checksum": f"{layout_checksums[0]:016x}", "chain_rows_checksum": f"{layout_checksums[1]:016x}",
                        "genome_checksum_recorded": recorded.get("checksum"), "slot_table_checksum_recorded": recorded.get("slot_table_checksum"),
                        "inputs_are_the_recorded_ones": (None if not recorded.get("checksum") else
                                                         bool(recorded["checksum"] == f"{genome_checksum:016x}" and

@@ -142,6 +142,9 @@ int urmapx_index_validate(const urmapx_index *, urmapx_validate_report *out);
  * genome and which table it mapped against (the reference has no counterpart; its -ufi_validate checks consistency, not identity). */
 int urmapx_checksum_device(int device, const void *d_ptr, uint64_t nbytes, uint64_t *out);
 int urmapx_index_checksum(const urmapx_index *, uint64_t out[2]);
+/* the same over the layouts DERIVED from the table at upload: out[0] slot16 (16 * slot_count bytes), out[1] the chain rows (4 bytes per
+ * position); 0 for a layout that was not built.  Two uploads of one table must agree, whichever way the layouts were built. */
+int urmapx_index_layout_checksum(const urmapx_index *, uint64_t out[2]);
 uint32_t urmapx_index_word_length(const urmapx_index *);
 uint32_t urmapx_index_max_ix(const urmapx_index *);
 uint64_t urmapx_index_slot_count(const urmapx_index *);

@@ -83,6 +83,18 @@ def test_the_genome_on_the_device_is_the_recorded_one(big):
     assert f"{table:016x}" == g["slot_table_checksum"]  # the GPU-assisted builder's table == the host builder's, recorded in the build container
 
 
+def test_checksum_of_odd_sizes_and_a_misaligned_pointer(big):
+    """urmapx_checksum_device: the documented sum for sizes around the word and the block boundaries; a pointer that is not 8-byte aligned is refused"""
+    torch, api, bench = big["torch"], big["api"], big["bench"]
+    g = torch.Generator(device="cuda").manual_seed(3)
+    for n in (1, 7, 8, 9, 2047, 2048, 2049, (1 << 20) + 5, 40_000_003):
+        t = torch.randint(0, 256, (n + 16,), dtype=torch.uint8, generator=g, device="cuda")
+        assert t.data_ptr() % 8 == 0
+        assert api.checksum_device(0, t.data_ptr(), n) == bench.array_checksum(t[:n].cpu().numpy()), n
+    with pytest.raises(api.UrmapxError):
+        api.checksum_device(0, t.data_ptr() + 4, 64)
+
+
 def _sam_lines(path):
     """(offset of the first record, offsets of every record's first byte, file size): newline positions, a piece at a time"""
     size = os.path.getsize(path)

@@ -920,10 +920,15 @@ def test_chain_rows_on_and_off_give_the_oracle(dense_case, tmp_path, monkeypatch
     pairs = [x for ab in zip(r1, r2) for x in ab]
     pb, po = reads_to_arrays(pairs)
     pres, ppaths, _ = c["oracle_index"].map_pe(pb, po, threads=4)
-    sizes = {}
-    for mode in ("slot16", "rows", "walk"):  # what a device with room for everything / for the rows only / for neither runs
+    sizes, sums = {}, {}
+    # what a device with room for everything runs -- built in one go (round 6: slot16 is its own scratch) or in two steps through the per-slot
+    # info entries (URMAPX_TWO_STEP_LAYOUT, the round-5 build) --, one with room for the rows only, one with room for neither
+    for mode in ("slot16", "slot16_two_step", "rows", "walk"):
         off = mode == "walk"
+        if mode == "slot16_two_step":
+            monkeypatch.setenv("URMAPX_TWO_STEP_LAYOUT", "1")
         if mode == "rows":
+            monkeypatch.delenv("URMAPX_TWO_STEP_LAYOUT")
             monkeypatch.setenv("URMAPX_NO_SLOT16", "1")  # search_se_kernel<.., ROWS 1>, the pair kernel's info-entry lookup
         if off:
             monkeypatch.delenv("URMAPX_NO_SLOT16")
@@ -931,6 +936,7 @@ def test_chain_rows_on_and_off_give_the_oracle(dense_case, tmp_path, monkeypatch
         idx = api.Index.open(c["ufi"]).upload(0)
         assert (idx.chain_row_bytes() == 0) == off
         sizes[mode] = idx.chain_row_bytes()
+        sums[mode] = idx.layout_checksum()
         m = api.Mapper(idx, device=0)
         g, gops = m.map_se(bases, offs)
         for name in ("dbpos", "seq_index", "coord", "score", "second", "mapq", "exit_phase", "hit_count"):
@@ -947,6 +953,9 @@ def test_chain_rows_on_and_off_give_the_oracle(dense_case, tmp_path, monkeypatch
         m.close()
         idx.close()
     assert sizes["slot16"] > sizes["rows"] > 0  # (the 16-byte table is there by default, and is what URMAPX_NO_SLOT16 leaves out)
+    assert sizes["slot16"] == sizes["slot16_two_step"]  # the same layouts resident either way (slot16 + rows; the info entries are dropped)
+    assert sums["slot16"] == sums["slot16_two_step"] and sums["slot16"][0] != 0 and sums["slot16"][1] != 0  # and the same BYTES in them
+    assert sums["rows"][0] == 0 and sums["rows"][1] == sums["slot16"][1] and sums["walk"] == (0, 0)
 
 
 @pytest.mark.gpu

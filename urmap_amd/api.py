@@ -34,7 +34,7 @@ EXPORTS = (
     "urmapx_make_ufi", "urmapx_make_ufi_opts", "urmapx_build_slots", "urmapx_make_ufi_gpu", "urmapx_build_slots_gpu", "urmapx_sam_se", "urmapx_sam_header_sq", "urmapx_ctx_phase_cycles", "urmapx_ctx_read_cycles", "urmapx_ctx_stage_ms", "urmapx_ctx_phase3", "urmapx_ctx_round_ms", "urmapx_ctx_dp_rounds", "urmapx_ctx_dp_stats", "urmapx_map_pe", "urmapx_sam_pe", "urmapx_map_pe_device", "urmapx_ctx_set_pe_veryfast",
     "urmapx_gunzip_file", "urmapx_fastq_open", "urmapx_fastq_next", "urmapx_fastq_error", "urmapx_fastq_close",
     "urmapx_ctx_gather_microbench", "urmapx_map_files", "urmapx_host_pool_trim", "urmapx_text_create", "urmapx_text_destroy", "urmapx_text_map_se", "urmapx_text_map_pe", "urmapx_pgzip_simd", "urmapx_index_open_device", "urmapx_text_fetch_sam", "urmapx_text_set_deferred", "urmapx_text_wait", "urmapx_text_fetch_pairs", "urmapx_ctx_set_pair_info", "urmapx_ctx_get_pair_info", "urmapx_tab_pe",
-    "urmapx_checksum_device", "urmapx_index_checksum",
+    "urmapx_checksum_device", "urmapx_index_checksum", "urmapx_index_layout_checksum",
 )
 
 
@@ -116,6 +116,7 @@ def lib():
     L.urmapx_index_validate.argtypes = [vp, C.POINTER(ValidateReport)]
     L.urmapx_checksum_device.argtypes = [i32, vp, u64, C.POINTER(u64)]
     L.urmapx_index_checksum.argtypes = [vp, C.POINTER(u64)]
+    L.urmapx_index_layout_checksum.argtypes = [vp, C.POINTER(u64)]
     L.urmapx_index_label.restype = cp
     L.urmapx_index_label.argtypes = [vp, u32]
     L.urmapx_index_seq_length.restype = u32
@@ -309,6 +310,12 @@ class Index:
         """(slot table, sequence store): urmapx_index_checksum over the resident arrays -- which table and which genome this is"""
         out = (C.c_uint64 * 2)()
         _check(lib().urmapx_index_checksum(self.h, out), "urmapx_index_checksum")
+        return int(out[0]), int(out[1])
+
+    def layout_checksum(self):
+        """(slot16, chain rows): urmapx_index_layout_checksum -- the layouts derived from the table at upload (0: not built)"""
+        out = (C.c_uint64 * 2)()
+        _check(lib().urmapx_index_layout_checksum(self.h, out), "urmapx_index_layout_checksum")
         return int(out[0]), int(out[1])
 
     @property

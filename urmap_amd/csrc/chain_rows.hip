@@ -187,6 +187,106 @@ hipError_t build_slot16(const uint8_t *d_blob, uint64_t slot_count, const uint2 
 	return hipSuccess;
 }
 
+// ---- slot16 and the rows WITHOUT the per-slot info entries in between (round 6) ----
+// build_chain_rows + build_slot16 hold 8 bytes of info per slot (43 GB at hg38 scale) beside the table, the rows and slot16 until slot16 is
+// written: 160 GB at the peak of an upload for 122 GB of resident index.  Here slot16 is its own scratch: pass 1 writes every slot's own
+// position, tally and row length into it (and the groups' row totals), pass 2 takes the lengths from there, writes each head's row and sets
+// .x (the row's first position) and .z (second position, or the row's place in `rows`).  Same bytes in slot16 and rows as the two-step build.
+__global__ __launch_bounds__(CR_GROUP) void rows_len16_kernel(const uint8_t *__restrict__ blob, uint64_t N, int maxIx, uint4 *__restrict__ out,
+                                                              uint32_t *__restrict__ groupsum, uint32_t groups) {
+	__shared__ uint32_t wsum[CR_GROUP / 64];
+	for (uint32_t g = blockIdx.x; g < groups; g += gridDim.x) {
+		const uint64_t s = (uint64_t)g * CR_GROUP + threadIdx.x;
+		uint32_t len = 0;
+		if (s < N) {
+			uint32_t T, pos;
+			load_slot(blob, s, T, pos);
+			if (heads_a_row(T)) len = (uint32_t)chain_row(blob, N, maxIx, s, T, pos, nullptr);
+			const uint32_t l16 = heads_a_row(T) ? len : ((T & TALLY_MY_BIT) != 0 ? 1u : 0u);  // BOTH1 / PLUS1: a row of one, its own position
+			out[s] = make_uint4(pos, T | (l16 << 8), 0u, 0u);
+		}
+		uint32_t v = len;
+		for (int d = 32; d; d >>= 1) v += __shfl_xor(v, d, 64);
+		__syncthreads();
+		if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = v;
+		__syncthreads();
+		if (threadIdx.x == 0) {
+			uint32_t t = 0;
+			for (int w = 0; w < CR_GROUP / 64; ++w) t += wsum[w];
+			groupsum[g] = t;
+		}
+	}
+}
+__global__ __launch_bounds__(CR_GROUP) void rows_fill16_kernel(const uint8_t *__restrict__ blob, uint64_t N, int maxIx, uint4 *__restrict__ out,
+                                                               const uint64_t *__restrict__ rowbase, uint32_t *__restrict__ rows, uint32_t groups) {
+	__shared__ uint32_t wsum[CR_GROUP / 64];
+	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	for (uint32_t g = blockIdx.x; g < groups; g += gridDim.x) {
+		const uint64_t s = (uint64_t)g * CR_GROUP + threadIdx.x;
+		uint32_t T = 0, len = 0;
+		if (s < N) {
+			const uint32_t y = out[s].y;
+			T = y & 0xFFu;
+			len = heads_a_row(T) ? (y >> 8) & 0xFFu : 0u;
+		}
+		uint32_t inc = len;  // inclusive prefix inside the wavefront
+		for (int d = 1; d < 64; d <<= 1) {
+			const uint32_t up = __shfl_up(inc, d, 64);
+			if (lane >= d) inc += up;
+		}
+		__syncthreads();
+		if (lane == 63) wsum[w] = inc;
+		__syncthreads();
+		uint32_t before = 0;
+		for (int k = 0; k < w; ++k) before += wsum[k];
+		if (s < N && len) {
+			const uint64_t at = rowbase[g] + (before + inc - len);
+			uint32_t T2, pos;
+			load_slot(blob, s, T2, pos);
+			uint32_t *const row = rows + at;
+			(void)chain_row(blob, N, maxIx, s, T2, pos, row);
+			out[s].x = row[0];  // the slot's own position, except behind a long link (its middle slot's)
+			out[s].z = len <= 2 ? (len > 1 ? row[1] : 0u) : (uint32_t)at;
+		}
+	}
+}
+// null / null on return if there is no room (the caller falls back to the two-step build, then to the row layout, then to the walk)
+hipError_t build_slot16_direct(const uint8_t *d_blob, uint64_t slot_count, uint32_t max_ix, uint4 **d_slot16, uint32_t **d_rows, uint64_t *total_rows) {
+	*d_slot16 = nullptr; *d_rows = nullptr; *total_rows = 0;
+	if (max_ix > (uint32_t)CR_ROW_CAP || max_ix < 1 || slot_count == 0) return hipSuccess;
+	const uint64_t groups = (slot_count + CR_GROUP - 1) / CR_GROUP;
+	if (groups > 0x7FFFFFFFull) return hipSuccess;
+	uint4 *out = nullptr;
+	uint32_t *gsum = nullptr, *rows = nullptr;
+	uint64_t *base = nullptr;
+	auto drop = [&]() { (void)hipFree(out); (void)hipFree(gsum); (void)hipFree(base); (void)hipFree(rows); (void)hipGetLastError(); };
+	if (hipMalloc((void **)&out, (slot_count + 1) * sizeof(uint4)) != hipSuccess || hipMalloc((void **)&gsum, groups * 4) != hipSuccess ||
+	    hipMalloc((void **)&base, groups * 8) != hipSuccess) { drop(); return hipSuccess; }
+	const unsigned grid = (unsigned)(groups < (1u << 20) ? groups : (1u << 20));
+	hipLaunchKernelGGL(rows_len16_kernel, dim3(grid), dim3(CR_GROUP), 0, nullptr, d_blob, slot_count, (int)max_ix, out, gsum, (uint32_t)groups);
+	hipError_t e = hipGetLastError();
+	std::vector<uint32_t> hs(groups);
+	if (e == hipSuccess) e = hipMemcpy(hs.data(), gsum, groups * 4, hipMemcpyDeviceToHost);
+	if (e != hipSuccess) { drop(); return e; }
+	std::vector<uint64_t> hb(groups);
+	uint64_t total = 0;
+	for (uint64_t g = 0; g < groups; ++g) { hb[g] = total; total += hs[g]; }
+	(void)hipFree(gsum); gsum = nullptr;
+	if (total >= 0xFFFFFFFFull) { drop(); return hipSuccess; }
+	if (hipMalloc((void **)&rows, (total + 64) * 4) != hipSuccess) { drop(); return hipSuccess; }
+	e = hipMemcpy(base, hb.data(), groups * 8, hipMemcpyHostToDevice);
+	if (e == hipSuccess) e = hipMemset(out + slot_count, 0, sizeof(uint4));
+	if (e == hipSuccess) {
+		hipLaunchKernelGGL(rows_fill16_kernel, dim3(grid), dim3(CR_GROUP), 0, nullptr, d_blob, slot_count, (int)max_ix, out, base, rows, (uint32_t)groups);
+		e = hipGetLastError();
+	}
+	if (e == hipSuccess) e = hipDeviceSynchronize();
+	(void)hipFree(base); base = nullptr;
+	if (e != hipSuccess) { drop(); return e; }
+	*d_slot16 = out; *d_rows = rows; *total_rows = total;
+	return hipSuccess;
+}
+
 // ---- UFIndex::Validate (ufindex.cpp:611-658) over a resident table ----
 // ValidateSlot for every slot, one thread per slot: a slot whose tally says "mine" heads a row; GetRow_Validate
 // (ufindex.cpp:834-881) collects the row's positions link by link (the head must be "mine", every later link "other", a long

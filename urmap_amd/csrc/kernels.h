@@ -177,6 +177,7 @@ hipError_t launch_search_pe_slow(const DevIndex &X, const urmapx_params &P, cons
                                  int all_pairs, hipStream_t s);
 
 // chain_rows.hip: the rows of every chain head of a resident slot table (all three null if they cannot be had)
+hipError_t build_slot16_direct(const uint8_t *d_blob, uint64_t slot_count, uint32_t max_ix, uint4 **d_slot16, uint32_t **d_rows, uint64_t *total_rows);
 hipError_t build_slot16(const uint8_t *d_blob, uint64_t slot_count, const uint2 *d_info, const uint64_t *d_base, const uint32_t *d_rows, uint4 **d_slot16);
 hipError_t build_chain_rows(const uint8_t *d_blob, uint64_t slot_count, uint32_t max_ix, uint2 **d_info, uint64_t **d_base, uint32_t **d_rows,
                             uint64_t *total_rows);

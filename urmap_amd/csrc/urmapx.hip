@@ -313,7 +313,17 @@ static int upload_directory(urmapx_index *I) {
 	if (rc) return rc;
 	// every chain head's row, contiguous (chain_rows.hip): 4 bytes per slot + 4 per indexed position.  URMAPX_NO_CHAIN_ROWS=1
 	// (measurement, tests): the kernels walk the chains hop by hop, as they do when the rows do not fit the device
-	if (!getenv("URMAPX_NO_CHAIN_ROWS")) {
+	// round 6: slot16 and the rows in one go, without the 8 bytes of info per slot the two-step build below holds meanwhile (43 GB at hg38 scale:
+	// 160 GB at the peak of an upload instead of 122).  The two-step build remains for whoever wants the info entries (URMAPX_NO_SLOT16,
+	// URMAPX_PARK_PHASE3, URMAPX_KEEP_ROWINFO, URMAPX_TWO_STEP_LAYOUT=1 for the A/B) and as the fallback when there is no room for slot16.
+	if (!getenv("URMAPX_NO_CHAIN_ROWS") && !getenv("URMAPX_NO_SLOT16") && !getenv("URMAPX_PARK_PHASE3") && !getenv("URMAPX_KEEP_ROWINFO") && !getenv("URMAPX_TWO_STEP_LAYOUT")) {
+		const hipError_t e = build_slot16_direct(I->d_blob, I->slotCount, I->maxIx, &I->d_slot16, &I->d_rows, &I->n_rows);
+		if (getenv("URMAPX_VERBOSE"))
+			fprintf(stderr, "urmapx: slot16 + rows %s in one build: %llu positions in rows, %.2f GB (hip: %s)\n", I->d_slot16 ? "built" : "NOT built",
+			        (unsigned long long)I->n_rows, I->d_slot16 ? (16.0 * (double)I->slotCount + 4.0 * (double)I->n_rows) / 1e9 : 0.0, hipGetErrorString(e));
+		HIP_TRY(e);
+	}
+	if (!I->d_slot16 && !getenv("URMAPX_NO_CHAIN_ROWS")) {
 		const hipError_t e = build_chain_rows(I->d_blob, I->slotCount, I->maxIx, &I->d_rowinfo, &I->d_rowbase, &I->d_rows, &I->n_rows);
 		if (getenv("URMAPX_VERBOSE"))
 			fprintf(stderr, "urmapx: chain rows %s: %llu positions in rows, %.2f GB (hip: %s)\n", I->d_rows ? "built" : "NOT built",
@@ -465,6 +475,15 @@ int urmapx_index_checksum(const urmapx_index *I, uint64_t out[2]) {
 	HIP_TRY(hipSetDevice(I->device));
 	HIP_TRY(checksum_device(I->d_blob, 5ull * I->slotCount, &out[0]));
 	HIP_TRY(checksum_device(I->d_seq, I->seqDataSize, &out[1]));
+	return URMAPX_OK;
+}
+int urmapx_index_layout_checksum(const urmapx_index *I, uint64_t out[2]) {
+	if (!I || !out) return URMAPX_E_ARG;
+	if (!I->d_blob || I->device < 0) return URMAPX_E_ARG;
+	out[0] = out[1] = 0;
+	HIP_TRY(hipSetDevice(I->device));
+	if (I->d_slot16) HIP_TRY(checksum_device(I->d_slot16, 16ull * I->slotCount, &out[0]));
+	if (I->d_rows) HIP_TRY(checksum_device(I->d_rows, 4ull * I->n_rows, &out[1]));
 	return URMAPX_OK;
 }
 uint32_t urmapx_index_word_length(const urmapx_index *I) { return I->W; }
