@@ -1187,7 +1187,7 @@ def main():
     leg_n = world > 1 and not pe and L == 150 and not args.no_e2e  # the N > 1 file-to-file leg: rank 0 maps over all N devices
     if leg_n and rank != 0:
         # this rank is done: its replica (122 GB at hg38 scale) and its contexts leave the device before rank 0 puts a replica of its
-        # own there for the file-to-file leg (two resident indexes + the 160 GB peak of a slot16 build would not fit 288 GB)
+        # own there for the file-to-file leg (two resident indexes of 122 GB and the contexts of both would not fit 288 GB)
         for m in mappers:
             m.close()
         index.close()
