@@ -61,6 +61,10 @@ def parse_args():
     ap.add_argument("--no-e2e", action="store_true", help="skip the FASTQ file -> SAM file run")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("URMAP_BENCH_STREAMS", 1)),
                     help="mapping contexts (HIP streams) a batch is split over, as urmap -streams does; 1 keeps the launches of a step back to back so that their times add up to the step (2: -2 %% at 150 bp, +5 %% at 250 bp since round 4 made phase 6 cheap; launches overlap)")
+    ap.add_argument("--contexts", type=int, default=int(os.environ.get("URMAP_BENCH_CONTEXTS", 2)),
+                    help="mapping contexts of the device that whole batches alternate over, each on its own HIP stream -- how urmap -streams K (default 2) runs a device: "
+                         "one context's search kernel fills the CUs that the other's tail and phase-6 launches leave idle (round 6: 48.9 -> 54 M reads/s at 150 bp, pairs 50.4 -> 63.2 M, "
+                         "profiles/r6/two_contexts_and_batch_size.txt); 1 = one context, its steps back to back (rounds 1-5; --streams then splits a batch)")
     ap.add_argument("--mode", choices=("se", "pe"), default="se", help="pe: 2x150 read pairs through State2::Search4 (config 3; not the headline metric)")
     return ap.parse_args()
 
@@ -498,8 +502,11 @@ class Workload:
     maps it: split over `streams` mapping contexts of the device (urmap -streams K, default 2), each with its own HIP
     stream, so that one context's probe / DP / finalize launches overlap the other's search kernel."""
 
-    def __init__(self, torch, api, device, d_seq, seq_lengths, seq_offsets, pe, L, sub, indel, nb, n_batches, seed, streams=1):
+    def __init__(self, torch, api, device, d_seq, seq_lengths, seq_offsets, pe, L, sub, indel, nb, n_batches, seed, streams=1, contexts=1):
         self.pe, self.L, self.nb, self.api, self.torch = pe, L, nb, api, torch
+        self.contexts = max(1, contexts)
+        if self.contexts > 1:
+            streams = 1  # whole batches alternate over the contexts (round 6); a batch is not split
         self.batches = []
         for b in range(n_batches):
             if pe:
@@ -517,7 +524,24 @@ class Workload:
                                "d_results": torch.zeros(n * api.RESULT_DTYPE.itemsize, dtype=torch.uint8, device=device),
                                "d_pathops": torch.zeros(n * api.MAX_PATH_OPS, dtype=torch.int16, device=device),
                                "d_used": torch.zeros(1, dtype=torch.int32, device=device)})
+        # round 6: `contexts` > 1 -- whole batches ALTERNATE over that many mapping contexts of the device, each with its own HIP stream and its own
+        # output arrays, as the lanes of urmapx_map_files (urmap -streams K, default 2) run a device: context B's search kernel fills the CUs that
+        # context A's tail and phase-6 launches leave idle.  Every step is still one pass of the hot path over one whole batch.
+        self.outs = [self.parts[0]]
+        for _ in range(1, self.contexts):
+            p0 = self.parts[0]
+            self.outs.append({"lo": 0, "n": p0["n"], "d_offs": p0["d_offs"], "d_results": torch.zeros_like(p0["d_results"]),
+                              "d_pathops": torch.zeros_like(p0["d_pathops"]), "d_used": torch.zeros_like(p0["d_used"])})
         self.last = None
+
+    def step_on(self, m, c, b):
+        """batch b on context c (alternating mode): launches only, no wait"""
+        self.last = self.batches[b % len(self.batches)]
+        self.parts = [self.outs[c]]
+        p = self.outs[c]
+        f = m.map_pe_device if self.pe else m.map_se_device
+        f(self.last.data_ptr(), p["d_offs"].data_ptr(), p["n"] // 2 if self.pe else p["n"], p["n"] * self.L, self.L,
+          p["d_results"].data_ptr(), p["d_pathops"].data_ptr(), p["d_used"].data_ptr())
 
     def step(self, mappers, b):
         self.last = self.batches[b % len(self.batches)]
@@ -528,10 +552,16 @@ class Workload:
 
     def timed(self, mappers, steps, warmup, barrier=None):
         """W untimed steps, then K timed ones -> (seconds, mean ms per launch [probe, search]); stage_ms / dp_stats too"""
-        mappers = list(mappers)[: len(self.parts)]
+        alternating = self.contexts > 1 and len(list(mappers)) >= self.contexts
+        mappers = list(mappers)[: self.contexts] if alternating else list(mappers)[: len(self.parts)]
         self.torch.cuda.synchronize()  # the batches were written on torch's stream; the contexts run on streams of their own
-        for w in range(warmup):
-            self.step(mappers, w)
+        # (alternating: every context takes at least one untimed step when any warm-up is asked for -- its first call allocates its device arrays)
+        self.warmup_run = max(warmup, self.contexts) if alternating and warmup > 0 else warmup
+        for w in range(self.warmup_run):
+            if alternating:
+                self.step_on(mappers[w % self.contexts], w % self.contexts, w)
+            else:
+                self.step(mappers, w)
         for m in mappers:
             m.sync()
         if barrier:
@@ -540,25 +570,44 @@ class Workload:
         self.stage_ms = np.zeros(7)
         self.round_ms = None
         self.p3_ms, self.p3_stats = np.zeros(3), np.zeros(2)
+        share = 1.0 if alternating else 1.0 / len(mappers)
+
+        def collect(m):  # the launches of the step this context has just finished, by the events on its own stream
+            nonlocal kms
+            kms += np.array(m.last_kernel_ms()) * share
+            if not self.pe:
+                self.stage_ms += np.array(m.stage_ms()) * share
+                rm = np.array(m.round_ms()) * share / max(1, steps)
+                self.round_ms = rm if self.round_ms is None else self.round_ms + rm
+                p3m, p3s = m.phase3()
+                self.p3_ms += np.array(p3m) * share / max(1, steps)
+                self.p3_stats += np.array(p3s, dtype=np.float64) / max(1, steps)
         t0 = time.perf_counter()
-        for k in range(steps):
-            self.step(mappers, warmup + k)
-            for m in mappers:
-                m.sync()
-            for m in mappers:
-                kms += np.array(m.last_kernel_ms()) / len(mappers)
-                if not self.pe:
-                    self.stage_ms += np.array(m.stage_ms()) / len(mappers)
-                    rm = np.array(m.round_ms()) / len(mappers) / max(1, steps)
-                    self.round_ms = rm if self.round_ms is None else self.round_ms + rm
-                    p3m, p3s = m.phase3()
-                    self.p3_ms += np.array(p3m) / len(mappers) / max(1, steps)
-                    self.p3_stats += np.array(p3s, dtype=np.float64) / max(1, steps)
+        if alternating:
+            C = self.contexts
+            for k in range(steps):
+                c = k % C
+                if k >= C:  # this context's step k - C must be done before its arrays are reused; the other contexts run on
+                    mappers[c].sync()
+                    collect(mappers[c])
+                self.step_on(mappers[c], c, warmup + k)
+            for k in range(max(0, steps - C), steps):  # the last step of every context, oldest first: the one that ran step K - 1 is waited for last
+                mappers[k % C].sync()
+                collect(mappers[k % C])
+            last_m = [mappers[(steps - 1) % C]]
+        else:
+            for k in range(steps):
+                self.step(mappers, warmup + k)
+                for m in mappers:
+                    m.sync()
+                for m in mappers:
+                    collect(m)
+            last_m = mappers
         self.own_s = time.perf_counter() - t0  # this rank's K steps, before it waits for the others
         if barrier:
             barrier()
         self.stage_ms /= max(1, steps)
-        self.dp_stats = None if self.pe else [int(x) for x in np.sum([m.dp_stats() for m in mappers], axis=0)]
+        self.dp_stats = None if self.pe else [int(x) for x in np.sum([m.dp_stats() for m in last_m], axis=0)]
         return time.perf_counter() - t0, kms / max(1, steps)
 
     def results(self):
@@ -615,6 +664,29 @@ class Workload:
             parity["mismatches"] = diffs
             parity["status_values"] = [int(x) for x in np.unique(g["status"])]
         return parity, {k: v / max(1, cnt["n_reads"]) for k, v in cnt.items()}, t_cpu
+
+
+def run_timed(wl, mappers, steps, warmup, barrier=None, alone_steps=3):
+    """wl.timed over the contexts the run uses, and -- when batches alternate over several -- a few steps of ONE context with the device to itself afterwards
+    (outside the timed region): what each launch takes when nothing shares the device with it.  -> (seconds, kms, alone | None)"""
+    dt, kms = wl.timed(mappers, steps, warmup, barrier)
+    alone = None
+    if wl.contexts > 1 and alone_steps > 0 and len(mappers) >= wl.contexts:
+        keep = (wl.stage_ms.copy(), wl.round_ms, wl.p3_ms.copy(), wl.p3_stats.copy(), wl.dp_stats, wl.own_s)
+        C, wl.contexts = wl.contexts, 1
+        adt, akms = wl.timed([mappers[0]], alone_steps, 1)
+        alone = {"ms_per_step": 1e3 * adt / alone_steps, "reads_per_s": alone_steps * wl.nb / adt, "kms": akms, "stage_ms": wl.stage_ms.copy(), "p3_ms": wl.p3_ms.copy(),
+                 "steps": alone_steps}
+        wl.contexts = C
+        wl.stage_ms, wl.round_ms, wl.p3_ms, wl.p3_stats, wl.dp_stats, wl.own_s = keep
+    return dt, kms, alone
+
+
+def alone_block(alone, contexts):
+    return None if alone is None else {
+        "value": round(alone["reads_per_s"], 1), "unit": "reads/s", "ms_per_step": round(alone["ms_per_step"], 3), "steps": alone["steps"],
+        "what": f"ONE mapping context running its steps back to back with the device to itself (the timed region of rounds 1-5), measured after the timed region of this run, "
+                f"in which whole batches alternate over {contexts} contexts: the kernels' `alone_ms` come from these steps"}
 
 
 def write_fastq_fixed(path, reads_u8, n, L, first=0):
@@ -1071,7 +1143,7 @@ def run_e2e_pairs(torch, api, oi, index, device, d_seq, seq_lengths, seq_offsets
     return out
 
 
-def kernel_table(api, pe, L, nb, kms, counters, total_bp, gather_loads_s, stage_ms=None, p3_ms=None):
+def kernel_table(api, pe, L, nb, kms, counters, total_bp, gather_loads_s, stage_ms=None, p3_ms=None, alone=None):
     """Per-launch roofline figures.  Algorithmic bytes per read from the reference algorithm's own access counts
     (SURVEY.md 8d), counted by the oracle on the sample: probe kernel 5 B per GetBlob + the read; search kernel 5 B per
     chain slot + compared reference bases + the result record; DP kernel the target bases of the DP windows + the
@@ -1099,11 +1171,22 @@ def kernel_table(api, pe, L, nb, kms, counters, total_bp, gather_loads_s, stage_
         rows.append(("second pass (search + dp + finalize over the reads whose lists outgrew the first)", float(sum(stage_ms[3:6])), 0.0))
         rows.append(("general kernel (reads outside the fast kernels' domain; usually none)", float(stage_ms[6]), 0.0))
     sector_peak = 64.0 * gather_loads_s / 1e9
+    alone_ms = {}
+    if alone is not None:  # the same launches with the device to themselves (run_timed)
+        if pe:
+            alone_ms["search_pe_kernel"] = float(alone["kms"][1])
+        else:
+            a3 = float(alone["p3_ms"][1]) if alone["p3_ms"][0] > 0 else 0.0
+            alone_ms = {"search_se_kernel": float(alone["stage_ms"][0]) - a3, "dp_kernel": float(alone["stage_ms"][1]) + a3, "finalize_se_kernel": float(alone["stage_ms"][2])}
     kern = []
     for name, ms, alg in rows:
         ach = alg * nb / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         k = {"kernel": name, "avg_ms": round(ms, 4), "alg_bytes_per_read": round(alg, 1),
              "achieved_GBs": round(ach, 2), "frac": round(ach / HBM_PEAK_GBS, 5)}
+        if name in alone_ms and alone_ms[name] > 0:
+            k["alone_ms"] = round(alone_ms[name], 4)
+            k["alone_achieved_GBs"] = round(alg * nb / (alone_ms[name] * 1e-3) / 1e9, 2)
+            k["alone_frac"] = round(k["alone_achieved_GBs"] / HBM_PEAK_GBS, 5)
         src = {}
         t = pmc_traffic(name, nb, total_bp, L, "pe" if pe else "se", source=src)
         k["hbm_read_bytes_per_launch_pmc"] = t
@@ -1167,18 +1250,20 @@ def main():
         recorded = json.load(open(os.path.join(ROOT, "tests", "golden", "bench_genome.json"))).get(f"{args.genome_mbp:g}", {})
     except (OSError, ValueError):
         pass
-    mappers = [api.Mapper(index, device=dev_index, method=6) for _ in range(max(1, args.streams))]
+    contexts = max(1, args.contexts)
+    mappers = [api.Mapper(index, device=dev_index, method=6) for _ in range(contexts if contexts > 1 else max(1, args.streams))]
     mapper = mappers[0]
 
     nb = args.reads_per_step
     pe = args.mode == "pe"
     n_batches = min(args.steps + args.warmup, 10)
     wl = Workload(torch, api, device, d_seq, seq_lengths, seq_offsets, pe, L, args.sub, args.indel, nb, n_batches, 1000 + 97 * rank,
-                  streams=len(mappers))
+                  streams=len(mappers), contexts=contexts)
     torch.cuda.synchronize()
     setup_s = time.time() - t_setup
 
-    dt, kms = wl.timed(mappers, args.steps, args.warmup, barrier=lambda: R.barrier(torch))
+    # (the one-context steps behind the timed region run on rank 0 only: they feed the line's `alone_ms` / `sequential`, nothing is gathered from them)
+    dt, kms, alone = run_timed(wl, mappers, args.steps, args.warmup, barrier=lambda: R.barrier(torch), alone_steps=3 if rank == 0 else 0)
     # every rank's own numbers, for the N > 1 line: its steps between the two barriers, its set-up (genome, index placement, batches)
     per_rank = R.all_gather_floats(torch, [wl.own_s, setup_s, t_index.get("make_ufi", 0.0), t_index.get("upload", 0.0), t_index.get("broadcast_s") or 0.0])
     dt = R.max_over_ranks(torch, dt)
@@ -1237,8 +1322,8 @@ def main():
             gather_loads_s = mapper.gather_microbench(1 << 28)
         except Exception:
             gather_loads_s = 0.0
-        npl = nb // len(mappers)  # reads per launch: the batch is split over the contexts
-        kern = kernel_table(api, pe, L, npl, kms, counters, total_bp, gather_loads_s, None if pe else wl.stage_ms, None if pe else wl.p3_ms)
+        npl = nb if contexts > 1 else nb // len(mappers)  # reads per launch: whole batches alternate over the contexts, or (--contexts 1 --streams K) a batch is split
+        kern = kernel_table(api, pe, L, npl, kms, counters, total_bp, gather_loads_s, None if pe else wl.stage_ms, None if pe else wl.p3_ms, alone=alone)
         dom = int(np.argmax([k["avg_ms"] if not k["kernel"].startswith(("second pass", "general kernel")) else 0.0 for k in kern]))
         dp_stats = wl.dp_stats
         key = "pe150" if pe else ("se150" if L == 150 else ("se250" if L == 250 else None))
@@ -1258,7 +1343,7 @@ def main():
             "config": {"workload": f"{L} bp {'PE mates (pairs interleaved)' if pe else 'SE reads'} vs synthetic hg38-shaped {args.genome_mbp:g} Mbp genome "
                                    f"({slots} slots = GetPrime({fasta_bytes} FASTA bytes / 0.6), {5 * slots / 1e9:.2f} GB slot table + "
                                    f"{len(seq_np) / 1e9:.2f} GB sequence resident in HBM); {nb} reads/step, {args.sub:g} sub, {args.indel:g} indel",
-                       "reads_per_step": nb, "streams": len(mappers), "reads_per_launch": nb // len(mappers),
+                       "reads_per_step": nb, "contexts": contexts, "streams": 1 if contexts > 1 else len(mappers), "reads_per_launch": npl,
                        "read_len": L, "genome_bp": int(len(seq_np)), "slots": int(slots),
                        "genome": genome_desc,
                        "genome_checksum": f"{genome_checksum:016x}", "slot_table_checksum": f"{table_checksum:016x}",
@@ -1292,6 +1377,9 @@ def main():
                          "limiter": KERNEL_LIMITER.get(kern[dom]["kernel"], ""),
                          "whole_step": {"alg_bytes_per_read": round(sum(k["alg_bytes_per_read"] for k in kern), 1),
                                         "achieved_GBs": round(sum(k["alg_bytes_per_read"] for k in kern) * nb / (dt / args.steps) / 1e9, 2)},
+                         "kernel_alone": ({"avg_ms": kern[dom]["alone_ms"], "achieved": kern[dom]["alone_achieved_GBs"], "frac": kern[dom]["alone_frac"],
+                                           "note": "the same kernel with the device to itself (`sequential`); `achieved` / `frac` above are of the timed region, where the other context's launches run beside it"}
+                                          if "alone_ms" in kern[dom] else None),
                          "traffic": kern[dom]["hbm_read_bytes_per_launch_pmc"],
                          "write_bytes": kern[dom]["hbm_write_bytes_per_launch_pmc"],
                          "traffic_source": ((kern[dom]["pmc_source"] or {}).get("fetch") and
@@ -1300,9 +1388,13 @@ def main():
                          "random_gather_peak": {"slot_reads_per_s": round(gather_loads_s), "sector_GBs": round(64.0 * gather_loads_s / 1e9, 1),
                                                 "note": "measured in this run: independent random 5-byte slot reads over the resident table, 64 B sector each"}},
             "kernels": kern,
-            "kernels_note": (f"a step = {len(mappers)} contexts x {nb // len(mappers)} reads on HIP streams of their own (urmap -streams {len(mappers)}): "
-                             "avg_ms is per launch and launches of different contexts overlap, so the rows add up to more than ms_per_step"
-                             if len(mappers) > 1 else "one context: the rows add up to ms_per_step"),
+            "kernels_note": (f"whole batches alternate over {contexts} mapping contexts, each on its own HIP stream (how urmap -streams {contexts} runs a device): avg_ms is a launch's duration by the events "
+                             "on its own stream WHILE the other context's launches share the device -- the rows add up to more than ms_per_step; alone_ms is the same launch with the device to "
+                             "itself (`sequential`: one context, steps back to back, after the timed region) and those rows add up to sequential.ms_per_step"
+                             if contexts > 1 else
+                             (f"a step = {len(mappers)} contexts x {nb // len(mappers)} reads on HIP streams of their own: avg_ms is per launch and launches of different contexts overlap, "
+                              "so the rows add up to more than ms_per_step" if len(mappers) > 1 else "one context: the rows add up to ms_per_step")),
+            "sequential": alone_block(alone, contexts),
             "parity": parity,
             "work_per_read": {k: round(v, 2) for k, v in counters.items()},
         }
@@ -1350,13 +1442,13 @@ def main():
                 t0 = time.time()
                 del wl
                 torch.cuda.empty_cache()
-                wl = Workload(torch, api, device, d_seq, seq_lengths, seq_offsets, ope, oL, osub, oindel, nb, 3, 5000, streams=len(mappers))
+                wl = Workload(torch, api, device, d_seq, seq_lengths, seq_offsets, ope, oL, osub, oindel, nb, 3, 5000, streams=len(mappers), contexts=contexts)
                 osteps, owarm = 10, 2
-                odt, okms = wl.timed(mappers, osteps, owarm)
+                odt, okms, oalone = run_timed(wl, mappers, osteps, owarm)
                 opar, ocnt, ot = wl.check(oi, min(nb, 200_000), cores)
-                okern = kernel_table(api, ope, oL, npl, okms, ocnt, total_bp, gather_loads_s, None if ope else wl.stage_ms, None if ope else wl.p3_ms)
+                okern = kernel_table(api, ope, oL, npl, okms, ocnt, total_bp, gather_loads_s, None if ope else wl.stage_ms, None if ope else wl.p3_ms, alone=oalone)
                 others[name] = {"metric": metric_name(ope, oL), "value": round(osteps * nb / odt, 1), "unit": "reads/s", "steps": osteps, "warmup": owarm,
-                                "ms_per_step": round(1e3 * odt / osteps, 3), "kernels": okern, "parity": opar,
+                                "ms_per_step": round(1e3 * odt / osteps, 3), "contexts": contexts, "sequential": alone_block(oalone, contexts), "kernels": okern, "parity": opar,
                                 "work_per_read": {k: round(v, 2) for k, v in ocnt.items()},
                                 "cpu_port_reads_per_s": round(opar["reads_checked"] / ot, 1), "cpu_port_threads": cores,
                                 "sub": osub, "indel": oindel, "wall_s": round(time.time() - t0, 1)}
