@@ -1179,14 +1179,18 @@ def kernel_table(api, pe, L, nb, kms, counters, total_bp, gather_loads_s, stage_
             a3 = float(alone["p3_ms"][1]) if alone["p3_ms"][0] > 0 else 0.0
             alone_ms = {"search_se_kernel": float(alone["stage_ms"][0]) - a3, "dp_kernel": float(alone["stage_ms"][1]) + a3, "finalize_se_kernel": float(alone["stage_ms"][2])}
     kern = []
-    for name, ms, alg in rows:
+    for name, ev_ms, alg in rows:
+        # Batches alternating over several contexts: the interval between the events around a launch on its context's stream begins when that STREAM is ready, not when
+        # the kernel gets CUs -- it holds the wait for the other context's kernel to leave the device (pairs: 28.7 ms of events around a 20.0 ms kernel, rocprofv3
+        # kernel trace of the same command, profiles/r6/kernel_stats_hg38scale_pe_two_contexts.csv).  A launch's duration is therefore taken from the one-context steps
+        # that follow the timed region (run_timed: the same launch on the same batches with the device to itself; HIP events, this process, this run).
+        ms = alone_ms[name] if name in alone_ms and alone_ms[name] > 0 else ev_ms
         ach = alg * nb / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         k = {"kernel": name, "avg_ms": round(ms, 4), "alg_bytes_per_read": round(alg, 1),
              "achieved_GBs": round(ach, 2), "frac": round(ach / HBM_PEAK_GBS, 5)}
         if name in alone_ms and alone_ms[name] > 0:
-            k["alone_ms"] = round(alone_ms[name], 4)
-            k["alone_achieved_GBs"] = round(alg * nb / (alone_ms[name] * 1e-3) / 1e9, 2)
-            k["alone_frac"] = round(k["alone_achieved_GBs"] / HBM_PEAK_GBS, 5)
+            k["avg_ms_is"] = "the launch with the device to itself (one-context steps after the timed region)"
+            k["timed_region_event_ms"] = round(ev_ms, 4)  # includes the wait for the other context's kernels
         src = {}
         t = pmc_traffic(name, nb, total_bp, L, "pe" if pe else "se", source=src)
         k["hbm_read_bytes_per_launch_pmc"] = t
@@ -1263,7 +1267,7 @@ def main():
     setup_s = time.time() - t_setup
 
     # (the one-context steps behind the timed region run on rank 0 only: they feed the line's `alone_ms` / `sequential`, nothing is gathered from them)
-    dt, kms, alone = run_timed(wl, mappers, args.steps, args.warmup, barrier=lambda: R.barrier(torch), alone_steps=3 if rank == 0 else 0)
+    dt, kms, alone = run_timed(wl, mappers, args.steps, args.warmup, barrier=lambda: R.barrier(torch), alone_steps=5 if rank == 0 else 0)
     # every rank's own numbers, for the N > 1 line: its steps between the two barriers, its set-up (genome, index placement, batches)
     per_rank = R.all_gather_floats(torch, [wl.own_s, setup_s, t_index.get("make_ufi", 0.0), t_index.get("upload", 0.0), t_index.get("broadcast_s") or 0.0])
     dt = R.max_over_ranks(torch, dt)
@@ -1377,9 +1381,10 @@ def main():
                          "limiter": KERNEL_LIMITER.get(kern[dom]["kernel"], ""),
                          "whole_step": {"alg_bytes_per_read": round(sum(k["alg_bytes_per_read"] for k in kern), 1),
                                         "achieved_GBs": round(sum(k["alg_bytes_per_read"] for k in kern) * nb / (dt / args.steps) / 1e9, 2)},
-                         "kernel_alone": ({"avg_ms": kern[dom]["alone_ms"], "achieved": kern[dom]["alone_achieved_GBs"], "frac": kern[dom]["alone_frac"],
-                                           "note": "the same kernel with the device to itself (`sequential`); `achieved` / `frac` above are of the timed region, where the other context's launches run beside it"}
-                                          if "alone_ms" in kern[dom] else None),
+                         "duration_from": ("one-context steps after the timed region (`sequential`): HIP events around the launch with the device to itself, "
+                                           f"{kern[dom]['avg_ms']} ms; in the timed region whole batches alternate over {contexts} contexts and the events around a launch also hold its wait "
+                                           f"for the other context's kernels ({kern[dom]['timed_region_event_ms']} ms; rocprofv3's kernel trace of this command: profiles/r6/kernel_stats_hg38scale_*_two_contexts.csv)"
+                                           if "timed_region_event_ms" in kern[dom] else "HIP events around the launch in the timed region (one context)"),
                          "traffic": kern[dom]["hbm_read_bytes_per_launch_pmc"],
                          "write_bytes": kern[dom]["hbm_write_bytes_per_launch_pmc"],
                          "traffic_source": ((kern[dom]["pmc_source"] or {}).get("fetch") and
@@ -1388,9 +1393,9 @@ def main():
                          "random_gather_peak": {"slot_reads_per_s": round(gather_loads_s), "sector_GBs": round(64.0 * gather_loads_s / 1e9, 1),
                                                 "note": "measured in this run: independent random 5-byte slot reads over the resident table, 64 B sector each"}},
             "kernels": kern,
-            "kernels_note": (f"whole batches alternate over {contexts} mapping contexts, each on its own HIP stream (how urmap -streams {contexts} runs a device): avg_ms is a launch's duration by the events "
-                             "on its own stream WHILE the other context's launches share the device -- the rows add up to more than ms_per_step; alone_ms is the same launch with the device to "
-                             "itself (`sequential`: one context, steps back to back, after the timed region) and those rows add up to sequential.ms_per_step"
+            "kernels_note": (f"whole batches alternate over {contexts} mapping contexts, each on its own HIP stream (how urmap -streams {contexts} runs a device): "
+                             "avg_ms is a launch's duration with the device to itself (`sequential`: one context, steps back to back, after the timed region) -- those rows add up to sequential.ms_per_step; "
+                             "timed_region_event_ms is the interval between the events around the launch on its context's stream in the timed region, which also holds the wait for the other context's kernels"
                              if contexts > 1 else
                              (f"a step = {len(mappers)} contexts x {nb // len(mappers)} reads on HIP streams of their own: avg_ms is per launch and launches of different contexts overlap, "
                               "so the rows add up to more than ms_per_step" if len(mappers) > 1 else "one context: the rows add up to ms_per_step")),
