@@ -25,6 +25,10 @@ import time
 # workers get the whole process throttled (round 5: the file-to-file legs ran at a third of their rate in half of the runs until the
 # library made its own teams sleep; this covers the teams it does not own).  Before any OpenMP runtime is loaded.
 os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+# The HIP runtime spreads a process's streams over four hardware queues by default, and streams that share a queue take turns.  This process has torch's stream, two mapping
+# contexts' and, in the file-to-file legs, two streams per lane: the lanes ran at 29 M reads/s with the default and at 39-40 M with 8 or 16 queues (profiles/r6/hw_queues.txt).
+# The command line and the library set the same (urmap_main.cpp, urmapx.hip); here torch starts the runtime first, so it is set before torch is imported.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 import numpy as np
 

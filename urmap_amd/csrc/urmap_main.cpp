@@ -319,6 +319,10 @@ static int cmd_ufi_validate(const Opts &o) {
 
 int main(int argc, char **argv) {
 	setenv("OMP_WAIT_POLICY", "passive", 0);  // idle pool threads sleep: three pipeline stages share the cores
+	// The HIP runtime spreads a process's streams over FOUR hardware queues unless told otherwise, and streams that share one take turns: two lanes are four
+	// streams (a lane's own and its copy-back stream), beside the loader's.  Before the runtime starts (round 6: the lanes of a process with a few more streams
+	// ran at 29 M reads/s instead of 39 M until this was set; profiles/r6/hw_queues.txt).  The library sets the same when it is loaded (urmapx.hip).
+	setenv("GPU_MAX_HW_QUEUES", "16", 0);
 	Opts o = parse(argc, argv);
 	log_open(o, argc, argv);
 	if (!o.map.empty() || !o.map2.empty()) { const int rc = cmd_map(o, argc, argv); log_close(); return rc; }

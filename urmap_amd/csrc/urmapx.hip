@@ -105,6 +105,12 @@ struct urmapx_ctx {
 
 namespace urx {
 AllocClock &alloc_clock() { static AllocClock c{}; return c; }
+
+// When the library is loaded: ask the HIP runtime for more than its default of four hardware queues per device, unless the process has its own
+// setting.  A process's streams are spread over those queues and streams that share one take turns; urmapx_map_files runs two streams per lane
+// (the lane's and its copy-back stream), a caller with contexts of its own a few more.  It only takes effect if the runtime has not started yet
+// (a host that initialises HIP first -- torch -- sets GPU_MAX_HW_QUEUES itself: INTEGRATION.md); measured: profiles/r6/hw_queues.txt.
+__attribute__((constructor)) static void urx_more_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
 hipStream_t ctx_stream(urmapx_ctx *C) { return C->stream; }
 int ctx_device(const urmapx_ctx *C) { return C->device; }
 const urmapx_index *ctx_index(const urmapx_ctx *C) { return C->index; }
