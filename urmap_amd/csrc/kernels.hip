@@ -1062,7 +1062,6 @@ struct SearchWave {
 // 2 = the second launch: the reads PART 1 parked at phase 3, from the replay of AlignHSP's bookkeeping over their jobs onwards
 // (phases 4-5, then parked for phase 6 like any other read).  n = the batch's reads (PART 2: read from dp3's counter).
 // ROWS: 0 = chains walked hop by hop, 1 = rows looked up in the row layout (rows_fetch), 2 = everything with the probe (DevIndex::slot16)
-#define DBG_NOPF(DBG_) false
 template <int NCH, bool OVF, bool DBG, int ROWS = 0, int PART = 0>
 __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel(DevIndex X, urmapx_params P, const uint8_t *__restrict__ bases,
                                                        const uint64_t *__restrict__ offs, uint32_t n,
@@ -1096,7 +1095,7 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 	// candidate queue (ring): reference position, query position | plus << 14 | second phase << 15
 	__shared__ __attribute__((aligned(8))) uint32_t cq_db[128];
 	__shared__ uint16_t cq_qp[128];
-	constexpr bool PF = (URX_PREFETCH & 1) != 0 && !DBG_NOPF(DBG);
+	constexpr bool PF = (URX_PREFETCH & 1) != 0;
 	__shared__ uint32_t pf_sink[URX_PREFETCH ? 64 : 1];  // where the L2 touches land (glds_touch); never read
 	// between two gather steps both are idle: the next read's slot numbers are staged there on their way to the pr_* arrays
 	static_assert(SW::NSEG * 64 * 4 <= sizeof(pre) && 2 * SW::NSEG * 8 <= sizeof(cq_db), "staging");
