@@ -554,6 +554,30 @@ def test_pe_matches_oracle(small_case, tmp_path, rl, s1, s2, indel, n):
         raise AssertionError(f"{len(bad)} differing records of {len(w)}, first: {g[bad[0]][:200]!r} vs {w[bad[0]][:200]!r}")
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,rl", [(16, 150), (16, 192), (21, 190), (30, 150)])
+def test_pairs_on_an_index_with_another_word_length(small_case, tmp_path, w, rl):
+    """-make_ufi -wordlength W: pairs against indexes whose words are not 24 letters.  With W = 16 a 192-base mate has 177 k-mer starts -- more than the
+    first pass's pending lists hold since round 6 (kernels_pe.hip: QMAX - 16) -- and the pair must come out of the general pair kernel with the oracle's
+    records, not out of an overrun list."""
+    import os
+    import oracle_lib as ol
+    from urmap_amd import synth
+    idx = ol.Index.build(small_case["fasta"], 524309, word_length=w)
+    ufi = os.path.join(tmp_path, f"w{w}.ufi")
+    idx.save(ufi)
+    r1, r2 = synth.make_pairs(900 + w + rl, small_case["genome"], 600, read_len=rl, sub1=0.01, sub2=0.02, ins=0.001, dele=0.001)
+    f1, f2 = os.path.join(tmp_path, "r1.fq"), os.path.join(tmp_path, "r2.fq")
+    synth.write_fastq(f1, r1)
+    synth.write_fastq(f2, r2)
+    osam = os.path.join(tmp_path, "o.sam")
+    idx.map_file_pe(f1, f2, osam, threads=4)
+    got = _map_pe_sam(ufi, f1, f2)
+    want = open(osam, "rb").read()
+    assert got == want
+    assert want.count(b"\t99\t") + want.count(b"\t83\t") > 100  # proper pairs were found
+
+
 @pytest.mark.parametrize("name", ["pe150", "pe100_noisy"])
 def test_cli_map2_reproduces_reference_sam(tmp_path, name):
     """`urmap -map2 R1 -reverse R2 -ufi UFI -samout SAM` (map2.cpp:39-90) vs the reference's golden SAM."""

@@ -1090,6 +1090,8 @@ __global__ __launch_bounds__(64, TIER == 2 ? 1 : URX_PE_WAVES(NCH)) void search_
 			res[a].score = 0; res[a].second = 0; res[a].mapq = 0; res[a].plus = 0; res[a].exit_phase = 0; res[a].status = 0;
 			res[a].hit_count = 0; res[a].path_nops = 0; res[a].path_off = 0;
 			if (QL < W || QL > QMAX || W > 32 || X.maxIx > 32 || QL - (W - 1) > 256) bad = true;  // pending positions are bytes
+			// (diet 2: this pass's pending lists hold QMAX - 16 positions -- enough for every W >= 17; an index with shorter words sends such a pair to the general kernel)
+			if (MateLds<NCH, TIER>::PACK && QL - (W - 1) > QMAX - 16) bad = true;
 			hot(a).QL = QL; hot(a).nwords = QL - (W - 1);
 		}
 		if (bad) {
