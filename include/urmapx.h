@@ -204,9 +204,10 @@ int urmapx_ctx_dp_rounds(urmapx_ctx *, uint32_t lo[8], int *rounds);
  * the search stage ([0] above) is then three launches -- ms[0] the first search launch (seed + probe + phases 1-2 for every read,
  * phases 4-5 for the reads with nothing to align in phase 3), ms[1] phase 3's flank-DP launch, ms[2] the search launch over the reads
  * parked at phase 3 (replay of AlignHSP's bookkeeping, phases 4-5).  stats[0] = DpJobs made for phase 3, stats[1] = reads parked there.
- * All zero when phase 3 ran inside the search kernel, which is the DEFAULT: measured at hg38 scale the three launches take 6 % longer than
- * the one.  URMAPX_PARK_PHASE3=1 in the environment turns the parking on (reads of up to 320 bases, an index with the
- * row layout). */
+ * All zero when phase 3 ran inside the search kernel (the context records which it was; round 6), which is the DEFAULT: measured at hg38 scale
+ * the three launches take 6 % longer than the one (profiles/r5/README.md).  URMAPX_PARK_PHASE3=1 in the environment -- set BEFORE the index is
+ * uploaded: the parked variant needs the row layout, which an upload without the knob drops once slot16 is built -- turns the parking on (reads
+ * of up to 320 bases). */
 int urmapx_ctx_phase3(urmapx_ctx *, float ms[3], uint32_t stats[2]);
 /* Statistics of the same call, per pass (4 numbers each): HSPs handed to the DP launches, reads they belong to, how many
  * of those DPs the ordered replay of AlignHSP (alignhsp.cpp:60-172) looked at, and how many were dropped before their DP

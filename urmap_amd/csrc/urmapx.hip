@@ -97,6 +97,7 @@ struct urmapx_ctx {
 	int fin_blocks[6] = {0, 0, 0, 0, 0, 0};
 	hipEvent_t stage_ev[STAGE_EVENTS] = {};
 	bool stage_valid = false;
+	bool p3_parked = false;  // the last single-end call ran with phase 3 parked (URMAPX_PARK_PHASE3 and the row layout resident): urmapx_ctx_phase3 reports only then
 	uint32_t pairinfo_n = 0;
 	uint32_t stats_reads = 0;  // diagnostics: reads of the last single-end call with per-read cycle counts
 	int pe_blocks[4] = {0, 0, 0, 0};
@@ -584,7 +585,9 @@ int urmapx_ctx_stage_ms(urmapx_ctx *C, float ms[7]) {
 int urmapx_ctx_phase3(urmapx_ctx *C, float ms[3], uint32_t stats[2]) {
 	if (!C || !ms || !stats) return URMAPX_E_ARG;
 	ms[0] = ms[1] = ms[2] = 0; stats[0] = stats[1] = 0;
-	if (!C->stage_valid || !C->dpbuf.p) return URMAPX_OK;
+	// (what is reported is the real state of the call, not a guess from the times -- two events with nothing between them are microseconds apart
+	// once another context's launches share the device)
+	if (!C->stage_valid || !C->dpbuf.p || !C->p3_parked) return URMAPX_OK;
 	HIP_TRY(hipEventSynchronize(C->stage_ev[STAGE_LAST]));
 	HIP_TRY(hipEventElapsedTime(&ms[0], C->stage_ev[0], C->stage_ev[STAGE_P3_MAIN]));
 	HIP_TRY(hipEventElapsedTime(&ms[1], C->stage_ev[STAGE_P3_MAIN], C->stage_ev[STAGE_P3_DP]));
@@ -592,7 +595,6 @@ int urmapx_ctx_phase3(urmapx_ctx *C, float ms[3], uint32_t stats[2]) {
 	uint32_t buf[2];
 	HIP_TRY(hipMemcpy(buf, C->dpbuf.p + 32, sizeof buf, hipMemcpyDeviceToHost));
 	stats[0] = buf[0]; stats[1] = buf[1];
-	if (buf[1] == 0 && buf[0] == 0 && ms[1] < 1e-3f && ms[2] < 1e-3f) { ms[0] = 0; }
 	return URMAPX_OK;
 }
 
@@ -767,6 +769,7 @@ int urmapx_map_se_device(urmapx_ctx *C, const void *d_bases, const void *d_offs,
 			at3[3] = need; need += (size_t)fin_cap3 * p3w * 4;
 		}
 		if ((rc = C->dpbuf.ensure(need))) return rc;
+		C->p3_parked = p3w != 0;
 		if (p3w) {
 			DpWork &d = wk.dp3;
 			d.jobs = reinterpret_cast<DpJob *>(C->dpbuf.p + at3[0]);
