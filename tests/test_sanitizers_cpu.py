@@ -136,9 +136,12 @@ def test_shards_pairs_tab_and_compressed_input(san, reads, which):
     open(gz, "wb").write(gzip.compress(data, 4))
     import bench
     open(bg, "wb").write(bench.bgzf_bytes(data))
-    for name, src, env in (("gz", gz, {"URMAPX_PGZIP_SEGMENT": "65536"}), ("bgzf", bg, {})):
+    # (gzip at three chunk sizes: smaller than a segment's text -- through the reader's own buffer; room for two or three of a round's four segments -- a smaller
+    # round written straight into the chunk, then a short read; room for whole rounds)
+    for name, src, env, batch in (("gz", gz, {"URMAPX_PGZIP_SEGMENT": "65536"}, 1200), ("gz_fit", gz, {"URMAPX_PGZIP_SEGMENT": "65536"}, 3200),
+                                  ("gz_rounds", gz, {"URMAPX_PGZIP_SEGMENT": "65536"}, 20000), ("bgzf", bg, {}, 1200)):
         sam = os.path.join(d, f"{which}_{name}.sam")
-        rc, out = run(exe, ["map", src, "-o", sam, "-batch", 1200], dict(env, URX_STUB_MAP="1"))
+        rc, out = run(exe, ["map", src, "-o", sam, "-batch", batch], dict(env, URX_STUB_MAP="1"))
         assert rc == 0, out
         assert open(sam, "rb").read() == open(one, "rb").read(), name
     sam = os.path.join(d, f"{which}_stdin.sam")

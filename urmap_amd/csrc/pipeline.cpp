@@ -492,6 +492,7 @@ public:
 		return true;
 	}
 	bool is_gz() const { return gz_; }
+	bool returns_whole_rounds() const { return gz_ && !bgzf_ && !pipe_; }  // a plain gzip stream through ParallelGunzip
 	bool is_bgzf() const { return bgzf_; }
 	bool failed() const { return bad_; }
 	uint64_t compressed_size() const { return csize_; }
@@ -1098,6 +1099,9 @@ int map_files_impl(urmapx_index *I, const urmapx_map_options *opt, const InputRa
 								const size_t k = src1.read(j->in + n, std::min(area1, target + (64u << 10)) - n, read_threads);
 								if (k == 0) eof1 = true;
 								n += k;
+								// a gzip stream's reader hands out whole rounds written straight into this buffer and returns short when the next round
+								// would not fit (pgzip.cpp): a chunk that is three quarters full is a chunk -- asking for the rest would cost a copy of a whole round
+								if (src1.returns_whole_rounds() && n >= target - target / 4) break;
 							}
 							if (src1.failed()) break;
 							cut = eof1 ? n : last_record_start(j->in, n);
