@@ -666,20 +666,19 @@ size_t ParallelGunzip::read(char *dst, size_t cap, int threads) {
 		// ---- one round of the parallel road ----
 		const double tr0 = omp_get_wtime();
 		const uint64_t B0 = D.cbits >> 3;
-		int T = (int)std::min<uint64_t>((uint64_t)threads, std::max<uint64_t>(1, (D.csize - B0 + D.seg_bytes - 1) / D.seg_bytes));
 		// Round 6: the round is fitted to what is left of the caller's buffer, so that its text is written THERE (`direct` below) instead of into obuf and copied
-		// out -- the copy was a third of the reader's time per chunk of urmapx_map_files (178 MB of text per round of 16 segments against chunks of 165 MB: every
-		// round missed).  A round of fewer segments if at least half of them fit; else, if this call has already produced text, a short read -- the caller comes
-		// back with room for a round (urmapx_map_files takes a chunk that is three quarters full); a caller whose whole buffer is smaller goes through obuf as before.
-		if (D.out_per_in > 0.0) {
-			const double seg_out = (double)D.seg_bytes * D.out_per_in * 1.04;
-			const int fit = (int)std::min<double>((double)(cap - done) / seg_out, 1e6);
-			if (fit < T) {
-				if (fit >= std::max(2, T / 2)) T = fit;
-				else if (done > 0) break;
-			}
+		// out -- the copy was a third of the reader's time per chunk of urmapx_map_files (178 MB of text per round of 16 segments against chunks of 86-173 MB: every
+		// round missed).  Same number of segments (one per thread), SHORTER segments; if even segments an eighth of the usual size do not fit and this call has
+		// already produced text, a short read -- the caller comes back with room for a round (urmapx_map_files takes a chunk that is three quarters full); a caller
+		// whose whole buffer is smaller than that goes through obuf as before.
+		size_t seg = D.seg_bytes;
+		int T = (int)std::min<uint64_t>((uint64_t)threads, std::max<uint64_t>(1, (D.csize - B0 + seg - 1) / seg));
+		if (D.out_per_in > 0.0 && (double)T * (double)seg * D.out_per_in * 1.04 > (double)(cap - done)) {
+			const size_t seg_fit = (size_t)((double)(cap - done) / ((double)T * D.out_per_in * 1.04)) & ~(size_t)4095;
+			if (seg_fit >= D.seg_bytes / 8 && seg_fit >= 4096) seg = seg_fit;
+			else if (done > 0) break;
 		}
-		const uint64_t B1 = std::min<uint64_t>(D.csize, B0 + (uint64_t)T * D.seg_bytes);
+		const uint64_t B1 = std::min<uint64_t>(D.csize, B0 + (uint64_t)T * seg);
 		const uint64_t Bread = std::min<uint64_t>(D.csize, B1 + SLACK);
 		std::vector<uint8_t> &cbuf = D.cbuf;
 		if (cbuf.size() < (size_t)(Bread - B0) + 16) cbuf.resize((size_t)(Bread - B0) + 16);
@@ -691,13 +690,13 @@ size_t ParallelGunzip::read(char *dst, size_t cap, int threads) {
 		const bool last_round = B1 == D.csize;
 		std::vector<SegDecoder> &segs = D.segs;
 		if ((int)segs.size() < T) segs.resize((size_t)T);
-		for (SegDecoder &S : segs) { S.reset(); S.hint = (size_t)D.seg_bytes * 6; }  // FASTQ text deflates to a fifth or less; more grows the buffer
+		for (SegDecoder &S : segs) { S.reset(); S.hint = (size_t)seg * 6; }  // FASTQ text deflates to a fifth or less; more grows the buffer
 		std::vector<uint64_t> start((size_t)T, ~0ull);
 		start[0] = D.cbits - B0 * 8;
 		// 1. block starts behind the cuts
 #pragma omp parallel for schedule(dynamic, 1) num_threads(T)
 		for (int i = 1; i < T; ++i) {
-			const uint64_t lo = (uint64_t)i * D.seg_bytes * 8, hi = std::min<uint64_t>(cut_bits, (uint64_t)(i + 1) * D.seg_bytes * 8);
+			const uint64_t lo = (uint64_t)i * seg * 8, hi = std::min<uint64_t>(cut_bits, (uint64_t)(i + 1) * seg * 8);
 			SegDecoder S;
 			S.B.p = cbuf.data(); S.B.end = end_bits;
 			for (uint64_t b = lo; b < hi; ++b) {
@@ -736,7 +735,7 @@ size_t ParallelGunzip::read(char *dst, size_t cap, int threads) {
 		for (int a = 0; a < A; ++a) {
 			SegDecoder &S = segs[(size_t)act[(size_t)a]];
 			S.B.p = cbuf.data(); S.B.end = end_bits; S.B.pos = start[(size_t)act[(size_t)a]];
-			S.grow(D.seg_bytes * 6);
+			S.grow(seg * 6);
 			const uint64_t target = a + 1 < A ? start[(size_t)act[(size_t)a + 1]] : (last_round ? ~0ull : cut_bits);
 			S.run<false>(target, 1 << 30);
 		}
