@@ -174,6 +174,10 @@ static constexpr uint32_t PK_MASK = 1023u, PK_LEN_SH = 10, PK_SCORE_SH = 20, PK_
 #ifndef URX_PREFETCH
 #define URX_PREFETCH 0  // bit 0: the next batch's windows, bit 1: a read's long rows
 #endif
+#ifndef URX_SCAN_AHEAD
+#define URX_SCAN_AHEAD 0  // the candidate scan of the next batch issued behind the current batch's window loads (0: the round-5 loop)
+#endif
+static_assert(!(URX_SCAN_AHEAD && (URX_PREFETCH & 1)), "the L2 touches of the next batch's windows belong to the round-5 loop");
 #ifndef URX_HSP_CAP
 #define URX_HSP_CAP (URX_PREFETCH ? 192 : 256)  // build-time experiment (profiles/r5/ab_waves5.txt): 64 frees 1.5 KB of LDS per block
 #endif
@@ -1417,6 +1421,69 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 					if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long *>(stats) + 1 + slot, (unsigned long long)(now - tsub));
 					tsub = now;
 				};
+#if URX_SCAN_AHEAD
+				// Round 6 (second half): the scan is split.  scan_issue locates the candidates of the next 64 list positions and ISSUES the
+				// reads that name their reference positions (the block's row store in global scratch, and behind it DevIndex::rows for rows of
+				// three and more: two dependent round trips); scan_finish filters and queues them.  One turn of the loop = the scan step the
+				// queue will want after this batch is issued, the batch (if the queue holds one) is gathered, walked and consumed, the scan
+				// step is finished: the binary search over the prefix array and both round trips run beside the batch's window gather instead
+				// of in front of the next one.  Each part exists once (the kernel has to stay inside the instruction cache).
+				const bool have_batch = qcount >= 64 || (scanned >= total && qcount > 0);
+				const int nb = have_batch ? (qcount < 64 ? qcount : 64) : 0;
+				const bool want_scan = scanned < total && qcount - nb < 64;
+				if (!have_batch && !want_scan) break;
+				uint32_t c_qpos = 0, c_db = 0;
+				bool c_plus = true, c_second = false;
+				const bool c_ok = lane < nb;
+				if (c_ok) {
+					const int pos = (qhead + lane) & 127;
+					c_db = cq_db[pos];
+					const uint32_t qp = cq_qp[pos];
+					c_qpos = qp & 0x3FFFu; c_plus = (qp & 0x4000u) != 0; c_second = (qp & 0x8000u) != 0;
+				}
+				qhead = (qhead + nb) & 127; qcount -= nb;
+				const bool c_live = c_ok;
+				uint32_t a_db = 0, a_meta = 0;
+				if (want_scan) {  // wave-uniform
+					const int g = scanned + lane;
+					if (g < total) {
+						int row, k;
+						uint32_t s_qpos;
+						bool s_plus;
+						S.locate(g, 2 * SW::NSEG * 64, row, k);
+						if (step == 1) {  // BOTH1 seeds: plus-strand seed first, then minus (search1m6.cpp:69-108)
+							if (row >= NCH * 64) row -= NCH * 64;
+							s_qpos = (uint32_t)row;
+							uint32_t tp, pp, tm, pm;
+							S.probe_get(0, row, tp, pp);
+							S.probe_get(1, row, tm, pm);
+							if (k == 0 && tp == TALLY_BOTH1) { s_plus = true; a_db = pp; }
+							else { s_plus = false; a_db = pm; }
+						} else {  // chain rows: [strand][chunk][k][lane]
+							int seg = row >> 6;
+							const int l = row & 63;
+							const bool short_row = seg < SW::NSEG;  // the list's first half: rows of at most two (phase 4)
+							if (seg >= SW::NSEG) seg -= SW::NSEG;
+							s_plus = seg < NCH;
+							s_qpos = (uint32_t)((seg - (s_plus ? 0 : NCH)) * 64 + l);
+							if constexpr (ROWS != 0) a_db = S.row_entry(seg, k, l, short_row);
+							else a_db = S.rowstore[((size_t)seg * ROW_CAP + k) * 64 + l];
+						}
+						a_meta = s_qpos | (s_plus ? 0x4000u : 0u) | (g >= totalFirst ? 0x8000u : 0u) | 0x10000u;
+					}
+					scanned += 64;
+				}
+				laps(8);
+				uint64_t mm[NCH];
+#pragma unroll
+				for (int c = 0; c < NCH; ++c) mm[c] = 0;
+				if (nb > 0) {  // wave-uniform
+				if (q_other) {  // wave-uniform: a read with bytes outside the code list (IUPAC beyond N, 'u')
+					if (c_live) lane_mismatch_mask<NCH>(g_seq, c_db - c_qpos, sQ2 + (c_plus ? 0 : SW::QMAX), QL, mm);
+				} else {
+					if (c_live) lane_mismatch_planes<NCH>(g_seqp, c_db - c_qpos, qpl + (c_plus ? 0 : 2 * NCH), QL, mm);
+				}
+#else
 				// (PF: the scan runs one step ahead -- up to 128 queued -- so that the batch after this one is known when its windows are touched)
 				while (qcount < (PF ? 65 : 64) && scanned < total) {
 					const int g = scanned + lane;
@@ -1493,6 +1560,7 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 						glds_touch(reinterpret_cast<const uint8_t *>(g_seqp + (ndblo >> 5)), 16 * ((QL - 1) / 32 + 2), lds_addr(pf_sink));
 					}
 				}
+#endif
 				laps(9);
 				// ExtendPen's two x-drop walks (extendpen.cpp:25-78), every lane on its own bit vector.  The accumulated
 				// penalty only grows along the walk and the cap only falls: a lane over the cap as it stands now is over
@@ -1549,6 +1617,22 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 						                 !(S.hitCount != hc0 && (my_dblo >> 6) == (dblo >> 6)));
 				}
 				laps(11);
+#if URX_SCAN_AHEAD
+				}  // nb > 0
+				if (want_scan && !done) {  // the scan step issued above: filter and queue (extendpen.cpp:12-17)
+					const uint32_t s_qpos = a_meta & 0x3FFFu;
+					bool ok = (a_meta & 0x10000u) != 0 && a_db >= s_qpos;
+					ok = ok && !S.overlaps_any_hit(a_db - s_qpos);
+					const uint64_t m = __ballot(ok);
+					if (ok) {
+						const int pos = (qhead + qcount + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))) & 127;
+						cq_db[pos] = a_db;
+						cq_qp[pos] = (uint16_t)(a_meta & 0xFFFFu);
+					}
+					qcount += __builtin_popcountll(m);
+					URX_SYNC();
+				}
+#endif
 			}
 
 			if (step == 1) {
