@@ -1066,3 +1066,38 @@ def test_short_flanks_with_a_gap_next_to_the_read_ends(small_case, gpu, lo, hi):
     assert sum(("I" in p or "D" in p) for p in opaths) > len(reads) // 3  # the gaps are aligned, not clipped away
     gres, gops = gpu["mapper"].map_se(bases, offs)
     compare_results(gres, gops, ores, opaths)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,hi", [(24, 151), (24, 152), (30, 157), (30, 158), (16, 143), (16, 144)])
+def test_two_chunk_instance_up_to_128_kmer_starts(small_case, tmp_path, monkeypatch, w, hi):
+    """Round 6: a batch whose longest read has at most 128 k-mer starts (150 bases at W = 24) is mapped by search_se_kernel<3, .., KCH = 2>: slot entries,
+    prefix array and chain groups for two chunks of 64 starts instead of three, the row store in LDS.  Either side of the limit for three word lengths
+    (hi - W + 1 = 128: the two-chunk instance; 129: the three-chunk one), every read length from W up in the batch, N / lower case / IUPAC reads among them:
+    the oracle's results, and the same results with the instance switched off (URMAPX_NO_K2)."""
+    import os
+    import oracle_lib as ol
+    from urmap_amd import api, synth
+    from conftest import reads_to_arrays
+    if w == 24:
+        oi, ufi = small_case["oracle_index"], small_case["ufi"]
+    else:
+        oi = ol.Index.build(small_case["fasta"], 524309, word_length=w)
+        ufi = os.path.join(tmp_path, f"w{w}.ufi")
+        oi.save(ufi)
+    rng = np.random.default_rng(100 * w + hi)
+    reads = []
+    for i, L in enumerate(rng.integers(w, hi + 1, size=300).tolist() + [hi] * 300 + [w, hi - 1]):
+        reads += synth.make_reads(9000 + 17 * i + hi, small_case["genome"], 1, read_len=int(L), sub=0.02, ins=0.002, dele=0.002)
+    reads = mutate_edge_reads(reads, hi)
+    bases, offs = reads_to_arrays(reads)
+    ores, opaths, _ = oi.map_se(bases, offs, threads=4)
+    idx = api.Index.open(ufi).upload(0)
+    m = api.Mapper(idx, device=0, method=6)
+    gres, gops = m.map_se(bases, offs)
+    compare_results(gres, gops, ores, opaths)
+    monkeypatch.setenv("URMAPX_NO_K2", "1")
+    gres3, gops3 = m.map_se(bases, offs)
+    compare_results(gres3, gops3, ores, opaths)
+    m.close()
+    idx.close()

@@ -174,10 +174,8 @@ static constexpr uint32_t PK_MASK = 1023u, PK_LEN_SH = 10, PK_SCORE_SH = 20, PK_
 #ifndef URX_PREFETCH
 #define URX_PREFETCH 0  // bit 0: the next batch's windows, bit 1: a read's long rows
 #endif
-#ifndef URX_SCAN_AHEAD
-#define URX_SCAN_AHEAD 0  // the candidate scan of the next batch issued behind the current batch's window loads (0: the round-5 loop)
-#endif
-static_assert(!(URX_SCAN_AHEAD && (URX_PREFETCH & 1)), "the L2 touches of the next batch's windows belong to the round-5 loop");
+// (The scan of the next batch issued beside the current batch's window gather -- URX_SCAN_AHEAD, commit f9ec288 -- was bit-identical and 5-17 % slower:
+// profiles/r6/ab_scan_ahead.txt.)
 #ifndef URX_HSP_CAP
 #define URX_HSP_CAP (URX_PREFETCH ? 192 : 256)  // build-time experiment (profiles/r5/ab_waves5.txt): 64 frees 1.5 KB of LDS per block
 #endif
@@ -239,14 +237,18 @@ static constexpr int SE_HITW1 = URX_SE_HITW1;
 // LAYOUT 1 (round 5): the slot entries in LDS come out of DevIndex::slot16 -- pr_lo = the slot's position, pr_hi = tally | row length
 // << 8, pr_sl = the row's second position (rows of two) or its index in DevIndex::rows -- instead of the two dwords around the
 // 5-byte slot and the slot number's low half
-template <int NCH, bool OVF, int LAYOUT = 0>
+// KCH (round 6): the chunks of 64 k-MER START positions the instance holds per strand -- NCH by default (every base but the last W - 1 starts a k-mer);
+// an instance for reads whose QL - W + 1 k-mers fit fewer chunks (150 bases, W = 24: 127 starts = two chunks of a three-chunk read) keeps slot entries,
+// prefix array and chain groups for those only: a third less LDS in them, a third fewer group steps in every unrolled loop over them
+template <int NCH, bool OVF, int LAYOUT = 0, int KCH = NCH>
 struct SearchWave {
+	static_assert(KCH >= 1 && KCH <= NCH, "k-mer chunks");
 	static constexpr int QMAX = 64 * NCH;
 	// rows of the narrow DP's trace buffer: a flank is at most QMAX - W long (the HSP holds the seed), longer problems
 	// take the wide path
 	static constexpr int TB_ROWS8 = (QMAX - 24) / 8 + 2;
 	static constexpr int WIDE_LB = QMAX + 64;
-	static constexpr int NSEG = 2 * NCH;  // candidate row segments: [strand][chunk] or [chunk]
+	static constexpr int NSEG = 2 * KCH;  // candidate row segments: [strand][chunk] or [chunk]
 
 	const DevIndex &X;
 	const urmapx_params &P;
@@ -588,7 +590,7 @@ struct SearchWave {
 			uint32_t *const px = hx + 2 * P3_HSP;
 #pragma unroll
 			for (int g = 0; g < NSEG; ++g)
-				if (64 * (g % NCH) < nwords) {
+				if (64 * (g % KCH) < nwords) {
 					px[g * 64 + lane] = pr_lo[g * 64 + lane];
 					px[(NSEG + g) * 64 + lane] = pr_hi[g * 64 + lane];
 					px[(2 * NSEG + g) * 64 + lane] = pr_sl[g * 64 + lane];
@@ -615,7 +617,7 @@ struct SearchWave {
 		wait_lgkm0();  // every earlier LDS read of the pr_* arrays has returned
 #pragma unroll
 		for (int g = 0; g < NSEG; ++g)
-			if (64 * (g % NCH) < nwords) {
+			if (64 * (g % KCH) < nwords) {
 				glds_dword(px + g * 64 + lane, lds_addr(pr_lo + g * 64));
 				glds_dword(px + (NSEG + g) * 64 + lane, lds_addr(pr_hi + g * 64));
 				glds_dword(px + (2 * NSEG + g) * 64 + lane, lds_addr(pr_sl + g * 64));
@@ -763,7 +765,7 @@ struct SearchWave {
 	}
 
 	// ---- this read's k-mer slots, as the LDS-DMA gathers of probe_gather left them ----
-	// entry e = strand * NCH*64 + i, i = the PLUS-strand position of the k-mer's bases: the minus-strand k-mer at minus
+	// entry e = strand * KCH*64 + i, i = the PLUS-strand position of the k-mer's bases: the minus-strand k-mer at minus
 	// position q covers the same bases as the plus-strand k-mer at nwords-1-q.  pr_lo / pr_hi = the two aligned dwords
 	// around the 5-byte slot, pr_sl = the low half of the slot number (its two low bits say where the slot starts in
 	// them: 5*slot = slot mod 4), pr_hb = bit 32 of the slot numbers of a chunk as one ballot word per [strand][chunk].
@@ -772,7 +774,7 @@ struct SearchWave {
 	uint64_t *pr_hb;
 	uint32_t pf_sink = 0;  // LDS address of the L2 touches' sink (dev_common.h: glds_touch); 0: no touches
 	__device__ __forceinline__ void probe_get(int s, int q, uint32_t &tally, uint32_t &pos) const {
-		const int e = s * NCH * 64 + (s ? nwords - 1 - q : q);
+		const int e = s * KCH * 64 + (s ? nwords - 1 - q : q);
 		if constexpr (LAYOUT == 1) {
 			pos = pr_lo[e];
 			tally = pr_hi[e] & 0xFFu;
@@ -809,7 +811,7 @@ struct SearchWave {
 		uint64_t lo0, hi0, inv0, invm0;
 		planes(0, lo0, hi0, inv0, invm0);
 #pragma unroll
-		for (int c = 0; c < NCH; ++c) {
+		for (int c = 0; c < KCH; ++c) {
 			if (64u * c < nwn) {  // wave-uniform: chunks that hold a k-mer start
 				uint64_t lo1 = 0, hi1 = 0, inv1 = ~0ull, invm1 = ~0ull;
 				if (c + 1 < NCH && 64 * (c + 1) < QLn) planes(c + 1, lo1, hi1, inv1, invm1);
@@ -817,12 +819,12 @@ struct SearchWave {
 				bool vp, vm;
 				kmer_slots(X, lo0, hi0, inv0, invm0, lo1, hi1, inv1, invm1, lane, 64u * c + lane, nwn, sp, sm, vp, vm);
 				stage_sl[c * 64 + lane] = (uint32_t)sp;
-				stage_sl[(NCH + c) * 64 + lane] = (uint32_t)sm;
+				stage_sl[(KCH + c) * 64 + lane] = (uint32_t)sm;
 				const uint64_t hbp = __ballot(vp && ((sp >> 32) & 1ull)), hbm = __ballot(vm && ((sm >> 32) & 1ull));
 				const uint64_t okp = __ballot(vp), okm = __ballot(vm);
 				if (lane == 0) {
 					stage_b[2 * c] = hbp; stage_b[2 * c + 1] = okp;
-					stage_b[2 * (NCH + c)] = hbm; stage_b[2 * (NCH + c) + 1] = okm;
+					stage_b[2 * (KCH + c)] = hbm; stage_b[2 * (KCH + c) + 1] = okm;
 				}
 				lo0 = lo1; hi0 = hi1; inv0 = inv1; invm0 = invm1;
 			}
@@ -835,7 +837,7 @@ struct SearchWave {
 		wait_lgkm0();  // every earlier LDS read of the pr_* arrays has returned
 #pragma unroll
 		for (int g = 0; g < NSEG; ++g) {
-			if (64u * (g % NCH) < nwn) {
+			if (64u * (g % KCH) < nwn) {
 				const uint64_t hb = stage_b[2 * g], ok = stage_b[2 * g + 1];
 				const bool v = (ok >> lane) & 1ull;
 				const uint32_t sl = stage_sl[g * 64 + lane];
@@ -870,13 +872,13 @@ struct SearchWave {
 		const int lane = fresh_lane(this->lane);  // dev_common.h: lane-derived values are remade here, not carried (and spilled) from the top of the kernel
 #pragma unroll
 		for (int g = 0; g < NSEG; ++g) {
-			const int s2 = g / NCH, c = g % NCH;
+			const int s2 = g / KCH, c = g % KCH;
 			const int p = 64 * c + lane;
 			T[g] = 0; ps[g] = 0; sl[g] = 0;
 			if constexpr (LAYOUT == 1) {
 				// sl carries what rows_fetch needs instead of a slot number: row length | (second position or row index) << 32
 				if (p < nwords) {
-					const int e = s2 * NCH * 64 + (s2 ? nwords - 1 - p : p);
+					const int e = s2 * KCH * 64 + (s2 ? nwords - 1 - p : p);
 					const uint32_t hi = pr_hi[e];
 					ps[g] = pr_lo[e];
 					T[g] = hi & 0xFFu;
@@ -889,7 +891,7 @@ struct SearchWave {
 			act[g] = (T[g] & TALLY_MY_BIT) != 0 && T[g] != TALLY_BOTH1;
 			if (act[g]) {
 				const int i = s2 ? nwords - 1 - p : p;
-				sl[g] = (uint64_t)pr_sl[s2 * NCH * 64 + i] | (((pr_hb[s2 * NCH + (i >> 6)] >> (i & 63)) & 1ull) << 32);
+				sl[g] = (uint64_t)pr_sl[s2 * KCH * 64 + i] | (((pr_hb[s2 * KCH + (i >> 6)] >> (i & 63)) & 1ull) << 32);
 			}
 		}
 	}
@@ -1066,7 +1068,10 @@ struct SearchWave {
 // 2 = the second launch: the reads PART 1 parked at phase 3, from the replay of AlignHSP's bookkeeping over their jobs onwards
 // (phases 4-5, then parked for phase 6 like any other read).  n = the batch's reads (PART 2: read from dp3's counter).
 // ROWS: 0 = chains walked hop by hop, 1 = rows looked up in the row layout (rows_fetch), 2 = everything with the probe (DevIndex::slot16)
-template <int NCH, bool OVF, bool DBG, int ROWS = 0, int PART = 0>
+// KCH: see SearchWave.  KCH < NCH (the slot16 layout only): the block's row store -- the chain heads' first positions and second positions / row indexes
+// that rows_fetch keeps for the candidate scans of phases 4 and 5 -- lies in the LDS the smaller arrays free, not in global scratch: no store per chain
+// group and no L2 round trip in front of every scan step
+template <int NCH, bool OVF, bool DBG, int ROWS = 0, int PART = 0, int KCH = NCH>
 __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel(DevIndex X, urmapx_params P, const uint8_t *__restrict__ bases,
                                                        const uint64_t *__restrict__ offs, uint32_t n,
                                                        urmapx_result *__restrict__ results,
@@ -1078,7 +1083,8 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
                                                        DpWork dp, DpWork dp3) {
 	static_assert(PART == 0 || (!OVF && !DBG && ROWS == 1), "phase 3 is parked by the production first pass only");
 	// stats != nullptr (URMAPX_PHASE_STATS): per-phase shader cycles are accumulated into stats (u64 each, from byte 8)
-	using SW = SearchWave<NCH, OVF, ROWS == 2 ? 1 : 0>;
+	static_assert(KCH == NCH || (ROWS == 2 && PART == 0 && !OVF && !DBG), "fewer k-mer chunks: the production first pass on the slot16 layout");
+	using SW = SearchWave<NCH, OVF, ROWS == 2 ? 1 : 0, KCH>;
 	constexpr int NQ_BYTES = ((SW::QMAX + 4 + 255) / 256) * 256;  // the next read's bytes from a 4-byte aligned address on, in 256-byte DMA pieces
 	__shared__ __attribute__((aligned(16))) uint8_t sQ2[2 * SW::QMAX];  // plus strand, then reverse complement
 	uint8_t *const sQp = sQ2, *const sQm = sQ2 + SW::QMAX;
@@ -1101,6 +1107,7 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 	__shared__ uint16_t cq_qp[128];
 	constexpr bool PF = (URX_PREFETCH & 1) != 0;
 	__shared__ uint32_t pf_sink[URX_PREFETCH ? 64 : 1];  // where the L2 touches land (glds_touch); never read
+	__shared__ uint32_t rs_lds[KCH < NCH ? 2 * SW::NSEG * 64 : 1];  // KCH < NCH: the row store (rows_fetch, row_entry)
 	// between two gather steps both are idle: the next read's slot numbers are staged there on their way to the pr_* arrays
 	static_assert(SW::NSEG * 64 * 4 <= sizeof(pre) && 2 * SW::NSEG * 8 <= sizeof(cq_db), "staging");
 	uint32_t *const stage_sl = reinterpret_cast<uint32_t *>(pre);
@@ -1120,7 +1127,8 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 	if constexpr ((URX_PREFETCH & 2) != 0) S.pf_sink = lds_addr(pf_sink);
 	{
 		uint8_t *sc = scratch + (size_t)blockIdx.x * scratch_stride;
-		S.rowstore = reinterpret_cast<uint32_t *>(sc);
+		if constexpr (KCH < NCH) S.rowstore = rs_lds;
+		else S.rowstore = reinterpret_cast<uint32_t *>(sc);
 		S.ws.carve(sc + (size_t)SW::NSEG * ROW_CAP * 64 * 4, SW::QMAX, SW::WIDE_LB);
 		// the trace cells of phase 3's banded DP live in this block's global scratch (phase 6 has kernels of its own with
 		// the trace in LDS): 6 KB of LDS per block went to the slot entries instead
@@ -1132,7 +1140,7 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 		S.hit_wsh = (hsp_lds_cap >= 64 && hsp_lds_cap <= HSP_CAP) ? 4 : 6;
 	}
 	const bool geom_ok = W <= 32 && X.maxIx <= (uint32_t)ROW_CAP;
-	auto len_ok = [&](int ql) { return geom_ok && ql >= W && ql <= SW::QMAX; };
+	auto len_ok = [&](int ql) { return geom_ok && ql >= W && ql <= SW::QMAX && ql - (W - 1) <= 64 * KCH; };
 
 	// Reads are handed out by a ticket counter, not by a fixed stride: the cost of a read is heavy-tailed (a read in a
 	// repeat family aligns up to 256 HSPs in phase 6), and with a fixed assignment the blocks that draw such reads
@@ -1381,9 +1389,9 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 			int cnt[2 * SW::NSEG];
 #pragma unroll
 			for (int g = 0; g < 2 * SW::NSEG; ++g) cnt[g] = 0;
-			if (step == 1) {  // segments [0, NCH): phase 1 (stride positions), [NCH, 2 NCH): phase 2
+			if (step == 1) {  // segments [0, KCH): phase 1 (stride positions), [KCH, 2 KCH): phase 2
 #pragma unroll
-				for (int c = 0; c < NCH; ++c) {
+				for (int c = 0; c < KCH; ++c) {
 					const int p = 64 * c + lane;
 					int nb1 = 0;
 					if (p < nwords) {
@@ -1394,7 +1402,7 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 					}
 					const bool onStride = (p % W) == 0;
 					cnt[c] = onStride ? nb1 : 0;
-					cnt[NCH + c] = onStride ? 0 : nb1;
+					cnt[KCH + c] = onStride ? 0 : nb1;
 				}
 			} else {  // segments [0, NSEG): rows <= 2 (phase 4), [NSEG, 2 NSEG): rows > 2 (phase 5)
 #pragma unroll
@@ -1404,7 +1412,7 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 				}
 			}
 			const int total = S.template scan_counts<2 * SW::NSEG>(cnt);
-			const int totalFirst = (int)S.pre[(step == 1 ? NCH : SW::NSEG) * 64];  // candidates of the first of the two phases
+			const int totalFirst = (int)S.pre[(step == 1 ? KCH : SW::NSEG) * 64];  // candidates of the first of the two phases
 			bool crossed = false;
 			// The candidate stream is first filtered -- a candidate on the 64-base diagonal block of a hit already found
 			// returns at once in the reference (extendpen.cpp:15-17), and hits are never removed -- and the survivors are
@@ -1421,69 +1429,6 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 					if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long *>(stats) + 1 + slot, (unsigned long long)(now - tsub));
 					tsub = now;
 				};
-#if URX_SCAN_AHEAD
-				// Round 6 (second half): the scan is split.  scan_issue locates the candidates of the next 64 list positions and ISSUES the
-				// reads that name their reference positions (the block's row store in global scratch, and behind it DevIndex::rows for rows of
-				// three and more: two dependent round trips); scan_finish filters and queues them.  One turn of the loop = the scan step the
-				// queue will want after this batch is issued, the batch (if the queue holds one) is gathered, walked and consumed, the scan
-				// step is finished: the binary search over the prefix array and both round trips run beside the batch's window gather instead
-				// of in front of the next one.  Each part exists once (the kernel has to stay inside the instruction cache).
-				const bool have_batch = qcount >= 64 || (scanned >= total && qcount > 0);
-				const int nb = have_batch ? (qcount < 64 ? qcount : 64) : 0;
-				const bool want_scan = scanned < total && qcount - nb < 64;
-				if (!have_batch && !want_scan) break;
-				uint32_t c_qpos = 0, c_db = 0;
-				bool c_plus = true, c_second = false;
-				const bool c_ok = lane < nb;
-				if (c_ok) {
-					const int pos = (qhead + lane) & 127;
-					c_db = cq_db[pos];
-					const uint32_t qp = cq_qp[pos];
-					c_qpos = qp & 0x3FFFu; c_plus = (qp & 0x4000u) != 0; c_second = (qp & 0x8000u) != 0;
-				}
-				qhead = (qhead + nb) & 127; qcount -= nb;
-				const bool c_live = c_ok;
-				uint32_t a_db = 0, a_meta = 0;
-				if (want_scan) {  // wave-uniform
-					const int g = scanned + lane;
-					if (g < total) {
-						int row, k;
-						uint32_t s_qpos;
-						bool s_plus;
-						S.locate(g, 2 * SW::NSEG * 64, row, k);
-						if (step == 1) {  // BOTH1 seeds: plus-strand seed first, then minus (search1m6.cpp:69-108)
-							if (row >= NCH * 64) row -= NCH * 64;
-							s_qpos = (uint32_t)row;
-							uint32_t tp, pp, tm, pm;
-							S.probe_get(0, row, tp, pp);
-							S.probe_get(1, row, tm, pm);
-							if (k == 0 && tp == TALLY_BOTH1) { s_plus = true; a_db = pp; }
-							else { s_plus = false; a_db = pm; }
-						} else {  // chain rows: [strand][chunk][k][lane]
-							int seg = row >> 6;
-							const int l = row & 63;
-							const bool short_row = seg < SW::NSEG;  // the list's first half: rows of at most two (phase 4)
-							if (seg >= SW::NSEG) seg -= SW::NSEG;
-							s_plus = seg < NCH;
-							s_qpos = (uint32_t)((seg - (s_plus ? 0 : NCH)) * 64 + l);
-							if constexpr (ROWS != 0) a_db = S.row_entry(seg, k, l, short_row);
-							else a_db = S.rowstore[((size_t)seg * ROW_CAP + k) * 64 + l];
-						}
-						a_meta = s_qpos | (s_plus ? 0x4000u : 0u) | (g >= totalFirst ? 0x8000u : 0u) | 0x10000u;
-					}
-					scanned += 64;
-				}
-				laps(8);
-				uint64_t mm[NCH];
-#pragma unroll
-				for (int c = 0; c < NCH; ++c) mm[c] = 0;
-				if (nb > 0) {  // wave-uniform
-				if (q_other) {  // wave-uniform: a read with bytes outside the code list (IUPAC beyond N, 'u')
-					if (c_live) lane_mismatch_mask<NCH>(g_seq, c_db - c_qpos, sQ2 + (c_plus ? 0 : SW::QMAX), QL, mm);
-				} else {
-					if (c_live) lane_mismatch_planes<NCH>(g_seqp, c_db - c_qpos, qpl + (c_plus ? 0 : 2 * NCH), QL, mm);
-				}
-#else
 				// (PF: the scan runs one step ahead -- up to 128 queued -- so that the batch after this one is known when its windows are touched)
 				while (qcount < (PF ? 65 : 64) && scanned < total) {
 					const int g = scanned + lane;
@@ -1493,7 +1438,7 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 						int row, k;
 						S.locate(g, 2 * SW::NSEG * 64, row, k);
 						if (step == 1) {  // BOTH1 seeds: plus-strand seed first, then minus (search1m6.cpp:69-108)
-							if (row >= NCH * 64) row -= NCH * 64;
+							if (row >= KCH * 64) row -= KCH * 64;
 							s_qpos = (uint32_t)row;
 							uint32_t tp, pp, tm, pm;
 							S.probe_get(0, row, tp, pp);
@@ -1505,8 +1450,8 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 							const int l = row & 63;
 							const bool short_row = seg < SW::NSEG;  // the list's first half: rows of at most two (phase 4)
 							if (seg >= SW::NSEG) seg -= SW::NSEG;
-							s_plus = seg < NCH;
-							s_qpos = (uint32_t)((seg - (s_plus ? 0 : NCH)) * 64 + l);
+							s_plus = seg < KCH;
+							s_qpos = (uint32_t)((seg - (s_plus ? 0 : KCH)) * 64 + l);
 							if constexpr (ROWS != 0) s_db = S.row_entry(seg, k, l, short_row);
 							else s_db = S.rowstore[((size_t)seg * ROW_CAP + k) * 64 + l];
 						}
@@ -1560,7 +1505,6 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 						glds_touch(reinterpret_cast<const uint8_t *>(g_seqp + (ndblo >> 5)), 16 * ((QL - 1) / 32 + 2), lds_addr(pf_sink));
 					}
 				}
-#endif
 				laps(9);
 				// ExtendPen's two x-drop walks (extendpen.cpp:25-78), every lane on its own bit vector.  The accumulated
 				// penalty only grows along the walk and the cap only falls: a lane over the cap as it stands now is over
@@ -1617,22 +1561,6 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 						                 !(S.hitCount != hc0 && (my_dblo >> 6) == (dblo >> 6)));
 				}
 				laps(11);
-#if URX_SCAN_AHEAD
-				}  // nb > 0
-				if (want_scan && !done) {  // the scan step issued above: filter and queue (extendpen.cpp:12-17)
-					const uint32_t s_qpos = a_meta & 0x3FFFu;
-					bool ok = (a_meta & 0x10000u) != 0 && a_db >= s_qpos;
-					ok = ok && !S.overlaps_any_hit(a_db - s_qpos);
-					const uint64_t m = __ballot(ok);
-					if (ok) {
-						const int pos = (qhead + qcount + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))) & 127;
-						cq_db[pos] = a_db;
-						cq_qp[pos] = (uint16_t)(a_meta & 0xFFFFu);
-					}
-					qcount += __builtin_popcountll(m);
-					URX_SYNC();
-				}
-#endif
 			}
 
 			if (step == 1) {
@@ -2564,6 +2492,11 @@ hipError_t launch_search_se(const DevIndex &X, const urmapx_params &P, const uin
 	hipLaunchKernelGGL((search_se_kernel<NCH_, false, false, 2>), GRID_, block, 0, s, X, P, d_bases, d_offs, n, d_results,            \
 	                   d_path_ops, d_path_used, no_stats3, wk.scratch, wk.scratch_stride, X.seq, X.blob, X.seqp, wk.ticket,          \
 	                   wk.hsp_lds_cap, wk.ovf_list, OVFBASE_, DP_, no_dp)
+	// the same with fewer k-mer chunks than byte chunks (SearchWave: KCH) and the row store in LDS
+#define URX_LAUNCH_SE_S16K(NCH_, KCH_, GRID_, OVFBASE_, DP_)                                                                        \
+	hipLaunchKernelGGL((search_se_kernel<NCH_, false, false, 2, 0, KCH_>), GRID_, block, 0, s, X, P, d_bases, d_offs, n, d_results,   \
+	                   d_path_ops, d_path_used, no_stats3, wk.scratch, wk.scratch_stride, X.seq, X.blob, X.seqp, wk.ticket,          \
+	                   wk.hsp_lds_cap, wk.ovf_list, OVFBASE_, DP_, no_dp)
 	// phase 3 parked (round 5): the first launch (PART 1: no banded DP inside), phase 3's flank DPs (every job made, no round lists),
 	// the second launch over the reads parked there (PART 2; wk.ticket + 2: a work counter of its own)
 #define URX_LAUNCH_SE_P3(NCH_)                                                                                                      \
@@ -2603,12 +2536,15 @@ hipError_t launch_search_se(const DevIndex &X, const urmapx_params &P, const uin
 	const bool diag = wk.stats != nullptr && (nch == 3 || nch == 4);  // diagnostic instantiations: 150 / 250 bp classes, phase 6 inline
 	uint32_t *const no_stats3 = nullptr;
 	// phase 3 parked: reads of up to 320 bases on an index with the row layout, phase 6 as launches of its own (the default)
+	// round 6: every read of the batch has at most 128 k-mer starts (150 bases at W = 24): the instance that keeps two chunks of them (URMAPX_NO_K2=1: A/B, tests)
+	const bool k2 = getenv("URMAPX_NO_K2") == nullptr && max_read_len >= X.W && max_read_len - (X.W - 1) <= 128u;
 	const bool p3 = !diag && wk.dp3.jobs && wk.dp[0].jobs && wk.dp_blocks > 0 && X.rowinfo && nch <= 5 && wk.stats == nullptr;
 	if (p3 && nch == 2) URX_LAUNCH_SE_P3(2);
 	else if (p3 && nch == 3) URX_LAUNCH_SE_P3(3);
 	else if (p3 && nch == 4) URX_LAUNCH_SE_P3(4);
 	else if (p3) URX_LAUNCH_SE_P3(5);
 	else if (!diag && X.slot16 && wk.stats == nullptr && nch == 2) URX_LAUNCH_SE_S16(2, grid, no_ovf, wk.dp[0]);  // slots, row lengths and second positions in one gather
+	else if (!diag && X.slot16 && wk.stats == nullptr && nch == 3 && k2) URX_LAUNCH_SE_S16K(3, 2, grid, no_ovf, wk.dp[0]);  // 150-base reads: 127 k-mer starts
 	else if (!diag && X.slot16 && wk.stats == nullptr && nch == 3) URX_LAUNCH_SE_S16(3, grid, no_ovf, wk.dp[0]);
 	else if (!diag && X.slot16 && wk.stats == nullptr && nch == 4) URX_LAUNCH_SE_S16(4, grid, no_ovf, wk.dp[0]);
 	else if (!diag && X.slot16 && wk.stats == nullptr && nch == 5) URX_LAUNCH_SE_S16(5, grid, no_ovf, wk.dp[0]);
@@ -2668,6 +2604,7 @@ hipError_t launch_search_se(const DevIndex &X, const urmapx_params &P, const uin
 #undef URX_LAUNCH_SE_ROWS
 #undef URX_LAUNCH_SE_P3
 #undef URX_LAUNCH_SE_S16
+#undef URX_LAUNCH_SE_S16K
 #undef URX_LAUNCH_DP
 	return hipGetLastError();
 }
