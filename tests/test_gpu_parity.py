@@ -1101,3 +1101,36 @@ def test_two_chunk_instance_up_to_128_kmer_starts(small_case, tmp_path, monkeypa
     compare_results(gres3, gops3, ores, opaths)
     m.close()
     idx.close()
+
+
+@pytest.mark.gpu
+def test_a_genome_of_more_than_64_sequences(tmp_path):
+    """PosToCoordL (ufindex.cpp:729-755) on the device: up to 64 sequences every lane tests one (round 6), more than that the binary search over the
+    offsets runs -- 70 sequences of 4 kbp, single reads and pairs against the oracle (sequence index and coordinate are compared per read)."""
+    import os
+    import oracle_lib as ol
+    from urmap_amd import api, synth
+    from conftest import reads_to_arrays
+    g = synth.make_genome(707, [4000] * 70, repeat_frac=0.2, n_families=6)
+    fa = os.path.join(tmp_path, "many.fa")
+    synth.write_fasta(fa, g)
+    oi = ol.Index.build(fa, 524309)
+    ufi = os.path.join(tmp_path, "many.ufi")
+    oi.save(ufi)
+    reads = synth.make_reads(708, g, 2000, read_len=150, sub=0.01, ins=0.001, dele=0.001, random_frac=0.02)
+    bases, offs = reads_to_arrays(reads)
+    ores, opaths, _ = oi.map_se(bases, offs, threads=4)
+    assert len(np.unique(ores["seq_index"][ores["dbpos"] != 0xFFFFFFFF])) > 64
+    idx = api.Index.open(ufi).upload(0)
+    m = api.Mapper(idx, device=0, method=6)
+    gres, gops = m.map_se(bases, offs)
+    compare_results(gres, gops, ores, opaths)
+    m.close()
+    idx.close()
+    r1, r2 = synth.make_pairs(709, g, 600, read_len=150, sub1=0.01, sub2=0.02, ins=0.001, dele=0.001)
+    f1, f2 = os.path.join(tmp_path, "r1.fq"), os.path.join(tmp_path, "r2.fq")
+    synth.write_fastq(f1, r1)
+    synth.write_fastq(f2, r2)
+    osam = os.path.join(tmp_path, "o.sam")
+    oi.map_file_pe(f1, f2, osam, threads=4)
+    assert _map_pe_sam(ufi, f1, f2) == open(osam, "rb").read()

@@ -141,6 +141,12 @@ __device__ __forceinline__ void load_slot(const uint8_t *blob, uint64_t slot, ui
 	pos = (uint32_t)(v >> 8);
 }
 
+// PosToCoordL on the device (search_se_kernel: fill_result_core; search_pe_kernel's output): up to 64 sequences every lane tests one
+// (one round of loads instead of the binary search's five or six dependent ones); 0: the binary search always (A/B builds)
+#ifndef URX_SEQ_LANES
+#define URX_SEQ_LANES 1
+#endif
+
 // wave-uniform bit vector of 64*N bits kept in registers
 template <int N>
 struct BitVec {

@@ -729,6 +729,19 @@ struct SearchWave {
 		if (haveTop) {
 			uint32_t lo = 0, hi = X.seqCount - 1;
 			uint32_t found = 0xFFFFFFFFu, coord = 0xFFFFFFFFu, tl = 0;
+			if (URX_SEQ_LANES && X.seqCount <= 64u) {
+				// up to 64 sequences (a human genome's chromosomes): every lane tests one -- one round of loads where the search below makes
+				// five or six dependent ones; the sequences do not overlap, so at most one lane holds the position
+				const int lane = fresh_lane(this->lane);
+				const bool mine = (uint32_t)lane < X.seqCount;
+				const uint32_t o = mine ? X.seqOffsets[lane] : 0u, sl = mine ? X.seqLengths[lane] : 0u;
+				const uint64_t m = __ballot(mine && top_db >= o && top_db < o + sl);
+				if (m) {
+					const int k = __builtin_ctzll(m);
+					found = (uint32_t)k; coord = top_db - rdlane(o, k); tl = rdlane(sl, k);
+				}
+				hi = 0xFFFFFFFFu;  // (the search below is skipped)
+			}
 			while (lo <= hi && hi != 0xFFFFFFFFu) {
 				uint32_t k = (lo + hi) / 2;
 				uint32_t o = X.seqOffsets[k], sl = X.seqLengths[k];
@@ -1068,9 +1081,9 @@ struct SearchWave {
 // 2 = the second launch: the reads PART 1 parked at phase 3, from the replay of AlignHSP's bookkeeping over their jobs onwards
 // (phases 4-5, then parked for phase 6 like any other read).  n = the batch's reads (PART 2: read from dp3's counter).
 // ROWS: 0 = chains walked hop by hop, 1 = rows looked up in the row layout (rows_fetch), 2 = everything with the probe (DevIndex::slot16)
-// KCH: see SearchWave.  KCH < NCH (the slot16 layout only): the block's row store -- the chain heads' first positions and second positions / row indexes
-// that rows_fetch keeps for the candidate scans of phases 4 and 5 -- lies in the LDS the smaller arrays free, not in global scratch: no store per chain
-// group and no L2 round trip in front of every scan step
+// KCH: see SearchWave.  KCH < NCH (the slot16 layout only), and the class of reads of up to 128 bases, whose block has the room anyway: the block's row
+// store -- the chain heads' first positions and second positions / row indexes that rows_fetch keeps for the candidate scans of phases 4 and 5 -- lies in
+// LDS (what the smaller arrays free), not in global scratch: no store per chain group and no L2 round trip in front of every scan step
 template <int NCH, bool OVF, bool DBG, int ROWS = 0, int PART = 0, int KCH = NCH>
 __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel(DevIndex X, urmapx_params P, const uint8_t *__restrict__ bases,
                                                        const uint64_t *__restrict__ offs, uint32_t n,
@@ -1107,7 +1120,8 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 	__shared__ uint16_t cq_qp[128];
 	constexpr bool PF = (URX_PREFETCH & 1) != 0;
 	__shared__ uint32_t pf_sink[URX_PREFETCH ? 64 : 1];  // where the L2 touches land (glds_touch); never read
-	__shared__ uint32_t rs_lds[KCH < NCH ? 2 * SW::NSEG * 64 : 1];  // KCH < NCH: the row store (rows_fetch, row_entry)
+	constexpr bool RS_LDS = KCH < NCH || (NCH == 2 && ROWS == 2 && PART == 0 && !OVF && !DBG);
+	__shared__ uint32_t rs_lds[RS_LDS ? 2 * SW::NSEG * 64 : 1];  // the row store (rows_fetch, row_entry)
 	// between two gather steps both are idle: the next read's slot numbers are staged there on their way to the pr_* arrays
 	static_assert(SW::NSEG * 64 * 4 <= sizeof(pre) && 2 * SW::NSEG * 8 <= sizeof(cq_db), "staging");
 	uint32_t *const stage_sl = reinterpret_cast<uint32_t *>(pre);
@@ -1127,7 +1141,7 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 	if constexpr ((URX_PREFETCH & 2) != 0) S.pf_sink = lds_addr(pf_sink);
 	{
 		uint8_t *sc = scratch + (size_t)blockIdx.x * scratch_stride;
-		if constexpr (KCH < NCH) S.rowstore = rs_lds;
+		if constexpr (RS_LDS) S.rowstore = rs_lds;
 		else S.rowstore = reinterpret_cast<uint32_t *>(sc);
 		S.ws.carve(sc + (size_t)SW::NSEG * ROW_CAP * 64 * 4, SW::QMAX, SW::WIDE_LB);
 		// the trace cells of phase 3's banded DP live in this block's global scratch (phase 6 has kernels of its own with

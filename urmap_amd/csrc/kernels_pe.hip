@@ -205,6 +205,10 @@ struct Mate {
 	lds_ptr<uint32_t> cq_db;      // LDS [128]: candidate queue of the pending stage (ring)
 	lds_ptr<uint16_t> cq_qp;      // LDS [128]
 	uint32_t *rowstore;   // global, this block: [strand][chunk][k][lane]
+	// Round 6: with DevIndex::slot16 the pending stage keeps two words per chain head (second position or row index, first position) and keeps them in LDS --
+	// 2 x 2 NCH x 64 words behind the prefix array in seed_area, which is idle while the chain rows are gathered and consumed (AlignHSP's buffers and the
+	// wide-band DP's rows live there at other times): no store per group to global scratch, no L2 round trip in front of every candidate step
+	lds_ptr<uint32_t> rs_lds;
 
 	__device__ __forceinline__ bool overlaps_hit(uint32_t db) const {
 		bool eq = false;
@@ -652,8 +656,8 @@ struct Mate {
 #pragma unroll
 				for (int g = 0; g < NG; ++g) {
 					if (!wact[g]) { wK[g] = 0; continue; }
-					rowstore[(size_t)g * 64 + lane] = wx[g];
-					rowstore[(size_t)(NG + g) * 64 + lane] = wps[g];
+					rs_lds[g * 64 + lane] = wx[g];
+					rs_lds[(NG + g) * 64 + lane] = wps[g];
 				}
 				any = false;
 			} else if (lookup) {
@@ -811,9 +815,9 @@ struct Mate {
 							c_q = pend[s][base + lo];
 							if (X->slot16) {
 								const int g = s * NCH + (base >> 6);
-								if (k == 0) c_db = rowstore[(size_t)(2 * NCH + g) * 64 + lo];
+								if (k == 0) c_db = rs_lds[(2 * NCH + g) * 64 + lo];
 								else {
-									const uint32_t x = rowstore[(size_t)g * 64 + lo];
+									const uint32_t x = rs_lds[g * 64 + lo];
 									c_db = round == 0 ? x : X->rows[(size_t)x + (uint32_t)k];  // round 0: rows of at most two
 								}
 							} else if (X->rowinfo) {
@@ -1047,6 +1051,8 @@ __global__ __launch_bounds__(64, TIER == 2 ? 1 : URX_PE_WAVES(NCH)) void search_
 	mshared.ropsL = to_lds(ropsL); mshared.ropsR = to_lds(ropsR); mshared.cand = to_lds(cand);
 	mshared.rowlen = to_lds(rowlen); mshared.pre = to_lds(pre); mshared.cq_db = to_lds(cq_db); mshared.cq_qp = to_lds(cq_qp);
 	mshared.rowstore = reinterpret_cast<uint32_t *>(sc + pe_rowstore_offset(QMAX));
+	static_assert(sizeof(seed_area) >= 256 + 2 * 2 * NCH * 64 * 4, "the pending stage's row store (slot16 layout) behind the prefix array");
+	mshared.rs_lds = to_lds(seed_area + 64);
 	mshared.ws.carve(sc + (size_t)2 * PE_HIT_CAP * PE_HITW1 * URMAPX_MAX_PATH_OPS * 2, QMAX, PE_SCAN_SEG + 2 * QMAX + 64);
 	mshared.L = to_lds(&ml[0]);
 	auto mate = [&](int a) -> M { M r = mshared; r.L = to_lds(&ml[a]); return r; };
@@ -1476,6 +1482,16 @@ __global__ __launch_bounds__(64, TIER == 2 ? 1 : URX_PE_WAVES(NCH)) void search_
 				R.score = (int16_t)(sp >> 1);
 				uint32_t lo = 0, hi = X.seqCount - 1;
 				uint32_t found = 0xFFFFFFFFu, coord = 0xFFFFFFFFu, tl = 0;
+				if (URX_SEQ_LANES && X.seqCount <= 64u) {  // every lane tests one sequence: one round of loads (search_se_kernel: fill_result_core)
+					const bool mine = (uint32_t)lane < X.seqCount;
+					const uint32_t o = mine ? X.seqOffsets[lane] : 0u, sl = mine ? X.seqLengths[lane] : 0u;
+					const uint64_t m = __ballot(mine && db >= o && db < o + sl);
+					if (m) {
+						const int k = __builtin_ctzll(m);
+						found = (uint32_t)k; coord = db - rdlane(o, k); tl = rdlane(sl, k);
+					}
+					hi = 0xFFFFFFFFu;
+				}
 				while (lo <= hi && hi != 0xFFFFFFFFu) {
 					uint32_t k = (lo + hi) / 2;
 					uint32_t o = X.seqOffsets[k], sl = X.seqLengths[k];
