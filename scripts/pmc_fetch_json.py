@@ -9,7 +9,7 @@ mode, L, genome_bp, code, steps = sys.argv[3], int(sys.argv[4]), float(sys.argv[
 counter = sys.argv[9] if len(sys.argv) > 9 else "FETCH_SIZE"
 field = "hbm_read_bytes_per_launch" if counter == "FETCH_SIZE" else "hbm_write_bytes_per_launch"
 out = {"source": "rocprofv3 --pmc " + counter + " -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-other-workloads --no-e2e "
-                 + (sys.argv[8] if len(sys.argv) > 8 else "") + " (hg38-scale workload, 1M reads per launch), scripts/r6_profile.sh (r5_profile.sh in round 5)",
+                 + (sys.argv[8] if len(sys.argv) > 8 else "") + " (hg38-scale workload, 1M reads per launch), scripts/r6_profile2.sh (r6_profile.sh in the first half of round 6, r5_profile.sh in round 5)",
        "unit_note": "FETCH_SIZE / WRITE_SIZE are reported in KiB; for this random 64-byte-sector access pattern it matches the known byte count of the "
                     "probe kernel (k-mers x 64 B + 6 % line-straddling slots + the read), so no gfx950 half-count correction applies "
                     "(that correction is for wide coalesced 128-B requests, MI355X_MICROARCH.md HBM section)",
