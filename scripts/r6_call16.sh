@@ -1,4 +1,4 @@
-# GPU box, round 6 call 16: the code that ships (16 hardware queues): whole GPU suite + smoke(), the default bench line
+# GPU box, round 6 calls 16, 22 and 30: the code that ships (16 hardware queues): whole GPU suite + smoke(), the default bench line
 mkdir -p gpurun_out/r6p
 ( time python -m pytest tests/ -x -q -m gpu ) > gpurun_out/r6p/pytest_gpu.txt 2>&1
 tail -4 gpurun_out/r6p/pytest_gpu.txt
