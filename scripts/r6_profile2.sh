@@ -5,9 +5,9 @@
 # and two --pmc SQ_* passes, counters always in runs of their own, one context.
 R=$GRAFT_REPO_ROOT; cd /tmp; export TMPDIR=/tmp
 export URMAP_BENCH_INDEX_CACHE=/dev/shm/urmap_idx
-O=$R/gpurun_out/r6b/prof; mkdir -p $O
+V=${V:-r6b}
+O=$R/gpurun_out/$V/prof; mkdir -p $O
 T="timeout 900"
-V=r6b
 for wl in ${WORKLOADS:-se150 pe se250}; do
   case $wl in
     se150) W="";;

@@ -16,15 +16,15 @@ SO = os.path.join(ROOT, "urmap_amd", "liburmapx.so")
 # kernel: (min waves per SIMD, max VGPRs, max spilled VGPRs, max spilled SGPRs, max scratch bytes per lane, max LDS bytes)
 CEILINGS = {
     # (template arguments: byte chunks, second pass, diagnostic, row layout (2 = slot16), phase-3 part, chunks of k-mer starts)
-    "search_se_kernel<3, false, false, 2, 0, 2>": (4, 128, 34, 232, 112, 10000),  # 150-base reads, the headline kernel since round 6: two chunks of k-mer starts, row store in LDS
+    "search_se_kernel<3, false, false, 2, 0, 2>": (4, 128, 34, 246, 112, 10000),  # 150-base reads, the headline kernel since round 6: two chunks of k-mer starts, row store in LDS
     "search_se_kernel<3, false, false, 2, 0, 3>": (4, 128, 62, 252, 168, 10048),  # reads of 152-192 bases at W = 24 (and URMAPX_NO_K2): three chunks, row store in global scratch
     "search_se_kernel<4, false, false, 2, 0, 4>": (3, 168, 4, 276, 16, 12560),    # 250-base reads
     "search_se_kernel<2, false, false, 2, 0, 2>": (4, 128, 28, 230, 112, 9808),   # reads of up to 128 bases (row store in LDS: 7 760 + 2 048 B)
     "search_se_kernel<3, false, false, 1, 0, 3>": (4, 128, 55, 256, 168, 10048),  # the same on an index without slot16 (row layout only)
-    "search_se_kernel<3, false, false, 1, 1, 3>": (4, 128, 16, 252, 64, 10048),   # URMAPX_PARK_PHASE3=1: first launch (no banded DP inside)
+    "search_se_kernel<3, false, false, 1, 1, 3>": (4, 128, 37, 292, 64, 10048),   # URMAPX_PARK_PHASE3=1: first launch (no banded DP inside)
     "search_se_kernel<3, false, false, 1, 2, 3>": (4, 120, 0, 150, 0, 10048),     # ... second launch (the reads parked at phase 3)
-    "search_pe_kernel<3, 0>": (4, 128, 76, 292, 288, 10240),                    # 2 x 150 pairs; round 6: the LDS diet (kernels_pe.hip: URX_PE_DIET 2) -- FOUR waves per SIMD, 16 blocks x 10 240 B = a CU's 160 KB
-    "search_pe_kernel<2, 0>": (4, 128, 70, 296, 256, 8256),                     # pairs of reads of up to 128 bases, same diet
+    "search_pe_kernel<3, 0>": (4, 128, 80, 302, 304, 10240),                    # 2 x 150 pairs; round 6: the LDS diet (kernels_pe.hip: URX_PE_DIET 2) -- FOUR waves per SIMD, 16 blocks x 10 240 B = a CU's 160 KB
+    "search_pe_kernel<2, 0>": (4, 128, 75, 296, 272, 8256),                     # pairs of reads of up to 128 bases, same diet
     "dp_kernel<3>": (6, 80, 0, 65, 8, 3456),
     "dp_kernel<4>": (6, 80, 0, 65, 8, 4352),
     "finalize_se_kernel<3, false>": (8, 64, 0, 30, 0, 4480),

@@ -71,6 +71,17 @@ __device__ __forceinline__ uint32_t letter_of(uint32_t c) {
 	return u == 'A' ? 0u : u == 'C' ? 1u : u == 'G' ? 2u : (u == 'T' || u == 'U') ? 3u : 4u;
 }
 
+// Reads are upper-case ACGT almost always, and for those four bytes (c >> 1) & 3 is 0 / 1 / 3 / 2 (A / C / G / T): membership, complement (alpha.cpp:3005) and
+// the 4-bit code (seq_code below: A 0, C 1, G 2, T 3) are one byte picked out of a constant -- four instructions where the general functions take a dozen to forty.
+// The search kernels test a read once (one ballot) and take these when every byte passes; any other read (N, lower case, IUPAC) takes the general functions.
+#ifndef URX_ACGT_FAST
+#define URX_ACGT_FAST 1  // 0: the general functions always (A/B builds)
+#endif
+__device__ __forceinline__ uint32_t acgt_pick(uint32_t table, uint32_t c) { return (table >> (((c >> 1) & 3u) << 3)) & 0xFFu; }
+__device__ __forceinline__ bool is_upper_acgt(uint32_t c) { return c == acgt_pick(0x47544341u, c); }
+__device__ __forceinline__ uint32_t comp_char_acgt(uint32_t c) { return acgt_pick(0x43414754u, c); }
+__device__ __forceinline__ uint32_t seq_code_acgt(uint32_t c) { return acgt_pick(0x02030100u, c); }
+
 // complement char, alpha.cpp:3005 (g_CharToCompChar): IUPAC, case preserving, 'u' and everything else -> '?'
 __device__ __forceinline__ uint32_t comp_char(uint32_t c) {
 	uint32_t up = c & 0xDFu;
@@ -277,8 +288,28 @@ __device__ __forceinline__ void xdrop_walk_lane(const uint64_t (&w)[N], int qpos
 // Mismatches outside the seed window [qpos, qpos + W) of a lane's bit vector.  ExtendPen never looks inside the seed
 // (extendpen.cpp:24-27), so this is the most its walks can meet: a full-length hit costs exactly -mis times this, and no
 // score along the walks exceeds QL minus this.
+#ifndef URX_SEED_FUNNEL
+#define URX_SEED_FUNNEL 1  // 0: the round-2 form (per word: two 64-bit masks from the seed's bounds, 24 instructions a word)
+#endif
 template <int N>
 __device__ __forceinline__ int mismatches_outside_seed(const uint64_t (&w)[N], int qpos, int W) {
+#if URX_SEED_FUNNEL
+	// all mismatches, minus those among the W <= 32 seed bits: the two dwords that hold bits qpos .. qpos + 31 picked out of the vector, one funnel shift
+	int pc = 0;
+#pragma unroll
+	for (int c = 0; c < N; ++c) pc += __builtin_popcountll(w[c]);
+	const int d = qpos >> 5;
+	uint32_t a = 0, b = 0;  // dwords d and d + 1 (0 beyond the vector)
+#pragma unroll
+	for (int i = 0; i < 2 * N; ++i) {
+		const uint32_t dw = (i & 1) ? (uint32_t)(w[i >> 1] >> 32) : (uint32_t)w[i >> 1];
+		a = d == i ? dw : a;
+		b = d + 1 == i ? dw : b;
+	}
+	const uint32_t x = __builtin_amdgcn_alignbit(b, a, (uint32_t)qpos & 31u);
+	const uint32_t m = W >= 32 ? 0xFFFFFFFFu : ((1u << W) - 1u);
+	return pc - __builtin_popcount(x & m);
+#else
 	int pc = 0;
 #pragma unroll
 	for (int c = 0; c < N; ++c) {
@@ -288,6 +319,7 @@ __device__ __forceinline__ int mismatches_outside_seed(const uint64_t (&w)[N], i
 		pc += __builtin_popcountll(w[c] & ~(below_hi & ~below_lo));
 	}
 	return pc;
+#endif
 }
 
 // inclusive prefix sum of a non-negative int over the 64 lanes (DPP, same ladder as wave_prefix_max)
@@ -487,11 +519,44 @@ __device__ __forceinline__ void lds_sync() {
 // position 64c + l out of the read's ballot planes (bit p of lo / hi = letter bits of base p, inv / invm = base p cannot
 // be part of a plus- / minus-strand k-mer), c0 = the chunk's words, c1 = the next chunk's.  sp = plus-strand slot at that
 // position; sm = slot of the reverse-complement k-mer over the same bases (minus-strand position nwords-1-p).
+#ifndef URX_KMER_STREAM
+#define URX_KMER_STREAM 1  // 0: the round-1 form below (each lane spreads its own planes: four bit interleaves of 15 instructions per k-mer pair)
+#endif
 __device__ __forceinline__ void kmer_slots(const DevIndex &X, uint64_t lo0, uint64_t hi0, uint64_t inv0, uint64_t invm0, uint64_t lo1,
                                            uint64_t hi1, uint64_t inv1, uint64_t invm1, int lane, uint32_t p, uint32_t nwords,
                                            uint64_t &sp, uint64_t &sm, bool &vp, bool &vm) {
 	const uint32_t W = X.W;
 	const uint64_t wmask = (W >= 32) ? 0xFFFFFFFFull : ((1ull << W) - 1ull);
+#if URX_KMER_STREAM
+	// Round 6: the bit interleave of the two letter planes is the same for every lane -- it is done ONCE, on the wave-uniform ballot words (scalar
+	// instructions), for the 96 bases a chunk's k-mers can cover: stream S has bit 2i = low letter bit of base i, bit 2i + 1 = high bit; stream T the two
+	// swapped.  A lane's words are 2W bits cut out of the streams at bit 2 * lane: the minus-strand word is the complement of S's piece (letters
+	// complemented, order as it lies), the plus-strand word the bit reversal of T's piece (first base most significant; reversing the bits of a letter
+	// pair whose bits were swapped leaves each letter as it was).
+	uint64_t finv = inv0 >> lane, finvm = invm0 >> lane;
+	if (lane) {
+		finv |= inv1 << (64 - lane);
+		finvm |= invm1 << (64 - lane);
+	}
+	finv &= wmask; finvm &= wmask;
+	vp = p < nwords && finv == 0;
+	vm = p < nwords && finvm == 0;
+	const uint64_t a0 = spread32(lo0), a1 = spread32(lo0 >> 32), a2 = spread32(lo1);
+	const uint64_t b0 = spread32(hi0), b1 = spread32(hi0 >> 32), b2 = spread32(hi1);
+	const uint64_t S0 = a0 | (b0 << 1), S1 = a1 | (b1 << 1), S2 = a2 | (b2 << 1);
+	const uint64_t T0 = b0 | (a0 << 1), T1 = b1 | (a1 << 1), T2 = b2 | (a2 << 1);
+	const bool up = lane >= 32;
+	const uint32_t sh = (2u * (uint32_t)lane) & 63u;
+	const uint64_t sA = up ? S1 : S0, sB = up ? S2 : S1, tA = up ? T1 : T0, tB = up ? T2 : T1;
+	uint64_t segS = sA >> sh, segT = tA >> sh;
+	if (sh) {
+		segS |= sB << (64u - sh);
+		segT |= tB << (64u - sh);
+	}
+	const uint64_t m2 = (W >= 32) ? ~0ull : ((1ull << (2u * W)) - 1ull);
+	const uint64_t wp = __brevll(segT & m2) >> (64u - 2u * W);
+	const uint64_t wm = ~segS & m2;
+#else
 	uint64_t flo = lo0 >> lane, fhi = hi0 >> lane, finv = inv0 >> lane, finvm = invm0 >> lane;
 	if (lane) {
 		flo |= lo1 << (64 - lane);
@@ -507,6 +572,7 @@ __device__ __forceinline__ void kmer_slots(const DevIndex &X, uint64_t lo0, uint
 	const uint64_t wp = spread32(rlo) | (spread32(rhi) << 1);
 	// reverse-complement word covering the same bases: letters complemented, order already reversed
 	const uint64_t wm = spread32(~flo & wmask) | (spread32(~fhi & wmask) << 1);
+#endif
 	sp = mod_slots(murmur64(wp & X.shiftMask), X.slotCount, X.slotMagic);
 	sm = mod_slots(murmur64(wm & X.shiftMask), X.slotCount, X.slotMagic);
 }

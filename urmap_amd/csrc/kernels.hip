@@ -1024,10 +1024,31 @@ struct SearchWave {
 		return X.rows[(size_t)rowstore[(size_t)seg * 64 + l] + (uint32_t)k];
 	}
 
-	// exclusive prefix over NS segments of per-lane counts -> pre[]; returns the total
+	// exclusive prefix over the first `used` of NS segments of per-lane counts -> pre[]; returns the total.  (Round 6: two segments per prefix sum -- a
+	// lane's count is at most ROW_CAP = 32, a segment's total at most 2 048, so two of them ride in the halves of one word and no carry crosses --, and the
+	// segments a step does not use are not summed: phases 1-2 fill a quarter of the list's segments.  URX_SCAN_PACK=0: one sum per segment, all of them.)
+#ifndef URX_SCAN_PACK
+#define URX_SCAN_PACK 0  // measured: -0.8 % on the 250-base search, +0.7 % on the 150-base one (18 more spilled registers in the two-chunk instance): off (profiles/r6/ab_instruction_trims.txt)
+#endif
 	template <int NS>
-	__device__ __forceinline__ int scan_counts(const int (&cnt)[NS]) {
+	__device__ __forceinline__ int scan_counts(const int (&cnt)[NS], int used) {
+		static_assert(NS % 2 == 0, "segments are summed two at a time");
 		int carry = 0;
+#if URX_SCAN_PACK
+#pragma unroll
+		for (int sgm = 0; sgm < NS; sgm += 2) {
+			if (sgm < used) {  // wave-uniform
+				const int inc = wave_prefix_sum(cnt[sgm] | (cnt[sgm + 1] << 16));
+				const uint32_t tot = (uint32_t)rdlane(inc, 63);
+				const int t0 = (int)(tot & 0xFFFFu), t1 = (int)(tot >> 16);
+				pre[sgm * 64 + lane] = (uint16_t)(carry + (inc & 0xFFFF) - cnt[sgm]);
+				pre[(sgm + 1) * 64 + lane] = (uint16_t)(carry + t0 + (int)((uint32_t)inc >> 16) - cnt[sgm + 1]);
+				carry += t0 + t1;
+			}
+		}
+		if (lane == 0) pre[used * 64] = (uint16_t)carry;
+#else
+		used = NS;
 #pragma unroll
 		for (int sgm = 0; sgm < NS; ++sgm) {
 			int inc = wave_prefix_sum(cnt[sgm]);
@@ -1035,6 +1056,7 @@ struct SearchWave {
 			carry += rdlane(inc, 63);
 		}
 		if (lane == 0) pre[NS * 64] = (uint16_t)carry;
+#endif
 		if (carry > 0xFFFF) status |= URMAPX_ST_HSP_OVERFLOW;  // only a 1024-base read whose every k-mer owns a full chain gets here
 		URX_SYNC();
 		return carry;
@@ -1251,13 +1273,22 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 			wait_vm0();
 			URX_SYNC();
 			const int mis = (int)(reinterpret_cast<uintptr_t>(bases + off) & 3);
+			// (dev_common.h: URX_ACGT_FAST) a read of upper-case ACGT only -- nearly every read -- takes the four-instruction complement and code
+			uint32_t chv[NCH];
+			bool plain = true;
+#pragma unroll
+			for (int c = 0; c < NCH; ++c) {
+				const int p = 64 * c + lane;
+				chv[c] = p < QL ? (uint32_t)nextQ[mis + p] : (uint32_t)'A';
+				plain = plain && is_upper_acgt(chv[c]);
+			}
+			const bool acgt = URX_ACGT_FAST && __ballot(!plain) == 0;  // wave-uniform
 #pragma unroll
 			for (int c = 0; c < NCH; ++c) {
 				const int p = 64 * c + lane;
 				if (p < QL) {
-					const uint8_t ch = nextQ[mis + p];
-					sQp[p] = ch;
-					sQm[QL - 1 - p] = (uint8_t)comp_char(ch);
+					sQp[p] = (uint8_t)chv[c];
+					sQm[QL - 1 - p] = (uint8_t)(acgt ? comp_char_acgt(chv[c]) : comp_char(chv[c]));
 				}
 			}
 			URX_SYNC();
@@ -1270,9 +1301,15 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 				for (int c = 0; c < NCH; ++c) {
 					if (64 * c < QL) {
 						const int p = 64 * c + lane;
-						const uint32_t code = p < QL ? seq_code(sQ2[s * SW::QMAX + p], SEQ_CODE_QOTHER) : 0u;
-						const uint64_t b0 = __ballot(code & 1u), b1 = __ballot(code & 2u), b2 = __ballot(code & 4u), b3 = __ballot(code & 8u);
-						oth |= __ballot(code == SEQ_CODE_QOTHER);
+						uint64_t b0, b1, b2 = 0, b3 = 0;
+						if (acgt) {  // codes 0..3: the two upper planes are empty
+							const uint32_t code = p < QL ? seq_code_acgt(sQ2[s * SW::QMAX + p]) : 0u;
+							b0 = __ballot(code & 1u); b1 = __ballot(code & 2u);
+						} else {
+							const uint32_t code = p < QL ? seq_code(sQ2[s * SW::QMAX + p], SEQ_CODE_QOTHER) : 0u;
+							b0 = __ballot(code & 1u); b1 = __ballot(code & 2u); b2 = __ballot(code & 4u); b3 = __ballot(code & 8u);
+							oth |= __ballot(code == SEQ_CODE_QOTHER);
+						}
 						if (lane < 2) {
 							const int shh = 32 * lane;
 							qpl[s * 2 * NCH + 2 * c + lane] = make_uint4((uint32_t)(b0 >> shh), (uint32_t)(b1 >> shh), (uint32_t)(b2 >> shh), (uint32_t)(b3 >> shh));
@@ -1425,7 +1462,8 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 					cnt[SW::NSEG + g] = rl[g] > 2 ? rl[g] : 0;
 				}
 			}
-			const int total = S.template scan_counts<2 * SW::NSEG>(cnt);
+			const int used = URX_SCAN_PACK ? (step == 1 ? 2 * KCH : 2 * SW::NSEG) : 2 * SW::NSEG;  // segments of this step's list: phases 1-2 fill the first 2 KCH
+			const int total = S.template scan_counts<2 * SW::NSEG>(cnt, used);
 			const int totalFirst = (int)S.pre[(step == 1 ? KCH : SW::NSEG) * 64];  // candidates of the first of the two phases
 			bool crossed = false;
 			// The candidate stream is first filtered -- a candidate on the 64-base diagonal block of a hit already found
@@ -1450,7 +1488,7 @@ __global__ __launch_bounds__(64, SEARCH_WAVES_PER_EU(NCH)) void search_se_kernel
 					bool s_plus = true, ok = false;
 					if (g < total) {
 						int row, k;
-						S.locate(g, 2 * SW::NSEG * 64, row, k);
+						S.locate(g, used * 64, row, k);
 						if (step == 1) {  // BOTH1 seeds: plus-strand seed first, then minus (search1m6.cpp:69-108)
 							if (row >= KCH * 64) row -= KCH * 64;
 							s_qpos = (uint32_t)row;

@@ -1115,19 +1115,30 @@ __global__ __launch_bounds__(64, TIER == 2 ? 1 : URX_PE_WAVES(NCH)) void search_
 		}
 		// ---- InitPE x2 (state1.cpp:95-127) ----
 		uint32_t qch[2][2][NCH];  // this lane's bytes of the two mates, both strands (locals: every index below is a constant after unrolling)
+		bool acgt[2];
 #pragma unroll
 		for (int a = 0; a < 2; ++a) {
 			const uint8_t *q = bases + offs[2 * pr + a];
 			const int QL = hot(a).QL;
+			// (dev_common.h: URX_ACGT_FAST) a mate of upper-case ACGT only takes the four-instruction complement and code
+			bool plain = true;
 #pragma unroll
 			for (int c = 0; c < NCH; ++c) {
 				const int p = 64 * c + lane;
-				uint32_t cp = 0, cm = 0;
+				uint32_t cp = 0, cmr = 0;
+				if (p < QL) { cp = q[p]; cmr = q[QL - 1 - p]; }
+				plain = plain && (p >= QL || is_upper_acgt(cp));
+				qch[a][0][c] = cp; qch[a][1][c] = cmr;
+			}
+			acgt[a] = URX_ACGT_FAST && __ballot(!plain) == 0;  // wave-uniform
+#pragma unroll
+			for (int c = 0; c < NCH; ++c) {
+				const int p = 64 * c + lane;
 				if (p < QL) {
-					cp = q[p]; cm = comp_char(q[QL - 1 - p]);
-					ml[a].sQ[0][p] = (uint8_t)cp; ml[a].sQ[1][p] = (uint8_t)cm;
+					const uint32_t cm = acgt[a] ? comp_char_acgt(qch[a][1][c]) : comp_char(qch[a][1][c]);
+					qch[a][1][c] = cm;
+					ml[a].sQ[0][p] = (uint8_t)qch[a][0][c]; ml[a].sQ[1][p] = (uint8_t)cm;
 				}
-				qch[a][0][c] = cp; qch[a][1][c] = cm;
 			}
 			hot(a).pendCount[0] = hot(a).pendCount[1] = 0;
 			hot(a).hitCount = 0; hot(a).hspCount = 0; hot(a).topHit = -1;
@@ -1145,9 +1156,15 @@ __global__ __launch_bounds__(64, TIER == 2 ? 1 : URX_PE_WAVES(NCH)) void search_
 				for (int c = 0; c < NCH; ++c) {
 					if (64 * c < hot(a).QL) {
 						const int p = 64 * c + lane;
-						const uint32_t code = p < hot(a).QL ? seq_code(qch[a][st][c], SEQ_CODE_QOTHER) : 0u;
-						const uint64_t b0 = __ballot(code & 1u), b1 = __ballot(code & 2u), b2 = __ballot(code & 4u), b3 = __ballot(code & 8u);
-						oth |= __ballot(code == SEQ_CODE_QOTHER);
+						uint64_t b0, b1, b2 = 0, b3 = 0;
+						if (acgt[a]) {  // codes 0..3: the two upper planes are empty
+							const uint32_t code = p < hot(a).QL ? seq_code_acgt(qch[a][st][c]) : 0u;
+							b0 = __ballot(code & 1u); b1 = __ballot(code & 2u);
+						} else {
+							const uint32_t code = p < hot(a).QL ? seq_code(qch[a][st][c], SEQ_CODE_QOTHER) : 0u;
+							b0 = __ballot(code & 1u); b1 = __ballot(code & 2u); b2 = __ballot(code & 4u); b3 = __ballot(code & 8u);
+							oth |= __ballot(code == SEQ_CODE_QOTHER);
+						}
 						if (lane < 2) {
 							const int shh = 32 * lane;
 							ml[a].qpl[st][2 * c + lane] = make_uint4((uint32_t)(b0 >> shh), (uint32_t)(b1 >> shh), (uint32_t)(b2 >> shh), (uint32_t)(b3 >> shh));
