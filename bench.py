@@ -36,7 +36,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-CODE_VERSION = "r6c"   # committed PMC profiles carry the code version they were taken on (pmc_traffic); r6b: two chunks of k-mer starts, row stores in LDS, PosToCoordL by lanes; r6c: + the instruction trims (profiles/r6/ab_instruction_trims.txt)
+CODE_VERSION = "r6d"   # committed PMC profiles carry the code version they were taken on (pmc_traffic); r6b: two chunks of k-mer starts, row stores in LDS, PosToCoordL by lanes; r6c: + the instruction trims of calls 31-34 (profiles/r6/ab_instruction_trims.txt); r6d: + call 35
 
 # work per read of the reference on the survey's 40 Mbp planning genome (instrumented build)
 SURVEY_WORK_PER_READ = {

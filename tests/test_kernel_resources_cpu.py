@@ -20,8 +20,8 @@ CEILINGS = {
     "search_se_kernel<3, false, false, 2, 0, 3>": (4, 128, 62, 252, 168, 10048),  # reads of 152-192 bases at W = 24 (and URMAPX_NO_K2): three chunks, row store in global scratch
     "search_se_kernel<4, false, false, 2, 0, 4>": (3, 168, 4, 276, 16, 12560),    # 250-base reads
     "search_se_kernel<2, false, false, 2, 0, 2>": (4, 128, 28, 230, 112, 9808),   # reads of up to 128 bases (row store in LDS: 7 760 + 2 048 B)
-    "search_se_kernel<3, false, false, 1, 0, 3>": (4, 128, 55, 256, 168, 10048),  # the same on an index without slot16 (row layout only)
-    "search_se_kernel<3, false, false, 1, 1, 3>": (4, 128, 37, 292, 64, 10048),   # URMAPX_PARK_PHASE3=1: first launch (no banded DP inside)
+    "search_se_kernel<3, false, false, 1, 0, 3>": (4, 128, 56, 270, 168, 10048),  # the same on an index without slot16 (row layout only)
+    "search_se_kernel<3, false, false, 1, 1, 3>": (4, 128, 88, 292, 64, 10048),   # URMAPX_PARK_PHASE3=1 (opt-in, measured slower): first launch (no banded DP inside)
     "search_se_kernel<3, false, false, 1, 2, 3>": (4, 120, 0, 150, 0, 10048),     # ... second launch (the reads parked at phase 3)
     "search_pe_kernel<3, 0>": (4, 128, 80, 302, 304, 10240),                    # 2 x 150 pairs; round 6: the LDS diet (kernels_pe.hip: URX_PE_DIET 2) -- FOUR waves per SIMD, 16 blocks x 10 240 B = a CU's 160 KB
     "search_pe_kernel<2, 0>": (4, 128, 75, 296, 272, 8256),                     # pairs of reads of up to 128 bases, same diet

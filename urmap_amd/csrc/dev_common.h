@@ -213,6 +213,9 @@ struct BitVec {
 // return the full walk's result and the caller compares their penalty with the cap in order.
 // The walk visits mismatches only.  The loop over the N words is wave-uniform and unrolled; inside a word the set
 // bits are consumed one by one (x &= x - 1), so an iteration is ~20 VALU instructions with no word selection.
+#ifndef URX_WALK_IN_TEST
+#define URX_WALK_IN_TEST 0  // 1: the forward walk tests every mismatch position against the read's length (rounds 2-5)
+#endif
 template <int N>
 __device__ __forceinline__ void xdrop_walk_lane(const uint64_t (&w)[N], int qpos, int W, int QL, int mis, int xdrop, int cap,
                                                 int &bst_out, int &startpos_out, int &endpos_out, int &pen_out) {
@@ -231,6 +234,7 @@ __device__ __forceinline__ void xdrop_walk_lane(const uint64_t (&w)[N], int qpos
 		while (x) {
 			const int m = 64 * c + __builtin_ctzll(x);
 			x &= x - 1;
+#if URX_WALK_IN_TEST
 			const bool in = m < QL;  // padding bits past the read end the word; the tail run below ends the walk
 			const int s1 = score + (m - cur);
 			const bool nb = in && m > cur && s1 > bst;
@@ -242,6 +246,19 @@ __device__ __forceinline__ void xdrop_walk_lane(const uint64_t (&w)[N], int qpos
 			const bool stop = in && (bst - score > xdrop || pen > cap);
 			alive = alive && !stop;
 			x = (stop || !in) ? 0ull : x;
+#else
+			// (no bit at or beyond QL is ever set: lane_mismatch_planes and lane_mismatch_mask clear them -- the test for them cost six of the loop's 22 instructions)
+			const int s1 = score + (m - cur);
+			const bool nb = m > cur && s1 > bst;
+			bst = nb ? s1 : bst;
+			endpos = nb ? m - 1 : endpos;
+			score = s1 + mis;
+			pen -= mis;
+			cur = m + 1;
+			const bool stop = bst - score > xdrop || pen > cap;
+			alive = alive && !stop;
+			x = stop ? 0ull : x;
+#endif
 		}
 	}
 	{  // no mismatch left: the run to the end of the read
