@@ -8,6 +8,11 @@
 
 namespace urx {
 
+// 1: the pair kernel's letter planes kept as ONE interleaved stream (probe_pair / slot_from_planes below); 0: two planes, interleaved per lane and k-mer (rounds 4-6)
+#ifndef URX_SLOT_STREAM
+#define URX_SLOT_STREAM 0  // measured: pairs 18.0 -> 18.3 ms per 1 M reads (the stream's words are made on the scalar unit at the start of every pair, the cuts it saves are rarer): off (profiles/r6/ab_instruction_trims.txt)
+#endif
+
 // The k-mers of NC 64-position chunks of one read: all slot numbers first, then all 2*NC slot loads in flight
 // together, then the stores (the loads are random 64-byte sectors of a 26 GB table: their latency is the kernel).
 template <int NCH, int NC, int C0 = 0>
@@ -133,7 +138,17 @@ __device__ __forceinline__ void probe_pair(const DevIndex &X, const uint8_t *__r
 		if (lane == 0) {
 			const lds_ptr<uint64_t> k = a ? kpl1 : kpl0;
 #pragma unroll
-			for (int c = 0; c <= NCH; ++c) { k[c] = lo[a][c]; k[(NCH + 1) + c] = hi[a][c]; k[2 * (NCH + 1) + c] = inv[a][c]; k[3 * (NCH + 1) + c] = invm[a][c]; }
+			for (int c = 0; c <= NCH; ++c) {
+#if URX_SLOT_STREAM
+				// the two letter planes as ONE interleaved stream (dev_common.h: kmer_slots): word 2c = bases 64c .. 64c + 31, bit 2i = low letter bit of base i,
+				// bit 2i + 1 = high bit -- what slot_from_planes cuts a k-mer's 2W bits out of (the spreads are the ones kmer_slots makes of the same ballots)
+				k[2 * c] = spread32(lo[a][c]) | (spread32(hi[a][c]) << 1);
+				k[2 * c + 1] = spread32(lo[a][c] >> 32) | (spread32(hi[a][c] >> 32) << 1);
+#else
+				k[c] = lo[a][c]; k[(NCH + 1) + c] = hi[a][c];
+#endif
+				k[2 * (NCH + 1) + c] = inv[a][c]; k[3 * (NCH + 1) + c] = invm[a][c];
+			}
 		}
 	}
 	uint64_t sp[2][NCH], sm[2][NCH];
@@ -214,11 +229,25 @@ __device__ __forceinline__ uint64_t slot_from_planes(const DevIndex &X, lds_ptr<
 		if (sh) f |= w1 << (64u - sh);
 		return f & wmask;
 	};
-	const uint64_t flo = cut(0), fhi = cut(1), fbad = cut(s ? 3 : 2);
+	const uint64_t fbad = cut(s ? 3 : 2);
 	if (fbad) return ~0ull;
 	uint64_t w;
+#if URX_SLOT_STREAM
+	// 2W bits of the interleaved stream from bit 2p (words 2c, 2c + 1 of a chunk: index p >> 5)
+	const uint32_t wi = p >> 5, sh2 = (2u * p) & 63u;
+	uint64_t seg = kpl[wi] >> sh2;
+	if (sh2) seg |= kpl[wi + 1] << (64u - sh2);  // wi + 1 <= 2 NCH: the pad chunk's words
+	const uint64_t m2 = (W >= 32) ? ~0ull : ((1ull << (2u * W)) - 1ull);
+	if (s == 0) {  // first base most significant: the letters' bits swapped, then the piece bit-reversed
+		const uint64_t t = ((seg & 0x5555555555555555ull) << 1) | ((seg >> 1) & 0x5555555555555555ull);
+		w = __brevll(t & m2) >> (64u - 2u * W);
+	} else
+		w = ~seg & m2;
+#else
+	const uint64_t flo = cut(0), fhi = cut(1);
 	if (s == 0) w = spread32(__brevll(flo) >> (64 - W)) | (spread32(__brevll(fhi) >> (64 - W)) << 1);
 	else w = spread32(~flo & wmask) | (spread32(~fhi & wmask) << 1);
+#endif
 	return mod_slots(murmur64(w & X.shiftMask), X.slotCount, X.slotMagic);
 }
 
