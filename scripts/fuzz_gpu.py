@@ -26,7 +26,8 @@ cores = bench.host_cores()
 bad = 0
 cases = [(False, 150, 0.01, 0.001), (False, 150, 0.03, 0.01), (False, 100, 0.02, 0.004), (False, 250, 0.04, 0.01), (False, 250, 0.01, 0.002),
          (False, 300, 0.03, 0.008), (False, 64, 0.01, 0.0), (True, 150, 0.01, 0.001), (True, 100, 0.03, 0.005), (True, 250, 0.02, 0.004),
-         (False, 500, 0.02, 0.004), (False, 1000, 0.01, 0.002), (True, 270, 0.03, 0.006)]  # round 3: the 512 / 1024-base kernel classes, the longest pairs
+         (False, 500, 0.02, 0.004), (False, 1000, 0.01, 0.002), (True, 270, 0.03, 0.006),  # round 3: the 512 / 1024-base kernel classes, the longest pairs
+         (False, 151, 0.02, 0.004), (False, 152, 0.02, 0.004), (False, 128, 0.03, 0.006), (True, 151, 0.02, 0.004)]  # round 6: either side of the two-chunk instance's 128 k-mer starts, the <2> class with its row store in LDS
 n_all = n
 for ci, (pe, L, sub, indel) in enumerate(cases):
     n = n_all if L <= 300 else n_all // 4
